@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CGNR iterations/sec @ 4096x2048 ComplexF32 (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is ONE CGNR iteration (src/CGNR.jl:143-178) of the matrix-free normal operator on a dense
+column-major ComplexF32 4096x2048 A that is already resident in HBM: t = A p, v = A^H t, then the
+fused BLAS-1 update.  lambda = 0, relTol = 0 (SURVEY.md 8d "headline metric run").
+
+N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE config 4 -- independent
+solves sharded one per GPU, distinct A per rank, no data-path collective -> weak scaling; the only
+collectives are the barrier and the max-over-ranks of the elapsed time.  `--workload rowsharded`
+runs BASELINE config 5 instead (one tall A row-partitioned, one all-reduce of A^H t per iteration).
+
+Prints ONE JSON line on rank 0 with `roofline` and (N = 1) `cpu_baseline` objects.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+# CG converges geometrically on the well-conditioned randn matrix (hard part 4): left running
+# for hundreds of iterations the recursive residual underflows Float32 and alpha becomes 0/0.  The
+# bench therefore times back-to-back SOLVES of SEGMENT iterations each (BASELINE configs 4/5 use 32);
+# the init! of every solve (one extra GEMV) is inside the timed region but not counted as a step.
+SEGMENT = 32
+
+
+def make_A(M, N, seed, dtype=np.complex64):
+    """zero-mean normal entries, complex = (g1 + i g2)/sqrt 2; generated in float32"""
+    rng = np.random.default_rng(seed)
+    if np.dtype(dtype).kind == "c":
+        A = np.empty((M, N), dtype=np.complex64, order="F")
+        s = np.float32(1 / math.sqrt(2))
+        A.real = rng.standard_normal((N, M), dtype=np.float32).T * s
+        A.imag = rng.standard_normal((N, M), dtype=np.float32).T * s
+    else:
+        A = np.asfortranarray(rng.standard_normal((N, M), dtype=np.float32).T)
+    return A
+
+
+def bytes_per_cgnr_iteration(M, N, s):
+    """algorithmic bytes: A read twice + the length-N / length-M vector traffic"""
+    return 2 * M * N * s + (16 * N + 2 * M) * s
+
+
+def cpu_baseline_cgnr(A, b, budget_s=12.0, max_iters=400):
+    """the oracle's CGNR (NumPy/OpenBLAS restatement of src/CGNR.jl:143-178) timed on the host"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rls_oracle as O
+
+    s = O.CGNR(A, iterations=SEGMENT, relTol=0.0)
+    s.init(b)
+    for _ in range(5):
+        s.iterate()
+    n, t0 = 0, time.perf_counter()
+    while n < max_iters and time.perf_counter() - t0 < budget_s:
+        s.init(b)  # same cadence as the GPU leg: one solve = init! + SEGMENT iterations
+        for _ in range(SEGMENT):
+            s.iterate()
+        n += SEGMENT
+    dt = time.perf_counter() - t0
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            threads = blas[0]["num_threads"]
+    except Exception:
+        pass
+    return {"value": n / dt, "unit": "iterations/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} CGNR iterations of the same {A.shape[0]}x{A.shape[1]} complex64 problem, NumPy/OpenBLAS "
+                      f"restatement (oracle/rls_oracle.py), {dt:.1f} s",
+            "ms_per_step": 1e3 * dt / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="cgnr", choices=["cgnr", "rowsharded"])
+    ap.add_argument("--M", type=int, default=4096)
+    ap.add_argument("--N", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=200)
+    args = ap.parse_args()
+
+    import torch  # plumbing: device selection, barrier, max-over-ranks
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import rls_amd as rls
+
+    ctx = rls.Context(local_rank)
+    M, N = args.M, args.N
+    dt = np.complex64
+    s = np.dtype(dt).itemsize
+    K, W = args.steps, args.warmup
+
+    if args.workload == "rowsharded":
+        from importlib import import_module
+
+        mg = import_module("rls_amd.multigpu")
+        result = mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W)
+        if rank == 0:
+            print(json.dumps(result))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- data: resident in HBM before the timed region ------------------------------------
+    A = make_A(M, N, seed=2 if world == 1 else 100 + rank)
+    rng = np.random.default_rng(1000 + rank)
+    x_true = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(dt)
+    b = (A @ x_true).astype(dt)
+    Ad = rls.DeviceMatrix.from_host(A, ctx)
+    bd = rls.DeviceVector.from_host(b, ctx)
+    solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
+    rls.init_(solver, bd)
+    st = solver.state
+    lib, h = ctx.lib, ctx.handle
+
+    def step(n):
+        while n > 0:
+            m = min(n, SEGMENT)
+            rls.init_(solver, bd)  # asynchronous: r = A^H b, then the init kernel
+            rls._lib.check(h, lib.rls_cgnr_step(st._plan, m), "rls_cgnr_step")
+            n -= m
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    step(W)
+    barrier()
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    step(K)
+    ev_ms = ctx.timer_stop_ms()  # hipEvents on the stream the kernels run on; synchronises
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st._refresh(lib)
+    assert st.iteration == ((K - 1) % SEGMENT) + 1, (st.iteration, K)
+    assert math.isfinite(st._residual), "CGNR residual is not finite"
+
+    # ---- per-kernel launch duration, hipEvents around back-to-back launches ---------------
+    reps = args.kernel_reps
+    p = rls.DeviceVector.from_host(x_true, ctx)
+    t = rls.DeviceVector(M, dt, ctx)
+    v = rls.DeviceVector(N, dt, ctx)
+    kern = {}
+    for name, fn in (("gemv_n (t = A p)", lambda: Ad.gemv_(0, p, t)), ("gemv_c (v = A^H t)", lambda: Ad.gemv_(2, t, v))):
+        for _ in range(10):
+            fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop_ms() / reps
+        by = M * N * s + (M + N) * s
+        kern[name] = {"us_per_launch": 1e3 * ms, "bytes_per_launch": by, "GBps": by / (ms * 1e-3) / 1e9}
+    dom = max(kern, key=lambda k: kern[k]["us_per_launch"])
+    bytes_iter = bytes_per_cgnr_iteration(M, N, s)
+    iter_gbs = bytes_iter * K / (ev_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "CGNR iterations/sec @4096x2048 CF32; achieved HBM GB/s vs roofline",
+            "value": world * K / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "c64 (ComplexF32 storage and arithmetic; scalar reductions accumulated in f64)",
+            "data": "synthetic",
+            "config": {"workload": f"CGNR matrix-free normal operator, dense column-major ComplexF32 {M}x{N}, lambda=0, "
+                                   f"relTol=0, back-to-back solves of {SEGMENT} iterations (BASELINE configs[1] shape; configs[3] sharding at N>1: one independent "
+                                   f"solve per GPU, no collectives)",
+                       "M": M, "N": N, "problems_per_gpu": 1},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "per_kernel": kern,
+                         "iteration": {"bytes": bytes_iter, "GBps": iter_gbs, "frac": iter_gbs / HBM_PEAK_GBS,
+                                       "us_hip_events": 1e3 * ev_ms / K}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_cgnr(A, b)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

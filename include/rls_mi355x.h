@@ -1,0 +1,236 @@
+/*
+ * rls_mi355x.h -- C ABI of librls_mi355x.so: the MI355X (gfx950) backend for the iterative inner
+ * loop of RegularizedLeastSquares.jl (CGNR / FISTA / ADMM on a dense operator).
+ *
+ * The reference has no FFI today: its backend boundary is Julia multiple dispatch on the array
+ * type of A / b.  Every entry point below names the reference method(s) a Julia
+ * extension would overload with a `ccall` to it (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C linkage; every function returns an int32 status: 0 = OK, >0 = hipError_t,
+ *     <0 = RLS_E_*.  rls_last_error_string(ctx) describes the last failure on that context.
+ *   - all array arguments are DEVICE pointers owned by the caller, unless the name says _h (host).
+ *   - matrices are column-major with an explicit leading dimension `lda` in ELEMENTS
+ *     (Julia `Matrix`); complex = interleaved (re, im) float pairs.
+ *   - complex scalars cross the boundary as two floats (no struct-by-value).
+ *   - work is enqueued on the context's stream and is asynchronous; only functions that return
+ *     host scalars (rls_nrm2, rls_dotc, *_status, memcpy_d2h) synchronise.
+ *   - the library is re-entrant: all mutable state lives in rls_ctx (one per host thread / GPU).
+ */
+#ifndef RLS_MI355X_H
+#define RLS_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLS_ABI_VERSION 1
+
+typedef struct rls_ctx rls_ctx;           /* device + stream + workspace                           */
+typedef struct rls_operator rls_operator; /* dense forward operator A (+ optional Gram matrix)     */
+typedef struct rls_cgnr rls_cgnr;         /* fused CGNR plan bound to caller-owned state vectors   */
+typedef struct rls_fista rls_fista;       /* fused FISTA plan                                      */
+typedef struct rls_cg rls_cg;             /* fused cg! plan (ADMM x-update)                        */
+
+enum { RLS_F32 = 0, RLS_C32 = 1 };                 /* Float32, ComplexF32                          */
+enum { RLS_OP_N = 0, RLS_OP_T = 1, RLS_OP_C = 2 }; /* A, transpose(A), adjoint(A)                  */
+enum { RLS_NORMAL_MATRIXFREE = 0, RLS_NORMAL_GRAM = 1 };
+
+enum {
+  RLS_E_INVALID = -1,   /* bad argument (null pointer, negative size, unknown dtype/op)            */
+  RLS_E_UNSUPPORTED = -2,
+  RLS_E_WORKSPACE = -3, /* workspace too small / allocation failed                                */
+  RLS_E_STATE = -4      /* call out of order (e.g. step before init)                              */
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * context / memory.   Julia side: the device vector type's constructor, finalizer, copyto!, Array().
+ * ------------------------------------------------------------------------------------------- */
+int32_t rls_abi_version(void);
+int32_t rls_ctx_create(int32_t device, rls_ctx** out);
+/* borrow an existing hipStream_t (e.g. torch's current stream); the ctx does not destroy it */
+int32_t rls_ctx_create_on_stream(int32_t device, void* hip_stream, rls_ctx** out);
+int32_t rls_ctx_destroy(rls_ctx* ctx);
+int32_t rls_ctx_sync(rls_ctx* ctx);
+void* rls_ctx_stream(rls_ctx* ctx);
+const char* rls_last_error_string(rls_ctx* ctx);
+int32_t rls_device_count(int32_t* out);
+/* kernel-selection knobs for measurement sweeps ("gemvn_g", "gemvn_waves", "gemvt_cols",
+ * "graph_chunk", "use_graph", "fuse_level"); 0 = built-in heuristic.  Not part of the reference. */
+int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
+
+int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out);  /* similar(b, dims...)  src/CGNR.jl:92-95 */
+int32_t rls_free(rls_ctx* ctx, void* p);
+int32_t rls_memcpy_h2d(rls_ctx* ctx, void* dst, const void* src_h, size_t bytes);
+int32_t rls_memcpy_d2h(rls_ctx* ctx, void* dst_h, const void* src, size_t bytes); /* synchronises */
+int32_t rls_memcpy_d2d(rls_ctx* ctx, void* dst, const void* src, size_t bytes);   /* copyto! src/CGNR.jl:126 */
+int32_t rls_fill(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, float re, float im); /* v .= c  src/CGNR.jl:108-115, src/FISTA.jl:121-123 */
+
+/* timing helpers for the measurement harness (hipEvents on the ctx stream) */
+int32_t rls_timer_start(rls_ctx* ctx);
+int32_t rls_timer_stop_ms(rls_ctx* ctx, float* ms_out); /* synchronises */
+
+/* ---------------------------------------------------------------------------------------------
+ * BLAS-2:  y = alpha * op(A) * x + beta * y       (5-arg mul!)
+ * replaces LinearAlgebra.mul!(y, A, x) / mul!(x, adjoint(A), y):  src/CGNR.jl:132,151
+ * src/FISTA.jl:114,152  src/ADMM.jl:198  and the 5-arg form src/CGNR.jl:119, src/ADMM.jl:239-240
+ * ------------------------------------------------------------------------------------------- */
+int32_t rls_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int64_t N, float alpha_re, float alpha_im,
+                 const void* A, int64_t lda, const void* x, float beta_re, float beta_im, void* y);
+
+/* ---------------------------------------------------------------------------------------------
+ * BLAS-1.   replaces norm / dot / rmul! / fused broadcasts: src/CGNR.jl:125,153-174,182
+ * src/FISTA.jl:118,147-156,172  src/ADMM.jl:236-309
+ * result_h: host float[2] (re, im); the *_dev forms write float[2] to device memory, no sync.
+ * ------------------------------------------------------------------------------------------- */
+int32_t rls_nrm2(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, float* result_h);
+int32_t rls_nrm2_dev(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, float* result_d);
+int32_t rls_dotc(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* y, float* result_h); /* conj(x).y */
+int32_t rls_dotc_dev(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* y, float* result_d);
+int32_t rls_asum(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, float* result_h); /* norm(x,1) with complex modulus: ProxL1.jl:29-32 */
+int32_t rls_scal(rls_ctx* ctx, int32_t dtype, int64_t n, float a_re, float a_im, void* x);                   /* rmul!(x, a)   */
+int32_t rls_axpy(rls_ctx* ctx, int32_t dtype, int64_t n, float a_re, float a_im, const void* x, void* y);    /* y .+= a .* x  */
+int32_t rls_axpby(rls_ctx* ctx, int32_t dtype, int64_t n, float a_re, float a_im, const void* x, float b_re,
+                  float b_im, void* y);                                                                      /* y = a x + b y */
+/* z = a x + b y (out of place; z may alias x or y): src/ADMM.jl:282-284 */
+int32_t rls_lincomb(rls_ctx* ctx, int32_t dtype, int64_t n, float a_re, float a_im, const void* x, float b_re,
+                    float b_im, const void* y, void* z);
+
+/* ---------------------------------------------------------------------------------------------
+ * proximal maps (in place).   replaces prox!(reg, x, lambda)
+ * ------------------------------------------------------------------------------------------- */
+int32_t rls_prox_l1(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, float lambda);        /* src/proximalMaps/ProxL1.jl:18-22 */
+int32_t rls_prox_l2(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, float lambda);        /* src/proximalMaps/ProxL2.jl:18-21 */
+int32_t rls_prox_l21(rls_ctx* ctx, int32_t dtype, int64_t n, int64_t slices, void* x, float lambda); /* ProxL21.jl:30-35; ext/..GPUArraysExt/ProxL21.jl:1-12 */
+int32_t rls_prox_positive(rls_ctx* ctx, int32_t dtype, int64_t n, void* x);                /* ProxPositive.jl:16-20, Utils.jl:114-144 */
+int32_t rls_prox_real(rls_ctx* ctx, int32_t dtype, int64_t n, void* x);                    /* ProxReal.jl:16-19 */
+int32_t rls_norm_l21(rls_ctx* ctx, int32_t dtype, int64_t n, int64_t slices, const void* x, float lambda,
+                     float* result_h);                                                     /* ProxL21.jl:42-46 */
+
+/* TV.  shape[ndims] column-major extents; dims[ntv] 0-based dimensions differenced, in order.
+ * Gradient layout = LinearOperatorCollection.GradientOp: per dim d a block of
+ * prod(shape with shape[d]-1) forward differences g[i] = x[i] - x[i+e_d], blocks concatenated. */
+int64_t rls_tv_grad_len(int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims);
+/* g = alpha * grad(x) + beta * g           mul!(pq, grad, xTmp, 1/(8 lambda), 1)  ProxTV.jl:109 */
+int32_t rls_tv_grad(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                    const int32_t* dims, const void* x, void* g, float alpha, float beta);
+/* x = alpha * grad^T(g) + beta * x         mul!(xTmp, transpose(grad), rs, -lambda, 1)  ProxTV.jl:108,123 */
+int32_t rls_tv_grad_t(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                      const int32_t* dims, const void* g, void* x, float alpha, float beta);
+int32_t rls_tv_restrict(rls_ctx* ctx, int32_t dtype, int64_t n, void* pq);                /* tv_restrictMagnitude! ProxTV.jl:135-139; ext/..ProxTV.jl:1-8 */
+int32_t rls_tv_lincomb(rls_ctx* ctx, int32_t dtype, int64_t n, void* rs, float t3, const void* pq, float t2,
+                       const void* pqOld);                                                /* tv_linearcomb! ProxTV.jl:141-145; ext/..ProxTV.jl:10-17 */
+/* whole FGP loop: proxTV!(x, lambda, p::TVParams; iterationsTV)  ProxTV.jl:89-125.
+ * workspace: >= rls_prox_tv_workspace_bytes(...) bytes of device scratch (the TVParams buffers). */
+size_t rls_prox_tv_workspace_bytes(int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                                   const int32_t* dims);
+int32_t rls_prox_tv_fgp(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                        const int32_t* dims, void* x, float lambda, int32_t iterations, void* workspace,
+                        size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * operator handle: the backend's operator type for A (SURVEY 3.1 "two operator modes").
+ * A' * A on it yields the lazy normal operator (matrix-free, two GEMVs) unless a Gram matrix is set.
+ * ------------------------------------------------------------------------------------------- */
+int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,
+                            rls_operator** out);
+int32_t rls_operator_set_gram(rls_operator* op, const void* AHA, int64_t ld); /* explicit AHA= keyword: src/CGNR.jl:46-49 */
+int32_t rls_operator_destroy(rls_operator* op);
+/* y = A x, x = A^H y, v = A^H A p (mul!(v, AHA, p): src/CGNR.jl:151, src/FISTA.jl:152, src/Utils.jl:278) */
+int32_t rls_operator_mul(rls_operator* op, const void* x, void* y);
+int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x);
+int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v);
+/* setup GEMM AHA = A' * A (src/CGNR.jl:49) on device; G is N x N column-major, ld >= N */
+int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G, int64_t ld);
+
+/* ---------------------------------------------------------------------------------------------
+ * fused CGNR.   replaces init!(::CGNR, ::CGNRState, b) src/CGNR.jl:107-130 and
+ * iterate(::CGNR, ::CGNRState) src/CGNR.jl:143-178 + done() :181-185 for device state vectors.
+ * x, r (= x0 in the reference), p (= pl), v (= vl): caller-owned length-N device vectors.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rls_cgnr_status {
+  int32_t iteration; /* state.iteration                                                          */
+  int32_t done;      /* converged || iteration >= min(iterations, N)   src/CGNR.jl:185           */
+  float alpha_re, alpha_im; /* state.alphal (complex-typed for complex problems)                 */
+  float beta_re, beta_im;
+  float zeta;     /* ||r||^2 at the start of the last iteration                                  */
+  float residual; /* ||r|| now: solverconvergence(state).residual  src/CGNR.jl:136               */
+  float z0;       /* ||A^H b||                                                                   */
+} rls_cgnr_status;
+
+int32_t rls_cgnr_create(rls_operator* op, void* x, void* r, void* p, void* v, rls_cgnr** out);
+int32_t rls_cgnr_destroy(rls_cgnr* s);
+/* b: length M (or length N when the operator has only a Gram matrix: b must then be A^H b) */
+int32_t rls_cgnr_init(rls_cgnr* s, const void* b, float lambda, float rel_tol, int32_t iterations);
+/* enqueue n_steps iterations (no-ops once done); asynchronous, graph-replayed */
+int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps);
+int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h); /* synchronises */
+
+/* ---------------------------------------------------------------------------------------------
+ * fused FISTA.   replaces init!/iterate(::FISTA, ::FISTAState) src/FISTA.jl:110-129,139-185.
+ * reg_kind selects the proximal map applied with rho*lambda (src/FISTA.jl:164); proj_kind the
+ * projection applied every iteration (:166-168).
+ * ------------------------------------------------------------------------------------------- */
+enum { RLS_REG_NONE = 0, RLS_REG_L1 = 1, RLS_REG_L2 = 2, RLS_REG_L21 = 3, RLS_REG_TV = 4 };
+enum { RLS_PROJ_NONE = 0, RLS_PROJ_REAL = 1, RLS_PROJ_POSITIVE = 2 };
+
+typedef struct rls_fista_status {
+  int32_t iteration;
+  int32_t done;
+  float theta, theta_old;
+  float rel_res_norm; /* ||res|| / ||x0||   src/FISTA.jl:156                                      */
+  float residual;     /* ||res||: solverconvergence  src/FISTA.jl:131                             */
+  float norm_x0;
+} rls_fista_status;
+
+/* x, x0, xold, res: caller-owned length-N device vectors.  The plan swaps x/xold internally by
+ * pointer as the reference does (:144-146); rls_fista_solution() returns the current x. */
+int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* res, rls_fista** out);
+int32_t rls_fista_destroy(rls_fista* s);
+int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t l21_slices, int32_t proj_kind);
+int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, float rel_tol, int32_t iterations,
+                       int32_t restart_gradient);
+/* optional warm start x0 != 0 (init!(solver, b; x0), src/FISTA.jl:110,120): call right after init */
+int32_t rls_fista_set_start(rls_fista* s, const void* x_init);
+int32_t rls_fista_step(rls_fista* s, int32_t n_steps);
+int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out_h);
+int32_t rls_fista_solution(rls_fista* s, void** x_out); /* device pointer currently holding state.x */
+
+/* ---------------------------------------------------------------------------------------------
+ * fused cg!   replaces IterativeSolvers.cg!(x, AHA + rho*I, b; maxiter, reltol, statevars)
+ * call site src/ADMM.jl:244 (identity regTrafo: compositeAHA u = AHA u + rho u, :84,141-159).
+ * u, r, c: the CGStateVariables scratch (src/ADMM.jl:129).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rls_cg_status {
+  int32_t iterations; /* CG iterations actually performed                                        */
+  float residual;     /* ||r|| at exit                                                            */
+  float tol;          /* max(reltol * ||r0||, 0)                                                  */
+} rls_cg_status;
+int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out);
+int32_t rls_cg_destroy(rls_cg* s);
+/* solves (AHA + rho I) x = b starting from x (warm start); asynchronous */
+int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxiter, float reltol);
+int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out_h);
+
+/* ---------------------------------------------------------------------------------------------
+ * row-sharded operation (BASELINE config 5).  One process per GPU holds rows
+ * [r*M/P, (r+1)*M/P) of A repacked contiguous; x, r, p, v and all scalars are replicated.
+ * The plan is split at the one exchange step so the host can run the all-reduce (RCCL via
+ * torch.distributed / a Julia RCCL binding) on the ctx stream between the two halves:
+ *     rls_cgnr_step_local_a(s)  : t = A_g p ; v_partial = A_g^H t
+ *     allreduce(sum, v, N elements)  -- caller, same stream
+ *     rls_cgnr_step_local_b(s)  : scalars + vector updates on the replicated state
+ * init is split the same way (r_partial = A_g^H b_g ; allreduce ; finish).
+ * ------------------------------------------------------------------------------------------- */
+int32_t rls_cgnr_init_local_a(rls_cgnr* s, const void* b_local, float lambda, float rel_tol, int32_t iterations);
+int32_t rls_cgnr_init_local_b(rls_cgnr* s);
+int32_t rls_cgnr_step_local_a(rls_cgnr* s);
+int32_t rls_cgnr_step_local_b(rls_cgnr* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLS_MI355X_H */

@@ -1,0 +1,851 @@
+"""CPU oracle: NumPy restatement of the RegularizedLeastSquares.jl inner loop.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``regularizedleastsquares.jl_amd/`` may
+import this file; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` do, and there only as the checker.
+
+What is restated (citations relative to /root/reference, v0.16.12):
+  * CGNR            src/CGNR.jl:48-185
+  * FISTA           src/FISTA.jl:57-189
+  * ADMM            src/ADMM.jl:80-332
+  * cg!             IterativeSolvers v0.9 (NOT in the reference tree; restated from
+                    the published algorithm, call site src/ADMM.jl:244)
+  * prox maps       src/proximalMaps/ProxL1.jl:18-22, ProxL2.jl:18-21, ProxL21.jl:26-35,
+                    ProxTV.jl:82-145, ProxPositive.jl:16-20, ProxReal.jl:16-19,
+                    src/Utils.jl:114-144 (enfReal!/enfPos!)
+  * GradientOp      LinearOperatorCollection v2 (NOT in tree; call sites ProxTV.jl:46,108-109,123)
+  * power_iterations src/Utils.jl:262-287
+  * solve! cadence  src/RegularizedLeastSquares.jl:103-117
+  * matrix solves   src/MultiThreading.jl:30-79
+
+Pinning status: the reference is Julia and Julia is not installed in the build
+container, so the reference itself cannot be executed.  The reference holds no
+golden vectors for this path; its exact known-answer tests (L2 closed form,
+Positive projection, callback cadence, matrix-solve == column solves, CGNR vs the
+least-squares solution) are replayed in tests/test_oracle.py.  cg! and GradientOp
+come from third-party packages that are absent from the tree: for those two the
+oracle is "parity unpinned" (see DESIGN.md section 3).
+
+All arithmetic runs in the dtype of the inputs: pass float32/complex64 to mirror
+the reference's Float32 path, float64/complex128 for the high-precision truth.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------
+
+
+def real_dtype(dt) -> np.dtype:
+    return np.empty(0, dtype=dt).real.dtype
+
+
+def _rt(x):
+    """real scalar type constructor for array x"""
+    return real_dtype(x.dtype).type
+
+
+def dotc(x, y):
+    """Julia dot(x, y): conjugates the FIRST argument (BLAS dotc)."""
+    return np.vdot(x, y)
+
+
+def nrm2(x):
+    return np.linalg.norm(x)
+
+
+# --------------------------------------------------------------------------------------
+# operators (the L1 "array/operator protocol" of SURVEY section 1)
+# --------------------------------------------------------------------------------------
+
+
+class DenseOp:
+    """Dense forward operator A (M x N)."""
+
+    def __init__(self, A):
+        self.A = np.asarray(A)
+        self.dtype = self.A.dtype
+        self.shape = self.A.shape
+
+    def mul(self, x):
+        return self.A @ x
+
+    def mul_adj(self, y):
+        return self.A.conj().T @ y
+
+
+class NormalOp:
+    """Matrix-free normal operator: v = A^H (A p) -- two GEMVs
+    (LinearOperatorCollection.normalOperator; docs/src/literate/howto/normal_operator.jl:37-44)."""
+
+    def __init__(self, A: DenseOp):
+        self.A = A
+        self.dtype = A.dtype
+        n = A.shape[1]
+        self.shape = (n, n)
+
+    def mul(self, x):
+        return self.A.mul_adj(self.A.mul(x))
+
+
+class GramOp:
+    """Gram-mode normal operator: AHA = A'*A formed once (src/CGNR.jl:49), one N x N GEMV per apply."""
+
+    def __init__(self, A=None, AHA=None):
+        if AHA is None:
+            A = np.asarray(A)
+            AHA = A.conj().T @ A
+        self.G = np.asarray(AHA)
+        self.dtype = self.G.dtype
+        self.shape = self.G.shape
+
+    def mul(self, x):
+        return self.G @ x
+
+
+# --------------------------------------------------------------------------------------
+# proximal maps
+# --------------------------------------------------------------------------------------
+
+
+def prox_l1(x, lam):
+    """src/proximalMaps/ProxL1.jl:18-22.  eps is added to the real part only."""
+    T = _rt(x)
+    eps = np.finfo(T).eps
+    lam = T(lam)
+    ax = np.abs(x)
+    shrink = np.maximum(ax - lam, T(0))
+    x[...] = (shrink * (x + eps)) / (ax + eps)
+    return x
+
+
+def norm_l1(x, lam):
+    """src/proximalMaps/ProxL1.jl:29-32"""
+    return _rt(x)(lam) * np.sum(np.abs(x))
+
+
+def prox_l2(x, lam):
+    """src/proximalMaps/ProxL2.jl:18-21: the Float64 literals promote the factor to Float64; the
+    product is rounded back to the element type on store."""
+    factor = 1.0 / (1.0 + 2.0 * float(lam))
+    if np.iscomplexobj(x):
+        x[...] = (x.astype(np.complex128) * factor).astype(x.dtype)
+    else:
+        x[...] = (x.astype(np.float64) * factor).astype(x.dtype)
+    return x
+
+
+def prox_l21(x, lam, slices):
+    """src/proximalMaps/ProxL21.jl:30-35.  x is sliceLength x slices column-major; a group is one
+    ROW (stride sliceLength).  An all-zero group evaluates (0-lam)/0: -Inf -> 0 for lam>0, NaN for
+    lam==0 (Julia's max propagates NaN, as does np.maximum)."""
+    T = _rt(x)
+    lam = T(lam)
+    n = x.shape[0]
+    slen = n // slices
+    # group i = x[i:sliceLength:end]: the stride runs to the END of x, so a ragged tail
+    # (n % slices != 0) joins its group; element k uses group k mod slen (mod1 in the reference)
+    idx = np.arange(n) % slen
+    g = _l21_group_norms(x, slen, idx)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fac = np.maximum((g - lam) / g, T(0)).astype(T)
+    x[...] = x * fac[idx]
+    return x
+
+
+def _l21_group_norms(x, slen, idx):
+    T = _rt(x)
+    a2 = (x.real.astype(T) ** 2 + x.imag.astype(T) ** 2) if np.iscomplexobj(x) else x.astype(T) ** 2
+    return np.sqrt(np.bincount(idx, weights=a2.astype(np.float64), minlength=slen)).astype(T)
+
+
+def norm_l21(x, lam, slices):
+    """src/proximalMaps/ProxL21.jl:42-46"""
+    T = _rt(x)
+    slen = x.shape[0] // slices
+    g = _l21_group_norms(x, slen, np.arange(x.shape[0]) % slen)
+    return T(lam) * np.sum(g)
+
+
+def enf_real(x):
+    """src/Utils.jl:114-125"""
+    if np.iscomplexobj(x):
+        x.imag[...] = 0
+    return x
+
+
+def enf_pos(x):
+    """src/Utils.jl:130-144.  Complex: re<0 => x = im*imag(x) (real part dropped, imaginary kept)."""
+    if np.iscomplexobj(x):
+        neg = x.real < 0
+        x.real[neg] = 0
+    else:
+        x[x < 0] = 0
+    return x
+
+
+def prox_positive(x):
+    """src/proximalMaps/ProxPositive.jl:16-20"""
+    enf_real(x)
+    enf_pos(x)
+    return x
+
+
+def prox_real(x):
+    """src/proximalMaps/ProxReal.jl:16-19"""
+    enf_real(x)
+    return x
+
+
+# ---- GradientOp (LinearOperatorCollection v2; restated, not in tree) ------------------
+
+
+def _grad_block_len(shape, d):
+    n = 1
+    for k, s in enumerate(shape):
+        n *= (s - 1) if k == d else s
+    return n
+
+
+def grad_len(shape, dims):
+    return sum(_grad_block_len(shape, d) for d in dims)
+
+
+def _as_dims(shape, dims):
+    """dims are 1-based in the reference API; returns 0-based tuple."""
+    if dims is None:
+        return tuple(range(len(shape)))
+    if isinstance(dims, (int, np.integer)):
+        return (int(dims) - 1,)
+    return tuple(int(d) - 1 for d in dims)
+
+
+def grad_apply(x, shape, dims0):
+    """g = grad(x): per dim d, g[i] = img[i] - img[i + e_d]; output extent shape[d]-1 along d; blocks
+    concatenated in dims order.  Arrays are column-major (Julia reshape)."""
+    img = x.reshape(shape, order="F")
+    out = []
+    for d in dims0:
+        lo = [slice(None)] * len(shape)
+        hi = [slice(None)] * len(shape)
+        lo[d] = slice(0, shape[d] - 1)
+        hi[d] = slice(1, shape[d])
+        out.append((img[tuple(lo)] - img[tuple(hi)]).reshape(-1, order="F"))
+    return np.concatenate(out) if out else np.zeros(0, dtype=x.dtype)
+
+
+def grad_apply_t(g, shape, dims0):
+    """x = grad^T g: +g at i, -g at i + e_d."""
+    res = np.zeros(shape, dtype=g.dtype, order="F")
+    off = 0
+    for d in dims0:
+        bshape = list(shape)
+        bshape[d] -= 1
+        n = int(np.prod(bshape))
+        gb = g[off : off + n].reshape(bshape, order="F")
+        off += n
+        lo = [slice(None)] * len(shape)
+        hi = [slice(None)] * len(shape)
+        lo[d] = slice(0, shape[d] - 1)
+        hi[d] = slice(1, shape[d])
+        res[tuple(lo)] += gb
+        res[tuple(hi)] -= gb
+    return res.reshape(-1, order="F")
+
+
+def prox_tv_fgp(x, lam, shape, dims=None, iterationsTV=10):
+    """Fast gradient projection, src/proximalMaps/ProxTV.jl:89-125 (the only TV algorithm reachable
+    through prox!).  Anisotropic per-component clip (ProxTV.jl:135-139); step constant
+    1/(8 lam) whatever the number of dims (ProxTV.jl:109)."""
+    T = _rt(x)
+    lam = T(lam)
+    dims0 = _as_dims(shape, dims)
+    ng = grad_len(shape, dims0)
+    pq = np.zeros(ng, dtype=x.dtype)
+    rs = np.zeros(ng, dtype=x.dtype)
+    pqOld = np.zeros(ng, dtype=x.dtype)
+    t = T(1)
+    step = T(1) / (T(8) * lam)
+    for _ in range(iterationsTV):
+        pqTmp = pqOld
+        pqOld = pq
+        pq = rs  # aliases rs: pq is updated in place in the buffer that held rs (:104,109)
+        xTmp = x.copy()
+        xTmp = (xTmp + (-lam) * grad_apply_t(rs, shape, dims0)).astype(x.dtype)
+        pq[...] = (step * grad_apply(xTmp, shape, dims0) + pq).astype(x.dtype)
+        pq[...] = pq / np.maximum(T(1), np.abs(pq))
+        tOld = t
+        t = (T(1) + np.sqrt(T(1) + T(4) * tOld * tOld)) / T(2)
+        t2 = (tOld - T(1)) / t
+        t3 = T(1) + t2
+        rs = pqTmp
+        rs[...] = t3 * pq - t2 * pqOld
+    x[...] = (x + (-lam) * grad_apply_t(pq, shape, dims0)).astype(x.dtype)
+    return x
+
+
+def norm_tv(x, lam, shape, dims=None):
+    """src/proximalMaps/ProxTV.jl:152-155"""
+    return _rt(x)(lam) * np.sum(np.abs(grad_apply(x, shape, _as_dims(shape, dims))))
+
+
+# --------------------------------------------------------------------------------------
+# regularisation types (names preserved from the reference API)
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class L1Regularization:
+    lam: float
+
+    def prox(self, x, lam=None):
+        return prox_l1(x, self.lam if lam is None else lam)
+
+    def norm(self, x, lam=None):
+        return norm_l1(x, self.lam if lam is None else lam)
+
+
+@dataclass
+class L2Regularization:
+    lam: float
+
+    def prox(self, x, lam=None):
+        return prox_l2(x, self.lam if lam is None else lam)
+
+    def norm(self, x, lam=None):
+        lam = self.lam if lam is None else lam
+        return _rt(x)(lam) * nrm2(x) ** 2
+
+
+@dataclass
+class L21Regularization:
+    lam: float
+    slices: int = 1
+
+    def prox(self, x, lam=None):
+        return prox_l21(x, self.lam if lam is None else lam, self.slices)
+
+    def norm(self, x, lam=None):
+        return norm_l21(x, self.lam if lam is None else lam, self.slices)
+
+
+@dataclass
+class TVRegularization:
+    lam: float
+    shape: Sequence[int] = (0,)
+    dims: Optional[Sequence[int]] = None
+    iterationsTV: int = 10  # ctor default src/proximalMaps/ProxTV.jl:39
+
+    def prox(self, x, lam=None):
+        return prox_tv_fgp(x, self.lam if lam is None else lam, tuple(self.shape), self.dims, self.iterationsTV)
+
+    def norm(self, x, lam=None):
+        return norm_tv(x, self.lam if lam is None else lam, tuple(self.shape), self.dims)
+
+
+class PositiveRegularization:
+    lam = None
+
+    def prox(self, x, lam=None):
+        return prox_positive(x)
+
+
+class RealRegularization:
+    lam = None
+
+    def prox(self, x, lam=None):
+        return prox_real(x)
+
+
+def _is_projection(r):
+    return isinstance(r, (PositiveRegularization, RealRegularization))
+
+
+# --------------------------------------------------------------------------------------
+# CGNR  (src/CGNR.jl)
+# --------------------------------------------------------------------------------------
+
+
+class CGNR:
+    """src/CGNR.jl:48-89 (ctor), :107-130 (init!), :143-178 (iterate), :181-185 (done)."""
+
+    def __init__(self, A, AHA=None, reg=None, iterations=10, relTol=None, normal="matrixfree"):
+        self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        if AHA is None:
+            AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
+        elif not hasattr(AHA, "mul"):
+            AHA = GramOp(AHA=AHA)
+        self.AHA = AHA
+        self.dtype = np.dtype(AHA.dtype)
+        self.T = real_dtype(self.dtype).type
+        regs = [] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
+        l2 = [r for r in regs if isinstance(r, L2Regularization)]
+        if len(l2) > 1:
+            raise ValueError("Cannot unambigiously retrieve reg term of type L2Regularization")
+        self.L2 = l2[0] if l2 else L2Regularization(0.0)
+        self.constr = [r for r in regs if _is_projection(r)]
+        rest = [r for r in regs if not isinstance(r, L2Regularization) and not _is_projection(r)]
+        if rest:
+            raise ValueError(f"CGNR does not allow for more additional regularization terms, found {len(rest)}")
+        self.iterations = int(iterations)
+        self.relTol = self.T(np.finfo(self.T).eps if relTol is None else relTol)
+        n = AHA.shape[1]
+        self.N = n
+        self.x = np.zeros(n, self.dtype)
+        self.r = np.zeros(n, self.dtype)  # x0 in the reference: the normal-equation residual
+        self.p = np.zeros(n, self.dtype)
+        self.v = np.zeros(n, self.dtype)
+        self.alpha = self.dtype.type(0)
+        self.beta = self.dtype.type(0)
+        self.zeta = self.dtype.type(0)
+        self.iteration = 0
+        self.z0 = self.T(0)
+
+    def init(self, b):
+        b = np.asarray(b, dtype=self.dtype)
+        self.p[:] = 0
+        self.v[:] = 0
+        self.alpha = self.dtype.type(0)
+        self.beta = self.dtype.type(0)
+        self.zeta = self.dtype.type(0)
+        self.iteration = 0
+        self.x[:] = 0
+        if self.A is None:
+            self.r[:] = b  # initCGNR(x0, ::Nothing, b)  src/CGNR.jl:134
+        else:
+            self.r[:] = self.A.mul_adj(b)  # src/CGNR.jl:132
+        self.z0 = self.T(nrm2(self.r))
+        self.p[:] = self.r
+
+    def converged(self):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return self.T(nrm2(self.r)) / self.z0 <= self.relTol
+
+    def done(self):
+        return bool(self.converged()) or self.iteration >= min(self.iterations, self.N)
+
+    def iterate(self):
+        if self.done():
+            for c in self.constr:
+                c.prox(self.x)
+            return None
+        T = self.T
+        self.v[:] = self.AHA.mul(self.p)
+        self.zeta = self.dtype.type(T(nrm2(self.r)) ** 2)
+        normvl = self.dtype.type(dotc(self.p, self.v))
+        lam = T(self.L2.lam)
+        if lam > 0:
+            self.alpha = self.dtype.type(self.zeta / (normvl + lam * T(nrm2(self.p)) ** 2))
+        else:
+            self.alpha = self.dtype.type(self.zeta / normvl)
+        self.x += self.p * self.alpha
+        self.r += self.v * (-self.alpha)
+        if lam > 0:
+            self.r += self.p * (-lam) * self.alpha
+        self.beta = self.dtype.type(dotc(self.r, self.r) / self.zeta)
+        self.p *= self.beta
+        self.p += self.r
+        self.iteration += 1
+        return self.x
+
+    def solution(self):
+        return self.x
+
+    def convergence(self):
+        return {"residual": self.T(nrm2(self.r))}
+
+
+# --------------------------------------------------------------------------------------
+# FISTA  (src/FISTA.jl)
+# --------------------------------------------------------------------------------------
+
+
+def power_iterations(AHA, b0, rtol=1e-3, maxiter=30):
+    """src/Utils.jl:264-287 with an injectable start vector (the reference draws it from Julia's
+    global RNG, which cannot be replayed)."""
+    b = np.array(b0, dtype=AHA.dtype)
+    lam = np.inf
+    for _ in range(maxiter):
+        b = b / nrm2(b)
+        bold = b
+        b = AHA.mul(bold)
+        lam_old = lam
+        lam = abs(dotc(bold, b))
+        if abs(lam / lam_old - 1) < rtol:
+            return lam
+    return lam
+
+
+class FISTA:
+    """src/FISTA.jl:57-92 (ctor), :110-129 (init!), :139-185 (iterate), :187-189 (done)."""
+
+    def __init__(self, A, AHA=None, reg=None, iterations=50, rho=None, theta=1, relTol=None,
+                 restart="none", normal="matrixfree"):
+        self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        if AHA is None:
+            AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
+        elif not hasattr(AHA, "mul"):
+            AHA = GramOp(AHA=AHA)
+        self.AHA = AHA
+        self.dtype = np.dtype(AHA.dtype)
+        self.T = real_dtype(self.dtype).type
+        regs = [L1Regularization(0.0)] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
+        self.proj = [r for r in regs if _is_projection(r)]
+        rest = [r for r in regs if not _is_projection(r)]
+        if len(rest) != 1:
+            raise ValueError(f"FISTA does not allow for more additional regularization terms, found {len(rest)}")
+        self.reg = rest[0]
+        if rho is None:
+            raise ValueError("oracle FISTA needs an explicit rho (the reference default uses the global RNG)")
+        self.rho = self.T(rho)
+        self.theta0 = self.T(theta)
+        self.iterations = int(iterations)
+        self.relTol = self.T(np.finfo(self.T).eps if relTol is None else relTol)
+        self.restart = restart
+        n = AHA.shape[1]
+        self.x = np.zeros(n, self.dtype)
+        self.x0 = np.zeros(n, self.dtype)
+        self.xold = np.zeros(n, self.dtype)
+        self.res = np.zeros(n, self.dtype)
+        self.theta = self.T(theta)
+        self.theta_old = self.T(theta)
+        self.iteration = 0
+        self.norm_x0 = self.T(1)
+        self.rel_res_norm = self.T(np.inf)
+
+    def init(self, b, x0=0, theta=1):
+        b = np.asarray(b, dtype=self.dtype)
+        if self.A is None:
+            self.x0[:] = b
+        else:
+            self.x0[:] = self.A.mul_adj(b)
+        self.iteration = 0
+        self.norm_x0 = self.T(nrm2(self.x0))
+        self.x[:] = x0
+        self.xold[:] = 0
+        self.res[:] = np.inf
+        self.theta = self.T(theta)
+        self.theta_old = self.T(theta)
+        self.rel_res_norm = self.T(np.inf)
+
+    def done(self):
+        return bool(self.rel_res_norm < self.relTol) or self.iteration >= self.iterations
+
+    def iterate(self):
+        if self.done():
+            return None
+        T = self.T
+        self.x, self.xold = self.xold, self.x  # pointer swap :144-146
+        self.x *= (T(1) - self.theta_old) / self.theta
+        self.x += ((self.theta_old - T(1)) / self.theta + T(1)) * self.xold
+        self.res[:] = self.AHA.mul(self.x)
+        self.res -= self.x0
+        self.x -= self.rho * self.res
+        self.rel_res_norm = T(nrm2(self.res)) / self.norm_x0
+        self.reg.prox(self.x, self.rho * T(self.reg.lam))
+        for pr in self.proj:
+            pr.prox(self.x)
+        if self.restart == "gradient":
+            if np.real(dotc(self.res, self.x - self.xold)) > 0:
+                self.theta = T(1)
+        self.theta_old = self.theta
+        self.theta = (T(1) + np.sqrt(T(1) + T(4) * self.theta_old * self.theta_old)) / T(2)
+        self.iteration += 1
+        return self.x
+
+    def solution(self):
+        return self.x
+
+    def convergence(self):
+        return {"residual": self.T(nrm2(self.res))}
+
+
+# --------------------------------------------------------------------------------------
+# IterativeSolvers.cg!  (v0.9; restated -- parity unpinned)
+# --------------------------------------------------------------------------------------
+
+
+def cg_inplace(x, Aop: Callable, b, maxiter, reltol, abstol=0.0):
+    """Unpreconditioned CG with warm start: u=0; r=b-A x; tol=max(reltol*||r||, abstol); prev=1.
+    Returns number of iterations performed."""
+    T = _rt(x)
+    u = np.zeros_like(x)
+    r = b.copy()
+    c = Aop(x)
+    r -= c
+    residual = T(nrm2(r))
+    tol = max(T(reltol) * residual, T(abstol))
+    prev = T(1)
+    it = 0
+    while it < maxiter and residual > tol:
+        beta = residual * residual / (prev * prev)
+        u[:] = r + beta * u
+        c = Aop(u)
+        alpha = x.dtype.type(residual * residual / dotc(u, c))
+        x += alpha * u
+        r -= alpha * c
+        prev = residual
+        residual = T(nrm2(r))
+        it += 1
+    return it
+
+
+# --------------------------------------------------------------------------------------
+# ADMM  (src/ADMM.jl)
+# --------------------------------------------------------------------------------------
+
+
+class IdentityTrafo:
+    """opEye (src/ADMM.jl:84)"""
+
+    def __init__(self, n):
+        self.n_out = n
+
+    def mul(self, x):
+        return x.copy()
+
+    def mul_adj(self, z):
+        return z.copy()
+
+
+class GradientTrafo:
+    """regTrafo = GradientOp(...)  (src/ADMM.jl:74)"""
+
+    def __init__(self, shape, dims=None):
+        self.shape = tuple(shape)
+        self.dims0 = _as_dims(self.shape, dims)
+        self.n_out = grad_len(self.shape, self.dims0)
+
+    def mul(self, x):
+        return grad_apply(x, self.shape, self.dims0)
+
+    def mul_adj(self, g):
+        return grad_apply_t(g, self.shape, self.dims0)
+
+
+class ADMM:
+    """src/ADMM.jl:80-162 (ctor), :191-220 (init!), :230-322 (iterate), :324-332 (converged/done)."""
+
+    def __init__(self, A, AHA=None, reg=None, regTrafo=None, rho=1e-1, vary_rho="none", iterations=10,
+                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree"):
+        self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        if AHA is None:
+            AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
+        elif not hasattr(AHA, "mul"):
+            AHA = GramOp(AHA=AHA)
+        self.AHA = AHA
+        self.dtype = np.dtype(AHA.dtype)
+        self.T = real_dtype(self.dtype).type
+        T = self.T
+        n = AHA.shape[1]
+        regs = [L1Regularization(0.0)] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
+        self.proj = [r for r in regs if _is_projection(r)]
+        self.reg = [r for r in regs if not _is_projection(r)]
+        if regTrafo is None:
+            regTrafo = [IdentityTrafo(n) for _ in self.reg]
+        elif not isinstance(regTrafo, (list, tuple)):
+            regTrafo = [regTrafo]
+        self.regTrafo = list(regTrafo)
+        assert len(self.reg) == len(self.regTrafo), "reg and regTrafo must have the same length"
+        if np.isscalar(rho):
+            self.rho0 = np.array([T(rho) for _ in self.reg], dtype=T)
+        else:
+            self.rho0 = np.asarray(rho, dtype=T)
+        self.vary_rho = vary_rho
+        self.iterations = int(iterations)
+        self.iterationsCG = int(iterationsCG)
+        eps = np.finfo(T).eps
+        self.absTol = T(eps if absTol is None else absTol)
+        self.relTol = T(eps if relTol is None else relTol)
+        self.tolInner = T(tolInner)
+        self.x = np.zeros(n, self.dtype)
+        self.xold = np.zeros(n, self.dtype)
+        self.beta = np.zeros(n, self.dtype)
+        self.beta_y = np.zeros(n, self.dtype)
+        self.z = [np.zeros(t.n_out, self.dtype) for t in self.regTrafo]
+        self.zold = [np.zeros(t.n_out, self.dtype) for t in self.regTrafo]
+        self.u = [np.zeros(t.n_out, self.dtype) for t in self.regTrafo]
+        self.uold = [np.zeros(t.n_out, self.dtype) for t in self.regTrafo]
+        k = len(self.reg)
+        self.rho = self.rho0.copy()
+        self.rk = np.full(k, np.inf, T)
+        self.sk = np.full(k, np.inf, T)
+        self.eps_pri = np.zeros(k, T)
+        self.eps_dua = np.zeros(k, T)
+        self.Delta = np.full(k, np.inf, T)
+        self.sigma_abs = T(0)
+        self.iteration = 0
+        self.cg_iters: List[int] = []
+
+    def composite_mul(self, u):
+        """compositeAHA = AHA + sum_i rho_i Phi_i^H Phi_i  (src/ADMM.jl:141-159)"""
+        out = self.AHA.mul(u)
+        for i, t in enumerate(self.regTrafo):
+            out = out + self.rho[i] * t.mul_adj(t.mul(u))
+        return out.astype(self.dtype)
+
+    def init(self, b, x0=0):
+        b = np.asarray(b, dtype=self.dtype)
+        T = self.T
+        self.x[:] = x0
+        if self.A is None:
+            self.beta_y[:] = b
+        else:
+            self.beta_y[:] = self.A.mul_adj(b)
+        for i, t in enumerate(self.regTrafo):
+            self.z[i][:] = t.mul(self.x)
+            self.u[i][:] = 0
+        self.rk[:] = np.inf
+        self.sk[:] = np.inf
+        self.eps_pri[:] = 0
+        self.eps_dua[:] = 0
+        self.sigma_abs = T(np.sqrt(T(len(b)))) * self.absTol
+        self.Delta[:] = np.inf
+        self.rho[:] = self.rho0
+        self.iteration = 0
+        self.cg_iters = []
+
+    def converged(self):
+        for i in range(len(self.reg)):
+            if self.rk[i] >= self.sigma_abs + self.relTol * self.eps_pri[i]:
+                return False
+            if self.sk[i] >= self.sigma_abs + self.relTol * self.eps_dua[i]:
+                return False
+        return True
+
+    def done(self):
+        return self.converged() or self.iteration >= self.iterations
+
+    def iterate(self):
+        if self.done():
+            return None
+        T = self.T
+        # 1. x update: (A'A + sum rho Phi'Phi) x = A'b + sum rho Phi'(z - u)       :236-244
+        self.beta[:] = self.beta_y
+        for i, t in enumerate(self.regTrafo):
+            self.beta += self.rho[i] * t.mul_adj(self.z[i])
+            self.beta += (-self.rho[i]) * t.mul_adj(self.u[i])
+        self.xold[:] = self.x
+        self.cg_iters.append(cg_inplace(self.x, self.composite_mul, self.beta, self.iterationsCG, self.tolInner))
+        for pr in self.proj:
+            pr.prox(self.x)
+        for i, t in enumerate(self.regTrafo):
+            self.z[i], self.zold[i] = self.zold[i], self.z[i]  # swap :252-254
+            self.z[i][:] = t.mul(self.x)
+            self.z[i] += self.u[i]
+            if self.rho[i] != 0:
+                self.reg[i].prox(self.z[i], T(self.reg[i].lam) / (T(2) * self.rho[i]))  # :261
+            self.uold[i][:] = self.u[i]
+            self.u[i] += t.mul(self.x)
+            self.u[i] -= self.z[i]
+            # convergence bookkeeping that hijacks xold / zold as scratch :282-299
+            self.xold[:] = self.x - self.xold
+            self.zold[i][:] = self.z[i] - self.zold[i]
+            self.uold[i][:] = self.u[i] - self.uold[i]
+            Delta_old = self.Delta[i]
+            self.Delta[i] = T(nrm2(self.xold)) + T(nrm2(self.zold[i])) + T(nrm2(self.uold[i]))
+            self.xold[:] = t.mul_adj(self.zold[i])
+            self.sk[i] = self.rho[i] * T(nrm2(self.xold))
+            self.zold[i][:] = t.mul(self.x)
+            self.eps_pri[i] = max(T(nrm2(self.zold[i])), T(nrm2(self.z[i])))
+            self.zold[i] -= self.z[i]
+            self.rk[i] = T(nrm2(self.zold[i]))
+            self.xold[:] = t.mul_adj(self.u[i])
+            self.eps_dua[i] = self.rho[i] * T(nrm2(self.xold))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if (self.vary_rho == "balance" and self.rk[i] / self.eps_pri[i] > T(10) * self.sk[i] / self.eps_dua[i]) or (
+                    self.vary_rho == "PnP" and self.Delta[i] / Delta_old > T(0.9)
+                ):
+                    self.rho[i] *= T(2)
+                    self.u[i] /= T(2)
+                elif self.vary_rho == "balance" and self.sk[i] / self.eps_dua[i] > T(10) * self.rk[i] / self.eps_pri[i]:
+                    self.rho[i] /= T(2)
+                    self.u[i] *= T(2)
+        self.iteration += 1
+        return self.x
+
+    def solution(self):
+        return self.x
+
+    def convergence(self):
+        return {"primal": self.rk.copy(), "dual": self.sk.copy()}
+
+
+# --------------------------------------------------------------------------------------
+# driver: solve! cadence and matrix right-hand sides
+# --------------------------------------------------------------------------------------
+
+
+def solve(solver, b, callbacks=None, **kw):
+    """src/RegularizedLeastSquares.jl:103-117: init!, callbacks(solver, 0), then one callback per
+    completed iteration.  A 2-D b runs the SequentialState/MultiThreadingState semantics of
+    src/MultiThreading.jl:30-79 (independent per-column states, per-column retirement)."""
+    b = np.asarray(b)
+    if callbacks is None:
+        callbacks = []
+    elif callable(callbacks):
+        callbacks = [callbacks]
+    if b.ndim == 2:
+        return _solve_matrix(solver, b, callbacks, **kw)
+    solver.init(b, **kw)
+    for cb in callbacks:
+        cb(solver, 0)
+    it = 0
+    while solver.iterate() is not None:
+        it += 1
+        for cb in callbacks:
+            cb(solver, it)
+    return solver.solution()
+
+
+def _solve_matrix(solver, B, callbacks, **kw):
+    import copy
+
+    states = [copy.deepcopy(solver) for _ in range(B.shape[1])]
+    for s, col in zip(states, B.T):
+        s.init(np.ascontiguousarray(col), **kw)
+    active = [True] * len(states)
+    for cb in callbacks:
+        cb(solver, 0)
+    it = 0
+    while any(active):
+        for i, s in enumerate(states):
+            if active[i] and s.iterate() is None:
+                active[i] = False
+        it += 1
+        # iterate(solver, ::AbstractMatrixSolverState) returns non-nothing whenever a state was
+        # active at entry, so the callback also fires for the round that retires the last state
+        for cb in callbacks:
+            cb(solver, it)
+    solver._matrix_states = states
+    return np.stack([s.solution() for s in states], axis=1)
+
+
+# --------------------------------------------------------------------------------------
+# synthetic inputs: zero-mean normal entries, planted solution
+# --------------------------------------------------------------------------------------
+
+
+def make_problem(M, N, dtype, seed, n_rhs=None):
+    """A ~ randn (complex: (g1 + i g2)/sqrt 2), x_true ~ randn, b = A x_true computed in float64 and
+    cast.  Returns (A [Fortran order], x_true, b)."""
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(dtype)
+    cplx = dt.kind == "c"
+
+    def draw(*shape):
+        if cplx:
+            return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / math.sqrt(2.0)
+        return rng.standard_normal(shape)
+
+    A64 = draw(M, N)
+    xs = (N,) if n_rhs is None else (N, n_rhs)
+    x64 = draw(*xs)
+    b64 = A64 @ x64
+    return np.asfortranarray(A64.astype(dt)), x64.astype(dt), np.asfortranarray(b64.astype(dt))

@@ -1,0 +1,20 @@
+"""MI355X (gfx950) backend for the iterative inner loop of RegularizedLeastSquares.jl.
+
+Host-side mirror of the reference interface for the hot path only (CGNR / FISTA / ADMM on a dense
+operator, BLAS-1, prox L1 / L2 / L21 / TV / Positive / Real); every numeric step runs in
+librls_mi355x.so (hand-written HIP, C ABI in include/rls_mi355x.h).  Julia's `f!` is spelled `f_`.
+
+The directory name contains a dot, so it cannot be imported with a plain `import` statement:
+use the `rls_amd` shim at the repository root (`import rls_amd`).
+"""
+from ._lib import LIB_PATH, RLSError, load  # noqa: F401
+from .arrays import Context, DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle, default_context  # noqa: F401
+from .regularization import (AbstractParameterizedRegularization, AbstractProjectionRegularization,  # noqa: F401
+                             AbstractRegularization, GradientOp, L1Regularization, L2Regularization,
+                             L21Regularization, MeasurementBasedNormalization, NoNormalization,
+                             PositiveRegularization, RealRegularization, SystemMatrixBasedNormalization,
+                             TVRegularization, lam, norm, prox_)
+from .solvers import (ADMM, CGNR, FISTA, AbstractLinearSolver, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
+                      SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,
+                      iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,
+                      solverstate)

@@ -1,0 +1,153 @@
+"""ctypes binding of librls_mi355x.so (C ABI: include/rls_mi355x.h).
+
+There is NO fallback: if the shared library is missing, or a call returns a non-zero status, this
+module raises.  The product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librls_mi355x.so")
+
+F32, C32 = 0, 1
+OP_N, OP_T, OP_C = 0, 1, 2
+REG_NONE, REG_L1, REG_L2, REG_L21, REG_TV = 0, 1, 2, 3, 4
+PROJ_NONE, PROJ_REAL, PROJ_POSITIVE = 0, 1, 2
+
+
+class RLSError(RuntimeError):
+    pass
+
+
+class CgnrStatus(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("done", C.c_int32), ("alpha_re", C.c_float), ("alpha_im", C.c_float),
+                ("beta_re", C.c_float), ("beta_im", C.c_float), ("zeta", C.c_float), ("residual", C.c_float),
+                ("z0", C.c_float)]
+
+
+class FistaStatus(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("done", C.c_int32), ("theta", C.c_float), ("theta_old", C.c_float),
+                ("rel_res_norm", C.c_float), ("residual", C.c_float), ("norm_x0", C.c_float)]
+
+
+class CgStatus(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("residual", C.c_float), ("tol", C.c_float)]
+
+
+_vp, _i32, _i64, _f, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_pvp = C.POINTER(C.c_void_p)
+_pf = C.POINTER(C.c_float)
+_pi64 = C.POINTER(C.c_int64)
+_pi32 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes).  Must list every symbol the header declares (tests/test_abi.py checks).
+PROTOTYPES = {
+    "rls_abi_version": (_i32, []),
+    "rls_ctx_create": (_i32, [_i32, _pvp]),
+    "rls_ctx_create_on_stream": (_i32, [_i32, _vp, _pvp]),
+    "rls_ctx_destroy": (_i32, [_vp]),
+    "rls_ctx_sync": (_i32, [_vp]),
+    "rls_ctx_stream": (_vp, [_vp]),
+    "rls_last_error_string": (C.c_char_p, [_vp]),
+    "rls_device_count": (_i32, [_pi32]),
+    "rls_tune_set": (_i32, [_vp, C.c_char_p, _i32]),
+    "rls_malloc": (_i32, [_vp, _sz, _pvp]),
+    "rls_free": (_i32, [_vp, _vp]),
+    "rls_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "rls_memcpy_d2h": (_i32, [_vp, _vp, _vp, _sz]),
+    "rls_memcpy_d2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "rls_fill": (_i32, [_vp, _i32, _i64, _vp, _f, _f]),
+    "rls_timer_start": (_i32, [_vp]),
+    "rls_timer_stop_ms": (_i32, [_vp, _pf]),
+    "rls_gemv": (_i32, [_vp, _i32, _i32, _i64, _i64, _f, _f, _vp, _i64, _vp, _f, _f, _vp]),
+    "rls_nrm2": (_i32, [_vp, _i32, _i64, _vp, _pf]),
+    "rls_nrm2_dev": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "rls_dotc": (_i32, [_vp, _i32, _i64, _vp, _vp, _pf]),
+    "rls_dotc_dev": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    "rls_asum": (_i32, [_vp, _i32, _i64, _vp, _pf]),
+    "rls_scal": (_i32, [_vp, _i32, _i64, _f, _f, _vp]),
+    "rls_axpy": (_i32, [_vp, _i32, _i64, _f, _f, _vp, _vp]),
+    "rls_axpby": (_i32, [_vp, _i32, _i64, _f, _f, _vp, _f, _f, _vp]),
+    "rls_lincomb": (_i32, [_vp, _i32, _i64, _f, _f, _vp, _f, _f, _vp, _vp]),
+    "rls_prox_l1": (_i32, [_vp, _i32, _i64, _vp, _f]),
+    "rls_prox_l2": (_i32, [_vp, _i32, _i64, _vp, _f]),
+    "rls_prox_l21": (_i32, [_vp, _i32, _i64, _i64, _vp, _f]),
+    "rls_prox_positive": (_i32, [_vp, _i32, _i64, _vp]),
+    "rls_prox_real": (_i32, [_vp, _i32, _i64, _vp]),
+    "rls_norm_l21": (_i32, [_vp, _i32, _i64, _i64, _vp, _f, _pf]),
+    "rls_tv_grad_len": (_i64, [_i32, _pi64, _i32, _pi32]),
+    "rls_tv_grad": (_i32, [_vp, _i32, _i32, _pi64, _i32, _pi32, _vp, _vp, _f, _f]),
+    "rls_tv_grad_t": (_i32, [_vp, _i32, _i32, _pi64, _i32, _pi32, _vp, _vp, _f, _f]),
+    "rls_tv_restrict": (_i32, [_vp, _i32, _i64, _vp]),
+    "rls_tv_lincomb": (_i32, [_vp, _i32, _i64, _vp, _f, _vp, _f, _vp]),
+    "rls_prox_tv_workspace_bytes": (_sz, [_i32, _i32, _pi64, _i32, _pi32]),
+    "rls_prox_tv_fgp": (_i32, [_vp, _i32, _i32, _pi64, _i32, _pi32, _vp, _f, _i32, _vp, _sz]),
+    "rls_operator_create": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _pvp]),
+    "rls_operator_set_gram": (_i32, [_vp, _vp, _i64]),
+    "rls_operator_destroy": (_i32, [_vp]),
+    "rls_operator_mul": (_i32, [_vp, _vp, _vp]),
+    "rls_operator_mul_adj": (_i32, [_vp, _vp, _vp]),
+    "rls_operator_mul_normal": (_i32, [_vp, _vp, _vp]),
+    "rls_gram": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _i64]),
+    "rls_cgnr_create": (_i32, [_vp, _vp, _vp, _vp, _vp, _pvp]),
+    "rls_cgnr_destroy": (_i32, [_vp]),
+    "rls_cgnr_init": (_i32, [_vp, _vp, _f, _f, _i32]),
+    "rls_cgnr_step": (_i32, [_vp, _i32]),
+    "rls_cgnr_get_status": (_i32, [_vp, C.POINTER(CgnrStatus)]),
+    "rls_cgnr_init_local_a": (_i32, [_vp, _vp, _f, _f, _i32]),
+    "rls_cgnr_init_local_b": (_i32, [_vp]),
+    "rls_cgnr_step_local_a": (_i32, [_vp]),
+    "rls_cgnr_step_local_b": (_i32, [_vp]),
+    "rls_fista_create": (_i32, [_vp, _vp, _vp, _vp, _vp, _pvp]),
+    "rls_fista_destroy": (_i32, [_vp]),
+    "rls_fista_set_reg": (_i32, [_vp, _i32, _f, _i64, _i32]),
+    "rls_fista_init": (_i32, [_vp, _vp, _f, _f, _f, _i32, _i32]),
+    "rls_fista_set_start": (_i32, [_vp, _vp]),
+    "rls_fista_step": (_i32, [_vp, _i32]),
+    "rls_fista_get_status": (_i32, [_vp, C.POINTER(FistaStatus)]),
+    "rls_fista_solution": (_i32, [_vp, _pvp]),
+    "rls_cg_create": (_i32, [_vp, _vp, _vp, _vp, _pvp]),
+    "rls_cg_destroy": (_i32, [_vp]),
+    "rls_cg_solve": (_i32, [_vp, _vp, _vp, _f, _i32, _f]),
+    "rls_cg_get_status": (_i32, [_vp, C.POINTER(CgStatus)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C regularizedleastsquares.jl_amd/csrc`).  There is no CPU fallback.")
+    # torch bundles its own libamdhip64.so under the same soname; whichever HIP runtime is loaded
+    # first serves both, so bring torch's in first when torch is installed (two runtimes in one
+    # process would not share streams or allocations).
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing only; the library itself links libamdhip64 directly
+            pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, status, what=""):
+    if status != 0:
+        msg = ""
+        if ctx_handle:
+            raw = load().rls_last_error_string(ctx_handle)
+            msg = raw.decode() if raw else ""
+        raise RLSError(f"{what} failed with status {status}: {msg}")

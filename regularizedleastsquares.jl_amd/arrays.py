@@ -1,0 +1,342 @@
+"""Device array / operator types: the backend's answer to the reference's implicit array protocol
+(layer L1; section 8b "methods the unchanged solvers call").
+
+  Context       rls_ctx: one per GPU (device + stream + reduction workspace)
+  DeviceVector  the vector type of b and of every solver state vector (`similar(b, n)`)
+  DeviceMatrix  the operator type of A: column-major dense matrix; `A.H @ A`-style normal operators
+                are lazy (`NormalOperator`) so the unchanged constructors land in matrix-free mode
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import C32, F32, OP_C, OP_N, OP_T, RLSError, check
+
+_DT = {np.dtype(np.float32): F32, np.dtype(np.complex64): C32}
+_NP = {F32: np.dtype(np.float32), C32: np.dtype(np.complex64)}
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt not in _DT:
+        raise TypeError(f"the MI355X backend computes in Float32 / ComplexF32; got {dt}")
+    return _DT[dt]
+
+
+class Context:
+    """rls_ctx wrapper.  `stream=None` creates a private non-blocking stream; pass a hipStream_t
+    handle (e.g. torch.cuda.current_stream().cuda_stream) to share one."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        if stream is None:
+            st = self.lib.rls_ctx_create(device, C.byref(h))
+        else:
+            st = self.lib.rls_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h))
+        if st != 0 or not h:
+            raise RLSError(f"rls_ctx_create(device={device}) failed with status {st}: no usable MI355X device? "
+                           "(there is no CPU fallback)")
+        self.handle = h
+        self.device = device
+
+    def sync(self):
+        check(self.handle, self.lib.rls_ctx_sync(self.handle), "rls_ctx_sync")
+
+    def tune(self, **kw):
+        for k, v in kw.items():
+            check(self.handle, self.lib.rls_tune_set(self.handle, k.encode(), int(v)), f"rls_tune_set({k})")
+
+    @property
+    def stream(self) -> int:
+        return self.lib.rls_ctx_stream(self.handle) or 0
+
+    def timer_start(self):
+        check(self.handle, self.lib.rls_timer_start(self.handle), "rls_timer_start")
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        check(self.handle, self.lib.rls_timer_stop_ms(self.handle, C.byref(ms)), "rls_timer_stop_ms")
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.rls_ctx_destroy(self.handle)
+            self.handle = None
+
+
+_default_ctx: Dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class _DeviceBuffer:
+    """owning device allocation (the Julia side would attach a finalizer calling rls_free)"""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.handle, ctx.lib.rls_malloc(ctx.handle, max(self.nbytes, 1), C.byref(p)), "rls_malloc")
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.ctx.lib.rls_free(self.ctx.handle, C.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = None
+
+
+class DeviceVector:
+    """Length-n Float32 / ComplexF32 vector in HBM."""
+
+    def __init__(self, n: int, dtype, ctx: Optional[Context] = None, _buf=None, _offset=0):
+        self.ctx = ctx or default_context()
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self.code = dtype_code(self.dtype)
+        self._buf = _buf or _DeviceBuffer(self.ctx, self.n * self.dtype.itemsize)
+        self.ptr = self._buf.ptr + _offset
+
+    # --- construction -----------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, a, ctx: Optional[Context] = None) -> "DeviceVector":
+        a = np.ascontiguousarray(a)
+        if a.ndim != 1:
+            raise ValueError("DeviceVector.from_host expects a 1-D array")
+        v = cls(a.shape[0], a.dtype, ctx)
+        v.copy_from_host(a)
+        return v
+
+    def similar(self, n: Optional[int] = None) -> "DeviceVector":
+        return DeviceVector(self.n if n is None else n, self.dtype, self.ctx)
+
+    def copy(self) -> "DeviceVector":
+        out = self.similar()
+        out.copy_from(self)
+        return out
+
+    # --- transfers --------------------------------------------------------------------------
+    def copy_from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.size != self.n:
+            raise ValueError(f"size mismatch: {a.size} vs {self.n}")
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_memcpy_h2d(h, self.ptr, a.ctypes.data, a.nbytes), "rls_memcpy_h2d")
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=self.dtype)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_memcpy_d2h(h, out.ctypes.data, self.ptr, out.nbytes), "rls_memcpy_d2h")
+        return out
+
+    def copy_from(self, other: "DeviceVector"):
+        if other.n != self.n or other.dtype != self.dtype:
+            raise ValueError("copy_from: shape/dtype mismatch")
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_memcpy_d2d(h, self.ptr, other.ptr, self.n * self.dtype.itemsize), "rls_memcpy_d2d")
+
+    # --- BLAS-1 (names follow LinearAlgebra) ----------------------------------------------------
+    def fill_(self, value):
+        value = complex(value)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_fill(h, self.code, self.n, self.ptr, value.real, value.imag), "rls_fill")
+        return self
+
+    def norm(self) -> float:
+        r = (C.c_float * 2)()
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_nrm2(h, self.code, self.n, self.ptr, r), "rls_nrm2")
+        return float(r[0])
+
+    def norm1(self) -> float:
+        r = (C.c_float * 2)()
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_asum(h, self.code, self.n, self.ptr, r), "rls_asum")
+        return float(r[0])
+
+    def dot(self, other: "DeviceVector"):
+        """dot(self, other) = conj(self) . other"""
+        r = (C.c_float * 2)()
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_dotc(h, self.code, self.n, self.ptr, other.ptr, r), "rls_dotc")
+        return complex(r[0], r[1]) if self.code == C32 else float(r[0])
+
+    def rmul_(self, a):
+        a = complex(a)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_scal(h, self.code, self.n, a.real, a.imag, self.ptr), "rls_scal")
+        return self
+
+    def axpy_(self, a, x: "DeviceVector"):
+        """self .+= a .* x"""
+        a = complex(a)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_axpy(h, self.code, self.n, a.real, a.imag, x.ptr, self.ptr), "rls_axpy")
+        return self
+
+    def axpby_(self, a, x: "DeviceVector", b):
+        """self = a x + b self"""
+        a, b = complex(a), complex(b)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_axpby(h, self.code, self.n, a.real, a.imag, x.ptr, b.real, b.imag, self.ptr), "rls_axpby")
+        return self
+
+    def lincomb_(self, a, x: "DeviceVector", b, y: "DeviceVector"):
+        """self = a x + b y"""
+        a, b = complex(a), complex(b)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_lincomb(h, self.code, self.n, a.real, a.imag, x.ptr, b.real, b.imag, y.ptr, self.ptr),
+              "rls_lincomb")
+        return self
+
+    def __len__(self):
+        return self.n
+
+
+class DeviceMatrix:
+    """Dense M x N operator in HBM, column-major with leading dimension lda (Julia `Matrix`)."""
+
+    def __init__(self, M: int, N: int, dtype, ctx: Optional[Context] = None, lda: Optional[int] = None):
+        self.ctx = ctx or default_context()
+        self.M, self.N = int(M), int(N)
+        self.lda = int(lda if lda is not None else max(self.M, 1))
+        self.dtype = np.dtype(dtype)
+        self.code = dtype_code(self.dtype)
+        self._buf = _DeviceBuffer(self.ctx, self.lda * self.N * self.dtype.itemsize)
+        self.ptr = self._buf.ptr
+        self._op = None
+
+    @classmethod
+    def from_host(cls, A, ctx: Optional[Context] = None) -> "DeviceMatrix":
+        A = np.asarray(A)
+        if A.ndim != 2:
+            raise ValueError("DeviceMatrix.from_host expects a 2-D array")
+        Af = np.asfortranarray(A)
+        m = cls(A.shape[0], A.shape[1], Af.dtype, ctx)
+        lib, h = m.ctx.lib, m.ctx.handle
+        check(h, lib.rls_memcpy_h2d(h, m.ptr, Af.ctypes.data, Af.nbytes), "rls_memcpy_h2d")
+        return m
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty((self.lda, self.N), dtype=self.dtype, order="F")
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_memcpy_d2h(h, out.ctypes.data, self.ptr, out.nbytes), "rls_memcpy_d2h")
+        return out[: self.M, :]
+
+    @property
+    def shape(self):
+        return (self.M, self.N)
+
+    def size(self, i: int) -> int:  # 1-based like Julia's size(A, i)
+        return (self.M, self.N)[i - 1]
+
+    def column(self, j: int) -> DeviceVector:
+        """b[:, j] (0-based j) as a fresh vector: the reference copies columns (src/MultiThreading.jl:35)"""
+        v = DeviceVector(self.M, self.dtype, self.ctx)
+        lib, h = self.ctx.lib, self.ctx.handle
+        off = j * self.lda * self.dtype.itemsize
+        check(h, lib.rls_memcpy_d2d(h, v.ptr, self.ptr + off, self.M * self.dtype.itemsize), "rls_memcpy_d2d")
+        return v
+
+    # --- mul! -------------------------------------------------------------------------------
+    def gemv_(self, op: int, x: DeviceVector, y: DeviceVector, alpha=1.0, beta=0.0):
+        """y = alpha * op(A) * x + beta * y     (5-arg mul!)"""
+        alpha, beta = complex(alpha), complex(beta)
+        nx, ny = (self.N, self.M) if op == OP_N else (self.M, self.N)
+        if x.n != nx or y.n != ny:
+            raise ValueError(f"gemv: dimension mismatch: A is {self.M}x{self.N}, x {x.n}, y {y.n}, op {op}")
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_gemv(h, self.code, op, self.M, self.N, alpha.real, alpha.imag, self.ptr, self.lda, x.ptr,
+                              beta.real, beta.imag, y.ptr), "rls_gemv")
+        return y
+
+    def mul_(self, y: DeviceVector, x: DeviceVector, alpha=1.0, beta=0.0):
+        return self.gemv_(OP_N, x, y, alpha, beta)
+
+    def mul_adj_(self, x: DeviceVector, y: DeviceVector, alpha=1.0, beta=0.0):
+        return self.gemv_(OP_C, y, x, alpha, beta)
+
+    def mul_transpose_(self, x: DeviceVector, y: DeviceVector, alpha=1.0, beta=0.0):
+        return self.gemv_(OP_T, y, x, alpha, beta)
+
+    def __matmul__(self, x: DeviceVector) -> DeviceVector:  # allocating A * x  (src/ADMM.jl:203)
+        return self.mul_(DeviceVector(self.M, self.dtype, self.ctx), x)
+
+    def gram(self) -> "DeviceMatrix":
+        """explicit AHA = A' * A on device (src/CGNR.jl:49); pass as AHA= for Gram mode"""
+        G = DeviceMatrix(self.N, self.N, self.dtype, self.ctx)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_gram(h, self.code, self.M, self.N, self.ptr, self.lda, G.ptr, G.lda), "rls_gram")
+        return G
+
+    def normal_operator(self) -> "NormalOperator":
+        """A' * A as the unchanged constructors evaluate it: lazy, matrix-free (two GEMVs per apply)"""
+        return NormalOperator(self)
+
+
+class OperatorHandle:
+    """rls_operator: forward matrix and/or Gram matrix bound to a context."""
+
+    def __init__(self, A: Optional[DeviceMatrix], gram: Optional[DeviceMatrix] = None):
+        src = A if A is not None else gram
+        if src is None:
+            raise ValueError("OperatorHandle needs A or a Gram matrix")
+        self.ctx = src.ctx
+        self.A, self.gram = A, gram
+        self.dtype, self.code = src.dtype, src.code
+        self.M = A.M if A is not None else 0
+        self.N = A.N if A is not None else gram.N
+        lib, h = self.ctx.lib, self.ctx.handle
+        o = C.c_void_p()
+        check(h, lib.rls_operator_create(h, self.code, self.M, self.N, A.ptr if A is not None else None,
+                                         A.lda if A is not None else 0, C.byref(o)), "rls_operator_create")
+        self.handle = o
+        if gram is not None:
+            if gram.M != self.N or gram.N != self.N:
+                raise ValueError("Gram matrix must be N x N")
+            check(h, lib.rls_operator_set_gram(o, gram.ptr, gram.lda), "rls_operator_set_gram")
+
+    def mul_normal_(self, v: DeviceVector, p: DeviceVector):
+        check(self.ctx.handle, self.ctx.lib.rls_operator_mul_normal(self.handle, p.ptr, v.ptr), "rls_operator_mul_normal")
+        return v
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx.lib.rls_operator_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+class NormalOperator:
+    """Lazy A^H A (LinearOperatorCollection.normalOperator): size N x N, eltype of A."""
+
+    def __init__(self, A: DeviceMatrix):
+        self.A = A
+        self.dtype = A.dtype
+        self.ctx = A.ctx
+        self.shape = (A.N, A.N)
+        self._handle = None
+
+    def size(self, i: int) -> int:
+        return self.A.N
+
+    def handle(self) -> OperatorHandle:
+        if self._handle is None:
+            self._handle = OperatorHandle(self.A)
+        return self._handle
+
+    def mul_(self, v: DeviceVector, p: DeviceVector):
+        return self.handle().mul_normal_(v, p)

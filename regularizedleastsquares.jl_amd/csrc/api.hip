@@ -1,0 +1,171 @@
+// Context, memory and timing entry points of the C ABI (include/rls_mi355x.h).
+#include "rls_common.hpp"
+
+#include <cstdlib>
+
+static int32_t ctx_setup(rls_ctx* ctx) {
+  RLS_HIP(ctx, hipEventCreate(&ctx->ev0));
+  RLS_HIP(ctx, hipEventCreate(&ctx->ev1));
+  RLS_HIP(ctx, hipMalloc((void**)&ctx->red_d, sizeof(double) * RLS_RED_SLOTS));
+  RLS_HIP(ctx, hipMalloc((void**)&ctx->res_d, sizeof(float) * RLS_RES_FLOATS));
+  RLS_HIP(ctx, hipHostMalloc((void**)&ctx->res_h, sizeof(float) * RLS_RES_FLOATS, hipHostMallocDefault));
+  return 0;
+}
+
+static int32_t ctx_create_impl(int32_t device, void* stream, bool borrow, rls_ctx** out) {
+  if (!out) return RLS_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess) return (int32_t)e;
+  if (device < 0 || device >= ndev) return RLS_E_INVALID;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return (int32_t)e;
+  rls_ctx* ctx = new rls_ctx();
+  ctx->device = device;
+  if (borrow) {
+    ctx->stream = (hipStream_t)stream;
+    ctx->own_stream = false;
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return (int32_t)e;
+    }
+    ctx->own_stream = true;
+  }
+  int32_t st = ctx_setup(ctx);
+  if (st != 0) {
+    rls_ctx_destroy(ctx);
+    return st;
+  }
+  *out = ctx;
+  return 0;
+}
+
+extern "C" {
+
+int32_t rls_abi_version(void) { return RLS_ABI_VERSION; }
+
+int32_t rls_device_count(int32_t* out) {
+  if (!out) return RLS_E_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *out = (e == hipSuccess) ? n : 0;
+  return (int32_t)e;
+}
+
+int32_t rls_ctx_create(int32_t device, rls_ctx** out) { return ctx_create_impl(device, nullptr, false, out); }
+int32_t rls_ctx_create_on_stream(int32_t device, void* hip_stream, rls_ctx** out) {
+  return ctx_create_impl(device, hip_stream, true, out);
+}
+
+int32_t rls_ctx_destroy(rls_ctx* ctx) {
+  RLS_CHECK_CTX(ctx);
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->red_d) hipFree(ctx->red_d);
+  if (ctx->res_d) hipFree(ctx->res_d);
+  if (ctx->res_h) hipHostFree(ctx->res_h);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int32_t rls_ctx_sync(rls_ctx* ctx) {
+  RLS_CHECK_CTX(ctx);
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+void* rls_ctx_stream(rls_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+const char* rls_last_error_string(rls_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
+  RLS_CHECK_CTX(ctx);
+  if (!key) return RLS_E_INVALID;
+  if (!strcmp(key, "gemvn_g")) ctx->tune.gemvn_g = value;
+  else if (!strcmp(key, "gemvn_waves")) ctx->tune.gemvn_waves = value;
+  else if (!strcmp(key, "gemvt_cols")) ctx->tune.gemvt_cols = value;
+  else if (!strcmp(key, "graph_chunk")) ctx->tune.graph_chunk = value;
+  else if (!strcmp(key, "use_graph")) ctx->tune.use_graph = value;
+  else if (!strcmp(key, "fuse_level")) ctx->tune.fuse_level = value;
+  else return rls_fail(ctx, RLS_E_INVALID, "tune_set: unknown key");
+  return 0;
+}
+
+int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out) {
+  RLS_CHECK_CTX(ctx);
+  if (!out) return rls_fail(ctx, RLS_E_INVALID, "malloc: null out");
+  *out = nullptr;
+  if (bytes == 0) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipMalloc(out, bytes));
+  return 0;
+}
+
+int32_t rls_free(rls_ctx* ctx, void* p) {
+  RLS_CHECK_CTX(ctx);
+  if (!p) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, hipFree(p));
+  return 0;
+}
+
+int32_t rls_memcpy_h2d(rls_ctx* ctx, void* dst, const void* src_h, size_t bytes) {
+  RLS_CHECK_CTX(ctx);
+  if (bytes == 0) return 0;
+  if (!dst || !src_h) return rls_fail(ctx, RLS_E_INVALID, "memcpy_h2d: null pointer");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  // pageable host memory: the copy is staged, so wait for it before the caller may reuse src_h
+  RLS_HIP(ctx, hipMemcpyAsync(dst, src_h, bytes, hipMemcpyHostToDevice, ctx->stream));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int32_t rls_memcpy_d2h(rls_ctx* ctx, void* dst_h, const void* src, size_t bytes) {
+  RLS_CHECK_CTX(ctx);
+  if (bytes == 0) return 0;
+  if (!dst_h || !src) return rls_fail(ctx, RLS_E_INVALID, "memcpy_d2h: null pointer");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipMemcpyAsync(dst_h, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int32_t rls_memcpy_d2d(rls_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  RLS_CHECK_CTX(ctx);
+  if (bytes == 0) return 0;
+  if (!dst || !src) return rls_fail(ctx, RLS_E_INVALID, "memcpy_d2d: null pointer");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+int32_t rls_timer_start(rls_ctx* ctx) {
+  RLS_CHECK_CTX(ctx);
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return 0;
+}
+
+int32_t rls_timer_stop_ms(rls_ctx* ctx, float* ms_out) {
+  RLS_CHECK_CTX(ctx);
+  if (!ms_out) return rls_fail(ctx, RLS_E_INVALID, "timer_stop: null out");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  RLS_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  RLS_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return 0;
+}
+
+int32_t rls_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int64_t N, float alpha_re, float alpha_im,
+                 const void* A, int64_t lda, const void* x, float beta_re, float beta_im, void* y) {
+  return rls_launch_gemv(ctx, dtype, op, M, N, alpha_re, alpha_im, A, lda, x, beta_re, beta_im, y, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI glue of librls_mi355x.so.
+// Public contract: include/rls_mi355x.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/rls_mi355x.h"
+
+#define RLS_WAVE 64
+
+struct rls_tuning {
+  int gemvn_g = 0;      // lanes per row group in gemv_n (0 = heuristic)
+  int gemvn_waves = 0;  // waves per workgroup in gemv_n (0 = heuristic)
+  int gemvt_cols = 0;   // columns per workgroup in gemv_t (0 = heuristic)
+  int graph_chunk = 16; // iterations captured per hipGraph
+  int use_graph = 1;
+  int fuse_level = 1;   // 0: separate BLAS-1 style update kernel; 1: fused update
+};
+
+struct rls_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[512] = {0};
+  // reduction scratch: partial sums (double) + a few result slots, and a pinned host mirror
+  double* red_d = nullptr;  // [RLS_RED_SLOTS] doubles
+  float* res_d = nullptr;   // small float result block on device
+  float* res_h = nullptr;   // pinned host mirror
+  rls_tuning tune;
+};
+
+constexpr int RLS_RED_SLOTS = 4096;
+constexpr int RLS_RES_FLOATS = 64;
+
+#define RLS_CHECK_CTX(ctx)            \
+  do {                                \
+    if (!(ctx)) return RLS_E_INVALID; \
+  } while (0)
+
+static inline int32_t rls_fail(rls_ctx* ctx, int32_t code, const char* what) {
+  if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s (code %d)", what, (int)code);
+  return code;
+}
+
+#define RLS_HIP(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      if (ctx)                                                                                   \
+        snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #expr,                 \
+                 hipGetErrorString(_e), __FILE__, __LINE__);                                     \
+      return (int32_t)_e;                                                                        \
+    }                                                                                            \
+  } while (0)
+
+#define RLS_TRY(expr)            \
+  do {                           \
+    int32_t _s = (expr);         \
+    if (_s != 0) return _s;      \
+  } while (0)
+
+static inline size_t rls_elem_size(int32_t dtype) { return dtype == RLS_C32 ? 8 : 4; }
+static inline bool rls_dtype_ok(int32_t dtype) { return dtype == RLS_F32 || dtype == RLS_C32; }
+
+// ---------------------------------------------------------------------------------------------
+// device-side scalar helpers: element type E is float (RLS_F32) or float2 (RLS_C32)
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+template <typename E>
+struct elem;
+template <>
+struct elem<float> {
+  static constexpr bool cplx = false;
+  static constexpr int vec = 4;  // elements per 16-byte load
+  __device__ static inline float zero() { return 0.f; }
+  __device__ static inline float make(float re, float) { return re; }
+  __device__ static inline float mul(float a, float b) { return a * b; }
+  __device__ static inline float mulc(float a, float b) { return a * b; }  // conj(a)*b
+  __device__ static inline float fma(float a, float b, float c) { return fmaf(a, b, c); }
+  __device__ static inline float fmac(float a, float b, float c) { return fmaf(a, b, c); }  // conj(a)*b + c
+  __device__ static inline float add(float a, float b) { return a + b; }
+  __device__ static inline float sub(float a, float b) { return a - b; }
+  __device__ static inline float scale(float s, float a) { return s * a; }
+  __device__ static inline float abs2(float a) { return a * a; }
+  __device__ static inline float absv(float a) { return fabsf(a); }
+  __device__ static inline float re(float a) { return a; }
+  __device__ static inline float im(float) { return 0.f; }
+};
+template <>
+struct elem<float2> {
+  static constexpr bool cplx = true;
+  static constexpr int vec = 2;
+  __device__ static inline float2 zero() { return make_float2(0.f, 0.f); }
+  __device__ static inline float2 make(float re, float im) { return make_float2(re, im); }
+  __device__ static inline float2 mul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  }
+  __device__ static inline float2 mulc(float2 a, float2 b) {  // conj(a) * b
+    return make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+  }
+  __device__ static inline float2 fma(float2 a, float2 b, float2 c) {  // a*b + c
+    float re = fmaf(a.x, b.x, c.x);
+    float im = fmaf(a.x, b.y, c.y);
+    re = fmaf(-a.y, b.y, re);
+    im = fmaf(a.y, b.x, im);
+    return make_float2(re, im);
+  }
+  __device__ static inline float2 fmac(float2 a, float2 b, float2 c) {  // conj(a)*b + c
+    float re = fmaf(a.x, b.x, c.x);
+    float im = fmaf(a.x, b.y, c.y);
+    re = fmaf(a.y, b.y, re);
+    im = fmaf(-a.y, b.x, im);
+    return make_float2(re, im);
+  }
+  __device__ static inline float2 add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+  __device__ static inline float2 sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+  __device__ static inline float2 scale(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
+  __device__ static inline float abs2(float2 a) { return fmaf(a.x, a.x, a.y * a.y); }
+  __device__ static inline float absv(float2 a) { return hypotf(a.x, a.y); }
+  __device__ static inline float re(float2 a) { return a.x; }
+  __device__ static inline float im(float2 a) { return a.y; }
+};
+
+// complex scalar carried in double precision on the device (alpha, beta, dot results)
+struct dcomplex {
+  double re, im;
+};
+__device__ static inline dcomplex dc_div(dcomplex a, dcomplex b) {
+  double d = b.re * b.re + b.im * b.im;
+  return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+
+// wave-level sum (64 lanes), result valid in every lane
+__device__ static inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// block-level sum of up to 16 waves; `smem` needs 16 doubles; result valid in every thread.
+// Deterministic: fixed tree inside the wave, fixed order across waves.
+__device__ static inline double block_sum(double v, double* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // protect smem reuse across consecutive calls
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < nw; ++i) s += smem[i];
+  return s;
+}
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch entry points implemented in the .hip files (all enqueue on ctx->stream)
+// ---------------------------------------------------------------------------------------------
+// gemv.hip.  `skip` (nullable) is a device int: when non-zero at kernel entry the kernel is a no-op
+int32_t rls_launch_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int64_t N, float ar, float ai,
+                        const void* A, int64_t lda, const void* x, float br, float bi, void* y, const int* skip);

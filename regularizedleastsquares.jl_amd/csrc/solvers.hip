@@ -1,0 +1,951 @@
+// Operator handle and the fused solver steps: CGNR (src/CGNR.jl:107-185), FISTA
+// (src/FISTA.jl:110-189) and IterativeSolvers.cg! as ADMM calls it (src/ADMM.jl:244).
+//
+// One iteration = the normal-operator apply (two GEMVs, matrix-free; one in Gram mode) plus ONE
+// single-workgroup "update" kernel that holds every scalar (alpha, beta, zeta, theta, residuals,
+// iteration count, done flag) in device memory, so the host never synchronises inside the loop
+// (the reference's generic GPU path pays 4-5 blocking scalar read-backs per iteration).
+// Once `done` is set every later kernel of the plan exits at entry, which reproduces the
+// reference's "stop at the first iteration where done() holds" exactly while letting the host
+// enqueue iterations in hipGraph-captured chunks.
+#include "rls_common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// operator
+// ---------------------------------------------------------------------------------------------
+struct rls_operator {
+  rls_ctx* ctx;
+  int32_t dtype;
+  int64_t M, N;
+  const void* A;  // may be null (Gram-only operator)
+  int64_t lda;
+  const void* G;  // Gram matrix (N x N) or null
+  int64_t ldg;
+  void* t;        // length-M scratch for the matrix-free normal operator
+};
+
+static int32_t op_normal(rls_operator* op, const void* p, void* v, const int* skip) {
+  rls_ctx* ctx = op->ctx;
+  if (op->G) return rls_launch_gemv(ctx, op->dtype, RLS_OP_N, op->N, op->N, 1.f, 0.f, op->G, op->ldg, p, 0.f, 0.f, v, skip);
+  if (!op->A) return rls_fail(ctx, RLS_E_STATE, "operator has neither A nor a Gram matrix");
+  RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_N, op->M, op->N, 1.f, 0.f, op->A, op->lda, p, 0.f, 0.f, op->t, skip));
+  return rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, op->t, 0.f, 0.f, v, skip);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hipGraph chunking shared by the three plans
+// ---------------------------------------------------------------------------------------------
+struct step_graph {
+  hipGraphExec_t exec = nullptr;
+  int steps = 0;
+  bool failed = false;
+};
+
+template <typename F>
+static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue_one) {
+  const int chunk = ctx->tune.graph_chunk;
+  while (n_steps > 0) {
+    if (ctx->tune.use_graph && chunk > 1 && n_steps >= chunk && !big->failed) {
+      if (!big->exec || big->steps != chunk) {
+        if (big->exec) {
+          hipGraphExecDestroy(big->exec);
+          big->exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        int32_t st = 0;
+        if (e == hipSuccess) {
+          for (int i = 0; i < chunk && st == 0; ++i) st = enqueue_one();
+          e = hipStreamEndCapture(ctx->stream, &graph);
+        }
+        if (e != hipSuccess || st != 0 || !graph ||
+            hipGraphInstantiate(&big->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+          big->failed = true;  // fall back to eager launches (still the HIP kernels)
+          big->exec = nullptr;
+          (void)hipGetLastError();
+        } else {
+          big->steps = chunk;
+        }
+        if (graph) hipGraphDestroy(graph);
+        if (big->failed) continue;
+      }
+      RLS_HIP(ctx, hipGraphLaunch(big->exec, ctx->stream));
+      n_steps -= chunk;
+    } else {
+      RLS_TRY(enqueue_one());
+      n_steps -= 1;
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CGNR
+// ---------------------------------------------------------------------------------------------
+struct cgnr_scalars {
+  double rr;     // ||r||^2 now
+  double z0;     // ||A^H b||
+  double zeta;   // ||r||^2 at the start of the last iteration
+  double alpha_re, alpha_im, beta_re, beta_im;
+  float lambda, rel_tol;
+  int iteration, max_iter, done, pad;
+};
+
+struct rls_cgnr {
+  rls_operator* op;
+  int device;
+  void *x, *r, *p, *v;
+  cgnr_scalars* sc;    // device
+  cgnr_scalars* sc_h;  // pinned host
+  step_graph graph;
+  bool initialised;
+};
+
+constexpr int UPD_THREADS = 1024;
+
+// after r = A^H b:  x = 0, v = 0, p = r, z0 = ||r||, scalars reset          (src/CGNR.jl:108-126)
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void cgnr_init_kernel(E* __restrict__ x, const E* __restrict__ r,
+                                                                E* __restrict__ p, E* __restrict__ v, int64_t n,
+                                                                cgnr_scalars* sc, float lambda, float rel_tol,
+                                                                int max_iter) {
+  __shared__ double sm[16];
+  double rr = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E ri = r[i];
+    x[i] = elem<E>::zero();
+    v[i] = elem<E>::zero();
+    p[i] = ri;
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum(rr, sm);
+  if (threadIdx.x == 0) {
+    sc->rr = rr;
+    sc->z0 = sqrt(rr);
+    sc->zeta = 0.0;
+    sc->alpha_re = sc->alpha_im = sc->beta_re = sc->beta_im = 0.0;
+    sc->lambda = lambda;
+    sc->rel_tol = rel_tol;
+    sc->iteration = 0;
+    sc->max_iter = max_iter;
+    // done() evaluated before the first iteration: ||r||/z0 <= relTol || 0 >= min(iterations, N)
+    const float ratio = (float)(sqrt(rr) / sqrt(rr));  // NaN when r == 0, as in the reference
+    sc->done = (ratio <= rel_tol) || (0 >= max_iter);
+  }
+}
+
+// the BLAS-1 part of one CGNR iteration, src/CGNR.jl:153-176, after v = AHA p
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void cgnr_update_kernel(E* __restrict__ x, E* __restrict__ r,
+                                                                  E* __restrict__ p, const E* __restrict__ v,
+                                                                  int64_t n, cgnr_scalars* sc) {
+  if (sc->done) return;
+  __shared__ double sm[16];
+  const float lambda = sc->lambda;
+  const double zeta = sc->rr;  // zeta = ||r||^2                                        :153
+  // normvl = <p, v> (conjugating, complex-typed) and ||p||^2                           :154,158
+  double nre = 0.0, nim = 0.0, pp = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E pi = p[i], vi = v[i];
+    nre += (double)elem<E>::re(pi) * (double)elem<E>::re(vi) + (double)elem<E>::im(pi) * (double)elem<E>::im(vi);
+    if constexpr (elem<E>::cplx)
+      nim += (double)elem<E>::re(pi) * (double)elem<E>::im(vi) - (double)elem<E>::im(pi) * (double)elem<E>::re(vi);
+    if (lambda > 0.f)
+      pp += (double)elem<E>::re(pi) * (double)elem<E>::re(pi) + (double)elem<E>::im(pi) * (double)elem<E>::im(pi);
+  }
+  nre = block_sum(nre, sm);
+  if constexpr (elem<E>::cplx) nim = block_sum(nim, sm);
+  if (lambda > 0.f) pp = block_sum(pp, sm);
+  // alpha = zeta / (normvl + lambda ||p||^2)                                            :156-161
+  dcomplex den = {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim};
+  dcomplex alpha = dc_div({zeta, 0.0}, den);
+  const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
+  const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
+  // x += alpha p ; r -= alpha v ; r -= lambda alpha p                                   :163-169
+  double rr = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E pi = p[i];
+    x[i] = elem<E>::fma(pi, a, x[i]);
+    E ri = elem<E>::fma(v[i], na, r[i]);
+    if (lambda > 0.f) ri = elem<E>::fma(elem<E>::scale(-lambda, pi), a, ri);
+    r[i] = ri;
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum(rr, sm);
+  // beta = <r, r> / zeta ; p = beta p + r                                               :171-174
+  const double beta = rr / zeta;
+  const float bf = (float)beta;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) p[i] = elem<E>::add(elem<E>::scale(bf, p[i]), r[i]);
+  if (threadIdx.x == 0) {
+    sc->zeta = zeta;
+    sc->rr = rr;
+    sc->alpha_re = alpha.re;
+    sc->alpha_im = alpha.im;
+    sc->beta_re = beta;
+    sc->beta_im = 0.0;
+    const int it = sc->iteration + 1;
+    sc->iteration = it;
+    const float ratio = (float)(sqrt(rr) / sc->z0);
+    sc->done = (ratio <= sc->rel_tol) || (it >= sc->max_iter);  // :181-185
+  }
+}
+
+template <typename E>
+static void cgnr_launch_init(rls_cgnr* s, float lambda, float rel_tol, int max_iter) {
+  rls_operator* op = s->op;
+  hipLaunchKernelGGL(cgnr_init_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->x, (const E*)s->r,
+                     (E*)s->p, (E*)s->v, op->N, s->sc, lambda, rel_tol, max_iter);
+}
+template <typename E>
+static void cgnr_launch_update(rls_cgnr* s) {
+  rls_operator* op = s->op;
+  hipLaunchKernelGGL(cgnr_update_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->x, (E*)s->r,
+                     (E*)s->p, (const E*)s->v, op->N, s->sc);
+}
+
+static int32_t launch_status(rls_ctx* ctx) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+static int32_t cgnr_enqueue_update(rls_cgnr* s) {
+  if (s->op->dtype == RLS_F32)
+    cgnr_launch_update<float>(s);
+  else
+    cgnr_launch_update<float2>(s);
+  return launch_status(s->op->ctx);
+}
+
+static int32_t cgnr_enqueue_iteration(rls_cgnr* s) {
+  RLS_TRY(op_normal(s->op, s->p, s->v, &s->sc->done));
+  return cgnr_enqueue_update(s);
+}
+
+static int32_t cgnr_effective_iterations(rls_cgnr* s, int32_t iterations) {
+  // iteration >= min(solver.iterations, size(AHA, 2))    src/CGNR.jl:185
+  int64_t m = iterations < s->op->N ? iterations : s->op->N;
+  return (int32_t)(m < 0 ? 0 : m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FISTA
+// ---------------------------------------------------------------------------------------------
+struct fista_scalars {
+  double norm_x0, res_norm, rel_res_norm;
+  float rho, theta, theta_old, rel_tol, lambda;
+  int iteration, max_iter, done, restart, reg_kind, proj_kind;
+  long long l21_slices;
+};
+
+struct rls_fista {
+  rls_operator* op;
+  int device;
+  void* buf[2];  // x / xold, swapped by iteration parity: state.x == buf[iteration & 1]
+  void *x0, *res;
+  void* y;       // extrapolated point (plan-owned), the GEMV input
+  fista_scalars* sc;
+  fista_scalars* sc_h;
+  step_graph graph;
+  int32_t reg_kind, proj_kind;
+  float lambda;
+  int64_t l21_slices;
+  bool initialised;
+};
+
+template <typename E>
+__device__ static inline E fista_prox_elem(E v, int reg_kind, float thr) {
+  if (reg_kind == RLS_REG_L1) {
+    const float eps = 1.1920929e-07f;
+    const float a = elem<E>::absv(v);
+    const float sh = fmaxf(a - thr, 0.f);
+    const float den = a + eps;
+    return elem<E>::make((sh * (elem<E>::re(v) + eps)) / den, (sh * elem<E>::im(v)) / den);
+  }
+  if (reg_kind == RLS_REG_L2) {
+    const double f = 1.0 / (1.0 + 2.0 * (double)thr);
+    return elem<E>::make((float)((double)elem<E>::re(v) * f), (float)((double)elem<E>::im(v) * f));
+  }
+  return v;
+}
+template <typename E>
+__device__ static inline E fista_proj_elem(E v, int proj_kind) {
+  if (proj_kind == RLS_PROJ_NONE) return v;
+  float re = elem<E>::re(v);
+  if (proj_kind == RLS_PROJ_POSITIVE && re < 0.f) re = 0.f;
+  return elem<E>::make(re, 0.f);
+}
+
+// x0 = A^H b is already in place.  x = x_init (zero), xold = 0, res = Inf, y = x   (src/FISTA.jl:110-129)
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__ b0, E* __restrict__ b1,
+                                                                 const E* __restrict__ x0, E* __restrict__ res,
+                                                                 E* __restrict__ y, int64_t n, fista_scalars* sc,
+                                                                 float rho, float theta, float rel_tol, int max_iter,
+                                                                 int restart, int reg_kind, int proj_kind,
+                                                                 float lambda, long long slices) {
+  __shared__ double sm[16];
+  double nn = 0.0;
+  const float inf = __builtin_huge_valf();
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E v = x0[i];
+    nn += (double)elem<E>::re(v) * (double)elem<E>::re(v) + (double)elem<E>::im(v) * (double)elem<E>::im(v);
+    b0[i] = elem<E>::zero();
+    b1[i] = elem<E>::zero();
+    y[i] = elem<E>::zero();
+    res[i] = elem<E>::make(inf, 0.f);
+  }
+  nn = block_sum(nn, sm);
+  if (threadIdx.x == 0) {
+    sc->norm_x0 = sqrt(nn);
+    sc->res_norm = (double)inf;
+    sc->rel_res_norm = (double)inf;
+    sc->rho = rho;
+    sc->theta = theta;
+    sc->theta_old = theta;
+    sc->rel_tol = rel_tol;
+    sc->lambda = lambda;
+    sc->iteration = 0;
+    sc->max_iter = max_iter;
+    sc->done = (0 >= max_iter);
+    sc->restart = restart;
+    sc->reg_kind = reg_kind;
+    sc->proj_kind = proj_kind;
+    sc->l21_slices = slices;
+  }
+}
+
+// everything of src/FISTA.jl:153-180 after res = AHA y, plus the NEXT iteration's momentum step
+// (:144-148) so that one iteration is GEMV, GEMV, this kernel.
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict__ b0, E* __restrict__ b1,
+                                                                   const E* __restrict__ x0, E* __restrict__ res,
+                                                                   E* __restrict__ y, int64_t n, fista_scalars* sc) {
+  if (sc->done) return;
+  __shared__ double sm[16];
+  const int it = sc->iteration;
+  E* xnew = (it & 1) ? b0 : b1;  // after the reference's pointer swap: state.x      :144-146
+  E* xold = (it & 1) ? b1 : b0;  // holds x_k
+  const float rho = sc->rho;
+  const int reg_kind = sc->reg_kind, proj_kind = sc->proj_kind;
+  const float thr = rho * sc->lambda;  // prox!(reg, x, rho * lambda(reg))             :164
+  double rn = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E ri = elem<E>::sub(res[i], x0[i]);                       // res .-= x0      :153
+    res[i] = ri;
+    rn += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+    E xi = elem<E>::sub(y[i], elem<E>::scale(rho, ri));             // x .-= rho .* res :154
+    if (reg_kind != RLS_REG_L21) xi = fista_proj_elem<E>(fista_prox_elem<E>(xi, reg_kind, thr), proj_kind);
+    xnew[i] = xi;
+  }
+  if (reg_kind == RLS_REG_L21) {  // group soft-threshold needs the whole new x         ProxL21.jl:30-35
+    __syncthreads();
+    const int64_t slen = n / sc->l21_slices;
+    for (int64_t g = threadIdx.x; g < slen; g += UPD_THREADS) {
+      float s2 = 0.f;
+      for (int64_t k = g; k < n; k += slen) s2 += elem<E>::abs2(xnew[k]);
+      const float gn = sqrtf(s2);
+      const float q = (gn - thr) / gn;
+      const float fac = (q != q) ? q : fmaxf(q, 0.f);
+      for (int64_t k = g; k < n; k += slen) xnew[k] = fista_proj_elem<E>(elem<E>::scale(fac, xnew[k]), proj_kind);
+    }
+    __syncthreads();
+  }
+  rn = block_sum(rn, sm);
+  float theta = sc->theta;
+  if (sc->restart) {  // real(res . (x - xold)) > 0  => theta = 1                       :171-176
+    double d = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+      const E df = elem<E>::sub(xnew[i], xold[i]);
+      const E ri = res[i];
+      d += (double)elem<E>::re(ri) * (double)elem<E>::re(df) + (double)elem<E>::im(ri) * (double)elem<E>::im(df);
+    }
+    d = block_sum(d, sm);
+    if (d > 0.0) theta = 1.f;
+  }
+  const float theta_old = theta;                                     // :179
+  theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;    // :180
+  const double res_norm = sqrt(rn);
+  const float rel = (float)(res_norm / sc->norm_x0);                 // :156
+  const int done = (rel < sc->rel_tol) || (it + 1 >= sc->max_iter);  // :187-189
+  if (!done) {
+    // next iteration's Nesterov step, formed out of place in y                         :147-148
+    const float c1 = (1.f - theta_old) / theta;
+    const float c2 = (theta_old - 1.f) / theta + 1.f;
+    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS)
+      y[i] = elem<E>::add(elem<E>::scale(c1, xold[i]), elem<E>::scale(c2, xnew[i]));
+  }
+  if (threadIdx.x == 0) {
+    sc->res_norm = res_norm;
+    sc->rel_res_norm = (double)rel;
+    sc->theta = theta;
+    sc->theta_old = theta_old;
+    sc->iteration = it + 1;
+    sc->done = done;
+  }
+}
+
+static int32_t fista_enqueue_iteration(rls_fista* s) {
+  rls_operator* op = s->op;
+  RLS_TRY(op_normal(op, s->y, s->res, &s->sc->done));
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(fista_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (float*)s->buf[0],
+                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc);
+  else
+    hipLaunchKernelGGL(fista_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream,
+                       (float2*)s->buf[0], (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y,
+                       op->N, s->sc);
+  return launch_status(op->ctx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cg!  (IterativeSolvers v0.9 semantics, restated; see oracle/rls_oracle.py::cg_inplace)
+// ---------------------------------------------------------------------------------------------
+struct cg_scalars {
+  double residual, prev, tol;
+  float rho, reltol;
+  int iteration, maxiter, done, pad;
+};
+
+struct rls_cg {
+  rls_operator* op;
+  int device;
+  void *u, *r, *c;
+  cg_scalars* sc;
+  cg_scalars* sc_h;
+};
+
+// c = AHA x is in place.  c += rho x ; r = b - c ; residual = ||r|| ; tol ; u = r (= r + beta*0)
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restrict__ x, const E* __restrict__ b,
+                                                               E* __restrict__ u, E* __restrict__ r,
+                                                               const E* __restrict__ c, int64_t n, cg_scalars* sc,
+                                                               float rho, float reltol, int maxiter) {
+  __shared__ double sm[16];
+  double rr = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E ci = elem<E>::add(c[i], elem<E>::scale(rho, x[i]));
+    const E ri = elem<E>::sub(b[i], ci);
+    r[i] = ri;
+    u[i] = ri;  // first iteration: beta = residual^2 / 1^2 multiplies u == 0
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum(rr, sm);
+  if (threadIdx.x == 0) {
+    const double residual = sqrt(rr);
+    const double tol = fmax((double)((float)reltol * (float)residual), 0.0);
+    sc->residual = residual;
+    sc->prev = 1.0;
+    sc->tol = tol;
+    sc->rho = rho;
+    sc->reltol = reltol;
+    sc->iteration = 0;
+    sc->maxiter = maxiter;
+    sc->done = (0 >= maxiter) || ((float)residual <= (float)tol);
+  }
+}
+
+// after c = AHA u:  c += rho u ; alpha = residual^2 / <u, c> ; x += alpha u ; r -= alpha c ;
+// residual = ||r|| ; then the next direction u = r + beta u
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void cg_update_kernel(E* __restrict__ x, E* __restrict__ u,
+                                                                E* __restrict__ r, E* __restrict__ c, int64_t n,
+                                                                cg_scalars* sc) {
+  if (sc->done) return;
+  __shared__ double sm[16];
+  const float rho = sc->rho;
+  double dre = 0.0, dim_ = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E ui = u[i];
+    const E ci = elem<E>::add(c[i], elem<E>::scale(rho, ui));
+    c[i] = ci;
+    dre += (double)elem<E>::re(ui) * (double)elem<E>::re(ci) + (double)elem<E>::im(ui) * (double)elem<E>::im(ci);
+    if constexpr (elem<E>::cplx)
+      dim_ += (double)elem<E>::re(ui) * (double)elem<E>::im(ci) - (double)elem<E>::im(ui) * (double)elem<E>::re(ci);
+  }
+  dre = block_sum(dre, sm);
+  if constexpr (elem<E>::cplx) dim_ = block_sum(dim_, sm);
+  const double res = sc->residual;
+  dcomplex alpha = dc_div({res * res, 0.0}, {dre, dim_});
+  const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
+  const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
+  double rr = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    x[i] = elem<E>::fma(a, u[i], x[i]);
+    const E ri = elem<E>::fma(na, c[i], r[i]);
+    r[i] = ri;
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum(rr, sm);
+  const double residual = sqrt(rr);
+  const int it = sc->iteration + 1;
+  const int done = (it >= sc->maxiter) || ((float)residual <= (float)sc->tol);
+  if (!done) {
+    const float beta = (float)(rr / (res * res));
+    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) u[i] = elem<E>::add(r[i], elem<E>::scale(beta, u[i]));
+  }
+  if (threadIdx.x == 0) {
+    sc->prev = res;
+    sc->residual = residual;
+    sc->iteration = it;
+    sc->done = done;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram matrix  G = A^H A  (setup GEMM, src/CGNR.jl:49).  LDS-tiled, f32 FMA; not on the
+// per-iteration path.  64 x 64 output tile per workgroup, K streamed in 16-row panels.
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void gram_kernel(const E* __restrict__ A, int64_t lda, int64_t M, int64_t N,
+                                                   E* __restrict__ G, int64_t ldg) {
+  constexpr int T = 64, KP = 16;
+  __shared__ E sa[KP][T + 1];
+  __shared__ E sb[KP][T + 1];
+  const int64_t i0 = (int64_t)blockIdx.x * T, j0 = (int64_t)blockIdx.y * T;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;  // 16 x 16 threads, 4 x 4 outputs each
+  E acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = elem<E>::zero();
+  for (int64_t k0 = 0; k0 < M; k0 += KP) {
+    for (int idx = threadIdx.x; idx < KP * T; idx += 256) {
+      const int kk = idx % KP, cc = idx / KP;
+      const int64_t k = k0 + kk;
+      sa[kk][cc] = (k < M && i0 + cc < N) ? A[(i0 + cc) * lda + k] : elem<E>::zero();
+      sb[kk][cc] = (k < M && j0 + cc < N) ? A[(j0 + cc) * lda + k] : elem<E>::zero();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      E av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = sa[kk][ty * 4 + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = sb[kk][tx * 4 + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = elem<E>::fmac(av[a], bv[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+      if (i < N && j < N) G[j * ldg + i] = acc[a][b];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+template <typename S>
+static int32_t alloc_scalars(rls_ctx* ctx, S** d, S** h) {
+  RLS_HIP(ctx, hipMalloc((void**)d, sizeof(S)));
+  RLS_HIP(ctx, hipMemset(*d, 0, sizeof(S)));
+  RLS_HIP(ctx, hipHostMalloc((void**)h, sizeof(S), hipHostMallocDefault));
+  memset(*h, 0, sizeof(S));
+  return 0;
+}
+template <typename S>
+static int32_t fetch_scalars(rls_ctx* ctx, S* d, S* h) {
+  RLS_HIP(ctx, hipMemcpyAsync(h, d, sizeof(S), hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" {
+
+int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,
+                            rls_operator** out) {
+  RLS_CHECK_CTX(ctx);
+  if (!out || !rls_dtype_ok(dtype) || M < 0 || N <= 0) return rls_fail(ctx, RLS_E_INVALID, "operator_create: bad argument");
+  if (A && (M <= 0 || lda < M)) return rls_fail(ctx, RLS_E_INVALID, "operator_create: bad shape/lda");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_operator* op = new rls_operator();
+  op->ctx = ctx;
+  op->dtype = dtype;
+  op->M = M;
+  op->N = N;
+  op->A = A;
+  op->lda = lda;
+  op->G = nullptr;
+  op->ldg = 0;
+  op->t = nullptr;
+  if (A) {
+    hipError_t e = hipMalloc(&op->t, (size_t)M * rls_elem_size(dtype));
+    if (e != hipSuccess) {
+      delete op;
+      return rls_fail(ctx, (int32_t)e, "operator_create: hipMalloc failed");
+    }
+  }
+  *out = op;
+  return 0;
+}
+
+int32_t rls_operator_set_gram(rls_operator* op, const void* AHA, int64_t ld) {
+  if (!op) return RLS_E_INVALID;
+  if (AHA && ld < op->N) return rls_fail(op->ctx, RLS_E_INVALID, "operator_set_gram: ld < N");
+  op->G = AHA;
+  op->ldg = ld;
+  return 0;
+}
+
+int32_t rls_operator_destroy(rls_operator* op) {
+  if (!op) return RLS_E_INVALID;
+  if (op->t) hipFree(op->t);  // hipFree resolves the owning device from the pointer
+  delete op;
+  return 0;
+}
+
+int32_t rls_operator_mul(rls_operator* op, const void* x, void* y) {
+  if (!op) return RLS_E_INVALID;
+  if (!op->A) return rls_fail(op->ctx, RLS_E_STATE, "operator_mul: operator has no forward matrix");
+  return rls_launch_gemv(op->ctx, op->dtype, RLS_OP_N, op->M, op->N, 1.f, 0.f, op->A, op->lda, x, 0.f, 0.f, y, nullptr);
+}
+int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x) {
+  if (!op) return RLS_E_INVALID;
+  if (!op->A) return rls_fail(op->ctx, RLS_E_STATE, "operator_mul_adj: operator has no forward matrix");
+  return rls_launch_gemv(op->ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, y, 0.f, 0.f, x, nullptr);
+}
+int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v) {
+  if (!op || !p || !v) return RLS_E_INVALID;
+  return op_normal(op, p, v, nullptr);
+}
+
+int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G, int64_t ld) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !G || lda < M || ld < N)
+    return rls_fail(ctx, RLS_E_INVALID, "gram: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(gram_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)A, lda, M, N, (float*)G, ld);
+  else
+    hipLaunchKernelGGL(gram_kernel<float2>, grid, dim3(256), 0, ctx->stream, (const float2*)A, lda, M, N, (float2*)G, ld);
+  return launch_status(ctx);
+}
+
+// ---- CGNR -----------------------------------------------------------------------------------
+int32_t rls_cgnr_create(rls_operator* op, void* x, void* r, void* p, void* v, rls_cgnr** out) {
+  if (!op) return RLS_E_INVALID;
+  if (!x || !r || !p || !v || !out) return rls_fail(op->ctx, RLS_E_INVALID, "cgnr_create: null pointer");
+  RLS_HIP(op->ctx, hipSetDevice(op->ctx->device));
+  rls_cgnr* s = new rls_cgnr();
+  s->op = op;
+  s->device = op->ctx->device;
+  s->x = x;
+  s->r = r;
+  s->p = p;
+  s->v = v;
+  s->initialised = false;
+  int32_t st = alloc_scalars(op->ctx, &s->sc, &s->sc_h);
+  if (st != 0) {
+    delete s;
+    return st;
+  }
+  *out = s;
+  return 0;
+}
+
+int32_t rls_cgnr_destroy(rls_cgnr* s) {
+  if (!s) return RLS_E_INVALID;
+  hipSetDevice(s->device);
+  if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
+  hipFree(s->sc);
+  hipHostFree(s->sc_h);
+  delete s;
+  return 0;
+}
+
+int32_t rls_cgnr_init_local_a(rls_cgnr* s, const void* b, float lambda, float rel_tol, int32_t iterations) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (!b) return rls_fail(ctx, RLS_E_INVALID, "cgnr_init: null b");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  // r = A^H b   (initCGNR, src/CGNR.jl:132) ; without A, b already is A^H b (:134)
+  if (op->A)
+    RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, b, 0.f, 0.f, s->r, nullptr));
+  else
+    RLS_HIP(ctx, hipMemcpyAsync(s->r, b, (size_t)op->N * rls_elem_size(op->dtype), hipMemcpyDeviceToDevice, ctx->stream));
+  s->sc_h->lambda = lambda;
+  s->sc_h->rel_tol = rel_tol;
+  s->sc_h->max_iter = cgnr_effective_iterations(s, iterations);
+  return 0;
+}
+
+int32_t rls_cgnr_init_local_b(rls_cgnr* s) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->op->dtype == RLS_F32)
+    cgnr_launch_init<float>(s, s->sc_h->lambda, s->sc_h->rel_tol, s->sc_h->max_iter);
+  else
+    cgnr_launch_init<float2>(s, s->sc_h->lambda, s->sc_h->rel_tol, s->sc_h->max_iter);
+  s->initialised = true;
+  return launch_status(ctx);
+}
+
+int32_t rls_cgnr_init(rls_cgnr* s, const void* b, float lambda, float rel_tol, int32_t iterations) {
+  RLS_TRY(rls_cgnr_init_local_a(s, b, lambda, rel_tol, iterations));
+  return rls_cgnr_init_local_b(s);
+}
+
+int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
+  if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr_step: n_steps < 0");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  return run_steps(ctx, &s->graph, n_steps, [s]() { return cgnr_enqueue_iteration(s); });
+}
+
+int32_t rls_cgnr_step_local_a(rls_cgnr* s) {
+  if (!s) return RLS_E_INVALID;
+  if (!s->initialised) return rls_fail(s->op->ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
+  RLS_HIP(s->op->ctx, hipSetDevice(s->op->ctx->device));
+  return op_normal(s->op, s->p, s->v, &s->sc->done);
+}
+int32_t rls_cgnr_step_local_b(rls_cgnr* s) {
+  if (!s) return RLS_E_INVALID;
+  if (!s->initialised) return rls_fail(s->op->ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
+  RLS_HIP(s->op->ctx, hipSetDevice(s->op->ctx->device));
+  return cgnr_enqueue_update(s);
+}
+
+int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const float lambda = s->sc_h->lambda, rel_tol = s->sc_h->rel_tol;
+  const int max_iter = s->sc_h->max_iter;
+  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  const cgnr_scalars& h = *s->sc_h;
+  out->iteration = h.iteration;
+  out->done = h.done;
+  out->alpha_re = (float)h.alpha_re;
+  out->alpha_im = (float)h.alpha_im;
+  out->beta_re = (float)h.beta_re;
+  out->beta_im = (float)h.beta_im;
+  out->zeta = (float)h.zeta;
+  out->residual = (float)sqrt(h.rr);
+  out->z0 = (float)h.z0;
+  (void)lambda;
+  (void)rel_tol;
+  (void)max_iter;
+  return 0;
+}
+
+// ---- FISTA ----------------------------------------------------------------------------------
+int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* res, rls_fista** out) {
+  if (!op) return RLS_E_INVALID;
+  rls_ctx* ctx = op->ctx;
+  if (!x || !x0 || !xold || !res || !out) return rls_fail(ctx, RLS_E_INVALID, "fista_create: null pointer");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_fista* s = new rls_fista();
+  s->op = op;
+  s->device = op->ctx->device;
+  s->buf[0] = x;
+  s->buf[1] = xold;
+  s->x0 = x0;
+  s->res = res;
+  s->y = nullptr;
+  s->reg_kind = RLS_REG_L1;
+  s->proj_kind = RLS_PROJ_NONE;
+  s->lambda = 0.f;
+  s->l21_slices = 1;
+  s->initialised = false;
+  hipError_t e = hipMalloc(&s->y, (size_t)op->N * rls_elem_size(op->dtype));
+  if (e != hipSuccess) {
+    delete s;
+    return rls_fail(ctx, (int32_t)e, "fista_create: hipMalloc failed");
+  }
+  int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
+  if (st != 0) {
+    hipFree(s->y);
+    delete s;
+    return st;
+  }
+  *out = s;
+  return 0;
+}
+
+int32_t rls_fista_destroy(rls_fista* s) {
+  if (!s) return RLS_E_INVALID;
+  hipSetDevice(s->device);
+  if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
+  hipFree(s->y);
+  hipFree(s->sc);
+  hipHostFree(s->sc_h);
+  delete s;
+  return 0;
+}
+
+int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t l21_slices, int32_t proj_kind) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (reg_kind == RLS_REG_TV)
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "fused FISTA: TV prox is not fused; drive FISTA from the primitives");
+  if (reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L21 || proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE)
+    return rls_fail(ctx, RLS_E_INVALID, "fista_set_reg: unknown kind");
+  if (reg_kind == RLS_REG_L21 && (l21_slices <= 0 || s->op->N / l21_slices == 0))
+    return rls_fail(ctx, RLS_E_INVALID, "fista_set_reg: slices must be in 1..N");
+  s->reg_kind = reg_kind;
+  s->proj_kind = proj_kind;
+  s->lambda = lambda;
+  s->l21_slices = l21_slices > 0 ? l21_slices : 1;
+  return 0;
+}
+
+int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, float rel_tol, int32_t iterations,
+                       int32_t restart_gradient) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (!b) return rls_fail(ctx, RLS_E_INVALID, "fista_init: null b");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (op->A)
+    RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, b, 0.f, 0.f, s->x0, nullptr));
+  else
+    RLS_HIP(ctx, hipMemcpyAsync(s->x0, b, (size_t)op->N * rls_elem_size(op->dtype), hipMemcpyDeviceToDevice, ctx->stream));
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(fista_init_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
+                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc, rho, theta,
+                       rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
+                       (long long)s->l21_slices);
+  else
+    hipLaunchKernelGGL(fista_init_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)s->buf[0],
+                       (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc, rho,
+                       theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
+                       (long long)s->l21_slices);
+  s->initialised = true;
+  return launch_status(ctx);
+}
+
+int32_t rls_fista_set_start(rls_fista* s, const void* x_init) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_set_start before fista_init");
+  if (!x_init) return rls_fail(ctx, RLS_E_INVALID, "fista_set_start: null pointer");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)s->op->N * rls_elem_size(s->op->dtype);
+  // iteration 0: state.x == buf[0]; the first extrapolated point is 0*xold + 1*x == x
+  RLS_HIP(ctx, hipMemcpyAsync(s->buf[0], x_init, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  RLS_HIP(ctx, hipMemcpyAsync(s->y, x_init, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_step before fista_init");
+  if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "fista_step: n_steps < 0");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_iteration(s); });
+}
+
+int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_get_status before fista_init");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  const fista_scalars& h = *s->sc_h;
+  out->iteration = h.iteration;
+  out->done = h.done;
+  out->theta = h.theta;
+  out->theta_old = h.theta_old;
+  out->rel_res_norm = (float)h.rel_res_norm;
+  out->residual = (float)h.res_norm;
+  out->norm_x0 = (float)h.norm_x0;
+  return 0;
+}
+
+int32_t rls_fista_solution(rls_fista* s, void** x_out) {
+  if (!s || !x_out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_solution before fista_init");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  *x_out = s->buf[s->sc_h->iteration & 1];
+  return 0;
+}
+
+// ---- cg! ------------------------------------------------------------------------------------
+int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out) {
+  if (!op) return RLS_E_INVALID;
+  rls_ctx* ctx = op->ctx;
+  if (!u || !r || !c || !out) return rls_fail(ctx, RLS_E_INVALID, "cg_create: null pointer");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_cg* s = new rls_cg();
+  s->op = op;
+  s->device = op->ctx->device;
+  s->u = u;
+  s->r = r;
+  s->c = c;
+  int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
+  if (st != 0) {
+    delete s;
+    return st;
+  }
+  *out = s;
+  return 0;
+}
+
+int32_t rls_cg_destroy(rls_cg* s) {
+  if (!s) return RLS_E_INVALID;
+  hipSetDevice(s->device);
+  hipFree(s->sc);
+  hipHostFree(s->sc_h);
+  delete s;
+  return 0;
+}
+
+int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxiter, float reltol) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_solve: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n = op->N;
+  // warm start: one operator apply for r = b - (AHA + rho I) x
+  RLS_TRY(op_normal(op, x, s->c, nullptr));
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                       (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->sc, rho, reltol, maxiter);
+  else
+    hipLaunchKernelGGL(cg_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                       (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->sc, rho, reltol,
+                       maxiter);
+  RLS_TRY(launch_status(ctx));
+  for (int it = 0; it < maxiter; ++it) {
+    RLS_TRY(op_normal(op, s->u, s->c, &s->sc->done));
+    if (op->dtype == RLS_F32)
+      hipLaunchKernelGGL(cg_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)x, (float*)s->u,
+                         (float*)s->r, (float*)s->c, n, s->sc);
+    else
+      hipLaunchKernelGGL(cg_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)x,
+                         (float2*)s->u, (float2*)s->r, (float2*)s->c, n, s->sc);
+    RLS_TRY(launch_status(ctx));
+  }
+  return 0;
+}
+
+int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  out->iterations = s->sc_h->iteration;
+  out->residual = (float)s->sc_h->residual;
+  out->tol = (float)s->sc_h->tol;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+// Total-variation proximal map: GradientOp stencils + the FGP loop of
+// src/proximalMaps/ProxTV.jl:89-125 (helpers :127-145, GPU helpers ext/..GPUArraysExt/ProxTV.jl:1-17).
+//
+// GradientOp (LinearOperatorCollection v2, not in the reference tree; restated): for every dim d in
+// `dims`, g_d[i] = x[i] - x[i + e_d] on the column-major array of extents `shape`, extent
+// shape[d]-1 along d; blocks concatenated in dims order.  The transpose is written as a gather
+// (+g at i, -g at i - e_d) so it needs no atomics and is bit-reproducible.
+//
+// FGP is launch-bound, not byte-bound (hard part 9): for images whose duals fit in one
+// CU's 160 KiB LDS the whole loop is ONE single-workgroup kernel with workgroup barriers;
+// larger images use two launches per FGP iteration.  Two dual buffers suffice: pq is formed in
+// place over rs, and the new rs overwrites the old pq element by element.
+#include "rls_common.hpp"
+
+namespace {
+
+constexpr int TV_MAXD = 4;
+
+struct tv_geom {
+  int ndims, ntv;
+  int64_t shape[TV_MAXD];
+  int64_t stride[TV_MAXD];           // x strides (column-major)
+  int dims[TV_MAXD];                 // differenced dims, in order
+  int64_t goff[TV_MAXD + 1];         // start of block k inside g; goff[ntv] = total length
+  int64_t bstride[TV_MAXD][TV_MAXD]; // strides of block k (extent shape[d]-1 along its dim)
+  int64_t n;
+};
+
+static bool make_geom(int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims, tv_geom* g) {
+  if (ndims < 1 || ndims > TV_MAXD || ntv < 0 || ntv > TV_MAXD || !shape || (ntv > 0 && !dims)) return false;
+  g->ndims = ndims;
+  g->ntv = ntv;
+  int64_t n = 1;
+  for (int k = 0; k < TV_MAXD; ++k) {
+    g->shape[k] = k < ndims ? shape[k] : 1;
+    if (g->shape[k] < 1) return false;
+    g->stride[k] = n;
+    n *= g->shape[k];
+  }
+  g->n = n;
+  int64_t off = 0;
+  for (int k = 0; k < ntv; ++k) {
+    const int d = dims[k];
+    if (d < 0 || d >= ndims) return false;
+    g->dims[k] = d;
+    g->goff[k] = off;
+    int64_t bs = 1;
+    for (int m = 0; m < TV_MAXD; ++m) {
+      g->bstride[k][m] = bs;
+      bs *= (m == d) ? (g->shape[m] - 1) : g->shape[m];
+    }
+    off += bs;
+  }
+  for (int k = ntv; k <= TV_MAXD; ++k) g->goff[k] = off;
+  return true;
+}
+
+// (grad x)[gi] for a global dual index gi
+template <typename E>
+__device__ static inline E grad_at(const E* x, const tv_geom& G, int64_t gi) {
+  int k = 0;
+  while (k + 1 < G.ntv && gi >= G.goff[k + 1]) ++k;
+  const int d = G.dims[k];
+  int64_t li = gi - G.goff[k], xi = 0;
+#pragma unroll
+  for (int m = 0; m < TV_MAXD; ++m) {
+    const int64_t ext = (m == d) ? (G.shape[m] - 1) : G.shape[m];
+    const int64_t c = li % ext;
+    li /= ext;
+    xi += c * G.stride[m];
+  }
+  return elem<E>::sub(x[xi], x[xi + G.stride[d]]);
+}
+
+// (grad^T g)[xi]
+template <typename E>
+__device__ static inline E gradt_at(const E* g, const tv_geom& G, int64_t xi) {
+  int64_t c[TV_MAXD];
+  int64_t r = xi;
+#pragma unroll
+  for (int m = 0; m < TV_MAXD; ++m) {
+    c[m] = r % G.shape[m];
+    r /= G.shape[m];
+  }
+  E s = elem<E>::zero();
+  for (int k = 0; k < G.ntv; ++k) {
+    const int d = G.dims[k];
+    int64_t bi = 0;
+#pragma unroll
+    for (int m = 0; m < TV_MAXD; ++m) bi += c[m] * G.bstride[k][m];
+    const E* gb = g + G.goff[k];
+    if (c[d] < G.shape[d] - 1) s = elem<E>::add(s, gb[bi]);
+    if (c[d] > 0) s = elem<E>::sub(s, gb[bi - G.bstride[k][d]]);
+  }
+  return s;
+}
+
+// tv_restrictMagnitude!: q /= max(1, |q|)   (ProxTV.jl:135-139)
+template <typename E>
+__device__ static inline E tv_clip(E q) {
+  const float m = fmaxf(1.f, elem<E>::absv(q));
+  return elem<E>::make(elem<E>::re(q) / m, elem<E>::im(q) / m);
+}
+
+#define GRID_STRIDE(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+template <typename E>
+__global__ void grad_kernel(const E* x, E* g, tv_geom G, float alpha, float beta) {
+  GRID_STRIDE(gi, G.goff[G.ntv]) {
+    E v = elem<E>::scale(alpha, grad_at<E>(x, G, gi));
+    if (beta != 0.f) v = elem<E>::add(v, elem<E>::scale(beta, g[gi]));
+    g[gi] = v;
+  }
+}
+
+// out = alpha * grad^T(g) + beta * xin   (out may alias xin)
+template <typename E>
+__global__ void gradt_kernel(const E* g, const E* xin, E* out, tv_geom G, float alpha, float beta) {
+  GRID_STRIDE(xi, G.n) {
+    E v = elem<E>::scale(alpha, gradt_at<E>(g, G, xi));
+    if (beta != 0.f) v = elem<E>::add(v, elem<E>::scale(beta, xin[xi]));
+    out[xi] = v;
+  }
+}
+
+template <typename E>
+__global__ void restrict_kernel(E* pq, int64_t n) {
+  GRID_STRIDE(i, n) pq[i] = tv_clip<E>(pq[i]);
+}
+
+template <typename E>
+__global__ void tv_lincomb_kernel(E* rs, float t3, const E* pq, float t2, const E* pqOld, int64_t n) {
+  GRID_STRIDE(i, n) rs[i] = elem<E>::sub(elem<E>::scale(t3, pq[i]), elem<E>::scale(t2, pqOld[i]));
+}
+
+// FGP dual update (multi-launch path): pq = clip(rs + step * grad(xTmp)) in place over rs, then
+// the new rs = t3*pq - t2*pqOld overwrites pqOld.
+template <typename E>
+__global__ void fgp_dual_kernel(E* brs, E* bpq, const E* xtmp, tv_geom G, float step, float t2, float t3) {
+  GRID_STRIDE(gi, G.goff[G.ntv]) {
+    E q = elem<E>::add(elem<E>::scale(step, grad_at<E>(xtmp, G, gi)), brs[gi]);
+    q = tv_clip<E>(q);
+    const E old = bpq[gi];
+    brs[gi] = q;
+    bpq[gi] = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, old));
+  }
+}
+
+// whole FGP loop in one workgroup; duals and xTmp live in LDS
+template <typename E>
+__global__ __launch_bounds__(1024) void fgp_fused_kernel(E* __restrict__ x, tv_geom G, float lam, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int64_t ng = G.goff[G.ntv], n = G.n;
+  E* b0 = reinterpret_cast<E*>(smem_raw);
+  E* b1 = b0 + ng;
+  E* xt = b1 + ng;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  for (int64_t i = tid; i < ng; i += nth) {
+    b0[i] = elem<E>::zero();
+    b1[i] = elem<E>::zero();
+  }
+  __syncthreads();
+  E* brs = b0;
+  E* bpq = b1;
+  float t = 1.f;
+  const float step = 1.f / (8.f * lam);
+  for (int it = 0; it < iters; ++it) {
+    for (int64_t i = tid; i < n; i += nth)
+      xt[i] = elem<E>::add(x[i], elem<E>::scale(-lam, gradt_at<E>(brs, G, i)));
+    __syncthreads();
+    const float tOld = t;
+    t = (1.f + sqrtf(1.f + 4.f * tOld * tOld)) / 2.f;
+    const float t2 = (tOld - 1.f) / t, t3 = 1.f + t2;
+    for (int64_t gi = tid; gi < ng; gi += nth) {
+      E q = elem<E>::add(elem<E>::scale(step, grad_at<E>(xt, G, gi)), brs[gi]);
+      q = tv_clip<E>(q);
+      const E old = bpq[gi];
+      brs[gi] = q;
+      bpq[gi] = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, old));
+    }
+    __syncthreads();
+    E* tmp = brs;
+    brs = bpq;
+    bpq = tmp;  // bpq now holds the newest pq
+  }
+  for (int64_t i = tid; i < n; i += nth) x[i] = elem<E>::add(x[i], elem<E>::scale(-lam, gradt_at<E>(bpq, G, i)));
+}
+
+constexpr size_t FGP_LDS_BUDGET = 160 * 1024 - 512;
+
+static int32_t tv_status(rls_ctx* ctx) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+static inline unsigned tv_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <typename E>
+int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E* ws) {
+  const int64_t ng = G.goff[G.ntv], n = G.n;
+  const size_t lds = (size_t)(2 * ng + n) * sizeof(E);
+  if (lds <= FGP_LDS_BUDGET) {
+    RLS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp_fused_kernel<E>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3(1), dim3(1024), lds, ctx->stream, x, G, lam, iters);
+    return tv_status(ctx);
+  }
+  E* brs = ws;
+  E* bpq = ws + ng;
+  E* xt = ws + 2 * ng;
+  RLS_HIP(ctx, hipMemsetAsync(ws, 0, (size_t)2 * ng * sizeof(E), ctx->stream));
+  float t = 1.f;
+  const float step = 1.f / (8.f * lam);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(gradt_kernel<E>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, brs, x, xt, G, -lam, 1.f);
+    const float tOld = t;
+    t = (1.f + sqrtf(1.f + 4.f * tOld * tOld)) / 2.f;
+    const float t2 = (tOld - 1.f) / t, t3 = 1.f + t2;
+    hipLaunchKernelGGL(fgp_dual_kernel<E>, dim3(tv_grid(ng)), dim3(256), 0, ctx->stream, brs, bpq, xt, G, step, t2, t3);
+    E* tmp = brs;
+    brs = bpq;
+    bpq = tmp;
+  }
+  hipLaunchKernelGGL(gradt_kernel<E>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, bpq, x, x, G, -lam, 1.f);
+  return tv_status(ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t rls_tv_grad_len(int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims) {
+  tv_geom G;
+  if (!make_geom(ndims, shape, ntv, dims, &G)) return -1;
+  return G.goff[G.ntv];
+}
+
+size_t rls_prox_tv_workspace_bytes(int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                                   const int32_t* dims) {
+  tv_geom G;
+  if (!rls_dtype_ok(dtype) || !make_geom(ndims, shape, ntv, dims, &G)) return 0;
+  return (size_t)(2 * G.goff[G.ntv] + G.n) * rls_elem_size(dtype);
+}
+
+int32_t rls_tv_grad(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims,
+                    const void* x, void* g, float alpha, float beta) {
+  RLS_CHECK_CTX(ctx);
+  tv_geom G;
+  if (!rls_dtype_ok(dtype) || !x || !g || !make_geom(ndims, shape, ntv, dims, &G))
+    return rls_fail(ctx, RLS_E_INVALID, "tv_grad: bad argument");
+  if (G.goff[G.ntv] == 0) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(grad_kernel<float>, dim3(tv_grid(G.goff[G.ntv])), dim3(256), 0, ctx->stream, (const float*)x,
+                       (float*)g, G, alpha, beta);
+  else
+    hipLaunchKernelGGL(grad_kernel<float2>, dim3(tv_grid(G.goff[G.ntv])), dim3(256), 0, ctx->stream, (const float2*)x,
+                       (float2*)g, G, alpha, beta);
+  return tv_status(ctx);
+}
+
+int32_t rls_tv_grad_t(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                      const int32_t* dims, const void* g, void* x, float alpha, float beta) {
+  RLS_CHECK_CTX(ctx);
+  tv_geom G;
+  if (!rls_dtype_ok(dtype) || !x || !g || !make_geom(ndims, shape, ntv, dims, &G))
+    return rls_fail(ctx, RLS_E_INVALID, "tv_grad_t: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(gradt_kernel<float>, dim3(tv_grid(G.n)), dim3(256), 0, ctx->stream, (const float*)g,
+                       (const float*)x, (float*)x, G, alpha, beta);
+  else
+    hipLaunchKernelGGL(gradt_kernel<float2>, dim3(tv_grid(G.n)), dim3(256), 0, ctx->stream, (const float2*)g,
+                       (const float2*)x, (float2*)x, G, alpha, beta);
+  return tv_status(ctx);
+}
+
+int32_t rls_tv_restrict(rls_ctx* ctx, int32_t dtype, int64_t n, void* pq) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && !pq)) return rls_fail(ctx, RLS_E_INVALID, "tv_restrict: bad argument");
+  if (n == 0) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(restrict_kernel<float>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, (float*)pq, n);
+  else
+    hipLaunchKernelGGL(restrict_kernel<float2>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, (float2*)pq, n);
+  return tv_status(ctx);
+}
+
+int32_t rls_tv_lincomb(rls_ctx* ctx, int32_t dtype, int64_t n, void* rs, float t3, const void* pq, float t2,
+                       const void* pqOld) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && (!rs || !pq || !pqOld)))
+    return rls_fail(ctx, RLS_E_INVALID, "tv_lincomb: bad argument");
+  if (n == 0) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(tv_lincomb_kernel<float>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, (float*)rs, t3,
+                       (const float*)pq, t2, (const float*)pqOld, n);
+  else
+    hipLaunchKernelGGL(tv_lincomb_kernel<float2>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, (float2*)rs, t3,
+                       (const float2*)pq, t2, (const float2*)pqOld, n);
+  return tv_status(ctx);
+}
+
+int32_t rls_prox_tv_fgp(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                        const int32_t* dims, void* x, float lambda, int32_t iterations, void* workspace,
+                        size_t workspace_bytes) {
+  RLS_CHECK_CTX(ctx);
+  tv_geom G;
+  if (!rls_dtype_ok(dtype) || !x || iterations < 0 || !make_geom(ndims, shape, ntv, dims, &G))
+    return rls_fail(ctx, RLS_E_INVALID, "prox_tv_fgp: bad argument");
+  const size_t need = (size_t)(2 * G.goff[G.ntv] + G.n) * rls_elem_size(dtype);
+  const bool fused = need <= FGP_LDS_BUDGET;
+  if (!fused && (!workspace || workspace_bytes < need))
+    return rls_fail(ctx, RLS_E_WORKSPACE, "prox_tv_fgp: workspace too small");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32) return fgp_typed<float>(ctx, G, (float*)x, lambda, iterations, (float*)workspace);
+  return fgp_typed<float2>(ctx, G, (float2*)x, lambda, iterations, (float2*)workspace);
+}
+
+}  // extern "C"

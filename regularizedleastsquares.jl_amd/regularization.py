@@ -1,0 +1,218 @@
+"""Regularisation types and prox!/norm dispatch, mirroring the reference's type tree
+(src/Regularization/Regularization.jl:1-57, src/proximalMaps/*.jl) for device vectors.
+
+Julia's `prox!(reg, x, lambda)` is `prox_(reg, x, lam)` here (trailing underscore = in place).
+Both call forms of the reference are kept:
+    prox_(reg_instance, x)            -> uses lambda(reg)         Regularization.jl:17
+    prox_(RegType, x, lam, **kw)      -> constructs RegType(lam; kw...) first   Regularization.jl:39,55
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+from ._lib import check
+from .arrays import DeviceVector
+
+
+class AbstractRegularization:
+    pass
+
+
+class AbstractParameterizedRegularization(AbstractRegularization):
+    lam: float
+
+
+class AbstractProjectionRegularization(AbstractRegularization):
+    lam = None
+
+
+class L1Regularization(AbstractParameterizedRegularization):
+    """src/proximalMaps/ProxL1.jl"""
+
+    def __init__(self, lam, **_kw):
+        self.lam = float(lam)
+
+    def prox_(self, x: DeviceVector, lam: float):
+        check(x.ctx.handle, x.ctx.lib.rls_prox_l1(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l1")
+        return x
+
+    def norm(self, x: DeviceVector, lam: float) -> float:
+        return float(lam) * x.norm1()
+
+
+class L2Regularization(AbstractParameterizedRegularization):
+    """src/proximalMaps/ProxL2.jl"""
+
+    def __init__(self, lam, **_kw):
+        self.lam = float(lam)
+
+    def prox_(self, x: DeviceVector, lam: float):
+        check(x.ctx.handle, x.ctx.lib.rls_prox_l2(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l2")
+        return x
+
+    def norm(self, x: DeviceVector, lam: float) -> float:
+        return float(lam) * x.norm() ** 2
+
+
+class L21Regularization(AbstractParameterizedRegularization):
+    """src/proximalMaps/ProxL21.jl"""
+
+    def __init__(self, lam, slices: int = 1, **_kw):
+        self.lam = float(lam)
+        self.slices = int(slices)
+
+    def prox_(self, x: DeviceVector, lam: float):
+        check(x.ctx.handle, x.ctx.lib.rls_prox_l21(x.ctx.handle, x.code, x.n, self.slices, x.ptr, float(lam)), "rls_prox_l21")
+        return x
+
+    def norm(self, x: DeviceVector, lam: float) -> float:
+        r = (C.c_float * 2)()
+        check(x.ctx.handle, x.ctx.lib.rls_norm_l21(x.ctx.handle, x.code, x.n, self.slices, x.ptr, float(lam), r), "rls_norm_l21")
+        return float(r[0])
+
+
+def _tv_geometry(shape: Sequence[int], dims) -> Tuple:
+    shape = tuple(int(s) for s in shape)
+    if dims is None:
+        d0 = tuple(range(len(shape)))
+    elif isinstance(dims, int):
+        d0 = (dims - 1,)  # dims are 1-based in the reference API
+    else:
+        d0 = tuple(int(d) - 1 for d in dims)
+    cs = (C.c_int64 * len(shape))(*shape)
+    cd = (C.c_int32 * max(len(d0), 1))(*d0)
+    return shape, d0, cs, cd
+
+
+class TVRegularization(AbstractParameterizedRegularization):
+    """src/proximalMaps/ProxTV.jl: FGP (the only algorithm reachable through prox!).
+    Default iterationsTV = 10 as the constructor has it (:39)."""
+
+    def __init__(self, lam, shape=(0,), dims=None, iterationsTV: int = 10, **_kw):
+        self.lam = float(lam)
+        self.shape = tuple(int(s) for s in shape)
+        self.dims = dims
+        self.iterationsTV = int(iterationsTV)
+        self._ws = None  # TVParams scratch: per regulariser instance, as in the reference (:83-85)
+
+    def prox_(self, x: DeviceVector, lam: float):
+        shape, d0, cs, cd = _tv_geometry(self.shape, self.dims)
+        n = 1
+        for s in shape:
+            n *= s
+        if n != x.n:
+            raise ValueError(f"TVRegularization: prod(shape)={n} does not match length(x)={x.n}")
+        lib, h = x.ctx.lib, x.ctx.handle
+        need = lib.rls_prox_tv_workspace_bytes(x.code, len(shape), cs, len(d0), cd)
+        if self._ws is None or self._ws.n * self._ws.dtype.itemsize < need or self._ws.ctx is not x.ctx:
+            self._ws = DeviceVector((need + x.dtype.itemsize - 1) // x.dtype.itemsize, x.dtype, x.ctx)
+        check(h, lib.rls_prox_tv_fgp(h, x.code, len(shape), cs, len(d0), cd, x.ptr, float(lam), self.iterationsTV,
+                                     self._ws.ptr, self._ws.n * self._ws.dtype.itemsize), "rls_prox_tv_fgp")
+        return x
+
+    def norm(self, x: DeviceVector, lam: float) -> float:
+        g = GradientOp(self.shape, self.dims).mul(x)
+        return float(lam) * g.norm1()
+
+
+class PositiveRegularization(AbstractProjectionRegularization):
+    """src/proximalMaps/ProxPositive.jl"""
+
+    def __init__(self, **_kw):
+        pass
+
+    def prox_(self, x: DeviceVector, lam=None):
+        check(x.ctx.handle, x.ctx.lib.rls_prox_positive(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_positive")
+        return x
+
+
+class RealRegularization(AbstractProjectionRegularization):
+    """src/proximalMaps/ProxReal.jl"""
+
+    def __init__(self, **_kw):
+        pass
+
+    def prox_(self, x: DeviceVector, lam=None):
+        check(x.ctx.handle, x.ctx.lib.rls_prox_real(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_real")
+        return x
+
+
+class GradientOp:
+    """LinearOperatorCollection.GradientOp on device vectors (call sites ProxTV.jl:46,108-109,123;
+    as an ADMM regTrafo: src/ADMM.jl:74)."""
+
+    def __init__(self, shape, dims=None):
+        self.shape, self.d0, self._cs, self._cd = _tv_geometry(shape, dims)
+        self.n_in = 1
+        for s in self.shape:
+            self.n_in *= s
+        from . import _lib
+        self.n_out = int(_lib.load().rls_tv_grad_len(len(self.shape), self._cs, len(self.d0), self._cd))
+
+    def size(self, i):
+        return (self.n_out, self.n_in)[i - 1]
+
+    def mul_(self, g: DeviceVector, x: DeviceVector, alpha=1.0, beta=0.0):
+        lib, h = x.ctx.lib, x.ctx.handle
+        check(h, lib.rls_tv_grad(h, x.code, len(self.shape), self._cs, len(self.d0), self._cd, x.ptr, g.ptr,
+                                 float(alpha), float(beta)), "rls_tv_grad")
+        return g
+
+    def mul_adj_(self, x: DeviceVector, g: DeviceVector, alpha=1.0, beta=0.0):
+        lib, h = x.ctx.lib, x.ctx.handle
+        check(h, lib.rls_tv_grad_t(h, x.code, len(self.shape), self._cs, len(self.d0), self._cd, g.ptr, x.ptr,
+                                   float(alpha), float(beta)), "rls_tv_grad_t")
+        return x
+
+    def mul(self, x: DeviceVector) -> DeviceVector:
+        return self.mul_(DeviceVector(self.n_out, x.dtype, x.ctx), x)
+
+
+# ---- normalisation plumbing (src/Regularization/NormalizedRegularization.jl:40-84) ------------
+
+
+class NoNormalization:
+    pass
+
+
+class MeasurementBasedNormalization:
+    pass
+
+
+class SystemMatrixBasedNormalization:
+    pass
+
+
+def normalize(norm_scheme, regs, A=None, b=None):
+    """NoNormalization -> identity (:59,69).  The other schemes are setup-time scalars outside the
+    inner loop and are not part of this backend."""
+    if norm_scheme is None or isinstance(norm_scheme, NoNormalization):
+        return regs
+    raise NotImplementedError(f"{type(norm_scheme).__name__} is outside the hot-path scope; use NoNormalization()")
+
+
+# ---- generic entry points --------------------------------------------------------------------
+
+
+def lam(reg):
+    """lambda(reg)  (Regularization.jl:29; projections have none, :42)"""
+    return getattr(reg, "lam", None)
+
+
+def prox_(reg, x: DeviceVector, lam_: Optional[float] = None, **kw):
+    if isinstance(reg, type):
+        if issubclass(reg, AbstractProjectionRegularization):
+            return reg(**kw).prox_(x)
+        if lam_ is None:
+            raise TypeError("prox_(RegType, x, lam): lam is required")
+        return reg(lam_, **kw).prox_(x, lam_)
+    if isinstance(reg, AbstractProjectionRegularization):
+        return reg.prox_(x)
+    return reg.prox_(x, reg.lam if lam_ is None else lam_)
+
+
+def norm(reg, x: DeviceVector, lam_: Optional[float] = None, **kw):
+    if isinstance(reg, type):
+        return reg(lam_, **kw).norm(x, lam_)
+    return reg.norm(x, reg.lam if lam_ is None else lam_)

@@ -1,0 +1,813 @@
+"""Host-side mirror of the reference's solver API for device arrays:
+createLinearSolver / solve! / init! / iterate / solversolution / solverconvergence, the solver types
+CGNR, FISTA, ADMM and the matrix-right-hand-side schedulers.
+
+Julia `f!` is `f_` here.  Every numeric step is a call into librls_mi355x.so; this file owns control
+flow only (what src/RegularizedLeastSquares.jl:103-131,288-294 and the ctor / init! / iterate
+bodies of src/CGNR.jl, src/FISTA.jl, src/ADMM.jl, src/MultiThreading.jl own in the reference).
+The call sequences are exactly the ones the Julia extension issues (julia/ in this repo), so
+parity of this harness is parity of the extension.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import inspect
+import math
+import warnings
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, CgnrStatus, CgStatus,
+                   FistaStatus, check)
+from .arrays import DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle
+from .regularization import (AbstractProjectionRegularization, GradientOp, L1Regularization, L2Regularization,
+                             L21Regularization, NoNormalization, PositiveRegularization, RealRegularization,
+                             TVRegularization, normalize)
+
+_EPS32 = float(np.finfo(np.float32).eps)
+
+
+# --------------------------------------------------------------------------------------------
+# shared plumbing
+# --------------------------------------------------------------------------------------------
+
+
+def _as_list(reg):
+    if reg is None:
+        return []
+    return list(reg) if isinstance(reg, (list, tuple)) else [reg]
+
+
+def _resolve_operator(A, AHA):
+    """Returns (A: DeviceMatrix|None, OperatorHandle).  AHA=None means the constructor default
+    `A' * A`, which for this backend's operator type is the lazy normal operator (matrix-free)."""
+    if A is not None and not isinstance(A, DeviceMatrix):
+        raise TypeError("A must be a DeviceMatrix (the backend is selected by the array type, as in the reference)")
+    gram = None
+    if AHA is None:
+        if A is None:
+            raise ValueError("either A or AHA is required")
+    elif isinstance(AHA, NormalOperator):
+        if A is None:
+            A = AHA.A
+    elif isinstance(AHA, DeviceMatrix):
+        gram = AHA
+    else:
+        raise TypeError("AHA must be a DeviceMatrix (Gram matrix) or a NormalOperator")
+    return A, OperatorHandle(A, gram)
+
+
+class AbstractLinearSolver:
+    state = None
+
+    # preserved accessors (src/RegularizedLeastSquares.jl:163-183)
+    def solversolution(self):
+        return solversolution(self.state)
+
+    def solverconvergence(self):
+        return solverconvergence(self.state)
+
+
+class AbstractSolverState:
+    pass
+
+
+def solverstate(solver):
+    return solver.state
+
+
+def solversolution(obj):
+    st = obj.state if isinstance(obj, AbstractLinearSolver) else obj
+    if isinstance(st, AbstractMatrixSolverState):
+        return [solversolution(s) for s in st.states]  # hcat of columns (src/MultiThreading.jl:79)
+    return st.x
+
+
+def solverconvergence(obj):
+    st = obj.state if isinstance(obj, AbstractLinearSolver) else obj
+    return st.convergence()
+
+
+# --------------------------------------------------------------------------------------------
+# CGNR
+# --------------------------------------------------------------------------------------------
+
+
+class CGNRState(AbstractSolverState):
+    """src/CGNR.jl:13-24.  x0 is the normal-equation residual (x₀ in the reference)."""
+
+    def __init__(self, relTol):
+        self.x = self.x0 = self.pl = self.vl = None
+        self.alphal = self.betal = self.zetal = 0.0
+        self.iteration = 0
+        self.relTol = float(relTol)
+        self.z0 = 0.0
+        self._plan = None
+        self._done = False
+
+    def _refresh(self, lib):
+        st = CgnrStatus()
+        check(self.x.ctx.handle, lib.rls_cgnr_get_status(self._plan, C.byref(st)), "rls_cgnr_get_status")
+        cplx = self.x.dtype.kind == "c"
+        self.alphal = complex(st.alpha_re, st.alpha_im) if cplx else st.alpha_re
+        self.betal = complex(st.beta_re, st.beta_im) if cplx else st.beta_re
+        self.zetal = st.zeta
+        self.iteration = st.iteration
+        self.z0 = st.z0
+        self._done = bool(st.done)
+        self._residual = st.residual
+        return st
+
+    def convergence(self):
+        self._refresh(self.x.ctx.lib)
+        return {"residual": self._residual}  # src/CGNR.jl:136
+
+    def __del__(self):
+        try:
+            if self._plan and self.x is not None and self.x.ctx.handle:
+                self.x.ctx.lib.rls_cgnr_destroy(self._plan)
+        except Exception:
+            pass
+        self._plan = None
+
+
+class CGNR(AbstractLinearSolver):
+    """src/CGNR.jl:48-89"""
+
+    def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 10, relTol=_EPS32):
+        self.A, self._op = _resolve_operator(A, AHA)
+        self.AHA = AHA if AHA is not None else self.A.normal_operator()
+        regs = normalize(normalizeReg, _as_list(reg), self.A, None)
+        l2 = [r for r in regs if isinstance(r, L2Regularization)]
+        if len(l2) > 1:
+            raise ValueError(f"Cannot unambigiously retrieve reg term of type L2Regularization, found {len(l2)} instances")
+        self.L2 = l2[0] if l2 else L2Regularization(0.0)
+        self.constr = [r for r in regs if isinstance(r, (RealRegularization, PositiveRegularization))]
+        rest = [r for r in regs if r not in l2 and r not in self.constr]
+        if rest:
+            raise ValueError(f"CGNR does not allow for more additional regularization terms, found {len(rest)}")
+        self.normalizeReg = normalizeReg or NoNormalization()
+        self.iterations = int(iterations)
+        self.state = CGNRState(relTol)
+
+    def _new_state(self):
+        return CGNRState(self.state.relTol if not isinstance(self.state, AbstractMatrixSolverState) else self.state.states[0].relTol)
+
+    def init_(self, state: CGNRState, b: DeviceVector, x0=0):
+        """init!(solver, state, b; x0 = 0)  src/CGNR.jl:91-130"""
+        if not (np.isscalar(x0) and x0 == 0):
+            # the reference's x0 != 0 branch reads a field that does not exist (src/CGNR.jl:119)
+            raise NotImplementedError("CGNR: x0 != 0 is unsupported (it throws in the reference as well)")
+        N = self._op.N
+        lib = b.ctx.lib
+        if state.x is None or state.x.ctx is not b.ctx or state.x.dtype != b.dtype or state.x.n != N:
+            state.x, state.x0, state.pl, state.vl = (b.similar(N) for _ in range(4))  # similar(b, ...) :92-95
+            if state._plan:
+                lib.rls_cgnr_destroy(state._plan)
+            plan = C.c_void_p()
+            check(b.ctx.handle, lib.rls_cgnr_create(self._op.handle, state.x.ptr, state.x0.ptr, state.pl.ptr,
+                                                    state.vl.ptr, C.byref(plan)), "rls_cgnr_create")
+            state._plan = plan
+            state._keep = (self._op, b.ctx)  # destruction order: plan before operator before context
+        expect = self._op.M if self.A is not None else N
+        if b.n != expect:
+            raise ValueError(f"DimensionMismatch: b has length {b.n}, expected {expect}")
+        check(b.ctx.handle, lib.rls_cgnr_init(state._plan, b.ptr, float(self.L2.lam), state.relTol, self.iterations),
+              "rls_cgnr_init")
+        state.iteration = 0
+        state._done = False
+        state._finalised = False
+
+    def iterate(self, state: Optional[CGNRState] = None):
+        """iterate(solver, state)  src/CGNR.jl:143-178; returns None when done"""
+        state = state or self.state
+        lib = state.x.ctx.lib
+        state._refresh(lib)
+        if state._done:
+            if not getattr(state, "_finalised", False):
+                for r in self.constr:  # constraints applied once, at exit  :145-147
+                    r.prox_(state.x)
+                state._finalised = True
+            return None
+        check(state.x.ctx.handle, lib.rls_cgnr_step(state._plan, 1), "rls_cgnr_step")
+        return state.x, state
+
+    def _run(self, state: CGNRState):
+        """no callbacks: enqueue every remaining iteration (no-ops once done) and finalise"""
+        lib = state.x.ctx.lib
+        n = max(min(self.iterations, self._op.N) - state.iteration, 0)
+        check(state.x.ctx.handle, lib.rls_cgnr_step(state._plan, n), "rls_cgnr_step")
+        while self.iterate(state) is not None:  # normally returns None at once
+            pass
+
+
+# --------------------------------------------------------------------------------------------
+# FISTA
+# --------------------------------------------------------------------------------------------
+
+
+def power_iterations(AHA, b0: DeviceVector, rtol=1e-3, maxiter=30) -> float:
+    """src/Utils.jl:262-287 on device vectors.  The start vector is an argument: the reference draws
+    it from Julia's global RNG, which no other runtime can replay."""
+    b = b0.copy()
+    bold = b0.similar()
+    lam_ = math.inf
+    for _ in range(maxiter):
+        b.rmul_(1.0 / b.norm())
+        b, bold = bold, b
+        AHA.mul_(b, bold)
+        lam_old = lam_
+        lam_ = abs(bold.dot(b))
+        if abs(lam_ / lam_old - 1) < rtol:
+            return lam_
+    return lam_
+
+
+class FISTAState(AbstractSolverState):
+    """src/FISTA.jl:15-27"""
+
+    def __init__(self, rho, theta, relTol):
+        self.x = self.x0 = self.xold = self.res = None
+        self.rho = float(rho)
+        self.theta = self.thetaold = float(theta)
+        self.iteration = 0
+        self.relTol = float(relTol)
+        self.norm_x0 = 1.0
+        self.rel_res_norm = math.inf
+        self._plan = None
+        self._bufs = None
+        self._done = False
+
+    def _refresh(self, lib):
+        st = FistaStatus()
+        h = self._bufs[0].ctx.handle
+        check(h, lib.rls_fista_get_status(self._plan, C.byref(st)), "rls_fista_get_status")
+        self.theta, self.thetaold = st.theta, st.theta_old
+        self.iteration = st.iteration
+        self.rel_res_norm = st.rel_res_norm
+        self.norm_x0 = st.norm_x0
+        self._residual = st.residual
+        self._done = bool(st.done)
+        # the reference swaps x / xold by pointer every iteration (src/FISTA.jl:144-146)
+        self.x, self.xold = (self._bufs[st.iteration & 1], self._bufs[(st.iteration + 1) & 1])
+        return st
+
+    def convergence(self):
+        if self._plan:
+            self._refresh(self.x.ctx.lib)
+            return {"residual": self._residual}
+        return {"residual": self.res.norm()}  # src/FISTA.jl:131
+
+    def __del__(self):
+        try:
+            if self._plan and self._bufs and self._bufs[0].ctx.handle:
+                self._bufs[0].ctx.lib.rls_fista_destroy(self._plan)
+        except Exception:
+            pass
+        self._plan = None
+
+
+class FISTA(AbstractLinearSolver):
+    """src/FISTA.jl:57-92.  `rho` defaults to 0.95 / power_iterations(AHA) as in the reference; pass it
+    explicitly for reproducible runs (the reference's default depends on the global RNG)."""
+
+    def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 50, verbose: bool = False,
+                 rho=None, theta=1, relTol=_EPS32, restart: str = "none"):
+        self.A, self._op = _resolve_operator(A, AHA)
+        self.AHA = AHA if AHA is not None else self.A.normal_operator()
+        regs = _as_list(reg) or [L1Regularization(0.0)]
+        self.proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
+        rest = [r for r in regs if not isinstance(r, AbstractProjectionRegularization)]
+        if len(rest) != 1:
+            raise ValueError(f"FISTA does not allow for more additional regularization terms, found {len(rest)}")
+        self.reg = normalize(normalizeReg, rest, self.A, None)[0]
+        self.normalizeReg = normalizeReg or NoNormalization()
+        self.verbose = bool(verbose)
+        if restart not in ("none", "gradient"):
+            raise ValueError("restart must be 'none' or 'gradient'")
+        self.restart = restart
+        self.iterations = int(iterations)
+        if rho is None:
+            n = self._op.N
+            rng = np.random.default_rng()
+            v = rng.standard_normal(n).astype(np.float32)
+            if self._op.dtype.kind == "c":
+                v = (v + 1j * rng.standard_normal(n)).astype(np.complex64)
+            start = DeviceVector.from_host(v, self._op.ctx)
+            rho = 0.95 / power_iterations(_NormalApply(self._op), start)
+        self.state = FISTAState(rho, theta, relTol)
+
+    def _fused_kinds(self):
+        """(reg_kind, lambda, slices, proj_kind) when the update is fusable, else None"""
+        r = self.reg
+        if isinstance(r, L1Regularization):
+            kind, slices = REG_L1, 1
+        elif isinstance(r, L2Regularization):
+            kind, slices = REG_L2, 1
+        elif isinstance(r, L21Regularization):
+            kind, slices = REG_L21, r.slices
+        else:
+            return None
+        if len(self.proj) > 1:
+            return None
+        pk = PROJ_NONE
+        if self.proj:
+            pk = PROJ_POSITIVE if isinstance(self.proj[0], PositiveRegularization) else PROJ_REAL
+        return kind, float(r.lam), slices, pk
+
+    def _new_state(self):
+        s = self.state.states[0] if isinstance(self.state, AbstractMatrixSolverState) else self.state
+        return FISTAState(s.rho, s.theta if s.iteration == 0 else 1.0, s.relTol)
+
+    def init_(self, state: FISTAState, b: DeviceVector, x0=0, theta=1):
+        """init!(solver, state, b; x0 = 0, theta = 1)   src/FISTA.jl:94-129"""
+        N = self._op.N
+        lib, h = b.ctx.lib, b.ctx.handle
+        fused = self._fused_kinds()
+        fresh = state._bufs is None or state._bufs[0].ctx is not b.ctx or state._bufs[0].dtype != b.dtype
+        if fresh:
+            state._bufs = [b.similar(N), b.similar(N)]
+            state.x0, state.res = b.similar(N), b.similar(N)
+            if state._plan:
+                lib.rls_fista_destroy(state._plan)
+                state._plan = None
+            if fused is not None:
+                plan = C.c_void_p()
+                check(h, lib.rls_fista_create(self._op.handle, state._bufs[0].ptr, state.x0.ptr, state._bufs[1].ptr,
+                                              state.res.ptr, C.byref(plan)), "rls_fista_create")
+                state._plan = plan
+                state._keep = (self._op, b.ctx)
+        state.x, state.xold = state._bufs
+        if fused is not None:
+            kind, lam_, slices, pk = fused
+            check(h, lib.rls_fista_set_reg(state._plan, kind, lam_, slices, pk), "rls_fista_set_reg")
+            check(h, lib.rls_fista_init(state._plan, b.ptr, state.rho, float(theta), state.relTol, self.iterations,
+                                        1 if self.restart == "gradient" else 0), "rls_fista_init")
+            if not (np.isscalar(x0) and x0 == 0):
+                xs = x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx)
+                check(h, lib.rls_fista_set_start(state._plan, xs.ptr), "rls_fista_set_start")
+        else:
+            # generic path from primitives (TV prox etc.)
+            if self.A is None:
+                state.x0.copy_from(b)
+            else:
+                self.A.mul_adj_(state.x0, b)
+            state.norm_x0 = state.x0.norm()
+            if np.isscalar(x0):
+                state.x.fill_(x0)
+            else:
+                state.x.copy_from(x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx))
+            state.xold.fill_(0)
+            state.res.fill_(math.inf)
+            state.rel_res_norm = math.inf
+        state.iteration = 0
+        state.theta = state.thetaold = float(theta)
+        state._done = False
+
+    def iterate(self, state: Optional[FISTAState] = None):
+        state = state or self.state
+        if state._plan:
+            lib = state.x.ctx.lib
+            state._refresh(lib)
+            if state._done:
+                return None
+            check(state.x.ctx.handle, lib.rls_fista_step(state._plan, 1), "rls_fista_step")
+            state.iteration += 1
+            state.x, state.xold = state.xold, state.x
+            return state.x, state
+        return self._iterate_generic(state)
+
+    def _iterate_generic(self, state: FISTAState):
+        """src/FISTA.jl:139-185 from primitives (one host read-back for the residual norm)"""
+        if state.rel_res_norm < state.relTol or state.iteration >= self.iterations:
+            return None
+        f32 = np.float32
+        state.x, state.xold = state.xold, state.x
+        th, tho = f32(state.theta), f32(state.thetaold)
+        state.x.rmul_(float((f32(1) - tho) / th))
+        state.x.axpy_(float((tho - f32(1)) / th + f32(1)), state.xold)
+        _NormalApply(self._op).mul_(state.res, state.x)
+        state.res.axpy_(-1.0, state.x0)
+        state.x.axpy_(-state.rho, state.res)
+        state.rel_res_norm = state.res.norm() / state.norm_x0
+        if self.verbose:
+            print(f"Iteration {state.iteration}; rel. residual = {state.rel_res_norm}")
+        self.reg.prox_(state.x, float(f32(state.rho) * f32(self.reg.lam)))
+        for pr in self.proj:
+            pr.prox_(state.x)
+        if self.restart == "gradient":
+            d = state.x.copy().axpy_(-1.0, state.xold)
+            if np.real(state.res.dot(d)) > 0:
+                state.theta = 1.0
+        state.thetaold = state.theta
+        t = f32(state.thetaold)
+        state.theta = float((f32(1) + np.sqrt(f32(1) + f32(4) * t * t)) / f32(2))
+        state.iteration += 1
+        return state.x, state
+
+    def _run(self, state: FISTAState):
+        if state._plan:
+            lib = state.x.ctx.lib
+            check(state.x.ctx.handle, lib.rls_fista_step(state._plan, max(self.iterations - state.iteration, 0)),
+                  "rls_fista_step")
+            state._refresh(lib)
+        while self.iterate(state) is not None:
+            pass
+
+
+class _NormalApply:
+    """mul!(v, AHA, p) through the operator handle"""
+
+    def __init__(self, op: OperatorHandle):
+        self.op = op
+
+    def mul_(self, v, p):
+        return self.op.mul_normal_(v, p)
+
+
+# --------------------------------------------------------------------------------------------
+# ADMM
+# --------------------------------------------------------------------------------------------
+
+
+class _Identity:
+    """opEye (src/ADMM.jl:84)"""
+
+    identity = True
+
+    def __init__(self, n):
+        self.n_out = n
+
+    def mul_(self, z, x, alpha=1.0, beta=0.0):
+        return z.lincomb_(alpha, x, beta, z) if beta != 0 else z.lincomb_(alpha, x, 0.0, x)
+
+    def mul_adj_(self, x, z, alpha=1.0, beta=0.0):
+        return x.lincomb_(alpha, z, beta, x) if beta != 0 else x.lincomb_(alpha, z, 0.0, z)
+
+
+class ADMMState(AbstractSolverState):
+    """src/ADMM.jl:19-46"""
+
+    def __init__(self, nreg, rho, absTol, relTol, tolInner):
+        self.x = self.xold = self.beta = self.beta_y = None
+        self.z: List[DeviceVector] = []
+        self.zold: List[DeviceVector] = []
+        self.u: List[DeviceVector] = []
+        self.uold: List[DeviceVector] = []
+        self.rho = np.array(rho, dtype=np.float32)
+        self.iteration = 0
+        self.rk = np.full(nreg, np.inf, np.float32)
+        self.sk = np.full(nreg, np.inf, np.float32)
+        self.eps_pri = np.zeros(nreg, np.float32)
+        self.eps_dua = np.zeros(nreg, np.float32)
+        self.sigma_abs = np.float32(0)
+        self.Delta = np.full(nreg, np.inf, np.float32)
+        self.absTol, self.relTol, self.tolInner = np.float32(absTol), np.float32(relTol), np.float32(tolInner)
+        self.cg_u = self.cg_r = self.cg_c = None
+        self._cg = None
+        self.cg_iterations: List[int] = []
+
+    def convergence(self):
+        return {"primal": self.rk.copy(), "dual": self.sk.copy()}  # src/ADMM.jl:222
+
+    def __del__(self):
+        try:
+            if self._cg and self.x is not None and self.x.ctx.handle:
+                self.x.ctx.lib.rls_cg_destroy(self._cg)
+        except Exception:
+            pass
+        self._cg = None
+
+
+class ADMM(AbstractLinearSolver):
+    """src/ADMM.jl:80-162"""
+
+    def __init__(self, A=None, *, AHA=None, precon=None, reg=None, regTrafo=None, normalizeReg=None, rho=1e-1,
+                 vary_rho: str = "none", iterations: int = 10, iterationsCG: int = 10, absTol=_EPS32, relTol=_EPS32,
+                 tolInner=1e-5, verbose: bool = False):
+        if precon is not None:
+            raise NotImplementedError("only the Identity() preconditioner is supported")
+        self.A, self._op = _resolve_operator(A, AHA)
+        self.AHA = AHA if AHA is not None else self.A.normal_operator()
+        regs = _as_list(reg) or [L1Regularization(0.0)]
+        self.proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
+        self.reg = normalize(normalizeReg, [r for r in regs if not isinstance(r, AbstractProjectionRegularization)], self.A, None)
+        n = self._op.N
+        trafos = _as_list(regTrafo) or [_Identity(n) for _ in self.reg]
+        if len(trafos) != len(self.reg):
+            raise AssertionError("reg and regTrafo must have the same length")
+        self.regTrafo = trafos
+        self.rho = [float(rho)] * len(self.reg) if np.isscalar(rho) else [float(r) for r in rho]
+        if vary_rho not in ("none", "balance", "PnP"):
+            raise ValueError("vary_rho must be 'none', 'balance' or 'PnP'")
+        self.vary_rho = vary_rho
+        self.verbose = bool(verbose)
+        self.iterations = int(iterations)
+        self.iterationsCG = int(iterationsCG)
+        self.normalizeReg = normalizeReg or NoNormalization()
+        self.state = ADMMState(len(self.reg), self.rho, absTol, relTol, tolInner)
+
+    def _new_state(self):
+        s = self.state.states[0] if isinstance(self.state, AbstractMatrixSolverState) else self.state
+        return ADMMState(len(self.reg), self.rho, s.absTol, s.relTol, s.tolInner)
+
+    def _all_identity(self):
+        return all(getattr(t, "identity", False) for t in self.regTrafo)
+
+    def init_(self, state: ADMMState, b: DeviceVector, x0=0):
+        """src/ADMM.jl:166-220"""
+        N = self._op.N
+        lib, h = b.ctx.lib, b.ctx.handle
+        if state.x is None or state.x.ctx is not b.ctx or state.x.dtype != b.dtype:
+            state.x, state.xold, state.beta, state.beta_y = (b.similar(N) for _ in range(4))
+            state.z = [b.similar(t.n_out) for t in self.regTrafo]
+            state.zold = [b.similar(t.n_out) for t in self.regTrafo]
+            state.u = [b.similar(t.n_out) for t in self.regTrafo]
+            state.uold = [b.similar(t.n_out) for t in self.regTrafo]
+            state.cg_u, state.cg_r, state.cg_c = (b.similar(N) for _ in range(3))  # CGStateVariables :129,177
+            if state._cg:
+                lib.rls_cg_destroy(state._cg)
+            plan = C.c_void_p()
+            check(h, lib.rls_cg_create(self._op.handle, state.cg_u.ptr, state.cg_r.ptr, state.cg_c.ptr, C.byref(plan)),
+                  "rls_cg_create")
+            state._cg = plan
+            state._keep = (self._op, b.ctx)
+        if np.isscalar(x0):
+            state.x.fill_(x0)
+        else:
+            state.x.copy_from(x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx))
+        if self.A is None:
+            state.beta_y.copy_from(b)
+        else:
+            self.A.mul_adj_(state.beta_y, b)
+        for i, t in enumerate(self.regTrafo):
+            t.mul_(state.z[i], state.x)
+            state.u[i].fill_(0)
+        state.rk[:] = np.inf
+        state.sk[:] = np.inf
+        state.eps_pri[:] = 0
+        state.eps_dua[:] = 0
+        state.sigma_abs = np.float32(np.sqrt(np.float32(b.n))) * state.absTol
+        state.Delta[:] = np.inf
+        state.rho[:] = self.rho
+        state.iteration = 0
+        state.cg_iterations = []
+
+    def converged(self, state):
+        for i in range(len(self.reg)):
+            if state.rk[i] >= state.sigma_abs + state.relTol * state.eps_pri[i]:
+                return False
+            if state.sk[i] >= state.sigma_abs + state.relTol * state.eps_dua[i]:
+                return False
+        return True
+
+    def done(self, state):
+        return self.converged(state) or state.iteration >= self.iterations
+
+    def _composite_mul(self, state, out, v, tmp_list):
+        """compositeAHA * v = AHA v + sum_i rho_i Phi_i^H Phi_i v   (src/ADMM.jl:141-159)"""
+        self._op.mul_normal_(out, v)
+        for i, t in enumerate(self.regTrafo):
+            if getattr(t, "identity", False):
+                out.axpy_(float(state.rho[i]), v)
+            else:
+                t.mul_(tmp_list[i], v)
+                t.mul_adj_(out, tmp_list[i], float(state.rho[i]), 1.0)
+        return out
+
+    def _cg_generic(self, state):
+        """IterativeSolvers.cg! from primitives (non-identity regTrafo); see oracle cg_inplace"""
+        f32 = np.float32
+        x, b = state.x, state.beta
+        u, r, c = state.cg_u, state.cg_r, state.cg_c
+        tmp = state.zold  # free at this point of the iteration
+        u.fill_(0)
+        r.copy_from(b)
+        self._composite_mul(state, c, x, tmp)
+        r.axpy_(-1.0, c)
+        residual = f32(r.norm())
+        tol = max(f32(state.tolInner) * residual, f32(0))
+        prev = f32(1)
+        it = 0
+        while it < self.iterationsCG and residual > tol:
+            beta = residual * residual / (prev * prev)
+            u.lincomb_(1.0, r, float(beta), u)
+            self._composite_mul(state, c, u, tmp)
+            alpha = complex(residual * residual) / complex(u.dot(c))
+            x.axpy_(alpha, u)
+            r.axpy_(-alpha, c)
+            prev = residual
+            residual = f32(r.norm())
+            it += 1
+        return it
+
+    def iterate(self, state: Optional[ADMMState] = None):
+        """src/ADMM.jl:230-322"""
+        state = state or self.state
+        if self.done(state):
+            return None
+        f32 = np.float32
+        lib, h = state.x.ctx.lib, state.x.ctx.handle
+        # 1. x update                                                                  :236-244
+        state.beta.copy_from(state.beta_y)
+        for i, t in enumerate(self.regTrafo):
+            t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
+            t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
+        state.xold.copy_from(state.x)
+        if self._all_identity():
+            rho_sum = float(np.sum(state.rho, dtype=np.float32))
+            check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, rho_sum, self.iterationsCG,
+                                      float(state.tolInner)), "rls_cg_solve")
+            st = CgStatus()
+            check(h, lib.rls_cg_get_status(state._cg, C.byref(st)), "rls_cg_get_status")
+            state.cg_iterations.append(int(st.iterations))
+        else:
+            state.cg_iterations.append(self._cg_generic(state))
+        for pr in self.proj:
+            pr.prox_(state.x)
+        # 2./3. z and u updates + convergence bookkeeping                              :251-309
+        for i, t in enumerate(self.regTrafo):
+            state.z[i], state.zold[i] = state.zold[i], state.z[i]
+            t.mul_(state.z[i], state.x)
+            state.z[i].axpy_(1.0, state.u[i])
+            if state.rho[i] != 0:
+                self.reg[i].prox_(state.z[i], float(f32(self.reg[i].lam) / (f32(2) * state.rho[i])))
+            state.uold[i].copy_from(state.u[i])
+            t.mul_(state.u[i], state.x, 1.0, 1.0)
+            state.u[i].axpy_(-1.0, state.z[i])
+            state.xold.lincomb_(1.0, state.x, -1.0, state.xold)
+            state.zold[i].lincomb_(1.0, state.z[i], -1.0, state.zold[i])
+            state.uold[i].lincomb_(1.0, state.u[i], -1.0, state.uold[i])
+            Delta_old = state.Delta[i]
+            state.Delta[i] = f32(state.xold.norm()) + f32(state.zold[i].norm()) + f32(state.uold[i].norm())
+            t.mul_adj_(state.xold, state.zold[i])
+            state.sk[i] = state.rho[i] * f32(state.xold.norm())
+            t.mul_(state.zold[i], state.x)
+            state.eps_pri[i] = max(f32(state.zold[i].norm()), f32(state.z[i].norm()))
+            state.zold[i].axpy_(-1.0, state.z[i])
+            state.rk[i] = f32(state.zold[i].norm())
+            t.mul_adj_(state.xold, state.u[i])
+            state.eps_dua[i] = state.rho[i] * f32(state.xold.norm())
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if (self.vary_rho == "balance" and state.rk[i] / state.eps_pri[i] > f32(10) * state.sk[i] / state.eps_dua[i]) or (
+                        self.vary_rho == "PnP" and state.Delta[i] / Delta_old > f32(0.9)):
+                    state.rho[i] *= f32(2)
+                    state.u[i].rmul_(0.5)
+                elif self.vary_rho == "balance" and state.sk[i] / state.eps_dua[i] > f32(10) * state.rk[i] / state.eps_pri[i]:
+                    state.rho[i] /= f32(2)
+                    state.u[i].rmul_(2.0)
+            if self.verbose:
+                print(f"rk[{i}]/eps_pri[{i}] = {state.rk[i] / state.eps_pri[i]}")
+                print(f"sk[{i}]/eps_dua[{i}] = {state.sk[i] / state.eps_dua[i]}")
+                print(f"new rho[{i}] = {state.rho[i]}")
+        state.iteration += 1
+        return state.x, state
+
+    def _run(self, state):
+        while self.iterate(state) is not None:
+            pass
+
+
+# --------------------------------------------------------------------------------------------
+# matrix right-hand sides: src/MultiThreading.jl
+# --------------------------------------------------------------------------------------------
+
+
+class AbstractMatrixSolverState(AbstractSolverState):
+    def __init__(self, states):
+        self.states = list(states)
+        self.active = [True] * len(self.states)
+
+    def convergence(self):
+        return [s.convergence() for s in self.states]
+
+
+class SequentialState(AbstractMatrixSolverState):
+    """src/MultiThreading.jl:8-12"""
+
+
+class MultiThreadingState(AbstractMatrixSolverState):
+    """src/MultiThreading.jl:19-23.  On one GPU the columns are independent streams of kernels on the
+    context's queue; across GPUs, columns are sharded one set per device (multigpu.MultiSolve)."""
+
+
+def _columns(b) -> List[DeviceVector]:
+    if isinstance(b, DeviceMatrix):
+        return [b.column(j) for j in range(b.N)]
+    return list(b)
+
+
+# --------------------------------------------------------------------------------------------
+# driver API
+# --------------------------------------------------------------------------------------------
+
+
+def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
+    """init!(solver, b; kwargs...)   src/RegularizedLeastSquares.jl:190, src/MultiThreading.jl:30-43"""
+    if isinstance(b, DeviceVector):
+        if isinstance(solver.state, AbstractMatrixSolverState):
+            solver.state = solver.state.states[0]  # :39-43
+        solver.init_(solver.state, b, **kw)
+        return
+    cols = _columns(b)
+    states = [solver._new_state() for _ in cols]  # deep copies of the state  :45-48
+    solver.state = scheduler(states)
+    for s, col in zip(states, cols):
+        solver.init_(s, col, **kw)
+    solver.state.active = [True] * len(states)
+
+
+def iterate(solver: AbstractLinearSolver):
+    """iterate(solver)   src/RegularizedLeastSquares.jl:191, src/MultiThreading.jl:52-78"""
+    st = solver.state
+    if isinstance(st, AbstractMatrixSolverState):
+        idx = [i for i, a in enumerate(st.active) if a]
+        if not idx:
+            return None
+        for i in idx:
+            if solver.iterate(st.states[i]) is None:
+                st.active[i] = False
+        return st.active, st
+    return solver.iterate(st)
+
+
+def solve_(solver: AbstractLinearSolver, b, callbacks=None, **kw):
+    """solve!(solver, b; callbacks, kwargs...)   src/RegularizedLeastSquares.jl:103-117.
+    Callbacks fire once after init! (iteration 0) and once per completed iteration."""
+    if callbacks is None:
+        cbs: List[Callable] = []
+    elif callable(callbacks):
+        cbs = [callbacks]
+    else:
+        cbs = list(callbacks)
+    init_(solver, b, **kw)
+    for cb in cbs:
+        cb(solver, 0)
+    if not cbs:
+        st = solver.state
+        for s in (st.states if isinstance(st, AbstractMatrixSolverState) else [st]):
+            solver._run(s)
+        if isinstance(st, AbstractMatrixSolverState):
+            st.active = [False] * len(st.states)
+        return solversolution(solver)
+    it = 0
+    while iterate(solver) is not None:
+        it += 1
+        for cb in cbs:
+            cb(solver, it)
+    return solversolution(solver)
+
+
+def _filter_kwargs(T, kwarg_warning, kwargs):
+    """filterKwargs  src/RegularizedLeastSquares.jl:267-278"""
+    names = set(inspect.signature(T.__init__).parameters) - {"self"}
+    kept = {k: v for k, v in kwargs.items() if k in names}
+    dropped = [k for k in kwargs if k not in names]
+    if dropped and kwarg_warning:
+        warnings.warn("The following arguments were passed but filtered out: " + ", ".join(dropped) +
+                      ". Please watch closely if this introduces unexpexted behaviour in your code.")
+    return kept
+
+
+def createLinearSolver(solver_type, A=None, *, kwargWarning: bool = True, **kwargs):
+    """createLinearSolver(T, A; kwargs...) / createLinearSolver(T; AHA, kwargs...)  :288-294"""
+    if not (isinstance(solver_type, type) and issubclass(solver_type, AbstractLinearSolver)):
+        raise TypeError("solver must be an AbstractLinearSolver type")
+    return solver_type(A, **_filter_kwargs(solver_type, kwargWarning, kwargs))
+
+
+def linearSolverList():
+    return [CGNR, FISTA, ADMM]
+
+
+# ---- callbacks (src/Callbacks.jl) -- thin host-side helpers ------------------------------------
+
+
+class StoreSolutionCallback:
+    def __init__(self):
+        self.solutions = []
+
+    def __call__(self, solver, _it):
+        x = solversolution(solver)
+        self.solutions.append([v.to_host() for v in x] if isinstance(x, list) else x.to_host())
+
+
+class StoreConvergenceCallback:
+    def __init__(self):
+        self.convMeas = {}
+
+    def __call__(self, solver, _it):
+        for k, v in solverconvergence(solver).items():
+            self.convMeas.setdefault(k, []).append(v)
+
+
+class CompareSolutionCallback:
+    def __init__(self, ref, cmp=None):
+        self.ref = np.asarray(ref)
+        self.cmp = cmp or (lambda r, x: float(np.linalg.norm(r - x) / np.linalg.norm(r)))
+        self.results = []
+
+    def __call__(self, solver, _it):
+        self.results.append(self.cmp(self.ref, solversolution(solver).to_host()))

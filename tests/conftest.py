@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rls():
+    """the product package; GPU tests go through its ctypes binding of the C ABI"""
+    import rls_amd
+
+    return rls_amd
+
+
+@pytest.fixture(scope="session")
+def ctx(rls):
+    return rls.default_context(0)

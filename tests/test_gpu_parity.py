@@ -1,0 +1,472 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Tolerances: 1e-5 relative l2 on iterates (BASELINE.json north_star, Float32); elementwise
+kernels 2e-6; reductions 1e-6.  Run on the GPU box with `pytest -m gpu`."""
+import math
+
+import numpy as np
+import pytest
+
+import rls_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_ITER = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    d = np.linalg.norm(a.astype(np.complex128) - b.astype(np.complex128))
+    n = np.linalg.norm(b.astype(np.complex128))
+    return d / n if n > 0 else d
+
+
+def rnd(rng, n, dt):
+    v = rng.standard_normal(n)
+    if np.dtype(dt).kind == "c":
+        v = (v + 1j * rng.standard_normal(n)) / math.sqrt(2)
+    return v.astype(dt)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMV
+# ---------------------------------------------------------------------------------------------
+SHAPES = [(256, 128), (4096, 2048), (1000, 333), (37, 5), (1, 1), (64, 4097), (8192, 96), (130, 2050)]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemv_all_ops(rls, ctx, dt, shape):
+    M, N = shape
+    rng = np.random.default_rng(M * 7919 + N)
+    A = rnd(rng, M * N, dt).reshape(M, N)
+    xN, xM = rnd(rng, N, dt), rnd(rng, M, dt)
+    Ad = rls.DeviceMatrix.from_host(A)
+    A64 = A.astype(np.complex128)
+    # y = A x
+    y = rls.DeviceVector(M, dt)
+    Ad.gemv_(0, rls.DeviceVector.from_host(xN), y)
+    assert rel(y.to_host(), A64 @ xN) < 2e-6
+    # y = A^T x and y = A^H x
+    for op, ref in ((1, A64.T @ xM), (2, A64.conj().T @ xM)):
+        z = rls.DeviceVector(N, dt)
+        Ad.gemv_(op, rls.DeviceVector.from_host(xM), z)
+        assert rel(z.to_host(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_gemv_alpha_beta_and_lda(rls, ctx, dt):
+    """5-arg mul! with a padded leading dimension that breaks 16-byte column alignment"""
+    rng = np.random.default_rng(5)
+    M, N, lda = 100, 37, 101
+    A = rnd(rng, M * N, dt).reshape(M, N)
+    Ad = rls.DeviceMatrix(M, N, dt, lda=lda)
+    buf = np.zeros((lda, N), dtype=dt, order="F")
+    buf[:M] = A
+    import ctypes as C
+    rls._lib.check(ctx.handle, ctx.lib.rls_memcpy_h2d(ctx.handle, Ad.ptr, buf.ctypes.data, buf.nbytes), "h2d")
+    alpha, beta = (0.7 - 0.2j, -1.3 + 0.5j) if np.dtype(dt).kind == "c" else (0.7, -1.3)
+    x, y0 = rnd(rng, N, dt), rnd(rng, M, dt)
+    y = rls.DeviceVector.from_host(y0)
+    Ad.gemv_(0, rls.DeviceVector.from_host(x), y, alpha, beta)
+    assert rel(y.to_host(), alpha * (A.astype(np.complex128) @ x) + beta * y0) < 2e-6
+    xm, z0 = rnd(rng, M, dt), rnd(rng, N, dt)
+    z = rls.DeviceVector.from_host(z0)
+    Ad.gemv_(2, rls.DeviceVector.from_host(xm), z, alpha, beta)
+    assert rel(z.to_host(), alpha * (A.astype(np.complex128).conj().T @ xm) + beta * z0) < 2e-6
+
+
+def test_gemv_beta_zero_ignores_nan(rls, ctx):
+    """BLAS semantics: beta == 0 must not read y"""
+    rng = np.random.default_rng(6)
+    A = rnd(rng, 64 * 32, np.float32).reshape(64, 32)
+    x = rnd(rng, 32, np.float32)
+    y = rls.DeviceVector.from_host(np.full(64, np.nan, np.float32))
+    rls.DeviceMatrix.from_host(A).gemv_(0, rls.DeviceVector.from_host(x), y)
+    assert np.all(np.isfinite(y.to_host()))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_gemv_is_deterministic(rls, ctx, dt):
+    rng = np.random.default_rng(8)
+    A = rls.DeviceMatrix.from_host(rnd(rng, 2048 * 1024, dt).reshape(2048, 1024))
+    x = rls.DeviceVector.from_host(rnd(rng, 1024, dt))
+    t = rls.DeviceVector.from_host(rnd(rng, 2048, dt))
+    y1, y2 = rls.DeviceVector(2048, dt), rls.DeviceVector(2048, dt)
+    z1, z2 = rls.DeviceVector(1024, dt), rls.DeviceVector(1024, dt)
+    A.gemv_(0, x, y1), A.gemv_(0, x, y2), A.gemv_(2, t, z1), A.gemv_(2, t, z2)
+    assert np.array_equal(y1.to_host(), y2.to_host()) and np.array_equal(z1.to_host(), z2.to_host())
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_gemv_tuning_variants_agree(rls, ctx, dt):
+    """every kernel variant the heuristics can pick gives the same answer to rounding"""
+    rng = np.random.default_rng(9)
+    M, N = 1024, 768
+    A = rnd(rng, M * N, dt).reshape(M, N)
+    Ad = rls.DeviceMatrix.from_host(A)
+    x, t = rnd(rng, N, dt), rnd(rng, M, dt)
+    xd, td = rls.DeviceVector.from_host(x), rls.DeviceVector.from_host(t)
+    refn, refc = A.astype(np.complex128) @ x, A.astype(np.complex128).conj().T @ t
+    try:
+        for g in (8, 16, 32, 64):
+            for w in (4, 8, 16):
+                ctx.tune(gemvn_g=g, gemvn_waves=w)
+                y = rls.DeviceVector(M, dt)
+                Ad.gemv_(0, xd, y)
+                assert rel(y.to_host(), refn) < 2e-6, (g, w)
+        for c in (1, 2, 4, 8):
+            ctx.tune(gemvt_cols=c)
+            z = rls.DeviceVector(N, dt)
+            Ad.gemv_(2, td, z)
+            assert rel(z.to_host(), refc) < 2e-6, c
+    finally:
+        ctx.tune(gemvn_g=0, gemvn_waves=0, gemvt_cols=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# BLAS-1
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("n", [1, 63, 2048, 100_003])
+def test_blas1(rls, ctx, dt, n):
+    rng = np.random.default_rng(n)
+    x, y = rnd(rng, n, dt), rnd(rng, n, dt)
+    xd, yd = rls.DeviceVector.from_host(x), rls.DeviceVector.from_host(y)
+    x64, y64 = x.astype(np.complex128), y.astype(np.complex128)
+    assert abs(xd.norm() - np.linalg.norm(x64)) <= 1e-6 * np.linalg.norm(x64)
+    assert abs(xd.norm1() - np.sum(np.abs(x64))) <= 1e-6 * np.sum(np.abs(x64))
+    d = xd.dot(yd)
+    assert abs(d - np.vdot(x64, y64)) <= 1e-6 * np.linalg.norm(x64) * np.linalg.norm(y64)
+    a = (0.3 - 1.1j) if np.dtype(dt).kind == "c" else 0.3
+    b = (-0.4 + 0.2j) if np.dtype(dt).kind == "c" else -0.4
+    assert rel(yd.copy().axpy_(a, xd).to_host(), y64 + a * x64) < 2e-7 * 4
+    assert rel(yd.copy().axpby_(a, xd, b).to_host(), a * x64 + b * y64) < 2e-7 * 4
+    assert rel(xd.copy().rmul_(a).to_host(), a * x64) < 2e-7 * 4
+    z = rls.DeviceVector(n, dt).lincomb_(a, xd, b, yd)
+    assert rel(z.to_host(), a * x64 + b * y64) < 2e-7 * 4
+    assert np.array_equal(rls.DeviceVector(n, dt).fill_(2.5).to_host(), np.full(n, 2.5, dt))
+
+
+def test_empty_vectors(rls, ctx):
+    v = rls.DeviceVector(0, np.float32)
+    assert v.norm() == 0.0 and v.to_host().size == 0
+    v.fill_(1.0), v.rmul_(2.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# prox maps
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_prox_l1_l2_positive_real(rls, ctx, dt):
+    rng = np.random.default_rng(11)
+    n = 5000
+    x = rnd(rng, n, dt)
+    x[:7] = 0  # exact zeros
+    x[7:14] *= 1e-3  # |x| < lambda
+    lam = 0.35
+    for Reg, ofn in ((rls.L1Regularization, O.prox_l1), (rls.L2Regularization, O.prox_l2)):
+        got = rls.prox_(Reg, rls.DeviceVector.from_host(x), lam).to_host()
+        want = ofn(x.copy(), lam)
+        assert rel(got, want) < 2e-6, Reg.__name__
+        got2 = rls.prox_(Reg(lam), rls.DeviceVector.from_host(x)).to_host()  # instance form uses lambda(reg)
+        assert np.array_equal(got, got2)
+    assert np.array_equal(rls.prox_(rls.PositiveRegularization, rls.DeviceVector.from_host(x)).to_host(),
+                          O.prox_positive(x.copy()))
+    assert np.array_equal(rls.prox_(rls.RealRegularization, rls.DeviceVector.from_host(x)).to_host(),
+                          O.prox_real(x.copy()))
+
+
+def test_prox_l2_closed_form(rls, ctx):
+    """reference known answer: x / (1 + 2 lambda)   (test/testProxMaps.jl:13)"""
+    x = np.zeros(256, np.float32)
+    x[[3, 77, 200]] = [0.2, 0.9, 0.5]
+    got = rls.prox_(rls.L2Regularization, rls.DeviceVector.from_host(x), 0.01).to_host()
+    assert rel(got, x / (1 + 2 * 0.01)) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("n,slices", [(2048, 8), (1000, 7), (64, 64), (10, 3)])
+def test_prox_l21(rls, ctx, dt, n, slices):
+    rng = np.random.default_rng(n + slices)
+    x = rnd(rng, n, dt)
+    slen = n // slices
+    x[0::slen] = 0  # one all-zero group: (0 - lam)/0 = -Inf -> clipped to 0
+    lam = 0.8
+    got = rls.prox_(rls.L21Regularization, rls.DeviceVector.from_host(x), lam, slices=slices).to_host()
+    want = O.prox_l21(x.copy(), lam, slices)
+    assert rel(got, want) < 2e-6
+    nrm = rls.norm(rls.L21Regularization(lam, slices=slices), rls.DeviceVector.from_host(x))
+    assert abs(nrm - O.norm_l21(x, lam, slices)) <= 2e-6 * abs(O.norm_l21(x, lam, slices))
+
+
+def test_prox_l21_zero_group_lambda_zero_is_nan(rls, ctx):
+    """0/0 = NaN propagates through max as in Julia (hard part 5)"""
+    x = np.ones(8, np.float32)
+    x[0::4] = 0
+    got = rls.prox_(rls.L21Regularization, rls.DeviceVector.from_host(x), 0.0, slices=2).to_host()
+    assert np.isnan(got[0]) and np.isnan(got[4]) and np.all(got[[1, 2, 3, 5, 6, 7]] == 1.0)
+
+
+TV_CASES = [((16, 16), None), ((64, 64), None), ((8, 8), (1,)), ((8, 8), (2,)), ((5, 4, 3), None), ((300,), None),
+            ((7, 9), (2, 1)), ((256, 256), None)]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("shape,dims", TV_CASES)
+def test_tv_gradient_and_prox(rls, ctx, dt, shape, dims):
+    rng = np.random.default_rng(int(np.prod(shape)))
+    n = int(np.prod(shape))
+    x = rnd(rng, n, dt)
+    d0 = O._as_dims(shape, dims)
+    G = rls.GradientOp(shape, dims)
+    assert G.n_out == O.grad_len(shape, d0)
+    xd = rls.DeviceVector.from_host(x)
+    g = G.mul(xd)
+    assert rel(g.to_host(), O.grad_apply(x, shape, d0)) < 1e-6
+    gv = rnd(rng, G.n_out, dt)
+    back = rls.DeviceVector(n, dt)
+    G.mul_adj_(back, rls.DeviceVector.from_host(gv))
+    assert rel(back.to_host(), O.grad_apply_t(gv, shape, d0)) < 1e-6
+    lam = 0.3
+    got = rls.prox_(rls.TVRegularization, rls.DeviceVector.from_host(x), lam, shape=shape, dims=dims).to_host()
+    want = O.prox_tv_fgp(x.copy(), lam, shape, dims, 10)
+    assert rel(got, want) < 1e-5
+
+
+def test_tv_pieces_match_fused(rls, ctx):
+    """the separately exported FGP pieces (the methods the Julia ext overloads one by one) compose
+    to the fused kernel's result"""
+    rng = np.random.default_rng(3)
+    shape, lam = (12, 10), 0.25
+    x = rnd(rng, 120, np.float32)
+    fused = rls.prox_(rls.TVRegularization, rls.DeviceVector.from_host(x), lam, shape=shape).to_host()
+    import ctypes as C
+    G = rls.GradientOp(shape)
+    lib, h = ctx.lib, ctx.handle
+    xd = rls.DeviceVector.from_host(x)
+    xt = rls.DeviceVector(120, np.float32)
+    pq, rs, pqo = (rls.DeviceVector(G.n_out, np.float32).fill_(0) for _ in range(3))
+    t = np.float32(1)
+    for _ in range(10):
+        pqt, pqo, pq = pqo, pq, rs
+        xt.copy_from(xd)
+        G.mul_adj_(xt, rs, -lam, 1.0)
+        G.mul_(pq, xt, 1.0 / (8 * lam), 1.0)
+        rls._lib.check(h, lib.rls_tv_restrict(h, 0, G.n_out, pq.ptr), "restrict")
+        told = t
+        t = (np.float32(1) + np.sqrt(np.float32(1) + np.float32(4) * told * told)) / np.float32(2)
+        t2 = (told - 1) / t
+        rs = pqt
+        rls._lib.check(h, lib.rls_tv_lincomb(h, 0, G.n_out, rs.ptr, float(1 + t2), pq.ptr, float(t2), pqo.ptr), "lincomb")
+    G.mul_adj_(xd, pq, -lam, 1.0)
+    assert rel(xd.to_host(), fused) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# solvers
+# ---------------------------------------------------------------------------------------------
+def _cgnr_pair(rls, M, N, dt, seed, lam, iters, mode="matrixfree"):
+    A, xt, b = O.make_problem(M, N, dt, seed)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    reg = O.L2Regularization(lam)
+    ref = O.CGNR(A.astype(dt64), reg=reg, iterations=iters, relTol=0.0, normal=mode)
+    Ad = rls.DeviceMatrix.from_host(A)
+    kw = dict(AHA=Ad.gram()) if mode == "gram" else {}
+    sol = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), iterations=iters, relTol=0.0, **kw)
+    return ref, sol, b, dt64
+
+
+@pytest.mark.parametrize("dt,M,N,lam", [(np.float32, 256, 128, 1e-2), (np.complex64, 64, 32, 0.0),
+                                       (np.complex64, 4096, 2048, 0.0), (np.float32, 1000, 300, 0.5)])
+def test_cgnr_iterates_match_oracle(rls, ctx, dt, M, N, lam):
+    """per-iteration x, r, p and alpha, beta against the float64 oracle (SURVEY 8d parity gate)"""
+    iters = 32 if M >= 1000 else 10
+    ref, sol, b, dt64 = _cgnr_pair(rls, M, N, dt, 1, lam, iters)
+    ref.init(b.astype(dt64))
+    rls.init_(sol, rls.DeviceVector.from_host(b))
+    checks = {1, 5, 10, 32}
+    for it in range(1, iters + 1):
+        assert ref.iterate() is not None
+        assert rls.iterate(sol) is not None
+        if it in checks:
+            st = sol.state
+            assert rel(st.x.to_host(), ref.x) < TOL_ITER, it
+            assert rel(st.pl.to_host(), ref.p) < TOL_ITER * 10, it
+            assert np.linalg.norm(st.x0.to_host() - ref.r) < TOL_ITER * np.linalg.norm(ref.A.mul_adj(b.astype(dt64))), it
+            st._refresh(ctx.lib)
+            assert abs(st.alphal - ref.alpha) < 1e-5 * abs(ref.alpha)
+            assert abs(st.betal - ref.beta) < 1e-4 * abs(ref.beta)
+    assert rls.iterate(sol) is None and ref.iterate() is None
+    assert sol.state.iteration == iters
+
+
+def test_cgnr_gram_mode_and_float32_oracle(rls, ctx):
+    ref, sol, b, dt64 = _cgnr_pair(rls, 512, 256, np.complex64, 3, 1e-3, 10, mode="gram")
+    O.solve(ref, b.astype(dt64))
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert rel(x, ref.x) < TOL_ITER
+    A, _, _ = O.make_problem(512, 256, np.complex64, 3)
+    ref32 = O.CGNR(A, reg=O.L2Regularization(1e-3), iterations=10, relTol=0.0)
+    O.solve(ref32, b)
+    assert rel(x, ref32.x) < TOL_ITER
+
+
+def test_cgnr_callbacks_cadence_and_lstsq(rls, ctx):
+    """reference known answers: callbacks fire iterations+1 times and solutions[end] == x_approx
+    (test/testCallbacks.jl:6-16); CGNR converges to the least-squares solution."""
+    A, xt, b = O.make_problem(32, 32, np.float32, 4)
+    Ad = rls.DeviceMatrix.from_host(A)
+    sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=10, relTol=0.0)
+    cb = rls.StoreSolutionCallback()
+    count = []
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b), callbacks=[cb, lambda s, i: count.append(i)])
+    assert len(cb.solutions) == 11 and count == list(range(11))
+    assert np.array_equal(cb.solutions[-1], x.to_host())
+    A2, x2, b2 = O.make_problem(256, 128, np.float32, 5)
+    sol2 = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A2), iterations=128, relTol=0.0)
+    xs = rls.solve_(sol2, rls.DeviceVector.from_host(b2)).to_host()
+    xl = np.linalg.lstsq(A2.astype(np.float64), b2.astype(np.float64), rcond=None)[0]
+    assert rel(xs, xl) < 1e-4
+
+
+def test_cgnr_reltol_stops_early_and_constraints(rls, ctx):
+    A, xt, b = O.make_problem(128, 64, np.complex64, 6)
+    ref = O.CGNR(A, reg=[O.PositiveRegularization()], iterations=64, relTol=1e-3)
+    O.solve(ref, b)
+    sol = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A), reg=[rls.PositiveRegularization()],
+                                 iterations=64, relTol=1e-3)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert sol.state.iteration == ref.iteration < 64
+    assert rel(x, ref.x) < 1e-5 and np.all(x.imag == 0) and np.all(x.real >= 0)
+
+
+def test_create_linear_solver_filters_unknown_kwargs(rls, ctx):
+    A, _, _ = O.make_problem(16, 8, np.float32, 1)
+    with pytest.warns(UserWarning, match="filtered out"):
+        rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A), iterations=3, shape=(2, 4))
+    with pytest.raises(ValueError, match="additional regularization"):
+        rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.1))
+
+
+@pytest.mark.parametrize("restart", ["none", "gradient"])
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 64, 32), (np.complex64, 4096, 2048), (np.float32, 300, 120)])
+def test_fista_l1_matches_oracle(rls, ctx, dt, M, N, restart):
+    A, xt, b = O.make_problem(M, N, dt, 2)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    A64, b64 = A.astype(dt64), b.astype(dt64)
+    smax = np.linalg.norm(A64, 2)
+    rho = 0.95 / smax ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    iters = 50
+    ref = O.FISTA(A64, reg=O.L1Regularization(lam), rho=rho, iterations=iters, restart=restart)
+    O.solve(ref, b64)
+    sol = rls.createLinearSolver(rls.FISTA, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(lam), rho=rho,
+                                 iterations=iters, restart=restart)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert sol.state.iteration == iters
+    assert rel(x, ref.x) < TOL_ITER
+    assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
+
+
+def test_fista_step_by_step_equals_batched_and_proj(rls, ctx):
+    A, xt, b = O.make_problem(200, 80, np.complex64, 9)
+    smax = np.linalg.norm(A.astype(np.complex128), 2)
+    kw = dict(reg=[rls.L1Regularization(0.05), rls.PositiveRegularization()], rho=0.9 / smax ** 2, iterations=20)
+    Ad = rls.DeviceMatrix.from_host(A)
+    s1 = rls.createLinearSolver(rls.FISTA, Ad, **kw)
+    x1 = rls.solve_(s1, rls.DeviceVector.from_host(b)).to_host()
+    s2 = rls.createLinearSolver(rls.FISTA, Ad, **kw)
+    seen = []
+    x2 = rls.solve_(s2, rls.DeviceVector.from_host(b), callbacks=lambda s, i: seen.append(i)).to_host()
+    assert seen == list(range(21)) and np.array_equal(x1, x2)
+    ref = O.FISTA(A, reg=[O.L1Regularization(0.05), O.PositiveRegularization()], rho=0.9 / smax ** 2, iterations=20)
+    O.solve(ref, b)
+    assert rel(x1, ref.x) < TOL_ITER and np.all(x1.imag == 0) and np.all(x1.real >= 0)
+
+
+@pytest.mark.parametrize("regname", ["l21", "l2", "tv"])
+def test_fista_other_regs(rls, ctx, regname):
+    A, xt, b = O.make_problem(160, 64, np.float32, 12)
+    smax = np.linalg.norm(A.astype(np.float64), 2)
+    rho = 0.9 / smax ** 2
+    if regname == "l21":
+        r_o, r_d = O.L21Regularization(2.0, slices=4), rls.L21Regularization(2.0, slices=4)
+    elif regname == "l2":
+        r_o, r_d = O.L2Regularization(0.5), rls.L2Regularization(0.5)
+    else:
+        r_o, r_d = O.TVRegularization(2.0, shape=(8, 8)), rls.TVRegularization(2.0, shape=(8, 8))
+    ref = O.FISTA(A, reg=r_o, rho=rho, iterations=15)
+    O.solve(ref, b)
+    sol = rls.createLinearSolver(rls.FISTA, rls.DeviceMatrix.from_host(A), reg=r_d, rho=rho, iterations=15)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert rel(x, ref.x) < 2e-5
+
+
+@pytest.mark.parametrize("dt,M,N,shape", [(np.float32, 128, 64, (8, 8)), (np.float32, 8192, 4096, (64, 64)),
+                                         (np.complex64, 96, 36, (6, 6))])
+def test_admm_tv_matches_oracle(rls, ctx, dt, M, N, shape):
+    A, xt, b = O.make_problem(M, N, dt, 3)
+    kw = dict(rho=0.1, iterations=10, iterationsCG=10, tolInner=1e-5)
+    ref = O.ADMM(A, reg=O.TVRegularization(1e-2, shape=shape), **kw)
+    O.solve(ref, b)
+    sol = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.TVRegularization(1e-2, shape=shape), **kw)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert sol.state.iteration == ref.iteration
+    assert sol.state.cg_iterations == ref.cg_iters
+    assert rel(x, ref.x) < 2e-5
+    assert np.allclose(sol.state.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(sol.state.sk, ref.sk, rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("vary", ["none", "balance", "PnP"])
+def test_admm_l1_vary_rho_and_gradient_trafo(rls, ctx, vary):
+    A, xt, b = O.make_problem(100, 48, np.float32, 21)
+    kw = dict(rho=0.5, iterations=8, vary_rho=vary)
+    ref = O.ADMM(A, reg=O.L1Regularization(0.05), **kw)
+    O.solve(ref, b)
+    sol = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05), **kw)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert rel(x, ref.x) < 5e-5 and np.allclose(sol.state.rho, ref.rho)
+    # TV as L1-of-gradient (src/ADMM.jl:74): regTrafo = GradientOp
+    ref2 = O.ADMM(A, reg=O.L1Regularization(0.05), regTrafo=O.GradientTrafo((8, 6)), rho=0.5, iterations=5)
+    O.solve(ref2, b)
+    sol2 = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05),
+                                  regTrafo=rls.GradientOp((8, 6)), rho=0.5, iterations=5)
+    x2 = rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host()
+    assert rel(x2, ref2.x) < 5e-5
+
+
+@pytest.mark.parametrize("scheduler", ["SequentialState", "MultiThreadingState"])
+def test_matrix_rhs_equals_column_solves(rls, ctx, scheduler):
+    """reference property: matrix solve == column-by-column solves, and a vector solve still works
+    afterwards (test/testMultiThreading.jl:10-18)"""
+    A, X, B = O.make_problem(96, 48, np.complex64, 7, n_rhs=4)
+    Ad = rls.DeviceMatrix.from_host(A)
+    S = rls.createLinearSolver(rls.CGNR, Ad, iterations=48)
+    cols = [rls.solve_(S, rls.DeviceVector.from_host(B[:, j])).to_host() for j in range(4)]
+    xs = rls.solve_(S, rls.DeviceMatrix.from_host(B), scheduler=getattr(rls, scheduler))
+    for j in range(4):
+        assert np.array_equal(xs[j].to_host(), cols[j])
+        assert rel(cols[j], X[:, j]) < 1e-3
+    again = rls.solve_(S, rls.DeviceVector.from_host(B[:, 0])).to_host()
+    assert np.array_equal(again, cols[0])
+
+
+def test_power_iterations(rls, ctx):
+    A, _, _ = O.make_problem(300, 100, np.complex64, 31)
+    rng = np.random.default_rng(0)
+    v0 = rnd(rng, 100, np.complex64)
+    want = O.power_iterations(O.NormalOp(O.DenseOp(A)), v0)
+    got = rls.power_iterations(rls.DeviceMatrix.from_host(A).normal_operator(), rls.DeviceVector.from_host(v0))
+    assert abs(got - want) < 1e-4 * want
+
+
+def test_errors_are_loud(rls, ctx):
+    A, _, b = O.make_problem(16, 8, np.float32, 1)
+    Ad = rls.DeviceMatrix.from_host(A)
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        rls.solve_(rls.CGNR(Ad), rls.DeviceVector.from_host(b[:5]))
+    with pytest.raises(TypeError):
+        rls.DeviceVector.from_host(np.zeros(4, np.float64))
+    with pytest.raises(rls.RLSError):
+        rls.prox_(rls.L21Regularization, rls.DeviceVector.from_host(np.ones(4, np.float32)), 0.1, slices=9)
