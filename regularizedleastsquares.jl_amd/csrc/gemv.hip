@@ -14,33 +14,6 @@
 //      wave shuffles and one LDS pass, so no cross-workgroup reduction (and no atomics) is needed.
 #include "rls_common.hpp"
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-template <typename E, int NV>
-struct chunk {
-  E e[NV];
-};
-
-template <typename E, int NV>
-__device__ static inline chunk<E, NV> load_chunk(const E* p) {
-  chunk<E, NV> c;
-  if constexpr (NV * sizeof(E) == 16) {
-    f4 v = *reinterpret_cast<const f4*>(p);
-    c = __builtin_bit_cast(chunk<E, NV>, v);
-  } else {
-    static_assert(NV == 1, "scalar chunk");
-    c.e[0] = *p;
-  }
-  return c;
-}
-template <typename E, int NV>
-__device__ static inline chunk<E, NV> zero_chunk() {
-  chunk<E, NV> c;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) c.e[i] = elem<E>::zero();
-  return c;
-}
-
 // ---------------------------------------------------------------------------------------------
 // gemv_t
 // ---------------------------------------------------------------------------------------------
@@ -58,14 +31,44 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const E* __restrict_
 #pragma unroll
   for (int c = 0; c < COLS; ++c) acc[c] = elem<E>::zero();
 
-  for (int64_t base = 0; base < Mc; base += (int64_t)THREADS * U) {
+  // Loads must never sit under a branch: hipcc then waits vmcnt(0) after each one and a wave has a
+  // single 16-byte load in flight.  Full tiles run unpredicated; the ragged tail clamps its
+  // addresses (always-valid loads) and zeroes the dead lanes with selects.
+  const int64_t span = (int64_t)THREADS * U;
+  const int64_t full = (Mc / span) * span;
+  for (int64_t base = 0; base < full; base += span) {
     chunk<E, NV> xr[U];
-    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xr[u] = load_chunk<E, NV>(x + (base + (int64_t)u * THREADS + tid) * NV);
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+      const int64_t j = (j0 + c < N) ? (j0 + c) : (N - 1);
+      const E* col = A + j * lda + (base + tid) * NV;
+      chunk<E, NV> a[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] = load_chunk<E, NV>(col + (int64_t)u * THREADS * NV);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          if constexpr (CONJ)
+            acc[c] = elem<E>::fmac(a[u].e[i], xr[u].e[i], acc[c]);
+          else
+            acc[c] = elem<E>::fma(a[u].e[i], xr[u].e[i], acc[c]);
+        }
+      }
+    }
+  }
+  if (full < Mc) {
+    chunk<E, NV> xr[U];
+    int64_t idc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t idx = base + (int64_t)u * THREADS + tid;
-      ok[u] = idx < Mc;
-      xr[u] = ok[u] ? load_chunk<E, NV>(x + idx * NV) : zero_chunk<E, NV>();
+      const int64_t idx = full + (int64_t)u * THREADS + tid;
+      const bool ok = idx < Mc;
+      idc[u] = ok ? idx : (Mc - 1);
+      xr[u] = load_chunk<E, NV>(x + idc[u] * NV);
+      if (!ok) xr[u] = zero_chunk<E, NV>();
     }
 #pragma unroll
     for (int c = 0; c < COLS; ++c) {
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const E* __restrict_
       chunk<E, NV> a[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int64_t idx = base + (int64_t)u * THREADS + tid;
-        a[u] = ok[u] ? load_chunk<E, NV>(col + idx * NV) : zero_chunk<E, NV>();
+        a[u] = load_chunk<E, NV>(col + idc[u] * NV);
+        if (full + (int64_t)u * THREADS + tid >= Mc) a[u] = zero_chunk<E, NV>();
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -148,23 +151,40 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_n_kernel(const E* __restrict_
     __syncthreads();
     for (int i = tid; i < nt; i += THREADS) xs[i] = x[t0 + i];
     __syncthreads();
-    const int rounds = (nt + CPR - 1) / CPR;
+    // full rounds (every slot of every wave has a valid column) run unpredicated, U loads in
+    // flight per lane; the remainder clamps the column and zeroes x instead of branching
     const E* At = Ab + t0 * lda;
-    for (int k = 0; k < rounds; k += U) {
+    const int slot = w * S + s;
+    const int full_rounds = nt / CPR;
+    const int main_rounds = (full_rounds / U) * U;
+    for (int k = 0; k < main_rounds; k += U) {
       chunk<E, NV> a[U];
       E xv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int jl = (k + u) * CPR + w * S + s;
-        const bool ok = jl < nt;
-        a[u] = ok ? load_chunk<E, NV>(At + (int64_t)jl * lda) : zero_chunk<E, NV>();
-        xv[u] = ok ? xs[jl] : elem<E>::zero();
+        const int jl = (k + u) * CPR + slot;
+        a[u] = load_chunk<E, NV>(At + (int64_t)jl * lda);
+        xv[u] = xs[jl];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[u].e[i], xv[u], acc[i]);
       }
+    }
+    const int rounds = (nt + CPR - 1) / CPR;
+    for (int k = main_rounds; k < rounds; ++k) {
+      const int jl = k * CPR + slot;
+      const bool ok = jl < nt;
+      const int jc = ok ? jl : (nt - 1);
+      chunk<E, NV> a = load_chunk<E, NV>(At + (int64_t)jc * lda);
+      E xv = xs[jc];
+      if (!ok) {
+        xv = elem<E>::zero();
+        a = zero_chunk<E, NV>();
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a.e[i], xv, acc[i]);
     }
   }
 

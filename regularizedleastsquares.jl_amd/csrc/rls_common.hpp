@@ -18,6 +18,7 @@ struct rls_tuning {
   int graph_chunk = 16; // iterations captured per hipGraph
   int use_graph = 1;
   int fuse_level = 1;   // 0: separate BLAS-1 style update kernel; 1: fused update
+  int fused_normal = 1; // 1: one-pass register-slab normal operator when the shape allows it
 };
 
 struct rls_ctx {
@@ -158,6 +159,35 @@ __device__ static inline double block_sum(double v, double* smem) {
   for (int i = 0; i < nw; ++i) s += smem[i];
   return s;
 }
+
+// 16-byte (or element-sized) register chunks of a matrix column
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename E, int NV>
+struct chunk {
+  E e[NV];
+};
+
+template <typename E, int NV>
+__device__ static inline chunk<E, NV> load_chunk(const E* p) {
+  chunk<E, NV> c;
+  if constexpr (NV * sizeof(E) == 16) {
+    f4 v = *reinterpret_cast<const f4*>(p);
+    c = __builtin_bit_cast(chunk<E, NV>, v);
+  } else {
+    static_assert(NV == 1, "scalar chunk");
+    c.e[0] = *p;
+  }
+  return c;
+}
+template <typename E, int NV>
+__device__ static inline chunk<E, NV> zero_chunk() {
+  chunk<E, NV> c;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) c.e[i] = elem<E>::zero();
+  return c;
+}
+
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------------------------------------
@@ -166,3 +196,9 @@ __device__ static inline double block_sum(double v, double* smem) {
 // gemv.hip.  `skip` (nullable) is a device int: when non-zero at kernel entry the kernel is a no-op
 int32_t rls_launch_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int64_t N, float ar, float ai,
                         const void* A, int64_t lda, const void* x, float br, float bi, void* y, const int* skip);
+// normal.hip: v = A^H A p in ONE pass over A (slab of A held in registers between the two products).
+// Returns the slab workspace size in bytes (0 = shape not supported by the fused kernel).
+void rls_normal_force_group(int g);
+size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
+int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,
+                                const void* p, void* v, void* slab, const int* skip);

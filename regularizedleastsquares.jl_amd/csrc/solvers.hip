@@ -22,12 +22,15 @@ struct rls_operator {
   const void* G;  // Gram matrix (N x N) or null
   int64_t ldg;
   void* t;        // length-M scratch for the matrix-free normal operator
+  void* slab;     // per-workgroup partial-v slab of the fused one-pass normal operator (or null)
 };
 
 static int32_t op_normal(rls_operator* op, const void* p, void* v, const int* skip) {
   rls_ctx* ctx = op->ctx;
   if (op->G) return rls_launch_gemv(ctx, op->dtype, RLS_OP_N, op->N, op->N, 1.f, 0.f, op->G, op->ldg, p, 0.f, 0.f, v, skip);
   if (!op->A) return rls_fail(ctx, RLS_E_STATE, "operator has neither A nor a Gram matrix");
+  if (op->slab && ctx->tune.fused_normal)
+    return rls_launch_normal_fused(ctx, op->dtype, op->M, op->N, op->A, op->lda, p, v, op->slab, skip);
   RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_N, op->M, op->N, 1.f, 0.f, op->A, op->lda, p, 0.f, 0.f, op->t, skip));
   return rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, op->t, 0.f, 0.f, v, skip);
 }
@@ -576,9 +579,13 @@ int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, c
   op->G = nullptr;
   op->ldg = 0;
   op->t = nullptr;
+  op->slab = nullptr;
   if (A) {
     hipError_t e = hipMalloc(&op->t, (size_t)M * rls_elem_size(dtype));
+    const size_t ws = rls_normal_fused_workspace(dtype, M, N, A, lda);
+    if (e == hipSuccess && ws > 0) e = hipMalloc(&op->slab, ws);
     if (e != hipSuccess) {
+      if (op->t) hipFree(op->t);
       delete op;
       return rls_fail(ctx, (int32_t)e, "operator_create: hipMalloc failed");
     }
@@ -597,6 +604,7 @@ int32_t rls_operator_set_gram(rls_operator* op, const void* AHA, int64_t ld) {
 
 int32_t rls_operator_destroy(rls_operator* op) {
   if (!op) return RLS_E_INVALID;
+  if (op->slab) hipFree(op->slab);
   if (op->t) hipFree(op->t);  // hipFree resolves the owning device from the pointer
   delete op;
   return 0;

@@ -124,6 +124,37 @@ def test_gemv_tuning_variants_agree(rls, ctx, dt):
         ctx.tune(gemvn_g=0, gemvn_waves=0, gemvt_cols=0)
 
 
+NORMAL_SHAPES = [(4096, 2048), (256, 128), (1000, 300), (8192, 4096), (64, 700), (2048, 1025), (12, 3)]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("shape", NORMAL_SHAPES)
+def test_normal_operator_one_pass_vs_two_pass(rls, ctx, dt, shape):
+    """mul!(v, AHA, p): the one-pass register-slab kernel, the two-GEMV path and float64 agree"""
+    M, N = shape
+    rng = np.random.default_rng(M + 3 * N)
+    A = rnd(rng, M * N, dt).reshape(M, N)
+    p = rnd(rng, N, dt)
+    Ad = rls.DeviceMatrix.from_host(A)
+    op = Ad.normal_operator()
+    pd = rls.DeviceVector.from_host(p)
+    A64 = A.astype(np.complex128)
+    want = A64.conj().T @ (A64 @ p)
+    out = {}
+    try:
+        for mode in (1, 0):
+            ctx.tune(fused_normal=mode)
+            v = rls.DeviceVector(N, dt).fill_(np.nan)
+            op.mul_(v, pd)
+            out[mode] = v.to_host()
+            assert rel(out[mode], want) < 3e-6, mode
+    finally:
+        ctx.tune(fused_normal=1)
+    v2 = rls.DeviceVector(N, dt)
+    op.mul_(v2, pd)
+    assert np.array_equal(v2.to_host(), out[1])  # deterministic
+
+
 # ---------------------------------------------------------------------------------------------
 # BLAS-1
 # ---------------------------------------------------------------------------------------------
@@ -292,8 +323,10 @@ def test_cgnr_iterates_match_oracle(rls, ctx, dt, M, N, lam):
         if it in checks:
             st = sol.state
             assert rel(st.x.to_host(), ref.x) < TOL_ITER, it
-            assert rel(st.pl.to_host(), ref.p) < TOL_ITER * 10, it
-            assert np.linalg.norm(st.x0.to_host() - ref.r) < TOL_ITER * np.linalg.norm(ref.A.mul_adj(b.astype(dt64))), it
+            # r and p shrink geometrically: compare them on the scale of the initial residual A^H b
+            r0 = np.linalg.norm(ref.A.mul_adj(b.astype(dt64)))
+            assert np.linalg.norm(st.pl.to_host() - ref.p) < TOL_ITER * r0, it
+            assert np.linalg.norm(st.x0.to_host() - ref.r) < TOL_ITER * r0, it
             st._refresh(ctx.lib)
             assert abs(st.alphal - ref.alpha) < 1e-5 * abs(ref.alpha)
             assert abs(st.betal - ref.beta) < 1e-4 * abs(ref.beta)
