@@ -168,6 +168,10 @@ int32_t rls_cgnr_init(rls_cgnr* s, const void* b, float lambda, float rel_tol, i
 /* enqueue n_steps iterations (no-ops once done); asynchronous, graph-replayed */
 int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps);
 int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h); /* synchronises */
+/* measurement harness only: n_steps iterations with hipEvents around each kernel of the fused
+ * pipeline; average device microseconds per launch of the one-pass normal-operator kernel and of
+ * the partial-sum reduce kernel.  RLS_E_UNSUPPORTED when the shape runs on the two-GEMV path. */
+int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, float* us_reduce);
 
 /* ---------------------------------------------------------------------------------------------
  * fused FISTA.   replaces init!/iterate(::FISTA, ::FISTAState) src/FISTA.jl:110-129,139-185.

@@ -94,8 +94,11 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "use_graph")) ctx->tune.use_graph = value;
   else if (!strcmp(key, "fuse_level")) ctx->tune.fuse_level = value;
   else if (!strcmp(key, "fused_normal")) ctx->tune.fused_normal = value;
+  else if (!strcmp(key, "cgnr_pipeline")) ctx->tune.cgnr_pipeline = value;
   else if (!strcmp(key, "slab_g")) {  // process-wide; must be set before the operator is created
     rls_normal_force_group(value);
+  } else if (!strcmp(key, "slab_wv")) {
+    rls_normal_force_waves(value);
   }
   else return rls_fail(ctx, RLS_E_INVALID, "tune_set: unknown key");
   return 0;

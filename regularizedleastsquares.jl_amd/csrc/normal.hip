@@ -13,13 +13,27 @@
 // once + 2 * nwg*N*s for the partials, instead of 2*M*N*s.
 //
 // Lane layout inside a wave: g = lane % G picks the 16-byte row chunk, s = lane / G one of the
-// 64/G column slots; wave w of 16 and load k cover column (k*16 + w)*(64/G) + s.
+// 64/G column slots; wave w of WV and load k cover column (k*WV + w)*(64/G) + s.
 #include "rls_common.hpp"
+
+// Diagnostic build only (-DRLS_STAMPS): wall-clock stamps (100 MHz s_memrealtime) of one workgroup's
+// phases, written to a buffer nothing else reads.  Never compiled into the shipped library.
+#ifdef RLS_STAMPS
+__device__ unsigned long long g_stamps[16 * 8];
+#define STAMP(slot)                                                                         \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && (blockIdx.x % 37) == 5 && blockIdx.x / 37 < 8)                  \
+      g_stamps[(blockIdx.x / 37) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();         \
+  } while (0)
+#else
+#define STAMP(slot) \
+  do {              \
+  } while (0)
+#endif
 
 namespace {
 
-constexpr int NWAVES = 16;
-constexpr int NTHREADS = NWAVES * 64;
+constexpr int FIN_THREADS = 1024;  // the single-workgroup finish kernel
 
 // blocks b and b+8 are observed to share an XCD (speed only, never correctness): with 64-byte
 // row chunks (G = 4) two neighbouring row blocks split every 128-byte line, so give them to
@@ -39,92 +53,447 @@ __device__ static inline float group_sum(float v) {
   return v;
 }
 
-template <typename E, int G, int K>
-__global__ __launch_bounds__(NTHREADS) void normal_slab_kernel(const E* __restrict__ A, int64_t lda,
-                                                               const E* __restrict__ p, E* __restrict__ slab,
-                                                               int64_t Mc, int64_t N, int pair,
-                                                               const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  constexpr int NV = elem<E>::vec;
-  constexpr int S = 64 / G;
-  constexpr int CPR = NWAVES * S;
-  constexpr int NMAX = K * CPR;
-  __shared__ E xs[NMAX];  // p, later this workgroup's partial v
-  __shared__ E part[NWAVES][G][NV];
-  __shared__ E tw[G * NV];
+// ---- the slab core, shared by the plain normal operator and the CGNR pipeline ---------------
+// G lanes per row chunk, K loads per lane, WV waves per workgroup.  WV = 8 gives every lane 256
+// VGPRs (2 waves per SIMD), so a K = 32 slab (128 VGPRs) leaves room for the rest of the kernel;
+// at WV = 16 / K = 16 the same slab sits against a 128-VGPR ceiling and the kernel spills.
+template <typename E, int G, int K, int WV>
+struct slab_cfg {
+  static constexpr int NV = elem<E>::vec;
+  static constexpr int S = 64 / G;
+  static constexpr int NT = WV * 64;
+  static constexpr int CPR = WV * S;
+  static constexpr int NMAX = K * CPR;
+  static constexpr int EPT = NMAX >= NT ? NMAX / NT : 1;  // vector elements per thread
+};
 
+// LDS image of one workgroup (dynamic LDS: > 64 KiB).  xg is the exchange area of the second product:
+// every lane stores its two-row (four-row for real) contribution to a column, one padded plane per
+// row chunk g (pad = 64 B so the G planes start on different banks: 2-way at worst on the store,
+// free; the column sums then read consecutive 8-byte words, conflict-free).
+template <typename E, int G, int K, int WV>
+struct slab_lds {
+  static constexpr int PAD = 64 / (int)sizeof(E);
+  E xg[G][slab_cfg<E, G, K, WV>::NMAX + PAD];
+  E xs[slab_cfg<E, G, K, WV>::NMAX];  // the GEMV input vector
+  E part[WV][G][elem<E>::vec];
+  E tw[G * elem<E>::vec];
+  double red[48];
+};
+
+// Issue every load of the slab before anything waits.  Addresses are a wave-uniform 64-bit base per
+// load (SGPRs) plus ONE 32-bit lane offset shared by all K loads, so the K addresses cost a single
+// VGPR instead of 2K (the slab itself already takes 4K of the 128 available).  Ragged shapes clamp
+// the lane offset per load (always-valid addresses, never a branch); the dead lanes are zeroed in
+// slab_finish.
+template <typename E, int G, int K, int WV, bool FULL>
+__device__ static inline void slab_load(chunk<E, elem<E>::vec> (&a)[K], const E* __restrict__ A, int64_t lda,
+                                        int64_t Mc, int64_t N, int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane % G, slot = w * C::S + lane / G;
+  const int64_t chunk_id = row_block_of(blockIdx.x, pair) * G + g;  // pair only if gridDim.x % 16 == 0
+  const uint32_t row_off = (uint32_t)((chunk_id < Mc ? chunk_id : (Mc - 1)) * 16);
+  const uint32_t col_b = (uint32_t)(lda * (int64_t)sizeof(E));  // host guarantees 128 * col_b < 2^32
+  const char* base = reinterpret_cast<const char*>(A);
+  if constexpr (FULL) {  // N == NMAX and every row chunk valid: no clamps at all
+    const uint32_t off = row_off + (uint32_t)slot * col_b;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const char* bk = base + (int64_t)(k * C::CPR) * (lda * (int64_t)sizeof(E));
+      a[k] = load_chunk<E, C::NV>(reinterpret_cast<const E*>(bk + off));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int last = (int)N - 1 - k * C::CPR;  // last valid slot of this round (may be negative)
+      const int kc = last >= 0 ? k : 0;          // rounds entirely past N re-read round 0 (zeroed later)
+      const int sc = last >= 0 ? (slot < last ? slot : last) : slot;
+      const char* bk = base + (int64_t)(kc * C::CPR) * (lda * (int64_t)sizeof(E));
+      a[k] = load_chunk<E, C::NV>(reinterpret_cast<const E*>(bk + (row_off + (uint32_t)sc * col_b)));
+    }
+  }
+}
+
+// with L.xs holding the input vector (zero beyond N): t_w = A_w xs, partial v = A_w^H t_w -> slab row
+template <typename E, int G, int K, int WV, bool FULL>
+__device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L, E* __restrict__ slab,
+                                          int64_t Mc, int64_t N, int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int g = lane % G, s = lane / G;
-  const int slot = w * S + s;
-  const int64_t rb = row_block_of(blockIdx.x, pair);  // pair only when gridDim.x % 16 == 0 (bijective)
-  const int64_t chunk_id = rb * G + g;
-  const bool row_ok = chunk_id < Mc;
-  const E* Ab = A + (row_ok ? chunk_id : (Mc - 1)) * NV;
-
-  // the slab: every load is issued before anything waits (addresses clamped, never branched)
-  chunk<E, NV> a[K];
+  const int g = lane % G, s = lane / G, slot = w * C::S + s;
+  const bool row_ok = row_block_of(blockIdx.x, pair) * G + g < Mc;
+  if constexpr (!FULL) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int jl = k * CPR + slot;
-    const int jc = jl < N ? jl : (int)(N - 1);
-    a[k] = load_chunk<E, NV>(Ab + (int64_t)jc * lda);
+    for (int k = 0; k < K; ++k) {
+      if (k * C::CPR + slot >= N || !row_ok) a[k] = zero_chunk<E, NV>();
+    }
   }
-  for (int i = tid; i < NMAX; i += NTHREADS) xs[i] = i < N ? p[i] : elem<E>::zero();
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int jl = k * CPR + slot;
-    if (jl >= N || !row_ok) a[k] = zero_chunk<E, NV>();
-  }
-  __syncthreads();
+  __syncthreads();  // xs complete
+  STAMP(4);
 
-  // t_w = A_w p
   E acc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = elem<E>::zero();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const E xv = xs[k * CPR + slot];
+    // bound the scheduler's look-ahead: without this it hoists all K LDS reads (2K more VGPRs on
+    // top of the 4K the slab holds) and spills
+    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+    const E xv = L.xs[k * C::CPR + slot];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[k].e[i], xv, acc[i]);
   }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int off = G; off < 64; off <<= 1) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      float re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
-      float im = elem<E>::cplx ? elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64) : 0.f;
+      float re, im = 0.f;
+      if (off == 8) {  // lanes l and l ^ 8 share a row of 16: row_ror:8 is the same exchange
+        re = elem<E>::re(acc[i]) + dpp_f(elem<E>::re(acc[i]), 0x128);
+        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + dpp_f(elem<E>::im(acc[i]), 0x128);
+      } else {
+        re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
+        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
+      }
       acc[i] = elem<E>::make(re, im);
     }
   }
   if (s == 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) part[w][g][i] = acc[i];
+    for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
   }
   __syncthreads();
   if (tid < G * NV) {
     const int gg = tid / NV, i = tid % NV;
     E sum = elem<E>::zero();
 #pragma unroll
-    for (int ww = 0; ww < NWAVES; ++ww) sum = elem<E>::add(sum, part[ww][gg][i]);
-    tw[tid] = sum;
+    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+    L.tw[tid] = sum;
   }
   __syncthreads();
 
-  // partial v = A_w^H t_w from the same registers
+  STAMP(5);
   E tr[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) tr[i] = tw[g * NV + i];
+  for (int i = 0; i < NV; ++i) tr[i] = L.tw[g * NV + i];
+  // The sum over the G lanes that share a column goes through LDS, not DPP: per column a lane does
+  // one store here and the G-term sum below costs G reads per OUTPUT column, against 2*log2(G)
+  // cross-lane adds per lane per load with shuffles (that phase was VALU-bound at 3 us).
 #pragma unroll
   for (int k = 0; k < K; ++k) {
+    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
     E q = elem<E>::zero();
 #pragma unroll
     for (int i = 0; i < NV; ++i) q = elem<E>::fmac(a[k].e[i], tr[i], q);
-    q = elem<E>::make(group_sum<G>(elem<E>::re(q)), elem<E>::cplx ? group_sum<G>(elem<E>::im(q)) : 0.f);
-    if (g == 0) xs[k * CPR + slot] = q;
+    L.xg[g][k * C::CPR + slot] = q;
   }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  STAMP(6);
   E* out = slab + (int64_t)blockIdx.x * N;
-  for (int i = tid; i < N; i += NTHREADS) out[i] = xs[i];
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) {
+    const int c = tid + e * C::NT;
+    if (c < C::NMAX) {
+      E sum = L.xg[0][c];
+#pragma unroll
+      for (int gg = 1; gg < G; ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
+      if (c < N) out[c] = sum;
+    }
+  }
+}
+
+template <typename E, int G, int K, int WV, bool FULL>
+__global__ __launch_bounds__(WV * 64) void normal_slab_kernel(const E* __restrict__ A, int64_t lda,
+                                                               const E* __restrict__ p, E* __restrict__ slab,
+                                                               int64_t Mc, int64_t N, int pair,
+                                                               const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  using C = slab_cfg<E, G, K, WV>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
+  // p first (it must not queue behind the slab: loads return in issue order), then the slab
+  E pv[C::EPT];
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * C::NT;
+    pv[e] = p[i < N ? i : (N - 1)];
+    if (i >= N) pv[e] = elem<E>::zero();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, C::NV> a[K];
+  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) {
+    const int i = threadIdx.x + e * C::NT;
+    if (i < C::NMAX) L.xs[i] = pv[e];
+  }
+  slab_finish<E, G, K, WV, FULL>(a, L, slab, Mc, N, pair);
+}
+
+// ---- CGNR pipeline: iteration = K_A (finish the previous update + one pass over A) + K_R -----
+// The BLAS-1 part of src/CGNR.jl:153-176 for the elements one thread owns.  Every workgroup runs it
+// redundantly (same inputs, same summation order => identical alpha, beta, done); `writer` says
+// whether this workgroup also stores x, r, p.  Returns p_new in pn[].
+template <typename E, int EPT, int NT>
+__device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre, double nim, double pp,
+                                              const E (&pv)[EPT], const E (&rv)[EPT], const E (&vv)[EPT], int64_t N,
+                                              double* red, E (&pn)[EPT], E (&rn)[EPT], E& a_out,
+                                              cgnr_scalars& Sn) {
+  const int tid = threadIdx.x;
+  block_sum3(nre, nim, pp, red);
+  const float lambda = S.lambda;
+  const double zeta = S.rr;
+  const dcomplex alpha = dc_div({zeta, 0.0}, {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim});
+  const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
+  const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
+  double rr = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * NT;
+    E ri = elem<E>::fma(vv[e], na, rv[e]);
+    if (lambda > 0.f) ri = elem<E>::fma(elem<E>::scale(-lambda, pv[e]), a, ri);
+    if (i >= N) ri = elem<E>::zero();
+    rn[e] = ri;
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum(rr, red);
+  const double beta = rr / zeta;
+  const float bf = (float)beta;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) pn[e] = elem<E>::add(elem<E>::scale(bf, pv[e]), rn[e]);
+  a_out = a;
+  Sn = S;
+  Sn.zeta = zeta;
+  Sn.rr = rr;
+  Sn.alpha_re = alpha.re;
+  Sn.alpha_im = alpha.im;
+  Sn.beta_re = beta;
+  Sn.beta_im = 0.0;
+  Sn.iteration = S.iteration + 1;
+  const float ratio = (float)(sqrt(rr) / S.z0);
+  Sn.done = (ratio <= S.rel_tol) || (Sn.iteration >= S.max_iter);
+  return Sn.done != 0;
+}
+
+template <typename E, int G, int K, int WV, bool FULL>
+__global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* __restrict__ x,
+                                                               E* r0, E* p0, E* r1, E* p1, const E* __restrict__ v,
+                                                               E* __restrict__ slab, const double* __restrict__ dots,
+                                                               int ndots, const cgnr_scalars* __restrict__ sc,
+                                                               cgnr_scalars* __restrict__ scn, int64_t Mc, int64_t N,
+                                                               int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int EPT = C::EPT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
+  const int tid = threadIdx.x;
+  const bool writer = blockIdx.x == 0;
+  STAMP(0);
+  // Every load is issued up front and none depends on the scalars: vmcnt retires in order, so the
+  // small vector loads go first (both candidate buffers; the right one is selected afterwards) and
+  // the CG update below runs while the slab is still in flight.
+  E pa[EPT], pb[EPT], ra[EPT], rb_[EPT], vv[EPT], xv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    const int64_t ic = i < N ? i : (N - 1);
+    xv[e] = x[ic];  // only workgroup 0 stores x, but a late load would queue behind the slab
+    pa[e] = p0[ic];
+    pb[e] = p1[ic];
+    ra[e] = r0[ic];
+    rb_[e] = r1[ic];
+    vv[e] = v[ic];
+  }
+  // this thread's share of the partial dots (clamped address; dead lanes zeroed by select)
+  const int dtid = tid < ndots ? tid : 0;
+  double d0 = dots[4 * dtid], d1 = dots[4 * dtid + 1], d2 = dots[4 * dtid + 2];
+  // A CU's vector-memory path returns loads in issue order (measured with stamps: issued ahead of
+  // the slab but not waited for, these small loads still came back 10 us later, together with it).
+  // So let them land while the memory system is idle (~1.5 us), THEN issue the 256 KiB slab and run
+  // the CG update underneath its flight.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, C::NV> a[K];
+  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid >= ndots) d0 = d1 = d2 = 0.0;
+  STAMP(1);
+  const cgnr_scalars S = *sc;
+  if (S.done) {
+    if (writer && tid == 0) {
+      cgnr_scalars Sn = S;
+      Sn.fresh = 0;
+      *scn = Sn;
+    }
+    return;
+  }
+  E pv[EPT], rv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    pv[e] = S.cur ? pb[e] : pa[e];
+    rv[e] = S.cur ? rb_[e] : ra[e];
+    if (i >= N) pv[e] = elem<E>::zero();
+  }
+
+  STAMP(2);
+  cgnr_scalars Sn;
+  if (S.pending) {
+    E pn[EPT], rn[EPT], al;
+    const bool done = cg_update_elems<E, EPT, C::NT>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    if (writer) {
+      E* rw = S.cur ? r0 : r1;
+      E* pw = S.cur ? p0 : p1;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        if (i < N) {
+          x[i] = elem<E>::fma(pv[e], al, xv[e]);
+          rw[i] = rn[e];
+          pw[i] = pn[e];
+        }
+      }
+    }
+    Sn.cur = 1 - S.cur;
+    Sn.pending = done ? 0 : 1;
+    Sn.fresh = done ? 0 : 1;
+    if (writer && tid == 0) *scn = Sn;
+    if (done) return;  // uniform: every workgroup derived the same scalars
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = pn[e];
+    }
+  } else {
+    Sn = S;
+    Sn.pending = 1;
+    Sn.fresh = 1;
+    if (writer && tid == 0) *scn = Sn;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = pv[e];
+    }
+  }
+  STAMP(3);
+  slab_finish<E, G, K, WV, FULL>(a, L, slab, Mc, N, pair);
+  STAMP(7);
+}
+
+// K_R: v = sum of the slab rows (fixed order) for 16 columns per workgroup, the partial dots
+// <p, v> and ||p||^2 for those columns, and the commit of the staged scalars.
+template <typename E>
+__global__ __launch_bounds__(256) void cgnr_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
+                                                          E* __restrict__ v, const E* p0, const E* p1,
+                                                          double* __restrict__ dots, cgnr_scalars* __restrict__ sc,
+                                                          const cgnr_scalars* __restrict__ scn) {
+  const cgnr_scalars Sn = *scn;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cgnr_scalars c = Sn;
+    c.fresh = 0;
+    *sc = c;
+  }
+  if (!Sn.fresh) return;
+  __shared__ E sm[16][16];
+  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16;
+  const int64_t j = (int64_t)blockIdx.x * 16 + cx;
+  const int64_t jc = j < N ? j : (N - 1);
+  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
+  int wgi = wy;
+  for (; wgi + 16 < nwg; wgi += 32) {
+    s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
+    s1 = elem<E>::add(s1, slab[(int64_t)(wgi + 16) * N + jc]);
+  }
+  if (wgi < nwg) s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
+  sm[wy][cx] = elem<E>::add(s0, s1);
+  __syncthreads();
+  if (wy == 0) {
+    E t = elem<E>::zero();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t = elem<E>::add(t, sm[i][cx]);
+    double dre = 0.0, dim_ = 0.0, pp = 0.0;
+    if (j < N) {
+      v[j] = t;
+      const E pj = (Sn.cur ? p1 : p0)[j];
+      dre = (double)elem<E>::re(pj) * (double)elem<E>::re(t) + (double)elem<E>::im(pj) * (double)elem<E>::im(t);
+      dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(t) - (double)elem<E>::im(pj) * (double)elem<E>::re(t);
+      pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {  // lanes 0..15 of wave 0
+      dre += __shfl_xor(dre, off, 64);
+      dim_ += __shfl_xor(dim_, off, 64);
+      pp += __shfl_xor(pp, off, 64);
+    }
+    if (cx == 0) {
+      dots[4 * blockIdx.x] = dre;
+      dots[4 * blockIdx.x + 1] = dim_;
+      dots[4 * blockIdx.x + 2] = pp;
+    }
+  }
+}
+
+// K_F: apply a pending update and bring r, p back into the caller's vectors (single workgroup)
+template <typename E, int EPT>
+__global__ __launch_bounds__(FIN_THREADS) void cgnr_pipe_f_kernel(E* __restrict__ x, E* r0, E* p0, E* r1, E* p1,
+                                                               const E* __restrict__ v,
+                                                               const double* __restrict__ dots, int ndots,
+                                                               cgnr_scalars* __restrict__ sc, int64_t N) {
+  __shared__ double red[48];
+  const cgnr_scalars S = *sc;
+  const int tid = threadIdx.x;
+  if (!S.pending && S.cur == 0) return;
+  const E* rc = S.cur ? r1 : r0;
+  const E* pc = S.cur ? p1 : p0;
+  E pv[EPT], rv[EPT], vv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * FIN_THREADS;
+    const int64_t ic = i < N ? i : (N - 1);
+    pv[e] = pc[ic];
+    rv[e] = rc[ic];
+    vv[e] = v[ic];
+  }
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+  if (tid < ndots) {
+    d0 = dots[4 * tid];
+    d1 = dots[4 * tid + 1];
+    d2 = dots[4 * tid + 2];
+  }
+  cgnr_scalars Sn = S;
+  if (S.pending && !S.done) {
+    E pn[EPT], rn[EPT], al;
+    cg_update_elems<E, EPT, FIN_THREADS>(S, d0, d1, d2, pv, rv, vv, N, red, pn, rn, al, Sn);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * FIN_THREADS;
+      if (i < N) {
+        x[i] = elem<E>::fma(pv[e], al, x[i]);
+        r0[i] = rn[e];
+        p0[i] = pn[e];
+      }
+    }
+  } else if (S.cur) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * FIN_THREADS;
+      if (i < N) {
+        r0[i] = rv[e];
+        p0[i] = pv[e];
+      }
+    }
+  }
+  Sn.pending = 0;
+  Sn.cur = 0;
+  Sn.fresh = 0;
+  __syncthreads();
+  if (tid == 0) *sc = Sn;
 }
 
 // v[j] = sum_w slab[w][j] in a fixed order: 16 columns per workgroup, 16 row groups per column
@@ -154,22 +523,27 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const E* __restrict__ 
 }
 
 struct fused_cfg {
-  int G, K;
+  int G, K, WV;
 };
 
-static int g_force_g = 0;  // measurement override (rls_tune_set "slab_g"): 0 = heuristic
+static int g_force_g = 0;   // measurement overrides (rls_tune_set "slab_g" / "slab_wv"): 0 = heuristic
+static int g_force_wv = 0;
+
+// candidate slab shapes, smallest column capacity first; NMAX = K * WV * (64 / G)
+static const fused_cfg kCfgs[] = {{8, 8, 8}, {8, 16, 8}, {8, 32, 8}, {4, 32, 8}, {8, 16, 16}, {4, 16, 16}};
 
 template <typename E>
 static bool pick_cfg(int64_t N, fused_cfg* c) {
-  // NMAX = K * 16 * (64 / G) columns fit in the register slab
-  for (int G : {8, 4}) {
-    if (g_force_g && G != g_force_g) continue;
-    const int cpr = 16 * (64 / G);
-    for (int K : {4, 8, 16}) {
-      if (N <= (int64_t)K * cpr) {
-        *c = {G, K};
-        return true;
-      }
+  const int wv = g_force_wv ? g_force_wv : 8;
+  for (const fused_cfg& k : kCfgs) {
+    if (k.WV != wv) continue;
+    if (g_force_g && k.G != g_force_g) continue;
+    const int64_t nmax = (int64_t)k.K * k.WV * (64 / k.G);
+    // LDS image (slab_lds): G exchange planes + the input vector + small scratch must fit in 160 KiB
+    const int64_t lds = (k.G * (nmax + 64 / (int64_t)sizeof(E)) + nmax) * (int64_t)sizeof(E) + 4096;
+    if (N <= nmax && lds <= 160 * 1024) {
+      *c = k;
+      return true;
     }
   }
   return false;
@@ -179,8 +553,11 @@ template <typename E>
 static bool fused_ok(int64_t M, int64_t N, const void* A, int64_t lda) {
   constexpr int V = elem<E>::vec;
   fused_cfg c;
-  return A && M > 0 && N > 0 && M % V == 0 && lda % V == 0 && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
-         pick_cfg<E>(N, &c);
+  if (!(A && M > 0 && N > 0 && M % V == 0 && lda % V == 0 && (reinterpret_cast<uintptr_t>(A) % 16 == 0))) return false;
+  if (!pick_cfg<E>(N, &c)) return false;
+  // 32-bit lane offsets: (slots per round) * column stride + row offset must stay below 2^32
+  const int64_t cpr = c.WV * (64 / c.G);
+  return cpr * lda * (int64_t)sizeof(E) + (M / V) * 16 < (int64_t)0xffffffffll;
 }
 
 template <typename E>
@@ -191,11 +568,60 @@ static int64_t fused_nwg(int64_t M, int64_t N) {
   return (Mc + c.G - 1) / c.G;
 }
 
-template <typename E, int G, int K>
+template <typename KernelT>
+static void allow_big_lds(KernelT* k, size_t lds) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <typename E, int G, int K, int WV>
 static void launch_slab(rls_ctx* ctx, const E* A, int64_t lda, const E* p, E* slab, int64_t M, int64_t N, int nwg,
                         const int* skip) {
-  hipLaunchKernelGGL((normal_slab_kernel<E, G, K>), dim3(nwg), dim3(NTHREADS), 0, ctx->stream, A, lda, p, slab,
-                     M / elem<E>::vec, N, (G == 4 && nwg % 16 == 0) ? 1 : 0, skip);
+  using C = slab_cfg<E, G, K, WV>;
+  const int64_t Mc = M / C::NV;
+  const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+  constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
+  static bool attr_set = false;  // per template instantiation
+  if (!attr_set) {
+    allow_big_lds(&normal_slab_kernel<E, G, K, WV, true>, lds);
+    allow_big_lds(&normal_slab_kernel<E, G, K, WV, false>, lds);
+    attr_set = true;
+  }
+  if (N == C::NMAX && (int64_t)nwg * G == Mc)
+    hipLaunchKernelGGL((normal_slab_kernel<E, G, K, WV, true>), dim3(nwg), dim3(C::NT), lds, ctx->stream, A, lda, p,
+                       slab, Mc, N, pair, skip);
+  else
+    hipLaunchKernelGGL((normal_slab_kernel<E, G, K, WV, false>), dim3(nwg), dim3(C::NT), lds, ctx->stream, A, lda, p,
+                       slab, Mc, N, pair, skip);
+}
+
+template <typename E, int G, int K, int WV>
+static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
+  using C = slab_cfg<E, G, K, WV>;
+  const int64_t Mc = P.M / C::NV;
+  const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+  constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false>, lds);
+    attr_set = true;
+  }
+  if (P.N == C::NMAX && (int64_t)nwg * G == Mc)
+    hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, true>), dim3(nwg), dim3(C::NT), lds, ctx->stream,
+                       (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v,
+                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair);
+  else
+    hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, false>), dim3(nwg), dim3(C::NT), lds, ctx->stream,
+                       (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v,
+                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair);
+}
+
+#define RLS_FOR_EACH_CFG(X) X(8, 8, 8) X(8, 16, 8) X(8, 32, 8) X(4, 32, 8) X(8, 16, 16) X(4, 16, 16)
+
+static int32_t launch_status(rls_ctx* ctx) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
 }
 
 template <typename E>
@@ -204,20 +630,70 @@ static int32_t normal_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A, int6
   fused_cfg c;
   if (!pick_cfg<E>(N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "normal_fused: N too large for a register slab");
   const int nwg = (int)fused_nwg<E>(M, N);
-#define RLS_SLAB_CASE(GG, KK) \
-  if (c.G == GG && c.K == KK) launch_slab<E, GG, KK>(ctx, A, lda, p, slab, M, N, nwg, skip);
-  RLS_SLAB_CASE(8, 4) RLS_SLAB_CASE(8, 8) RLS_SLAB_CASE(8, 16) RLS_SLAB_CASE(4, 4) RLS_SLAB_CASE(4, 8) RLS_SLAB_CASE(4, 16)
+#define RLS_SLAB_CASE(GG, KK, WW) \
+  if (c.G == GG && c.K == KK && c.WV == WW) launch_slab<E, GG, KK, WW>(ctx, A, lda, p, slab, M, N, nwg, skip);
+  RLS_FOR_EACH_CFG(RLS_SLAB_CASE)
 #undef RLS_SLAB_CASE
   hipLaunchKernelGGL(slab_reduce_kernel<E>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, ctx->stream, slab, nwg, N,
                      v, skip);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
-  return 0;
+  return launch_status(ctx);
+}
+
+template <typename E>
+static int32_t pipe_iteration_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, int which = 3) {
+  fused_cfg c;
+  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr pipeline: N too large");
+  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+#define RLS_PIPE_CASE(GG, KK, WW) \
+  if (c.G == GG && c.K == KK && c.WV == WW) launch_pipe_a<E, GG, KK, WW>(ctx, P, nwg);
+  if (which & 1) {
+    RLS_FOR_EACH_CFG(RLS_PIPE_CASE)
+  }
+#undef RLS_PIPE_CASE
+  if (which & 2)
+    hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots), dim3(256), 0, ctx->stream, (const E*)P.slab,
+                       nwg, P.N, (E*)P.v, (const E*)P.p0, (const E*)P.p1, P.dots, P.sc, P.scn);
+  return launch_status(ctx);
+}
+
+template <typename E>
+static int32_t pipe_finish_typed(rls_ctx* ctx, const rls_cgnr_pipe& P) {
+  const int ept = (int)((P.N + FIN_THREADS - 1) / FIN_THREADS);
+#define RLS_FIN_CASE(EE)                                                                                         \
+  hipLaunchKernelGGL((cgnr_pipe_f_kernel<E, EE>), dim3(1), dim3(FIN_THREADS), 0, ctx->stream, (E*)P.x, (E*)P.r0, \
+                     (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, P.dots, P.ndots, P.sc, P.N)
+  if (ept <= 1) RLS_FIN_CASE(1);
+  else if (ept <= 2) RLS_FIN_CASE(2);
+  else RLS_FIN_CASE(4);
+#undef RLS_FIN_CASE
+  return launch_status(ctx);
 }
 
 }  // namespace
 
 void rls_normal_force_group(int g) { g_force_g = g; }
+void rls_normal_force_waves(int wv) { g_force_wv = wv; }
+
+#ifdef RLS_STAMPS
+extern "C" int32_t rls_debug_stamps(unsigned long long* out_h) {
+  return (int32_t)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16 * 8);
+}
+#endif
+
+int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P) {
+  if (dtype == RLS_F32) return pipe_iteration_typed<float>(ctx, P);
+  return pipe_iteration_typed<float2>(ctx, P);
+}
+// which: 1 = only the normal-operator kernel K_A, 2 = only the reduce kernel K_R (both are
+// idempotent when repeated: K_A reads the committed scalars and K_R the staged ones)
+int32_t rls_cgnr_pipe_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, int which) {
+  if (dtype == RLS_F32) return pipe_iteration_typed<float>(ctx, P, which);
+  return pipe_iteration_typed<float2>(ctx, P, which);
+}
+int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P) {
+  if (dtype == RLS_F32) return pipe_finish_typed<float>(ctx, P);
+  return pipe_finish_typed<float2>(ctx, P);
+}
 
 size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (dtype == RLS_F32) return fused_ok<float>(M, N, A, lda) ? (size_t)fused_nwg<float>(M, N) * N * 4 : 0;

@@ -19,6 +19,7 @@ struct rls_tuning {
   int use_graph = 1;
   int fuse_level = 1;   // 0: separate BLAS-1 style update kernel; 1: fused update
   int fused_normal = 1; // 1: one-pass register-slab normal operator when the shape allows it
+  int cgnr_pipeline = 1; // 1: CGNR as slab kernel (with the CG update in its prologue) + reduce kernel
 };
 
 struct rls_ctx {
@@ -135,15 +136,41 @@ __device__ static inline dcomplex dc_div(dcomplex a, dcomplex b) {
   return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
 }
 
-// wave-level sum (64 lanes), result valid in every lane
+// wave-level sum (64 lanes), result valid in every lane.  The first four butterfly steps stay
+// inside a row of 16 lanes and use DPP (full-rate VALU): quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror; only the two cross-row steps go through ds_bpermute.
+__device__ static inline float dpp_f(float v, int ctrl) {
+  switch (ctrl) {
+    case 0xB1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    case 0x4E: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    case 0x141: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    case 0x140: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  }
+}
+__device__ static inline double dpp_d(double v, int ctrl) {
+  const long long b = __builtin_bit_cast(long long, v);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  lo = __builtin_bit_cast(int, dpp_f(__builtin_bit_cast(float, lo), ctrl));
+  hi = __builtin_bit_cast(int, dpp_f(__builtin_bit_cast(float, hi), ctrl));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 __device__ static inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v += dpp_d(v, 0xB1);
+  v += dpp_d(v, 0x4E);
+  v += dpp_d(v, 0x141);
+  v += dpp_d(v, 0x140);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ static inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v += dpp_f(v, 0xB1);
+  v += dpp_f(v, 0x4E);
+  v += dpp_f(v, 0x141);
+  v += dpp_f(v, 0x140);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -158,6 +185,30 @@ __device__ static inline double block_sum(double v, double* smem) {
   double s = 0.0;
   for (int i = 0; i < nw; ++i) s += smem[i];
   return s;
+}
+
+// three sums with one barrier pair; `smem` needs 48 doubles
+__device__ static inline void block_sum3(double& a, double& b, double& c, double* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  __syncthreads();
+  if (lane == 0) {
+    smem[w] = a;
+    smem[16 + w] = b;
+    smem[32 + w] = c;
+  }
+  __syncthreads();
+  double sa = 0.0, sb = 0.0, sc = 0.0;
+  for (int i = 0; i < nw; ++i) {
+    sa += smem[i];
+    sb += smem[16 + i];
+    sc += smem[32 + i];
+  }
+  a = sa;
+  b = sb;
+  c = sc;
 }
 
 // 16-byte (or element-sized) register chunks of a matrix column
@@ -190,6 +241,32 @@ __device__ static inline chunk<E, NV> zero_chunk() {
 
 #endif  // __HIPCC__
 
+// device-resident CGNR scalars (src/CGNR.jl:13-24) plus the state of the fused pipeline
+struct cgnr_scalars {
+  double rr;     // ||r||^2 now
+  double z0;     // ||A^H b||
+  double zeta;   // ||r||^2 at the start of the last iteration
+  double alpha_re, alpha_im, beta_re, beta_im;
+  float lambda, rel_tol;
+  int iteration, max_iter, done;
+  int pending;   // v and its partial dots are computed for the current p; the update is not applied yet
+  int cur;       // which (r, p) pair is current: 0 = the caller's vectors, 1 = the plan's scratch
+  int fresh;     // staging copy only: this round's K_A produced slab partials
+};
+
+// everything the CGNR pipeline kernels need (normal.hip)
+struct rls_cgnr_pipe {
+  const void* A;
+  int64_t lda, M, N;
+  void *x, *r0, *p0, *r1, *p1, *v, *slab;
+  double* dots;  // [ndots][4]
+  int ndots;     // ceil(N / 16)
+  cgnr_scalars *sc, *scn;
+};
+int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
+int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
+int32_t rls_cgnr_pipe_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, int which);
+
 // ---------------------------------------------------------------------------------------------
 // host-side launch entry points implemented in the .hip files (all enqueue on ctx->stream)
 // ---------------------------------------------------------------------------------------------
@@ -199,6 +276,7 @@ int32_t rls_launch_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int6
 // normal.hip: v = A^H A p in ONE pass over A (slab of A held in registers between the two products).
 // Returns the slab workspace size in bytes (0 = shape not supported by the fused kernel).
 void rls_normal_force_group(int g);
+void rls_normal_force_waves(int wv);
 size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,
                                 const void* p, void* v, void* slab, const int* skip);

@@ -41,6 +41,7 @@ static int32_t op_normal(rls_operator* op, const void* p, void* v, const int* sk
 struct step_graph {
   hipGraphExec_t exec = nullptr;
   int steps = 0;
+  int mode = 0;  // which kernel sequence was captured
   bool failed = false;
 };
 
@@ -85,15 +86,6 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
 // ---------------------------------------------------------------------------------------------
 // CGNR
 // ---------------------------------------------------------------------------------------------
-struct cgnr_scalars {
-  double rr;     // ||r||^2 now
-  double z0;     // ||A^H b||
-  double zeta;   // ||r||^2 at the start of the last iteration
-  double alpha_re, alpha_im, beta_re, beta_im;
-  float lambda, rel_tol;
-  int iteration, max_iter, done, pad;
-};
-
 struct rls_cgnr {
   rls_operator* op;
   int device;
@@ -102,7 +94,36 @@ struct rls_cgnr {
   cgnr_scalars* sc_h;  // pinned host
   step_graph graph;
   bool initialised;
+  // fused pipeline (normal.hip): alternate (r, p) pair, partial dots, staged scalars
+  void *r1, *p1;
+  double* dots;
+  cgnr_scalars* scn;
 };
+
+static bool cgnr_use_pipeline(const rls_cgnr* s) {
+  const rls_ctx* ctx = s->op->ctx;
+  return s->r1 && s->op->slab && !s->op->G && ctx->tune.fused_normal && ctx->tune.cgnr_pipeline;
+}
+
+static rls_cgnr_pipe cgnr_pipe_desc(const rls_cgnr* s) {
+  rls_cgnr_pipe P;
+  P.A = s->op->A;
+  P.lda = s->op->lda;
+  P.M = s->op->M;
+  P.N = s->op->N;
+  P.x = s->x;
+  P.r0 = s->r;
+  P.p0 = s->p;
+  P.r1 = s->r1;
+  P.p1 = s->p1;
+  P.v = s->v;
+  P.slab = s->op->slab;
+  P.dots = s->dots;
+  P.ndots = (int)((s->op->N + 15) / 16);
+  P.sc = s->sc;
+  P.scn = s->scn;
+  return P;
+}
 
 constexpr int UPD_THREADS = 1024;
 
@@ -131,6 +152,9 @@ __global__ __launch_bounds__(UPD_THREADS) void cgnr_init_kernel(E* __restrict__ 
     sc->rel_tol = rel_tol;
     sc->iteration = 0;
     sc->max_iter = max_iter;
+    sc->pending = 0;
+    sc->cur = 0;
+    sc->fresh = 0;
     // done() evaluated before the first iteration: ||r||/z0 <= relTol || 0 >= min(iterations, N)
     const float ratio = (float)(sqrt(rr) / sqrt(rr));  // NaN when r == 0, as in the reference
     sc->done = (ratio <= rel_tol) || (0 >= max_iter);
@@ -651,10 +675,27 @@ int32_t rls_cgnr_create(rls_operator* op, void* x, void* r, void* p, void* v, rl
   s->p = p;
   s->v = v;
   s->initialised = false;
+  s->r1 = s->p1 = nullptr;
+  s->dots = nullptr;
+  s->scn = nullptr;
   int32_t st = alloc_scalars(op->ctx, &s->sc, &s->sc_h);
   if (st != 0) {
     delete s;
     return st;
+  }
+  if (op->slab) {  // scratch of the fused pipeline
+    const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
+    const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double);
+    hipError_t e = hipMalloc(&s->r1, vb);
+    if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->dots, nd);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = hipMemset(s->dots, 0, nd);
+    if (e == hipSuccess) e = hipMemset(s->scn, 0, sizeof(cgnr_scalars));
+    if (e != hipSuccess) {
+      rls_cgnr_destroy(s);
+      return rls_fail(op->ctx, (int32_t)e, "cgnr_create: hipMalloc failed");
+    }
   }
   *out = s;
   return 0;
@@ -664,6 +705,10 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
+  if (s->r1) hipFree(s->r1);
+  if (s->p1) hipFree(s->p1);
+  if (s->dots) hipFree(s->dots);
+  if (s->scn) hipFree(s->scn);
   hipFree(s->sc);
   hipHostFree(s->sc_h);
   delete s;
@@ -710,7 +755,59 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
   if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr_step: n_steps < 0");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (cgnr_use_pipeline(s)) {
+    // iteration k = K_A (applies update k-1 in its prologue, then one pass over A) + K_R; the last
+    // update of this call is applied by K_F, which also returns r, p to the caller's vectors
+    const rls_cgnr_pipe P = cgnr_pipe_desc(s);
+    const int32_t dtype = s->op->dtype;
+    if (s->graph.steps && s->graph.mode != 1) {  // graph captured for the other kernel sequence
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph.mode = 1;
+    RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
+    return rls_cgnr_pipe_finish(ctx, dtype, P);
+  }
+  if (s->graph.steps && s->graph.mode != 0) {
+    hipGraphExecDestroy(s->graph.exec);
+    s->graph = step_graph();
+  }
+  s->graph.mode = 0;
   return run_steps(ctx, &s->graph, n_steps, [s]() { return cgnr_enqueue_iteration(s); });
+}
+
+// measurement only: the two kernels of the fused pipeline timed separately.  Each is idempotent
+// when repeated (K_A reads the committed scalars and writes the staged ones, K_R the reverse), so
+// after one ordinary iteration the normal-operator kernel is launched n_steps times back to back
+// between two hipEvents, then the reduce kernel likewise; the averages are what rocprofv3 reports
+// for back-to-back dispatches.  The solver state afterwards is that of ONE more iteration.
+int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, float* us_reduce) {
+  if (!s || !us_normal || !us_reduce || n_steps <= 0) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step_profiled before cgnr_init");
+  if (!cgnr_use_pipeline(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr_step_profiled: fused pipeline not active");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const rls_cgnr_pipe P = cgnr_pipe_desc(s);
+  const int32_t dtype = s->op->dtype;
+  RLS_TRY(rls_cgnr_pipe_iteration(ctx, dtype, P));  // leaves an update pending: K_A then does full work
+  hipEvent_t ev[3];
+  for (auto& e : ev) RLS_HIP(ctx, hipEventCreate(&e));
+  int32_t st = 0;
+  RLS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  for (int i = 0; i < n_steps && st == 0; ++i) st = rls_cgnr_pipe_launch(ctx, dtype, P, 1);
+  RLS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+  for (int i = 0; i < n_steps && st == 0; ++i) st = rls_cgnr_pipe_launch(ctx, dtype, P, 2);
+  RLS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+  RLS_HIP(ctx, hipEventSynchronize(ev[2]));
+  float a = 0.f, r = 0.f;
+  RLS_HIP(ctx, hipEventElapsedTime(&a, ev[0], ev[1]));
+  RLS_HIP(ctx, hipEventElapsedTime(&r, ev[1], ev[2]));
+  for (auto& e : ev) hipEventDestroy(e);
+  if (st != 0) return st;
+  RLS_TRY(rls_cgnr_pipe_finish(ctx, dtype, P));
+  *us_normal = 1e3f * a / n_steps;
+  *us_reduce = 1e3f * r / n_steps;
+  return 0;
 }
 
 int32_t rls_cgnr_step_local_a(rls_cgnr* s) {
