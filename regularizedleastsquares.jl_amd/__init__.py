@@ -18,3 +18,5 @@ from .solvers import (ADMM, CGNR, FISTA, AbstractLinearSolver, CompareSolutionCa
                       SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,
                       iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,
                       solverstate)
+from . import multigpu  # noqa: F401,E402
+from .multigpu import MultiSolve, RowShardedCGNR, shard_columns, shard_rows  # noqa: F401,E402

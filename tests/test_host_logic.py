@@ -1,0 +1,59 @@
+"""CPU tests of the host-side logic that needs no device: kwarg filtering, partitioning, TV geometry."""
+import warnings
+
+import numpy as np
+import pytest
+
+
+def test_filter_kwargs_warns_like_the_reference(rls):
+    from rls_amd.solvers import _filter_kwargs
+
+    with pytest.warns(UserWarning, match="filtered out: shape"):
+        kept = _filter_kwargs(rls.CGNR, True, dict(iterations=3, shape=(2, 2)))
+    assert kept == {"iterations": 3}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert _filter_kwargs(rls.FISTA, False, dict(rho=0.1, bogus=1)) == {"rho": 0.1}
+    assert rls.linearSolverList() == [rls.CGNR, rls.FISTA, rls.ADMM]
+
+
+def test_shard_columns_covers_every_column_once(rls):
+    for n, w in ((64, 8), (10, 4), (3, 8), (0, 2)):
+        seen = []
+        for r in range(w):
+            seen += list(rls.shard_columns(n, w, r))
+        assert seen == list(range(n))
+    assert list(rls.shard_columns(64, 8, 3)) == list(range(24, 32))  # columns 8k..8k+7 on GPU k
+    with pytest.raises(ValueError):
+        rls.shard_columns(4, 2, 2)
+
+
+def test_shard_rows_is_aligned_and_complete(rls):
+    for M, w in ((65536, 8), (1000, 3), (10, 4)):
+        blocks = [rls.shard_rows(M, w, r) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == M
+        for (lo, hi), (lo2, _) in zip(blocks, blocks[1:]):
+            assert hi == lo2 and lo % 4 == 0
+    assert rls.shard_rows(65536, 8, 2) == (16384, 24576)
+
+
+def test_tv_geometry_and_regularization_plumbing(rls):
+    from rls_amd.regularization import _tv_geometry, lam, normalize
+
+    shape, d0, _, _ = _tv_geometry((8, 6), None)
+    assert shape == (8, 6) and d0 == (0, 1)
+    assert _tv_geometry((8, 6), 2)[1] == (1,) and _tv_geometry((8, 6), (2, 1))[1] == (1, 0)
+    assert lam(rls.L1Regularization(0.25)) == 0.25 and lam(rls.PositiveRegularization()) is None
+    regs = [rls.L2Regularization(1.0)]
+    assert normalize(rls.NoNormalization(), regs) is regs
+    with pytest.raises(NotImplementedError):
+        normalize(rls.MeasurementBasedNormalization(), regs)
+    assert rls.TVRegularization(0.1, shape=(4, 4)).iterationsTV == 10  # ctor default, ProxTV.jl:39
+
+
+def test_dtype_guard(rls):
+    from rls_amd.arrays import dtype_code
+
+    assert dtype_code(np.float32) == 0 and dtype_code(np.complex64) == 1
+    with pytest.raises(TypeError, match="Float32 / ComplexF32"):
+        dtype_code(np.float64)

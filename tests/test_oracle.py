@@ -1,0 +1,239 @@
+"""CPU tests of the oracle (oracle/rls_oracle.py): the reference's own exact known-answer tests for
+this path replayed in NumPy, closed forms, and the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import rls_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+# ---- reference known answers ------------------------------------------------------------------
+def test_l2_prox_closed_form():
+    """test/testProxMaps.jl:13: x / (1 + 2 lambda)"""
+    rng = np.random.default_rng(1234)
+    x = np.zeros(256)
+    x[rng.integers(0, 256, 5)] = rng.random(5)
+    lam = 0.01
+    got = O.prox_l2(x.copy(), lam)
+    assert rel(got, x / (1 + 2 * lam)) < 1e-12
+    assert 0.5 * np.linalg.norm(x - got) ** 2 + lam * np.linalg.norm(got) ** 2 <= lam * np.linalg.norm(x) ** 2
+
+
+def test_positive_and_real_projection():
+    """test/testProxMaps.jl:139-164: explicit reference projection"""
+    rng = np.random.default_rng(1234)
+    x = rng.standard_normal(256) + 1j * rng.standard_normal(256)
+    want = np.maximum(x.real, 0)
+    got = O.prox_positive(x.copy())
+    assert np.array_equal(got, want.astype(complex))
+    assert np.array_equal(O.prox_real(x.copy()), x.real.astype(complex))
+    xr = rng.standard_normal(64)
+    assert np.array_equal(O.prox_positive(xr.copy()), np.maximum(xr, 0))
+    assert np.array_equal(O.prox_real(xr.copy()), xr)
+
+
+def test_l1_prox_denoises_and_decreases_objective():
+    """test/testProxMaps.jl:17-39 (statistical assertions)"""
+    rng = np.random.default_rng(1234)
+    N, sigma = 256, 0.03
+    x = np.zeros(N)
+    x[rng.integers(0, N, 5)] = (1 - 2 * sigma) * rng.random(5) + 2 * sigma
+    s = np.sum(np.abs(x)) / N * sigma
+    noisy = x + s / np.sqrt(2) * (rng.standard_normal(N) + 1j * rng.standard_normal(N))
+    den = O.prox_l1(noisy.copy(), 2 * s)
+    assert np.linalg.norm(x - den) <= np.linalg.norm(x - noisy)
+    assert np.linalg.norm(x - den) / np.linalg.norm(x) < 0.1
+    assert 0.5 * np.linalg.norm(noisy - den) ** 2 + O.norm_l1(den, 2 * s) <= O.norm_l1(noisy, 2 * s)
+
+
+def test_l1_prox_exact_values():
+    x = np.array([3.0, -0.5, 0.0, 1e-4, 2.0 + 2.0j], dtype=np.complex128)
+    got = O.prox_l1(x.copy(), 1.0)
+    assert abs(got[0] - 2.0) < 1e-12 and got[1] == 0 and got[2] == 0 and got[3] == 0
+    assert abs(abs(got[4]) - (abs(x[4]) - 1.0)) < 1e-12 and abs(np.angle(got[4]) - np.pi / 4) < 1e-12
+
+
+def test_l21_prox_matches_definition_and_edge_cases():
+    rng = np.random.default_rng(0)
+    n, slices = 40, 5
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    slen = n // slices
+    want = x.copy()
+    for i in range(slen):
+        g = np.linalg.norm(x[i::slen])
+        want[i::slen] *= max((g - 0.7) / g, 0)
+    assert rel(O.prox_l21(x.copy(), 0.7, slices), want) < 1e-12
+    # ragged tail joins its group (x[i:sliceLength:end] runs to the end of x)
+    y = rng.standard_normal(10)
+    want = y.copy()
+    for i in range(3):
+        g = np.linalg.norm(y[i::3])
+        want[i::3] *= max((g - 0.2) / g, 0)
+    assert rel(O.prox_l21(y.copy(), 0.2, 3), want) < 1e-12
+    # all-zero group: 0 for lam > 0, NaN for lam == 0 (Julia's max propagates NaN)
+    z = np.ones(8)
+    z[0::4] = 0
+    assert np.all(O.prox_l21(z.copy(), 0.5, 2)[0::4] == 0)
+    assert np.all(np.isnan(O.prox_l21(z.copy(), 0.0, 2)[0::4]))
+
+
+def test_gradient_operator_is_adjoint_pair_and_matches_differences():
+    rng = np.random.default_rng(3)
+    for shape, dims in (((6, 5), (0, 1)), ((4, 3, 5), (0, 1, 2)), ((7,), (0,)), ((6, 5), (1,))):
+        n = int(np.prod(shape))
+        x = rng.standard_normal(n)
+        g = O.grad_apply(x, shape, dims)
+        assert g.shape[0] == O.grad_len(shape, dims)
+        y = rng.standard_normal(g.shape[0])
+        assert abs(np.dot(g, y) - np.dot(x, O.grad_apply_t(y, shape, dims))) < 1e-10
+    img = np.arange(12.0).reshape(4, 3, order="F")
+    g = O.grad_apply(img.reshape(-1, order="F"), (4, 3), (0, 1))
+    assert np.allclose(g[:9], -1.0) and np.allclose(g[9:], -4.0)  # x[i] - x[i+1]; no boundary row
+
+
+def test_tv_prox_directional_equals_per_column_and_denoises():
+    """test/testProxMaps.jl:106-136 (batched 2-D call == per-column 1-D calls) and :75-103"""
+    rng = np.random.default_rng(5)
+    N = 24
+    x = np.zeros((N, N))
+    for _ in range(4):
+        x[:, rng.integers(0, N):] += rng.standard_normal()
+    noisy = x + 0.05 * rng.standard_normal((N, N))
+    a = O.prox_tv_fgp(noisy.reshape(-1, order="F").copy(), 0.1, (N, N), (1,), 10).reshape(N, N, order="F")
+    b = noisy.copy()
+    for j in range(N):
+        b[:, j] = O.prox_tv_fgp(noisy[:, j].copy(), 0.1, (N,), (1,), 10)
+    assert rel(a, b) < 1e-12
+    piece = np.zeros((N, N))
+    piece[5:, 9:] += 1.0
+    piece[14:, 3:] -= 0.7
+    noisy = piece + 0.05 * rng.standard_normal((N, N))
+    den = O.prox_tv_fgp(noisy.reshape(-1, order="F").copy(), 0.1, (N, N), None, 20).reshape(N, N, order="F")
+    assert np.linalg.norm(den - piece) < np.linalg.norm(noisy - piece)
+
+
+def test_tv_fgp_equals_dense_matrix_fgp():
+    """independent check: the same FGP recursion written with an explicit gradient matrix"""
+    rng = np.random.default_rng(9)
+    shape, lam, iters = (5, 4), 0.3, 10
+    n = 20
+    D = np.stack([O.grad_apply(e, shape, (0, 1)) for e in np.eye(n)], axis=1)
+    x = rng.standard_normal(n)
+    pq = np.zeros(D.shape[0]); rs = pq.copy(); pqo = pq.copy(); t = 1.0
+    for _ in range(iters):
+        pqo = pq
+        xt = x - lam * D.T @ rs
+        pq = rs + D @ xt / (8 * lam)
+        pq = pq / np.maximum(1, np.abs(pq))
+        to = t; t = (1 + np.sqrt(1 + 4 * to * to)) / 2
+        rs = (1 + (to - 1) / t) * pq - ((to - 1) / t) * pqo
+    want = x - lam * D.T @ pq
+    assert rel(O.prox_tv_fgp(x.copy(), lam, shape, None, iters), want) < 1e-12
+
+
+def test_callback_cadence_and_last_solution():
+    """test/testCallbacks.jl:6-16: iterations + 1 callbacks, solutions[end] == x_approx"""
+    A, x, b = O.make_problem(32, 32, np.float64, 1)
+    s = O.CGNR(A, iterations=10, relTol=0.0)
+    seen, sols = [], []
+    out = O.solve(s, b, callbacks=[lambda sv, i: seen.append(i), lambda sv, i: sols.append(sv.solution().copy())])
+    assert seen == list(range(11)) and np.array_equal(sols[-1], out)
+    assert np.linalg.norm(sols[0] - x) > np.linalg.norm(sols[-1] - x)
+
+
+def test_matrix_solve_equals_column_solves():
+    """test/testMultiThreading.jl:10-18, docs/.../multi_threading.jl:40 (==)"""
+    A, X, B = O.make_problem(12, 6, np.complex64, 3, n_rhs=4)
+    s = O.CGNR(A, iterations=100)
+    cols = np.stack([O.solve(O.CGNR(A, iterations=100), B[:, j]).copy() for j in range(4)], axis=1)
+    assert np.array_equal(O.solve(s, B), cols)
+    assert rel(cols, X) < 0.1
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_solvers_converge_on_small_systems(dt):
+    """test/testSolvers.jl:3-43: random 3x2-style systems, rtol 0.1 (here 12x6, zero-mean entries)"""
+    A, x, b = O.make_problem(12, 6, dt, 11)
+    smax = np.linalg.norm(A.astype(np.complex128), 2)
+    assert rel(O.solve(O.CGNR(A, iterations=100), b), x) < 0.1
+    assert rel(O.solve(O.FISTA(A, reg=O.L1Regularization(1e-6), rho=0.95 / smax ** 2, iterations=200), b), x) < 0.1
+    assert rel(O.solve(O.ADMM(A, reg=O.L1Regularization(1e-6), iterations=100), b), x) < 0.1
+    AHA = A.conj().T @ A
+    assert rel(O.solve(O.CGNR(None, AHA=AHA, iterations=100), A.conj().T @ b), x) < 0.1  # AHA-only (:45-65)
+
+
+def test_cgnr_closed_forms():
+    A, x, b = O.make_problem(64, 32, np.complex128, 3)
+    for lam in (0.0, 0.5):
+        s = O.CGNR(A, reg=O.L2Regularization(lam), iterations=32, relTol=0.0)
+        want = np.linalg.solve(A.conj().T @ A + lam * np.eye(32), A.conj().T @ b)
+        assert rel(O.solve(s, b), want) < 1e-8
+    with pytest.raises(ValueError):
+        O.CGNR(A, reg=O.L1Regularization(0.1))
+
+
+def test_cg_inplace_solves_spd_system_and_counts_iterations():
+    rng = np.random.default_rng(2)
+    B = rng.standard_normal((20, 20))
+    Aop = B.T @ B + 0.5 * np.eye(20)
+    b = rng.standard_normal(20)
+    x = np.zeros(20)
+    it = O.cg_inplace(x, lambda v: Aop @ v, b, maxiter=200, reltol=1e-12)
+    assert rel(x, np.linalg.solve(Aop, b)) < 1e-8 and 0 < it <= 200
+    # warm start: the tolerance is relative to the INITIAL residual b - A x0 (cg! semantics), so a
+    # nearly exact x0 still iterates on rounding noise but must stay a solution
+    x2 = np.linalg.solve(Aop, b) + 1e-6 * rng.standard_normal(20)
+    it2 = O.cg_inplace(x2, lambda v: Aop @ v, b, maxiter=10, reltol=1e-3)
+    assert it2 <= 10 and rel(x2, np.linalg.solve(Aop, b)) < 1e-6
+
+
+def test_power_iterations_estimates_top_eigenvalue():
+    A, _, _ = O.make_problem(80, 30, np.complex128, 4)
+    lam = O.power_iterations(O.NormalOp(O.DenseOp(A)), np.ones(30, dtype=np.complex128), rtol=1e-6, maxiter=500)
+    assert abs(lam - np.linalg.norm(A, 2) ** 2) / lam < 1e-3
+
+
+def test_float32_oracle_tracks_float64_oracle():
+    """the parity bar (1e-5) is only meaningful on well-conditioned inputs: SURVEY 7, hard part 4"""
+    A, x, b = O.make_problem(256, 128, np.complex64, 1)
+    s32 = O.CGNR(A, iterations=10, relTol=0.0); O.solve(s32, b)
+    s64 = O.CGNR(A.astype(np.complex128), iterations=10, relTol=0.0); O.solve(s64, b.astype(np.complex128))
+    assert rel(s32.x, s64.x) < 5e-6
+
+
+# ---- golden fixtures --------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dt64", [("cgnr_256x128_f32.npz", np.float64), ("cgnr_64x32_c64.npz", np.complex128)])
+def test_golden_cgnr(name, dt64):
+    g = np.load(os.path.join(GOLD, name))
+    s = O.CGNR(g["A"].astype(dt64), reg=O.L2Regularization(float(g["lam"])), iterations=len(g["x"]), relTol=0.0)
+    s.init(g["b"].astype(dt64))
+    for k in range(len(g["x"])):
+        s.iterate()
+        assert rel(s.x, g["x"][k]) < 1e-12 and rel(s.p, g["p"][k]) < 1e-10
+        assert abs(s.alpha - g["alpha"][k]) < 1e-12 * abs(g["alpha"][k])
+
+
+def test_golden_fista_admm_prox():
+    g = np.load(os.path.join(GOLD, "fista_l1_64x32_c64.npz"))
+    for restart in ("none", "gradient"):
+        s = O.FISTA(g["A"].astype(np.complex128), reg=O.L1Regularization(float(g["lam"])), rho=float(g["rho"]),
+                    iterations=50, restart=restart)
+        O.solve(s, g["b"].astype(np.complex128))
+        assert rel(s.x, g["x_" + restart]) < 1e-12
+    g = np.load(os.path.join(GOLD, "admm_tv_128x64_f32.npz"))
+    s = O.ADMM(g["A"].astype(np.float64), reg=O.TVRegularization(1e-2, shape=(8, 8)), rho=0.1, iterations=10)
+    O.solve(s, g["b"].astype(np.float64))
+    assert rel(s.x, g["x"]) < 1e-12 and list(g["cg_iters"]) == s.cg_iters
+    g = np.load(os.path.join(GOLD, "prox_cases.npz"))
+    for tag in ("f32", "c64"):
+        x = g[f"x_{tag}"]
+        assert np.array_equal(O.prox_l1(x.copy(), 0.35), g[f"l1_{tag}"])
+        assert np.array_equal(O.prox_l21(x.copy(), 0.8, 8), g[f"l21_{tag}"])
+        assert np.array_equal(O.prox_positive(x.copy()), g[f"pos_{tag}"])
