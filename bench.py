@@ -219,6 +219,14 @@ def main():
                       "launches_per_iteration": 0 if rc == 0 else 1}
     used = {k: v_ for k, v_ in kern.items() if v_["launches_per_iteration"] > 0}
     dom = max(used, key=lambda k: used[k]["us_per_launch"])
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    # separate rocprofv3 --pmc runs of tools/pmc_probe.py; tools/pmc_summarize.py); null if not collected
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        traffic = pmc["kernels"][dom.split(" ")[0]]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
 
     if rank == 0:
         out = {
@@ -239,7 +247,7 @@ def main():
                                    f"solve per GPU, no collectives)",
                        "M": M, "N": N, "problems_per_gpu": 1},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "achieved = algorithmic bytes (reference path: A read twice per iteration) / device "
                                  "time per launch; the one-pass kernel reads A once, see min_hbm_bytes_per_launch",
                          "per_kernel": kern,

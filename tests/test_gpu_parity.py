@@ -503,3 +503,27 @@ def test_errors_are_loud(rls, ctx):
         rls.DeviceVector.from_host(np.zeros(4, np.float64))
     with pytest.raises(rls.RLSError):
         rls.prox_(rls.L21Regularization, rls.DeviceVector.from_host(np.ones(4, np.float32)), 0.1, slices=9)
+
+
+def test_row_sharded_cgnr_single_rank_on_gpu(rls, ctx):
+    """BASELINE config 5 control flow on one GPU (world = 1: the all-reduce is the identity): the split
+    half-steps rls_cgnr_{init,step}_local_{a,b} on torch-owned state vectors equal the oracle"""
+    import torch
+
+    A, xt, b = O.make_problem(1024, 384, np.complex64, 13)
+    ops = rls.multigpu.HipLocalOps(rls, A, torch.cuda.current_device())
+    s = rls.RowShardedCGNR(ops, None, lam=1e-3, iterations=16, relTol=0.0)
+    x = s.solve(b)
+    ref = O.CGNR(A.astype(np.complex128), reg=O.L2Regularization(1e-3), iterations=16, relTol=0.0)
+    O.solve(ref, b.astype(np.complex128))
+    assert rel(x, ref.x) < TOL_ITER and ops.status()["iteration"] == 16
+    ops.close()
+
+
+def test_multisolve_single_rank(rls, ctx):
+    """BASELINE config 4 sharding at world = 1 (all columns local) equals column solves"""
+    A, X, B = O.make_problem(128, 64, np.complex64, 17, n_rhs=5)
+    Ad = rls.DeviceMatrix.from_host(A)
+    ms = rls.MultiSolve(rls, lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=64))
+    got = ms.solve(B)
+    assert got.shape == (64, 5) and rel(got, X) < 1e-3

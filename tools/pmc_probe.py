@@ -1,0 +1,22 @@
+"""Minimal dispatch sequence for rocprofv3 --pmc passes: eager launches (no hipGraph), a handful of
+CGNR iterations of the headline problem.  usage: rocprofv3 --pmc FETCH_SIZE ... -- python3 tools/pmc_probe.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa
+import rls_amd as rls
+from bench import make_A
+ctx = rls.Context(0)
+ctx.tune(use_graph=0)
+M, N = 4096, 2048
+A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
+b = rls.DeviceVector.from_host((A @ np.ones(N, np.complex64)).astype(np.complex64), ctx)
+solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+rls.init_(solver, b)
+ctx.lib.rls_cgnr_step(solver.state._plan, 6)
+ctx.sync()
+p = rls.DeviceVector.from_host(np.ones(N, np.complex64), ctx); t = rls.DeviceVector(M, np.complex64, ctx); v = rls.DeviceVector(N, np.complex64, ctx)
+for _ in range(3):
+    Ad.gemv_(0, p, t); Ad.gemv_(2, t, v)
+ctx.sync()
+print("pmc probe done", flush=True)
