@@ -219,6 +219,16 @@ int32_t rls_cg_destroy(rls_cg* s);
 int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxiter, float reltol);
 int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out_h);
 
+/* ADMM elementwise steps for an identity regTrafo (the default opEye, src/ADMM.jl:84), fused:
+ *   rls_admm_pre :  beta = (accumulate ? beta : beta_y) + rho (z - u) ; xold = x            src/ADMM.jl:236-243
+ *   rls_admm_post:  u += x - z and the seven norms of the convergence bookkeeping src/ADMM.jl:265-299 in one
+ *                   launch; out_h[6] = { Delta, ||z-zold||, eps_pri, r, ||u||, ||x-xold|| } (synchronises;
+ *                   s = rho*out[1], eps_dua = rho*out[4]) */
+int32_t rls_admm_pre(rls_ctx* ctx, int32_t dtype, int64_t n, void* beta, const void* beta_y, const void* z,
+                     const void* u, const void* x, void* xold, float rho, int32_t accumulate);
+int32_t rls_admm_post(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* xold, const void* z,
+                      const void* zold, void* u, float* out_h);
+
 /* ---------------------------------------------------------------------------------------------
  * row-sharded operation (BASELINE config 5).  One process per GPU holds rows
  * [r*M/P, (r+1)*M/P) of A repacked contiguous; x, r, p, v and all scalars are replicated.

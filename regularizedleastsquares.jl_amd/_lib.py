@@ -114,6 +114,8 @@ PROTOTYPES = {
     "rls_cg_destroy": (_i32, [_vp]),
     "rls_cg_solve": (_i32, [_vp, _vp, _vp, _f, _i32, _f]),
     "rls_cg_get_status": (_i32, [_vp, C.POINTER(CgStatus)]),
+    "rls_admm_pre": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32]),
+    "rls_admm_post": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _pf]),
 }
 
 _lib = None

@@ -99,6 +99,12 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
     rls_normal_force_group(value);
   } else if (!strcmp(key, "slab_wv")) {
     rls_normal_force_waves(value);
+  } else if (!strcmp(key, "tv_fused_max_n")) {
+    rls_tv_set_fused_max_n(value);
+  } else if (!strcmp(key, "slab_order")) {
+    rls_normal_order_mode(value);
+  } else if (!strcmp(key, "red_threads")) {
+    rls_normal_red_threads(value);
   }
   else return rls_fail(ctx, RLS_E_INVALID, "tune_set: unknown key");
   return 0;

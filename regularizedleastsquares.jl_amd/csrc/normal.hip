@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
                                                                E* __restrict__ slab, const double* __restrict__ dots,
                                                                int ndots, const cgnr_scalars* __restrict__ sc,
                                                                cgnr_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                               int pair) {
+                                                               int pair, int order_mode) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int EPT = C::EPT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -317,7 +317,13 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
   // the slab but not waited for, these small loads still came back 10 us later, together with it).
   // So let them land while the memory system is idle (~1.5 us), THEN issue the 256 KiB slab and run
   // the CG update underneath its flight.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (order_mode == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    // every wave has ISSUED its small loads before any wave issues slab loads: inside the CU they are
+    // then ahead of the whole slab in the in-order return queue, and nothing waits for them here
+    __builtin_amdgcn_s_barrier();
+  }
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, C::NV> a[K];
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
 // K_R: v = sum of the slab rows (fixed order) for 16 columns per workgroup, the partial dots
 // <p, v> and ||p||^2 for those columns, and the commit of the staged scalars.
 template <typename E>
-__global__ __launch_bounds__(256) void cgnr_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
+__global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
                                                           E* __restrict__ v, const E* p0, const E* p1,
                                                           double* __restrict__ dots, cgnr_scalars* __restrict__ sc,
                                                           const cgnr_scalars* __restrict__ scn) {
@@ -400,23 +406,22 @@ __global__ __launch_bounds__(256) void cgnr_pipe_r_kernel(const E* __restrict__ 
     *sc = c;
   }
   if (!Sn.fresh) return;
-  __shared__ E sm[16][16];
-  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16;
+  __shared__ E sm[64][16];
+  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;  // ny row groups
   const int64_t j = (int64_t)blockIdx.x * 16 + cx;
   const int64_t jc = j < N ? j : (N - 1);
   E s0 = elem<E>::zero(), s1 = elem<E>::zero();
   int wgi = wy;
-  for (; wgi + 16 < nwg; wgi += 32) {
+  for (; wgi + ny < nwg; wgi += 2 * ny) {
     s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
-    s1 = elem<E>::add(s1, slab[(int64_t)(wgi + 16) * N + jc]);
+    s1 = elem<E>::add(s1, slab[(int64_t)(wgi + ny) * N + jc]);
   }
   if (wgi < nwg) s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
   sm[wy][cx] = elem<E>::add(s0, s1);
   __syncthreads();
   if (wy == 0) {
     E t = elem<E>::zero();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t = elem<E>::add(t, sm[i][cx]);
+    for (int i = 0; i < ny; ++i) t = elem<E>::add(t, sm[i][cx]);
     double dre = 0.0, dim_ = 0.0, pp = 0.0;
     if (j < N) {
       v[j] = t;
@@ -528,6 +533,8 @@ struct fused_cfg {
 
 static int g_force_g = 0;   // measurement overrides (rls_tune_set "slab_g" / "slab_wv"): 0 = heuristic
 static int g_force_wv = 0;
+static int g_order_mode = 1;  // 0: wait for the small loads, 1: barrier only (rls_tune_set "slab_order")
+static int g_red_threads = 1024;  // reduce kernel: 16 columns x 64 row groups per workgroup (-1.0 us vs 256)
 
 // candidate slab shapes, smallest column capacity first; NMAX = K * WV * (64 / G)
 static const fused_cfg kCfgs[] = {{8, 8, 8}, {8, 16, 8}, {8, 32, 8}, {4, 32, 8}, {8, 16, 16}, {4, 16, 16}};
@@ -609,11 +616,11 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   if (P.N == C::NMAX && (int64_t)nwg * G == Mc)
     hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, true>), dim3(nwg), dim3(C::NT), lds, ctx->stream,
                        (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v,
-                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair);
+                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode);
   else
     hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, false>), dim3(nwg), dim3(C::NT), lds, ctx->stream,
                        (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v,
-                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair);
+                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode);
 }
 
 #define RLS_FOR_EACH_CFG(X) X(8, 8, 8) X(8, 16, 8) X(8, 32, 8) X(4, 32, 8) X(8, 16, 16) X(4, 16, 16)
@@ -651,7 +658,7 @@ static int32_t pipe_iteration_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, int wh
   }
 #undef RLS_PIPE_CASE
   if (which & 2)
-    hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots), dim3(256), 0, ctx->stream, (const E*)P.slab,
+    hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots), dim3(g_red_threads), 0, ctx->stream, (const E*)P.slab,
                        nwg, P.N, (E*)P.v, (const E*)P.p0, (const E*)P.p1, P.dots, P.sc, P.scn);
   return launch_status(ctx);
 }
@@ -673,6 +680,8 @@ static int32_t pipe_finish_typed(rls_ctx* ctx, const rls_cgnr_pipe& P) {
 
 void rls_normal_force_group(int g) { g_force_g = g; }
 void rls_normal_force_waves(int wv) { g_force_wv = wv; }
+void rls_normal_order_mode(int m) { g_order_mode = m; }
+void rls_normal_red_threads(int t) { g_red_threads = t; }
 
 #ifdef RLS_STAMPS
 extern "C" int32_t rls_debug_stamps(unsigned long long* out_h) {

@@ -275,8 +275,11 @@ int32_t rls_launch_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int6
                         const void* A, int64_t lda, const void* x, float br, float bi, void* y, const int* skip);
 // normal.hip: v = A^H A p in ONE pass over A (slab of A held in registers between the two products).
 // Returns the slab workspace size in bytes (0 = shape not supported by the fused kernel).
+void rls_tv_set_fused_max_n(int64_t n);
 void rls_normal_force_group(int g);
 void rls_normal_force_waves(int wv);
+void rls_normal_order_mode(int m);
+void rls_normal_red_threads(int t);
 size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,
                                 const void* p, void* v, void* slab, const int* skip);

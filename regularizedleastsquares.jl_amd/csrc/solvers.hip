@@ -41,6 +41,7 @@ static int32_t op_normal(rls_operator* op, const void* p, void* v, const int* sk
 struct step_graph {
   hipGraphExec_t exec = nullptr;
   int steps = 0;
+  void* x_bound = nullptr;  // cg plans: the solution vector whose address the captured kernels carry
   int mode = 0;  // which kernel sequence was captured
   bool failed = false;
 };
@@ -440,7 +441,126 @@ struct rls_cg {
   void *u, *r, *c;
   cg_scalars* sc;
   cg_scalars* sc_h;
+  // fused pipeline (normal.hip): cg! on (AHA + rho I) is the CGNR recurrence with lambda = rho and the
+  // start residual b - (AHA + rho I) x0, so it reuses the two-launch CGNR pipeline (p = u, v = c)
+  void *r1, *p1;
+  double* dots;
+  cgnr_scalars *psc, *pscn, *psc_h;
+  step_graph graph;
+  bool used_pipeline;
 };
+
+static bool cg_use_pipeline(const rls_cg* s) {
+  const rls_ctx* ctx = s->op->ctx;
+  return s->r1 && s->op->slab && !s->op->G && ctx->tune.fused_normal && ctx->tune.cgnr_pipeline;
+}
+
+static rls_cgnr_pipe cg_pipe_desc(const rls_cg* s, void* x) {
+  rls_cgnr_pipe P;
+  P.A = s->op->A;
+  P.lda = s->op->lda;
+  P.M = s->op->M;
+  P.N = s->op->N;
+  P.x = x;
+  P.r0 = s->r;
+  P.p0 = s->u;
+  P.r1 = s->r1;
+  P.p1 = s->p1;
+  P.v = s->c;
+  P.slab = s->op->slab;
+  P.dots = s->dots;
+  P.ndots = (int)((s->op->N + 15) / 16);
+  P.sc = s->psc;
+  P.scn = s->pscn;
+  return P;
+}
+
+// warm start of the pipeline: c = AHA x is in place; r = b - c - rho x, u = r, scalars reset.
+// done at entry mirrors cg!: residual <= tol = reltol * residual (only for reltol >= 1) or maxiter == 0;
+// r == 0 exactly is also final (the next alpha would be 0/0).
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void cg_pipe_start_kernel(const E* __restrict__ x, const E* __restrict__ b,
+                                                                    E* __restrict__ u, E* __restrict__ r,
+                                                                    const E* __restrict__ c, int64_t n,
+                                                                    cgnr_scalars* sc, float rho, float reltol,
+                                                                    int maxiter) {
+  __shared__ double sm[16];
+  double rr = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E ci = elem<E>::add(c[i], elem<E>::scale(rho, x[i]));
+    const E ri = elem<E>::sub(b[i], ci);
+    r[i] = ri;
+    u[i] = ri;
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum(rr, sm);
+  if (threadIdx.x == 0) {
+    sc->rr = rr;
+    sc->z0 = sqrt(rr);
+    sc->zeta = 0.0;
+    sc->alpha_re = sc->alpha_im = sc->beta_re = sc->beta_im = 0.0;
+    sc->lambda = rho;
+    sc->rel_tol = reltol;
+    sc->iteration = 0;
+    sc->max_iter = maxiter;
+    sc->pending = 0;
+    sc->cur = 0;
+    sc->fresh = 0;
+    sc->done = (maxiter <= 0) || (rr == 0.0) || (1.0f <= reltol);
+  }
+}
+
+// ADMM bookkeeping for an identity regTrafo, src/ADMM.jl:259-299 in ONE single-workgroup launch:
+//   u_new = u + x - z ;  Delta = ||x-xold|| + ||z-zold|| + ||u_new-u|| ;  s = rho ||z-zold|| ;
+//   eps_pri = max(||x||, ||z||) ; r = ||x-z|| ; eps_dua = rho ||u_new||
+// (with Phi = I the reference's hijacked scratch sequence reduces to exactly these seven norms).
+// out[0..5] = Delta, s/rho, eps_pri, r, eps_dua/rho, ||x-xold||   (floats; rho applied on the host)
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void admm_post_kernel(const E* __restrict__ x, const E* __restrict__ xold,
+                                                                const E* __restrict__ z, const E* __restrict__ zold,
+                                                                E* __restrict__ u, int64_t n, float* __restrict__ out) {
+  __shared__ double sm[48];
+  double dx = 0, dz = 0, du = 0, nx = 0, nz = 0, nxz = 0, nu = 0;
+  auto sq = [](E a) { return (double)elem<E>::re(a) * (double)elem<E>::re(a) + (double)elem<E>::im(a) * (double)elem<E>::im(a); };
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    const E xi = x[i], zi = z[i], ui = u[i];
+    const E xz = elem<E>::sub(xi, zi);
+    const E un = elem<E>::sub(elem<E>::add(ui, xi), zi);  // u += x ; u -= z   (:266-267)
+    u[i] = un;
+    dx += sq(elem<E>::sub(xi, xold[i]));
+    dz += sq(elem<E>::sub(zi, zold[i]));
+    du += sq(elem<E>::sub(un, ui));
+    nx += sq(xi);
+    nz += sq(zi);
+    nxz += sq(xz);
+    nu += sq(un);
+  }
+  block_sum3(dx, dz, du, sm);
+  block_sum3(nx, nz, nxz, sm);
+  nu = block_sum(nu, sm);
+  if (threadIdx.x == 0) {
+    out[0] = (float)sqrt(dx) + (float)sqrt(dz) + (float)sqrt(du);
+    out[1] = (float)sqrt(dz);
+    out[2] = fmaxf((float)sqrt(nx), (float)sqrt(nz));
+    out[3] = (float)sqrt(nxz);
+    out[4] = (float)sqrt(nu);
+    out[5] = (float)sqrt(dx);
+  }
+}
+
+// beta = beta_y + rho (z - u) ; xold = x      (src/ADMM.jl:236-243, identity regTrafo)
+template <typename E>
+__global__ void admm_pre_kernel(E* __restrict__ beta, const E* __restrict__ beta_y, const E* __restrict__ z,
+                                const E* __restrict__ u, const E* __restrict__ x, E* __restrict__ xold, int64_t n,
+                                float rho, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    E bi = accumulate ? beta[i] : beta_y[i];
+    bi = elem<E>::add(bi, elem<E>::scale(rho, z[i]));
+    bi = elem<E>::add(bi, elem<E>::scale(-rho, u[i]));
+    beta[i] = bi;
+    if (!accumulate) xold[i] = x[i];
+  }
+}
 
 // c = AHA x is in place.  c += rho x ; r = b - c ; residual = ||r|| ; tol ; u = r (= r + beta*0)
 template <typename E>
@@ -994,10 +1114,28 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   s->u = u;
   s->r = r;
   s->c = c;
+  s->r1 = s->p1 = nullptr;
+  s->dots = nullptr;
+  s->psc = s->pscn = s->psc_h = nullptr;
+  s->used_pipeline = false;
   int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
   if (st != 0) {
     delete s;
     return st;
+  }
+  if (op->slab) {
+    const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
+    const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double);
+    hipError_t e = hipMalloc(&s->r1, vb);
+    if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->dots, nd);
+    if (e == hipSuccess) e = hipMemset(s->dots, 0, nd);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->pscn, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = hipMemset(s->pscn, 0, sizeof(cgnr_scalars));
+    if (e != hipSuccess || alloc_scalars(ctx, &s->psc, &s->psc_h) != 0) {
+      rls_cg_destroy(s);
+      return rls_fail(ctx, (int32_t)e, "cg_create: hipMalloc failed");
+    }
   }
   *out = s;
   return 0;
@@ -1006,6 +1144,13 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
 int32_t rls_cg_destroy(rls_cg* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
+  if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
+  if (s->r1) hipFree(s->r1);
+  if (s->p1) hipFree(s->p1);
+  if (s->dots) hipFree(s->dots);
+  if (s->psc) hipFree(s->psc);
+  if (s->pscn) hipFree(s->pscn);
+  if (s->psc_h) hipHostFree(s->psc_h);
   hipFree(s->sc);
   hipHostFree(s->sc_h);
   delete s;
@@ -1021,6 +1166,27 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
   const int64_t n = op->N;
   // warm start: one operator apply for r = b - (AHA + rho I) x
   RLS_TRY(op_normal(op, x, s->c, nullptr));
+  s->used_pipeline = cg_use_pipeline(s);
+  if (s->used_pipeline) {
+    if (op->dtype == RLS_F32)
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                         (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->psc, rho, reltol,
+                         maxiter);
+    else
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                         (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->psc, rho, reltol,
+                         maxiter);
+    RLS_TRY(launch_status(ctx));
+    const rls_cgnr_pipe P = cg_pipe_desc(s, x);
+    const int32_t dtype = op->dtype;
+    if (s->graph.exec && s->graph.x_bound != x) {  // the captured kernels carry x's address
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph.x_bound = x;
+    RLS_TRY(run_steps(ctx, &s->graph, maxiter, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
+    return rls_cgnr_pipe_finish(ctx, dtype, P);
+  }
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
                        (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->sc, rho, reltol, maxiter);
@@ -1046,10 +1212,56 @@ int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->used_pipeline) {
+    RLS_TRY(fetch_scalars(ctx, s->psc, s->psc_h));
+    out->iterations = s->psc_h->iteration;
+    out->residual = (float)sqrt(s->psc_h->rr);
+    out->tol = s->psc_h->rel_tol * (float)s->psc_h->z0;
+    return 0;
+  }
   RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
   out->iterations = s->sc_h->iteration;
   out->residual = (float)s->sc_h->residual;
   out->tol = (float)s->sc_h->tol;
+  return 0;
+}
+
+// ---- ADMM fused elementwise steps (identity regTrafo) ----------------------------------------
+int32_t rls_admm_pre(rls_ctx* ctx, int32_t dtype, int64_t n, void* beta, const void* beta_y, const void* z,
+                     const void* u, const void* x, void* xold, float rho, int32_t accumulate) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && (!beta || !beta_y || !z || !u || !x || !xold)))
+    return rls_fail(ctx, RLS_E_INVALID, "admm_pre: bad argument");
+  if (n == 0) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned grid = (unsigned)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(admm_pre_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (float*)beta, (const float*)beta_y,
+                       (const float*)z, (const float*)u, (const float*)x, (float*)xold, n, rho, accumulate);
+  else
+    hipLaunchKernelGGL(admm_pre_kernel<float2>, dim3(grid), dim3(256), 0, ctx->stream, (float2*)beta,
+                       (const float2*)beta_y, (const float2*)z, (const float2*)u, (const float2*)x, (float2*)xold, n,
+                       rho, accumulate);
+  return launch_status(ctx);
+}
+
+int32_t rls_admm_post(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* xold, const void* z,
+                      const void* zold, void* u, float* out_h) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n <= 0 || !x || !xold || !z || !zold || !u || !out_h)
+    return rls_fail(ctx, RLS_E_INVALID, "admm_post: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(admm_post_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                       (const float*)xold, (const float*)z, (const float*)zold, (float*)u, n, ctx->res_d);
+  else
+    hipLaunchKernelGGL(admm_post_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                       (const float2*)xold, (const float2*)z, (const float2*)zold, (float2*)u, n, ctx->res_d);
+  RLS_TRY(launch_status(ctx));
+  RLS_HIP(ctx, hipMemcpyAsync(ctx->res_h, ctx->res_d, sizeof(float) * 6, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 6; ++i) out_h[i] = ctx->res_h[i];
   return 0;
 }
 

@@ -12,6 +12,9 @@
 // place over rs, and the new rs overwrites the old pq element by element.
 #include "rls_common.hpp"
 
+#include <map>
+#include <mutex>
+
 namespace {
 
 constexpr int TV_MAXD = 4;
@@ -95,6 +98,67 @@ __device__ static inline E gradt_at(const E* g, const tv_geom& G, int64_t xi) {
   return s;
 }
 
+// 32-bit twin of tv_geom for the LDS-resident kernel (n, ng < 2^31 there): the stencil index math
+// is what that kernel spends its time on, and 64-bit div/mod is ~4x the instructions of 32-bit
+struct tv_geom32 {
+  int ndims, ntv;
+  unsigned shape[TV_MAXD], stride[TV_MAXD];
+  int dims[TV_MAXD];
+  unsigned goff[TV_MAXD + 1];
+  unsigned bstride[TV_MAXD][TV_MAXD];
+  unsigned n;
+};
+static tv_geom32 narrow_geom(const tv_geom& G) {
+  tv_geom32 g;
+  g.ndims = G.ndims;
+  g.ntv = G.ntv;
+  g.n = (unsigned)G.n;
+  for (int k = 0; k < TV_MAXD; ++k) {
+    g.shape[k] = (unsigned)G.shape[k];
+    g.stride[k] = (unsigned)G.stride[k];
+    g.dims[k] = G.dims[k];
+    for (int m = 0; m < TV_MAXD; ++m) g.bstride[k][m] = (unsigned)G.bstride[k][m];
+  }
+  for (int k = 0; k <= TV_MAXD; ++k) g.goff[k] = (unsigned)G.goff[k];
+  return g;
+}
+
+template <typename E>
+__device__ static inline E grad_at32(const E* x, const tv_geom32& G, unsigned gi) {
+  int k = 0;
+  while (k + 1 < G.ntv && gi >= G.goff[k + 1]) ++k;
+  const int d = G.dims[k];
+  unsigned li = gi - G.goff[k], xi = 0;
+  for (int m = 0; m < G.ndims; ++m) {
+    const unsigned ext = (m == d) ? (G.shape[m] - 1) : G.shape[m];
+    const unsigned q = li / ext;
+    xi += (li - q * ext) * G.stride[m];
+    li = q;
+  }
+  return elem<E>::sub(x[xi], x[xi + G.stride[d]]);
+}
+
+template <typename E>
+__device__ static inline E gradt_at32(const E* g, const tv_geom32& G, unsigned xi) {
+  unsigned c[TV_MAXD];
+  unsigned r = xi;
+  for (int m = 0; m < G.ndims; ++m) {
+    const unsigned q = r / G.shape[m];
+    c[m] = r - q * G.shape[m];
+    r = q;
+  }
+  E s = elem<E>::zero();
+  for (int k = 0; k < G.ntv; ++k) {
+    const int d = G.dims[k];
+    unsigned bi = 0;
+    for (int m = 0; m < G.ndims; ++m) bi += c[m] * G.bstride[k][m];
+    const E* gb = g + G.goff[k];
+    if (c[d] < G.shape[d] - 1) s = elem<E>::add(s, gb[bi]);
+    if (c[d] > 0) s = elem<E>::sub(s, gb[bi - G.bstride[k][d]]);
+  }
+  return s;
+}
+
 // tv_restrictMagnitude!: q /= max(1, |q|)   (ProxTV.jl:135-139)
 template <typename E>
 __device__ static inline E tv_clip(E q) {
@@ -147,33 +211,38 @@ __global__ void fgp_dual_kernel(E* brs, E* bpq, const E* xtmp, tv_geom G, float 
   }
 }
 
-// whole FGP loop in one workgroup; duals and xTmp live in LDS
+// whole FGP loop in one workgroup; the image, xTmp and both dual buffers live in LDS (a global
+// re-read of x in every FGP iteration cost ~6 us of dependent latency per iteration)
 template <typename E>
-__global__ __launch_bounds__(1024) void fgp_fused_kernel(E* __restrict__ x, tv_geom G, float lam, int iters) {
+__global__ __launch_bounds__(1024) void fgp_fused_kernel(E* __restrict__ x, tv_geom32 G, float lam, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int64_t ng = G.goff[G.ntv], n = G.n;
+  const unsigned ng = G.goff[G.ntv], n = G.n;
   E* b0 = reinterpret_cast<E*>(smem_raw);
   E* b1 = b0 + ng;
   E* xt = b1 + ng;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  for (int64_t i = tid; i < ng; i += nth) {
+  E* xl = xt + n;
+  const unsigned tid = threadIdx.x, nth = blockDim.x;
+  for (unsigned i = tid; i < ng; i += nth) {
     b0[i] = elem<E>::zero();
     b1[i] = elem<E>::zero();
   }
+  for (unsigned i = tid; i < n; i += nth) xl[i] = x[i];
   __syncthreads();
   E* brs = b0;
   E* bpq = b1;
   float t = 1.f;
   const float step = 1.f / (8.f * lam);
   for (int it = 0; it < iters; ++it) {
-    for (int64_t i = tid; i < n; i += nth)
-      xt[i] = elem<E>::add(x[i], elem<E>::scale(-lam, gradt_at<E>(brs, G, i)));
+#pragma unroll 4
+    for (unsigned i = tid; i < n; i += nth)
+      xt[i] = elem<E>::add(xl[i], elem<E>::scale(-lam, gradt_at32<E>(brs, G, i)));
     __syncthreads();
     const float tOld = t;
     t = (1.f + sqrtf(1.f + 4.f * tOld * tOld)) / 2.f;
     const float t2 = (tOld - 1.f) / t, t3 = 1.f + t2;
-    for (int64_t gi = tid; gi < ng; gi += nth) {
-      E q = elem<E>::add(elem<E>::scale(step, grad_at<E>(xt, G, gi)), brs[gi]);
+#pragma unroll 4
+    for (unsigned gi = tid; gi < ng; gi += nth) {
+      E q = elem<E>::add(elem<E>::scale(step, grad_at32<E>(xt, G, gi)), brs[gi]);
       q = tv_clip<E>(q);
       const E old = bpq[gi];
       brs[gi] = q;
@@ -184,10 +253,38 @@ __global__ __launch_bounds__(1024) void fgp_fused_kernel(E* __restrict__ x, tv_g
     brs = bpq;
     bpq = tmp;  // bpq now holds the newest pq
   }
-  for (int64_t i = tid; i < n; i += nth) x[i] = elem<E>::add(x[i], elem<E>::scale(-lam, gradt_at<E>(bpq, G, i)));
+#pragma unroll 4
+  for (unsigned i = tid; i < n; i += nth) x[i] = elem<E>::add(xl[i], elem<E>::scale(-lam, gradt_at32<E>(bpq, G, i)));
+}
+
+// small per-context cache of captured FGP launch sequences (multi-launch path)
+struct fgp_graph_key {
+  const void *x, *ws;
+  float lam;
+  int iters, dtype;
+  tv_geom G;
+};
+struct fgp_graph_cache {
+  struct entry {
+    fgp_graph_key key;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long stamp = 0;
+  };
+  entry entries[8];
+  unsigned long long clock = 0;
+};
+static fgp_graph_cache& fgp_cache_for(rls_ctx* ctx) {
+  // contexts are few and long-lived; the caches are leaked with the process (graphs hold no device memory)
+  static std::map<rls_ctx*, fgp_graph_cache*> caches;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = caches.find(ctx);
+  if (it == caches.end()) it = caches.emplace(ctx, new fgp_graph_cache()).first;
+  return *it->second;
 }
 
 constexpr size_t FGP_LDS_BUDGET = 160 * 1024 - 512;
+static int64_t g_fused_max_n = 2048;  // larger images: one CU is slower than 2 chip-wide launches per FGP iteration
 
 static int32_t tv_status(rls_ctx* ctx) {
   hipError_t e = hipGetLastError();
@@ -204,34 +301,84 @@ static inline unsigned tv_grid(int64_t n) {
 template <typename E>
 int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E* ws) {
   const int64_t ng = G.goff[G.ntv], n = G.n;
-  const size_t lds = (size_t)(2 * ng + n) * sizeof(E);
-  if (lds <= FGP_LDS_BUDGET) {
+  const size_t lds = (size_t)(2 * ng + 2 * n) * sizeof(E);
+  if (lds <= FGP_LDS_BUDGET && n <= g_fused_max_n) {
     RLS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp_fused_kernel<E>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3(1), dim3(1024), lds, ctx->stream, x, G, lam, iters);
+    hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3(1), dim3(1024), lds, ctx->stream, x, narrow_geom(G), lam, iters);
     return tv_status(ctx);
   }
-  E* brs = ws;
-  E* bpq = ws + ng;
-  E* xt = ws + 2 * ng;
-  RLS_HIP(ctx, hipMemsetAsync(ws, 0, (size_t)2 * ng * sizeof(E), ctx->stream));
-  float t = 1.f;
-  const float step = 1.f / (8.f * lam);
-  for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(gradt_kernel<E>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, brs, x, xt, G, -lam, 1.f);
-    const float tOld = t;
-    t = (1.f + sqrtf(1.f + 4.f * tOld * tOld)) / 2.f;
-    const float t2 = (tOld - 1.f) / t, t3 = 1.f + t2;
-    hipLaunchKernelGGL(fgp_dual_kernel<E>, dim3(tv_grid(ng)), dim3(256), 0, ctx->stream, brs, bpq, xt, G, step, t2, t3);
-    E* tmp = brs;
-    brs = bpq;
-    bpq = tmp;
+  // Multi-launch path: 2 chip-wide launches per FGP iteration.  Eager, the 2*iters + 2 launches are
+  // host-bound (~3.8 us each measured); the whole sequence is therefore captured once per
+  // (x, workspace, lambda, iterations, geometry) and replayed as a hipGraph (ADMM calls prox! with the
+  // same few argument sets every outer iteration).  Capture failure falls back to eager launches.
+  auto enqueue = [&]() -> int32_t {
+    E* brs = ws;
+    E* bpq = ws + ng;
+    E* xt = ws + 2 * ng;
+    RLS_HIP(ctx, hipMemsetAsync(ws, 0, (size_t)2 * ng * sizeof(E), ctx->stream));
+    float t = 1.f;
+    const float step = 1.f / (8.f * lam);
+    for (int it = 0; it < iters; ++it) {
+      hipLaunchKernelGGL(gradt_kernel<E>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, brs, x, xt, G, -lam, 1.f);
+      const float tOld = t;
+      t = (1.f + sqrtf(1.f + 4.f * tOld * tOld)) / 2.f;
+      const float t2 = (tOld - 1.f) / t, t3 = 1.f + t2;
+      hipLaunchKernelGGL(fgp_dual_kernel<E>, dim3(tv_grid(ng)), dim3(256), 0, ctx->stream, brs, bpq, xt, G, step, t2, t3);
+      E* tmp = brs;
+      brs = bpq;
+      bpq = tmp;
+    }
+    hipLaunchKernelGGL(gradt_kernel<E>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, bpq, x, x, G, -lam, 1.f);
+    return tv_status(ctx);
+  };
+  if (!ctx->tune.use_graph) return enqueue();
+  fgp_graph_key key;
+  memset(&key, 0, sizeof(key));
+  key.x = x;
+  key.ws = ws;
+  key.lam = lam;
+  key.iters = iters;
+  key.dtype = (int)sizeof(E);
+  key.G = G;
+  fgp_graph_cache& cache = fgp_cache_for(ctx);
+  for (auto& e : cache.entries) {
+    if (e.exec && memcmp(&e.key, &key, sizeof(key)) == 0) {
+      e.stamp = ++cache.clock;
+      RLS_HIP(ctx, hipGraphLaunch(e.exec, ctx->stream));
+      return 0;
+    }
   }
-  hipLaunchKernelGGL(gradt_kernel<E>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, bpq, x, x, G, -lam, 1.f);
-  return tv_status(ctx);
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipError_t err = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+  int32_t st = 0;
+  if (err == hipSuccess) {
+    st = enqueue();
+    err = hipStreamEndCapture(ctx->stream, &graph);
+  }
+  if (err != hipSuccess || st != 0 || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    if (graph) hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return enqueue();  // eager, still the HIP kernels
+  }
+  hipGraphDestroy(graph);
+  fgp_graph_cache::entry* victim = &cache.entries[0];
+  for (auto& e : cache.entries)
+    if (!e.exec || e.stamp < victim->stamp) victim = (!victim->exec ? victim : &e);
+  for (auto& e : cache.entries)
+    if (!e.exec) victim = &e;
+  if (victim->exec) hipGraphExecDestroy(victim->exec);
+  victim->key = key;
+  victim->exec = exec;
+  victim->stamp = ++cache.clock;
+  RLS_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+  return 0;
 }
 
 }  // namespace
+
+void rls_tv_set_fused_max_n(int64_t n) { g_fused_max_n = n; }
 
 extern "C" {
 
@@ -317,7 +464,7 @@ int32_t rls_prox_tv_fgp(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_
   if (!rls_dtype_ok(dtype) || !x || iterations < 0 || !make_geom(ndims, shape, ntv, dims, &G))
     return rls_fail(ctx, RLS_E_INVALID, "prox_tv_fgp: bad argument");
   const size_t need = (size_t)(2 * G.goff[G.ntv] + G.n) * rls_elem_size(dtype);
-  const bool fused = need <= FGP_LDS_BUDGET;
+  const bool fused = need + (size_t)G.n * rls_elem_size(dtype) <= FGP_LDS_BUDGET && G.n <= g_fused_max_n;
   if (!fused && (!workspace || workspace_bytes < need))
     return rls_fail(ctx, RLS_E_WORKSPACE, "prox_tv_fgp: workspace too small");
   RLS_HIP(ctx, hipSetDevice(ctx->device));

@@ -507,6 +507,7 @@ class ADMM(AbstractLinearSolver):
         self.iterations = int(iterations)
         self.iterationsCG = int(iterationsCG)
         self.normalizeReg = normalizeReg or NoNormalization()
+        self._track_cg = True  # record the inner CG iteration counts (one extra host read-back per outer iteration)
         self.state = ADMMState(len(self.reg), self.rho, absTol, relTol, tolInner)
 
     def _new_state(self):
@@ -610,23 +611,33 @@ class ADMM(AbstractLinearSolver):
             return None
         f32 = np.float32
         lib, h = state.x.ctx.lib, state.x.ctx.handle
+        fused = self._all_identity() and len(self.reg) == 1
         # 1. x update                                                                  :236-244
-        state.beta.copy_from(state.beta_y)
-        for i, t in enumerate(self.regTrafo):
-            t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
-            t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
-        state.xold.copy_from(state.x)
+        if fused:
+            check(h, lib.rls_admm_pre(h, state.x.code, state.x.n, state.beta.ptr, state.beta_y.ptr, state.z[0].ptr,
+                                      state.u[0].ptr, state.x.ptr, state.xold.ptr, float(state.rho[0]), 0), "rls_admm_pre")
+        else:
+            state.beta.copy_from(state.beta_y)
+            for i, t in enumerate(self.regTrafo):
+                t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
+                t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
+            state.xold.copy_from(state.x)
         if self._all_identity():
             rho_sum = float(np.sum(state.rho, dtype=np.float32))
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, rho_sum, self.iterationsCG,
                                       float(state.tolInner)), "rls_cg_solve")
-            st = CgStatus()
-            check(h, lib.rls_cg_get_status(state._cg, C.byref(st)), "rls_cg_get_status")
-            state.cg_iterations.append(int(st.iterations))
+            if not fused or self.verbose or self._track_cg:
+                st = CgStatus()
+                check(h, lib.rls_cg_get_status(state._cg, C.byref(st)), "rls_cg_get_status")
+                state.cg_iterations.append(int(st.iterations))
         else:
             state.cg_iterations.append(self._cg_generic(state))
         for pr in self.proj:
             pr.prox_(state.x)
+        if fused:
+            self._zu_update_fused(state)
+            state.iteration += 1
+            return state.x, state
         # 2./3. z and u updates + convergence bookkeeping                              :251-309
         for i, t in enumerate(self.regTrafo):
             state.z[i], state.zold[i] = state.zold[i], state.z[i]
@@ -664,6 +675,36 @@ class ADMM(AbstractLinearSolver):
                 print(f"new rho[{i}] = {state.rho[i]}")
         state.iteration += 1
         return state.x, state
+
+    def _zu_update_fused(self, state):
+        """src/ADMM.jl:251-309 for one regulariser with the identity regTrafo: the z-update, then ONE
+        launch for u += x - z and all seven norms of the convergence bookkeeping, ONE host read-back"""
+        f32 = np.float32
+        lib, h = state.x.ctx.lib, state.x.ctx.handle
+        i = 0
+        state.z[i], state.zold[i] = state.zold[i], state.z[i]
+        state.z[i].lincomb_(1.0, state.x, 1.0, state.u[i])
+        if state.rho[i] != 0:
+            self.reg[i].prox_(state.z[i], float(f32(self.reg[i].lam) / (f32(2) * state.rho[i])))
+        out = (C.c_float * 6)()
+        check(h, lib.rls_admm_post(h, state.x.code, state.x.n, state.x.ptr, state.xold.ptr, state.z[i].ptr,
+                                   state.zold[i].ptr, state.u[i].ptr, out), "rls_admm_post")
+        Delta_old = state.Delta[i]
+        state.Delta[i] = f32(out[0])
+        state.sk[i] = state.rho[i] * f32(out[1])
+        state.eps_pri[i] = f32(out[2])
+        state.rk[i] = f32(out[3])
+        state.eps_dua[i] = state.rho[i] * f32(out[4])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if (self.vary_rho == "balance" and state.rk[i] / state.eps_pri[i] > f32(10) * state.sk[i] / state.eps_dua[i]) or (
+                    self.vary_rho == "PnP" and state.Delta[i] / Delta_old > f32(0.9)):
+                state.rho[i] *= f32(2)
+                state.u[i].rmul_(0.5)
+            elif self.vary_rho == "balance" and state.sk[i] / state.eps_dua[i] > f32(10) * state.rk[i] / state.eps_pri[i]:
+                state.rho[i] /= f32(2)
+                state.u[i].rmul_(2.0)
+        if self.verbose:
+            print(f"rk/eps_pri = {state.rk[i] / state.eps_pri[i]}  sk/eps_dua = {state.sk[i] / state.eps_dua[i]}  rho = {state.rho[i]}")
 
     def _run(self, state):
         while self.iterate(state) is not None:

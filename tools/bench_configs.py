@@ -1,0 +1,30 @@
+"""Timing of BASELINE configs 2 and 3 (FISTA+L1 4096x2048 CF32; ADMM+TV 8192x4096 F32) -- parity-test cases, not
+the bench line; prints us per (outer) iteration from hipEvents."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa
+import rls_amd as rls
+from bench import make_A
+ctx = rls.Context(0)
+which = sys.argv[1:] or ["fista", "admm"]
+if "fista" in which:
+    M, N = 4096, 2048
+    A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
+    b = rls.DeviceVector.from_host((A @ np.ones(N, np.complex64)).astype(np.complex64), ctx)
+    S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2, iterations=50)
+    for _ in range(20): rls.solve_(S, b)
+    ctx.sync(); ctx.timer_start()
+    for _ in range(20): rls.init_(S, b); ctx.lib.rls_fista_step(S.state._plan, 50)
+    us = ctx.timer_stop_ms() * 1e3 / 1000
+    print(f"config 2: FISTA+L1 4096x2048 CF32: {us:.2f} us/iteration ({1e6/us:.0f} it/s)")
+if "admm" in which:
+    M, N = 8192, 4096
+    A = make_A(M, N, 3, np.float32); Ad = rls.DeviceMatrix.from_host(A, ctx)
+    b = rls.DeviceVector.from_host((A @ np.ones(N, np.float32)).astype(np.float32), ctx)
+    S = rls.createLinearSolver(rls.ADMM, Ad, reg=rls.TVRegularization(1e-2, shape=(64, 64)), rho=0.1, iterations=10, iterationsCG=10, tolInner=1e-5)
+    rls.solve_(S, b); rls.solve_(S, b); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(5): rls.solve_(S, b)
+    ctx.sync(); dt = time.perf_counter() - t0
+    print(f"config 3: ADMM+TV 8192x4096 F32: {1e3*dt/50:.3f} ms/outer iteration (CG its {S.state.cg_iterations})")
