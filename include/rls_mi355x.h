@@ -168,6 +168,16 @@ int32_t rls_cgnr_init(rls_cgnr* s, const void* b, float lambda, float rel_tol, i
 /* enqueue n_steps iterations (no-ops once done); asynchronous, graph-replayed */
 int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps);
 int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h); /* synchronises */
+/* Batched plan (BASELINE config 4, shared-A flavour; semantics of solve!(solver, B; scheduler =
+ * MultiThreadingState), src/MultiThreading.jl:30-79): nrhs independent CGNR solves that share ONE pass over A
+ * per iteration.  X, R, P, V: caller-owned N x nrhs column-major device matrices, leading dimension ldv;
+ * B: M x nrhs, leading dimension ldb.  Every column keeps its own scalars and its own `done` flag
+ * (columns retire independently); rls_cgnr_step advances all of them.  RLS_E_UNSUPPORTED when the shape
+ * does not run on the one-pass kernel (then use one plan per column). */
+int32_t rls_cgnr_create_batched(rls_operator* op, int32_t nrhs, void* X, void* R, void* P, void* V, int64_t ldv,
+                                rls_cgnr** out);
+int32_t rls_cgnr_init_batched(rls_cgnr* s, const void* B, int64_t ldb, float lambda, float rel_tol, int32_t iterations);
+int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out_h /* [nrhs] */);
 /* measurement harness only: n_steps iterations with hipEvents around each kernel of the fused
  * pipeline; average device microseconds per launch of the one-pass normal-operator kernel and of
  * the partial-sum reduce kernel.  RLS_E_UNSUPPORTED when the shape runs on the two-GEMV path. */

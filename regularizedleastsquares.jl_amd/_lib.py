@@ -97,6 +97,9 @@ PROTOTYPES = {
     "rls_cgnr_init": (_i32, [_vp, _vp, _f, _f, _i32]),
     "rls_cgnr_step": (_i32, [_vp, _i32]),
     "rls_cgnr_get_status": (_i32, [_vp, C.POINTER(CgnrStatus)]),
+    "rls_cgnr_create_batched": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _pvp]),
+    "rls_cgnr_init_batched": (_i32, [_vp, _vp, _i64, _f, _f, _i32]),
+    "rls_cgnr_get_status_batched": (_i32, [_vp, C.POINTER(CgnrStatus)]),
     "rls_cgnr_step_profiled": (_i32, [_vp, _i32, _pf, _pf]),
     "rls_cgnr_init_local_a": (_i32, [_vp, _vp, _f, _f, _i32]),
     "rls_cgnr_init_local_b": (_i32, [_vp]),

@@ -281,61 +281,55 @@ __device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre,
   return Sn.done != 0;
 }
 
-template <typename E, int G, int K, int WV, bool FULL>
-__global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* __restrict__ x,
-                                                               E* r0, E* p0, E* r1, E* p1, const E* __restrict__ v,
-                                                               E* __restrict__ slab, const double* __restrict__ dots,
-                                                               int ndots, const cgnr_scalars* __restrict__ sc,
-                                                               cgnr_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                               int pair, int order_mode) {
-  using C = slab_cfg<E, G, K, WV>;
-  constexpr int EPT = C::EPT;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
+// the small per-RHS vector loads of K_A (both candidate buffers; the right one is selected once the
+// scalars are known) and this thread's share of the partial dots
+template <typename E, int EPT>
+struct pipe_small {
+  E pa[EPT], pb[EPT], ra[EPT], rb[EPT], vv[EPT], xv[EPT];
+  double d0, d1, d2;
+};
+
+template <typename E, int EPT, int NT>
+__device__ static inline void pipe_load_small(pipe_small<E, EPT>& s, const E* x, const E* r0, const E* p0, const E* r1,
+                                              const E* p1, const E* v, const double* dots, int ndots, int64_t N,
+                                              int64_t vo, int b) {
   const int tid = threadIdx.x;
-  const bool writer = blockIdx.x == 0;
-  STAMP(0);
-  // Every load is issued up front and none depends on the scalars: vmcnt retires in order, so the
-  // small vector loads go first (both candidate buffers; the right one is selected afterwards) and
-  // the CG update below runs while the slab is still in flight.
-  E pa[EPT], pb[EPT], ra[EPT], rb_[EPT], vv[EPT], xv[EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
-    const int64_t i = tid + (int64_t)e * C::NT;
-    const int64_t ic = i < N ? i : (N - 1);
-    xv[e] = x[ic];  // only workgroup 0 stores x, but a late load would queue behind the slab
-    pa[e] = p0[ic];
-    pb[e] = p1[ic];
-    ra[e] = r0[ic];
-    rb_[e] = r1[ic];
-    vv[e] = v[ic];
+    const int64_t i = tid + (int64_t)e * NT;
+    const int64_t ic = vo + (i < N ? i : (N - 1));
+    s.xv[e] = x[ic];  // only workgroup 0 stores x, but a late load would queue behind the slab
+    s.pa[e] = p0[ic];
+    s.pb[e] = p1[ic];
+    s.ra[e] = r0[ic];
+    s.rb[e] = r1[ic];
+    s.vv[e] = v[ic];
   }
-  // this thread's share of the partial dots (clamped address; dead lanes zeroed by select)
-  const int dtid = tid < ndots ? tid : 0;
-  double d0 = dots[4 * dtid], d1 = dots[4 * dtid + 1], d2 = dots[4 * dtid + 2];
-  // A CU's vector-memory path returns loads in issue order (measured with stamps: issued ahead of
-  // the slab but not waited for, these small loads still came back 10 us later, together with it).
-  // So let them land while the memory system is idle (~1.5 us), THEN issue the 256 KiB slab and run
-  // the CG update underneath its flight.
-  if (order_mode == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    // every wave has ISSUED its small loads before any wave issues slab loads: inside the CU they are
-    // then ahead of the whole slab in the in-order return queue, and nothing waits for them here
-    __builtin_amdgcn_s_barrier();
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  chunk<E, C::NV> a[K];
-  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
-  __builtin_amdgcn_sched_barrier(0);
-  if (tid >= ndots) d0 = d1 = d2 = 0.0;
-  STAMP(1);
-  const cgnr_scalars S = *sc;
+  const int dtid = tid < ndots ? tid : 0;  // clamped address; dead lanes zeroed by the caller
+  const double* db = dots + (int64_t)b * 4 * ndots;
+  s.d0 = db[4 * dtid];
+  s.d1 = db[4 * dtid + 1];
+  s.d2 = db[4 * dtid + 2];
+}
+
+// CG update of one right-hand side (every workgroup redundantly; workgroup 0 stores) followed by the
+// two products from the register slab.  Wave-uniform control flow: every thread reads the same scalars.
+template <typename E, int G, int K, int WV, bool FULL>
+__device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L,
+                                               pipe_small<E, slab_cfg<E, G, K, WV>::EPT>& sm, E* x, E* r0, E* p0,
+                                               E* r1, E* p1, E* slab_b, const cgnr_scalars* sc_b, cgnr_scalars* scn_b,
+                                               int ndots, int64_t Mc, int64_t N, int64_t vo, int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int EPT = C::EPT;
+  const int tid = threadIdx.x;
+  const bool writer = blockIdx.x == 0;
+  if (tid >= ndots) sm.d0 = sm.d1 = sm.d2 = 0.0;
+  const cgnr_scalars S = *sc_b;
   if (S.done) {
     if (writer && tid == 0) {
       cgnr_scalars Sn = S;
       Sn.fresh = 0;
-      *scn = Sn;
+      *scn_b = Sn;
     }
     return;
   }
@@ -343,24 +337,23 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int64_t i = tid + (int64_t)e * C::NT;
-    pv[e] = S.cur ? pb[e] : pa[e];
-    rv[e] = S.cur ? rb_[e] : ra[e];
+    pv[e] = S.cur ? sm.pb[e] : sm.pa[e];
+    rv[e] = S.cur ? sm.rb[e] : sm.ra[e];
     if (i >= N) pv[e] = elem<E>::zero();
   }
-
   STAMP(2);
   cgnr_scalars Sn;
   if (S.pending) {
     E pn[EPT], rn[EPT], al;
-    const bool done = cg_update_elems<E, EPT, C::NT>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    const bool done = cg_update_elems<E, EPT, C::NT>(S, sm.d0, sm.d1, sm.d2, pv, rv, sm.vv, N, L.red, pn, rn, al, Sn);
     if (writer) {
-      E* rw = S.cur ? r0 : r1;
-      E* pw = S.cur ? p0 : p1;
+      E* rw = (S.cur ? r0 : r1) + vo;
+      E* pw = (S.cur ? p0 : p1) + vo;
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         const int64_t i = tid + (int64_t)e * C::NT;
         if (i < N) {
-          x[i] = elem<E>::fma(pv[e], al, xv[e]);
+          x[vo + i] = elem<E>::fma(pv[e], al, sm.xv[e]);
           rw[i] = rn[e];
           pw[i] = pn[e];
         }
@@ -369,7 +362,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
     Sn.cur = 1 - S.cur;
     Sn.pending = done ? 0 : 1;
     Sn.fresh = done ? 0 : 1;
-    if (writer && tid == 0) *scn = Sn;
+    if (writer && tid == 0) *scn_b = Sn;
     if (done) return;  // uniform: every workgroup derived the same scalars
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -380,7 +373,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
     Sn = S;
     Sn.pending = 1;
     Sn.fresh = 1;
-    if (writer && tid == 0) *scn = Sn;
+    if (writer && tid == 0) *scn_b = Sn;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int i = tid + e * C::NT;
@@ -388,8 +381,55 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
     }
   }
   STAMP(3);
-  slab_finish<E, G, K, WV, FULL>(a, L, slab, Mc, N, pair);
+  slab_finish<E, G, K, WV, FULL>(a, L, slab_b, Mc, N, pair);
   STAMP(7);
+}
+
+// One or several right-hand sides share the slab: the A loads happen once, then each RHS runs its CG
+// update + the two products from the same registers (BASELINE config 4, shared-A flavour).  Per-RHS
+// arrays are `vstride` elements apart (x, r0, p0, r1, p1, v), `slab_stride` (slab) and 4*ndots (dots).
+struct pipe_rhs_ptrs {
+  int64_t vstride, slab_stride;
+  int nrhs;
+};
+
+template <typename E, int G, int K, int WV, bool FULL, bool BATCHED>
+__global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* __restrict__ x,
+                                                               E* r0, E* p0, E* r1, E* p1, const E* __restrict__ v,
+                                                               E* __restrict__ slab, const double* __restrict__ dots,
+                                                               int ndots, const cgnr_scalars* __restrict__ sc,
+                                                               cgnr_scalars* __restrict__ scn, int64_t Mc, int64_t N,
+                                                               int pair, int order_mode, pipe_rhs_ptrs R) {
+  using C = slab_cfg<E, G, K, WV>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
+  STAMP(0);
+  // First right-hand side: its small loads go out ahead of the slab.  A CU's vector-memory path
+  // returns loads in issue order (measured with stamps), so every wave issues them, a workgroup
+  // barrier makes sure no wave has slab loads queued in front of another wave's small loads, and only
+  // then the 256 KiB slab goes out; the CG update runs under its flight.
+  pipe_small<E, C::EPT> sm;
+  pipe_load_small<E, C::EPT, C::NT>(sm, x, r0, p0, r1, p1, v, dots, ndots, N, 0, 0);
+  if (order_mode == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    __builtin_amdgcn_s_barrier();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, C::NV> a[K];
+  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+  pipe_process_rhs<E, G, K, WV, FULL>(a, L, sm, x, r0, p0, r1, p1, slab, sc, scn, ndots, Mc, N, 0, pair);
+  // further right-hand sides reuse the registers (a separate instantiation: with the loop present the
+  // compiler hoists per-load address math out of it and the single-RHS kernel spills)
+  if constexpr (BATCHED)
+  for (int b = 1; b < R.nrhs; ++b) {
+    const int64_t vo = (int64_t)b * R.vstride;
+    pipe_load_small<E, C::EPT, C::NT>(sm, x, r0, p0, r1, p1, v, dots, ndots, N, vo, b);
+    pipe_process_rhs<E, G, K, WV, FULL>(a, L, sm, x, r0, p0, r1, p1, slab + (int64_t)b * R.slab_stride, sc + b, scn + b,
+                                         ndots, Mc, N, vo, pair);
+  }
 }
 
 // K_R: v = sum of the slab rows (fixed order) for 16 columns per workgroup, the partial dots
@@ -398,14 +438,20 @@ template <typename E>
 __global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
                                                           E* __restrict__ v, const E* p0, const E* p1,
                                                           double* __restrict__ dots, cgnr_scalars* __restrict__ sc,
-                                                          const cgnr_scalars* __restrict__ scn) {
-  const cgnr_scalars Sn = *scn;
+                                                          const cgnr_scalars* __restrict__ scn, pipe_rhs_ptrs R) {
+  const int b = blockIdx.y;  // right-hand side
+  const cgnr_scalars Sn = scn[b];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     cgnr_scalars c = Sn;
     c.fresh = 0;
-    *sc = c;
+    sc[b] = c;
   }
   if (!Sn.fresh) return;
+  slab += (int64_t)b * R.slab_stride;
+  v += (int64_t)b * R.vstride;
+  p0 += (int64_t)b * R.vstride;
+  p1 += (int64_t)b * R.vstride;
+  dots += (int64_t)b * 4 * gridDim.x;
   __shared__ E sm[64][16];
   const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;  // ny row groups
   const int64_t j = (int64_t)blockIdx.x * 16 + cx;
@@ -449,8 +495,18 @@ template <typename E, int EPT>
 __global__ __launch_bounds__(FIN_THREADS) void cgnr_pipe_f_kernel(E* __restrict__ x, E* r0, E* p0, E* r1, E* p1,
                                                                const E* __restrict__ v,
                                                                const double* __restrict__ dots, int ndots,
-                                                               cgnr_scalars* __restrict__ sc, int64_t N) {
+                                                               cgnr_scalars* __restrict__ sc, int64_t N,
+                                                               pipe_rhs_ptrs R) {
   __shared__ double red[48];
+  const int b = blockIdx.x;  // right-hand side
+  sc += b;
+  x += (int64_t)b * R.vstride;
+  r0 += (int64_t)b * R.vstride;
+  p0 += (int64_t)b * R.vstride;
+  r1 += (int64_t)b * R.vstride;
+  p1 += (int64_t)b * R.vstride;
+  v += (int64_t)b * R.vstride;
+  dots += (int64_t)b * 4 * ndots;
   const cgnr_scalars S = *sc;
   const int tid = threadIdx.x;
   if (!S.pending && S.cur == 0) return;
@@ -601,6 +657,14 @@ static void launch_slab(rls_ctx* ctx, const E* A, int64_t lda, const E* p, E* sl
                        slab, Mc, N, pair, skip);
 }
 
+static pipe_rhs_ptrs rhs_of(const rls_cgnr_pipe& P, int nwg) {
+  pipe_rhs_ptrs R;
+  R.nrhs = P.nrhs > 0 ? P.nrhs : 1;
+  R.vstride = P.vstride;
+  R.slab_stride = (int64_t)nwg * P.N;
+  return R;
+}
+
 template <typename E, int G, int K, int WV>
 static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   using C = slab_cfg<E, G, K, WV>;
@@ -609,18 +673,23 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   static bool attr_set = false;
   if (!attr_set) {
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true>, lds);
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, true>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, true>, lds);
     attr_set = true;
   }
-  if (P.N == C::NMAX && (int64_t)nwg * G == Mc)
-    hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, true>), dim3(nwg), dim3(C::NT), lds, ctx->stream,
-                       (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v,
-                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode);
-  else
-    hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, false>), dim3(nwg), dim3(C::NT), lds, ctx->stream,
-                       (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v,
-                       (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode);
+  const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
+  const bool batched = P.nrhs > 1;
+#define RLS_LAUNCH_A(FULLV, BATCHV)                                                                                  \
+  hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV>), dim3(nwg), dim3(C::NT), lds, ctx->stream,      \
+                     (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, (E*)P.slab, \
+                     P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, rhs_of(P, nwg))
+  if (full && !batched) RLS_LAUNCH_A(true, false);
+  else if (!full && !batched) RLS_LAUNCH_A(false, false);
+  else if (full) RLS_LAUNCH_A(true, true);
+  else RLS_LAUNCH_A(false, true);
+#undef RLS_LAUNCH_A
 }
 
 #define RLS_FOR_EACH_CFG(X) X(8, 8, 8) X(8, 16, 8) X(8, 32, 8) X(4, 32, 8) X(8, 16, 16) X(4, 16, 16)
@@ -658,8 +727,9 @@ static int32_t pipe_iteration_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, int wh
   }
 #undef RLS_PIPE_CASE
   if (which & 2)
-    hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots), dim3(g_red_threads), 0, ctx->stream, (const E*)P.slab,
-                       nwg, P.N, (E*)P.v, (const E*)P.p0, (const E*)P.p1, P.dots, P.sc, P.scn);
+    hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots, (unsigned)(P.nrhs > 0 ? P.nrhs : 1)),
+                       dim3(g_red_threads), 0, ctx->stream, (const E*)P.slab, nwg, P.N, (E*)P.v, (const E*)P.p0,
+                       (const E*)P.p1, P.dots, P.sc, P.scn, rhs_of(P, nwg));
   return launch_status(ctx);
 }
 
@@ -667,8 +737,9 @@ template <typename E>
 static int32_t pipe_finish_typed(rls_ctx* ctx, const rls_cgnr_pipe& P) {
   const int ept = (int)((P.N + FIN_THREADS - 1) / FIN_THREADS);
 #define RLS_FIN_CASE(EE)                                                                                         \
-  hipLaunchKernelGGL((cgnr_pipe_f_kernel<E, EE>), dim3(1), dim3(FIN_THREADS), 0, ctx->stream, (E*)P.x, (E*)P.r0, \
-                     (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, P.dots, P.ndots, P.sc, P.N)
+  hipLaunchKernelGGL((cgnr_pipe_f_kernel<E, EE>), dim3((unsigned)(P.nrhs > 0 ? P.nrhs : 1)), dim3(FIN_THREADS), 0, \
+                     ctx->stream, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, P.dots, P.ndots, P.sc, \
+                     P.N, rhs_of(P, 0))
   if (ept <= 1) RLS_FIN_CASE(1);
   else if (ept <= 2) RLS_FIN_CASE(2);
   else RLS_FIN_CASE(4);

@@ -259,9 +259,11 @@ struct rls_cgnr_pipe {
   const void* A;
   int64_t lda, M, N;
   void *x, *r0, *p0, *r1, *p1, *v, *slab;
-  double* dots;  // [ndots][4]
+  double* dots;  // [nrhs][ndots][4]
   int ndots;     // ceil(N / 16)
-  cgnr_scalars *sc, *scn;
+  cgnr_scalars *sc, *scn;  // [nrhs]
+  int nrhs = 1;            // right-hand sides sharing one pass over A
+  int64_t vstride = 0;     // elements between consecutive right-hand sides in x, r, p, v
 };
 int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);

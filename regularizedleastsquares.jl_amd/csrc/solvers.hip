@@ -99,6 +99,10 @@ struct rls_cgnr {
   void *r1, *p1;
   double* dots;
   cgnr_scalars* scn;
+  // batched plans: nrhs right-hand sides, columns ldv elements apart, own partial-row slab
+  int nrhs;
+  int64_t ldv;
+  void* slab_b;
 };
 
 static bool cgnr_use_pipeline(const rls_cgnr* s) {
@@ -118,11 +122,13 @@ static rls_cgnr_pipe cgnr_pipe_desc(const rls_cgnr* s) {
   P.r1 = s->r1;
   P.p1 = s->p1;
   P.v = s->v;
-  P.slab = s->op->slab;
+  P.slab = s->slab_b ? s->slab_b : s->op->slab;
   P.dots = s->dots;
   P.ndots = (int)((s->op->N + 15) / 16);
   P.sc = s->sc;
   P.scn = s->scn;
+  P.nrhs = s->nrhs;
+  P.vstride = s->ldv;
   return P;
 }
 
@@ -783,13 +789,18 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
 }
 
 // ---- CGNR -----------------------------------------------------------------------------------
-int32_t rls_cgnr_create(rls_operator* op, void* x, void* r, void* p, void* v, rls_cgnr** out) {
+static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r, void* p, void* v, int64_t ldv,
+                                rls_cgnr** out) {
   if (!op) return RLS_E_INVALID;
-  if (!x || !r || !p || !v || !out) return rls_fail(op->ctx, RLS_E_INVALID, "cgnr_create: null pointer");
-  RLS_HIP(op->ctx, hipSetDevice(op->ctx->device));
+  rls_ctx* ctx = op->ctx;
+  if (!x || !r || !p || !v || !out || nrhs < 1 || ldv < op->N)
+    return rls_fail(ctx, RLS_E_INVALID, "cgnr_create: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (nrhs > 1 && !(op->slab && !op->G))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR needs the one-pass register-slab operator (shape/alignment)");
   rls_cgnr* s = new rls_cgnr();
   s->op = op;
-  s->device = op->ctx->device;
+  s->device = ctx->device;
   s->x = x;
   s->r = r;
   s->p = p;
@@ -798,27 +809,46 @@ int32_t rls_cgnr_create(rls_operator* op, void* x, void* r, void* p, void* v, rl
   s->r1 = s->p1 = nullptr;
   s->dots = nullptr;
   s->scn = nullptr;
-  int32_t st = alloc_scalars(op->ctx, &s->sc, &s->sc_h);
-  if (st != 0) {
-    delete s;
-    return st;
-  }
-  if (op->slab) {  // scratch of the fused pipeline
-    const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
-    const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double);
-    hipError_t e = hipMalloc(&s->r1, vb);
+  s->sc = nullptr;
+  s->sc_h = nullptr;
+  s->nrhs = nrhs;
+  s->ldv = ldv;
+  s->slab_b = nullptr;
+  const size_t sb = sizeof(cgnr_scalars) * (size_t)nrhs;
+  hipError_t e = hipMalloc((void**)&s->sc, sb);
+  if (e == hipSuccess) e = hipMemset(s->sc, 0, sb);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&s->sc_h, sb, hipHostMallocDefault);
+  if (e == hipSuccess) memset(s->sc_h, 0, sb);
+  if (e == hipSuccess && op->slab) {  // scratch of the fused pipeline
+    const size_t vb = (size_t)ldv * nrhs * rls_elem_size(op->dtype);
+    const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double) * nrhs;
+    e = hipMalloc(&s->r1, vb);
     if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
+    if (e == hipSuccess) e = hipMemset(s->r1, 0, vb);
+    if (e == hipSuccess) e = hipMemset(s->p1, 0, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&s->dots, nd);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sb);
     if (e == hipSuccess) e = hipMemset(s->dots, 0, nd);
-    if (e == hipSuccess) e = hipMemset(s->scn, 0, sizeof(cgnr_scalars));
-    if (e != hipSuccess) {
-      rls_cgnr_destroy(s);
-      return rls_fail(op->ctx, (int32_t)e, "cgnr_create: hipMalloc failed");
-    }
+    if (e == hipSuccess) e = hipMemset(s->scn, 0, sb);
+    if (e == hipSuccess && nrhs > 1)
+      e = hipMalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
+  }
+  if (e != hipSuccess) {
+    rls_cgnr_destroy(s);
+    return rls_fail(ctx, (int32_t)e, "cgnr_create: allocation failed");
   }
   *out = s;
   return 0;
+}
+
+int32_t rls_cgnr_create(rls_operator* op, void* x, void* r, void* p, void* v, rls_cgnr** out) {
+  if (!op) return RLS_E_INVALID;
+  return cgnr_create_impl(op, 1, x, r, p, v, op->N, out);
+}
+
+int32_t rls_cgnr_create_batched(rls_operator* op, int32_t nrhs, void* X, void* R, void* P, void* V, int64_t ldv,
+                                rls_cgnr** out) {
+  return cgnr_create_impl(op, nrhs, X, R, P, V, ldv, out);
 }
 
 int32_t rls_cgnr_destroy(rls_cgnr* s) {
@@ -829,8 +859,9 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->p1) hipFree(s->p1);
   if (s->dots) hipFree(s->dots);
   if (s->scn) hipFree(s->scn);
-  hipFree(s->sc);
-  hipHostFree(s->sc_h);
+  if (s->slab_b) hipFree(s->slab_b);
+  if (s->sc) hipFree(s->sc);
+  if (s->sc_h) hipHostFree(s->sc_h);
   delete s;
   return 0;
 }
@@ -840,6 +871,7 @@ int32_t rls_cgnr_init_local_a(rls_cgnr* s, const void* b, float lambda, float re
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
   if (!b) return rls_fail(ctx, RLS_E_INVALID, "cgnr_init: null b");
+  if (s->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "cgnr_init on a batched plan: use rls_cgnr_init_batched");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   // r = A^H b   (initCGNR, src/CGNR.jl:132) ; without A, b already is A^H b (:134)
   if (op->A)
@@ -869,6 +901,58 @@ int32_t rls_cgnr_init(rls_cgnr* s, const void* b, float lambda, float rel_tol, i
   return rls_cgnr_init_local_b(s);
 }
 
+int32_t rls_cgnr_init_batched(rls_cgnr* s, const void* B, int64_t ldb, float lambda, float rel_tol, int32_t iterations) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (!B || !op->A || ldb < op->M) return rls_fail(ctx, RLS_E_INVALID, "cgnr_init_batched: bad argument");
+  if (!cgnr_use_pipeline(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr_init_batched: fused pipeline not active");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t es = rls_elem_size(op->dtype);
+  const int max_iter = cgnr_effective_iterations(s, iterations);
+  for (int b = 0; b < s->nrhs; ++b) {
+    char* rb = (char*)s->r + (size_t)b * s->ldv * es;
+    RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda,
+                            (const char*)B + (size_t)b * ldb * es, 0.f, 0.f, rb, nullptr));
+    char* xb = (char*)s->x + (size_t)b * s->ldv * es;
+    char* pb = (char*)s->p + (size_t)b * s->ldv * es;
+    char* vb = (char*)s->v + (size_t)b * s->ldv * es;
+    if (op->dtype == RLS_F32)
+      hipLaunchKernelGGL(cgnr_init_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)xb,
+                         (const float*)rb, (float*)pb, (float*)vb, op->N, s->sc + b, lambda, rel_tol, max_iter);
+    else
+      hipLaunchKernelGGL(cgnr_init_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)xb,
+                         (const float2*)rb, (float2*)pb, (float2*)vb, op->N, s->sc + b, lambda, rel_tol, max_iter);
+  }
+  s->sc_h->lambda = lambda;
+  s->sc_h->rel_tol = rel_tol;
+  s->sc_h->max_iter = max_iter;
+  s->initialised = true;
+  return launch_status(ctx);
+}
+
+int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipMemcpyAsync(s->sc_h, s->sc, sizeof(cgnr_scalars) * (size_t)s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < s->nrhs; ++b) {
+    const cgnr_scalars& h = s->sc_h[b];
+    out[b].iteration = h.iteration;
+    out[b].done = h.done;
+    out[b].alpha_re = (float)h.alpha_re;
+    out[b].alpha_im = (float)h.alpha_im;
+    out[b].beta_re = (float)h.beta_re;
+    out[b].beta_im = (float)h.beta_im;
+    out[b].zeta = (float)h.zeta;
+    out[b].residual = (float)sqrt(h.rr);
+    out[b].z0 = (float)h.z0;
+  }
+  return 0;
+}
+
 int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
@@ -888,6 +972,7 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
     RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
     return rls_cgnr_pipe_finish(ctx, dtype, P);
   }
+  if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR: fused pipeline switched off");
   if (s->graph.steps && s->graph.mode != 0) {
     hipGraphExecDestroy(s->graph.exec);
     s->graph = step_graph();

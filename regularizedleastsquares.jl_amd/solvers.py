@@ -80,6 +80,8 @@ def solverstate(solver):
 
 def solversolution(obj):
     st = obj.state if isinstance(obj, AbstractLinearSolver) else obj
+    if isinstance(st, BatchedState):
+        return st.solutions()
     if isinstance(st, AbstractMatrixSolverState):
         return [solversolution(s) for s in st.states]  # hcat of columns (src/MultiThreading.jl:79)
     return st.x
@@ -153,7 +155,10 @@ class CGNR(AbstractLinearSolver):
         self.state = CGNRState(relTol)
 
     def _new_state(self):
-        return CGNRState(self.state.relTol if not isinstance(self.state, AbstractMatrixSolverState) else self.state.states[0].relTol)
+        st = self.state
+        if isinstance(st, AbstractMatrixSolverState) and not isinstance(st, BatchedState):
+            st = st.states[0]
+        return CGNRState(st.relTol)
 
     def init_(self, state: CGNRState, b: DeviceVector, x0=0):
         """init!(solver, state, b; x0 = 0)  src/CGNR.jl:91-130"""
@@ -734,6 +739,50 @@ class MultiThreadingState(AbstractMatrixSolverState):
     context's queue; across GPUs, columns are sharded one set per device (multigpu.MultiSolve)."""
 
 
+class BatchedState(AbstractMatrixSolverState):
+    """Backend-specific scheduler for matrix right-hand sides: the K columns advance TOGETHER and share
+    one pass over A per iteration (rls_cgnr_*_batched).  Same semantics as MultiThreadingState --
+    independent per-column scalars and per-column retirement -- so results are those of column-by-column
+    solves.  Solvers / shapes the fused batched plan does not cover fall back to MultiThreadingState."""
+
+    def __init__(self, solver, B: DeviceMatrix):
+        self.states = []
+        self.active = [True] * B.N
+        self.solver = solver
+        self.K = B.N
+        op = solver._op
+        ctx = B.ctx
+        N = op.N
+        self.X, self.R, self.P, self.V = (DeviceMatrix(N, B.N, B.dtype, ctx) for _ in range(4))
+        lib, h = ctx.lib, ctx.handle
+        plan = C.c_void_p()
+        check(h, lib.rls_cgnr_create_batched(op.handle, B.N, self.X.ptr, self.R.ptr, self.P.ptr, self.V.ptr, N,
+                                             C.byref(plan)), "rls_cgnr_create_batched")
+        self._plan = plan
+        self._keep = (op, ctx)
+        self.iteration = 0
+
+    def status(self):
+        st = (CgnrStatus * self.K)()
+        ctx = self.X.ctx
+        check(ctx.handle, ctx.lib.rls_cgnr_get_status_batched(self._plan, st), "rls_cgnr_get_status_batched")
+        return list(st)
+
+    def convergence(self):
+        return [{"residual": s.residual} for s in self.status()]
+
+    def solutions(self) -> List[DeviceVector]:
+        return [self.X.column(j) for j in range(self.K)]
+
+    def __del__(self):
+        try:
+            if self._plan and self.X.ctx.handle:
+                self.X.ctx.lib.rls_cgnr_destroy(self._plan)
+        except Exception:
+            pass
+        self._plan = None
+
+
 def _columns(b) -> List[DeviceVector]:
     if isinstance(b, DeviceMatrix):
         return [b.column(j) for j in range(b.N)]
@@ -748,10 +797,29 @@ def _columns(b) -> List[DeviceVector]:
 def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
     """init!(solver, b; kwargs...)   src/RegularizedLeastSquares.jl:190, src/MultiThreading.jl:30-43"""
     if isinstance(b, DeviceVector):
-        if isinstance(solver.state, AbstractMatrixSolverState):
+        if isinstance(solver.state, BatchedState):
+            solver.state = CGNRState(solver.state.relTol)
+        elif isinstance(solver.state, AbstractMatrixSolverState):
             solver.state = solver.state.states[0]  # :39-43
         solver.init_(solver.state, b, **kw)
         return
+    if scheduler is BatchedState:
+        if isinstance(solver, CGNR) and isinstance(b, DeviceMatrix) and b.N > 1 and not solver.constr:
+            try:
+                st = BatchedState(solver, b)
+                lib, h = b.ctx.lib, b.ctx.handle
+                relTol = (solver.state.states[0] if isinstance(solver.state, AbstractMatrixSolverState) and solver.state.states
+                          else solver.state).relTol if not isinstance(solver.state, BatchedState) else solver.state.relTol
+                st.relTol = relTol
+                check(h, lib.rls_cgnr_init_batched(st._plan, b.ptr, b.lda, float(solver.L2.lam), float(relTol),
+                                                   solver.iterations), "rls_cgnr_init_batched")
+                solver.state = st
+                return
+            except _lib.RLSError:
+                pass  # shape not covered by the one-pass kernel: independent per-column plans instead
+        scheduler = MultiThreadingState
+    if isinstance(solver.state, BatchedState):
+        solver.state = CGNRState(solver.state.relTol)
     cols = _columns(b)
     states = [solver._new_state() for _ in cols]  # deep copies of the state  :45-48
     solver.state = scheduler(states)
@@ -763,6 +831,16 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
 def iterate(solver: AbstractLinearSolver):
     """iterate(solver)   src/RegularizedLeastSquares.jl:191, src/MultiThreading.jl:52-78"""
     st = solver.state
+    if isinstance(st, BatchedState):
+        stat = st.status()
+        st.active = [not s_.done for s_ in stat]
+        if not any(st.active):
+            return None
+        if st.iteration > solver.iterations + 1:
+            raise _lib.RLSError("batched CGNR: a column did not reach done() within `iterations` steps")
+        check(st.X.ctx.handle, st.X.ctx.lib.rls_cgnr_step(st._plan, 1), "rls_cgnr_step")
+        st.iteration += 1
+        return st.active, st
     if isinstance(st, AbstractMatrixSolverState):
         idx = [i for i, a in enumerate(st.active) if a]
         if not idx:
@@ -786,6 +864,12 @@ def solve_(solver: AbstractLinearSolver, b, callbacks=None, **kw):
     init_(solver, b, **kw)
     for cb in cbs:
         cb(solver, 0)
+    if not cbs and isinstance(solver.state, BatchedState):
+        st = solver.state
+        check(st.X.ctx.handle, st.X.ctx.lib.rls_cgnr_step(st._plan, min(solver.iterations, solver._op.N)), "rls_cgnr_step")
+        while iterate(solver) is not None:  # normally returns None at once
+            pass
+        return solversolution(solver)
     if not cbs:
         st = solver.state
         for s in (st.states if isinstance(st, AbstractMatrixSolverState) else [st]):

@@ -527,3 +527,31 @@ def test_multisolve_single_rank(rls, ctx):
     ms = rls.MultiSolve(rls, lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=64))
     got = ms.solve(B)
     assert got.shape == (64, 5) and rel(got, X) < 1e-3
+
+
+@pytest.mark.parametrize("dt,M,N,K", [(np.complex64, 4096, 2048, 8), (np.float32, 512, 256, 3), (np.complex64, 96, 40, 5)])
+def test_batched_matrix_rhs_shares_one_pass_over_A(rls, ctx, dt, M, N, K):
+    """BatchedState: K right-hand sides per pass over A == column-by-column solves (and the oracle),
+    including columns that retire early (relTol) while others continue"""
+    A, X, B = O.make_problem(M, N, dt, 23, n_rhs=K)
+    B = np.asfortranarray(B)
+    B[:, 0] *= 1e-3  # different scales: per-column scalars must stay independent
+    Ad = rls.DeviceMatrix.from_host(A)
+    iters = 12
+    for relTol in (0.0, 1e-4):
+        S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=relTol)
+        xs = rls.solve_(S, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
+        its = [s_.iteration for s_ in S.state.status()] if isinstance(S.state, rls.BatchedState) else None
+        dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+        for j in range(K):
+            ref = O.CGNR(A.astype(dt64), reg=O.L2Regularization(1e-3), iterations=iters, relTol=relTol)
+            O.solve(ref, B[:, j].astype(dt64))
+            assert rel(xs[j].to_host(), ref.x) < 2e-5, (relTol, j)
+            if its is not None:
+                assert abs(its[j] - ref.iteration) <= (1 if relTol > 0 else 0), (its, j, ref.iteration)
+    # a vector solve still works afterwards (src/MultiThreading.jl:39-43)
+    S2 = rls.createLinearSolver(rls.CGNR, Ad, iterations=iters, relTol=0.0)
+    rls.solve_(S2, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
+    v = rls.solve_(S2, rls.DeviceVector.from_host(B[:, 1])).to_host()
+    ref = O.CGNR(A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64), iterations=iters, relTol=0.0)
+    assert rel(v, O.solve(ref, B[:, 1].astype(ref.dtype))) < 2e-5
