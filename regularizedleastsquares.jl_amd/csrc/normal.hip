@@ -583,6 +583,218 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const E* __restrict__ 
   }
 }
 
+// ---- FISTA pipeline: iteration = K_A (previous gradient/prox/momentum update + one pass over A) + K_R --
+// src/FISTA.jl:153-180 for the elements one thread owns, plus the NEXT iteration's Nesterov step (:144-148).
+// Every workgroup runs it redundantly (same inputs, same summation order => identical scalars).
+template <typename E, int EPT, int NT>
+__device__ static inline bool fista_update_elems(const fista_scalars& S, const E (&raw)[EPT], const E (&x0v)[EPT],
+                                                 const E (&yv)[EPT], const E (&xk)[EPT], int64_t N, double* red,
+                                                 E (&ri)[EPT], E (&xn)[EPT], E (&yn)[EPT], fista_scalars& Sn) {
+  const int tid = threadIdx.x;
+  const float rho = S.rho, thr = S.rho * S.lambda;  // prox!(reg, x, rho * lambda(reg))        :164
+  double rn = 0.0, d = 0.0, zero = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * NT;
+    E r = elem<E>::sub(raw[e], x0v[e]);                                   // res .-= x0      :153
+    E xv = elem<E>::sub(yv[e], elem<E>::scale(rho, r));                   // x .-= rho .* res :154
+    xv = fista_proj_elem<E>(fista_prox_elem<E>(xv, S.reg_kind, thr), S.proj_kind);
+    if (i >= N) {
+      r = elem<E>::zero();
+      xv = elem<E>::zero();
+    }
+    ri[e] = r;
+    xn[e] = xv;
+    rn += (double)elem<E>::re(r) * (double)elem<E>::re(r) + (double)elem<E>::im(r) * (double)elem<E>::im(r);
+    const E df = elem<E>::sub(xv, xk[e]);
+    d += (double)elem<E>::re(r) * (double)elem<E>::re(df) + (double)elem<E>::im(r) * (double)elem<E>::im(df);
+  }
+  block_sum3(rn, d, zero, red);
+  float theta = S.theta;
+  if (S.restart && d > 0.0) theta = 1.f;                                  // gradient restart  :171-176
+  const float theta_old = theta;                                          // :179
+  theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;         // :180
+  const double res_norm = sqrt(rn);
+  const float rel = (float)(res_norm / S.norm_x0);                        // :156
+  const int done = (rel < S.rel_tol) || (S.iteration + 1 >= S.max_iter);  // :187-189
+  const float c1 = (1.f - theta_old) / theta, c2 = (theta_old - 1.f) / theta + 1.f;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) yn[e] = elem<E>::add(elem<E>::scale(c1, xk[e]), elem<E>::scale(c2, xn[e]));
+  Sn = S;
+  Sn.res_norm = res_norm;
+  Sn.rel_res_norm = (double)rel;
+  Sn.theta = theta;
+  Sn.theta_old = theta_old;
+  Sn.iteration = S.iteration + 1;
+  Sn.done = done;
+  return done != 0;
+}
+
+template <typename E, int G, int K, int WV, bool FULL>
+__global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
+                                                                const E* __restrict__ x0, E* __restrict__ res, E* y0,
+                                                                E* y1, const E* __restrict__ res_raw,
+                                                                E* __restrict__ slab,
+                                                                const fista_scalars* __restrict__ sc,
+                                                                fista_scalars* __restrict__ scn, int64_t Mc, int64_t N,
+                                                                int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int EPT = C::EPT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
+  const int tid = threadIdx.x;
+  const bool writer = blockIdx.x == 0;
+  // small loads first (both candidates of every ping-pong pair), barrier, then the slab: see K_A of CGNR
+  E raw[EPT], x0v[EPT], ya[EPT], yb[EPT], ba[EPT], bb[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    const int64_t ic = i < N ? i : (N - 1);
+    raw[e] = res_raw[ic];
+    x0v[e] = x0[ic];
+    ya[e] = y0[ic];
+    yb[e] = y1[ic];
+    ba[e] = b0[ic];
+    bb[e] = b1[ic];
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, C::NV> a[K];
+  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  const fista_scalars S = *sc;
+  if (S.done) {
+    if (writer && tid == 0) {
+      fista_scalars Sn = S;
+      Sn.fresh = 0;
+      *scn = Sn;
+    }
+    return;
+  }
+  E yv[EPT], xk[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    yv[e] = S.ycur ? yb[e] : ya[e];
+    xk[e] = (S.iteration & 1) ? bb[e] : ba[e];  // state.x == buf[iteration & 1]
+    if (i >= N) yv[e] = elem<E>::zero();
+  }
+  fista_scalars Sn;
+  if (S.pending) {
+    E ri[EPT], xn[EPT], yn[EPT];
+    const bool done = fista_update_elems<E, EPT, C::NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    if (writer) {
+      E* xw = (S.iteration & 1) ? b0 : b1;  // the reference's pointer swap: new x goes where x_{k-1} was
+      E* yw = S.ycur ? y0 : y1;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        if (i < N) {
+          xw[i] = xn[e];
+          res[i] = ri[e];
+          if (!done) yw[i] = yn[e];
+        }
+      }
+    }
+    Sn.ycur = done ? S.ycur : 1 - S.ycur;
+    Sn.pending = done ? 0 : 1;
+    Sn.fresh = done ? 0 : 1;
+    if (writer && tid == 0) *scn = Sn;
+    if (done) return;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = yn[e];
+    }
+  } else {
+    Sn = S;
+    Sn.pending = 1;
+    Sn.fresh = 1;
+    if (writer && tid == 0) *scn = Sn;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = yv[e];
+    }
+  }
+  slab_finish<E, G, K, WV, FULL>(a, L, slab, Mc, N, pair);
+}
+
+// K_R of FISTA: res_raw = sum of the slab rows (fixed order) + commit of the staged scalars
+template <typename E>
+__global__ __launch_bounds__(1024) void fista_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
+                                                            E* __restrict__ res_raw, fista_scalars* __restrict__ sc,
+                                                            const fista_scalars* __restrict__ scn) {
+  const fista_scalars Sn = *scn;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    fista_scalars c = Sn;
+    c.fresh = 0;
+    *sc = c;
+  }
+  if (!Sn.fresh) return;
+  __shared__ E sm[64][16];
+  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;
+  const int64_t j = (int64_t)blockIdx.x * 16 + cx;
+  const int64_t jc = j < N ? j : (N - 1);
+  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
+  int wgi = wy;
+  for (; wgi + ny < nwg; wgi += 2 * ny) {
+    s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
+    s1 = elem<E>::add(s1, slab[(int64_t)(wgi + ny) * N + jc]);
+  }
+  if (wgi < nwg) s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
+  sm[wy][cx] = elem<E>::add(s0, s1);
+  __syncthreads();
+  if (wy == 0 && j < N) {
+    E t = elem<E>::zero();
+    for (int i = 0; i < ny; ++i) t = elem<E>::add(t, sm[i][cx]);
+    res_raw[j] = t;
+  }
+}
+
+// K_F of FISTA: apply a pending update (single workgroup)
+template <typename E, int EPT>
+__global__ __launch_bounds__(FIN_THREADS) void fista_pipe_f_kernel(E* b0, E* b1, const E* __restrict__ x0,
+                                                                    E* __restrict__ res, E* y0, E* y1,
+                                                                    const E* __restrict__ res_raw,
+                                                                    fista_scalars* __restrict__ sc, int64_t N) {
+  __shared__ double red[48];
+  const fista_scalars S = *sc;
+  if (!S.pending || S.done) return;
+  const int tid = threadIdx.x;
+  const E* yc = S.ycur ? y1 : y0;
+  const E* xc = (S.iteration & 1) ? b1 : b0;
+  E raw[EPT], x0v[EPT], yv[EPT], xk[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * FIN_THREADS;
+    const int64_t ic = i < N ? i : (N - 1);
+    raw[e] = res_raw[ic];
+    x0v[e] = x0[ic];
+    yv[e] = yc[ic];
+    xk[e] = xc[ic];
+  }
+  E ri[EPT], xn[EPT], yn[EPT];
+  fista_scalars Sn;
+  const bool done = fista_update_elems<E, EPT, FIN_THREADS>(S, raw, x0v, yv, xk, N, red, ri, xn, yn, Sn);
+  E* xw = (S.iteration & 1) ? b0 : b1;
+  E* yw = S.ycur ? y0 : y1;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * FIN_THREADS;
+    if (i < N) {
+      xw[i] = xn[e];
+      res[i] = ri[e];
+      if (!done) yw[i] = yn[e];
+    }
+  }
+  Sn.ycur = done ? S.ycur : 1 - S.ycur;
+  Sn.pending = 0;
+  Sn.fresh = 0;
+  __syncthreads();
+  if (tid == 0) *sc = Sn;
+}
+
 struct fused_cfg {
   int G, K, WV;
 };
@@ -747,7 +959,64 @@ static int32_t pipe_finish_typed(rls_ctx* ctx, const rls_cgnr_pipe& P) {
   return launch_status(ctx);
 }
 
+template <typename E, int G, int K, int WV>
+static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg) {
+  using C = slab_cfg<E, G, K, WV>;
+  const int64_t Mc = P.M / C::NV;
+  const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+  constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true>, lds);
+    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false>, lds);
+    attr_set = true;
+  }
+#define RLS_LAUNCH_FA(FULLV)                                                                                       \
+  hipLaunchKernelGGL((fista_pipe_a_kernel<E, G, K, WV, FULLV>), dim3(nwg), dim3(C::NT), lds, ctx->stream,           \
+                     (const E*)P.A, P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1,      \
+                     (const E*)P.res_raw, (E*)P.slab, P.sc, P.scn, Mc, P.N, pair)
+  if (P.N == C::NMAX && (int64_t)nwg * G == Mc) RLS_LAUNCH_FA(true);
+  else RLS_LAUNCH_FA(false);
+#undef RLS_LAUNCH_FA
+}
+
+template <typename E>
+static int32_t fista_iteration_typed(rls_ctx* ctx, const rls_fista_pipe& P) {
+  fused_cfg c;
+  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista pipeline: N too large");
+  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+#define RLS_FISTA_CASE(GG, KK, WW) \
+  if (c.G == GG && c.K == KK && c.WV == WW) launch_fista_a<E, GG, KK, WW>(ctx, P, nwg);
+  RLS_FOR_EACH_CFG(RLS_FISTA_CASE)
+#undef RLS_FISTA_CASE
+  hipLaunchKernelGGL(fista_pipe_r_kernel<E>, dim3((unsigned)((P.N + 15) / 16)), dim3(g_red_threads), 0, ctx->stream,
+                     (const E*)P.slab, nwg, P.N, (E*)P.res_raw, P.sc, P.scn);
+  return launch_status(ctx);
+}
+
+template <typename E>
+static int32_t fista_finish_typed(rls_ctx* ctx, const rls_fista_pipe& P) {
+  const int ept = (int)((P.N + FIN_THREADS - 1) / FIN_THREADS);
+#define RLS_FFIN_CASE(EE)                                                                                        \
+  hipLaunchKernelGGL((fista_pipe_f_kernel<E, EE>), dim3(1), dim3(FIN_THREADS), 0, ctx->stream, (E*)P.b0, (E*)P.b1, \
+                     (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (const E*)P.res_raw, P.sc, P.N)
+  if (ept <= 1) RLS_FFIN_CASE(1);
+  else if (ept <= 2) RLS_FFIN_CASE(2);
+  else RLS_FFIN_CASE(4);
+#undef RLS_FFIN_CASE
+  return launch_status(ctx);
+}
+
 }  // namespace
+
+int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P) {
+  if (dtype == RLS_F32) return fista_iteration_typed<float>(ctx, P);
+  return fista_iteration_typed<float2>(ctx, P);
+}
+int32_t rls_fista_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P) {
+  if (dtype == RLS_F32) return fista_finish_typed<float>(ctx, P);
+  return fista_finish_typed<float2>(ctx, P);
+}
 
 void rls_normal_force_group(int g) { g_force_g = g; }
 void rls_normal_force_waves(int wv) { g_force_wv = wv; }

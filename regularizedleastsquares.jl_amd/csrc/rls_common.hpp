@@ -211,6 +211,31 @@ __device__ static inline void block_sum3(double& a, double& b, double& c, double
   c = sc;
 }
 
+// elementwise prox / projection used by the fused FISTA updates (src/proximalMaps/ProxL1.jl:18-22,
+// ProxL2.jl:18-21, src/Utils.jl:114-144); kinds are the RLS_REG_* / RLS_PROJ_* codes of the C ABI
+template <typename E>
+__device__ static inline E fista_prox_elem(E v, int reg_kind, float thr) {
+  if (reg_kind == RLS_REG_L1) {
+    const float eps = 1.1920929e-07f;
+    const float a = elem<E>::absv(v);
+    const float sh = fmaxf(a - thr, 0.f);
+    const float den = a + eps;
+    return elem<E>::make((sh * (elem<E>::re(v) + eps)) / den, (sh * elem<E>::im(v)) / den);
+  }
+  if (reg_kind == RLS_REG_L2) {
+    const double f = 1.0 / (1.0 + 2.0 * (double)thr);
+    return elem<E>::make((float)((double)elem<E>::re(v) * f), (float)((double)elem<E>::im(v) * f));
+  }
+  return v;
+}
+template <typename E>
+__device__ static inline E fista_proj_elem(E v, int proj_kind) {
+  if (proj_kind == RLS_PROJ_NONE) return v;
+  float re = elem<E>::re(v);
+  if (proj_kind == RLS_PROJ_POSITIVE && re < 0.f) re = 0.f;
+  return elem<E>::make(re, 0.f);
+}
+
 // 16-byte (or element-sized) register chunks of a matrix column
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -253,6 +278,30 @@ struct cgnr_scalars {
   int cur;       // which (r, p) pair is current: 0 = the caller's vectors, 1 = the plan's scratch
   int fresh;     // staging copy only: this round's K_A produced slab partials
 };
+
+// device-resident FISTA scalars (src/FISTA.jl:15-27) plus the state of the fused pipeline
+struct fista_scalars {
+  double norm_x0, res_norm, rel_res_norm;
+  float rho, theta, theta_old, rel_tol, lambda;
+  int iteration, max_iter, done, restart, reg_kind, proj_kind;
+  long long l21_slices;
+  int pending;  // res_raw = AHA y[ycur] is computed; the gradient/prox update is not applied yet
+  int ycur;     // which extrapolated-point buffer is current
+  int fresh;    // staging copy only
+};
+
+// everything the FISTA pipeline kernels need (normal.hip)
+struct rls_fista_pipe {
+  const void* A;
+  int64_t lda, M, N;
+  void *b0, *b1;        // x / xold (caller's), swapped by iteration parity
+  void *x0, *res;       // A^H b ; state.res (caller's)
+  void *y0, *y1;        // extrapolated point, ping-pong (plan scratch)
+  void *res_raw, *slab; // AHA y before "- x0" ; per-workgroup partial rows
+  fista_scalars *sc, *scn;
+};
+int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
+int32_t rls_fista_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
 
 // everything the CGNR pipeline kernels need (normal.hip)
 struct rls_cgnr_pipe {

@@ -265,19 +265,15 @@ static int32_t cgnr_effective_iterations(rls_cgnr* s, int32_t iterations) {
 // ---------------------------------------------------------------------------------------------
 // FISTA
 // ---------------------------------------------------------------------------------------------
-struct fista_scalars {
-  double norm_x0, res_norm, rel_res_norm;
-  float rho, theta, theta_old, rel_tol, lambda;
-  int iteration, max_iter, done, restart, reg_kind, proj_kind;
-  long long l21_slices;
-};
-
 struct rls_fista {
   rls_operator* op;
   int device;
   void* buf[2];  // x / xold, swapped by iteration parity: state.x == buf[iteration & 1]
   void *x0, *res;
   void* y;       // extrapolated point (plan-owned), the GEMV input
+  void *y1, *res_raw;  // fused pipeline: second extrapolated-point buffer, AHA y before "- x0"
+  fista_scalars* scn;  // staged scalars
+  bool use_pipe;
   fista_scalars* sc;
   fista_scalars* sc_h;
   step_graph graph;
@@ -286,29 +282,6 @@ struct rls_fista {
   int64_t l21_slices;
   bool initialised;
 };
-
-template <typename E>
-__device__ static inline E fista_prox_elem(E v, int reg_kind, float thr) {
-  if (reg_kind == RLS_REG_L1) {
-    const float eps = 1.1920929e-07f;
-    const float a = elem<E>::absv(v);
-    const float sh = fmaxf(a - thr, 0.f);
-    const float den = a + eps;
-    return elem<E>::make((sh * (elem<E>::re(v) + eps)) / den, (sh * elem<E>::im(v)) / den);
-  }
-  if (reg_kind == RLS_REG_L2) {
-    const double f = 1.0 / (1.0 + 2.0 * (double)thr);
-    return elem<E>::make((float)((double)elem<E>::re(v) * f), (float)((double)elem<E>::im(v) * f));
-  }
-  return v;
-}
-template <typename E>
-__device__ static inline E fista_proj_elem(E v, int proj_kind) {
-  if (proj_kind == RLS_PROJ_NONE) return v;
-  float re = elem<E>::re(v);
-  if (proj_kind == RLS_PROJ_POSITIVE && re < 0.f) re = 0.f;
-  return elem<E>::make(re, 0.f);
-}
 
 // x0 = A^H b is already in place.  x = x_init (zero), xold = 0, res = Inf, y = x   (src/FISTA.jl:110-129)
 template <typename E>
@@ -346,6 +319,9 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__
     sc->reg_kind = reg_kind;
     sc->proj_kind = proj_kind;
     sc->l21_slices = slices;
+    sc->pending = 0;
+    sc->ycur = 0;
+    sc->fresh = 0;
   }
 }
 
@@ -417,6 +393,31 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
     sc->iteration = it + 1;
     sc->done = done;
   }
+}
+
+static bool fista_pipe_ok(const rls_fista* s) {
+  const rls_ctx* ctx = s->op->ctx;
+  return s->y1 && s->op->slab && !s->op->G && ctx->tune.fused_normal && ctx->tune.cgnr_pipeline &&
+         (s->reg_kind == RLS_REG_NONE || s->reg_kind == RLS_REG_L1 || s->reg_kind == RLS_REG_L2);
+}
+
+static rls_fista_pipe fista_pipe_desc(const rls_fista* s) {
+  rls_fista_pipe P;
+  P.A = s->op->A;
+  P.lda = s->op->lda;
+  P.M = s->op->M;
+  P.N = s->op->N;
+  P.b0 = s->buf[0];
+  P.b1 = s->buf[1];
+  P.x0 = s->x0;
+  P.res = s->res;
+  P.y0 = s->y;
+  P.y1 = s->y1;
+  P.res_raw = s->res_raw;
+  P.slab = s->op->slab;
+  P.sc = s->sc;
+  P.scn = s->scn;
+  return P;
 }
 
 static int32_t fista_enqueue_iteration(rls_fista* s) {
@@ -1071,14 +1072,33 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   s->lambda = 0.f;
   s->l21_slices = 1;
   s->initialised = false;
-  hipError_t e = hipMalloc(&s->y, (size_t)op->N * rls_elem_size(op->dtype));
+  s->y1 = s->res_raw = nullptr;
+  s->scn = nullptr;
+  s->use_pipe = false;
+  const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
+  hipError_t e = hipMalloc(&s->y, vb);
+  if (e == hipSuccess && op->slab) {
+    e = hipMalloc(&s->y1, vb);
+    if (e == hipSuccess) e = hipMalloc(&s->res_raw, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sizeof(fista_scalars));
+    if (e == hipSuccess) e = hipMemset(s->y1, 0, vb);
+    if (e == hipSuccess) e = hipMemset(s->res_raw, 0, vb);
+    if (e == hipSuccess) e = hipMemset(s->scn, 0, sizeof(fista_scalars));
+  }
   if (e != hipSuccess) {
+    if (s->y) hipFree(s->y);
+    if (s->y1) hipFree(s->y1);
+    if (s->res_raw) hipFree(s->res_raw);
+    if (s->scn) hipFree(s->scn);
     delete s;
     return rls_fail(ctx, (int32_t)e, "fista_create: hipMalloc failed");
   }
   int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
   if (st != 0) {
     hipFree(s->y);
+    if (s->y1) hipFree(s->y1);
+    if (s->res_raw) hipFree(s->res_raw);
+    if (s->scn) hipFree(s->scn);
     delete s;
     return st;
   }
@@ -1091,6 +1111,9 @@ int32_t rls_fista_destroy(rls_fista* s) {
   hipSetDevice(s->device);
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
   hipFree(s->y);
+  if (s->y1) hipFree(s->y1);
+  if (s->res_raw) hipFree(s->res_raw);
+  if (s->scn) hipFree(s->scn);
   hipFree(s->sc);
   hipHostFree(s->sc_h);
   delete s;
@@ -1135,6 +1158,12 @@ int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, floa
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
                        (long long)s->l21_slices);
   s->initialised = true;
+  const bool pipe = fista_pipe_ok(s);
+  if (pipe != s->use_pipe && s->graph.exec) {  // the captured kernel sequence belongs to the other mode
+    hipGraphExecDestroy(s->graph.exec);
+    s->graph = step_graph();
+  }
+  s->use_pipe = pipe;
   return launch_status(ctx);
 }
 
@@ -1157,6 +1186,14 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_step before fista_init");
   if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "fista_step: n_steps < 0");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->use_pipe) {
+    // iteration k = K_A (applies the gradient/prox/momentum update k-1 in its prologue, then one pass
+    // over A for AHA y) + K_R (sums the partial rows); the last update of this call is applied by K_F
+    const rls_fista_pipe P = fista_pipe_desc(s);
+    const int32_t dtype = s->op->dtype;
+    RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P]() { return rls_fista_pipe_iteration(ctx, dtype, P); }));
+    return rls_fista_pipe_finish(ctx, dtype, P);
+  }
   return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_iteration(s); });
 }
 
