@@ -849,3 +849,247 @@ def make_problem(M, N, dtype, seed, n_rhs=None):
     x64 = draw(*xs)
     b64 = A64 @ x64
     return np.asfortranarray(A64.astype(dt)), x64.astype(dt), np.asfortranarray(b64.astype(dt))
+
+
+# --------------------------------------------------------------------------------------
+# next-tier solvers: OptISTA, POGM, SplitBregman -- same op mix as FISTA / ADMM
+# --------------------------------------------------------------------------------------
+
+
+class OptISTA:
+    """src/OptISTA.jl:61-110 (ctor), :129-160 (init!), :169-209 (iterate)"""
+
+    def __init__(self, A, AHA=None, reg=None, iterations=50, rho=None, theta=1, relTol=None, normal="matrixfree"):
+        self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        if AHA is None:
+            AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
+        elif not hasattr(AHA, "mul"):
+            AHA = GramOp(AHA=AHA)
+        self.AHA = AHA
+        self.dtype = np.dtype(AHA.dtype)
+        self.T = real_dtype(self.dtype).type
+        regs = [L1Regularization(0.0)] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
+        rest = [r for r in regs if not _is_projection(r)]
+        if len(rest) != 1:
+            raise ValueError(f"OptISTA does not allow for more additional regularization terms, found {len(rest)}")
+        self.reg = rest[0]
+        if rho is None:
+            raise ValueError("oracle OptISTA needs an explicit rho")
+        self.rho = self.T(rho)
+        self.iterations = int(iterations)
+        self.relTol = self.T(np.finfo(self.T).eps if relTol is None else relTol)
+        n = AHA.shape[1]
+        self.x, self.x0, self.y, self.z, self.zold, self.res = (np.zeros(n, self.dtype) for _ in range(6))
+        self.iteration = 0
+        self.rel_res_norm = self.T(np.inf)
+
+    def init(self, b, x0=0, theta=1):
+        T = self.T
+        b = np.asarray(b, dtype=self.dtype)
+        self.x0[:] = b if self.A is None else self.A.mul_adj(b)
+        self.norm_x0 = T(nrm2(self.x0))
+        self.x[:] = x0
+        self.y[:] = self.x
+        self.z[:] = self.x
+        self.zold[:] = self.x
+        self.res[:] = np.inf
+        self.theta = T(theta)
+        self.theta_old = T(theta)
+        tn = T(theta)
+        for _ in range(self.iterations - 1):
+            tn = (T(1) + np.sqrt(T(1) + T(4) * tn * tn)) / T(2)
+        self.theta_n = (T(1) + np.sqrt(T(1) + T(8) * tn * tn)) / T(2)
+        self.rel_res_norm = T(np.inf)
+        self.iteration = 0
+
+    def done(self):
+        return bool(self.rel_res_norm < self.relTol) or self.iteration >= self.iterations
+
+    def iterate(self):
+        if self.done():
+            return None
+        T = self.T
+        th, tn = self.theta, self.theta_n
+        self.gamma = T(2) * th / (tn * tn) * (tn * tn - T(2) * th * th + th)
+        self.theta_old = th
+        if self.iteration == self.iterations - 1:
+            self.theta = (T(1) + np.sqrt(T(1) + T(8) * th * th)) / T(2)
+        else:
+            self.theta = (T(1) + np.sqrt(T(1) + T(4) * th * th)) / T(2)
+        alpha = (self.theta_old - T(1)) / self.theta
+        beta = self.theta_old / self.theta
+        self.zold[:] = self.z
+        self.z[:] = self.y
+        self.res[:] = self.AHA.mul(self.x)
+        self.res -= self.x0
+        self.y -= (self.rho * self.gamma) * self.res
+        self.rel_res_norm = T(nrm2(self.res)) / self.norm_x0
+        self.reg.prox(self.y, self.rho * self.gamma * T(self.reg.lam))
+        self.z /= -self.gamma
+        self.z += self.x + self.y / self.gamma
+        self.x *= -beta
+        self.x += (T(1) + alpha + beta) * self.z
+        self.x -= alpha * self.zold
+        self.iteration += 1
+        return self.x
+
+    def solution(self):
+        return self.x
+
+
+class POGM:
+    """src/POGM.jl:75-110 (ctor), :133-160 (init!), :169-237 (iterate).  gamma is NOT reset by init!
+    (reference behaviour): it starts at 1 in a fresh solver and carries over between solves."""
+
+    def __init__(self, A, AHA=None, reg=None, iterations=50, rho=None, theta=1, sigma_fac=1, relTol=None,
+                 restart="none", normal="matrixfree"):
+        self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        if AHA is None:
+            AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
+        elif not hasattr(AHA, "mul"):
+            AHA = GramOp(AHA=AHA)
+        self.AHA = AHA
+        self.dtype = np.dtype(AHA.dtype)
+        self.T = real_dtype(self.dtype).type
+        regs = [L1Regularization(0.0)] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
+        self.proj = [r for r in regs if _is_projection(r)]
+        rest = [r for r in regs if not _is_projection(r)]
+        if len(rest) != 1:
+            raise ValueError(f"POGM does not allow for more additional regularization terms, found {len(rest)}")
+        self.reg = rest[0]
+        if rho is None:
+            raise ValueError("oracle POGM needs an explicit rho")
+        T = self.T
+        self.rho = T(rho)
+        self.sigma_fac = T(sigma_fac)
+        self.iterations = int(iterations)
+        self.relTol = T(np.finfo(T).eps if relTol is None else relTol)
+        self.restart = restart
+        n = AHA.shape[1]
+        self.x, self.x0, self.xold, self.y, self.z, self.w, self.res = (np.zeros(n, self.dtype) for _ in range(7))
+        self.gamma = T(1)
+        self.gamma_old = T(1)
+        self.sigma = T(1)
+        self.iteration = 0
+        self.rel_res_norm = T(np.inf)
+
+    def init(self, b, x0=0, theta=1):
+        T = self.T
+        b = np.asarray(b, dtype=self.dtype)
+        self.x0[:] = b if self.A is None else self.A.mul_adj(b)
+        self.norm_x0 = T(nrm2(self.x0))
+        self.x[:] = x0
+        self.xold[:] = 0
+        self.y[:] = 0
+        self.z[:] = 0
+        if self.restart != "none":
+            self.w[:] = 0
+        self.res[:] = np.inf
+        self.theta = T(theta)
+        self.theta_old = T(theta)
+        self.sigma = T(1)
+        self.rel_res_norm = T(np.inf)
+        self.iteration = 0
+
+    def done(self):
+        return bool(self.rel_res_norm < self.relTol) or self.iteration >= self.iterations
+
+    def iterate(self):
+        if self.done():
+            return None
+        T = self.T
+        self.xold[:] = self.x
+        self.res[:] = self.AHA.mul(self.x)
+        self.res -= self.x0
+        self.x -= self.rho * self.res
+        self.rel_res_norm = T(nrm2(self.res)) / self.norm_x0
+        self.theta_old = self.theta
+        if self.iteration == self.iterations - 1 and self.restart != "none":
+            self.theta = (T(1) + np.sqrt(T(1) + T(8) * self.theta_old ** 2)) / T(2)
+        else:
+            self.theta = (T(1) + np.sqrt(T(1) + T(4) * self.theta_old ** 2)) / T(2)
+        alpha = (self.theta_old - T(1)) / self.theta
+        beta = self.sigma * self.theta_old / self.theta
+        self.gamma_old = self.gamma
+        if self.restart == "gradient":
+            self.gamma = self.rho * (T(1) + alpha + beta)
+        else:
+            self.gamma = self.rho * (T(2) * self.theta_old + self.theta - T(1)) / self.theta
+        self.x, self.y = self.y, self.x  # swap
+        self.x *= -alpha
+        self.x += (T(1) + alpha + beta) * self.y
+        self.x -= (beta + self.rho * alpha / self.gamma_old) * self.xold
+        self.x += (self.rho * alpha / self.gamma_old) * self.z
+        self.z[:] = self.x
+        self.reg.prox(self.x, self.gamma * T(self.reg.lam))
+        for pr in self.proj:
+            pr.prox(self.x)
+        if self.restart == "gradient":
+            self.w += self.y + (self.rho / self.gamma) * (self.x - self.z)
+            if np.real((dotc(self.w, self.x) - dotc(self.w, self.z)) / self.gamma - dotc(self.w, self.res)) < 0:
+                self.sigma = T(1)
+                self.theta = T(1)
+            else:
+                self.sigma = self.sigma * self.sigma_fac
+            self.w[:] = (self.rho / self.gamma) * (self.z - self.x) - self.y
+        self.iteration += 1
+        return self.x
+
+    def solution(self):
+        return self.x
+
+
+class SplitBregman(ADMM):
+    """src/SplitBregman.jl:82-140 (ctor), :166-200 (init!), :204-271 (iterate), :273-282 (converged/done).
+    Shares ADMM's composite operator and cg!; prox threshold lambda/rho (no factor 2), Bregman update of
+    the right-hand side every iterationsInner inner iterations."""
+
+    def __init__(self, A, AHA=None, reg=None, regTrafo=None, rho=1e-1, iterations=10, iterationsInner=10,
+                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree"):
+        super().__init__(A, AHA=AHA, reg=reg, regTrafo=regTrafo, rho=rho, iterations=iterations,
+                         iterationsCG=iterationsCG, absTol=absTol, relTol=relTol, tolInner=tolInner, normal=normal)
+        self.iterationsInner = int(iterationsInner)
+        self.ybreg = np.zeros_like(self.x)
+
+    def init(self, b, x0=0):
+        super().init(b, x0=x0)
+        self.ybreg[:] = self.beta_y
+        self.iter_cnt = 1
+        self.iteration = 1
+
+    def done(self):
+        return self.converged() or (self.iteration == 1 and self.iter_cnt > self.iterations)
+
+    def iterate(self):
+        if self.done():
+            return None
+        T = self.T
+        self.beta[:] = self.beta_y
+        for i, t in enumerate(self.regTrafo):
+            self.beta += self.rho[i] * t.mul_adj(self.z[i])
+            self.beta += (-self.rho[i]) * t.mul_adj(self.u[i])
+        self.cg_iters.append(cg_inplace(self.x, self.composite_mul, self.beta, self.iterationsCG, self.tolInner))
+        for pr in self.proj:
+            pr.prox(self.x)
+        for i, t in enumerate(self.regTrafo):
+            self.z[i], self.zold[i] = self.zold[i], self.z[i]
+            self.z[i][:] = t.mul(self.x)
+            self.z[i] += self.u[i]
+            if self.rho[i] != 0:
+                self.reg[i].prox(self.z[i], T(self.reg[i].lam) / self.rho[i])
+            self.u[i] += t.mul(self.x)
+            self.u[i] -= self.z[i]
+            self.rk[i] = T(nrm2(t.mul(self.x) - self.z[i]))
+            self.sk[i] = T(nrm2(self.rho[i] * t.mul_adj(self.z[i] - self.zold[i])))
+            self.eps_pri[i] = max(T(nrm2(t.mul(self.x))), T(nrm2(self.z[i])))
+            self.eps_dua[i] = T(nrm2(self.rho[i] * t.mul_adj(self.u[i])))
+        if self.converged() or self.iteration >= self.iterationsInner:
+            self.beta_y += self.ybreg
+            self.beta_y -= self.AHA.mul(self.x)
+            for i, t in enumerate(self.regTrafo):
+                self.z[i][:] = t.mul(self.x)
+                self.u[i][:] = 0
+            self.iter_cnt += 1
+            self.iteration = 0
+        self.iteration += 1
+        return self.x

@@ -717,6 +717,305 @@ class ADMM(AbstractLinearSolver):
 
 
 # --------------------------------------------------------------------------------------------
+# next tier: OptISTA, POGM, SplitBregman -- re-sequencing of the same device kernels
+# --------------------------------------------------------------------------------------------
+
+
+def _default_rho(op):
+    """0.95 / power_iterations(AHA) with a NumPy-seeded start vector (the reference uses Julia's global RNG)"""
+    n = op.N
+    rng = np.random.default_rng()
+    v = rng.standard_normal(n).astype(np.float32)
+    if op.dtype.kind == "c":
+        v = (v + 1j * rng.standard_normal(n)).astype(np.complex64)
+    return 0.95 / power_iterations(_NormalApply(op), DeviceVector.from_host(v, op.ctx))
+
+
+def _split_regs(regs, name):
+    regs = _as_list(regs) or [L1Regularization(0.0)]
+    proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
+    rest = [r for r in regs if not isinstance(r, AbstractProjectionRegularization)]
+    if len(rest) != 1:
+        raise ValueError(f"{name} does not allow for more additional regularization terms, found {len(rest)}")
+    return rest[0], proj
+
+
+class _ProxGradState(AbstractSolverState):
+    def __init__(self, rho, theta, relTol, names):
+        self.rho = float(rho)
+        self.theta = self.thetaold = float(theta)
+        self.relTol = float(relTol)
+        self.iteration = 0
+        self.norm_x0 = 1.0
+        self.rel_res_norm = math.inf
+        self._names = names
+        for n in names:
+            setattr(self, n, None)
+
+    def _alloc(self, b, N):
+        if self.x is None or self.x.ctx is not b.ctx or self.x.dtype != b.dtype or self.x.n != N:
+            for n in self._names:
+                setattr(self, n, b.similar(N))
+
+    def convergence(self):
+        return {"residual": self.res.norm()}
+
+
+class OptISTA(AbstractLinearSolver):
+    """src/OptISTA.jl:61-110 (ctor), :129-160 (init!), :169-209 (iterate)"""
+
+    def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 50, verbose: bool = False,
+                 rho=None, theta=1, relTol=_EPS32):
+        self.A, self._op = _resolve_operator(A, AHA)
+        self.AHA = AHA if AHA is not None else self.A.normal_operator()
+        self.reg, self.proj = _split_regs(reg, "OptISTA")
+        self.reg = normalize(normalizeReg, [self.reg], self.A, None)[0]
+        self.normalizeReg = normalizeReg or NoNormalization()
+        self.verbose = bool(verbose)
+        self.iterations = int(iterations)
+        self.state = _ProxGradState(_default_rho(self._op) if rho is None else rho, theta, relTol,
+                                    ("x", "x0", "y", "z", "zold", "res"))
+
+    def _new_state(self):
+        s = self.state.states[0] if isinstance(self.state, AbstractMatrixSolverState) else self.state
+        return _ProxGradState(s.rho, 1.0, s.relTol, s._names)
+
+    def init_(self, st, b: DeviceVector, x0=0, theta=1):
+        f32 = np.float32
+        st._alloc(b, self._op.N)
+        if self.A is None:
+            st.x0.copy_from(b)
+        else:
+            self.A.mul_adj_(st.x0, b)
+        st.norm_x0 = st.x0.norm()
+        if np.isscalar(x0):
+            st.x.fill_(x0)
+        else:
+            st.x.copy_from(x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx))
+        for v in (st.y, st.z, st.zold):
+            v.copy_from(st.x)
+        st.res.fill_(math.inf)
+        st.theta = st.thetaold = float(theta)
+        tn = f32(theta)
+        for _ in range(self.iterations - 1):
+            tn = (f32(1) + np.sqrt(f32(1) + f32(4) * tn * tn)) / f32(2)
+        st.theta_n = float((f32(1) + np.sqrt(f32(1) + f32(8) * tn * tn)) / f32(2))
+        st.rel_res_norm = math.inf
+        st.iteration = 0
+
+    def iterate(self, st=None):
+        st = st or self.state
+        if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
+            return None
+        f32 = np.float32
+        th, tn, rho = f32(st.theta), f32(st.theta_n), f32(st.rho)
+        gamma = f32(2) * th / (tn * tn) * (tn * tn - f32(2) * th * th + th)
+        st.thetaold = float(th)
+        if st.iteration == self.iterations - 1:
+            thn = (f32(1) + np.sqrt(f32(1) + f32(8) * th * th)) / f32(2)
+        else:
+            thn = (f32(1) + np.sqrt(f32(1) + f32(4) * th * th)) / f32(2)
+        st.theta = float(thn)
+        alpha, beta = (th - f32(1)) / thn, th / thn
+        st.zold.copy_from(st.z)
+        st.z.copy_from(st.y)
+        _NormalApply(self._op).mul_(st.res, st.x)
+        st.res.axpy_(-1.0, st.x0)
+        st.y.axpy_(-float(rho * gamma), st.res)
+        st.rel_res_norm = st.res.norm() / st.norm_x0
+        if self.verbose:
+            print(f"Iteration {st.iteration}; rel. residual = {st.rel_res_norm}")
+        self.reg.prox_(st.y, float(rho * gamma * f32(self.reg.lam)))
+        st.z.lincomb_(float(f32(-1) / gamma), st.z, 1.0, st.x)      # z ./= -gamma ; z .+= x ...
+        st.z.axpy_(float(f32(1) / gamma), st.y)                     # ... .+ y ./ gamma
+        st.x.lincomb_(float(-beta), st.x, float(f32(1) + alpha + beta), st.z)
+        st.x.axpy_(float(-alpha), st.zold)
+        st.iteration += 1
+        return st.x, st
+
+    def _run(self, st):
+        while self.iterate(st) is not None:
+            pass
+
+
+class POGM(AbstractLinearSolver):
+    """src/POGM.jl:75-110 (ctor), :133-160 (init!), :169-237 (iterate).  gamma starts at 1 and is not reset
+    by init! (reference behaviour)."""
+
+    def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 50, verbose: bool = False,
+                 rho=None, theta=1, sigma_fac=1, relTol=_EPS32, restart: str = "none"):
+        self.A, self._op = _resolve_operator(A, AHA)
+        self.AHA = AHA if AHA is not None else self.A.normal_operator()
+        self.reg, self.proj = _split_regs(reg, "POGM")
+        self.reg = normalize(normalizeReg, [self.reg], self.A, None)[0]
+        self.normalizeReg = normalizeReg or NoNormalization()
+        if restart not in ("none", "gradient"):
+            raise ValueError("restart must be 'none' or 'gradient'")
+        self.restart = restart
+        self.verbose = bool(verbose)
+        self.iterations = int(iterations)
+        self.state = _ProxGradState(_default_rho(self._op) if rho is None else rho, theta, relTol,
+                                    ("x", "x0", "xold", "y", "z", "w", "res"))
+        self.state.gamma = 1.0
+        self.state.sigma = 1.0
+        self.state.sigma_fac = float(sigma_fac)
+
+    def _new_state(self):
+        s = self.state.states[0] if isinstance(self.state, AbstractMatrixSolverState) else self.state
+        n = _ProxGradState(s.rho, 1.0, s.relTol, s._names)
+        n.gamma, n.sigma, n.sigma_fac = s.gamma, 1.0, s.sigma_fac
+        return n
+
+    def init_(self, st, b: DeviceVector, x0=0, theta=1):
+        st._alloc(b, self._op.N)
+        if self.A is None:
+            st.x0.copy_from(b)
+        else:
+            self.A.mul_adj_(st.x0, b)
+        st.norm_x0 = st.x0.norm()
+        if np.isscalar(x0):
+            st.x.fill_(x0)
+        else:
+            st.x.copy_from(x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx))
+        for v in (st.xold, st.y, st.z, st.w):
+            v.fill_(0)
+        st.res.fill_(math.inf)
+        st.theta = st.thetaold = float(theta)
+        st.sigma = 1.0
+        st.rel_res_norm = math.inf
+        st.iteration = 0
+
+    def iterate(self, st=None):
+        st = st or self.state
+        if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
+            return None
+        f32 = np.float32
+        rho = f32(st.rho)
+        st.xold.copy_from(st.x)
+        _NormalApply(self._op).mul_(st.res, st.x)
+        st.res.axpy_(-1.0, st.x0)
+        st.x.axpy_(-float(rho), st.res)
+        st.rel_res_norm = st.res.norm() / st.norm_x0
+        if self.verbose:
+            print(f"Iteration {st.iteration}; rel. residual = {st.rel_res_norm}")
+        tho = f32(st.theta)
+        st.thetaold = float(tho)
+        if st.iteration == self.iterations - 1 and self.restart != "none":
+            th = (f32(1) + np.sqrt(f32(1) + f32(8) * tho * tho)) / f32(2)
+        else:
+            th = (f32(1) + np.sqrt(f32(1) + f32(4) * tho * tho)) / f32(2)
+        st.theta = float(th)
+        alpha = (tho - f32(1)) / th
+        beta = f32(st.sigma) * tho / th
+        gamma_old = f32(st.gamma)
+        if self.restart == "gradient":
+            gamma = rho * (f32(1) + alpha + beta)
+        else:
+            gamma = rho * (f32(2) * tho + th - f32(1)) / th
+        st.gamma = float(gamma)
+        st.x, st.y = st.y, st.x  # swap x and y
+        st.x.lincomb_(float(-alpha), st.x, float(f32(1) + alpha + beta), st.y)
+        st.x.axpy_(-float(beta + rho * alpha / gamma_old), st.xold)
+        st.x.axpy_(float(rho * alpha / gamma_old), st.z)
+        st.z.copy_from(st.x)
+        self.reg.prox_(st.x, float(gamma * f32(self.reg.lam)))
+        for pr in self.proj:
+            pr.prox_(st.x)
+        if self.restart == "gradient":
+            st.w.axpy_(1.0, st.y)
+            st.w.axpy_(float(rho / gamma), st.x)
+            st.w.axpy_(-float(rho / gamma), st.z)
+            crit = (complex(st.w.dot(st.x)) - complex(st.w.dot(st.z))) / complex(gamma) - complex(st.w.dot(st.res))
+            if crit.real < 0:
+                if self.verbose:
+                    print(f"Gradient restart at iter {st.iteration}")
+                st.sigma = 1.0
+                st.theta = 1.0
+            else:
+                st.sigma = float(f32(st.sigma) * f32(st.sigma_fac))
+            st.w.lincomb_(float(rho / gamma), st.z, -float(rho / gamma), st.x)
+            st.w.axpy_(-1.0, st.y)
+        st.iteration += 1
+        return st.x, st
+
+    def _run(self, st):
+        while self.iterate(st) is not None:
+            pass
+
+
+class SplitBregman(ADMM):
+    """src/SplitBregman.jl:82-140 (ctor), :166-200 (init!), :204-271 (iterate), :273-282 (converged / done).
+    Same composite operator and cg! as ADMM; prox threshold lambda / rho; the right-hand side gets its
+    Bregman update every `iterationsInner` inner iterations."""
+
+    def __init__(self, A=None, *, AHA=None, precon=None, reg=None, regTrafo=None, normalizeReg=None, rho=1e-1,
+                 iterations: int = 10, iterationsInner: int = 10, iterationsCG: int = 10, absTol=_EPS32, relTol=_EPS32,
+                 tolInner=1e-5, verbose: bool = False):
+        super().__init__(A, AHA=AHA, precon=precon, reg=reg, regTrafo=regTrafo, normalizeReg=normalizeReg, rho=rho,
+                         iterations=iterations, iterationsCG=iterationsCG, absTol=absTol, relTol=relTol,
+                         tolInner=tolInner, verbose=verbose)
+        self.iterationsInner = int(iterationsInner)
+
+    def init_(self, state, b: DeviceVector, x0=0):
+        super().init_(state, b, x0=x0)
+        if getattr(state, "ybreg", None) is None or state.ybreg.n != state.x.n or state.ybreg.ctx is not b.ctx:
+            state.ybreg = b.similar(self._op.N)
+        state.ybreg.copy_from(state.beta_y)
+        state.iter_cnt = 1
+        state.iteration = 1
+
+    def done(self, state):
+        return self.converged(state) or (state.iteration == 1 and state.iter_cnt > self.iterations)
+
+    def iterate(self, state=None):
+        state = state or self.state
+        if self.done(state):
+            return None
+        f32 = np.float32
+        lib, h = state.x.ctx.lib, state.x.ctx.handle
+        state.beta.copy_from(state.beta_y)
+        for i, t in enumerate(self.regTrafo):
+            t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
+            t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
+        if self._all_identity():
+            check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, float(np.sum(state.rho, dtype=np.float32)),
+                                      self.iterationsCG, float(state.tolInner)), "rls_cg_solve")
+        else:
+            self._cg_generic(state)
+        for pr in self.proj:
+            pr.prox_(state.x)
+        for i, t in enumerate(self.regTrafo):
+            state.z[i], state.zold[i] = state.zold[i], state.z[i]
+            t.mul_(state.z[i], state.x)
+            state.z[i].axpy_(1.0, state.u[i])
+            if state.rho[i] != 0:
+                self.reg[i].prox_(state.z[i], float(f32(self.reg[i].lam) / state.rho[i]))
+            t.mul_(state.u[i], state.x, 1.0, 1.0)
+            state.u[i].axpy_(-1.0, state.z[i])
+            tx = state.uold[i]  # scratch: Phi x
+            t.mul_(tx, state.x)
+            state.eps_pri[i] = max(f32(tx.norm()), f32(state.z[i].norm()))
+            tx.axpy_(-1.0, state.z[i])
+            state.rk[i] = f32(tx.norm())
+            tx.lincomb_(1.0, state.z[i], -1.0, state.zold[i])
+            t.mul_adj_(state.xold, tx, float(state.rho[i]), 0.0)
+            state.sk[i] = f32(state.xold.norm())
+            t.mul_adj_(state.xold, state.u[i], float(state.rho[i]), 0.0)
+            state.eps_dua[i] = f32(state.xold.norm())
+        if self.converged(state) or state.iteration >= self.iterationsInner:
+            state.beta_y.axpy_(1.0, state.ybreg)
+            self._op.mul_normal_(state.xold, state.x)
+            state.beta_y.axpy_(-1.0, state.xold)
+            for i, t in enumerate(self.regTrafo):
+                t.mul_(state.z[i], state.x)
+                state.u[i].fill_(0)
+            state.iter_cnt += 1
+            state.iteration = 0
+        state.iteration += 1
+        return state.x, state
+
+
+# --------------------------------------------------------------------------------------------
 # matrix right-hand sides: src/MultiThreading.jl
 # --------------------------------------------------------------------------------------------
 
@@ -904,7 +1203,9 @@ def createLinearSolver(solver_type, A=None, *, kwargWarning: bool = True, **kwar
 
 
 def linearSolverList():
-    return [CGNR, FISTA, ADMM]
+    """the solvers of the reference's linearSolverList() that this backend covers (Kaczmarz and the direct
+    solvers are outside the hot-path scope)"""
+    return [CGNR, FISTA, OptISTA, POGM, ADMM, SplitBregman]
 
 
 # ---- callbacks (src/Callbacks.jl) -- thin host-side helpers ------------------------------------

@@ -555,3 +555,39 @@ def test_batched_matrix_rhs_shares_one_pass_over_A(rls, ctx, dt, M, N, K):
     v = rls.solve_(S2, rls.DeviceVector.from_host(B[:, 1])).to_host()
     ref = O.CGNR(A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64), iterations=iters, relTol=0.0)
     assert rel(v, O.solve(ref, B[:, 1].astype(ref.dtype))) < 2e-5
+
+
+@pytest.mark.parametrize("name,kw", [("OptISTA", {}), ("POGM", {}), ("POGM", {"restart": "gradient"})])
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 256, 96), (np.float32, 4096, 2048)])
+def test_optista_pogm_match_oracle(rls, ctx, name, kw, dt, M, N):
+    """OptISTA (src/OptISTA.jl:169-209) and POGM (src/POGM.jl:169-237) re-sequence the same
+    device kernels; iterates against the float64 oracle"""
+    A, xt, b = O.make_problem(M, N, dt, 31)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    A64, b64 = A.astype(dt64), b.astype(dt64)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    ref = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=30, **kw)
+    O.solve(ref, b64)
+    sol = rls.createLinearSolver(getattr(rls, name), rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(lam),
+                                 rho=rho, iterations=30, **kw)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert sol.state.iteration == 30
+    assert rel(x, ref.x) < 3e-5
+
+
+def test_split_bregman_matches_oracle(rls, ctx):
+    """src/SplitBregman.jl:204-271, identity regTrafo and GradientOp regTrafo"""
+    A, xt, b = O.make_problem(160, 64, np.float32, 33)
+    kw = dict(rho=0.5, iterations=3, iterationsInner=4, iterationsCG=10)
+    ref = O.SplitBregman(A.astype(np.float64), reg=O.L1Regularization(0.05), **kw)
+    O.solve(ref, b.astype(np.float64))
+    sol = rls.createLinearSolver(rls.SplitBregman, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05), **kw)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert rel(x, ref.x) < 5e-5 and sol.state.iter_cnt == ref.iter_cnt
+    ref2 = O.SplitBregman(A.astype(np.float64), reg=O.L1Regularization(0.05), regTrafo=O.GradientTrafo((8, 8)), **kw)
+    O.solve(ref2, b.astype(np.float64))
+    sol2 = rls.createLinearSolver(rls.SplitBregman, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05),
+                                  regTrafo=rls.GradientOp((8, 8)), **kw)
+    x2 = rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host()
+    assert rel(x2, ref2.x) < 5e-5

@@ -169,6 +169,17 @@ def test_solvers_converge_on_small_systems(dt):
     assert rel(O.solve(O.CGNR(None, AHA=AHA, iterations=100), A.conj().T @ b), x) < 0.1  # AHA-only (:45-65)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+def test_next_tier_solvers_converge(dt):
+    """test/testSolvers.jl:3-43 style for OptISTA / POGM / SplitBregman"""
+    A, x, b = O.make_problem(24, 12, dt, 13)
+    rho = 0.95 / np.linalg.norm(A.astype(np.complex128), 2) ** 2
+    assert rel(O.solve(O.OptISTA(A, reg=O.L1Regularization(1e-6), rho=rho, iterations=300), b), x) < 0.1
+    assert rel(O.solve(O.POGM(A, reg=O.L1Regularization(1e-6), rho=rho, iterations=300), b), x) < 0.1
+    assert rel(O.solve(O.POGM(A, reg=O.L1Regularization(1e-6), rho=rho, iterations=300, restart="gradient"), b), x) < 0.1
+    assert rel(O.solve(O.SplitBregman(A, reg=O.L1Regularization(1e-6), iterations=20), b), x) < 0.1
+
+
 def test_cgnr_closed_forms():
     A, x, b = O.make_problem(64, 32, np.complex128, 3)
     for lam in (0.0, 0.5):
