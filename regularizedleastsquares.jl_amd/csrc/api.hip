@@ -95,6 +95,13 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "fuse_level")) ctx->tune.fuse_level = value;
   else if (!strcmp(key, "fused_normal")) ctx->tune.fused_normal = value;
   else if (!strcmp(key, "cgnr_pipeline")) ctx->tune.cgnr_pipeline = value;
+  else if (!strcmp(key, "batched_mfma")) ctx->tune.batched_mfma = value;
+  else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);
+  else if (!strcmp(key, "skinny_v_waves")) rls_skinny_tune(1, value);
+  else if (!strcmp(key, "skinny_v_splits")) rls_skinny_tune(2, value);
+  else if (!strcmp(key, "skinny_diag")) rls_skinny_tune(3, value);
+  else if (!strcmp(key, "skinny_t_u")) rls_skinny_tune(4, value);
+  else if (!strcmp(key, "skinny_v_u")) rls_skinny_tune(5, value);
   else if (!strcmp(key, "slab_g")) {  // process-wide; must be set before the operator is created
     rls_normal_force_group(value);
   } else if (!strcmp(key, "slab_wv")) {

@@ -20,6 +20,7 @@ struct rls_tuning {
   int fuse_level = 1;   // 0: separate BLAS-1 style update kernel; 1: fused update
   int fused_normal = 1; // 1: one-pass register-slab normal operator when the shape allows it
   int cgnr_pipeline = 1; // 1: CGNR as slab kernel (with the CG update in its prologue) + reduce kernel
+  int batched_mfma = 1;  // 1: batched plans run the two skinny products on the matrix cores (skinny.hip)
 };
 
 struct rls_ctx {
@@ -317,6 +318,25 @@ struct rls_cgnr_pipe {
 int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, int which);
+
+// everything the matrix-core batched kernels need (skinny.hip)
+struct rls_skinny {
+  const void* A;
+  int64_t lda, M, N;
+  int nrhs, ngroups, splits;  // ngroups = ceil(nrhs / 16); splits = row splits of the A^H T product
+  void *X, *R, *P, *V;        // N x nrhs, columns ldv elements apart (caller's)
+  int64_t ldv;
+  float *Ppack, *Tpack;       // MFMA-operand layouts of P (N x 16 ngroups) and T (M x 16 ngroups)
+  void* Vpart;                // [splits][16 ngroups][N] partial A^H T
+  cgnr_scalars* sc;           // [nrhs]
+};
+bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
+void rls_skinny_sizes(int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes, size_t* v_bytes,
+                      int* splits);
+int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb, float lambda,
+                        float rel_tol, int max_iter);
+int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which);
+void rls_skinny_tune(int which, int value);
 
 // ---------------------------------------------------------------------------------------------
 // host-side launch entry points implemented in the .hip files (all enqueue on ctx->stream)

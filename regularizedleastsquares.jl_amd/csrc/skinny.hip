@@ -1,0 +1,591 @@
+// K right-hand sides sharing one A on the matrix cores (BASELINE config 4, shared-A flavour; the
+// per-column semantics of solve!(solver, B; scheduler = MultiThreadingState), src/MultiThreading.jl:30-79).
+//
+// One CGNR iteration (src/CGNR.jl:143-178) of all K columns is three launches:
+//   skinny_t_kernel   T = A P        M x K   contraction over the columns of A
+//   skinny_v_kernel   V = A^H T      N x K   contraction over the rows of A (row-split partial sums)
+//   skinny_u_kernel   per column: v = sum of the partials, alpha, x, r, beta, p  (:153-176)
+// Both products run on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains): the 16-wide free index of the
+// B operand carries 16 right-hand sides, so A is streamed once per product for 16 solves; complex
+// arithmetic is four real MFMAs on the (re, im) parts of the operands.  K > 16 runs as groups of 16
+// (a grid dimension).  The skinny operands are kept as row-major panels of 16 right-hand sides,
+//   Pp[g][n][j] = P[n][16 g + j]   (N x 16),     Tp[g][m][j] = T[m][16 g + j]   (M x 16),
+// which is exactly the MFMA B-operand order: a wave reads 4 consecutive rows (64 elements) with one
+// contiguous load.  The partial-row slab of the one-pass kernel (normal.hip) would grow with K
+// (nwg x N x K), which is why this path streams A twice instead: 2 x 64 MiB out of the Infinity Cache
+// per 16 solve-iterations; at 16 right-hand sides both products are bound by the f32 MFMA rate.
+//
+// Measured on MI355X (4096 x 2048 ComplexF32, 16 RHS): one wave per SIMD (4-wave workgroups) overlaps
+// the loads with the MFMAs, two waves per SIMD do not (21.6 vs 13.6 us for T = A P); small load
+// batches beat deep ones (U = 4: 12.6 us, U = 16: 17.0 us); the MFMAs alone take 11.2 us.
+#include "rls_common.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ static inline f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// T = A P
+// workgroup = 16 rows of A x all columns; wave w takes the 4-column blocks nb = w, w + WV, ...
+// lane l: A operand = A[16 mb + (l & 15)][4 nb + (l >> 4)], B operand = Pp[g][4 nb + (l >> 4)][l & 15]
+// ---------------------------------------------------------------------------------------------
+template <typename E, int WV, int U>
+__device__ static inline void t_load(E (&a)[U], E (&p)[U], const E* __restrict__ Ap, int64_t lda,
+                                     const E* __restrict__ Pg, int w, int64_t i0) {
+  // no predication here: a select on a wave-uniform condition becomes a branch around the load, and the
+  // compiler then waits vmcnt(0) instead of counting (the callers only pass in-range steps)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t nb = w + WV * (i0 + u);
+    a[u] = Ap[nb * 4 * lda];
+    p[u] = Pg[nb * 64];
+  }
+}
+
+template <typename E, int U>
+__device__ static inline void t_mma(f32x4 (&acc)[4], const E (&a)[U], const E (&p)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if constexpr (elem<E>::cplx) {
+      const float ar = elem<E>::re(a[u]), ai = elem<E>::im(a[u]);
+      const float pr = elem<E>::re(p[u]), pi = elem<E>::im(p[u]);
+      acc[0] = mfma4(ar, pr, acc[0]);
+      acc[1] = mfma4(ai, pi, acc[1]);
+      acc[2] = mfma4(ar, pi, acc[2]);
+      acc[3] = mfma4(ai, pr, acc[3]);
+    } else {
+      acc[u & 1] = mfma4(elem<E>::re(a[u]), elem<E>::re(p[u]), acc[u & 1]);  // two chains: 40-cycle dependent latency
+    }
+  }
+}
+
+template <typename E, int WV, int U>
+__global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__ A, int64_t lda,
+                                                            const E* __restrict__ Pp, E* __restrict__ Tp, int64_t M,
+                                                            int64_t N) {
+  constexpr bool CX = elem<E>::cplx;
+  __shared__ float red[WV][2][4][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t mb = blockIdx.x, NB = N / 4;
+  const int g = blockIdx.y;
+  const E* Pg = Pp + (int64_t)g * N * 16 + lane;
+  const E* Ap = A + mb * 16 + (lane & 15) + (int64_t)(lane >> 4) * lda;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t ns = NB > w ? (NB - w + WV - 1) / WV : 0;
+  // software pipeline over batches of U steps, two register sets; the loop body has no branch around
+  // a load, so the waits are counted (vmcnt(N)) and the next batch stays in flight under the MFMAs
+  const int64_t nfull = ns / U;
+  if (nfull > 0) {
+    E a0[U], a1[U], p0[U], p1[U];
+    t_load<E, WV, U>(a0, p0, Ap, lda, Pg, w, 0);
+    int64_t b = 0;
+    for (; b + 2 < nfull; b += 2) {
+      // sched_barrier: keep the whole next batch of loads AHEAD of this batch's MFMAs (the scheduler
+      // otherwise sinks the loads towards their uses and the prefetch distance collapses)
+      t_load<E, WV, U>(a1, p1, Ap, lda, Pg, w, (b + 1) * U);
+      __builtin_amdgcn_sched_barrier(0);
+      t_mma<E, U>(acc, a0, p0);
+      __builtin_amdgcn_sched_barrier(0);
+      t_load<E, WV, U>(a0, p0, Ap, lda, Pg, w, (b + 2) * U);
+      __builtin_amdgcn_sched_barrier(0);
+      t_mma<E, U>(acc, a1, p1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (b + 1 < nfull) {
+      t_load<E, WV, U>(a1, p1, Ap, lda, Pg, w, (b + 1) * U);
+      t_mma<E, U>(acc, a0, p0);
+      t_mma<E, U>(acc, a1, p1);
+    } else {
+      t_mma<E, U>(acc, a0, p0);
+    }
+  }
+  for (int64_t i = nfull * U; i < ns; ++i) {  // remainder steps, one at a time
+    E a2[1], p2[1];
+    t_load<E, WV, 1>(a2, p2, Ap, lda, Pg, w, i);
+    t_mma<E, 1>(acc, a2, p2);
+  }
+  f32x4 tre, tim;
+  if constexpr (CX) {
+    tre = acc[0] - acc[1];
+    tim = acc[2] + acc[3];
+  } else {
+    tre = acc[0] + acc[1];
+    tim = tre;
+  }
+  // accumulator register t of lane (q = l >> 4, j = l & 15) is T[16 mb + 4 q + t][j]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    red[w][0][t][lane] = tre[t];
+    if constexpr (CX) red[w][1][t][lane] = tim[t];
+  }
+  __syncthreads();
+  E* out = Tp + ((int64_t)g * M + mb * 16) * 16;
+  for (int idx = threadIdx.x; idx < 256; idx += WV * 64) {  // idx = row * 16 + j
+    const int row = idx >> 4, j = idx & 15;
+    const int l = (row >> 2) * 16 + j, t = row & 3;
+    float re = 0.f, im = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) {
+      re += red[ww][0][t][l];
+      if constexpr (CX) im += red[ww][1][t][l];
+    }
+    out[idx] = elem<E>::make(re, im);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// V = A^H T (partial over a row split)
+// workgroup = 16 columns of A x the row blocks [lo, hi) of split s; wave w takes mb = lo + w, lo + w + WV, ...
+// lane l (q = l >> 4): A operand of step register t = conj(A[16 mb + 4 q + t][n0 + (l & 15)]) (one 32-byte
+// piece of the column per lane), B operand = Tp[g][16 mb + 4 q + t][l & 15]
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+struct v_regs {
+  float4 x0, x1;  // complex: rows (0,1), (2,3) as (re, im) pairs; real: x0 = rows 0..3
+  E t[4];
+};
+
+template <typename E, int WV, int U>
+__device__ static inline void v_load(v_regs<E> (&q)[U], const E* __restrict__ Ap, const E* __restrict__ Tg, int w,
+                                     int64_t lo, int64_t i0) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t mb = lo + w + WV * (i0 + u);
+    const float4* ap = reinterpret_cast<const float4*>(Ap + mb * 16);
+    q[u].x0 = ap[0];
+    if constexpr (elem<E>::cplx) q[u].x1 = ap[1];
+    const E* tp = Tg + mb * 256;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q[u].t[t] = tp[t * 16];
+  }
+}
+
+template <typename E, int U>
+__device__ static inline void v_mma(f32x4 (&acc)[4], const v_regs<E> (&q)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if constexpr (elem<E>::cplx) {
+      const float ar[4] = {q[u].x0.x, q[u].x0.z, q[u].x1.x, q[u].x1.z};
+      const float ai[4] = {q[u].x0.y, q[u].x0.w, q[u].x1.y, q[u].x1.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float tr = elem<E>::re(q[u].t[t]), ti = elem<E>::im(q[u].t[t]);
+        acc[0] = mfma4(ar[t], tr, acc[0]);
+        acc[1] = mfma4(ai[t], ti, acc[1]);
+        acc[2] = mfma4(ar[t], ti, acc[2]);
+        acc[3] = mfma4(ai[t], tr, acc[3]);
+      }
+    } else {
+      const float ar[4] = {q[u].x0.x, q[u].x0.y, q[u].x0.z, q[u].x0.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t & 1] = mfma4(ar[t], elem<E>::re(q[u].t[t]), acc[t & 1]);
+    }
+  }
+}
+
+template <typename E, int WV, int U>
+__global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__ A, int64_t lda,
+                                                            const E* __restrict__ Tp, E* __restrict__ Vpart,
+                                                            int64_t M, int64_t N, int nrhs_pad) {
+  constexpr bool CX = elem<E>::cplx;
+  __shared__ float red[WV][2][4][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n0 = (int64_t)blockIdx.x * 16, MB = M / 16;
+  const int s = blockIdx.y, S = gridDim.y, g = blockIdx.z;
+  const int64_t lo = s * MB / S, hi = (s + 1) * MB / S;
+  const E* Ap = A + (n0 + (lane & 15)) * lda + 4 * (lane >> 4);
+  const E* Tg = Tp + (int64_t)g * M * 16 + (lane >> 4) * 64 + (lane & 15);
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t ns = hi - lo > w ? (hi - lo - w + WV - 1) / WV : 0;
+  const int64_t nfull = ns / U;
+  if (nfull > 0) {
+    v_regs<E> q0[U], q1[U];
+    v_load<E, WV, U>(q0, Ap, Tg, w, lo, 0);
+    int64_t b = 0;
+    for (; b + 2 < nfull; b += 2) {
+      v_load<E, WV, U>(q1, Ap, Tg, w, lo, (b + 1) * U);
+      __builtin_amdgcn_sched_barrier(0);
+      v_mma<E, U>(acc, q0);
+      __builtin_amdgcn_sched_barrier(0);
+      v_load<E, WV, U>(q0, Ap, Tg, w, lo, (b + 2) * U);
+      __builtin_amdgcn_sched_barrier(0);
+      v_mma<E, U>(acc, q1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (b + 1 < nfull) {
+      v_load<E, WV, U>(q1, Ap, Tg, w, lo, (b + 1) * U);
+      v_mma<E, U>(acc, q0);
+      v_mma<E, U>(acc, q1);
+    } else {
+      v_mma<E, U>(acc, q0);
+    }
+  }
+  for (int64_t i = nfull * U; i < ns; ++i) {
+    v_regs<E> q2[1];
+    v_load<E, WV, 1>(q2, Ap, Tg, w, lo, i);
+    v_mma<E, 1>(acc, q2);
+  }
+  f32x4 vre, vim;
+  if constexpr (CX) {
+    vre = acc[0] + acc[1];
+    vim = acc[2] - acc[3];
+  } else {
+    vre = acc[0] + acc[1];
+    vim = vre;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    red[w][0][u][lane] = vre[u];
+    if constexpr (CX) red[w][1][u][lane] = vim[u];
+  }
+  __syncthreads();
+  // accumulator register u of lane (q, j) is V[n0 + 4 q + u][j]; stored per right-hand side (16 columns
+  // = one 128-byte line each) so that the update kernel reads its column contiguously
+  for (int idx = threadIdx.x; idx < 256; idx += WV * 64) {  // idx = j * 16 + column
+    const int j = idx >> 4, c = idx & 15;
+    const int l = (c >> 2) * 16 + j, u = c & 3;
+    float re = 0.f, im = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) {
+      re += red[ww][0][u][l];
+      if constexpr (CX) im += red[ww][1][u][l];
+    }
+    Vpart[((int64_t)s * nrhs_pad + 16 * g + j) * N + n0 + c] = elem<E>::make(re, im);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B (M x nrhs, column-major) -> Tp panels, so that the init product A^H B runs on skinny_v_kernel
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void skinny_pack_rows_kernel(const E* __restrict__ B, int64_t ldb, int nrhs,
+                                                               E* __restrict__ Tp, int64_t M, int ngroups) {
+  __shared__ E tile[16][65];
+  // one workgroup transposes 64 rows x 16 right-hand sides
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int g = blockIdx.y;
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const int j = idx >> 6, r = idx & 63;
+    const int rhs = 16 * g + j;
+    tile[j][r] = (rhs < nrhs && m0 + r < M) ? B[(int64_t)rhs * ldb + m0 + r] : elem<E>::zero();
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const int r = idx >> 4, j = idx & 15;
+    if (m0 + r < M) Tp[((int64_t)g * M + m0 + r) * 16 + j] = tile[j][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-column CG update (one workgroup per right-hand side), src/CGNR.jl:108-126 (INIT) / :153-176.
+// EPT > 0: the column lives in registers (N <= 1024 EPT), every load is issued before the first
+// reduction; EPT == 0: any N, the vectors are re-read between the reductions.
+// ---------------------------------------------------------------------------------------------
+constexpr int SKU_THREADS = 1024;
+
+template <typename E>
+__device__ static inline double abs2d(E a) {
+  return (double)elem<E>::re(a) * (double)elem<E>::re(a) + (double)elem<E>::im(a) * (double)elem<E>::im(a);
+}
+
+template <typename E>
+__device__ static inline E sum_parts(const E* __restrict__ Vpart, int S, int nrhs_pad, int b, int64_t N, int64_t i) {
+  E v = Vpart[(int64_t)b * N + i];
+  for (int s = 1; s < S; ++s) v = elem<E>::add(v, Vpart[((int64_t)s * nrhs_pad + b) * N + i]);
+  return v;
+}
+
+__device__ static inline void cg_scalars_init(cgnr_scalars* sc, double rr, float lambda, float rel_tol, int max_iter) {
+  sc->rr = rr;
+  sc->z0 = sqrt(rr);
+  sc->zeta = 0.0;
+  sc->alpha_re = sc->alpha_im = sc->beta_re = sc->beta_im = 0.0;
+  sc->lambda = lambda;
+  sc->rel_tol = rel_tol;
+  sc->iteration = 0;
+  sc->max_iter = max_iter;
+  sc->pending = 0;
+  sc->cur = 0;
+  sc->fresh = 0;
+  const float ratio = (float)(sqrt(rr) / sqrt(rr));  // NaN when r == 0, as in the reference
+  sc->done = (ratio <= rel_tol) || (0 >= max_iter);
+}
+
+__device__ static inline void cg_scalars_step(cgnr_scalars* sc, double zeta, double rr, dcomplex alpha, double beta) {
+  sc->zeta = zeta;
+  sc->rr = rr;
+  sc->alpha_re = alpha.re;
+  sc->alpha_im = alpha.im;
+  sc->beta_re = beta;
+  sc->beta_im = 0.0;
+  const int it = sc->iteration + 1;
+  sc->iteration = it;
+  const float ratio = (float)(sqrt(rr) / sc->z0);
+  sc->done = (ratio <= sc->rel_tol) || (it >= sc->max_iter);  // src/CGNR.jl:181-185
+}
+
+template <typename E, bool INIT, int EPT>
+__global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X, E* __restrict__ R, E* __restrict__ P,
+                                                               E* __restrict__ V, int64_t ldv,
+                                                               const E* __restrict__ Vpart, int S, int nrhs_pad,
+                                                               int64_t N, E* __restrict__ Pp, cgnr_scalars* scv,
+                                                               float lambda_in, float rel_tol, int max_iter) {
+  __shared__ double sm[48];
+  const int b = blockIdx.x;
+  cgnr_scalars* sc = scv + b;
+  E* x = X + (int64_t)b * ldv;
+  E* r = R + (int64_t)b * ldv;
+  E* p = P + (int64_t)b * ldv;
+  E* v = V + (int64_t)b * ldv;
+  E* pp_out = Pp + (int64_t)(b >> 4) * N * 16 + (b & 15);  // Pp[g][n][j]: element n at pp_out[16 n]
+  if constexpr (INIT) {
+    double rr = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+      const E ri = sum_parts<E>(Vpart, S, nrhs_pad, b, N, i);
+      x[i] = elem<E>::zero();
+      v[i] = elem<E>::zero();
+      r[i] = ri;
+      p[i] = ri;
+      pp_out[16 * i] = ri;
+      rr += abs2d<E>(ri);
+    }
+    rr = block_sum(rr, sm);
+    if (threadIdx.x == 0) cg_scalars_init(sc, rr, lambda_in, rel_tol, max_iter);
+  } else if constexpr (EPT > 0) {
+    if (sc->done) return;  // this column has retired (src/MultiThreading.jl:60-78); its panel entry stays
+    const float lambda = sc->lambda;
+    const double zeta = sc->rr;
+    E pv[EPT], xv[EPT], rv[EPT], vv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
+      const int64_t ic = i < N ? i : N - 1;
+      pv[e] = p[ic];
+      xv[e] = x[ic];
+      rv[e] = r[ic];
+      vv[e] = Vpart[(int64_t)b * N + ic];
+    }
+    for (int s = 1; s < S; ++s) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
+        vv[e] = elem<E>::add(vv[e], Vpart[((int64_t)s * nrhs_pad + b) * N + (i < N ? i : N - 1)]);
+      }
+    }
+    double nre = 0.0, nim = 0.0, pp = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
+      if (i >= N) {
+        pv[e] = elem<E>::zero();
+        vv[e] = elem<E>::zero();
+        rv[e] = elem<E>::zero();
+      }
+      nre += (double)elem<E>::re(pv[e]) * (double)elem<E>::re(vv[e]) + (double)elem<E>::im(pv[e]) * (double)elem<E>::im(vv[e]);
+      if constexpr (elem<E>::cplx)
+        nim += (double)elem<E>::re(pv[e]) * (double)elem<E>::im(vv[e]) - (double)elem<E>::im(pv[e]) * (double)elem<E>::re(vv[e]);
+      pp += abs2d<E>(pv[e]);
+    }
+    block_sum3(nre, nim, pp, sm);
+    const dcomplex den = {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim};
+    const dcomplex alpha = dc_div({zeta, 0.0}, den);
+    const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
+    const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
+    double rr = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      xv[e] = elem<E>::fma(pv[e], a, xv[e]);
+      E ri = elem<E>::fma(vv[e], na, rv[e]);
+      if (lambda > 0.f) ri = elem<E>::fma(elem<E>::scale(-lambda, pv[e]), a, ri);
+      rv[e] = ri;
+      rr += abs2d<E>(ri);
+    }
+    rr = block_sum(rr, sm);
+    const double beta = rr / zeta;
+    const float bf = (float)beta;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
+      if (i < N) {
+        const E pn = elem<E>::add(elem<E>::scale(bf, pv[e]), rv[e]);
+        x[i] = xv[e];
+        r[i] = rv[e];
+        v[i] = vv[e];
+        p[i] = pn;
+        pp_out[16 * i] = pn;
+      }
+    }
+    if (threadIdx.x == 0) cg_scalars_step(sc, zeta, rr, alpha, beta);
+  } else {
+    if (sc->done) return;
+    const float lambda = sc->lambda;
+    const double zeta = sc->rr;
+    double nre = 0.0, nim = 0.0, pp = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+      const E vi = sum_parts<E>(Vpart, S, nrhs_pad, b, N, i);
+      v[i] = vi;
+      const E pi = p[i];
+      nre += (double)elem<E>::re(pi) * (double)elem<E>::re(vi) + (double)elem<E>::im(pi) * (double)elem<E>::im(vi);
+      if constexpr (elem<E>::cplx)
+        nim += (double)elem<E>::re(pi) * (double)elem<E>::im(vi) - (double)elem<E>::im(pi) * (double)elem<E>::re(vi);
+      pp += abs2d<E>(pi);
+    }
+    block_sum3(nre, nim, pp, sm);
+    const dcomplex den = {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim};
+    const dcomplex alpha = dc_div({zeta, 0.0}, den);
+    const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
+    const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
+    double rr = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+      const E pi = p[i];
+      x[i] = elem<E>::fma(pi, a, x[i]);
+      E ri = elem<E>::fma(v[i], na, r[i]);
+      if (lambda > 0.f) ri = elem<E>::fma(elem<E>::scale(-lambda, pi), a, ri);
+      r[i] = ri;
+      rr += abs2d<E>(ri);
+    }
+    rr = block_sum(rr, sm);
+    const double beta = rr / zeta;
+    const float bf = (float)beta;
+    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+      const E pn = elem<E>::add(elem<E>::scale(bf, p[i]), r[i]);
+      p[i] = pn;
+      pp_out[16 * i] = pn;
+    }
+    if (threadIdx.x == 0) cg_scalars_step(sc, zeta, rr, alpha, beta);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// measurement overrides (rls_tune_set "skinny_*"); defaults from tools/skinny_probe.py on MI355X
+static int g_t_waves = 4, g_t_u = 4, g_v_waves = 4, g_v_u = 1, g_v_splits = 0;
+void rls_skinny_tune(int which, int value) {
+  if (which == 0) g_t_waves = value;
+  if (which == 1) g_v_waves = value;
+  if (which == 2) g_v_splits = value;
+  if (which == 4) g_t_u = value;
+  if (which == 5) g_v_u = value;
+}
+
+bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!A || M < 16 || N < 16 || M % 16 || N % 16) return false;
+  const int V = dtype == RLS_C32 ? 2 : 4;
+  return ((uintptr_t)A % 16 == 0) && (lda % V == 0);
+}
+
+static int skinny_splits(int64_t M, int64_t N, int ngroups) {
+  if (g_v_splits > 0) return g_v_splits;
+  const int64_t MB = M / 16, wgs = (N / 16) * ngroups;
+  int64_t S = (512 + wgs - 1) / wgs;               // ~2 workgroups of 4 waves per CU
+  const int64_t smax = MB / 16 > 0 ? MB / 16 : 1;  // keep >= 16 row blocks (4 per wave) per split
+  if (S > smax) S = smax;
+  if (S > 16) S = 16;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+void rls_skinny_sizes(int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes, size_t* v_bytes,
+                      int* splits) {
+  const int G = (nrhs + 15) / 16;
+  const int S = skinny_splits(M, N, G);
+  *p_bytes = (size_t)G * N * 16 * rls_elem_size(dtype);
+  *t_bytes = (size_t)G * M * 16 * rls_elem_size(dtype);
+  *v_bytes = (size_t)S * G * 16 * N * rls_elem_size(dtype);
+  *splits = S;
+}
+
+static int32_t sk_status(rls_ctx* ctx) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+template <typename E>
+static void launch_t(rls_ctx* ctx, const rls_skinny& K) {
+  const dim3 grid((unsigned)(K.M / 16), (unsigned)K.ngroups);
+#define SK_T(W, UU)                                                                                                \
+  if (g_t_waves == W && g_t_u == UU) {                                                                             \
+    hipLaunchKernelGGL((skinny_t_kernel<E, W, UU>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda,     \
+                       (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);                                                  \
+    return;                                                                                                        \
+  }
+  SK_T(8, 4) SK_T(8, 8) SK_T(4, 8) SK_T(4, 2) SK_T(4, 16) SK_T(2, 4)
+#undef SK_T
+  hipLaunchKernelGGL((skinny_t_kernel<E, 4, 4>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
+                     (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);
+}
+
+template <typename E>
+static void launch_v(rls_ctx* ctx, const rls_skinny& K) {
+  const dim3 grid((unsigned)(K.N / 16), (unsigned)K.splits, (unsigned)K.ngroups);
+#define SK_V(W, UU)                                                                                                \
+  if (g_v_waves == W && g_v_u == UU) {                                                                             \
+    hipLaunchKernelGGL((skinny_v_kernel<E, W, UU>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda,     \
+                       (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16);                                  \
+    return;                                                                                                        \
+  }
+  SK_V(8, 1) SK_V(8, 2) SK_V(4, 2) SK_V(4, 4) SK_V(2, 1) SK_V(2, 2)
+#undef SK_V
+  hipLaunchKernelGGL((skinny_v_kernel<E, 4, 1>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
+                     (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16);
+}
+
+template <typename E, bool INIT, int EPT>
+static void launch_u_ept(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_tol, int max_iter) {
+  hipLaunchKernelGGL((skinny_u_kernel<E, INIT, EPT>), dim3((unsigned)K.nrhs), dim3(SKU_THREADS), 0, ctx->stream,
+                     (E*)K.X, (E*)K.R, (E*)K.P, (E*)K.V, K.ldv, (const E*)K.Vpart, K.splits, K.ngroups * 16, K.N,
+                     (E*)K.Ppack, K.sc, lambda, rel_tol, max_iter);
+}
+
+template <typename E, bool INIT>
+static void launch_u(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_tol, int max_iter) {
+  if (INIT || K.N > 8 * SKU_THREADS)
+    launch_u_ept<E, INIT, 0>(ctx, K, lambda, rel_tol, max_iter);
+  else if (K.N <= 2 * SKU_THREADS)
+    launch_u_ept<E, INIT, 2>(ctx, K, lambda, rel_tol, max_iter);
+  else if (K.N <= 4 * SKU_THREADS)
+    launch_u_ept<E, INIT, 4>(ctx, K, lambda, rel_tol, max_iter);
+  else
+    launch_u_ept<E, INIT, 8>(ctx, K, lambda, rel_tol, max_iter);
+}
+
+template <typename E>
+static int32_t skinny_init_typed(rls_ctx* ctx, const rls_skinny& K, const void* B, int64_t ldb, float lambda,
+                                 float rel_tol, int max_iter) {
+  const dim3 grid((unsigned)((K.M + 63) / 64), (unsigned)K.ngroups);
+  hipLaunchKernelGGL(skinny_pack_rows_kernel<E>, grid, dim3(256), 0, ctx->stream, (const E*)B, ldb, K.nrhs,
+                     (E*)K.Tpack, K.M, K.ngroups);
+  launch_v<E>(ctx, K);
+  launch_u<E, true>(ctx, K, lambda, rel_tol, max_iter);
+  return sk_status(ctx);
+}
+
+int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb, float lambda,
+                        float rel_tol, int max_iter) {
+  return dtype == RLS_F32 ? skinny_init_typed<float>(ctx, K, B, ldb, lambda, rel_tol, max_iter)
+                          : skinny_init_typed<float2>(ctx, K, B, ldb, lambda, rel_tol, max_iter);
+}
+
+// which: bit 0 = T kernel, bit 1 = V kernel, bit 2 = update kernel
+int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which) {
+  if (dtype == RLS_F32) {
+    if (which & 1) launch_t<float>(ctx, K);
+    if (which & 2) launch_v<float>(ctx, K);
+    if (which & 4) launch_u<float, false>(ctx, K, 0.f, 0.f, 0);
+  } else {
+    if (which & 1) launch_t<float2>(ctx, K);
+    if (which & 2) launch_v<float2>(ctx, K);
+    if (which & 4) launch_u<float2, false>(ctx, K, 0.f, 0.f, 0);
+  }
+  return sk_status(ctx);
+}

@@ -103,7 +103,33 @@ struct rls_cgnr {
   int nrhs;
   int64_t ldv;
   void* slab_b;
+  // batched plans on the matrix cores (skinny.hip): packed operands + row-split partials
+  bool skinny;
+  float *Ppack, *Tpack;
+  void* Vpart;
+  int splits;
 };
+
+static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
+  rls_skinny K;
+  K.A = s->op->A;
+  K.lda = s->op->lda;
+  K.M = s->op->M;
+  K.N = s->op->N;
+  K.nrhs = s->nrhs;
+  K.ngroups = (s->nrhs + 15) / 16;
+  K.splits = s->splits;
+  K.X = s->x;
+  K.R = s->r;
+  K.P = s->p;
+  K.V = s->v;
+  K.ldv = s->ldv;
+  K.Ppack = s->Ppack;
+  K.Tpack = s->Tpack;
+  K.Vpart = s->Vpart;
+  K.sc = s->sc;
+  return K;
+}
 
 static bool cgnr_use_pipeline(const rls_cgnr* s) {
   const rls_ctx* ctx = s->op->ctx;
@@ -797,9 +823,14 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   if (!x || !r || !p || !v || !out || nrhs < 1 || ldv < op->N)
     return rls_fail(ctx, RLS_E_INVALID, "cgnr_create: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  if (nrhs > 1 && !(op->slab && !op->G))
-    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR needs the one-pass register-slab operator (shape/alignment)");
+  const bool skinny = nrhs > 1 && !op->G && ctx->tune.batched_mfma && rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda);
+  if (nrhs > 1 && !skinny && !(op->slab && !op->G))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR needs 16-aligned M, N (matrix-core path) or the one-pass register-slab operator");
   rls_cgnr* s = new rls_cgnr();
+  s->skinny = skinny;
+  s->Ppack = s->Tpack = nullptr;
+  s->Vpart = nullptr;
+  s->splits = 1;
   s->op = op;
   s->device = ctx->device;
   s->x = x;
@@ -831,8 +862,16 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sb);
     if (e == hipSuccess) e = hipMemset(s->dots, 0, nd);
     if (e == hipSuccess) e = hipMemset(s->scn, 0, sb);
-    if (e == hipSuccess && nrhs > 1)
+    if (e == hipSuccess && nrhs > 1 && !skinny)
       e = hipMalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
+  }
+  if (e == hipSuccess && skinny) {
+    size_t pb, tb, vb;
+    rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+    e = hipMalloc((void**)&s->Ppack, pb);
+    if (e == hipSuccess) e = hipMemset(s->Ppack, 0, pb);  // the padding columns of the last group stay zero
+    if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
+    if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
   }
   if (e != hipSuccess) {
     rls_cgnr_destroy(s);
@@ -861,6 +900,9 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->dots) hipFree(s->dots);
   if (s->scn) hipFree(s->scn);
   if (s->slab_b) hipFree(s->slab_b);
+  if (s->Ppack) hipFree(s->Ppack);
+  if (s->Tpack) hipFree(s->Tpack);
+  if (s->Vpart) hipFree(s->Vpart);
   if (s->sc) hipFree(s->sc);
   if (s->sc_h) hipHostFree(s->sc_h);
   delete s;
@@ -907,10 +949,19 @@ int32_t rls_cgnr_init_batched(rls_cgnr* s, const void* B, int64_t ldb, float lam
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
   if (!B || !op->A || ldb < op->M) return rls_fail(ctx, RLS_E_INVALID, "cgnr_init_batched: bad argument");
-  if (!cgnr_use_pipeline(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr_init_batched: fused pipeline not active");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   const size_t es = rls_elem_size(op->dtype);
   const int max_iter = cgnr_effective_iterations(s, iterations);
+  if (s->skinny) {
+    // R = A^H B on the matrix cores (B packed as the T operand), then the per-column init
+    RLS_TRY(rls_skinny_init(ctx, op->dtype, cgnr_skinny_desc(s), B, ldb, lambda, rel_tol, max_iter));
+    s->sc_h->lambda = lambda;
+    s->sc_h->rel_tol = rel_tol;
+    s->sc_h->max_iter = max_iter;
+    s->initialised = true;
+    return 0;
+  }
+  if (!cgnr_use_pipeline(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr_init_batched: fused pipeline not active");
   for (int b = 0; b < s->nrhs; ++b) {
     char* rb = (char*)s->r + (size_t)b * s->ldv * es;
     RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda,
@@ -960,6 +1011,16 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
   if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr_step: n_steps < 0");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->skinny) {
+    const rls_skinny K = cgnr_skinny_desc(s);
+    const int32_t dtype = s->op->dtype;
+    if (s->graph.steps && s->graph.mode != 2) {
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph.mode = 2;
+    return run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &K]() { return rls_skinny_launch(ctx, dtype, K, 7); });
+  }
   if (cgnr_use_pipeline(s)) {
     // iteration k = K_A (applies update k-1 in its prologue, then one pass over A) + K_R; the last
     // update of this call is applied by K_F, which also returns r, p to the caller's vectors

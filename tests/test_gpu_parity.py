@@ -529,8 +529,18 @@ def test_multisolve_single_rank(rls, ctx):
     assert got.shape == (64, 5) and rel(got, X) < 1e-3
 
 
-@pytest.mark.parametrize("dt,M,N,K", [(np.complex64, 4096, 2048, 8), (np.float32, 512, 256, 3), (np.complex64, 96, 40, 5)])
-def test_batched_matrix_rhs_shares_one_pass_over_A(rls, ctx, dt, M, N, K):
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("dt,M,N,K", [(np.complex64, 4096, 2048, 8), (np.float32, 512, 256, 3), (np.complex64, 96, 40, 5),
+                                      (np.complex64, 272, 144, 20), (np.float32, 1040, 208, 33)])
+def test_batched_matrix_rhs_shares_one_pass_over_A(rls, ctx, dt, M, N, K, mfma):
+    ctx.tune(batched_mfma=mfma)
+    try:
+        _batched_case(rls, ctx, dt, M, N, K)
+    finally:
+        ctx.tune(batched_mfma=1)
+
+
+def _batched_case(rls, ctx, dt, M, N, K):
     """BatchedState: K right-hand sides per pass over A == column-by-column solves (and the oracle),
     including columns that retire early (relTol) while others continue"""
     A, X, B = O.make_problem(M, N, dt, 23, n_rhs=K)
