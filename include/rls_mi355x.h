@@ -145,6 +145,16 @@ int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x);
 int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v);
 /* setup GEMM AHA = A' * A (src/CGNR.jl:49) on device; G is N x N column-major, ld >= N */
 int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G, int64_t ld);
+/* squared row norms of A, out_d[m] = rownorm²(A, m) (src/Utils.jl:20-23) for all rows at once -- the
+ * mapreduce(abs2, +, A, dims = 2) of ext/RegularizedLeastSquaresGPUArraysExt/NormalizedRegularization.jl:1-5
+ * that normalize(::SystemMatrixBasedNormalization, A, b) (src/Regularization/NormalizedRegularization.jl:47-58)
+ * sums; out_d: device float[M].  Synchronises (setup path). */
+int32_t rls_rownorm2(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, float* out_d);
+/* B = diag(w) A: ProdOp(WeightingOp(w), A) (docs/src/literate/howto/normal_operator.jl:41-44, src/Utils.jl:23,102)
+ * materialised, so that the weighted operator and its normal operator A^H W^H W A run on the same kernels as a
+ * plain dense A.  w: device vector of length M, same dtype as A; B: M x N, leading dimension ldb (B may alias A). */
+int32_t rls_scale_rows(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* w, const void* A, int64_t lda,
+                       void* B, int64_t ldb);
 
 /* ---------------------------------------------------------------------------------------------
  * fused CGNR.   replaces init!(::CGNR, ::CGNRState, b) src/CGNR.jl:107-130 and

@@ -1093,3 +1093,28 @@ class SplitBregman(ADMM):
             self.iteration = 0
         self.iteration += 1
         return self.x
+
+
+# --------------------------------------------------------------------------------------------
+# regularisation normalisation (src/Regularization/NormalizedRegularization.jl:40-58) and the
+# row-weighted operator ProdOp(WeightingOp(w), A) (docs/src/literate/howto/normal_operator.jl:41-44)
+# --------------------------------------------------------------------------------------------
+
+
+def normalization_factor(scheme: str, A=None, b=None):
+    """scheme in {"none", "measurement", "systemmatrix"}; returns None for "none" (:59)"""
+    if scheme == "none":
+        return None
+    if scheme == "measurement":  # norm(b, 1) / length(b), 1 without b (:40-43)
+        return 1.0 if b is None else float(np.sum(np.abs(b)) / b.size)
+    if scheme == "systemmatrix":  # energy[m] = sqrt(rownorm²(A, m)); norm(energy)^2 / N (:47-58)
+        if A is None:
+            raise ValueError("SystemMatrixBasedNormalization requires supplying A to the constructor of the solver")
+        energy = np.sqrt(np.sum(np.abs(A) ** 2, axis=1))
+        return float(np.linalg.norm(energy) ** 2 / A.shape[1])
+    raise ValueError(scheme)
+
+
+def weighted_operator(w, A):
+    """(W A) as a dense matrix; its normal operator is A^H W^H W A"""
+    return np.asarray(w)[:, None] * A

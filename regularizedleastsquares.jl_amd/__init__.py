@@ -8,12 +8,13 @@ The directory name contains a dot, so it cannot be imported with a plain `import
 use the `rls_amd` shim at the repository root (`import rls_amd`).
 """
 from ._lib import LIB_PATH, RLSError, load  # noqa: F401
-from .arrays import Context, DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle, default_context  # noqa: F401
+from .arrays import (Context, DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle, ProdOp, WeightingOp,  # noqa: F401
+                     default_context, normalOperator)
 from .regularization import (AbstractParameterizedRegularization, AbstractProjectionRegularization,  # noqa: F401
                              AbstractRegularization, GradientOp, L1Regularization, L2Regularization,
                              L21Regularization, MeasurementBasedNormalization, NoNormalization,
                              PositiveRegularization, RealRegularization, SystemMatrixBasedNormalization,
-                             TVRegularization, lam, norm, prox_)
+                             TVRegularization, NormalizedRegularization, innerreg, lam, norm, normalize, prox_, scalefactor)
 from .solvers import (ADMM, CGNR, FISTA, POGM, OptISTA, SplitBregman, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
                       SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,
                       iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,

@@ -92,6 +92,8 @@ PROTOTYPES = {
     "rls_operator_mul_adj": (_i32, [_vp, _vp, _vp]),
     "rls_operator_mul_normal": (_i32, [_vp, _vp, _vp]),
     "rls_gram": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _i64]),
+    "rls_rownorm2": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp]),
+    "rls_scale_rows": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
     "rls_cgnr_create": (_i32, [_vp, _vp, _vp, _vp, _vp, _pvp]),
     "rls_cgnr_destroy": (_i32, [_vp]),
     "rls_cgnr_init": (_i32, [_vp, _vp, _f, _f, _i32]),

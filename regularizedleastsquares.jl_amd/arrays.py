@@ -280,9 +280,52 @@ class DeviceMatrix:
         check(h, lib.rls_gram(h, self.code, self.M, self.N, self.ptr, self.lda, G.ptr, G.lda), "rls_gram")
         return G
 
+    def rownorm2(self) -> "DeviceVector":
+        """rownorm²(A, m) for every row m (src/Utils.jl:20-23; GPU ext NormalizedRegularization.jl:1-5): real vector"""
+        out = DeviceVector(self.M, np.float32, self.ctx)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_rownorm2(h, self.code, self.M, self.N, self.ptr, self.lda, out.ptr), "rls_rownorm2")
+        return out
+
+    def scale_rows(self, w: "DeviceVector") -> "DeviceMatrix":
+        """diag(w) * A as a new dense matrix (ProdOp(WeightingOp(w), A) materialised)"""
+        if w.n != self.M or w.dtype != self.dtype:
+            raise ValueError("scale_rows: weights must have length size(A, 1) and the element type of A")
+        B = DeviceMatrix(self.M, self.N, self.dtype, self.ctx)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_scale_rows(h, self.code, self.M, self.N, w.ptr, self.ptr, self.lda, B.ptr, B.lda), "rls_scale_rows")
+        return B
+
     def normal_operator(self) -> "NormalOperator":
         """A' * A as the unchanged constructors evaluate it: lazy, matrix-free (two GEMVs per apply)"""
         return NormalOperator(self)
+
+
+class WeightingOp:
+    """LinearOperatorCollection.WeightingOp(weights): diag(weights) (docs/src/literate/howto/normal_operator.jl:41)"""
+
+    def __init__(self, weights: "DeviceVector"):
+        self.weights = weights
+
+
+def ProdOp(W: WeightingOp, A: DeviceMatrix) -> DeviceMatrix:
+    """ProdOp(WeightingOp(w), A) (docs/src/literate/howto/normal_operator.jl:42, src/Utils.jl:23,102).  On a GPU with
+    288 GB the weighted operator is materialised once as diag(w) A: A, its adjoint and the normal operator
+    A^H W^H W A (`normalOperator`) then run on the same one-pass / matrix-core kernels as any dense matrix,
+    instead of carrying a diagonal scale through every kernel."""
+    if not isinstance(W, WeightingOp):
+        raise TypeError("ProdOp: only ProdOp(WeightingOp(w), A) is supported")
+    w = W.weights
+    if w.dtype != A.dtype:
+        w = DeviceVector.from_host(w.to_host().astype(A.dtype), A.ctx)
+    WA = A.scale_rows(w)
+    WA.weights, WA.B = W.weights, A
+    return WA
+
+
+def normalOperator(A: DeviceMatrix) -> "NormalOperator":
+    """LinearOperatorCollection.normalOperator(A) (docs/src/literate/howto/normal_operator.jl:43)"""
+    return A.normal_operator()
 
 
 class OperatorHandle:

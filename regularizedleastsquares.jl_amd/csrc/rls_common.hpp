@@ -327,7 +327,8 @@ struct rls_skinny {
   void *X, *R, *P, *V;        // N x nrhs, columns ldv elements apart (caller's)
   int64_t ldv;
   float *Ppack, *Tpack;       // MFMA-operand layouts of P (N x 16 ngroups) and T (M x 16 ngroups)
-  void* Vpart;                // [splits][16 ngroups][N] partial A^H T
+  void* Vpart;                // [splits][16 ngroups][ldvp] partial A^H T
+  int64_t ldvp;               // elements between right-hand sides in Vpart (N for the solver plans)
   cgnr_scalars* sc;           // [nrhs]
 };
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
@@ -337,6 +338,8 @@ int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const 
                         float rel_tol, int max_iter);
 int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which);
 void rls_skinny_tune(int which, int value);
+int32_t rls_skinny_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
+                        int64_t ldg, void* panels);
 
 // ---------------------------------------------------------------------------------------------
 // host-side launch entry points implemented in the .hip files (all enqueue on ctx->stream)

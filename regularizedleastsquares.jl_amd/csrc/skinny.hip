@@ -191,7 +191,7 @@ __device__ static inline void v_mma(f32x4 (&acc)[4], const v_regs<E> (&q)[U]) {
 template <typename E, int WV, int U>
 __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__ A, int64_t lda,
                                                             const E* __restrict__ Tp, E* __restrict__ Vpart,
-                                                            int64_t M, int64_t N, int nrhs_pad) {
+                                                            int64_t M, int64_t N, int nrhs_pad, int64_t ldvp) {
   constexpr bool CX = elem<E>::cplx;
   __shared__ float red[WV][2][4][64];
   const int lane = threadIdx.x & 63;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__
       re += red[ww][0][u][l];
       if constexpr (CX) im += red[ww][1][u][l];
     }
-    Vpart[((int64_t)s * nrhs_pad + 16 * g + j) * N + n0 + c] = elem<E>::make(re, im);
+    Vpart[((int64_t)s * nrhs_pad + 16 * g + j) * ldvp + n0 + c] = elem<E>::make(re, im);
   }
 }
 
@@ -531,13 +531,13 @@ static void launch_v(rls_ctx* ctx, const rls_skinny& K) {
 #define SK_V(W, UU)                                                                                                \
   if (g_v_waves == W && g_v_u == UU) {                                                                             \
     hipLaunchKernelGGL((skinny_v_kernel<E, W, UU>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda,     \
-                       (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16);                                  \
+                       (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16, K.ldvp);                                  \
     return;                                                                                                        \
   }
   SK_V(8, 1) SK_V(8, 2) SK_V(4, 2) SK_V(4, 4) SK_V(2, 1) SK_V(2, 2)
 #undef SK_V
   hipLaunchKernelGGL((skinny_v_kernel<E, 4, 1>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
-                     (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16);
+                     (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16, K.ldvp);
 }
 
 template <typename E, bool INIT, int EPT>
@@ -588,4 +588,32 @@ int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int 
     if (which & 4) launch_u<float2, false>(ctx, K, 0.f, 0.f, 0);
   }
   return sk_status(ctx);
+}
+
+// G = A^H A (setup GEMM of src/CGNR.jl:49) on the matrix cores: the A^H T product with T = A, every
+// 16 columns of A forming one panel; `panels` is an M x N scratch in the operand layout.
+template <typename E>
+static int32_t skinny_gram_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A, int64_t lda, E* G, int64_t ldg,
+                                 E* panels) {
+  rls_skinny K{};
+  K.A = A;
+  K.lda = lda;
+  K.M = M;
+  K.N = N;
+  K.nrhs = (int)N;
+  K.ngroups = (int)(N / 16);
+  K.splits = 1;
+  K.Tpack = (float*)panels;
+  K.Vpart = G;
+  K.ldvp = ldg;
+  const dim3 grid((unsigned)((M + 63) / 64), (unsigned)K.ngroups);
+  hipLaunchKernelGGL(skinny_pack_rows_kernel<E>, grid, dim3(256), 0, ctx->stream, A, lda, (int)N, panels, M, K.ngroups);
+  launch_v<E>(ctx, K);
+  return sk_status(ctx);
+}
+
+int32_t rls_skinny_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
+                        int64_t ldg, void* panels) {
+  return dtype == RLS_F32 ? skinny_gram_typed<float>(ctx, M, N, (const float*)A, lda, (float*)G, ldg, (float*)panels)
+                          : skinny_gram_typed<float2>(ctx, M, N, (const float2*)A, lda, (float2*)G, ldg, (float2*)panels);
 }

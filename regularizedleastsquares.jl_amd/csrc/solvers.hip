@@ -127,6 +127,7 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
   K.Ppack = s->Ppack;
   K.Tpack = s->Tpack;
   K.Vpart = s->Vpart;
+  K.ldvp = s->op->N;
   K.sc = s->sc;
   return K;
 }
@@ -807,6 +808,16 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
   if (!rls_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !G || lda < M || ld < N)
     return rls_fail(ctx, RLS_E_INVALID, "gram: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->tune.batched_mfma && N <= 65535 * 16 && rls_skinny_ok(dtype, M, N, A, lda)) {
+    // matrix cores: A^H T with T = A in 16-column panels (skinny.hip); M x N scratch for the panels
+    void* panels = nullptr;
+    RLS_HIP(ctx, hipMalloc(&panels, (size_t)M * (size_t)N * rls_elem_size(dtype)));
+    int32_t st = rls_skinny_gram(ctx, dtype, M, N, A, lda, G, ld, panels);
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // setup path: the scratch is freed before returning
+    hipFree(panels);
+    if (st == 0 && e != hipSuccess) st = rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+    return st;
+  }
   dim3 grid((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(gram_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)A, lda, M, N, (float*)G, ld);

@@ -172,24 +172,79 @@ class GradientOp:
 # ---- normalisation plumbing (src/Regularization/NormalizedRegularization.jl:40-84) ------------
 
 
-class NoNormalization:
+class AbstractRegularizationNormalization:
     pass
 
 
-class MeasurementBasedNormalization:
-    pass
+class NoNormalization(AbstractRegularizationNormalization):
+    """lambda is used as given (:3-8)"""
 
 
-class SystemMatrixBasedNormalization:
-    pass
+class MeasurementBasedNormalization(AbstractRegularizationNormalization):
+    """lambda is scaled by norm(b, 1) / length(b) (:9-14, 40-43)"""
 
 
-def normalize(norm_scheme, regs, A=None, b=None):
-    """NoNormalization -> identity (:59,69).  The other schemes are setup-time scalars outside the
-    inner loop and are not part of this backend."""
+class SystemMatrixBasedNormalization(AbstractRegularizationNormalization):
+    """lambda is scaled by the mean energy of the system-matrix rows, sum_m rownorm²(A, m) / N (:15-20, 47-58)"""
+
+
+def NormalizedRegularization(reg, factor):
+    """NormalizedRegularization(reg, factor) (:29-38): lambda(reg) * factor.  Represented as a shallow copy of
+    `reg` whose `lam` is the scaled value (the unscaled one is kept, so a later normalize() *updates* the
+    factor as :73 does); type checks of the solvers keep seeing the inner regulariser."""
+    import copy
+    out = copy.copy(reg)
+    base = getattr(reg, "_base_lam", reg.lam)
+    out._base_lam = base
+    out._factor = float(factor)
+    out.lam = float(base) * float(factor)
+    return out
+
+
+def innerreg(reg):
+    if hasattr(reg, "_base_lam"):
+        import copy
+        out = copy.copy(reg)
+        out.lam = reg._base_lam
+        del out._base_lam, out._factor
+        return out
+    return reg
+
+
+def scalefactor(reg):
+    return getattr(reg, "_factor", 1.0)
+
+
+def normalization_factor(norm_scheme, A=None, b=None):
+    """normalize(scheme, A, b) -> factor or None (:40-59)"""
     if norm_scheme is None or isinstance(norm_scheme, NoNormalization):
+        return None
+    if isinstance(norm_scheme, MeasurementBasedNormalization):
+        if b is None:
+            return 1.0
+        return b.norm1() / b.n
+    if isinstance(norm_scheme, SystemMatrixBasedNormalization):
+        if A is None:
+            raise ValueError("SystemMatrixBasedNormalization requires supplying A to the constructor of the solver")
+        # energy[m] = sqrt(rownorm²(A, m)); trace = norm(energy)^2 / N   -- the sum of the squared row norms
+        return A.rownorm2().norm1() / A.N
+    raise TypeError(f"unknown normalization scheme {type(norm_scheme).__name__}")
+
+
+def normalize(norm_scheme, regs, A=None, b=None, in_solver: bool = False):
+    """normalize(scheme, regs, A, b) (:60-68) and, with in_solver=True, normalize(solver, scheme, regs, A, b)
+    as init! calls it (:82-84: the system-matrix factor was already applied by the constructor)."""
+    if in_solver and isinstance(norm_scheme, SystemMatrixBasedNormalization):
         return regs
-    raise NotImplementedError(f"{type(norm_scheme).__name__} is outside the hot-path scope; use NoNormalization()")
+    factor = normalization_factor(norm_scheme, A, b)
+    single = not isinstance(regs, (list, tuple))
+    out = []
+    for r in ([regs] if single else regs):
+        if factor is None or isinstance(r, AbstractProjectionRegularization) or not hasattr(r, "lam"):
+            out.append(r)
+        else:
+            out.append(NormalizedRegularization(r, factor))
+    return out[0] if single else out
 
 
 # ---- generic entry points --------------------------------------------------------------------

@@ -23,8 +23,8 @@ from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21,
                    FistaStatus, check)
 from .arrays import DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle
 from .regularization import (AbstractProjectionRegularization, GradientOp, L1Regularization, L2Regularization,
-                             L21Regularization, NoNormalization, PositiveRegularization, RealRegularization,
-                             TVRegularization, normalize)
+                             L21Regularization, MeasurementBasedNormalization, NoNormalization, PositiveRegularization,
+                             RealRegularization, TVRegularization, normalize)
 
 _EPS32 = float(np.finfo(np.float32).eps)
 
@@ -167,6 +167,7 @@ class CGNR(AbstractLinearSolver):
             raise NotImplementedError("CGNR: x0 != 0 is unsupported (it throws in the reference as well)")
         N = self._op.N
         lib = b.ctx.lib
+        self.L2 = normalize(self.normalizeReg, self.L2, self.A, b, in_solver=True)  # :129
         if state.x is None or state.x.ctx is not b.ctx or state.x.dtype != b.dtype or state.x.n != N:
             state.x, state.x0, state.pl, state.vl = (b.similar(N) for _ in range(4))  # similar(b, ...) :92-95
             if state._plan:
@@ -330,6 +331,9 @@ class FISTA(AbstractLinearSolver):
         """init!(solver, state, b; x0 = 0, theta = 1)   src/FISTA.jl:94-129"""
         N = self._op.N
         lib, h = b.ctx.lib, b.ctx.handle
+        if isinstance(self.normalizeReg, MeasurementBasedNormalization):  # :128 normalises with x0 = A^H b
+            x0n = b if self.A is None else self.A.mul_adj_(b.similar(N), b)
+            self.reg = normalize(self.normalizeReg, self.reg, self.A, x0n, in_solver=True)
         fused = self._fused_kinds()
         fresh = state._bufs is None or state._bufs[0].ctx is not b.ctx or state._bufs[0].dtype != b.dtype
         if fresh:
@@ -526,6 +530,7 @@ class ADMM(AbstractLinearSolver):
         """src/ADMM.jl:166-220"""
         N = self._op.N
         lib, h = b.ctx.lib, b.ctx.handle
+        self.reg = normalize(self.normalizeReg, self.reg, self.A, b, in_solver=True)  # :219
         if state.x is None or state.x.ctx is not b.ctx or state.x.dtype != b.dtype:
             state.x, state.xold, state.beta, state.beta_y = (b.similar(N) for _ in range(4))
             state.z = [b.similar(t.n_out) for t in self.regTrafo]
@@ -788,6 +793,7 @@ class OptISTA(AbstractLinearSolver):
         else:
             self.A.mul_adj_(st.x0, b)
         st.norm_x0 = st.x0.norm()
+        self.reg = normalize(self.normalizeReg, self.reg, self.A, st.x0, in_solver=True)  # src/OptISTA.jl:154
         if np.isscalar(x0):
             st.x.fill_(x0)
         else:
@@ -873,6 +879,7 @@ class POGM(AbstractLinearSolver):
         else:
             self.A.mul_adj_(st.x0, b)
         st.norm_x0 = st.x0.norm()
+        self.reg = normalize(self.normalizeReg, self.reg, self.A, st.x0, in_solver=True)  # src/POGM.jl:163
         if np.isscalar(x0):
             st.x.fill_(x0)
         else:
@@ -1103,7 +1110,8 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
         solver.init_(solver.state, b, **kw)
         return
     if scheduler is BatchedState:
-        if isinstance(solver, CGNR) and isinstance(b, DeviceMatrix) and b.N > 1 and not solver.constr:
+        if (isinstance(solver, CGNR) and isinstance(b, DeviceMatrix) and b.N > 1 and not solver.constr
+                and not isinstance(solver.normalizeReg, MeasurementBasedNormalization)):  # per-column lambda: not batched
             try:
                 st = BatchedState(solver, b)
                 lib, h = b.ctx.lib, b.ctx.handle

@@ -601,3 +601,69 @@ def test_split_bregman_matches_oracle(rls, ctx):
                                   regTrafo=rls.GradientOp((8, 8)), **kw)
     x2 = rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host()
     assert rel(x2, ref2.x) < 5e-5
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_normalization_schemes(rls, ctx, dt):
+    """MeasurementBased / SystemMatrixBased normalisation (src/Regularization/NormalizedRegularization.jl
+    :40-84) -- the factor is computed on the device and scales lambda exactly as the oracle's restatement does"""
+    A, xt, b = O.make_problem(192, 80, dt, 41)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    A64, b64 = A.astype(dt64), b.astype(dt64)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    f_sys = O.normalization_factor("systemmatrix", A64, None)
+    assert abs(Ad.rownorm2().norm1() / A.shape[1] - f_sys) < 1e-5 * f_sys
+    assert rel(Ad.rownorm2().to_host(), np.sum(np.abs(A64) ** 2, axis=1)) < 1e-6
+    lam = 0.05
+    for scheme, key, vec in ((rls.SystemMatrixBasedNormalization(), "systemmatrix", None),
+                             (rls.MeasurementBasedNormalization(), "measurement", b64)):
+        f = O.normalization_factor(key, A64, vec)
+        S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), normalizeReg=scheme, iterations=20)
+        x = rls.solve_(S, bd).to_host()
+        assert abs(S.L2.lam - lam * f) < 1e-5 * lam * f and rls.scalefactor(S.L2) == pytest.approx(f, rel=1e-5)
+        ref = O.CGNR(A64, reg=O.L2Regularization(lam * f), iterations=20)
+        assert rel(x, O.solve(ref, b64)) < 2e-5
+        # solving again re-normalises from the unscaled lambda (NormalizedRegularization.jl:73), it does not compound
+        rls.solve_(S, bd)
+        assert abs(S.L2.lam - lam * f) < 1e-5 * lam * f
+    # FISTA normalises with x0 = A^H b (src/FISTA.jl:128)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    f = O.normalization_factor("measurement", A64, A64.conj().T @ b64)
+    S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-3), normalizeReg=rls.MeasurementBasedNormalization(),
+                               rho=rho, iterations=25)
+    x = rls.solve_(S, bd).to_host()
+    ref = O.FISTA(A64, reg=O.L1Regularization(1e-3 * f), rho=rho, iterations=25)
+    assert rel(x, O.solve(ref, b64)) < 3e-5
+    with pytest.raises(ValueError):
+        rls.createLinearSolver(rls.CGNR, AHA=Ad.gram(), reg=rls.L2Regularization(lam),
+                               normalizeReg=rls.SystemMatrixBasedNormalization())
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_weighted_operator(rls, ctx, dt):
+    """ProdOp(WeightingOp(w), A) and its normal operator A^H W^H W A
+    (docs/src/literate/howto/normal_operator.jl:37-68): solve!(solver(WA; AHA = normalOperator(WA)), w .* b)"""
+    A, xt, b = O.make_problem(4096 if np.dtype(dt).kind == "c" else 256, 2048 if np.dtype(dt).kind == "c" else 96, dt, 43)
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.5, 1.5, A.shape[0]).astype(np.float32)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    WA64 = O.weighted_operator(w.astype(np.float64), A.astype(dt64))
+    wb64 = w.astype(np.float64) * b.astype(dt64)
+    WA = rls.ProdOp(rls.WeightingOp(rls.DeviceVector.from_host(w)), rls.DeviceMatrix.from_host(A))
+    assert rel(WA.to_host(), WA64) < 1e-6
+    S = rls.createLinearSolver(rls.CGNR, WA, AHA=rls.normalOperator(WA), reg=rls.L2Regularization(1e-4), iterations=16)
+    x = rls.solve_(S, rls.DeviceVector.from_host((w * b).astype(dt))).to_host()
+    ref = O.CGNR(WA64, reg=O.L2Regularization(1e-4), iterations=16)
+    assert rel(x, O.solve(ref, wb64)) < 2e-5
+    f = O.normalization_factor("systemmatrix", WA64, None)  # weights^2 * rownorm², GPU ext NormalizedRegularization.jl:7-12
+    assert abs(WA.rownorm2().norm1() / A.shape[1] - f) < 1e-5 * f
+
+
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 1024, 512), (np.float32, 528, 272), (np.complex64, 100, 36)])
+def test_gram_matrix_cores(rls, ctx, dt, M, N):
+    """setup GEMM AHA = A' * A (src/CGNR.jl:49): matrix-core path for 16-aligned shapes, plain kernel otherwise"""
+    A, _, _ = O.make_problem(M, N, dt, 47)
+    G = rls.DeviceMatrix.from_host(A).gram().to_host()
+    ref = A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
+    ref = ref.conj().T @ ref
+    assert rel(G, ref) < 2e-6

@@ -45,9 +45,17 @@ def test_tv_geometry_and_regularization_plumbing(rls):
     assert _tv_geometry((8, 6), 2)[1] == (1,) and _tv_geometry((8, 6), (2, 1))[1] == (1, 0)
     assert lam(rls.L1Regularization(0.25)) == 0.25 and lam(rls.PositiveRegularization()) is None
     regs = [rls.L2Regularization(1.0)]
-    assert normalize(rls.NoNormalization(), regs) is regs
-    with pytest.raises(NotImplementedError):
-        normalize(rls.MeasurementBasedNormalization(), regs)
+    out = normalize(rls.NoNormalization(), regs)
+    assert len(out) == len(regs) and all(a is b for a, b in zip(out, regs))
+    # MeasurementBasedNormalization without b: factor one (NormalizedRegularization.jl:44); projections are never scaled
+    nr = normalize(rls.MeasurementBasedNormalization(), [rls.L1Regularization(0.5), rls.PositiveRegularization()])
+    assert isinstance(nr[0], rls.L1Regularization) and nr[0].lam == 0.5 and rls.scalefactor(nr[0]) == 1.0
+    assert isinstance(nr[1], rls.PositiveRegularization)
+    scaled = rls.NormalizedRegularization(rls.L1Regularization(0.5), 4.0)
+    assert scaled.lam == 2.0 and rls.innerreg(scaled).lam == 0.5
+    assert rls.NormalizedRegularization(scaled, 3.0).lam == 1.5  # update, not compound (:73)
+    with pytest.raises(ValueError):
+        normalize(rls.SystemMatrixBasedNormalization(), regs)
     assert rls.TVRegularization(0.1, shape=(4, 4)).iterationsTV == 10  # ctor default, ProxTV.jl:39
 
 

@@ -180,6 +180,21 @@ def test_next_tier_solvers_converge(dt):
     assert rel(O.solve(O.SplitBregman(A, reg=O.L1Regularization(1e-6), iterations=20), b), x) < 0.1
 
 
+def test_normalization_factors():
+    """src/Regularization/NormalizedRegularization.jl:40-58"""
+    A = np.array([[3.0, 4.0], [0.0, 2.0], [1.0, 0.0]])
+    b = np.array([1.0, -2.0, 3.0j])
+    assert O.normalization_factor("none", A, b) is None
+    assert O.normalization_factor("measurement", A, b) == pytest.approx(2.0)
+    assert O.normalization_factor("measurement", A, None) == 1.0
+    assert O.normalization_factor("systemmatrix", A, None) == pytest.approx((25 + 4 + 1) / 2)
+    w = np.array([2.0, 1.0, 3.0])
+    WA = O.weighted_operator(w, A)  # GPU ext NormalizedRegularization.jl:7-12: weights^2 * rownorm²
+    assert O.normalization_factor("systemmatrix", WA, None) == pytest.approx((4 * 25 + 4 + 9) / 2)
+    with pytest.raises(ValueError):
+        O.normalization_factor("systemmatrix", None, b)
+
+
 def test_cgnr_closed_forms():
     A, x, b = O.make_problem(64, 32, np.complex128, 3)
     for lam in (0.0, 0.5):
