@@ -145,6 +145,24 @@ int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x);
 int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v);
 /* setup GEMM AHA = A' * A (src/CGNR.jl:49) on device; G is N x N column-major, ld >= N */
 int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G, int64_t ld);
+/* At = transpose(A) (no conjugation): N x M column-major, leading dimension ldat >= N.  Row k of A becomes the
+ * contiguous column k of At -- the "structure for row access" that the reference's row-action solvers ask for
+ * (createLinearSolver(Kaczmarz, transpose(A_T)), src/Kaczmarz.jl:391, dot_with_matrix_row(::Transpose…)
+ * src/Utils.jl:63-67, 82-86). */
+int32_t rls_transpose(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* At,
+                      int64_t ldat);
+/* Kaczmarz row sweeps: for i in usedIndices: iterate_row_index (src/Kaczmarz.jl:283-308) =
+ *   tau = dot_with_matrix_row(A, x, row) (src/Utils.jl:55-88, non-conjugating);
+ *   alpha = denom[i] * (u[row] - tau - eps_w * vl[row]);  kaczmarz_update!(A, x, row, alpha): x += alpha * conj(A[row,:])
+ *   (src/Kaczmarz.jl:435-517, GPU ext Kaczmarz.jl:1-31);  vl[row] += alpha * eps_w.
+ * At: transpose(A) as rls_transpose builds it.  X (N x nrhs, ldx), U (M x nrhs, ldu: the right-hand sides b),
+ * VL (M x nrhs, ldvl): one independent solve per column (src/MultiThreading.jl:30-79), one workgroup each.
+ * rows_d[i] (0-based row, = rowindex[usedIndices[i]]) and denom_d[i] in processing order, i < nused, rows distinct;
+ * n_sweeps repeats the same order.  X and VL are updated in place; asynchronous on the context's stream.
+ * RLS_E_UNSUPPORTED for N beyond the register-resident sweep (8192 chunks of 16 bytes = 16384 ComplexF32). */
+int32_t rls_kaczmarz_sweep(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* At, int64_t ldat,
+                           int32_t nrhs, void* X, int64_t ldx, const void* U, int64_t ldu, void* VL, int64_t ldvl,
+                           const int32_t* rows_d, const float* denom_d, int32_t nused, float eps_w, int32_t n_sweeps);
 /* squared row norms of A, out_d[m] = rownorm²(A, m) (src/Utils.jl:20-23) for all rows at once -- the
  * mapreduce(abs2, +, A, dims = 2) of ext/RegularizedLeastSquaresGPUArraysExt/NormalizedRegularization.jl:1-5
  * that normalize(::SystemMatrixBasedNormalization, A, b) (src/Regularization/NormalizedRegularization.jl:47-58)

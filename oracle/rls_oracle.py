@@ -1118,3 +1118,97 @@ def normalization_factor(scheme: str, A=None, b=None):
 def weighted_operator(w, A):
     """(W A) as a dense matrix; its normal operator is A^H W^H W A"""
     return np.asarray(w)[:, None] * A
+
+
+# --------------------------------------------------------------------------------------
+# Kaczmarz  (src/Kaczmarz.jl; SURVEY 8f-4)
+# --------------------------------------------------------------------------------------
+
+
+def init_kaczmarz(A, lam):
+    """initkaczmarz (src/Kaczmarz.jl:372-383): denom[i] = 1 / (rownorm²(A, row) + lambda) for the rows with
+    non-zero norm, rowindex = those rows (0-based here)"""
+    T = real_dtype(A.dtype).type
+    s2 = np.sum(np.abs(A) ** 2, axis=1).astype(T)
+    rowindex = np.nonzero(s2 > 0)[0]
+    denom = (T(1) / (s2[rowindex] + T(lam))).astype(T)
+    return denom, rowindex
+
+
+def row_probabilities(A, rowindex):
+    """rowProbabilities (src/Kaczmarz.jl:327-335)"""
+    s2 = np.sum(np.abs(A) ** 2, axis=1)
+    return s2[rowindex] / np.sum(s2)
+
+
+class Kaczmarz:
+    """src/Kaczmarz.jl:76-159 (ctor), :178-217 (init!), :283-299 (iterate), :303-308 (iterate_row_index),
+    :320 (done).  Deterministic row orders only are pinned: `shuffleRows` / `randomized` take the row order from
+    a NumPy generator (the reference uses Julia's global RNG), passed in as `order_fn(iteration) -> positions`.
+    The greedy-randomized variant is CPU-only in the reference (test/testKaczmarz.jl:114) and not restated.
+    L2 lambda may be a vector (Tikhonov matrix, :385-398): A <- A * diag(1/sqrt(lambda)), lambda = 1,
+    solution scaled by 1/sqrt(lambda) (:262-264)."""
+
+    def __init__(self, A, reg=None, iterations=10, order_fn=None):
+        A = np.asarray(A)
+        self.dtype = A.dtype
+        self.T = real_dtype(self.dtype).type
+        regs = [] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
+        l2 = [r for r in regs if isinstance(r, L2Regularization)]
+        self.L2 = l2[0] if l2 else L2Regularization(0.0)
+        proj = [r for r in regs if _is_projection(r)]
+        rest = [r for r in regs if not isinstance(r, L2Regularization) and not _is_projection(r)]
+        if len(rest) > 1:
+            raise ValueError(f"Kaczmarz does not allow for more than one additional regularization term, found {len(rest)}")
+        self.reg = proj + rest
+        lam = self.L2.lam
+        self.lam_vec = None
+        if np.ndim(lam) == 1:
+            self.lam_vec = np.asarray(lam, dtype=self.T)
+            A = (A * (self.T(1) / np.sqrt(self.lam_vec))[None, :]).astype(self.dtype)
+            lam = self.T(1)
+        self.A = A
+        self.lam = self.T(lam)
+        self.denom, self.rowindex = init_kaczmarz(A, self.lam)
+        self.iterations = int(iterations)
+        self.order_fn = order_fn
+        M, N = A.shape
+        self.u = np.zeros(M, self.dtype)
+        self.x = np.zeros(N, self.dtype)
+        self.vl = np.zeros(M, self.dtype)
+        self.eps_w = self.T(0)
+        self.iteration = 0
+
+    def init(self, b, x0=0):
+        self.x[:] = x0
+        self.vl[:] = 0
+        self.u[:] = b
+        self.eps_w = self.T(1) if self.lam_vec is not None else self.T(np.sqrt(self.lam))
+        self.iteration = 0
+
+    def done(self):
+        return self.iteration >= self.iterations
+
+    def iterate(self):
+        if self.done():
+            return None
+        order = range(len(self.rowindex)) if self.order_fn is None else self.order_fn(self.iteration)
+        for i in order:
+            row = self.rowindex[i]
+            a = self.A[row]
+            tau = np.sum(a * self.x)  # dot_with_matrix_row: dotu, no conjugation (src/Utils.jl:55-88)
+            alpha = self.denom[i] * (self.u[row] - tau - self.eps_w * self.vl[row])
+            self.x += alpha * np.conj(a)  # kaczmarz_update! (src/Kaczmarz.jl:435-439)
+            self.vl[row] += alpha * self.eps_w
+        for r in self.reg:
+            r.prox(self.x)
+        self.iteration += 1
+        return self.x
+
+    def solution(self):
+        if self.lam_vec is not None:
+            return self.x * (self.T(1) / np.sqrt(self.lam_vec))
+        return self.x
+
+    def convergence(self):
+        return {"residual": self.T(nrm2(self.A @ self.x - self.u))}

@@ -15,7 +15,7 @@ from .regularization import (AbstractParameterizedRegularization, AbstractProjec
                              L21Regularization, MeasurementBasedNormalization, NoNormalization,
                              PositiveRegularization, RealRegularization, SystemMatrixBasedNormalization,
                              TVRegularization, NormalizedRegularization, innerreg, lam, norm, normalize, prox_, scalefactor)
-from .solvers import (ADMM, CGNR, FISTA, POGM, OptISTA, SplitBregman, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
+from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
                       SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,
                       iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,
                       solverstate)

@@ -249,6 +249,11 @@ class DeviceMatrix:
         check(h, lib.rls_memcpy_d2d(h, v.ptr, self.ptr + off, self.M * self.dtype.itemsize), "rls_memcpy_d2d")
         return v
 
+    def column_view(self, j: int) -> DeviceVector:
+        """view(b, :, j): shares the matrix's memory (in-place operations on one column)"""
+        off = (self.ptr - self._buf.ptr) + j * self.lda * self.dtype.itemsize
+        return DeviceVector(self.M, self.dtype, self.ctx, _buf=self._buf, _offset=off)
+
     # --- mul! -------------------------------------------------------------------------------
     def gemv_(self, op: int, x: DeviceVector, y: DeviceVector, alpha=1.0, beta=0.0):
         """y = alpha * op(A) * x + beta * y     (5-arg mul!)"""

@@ -338,6 +338,7 @@ int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const 
                         float rel_tol, int max_iter);
 int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which);
 void rls_skinny_tune(int which, int value);
+void rls_kaczmarz_tune(int v);
 int32_t rls_skinny_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
                         int64_t ldg, void* panels);
 

@@ -42,10 +42,17 @@ class L1Regularization(AbstractParameterizedRegularization):
 
 
 class L2Regularization(AbstractParameterizedRegularization):
-    """src/proximalMaps/ProxL2.jl"""
+    """src/proximalMaps/ProxL2.jl.  lambda may be a vector (Tikhonov matrix, used by Kaczmarz: src/Kaczmarz.jl:385-398);
+    it is then kept in `lam_vector` and `lam` is NaN for the scalar consumers."""
 
     def __init__(self, lam, **_kw):
-        self.lam = float(lam)
+        import numpy as _np
+        if _np.ndim(lam) == 1:
+            self.lam_vector = _np.asarray(lam, dtype=_np.float32)
+            self.lam = float("nan")
+        else:
+            self.lam_vector = None
+            self.lam = float(lam)
 
     def prox_(self, x: DeviceVector, lam: float):
         check(x.ctx.handle, x.ctx.lib.rls_prox_l2(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l2")
@@ -198,6 +205,10 @@ def NormalizedRegularization(reg, factor):
     out._base_lam = base
     out._factor = float(factor)
     out.lam = float(base) * float(factor)
+    if getattr(reg, "lam_vector", None) is not None:  # Tikhonov matrix: the vector is what gets scaled
+        base_vec = getattr(reg, "_base_lam_vector", reg.lam_vector)
+        out._base_lam_vector = base_vec
+        out.lam_vector = base_vec * type(base_vec[0])(factor)
     return out
 
 

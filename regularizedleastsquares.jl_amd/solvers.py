@@ -24,7 +24,7 @@ from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21,
 from .arrays import DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle
 from .regularization import (AbstractProjectionRegularization, GradientOp, L1Regularization, L2Regularization,
                              L21Regularization, MeasurementBasedNormalization, NoNormalization, PositiveRegularization,
-                             RealRegularization, TVRegularization, normalize)
+                             RealRegularization, SystemMatrixBasedNormalization, TVRegularization, normalize)
 
 _EPS32 = float(np.finfo(np.float32).eps)
 
@@ -80,6 +80,8 @@ def solverstate(solver):
 
 def solversolution(obj):
     st = obj.state if isinstance(obj, AbstractLinearSolver) else obj
+    if isinstance(obj, AbstractLinearSolver) and hasattr(obj, "_solution") and isinstance(st, KaczmarzState):
+        return obj._solution(st)
     if isinstance(st, BatchedState):
         return st.solutions()
     if isinstance(st, AbstractMatrixSolverState):
@@ -1023,6 +1025,201 @@ class SplitBregman(ADMM):
 
 
 # --------------------------------------------------------------------------------------------
+# Kaczmarz row-action solver: src/Kaczmarz.jl
+# --------------------------------------------------------------------------------------------
+
+
+def _i32_device(a, ctx) -> DeviceVector:
+    """int32 host array -> device buffer (carried in a float32 DeviceVector, bit-preserving)"""
+    return DeviceVector.from_host(np.ascontiguousarray(a, dtype=np.int32).view(np.float32), ctx)
+
+
+class KaczmarzState(AbstractSolverState):
+    """src/Kaczmarz.jl:23-32.  nrhs > 1: the columns of a matrix right-hand side advance in ONE launch, one
+    workgroup per column (backend scheduler, same per-column results as MultiThreadingState)."""
+
+    def __init__(self):
+        self.u = self.x = self.vl = None
+        self.eps_w = 0.0
+        self.iteration = 0
+        self.usedIndices = None
+        self.nrhs = 1
+        self.matrix = False  # x, u, vl are DeviceMatrix (one column per right-hand side)
+        self._rows = self._den = None
+        self.A = None
+
+    def solutions(self) -> List[DeviceVector]:
+        return [self.x.column(j) for j in range(self.nrhs)]
+
+    def _views(self, M: DeviceMatrix) -> List[DeviceVector]:
+        return [M.column_view(j) for j in range(self.nrhs)]
+
+    def convergence(self):
+        """(; residual = norm(A * x - u))  src/Kaczmarz.jl:268"""
+        xs = self._views(self.x) if self.matrix else [self.x]
+        us = self._views(self.u) if self.matrix else [self.u]
+        out = []
+        for x, u in zip(xs, us):
+            t = u.similar(u.n)
+            self.A.mul_transpose_(t, x)  # A x through the stored transpose(A)
+            t.axpy_(-1.0, u)
+            out.append({"residual": t.norm()})
+        return out if self.matrix else out[0]
+
+
+class Kaczmarz(AbstractLinearSolver):
+    """Kaczmarz(A; reg = L2Regularization(0), normalizeReg = NoNormalization(), randomized = false,
+    subMatrixFraction = 0.15, shuffleRows = false, seed = 1234, iterations = 10)   src/Kaczmarz.jl:76-159.
+
+    The whole row sweep of one iteration (:283-299) is one kernel launch (rls_kaczmarz_sweep): x stays in
+    the registers of one workgroup, the rows of A stream through from a transposed copy of A (the
+    row-access layout of :391).  `shuffleRows` / `randomized` draw the row order from a NumPy generator
+    seeded with `seed` (the reference seeds Julia's global RNG, so the orders differ, not the method);
+    `greedy_randomized` is CPU-only in the reference (test/testKaczmarz.jl:114) and raises here."""
+
+    def __init__(self, A=None, *, reg=None, normalizeReg=None, randomized: bool = False, subMatrixFraction=0.15,
+                 shuffleRows: bool = False, seed: int = 1234, iterations: int = 10, greedy_randomized: bool = False,
+                 theta=None):
+        if not isinstance(A, DeviceMatrix):
+            raise TypeError("A must be a DeviceMatrix (the backend is selected by the array type, as in the reference)")
+        if greedy_randomized:
+            raise NotImplementedError("greedy randomized Kaczmarz is not defined for GPU arrays (test/testKaczmarz.jl:114)")
+        self.A_in = A
+        self.normalizeReg = normalizeReg or NoNormalization()
+        regs = normalize(normalizeReg, _as_list(reg) or [L2Regularization(0.0)], A, None)
+        l2 = [r for r in regs if isinstance(r, L2Regularization)]
+        self.L2 = l2[0] if l2 else L2Regularization(0.0)
+        proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
+        rest = [r for r in regs if r is not self.L2 and r not in proj]
+        if len(rest) > 1:
+            raise ValueError(f"Kaczmarz does not allow for more than one additional regularization term, found {len(rest)}")
+        self.reg = proj + rest
+        lam = self.L2.lam_vector if getattr(self.L2, "lam_vector", None) is not None else self.L2.lam
+        if np.ndim(lam) == 1 and not isinstance(self.normalizeReg, (NoNormalization, SystemMatrixBasedNormalization)):
+            raise ValueError("Tikhonov matrix for Kaczmarz is only valid with no or system matrix based normalization")
+        self.randomized, self.shuffleRows, self.seed = bool(randomized), bool(shuffleRows), int(seed)
+        self.iterations = int(iterations)
+        self.subMatrixSize = int(round(subMatrixFraction * A.M))
+        self._setup_rows(lam)
+        self.state = KaczmarzState()
+
+    # initkaczmarz (:372-398): transposed operator, denominators, row index
+    def _setup_rows(self, lam):
+        A, ctx = self.A_in, self.A_in.ctx
+        lib, h = ctx.lib, ctx.handle
+        At = DeviceMatrix(A.N, A.M, A.dtype, ctx)
+        check(h, lib.rls_transpose(h, A.code, A.M, A.N, A.ptr, A.lda, At.ptr, At.lda), "rls_transpose")
+        self._lam_vec = None
+        if np.ndim(lam) == 1:
+            # ||Ax - b||² + ||L x||², L = diag(sqrt(lambda)):  A <- A inv(L), lambda <- 1   (:385-395)
+            self._lam_vec = np.asarray(lam, dtype=np.float32)
+            w = DeviceVector.from_host((np.float32(1) / np.sqrt(self._lam_vec)).astype(A.dtype), ctx)
+            check(h, lib.rls_scale_rows(h, A.code, At.M, At.N, w.ptr, At.ptr, At.lda, At.ptr, At.lda), "rls_scale_rows")
+            Arow = DeviceMatrix(A.M, A.N, A.dtype, ctx)
+            check(h, lib.rls_transpose(h, A.code, At.M, At.N, At.ptr, At.lda, Arow.ptr, Arow.lda), "rls_transpose")
+            lam = 1.0
+        else:
+            Arow = A
+        self.At = At
+        self._lam_used = float(lam)
+        s2 = Arow.rownorm2().to_host()
+        self._s2 = s2
+        self.rowindex = np.nonzero(s2 > 0)[0].astype(np.int64)
+        self.denom = (np.float32(1) / (s2[self.rowindex] + np.float32(lam))).astype(np.float32)
+        self.rowIndexCycle = np.arange(len(self.rowindex))
+        self.probabilities = (s2[self.rowindex] / s2.sum()).astype(np.float64) if self.randomized else None
+
+    def _new_state(self):
+        return KaczmarzState()
+
+    def _upload_order(self, st, order):
+        ctx = self.A_in.ctx
+        st.usedIndices = np.asarray(order, dtype=np.int64)
+        st._rows = _i32_device(self.rowindex[st.usedIndices], ctx)
+        st._den = DeviceVector.from_host(self.denom[st.usedIndices], ctx)
+
+    def init_(self, st: KaczmarzState, b, x0=0):
+        """init!(solver, state, b; x0 = 0)   src/Kaczmarz.jl:178-217"""
+        A = self.A_in
+        lam_prev = self._lam_used
+        if self._lam_vec is None:
+            self.L2 = normalize(self.normalizeReg, self.L2, A, b if isinstance(b, DeviceVector) else None, in_solver=True)
+            self.reg = normalize(self.normalizeReg, self.reg, A, b if isinstance(b, DeviceVector) else None, in_solver=True)
+            if float(self.L2.lam) != lam_prev:  # lambda changed => recompute the denominators (:186-193)
+                self._lam_used = float(self.L2.lam)
+                self.denom = (np.float32(1) / (self._s2[self.rowindex] + np.float32(self._lam_used))).astype(np.float32)
+        self._rng = np.random.default_rng(self.seed) if (self.shuffleRows or self.randomized) else None
+        order = self.rowIndexCycle
+        if self.shuffleRows and not self.randomized:
+            order = self._rng.permutation(len(self.rowindex))
+        st.matrix = isinstance(b, DeviceMatrix)
+        nrhs = b.N if st.matrix else 1
+        st.nrhs = nrhs
+        st.A = self.At
+        if not st.matrix:
+            st.x, st.vl = b.similar(A.N), b.similar(A.M)
+            st.u = b.copy()
+        else:
+            st.x = DeviceMatrix(A.N, nrhs, b.dtype, b.ctx)
+            st.vl = DeviceMatrix(A.M, nrhs, b.dtype, b.ctx)
+            st.u = DeviceMatrix(A.M, nrhs, b.dtype, b.ctx)
+            for j, uj in enumerate(st._views(st.u)):
+                uj.copy_from(b.column_view(j))
+        for col in (st._views(st.x) if st.matrix else [st.x]):
+            if np.isscalar(x0):
+                col.fill_(x0)
+            else:
+                col.copy_from(x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx))
+        for col in (st._views(st.vl) if st.matrix else [st.vl]):
+            col.fill_(0)
+        if not self.randomized:
+            self._upload_order(st, order)
+        st.eps_w = 1.0 if self._lam_vec is not None else float(np.sqrt(np.float32(self._lam_used)))
+        st.iteration = 0
+
+    def _sweep(self, st, n_sweeps):
+        A, ctx = self.A_in, self.A_in.ctx
+        ldx = st.x.lda if st.matrix else A.N
+        ldu = st.u.lda if st.matrix else A.M
+        ldvl = st.vl.lda if st.matrix else A.M
+        check(ctx.handle, ctx.lib.rls_kaczmarz_sweep(ctx.handle, A.code, A.M, A.N, self.At.ptr, self.At.lda, st.nrhs,
+                                                      st.x.ptr, ldx, st.u.ptr, ldu, st.vl.ptr, ldvl, st._rows.ptr,
+                                                      st._den.ptr, len(st.usedIndices), float(st.eps_w), int(n_sweeps)),
+              "rls_kaczmarz_sweep")
+
+    def iterate(self, st: Optional[KaczmarzState] = None):
+        st = st or self.state
+        if st.iteration >= self.iterations:  # done (:320)
+            return None
+        if self.randomized:  # sample!(rowIndexCycle, weights(probabilities), usedIndices, replace = false)  :286-288
+            p = self.probabilities / self.probabilities.sum()
+            self._upload_order(st, self._rng.choice(len(self.rowindex), size=self.subMatrixSize, replace=False, p=p))
+        self._sweep(st, 1)
+        for r in self.reg:
+            for col in (st._views(st.x) if st.matrix else [st.x]):
+                r.prox_(col) if isinstance(r, AbstractProjectionRegularization) else r.prox_(col, r.lam)
+        st.iteration += 1
+        return st.x, st
+
+    def _run(self, st):
+        if not self.reg and not self.randomized and st.iteration < self.iterations:
+            self._sweep(st, self.iterations - st.iteration)  # every remaining sweep in one launch
+            st.iteration = self.iterations
+            return
+        while self.iterate(st) is not None:
+            pass
+
+    def _solution(self, st):
+        """solversolution(solver::Kaczmarz)  :262-265 (Tikhonov matrix: x .* 1 ./ sqrt.(lambda))"""
+        if self._lam_vec is None:
+            return st.solutions() if st.matrix else st.x
+        w = (np.float32(1) / np.sqrt(self._lam_vec)).astype(st.x.dtype)
+        cols = st.solutions() if st.matrix else [st.x]
+        out = [DeviceVector.from_host(c.to_host() * w, c.ctx) for c in cols]
+        return out if st.matrix else out[0]
+
+
+# --------------------------------------------------------------------------------------------
 # matrix right-hand sides: src/MultiThreading.jl
 # --------------------------------------------------------------------------------------------
 
@@ -1108,6 +1305,10 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
         elif isinstance(solver.state, AbstractMatrixSolverState):
             solver.state = solver.state.states[0]  # :39-43
         solver.init_(solver.state, b, **kw)
+        return
+    if scheduler is BatchedState and isinstance(solver, Kaczmarz) and isinstance(b, DeviceMatrix):
+        solver.state = KaczmarzState()
+        solver.init_(solver.state, b, **kw)  # all columns in one launch, one workgroup per column
         return
     if scheduler is BatchedState:
         if (isinstance(solver, CGNR) and isinstance(b, DeviceMatrix) and b.N > 1 and not solver.constr
@@ -1211,9 +1412,9 @@ def createLinearSolver(solver_type, A=None, *, kwargWarning: bool = True, **kwar
 
 
 def linearSolverList():
-    """the solvers of the reference's linearSolverList() that this backend covers (Kaczmarz and the direct
-    solvers are outside the hot-path scope)"""
-    return [CGNR, FISTA, OptISTA, POGM, ADMM, SplitBregman]
+    """the solvers of the reference's linearSolverList() that this backend covers (the direct solvers, DAX and
+    the primal-dual solver are outside the scope)"""
+    return [CGNR, Kaczmarz, FISTA, OptISTA, POGM, ADMM, SplitBregman]
 
 
 # ---- callbacks (src/Callbacks.jl) -- thin host-side helpers ------------------------------------

@@ -667,3 +667,127 @@ def test_gram_matrix_cores(rls, ctx, dt, M, N):
     ref = A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
     ref = ref.conj().T @ ref
     assert rel(G, ref) < 2e-6
+
+
+# ---- Kaczmarz --------------------------------------------------------------------
+
+
+def _one_row_update(rls, ctx, A, k, beta):
+    """kaczmarz_update!(A, x, k, beta) through the sweep entry point: x = 0, denom = 1, u[k] = beta, eps_w = 0"""
+    M, N = A.shape
+    Ad = rls.DeviceMatrix.from_host(A)
+    At = rls.DeviceMatrix(N, M, A.dtype, ctx)
+    lib, h = ctx.lib, ctx.handle
+    rls._lib.check(h, lib.rls_transpose(h, Ad.code, M, N, Ad.ptr, Ad.lda, At.ptr, At.lda), "rls_transpose")
+    assert np.array_equal(At.to_host(), A.T)
+    u = np.zeros(M, A.dtype)
+    u[k] = beta
+    x, ud, vl = rls.DeviceVector.from_host(np.zeros(N, A.dtype)), rls.DeviceVector.from_host(u), rls.DeviceVector.from_host(np.zeros(M, A.dtype))
+    rows = rls.DeviceVector.from_host(np.array([k], np.int32).view(np.float32))
+    den = rls.DeviceVector.from_host(np.ones(1, np.float32))
+    rls._lib.check(h, lib.rls_kaczmarz_sweep(h, Ad.code, M, N, At.ptr, At.lda, 1, x.ptr, N, ud.ptr, M, vl.ptr, M, rows.ptr,
+                                             den.ptr, 1, 0.0, 1), "rls_kaczmarz_sweep")
+    return x.to_host()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("M,N", [(16, 127), (127, 16), (40, 2048), (8, 5000)])
+def test_kaczmarz_update_known_answer(rls, ctx, dt, M, N):
+    """test/testKaczmarz.jl:6-35: kaczmarz_update!(A, b, k, beta) == beta * conj(A[k, :]) (odd and aligned lengths)"""
+    rng = np.random.default_rng(3)
+    A = rng.random((M, N)).astype(dt)
+    beta = dt(0.37)
+    if np.dtype(dt).kind == "c":
+        A = (A + 1j * rng.random((M, N))).astype(dt)
+        beta = dt(0.37 - 0.81j)
+    k = int(rng.integers(0, M))
+    got = _one_row_update(rls, ctx, np.asfortranarray(A), k, beta)
+    assert np.allclose(got, beta * np.conj(A[k, :]), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dt,M,N,lam,its", [(np.complex64, 127, 16, 0.0, 5), (np.float32, 256, 96, 0.05, 4),
+                                            (np.complex64, 96, 250, 0.1, 3), (np.complex64, 4096, 2048, 1e-2, 2)])
+def test_kaczmarz_matches_oracle(rls, ctx, dt, M, N, lam, its):
+    """src/Kaczmarz.jl:283-308: x and vl after `its` full sweeps against the float64 oracle"""
+    A, xt, b = O.make_problem(M, N, dt, 51)
+    A[min(3, M - 1), :] = 0  # a zero row is skipped by initkaczmarz (:376)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    ref = O.Kaczmarz(A.astype(dt64), reg=O.L2Regularization(lam), iterations=its)
+    xr = O.solve(ref, b.astype(dt64))
+    S = rls.createLinearSolver(rls.Kaczmarz, rls.DeviceMatrix.from_host(A), reg=rls.L2Regularization(lam), iterations=its)
+    assert len(S.rowindex) == M - 1
+    x = rls.solve_(S, rls.DeviceVector.from_host(b)).to_host()
+    assert S.state.iteration == its
+    assert rel(x, xr) < 5e-5
+    assert np.linalg.norm(S.state.vl.to_host() - ref.vl) <= 5e-5 * max(np.linalg.norm(ref.vl), 1e-30) + 1e-12
+    res = rls.solverconvergence(S)["residual"]
+    assert abs(res - np.linalg.norm(A.astype(dt64) @ xr - b.astype(dt64))) < 1e-3 * np.linalg.norm(b) + 1e-6
+    # step-by-step with callbacks == the single multi-sweep launch (callback cadence 0..n, test/testCallbacks.jl:6-16)
+    calls = []
+    S2 = rls.createLinearSolver(rls.Kaczmarz, rls.DeviceMatrix.from_host(A), reg=rls.L2Regularization(lam), iterations=its)
+    x2 = rls.solve_(S2, rls.DeviceVector.from_host(b), callbacks=lambda s_, it: calls.append(it)).to_host()
+    assert calls == list(range(its + 1)) and rel(x2, x) < 1e-6
+
+
+def test_kaczmarz_reference_test_suite(rls, ctx):
+    """test/testKaczmarz.jl:37-131 replayed on the device (Float32 instead of Float64 operands)"""
+    rng = np.random.default_rng(12345)
+    M, N = 12, 8
+    A = (rng.random((M, N)) + 1j * rng.random((M, N))).astype(np.complex64)
+    x = (rng.random(N) + 1j * rng.random(N)).astype(np.complex64)
+    b = (A.astype(np.complex128) @ x).astype(np.complex64)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+
+    def solve(Amat, iterations, bvec=bd, **kw):
+        S = rls.createLinearSolver(rls.Kaczmarz, Amat, iterations=iterations, **kw)
+        out = rls.solve_(S, bvec)
+        return out.to_host()
+
+    # Tikhonov matrix (:37-70)
+    regm = rng.random(N).astype(np.float32) + 0.1
+    x_matrix = solve(Ad, 100, reg=[rls.L2Regularization(regm)])
+    As = rls.DeviceMatrix.from_host(np.asfortranarray(A * (1 / np.sqrt(regm))[None, :]).astype(np.complex64))
+    x_approx = solve(As, 100, reg=[rls.L2Regularization(1.0)]) / np.sqrt(regm)
+    assert rel(x_matrix, x_approx) < 1e-4
+    lam = float(rng.random())
+    assert rel(solve(Ad, 100, reg=[rls.L2Regularization(np.full(N, lam, np.float32))]),
+               solve(Ad, 100, reg=[rls.L2Regularization(lam)])) < 1e-4
+    # weighting matrix (:72-90): d * A  vs  ProdOp(WeightingOp(w), A)
+    w = rng.random(M).astype(np.float32) + 0.1
+    reg = rls.L2Regularization(float(rng.random()))
+    dA = rls.DeviceMatrix.from_host(np.asfortranarray(w[:, None] * A).astype(np.complex64))
+    wA = rls.ProdOp(rls.WeightingOp(rls.DeviceVector.from_host(w)), Ad)
+    db = rls.DeviceVector.from_host((w * b).astype(np.complex64))
+    assert rel(solve(wA, 200, bvec=db, reg=reg), solve(dA, 200, bvec=db, reg=reg)) < 1e-5
+    # parameters (:94-131)
+    assert rel(solve(Ad, 200), x) < 0.1
+    assert rel(solve(Ad, 200, shuffleRows=True), x) < 0.1
+    assert rel(solve(Ad, 2000, randomized=True), x) < 0.1
+    with pytest.raises(NotImplementedError):
+        rls.createLinearSolver(rls.Kaczmarz, Ad, greedy_randomized=True)
+    for strategy in (rls.SystemMatrixBasedNormalization(), rls.MeasurementBasedNormalization()):
+        xa = solve(Ad, 200, randomized=True, reg=rls.L2Regularization(0.1), normalizeReg=strategy)
+        assert rel(xa, x) < 0.3
+    # closed form: Kaczmarz on the extended system converges to the Tikhonov solution
+    A64 = A.astype(np.complex128)
+    xt = np.linalg.solve(A64.conj().T @ A64 + 0.3 * np.eye(N), A64.conj().T @ b.astype(np.complex128))
+    assert rel(solve(Ad, 3000, reg=rls.L2Regularization(0.3)), xt) < 1e-4
+    # projection applied after every sweep (:294-296)
+    S = rls.createLinearSolver(rls.Kaczmarz, Ad, iterations=5, reg=[rls.L2Regularization(0.0), rls.RealRegularization()])
+    ref = O.Kaczmarz(A64, reg=[O.L2Regularization(0.0), O.RealRegularization()], iterations=5)
+    assert rel(rls.solve_(S, bd).to_host(), O.solve(ref, b.astype(np.complex128))) < 5e-5
+
+
+def test_kaczmarz_matrix_rhs_one_launch(rls, ctx):
+    """columns of a matrix right-hand side: one workgroup per column in one launch == column-by-column solves"""
+    A, X, B = O.make_problem(192, 128, np.complex64, 53, n_rhs=6)
+    Ad = rls.DeviceMatrix.from_host(A)
+    S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(0.02), iterations=6)
+    xs = rls.solve_(S, rls.DeviceMatrix.from_host(np.asfortranarray(B)), scheduler=rls.BatchedState)
+    S1 = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(0.02), iterations=6)
+    ys = rls.solve_(S1, rls.DeviceMatrix.from_host(np.asfortranarray(B)))  # MultiThreading semantics
+    for j in range(6):
+        one = rls.solve_(rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(0.02), iterations=6),
+                         rls.DeviceVector.from_host(B[:, j])).to_host()
+        assert np.array_equal(xs[j].to_host(), one) and np.array_equal(ys[j].to_host(), one)
+    assert len(rls.solverconvergence(S)) == 6

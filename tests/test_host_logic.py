@@ -14,7 +14,7 @@ def test_filter_kwargs_warns_like_the_reference(rls):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         assert _filter_kwargs(rls.FISTA, False, dict(rho=0.1, bogus=1)) == {"rho": 0.1}
-    assert rls.linearSolverList() == [rls.CGNR, rls.FISTA, rls.OptISTA, rls.POGM, rls.ADMM, rls.SplitBregman]
+    assert rls.linearSolverList() == [rls.CGNR, rls.Kaczmarz, rls.FISTA, rls.OptISTA, rls.POGM, rls.ADMM, rls.SplitBregman]
 
 
 def test_shard_columns_covers_every_column_once(rls):

@@ -180,6 +180,36 @@ def test_next_tier_solvers_converge(dt):
     assert rel(O.solve(O.SplitBregman(A, reg=O.L1Regularization(1e-6), iterations=20), b), x) < 0.1
 
 
+def test_kaczmarz_reference_known_answers():
+    """test/testKaczmarz.jl:37-131 on the oracle (Float64, as the reference's own test runs it) + the closed form
+    that pins the restatement independently: the sweeps converge to (A^H A + lambda I)^-1 A^H b"""
+    rng = np.random.default_rng(12345)
+    M, N = 12, 8
+    A = rng.random((M, N)) + 1j * rng.random((M, N))
+    x = rng.random(N) + 1j * rng.random(N)
+    b = A @ x
+    regm = rng.random(N)
+    x_matrix = O.solve(O.Kaczmarz(A, iterations=100, reg=[O.L2Regularization(regm)]), b)
+    x_approx = O.solve(O.Kaczmarz(A * (1 / np.sqrt(regm))[None, :], iterations=100, reg=[O.L2Regularization(1.0)]), b) / np.sqrt(regm)
+    assert rel(x_matrix, x_approx) < 1e-10
+    lam = rng.random()
+    assert np.allclose(O.solve(O.Kaczmarz(A, iterations=100, reg=[O.L2Regularization(lam)]), b),
+                       O.solve(O.Kaczmarz(A, iterations=100, reg=[O.L2Regularization(np.full(N, lam))]), b))
+    w = rng.random(M)
+    assert np.allclose(O.solve(O.Kaczmarz(O.weighted_operator(w, A), iterations=200, reg=O.L2Regularization(0.3)), w * b),
+                       O.solve(O.Kaczmarz(np.diag(w) @ A, iterations=200, reg=O.L2Regularization(0.3)), w * b))
+    assert rel(O.solve(O.Kaczmarz(A, iterations=200), b), x) < 0.1
+    perm = np.random.default_rng(1).permutation(M)
+    assert rel(O.solve(O.Kaczmarz(A, iterations=200, order_fn=lambda it: perm), b), x) < 0.1
+    xt = np.linalg.solve(A.conj().T @ A + 0.3 * np.eye(N), A.conj().T @ b)
+    assert rel(O.solve(O.Kaczmarz(A, iterations=3000, reg=O.L2Regularization(0.3)), b), xt) < 1e-10
+    # zero rows are skipped (initkaczmarz, src/Kaczmarz.jl:372-383)
+    A0 = A.copy()
+    A0[2] = 0
+    den, idx = O.init_kaczmarz(A0, 0.5)
+    assert 2 not in idx and len(idx) == M - 1 and np.allclose(den, 1 / (np.sum(np.abs(A0[idx]) ** 2, axis=1) + 0.5))
+
+
 def test_normalization_factors():
     """src/Regularization/NormalizedRegularization.jl:40-58"""
     A = np.array([[3.0, 4.0], [0.0, 2.0], [1.0, 0.0]])
