@@ -483,10 +483,12 @@ bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t l
   return ((uintptr_t)A % 16 == 0) && (lda % V == 0);
 }
 
-static int skinny_splits(int64_t M, int64_t N, int ngroups) {
+// Row splits of the A^H T product: a function of the shape only, NOT of the number of right-hand sides, so
+// that a column's arithmetic (and therefore its bits) does not depend on how many columns ride along.
+static int skinny_splits(int64_t M, int64_t N, int /*ngroups*/) {
   if (g_v_splits > 0) return g_v_splits;
-  const int64_t MB = M / 16, wgs = (N / 16) * ngroups;
-  int64_t S = (512 + wgs - 1) / wgs;               // ~2 workgroups of 4 waves per CU
+  const int64_t MB = M / 16, wgs = N / 16;
+  int64_t S = (512 + wgs - 1) / wgs;               // ~2 workgroups of 4 waves per CU for one group
   const int64_t smax = MB / 16 > 0 ? MB / 16 : 1;  // keep >= 16 row blocks (4 per wave) per split
   if (S > smax) S = smax;
   if (S > 16) S = 16;

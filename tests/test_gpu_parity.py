@@ -791,3 +791,71 @@ def test_kaczmarz_matrix_rhs_one_launch(rls, ctx):
                          rls.DeviceVector.from_host(B[:, j])).to_host()
         assert np.array_equal(xs[j].to_host(), one) and np.array_equal(ys[j].to_host(), one)
     assert len(rls.solverconvergence(S)) == 6
+
+
+# ---- BASELINE full sizes through size-independent properties -------------------------------------
+
+
+def test_config4_all_64_columns_full_size(rls, ctx):
+    """BASELINE config 4 (one A 4096 x 2048 CF32, 64 right-hand sides, 32 iterations, relTol = 0) on one GPU:
+    every column converges to its planted solution, a sample of columns matches the float64 oracle, and the
+    batched solve is linear in B (columns scaled / summed on the host give scaled / summed solutions)"""
+    A, X, B = O.make_problem(4096, 2048, np.complex64, 4, n_rhs=64)
+    Ad = rls.DeviceMatrix.from_host(A)
+    S = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+    xs = rls.solve_(S, rls.DeviceMatrix.from_host(np.asfortranarray(B)), scheduler=rls.BatchedState)
+    assert isinstance(S.state, rls.BatchedState) and len(xs) == 64
+    got = np.stack([x.to_host() for x in xs], axis=1)
+    errs = np.linalg.norm(got - X, axis=0) / np.linalg.norm(X, axis=0)
+    assert errs.max() < 1e-4
+    assert all(s_.iteration == 32 for s_ in S.state.status())
+    A64 = A.astype(np.complex128)
+    for j in (0, 17, 63):
+        ref = O.CGNR(A64, iterations=32, relTol=0.0)
+        assert rel(got[:, j], O.solve(ref, B[:, j].astype(np.complex128))) < 2e-5
+    # linearity: column 0 <- 2 b0 - 0.5i b1 must give 2 x0 - 0.5i x1
+    B2 = np.asfortranarray(B[:, :16]).copy()
+    B2[:, 0] = 2 * B[:, 0] - 0.5j * B[:, 1]
+    S2 = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+    ys = rls.solve_(S2, rls.DeviceMatrix.from_host(B2), scheduler=rls.BatchedState)
+    assert rel(ys[0].to_host(), 2 * got[:, 0] - 0.5j * got[:, 1]) < 5e-5
+    assert np.array_equal(ys[5].to_host(), got[:, 5])  # the other columns are untouched, bit for bit
+
+
+def test_config5_shard_size_properties(rls, ctx):
+    """BASELINE config 5 per-GPU shard (8192 x 8192 ComplexF32 = 512 MiB, two-GEMV path): adjoint identity,
+    linearity of the normal operator, monotone CGNR residual, and the iterates against a complex64 NumPy
+    restatement (the float64 oracle would need 1 GiB and minutes)"""
+    M = N = 8192
+    rng = np.random.default_rng(500)
+    A = np.empty((M, N), dtype=np.complex64, order="F")
+    s_ = np.float32(1 / np.sqrt(2))
+    for j0 in range(0, N, 1024):
+        A[:, j0:j0 + 1024] = (rng.standard_normal((M, 1024), dtype=np.float32)
+                              + 1j * rng.standard_normal((M, 1024), dtype=np.float32)) * s_
+    Ad = rls.DeviceMatrix.from_host(A)
+    x = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    y = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
+    xd, yd = rls.DeviceVector.from_host(x), rls.DeviceVector.from_host(y)
+    Ax = rls.DeviceVector(M, np.complex64, ctx)
+    Ahy = rls.DeviceVector(N, np.complex64, ctx)
+    Ad.mul_(Ax, xd)
+    Ad.mul_adj_(Ahy, yd)
+    lhs, rhs = np.vdot(y, Ax.to_host()), np.vdot(Ahy.to_host(), x)  # <y, A x> == <A^H y, x>
+    assert abs(lhs - rhs) < 2e-5 * abs(lhs)
+    assert rel(Ax.to_host(), A @ x) < 1e-5
+    op = rls.OperatorHandle(Ad)
+    z = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    v1, v2, v3 = (rls.DeviceVector(N, np.complex64, ctx) for _ in range(3))
+    op.mul_normal_(v1, xd)
+    op.mul_normal_(v2, rls.DeviceVector.from_host(z))
+    op.mul_normal_(v3, rls.DeviceVector.from_host((2 * x - 1j * z).astype(np.complex64)))
+    assert rel(v3.to_host(), 2 * v1.to_host() - 1j * v2.to_host()) < 1e-5
+    b = (A @ x).astype(np.complex64)
+    res = []
+    S = rls.createLinearSolver(rls.CGNR, Ad, iterations=8, relTol=0.0)
+    got = rls.solve_(S, rls.DeviceVector.from_host(b),
+                     callbacks=lambda s2, it: res.append(rls.solverconvergence(s2)["residual"])).to_host()
+    assert all(b2 < a2 for a2, b2 in zip(res[1:], res[2:]))  # CG on a well-conditioned matrix: monotone here
+    ref = O.CGNR(A, iterations=8, relTol=0.0)  # complex64 restatement, same operation order
+    assert rel(got, O.solve(ref, b)) < 1e-4
