@@ -12,7 +12,7 @@ using RLSMI355X, RegularizedLeastSquares, LinearAlgebra
 using RLSMI355X: RLSVector, RLSMatrix, RLSNormalOp, librls, check, dtypecode
 import RegularizedLeastSquares: prox!, proxL21!, proxTV!, enfReal!, enfPos!, tv_restrictMagnitude!, tv_linearcomb!,
                                 init!, iterate, CGNR, CGNRState, FISTA, FISTAState, L1Regularization, L2Regularization,
-                                TVParams, λ
+                                TVParams, λ, Kaczmarz, KaczmarzState, normalize, SystemMatrixBasedNormalization, done
 
 const V{T} = Union{RLSVector{T}, RLSVector{Complex{T}}}
 
@@ -101,6 +101,58 @@ function iterate(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
     return nothing
   end
   check(state.x.ctx, ccall((:rls_cgnr_step, librls[]), Int32, (Ptr{Cvoid}, Int32), plan, 1), "rls_cgnr_step")
+  state.iteration += 1
+  return state.x, state
+end
+
+# ---- setup path: SystemMatrixBasedNormalization (ext/RegularizedLeastSquaresGPUArraysExt/NormalizedRegularization.jl:1-5)
+function normalize(::SystemMatrixBasedNormalization, A::RLSMatrix{T}, b) where {T}
+  M, N = size(A)
+  e = RLSVector{real(T)}(undef, M; ctx = A.ctx)
+  check(A.ctx, ccall((:rls_rownorm2, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                     A.ctx.handle, dtypecode(T), M, N, A.ptr, M, e.ptr), "rls_rownorm2")
+  return sum(Array(e)) / N   # norm(sqrt.(rownorm²))^2 / N
+end
+
+# ---- fused Kaczmarz sweep: iterate(::Kaczmarz, ::KaczmarzState) = the loop of iterate_row_index (src/Kaczmarz.jl:283-308)
+# The solver is constructed on an RLSMatrix; the transposed copy and the device copies of rowindex / denom live
+# beside the state (rebuilt when init! recomputes the denominators, src/Kaczmarz.jl:186-193).
+const kaczmarz_aux = IdDict{Any,Any}()
+
+function kaczmarz_aux_for(solver::Kaczmarz, state::KaczmarzState{T,<:RLSVector}) where {T}
+  get!(kaczmarz_aux, state) do
+    A = solver.A::RLSMatrix{T}
+    M, N = size(A)
+    At = RLSVector{T}(undef, M * N; ctx = A.ctx)     # transpose(A), N x M column-major
+    check(A.ctx, ccall((:rls_transpose, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+                       A.ctx.handle, dtypecode(T), M, N, A.ptr, M, At.ptr, N), "rls_transpose")
+    (At = At, rows = Ref{Any}(nothing), den = Ref{Any}(nothing), key = Ref{Any}(nothing))
+  end
+end
+
+function iterate(solver::Kaczmarz, state::KaczmarzState{T,<:RLSVector}) where {T}
+  done(solver, state) && return nothing
+  aux = kaczmarz_aux_for(solver, state)
+  if solver.randomized   # the sampling stays on the host, as in the reference (src/Kaczmarz.jl:286-288)
+    RegularizedLeastSquares.StatsBase.sample!(RegularizedLeastSquares.Random.GLOBAL_RNG, solver.rowIndexCycle,
+      RegularizedLeastSquares.StatsBase.weights(solver.probabilities), state.usedIndices, replace = false)
+  end
+  key = (objectid(solver.denom), copy(state.usedIndices))
+  if aux.key[] != key   # upload the processing order: 0-based rows and their denominators
+    aux.rows[] = RLSVector(reinterpret(Float32, Int32.(solver.rowindex[state.usedIndices] .- 1)); ctx = state.x.ctx)
+    aux.den[] = RLSVector(Float32.(solver.denom[state.usedIndices]); ctx = state.x.ctx)
+    aux.key[] = key
+  end
+  A = solver.A::RLSMatrix{T}
+  M, N = size(A)
+  check(A.ctx, ccall((:rls_kaczmarz_sweep, librls[]), Int32,
+                     (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64,
+                      Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Int32),
+                     A.ctx.handle, dtypecode(T), M, N, aux.At.ptr, N, 1, state.x.ptr, N, state.u.ptr, M, state.vl.ptr, M,
+                     aux.rows[].ptr, aux.den[].ptr, length(state.usedIndices), Float32(real(state.ɛw)), 1), "rls_kaczmarz_sweep")
+  for r in solver.reg
+    prox!(r, state.x)
+  end
   state.iteration += 1
   return state.x, state
 end
