@@ -1163,15 +1163,23 @@ class Kaczmarz(AbstractLinearSolver):
             st.x = DeviceMatrix(A.N, nrhs, b.dtype, b.ctx)
             st.vl = DeviceMatrix(A.M, nrhs, b.dtype, b.ctx)
             st.u = DeviceMatrix(A.M, nrhs, b.dtype, b.ctx)
-            for j, uj in enumerate(st._views(st.u)):
-                uj.copy_from(b.column_view(j))
-        for col in (st._views(st.x) if st.matrix else [st.x]):
-            if np.isscalar(x0):
-                col.fill_(x0)
+            if b.lda == b.M and st.u.lda == st.u.M:  # contiguous: one copy for all columns
+                whole = lambda Mx: DeviceVector(Mx.M * Mx.N, Mx.dtype, Mx.ctx, _buf=Mx._buf, _offset=Mx.ptr - Mx._buf.ptr)
+                whole(st.u).copy_from(whole(b))
             else:
-                col.copy_from(x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx))
-        for col in (st._views(st.vl) if st.matrix else [st.vl]):
-            col.fill_(0)
+                for j, uj in enumerate(st._views(st.u)):
+                    uj.copy_from(b.column_view(j))
+        if st.matrix and np.isscalar(x0) and st.x.lda == st.x.M and st.vl.lda == st.vl.M:
+            for Mx, val in ((st.x, x0), (st.vl, 0)):
+                DeviceVector(Mx.M * Mx.N, Mx.dtype, Mx.ctx, _buf=Mx._buf, _offset=Mx.ptr - Mx._buf.ptr).fill_(val)
+        else:
+            for col in (st._views(st.x) if st.matrix else [st.x]):
+                if np.isscalar(x0):
+                    col.fill_(x0)
+                else:
+                    col.copy_from(x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx))
+            for col in (st._views(st.vl) if st.matrix else [st.vl]):
+                col.fill_(0)
         if not self.randomized:
             self._upload_order(st, order)
         st.eps_w = 1.0 if self._lam_vec is not None else float(np.sqrt(np.float32(self._lam_used)))
