@@ -795,6 +795,254 @@ __global__ __launch_bounds__(FIN_THREADS) void fista_pipe_f_kernel(E* b0, E* b1,
   if (tid == 0) *sc = Sn;
 }
 
+// ---- Gram-mode CGNR pipeline: ONE launch per iteration -----------------------------------------
+// With an explicit AHA (the reference constructor's default for a dense Matrix, AHA = A' * A,
+// src/CGNR.jl:49) the operator apply is one N x N GEMV.  A workgroup owns G*V ROWS of AHA (all columns,
+// register slab as above), so its rows of v = AHA p are complete: no partial slab, no reduce kernel.
+// Launch i reads the vectors / partial dots / scalars of parity q = i & 1 (written by launch i-1),
+// applies the pending CG update in its prologue (every workgroup redundantly, workgroup 0 stores) and
+// writes parity q ^ 1; nothing a launch reads is written by the same launch.
+template <typename E, int G, int K, int WV>
+struct gram_lds {
+  E xs[slab_cfg<E, G, K, WV>::NMAX];
+  E part[WV][G][elem<E>::vec];
+  E tw[G * elem<E>::vec];
+  double red[48];
+};
+
+template <typename E, int G, int K, int WV, bool FULL>
+__global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict__ Gm, int64_t ldg, E* __restrict__ x,
+                                                            const E* __restrict__ rc, const E* __restrict__ pc,
+                                                            E* __restrict__ rn_out, E* __restrict__ pn_out,
+                                                            const E* __restrict__ vc, E* __restrict__ vn,
+                                                            const double* __restrict__ dc, double* __restrict__ dn,
+                                                            int ndots, const cgnr_scalars* __restrict__ sc,
+                                                            cgnr_scalars* __restrict__ scn, int64_t Mc, int64_t N,
+                                                            int pair, int order_mode) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT;
+  __shared__ gram_lds<E, G, K, WV> L;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool writer = blockIdx.x == 0;
+  // the small loads go out ahead of the slab (a CU's vector-memory path returns loads in issue order)
+  E pv[EPT], rv[EPT], vv[EPT], xv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    const int64_t ic = i < N ? i : (N - 1);
+    xv[e] = x[ic];
+    pv[e] = pc[ic];
+    rv[e] = rc[ic];
+    vv[e] = vc[ic];
+  }
+  const int dtid = tid < ndots ? tid : 0;
+  double d0 = dc[4 * dtid], d1 = dc[4 * dtid + 1], d2 = dc[4 * dtid + 2];
+  if (order_mode == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    __builtin_amdgcn_s_barrier();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, NV> a[K];
+  slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid >= ndots) d0 = d1 = d2 = 0.0;
+  const cgnr_scalars S = *sc;
+  if (S.done) {  // no-op launch: carry the state over to the other parity
+    if (writer) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        if (i < N) {
+          rn_out[i] = rv[e];
+          pn_out[i] = pv[e];
+          vn[i] = vv[e];
+        }
+      }
+      if (tid == 0) *scn = S;
+    }
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    if (i >= N) pv[e] = elem<E>::zero();
+  }
+  cgnr_scalars Sn;
+  if (S.pending) {
+    E pn[EPT], rn[EPT], al;
+    const bool done = cg_update_elems<E, EPT, C::NT>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    Sn.pending = done ? 0 : 1;
+    if (writer) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        if (i < N) {
+          x[i] = elem<E>::fma(pv[e], al, xv[e]);
+          rn_out[i] = rn[e];
+          pn_out[i] = pn[e];
+          if (done) vn[i] = vv[e];
+        }
+      }
+      if (tid == 0) *scn = Sn;
+    }
+    if (done) return;  // uniform: every workgroup derived the same scalars
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = pn[e];
+    }
+  } else {
+    Sn = S;
+    Sn.pending = 1;
+    if (writer) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        if (i < N) {
+          rn_out[i] = rv[e];
+          pn_out[i] = pv[e];
+        }
+      }
+      if (tid == 0) *scn = Sn;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = pv[e];
+    }
+  }
+  // rows of v = AHA p owned by this workgroup (the first product of slab_finish)
+  const int g = lane % G, s = lane / G, slot = w * C::S + s;
+  const int64_t chunk_id = row_block_of(blockIdx.x, pair) * G + g;
+  if constexpr (!FULL) {
+    const bool row_ok = chunk_id < Mc;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k * C::CPR + slot >= N || !row_ok) a[k] = zero_chunk<E, NV>();
+    }
+  }
+  __syncthreads();  // xs complete
+  E acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = elem<E>::zero();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+    const E xe = L.xs[k * C::CPR + slot];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[k].e[i], xe, acc[i]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
+      float im = 0.f;
+      if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
+      acc[i] = elem<E>::make(re, im);
+    }
+  }
+  if (s == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
+  }
+  __syncthreads();
+  // thread t < G*NV owns row (first chunk of the workgroup) * NV + t: its v entry and its term of the dots
+  double dre = 0.0, dim_ = 0.0, pp = 0.0;
+  if (tid < G * NV) {
+    const int gg = tid / NV, i = tid % NV;
+    E sum = elem<E>::zero();
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+    const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
+    if (row < N) {
+      vn[row] = sum;
+      const E pj = L.xs[row];
+      dre = (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+      dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+      pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+    }
+  }
+  if (w == 0) {  // G*NV <= 16 lanes of wave 0 hold the terms; fixed-order butterfly
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      dre += __shfl_xor(dre, off, 64);
+      dim_ += __shfl_xor(dim_, off, 64);
+      pp += __shfl_xor(pp, off, 64);
+    }
+    if (lane == 0) {
+      dn[4 * blockIdx.x] = dre;
+      dn[4 * blockIdx.x + 1] = dim_;
+      dn[4 * blockIdx.x + 2] = pp;
+    }
+  }
+}
+
+// finish: apply the pending update of parity q and bring x, r, p, v back into the caller's vectors
+// (index 0); the scalars are written to both parities so that the next call starts at parity 0
+template <typename E, int EPT>
+__global__ __launch_bounds__(FIN_THREADS) void cgnr_gram_f_kernel(E* __restrict__ x, const E* rc, const E* pc, E* r0,
+                                                                  E* p0, const E* vc, E* v0,
+                                                                  const double* __restrict__ dc, int ndots,
+                                                                  const cgnr_scalars* sc, cgnr_scalars* sc0,
+                                                                  cgnr_scalars* sc1, int64_t N) {
+  __shared__ double red[48];
+  const int tid = threadIdx.x;
+  const cgnr_scalars S = *sc;
+  E pv[EPT], rv[EPT], vv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * FIN_THREADS;
+    const int64_t ic = i < N ? i : (N - 1);
+    pv[e] = pc[ic];
+    rv[e] = rc[ic];
+    vv[e] = vc[ic];
+    if (i >= N) pv[e] = elem<E>::zero();
+  }
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+  for (int t = tid; t < ndots; t += FIN_THREADS) {
+    d0 += dc[4 * t];
+    d1 += dc[4 * t + 1];
+    d2 += dc[4 * t + 2];
+  }
+  cgnr_scalars Sn = S;
+  if (S.pending && !S.done) {
+    E pn[EPT], rn[EPT], al;
+    cg_update_elems<E, EPT, FIN_THREADS>(S, d0, d1, d2, pv, rv, vv, N, red, pn, rn, al, Sn);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * FIN_THREADS;
+      if (i < N) {
+        x[i] = elem<E>::fma(pv[e], al, x[i]);
+        r0[i] = rn[e];
+        p0[i] = pn[e];
+        v0[i] = vv[e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * FIN_THREADS;
+      if (i < N) {
+        r0[i] = rv[e];
+        p0[i] = pv[e];
+        v0[i] = vv[e];
+      }
+    }
+  }
+  Sn.pending = 0;
+  Sn.cur = 0;
+  Sn.fresh = 0;
+  __syncthreads();
+  if (tid == 0) {
+    *sc0 = Sn;
+    *sc1 = Sn;
+  }
+}
+
+
 struct fused_cfg {
   int G, K, WV;
 };
@@ -1007,6 +1255,88 @@ static int32_t fista_finish_typed(rls_ctx* ctx, const rls_fista_pipe& P) {
   return launch_status(ctx);
 }
 
+// ---- Gram pipeline host side -------------------------------------------------------------------
+struct gram_cfg_t {
+  int K;
+};
+template <typename E>
+static bool gram_pick(int64_t N, int* K) {  // G = 4 (64-byte row pieces: 8 / 16 rows per workgroup), WV = 8
+  const int64_t cpr = 8 * (64 / 4);
+  for (int k : {8, 16, 32}) {
+    if (N <= k * cpr) {
+      *K = k;
+      return true;
+    }
+  }
+  return false;
+}
+
+template <typename E, int K>
+static void launch_gram(rls_ctx* ctx, const rls_gram_pipe& P, int q, int nwg) {
+  using C = slab_cfg<E, 4, K, 8>;
+  const int64_t Mc = P.N / C::NV;
+  const int pair = (nwg % 16 == 0) ? 1 : 0;
+  const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
+#define RLS_LAUNCH_G(FULLV)                                                                                          \
+  hipLaunchKernelGGL((cgnr_gram_kernel<E, 4, K, 8, FULLV>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,    \
+                     P.ldg, (E*)P.x, (const E*)P.r[q], (const E*)P.p[q], (E*)P.r[q ^ 1], (E*)P.p[q ^ 1],               \
+                     (const E*)P.v[q], (E*)P.v[q ^ 1], P.dots + (size_t)q * 4 * nwg, P.dots + (size_t)(q ^ 1) * 4 * nwg, \
+                     nwg, P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, g_order_mode)
+  if (full) RLS_LAUNCH_G(true);
+  else RLS_LAUNCH_G(false);
+#undef RLS_LAUNCH_G
+}
+
+template <typename E>
+static int32_t gram_iteration_typed(rls_ctx* ctx, const rls_gram_pipe& P, int q) {
+  int K = 0;
+  if (!gram_pick<E>(P.N, &K)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "gram pipeline: N too large");
+  const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
+  if (K == 8) launch_gram<E, 8>(ctx, P, q, nwg);
+  else if (K == 16) launch_gram<E, 16>(ctx, P, q, nwg);
+  else launch_gram<E, 32>(ctx, P, q, nwg);
+  return launch_status(ctx);
+}
+
+template <typename E>
+static int32_t gram_finish_typed(rls_ctx* ctx, const rls_gram_pipe& P, int q) {
+  const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
+  const int ept = (int)((P.N + FIN_THREADS - 1) / FIN_THREADS);
+#define RLS_GFIN_CASE(EE)                                                                                           \
+  hipLaunchKernelGGL((cgnr_gram_f_kernel<E, EE>), dim3(1), dim3(FIN_THREADS), 0, ctx->stream, (E*)P.x,               \
+                     (const E*)P.r[q], (const E*)P.p[q], (E*)P.r[0], (E*)P.p[0], (const E*)P.v[q], (E*)P.v[0],       \
+                     P.dots + (size_t)q * 4 * nwg, nwg, P.sc[q], P.sc[0], P.sc[1], P.N)
+  if (ept <= 1) RLS_GFIN_CASE(1);
+  else if (ept <= 2) RLS_GFIN_CASE(2);
+  else RLS_GFIN_CASE(4);
+#undef RLS_GFIN_CASE
+  return launch_status(ctx);
+}
+
+}  // namespace
+
+int rls_gram_pipe_nwg(int32_t dtype, int64_t N) {
+  const int V = dtype == RLS_C32 ? 2 : 4;
+  const int64_t Mc = N / V;
+  return (int)((Mc + 3) / 4);
+}
+bool rls_gram_pipe_ok(int32_t dtype, int64_t N, const void* G, int64_t ldg) {
+  const int V = dtype == RLS_C32 ? 2 : 4;
+  if (!G || N <= 0 || N % V || ldg % V || (reinterpret_cast<uintptr_t>(G) % 16)) return false;
+  if (N > 32 * 128 || N > 4 * FIN_THREADS) return false;
+  if (rls_gram_pipe_nwg(dtype, N) > 512) return false;  // the partial dots are summed one per thread (NT = 512)
+  return 128 * ldg * (int64_t)(dtype == RLS_C32 ? 8 : 4) + (N / V) * 16 < (int64_t)0xffffffffll;
+}
+int32_t rls_gram_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity) {
+  if (dtype == RLS_F32) return gram_iteration_typed<float>(ctx, P, parity & 1);
+  return gram_iteration_typed<float2>(ctx, P, parity & 1);
+}
+int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity) {
+  if (dtype == RLS_F32) return gram_finish_typed<float>(ctx, P, parity & 1);
+  return gram_finish_typed<float2>(ctx, P, parity & 1);
+}
+
+namespace {
 }  // namespace
 
 int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P) {

@@ -21,6 +21,7 @@ struct rls_tuning {
   int fused_normal = 1; // 1: one-pass register-slab normal operator when the shape allows it
   int cgnr_pipeline = 1; // 1: CGNR as slab kernel (with the CG update in its prologue) + reduce kernel
   int batched_mfma = 1;  // 1: batched plans run the two skinny products on the matrix cores (skinny.hip)
+  int gram_pipeline = 1; // 1: Gram-mode CGNR as one launch per iteration (normal.hip)
 };
 
 struct rls_ctx {
@@ -318,6 +319,20 @@ struct rls_cgnr_pipe {
 int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, int which);
+
+// Gram-mode CGNR pipeline (normal.hip): one launch per iteration, every buffer in two parities
+struct rls_gram_pipe {
+  const void* G;
+  int64_t ldg, N;
+  void* x;
+  void *r[2], *p[2], *v[2];   // index 0 = the caller's vectors, 1 = plan scratch
+  double* dots;               // [2][nwg][4]
+  cgnr_scalars* sc[2];
+};
+bool rls_gram_pipe_ok(int32_t dtype, int64_t N, const void* G, int64_t ldg);
+int rls_gram_pipe_nwg(int32_t dtype, int64_t N);
+int32_t rls_gram_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity);
+int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity);
 
 // everything the matrix-core batched kernels need (skinny.hip)
 struct rls_skinny {

@@ -103,12 +103,38 @@ struct rls_cgnr {
   int nrhs;
   int64_t ldv;
   void* slab_b;
+  // Gram-mode pipeline (normal.hip): one launch per iteration, second parity of v and the partial dots
+  bool gram_pipe;
+  void* v1;
+  double* gdots;
   // batched plans on the matrix cores (skinny.hip): packed operands + row-split partials
   bool skinny;
   float *Ppack, *Tpack;
   void* Vpart;
   int splits;
 };
+
+static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
+  return s->gram_pipe && s->op->G && s->op->ctx->tune.gram_pipeline;
+}
+
+static rls_gram_pipe cgnr_gram_desc(const rls_cgnr* s) {
+  rls_gram_pipe P;
+  P.G = s->op->G;
+  P.ldg = s->op->ldg;
+  P.N = s->op->N;
+  P.x = s->x;
+  P.r[0] = s->r;
+  P.r[1] = s->r1;
+  P.p[0] = s->p;
+  P.p[1] = s->p1;
+  P.v[0] = s->v;
+  P.v[1] = s->v1;
+  P.dots = s->gdots;
+  P.sc[0] = s->sc;
+  P.sc[1] = s->scn;
+  return P;
+}
 
 static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
   rls_skinny K;
@@ -839,6 +865,9 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR needs 16-aligned M, N (matrix-core path) or the one-pass register-slab operator");
   rls_cgnr* s = new rls_cgnr();
   s->skinny = skinny;
+  s->gram_pipe = false;
+  s->v1 = nullptr;
+  s->gdots = nullptr;
   s->Ppack = s->Tpack = nullptr;
   s->Vpart = nullptr;
   s->splits = 1;
@@ -876,6 +905,21 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess && nrhs > 1 && !skinny)
       e = hipMalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
   }
+  if (e == hipSuccess && nrhs == 1 && op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
+    const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
+    const size_t nd = (size_t)2 * rls_gram_pipe_nwg(op->dtype, op->N) * 4 * sizeof(double);
+    if (!s->r1) e = hipMalloc(&s->r1, vb);
+    if (e == hipSuccess && !s->p1) e = hipMalloc(&s->p1, vb);
+    if (e == hipSuccess) e = hipMalloc(&s->v1, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->gdots, nd);
+    if (e == hipSuccess && !s->scn) e = hipMalloc((void**)&s->scn, sb);
+    if (e == hipSuccess) e = hipMemset(s->r1, 0, vb);
+    if (e == hipSuccess) e = hipMemset(s->p1, 0, vb);
+    if (e == hipSuccess) e = hipMemset(s->v1, 0, vb);
+    if (e == hipSuccess) e = hipMemset(s->gdots, 0, nd);
+    if (e == hipSuccess) e = hipMemset(s->scn, 0, sb);
+    s->gram_pipe = e == hipSuccess;
+  }
   if (e == hipSuccess && skinny) {
     size_t pb, tb, vb;
     rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
@@ -911,6 +955,8 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->dots) hipFree(s->dots);
   if (s->scn) hipFree(s->scn);
   if (s->slab_b) hipFree(s->slab_b);
+  if (s->v1) hipFree(s->v1);
+  if (s->gdots) hipFree(s->gdots);
   if (s->Ppack) hipFree(s->Ppack);
   if (s->Tpack) hipFree(s->Tpack);
   if (s->Vpart) hipFree(s->Vpart);
@@ -1031,6 +1077,30 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
     }
     s->graph.mode = 2;
     return run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &K]() { return rls_skinny_launch(ctx, dtype, K, 7); });
+  }
+  if (cgnr_use_gram_pipeline(s)) {
+    // one launch per iteration; every call starts at parity 0 (the finish kernel brings the state back to
+    // the caller's vectors), and a graph chunk holds an even number of launches, so the captured parities
+    // are always the right ones
+    const rls_gram_pipe P = cgnr_gram_desc(s);
+    const int32_t dtype = s->op->dtype;
+    if (s->graph.steps && s->graph.mode != 3) {
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph.mode = 3;
+    int parity = 0;
+    auto one = [ctx, dtype, &P, &parity]() {
+      const int32_t st = rls_gram_pipe_iteration(ctx, dtype, P, parity);
+      parity ^= 1;
+      return st;
+    };
+    if (ctx->tune.graph_chunk % 2) {  // an odd chunk would replay the captured parities out of phase
+      for (int i = 0; i < n_steps; ++i) RLS_TRY(one());
+    } else {
+      RLS_TRY(run_steps(ctx, &s->graph, n_steps, one));
+    }
+    return rls_gram_pipe_finish(ctx, dtype, P, n_steps & 1);
   }
   if (cgnr_use_pipeline(s)) {
     // iteration k = K_A (applies update k-1 in its prologue, then one pass over A) + K_R; the last

@@ -345,6 +345,47 @@ def test_cgnr_gram_mode_and_float32_oracle(rls, ctx):
     assert rel(x, ref32.x) < TOL_ITER
 
 
+@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("dt,M,N,lam,iters", [(np.complex64, 4096, 2048, 0.0, 32), (np.float32, 600, 256, 1e-2, 12),
+                                              (np.complex64, 90, 46, 0.1, 9), (np.float32, 5000, 4096, 0.0, 6)])
+def test_cgnr_gram_pipeline_iterates(rls, ctx, dt, M, N, lam, iters, pipe):
+    """Gram mode (AHA = A' * A explicit, the constructor default for a dense Matrix, src/CGNR.jl:49): one launch per
+    iteration.  Step-by-step iterates, a single n-step call, relTol retirement, and the unfused path all agree with
+    the float64 oracle in Gram mode."""
+    ctx.tune(gram_pipeline=pipe)
+    try:
+        ref, sol, b, dt64 = _cgnr_pair(rls, M, N, dt, 7, lam, iters, mode="gram")
+        bd = rls.DeviceVector.from_host(b)
+        ref.init(b.astype(dt64))
+        rls.init_(sol, bd)
+        r0 = np.linalg.norm(ref.A.mul_adj(b.astype(dt64)))
+        for it in range(1, iters + 1):
+            assert ref.iterate() is not None and rls.iterate(sol) is not None
+            if it in (1, 2, 5, iters):
+                st = sol.state
+                assert rel(st.x.to_host(), ref.x) < 2 * TOL_ITER, it
+                assert np.linalg.norm(st.pl.to_host() - ref.p) < 2 * TOL_ITER * r0, it
+                assert np.linalg.norm(st.x0.to_host() - ref.r) < 2 * TOL_ITER * r0, it
+                assert np.linalg.norm(st.vl.to_host() - ref.v) < 2 * TOL_ITER * np.linalg.norm(ref.v) + 1e-30, it
+        assert rls.iterate(sol) is None and sol.state.iteration == iters
+        x_steps = sol.state.x.to_host()
+        x_once = rls.solve_(sol, bd).to_host()  # all iterations in one call (graph chunks + finish)
+        assert rel(x_once, x_steps) < 1e-6
+        # early retirement on relTol: same iteration count as the oracle (+-1 at the threshold)
+        tol = 1e-3
+        ref2 = O.CGNR(ref.A.A, reg=O.L2Regularization(lam), iterations=iters, relTol=tol, normal="gram")
+        O.solve(ref2, b.astype(dt64))
+        kw = dict(AHA=rls.DeviceMatrix.from_host(np.asfortranarray(ref.A.A.astype(dt))).gram())
+        sol2 = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(np.asfortranarray(ref.A.A.astype(dt))),
+                                      reg=rls.L2Regularization(lam), iterations=iters, relTol=tol, **kw)
+        x2 = rls.solve_(sol2, bd).to_host()
+        assert abs(sol2.state.iteration - ref2.iteration) <= 1
+        if sol2.state.iteration == ref2.iteration:
+            assert rel(x2, ref2.x) < 2 * TOL_ITER
+    finally:
+        ctx.tune(gram_pipeline=1)
+
+
 def test_cgnr_callbacks_cadence_and_lstsq(rls, ctx):
     """reference known answers: callbacks fire iterations+1 times and solutions[end] == x_approx
     (test/testCallbacks.jl:6-16); CGNR converges to the least-squares solution."""
