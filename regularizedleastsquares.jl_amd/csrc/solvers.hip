@@ -508,7 +508,32 @@ struct rls_cg {
   cgnr_scalars *psc, *pscn, *psc_h;
   step_graph graph;
   bool used_pipeline;
+  // Gram-mode pipeline: second parity of c (= v) and of the partial dots
+  void* v1;
+  double* gdots;
 };
+
+static bool cg_use_gram_pipeline(const rls_cg* s) {
+  return s->gdots && s->op->G && s->op->ctx->tune.gram_pipeline;
+}
+
+static rls_gram_pipe cg_gram_desc(const rls_cg* s, void* x) {
+  rls_gram_pipe P;
+  P.G = s->op->G;
+  P.ldg = s->op->ldg;
+  P.N = s->op->N;
+  P.x = x;
+  P.r[0] = s->r;
+  P.r[1] = s->r1;
+  P.p[0] = s->u;
+  P.p[1] = s->p1;
+  P.v[0] = s->c;
+  P.v[1] = s->v1;
+  P.dots = s->gdots;
+  P.sc[0] = s->psc;
+  P.sc[1] = s->pscn;
+  return P;
+}
 
 static bool cg_use_pipeline(const rls_cg* s) {
   const rls_ctx* ctx = s->op->ctx;
@@ -1382,12 +1407,29 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   s->dots = nullptr;
   s->psc = s->pscn = s->psc_h = nullptr;
   s->used_pipeline = false;
+  s->v1 = nullptr;
+  s->gdots = nullptr;
   int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
   if (st != 0) {
     delete s;
     return st;
   }
-  if (op->slab) {
+  if (op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
+    const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
+    const size_t nd = (size_t)2 * rls_gram_pipe_nwg(op->dtype, op->N) * 4 * sizeof(double);
+    hipError_t e = hipMalloc(&s->r1, vb);
+    if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
+    if (e == hipSuccess) e = hipMalloc(&s->v1, vb);
+    if (e == hipSuccess) e = hipMemset(s->v1, 0, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->gdots, nd);
+    if (e == hipSuccess) e = hipMemset(s->gdots, 0, nd);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->pscn, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = hipMemset(s->pscn, 0, sizeof(cgnr_scalars));
+    if (e != hipSuccess || alloc_scalars(ctx, &s->psc, &s->psc_h) != 0) {
+      rls_cg_destroy(s);
+      return rls_fail(ctx, (int32_t)e, "cg_create: hipMalloc failed");
+    }
+  } else if (op->slab) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
     const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double);
     hipError_t e = hipMalloc(&s->r1, vb);
@@ -1412,6 +1454,8 @@ int32_t rls_cg_destroy(rls_cg* s) {
   if (s->r1) hipFree(s->r1);
   if (s->p1) hipFree(s->p1);
   if (s->dots) hipFree(s->dots);
+  if (s->v1) hipFree(s->v1);
+  if (s->gdots) hipFree(s->gdots);
   if (s->psc) hipFree(s->psc);
   if (s->pscn) hipFree(s->pscn);
   if (s->psc_h) hipHostFree(s->psc_h);
@@ -1430,6 +1474,38 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
   const int64_t n = op->N;
   // warm start: one operator apply for r = b - (AHA + rho I) x
   RLS_TRY(op_normal(op, x, s->c, nullptr));
+  if (cg_use_gram_pipeline(s)) {
+    s->used_pipeline = true;
+    if (op->dtype == RLS_F32)
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                         (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->psc, rho, reltol,
+                         maxiter);
+    else
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                         (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->psc, rho, reltol,
+                         maxiter);
+    RLS_TRY(launch_status(ctx));
+    const rls_gram_pipe P = cg_gram_desc(s, x);
+    const int32_t dtype = op->dtype;
+    if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 3)) {  // the captured kernels carry x's address
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph.x_bound = x;
+    s->graph.mode = 3;
+    int parity = 0;
+    auto one = [ctx, dtype, &P, &parity]() {
+      const int32_t st = rls_gram_pipe_iteration(ctx, dtype, P, parity);
+      parity ^= 1;
+      return st;
+    };
+    if (ctx->tune.graph_chunk % 2) {
+      for (int i = 0; i < maxiter; ++i) RLS_TRY(one());
+    } else {
+      RLS_TRY(run_steps(ctx, &s->graph, maxiter, one));
+    }
+    return rls_gram_pipe_finish(ctx, dtype, P, maxiter & 1);
+  }
   s->used_pipeline = cg_use_pipeline(s);
   if (s->used_pipeline) {
     if (op->dtype == RLS_F32)
@@ -1443,11 +1519,12 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
     RLS_TRY(launch_status(ctx));
     const rls_cgnr_pipe P = cg_pipe_desc(s, x);
     const int32_t dtype = op->dtype;
-    if (s->graph.exec && s->graph.x_bound != x) {  // the captured kernels carry x's address
+    if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 1)) {  // the captured kernels carry x's address
       hipGraphExecDestroy(s->graph.exec);
       s->graph = step_graph();
     }
     s->graph.x_bound = x;
+    s->graph.mode = 1;
     RLS_TRY(run_steps(ctx, &s->graph, maxiter, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
     return rls_cgnr_pipe_finish(ctx, dtype, P);
   }

@@ -492,6 +492,27 @@ def test_admm_tv_matches_oracle(rls, ctx, dt, M, N, shape):
     assert np.allclose(sol.state.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(sol.state.sk, ref.sk, rtol=2e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("dt,M,N,shape", [(np.float32, 8192, 4096, (64, 64)), (np.complex64, 96, 36, (6, 6))])
+def test_admm_gram_mode_matches_oracle(rls, ctx, dt, M, N, shape):
+    """ADMM(A; AHA = A'*A) -- the constructor default of the reference for a dense Matrix (src/ADMM.jl:82): cg! on the
+    explicit Gram matrix runs through the one-launch-per-iteration Gram pipeline; config 3 shape included"""
+    A, xt, b = O.make_problem(M, N, dt, 3)
+    kw = dict(rho=0.1, iterations=6, iterationsCG=10, tolInner=1e-5)
+    ref = O.ADMM(A, reg=O.TVRegularization(1e-2, shape=shape), normal="gram", **kw)
+    O.solve(ref, b)
+    Ad = rls.DeviceMatrix.from_host(A)
+    sol = rls.createLinearSolver(rls.ADMM, Ad, AHA=Ad.gram(), reg=rls.TVRegularization(1e-2, shape=shape), **kw)
+    x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+    assert sol.state.iteration == ref.iteration and sol.state.cg_iterations == ref.cg_iters
+    assert rel(x, ref.x) < 3e-5
+    ctx.tune(gram_pipeline=0)
+    try:
+        sol2 = rls.createLinearSolver(rls.ADMM, Ad, AHA=Ad.gram(), reg=rls.TVRegularization(1e-2, shape=shape), **kw)
+        assert rel(rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host(), ref.x) < 3e-5
+    finally:
+        ctx.tune(gram_pipeline=1)
+
+
 @pytest.mark.parametrize("vary", ["none", "balance", "PnP"])
 def test_admm_l1_vary_rho_and_gradient_trafo(rls, ctx, vary):
     A, xt, b = O.make_problem(100, 48, np.float32, 21)
