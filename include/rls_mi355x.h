@@ -58,8 +58,13 @@ int32_t rls_ctx_sync(rls_ctx* ctx);
 void* rls_ctx_stream(rls_ctx* ctx);
 const char* rls_last_error_string(rls_ctx* ctx);
 int32_t rls_device_count(int32_t* out);
-/* kernel-selection knobs for measurement sweeps ("gemvn_g", "gemvn_waves", "gemvt_cols",
- * "graph_chunk", "use_graph", "fuse_level"); 0 = built-in heuristic.  Not part of the reference. */
+/* kernel-selection knobs for measurement sweeps and for forcing a path in the parity tests; not part of the
+ * reference.  Per context: "gemvn_g", "gemvn_waves", "gemvt_cols" (0 = heuristic), "graph_chunk", "use_graph",
+ * "fuse_level", "fused_normal" (one-pass normal operator), "cgnr_pipeline" (2-launch CGNR), "gram_pipeline"
+ * (1-launch Gram-mode CGNR / cg), "batched_mfma" (matrix-core batched path and Gram GEMM).  Process-wide
+ * (measurement only, set before the plan is created): "slab_g", "slab_wv", "slab_order", "red_threads",
+ * "tv_fused_max_n", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits",
+ * "kaczmarz_nt". */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
 
 int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out);  /* similar(b, dims...)  src/CGNR.jl:92-95 */

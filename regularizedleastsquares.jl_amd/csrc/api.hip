@@ -100,7 +100,6 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);
   else if (!strcmp(key, "skinny_v_waves")) rls_skinny_tune(1, value);
   else if (!strcmp(key, "skinny_v_splits")) rls_skinny_tune(2, value);
-  else if (!strcmp(key, "skinny_diag")) rls_skinny_tune(3, value);
   else if (!strcmp(key, "kaczmarz_nt")) rls_kaczmarz_tune(value);
   else if (!strcmp(key, "skinny_t_u")) rls_skinny_tune(4, value);
   else if (!strcmp(key, "skinny_v_u")) rls_skinny_tune(5, value);

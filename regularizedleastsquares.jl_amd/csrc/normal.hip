@@ -1256,9 +1256,6 @@ static int32_t fista_finish_typed(rls_ctx* ctx, const rls_fista_pipe& P) {
 }
 
 // ---- Gram pipeline host side -------------------------------------------------------------------
-struct gram_cfg_t {
-  int K;
-};
 template <typename E>
 static bool gram_pick(int64_t N, int* K) {  // G = 4 (64-byte row pieces: 8 / 16 rows per workgroup), WV = 8
   const int64_t cpr = 8 * (64 / 4);
@@ -1336,8 +1333,6 @@ int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P
   return gram_finish_typed<float2>(ctx, P, parity & 1);
 }
 
-namespace {
-}  // namespace
 
 int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P) {
   if (dtype == RLS_F32) return fista_iteration_typed<float>(ctx, P);
