@@ -246,7 +246,7 @@ __device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre,
                                               double* red, E (&pn)[EPT], E (&rn)[EPT], E& a_out,
                                               cgnr_scalars& Sn) {
   const int tid = threadIdx.x;
-  block_sum3(nre, nim, pp, red);
+  block_sum3_n<NT / 64>(nre, nim, pp, red);
   const float lambda = S.lambda;
   const double zeta = S.rr;
   const dcomplex alpha = dc_div({zeta, 0.0}, {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim});
@@ -262,7 +262,7 @@ __device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre,
     rn[e] = ri;
     rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
   }
-  rr = block_sum(rr, red);
+  rr = block_sum_n<NT / 64>(rr, red);
   const double beta = rr / zeta;
   const float bf = (float)beta;
 #pragma unroll
@@ -609,7 +609,7 @@ __device__ static inline bool fista_update_elems(const fista_scalars& S, const E
     const E df = elem<E>::sub(xv, xk[e]);
     d += (double)elem<E>::re(r) * (double)elem<E>::re(df) + (double)elem<E>::im(r) * (double)elem<E>::im(df);
   }
-  block_sum3(rn, d, zero, red);
+  block_sum3_n<NT / 64>(rn, d, zero, red);
   float theta = S.theta;
   if (S.restart && d > 0.0) theta = 1.f;                                  // gradient restart  :171-176
   const float theta_old = theta;                                          // :179
@@ -620,7 +620,7 @@ __device__ static inline bool fista_update_elems(const fista_scalars& S, const E
   const float c1 = (1.f - theta_old) / theta, c2 = (theta_old - 1.f) / theta + 1.f;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) yn[e] = elem<E>::add(elem<E>::scale(c1, xk[e]), elem<E>::scale(c2, xn[e]));
-  Sn = S;
+  RLS_FISTA_COPY(Sn, S);
   Sn.res_norm = res_norm;
   Sn.rel_res_norm = (double)rel;
   Sn.theta = theta;
@@ -662,12 +662,14 @@ __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restri
   chunk<E, C::NV> a[K];
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
-  const fista_scalars S = *sc;
+  fista_scalars S;
+  RLS_FISTA_COPY(S, *sc);
   if (S.done) {
     if (writer && tid == 0) {
-      fista_scalars Sn = S;
+      fista_scalars Sn;
+      RLS_FISTA_COPY(Sn, S);
       Sn.fresh = 0;
-      *scn = Sn;
+      RLS_FISTA_COPY(*scn, Sn);
     }
     return;
   }
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restri
     Sn.ycur = done ? S.ycur : 1 - S.ycur;
     Sn.pending = done ? 0 : 1;
     Sn.fresh = done ? 0 : 1;
-    if (writer && tid == 0) *scn = Sn;
+    if (writer && tid == 0) RLS_FISTA_COPY(*scn, Sn);
     if (done) return;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -707,10 +709,10 @@ __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restri
       if (i < C::NMAX) L.xs[i] = yn[e];
     }
   } else {
-    Sn = S;
+    RLS_FISTA_COPY(Sn, S);
     Sn.pending = 1;
     Sn.fresh = 1;
-    if (writer && tid == 0) *scn = Sn;
+    if (writer && tid == 0) RLS_FISTA_COPY(*scn, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int i = tid + e * C::NT;
@@ -725,11 +727,13 @@ template <typename E>
 __global__ __launch_bounds__(1024) void fista_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
                                                             E* __restrict__ res_raw, fista_scalars* __restrict__ sc,
                                                             const fista_scalars* __restrict__ scn) {
-  const fista_scalars Sn = *scn;
+  fista_scalars Sn;
+  RLS_FISTA_COPY(Sn, *scn);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    fista_scalars c = Sn;
+    fista_scalars c;
+    RLS_FISTA_COPY(c, Sn);
     c.fresh = 0;
-    *sc = c;
+    RLS_FISTA_COPY(*sc, c);
   }
   if (!Sn.fresh) return;
   __shared__ E sm[64][16];
@@ -759,7 +763,8 @@ __global__ __launch_bounds__(FIN_THREADS) void fista_pipe_f_kernel(E* b0, E* b1,
                                                                     const E* __restrict__ res_raw,
                                                                     fista_scalars* __restrict__ sc, int64_t N) {
   __shared__ double red[48];
-  const fista_scalars S = *sc;
+  fista_scalars S;
+  RLS_FISTA_COPY(S, *sc);
   if (!S.pending || S.done) return;
   const int tid = threadIdx.x;
   const E* yc = S.ycur ? y1 : y0;
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(FIN_THREADS) void fista_pipe_f_kernel(E* b0, E* b1,
   Sn.pending = 0;
   Sn.fresh = 0;
   __syncthreads();
-  if (tid == 0) *sc = Sn;
+  if (tid == 0) RLS_FISTA_COPY(*sc, Sn);
 }
 
 // ---- Gram-mode CGNR pipeline: ONE launch per iteration -----------------------------------------
@@ -809,6 +814,52 @@ struct gram_lds {
   E tw[G * elem<E>::vec];
   double red[48];
 };
+
+// rows of AHA * xs owned by this workgroup (the first product of slab_finish): after the call L.part holds the
+// per-wave partial sums, the caller adds them up for its row
+template <typename E, int G, int K, int WV, bool FULL>
+__device__ static inline void gram_rows(chunk<E, elem<E>::vec> (&a)[K], gram_lds<E, G, K, WV>& L, int64_t Mc, int64_t N,
+                                        int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane % G, s = lane / G, slot = w * C::S + s;
+  const int64_t chunk_id = row_block_of(blockIdx.x, pair) * G + g;
+  if constexpr (!FULL) {
+    const bool row_ok = chunk_id < Mc;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k * C::CPR + slot >= N || !row_ok) a[k] = zero_chunk<E, NV>();
+    }
+  }
+  __syncthreads();  // xs complete
+  E acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = elem<E>::zero();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+    const E xe = L.xs[k * C::CPR + slot];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[k].e[i], xe, acc[i]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
+      float im = 0.f;
+      if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
+      acc[i] = elem<E>::make(re, im);
+    }
+  }
+  if (s == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
+  }
+  __syncthreads();
+}
 
 template <typename E, int G, int K, int WV, bool FULL>
 __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict__ Gm, int64_t ldg, E* __restrict__ x,
@@ -912,43 +963,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
       if (i < C::NMAX) L.xs[i] = pv[e];
     }
   }
-  // rows of v = AHA p owned by this workgroup (the first product of slab_finish)
-  const int g = lane % G, s = lane / G, slot = w * C::S + s;
-  const int64_t chunk_id = row_block_of(blockIdx.x, pair) * G + g;
-  if constexpr (!FULL) {
-    const bool row_ok = chunk_id < Mc;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (k * C::CPR + slot >= N || !row_ok) a[k] = zero_chunk<E, NV>();
-    }
-  }
-  __syncthreads();  // xs complete
-  E acc[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) acc[i] = elem<E>::zero();
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
-    const E xe = L.xs[k * C::CPR + slot];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[k].e[i], xe, acc[i]);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int off = G; off < 64; off <<= 1) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
-      float im = 0.f;
-      if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
-      acc[i] = elem<E>::make(re, im);
-    }
-  }
-  if (s == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
-  }
-  __syncthreads();
+  gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
   // thread t < G*NV owns row (first chunk of the workgroup) * NV + t: its v entry and its term of the dots
   double dre = 0.0, dim_ = 0.0, pp = 0.0;
   if (tid < G * NV) {
@@ -1042,6 +1057,159 @@ __global__ __launch_bounds__(FIN_THREADS) void cgnr_gram_f_kernel(E* __restrict_
   }
 }
 
+
+// ---- Gram-mode FISTA: the same one-launch scheme (src/FISTA.jl:139-185 with AHA explicit, :58) ----
+// res_raw = AHA y exists in two parities; x / xold and y keep their own ping-pong (iteration parity, ycur).
+template <typename E, int G, int K, int WV, bool FULL>
+__global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
+                                                             const E* __restrict__ x0, E* __restrict__ res, E* y0,
+                                                             E* y1, const E* __restrict__ rr_cur,
+                                                             E* __restrict__ rr_next,
+                                                             const fista_scalars* __restrict__ sc,
+                                                             fista_scalars* __restrict__ scn, int64_t Mc, int64_t N,
+                                                             int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT;
+  __shared__ gram_lds<E, G, K, WV> L;
+  const int tid = threadIdx.x;
+  const bool writer = blockIdx.x == 0;
+  // the scalars go out FIRST: read after the slab loads they would be a vector load the compiler has to
+  // wait for with vmcnt(0), i.e. behind the whole slab (measured: 23 us per launch instead of 8)
+  fista_scalars S;
+  RLS_FISTA_COPY(S, *sc);
+  E raw[EPT], x0v[EPT], ya[EPT], yb[EPT], ba[EPT], bb[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    const int64_t ic = i < N ? i : (N - 1);
+    raw[e] = rr_cur[ic];
+    x0v[e] = x0[ic];
+    ya[e] = y0[ic];
+    yb[e] = y1[ic];
+    ba[e] = b0[ic];
+    bb[e] = b1[ic];
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, NV> a[K];
+  slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  // No early return below: every path reaches the row product, so the compiler cannot sink part of the
+  // slab loads under a branch (it did: 23 us per launch instead of 8); `active` guards the stores instead.
+  bool active = true;
+  E yv[EPT], xk[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * C::NT;
+    yv[e] = S.ycur ? yb[e] : ya[e];
+    xk[e] = (S.iteration & 1) ? bb[e] : ba[e];  // state.x == buf[iteration & 1]
+    if (i >= N) yv[e] = elem<E>::zero();
+  }
+  fista_scalars Sn;
+  if (S.done) {
+    if (writer && tid == 0) RLS_FISTA_COPY(*scn, S);
+    active = false;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = yv[e];
+    }
+  } else if (S.pending) {
+    E ri[EPT], xn[EPT], yn[EPT];
+    const bool done = fista_update_elems<E, EPT, C::NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    if (writer) {
+      E* xw = (S.iteration & 1) ? b0 : b1;
+      E* yw = S.ycur ? y0 : y1;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        if (i < N) {
+          xw[i] = xn[e];
+          res[i] = ri[e];
+          if (!done) yw[i] = yn[e];
+        }
+      }
+    }
+    Sn.ycur = done ? S.ycur : 1 - S.ycur;
+    Sn.pending = done ? 0 : 1;
+    Sn.fresh = 0;
+    if (writer && tid == 0) RLS_FISTA_COPY(*scn, Sn);
+    if (done) active = false;  // uniform: every workgroup derived the same scalars
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = yn[e];
+    }
+  } else {
+    RLS_FISTA_COPY(Sn, S);
+    Sn.pending = 1;
+    Sn.fresh = 0;
+    if (writer && tid == 0) RLS_FISTA_COPY(*scn, Sn);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = tid + e * C::NT;
+      if (i < C::NMAX) L.xs[i] = yv[e];
+    }
+  }
+  gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
+  if (active && tid < G * NV) {
+    const int gg = tid / NV, i = tid % NV;
+    E sum = elem<E>::zero();
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+    const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
+    if (row < N) rr_next[row] = sum;
+  }
+}
+
+template <typename E, int EPT>
+__global__ __launch_bounds__(FIN_THREADS) void fista_gram_f_kernel(E* b0, E* b1, const E* __restrict__ x0,
+                                                                   E* __restrict__ res, E* y0, E* y1,
+                                                                   const E* __restrict__ rr_cur,
+                                                                   const fista_scalars* sc, fista_scalars* sc0,
+                                                                   fista_scalars* sc1, int64_t N) {
+  __shared__ double red[48];
+  fista_scalars S;
+  RLS_FISTA_COPY(S, *sc);
+  const int tid = threadIdx.x;
+  fista_scalars Sn;
+  RLS_FISTA_COPY(Sn, S);
+  if (S.pending && !S.done) {
+    const E* yc = S.ycur ? y1 : y0;
+    const E* xc = (S.iteration & 1) ? b1 : b0;
+    E raw[EPT], x0v[EPT], yv[EPT], xk[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * FIN_THREADS;
+      const int64_t ic = i < N ? i : (N - 1);
+      raw[e] = rr_cur[ic];
+      x0v[e] = x0[ic];
+      yv[e] = yc[ic];
+      xk[e] = xc[ic];
+    }
+    E ri[EPT], xn[EPT], yn[EPT];
+    const bool done = fista_update_elems<E, EPT, FIN_THREADS>(S, raw, x0v, yv, xk, N, red, ri, xn, yn, Sn);
+    E* xw = (S.iteration & 1) ? b0 : b1;
+    E* yw = S.ycur ? y0 : y1;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * FIN_THREADS;
+      if (i < N) {
+        xw[i] = xn[e];
+        res[i] = ri[e];
+        if (!done) yw[i] = yn[e];
+      }
+    }
+    Sn.ycur = done ? S.ycur : 1 - S.ycur;
+  }
+  Sn.pending = 0;
+  Sn.fresh = 0;
+  __syncthreads();
+  if (tid == 0) {
+    RLS_FISTA_COPY(*sc0, Sn);
+    RLS_FISTA_COPY(*sc1, Sn);
+  }
+}
 
 struct fused_cfg {
   int G, K, WV;
@@ -1310,7 +1478,55 @@ static int32_t gram_finish_typed(rls_ctx* ctx, const rls_gram_pipe& P, int q) {
   return launch_status(ctx);
 }
 
+template <typename E, int K>
+static void launch_fista_gram(rls_ctx* ctx, const rls_fista_gram& P, int q, int nwg) {
+  using C = slab_cfg<E, 4, K, 8>;
+  const int64_t Mc = P.N / C::NV;
+  const int pair = (nwg % 16 == 0) ? 1 : 0;
+  const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
+#define RLS_LAUNCH_FG(FULLV)                                                                                        \
+  hipLaunchKernelGGL((fista_gram_kernel<E, 4, K, 8, FULLV>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,  \
+                     P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (const E*)P.rr[q],     \
+                     (E*)P.rr[q ^ 1], P.sc[q], P.sc[q ^ 1], Mc, P.N, pair)
+  if (full) RLS_LAUNCH_FG(true);
+  else RLS_LAUNCH_FG(false);
+#undef RLS_LAUNCH_FG
+}
+
+template <typename E>
+static int32_t fista_gram_iteration_typed(rls_ctx* ctx, const rls_fista_gram& P, int q) {
+  int K = 0;
+  if (!gram_pick<E>(P.N, &K)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "gram pipeline: N too large");
+  const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
+  if (K == 8) launch_fista_gram<E, 8>(ctx, P, q, nwg);
+  else if (K == 16) launch_fista_gram<E, 16>(ctx, P, q, nwg);
+  else launch_fista_gram<E, 32>(ctx, P, q, nwg);
+  return launch_status(ctx);
+}
+
+template <typename E>
+static int32_t fista_gram_finish_typed(rls_ctx* ctx, const rls_fista_gram& P, int q) {
+  const int ept = (int)((P.N + FIN_THREADS - 1) / FIN_THREADS);
+#define RLS_FGFIN_CASE(EE)                                                                                         \
+  hipLaunchKernelGGL((fista_gram_f_kernel<E, EE>), dim3(1), dim3(FIN_THREADS), 0, ctx->stream, (E*)P.b0, (E*)P.b1,  \
+                     (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (const E*)P.rr[q], P.sc[q], P.sc[0], P.sc[1], P.N)
+  if (ept <= 1) RLS_FGFIN_CASE(1);
+  else if (ept <= 2) RLS_FGFIN_CASE(2);
+  else RLS_FGFIN_CASE(4);
+#undef RLS_FGFIN_CASE
+  return launch_status(ctx);
+}
+
 }  // namespace
+
+int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity) {
+  if (dtype == RLS_F32) return fista_gram_iteration_typed<float>(ctx, P, parity & 1);
+  return fista_gram_iteration_typed<float2>(ctx, P, parity & 1);
+}
+int32_t rls_fista_gram_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity) {
+  if (dtype == RLS_F32) return fista_gram_finish_typed<float>(ctx, P, parity & 1);
+  return fista_gram_finish_typed<float2>(ctx, P, parity & 1);
+}
 
 int rls_gram_pipe_nwg(int32_t dtype, int64_t N) {
   const int V = dtype == RLS_C32 ? 2 : 4;

@@ -189,6 +189,47 @@ __device__ static inline double block_sum(double v, double* smem) {
   return s;
 }
 
+// The same with the wave count as a compile-time constant.  blockDim.x is read from the AQL dispatch packet
+// (s_load through the dispatch pointer); the packet lives in the queue ring in host-visible memory, so that
+// read costs microseconds and depends on the XCD -- harmless where it hides under other waits, 15 us per
+// launch where a barrier or an lgkmcnt(0) wait sits right behind it (measured on the Gram-mode FISTA kernel).
+template <int NW>
+__device__ static inline double block_sum_n(double v, double* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) s += smem[i];
+  return s;
+}
+template <int NW>
+__device__ static inline void block_sum3_n(double& a, double& b, double& c, double* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  __syncthreads();
+  if (lane == 0) {
+    smem[w] = a;
+    smem[16 + w] = b;
+    smem[32 + w] = c;
+  }
+  __syncthreads();
+  double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    sa += smem[i];
+    sb += smem[16 + i];
+    sc += smem[32 + i];
+  }
+  a = sa;
+  b = sb;
+  c = sc;
+}
+
 // three sums with one barrier pair; `smem` needs 48 doubles
 __device__ static inline void block_sum3(double& a, double& b, double& c, double* smem) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -291,6 +332,31 @@ struct fista_scalars {
   int ycur;     // which extrapolated-point buffer is current
   int fresh;    // staging copy only
 };
+// Field-by-field copy.  A plain struct assignment lets the compiler move the fields nobody touches as one
+// byte blob; when that blob is 12 bytes it stays in a private alloca, the alloca is promoted to LDS and
+// indexed with the flat thread id, whose workgroup sizes are read from the AQL dispatch packet in
+// host-visible memory: 15 us per launch on the Gram-mode FISTA kernel (measured, XCD-dependent).
+#define RLS_FISTA_COPY(dst, src)        \
+  do {                                  \
+    (dst).norm_x0 = (src).norm_x0;      \
+    (dst).res_norm = (src).res_norm;    \
+    (dst).rel_res_norm = (src).rel_res_norm; \
+    (dst).rho = (src).rho;              \
+    (dst).theta = (src).theta;          \
+    (dst).theta_old = (src).theta_old;  \
+    (dst).rel_tol = (src).rel_tol;      \
+    (dst).lambda = (src).lambda;        \
+    (dst).iteration = (src).iteration;  \
+    (dst).max_iter = (src).max_iter;    \
+    (dst).done = (src).done;            \
+    (dst).restart = (src).restart;      \
+    (dst).reg_kind = (src).reg_kind;    \
+    (dst).proj_kind = (src).proj_kind;  \
+    (dst).l21_slices = (src).l21_slices; \
+    (dst).pending = (src).pending;      \
+    (dst).ycur = (src).ycur;            \
+    (dst).fresh = (src).fresh;          \
+  } while (0)
 
 // everything the FISTA pipeline kernels need (normal.hip)
 struct rls_fista_pipe {
@@ -333,6 +399,17 @@ bool rls_gram_pipe_ok(int32_t dtype, int64_t N, const void* G, int64_t ldg);
 int rls_gram_pipe_nwg(int32_t dtype, int64_t N);
 int32_t rls_gram_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity);
 int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity);
+
+// Gram-mode FISTA pipeline (normal.hip)
+struct rls_fista_gram {
+  const void* G;
+  int64_t ldg, N;
+  void *b0, *b1, *x0, *res, *y0, *y1;
+  void* rr[2];              // AHA y before "- x0", two parities
+  fista_scalars* sc[2];
+};
+int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);
+int32_t rls_fista_gram_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);
 
 // everything the matrix-core batched kernels need (skinny.hip)
 struct rls_skinny {

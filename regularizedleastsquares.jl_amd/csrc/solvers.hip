@@ -325,8 +325,10 @@ struct rls_fista {
   void *x0, *res;
   void* y;       // extrapolated point (plan-owned), the GEMV input
   void *y1, *res_raw;  // fused pipeline: second extrapolated-point buffer, AHA y before "- x0"
-  fista_scalars* scn;  // staged scalars
+  fista_scalars* scn;  // staged scalars (slab pipeline) / second parity (Gram pipeline)
   bool use_pipe;
+  void* res_raw1;      // Gram pipeline: second parity of AHA y
+  bool use_gram;
   fista_scalars* sc;
   fista_scalars* sc_h;
   step_graph graph;
@@ -452,6 +454,30 @@ static bool fista_pipe_ok(const rls_fista* s) {
   const rls_ctx* ctx = s->op->ctx;
   return s->y1 && s->op->slab && !s->op->G && ctx->tune.fused_normal && ctx->tune.cgnr_pipeline &&
          (s->reg_kind == RLS_REG_NONE || s->reg_kind == RLS_REG_L1 || s->reg_kind == RLS_REG_L2);
+}
+
+static bool fista_gram_ok(const rls_fista* s) {
+  const rls_ctx* ctx = s->op->ctx;
+  return s->res_raw1 && s->op->G && ctx->tune.gram_pipeline &&
+         (s->reg_kind == RLS_REG_NONE || s->reg_kind == RLS_REG_L1 || s->reg_kind == RLS_REG_L2);
+}
+
+static rls_fista_gram fista_gram_desc(const rls_fista* s) {
+  rls_fista_gram P;
+  P.G = s->op->G;
+  P.ldg = s->op->ldg;
+  P.N = s->op->N;
+  P.b0 = s->buf[0];
+  P.b1 = s->buf[1];
+  P.x0 = s->x0;
+  P.res = s->res;
+  P.y0 = s->y;
+  P.y1 = s->y1;
+  P.rr[0] = s->res_raw;
+  P.rr[1] = s->res_raw1;
+  P.sc[0] = s->sc;
+  P.sc[1] = s->scn;
+  return P;
 }
 
 static rls_fista_pipe fista_pipe_desc(const rls_fista* s) {
@@ -1242,9 +1268,16 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   s->y1 = s->res_raw = nullptr;
   s->scn = nullptr;
   s->use_pipe = false;
+  s->res_raw1 = nullptr;
+  s->use_gram = false;
   const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
   hipError_t e = hipMalloc(&s->y, vb);
-  if (e == hipSuccess && op->slab) {
+  const bool gram = op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg);
+  if (e == hipSuccess && gram) {
+    e = hipMalloc(&s->res_raw1, vb);
+    if (e == hipSuccess) e = hipMemset(s->res_raw1, 0, vb);
+  }
+  if (e == hipSuccess && (op->slab || gram)) {
     e = hipMalloc(&s->y1, vb);
     if (e == hipSuccess) e = hipMalloc(&s->res_raw, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sizeof(fista_scalars));
@@ -1256,6 +1289,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
     if (s->y) hipFree(s->y);
     if (s->y1) hipFree(s->y1);
     if (s->res_raw) hipFree(s->res_raw);
+    if (s->res_raw1) hipFree(s->res_raw1);
     if (s->scn) hipFree(s->scn);
     delete s;
     return rls_fail(ctx, (int32_t)e, "fista_create: hipMalloc failed");
@@ -1265,6 +1299,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
     hipFree(s->y);
     if (s->y1) hipFree(s->y1);
     if (s->res_raw) hipFree(s->res_raw);
+    if (s->res_raw1) hipFree(s->res_raw1);
     if (s->scn) hipFree(s->scn);
     delete s;
     return st;
@@ -1280,6 +1315,7 @@ int32_t rls_fista_destroy(rls_fista* s) {
   hipFree(s->y);
   if (s->y1) hipFree(s->y1);
   if (s->res_raw) hipFree(s->res_raw);
+  if (s->res_raw1) hipFree(s->res_raw1);
   if (s->scn) hipFree(s->scn);
   hipFree(s->sc);
   hipHostFree(s->sc_h);
@@ -1325,12 +1361,14 @@ int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, floa
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
                        (long long)s->l21_slices);
   s->initialised = true;
-  const bool pipe = fista_pipe_ok(s);
-  if (pipe != s->use_pipe && s->graph.exec) {  // the captured kernel sequence belongs to the other mode
+  const bool gram = fista_gram_ok(s);
+  const bool pipe = !gram && fista_pipe_ok(s);
+  if ((pipe != s->use_pipe || gram != s->use_gram) && s->graph.exec) {  // captured for another kernel sequence
     hipGraphExecDestroy(s->graph.exec);
     s->graph = step_graph();
   }
   s->use_pipe = pipe;
+  s->use_gram = gram;
   return launch_status(ctx);
 }
 
@@ -1353,6 +1391,24 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_step before fista_init");
   if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "fista_step: n_steps < 0");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->use_gram) {
+    // explicit AHA: one launch per iteration (two-parity state, see cgnr_gram_kernel); the finish kernel
+    // applies the last update and leaves the scalars in both parities, so every call starts at parity 0
+    const rls_fista_gram P = fista_gram_desc(s);
+    const int32_t dtype = s->op->dtype;
+    int parity = 0;
+    auto one = [ctx, dtype, &P, &parity]() {
+      const int32_t st = rls_fista_gram_iteration(ctx, dtype, P, parity);
+      parity ^= 1;
+      return st;
+    };
+    if (ctx->tune.graph_chunk % 2) {
+      for (int i = 0; i < n_steps; ++i) RLS_TRY(one());
+    } else {
+      RLS_TRY(run_steps(ctx, &s->graph, n_steps, one));
+    }
+    return rls_fista_gram_finish(ctx, dtype, P, n_steps & 1);
+  }
   if (s->use_pipe) {
     // iteration k = K_A (applies the gradient/prox/momentum update k-1 in its prologue, then one pass
     // over A for AHA y) + K_R (sums the partial rows); the last update of this call is applied by K_F

@@ -492,6 +492,39 @@ def test_admm_tv_matches_oracle(rls, ctx, dt, M, N, shape):
     assert np.allclose(sol.state.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(sol.state.sk, ref.sk, rtol=2e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("dt,M,N,restart", [(np.complex64, 4096, 2048, "none"), (np.float32, 300, 120, "gradient"),
+                                            (np.complex64, 70, 34, "none")])
+def test_fista_gram_mode_matches_oracle(rls, ctx, dt, M, N, restart, pipe):
+    """FISTA(A; AHA = A'*A) (src/FISTA.jl:58, explicit Gram = the constructor default for a dense Matrix): one launch
+    per iteration; iterates step by step and in one call, with and without the pipeline, against the oracle"""
+    ctx.tune(gram_pipeline=pipe)
+    try:
+        A, xt, b = O.make_problem(M, N, dt, 9)
+        dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+        A64, b64 = A.astype(dt64), b.astype(dt64)
+        rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+        lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+        its = 25
+        ref = O.FISTA(A64, reg=[O.L1Regularization(lam), O.PositiveRegularization()] if restart == "gradient" else O.L1Regularization(lam),
+                      rho=rho, iterations=its, restart=restart, normal="gram")
+        Ad = rls.DeviceMatrix.from_host(A)
+        reg = [rls.L1Regularization(lam), rls.PositiveRegularization()] if restart == "gradient" else rls.L1Regularization(lam)
+        sol = rls.createLinearSolver(rls.FISTA, Ad, AHA=Ad.gram(), reg=reg, rho=rho, iterations=its, restart=restart)
+        bd = rls.DeviceVector.from_host(b)
+        ref.init(b64)
+        rls.init_(sol, bd)
+        for it in range(1, its + 1):
+            assert ref.iterate() is not None and rls.iterate(sol) is not None
+            if it in (1, 2, 7, its):
+                assert rel(sol.state.x.to_host(), ref.x) < 3e-5, it
+        assert rls.iterate(sol) is None
+        x_once = rls.solve_(sol, bd).to_host()
+        assert rel(x_once, ref.x) < 3e-5 and sol.state.iteration == its
+    finally:
+        ctx.tune(gram_pipeline=1)
+
+
 @pytest.mark.parametrize("dt,M,N,shape", [(np.float32, 8192, 4096, (64, 64)), (np.complex64, 96, 36, (6, 6))])
 def test_admm_gram_mode_matches_oracle(rls, ctx, dt, M, N, shape):
     """ADMM(A; AHA = A'*A) -- the constructor default of the reference for a dense Matrix (src/ADMM.jl:82): cg! on the
