@@ -431,6 +431,9 @@ int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const 
 int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which);
 void rls_skinny_tune(int which, int value);
 void rls_kaczmarz_tune(int v);
+bool rls_gram_tiles_ok(int64_t M, int64_t N);
+int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
+                       int64_t ldg);
 int32_t rls_skinny_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
                         int64_t ldg, void* panels);
 

@@ -592,6 +592,129 @@ int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int 
   return sk_status(ctx);
 }
 
+// ---------------------------------------------------------------------------------------------
+// G = A^H A as a Hermitian rank-M update on the matrix cores (setup GEMM of src/CGNR.jl:49, src/FISTA.jl:58,
+// src/ADMM.jl:82).  One workgroup = one 64 x 64 tile of the UPPER triangle (the mirror image is written as
+// the conjugate), 4 waves = 2 x 2 sub-tiles of 32 x 32, each two 16-column blocks on either side.  Both
+// MFMA operands are read straight from A in the same register layout (lane l: column 16 cb + (l & 15),
+// rows 16 mb + 4 (l >> 4) .. + 3 = one 32-byte piece), so nothing is staged or packed; the 64-column strips
+// come out of L2 / the Infinity Cache.  Entry (i, j) and entry (j, i) run the same products in the same
+// order, so the result is Hermitian bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+struct g_regs {
+  float4 x0, x1;  // complex: rows (0,1), (2,3) as (re, im) pairs; real: x0 = rows 0..3
+};
+
+template <typename E>
+__device__ static inline void g_load(g_regs<E> (&r)[4], const E* const (&col)[4], int64_t mb) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4* ap = reinterpret_cast<const float4*>(col[c] + mb * 16);
+    r[c].x0 = ap[0];
+    if constexpr (elem<E>::cplx) r[c].x1 = ap[1];
+  }
+}
+
+template <typename E>
+__device__ static inline void g_mma(f32x4 (&acc)[2][2][4], const g_regs<E> (&r)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if constexpr (elem<E>::cplx) {
+          const float4 ia = t < 2 ? r[a].x0 : r[a].x1, jb = t < 2 ? r[2 + b].x0 : r[2 + b].x1;
+          const float ar = (t & 1) ? ia.z : ia.x, ai = (t & 1) ? ia.w : ia.y;
+          const float br = (t & 1) ? jb.z : jb.x, bi = (t & 1) ? jb.w : jb.y;
+          acc[a][b][0] = mfma4(ar, br, acc[a][b][0]);
+          acc[a][b][1] = mfma4(ai, bi, acc[a][b][1]);
+          acc[a][b][2] = mfma4(ar, bi, acc[a][b][2]);
+          acc[a][b][3] = mfma4(ai, br, acc[a][b][3]);
+        } else {
+          const float ia[4] = {r[a].x0.x, r[a].x0.y, r[a].x0.z, r[a].x0.w};
+          const float jb[4] = {r[2 + b].x0.x, r[2 + b].x0.y, r[2 + b].x0.z, r[2 + b].x0.w};
+          acc[a][b][t & 1] = mfma4(ia[t], jb[t], acc[a][b][t & 1]);
+        }
+      }
+    }
+  }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const E* __restrict__ A, int64_t lda, E* __restrict__ G,
+                                                        int64_t ldg, int64_t M, int64_t N) {
+  constexpr bool CX = elem<E>::cplx;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // tile index -> (bi <= bj) of the upper triangle, T tiles per side
+  const int T = (int)(N / 64);
+  int bj = (int)((sqrtf(8.f * (float)blockIdx.x + 1.f) - 1.f) * 0.5f);
+  while ((bj + 1) * (bj + 2) / 2 <= (int)blockIdx.x) ++bj;
+  while (bj * (bj + 1) / 2 > (int)blockIdx.x) --bj;
+  const int bi = (int)blockIdx.x - bj * (bj + 1) / 2;
+  (void)T;
+  const int wi = w >> 1, wj = w & 1;
+  const int ib0 = bi * 4 + 2 * wi, jb0 = bj * 4 + 2 * wj;  // first 16-column block on either side
+  const E* col[4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    col[c] = A + ((int64_t)(ib0 + c) * 16 + (lane & 15)) * lda + 4 * (lane >> 4);
+    col[2 + c] = A + ((int64_t)(jb0 + c) * 16 + (lane & 15)) * lda + 4 * (lane >> 4);
+  }
+  f32x4 acc[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[a][b][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t MB = M / 16;
+  g_regs<E> r0[4], r1[4];
+  g_load<E>(r0, col, 0);
+  int64_t mb = 0;
+  for (; mb + 2 < MB; mb += 2) {
+    g_load<E>(r1, col, mb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    g_mma<E>(acc, r0);
+    __builtin_amdgcn_sched_barrier(0);
+    g_load<E>(r0, col, mb + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    g_mma<E>(acc, r1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (mb + 1 < MB) {
+    g_load<E>(r1, col, mb + 1);
+    g_mma<E>(acc, r0);
+    g_mma<E>(acc, r1);
+  } else {
+    g_mma<E>(acc, r0);
+  }
+  // accumulator register u of lane (q = l >> 4, j' = l & 15) is entry (row 4 q + u, column j') of the block
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f32x4 gre, gim;
+      if constexpr (CX) {
+        gre = acc[a][b][0] + acc[a][b][1];
+        gim = acc[a][b][2] - acc[a][b][3];
+      } else {
+        gre = acc[a][b][0] + acc[a][b][1];
+        gim = gre;
+      }
+      const int64_t j = (int64_t)(jb0 + b) * 16 + (lane & 15);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = (int64_t)(ib0 + a) * 16 + 4 * (lane >> 4) + u;
+        G[i + j * ldg] = elem<E>::make(gre[u], gim[u]);
+        G[j + i * ldg] = elem<E>::make(gre[u], -gim[u]);  // the mirror image (for a diagonal tile: the same values)
+      }
+    }
+  }
+}
+
 // G = A^H A (setup GEMM of src/CGNR.jl:49) on the matrix cores: the A^H T product with T = A, every
 // 16 columns of A forming one panel; `panels` is an M x N scratch in the operand layout.
 template <typename E>
@@ -611,6 +734,20 @@ static int32_t skinny_gram_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A,
   const dim3 grid((unsigned)((M + 63) / 64), (unsigned)K.ngroups);
   hipLaunchKernelGGL(skinny_pack_rows_kernel<E>, grid, dim3(256), 0, ctx->stream, A, lda, (int)N, panels, M, K.ngroups);
   launch_v<E>(ctx, K);
+  return sk_status(ctx);
+}
+
+bool rls_gram_tiles_ok(int64_t M, int64_t N) { return N % 64 == 0 && M % 16 == 0 && N / 64 <= 2000; }
+
+int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
+                       int64_t ldg) {
+  const int64_t T = N / 64;
+  const dim3 grid((unsigned)(T * (T + 1) / 2));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(gram_mfma_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)A, lda, (float*)G, ldg, M, N);
+  else
+    hipLaunchKernelGGL(gram_mfma_kernel<float2>, grid, dim3(256), 0, ctx->stream, (const float2*)A, lda, (float2*)G, ldg,
+                       M, N);
   return sk_status(ctx);
 }
 

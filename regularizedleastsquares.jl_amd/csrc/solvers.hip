@@ -885,6 +885,8 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
   if (!rls_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !G || lda < M || ld < N)
     return rls_fail(ctx, RLS_E_INVALID, "gram: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->tune.batched_mfma && rls_gram_tiles_ok(M, N) && rls_skinny_ok(dtype, M, N, A, lda))
+    return rls_gram_tiles(ctx, dtype, M, N, A, lda, G, ld);  // Hermitian 64 x 64 tiles, no scratch
   if (ctx->tune.batched_mfma && N <= 65535 * 16 && rls_skinny_ok(dtype, M, N, A, lda)) {
     // matrix cores: A^H T with T = A in 16-column panels (skinny.hip); M x N scratch for the panels
     void* panels = nullptr;

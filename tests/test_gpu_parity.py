@@ -754,7 +754,8 @@ def test_weighted_operator(rls, ctx, dt):
     assert abs(WA.rownorm2().norm1() / A.shape[1] - f) < 1e-5 * f
 
 
-@pytest.mark.parametrize("dt,M,N", [(np.complex64, 1024, 512), (np.float32, 528, 272), (np.complex64, 100, 36)])
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 1024, 512), (np.float32, 528, 272), (np.complex64, 100, 36),
+                                    (np.complex64, 4096, 2048), (np.float32, 400, 192), (np.complex64, 48, 64)])
 def test_gram_matrix_cores(rls, ctx, dt, M, N):
     """setup GEMM AHA = A' * A (src/CGNR.jl:49): matrix-core path for 16-aligned shapes, plain kernel otherwise"""
     A, _, _ = O.make_problem(M, N, dt, 47)
@@ -762,6 +763,8 @@ def test_gram_matrix_cores(rls, ctx, dt, M, N):
     ref = A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
     ref = ref.conj().T @ ref
     assert rel(G, ref) < 2e-6
+    if N % 64 == 0 and M % 16 == 0:  # Hermitian tile kernel: symmetric bit for bit
+        assert np.array_equal(G, G.conj().T)
 
 
 # ---- Kaczmarz --------------------------------------------------------------------
