@@ -150,6 +150,22 @@ int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x);
 int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v);
 /* setup GEMM AHA = A' * A (src/CGNR.jl:49) on device; G is N x N column-major, ld >= N */
 int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G, int64_t ld);
+/* Fused elementwise half of one OptISTA iteration (src/OptISTA.jl:176-204), after res = AHA x:
+ *   zold = z; z = y; res -= x0; y -= step res; prox!(reg, y, thr); z = c_z z + x + c_y y; x = c_x x + c_zn z + c_zo zold
+ * with step = rho gamma, thr = rho gamma lambda, c_z = -1/gamma, c_y = 1/gamma, c_x = -beta, c_zn = 1 + alpha + beta,
+ * c_zo = -alpha (host-side Float32 recurrences).  reg_kind: RLS_REG_NONE / L1 / L2.  *res_norm_h = ||res|| (synchronises). */
+int32_t rls_optista_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* x, void* y, void* z,
+                           void* zold, float step, int32_t reg_kind, float thr, float c_z, float c_y, float c_x,
+                           float c_zn, float c_zo, float* res_norm_h);
+/* Fused elementwise half of one POGM iteration (src/POGM.jl:176-233), after res = AHA x.  On entry xbuf = x_k and
+ * ybuf = y_{k-1}; on exit xbuf holds the gradient point x_k - rho res (the new y after the reference's swap, :203) and
+ * ybuf the new x: the caller swaps its two references.  x_new = prox(c_y y + c_x1 (x - rho res) + c_xo x + c_z z),
+ * z = the pre-prox value, xold = x_k.  restart != 0: the gradient-restart vector w is updated as in :218-232 with
+ * rho_over_gamma.  out_h: float[4] = { ||res||, real<w,x>, real<w,z>, real<w,res> } (synchronises). */
+int32_t rls_pogm_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                        void* xold, void* z, void* w, float rho, float c_y, float c_x1, float c_xo, float c_z,
+                        int32_t reg_kind, float thr, int32_t proj_kind, int32_t restart, float rho_over_gamma,
+                        float* out_h);
 /* At = transpose(A) (no conjugation): N x M column-major, leading dimension ldat >= N.  Row k of A becomes the
  * contiguous column k of At -- the "structure for row access" that the reference's row-action solvers ask for
  * (createLinearSolver(Kaczmarz, transpose(A_T)), src/Kaczmarz.jl:391, dot_with_matrix_row(::Transpose…)

@@ -1,0 +1,150 @@
+// Fused elementwise halves of the OptISTA and POGM iterations: everything of iterate that follows
+// res = AHA x (src/OptISTA.jl:176-204, src/POGM.jl:176-233) in ONE launch instead of 8-12 BLAS-1 style launches.
+// The momentum coefficients depend on the iteration index only and are computed by the host in Float32 exactly as
+// the reference does; the kernels return the data-dependent scalars (||res||, and for POGM's gradient restart the
+// real parts of <w,x>, <w,z>, <w,res>) through the context's result block.
+#include "rls_common.hpp"
+
+constexpr int PGM_THREADS = 1024;
+
+template <typename E>
+__device__ static inline double redot(E a, E b) {  // real(conj(a) * b)
+  return (double)elem<E>::re(a) * (double)elem<E>::re(b) + (double)elem<E>::im(a) * (double)elem<E>::im(b);
+}
+
+// zold = z; z = y; res -= x0; y -= step * res; prox(y, thr); z = z / (-gamma) + x + y / gamma;
+// x = -beta x + (1 + alpha + beta) z - alpha zold
+template <typename E>
+__global__ __launch_bounds__(PGM_THREADS) void optista_update_kernel(E* __restrict__ res, const E* __restrict__ x0,
+                                                                     E* __restrict__ x, E* __restrict__ y,
+                                                                     E* __restrict__ z, E* __restrict__ zold, int64_t n,
+                                                                     float step, int reg_kind, float thr, float c_z,
+                                                                     float c_y, float c_x, float c_zn, float c_zo,
+                                                                     float* __restrict__ out) {
+  __shared__ double sm[16];
+  double rn = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += PGM_THREADS) {
+    const E zo = z[i], ztmp = y[i], xi = x[i];
+    const E r = elem<E>::sub(res[i], x0[i]);
+    res[i] = r;
+    rn += redot<E>(r, r);
+    E yn = elem<E>::add(ztmp, elem<E>::scale(-step, r));
+    yn = fista_prox_elem<E>(yn, reg_kind, thr);
+    E zn = elem<E>::add(elem<E>::scale(c_z, ztmp), xi);
+    zn = elem<E>::add(zn, elem<E>::scale(c_y, yn));
+    E xn = elem<E>::add(elem<E>::scale(c_x, xi), elem<E>::scale(c_zn, zn));
+    xn = elem<E>::add(xn, elem<E>::scale(c_zo, zo));
+    zold[i] = zo;
+    y[i] = yn;
+    z[i] = zn;
+    x[i] = xn;
+  }
+  rn = block_sum(rn, sm);
+  if (threadIdx.x == 0) out[0] = (float)sqrt(rn);
+}
+
+// xbuf holds x_k, ybuf holds y_{k-1} on entry; on exit xbuf holds the gradient point (the new y after the
+// reference's swap, src/POGM.jl:203) and ybuf the new x, so the caller swaps its two references.
+template <typename E, bool RESTART>
+__global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict__ res, const E* __restrict__ x0,
+                                                                  E* __restrict__ xbuf, E* __restrict__ ybuf,
+                                                                  E* __restrict__ xold, E* __restrict__ z,
+                                                                  E* __restrict__ w, int64_t n, float rho, float c_y,
+                                                                  float c_x1, float c_xo, float c_z, int reg_kind,
+                                                                  float thr, int proj_kind, float rg,
+                                                                  float* __restrict__ out) {
+  __shared__ double sm[48];
+  double rn = 0.0, dwx = 0.0, dwz = 0.0, dwr = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += PGM_THREADS) {
+    const E xo = xbuf[i], yp = ybuf[i];
+    const E r = elem<E>::sub(res[i], x0[i]);              // res .-= x0                         :178
+    res[i] = r;
+    rn += redot<E>(r, r);
+    const E x1 = elem<E>::add(xo, elem<E>::scale(-rho, r));  // x .-= rho .* res               :179
+    E xn = elem<E>::add(elem<E>::scale(c_y, yp), elem<E>::scale(c_x1, x1));  // after the swap  :204-205
+    xn = elem<E>::add(xn, elem<E>::scale(c_xo, xo));
+    xn = elem<E>::add(xn, elem<E>::scale(c_z, z[i]));
+    const E zn = xn;                                      // z .= x                              :210
+    xn = fista_proj_elem<E>(fista_prox_elem<E>(xn, reg_kind, thr), proj_kind);
+    xold[i] = xo;
+    z[i] = zn;
+    xbuf[i] = x1;
+    ybuf[i] = xn;
+    if constexpr (RESTART) {                              // gradient restart                    :218-232
+      E wi = elem<E>::add(w[i], x1);
+      wi = elem<E>::add(wi, elem<E>::scale(rg, xn));
+      wi = elem<E>::add(wi, elem<E>::scale(-rg, zn));
+      dwx += redot<E>(wi, xn);
+      dwz += redot<E>(wi, zn);
+      dwr += redot<E>(wi, r);
+      E wn = elem<E>::add(elem<E>::scale(rg, zn), elem<E>::scale(-rg, xn));
+      w[i] = elem<E>::sub(wn, x1);
+    }
+  }
+  rn = block_sum(rn, sm);
+  if constexpr (RESTART) block_sum3(dwx, dwz, dwr, sm);
+  if (threadIdx.x == 0) {
+    out[0] = (float)sqrt(rn);
+    out[1] = (float)dwx;
+    out[2] = (float)dwz;
+    out[3] = (float)dwr;
+  }
+}
+
+static int32_t pgm_fetch(rls_ctx* ctx, float* out_h, int nfloats) {
+  RLS_HIP(ctx, hipMemcpyAsync(ctx->res_h, ctx->res_d, sizeof(float) * (size_t)nfloats, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < nfloats; ++i) out_h[i] = ctx->res_h[i];
+  return 0;
+}
+
+extern "C" {
+
+int32_t rls_optista_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* x, void* y, void* z,
+                           void* zold, float step, int32_t reg_kind, float thr, float c_z, float c_y, float c_x,
+                           float c_zn, float c_zo, float* res_norm_h) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !x || !y || !z || !zold || !res_norm_h ||
+      reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2)
+    return rls_fail(ctx, RLS_E_INVALID, "optista_update: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(optista_update_kernel<float>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float*)res,
+                       (const float*)x0, (float*)x, (float*)y, (float*)z, (float*)zold, n, step, reg_kind, thr, c_z, c_y,
+                       c_x, c_zn, c_zo, ctx->res_d);
+  else
+    hipLaunchKernelGGL(optista_update_kernel<float2>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float2*)res,
+                       (const float2*)x0, (float2*)x, (float2*)y, (float2*)z, (float2*)zold, n, step, reg_kind, thr, c_z,
+                       c_y, c_x, c_zn, c_zo, ctx->res_d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return pgm_fetch(ctx, res_norm_h, 1);
+}
+
+int32_t rls_pogm_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                        void* xold, void* z, void* w, float rho, float c_y, float c_x1, float c_xo, float c_z,
+                        int32_t reg_kind, float thr, int32_t proj_kind, int32_t restart, float rho_over_gamma,
+                        float* out_h) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !xbuf || !ybuf || !xold || !z || !out_h || (restart && !w) ||
+      reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2 || proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE)
+    return rls_fail(ctx, RLS_E_INVALID, "pogm_update: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+#define RLS_POGM(EE, RR)                                                                                             \
+  hipLaunchKernelGGL((pogm_update_kernel<EE, RR>), dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (EE*)res, (const EE*)x0, \
+                     (EE*)xbuf, (EE*)ybuf, (EE*)xold, (EE*)z, (EE*)w, n, rho, c_y, c_x1, c_xo, c_z, reg_kind, thr,     \
+                     proj_kind, rho_over_gamma, ctx->res_d)
+  if (dtype == RLS_F32) {
+    if (restart) RLS_POGM(float, true);
+    else RLS_POGM(float, false);
+  } else {
+    if (restart) RLS_POGM(float2, true);
+    else RLS_POGM(float2, false);
+  }
+#undef RLS_POGM
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return pgm_fetch(ctx, out_h, 4);
+}
+
+}  // extern "C"

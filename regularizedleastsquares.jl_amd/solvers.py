@@ -747,6 +747,27 @@ def _split_regs(regs, name):
     return rest[0], proj
 
 
+def _fusable_kinds(reg, proj):
+    """(reg_kind, proj_kind) when prox + projection run elementwise inside the fused update kernels, else None"""
+    if type(reg) is L1Regularization:
+        kind = REG_L1
+    elif type(reg) is L2Regularization and getattr(reg, "lam_vector", None) is None:
+        kind = REG_L2
+    else:
+        return None
+    if len(proj) > 1:
+        return None
+    pk = PROJ_NONE
+    if proj:
+        if isinstance(proj[0], PositiveRegularization):
+            pk = PROJ_POSITIVE
+        elif isinstance(proj[0], RealRegularization):
+            pk = PROJ_REAL
+        else:
+            return None
+    return kind, pk
+
+
 class _ProxGradState(AbstractSolverState):
     def __init__(self, rho, theta, relTol, names):
         self.rho = float(rho)
@@ -825,6 +846,20 @@ class OptISTA(AbstractLinearSolver):
             thn = (f32(1) + np.sqrt(f32(1) + f32(4) * th * th)) / f32(2)
         st.theta = float(thn)
         alpha, beta = (th - f32(1)) / thn, th / thn
+        fus = _fusable_kinds(self.reg, [])
+        if fus is not None:  # one launch for everything after the operator apply (rls_optista_update)
+            _NormalApply(self._op).mul_(st.res, st.x)
+            ctx = st.x.ctx
+            out = (C.c_float * 1)()
+            check(ctx.handle, ctx.lib.rls_optista_update(
+                ctx.handle, st.x.code, st.x.n, st.res.ptr, st.x0.ptr, st.x.ptr, st.y.ptr, st.z.ptr, st.zold.ptr,
+                float(rho * gamma), fus[0], float(rho * gamma * f32(self.reg.lam)), float(f32(-1) / gamma),
+                float(f32(1) / gamma), float(-beta), float(f32(1) + alpha + beta), float(-alpha), out), "rls_optista_update")
+            st.rel_res_norm = float(out[0]) / st.norm_x0
+            if self.verbose:
+                print(f"Iteration {st.iteration}; rel. residual = {st.rel_res_norm}")
+            st.iteration += 1
+            return st.x, st
         st.zold.copy_from(st.z)
         st.z.copy_from(st.y)
         _NormalApply(self._op).mul_(st.res, st.x)
@@ -900,13 +935,15 @@ class POGM(AbstractLinearSolver):
             return None
         f32 = np.float32
         rho = f32(st.rho)
-        st.xold.copy_from(st.x)
-        _NormalApply(self._op).mul_(st.res, st.x)
-        st.res.axpy_(-1.0, st.x0)
-        st.x.axpy_(-float(rho), st.res)
-        st.rel_res_norm = st.res.norm() / st.norm_x0
-        if self.verbose:
-            print(f"Iteration {st.iteration}; rel. residual = {st.rel_res_norm}")
+        fus = _fusable_kinds(self.reg, self.proj)
+        if fus is None:
+            st.xold.copy_from(st.x)
+            _NormalApply(self._op).mul_(st.res, st.x)
+            st.res.axpy_(-1.0, st.x0)
+            st.x.axpy_(-float(rho), st.res)
+            st.rel_res_norm = st.res.norm() / st.norm_x0
+            if self.verbose:
+                print(f"Iteration {st.iteration}; rel. residual = {st.rel_res_norm}")
         tho = f32(st.theta)
         st.thetaold = float(tho)
         if st.iteration == self.iterations - 1 and self.restart != "none":
@@ -922,6 +959,31 @@ class POGM(AbstractLinearSolver):
         else:
             gamma = rho * (f32(2) * tho + th - f32(1)) / th
         st.gamma = float(gamma)
+        if fus is not None:  # one launch for everything after the operator apply (rls_pogm_update)
+            _NormalApply(self._op).mul_(st.res, st.x)
+            ctx = st.x.ctx
+            out = (C.c_float * 4)()
+            restart = self.restart == "gradient"
+            check(ctx.handle, ctx.lib.rls_pogm_update(
+                ctx.handle, st.x.code, st.x.n, st.res.ptr, st.x0.ptr, st.x.ptr, st.y.ptr, st.xold.ptr, st.z.ptr,
+                st.w.ptr, float(rho), float(-alpha), float(f32(1) + alpha + beta), -float(beta + rho * alpha / gamma_old),
+                float(rho * alpha / gamma_old), fus[0], float(gamma * f32(self.reg.lam)), fus[1], int(restart),
+                float(rho / gamma), out), "rls_pogm_update")
+            st.x, st.y = st.y, st.x  # swap x and y (the kernel wrote the new x into the old y buffer)
+            st.rel_res_norm = float(out[0]) / st.norm_x0
+            if self.verbose:
+                print(f"Iteration {st.iteration}; rel. residual = {st.rel_res_norm}")
+            if restart:
+                crit = (f32(out[1]) - f32(out[2])) / gamma - f32(out[3])
+                if crit < 0:
+                    if self.verbose:
+                        print(f"Gradient restart at iter {st.iteration}")
+                    st.sigma = 1.0
+                    st.theta = 1.0
+                else:
+                    st.sigma = float(f32(st.sigma) * f32(st.sigma_fac))
+            st.iteration += 1
+            return st.x, st
         st.x, st.y = st.y, st.x  # swap x and y
         st.x.lincomb_(float(-alpha), st.x, float(f32(1) + alpha + beta), st.y)
         st.x.axpy_(-float(beta + rho * alpha / gamma_old), st.xold)
@@ -982,10 +1044,15 @@ class SplitBregman(ADMM):
             return None
         f32 = np.float32
         lib, h = state.x.ctx.lib, state.x.ctx.handle
-        state.beta.copy_from(state.beta_y)
-        for i, t in enumerate(self.regTrafo):
-            t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
-            t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
+        fused = self._all_identity() and len(self.reg) == 1
+        if fused:  # beta = beta_y + rho (z - u) in one launch (the same elementwise step as ADMM's)
+            check(h, lib.rls_admm_pre(h, state.x.code, state.x.n, state.beta.ptr, state.beta_y.ptr, state.z[0].ptr,
+                                      state.u[0].ptr, state.x.ptr, state.xold.ptr, float(state.rho[0]), 0), "rls_admm_pre")
+        else:
+            state.beta.copy_from(state.beta_y)
+            for i, t in enumerate(self.regTrafo):
+                t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
+                t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
         if self._all_identity():
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, float(np.sum(state.rho, dtype=np.float32)),
                                       self.iterationsCG, float(state.tolInner)), "rls_cg_solve")
@@ -993,7 +1060,21 @@ class SplitBregman(ADMM):
             self._cg_generic(state)
         for pr in self.proj:
             pr.prox_(state.x)
-        for i, t in enumerate(self.regTrafo):
+        if fused:
+            # z = prox(x + u, lambda / rho); u += x - z and the norms of :243-262 in one launch, one read-back
+            # (identity Phi: s = rho ||z - zold||, eps_dua = rho ||u||)
+            state.z[0], state.zold[0] = state.zold[0], state.z[0]
+            state.z[0].lincomb_(1.0, state.x, 1.0, state.u[0])
+            if state.rho[0] != 0:
+                self.reg[0].prox_(state.z[0], float(f32(self.reg[0].lam) / state.rho[0]))
+            out = (C.c_float * 6)()
+            check(h, lib.rls_admm_post(h, state.x.code, state.x.n, state.x.ptr, state.xold.ptr, state.z[0].ptr,
+                                       state.zold[0].ptr, state.u[0].ptr, out), "rls_admm_post")
+            state.sk[0] = state.rho[0] * f32(out[1])
+            state.eps_pri[0] = f32(out[2])
+            state.rk[0] = f32(out[3])
+            state.eps_dua[0] = state.rho[0] * f32(out[4])
+        for i, t in enumerate([] if fused else self.regTrafo):
             state.z[i], state.zold[i] = state.zold[i], state.z[i]
             t.mul_(state.z[i], state.x)
             state.z[i].axpy_(1.0, state.u[i])

@@ -681,6 +681,25 @@ def test_optista_pogm_match_oracle(rls, ctx, name, kw, dt, M, N):
     assert rel(x, ref.x) < 3e-5
 
 
+@pytest.mark.parametrize("name,kw", [("OptISTA", {}), ("POGM", {"restart": "gradient"})])
+def test_optista_pogm_generic_path_and_projection(rls, ctx, name, kw):
+    """regularisers the fused update kernels do not cover (L21) run the primitive-by-primitive path; POGM with a
+    Positive projection runs fused (src/POGM.jl:212-216)"""
+    A, xt, b = O.make_problem(192, 64, np.complex64, 37)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    ref = getattr(O, name)(A64, reg=O.L21Regularization(lam, slices=4), rho=rho, iterations=20, **kw)
+    sol = rls.createLinearSolver(getattr(rls, name), rls.DeviceMatrix.from_host(A), reg=rls.L21Regularization(lam, slices=4),
+                                 rho=rho, iterations=20, **kw)
+    assert rel(rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host(), O.solve(ref, b64)) < 3e-5
+    if name == "POGM":
+        ref = O.POGM(A64, reg=[O.L1Regularization(lam), O.PositiveRegularization()], rho=rho, iterations=20, **kw)
+        sol = rls.createLinearSolver(rls.POGM, rls.DeviceMatrix.from_host(A),
+                                     reg=[rls.L1Regularization(lam), rls.PositiveRegularization()], rho=rho, iterations=20, **kw)
+        assert rel(rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host(), O.solve(ref, b64)) < 3e-5
+
+
 def test_split_bregman_matches_oracle(rls, ctx):
     """src/SplitBregman.jl:204-271, identity regTrafo and GradientOp regTrafo"""
     A, xt, b = O.make_problem(160, 64, np.float32, 33)
