@@ -99,6 +99,56 @@ def cpu_baseline_cgnr(A, b, budget_s=14.0, max_iters=640):
             "ms_per_step": 1e3 * dt / n}
 
 
+def other_paths(rls, ctx, Ad, A, b):
+    """Untimed extras (N = 1, after the timed region): the other paths of SURVEY 8 on the same operator, a few
+    milliseconds each, so that one bench run shows them all.  None of this enters `value`."""
+    M, N = A.shape
+    out = {}
+    lib, h = ctx.lib, ctx.handle
+
+    def timed(run, n_inner, reps=8):
+        run(); run(); ctx.sync(); ctx.timer_start()
+        for _ in range(reps):
+            run()
+        return ctx.timer_stop_ms() * 1e3 / (reps * n_inner)
+
+    try:
+        rho = 0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2
+        S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
+        rls.solve_(S, b)
+        us = timed(lambda: (rls.init_(S, b), lib.rls_fista_step(S.state._plan, 48)), 48)
+        out["fista_l1_matrix_free (BASELINE configs[1])"] = {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
+        t0 = time.perf_counter(); G = Ad.gram(); ctx.sync(); t_gram = time.perf_counter() - t0
+        t0 = time.perf_counter(); G = Ad.gram(); ctx.sync(); t_gram = min(t_gram, time.perf_counter() - t0)
+        out["gram_gemm_AHA (setup, matrix cores)"] = {"ms": 1e3 * t_gram, "TFLOPs_nominal": 8.0 * N * N * M / t_gram / 1e12}
+        S = rls.createLinearSolver(rls.CGNR, Ad, AHA=G, iterations=32, relTol=0.0)
+        rls.solve_(S, b)
+        us = timed(lambda: (rls.init_(S, b), lib.rls_cgnr_step(S.state._plan, 32)), 32)
+        out["cgnr_gram_mode (AHA explicit, one launch per iteration)"] = {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
+        S = rls.createLinearSolver(rls.FISTA, Ad, AHA=G, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
+        rls.solve_(S, b)
+        us = timed(lambda: (rls.init_(S, b), lib.rls_fista_step(S.state._plan, 48)), 48)
+        out["fista_l1_gram_mode"] = {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
+        rng = np.random.default_rng(5)
+        for K in (16, 64):
+            X = (rng.standard_normal((N, K)) + 1j * rng.standard_normal((N, K))).astype(np.complex64)
+            Bd = rls.DeviceMatrix.from_host(np.asfortranarray((A @ X).astype(np.complex64)), ctx)
+            S = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+            rls.solve_(S, Bd, scheduler=rls.BatchedState)
+            st = S.state
+            us = timed(lambda: (rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, 32), "init"),
+                                rls._lib.check(h, lib.rls_cgnr_step(st._plan, 32), "step")), 32, reps=4)
+            out[f"cgnr_batched_{K}_rhs (BASELINE configs[3] on one GPU, f32 MFMA)"] = {
+                "us_per_batched_iteration": us, "solve_iterations_per_s": K * 1e6 / us}
+        S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(1e-3), iterations=4)
+        rls.solve_(S, b); ctx.sync()
+        t0 = time.perf_counter(); rls.solve_(S, b); ctx.sync(); dt = time.perf_counter() - t0
+        out["kaczmarz_row_sweeps (one launch per solve)"] = {"us_per_row_step": dt / (4 * M) * 1e6}
+    except Exception as e:  # the extras must never take the headline line down
+        out["error"] = repr(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +158,7 @@ def main():
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=200)
     args = ap.parse_args()
 
@@ -270,6 +321,8 @@ def main():
                          "iteration": {"bytes": bytes_iter, "GBps": iter_gbs, "frac": iter_gbs / HBM_PEAK_GBS,
                                        "us_hip_events": 1e3 * ev_ms / K}},
         }
+        if world == 1 and not args.no_extras and (M, N) == (4096, 2048):
+            out["other_paths"] = other_paths(rls, ctx, Ad, A, bd)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cgnr(A, b)
         print(json.dumps(out))
