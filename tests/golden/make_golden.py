@@ -74,7 +74,27 @@ def prox_cases():
     np.savez_compressed(os.path.join(HERE, "prox_cases.npz"), **out)
 
 
+def next_tier_cases():
+    """Kaczmarz, OptISTA, POGM (both restart modes), SplitBregman on one 96 x 40 ComplexF32 problem"""
+    A, xt, b = O.make_problem(96, 40, np.complex64, 7)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    out = dict(A=A, b=b, rho=rho, lam=lam)
+    k = O.Kaczmarz(A64, reg=O.L2Regularization(0.05), iterations=6)
+    out["kaczmarz_x"] = O.solve(k, b64).copy()
+    out["kaczmarz_vl"] = k.vl.copy()
+    out["optista_x"] = O.solve(O.OptISTA(A64, reg=O.L1Regularization(lam), rho=rho, iterations=30), b64).copy()
+    out["pogm_x"] = O.solve(O.POGM(A64, reg=O.L1Regularization(lam), rho=rho, iterations=30), b64).copy()
+    out["pogm_restart_x"] = O.solve(O.POGM(A64, reg=O.L1Regularization(lam), rho=rho, iterations=30, restart="gradient"), b64).copy()
+    sb = O.SplitBregman(A64, reg=O.L1Regularization(0.05), rho=0.5, iterations=3, iterationsInner=4, iterationsCG=10)
+    out["splitbregman_x"] = O.solve(sb, b64).copy()
+    out["splitbregman_cg_iters"] = np.array(sb.cg_iters)
+    np.savez_compressed(os.path.join(HERE, "next_tier_96x40_c64.npz"), **out)
+
+
 if __name__ == "__main__":
+    next_tier_cases()
     cgnr_case(256, 128, np.float32, 1, 1e-2, 10, "cgnr_256x128_f32.npz")      # BASELINE config 1
     cgnr_case(64, 32, np.complex64, 1, 0.0, 10, "cgnr_64x32_c64.npz")
     fista_case()

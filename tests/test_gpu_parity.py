@@ -976,3 +976,14 @@ def test_config5_shard_size_properties(rls, ctx):
     assert all(b2 < a2 for a2, b2 in zip(res[1:], res[2:]))  # CG on a well-conditioned matrix: monotone here
     ref = O.CGNR(A, iterations=8, relTol=0.0)  # complex64 restatement, same operation order
     assert rel(got, O.solve(ref, b)) < 1e-4
+
+
+def test_golden_next_tier_on_device(rls, ctx):
+    """the committed float64 fixtures of the SURVEY 8f solvers (tests/golden/next_tier_96x40_c64.npz)"""
+    import os
+    from test_oracle import _next_tier_solutions
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "next_tier_96x40_c64.npz"))
+    got = _next_tier_solutions(rls, g, wrap=lambda a: rls.DeviceMatrix.from_host(np.asfortranarray(a)),
+                               vec=lambda a: rls.DeviceVector.from_host(a))
+    for k, v in got.items():
+        assert rel(v.to_host(), g[k]) < 5e-5, k

@@ -276,6 +276,29 @@ def test_golden_cgnr(name, dt64):
         assert abs(s.alpha - g["alpha"][k]) < 1e-12 * abs(g["alpha"][k])
 
 
+def _next_tier_solutions(mod, g, wrap=lambda a: a, vec=lambda a: a):
+    """the five solver runs of tests/golden/next_tier_96x40_c64.npz through module `mod` (oracle or product)"""
+    A, b = wrap(g["A"]), vec(g["b"])
+    rho, lam = float(g["rho"]), float(g["lam"])
+    out = {}
+    solve = getattr(mod, "solve", None) or mod.solve_
+    k = mod.Kaczmarz(A, reg=mod.L2Regularization(0.05), iterations=6)
+    out["kaczmarz_x"] = solve(k, b)
+    out["optista_x"] = solve(mod.OptISTA(A, reg=mod.L1Regularization(lam), rho=rho, iterations=30), b)
+    out["pogm_x"] = solve(mod.POGM(A, reg=mod.L1Regularization(lam), rho=rho, iterations=30), b)
+    out["pogm_restart_x"] = solve(mod.POGM(A, reg=mod.L1Regularization(lam), rho=rho, iterations=30, restart="gradient"), b)
+    out["splitbregman_x"] = solve(mod.SplitBregman(A, reg=mod.L1Regularization(0.05), rho=0.5, iterations=3, iterationsInner=4,
+                                                   iterationsCG=10), b)
+    return out
+
+
+def test_golden_next_tier():
+    g = np.load(os.path.join(GOLD, "next_tier_96x40_c64.npz"))
+    got = _next_tier_solutions(O, g, wrap=lambda a: a.astype(np.complex128), vec=lambda a: a.astype(np.complex128))
+    for k, v in got.items():
+        assert rel(v, g[k]) < 1e-12, k
+
+
 def test_golden_fista_admm_prox():
     g = np.load(os.path.join(GOLD, "fista_l1_64x32_c64.npz"))
     for restart in ("none", "gradient"):
