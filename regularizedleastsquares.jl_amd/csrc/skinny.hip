@@ -469,12 +469,17 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
 // ---------------------------------------------------------------------------------------------
 // measurement overrides (rls_tune_set "skinny_*"); defaults from tools/skinny_probe.py on MI355X
 static int g_t_waves = 4, g_t_u = 4, g_v_waves = 4, g_v_u = 1, g_v_splits = 0;
+// dynamic LDS requested by the Gram tile kernel purely as an occupancy limiter: one workgroup (one wave per SIMD)
+// per CU keeps the MFMA pipe fed by a single instruction stream (0.92 ms vs 1.05 ms with three co-resident
+// workgroups at 4096 x 2048 CF32); rls_tune_set "gram_lds_kib"
+static int g_gram_lds = 96 * 1024;
 void rls_skinny_tune(int which, int value) {
   if (which == 0) g_t_waves = value;
   if (which == 1) g_v_waves = value;
   if (which == 2) g_v_splits = value;
   if (which == 4) g_t_u = value;
   if (which == 5) g_v_u = value;
+  if (which == 6) g_gram_lds = value * 1024;
 }
 
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
@@ -743,10 +748,15 @@ int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const 
                        int64_t ldg) {
   const int64_t T = N / 64;
   const dim3 grid((unsigned)(T * (T + 1) / 2));
+  const size_t lds = (size_t)g_gram_lds;  // occupancy limiter, see g_gram_lds
+  if (lds > 64 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_mfma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_mfma_kernel<float2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (dtype == RLS_F32)
-    hipLaunchKernelGGL(gram_mfma_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)A, lda, (float*)G, ldg, M, N);
+    hipLaunchKernelGGL(gram_mfma_kernel<float>, grid, dim3(256), lds, ctx->stream, (const float*)A, lda, (float*)G, ldg, M, N);
   else
-    hipLaunchKernelGGL(gram_mfma_kernel<float2>, grid, dim3(256), 0, ctx->stream, (const float2*)A, lda, (float2*)G, ldg,
+    hipLaunchKernelGGL(gram_mfma_kernel<float2>, grid, dim3(256), lds, ctx->stream, (const float2*)A, lda, (float2*)G, ldg,
                        M, N);
   return sk_status(ctx);
 }
