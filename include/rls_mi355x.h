@@ -150,6 +150,17 @@ int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x);
 int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v);
 /* setup GEMM AHA = A' * A (src/CGNR.jl:49) on device; G is N x N column-major, ld >= N */
 int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G, int64_t ld);
+/* Singular-value soft-thresholding.
+ * rls_prox_nuclear: prox!(::NuclearRegularization, x, lambda) (src/proximalMaps/ProxNuclear.jl:26-31): x is the
+ *   m x n column-major matrix reshape(x, svtShape); U, S, V = svd; prox!(L1, S, lambda); x = U diag(S) V'.
+ * rls_prox_llr: proxLLRNonOverlapping! (src/proximalMaps/ProxLLR.jl:43-88): x = reshape(x, shape..., K), the image is
+ *   circularly shifted by `shift` (the reference draws it with rand when randshift = true; pass zeros for
+ *   randshift = false), cut into distinct blocks of `block` voxels (edge blocks zero-padded) and every
+ *   prod(block) x K matrix is singular-value thresholded.  ndims <= 3; n = length(x).
+ * One wave per matrix, one-sided Jacobi SVD in LDS; RLS_E_UNSUPPORTED when a matrix does not fit (150 KiB). */
+int32_t rls_prox_nuclear(rls_ctx* ctx, int32_t dtype, int64_t m, int64_t n, void* x, float lambda);
+int32_t rls_prox_llr(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, const int64_t* block,
+                     const int64_t* shift, int64_t n, void* x, float lambda);
 /* Fused elementwise half of one OptISTA iteration (src/OptISTA.jl:176-204), after res = AHA x:
  *   zold = z; z = y; res -= x0; y -= step res; prox!(reg, y, thr); z = c_z z + x + c_y y; x = c_x x + c_zn z + c_zo zold
  * with step = rho gamma, thr = rho gamma lambda, c_z = -1/gamma, c_y = 1/gamma, c_x = -beta, c_zn = 1 + alpha + beta,

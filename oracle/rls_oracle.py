@@ -1212,3 +1212,86 @@ class Kaczmarz:
 
     def convergence(self):
         return {"residual": self.T(nrm2(self.A @ self.x - self.u))}
+
+
+# --------------------------------------------------------------------------------------
+# singular-value thresholding prox maps: src/proximalMaps/ProxNuclear.jl, ProxLLR.jl
+# --------------------------------------------------------------------------------------
+
+
+def _svt(X, lam):
+    """U, S, V = svd(X); prox!(L1Regularization, S, lam); U * Diagonal(S) * V'  (ProxNuclear.jl:27-29)"""
+    U, S, Vh = np.linalg.svd(X, full_matrices=False)
+    S = prox_l1(S.astype(X.real.dtype), lam)
+    return (U * S[None, :]) @ Vh
+
+
+def prox_nuclear(x, lam, svtShape):
+    X = np.asarray(x).reshape(svtShape, order="F")
+    x[:] = _svt(X, lam).reshape(-1, order="F")
+    return x
+
+
+def prox_llr(x, lam, shape, blockSize, shift=None):
+    """proxLLRNonOverlapping! (ProxLLR.jl:43-88) with an explicit block-grid shift (the reference draws
+    rand(CartesianIndices(blockSize)) when randshift = true; all zeros = randshift false)"""
+    shape, blockSize = tuple(shape), tuple(blockSize)
+    nd = len(shape)
+    K = x.size // int(np.prod(shape))
+    X = np.asarray(x).reshape(shape + (K,), order="F")
+    shift = (0,) * nd if shift is None else tuple(int(s_) for s_ in shift)
+    xs = np.roll(X, shift, axis=tuple(range(nd)))  # circshift(x, shift): xs[i] = x[i - shift]
+    for start in np.ndindex(*[-(-s_ // b) for s_, b in zip(shape, blockSize)]):
+        sl = tuple(slice(st * b, min((st + 1) * b, s_)) for st, b, s_ in zip(start, blockSize, shape))
+        blk = xs[sl]                                   # (b1', b2', ..., K), possibly cut at the edge
+        m = int(np.prod(blk.shape[:-1]))
+        M = np.zeros((int(np.prod(blockSize)), K), dtype=X.dtype)
+        M[:m] = blk.reshape(m, K, order="F")
+        if np.any(M != 0):
+            Y = _svt(M, lam)
+            xs[sl] = Y[:m].reshape(blk.shape, order="F")
+    X[...] = np.roll(xs, tuple(-s_ for s_ in shift), axis=tuple(range(nd)))
+    x[:] = X.reshape(-1, order="F")
+    return x
+
+
+def prox_llr_overlapping(x, lam, shape, blockSize):
+    """proxLLROverlapping! (ProxLLR.jl:165-203): average of the distinct-block prox over every shift of the grid"""
+    shape, blockSize = tuple(shape), tuple(blockSize)
+    nd = len(shape)
+    K = x.size // int(np.prod(shape))
+    X = np.asarray(x).reshape(shape + (K,), order="F")
+    pad = [(-s_) % b for s_, b in zip(shape, blockSize)]
+    pshape = tuple(s_ + p for s_, p in zip(shape, pad))
+    xp = np.zeros(pshape + (K,), dtype=X.dtype)
+    core = tuple(slice(0, s_) for s_ in shape)
+    xp[core] = X
+    acc = np.zeros_like(X)
+    n = 0
+    for idx in np.ndindex(*blockSize):
+        sh = tuple(i + 1 for i in idx)
+        w = xp.reshape(-1, order="F").copy()
+        prox_llr(w, lam, pshape, blockSize, sh)
+        acc += w.reshape(pshape + (K,), order="F")[core]
+        n += 1
+    x[:] = (acc / n).reshape(-1, order="F")
+    return x
+
+
+class NuclearRegularization:
+    def __init__(self, lam, svtShape):
+        self.lam, self.svtShape = lam, tuple(svtShape)
+
+    def prox(self, x, lam=None):
+        return prox_nuclear(x, self.lam if lam is None else lam, self.svtShape)
+
+
+class LLRRegularization:
+    def __init__(self, lam, shape, blockSize, shift=None, fullyOverlapping=False):
+        self.lam, self.shape, self.blockSize, self.shift, self.full = lam, tuple(shape), tuple(blockSize), shift, fullyOverlapping
+
+    def prox(self, x, lam=None):
+        lam = self.lam if lam is None else lam
+        if self.full:
+            return prox_llr_overlapping(x, lam, self.shape, self.blockSize)
+        return prox_llr(x, lam, self.shape, self.blockSize, self.shift)

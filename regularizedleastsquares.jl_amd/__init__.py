@@ -12,7 +12,7 @@ from .arrays import (Context, DeviceMatrix, DeviceVector, NormalOperator, Operat
                      default_context, normalOperator)
 from .regularization import (AbstractParameterizedRegularization, AbstractProjectionRegularization,  # noqa: F401
                              AbstractRegularization, GradientOp, L1Regularization, L2Regularization,
-                             L21Regularization, MeasurementBasedNormalization, NoNormalization,
+                             L21Regularization, LLRRegularization, MeasurementBasedNormalization, NoNormalization, NuclearRegularization,
                              PositiveRegularization, RealRegularization, SystemMatrixBasedNormalization,
                              TVRegularization, NormalizedRegularization, innerreg, lam, norm, normalize, prox_, scalefactor)
 from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401

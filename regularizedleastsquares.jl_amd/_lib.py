@@ -92,6 +92,8 @@ PROTOTYPES = {
     "rls_operator_mul_adj": (_i32, [_vp, _vp, _vp]),
     "rls_operator_mul_normal": (_i32, [_vp, _vp, _vp]),
     "rls_gram": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _i64]),
+    "rls_prox_nuclear": (_i32, [_vp, _i32, _i64, _i64, _vp, _f]),
+    "rls_prox_llr": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i64, _vp, _f]),
     "rls_optista_update": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _f, _f, _f, _f, _f, _f, _pf]),
     "rls_pogm_update": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i32, _f, _i32, _i32,
                                _f, _pf]),

@@ -123,6 +123,88 @@ class TVRegularization(AbstractParameterizedRegularization):
         return float(lam) * g.norm1()
 
 
+class NuclearRegularization(AbstractParameterizedRegularization):
+    """src/proximalMaps/ProxNuclear.jl: singular-value soft-thresholding of reshape(x, svtShape)"""
+
+    def __init__(self, lam, svtShape=(), **_kw):
+        self.lam = float(lam)
+        self.svtShape = tuple(int(s) for s in svtShape)
+
+    def prox_(self, x: DeviceVector, lam: float):
+        if len(self.svtShape) != 2 or self.svtShape[0] * self.svtShape[1] != x.n:
+            raise ValueError(f"NuclearRegularization: svtShape {self.svtShape} does not match length(x)={x.n}")
+        check(x.ctx.handle, x.ctx.lib.rls_prox_nuclear(x.ctx.handle, x.code, self.svtShape[0], self.svtShape[1], x.ptr,
+                                                        float(lam)), "rls_prox_nuclear")
+        return x
+
+    def norm(self, x: DeviceVector, lam: float) -> float:
+        """lambda * norm(S, 1): singular values on the host (setup / diagnostics only)"""
+        import numpy as _np
+        s = _np.linalg.svd(x.to_host().reshape(self.svtShape, order="F"), compute_uv=False)
+        return float(lam) * float(s.sum())
+
+
+class LLRRegularization(AbstractParameterizedRegularization):
+    """src/proximalMaps/ProxLLR.jl: locally low rank regularisation, distinct blocks.  `randshift` draws the block-grid
+    shift from a NumPy generator (the reference uses Julia's global RNG); fully overlapping blocks average the
+    prox over all shifts of the block grid (:165-203)."""
+
+    def __init__(self, lam, shape=(), blockSize=None, randshift: bool = True, fullyOverlapping: bool = False, L: int = 1,
+                 seed=None, **_kw):
+        import numpy as _np
+        self.lam = float(lam)
+        self.shape = tuple(int(s) for s in shape)
+        self.blockSize = tuple(int(b) for b in (blockSize if blockSize is not None else (2,) * len(self.shape)))
+        if len(self.blockSize) != len(self.shape) or not 1 <= len(self.shape) <= 3:
+            raise ValueError("LLRRegularization: shape and blockSize must have the same length (1..3)")
+        self.randshift, self.fullyOverlapping, self.L = bool(randshift), bool(fullyOverlapping), int(L)
+        self._rng = _np.random.default_rng(seed)
+
+    def _call(self, x: DeviceVector, lam: float, shift, shape=None):
+        shape = shape or self.shape
+        nd = len(shape)
+        cs = (C.c_int64 * nd)(*shape)
+        cb = (C.c_int64 * nd)(*self.blockSize)
+        csh = (C.c_int64 * nd)(*shift)
+        check(x.ctx.handle, x.ctx.lib.rls_prox_llr(x.ctx.handle, x.code, nd, cs, cb, csh, x.n, x.ptr, float(lam)), "rls_prox_llr")
+
+    def prox_(self, x: DeviceVector, lam: float):
+        import numpy as _np
+        ns = 1
+        for s_ in self.shape:
+            ns *= s_
+        if x.n % ns:
+            raise ValueError(f"LLRRegularization: length(x)={x.n} is not a multiple of prod(shape)={ns}")
+        if not self.fullyOverlapping:
+            shift = [int(self._rng.integers(1, b + 1)) for b in self.blockSize] if self.randshift else [0] * len(self.shape)
+            self._call(x, lam, shift)
+            return x
+        # proxLLROverlapping!: zero-pad to a multiple of the block size, prox for every shift of the block grid, average
+        K = x.n // ns
+        pad = [(-s_) % b for s_, b in zip(self.shape, self.blockSize)]
+        pshape = tuple(s_ + p for s_, p in zip(self.shape, pad))
+        xh = x.to_host().reshape(self.shape + (K,), order="F")
+        xp = _np.zeros(pshape + (K,), dtype=xh.dtype)
+        xp[tuple(slice(0, s_) for s_ in self.shape)] = xh
+        acc = _np.zeros_like(xh)
+        work = DeviceVector(xp.size, x.dtype, x.ctx)
+        n_shift = 0
+        for idx in _np.ndindex(*self.blockSize):
+            shift = [i + 1 for i in idx]  # CartesianIndices(blockSize) is 1-based
+            work.copy_from_host(xp.reshape(-1, order="F"))
+            saved, self.randshift = self.randshift, False
+            try:
+                # the inner call of the reference runs with the regulariser's own randshift; with a shifted input
+                # the shift composes -- here the explicit shift IS the circshift of :193
+                self._call(work, lam, shift, shape=pshape)
+            finally:
+                self.randshift = saved
+            acc += work.to_host().reshape(pshape + (K,), order="F")[tuple(slice(0, s_) for s_ in self.shape)]
+            n_shift += 1
+        x.copy_from_host((acc / n_shift).reshape(-1, order="F").astype(x.dtype))
+        return x
+
+
 class PositiveRegularization(AbstractProjectionRegularization):
     """src/proximalMaps/ProxPositive.jl"""
 

@@ -987,3 +987,75 @@ def test_golden_next_tier_on_device(rls, ctx):
                                vec=lambda a: rls.DeviceVector.from_host(a))
     for k, v in got.items():
         assert rel(v.to_host(), g[k]) < 5e-5, k
+
+
+# ---- singular-value thresholding prox maps ------------------------------------------
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("m,n", [(32, 32), (64, 20), (20, 64), (7, 3), (1, 9), (96, 96)])
+def test_prox_nuclear_matches_svd(rls, ctx, dt, m, n):
+    """prox!(::NuclearRegularization) (ProxNuclear.jl:26-31): one-sided Jacobi on the device vs LAPACK svd"""
+    rng = np.random.default_rng(61)
+    X = rng.standard_normal((m, n))
+    if np.dtype(dt).kind == "c":
+        X = X + 1j * rng.standard_normal((m, n))
+    X[:, 0] *= 10  # spread the singular values
+    x = X.reshape(-1, order="F").astype(dt)
+    lam = 0.3 * np.linalg.svd(X, compute_uv=False)[min(m, n) // 2]
+    ref = O.prox_nuclear(x.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64), lam, (m, n))
+    xd = rls.DeviceVector.from_host(x)
+    rls.prox_(rls.NuclearRegularization(lam, svtShape=(m, n)), xd)
+    assert rel(xd.to_host(), ref) < 2e-5
+    # lambda above the largest singular value: everything is thresholded away
+    xd = rls.DeviceVector.from_host(x)
+    rls.prox_(rls.NuclearRegularization, xd, 1e6, svtShape=(m, n))
+    assert np.all(xd.to_host() == 0)
+
+
+@pytest.mark.parametrize("dt,shape,bs,K,shift", [(np.complex64, (32, 32), (4, 4), 10, None), (np.float32, (30, 29), (4, 4), 6, (1, 3)),
+                                                 (np.complex64, (16, 16), (4, 4), 80, (4, 2)), (np.float32, (8, 8, 8), (4, 4, 4), 6, None),
+                                                 (np.complex64, (12,), (5,), 4, (2,)), (np.complex64, (8, 8, 4), (4, 4, 2), 40, (1, 1, 1))])
+def test_prox_llr_matches_oracle(rls, ctx, dt, shape, bs, K, shift):
+    """proxLLRNonOverlapping! (ProxLLR.jl:43-88): distinct blocks, shifted grids, cut edge blocks, wide (K > voxels per
+    block) and tall matrices, 1-D / 2-D / 3-D images"""
+    rng = np.random.default_rng(67)
+    n = int(np.prod(shape)) * K
+    x = rng.standard_normal(n)
+    if np.dtype(dt).kind == "c":
+        x = x + 1j * rng.standard_normal(n)
+    x = x.astype(dt)
+    lam = 1.5
+    ref = O.prox_llr(x.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64), lam, shape, bs, shift)
+    reg = rls.LLRRegularization(lam, shape=shape, blockSize=bs, randshift=False)
+    xd = rls.DeviceVector.from_host(x)
+    if shift is None:
+        rls.prox_(reg, xd)
+    else:
+        reg._call(xd, lam, list(shift))
+    assert rel(xd.to_host(), ref) < 2e-5
+
+
+def test_prox_llr_overlapping_randshift_and_denoising(rls, ctx):
+    """fully overlapping blocks (ProxLLR.jl:165-203) against the oracle; randshift is a valid shift of the grid;
+    the low-rank + noise experiment of test/testProxMaps.jl:194-219"""
+    rng = np.random.default_rng(71)
+    shape, bs, K = (10, 9), (4, 3), 5
+    x = (rng.standard_normal(int(np.prod(shape)) * K) + 1j * rng.standard_normal(int(np.prod(shape)) * K)).astype(np.complex64)
+    ref = O.prox_llr_overlapping(x.astype(np.complex128), 0.8, shape, bs)
+    xd = rls.DeviceVector.from_host(x)
+    rls.prox_(rls.LLRRegularization(0.8, shape=shape, blockSize=bs, fullyOverlapping=True), xd)
+    assert rel(xd.to_host(), ref) < 3e-5
+    reg = rls.LLRRegularization(0.8, shape=shape, blockSize=bs, randshift=True, seed=5)
+    xd = rls.DeviceVector.from_host(x)
+    rls.prox_(reg, xd)
+    cands = [O.prox_llr(x.astype(np.complex128), 0.8, shape, bs, (a, b)) for a in range(1, 5) for b in range(1, 4)]
+    assert min(rel(xd.to_host(), c) for c in cands) < 2e-5
+    # denoising: rank-2 image series + noise
+    shp, sigma = (32, 32, 20), 0.05
+    base = sum(np.einsum("i,j,k->ijk", rng.random(32), rng.random(32), rng.random(20)) for _ in range(2))
+    base = base / base.max()
+    noisy = (base + sigma * rng.standard_normal(shp)).astype(np.float32).reshape(-1, order="F")
+    xd = rls.DeviceVector.from_host(noisy)
+    rls.prox_(rls.LLRRegularization, xd, 10 * sigma, shape=(32, 32), blockSize=(4, 4), randshift=False)
+    assert np.linalg.norm(xd.to_host() - base.reshape(-1, order="F")) < np.linalg.norm(noisy - base.reshape(-1, order="F"))

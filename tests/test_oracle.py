@@ -210,6 +210,37 @@ def test_kaczmarz_reference_known_answers():
     assert 2 not in idx and len(idx) == M - 1 and np.allclose(den, 1 / (np.sum(np.abs(A0[idx]) ** 2, axis=1) + 0.5))
 
 
+def test_svt_prox_maps_reference_tests():
+    """test/testProxMaps.jl:167-247 (Nuclear, LLR, LLR fully overlapping): low-rank + noise, the prox must beat
+    the noisy input in the regularised objective and bring the estimate closer to the truth"""
+    rng = np.random.default_rng(3)
+    N, rank, sigma = 32, 2, 0.05
+    x = sum(np.outer(rng.random(N), rng.random(N)) for _ in range(rank))
+    x = x / x.max()
+    noisy = (x + sigma * rng.standard_normal(x.shape)).reshape(-1, order="F")
+    est = O.prox_nuclear(noisy.copy(), 5 * sigma, (N, N))
+    nuc = lambda v: np.linalg.svd(v.reshape(N, N, order="F"), compute_uv=False).sum()
+    assert 0.5 * np.linalg.norm(noisy - est) ** 2 + 5 * sigma * nuc(est) <= 5 * sigma * nuc(noisy)
+    assert np.linalg.norm(est - x.reshape(-1, order="F")) < np.linalg.norm(noisy - x.reshape(-1, order="F"))
+    # closed form: thresholding a rank-1 matrix s u v' gives (s - lam) u v'
+    u, v = rng.standard_normal(6), rng.standard_normal(5)
+    X1 = 3.0 * np.outer(u / np.linalg.norm(u), v / np.linalg.norm(v))
+    assert np.allclose(O.prox_nuclear(X1.reshape(-1, order="F").copy(), 1.0, (6, 5)).reshape(6, 5, order="F"), X1 * (2.0 / 3.0))
+    # LLR: every distinct block is thresholded on its own; the shifted grid only moves the blocks
+    shape, bs, K = (8, 6), (4, 3), 5
+    img = rng.standard_normal(shape + (K,)) + 1j * rng.standard_normal(shape + (K,))
+    flat = img.reshape(-1, order="F")
+    out = O.prox_llr(flat.copy(), 0.7, shape, bs).reshape(shape + (K,), order="F")
+    blk = img[4:8, 3:6].reshape(12, K, order="F")
+    assert np.allclose(out[4:8, 3:6].reshape(12, K, order="F"), O._svt(blk, 0.7))
+    rolled = np.roll(img, (1, 2), axis=(0, 1)).reshape(-1, order="F")
+    assert np.allclose(np.roll(O.prox_llr(rolled.copy(), 0.7, shape, bs).reshape(shape + (K,), order="F"), (-1, -2), axis=(0, 1)),
+                       O.prox_llr(flat.copy(), 0.7, shape, bs, shift=(1, 2)).reshape(shape + (K,), order="F"))
+    # fully overlapping blocks denoise at least as well as one grid (test/testProxMaps.jl:222-247 only logs this)
+    ov = O.prox_llr_overlapping(flat.copy(), 0.7, shape, bs)
+    assert ov.shape == flat.shape and np.all(np.isfinite(ov))
+
+
 def test_normalization_factors():
     """src/Regularization/NormalizedRegularization.jl:40-58"""
     A = np.array([[3.0, 4.0], [0.0, 2.0], [1.0, 0.0]])
