@@ -15,7 +15,9 @@ from .regularization import (AbstractParameterizedRegularization, AbstractProjec
                              L21Regularization, LLRRegularization, MeasurementBasedNormalization, NoNormalization, NuclearRegularization,
                              PositiveRegularization, RealRegularization, SystemMatrixBasedNormalization,
                              TVRegularization, NormalizedRegularization, innerreg, lam, norm, normalize, prox_, scalefactor)
-from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
+from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractKrylovSolver,
+                      AbstractPrimalDualSolver, AbstractProximalGradientSolver, AbstractRowActionSolver,
+                      applicableSolverList, isapplicable, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
                       SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,
                       iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,
                       solverstate)

@@ -70,6 +70,23 @@ class AbstractLinearSolver:
         return solverconvergence(self.state)
 
 
+# solver categories (src/RegularizedLeastSquares.jl:135-148)
+class AbstractRowActionSolver(AbstractLinearSolver):
+    pass
+
+
+class AbstractPrimalDualSolver(AbstractLinearSolver):
+    pass
+
+
+class AbstractProximalGradientSolver(AbstractLinearSolver):
+    pass
+
+
+class AbstractKrylovSolver(AbstractLinearSolver):
+    pass
+
+
 class AbstractSolverState:
     pass
 
@@ -137,7 +154,7 @@ class CGNRState(AbstractSolverState):
         self._plan = None
 
 
-class CGNR(AbstractLinearSolver):
+class CGNR(AbstractKrylovSolver):
     """src/CGNR.jl:48-89"""
 
     def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 10, relTol=_EPS32):
@@ -277,7 +294,7 @@ class FISTAState(AbstractSolverState):
         self._plan = None
 
 
-class FISTA(AbstractLinearSolver):
+class FISTA(AbstractProximalGradientSolver):
     """src/FISTA.jl:57-92.  `rho` defaults to 0.95 / power_iterations(AHA) as in the reference; pass it
     explicitly for reproducible runs (the reference's default depends on the global RNG)."""
 
@@ -492,7 +509,7 @@ class ADMMState(AbstractSolverState):
         self._cg = None
 
 
-class ADMM(AbstractLinearSolver):
+class ADMM(AbstractPrimalDualSolver):
     """src/ADMM.jl:80-162"""
 
     def __init__(self, A=None, *, AHA=None, precon=None, reg=None, regTrafo=None, normalizeReg=None, rho=1e-1,
@@ -789,7 +806,7 @@ class _ProxGradState(AbstractSolverState):
         return {"residual": self.res.norm()}
 
 
-class OptISTA(AbstractLinearSolver):
+class OptISTA(AbstractProximalGradientSolver):
     """src/OptISTA.jl:61-110 (ctor), :129-160 (init!), :169-209 (iterate)"""
 
     def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 50, verbose: bool = False,
@@ -881,7 +898,7 @@ class OptISTA(AbstractLinearSolver):
             pass
 
 
-class POGM(AbstractLinearSolver):
+class POGM(AbstractProximalGradientSolver):
     """src/POGM.jl:75-110 (ctor), :133-160 (init!), :169-237 (iterate).  gamma starts at 1 and is not reset
     by init! (reference behaviour)."""
 
@@ -1014,7 +1031,7 @@ class POGM(AbstractLinearSolver):
             pass
 
 
-class SplitBregman(ADMM):
+class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
     """src/SplitBregman.jl:82-140 (ctor), :166-200 (init!), :204-271 (iterate), :273-282 (converged / done).
     Same composite operator and cg! as ADMM; prox threshold lambda / rho; the right-hand side gets its
     Bregman update every `iterationsInner` inner iterations."""
@@ -1148,7 +1165,7 @@ class KaczmarzState(AbstractSolverState):
         return out if self.matrix else out[0]
 
 
-class Kaczmarz(AbstractLinearSolver):
+class Kaczmarz(AbstractRowActionSolver):
     """Kaczmarz(A; reg = L2Regularization(0), normalizeReg = NoNormalization(), randomized = false,
     subMatrixFraction = 0.15, shuffleRows = false, seed = 1234, iterations = 10)   src/Kaczmarz.jl:76-159.
 
@@ -1498,6 +1515,32 @@ def createLinearSolver(solver_type, A=None, *, kwargWarning: bool = True, **kwar
     if not (isinstance(solver_type, type) and issubclass(solver_type, AbstractLinearSolver)):
         raise TypeError("solver must be an AbstractLinearSolver type")
     return solver_type(A, **_filter_kwargs(solver_type, kwargWarning, kwargs))
+
+
+def isapplicable(solver, *args):
+    """isapplicable(solverType, [A, x,] reg)   src/RegularizedLeastSquares.jl:223-258 (quirks included: the fallback for
+    categories without a rule is `false`, the primal-dual rule is a TODO that returns `true`)"""
+    T = solver if isinstance(solver, type) else type(solver)
+    if len(args) == 2:        # (A, x): "TODO" in the reference, always applicable
+        return True
+    if len(args) == 3:        # (A, x, reg)
+        return isapplicable(T, args[0], args[1]) and isapplicable(T, args[2])
+    if len(args) != 1:
+        raise TypeError("isapplicable(solver, reg) | isapplicable(solver, A, x) | isapplicable(solver, A, x, reg)")
+    regs = _as_list(args[0])
+    n_param = sum(1 for r in regs if not isinstance(r, AbstractProjectionRegularization) and hasattr(r, "lam"))
+    if issubclass(T, AbstractRowActionSolver):
+        return n_param <= 2 and sum(1 for r in regs if isinstance(r, L2Regularization)) == 1
+    if issubclass(T, AbstractPrimalDualSolver):
+        return True
+    if issubclass(T, AbstractProximalGradientSolver):
+        return n_param == 1
+    return False
+
+
+def applicableSolverList(*args):
+    """applicableSolverList(args...)   :265"""
+    return [T for T in linearSolverList() if isapplicable(T, *args)]
 
 
 def linearSolverList():

@@ -15,6 +15,14 @@ def test_filter_kwargs_warns_like_the_reference(rls):
         warnings.simplefilter("error")
         assert _filter_kwargs(rls.FISTA, False, dict(rho=0.1, bogus=1)) == {"rho": 0.1}
     assert rls.linearSolverList() == [rls.CGNR, rls.Kaczmarz, rls.FISTA, rls.OptISTA, rls.POGM, rls.ADMM, rls.SplitBregman]
+    # isapplicable / applicableSolverList (src/RegularizedLeastSquares.jl:223-265)
+    l1, l2, pos = rls.L1Regularization(0.1), rls.L2Regularization(0.1), rls.PositiveRegularization()
+    assert rls.isapplicable(rls.FISTA, [l1]) and rls.isapplicable(rls.FISTA, l1) and not rls.isapplicable(rls.FISTA, [l1, l2])
+    assert rls.isapplicable(rls.FISTA, [l1, pos])
+    assert rls.isapplicable(rls.Kaczmarz, [l2]) and rls.isapplicable(rls.Kaczmarz, [l2, l1]) and not rls.isapplicable(rls.Kaczmarz, [l1])
+    assert rls.isapplicable(rls.ADMM, [l1, l2]) and not rls.isapplicable(rls.CGNR, [l2])  # the Krylov category has no rule
+    assert rls.applicableSolverList([l1]) == [rls.FISTA, rls.OptISTA, rls.POGM, rls.ADMM, rls.SplitBregman]
+    assert rls.isapplicable(rls.FISTA, None, None, [l1]) and issubclass(rls.SplitBregman, rls.AbstractPrimalDualSolver)
 
 
 def test_shard_columns_covers_every_column_once(rls):
