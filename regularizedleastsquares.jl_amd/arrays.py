@@ -9,6 +9,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -81,20 +82,31 @@ def default_context(device: int = 0) -> Context:
 class _DeviceBuffer:
     """owning device allocation (the Julia side would attach a finalizer calling rls_free)"""
 
+    _GUARD = 2 << 20  # RLS_GUARD_ALLOC=1 (test runs): own 2 MiB-granular allocation, data at its END
+
     def __init__(self, ctx: Context, nbytes: int):
         self.ctx = ctx
         self.nbytes = int(nbytes)
         p = C.c_void_p()
-        check(ctx.handle, ctx.lib.rls_malloc(ctx.handle, max(self.nbytes, 1), C.byref(p)), "rls_malloc")
-        self.ptr = p.value
+        if os.environ.get("RLS_GUARD_ALLOC") == "1":
+            # out-of-bounds reads past the end of a vector / matrix then leave the allocation and fault instead of
+            # silently reading a neighbour (how the slab_load overrun for N < 128 was found)
+            used = (max(self.nbytes, 1) + 15) // 16 * 16
+            total = (used + self._GUARD - 1) // self._GUARD * self._GUARD
+            check(ctx.handle, ctx.lib.rls_malloc(ctx.handle, total, C.byref(p)), "rls_malloc")
+            self._base = p.value
+            self.ptr = p.value + total - used
+        else:
+            check(ctx.handle, ctx.lib.rls_malloc(ctx.handle, max(self.nbytes, 1), C.byref(p)), "rls_malloc")
+            self._base = self.ptr = p.value
 
     def __del__(self):
         try:
-            if self.ptr and self.ctx.handle:
-                self.ctx.lib.rls_free(self.ctx.handle, C.c_void_p(self.ptr))
+            if self._base and self.ctx.handle:
+                self.ctx.lib.rls_free(self.ctx.handle, C.c_void_p(self._base))
         except Exception:
             pass
-        self.ptr = None
+        self.ptr = self._base = None
 
 
 class DeviceVector:

@@ -108,7 +108,10 @@ __device__ static inline void slab_load(chunk<E, elem<E>::vec> (&a)[K], const E*
     for (int k = 0; k < K; ++k) {
       const int last = (int)N - 1 - k * C::CPR;  // last valid slot of this round (may be negative)
       const int kc = last >= 0 ? k : 0;          // rounds entirely past N re-read round 0 (zeroed later)
-      const int sc = last >= 0 ? (slot < last ? slot : last) : slot;
+      // rounds past N re-read round 0, whose own last valid slot is min(CPR, N) - 1 (an unclamped slot read
+      // up to CPR - N columns past the end of A when N < CPR: harmless until the page behind A is unmapped)
+      const int last0 = (int)N - 1 < C::CPR - 1 ? (int)N - 1 : C::CPR - 1;
+      const int sc = last >= 0 ? (slot < last ? slot : last) : (slot < last0 ? slot : last0);
       const char* bk = base + (int64_t)(kc * C::CPR) * (lda * (int64_t)sizeof(E));
       a[k] = load_chunk<E, C::NV>(reinterpret_cast<const E*>(bk + (row_off + (uint32_t)sc * col_b)));
     }
