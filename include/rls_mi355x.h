@@ -63,7 +63,7 @@ int32_t rls_device_count(int32_t* out);
  * "fuse_level", "fused_normal" (one-pass normal operator), "cgnr_pipeline" (2-launch CGNR), "gram_pipeline"
  * (1-launch Gram-mode CGNR / cg), "batched_mfma" (matrix-core batched path and Gram GEMM).  Process-wide
  * (measurement only, set before the plan is created): "slab_g", "slab_wv", "slab_order", "red_threads",
- * "tv_fused_max_n", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits",
+ * "tv_fused_max_n", "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits",
  * "kaczmarz_nt". */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
 
@@ -298,6 +298,43 @@ int32_t rls_admm_pre(rls_ctx* ctx, int32_t dtype, int64_t n, void* beta, const v
                      const void* u, const void* x, void* xold, float rho, int32_t accumulate);
 int32_t rls_admm_post(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* xold, const void* z,
                       const void* zold, void* u, float* out_h);
+
+/* Whole ADMM outer iterations on the device for ONE regulariser with the identity regTrafo and vary_rho = :none
+ * (src/ADMM.jl:230-322; `done`/`converged` :324-330 evaluated on the device in Float32, so no host read-back
+ * between outer iterations).  Per outer iteration: the warm-started cg! of the plan `cg` on (AHA + rho I) with the
+ * right-hand side beta = beta_y + rho (z - u) formed inside its start kernel (:236-244), projections on x
+ * (:246-248), z = prox(x + u, lambda / (2 rho)) (:251-263; L1 / L2 inline, TV as one single-workgroup FGP launch),
+ * u += x - z and the residual norms (:265-299) in one launch.  Once `done` is set every later launch of the plan is
+ * a no-op.  rls_admm_init returns RLS_E_UNSUPPORTED when the regulariser cannot run inside the plan (callers then
+ * use rls_admm_pre / rls_cg_solve / prox / rls_admm_post).  z0 holds z at init; z alternates between z0 and z1
+ * (current z after k iterations: k odd -> z1).  All vectors are device pointers owned by the caller. */
+typedef struct rls_admm rls_admm;
+typedef struct rls_admm_params {
+  void *x, *xold, *beta, *beta_y, *z0, *z1, *u;
+  float rho;          /* fixed between two rls_admm_init calls */
+  float sigma_abs;    /* sqrt(length(b)) * absTol   src/ADMM.jl:214 */
+  float rel_tol;
+  int32_t iterations, iterations_cg;
+  float tol_inner;
+  int32_t reg_kind;   /* RLS_REG_NONE (also for rho == 0, :260) / RLS_REG_L1 / RLS_REG_L2 / RLS_REG_TV */
+  float prox_lambda;  /* lambda / (2 rho), formed by the caller in Float32 (:261) */
+  int32_t proj_kind;  /* RLS_PROJ_*; must be RLS_PROJ_NONE with RLS_REG_TV */
+  int32_t tv_ndims, tv_ntv, tv_iterations;
+  int32_t tv_dims[4];
+  int64_t tv_shape[4];
+} rls_admm_params;
+typedef struct rls_admm_status {
+  int32_t iteration, done;
+  float rk, sk, eps_pri, eps_dua, delta; /* of the last completed iteration */
+  int32_t cg_iterations;
+} rls_admm_status;
+int32_t rls_admm_create(rls_cg* cg, rls_admm** out);
+int32_t rls_admm_destroy(rls_admm* a);
+int32_t rls_admm_init(rls_admm* a, const rls_admm_params* p);
+int32_t rls_admm_step(rls_admm* a, int32_t n_outer); /* asynchronous; stops enqueuing at `iterations` */
+/* synchronises; log_h (nullable) receives min(iteration, log_records) records of 8 floats:
+ * Delta, sk, eps_pri, rk, eps_dua, inner cg! iterations, 0, 0 */
+int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out_h, float* log_h, int32_t log_records);
 
 /* ---------------------------------------------------------------------------------------------
  * row-sharded operation (BASELINE config 5).  One process per GPU holds rows

@@ -37,6 +37,20 @@ class CgStatus(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("residual", C.c_float), ("tol", C.c_float)]
 
 
+class AdmmParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("xold", C.c_void_p), ("beta", C.c_void_p), ("beta_y", C.c_void_p),
+                ("z0", C.c_void_p), ("z1", C.c_void_p), ("u", C.c_void_p), ("rho", C.c_float),
+                ("sigma_abs", C.c_float), ("rel_tol", C.c_float), ("iterations", C.c_int32),
+                ("iterations_cg", C.c_int32), ("tol_inner", C.c_float), ("reg_kind", C.c_int32),
+                ("prox_lambda", C.c_float), ("proj_kind", C.c_int32), ("tv_ndims", C.c_int32), ("tv_ntv", C.c_int32),
+                ("tv_iterations", C.c_int32), ("tv_dims", C.c_int32 * 4), ("tv_shape", C.c_int64 * 4)]
+
+
+class AdmmStatus(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("done", C.c_int32), ("rk", C.c_float), ("sk", C.c_float),
+                ("eps_pri", C.c_float), ("eps_dua", C.c_float), ("delta", C.c_float), ("cg_iterations", C.c_int32)]
+
+
 _vp, _i32, _i64, _f, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _pvp = C.POINTER(C.c_void_p)
 _pf = C.POINTER(C.c_float)
@@ -129,6 +143,11 @@ PROTOTYPES = {
     "rls_cg_get_status": (_i32, [_vp, C.POINTER(CgStatus)]),
     "rls_admm_pre": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32]),
     "rls_admm_post": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _pf]),
+    "rls_admm_create": (_i32, [_vp, _pvp]),
+    "rls_admm_destroy": (_i32, [_vp]),
+    "rls_admm_init": (_i32, [_vp, C.POINTER(AdmmParams)]),
+    "rls_admm_step": (_i32, [_vp, _i32]),
+    "rls_admm_get_status": (_i32, [_vp, C.POINTER(AdmmStatus), _pf, _i32]),
 }
 
 _lib = None

@@ -110,6 +110,8 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
     rls_normal_force_waves(value);
   } else if (!strcmp(key, "tv_fused_max_n")) {
     rls_tv_set_fused_max_n(value);
+  } else if (!strcmp(key, "tv_fused_2d")) {
+    rls_tv_set_fused_2d(value);
   } else if (!strcmp(key, "slab_order")) {
     rls_normal_order_mode(value);
   } else if (!strcmp(key, "red_threads")) {

@@ -446,6 +446,12 @@ int32_t rls_launch_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int6
 // normal.hip: v = A^H A p in ONE pass over A (slab of A held in registers between the two products).
 // Returns the slab workspace size in bytes (0 = shape not supported by the fused kernel).
 void rls_tv_set_fused_max_n(int64_t n);
+void rls_tv_set_fused_2d(int on);
+// tv.hip: the FGP loop as ONE single-workgroup launch, out = prox_TV(xin [+ add]) (`add`, `skip` nullable)
+bool rls_tv_single_ok(int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims);
+int32_t rls_tv_single_launch(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                             const int32_t* dims, const void* xin, const void* add, void* out, float lam, int iters,
+                             const int* skip);
 void rls_normal_force_group(int g);
 void rls_normal_force_waves(int wv);
 void rls_normal_order_mode(int m);

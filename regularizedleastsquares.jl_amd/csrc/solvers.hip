@@ -589,17 +589,49 @@ static rls_cgnr_pipe cg_pipe_desc(const rls_cg* s, void* x) {
 // warm start of the pipeline: c = AHA x is in place; r = b - c - rho x, u = r, scalars reset.
 // done at entry mirrors cg!: residual <= tol = reltol * residual (only for reltol >= 1) or maxiter == 0;
 // r == 0 exactly is also final (the next alpha would be 0/0).
+// ADMM plan (rls_admm_step): the start kernel also forms the right-hand side, b = beta_y + rho (z - u), keeps
+// xold = x (src/ADMM.jl:236-243, identity regTrafo), and turns the whole x-update into no-ops once the plan's
+// `done` flag is set.  All pointers null for a plain cg! call.
 template <typename E>
-__global__ __launch_bounds__(UPD_THREADS) void cg_pipe_start_kernel(const E* __restrict__ x, const E* __restrict__ b,
+struct admm_fuse {
+  const E *beta_y, *z, *u;
+  E *beta, *xold;
+  float rho;
+  const int* skip;
+};
+template <typename E>
+__device__ static inline E admm_rhs(const admm_fuse<E>& F, const E* b, const E* x, int64_t i) {
+  if (!F.beta_y) return b[i];
+  E bi = F.beta_y[i];
+  bi = elem<E>::add(bi, elem<E>::scale(F.rho, F.z[i]));
+  bi = elem<E>::add(bi, elem<E>::scale(-F.rho, F.u[i]));
+  F.beta[i] = bi;
+  F.xold[i] = x[i];
+  return bi;
+}
+
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void cg_pipe_start_kernel(const E* __restrict__ x, const E* b,
                                                                     E* __restrict__ u, E* __restrict__ r,
                                                                     const E* __restrict__ c, int64_t n,
                                                                     cgnr_scalars* sc, float rho, float reltol,
-                                                                    int maxiter) {
+                                                                    int maxiter, admm_fuse<E> F) {
   __shared__ double sm[16];
+  if (F.skip && *F.skip) {
+    if (threadIdx.x == 0) {
+      sc->iteration = 0;
+      sc->max_iter = maxiter;
+      sc->pending = 0;
+      sc->cur = 0;
+      sc->fresh = 0;
+      sc->done = 1;
+    }
+    return;
+  }
   double rr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
     const E ci = elem<E>::add(c[i], elem<E>::scale(rho, x[i]));
-    const E ri = elem<E>::sub(b[i], ci);
+    const E ri = elem<E>::sub(admm_rhs<E>(F, b, x, i), ci);
     r[i] = ri;
     u[i] = ri;
     rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
@@ -675,15 +707,23 @@ __global__ void admm_pre_kernel(E* __restrict__ beta, const E* __restrict__ beta
 
 // c = AHA x is in place.  c += rho x ; r = b - c ; residual = ||r|| ; tol ; u = r (= r + beta*0)
 template <typename E>
-__global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restrict__ x, const E* __restrict__ b,
+__global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restrict__ x, const E* b,
                                                                E* __restrict__ u, E* __restrict__ r,
                                                                const E* __restrict__ c, int64_t n, cg_scalars* sc,
-                                                               float rho, float reltol, int maxiter) {
+                                                               float rho, float reltol, int maxiter, admm_fuse<E> F) {
   __shared__ double sm[16];
+  if (F.skip && *F.skip) {
+    if (threadIdx.x == 0) {
+      sc->iteration = 0;
+      sc->maxiter = maxiter;
+      sc->done = 1;
+    }
+    return;
+  }
   double rr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
     const E ci = elem<E>::add(c[i], elem<E>::scale(rho, x[i]));
-    const E ri = elem<E>::sub(b[i], ci);
+    const E ri = elem<E>::sub(admm_rhs<E>(F, b, x, i), ci);
     r[i] = ri;
     u[i] = ri;  // first iteration: beta = residual^2 / 1^2 multiplies u == 0
     rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
@@ -813,6 +853,205 @@ template <typename S>
 static int32_t fetch_scalars(rls_ctx* ctx, S* d, S* h) {
   RLS_HIP(ctx, hipMemcpyAsync(h, d, sizeof(S), hipMemcpyDeviceToHost, ctx->stream));
   RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ADMM plan: whole outer iterations without host involvement (one regulariser, identity regTrafo)
+// ---------------------------------------------------------------------------------------------
+struct admm_scalars {
+  int iteration, done, max_iter, pad;
+  float rho, sigma_abs, rel_tol, pad2;
+};
+constexpr int ADMM_REC = 8;  // floats per log record: Delta, sk, eps_pri, rk, eps_dua, cg iterations, 0, 0
+
+struct rls_admm {
+  rls_cg* cg;
+  int device;
+  rls_admm_params P;
+  bool ready;
+  admm_scalars *sc, *sc_h;
+  float *log, *log_h;
+  int log_cap;
+  int enq;  // outer iterations enqueued since init (== device iteration unless the plan stopped early)
+};
+
+// src/ADMM.jl:246-309 in ONE single-workgroup launch: projections on x, z = prox(x + u) (L1 / L2 inline; a TV prox
+// has been written to `znew` by the FGP launch before this one), u += x - z, the seven norms (see admm_post_kernel),
+// then `converged` / `done` (:324-330) decided HERE in Float32 exactly as the host would, and one log record.
+template <typename E>
+__global__ __launch_bounds__(UPD_THREADS) void admm_zu_kernel(E* __restrict__ x, const E* __restrict__ xold,
+                                                              E* __restrict__ znew, const E* __restrict__ zold,
+                                                              E* __restrict__ u, int64_t n, int reg_kind, float lam,
+                                                              int proj_kind, int z_ready, admm_scalars* sc,
+                                                              const int* cg_iterations, float* __restrict__ log) {
+  __shared__ double sm[48];
+  if (sc->done) return;
+  double dx = 0, dz = 0, du = 0, nx = 0, nz = 0, nxz = 0, nu = 0;
+  auto sq = [](E a) { return (double)elem<E>::re(a) * (double)elem<E>::re(a) + (double)elem<E>::im(a) * (double)elem<E>::im(a); };
+  for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+    E xi = x[i];
+    if (proj_kind != RLS_PROJ_NONE) {
+      xi = fista_proj_elem<E>(xi, proj_kind);
+      x[i] = xi;
+    }
+    const E ui = u[i];
+    E zi;
+    if (z_ready) {
+      zi = znew[i];
+    } else {
+      zi = fista_prox_elem<E>(elem<E>::add(xi, ui), reg_kind, lam);
+      znew[i] = zi;
+    }
+    const E xz = elem<E>::sub(xi, zi);
+    const E un = elem<E>::sub(elem<E>::add(ui, xi), zi);  // u += x ; u -= z   (:266-267)
+    u[i] = un;
+    dx += sq(elem<E>::sub(xi, xold[i]));
+    dz += sq(elem<E>::sub(zi, zold[i]));
+    du += sq(elem<E>::sub(un, ui));
+    nx += sq(xi);
+    nz += sq(zi);
+    nxz += sq(xz);
+    nu += sq(un);
+  }
+  block_sum3(dx, dz, du, sm);
+  block_sum3(nx, nz, nxz, sm);
+  nu = block_sum(nu, sm);
+  if (threadIdx.x == 0) {
+    const float rho = sc->rho;
+    const float delta = (float)sqrt(dx) + (float)sqrt(dz) + (float)sqrt(du);
+    const float sk = __fmul_rn(rho, (float)sqrt(dz));
+    const float eps_pri = fmaxf((float)sqrt(nx), (float)sqrt(nz));
+    const float rk = (float)sqrt(nxz);
+    const float eps_dua = __fmul_rn(rho, (float)sqrt(nu));
+    const bool conv = rk < __fadd_rn(sc->sigma_abs, __fmul_rn(sc->rel_tol, eps_pri)) &&
+                      sk < __fadd_rn(sc->sigma_abs, __fmul_rn(sc->rel_tol, eps_dua));
+    const int it = sc->iteration;
+    float* rec = log + (int64_t)it * ADMM_REC;
+    rec[0] = delta;
+    rec[1] = sk;
+    rec[2] = eps_pri;
+    rec[3] = rk;
+    rec[4] = eps_dua;
+    rec[5] = (float)*cg_iterations;
+    rec[6] = rec[7] = 0.f;
+    sc->iteration = it + 1;
+    sc->done = conv || (it + 1 >= sc->max_iter);
+  }
+}
+
+template <typename E>
+__global__ void admm_reset_kernel(admm_scalars* sc, int max_iter, float rho, float sigma_abs, float rel_tol) {
+  sc->iteration = 0;
+  sc->max_iter = max_iter;
+  sc->done = max_iter <= 0;
+  sc->rho = rho;
+  sc->sigma_abs = sigma_abs;
+  sc->rel_tol = rel_tol;
+}
+
+// type-erased admm_fuse (null beta_y = plain cg!)
+struct admm_fuse_v {
+  const void *beta_y = nullptr, *z = nullptr, *u = nullptr;
+  void *beta = nullptr, *xold = nullptr;
+  float rho = 0.f;
+  const int* skip = nullptr;
+};
+template <typename E>
+static admm_fuse<E> typed_fuse(const admm_fuse_v& V) {
+  admm_fuse<E> F;
+  F.beta_y = (const E*)V.beta_y;
+  F.z = (const E*)V.z;
+  F.u = (const E*)V.u;
+  F.beta = (E*)V.beta;
+  F.xold = (E*)V.xold;
+  F.rho = V.rho;
+  F.skip = V.skip;
+  return F;
+}
+
+static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32_t maxiter, float reltol,
+                             const admm_fuse_v& FV) {
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  const int64_t n = op->N;
+  const admm_fuse<float> Ff = typed_fuse<float>(FV);
+  const admm_fuse<float2> Fc = typed_fuse<float2>(FV);
+  // warm start: one operator apply for r = b - (AHA + rho I) x
+  RLS_TRY(op_normal(op, x, s->c, FV.skip));
+  if (cg_use_gram_pipeline(s)) {
+    s->used_pipeline = true;
+    if (op->dtype == RLS_F32)
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                         (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->psc, rho, reltol,
+                         maxiter, Ff);
+    else
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                         (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->psc, rho, reltol,
+                         maxiter, Fc);
+    RLS_TRY(launch_status(ctx));
+    const rls_gram_pipe P = cg_gram_desc(s, x);
+    const int32_t dtype = op->dtype;
+    if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 3)) {  // the captured kernels carry x's address
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph.x_bound = x;
+    s->graph.mode = 3;
+    int parity = 0;
+    auto one = [ctx, dtype, &P, &parity]() {
+      const int32_t st = rls_gram_pipe_iteration(ctx, dtype, P, parity);
+      parity ^= 1;
+      return st;
+    };
+    if (ctx->tune.graph_chunk % 2) {
+      for (int i = 0; i < maxiter; ++i) RLS_TRY(one());
+    } else {
+      RLS_TRY(run_steps(ctx, &s->graph, maxiter, one));
+    }
+    return rls_gram_pipe_finish(ctx, dtype, P, maxiter & 1);
+  }
+  s->used_pipeline = cg_use_pipeline(s);
+  if (s->used_pipeline) {
+    if (op->dtype == RLS_F32)
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                         (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->psc, rho, reltol,
+                         maxiter, Ff);
+    else
+      hipLaunchKernelGGL(cg_pipe_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                         (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->psc, rho, reltol,
+                         maxiter, Fc);
+    RLS_TRY(launch_status(ctx));
+    const rls_cgnr_pipe P = cg_pipe_desc(s, x);
+    const int32_t dtype = op->dtype;
+    if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 1)) {  // the captured kernels carry x's address
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph.x_bound = x;
+    s->graph.mode = 1;
+    RLS_TRY(run_steps(ctx, &s->graph, maxiter, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
+    return rls_cgnr_pipe_finish(ctx, dtype, P);
+  }
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                       (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->sc, rho, reltol, maxiter,
+                       Ff);
+  else
+    hipLaunchKernelGGL(cg_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                       (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->sc, rho, reltol,
+                       maxiter, Fc);
+  RLS_TRY(launch_status(ctx));
+  for (int it = 0; it < maxiter; ++it) {
+    RLS_TRY(op_normal(op, s->u, s->c, &s->sc->done));
+    if (op->dtype == RLS_F32)
+      hipLaunchKernelGGL(cg_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)x, (float*)s->u,
+                         (float*)s->r, (float*)s->c, n, s->sc);
+    else
+      hipLaunchKernelGGL(cg_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)x,
+                         (float2*)s->u, (float2*)s->r, (float2*)s->c, n, s->sc);
+    RLS_TRY(launch_status(ctx));
+  }
   return 0;
 }
 
@@ -1525,86 +1764,10 @@ int32_t rls_cg_destroy(rls_cg* s) {
 
 int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxiter, float reltol) {
   if (!s) return RLS_E_INVALID;
-  rls_operator* op = s->op;
-  rls_ctx* ctx = op->ctx;
+  rls_ctx* ctx = s->op->ctx;
   if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_solve: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  const int64_t n = op->N;
-  // warm start: one operator apply for r = b - (AHA + rho I) x
-  RLS_TRY(op_normal(op, x, s->c, nullptr));
-  if (cg_use_gram_pipeline(s)) {
-    s->used_pipeline = true;
-    if (op->dtype == RLS_F32)
-      hipLaunchKernelGGL(cg_pipe_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
-                         (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->psc, rho, reltol,
-                         maxiter);
-    else
-      hipLaunchKernelGGL(cg_pipe_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
-                         (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->psc, rho, reltol,
-                         maxiter);
-    RLS_TRY(launch_status(ctx));
-    const rls_gram_pipe P = cg_gram_desc(s, x);
-    const int32_t dtype = op->dtype;
-    if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 3)) {  // the captured kernels carry x's address
-      hipGraphExecDestroy(s->graph.exec);
-      s->graph = step_graph();
-    }
-    s->graph.x_bound = x;
-    s->graph.mode = 3;
-    int parity = 0;
-    auto one = [ctx, dtype, &P, &parity]() {
-      const int32_t st = rls_gram_pipe_iteration(ctx, dtype, P, parity);
-      parity ^= 1;
-      return st;
-    };
-    if (ctx->tune.graph_chunk % 2) {
-      for (int i = 0; i < maxiter; ++i) RLS_TRY(one());
-    } else {
-      RLS_TRY(run_steps(ctx, &s->graph, maxiter, one));
-    }
-    return rls_gram_pipe_finish(ctx, dtype, P, maxiter & 1);
-  }
-  s->used_pipeline = cg_use_pipeline(s);
-  if (s->used_pipeline) {
-    if (op->dtype == RLS_F32)
-      hipLaunchKernelGGL(cg_pipe_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
-                         (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->psc, rho, reltol,
-                         maxiter);
-    else
-      hipLaunchKernelGGL(cg_pipe_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
-                         (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->psc, rho, reltol,
-                         maxiter);
-    RLS_TRY(launch_status(ctx));
-    const rls_cgnr_pipe P = cg_pipe_desc(s, x);
-    const int32_t dtype = op->dtype;
-    if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 1)) {  // the captured kernels carry x's address
-      hipGraphExecDestroy(s->graph.exec);
-      s->graph = step_graph();
-    }
-    s->graph.x_bound = x;
-    s->graph.mode = 1;
-    RLS_TRY(run_steps(ctx, &s->graph, maxiter, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
-    return rls_cgnr_pipe_finish(ctx, dtype, P);
-  }
-  if (op->dtype == RLS_F32)
-    hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
-                       (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->sc, rho, reltol, maxiter);
-  else
-    hipLaunchKernelGGL(cg_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
-                       (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->sc, rho, reltol,
-                       maxiter);
-  RLS_TRY(launch_status(ctx));
-  for (int it = 0; it < maxiter; ++it) {
-    RLS_TRY(op_normal(op, s->u, s->c, &s->sc->done));
-    if (op->dtype == RLS_F32)
-      hipLaunchKernelGGL(cg_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)x, (float*)s->u,
-                         (float*)s->r, (float*)s->c, n, s->sc);
-    else
-      hipLaunchKernelGGL(cg_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)x,
-                         (float2*)s->u, (float2*)s->r, (float2*)s->c, n, s->sc);
-    RLS_TRY(launch_status(ctx));
-  }
-  return 0;
+  return cg_solve_impl(s, x, b, rho, maxiter, reltol, admm_fuse_v());
 }
 
 int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {
@@ -1661,6 +1824,157 @@ int32_t rls_admm_post(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, con
   RLS_HIP(ctx, hipMemcpyAsync(ctx->res_h, ctx->res_d, sizeof(float) * 6, hipMemcpyDeviceToHost, ctx->stream));
   RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 6; ++i) out_h[i] = ctx->res_h[i];
+  return 0;
+}
+
+// ---- ADMM plan ------------------------------------------------------------------------------
+int32_t rls_admm_create(rls_cg* cg, rls_admm** out) {
+  if (!cg) return RLS_E_INVALID;
+  rls_ctx* ctx = cg->op->ctx;
+  if (!out) return rls_fail(ctx, RLS_E_INVALID, "admm_create: null out");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_admm* a = new rls_admm();
+  a->cg = cg;
+  a->device = ctx->device;
+  a->ready = false;
+  a->log = a->log_h = nullptr;
+  a->log_cap = 0;
+  a->enq = 0;
+  const int32_t st = alloc_scalars(ctx, &a->sc, &a->sc_h);
+  if (st != 0) {
+    delete a;
+    return st;
+  }
+  *out = a;
+  return 0;
+}
+
+int32_t rls_admm_destroy(rls_admm* a) {
+  if (!a) return RLS_E_INVALID;
+  hipSetDevice(a->device);
+  if (a->log) hipFree(a->log);
+  if (a->log_h) hipHostFree(a->log_h);
+  hipFree(a->sc);
+  hipHostFree(a->sc_h);
+  delete a;
+  return 0;
+}
+
+int32_t rls_admm_init(rls_admm* a, const rls_admm_params* p) {
+  if (!a) return RLS_E_INVALID;
+  rls_ctx* ctx = a->cg->op->ctx;
+  a->ready = false;
+  if (!p || !p->x || !p->xold || !p->beta || !p->beta_y || !p->z0 || !p->z1 || !p->u || p->iterations < 0 ||
+      p->iterations_cg < 0)
+    return rls_fail(ctx, RLS_E_INVALID, "admm_init: bad argument");
+  const int32_t dtype = a->cg->op->dtype;
+  switch (p->reg_kind) {
+    case RLS_REG_NONE:
+    case RLS_REG_L1:
+    case RLS_REG_L2:
+      break;
+    case RLS_REG_TV:
+      if (p->proj_kind != RLS_PROJ_NONE || p->tv_iterations < 0 ||
+          !rls_tv_single_ok(dtype, p->tv_ndims, p->tv_shape, p->tv_ntv, p->tv_dims))
+        return rls_fail(ctx, RLS_E_UNSUPPORTED, "admm_init: TV prox does not fit the single-workgroup FGP kernel");
+      {
+        int64_t n = 1;
+        for (int k = 0; k < p->tv_ndims; ++k) n *= p->tv_shape[k];
+        if (n != a->cg->op->N) return rls_fail(ctx, RLS_E_INVALID, "admm_init: prod(shape) != N");
+      }
+      break;
+    default:
+      return rls_fail(ctx, RLS_E_UNSUPPORTED, "admm_init: regulariser not fused (use the per-call path)");
+  }
+  if (p->proj_kind != RLS_PROJ_NONE && p->proj_kind != RLS_PROJ_REAL && p->proj_kind != RLS_PROJ_POSITIVE)
+    return rls_fail(ctx, RLS_E_INVALID, "admm_init: bad proj_kind");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const int cap = p->iterations > 0 ? p->iterations : 1;
+  if (cap > a->log_cap) {
+    if (a->log) hipFree(a->log);
+    if (a->log_h) hipHostFree(a->log_h);
+    a->log = a->log_h = nullptr;
+    a->log_cap = 0;
+    RLS_HIP(ctx, hipMalloc((void**)&a->log, sizeof(float) * ADMM_REC * cap));
+    RLS_HIP(ctx, hipHostMalloc((void**)&a->log_h, sizeof(float) * ADMM_REC * cap, hipHostMallocDefault));
+    a->log_cap = cap;
+  }
+  a->P = *p;
+  a->enq = 0;
+  hipLaunchKernelGGL(admm_reset_kernel<float>, dim3(1), dim3(1), 0, ctx->stream, a->sc, p->iterations, p->rho,
+                     p->sigma_abs, p->rel_tol);
+  RLS_TRY(launch_status(ctx));
+  a->ready = true;
+  return 0;
+}
+
+int32_t rls_admm_step(rls_admm* a, int32_t n_outer) {
+  if (!a) return RLS_E_INVALID;
+  rls_cg* cg = a->cg;
+  rls_ctx* ctx = cg->op->ctx;
+  if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_step before admm_init");
+  if (n_outer < 0) return rls_fail(ctx, RLS_E_INVALID, "admm_step: n_outer < 0");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const rls_admm_params& P = a->P;
+  const int32_t dtype = cg->op->dtype;
+  const int64_t n = cg->op->N;
+  for (int k = 0; k < n_outer && a->enq < P.iterations; ++k, ++a->enq) {
+    void* zcur = (a->enq & 1) ? P.z1 : P.z0;
+    void* znew = (a->enq & 1) ? P.z0 : P.z1;
+    admm_fuse_v F;
+    F.beta_y = P.beta_y;
+    F.z = zcur;
+    F.u = P.u;
+    F.beta = P.beta;
+    F.xold = P.xold;
+    F.rho = P.rho;
+    F.skip = &a->sc->done;
+    RLS_TRY(cg_solve_impl(cg, P.x, P.beta, P.rho, P.iterations_cg, P.tol_inner, F));  // :236-244
+    const int* cg_it = cg->used_pipeline ? &cg->psc->iteration : &cg->sc->iteration;
+    const int z_ready = P.reg_kind == RLS_REG_TV;
+    if (z_ready)
+      RLS_TRY(rls_tv_single_launch(ctx, dtype, P.tv_ndims, P.tv_shape, P.tv_ntv, P.tv_dims, P.x, P.u, znew,
+                                   P.prox_lambda, P.tv_iterations, &a->sc->done));
+    if (dtype == RLS_F32)
+      hipLaunchKernelGGL(admm_zu_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)P.x,
+                         (const float*)P.xold, (float*)znew, (const float*)zcur, (float*)P.u, n, P.reg_kind,
+                         P.prox_lambda, P.proj_kind, z_ready, a->sc, cg_it, a->log);
+    else
+      hipLaunchKernelGGL(admm_zu_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)P.x,
+                         (const float2*)P.xold, (float2*)znew, (const float2*)zcur, (float2*)P.u, n, P.reg_kind,
+                         P.prox_lambda, P.proj_kind, z_ready, a->sc, cg_it, a->log);
+    RLS_TRY(launch_status(ctx));
+  }
+  return 0;
+}
+
+int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int32_t log_records) {
+  if (!a || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = a->cg->op->ctx;
+  if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_get_status before admm_init");
+  if (log_records < 0 || (log_records > 0 && !log_h)) return rls_fail(ctx, RLS_E_INVALID, "admm_get_status: bad log");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const int nrec = a->enq < a->log_cap ? a->enq : a->log_cap;
+  if (nrec > 0)
+    RLS_HIP(ctx, hipMemcpyAsync(a->log_h, a->log, sizeof(float) * ADMM_REC * nrec, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_TRY(fetch_scalars(ctx, a->sc, a->sc_h));  // synchronises the stream
+  const int it = a->sc_h->iteration;
+  a->enq = it;  // a plan that stopped early continues (after a re-init only) from the device's count
+  out->iteration = it;
+  out->done = a->sc_h->done;
+  out->delta = out->sk = out->eps_pri = out->rk = out->eps_dua = 0.f;
+  out->cg_iterations = 0;
+  if (it > 0 && it <= nrec) {
+    const float* rec = a->log_h + (size_t)(it - 1) * ADMM_REC;
+    out->delta = rec[0];
+    out->sk = rec[1];
+    out->eps_pri = rec[2];
+    out->rk = rec[3];
+    out->eps_dua = rec[4];
+    out->cg_iterations = (int32_t)rec[5];
+  }
+  const int ncopy = it < log_records ? it : log_records;
+  for (int i = 0; i < ncopy * ADMM_REC; ++i) log_h[i] = a->log_h[i];
   return 0;
 }
 

@@ -213,9 +213,12 @@ __global__ void fgp_dual_kernel(E* brs, E* bpq, const E* xtmp, tv_geom G, float 
 
 // whole FGP loop in one workgroup; the image, xTmp and both dual buffers live in LDS (a global
 // re-read of x in every FGP iteration cost ~6 us of dependent latency per iteration)
+// out = prox_TV(xin [+ add]); `skip` (nullable) is a device flag that turns the launch into a no-op (ADMM plan)
 template <typename E>
-__global__ __launch_bounds__(1024) void fgp_fused_kernel(E* __restrict__ x, tv_geom32 G, float lam, int iters) {
+__global__ __launch_bounds__(1024) void fgp_fused_kernel(const E* xin, const E* add, E* x, tv_geom32 G, float lam,
+                                                         int iters, const int* skip) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (skip && *skip) return;
   const unsigned ng = G.goff[G.ntv], n = G.n;
   E* b0 = reinterpret_cast<E*>(smem_raw);
   E* b1 = b0 + ng;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(1024) void fgp_fused_kernel(E* __restrict__ x, tv_g
     b0[i] = elem<E>::zero();
     b1[i] = elem<E>::zero();
   }
-  for (unsigned i = tid; i < n; i += nth) xl[i] = x[i];
+  for (unsigned i = tid; i < n; i += nth) xl[i] = add ? elem<E>::add(xin[i], add[i]) : xin[i];
   __syncthreads();
   E* brs = b0;
   E* bpq = b1;
@@ -257,6 +260,102 @@ __global__ __launch_bounds__(1024) void fgp_fused_kernel(E* __restrict__ x, tv_g
   for (unsigned i = tid; i < n; i += nth) x[i] = elem<E>::add(xl[i], elem<E>::scale(-lam, gradt_at32<E>(bpq, G, i)));
 }
 
+// 2-D images (or 1-D signals), dims differenced in their natural order: every thread keeps its PPT pixels -- image,
+// both dual buffers, both components -- in registers; LDS only carries what a NEIGHBOUR reads (xTmp, and the dual
+// that grad^T is applied to), laid out on the pixel grid so that the neighbours are k+1 / k+nx and k-1 / k-nx.
+// Two workgroup barriers per FGP iteration, no index arithmetic inside the loop (the masks are formed once).
+// Same operation order as grad_at32 / gradt_at32 above.
+template <typename E, int PPT>
+__global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, const E* __restrict__ add,
+                                                     E* __restrict__ out, unsigned nx, unsigned ny, int use0, int use1,
+                                                     float lam, int iters, const int* __restrict__ skip) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (skip && *skip) return;
+  const unsigned n = nx * ny, tid = threadIdx.x, nth = blockDim.x;
+  E* xt = reinterpret_cast<E*>(smem_raw);
+  E* P = xt + n;
+  E* Q = P + n;
+  E xl[PPT], rp[PPT], rq[PPT], pp[PPT], pq[PPT], xv[PPT];
+  unsigned mIn = 0, mP = 0, mPm = 0, mQ = 0, mQm = 0;
+#pragma unroll
+  for (int m = 0; m < PPT; ++m) {
+    const unsigned k = tid + m * nth;
+    xl[m] = rp[m] = rq[m] = pp[m] = pq[m] = elem<E>::zero();
+    if (k < n) {
+      const unsigned j = k / nx, i = k - j * nx;
+      mIn |= 1u << m;
+      if (use0 && i + 1 < nx) mP |= 1u << m;
+      if (use0 && i > 0) mPm |= 1u << m;
+      if (use1 && j + 1 < ny) mQ |= 1u << m;
+      if (use1 && j > 0) mQm |= 1u << m;
+      xl[m] = add ? elem<E>::add(xin[k], add[k]) : xin[k];
+      P[k] = elem<E>::zero();
+      Q[k] = elem<E>::zero();
+    }
+  }
+  __syncthreads();
+  float t = 1.f;
+  const float step = 1.f / (8.f * lam);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < PPT; ++m) {
+      const unsigned k = tid + m * nth;
+      if (mIn >> m & 1) {
+        E s = elem<E>::zero();
+        if (mP >> m & 1) s = elem<E>::add(s, rp[m]);
+        if (mPm >> m & 1) s = elem<E>::sub(s, P[k - 1]);
+        if (mQ >> m & 1) s = elem<E>::add(s, rq[m]);
+        if (mQm >> m & 1) s = elem<E>::sub(s, Q[k - nx]);
+        xv[m] = elem<E>::add(xl[m], elem<E>::scale(-lam, s));
+        xt[k] = xv[m];
+      }
+    }
+    __syncthreads();
+    const float tOld = t;
+    t = (1.f + sqrtf(1.f + 4.f * tOld * tOld)) / 2.f;
+    const float t2 = (tOld - 1.f) / t, t3 = 1.f + t2;
+#pragma unroll
+    for (int m = 0; m < PPT; ++m) {
+      const unsigned k = tid + m * nth;
+      if (mP >> m & 1) {
+        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xt[k + 1])), rp[m]);
+        q = tv_clip<E>(q);
+        rp[m] = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pp[m]));
+        pp[m] = q;
+        P[k] = rp[m];
+      }
+      if (mQ >> m & 1) {
+        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xt[k + nx])), rq[m]);
+        q = tv_clip<E>(q);
+        rq[m] = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pq[m]));
+        pq[m] = q;
+        Q[k] = rq[m];
+      }
+    }
+    __syncthreads();
+  }
+  // x = x - lam * grad^T(newest pq)
+#pragma unroll
+  for (int m = 0; m < PPT; ++m) {
+    const unsigned k = tid + m * nth;
+    if (mP >> m & 1) P[k] = pp[m];
+    if (mQ >> m & 1) Q[k] = pq[m];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < PPT; ++m) {
+    const unsigned k = tid + m * nth;
+    if (mIn >> m & 1) {
+      E s = elem<E>::zero();
+      if (mP >> m & 1) s = elem<E>::add(s, pp[m]);
+      if (mPm >> m & 1) s = elem<E>::sub(s, P[k - 1]);
+      if (mQ >> m & 1) s = elem<E>::add(s, pq[m]);
+      if (mQm >> m & 1) s = elem<E>::sub(s, Q[k - nx]);
+      out[k] = elem<E>::add(xl[m], elem<E>::scale(-lam, s));
+    }
+  }
+}
+
 // small per-context cache of captured FGP launch sequences (multi-launch path)
 struct fgp_graph_key {
   const void *x, *ws;
@@ -285,6 +384,8 @@ static fgp_graph_cache& fgp_cache_for(rls_ctx* ctx) {
 
 constexpr size_t FGP_LDS_BUDGET = 160 * 1024 - 512;
 static int64_t g_fused_max_n = 2048;  // larger images: one CU is slower than 2 chip-wide launches per FGP iteration
+static int g_fused_2d = 1;            // the register-resident 2-D kernel (n <= 8192 pixels)
+constexpr int FGP2D_MAX_PPT = 8;
 
 static int32_t tv_status(rls_ctx* ctx) {
   hipError_t e = hipGetLastError();
@@ -298,16 +399,70 @@ static inline unsigned tv_grid(int64_t n) {
   return (unsigned)g;
 }
 
+// geometry of the register-resident kernel: (nx, ny, use0, use1), or false
+static bool fgp2d_geom(const tv_geom& G, size_t es, unsigned* nx, unsigned* ny, int* use0, int* use1) {
+  // complex images: 4 pixels per thread is the register limit at 1024 threads
+  if (!g_fused_2d || G.ndims > 2 || G.ntv < 1 || G.n > 1024 * (es > 4 ? FGP2D_MAX_PPT / 2 : FGP2D_MAX_PPT)) return false;
+  if ((size_t)3 * G.n * es > FGP_LDS_BUDGET) return false;
+  *use0 = *use1 = 0;
+  for (int k = 0; k < G.ntv; ++k) {
+    if (k > 0 && G.dims[k] <= G.dims[k - 1]) return false;  // natural order only (summation order of grad^T)
+    (G.dims[k] == 0 ? *use0 : *use1) = 1;
+  }
+  *nx = (unsigned)G.shape[0];
+  *ny = (unsigned)G.shape[1];
+  return true;
+}
+
+template <typename E, int PPT>
+static void fgp2d_launch(rls_ctx* ctx, unsigned nx, unsigned ny, int use0, int use1, const E* xin, const E* add, E* out,
+                         float lam, int iters, const int* skip) {
+  const unsigned n = nx * ny;
+  const size_t lds = (size_t)3 * n * sizeof(E);
+  unsigned nth = (n + PPT - 1) / PPT;
+  nth = (nth + 63) / 64 * 64;
+  if (nth > 1024) nth = 1024;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp2d_kernel<E, PPT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)lds);
+  hipLaunchKernelGGL((fgp2d_kernel<E, PPT>), dim3(1), dim3(nth), lds, ctx->stream, xin, add, out, nx, ny, use0, use1,
+                     lam, iters, skip);
+}
+
+// single-workgroup FGP (either kernel) when the geometry allows: out = prox_TV(xin [+ add]).  Returns false
+// (nothing launched) otherwise.
 template <typename E>
-int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E* ws) {
+static bool fgp_single_launch(rls_ctx* ctx, const tv_geom& G, const E* xin, const E* add, E* out, float lam, int iters,
+                              const int* skip) {
+  unsigned nx, ny;
+  int use0, use1;
+  if (fgp2d_geom(G, sizeof(E), &nx, &ny, &use0, &use1)) {
+    const unsigned n = nx * ny;
+    if (n <= 1024)
+      fgp2d_launch<E, 1>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+    else if (n <= 2048)
+      fgp2d_launch<E, 2>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+    else if (n <= 4096)
+      fgp2d_launch<E, 4>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+    else
+      fgp2d_launch<E, 8>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+    return true;
+  }
   const int64_t ng = G.goff[G.ntv], n = G.n;
   const size_t lds = (size_t)(2 * ng + 2 * n) * sizeof(E);
   if (lds <= FGP_LDS_BUDGET && n <= g_fused_max_n) {
-    RLS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp_fused_kernel<E>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3(1), dim3(1024), lds, ctx->stream, x, narrow_geom(G), lam, iters);
-    return tv_status(ctx);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp_fused_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3(1), dim3(1024), lds, ctx->stream, xin, add, out, narrow_geom(G), lam,
+                       iters, skip);
+    return true;
   }
+  return false;
+}
+
+template <typename E>
+int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E* ws) {
+  const int64_t ng = G.goff[G.ntv], n = G.n;
+  if (fgp_single_launch<E>(ctx, G, x, nullptr, x, lam, iters, nullptr)) return tv_status(ctx);
   // Multi-launch path: 2 chip-wide launches per FGP iteration.  Eager, the 2*iters + 2 launches are
   // host-bound (~3.8 us each measured); the whole sequence is therefore captured once per
   // (x, workspace, lambda, iterations, geometry) and replayed as a hipGraph (ADMM calls prox! with the
@@ -379,6 +534,33 @@ int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E*
 }  // namespace
 
 void rls_tv_set_fused_max_n(int64_t n) { g_fused_max_n = n; }
+void rls_tv_set_fused_2d(int on) { g_fused_2d = on; }
+
+static bool tv_single_ok(const tv_geom& G, size_t es) {
+  unsigned nx, ny;
+  int u0, u1;
+  if (fgp2d_geom(G, es, &nx, &ny, &u0, &u1)) return true;
+  return (size_t)(2 * G.goff[G.ntv] + 2 * G.n) * es <= FGP_LDS_BUDGET && G.n <= g_fused_max_n;
+}
+
+bool rls_tv_single_ok(int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims) {
+  tv_geom G;
+  return rls_dtype_ok(dtype) && make_geom(ndims, shape, ntv, dims, &G) && tv_single_ok(G, rls_elem_size(dtype));
+}
+
+int32_t rls_tv_single_launch(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
+                             const int32_t* dims, const void* xin, const void* add, void* out, float lam, int iters,
+                             const int* skip) {
+  tv_geom G;
+  if (!rls_dtype_ok(dtype) || !make_geom(ndims, shape, ntv, dims, &G))
+    return rls_fail(ctx, RLS_E_INVALID, "tv_single_launch: bad geometry");
+  const bool ok = dtype == RLS_F32
+                      ? fgp_single_launch<float>(ctx, G, (const float*)xin, (const float*)add, (float*)out, lam, iters, skip)
+                      : fgp_single_launch<float2>(ctx, G, (const float2*)xin, (const float2*)add, (float2*)out, lam,
+                                                  iters, skip);
+  if (!ok) return rls_fail(ctx, RLS_E_UNSUPPORTED, "tv_single_launch: image does not fit one workgroup");
+  return tv_status(ctx);
+}
 
 extern "C" {
 
@@ -464,7 +646,7 @@ int32_t rls_prox_tv_fgp(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_
   if (!rls_dtype_ok(dtype) || !x || iterations < 0 || !make_geom(ndims, shape, ntv, dims, &G))
     return rls_fail(ctx, RLS_E_INVALID, "prox_tv_fgp: bad argument");
   const size_t need = (size_t)(2 * G.goff[G.ntv] + G.n) * rls_elem_size(dtype);
-  const bool fused = need + (size_t)G.n * rls_elem_size(dtype) <= FGP_LDS_BUDGET && G.n <= g_fused_max_n;
+  const bool fused = tv_single_ok(G, rls_elem_size(dtype));
   if (!fused && (!workspace || workspace_bytes < need))
     return rls_fail(ctx, RLS_E_WORKSPACE, "prox_tv_fgp: workspace too small");
   RLS_HIP(ctx, hipSetDevice(ctx->device));

@@ -19,7 +19,8 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, CgnrStatus, CgStatus,
+from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, REG_TV, AdmmParams,
+                   AdmmStatus, CgnrStatus, CgStatus,
                    FistaStatus, check)
 from .arrays import DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle
 from .regularization import (AbstractProjectionRegularization, GradientOp, L1Regularization, L2Regularization,
@@ -495,6 +496,9 @@ class ADMMState(AbstractSolverState):
         self.absTol, self.relTol, self.tolInner = np.float32(absTol), np.float32(relTol), np.float32(tolInner)
         self.cg_u = self.cg_r = self.cg_c = None
         self._cg = None
+        self._admm = None       # rls_admm plan (whole outer iterations on the device) ...
+        self._plan_ok = False   # ... and whether this solve runs through it
+        self._zbufs = None
         self.cg_iterations: List[int] = []
 
     def convergence(self):
@@ -502,11 +506,13 @@ class ADMMState(AbstractSolverState):
 
     def __del__(self):
         try:
+            if self._admm and self.x is not None and self.x.ctx.handle:
+                self.x.ctx.lib.rls_admm_destroy(self._admm)
             if self._cg and self.x is not None and self.x.ctx.handle:
                 self.x.ctx.lib.rls_cg_destroy(self._cg)
         except Exception:
             pass
-        self._cg = None
+        self._cg = self._admm = None
 
 
 class ADMM(AbstractPrimalDualSolver):
@@ -536,6 +542,7 @@ class ADMM(AbstractPrimalDualSolver):
         self.iterationsCG = int(iterationsCG)
         self.normalizeReg = normalizeReg or NoNormalization()
         self._track_cg = True  # record the inner CG iteration counts (one extra host read-back per outer iteration)
+        self.use_device_plan = True  # whole outer iterations through rls_admm_step when the regulariser allows
         self.state = ADMMState(len(self.reg), self.rho, absTol, relTol, tolInner)
 
     def _new_state(self):
@@ -557,6 +564,9 @@ class ADMM(AbstractPrimalDualSolver):
             state.u = [b.similar(t.n_out) for t in self.regTrafo]
             state.uold = [b.similar(t.n_out) for t in self.regTrafo]
             state.cg_u, state.cg_r, state.cg_c = (b.similar(N) for _ in range(3))  # CGStateVariables :129,177
+            if state._admm:
+                lib.rls_admm_destroy(state._admm)
+                state._admm = None
             if state._cg:
                 lib.rls_cg_destroy(state._cg)
             plan = C.c_void_p()
@@ -564,6 +574,11 @@ class ADMM(AbstractPrimalDualSolver):
                   "rls_cg_create")
             state._cg = plan
             state._keep = (self._op, b.ctx)
+            state._zbufs = None
+        if len(self.reg) == 1:
+            if state._zbufs is None:
+                state._zbufs = (state.z[0], state.zold[0])
+            state.z[0], state.zold[0] = state._zbufs  # the device plan starts every solve with z in the first buffer
         if np.isscalar(x0):
             state.x.fill_(x0)
         else:
@@ -584,6 +599,84 @@ class ADMM(AbstractPrimalDualSolver):
         state.rho[:] = self.rho
         state.iteration = 0
         state.cg_iterations = []
+        self._init_plan(state)
+
+    def _plan_params(self, state):
+        """rls_admm_params when the whole outer iteration can run on the device, else None"""
+        if type(self) is not ADMM or not self.use_device_plan or not (self._all_identity() and len(self.reg) == 1 and self.vary_rho == "none"
+                                          and not self.verbose):
+            return None
+        reg, rho = self.reg[0], np.float32(state.rho[0])
+        P = AdmmParams()
+        if rho == 0:
+            P.reg_kind = REG_NONE
+        elif type(reg) is L1Regularization:
+            P.reg_kind = REG_L1
+        elif type(reg) is L2Regularization and getattr(reg, "lam_vector", None) is None:
+            P.reg_kind = REG_L2
+        elif type(reg) is TVRegularization and 1 <= len(reg.shape) <= 4:
+            from .regularization import _tv_geometry
+            shape, d0, _, _ = _tv_geometry(reg.shape, reg.dims)
+            if int(np.prod(shape)) != self._op.N or len(d0) > 4:
+                return None
+            P.reg_kind = REG_TV
+            P.tv_ndims, P.tv_ntv, P.tv_iterations = len(shape), len(d0), reg.iterationsTV
+            for k, v in enumerate(shape):
+                P.tv_shape[k] = v
+            for k, v in enumerate(d0):
+                P.tv_dims[k] = v
+        else:
+            return None
+        if len(self.proj) > 1 or (self.proj and P.reg_kind == REG_TV):
+            return None
+        P.proj_kind = PROJ_NONE
+        if self.proj:
+            if isinstance(self.proj[0], PositiveRegularization):
+                P.proj_kind = PROJ_POSITIVE
+            elif isinstance(self.proj[0], RealRegularization):
+                P.proj_kind = PROJ_REAL
+            else:
+                return None
+        with np.errstate(divide="ignore"):
+            P.prox_lambda = 0.0 if rho == 0 else float(np.float32(reg.lam) / (np.float32(2) * rho))  # :261
+        P.x, P.xold, P.beta, P.beta_y = state.x.ptr, state.xold.ptr, state.beta.ptr, state.beta_y.ptr
+        P.z0, P.z1, P.u = state._zbufs[0].ptr, state._zbufs[1].ptr, state.u[0].ptr
+        P.rho, P.sigma_abs, P.rel_tol = float(rho), float(state.sigma_abs), float(state.relTol)
+        P.iterations, P.iterations_cg, P.tol_inner = self.iterations, self.iterationsCG, float(state.tolInner)
+        return P
+
+    def _init_plan(self, state):
+        state._plan_ok = False
+        P = self._plan_params(state)
+        if P is None:
+            return
+        lib, h = state.x.ctx.lib, state.x.ctx.handle
+        if not state._admm:
+            plan = C.c_void_p()
+            check(h, lib.rls_admm_create(state._cg, C.byref(plan)), "rls_admm_create")
+            state._admm = plan
+        st = lib.rls_admm_init(state._admm, C.byref(P))
+        if st == -2:  # RLS_E_UNSUPPORTED
+            return  # e.g. a TV image too large for one workgroup: per-call path (still device kernels)
+        check(h, st, "rls_admm_init")
+        state._plan_ok = True
+
+    def _plan_advance(self, state, n_outer):
+        """n_outer iterations through the device plan, then ONE read-back of the scalars and the log"""
+        lib, h = state.x.ctx.lib, state.x.ctx.handle
+        check(h, lib.rls_admm_step(state._admm, int(n_outer)), "rls_admm_step")
+        st = AdmmStatus()
+        cap = max(self.iterations, 1)
+        log = (C.c_float * (8 * cap))()
+        check(h, lib.rls_admm_get_status(state._admm, C.byref(st), log, cap), "rls_admm_get_status")
+        it = int(st.iteration)
+        if it > 0:
+            state.Delta[0], state.sk[0], state.eps_pri[0] = st.delta, st.sk, st.eps_pri
+            state.rk[0], state.eps_dua[0] = st.rk, st.eps_dua
+        state.cg_iterations = [int(log[8 * k + 5]) for k in range(it)]
+        state.iteration = it
+        state.z[0], state.zold[0] = (state._zbufs[1], state._zbufs[0]) if it & 1 else state._zbufs
+        return bool(st.done)
 
     def converged(self, state):
         for i in range(len(self.reg)):
@@ -638,6 +731,9 @@ class ADMM(AbstractPrimalDualSolver):
         state = state or self.state
         if self.done(state):
             return None
+        if state._plan_ok:
+            self._plan_advance(state, 1)
+            return state.x, state
         f32 = np.float32
         lib, h = state.x.ctx.lib, state.x.ctx.handle
         fused = self._all_identity() and len(self.reg) == 1
@@ -736,6 +832,8 @@ class ADMM(AbstractPrimalDualSolver):
             print(f"rk/eps_pri = {state.rk[i] / state.eps_pri[i]}  sk/eps_dua = {state.sk[i] / state.eps_dua[i]}  rho = {state.rho[i]}")
 
     def _run(self, state):
+        if state._plan_ok and not self.done(state):
+            self._plan_advance(state, self.iterations - state.iteration)  # `done` is evaluated on the device
         while self.iterate(state) is not None:
             pass
 
@@ -1059,6 +1157,9 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
         state = state or self.state
         if self.done(state):
             return None
+        if state._plan_ok:
+            self._plan_advance(state, 1)
+            return state.x, state
         f32 = np.float32
         lib, h = state.x.ctx.lib, state.x.ctx.handle
         fused = self._all_identity() and len(self.reg) == 1

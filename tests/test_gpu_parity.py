@@ -492,6 +492,70 @@ def test_admm_tv_matches_oracle(rls, ctx, dt, M, N, shape):
     assert np.allclose(sol.state.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(sol.state.sk, ref.sk, rtol=2e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("dt,M,N,kind", [(np.float32, 128, 64, "tv"), (np.complex64, 96, 36, "tv"), (np.float32, 120, 48, "l1"),
+                                         (np.complex64, 90, 40, "l1pos"), (np.float32, 64, 32, "l2"),
+                                         (np.float32, 100, 60, "tv1d"), (np.float32, 100, 63, "tv3d")])
+def test_admm_device_plan_equals_per_call_path(rls, ctx, dt, M, N, kind):
+    """rls_admm_step (whole outer iterations on the device, `done` decided there) against the per-call sequence of the
+    same solver and against the oracle: same iteration count, inner cg! counts, residuals, solution -- step by step
+    with callbacks and in one go"""
+    A, xt, b = O.make_problem(M, N, dt, 21)
+    def regs(R):
+        if kind == "tv":
+            sh = {64: (8, 8), 36: (6, 6)}[N]
+            return R.TVRegularization(2e-2, shape=sh)
+        if kind == "tv1d":
+            return R.TVRegularization(2e-2, shape=(N,))
+        if kind == "tv3d":
+            return R.TVRegularization(2e-2, shape=(3, 7, 3))
+        if kind == "l1":
+            return R.L1Regularization(0.05)
+        if kind == "l1pos":
+            return [R.L1Regularization(0.05), R.PositiveRegularization()]
+        return R.L2Regularization(0.3)
+    kw = dict(rho=0.3, iterations=12, iterationsCG=6, tolInner=1e-4)
+    ref = O.ADMM(A, reg=regs(O), **kw)
+    O.solve(ref, b)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    sol = rls.createLinearSolver(rls.ADMM, Ad, reg=regs(rls), **kw)
+    x = rls.solve_(sol, bd).to_host()
+    assert sol.state._plan_ok
+    old = rls.createLinearSolver(rls.ADMM, Ad, reg=regs(rls), **kw)
+    old.use_device_plan = False
+    x_old = rls.solve_(old, bd).to_host()
+    assert not old.state._plan_ok
+    assert sol.state.iteration == old.state.iteration == ref.iteration
+    assert sol.state.cg_iterations == old.state.cg_iterations == ref.cg_iters
+    assert rel(x, ref.x) < 2e-5 and rel(x, x_old) < 2e-6
+    assert np.allclose(sol.state.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(sol.state.sk, ref.sk, rtol=2e-3, atol=1e-6)
+    assert np.allclose(sol.state.eps_pri, old.state.eps_pri, rtol=1e-5) and np.allclose(sol.state.eps_dua, old.state.eps_dua, rtol=1e-5)
+    assert rel(sol.state.z[0].to_host(), old.state.z[0].to_host()) < 2e-6
+    assert rel(sol.state.u[0].to_host(), old.state.u[0].to_host()) < 2e-5
+    # with callbacks: one plan iteration per host iteration, the same bits as the bulk run
+    seen = []
+    x_cb = rls.solve_(sol, bd, callbacks=lambda s, it: seen.append((it, s.state.iteration))).to_host()
+    assert seen == [(k, k) for k in range(ref.iteration + 1)]
+    assert np.array_equal(x_cb, x)
+
+
+def test_admm_device_plan_stops_when_converged(rls, ctx):
+    """`converged` (src/ADMM.jl:324-330) evaluated on the device: with loose tolerances the plan stops itself at the
+    iteration the oracle stops at, the remaining enqueued launches are no-ops, and a second solve re-arms it"""
+    A, xt, b = O.make_problem(150, 50, np.float32, 5)
+    kw = dict(rho=1.0, iterations=60, iterationsCG=10, tolInner=1e-6, absTol=1e-3, relTol=2e-2)
+    ref = O.ADMM(A, reg=O.L1Regularization(1e-3), **kw)
+    O.solve(ref, b)
+    assert 1 < ref.iteration < 60
+    sol = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(1e-3), **kw)
+    bd = rls.DeviceVector.from_host(b)
+    for _ in range(2):
+        x = rls.solve_(sol, bd).to_host()
+        assert sol.state._plan_ok and sol.state.iteration == ref.iteration
+        assert sol.converged(sol.state)
+        assert rel(x, ref.x) < 2e-5
+        assert len(sol.state.cg_iterations) == ref.iteration
+
+
 @pytest.mark.parametrize("pipe", [1, 0])
 @pytest.mark.parametrize("dt,M,N,restart", [(np.complex64, 4096, 2048, "none"), (np.float32, 300, 120, "gradient"),
                                             (np.complex64, 70, 34, "none")])
