@@ -350,6 +350,20 @@ int32_t rls_cgnr_init_local_a(rls_cgnr* s, const void* b_local, float lambda, fl
 int32_t rls_cgnr_init_local_b(rls_cgnr* s);
 int32_t rls_cgnr_step_local_a(rls_cgnr* s);
 int32_t rls_cgnr_step_local_b(rls_cgnr* s);
+/* FISTA (src/FISTA.jl:110-185) on a row shard, split at the same exchange step: the caller all-reduces x0 (= A^H b)
+ * between init_local_a and init_local_b, and `res` (= A^H A y) between step_local_a and step_local_b; the gradient
+ * step, prox and momentum run replicated.  x0 and res are the vectors given to rls_fista_create. */
+int32_t rls_fista_init_local_a(rls_fista* s, const void* b_local);
+int32_t rls_fista_init_local_b(rls_fista* s, float rho, float theta, float rel_tol, int32_t iterations,
+                               int32_t restart_gradient);
+int32_t rls_fista_step_local_a(rls_fista* s);
+int32_t rls_fista_step_local_b(rls_fista* s);
+/* cg! (call site src/ADMM.jl:244) on a row shard: the caller all-reduces c (given to rls_cg_create) after every
+ * rls_cg_local_apply.  apply(x) is the warm-start product AHA x; apply(NULL) is AHA u of one iteration and is
+ * skipped on the device once the solve is done, like the update, so a fixed `maxiter` iterations can be enqueued. */
+int32_t rls_cg_local_apply(rls_cg* s, const void* x);
+int32_t rls_cg_local_start(rls_cg* s, const void* x, const void* b, float rho, int32_t maxiter, float reltol);
+int32_t rls_cg_local_update(rls_cg* s, void* x);
 
 #ifdef __cplusplus
 }

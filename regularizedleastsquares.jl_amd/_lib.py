@@ -143,6 +143,13 @@ PROTOTYPES = {
     "rls_cg_get_status": (_i32, [_vp, C.POINTER(CgStatus)]),
     "rls_admm_pre": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32]),
     "rls_admm_post": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _pf]),
+    "rls_fista_init_local_a": (_i32, [_vp, _vp]),
+    "rls_fista_init_local_b": (_i32, [_vp, _f, _f, _f, _i32, _i32]),
+    "rls_fista_step_local_a": (_i32, [_vp]),
+    "rls_fista_step_local_b": (_i32, [_vp]),
+    "rls_cg_local_apply": (_i32, [_vp, _vp]),
+    "rls_cg_local_start": (_i32, [_vp, _vp, _vp, _f, _i32, _f]),
+    "rls_cg_local_update": (_i32, [_vp, _vp]),
     "rls_admm_create": (_i32, [_vp, _pvp]),
     "rls_admm_destroy": (_i32, [_vp]),
     "rls_admm_init": (_i32, [_vp, C.POINTER(AdmmParams)]),

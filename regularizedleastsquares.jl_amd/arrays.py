@@ -109,6 +109,11 @@ class _DeviceBuffer:
         self.ptr = self._base = None
 
 
+class _BorrowedBuffer:
+    def __init__(self, ptr: int, keep=None):
+        self.ptr, self._keep = int(ptr), keep
+
+
 class DeviceVector:
     """Length-n Float32 / ComplexF32 vector in HBM."""
 
@@ -129,6 +134,12 @@ class DeviceVector:
         v = cls(a.shape[0], a.dtype, ctx)
         v.copy_from_host(a)
         return v
+
+    @classmethod
+    def borrow(cls, ptr: int, n: int, dtype, ctx: Optional[Context] = None, keep=None) -> "DeviceVector":
+        """view of device memory owned by someone else (e.g. a torch tensor that torch.distributed all-reduces in
+        place); `keep` is held so the owner outlives the view"""
+        return cls(n, dtype, ctx, _buf=_BorrowedBuffer(ptr, keep))
 
     def similar(self, n: Optional[int] = None) -> "DeviceVector":
         return DeviceVector(self.n if n is None else n, self.dtype, self.ctx)

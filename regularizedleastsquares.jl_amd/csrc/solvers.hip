@@ -1580,8 +1580,8 @@ int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t 
   return 0;
 }
 
-int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, float rel_tol, int32_t iterations,
-                       int32_t restart_gradient) {
+// x0 = A^H b (src/FISTA.jl:114); on a row shard this is the partial sum the caller all-reduces
+int32_t rls_fista_init_local_a(rls_fista* s, const void* b) {
   if (!s) return RLS_E_INVALID;
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
@@ -1591,6 +1591,14 @@ int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, floa
     RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, b, 0.f, 0.f, s->x0, nullptr));
   else
     RLS_HIP(ctx, hipMemcpyAsync(s->x0, b, (size_t)op->N * rls_elem_size(op->dtype), hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel_tol, int32_t iterations,
+                                 int32_t restart_gradient, bool local) {
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(fista_init_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
                        (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc, rho, theta,
@@ -1602,14 +1610,50 @@ int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, floa
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
                        (long long)s->l21_slices);
   s->initialised = true;
-  const bool gram = fista_gram_ok(s);
-  const bool pipe = !gram && fista_pipe_ok(s);
+  // row-sharded plans exchange `res` between the operator apply and the update: two-half iterations only
+  const bool gram = !local && fista_gram_ok(s);
+  const bool pipe = !local && !gram && fista_pipe_ok(s);
   if ((pipe != s->use_pipe || gram != s->use_gram) && s->graph.exec) {  // captured for another kernel sequence
     hipGraphExecDestroy(s->graph.exec);
     s->graph = step_graph();
   }
   s->use_pipe = pipe;
   s->use_gram = gram;
+  return launch_status(ctx);
+}
+
+int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, float rel_tol, int32_t iterations,
+                       int32_t restart_gradient) {
+  RLS_TRY(rls_fista_init_local_a(s, b));
+  return fista_init_finish(s, rho, theta, rel_tol, iterations, restart_gradient, false);
+}
+
+int32_t rls_fista_init_local_b(rls_fista* s, float rho, float theta, float rel_tol, int32_t iterations,
+                               int32_t restart_gradient) {
+  if (!s) return RLS_E_INVALID;
+  return fista_init_finish(s, rho, theta, rel_tol, iterations, restart_gradient, true);
+}
+
+// one row-sharded iteration: res_partial = A_g^H A_g y ; [caller: all-reduce(res)] ; gradient step, prox, momentum
+int32_t rls_fista_step_local_a(rls_fista* s) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised || s->use_pipe || s->use_gram) return rls_fail(ctx, RLS_E_STATE, "fista_step_local before fista_init_local_b");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  return op_normal(s->op, s->y, s->res, &s->sc->done);
+}
+int32_t rls_fista_step_local_b(rls_fista* s) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (!s->initialised || s->use_pipe || s->use_gram) return rls_fail(ctx, RLS_E_STATE, "fista_step_local before fista_init_local_b");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(fista_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
+                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc);
+  else
+    hipLaunchKernelGGL(fista_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)s->buf[0],
+                       (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc);
   return launch_status(ctx);
 }
 
@@ -1768,6 +1812,51 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
   if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_solve: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   return cg_solve_impl(s, x, b, rho, maxiter, reltol, admm_fuse_v());
+}
+
+// row-sharded cg! (ADMM on a row-partitioned A): the operator apply and the update are separate calls with the
+// caller's all-reduce of c between them; the unfused scalars / kernels, `done` on the device as usual
+//   rls_cg_local_apply(s, x)      c_partial = A_g^H A_g x        (warm start; null = the direction u, skipped once done)
+//   rls_cg_local_start(...)       r = b - (c + rho x), u = r, residual, tol
+//   rls_cg_local_update(s, x)     alpha, x, r, residual, next direction
+int32_t rls_cg_local_apply(rls_cg* s, const void* x) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  return x ? op_normal(s->op, x, s->c, nullptr) : op_normal(s->op, s->u, s->c, &s->sc->done);
+}
+
+int32_t rls_cg_local_start(rls_cg* s, const void* x, const void* b, float rho, int32_t maxiter, float reltol) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_local_start: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  s->used_pipeline = false;
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
+                       (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, op->N, s->sc, rho, reltol,
+                       maxiter, typed_fuse<float>(admm_fuse_v()));
+  else
+    hipLaunchKernelGGL(cg_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
+                       (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, op->N, s->sc, rho, reltol,
+                       maxiter, typed_fuse<float2>(admm_fuse_v()));
+  return launch_status(ctx);
+}
+
+int32_t rls_cg_local_update(rls_cg* s, void* x) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (!x) return rls_fail(ctx, RLS_E_INVALID, "cg_local_update: null x");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(cg_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)x, (float*)s->u,
+                       (float*)s->r, (float*)s->c, op->N, s->sc);
+  else
+    hipLaunchKernelGGL(cg_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)x,
+                       (float2*)s->u, (float2*)s->r, (float2*)s->c, op->N, s->sc);
+  return launch_status(ctx);
 }
 
 int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {

@@ -10,6 +10,10 @@ Two modes, both new designs (the reference has no multi-process code, SURVEY 2.2
     exchange is ONE all-reduce(sum) of the N-vector A_g^H t_g per iteration (plus one at init for
     A^H b).  Scalars stay consistent without communication because every rank sums identical
     all-reduced vectors in the same order.
+  * RowShardedFISTA / RowShardedADMM -- the same partitioning for the other two solvers of the hot path
+    (last row): the operator apply is the only distributed step (one all-reduce of A_g^H A_g y
+    per FISTA iteration, of A_g^H A_g u per inner cg! iteration of ADMM); prox, momentum, z/u updates and
+    all scalars run replicated.
 
 The distributed control flow is written against a small "local ops" protocol so that it can be
 exercised on CPU with the gloo backend (tests/test_multigpu_gloo.py supply a NumPy implementation of
@@ -24,7 +28,8 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._lib import CgnrStatus, check
+from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, CgnrStatus, CgStatus,
+                   FistaStatus, check)
 
 
 # --------------------------------------------------------------------------------------------
@@ -186,6 +191,282 @@ class RowShardedCGNR:
         # every rank holds identical scalars, so `done` flips on the same iteration everywhere; the
         # steps past it are no-ops on the device, and the collective count stays matched
         self.step(min(self.iterations, self.ops.tensor("x").shape[0]))
+        return self.ops.solution()
+
+
+# --------------------------------------------------------------------------------------------
+# row-sharded FISTA and ADMM (same partitioning, same single exchange step per operator apply)
+# --------------------------------------------------------------------------------------------
+
+
+def _torch_vectors(torch, names, n, dtype, device):
+    tdt = torch.complex64 if np.dtype(dtype).kind == "c" else torch.float32
+    return {k: torch.zeros(n, dtype=tdt, device=f"cuda:{device}") for k in names}
+
+
+def _reg_codes(rls, reg, proj):
+    """(reg_kind, lambda, slices, proj_kind) of the fused elementwise update kernels"""
+    if reg is None:
+        kind, lam, slices = REG_NONE, 0.0, 1
+    elif type(reg) is rls.L1Regularization:
+        kind, lam, slices = REG_L1, reg.lam, 1
+    elif type(reg) is rls.L2Regularization and getattr(reg, "lam_vector", None) is None:
+        kind, lam, slices = REG_L2, reg.lam, 1
+    elif type(reg) is rls.L21Regularization:
+        kind, lam, slices = REG_L21, reg.lam, reg.slices
+    else:
+        raise NotImplementedError("row-sharded FISTA: L1 / L2 / L21 regularisation")
+    pk = PROJ_NONE
+    if proj is not None:
+        pk = PROJ_POSITIVE if isinstance(proj, rls.PositiveRegularization) else PROJ_REAL
+    return kind, float(lam), int(slices), pk
+
+
+class HipFistaOps:
+    """Rank-local half-steps of row-sharded FISTA on the GPU (rls_fista_init_local_a/b, rls_fista_step_local_a/b)."""
+
+    def __init__(self, rls, A_local: np.ndarray, device: int, reg=None, proj=None):
+        import torch
+
+        self.rls, self.torch = rls, torch
+        torch.cuda.set_device(device)
+        self.ctx = rls.Context(device, stream=torch.cuda.current_stream().cuda_stream)
+        self.A = rls.DeviceMatrix.from_host(A_local, self.ctx)
+        self.op = rls.OperatorHandle(self.A)
+        self.t = _torch_vectors(torch, ("x", "x0", "xold", "res"), self.A.N, self.A.dtype, device)
+        lib, h = self.ctx.lib, self.ctx.handle
+        plan = C.c_void_p()
+        check(h, lib.rls_fista_create(self.op.handle, self.t["x"].data_ptr(), self.t["x0"].data_ptr(),
+                                      self.t["xold"].data_ptr(), self.t["res"].data_ptr(), C.byref(plan)), "rls_fista_create")
+        self.plan = plan
+        kind, lam, slices, pk = _reg_codes(rls, reg, proj)
+        check(h, lib.rls_fista_set_reg(plan, kind, lam, slices, pk), "rls_fista_set_reg")
+        self._b = None
+
+    def init_a(self, b_local: np.ndarray):
+        self._b = self.rls.DeviceVector.from_host(b_local, self.ctx)
+        check(self.ctx.handle, self.ctx.lib.rls_fista_init_local_a(self.plan, self._b.ptr), "rls_fista_init_local_a")
+
+    def init_b(self, rho, theta, rel_tol, iterations, restart_gradient):
+        check(self.ctx.handle, self.ctx.lib.rls_fista_init_local_b(self.plan, float(rho), float(theta), float(rel_tol),
+                                                                   int(iterations), int(bool(restart_gradient))),
+              "rls_fista_init_local_b")
+
+    def step_a(self):
+        check(self.ctx.handle, self.ctx.lib.rls_fista_step_local_a(self.plan), "rls_fista_step_local_a")
+
+    def step_b(self):
+        check(self.ctx.handle, self.ctx.lib.rls_fista_step_local_b(self.plan), "rls_fista_step_local_b")
+
+    def tensor(self, name):
+        return self.t[name]
+
+    def status(self):
+        st = FistaStatus()
+        check(self.ctx.handle, self.ctx.lib.rls_fista_get_status(self.plan, C.byref(st)), "rls_fista_get_status")
+        return {"iteration": st.iteration, "done": bool(st.done), "rel_res_norm": st.rel_res_norm, "residual": st.residual}
+
+    def solution(self) -> np.ndarray:
+        p = C.c_void_p()
+        check(self.ctx.handle, self.ctx.lib.rls_fista_solution(self.plan, C.byref(p)), "rls_fista_solution")
+        for t in (self.t["x"], self.t["xold"]):  # the plan swaps x / xold by pointer (src/FISTA.jl:144-146)
+            if t.data_ptr() == p.value:
+                return t.cpu().numpy()
+        raise RuntimeError("rls_fista_solution returned a foreign pointer")
+
+    def sync(self):
+        self.ctx.sync()
+
+    def close(self):
+        if self.plan:
+            self.ctx.lib.rls_fista_destroy(self.plan)
+            self.plan = None
+
+
+class RowShardedFISTA:
+    """FISTA (src/FISTA.jl:110-185) on a row-partitioned A.  Per iteration: step_a (res_g = A_g^H A_g y),
+    all-reduce(res), step_b (gradient step, prox, momentum -- replicated).  `done` flips on the same iteration on
+    every rank (identical scalars), the steps past it are no-ops on the device, the collective count stays matched."""
+
+    def __init__(self, ops, dist=None, rho: float = 1.0, theta: float = 1.0, iterations: int = 50,
+                 relTol: float = float(np.finfo(np.float32).eps), restart: str = "none"):
+        if restart not in ("none", "gradient"):
+            raise ValueError("restart must be 'none' or 'gradient'")
+        self.ops, self.dist = ops, dist
+        self.rho, self.theta, self.iterations, self.relTol = float(rho), float(theta), int(iterations), float(relTol)
+        self.restart = restart
+
+    def _allreduce(self, name):
+        if self.dist is not None and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(self.ops.tensor(name), op=self.dist.ReduceOp.SUM)
+
+    def init(self, b_local):
+        self.ops.init_a(b_local)
+        self._allreduce("x0")  # x0 = sum_g A_g^H b_g   (src/FISTA.jl:114)
+        self.ops.init_b(self.rho, self.theta, self.relTol, self.iterations, self.restart == "gradient")
+
+    def step(self, n: int = 1):
+        for _ in range(n):
+            self.ops.step_a()
+            self._allreduce("res")
+            self.ops.step_b()
+
+    def solve(self, b_local):
+        self.init(b_local)
+        self.step(self.iterations)
+        return self.ops.solution()
+
+
+class HipAdmmOps:
+    """Rank-local steps of row-sharded ADMM on the GPU (one regulariser, identity regTrafo): rls_admm_pre / _post for
+    the replicated elementwise work, rls_cg_local_apply / _start / _update for the inner cg! whose operator apply is
+    the distributed step."""
+
+    def __init__(self, rls, A_local: np.ndarray, device: int, reg=None, proj=()):
+        import torch
+
+        self.rls, self.torch = rls, torch
+        torch.cuda.set_device(device)
+        self.ctx = rls.Context(device, stream=torch.cuda.current_stream().cuda_stream)
+        self.A = rls.DeviceMatrix.from_host(A_local, self.ctx)
+        self.op = rls.OperatorHandle(self.A)
+        n, dt = self.A.N, self.A.dtype
+        names = ("x", "xold", "beta", "beta_y", "z", "zold", "u", "cg_u", "cg_r", "cg_c")
+        self.t = _torch_vectors(torch, names, n, dt, device)
+        # DeviceVector views of the torch storage, for the prox maps and the fused elementwise entry points
+        self.v = {k: rls.DeviceVector.borrow(self.t[k].data_ptr(), n, dt, self.ctx, keep=self.t[k]) for k in names}
+        self.reg, self.proj = reg, list(proj)
+        lib, h = self.ctx.lib, self.ctx.handle
+        plan = C.c_void_p()
+        check(h, lib.rls_cg_create(self.op.handle, self.t["cg_u"].data_ptr(), self.t["cg_r"].data_ptr(),
+                                   self.t["cg_c"].data_ptr(), C.byref(plan)), "rls_cg_create")
+        self.cg = plan
+
+    def init_a(self, b_local: np.ndarray):
+        b = self.rls.DeviceVector.from_host(b_local, self.ctx)
+        self.A.mul_adj_(self.v["beta_y"], b)  # partial A_g^H b_g   (src/ADMM.jl:198)
+
+    def init_b(self):
+        for k in ("x", "z", "u"):  # x0 = 0, z = Phi x, u = 0   (:199-206)
+            self.v[k].fill_(0)
+
+    def pre(self, rho):
+        v, lib, h = self.v, self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_admm_pre(h, v["x"].code, v["x"].n, v["beta"].ptr, v["beta_y"].ptr, v["z"].ptr, v["u"].ptr,
+                                  v["x"].ptr, v["xold"].ptr, float(rho), 0), "rls_admm_pre")
+
+    def apply_x(self):
+        check(self.ctx.handle, self.ctx.lib.rls_cg_local_apply(self.cg, self.v["x"].ptr), "rls_cg_local_apply")
+
+    def cg_start(self, rho, maxiter, reltol):
+        check(self.ctx.handle, self.ctx.lib.rls_cg_local_start(self.cg, self.v["x"].ptr, self.v["beta"].ptr, float(rho),
+                                                               int(maxiter), float(reltol)), "rls_cg_local_start")
+
+    def apply_u(self):
+        check(self.ctx.handle, self.ctx.lib.rls_cg_local_apply(self.cg, None), "rls_cg_local_apply")
+
+    def cg_update(self):
+        check(self.ctx.handle, self.ctx.lib.rls_cg_local_update(self.cg, self.v["x"].ptr), "rls_cg_local_update")
+
+    def cg_iterations(self) -> int:
+        st = CgStatus()
+        check(self.ctx.handle, self.ctx.lib.rls_cg_get_status(self.cg, C.byref(st)), "rls_cg_get_status")
+        return int(st.iterations)
+
+    def post(self, prox_lambda):
+        """projections, z = prox(x + u), u += x - z and the norms (src/ADMM.jl:246-299); returns the 6-float record"""
+        v, lib, h = self.v, self.ctx.lib, self.ctx.handle
+        for pr in self.proj:
+            pr.prox_(v["x"])
+        self.t["z"], self.t["zold"] = self.t["zold"], self.t["z"]
+        v["z"], v["zold"] = v["zold"], v["z"]
+        v["z"].lincomb_(1.0, v["x"], 1.0, v["u"])
+        if prox_lambda is not None and self.reg is not None:
+            self.reg.prox_(v["z"], float(prox_lambda))
+        out = (C.c_float * 6)()
+        check(h, lib.rls_admm_post(h, v["x"].code, v["x"].n, v["x"].ptr, v["xold"].ptr, v["z"].ptr, v["zold"].ptr,
+                                   v["u"].ptr, out), "rls_admm_post")
+        return [float(o) for o in out]
+
+    def tensor(self, name):
+        return self.t[name]
+
+    def solution(self) -> np.ndarray:
+        self.ctx.sync()
+        return self.t["x"].cpu().numpy()
+
+    def sync(self):
+        self.ctx.sync()
+
+    def close(self):
+        if self.cg:
+            self.ctx.lib.rls_cg_destroy(self.cg)
+            self.cg = None
+
+
+class RowShardedADMM:
+    """ADMM (src/ADMM.jl:191-330; one regulariser, identity regTrafo, vary_rho = :none) on a row-partitioned A.
+    The x-update's cg! runs a fixed `iterationsCG` half-step pairs (apply_u, all-reduce(c), cg_update); its own
+    convergence is a device flag, so the collective count is the same on every rank whatever the data."""
+
+    def __init__(self, ops, dist=None, lam: float = 0.0, rho: float = 0.1, iterations: int = 10, iterationsCG: int = 10,
+                 absTol: float = float(np.finfo(np.float32).eps), relTol: float = float(np.finfo(np.float32).eps),
+                 tolInner: float = 1e-5):
+        self.ops, self.dist = ops, dist
+        self.lam, self.rho = np.float32(lam), np.float32(rho)
+        self.iterations, self.iterationsCG = int(iterations), int(iterationsCG)
+        self.absTol, self.relTol, self.tolInner = np.float32(absTol), np.float32(relTol), np.float32(tolInner)
+        self.iteration = 0
+        self.cg_iterations: List[int] = []
+
+    def _allreduce(self, name):
+        if self.dist is not None and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(self.ops.tensor(name), op=self.dist.ReduceOp.SUM)
+
+    def init(self, b_local, M_total: int):
+        self.ops.init_a(b_local)
+        self._allreduce("beta_y")
+        self.ops.init_b()
+        f32 = np.float32
+        self.rk = self.sk = f32(np.inf)
+        self.eps_pri = self.eps_dua = f32(0)
+        self.sigma_abs = f32(np.sqrt(f32(M_total))) * self.absTol  # sqrt(length(b)) of the WHOLE b  (:214)
+        self.iteration = 0
+        self.cg_iterations = []
+
+    def converged(self):
+        return bool(self.rk < self.sigma_abs + self.relTol * self.eps_pri and
+                    self.sk < self.sigma_abs + self.relTol * self.eps_dua)
+
+    def done(self):
+        return self.converged() or self.iteration >= self.iterations
+
+    def iterate(self):
+        if self.done():
+            return None
+        ops, f32 = self.ops, np.float32
+        ops.pre(self.rho)                                    # :236-243
+        ops.apply_x()
+        self._allreduce("cg_c")
+        ops.cg_start(self.rho, self.iterationsCG, self.tolInner)
+        for _ in range(self.iterationsCG):                   # cg!  :244
+            ops.apply_u()
+            self._allreduce("cg_c")
+            ops.cg_update()
+        with np.errstate(divide="ignore"):
+            rec = ops.post(None if self.rho == 0 else f32(self.lam) / (f32(2) * self.rho))  # :246-299
+        self.cg_iterations.append(ops.cg_iterations())
+        self.sk = self.rho * f32(rec[1])
+        self.eps_pri = f32(rec[2])
+        self.rk = f32(rec[3])
+        self.eps_dua = self.rho * f32(rec[4])
+        self.iteration += 1
+        return self.iteration
+
+    def solve(self, b_local, M_total: int):
+        self.init(b_local, M_total)
+        while self.iterate() is not None:
+            pass
         return self.ops.solution()
 
 

@@ -679,6 +679,104 @@ def test_row_sharded_cgnr_single_rank_on_gpu(rls, ctx):
     ops.close()
 
 
+class _TwoShards:
+    """two row shards of one problem on ONE GPU behind the local-ops protocol, with a stand-in for torch.distributed
+    whose all_reduce sums the two shards' tensors: exercises the partial products of the `local_a` halves and the
+    replicated `local_b` halves exactly as two ranks would (same stream, so the order is the enqueue order)"""
+
+    class Dist:
+        class ReduceOp:
+            SUM = "sum"
+
+        @staticmethod
+        def get_world_size():
+            return 2
+
+        @staticmethod
+        def all_reduce(pair, op=None):
+            total = pair[0] + pair[1]
+            pair[0].copy_(total)
+            pair[1].copy_(total)
+
+    def __init__(self, a, b):
+        self.shards = (a, b)
+
+    def tensor(self, name):
+        return tuple(s.tensor(name) for s in self.shards)
+
+    def __getattr__(self, name):
+        def call(*args):
+            if name in ("init_a",):
+                outs = [s.init_a(part) for s, part in zip(self.shards, args[0])]
+            else:
+                outs = [getattr(s, name)(*args) for s in self.shards]
+            return outs[0]
+        return call
+
+
+@pytest.mark.parametrize("dt", [np.complex64, np.float32])
+def test_row_sharded_fista_two_shards_on_gpu(rls, ctx, dt):
+    """SURVEY 8e last row: FISTA on a row-partitioned A; x0 and res are all-reduced, everything else is replicated"""
+    import torch
+
+    M, N = 768, 256
+    A, xt, b = O.make_problem(M, N, dt, 23)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    rho = 0.9 / np.linalg.norm(A.astype(dt64), 2) ** 2
+    lam = 0.05 * np.max(np.abs(A.conj().T @ b))
+    dev = torch.cuda.current_device()
+    lo = 388  # unequal shards, 4-row aligned
+    mk = lambda rows: rls.multigpu.HipFistaOps(rls, np.asfortranarray(A[rows]), dev, reg=rls.L1Regularization(lam),
+                                               proj=rls.PositiveRegularization() if dt == np.float32 else None)
+    pair = _TwoShards(mk(slice(0, lo)), mk(slice(lo, M)))
+    f = rls.RowShardedFISTA(pair, _TwoShards.Dist, rho=rho, iterations=30, relTol=0.0, restart="gradient")
+    f.init((b[:lo], b[lo:]))
+    f.step(30)
+    xs = [s.solution() for s in pair.shards]
+    assert np.array_equal(xs[0], xs[1])  # replicated state: bit-identical on both shards
+    regs = [O.L1Regularization(lam)] + ([O.PositiveRegularization()] if dt == np.float32 else [])
+    ref = O.FISTA(A.astype(dt64), reg=regs, rho=rho, iterations=30, relTol=0.0, restart="gradient")
+    O.solve(ref, b.astype(dt64))
+    assert rel(xs[0], ref.x) < 5e-5
+    assert all(s.status()["iteration"] == 30 for s in pair.shards)
+    # world = 1 (no collective) through the same entry points
+    one = rls.multigpu.HipFistaOps(rls, A, dev, reg=rls.L1Regularization(lam),
+                                   proj=rls.PositiveRegularization() if dt == np.float32 else None)
+    x1 = rls.RowShardedFISTA(one, None, rho=rho, iterations=30, relTol=0.0, restart="gradient").solve(b)
+    assert rel(x1, ref.x) < 5e-5
+    for s in pair.shards + (one,):
+        s.close()
+
+
+@pytest.mark.parametrize("kind", ["l1", "tv"])
+def test_row_sharded_admm_two_shards_on_gpu(rls, ctx, kind):
+    """SURVEY 8e last row: ADMM on a row-partitioned A; only cg!'s operator applies are all-reduced"""
+    import torch
+
+    M, N = 640, 144
+    A, xt, b = O.make_problem(M, N, np.float32, 29)
+    dev = torch.cuda.current_device()
+    lo = 300
+    reg_d = rls.L1Regularization(0.05) if kind == "l1" else rls.TVRegularization(0.05, shape=(12, 12))
+    reg_o = O.L1Regularization(0.05) if kind == "l1" else O.TVRegularization(0.05, shape=(12, 12))
+    mk = lambda rows: rls.multigpu.HipAdmmOps(rls, np.asfortranarray(A[rows]), dev, reg=reg_d)
+    pair = _TwoShards(mk(slice(0, lo)), mk(slice(lo, M)))
+    kw = dict(rho=0.3, iterations=9, iterationsCG=6, tolInner=1e-4)
+    a = rls.RowShardedADMM(pair, _TwoShards.Dist, lam=0.05, **kw)
+    a.init((b[:lo], b[lo:]), M)
+    while a.iterate() is not None:
+        pass
+    xs = [s.solution() for s in pair.shards]
+    assert np.array_equal(xs[0], xs[1])
+    ref = O.ADMM(A, reg=reg_o, **kw)
+    O.solve(ref, b)
+    assert a.iteration == ref.iteration and a.cg_iterations == ref.cg_iters
+    assert rel(xs[0], ref.x) < 3e-5
+    assert np.allclose(a.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(a.sk, ref.sk, rtol=2e-3, atol=1e-6)
+    for s in pair.shards:
+        s.close()
+
+
 def test_multisolve_single_rank(rls, ctx):
     """BASELINE config 4 sharding at world = 1 (all columns local) equals column solves"""
     A, X, B = O.make_problem(128, 64, np.complex64, 17, n_rhs=5)
