@@ -337,6 +337,27 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer); /* asynchronous; stops enqu
 int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out_h, float* log_h, int32_t log_records);
 
 /* ---------------------------------------------------------------------------------------------
+ * device pieces of the nested regularisation terms and of the plug-and-play input transforms
+ *   rls_gather / rls_scatter   z = view(x, findall(mask)) and back          src/Regularization/MaskedRegularization.jl:27-31
+ *   rls_stats                  out_h[5] = min, max, sum, sum of squares of the REAL parts, max |x| (modulus)
+ *                              (minimum/maximum src/Transforms.jl:9, mean/std :39, maximum(abs.(x))
+ *                              src/Regularization/ScaledRegularization.jl:55); synchronises
+ *   rls_shift_scale            inverse = 0: x = (x - shift) / scale ; 1: x = x * scale + shift      src/Transforms.jl:11-16,41-46
+ *   rls_clamp                  x = clamp(x, lo, hi)                                                 src/Transforms.jl:59
+ *   rls_restore_outside        out[m] = orig[m] where orig < lo or orig >= hi                       src/Transforms.jl:53,62-66
+ *   rls_complex_split / merge  real.(x), imag.(x) and back       src/Regularization/PlugAndPlayRegularization.jl:24-31
+ * idx: device int32, 0-based.  Float32 vectors unless a dtype is given.
+ * ------------------------------------------------------------------------------------------- */
+int32_t rls_gather(rls_ctx* ctx, int32_t dtype, int64_t m, const int32_t* idx, const void* x, void* out);
+int32_t rls_scatter(rls_ctx* ctx, int32_t dtype, int64_t m, const int32_t* idx, const void* in, void* x);
+int32_t rls_stats(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, double* out_h);
+int32_t rls_shift_scale(rls_ctx* ctx, int64_t n, float* x, float shift, float scale, int32_t inverse);
+int32_t rls_clamp(rls_ctx* ctx, int64_t n, float* x, float lo, float hi);
+int32_t rls_restore_outside(rls_ctx* ctx, int64_t n, float* out, const float* orig, float lo, float hi);
+int32_t rls_complex_split(rls_ctx* ctx, int64_t n, const void* z, float* re, float* im);
+int32_t rls_complex_merge(rls_ctx* ctx, int64_t n, const float* re, const float* im, void* z);
+
+/* ---------------------------------------------------------------------------------------------
  * row-sharded operation (BASELINE config 5).  One process per GPU holds rows
  * [r*M/P, (r+1)*M/P) of A repacked contiguous; x, r, p, v and all scalars are replicated.
  * The plan is split at the one exchange step so the host can run the all-reduce (RCCL via

@@ -364,7 +364,10 @@ class RealRegularization:
 
 
 def _is_projection(r):
-    return isinstance(r, (PositiveRegularization, RealRegularization))
+    """sinktype(r) <: AbstractProjectionRegularization (findsinks, Regularization.jl:86)"""
+    while getattr(r, "reg", None) is not None:  # nested terms: look at the sink
+        r = r.reg
+    return isinstance(r, (PositiveRegularization, RealRegularization)) or type(r).__name__ == "ProjectionRegularization"
 
 
 # --------------------------------------------------------------------------------------
@@ -1295,3 +1298,261 @@ class LLRRegularization:
         if self.full:
             return prox_llr_overlapping(x, lam, self.shape, self.blockSize)
         return prox_llr(x, lam, self.shape, self.blockSize, self.shift)
+
+
+# --------------------------------------------------------------------------------------
+# nested regularisation terms, projections by function, plug-and-play prior and its input transforms
+#   src/Regularization/NestedRegularization.jl, ScaledRegularization.jl, MaskedRegularization.jl,
+#   TransformedRegularization.jl, PlugAndPlayRegularization.jl, src/proximalMaps/ProxProj.jl, src/Transforms.jl
+# (test infrastructure, like everything in this file)
+# --------------------------------------------------------------------------------------
+
+
+def innerreg(reg):
+    """Regularization.jl:5 / NestedRegularization.jl:9"""
+    return getattr(reg, "reg", None)
+
+
+def collect_regs(reg):
+    """iterate(reg) (Regularization.jl:6): the chain outermost -> innermost"""
+    out = []
+    while reg is not None:
+        out.append(reg)
+        reg = innerreg(reg)
+    return out
+
+
+def sink(reg):
+    """NestedRegularization.jl:15"""
+    return collect_regs(reg)[-1]
+
+
+def reg_lambda(reg):
+    """lambda(reg): Regularization.jl:29, NestedRegularization.jl:23, ScaledRegularization.jl:23"""
+    if isinstance(reg, _Scaled):
+        return reg_lambda(reg.reg) * reg.scalefactor()
+    if innerreg(reg) is not None:
+        return reg_lambda(reg.reg)
+    return getattr(reg, "lam", None)
+
+
+class _Nested:
+    """prox!/norm forward to the inner term (NestedRegularization.jl:27-28); without lambda the nested lambda is
+    used for parameterised sinks (:25-26)"""
+
+    def __init__(self, reg):
+        self.reg = reg
+
+    @property
+    def lam(self):
+        return reg_lambda(self)
+
+    def _args(self, lam):
+        if lam is None and not _is_projection(self):
+            lam = reg_lambda(self)
+        return () if lam is None else (lam,)
+
+    def prox(self, x, lam=None):
+        return self._prox(x, *self._args(lam))
+
+    def norm(self, x, lam=None):
+        return self._norm(x, *self._args(lam))
+
+    def _prox(self, x, *args):
+        return self.reg.prox(x, *args)
+
+    def _norm(self, x, *args):
+        return self.reg.norm(x, *args)
+
+
+class MaskedRegularization(_Nested):
+    """MaskedRegularization.jl:19-37: prox!/norm on view(x, findall(mask))"""
+
+    def __init__(self, reg, mask):
+        super().__init__(reg)
+        self.mask = np.asarray(mask, dtype=bool)
+
+    def _prox(self, x, *args):
+        z = x[self.mask]
+        self.reg.prox(z, *args)
+        x[self.mask] = z
+        return x
+
+    def _norm(self, x, *args):
+        return self.reg.norm(x[self.mask], *args)
+
+
+class TransformedRegularization(_Nested):
+    """TransformedRegularization.jl:19-37: z = trafo * x ; prox!(reg, z) ; x = adjoint(trafo) * z.
+    `trafo`: a matrix (ndarray) or an object with mul / mul_adj."""
+
+    def __init__(self, reg, trafo):
+        super().__init__(reg)
+        self.trafo = DenseOp(trafo) if isinstance(trafo, np.ndarray) else trafo
+
+    def _prox(self, x, *args):
+        z = self.trafo.mul(x)
+        self.reg.prox(z, *args)
+        x[:] = self.trafo.mul_adj(z)
+        return x
+
+    def _norm(self, x, *args):
+        return self.reg.norm(self.trafo.mul(x), *args)
+
+
+class _Scaled(_Nested):
+    def scalefactor(self):
+        raise NotImplementedError
+
+
+class FixedScaledRegularization(_Scaled):
+    """ScaledRegularization.jl:27-35"""
+
+    def __init__(self, reg, factor):
+        super().__init__(reg)
+        self.factor = factor
+
+    def scalefactor(self):
+        return self.factor
+
+
+class FixedParameterRegularization(_Scaled):
+    """ScaledRegularization.jl:43-52: discards the lambda passed in, uses the inner one"""
+
+    def scalefactor(self):
+        return 1.0
+
+    def _prox(self, x, *discard):
+        return self.reg.prox(x, reg_lambda(self.reg))
+
+    def _norm(self, x, *discard):
+        return self.reg.norm(x, reg_lambda(self.reg))
+
+
+class AutoScaledRegularization(_Scaled):
+    """ScaledRegularization.jl:55-77: the factor is maximum(abs.(x)) of the first vector it sees"""
+
+    def __init__(self, reg):
+        super().__init__(reg)
+        self.factor = None
+
+    def scalefactor(self):
+        return 1.0 if self.factor is None else self.factor
+
+    def _first(self, x, lam):
+        if self.factor is None:
+            self.factor = _rt(x)(np.max(np.abs(x)))
+            return lam * self.factor
+        return lam
+
+    def _prox(self, x, lam):
+        return self.reg.prox(x, self._first(x, lam))
+
+    def _norm(self, x, lam):
+        return self.reg.norm(x, self._first(x, lam))
+
+
+class ProjectionRegularization:
+    """src/proximalMaps/ProxProj.jl:3-20"""
+
+    def __init__(self, projFunc=lambda x: x):
+        self.projFunc = projFunc
+
+    def prox(self, x, lam=None):
+        x[:] = self.projFunc(x)
+        return x
+
+    def norm(self, x, lam=None):
+        y = x.copy()
+        self.prox(y)
+        return np.inf if np.any(y != x) else 0.0
+
+
+class MinMaxTransform:
+    """src/Transforms.jl:4-16"""
+
+    def __init__(self, x):
+        self.min, self.max = np.min(x), np.max(x)
+
+    def transform(self, x):
+        return (x - self.min) / (self.max - self.min)
+
+    def inverse_transform(self, x):
+        return x * (self.max - self.min) + self.min
+
+
+class IdentityTransform:
+    """src/Transforms.jl:20-31"""
+
+    def __init__(self, x=None):
+        pass
+
+    def transform(self, x):
+        return x
+
+    def inverse_transform(self, x):
+        return x
+
+
+class ZTransform:
+    """src/Transforms.jl:34-46 (std is Julia's corrected sample standard deviation)"""
+
+    def __init__(self, x):
+        self.mean, self.std = np.mean(x), np.std(x, ddof=1)
+
+    def transform(self, x):
+        return (x - self.mean) / self.std
+
+    def inverse_transform(self, x):
+        return x * self.std + self.mean
+
+
+class ClampedScalingTransform:
+    """src/Transforms.jl:49-68"""
+
+    def __init__(self, x, v_min, v_max):
+        self.v_min, self.v_max = v_min, v_max
+        self.mask = (x < v_min) | (x >= v_max)
+        self.x = x
+
+    def transform(self, x):
+        return (np.clip(x, self.v_min, self.v_max) - self.v_min) / (self.v_max - self.v_min)
+
+    def inverse_transform(self, x):
+        out = x * (self.v_max - self.v_min) + self.v_min
+        out[self.mask] = self.x[self.mask]
+        return out
+
+
+class PlugAndPlayRegularization:
+    """src/Regularization/PlugAndPlayRegularization.jl:14-54.  PlugAndPlayRegularization(model, shape; ...) is the
+    reduced constructor (:22) with lambda = 1."""
+
+    def __init__(self, lam=1.0, model=None, shape=None, input_transform=MinMaxTransform, ignoreIm=False, **_kw):
+        if callable(lam) and not isinstance(lam, (int, float)):
+            lam, model, shape = 1.0, lam, model
+        self.lam, self.model, self.shape = lam, model, list(shape)
+        self.input_transform, self.ignoreIm = input_transform, bool(ignoreIm)
+        self.warnings = []
+
+    def prox(self, x, lam=None):
+        lam = self.lam if lam is None else lam
+        if np.iscomplexobj(x):
+            re = self.prox(np.ascontiguousarray(x.real), lam)
+            im = np.ascontiguousarray(x.imag) if self.ignoreIm else self.prox(np.ascontiguousarray(x.imag), lam)
+            x[:] = re + 1j * im
+            return x
+        if lam != self.lam and (lam < 0.0 or lam > 1.0):
+            temp = min(max(lam, 0.0), 1.0)
+            self.warnings.append(f"{type(self).__name__} was given λ with value {lam}. Valid range is [0, 1]. λ changed to temp")
+            lam = temp
+        out = x.copy().reshape(self.shape, order="F")
+        tf = self.input_transform(out)
+        out = tf.transform(out)
+        out = out - _rt(x)(lam) * (out - self.model(out))
+        out = tf.inverse_transform(out)
+        x[:] = out.reshape(-1, order="F")
+        return x
+
+
+PnPRegularization = PlugAndPlayRegularization

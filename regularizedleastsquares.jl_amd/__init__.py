@@ -14,7 +14,12 @@ from .regularization import (AbstractParameterizedRegularization, AbstractProjec
                              AbstractRegularization, GradientOp, L1Regularization, L2Regularization,
                              L21Regularization, LLRRegularization, MeasurementBasedNormalization, NoNormalization, NuclearRegularization,
                              PositiveRegularization, RealRegularization, SystemMatrixBasedNormalization,
-                             TVRegularization, NormalizedRegularization, innerreg, lam, norm, normalize, prox_, scalefactor)
+                             TVRegularization, NormalizedRegularization, innerreg, lam, norm, normalize, prox_, scalefactor,
+                             AbstractNestedRegularization, AbstractScaledRegularization, AutoScaledRegularization,
+                             ClampedScalingTransform, FixedParameterRegularization, FixedScaledRegularization,
+                             IdentityTransform, MaskedRegularization, MinMaxTransform, PlugAndPlayRegularization,
+                             PnPRegularization, ProjectionRegularization, TransformedRegularization, ZTransform,
+                             findfirst, findsink, findsinks, is_projection, sink, sinktype)
 from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractKrylovSolver,
                       AbstractPrimalDualSolver, AbstractProximalGradientSolver, AbstractRowActionSolver,
                       applicableSolverList, isapplicable, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401

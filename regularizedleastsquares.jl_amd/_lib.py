@@ -143,6 +143,14 @@ PROTOTYPES = {
     "rls_cg_get_status": (_i32, [_vp, C.POINTER(CgStatus)]),
     "rls_admm_pre": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32]),
     "rls_admm_post": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _pf]),
+    "rls_gather": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    "rls_scatter": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    "rls_stats": (_i32, [_vp, _i32, _i64, _vp, C.POINTER(C.c_double)]),
+    "rls_shift_scale": (_i32, [_vp, _i64, _vp, _f, _f, _i32]),
+    "rls_clamp": (_i32, [_vp, _i64, _vp, _f, _f]),
+    "rls_restore_outside": (_i32, [_vp, _i64, _vp, _vp, _f, _f]),
+    "rls_complex_split": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "rls_complex_merge": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "rls_fista_init_local_a": (_i32, [_vp, _vp]),
     "rls_fista_init_local_b": (_i32, [_vp, _f, _f, _f, _i32, _i32]),
     "rls_fista_step_local_a": (_i32, [_vp]),

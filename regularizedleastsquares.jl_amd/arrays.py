@@ -223,6 +223,20 @@ class DeviceVector:
               "rls_lincomb")
         return self
 
+    def stats(self):
+        """(min, max, sum, sum of squares) of the real parts and max |x|, one device pass (rls_stats)"""
+        out = (C.c_double * 5)()
+        check(self.ctx.handle, self.ctx.lib.rls_stats(self.ctx.handle, self.code, self.n, self.ptr, out), "rls_stats")
+        return [float(v) for v in out]
+
+    def shift_scale_(self, shift, scale, inverse: bool = False):
+        """Float32 only: x = (x - shift) / scale, or with inverse: x = x * scale + shift (src/Transforms.jl)"""
+        if self.dtype != np.float32:
+            raise TypeError("shift_scale_ acts on Float32 vectors")
+        check(self.ctx.handle, self.ctx.lib.rls_shift_scale(self.ctx.handle, self.n, self.ptr, float(shift), float(scale),
+                                                            1 if inverse else 0), "rls_shift_scale")
+        return self
+
     def __len__(self):
         return self.n
 

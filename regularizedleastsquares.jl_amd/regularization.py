@@ -258,6 +258,328 @@ class GradientOp:
         return self.mul_(DeviceVector(self.n_out, x.dtype, x.ctx), x)
 
 
+# ---- nested regularisation terms (src/Regularization/NestedRegularization.jl, ScaledRegularization.jl,
+# MaskedRegularization.jl, TransformedRegularization.jl), ProjectionRegularization (src/proximalMaps/ProxProj.jl)
+
+
+def collect(reg):
+    """iterate(reg) (Regularization.jl:6): the chain of terms, outermost first"""
+    out = []
+    while reg is not None:
+        out.append(reg)
+        reg = reg.reg if isinstance(reg, AbstractNestedRegularization) else None
+    return out
+
+
+def sink(reg):
+    """the innermost term (NestedRegularization.jl:15; a plain term is its own sink, Regularization.jl:8)"""
+    return collect(reg)[-1]
+
+
+def sinktype(reg):
+    return type(sink(reg))
+
+
+def is_projection(reg) -> bool:
+    """sinktype(reg) <: AbstractProjectionRegularization -- how the solvers sort their `reg` argument
+    (findsinks, Regularization.jl:86; call sites src/FISTA.jl:80, src/ADMM.jl:102, src/Kaczmarz.jl:98)"""
+    return isinstance(sink(reg), AbstractProjectionRegularization)
+
+
+def findsinks(T, regs):
+    """indices of the terms whose sink is a T (Regularization.jl:86)"""
+    return [i for i, r in enumerate(regs) if isinstance(sink(r), T)]
+
+
+def findsink(T, regs):
+    """index of THE term whose sink is a T, None if there is none, an error if ambiguous (Regularization.jl:75-84)"""
+    idx = findsinks(T, regs)
+    if not idx:
+        return None
+    if len(idx) > 1:
+        raise ValueError(f"Cannot unambigiously retrieve reg term of type {T.__name__}, found {len(idx)} instances")
+    return idx[0]
+
+
+def findfirst(T, reg):
+    """first term of the chain that is a T (Regularization.jl:69-73)"""
+    for r in collect(reg):
+        if isinstance(r, T):
+            return r
+    return None
+
+
+class AbstractNestedRegularization(AbstractRegularization):
+    """prox!/norm/lambda forward to the inner term (NestedRegularization.jl:23-28)"""
+
+    def __init__(self, reg):
+        self.reg = reg
+
+    @property
+    def lam(self):
+        return lam(self.reg)
+
+    def prox_(self, x: DeviceVector, *args):
+        return self.reg.prox_(x, *args)
+
+    def norm(self, x: DeviceVector, *args):
+        return self.reg.norm(x, *args)
+
+
+class MaskedRegularization(AbstractNestedRegularization):
+    """MaskedRegularization.jl:19-37: prox!/norm only see the elements of x whose mask entry is true
+    (rls_gather -> inner prox -> rls_scatter; the index list lives on the device)"""
+
+    def __init__(self, reg, mask):
+        import numpy as _np
+        super().__init__(reg)
+        self.mask = _np.asarray(mask, dtype=bool)
+        self._idx_h = _np.flatnonzero(self.mask).astype(_np.int32)
+        self._idx = None
+
+    def _gather(self, x: DeviceVector):
+        import numpy as _np
+        if x.n != self.mask.size:
+            raise ValueError(f"MaskedRegularization: mask has {self.mask.size} entries, x has {x.n}")
+        if self._idx is None or self._idx.ctx is not x.ctx:
+            self._idx = DeviceVector.from_host(self._idx_h.view(_np.float32), x.ctx)  # int32 payload in a 4-byte vector
+        z = DeviceVector(self._idx_h.size, x.dtype, x.ctx)
+        check(x.ctx.handle, x.ctx.lib.rls_gather(x.ctx.handle, x.code, z.n, self._idx.ptr, x.ptr, z.ptr), "rls_gather")
+        return z
+
+    def prox_(self, x: DeviceVector, *args):
+        z = self._gather(x)
+        self.reg.prox_(z, *args)
+        check(x.ctx.handle, x.ctx.lib.rls_scatter(x.ctx.handle, x.code, z.n, self._idx.ptr, z.ptr, x.ptr), "rls_scatter")
+        return x
+
+    def norm(self, x: DeviceVector, *args):
+        return self.reg.norm(self._gather(x), *args)
+
+
+class TransformedRegularization(AbstractNestedRegularization):
+    """TransformedRegularization.jl:19-37: z = trafo * x ; prox!(reg, z) ; x = adjoint(trafo) * z.  `trafo` is a
+    DeviceMatrix, a GradientOp or any object with mul_(z, x) / mul_adj_(x, z) and size(1)."""
+
+    def __init__(self, reg, trafo):
+        super().__init__(reg)
+        self.trafo = trafo
+
+    def _forward(self, x: DeviceVector):
+        t = self.trafo
+        n_out = t.size(1) if hasattr(t, "size") else t.n_out
+        return t.mul_(DeviceVector(n_out, x.dtype, x.ctx), x)
+
+    def prox_(self, x: DeviceVector, *args):
+        z = self._forward(x)
+        self.reg.prox_(z, *args)
+        self.trafo.mul_adj_(x, z)
+        return x
+
+    def norm(self, x: DeviceVector, *args):
+        return self.reg.norm(self._forward(x), *args)
+
+
+class AbstractScaledRegularization(AbstractNestedRegularization):
+    """lambda(reg) = lambda(innerreg(reg)) .* scalefactor(reg)   (ScaledRegularization.jl:9-23)"""
+
+    def scalefactor(self):
+        raise NotImplementedError(f"Scaled regularization term {type(self).__name__} must implement scalefactor")
+
+    @property
+    def lam(self):
+        return lam(self.reg) * self.scalefactor()
+
+
+class FixedScaledRegularization(AbstractScaledRegularization):
+    """ScaledRegularization.jl:27-35"""
+
+    def __init__(self, reg, factor):
+        super().__init__(reg)
+        self.factor = float(factor)
+
+    def scalefactor(self):
+        return self.factor
+
+
+class _NormalizedNested(FixedScaledRegularization):
+    """NormalizedRegularization around a nested term (NormalizedRegularization.jl:29-38,75-79)"""
+
+
+class FixedParameterRegularization(AbstractScaledRegularization):
+    """ScaledRegularization.jl:43-52: discards any lambda passed to it and uses the inner term's"""
+
+    def scalefactor(self):
+        return 1.0
+
+    def prox_(self, x: DeviceVector, *_discard):
+        return self.reg.prox_(x, lam(self.reg))
+
+    def norm(self, x: DeviceVector, *_discard):
+        return self.reg.norm(x, lam(self.reg))
+
+
+class AutoScaledRegularization(AbstractScaledRegularization):
+    """ScaledRegularization.jl:55-77: the first prox!/norm fixes the factor to maximum(abs.(x)) (rls_stats)"""
+
+    def __init__(self, reg):
+        super().__init__(reg)
+        self.factor = None
+
+    def scalefactor(self):
+        return 1.0 if self.factor is None else self.factor
+
+    def _first(self, x: DeviceVector, lam_):
+        if self.factor is None:
+            import numpy as _np
+            self.factor = float(_np.float32(x.stats()[4]))
+            return lam_ * self.factor
+        return lam_
+
+    def prox_(self, x: DeviceVector, lam_):
+        return self.reg.prox_(x, self._first(x, lam_))
+
+    def norm(self, x: DeviceVector, lam_):
+        return self.reg.norm(x, self._first(x, lam_))
+
+
+class ProjectionRegularization(AbstractProjectionRegularization):
+    """src/proximalMaps/ProxProj.jl:3-20.  projFunc maps a DeviceVector to a DeviceVector (a new one or x itself)."""
+
+    def __init__(self, projFunc=None, **_kw):
+        self.projFunc = projFunc if projFunc is not None else (lambda x: x)
+
+    def prox_(self, x: DeviceVector, lam=None):
+        y = self.projFunc(x)
+        if y is not x:
+            x.copy_from(y)
+        return x
+
+    def norm(self, x: DeviceVector, lam=None) -> float:
+        y = x.copy()
+        self.prox_(y)
+        y.axpy_(-1.0, x)
+        return float("inf") if y.norm() != 0 else 0.0
+
+
+# ---- plug-and-play prior and its input transforms (src/Regularization/PlugAndPlayRegularization.jl, src/Transforms.jl)
+
+
+class MinMaxTransform:
+    """src/Transforms.jl:4-16 on a Float32 device vector, in place"""
+
+    def __init__(self, x: DeviceVector):
+        st = x.stats()
+        self.min, self.max = float(st[0]), float(st[1])
+
+    def transform(self, x: DeviceVector):
+        return x.shift_scale_(self.min, self.max - self.min, inverse=False)
+
+    def inverse_transform(self, x: DeviceVector):
+        return x.shift_scale_(self.min, self.max - self.min, inverse=True)
+
+
+class IdentityTransform:
+    """src/Transforms.jl:20-31"""
+
+    def __init__(self, x=None):
+        pass
+
+    def transform(self, x):
+        return x
+
+    def inverse_transform(self, x):
+        return x
+
+
+class ZTransform:
+    """src/Transforms.jl:34-46; std = the corrected sample standard deviation (Statistics.std)"""
+
+    def __init__(self, x: DeviceVector):
+        import math
+        st, n = x.stats(), x.n
+        self.mean = st[2] / n
+        self.std = math.sqrt(max(st[3] - n * self.mean * self.mean, 0.0) / (n - 1)) if n > 1 else float("nan")
+
+    def transform(self, x: DeviceVector):
+        return x.shift_scale_(self.mean, self.std, inverse=False)
+
+    def inverse_transform(self, x: DeviceVector):
+        return x.shift_scale_(self.mean, self.std, inverse=True)
+
+
+class ClampedScalingTransform:
+    """src/Transforms.jl:49-68"""
+
+    def __init__(self, x: DeviceVector, v_min, v_max):
+        self.v_min, self.v_max = float(v_min), float(v_max)
+        self.x = x.copy()
+
+    def transform(self, x: DeviceVector):
+        check(x.ctx.handle, x.ctx.lib.rls_clamp(x.ctx.handle, x.n, x.ptr, self.v_min, self.v_max), "rls_clamp")
+        return x.shift_scale_(self.v_min, self.v_max - self.v_min, inverse=False)
+
+    def inverse_transform(self, x: DeviceVector):
+        x.shift_scale_(self.v_min, self.v_max - self.v_min, inverse=True)
+        check(x.ctx.handle, x.ctx.lib.rls_restore_outside(x.ctx.handle, x.n, x.ptr, self.x.ptr, self.v_min, self.v_max),
+              "rls_restore_outside")
+        return x
+
+
+class PlugAndPlayRegularization(AbstractParameterizedRegularization):
+    """src/Regularization/PlugAndPlayRegularization.jl:14-54.  `model` maps a real Float32 DeviceVector (attribute
+    `.shape` = the image shape) to a DeviceVector of the same length -- the learned prior is the user's code; the
+    input transform, the blend x - lambda (x - model(x)) and the real/imaginary split run on the device.
+    PlugAndPlayRegularization(model, shape; ...) is the reduced constructor (:22) with lambda = 1."""
+
+    def __init__(self, lam=1.0, *args, model=None, shape=None, input_transform=MinMaxTransform, ignoreIm: bool = False,
+                 **_kw):
+        if callable(lam):  # (model, shape; kwargs...)
+            model, shape, lam = lam, (args[0] if args else shape), 1.0
+        if model is None or shape is None:
+            raise TypeError("PlugAndPlayRegularization needs model and shape")
+        self.lam = float(lam)
+        self.model = model
+        self.shape = [int(s) for s in shape]
+        self.input_transform = input_transform
+        self.ignoreIm = bool(ignoreIm)
+
+    def prox_(self, x: DeviceVector, lam_):
+        import numpy as _np
+        import warnings
+        lib, h = x.ctx.lib, x.ctx.handle
+        if x.dtype.kind == "c":  # :24-31
+            re, im = DeviceVector(x.n, _np.float32, x.ctx), DeviceVector(x.n, _np.float32, x.ctx)
+            check(h, lib.rls_complex_split(h, x.n, x.ptr, re.ptr, im.ptr), "rls_complex_split")
+            self.prox_(re, lam_)
+            if not self.ignoreIm:
+                self.prox_(im, lam_)
+            check(h, lib.rls_complex_merge(h, x.n, re.ptr, im.ptr, x.ptr), "rls_complex_merge")
+            return x
+        lam_ = float(lam_)
+        if lam_ != self.lam and (lam_ < 0.0 or lam_ > 1.0):  # :34-38
+            temp = min(max(lam_, 0.0), 1.0)
+            warnings.warn(f"{type(self).__name__} was given λ with value {lam_}. Valid range is [0, 1]. λ changed to temp")
+            lam_ = temp
+        out = x.copy()
+        out.shape = tuple(self.shape)
+        tf = self.input_transform(out)
+        out = tf.transform(out)
+        out.shape = tuple(self.shape)
+        m = self.model(out)
+        diff = out.copy().axpy_(-1.0, m)  # out - model(out)
+        out.axpy_(-lam_, diff)            # out - lambda * (out - model(out))   :43
+        out = tf.inverse_transform(out)
+        x.copy_from(out)
+        return x
+
+    def norm(self, x, lam_=None):
+        raise NotImplementedError("the plug-and-play prior is defined by its proximal map only (no norm), as in the reference")
+
+
+PnPRegularization = PlugAndPlayRegularization
+
+
 # ---- normalisation plumbing (src/Regularization/NormalizedRegularization.jl:40-84) ------------
 
 
@@ -282,6 +604,9 @@ def NormalizedRegularization(reg, factor):
     `reg` whose `lam` is the scaled value (the unscaled one is kept, so a later normalize() *updates* the
     factor as :73 does); type checks of the solvers keep seeing the inner regulariser."""
     import copy
+    if isinstance(reg, AbstractNestedRegularization):
+        inner = reg.reg if isinstance(reg, _NormalizedNested) else reg  # :73 -- update, do not stack
+        return _NormalizedNested(inner, factor)
     out = copy.copy(reg)
     base = getattr(reg, "_base_lam", reg.lam)
     out._base_lam = base
@@ -295,6 +620,8 @@ def NormalizedRegularization(reg, factor):
 
 
 def innerreg(reg):
+    if isinstance(reg, AbstractNestedRegularization):
+        return reg.reg
     if hasattr(reg, "_base_lam"):
         import copy
         out = copy.copy(reg)
@@ -305,6 +632,8 @@ def innerreg(reg):
 
 
 def scalefactor(reg):
+    if isinstance(reg, AbstractScaledRegularization):
+        return reg.scalefactor()
     return getattr(reg, "_factor", 1.0)
 
 
@@ -333,7 +662,7 @@ def normalize(norm_scheme, regs, A=None, b=None, in_solver: bool = False):
     single = not isinstance(regs, (list, tuple))
     out = []
     for r in ([regs] if single else regs):
-        if factor is None or isinstance(r, AbstractProjectionRegularization) or not hasattr(r, "lam"):
+        if factor is None or not isinstance(sink(r), AbstractParameterizedRegularization):  # :70-79
             out.append(r)
         else:
             out.append(NormalizedRegularization(r, factor))
@@ -355,12 +684,16 @@ def prox_(reg, x: DeviceVector, lam_: Optional[float] = None, **kw):
         if lam_ is None:
             raise TypeError("prox_(RegType, x, lam): lam is required")
         return reg(lam_, **kw).prox_(x, lam_)
-    if isinstance(reg, AbstractProjectionRegularization):
+    if is_projection(reg):
         return reg.prox_(x)
     return reg.prox_(x, reg.lam if lam_ is None else lam_)
 
 
 def norm(reg, x: DeviceVector, lam_: Optional[float] = None, **kw):
     if isinstance(reg, type):
+        if issubclass(reg, AbstractProjectionRegularization):
+            return reg(**kw).norm(x)
         return reg(lam_, **kw).norm(x, lam_)
+    if is_projection(reg):
+        return reg.norm(x)
     return reg.norm(x, reg.lam if lam_ is None else lam_)

@@ -23,7 +23,8 @@ from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21,
                    AdmmStatus, CgnrStatus, CgStatus,
                    FistaStatus, check)
 from .arrays import DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle
-from .regularization import (AbstractProjectionRegularization, GradientOp, L1Regularization, L2Regularization,
+from .regularization import (AbstractParameterizedRegularization, AbstractProjectionRegularization, GradientOp,
+                             L1Regularization, L2Regularization, findsink, findsinks, is_projection, sink,
                              L21Regularization, MeasurementBasedNormalization, NoNormalization, PositiveRegularization,
                              RealRegularization, SystemMatrixBasedNormalization, TVRegularization, normalize)
 
@@ -162,11 +163,10 @@ class CGNR(AbstractKrylovSolver):
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         regs = normalize(normalizeReg, _as_list(reg), self.A, None)
-        l2 = [r for r in regs if isinstance(r, L2Regularization)]
-        if len(l2) > 1:
-            raise ValueError(f"Cannot unambigiously retrieve reg term of type L2Regularization, found {len(l2)} instances")
+        i2 = findsink(L2Regularization, regs)  # src/CGNR.jl:69 (sink type: nested / scaled L2 terms count)
+        l2 = [] if i2 is None else [regs[i2]]
         self.L2 = l2[0] if l2 else L2Regularization(0.0)
-        self.constr = [r for r in regs if isinstance(r, (RealRegularization, PositiveRegularization))]
+        self.constr = [regs[i] for i in findsinks((RealRegularization, PositiveRegularization), regs)]  # :77-78
         rest = [r for r in regs if r not in l2 and r not in self.constr]
         if rest:
             raise ValueError(f"CGNR does not allow for more additional regularization terms, found {len(rest)}")
@@ -304,8 +304,8 @@ class FISTA(AbstractProximalGradientSolver):
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         regs = _as_list(reg) or [L1Regularization(0.0)]
-        self.proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
-        rest = [r for r in regs if not isinstance(r, AbstractProjectionRegularization)]
+        self.proj = [r for r in regs if is_projection(r)]
+        rest = [r for r in regs if not is_projection(r)]
         if len(rest) != 1:
             raise ValueError(f"FISTA does not allow for more additional regularization terms, found {len(rest)}")
         self.reg = normalize(normalizeReg, rest, self.A, None)[0]
@@ -328,19 +328,24 @@ class FISTA(AbstractProximalGradientSolver):
     def _fused_kinds(self):
         """(reg_kind, lambda, slices, proj_kind) when the update is fusable, else None"""
         r = self.reg
-        if isinstance(r, L1Regularization):
+        if type(r) is L1Regularization:
             kind, slices = REG_L1, 1
-        elif isinstance(r, L2Regularization):
+        elif type(r) is L2Regularization and getattr(r, "lam_vector", None) is None:
             kind, slices = REG_L2, 1
-        elif isinstance(r, L21Regularization):
+        elif type(r) is L21Regularization:
             kind, slices = REG_L21, r.slices
         else:
-            return None
+            return None  # nested / transformed / learned terms: the generic path calls their prox_
         if len(self.proj) > 1:
             return None
         pk = PROJ_NONE
         if self.proj:
-            pk = PROJ_POSITIVE if isinstance(self.proj[0], PositiveRegularization) else PROJ_REAL
+            if type(self.proj[0]) is PositiveRegularization:
+                pk = PROJ_POSITIVE
+            elif type(self.proj[0]) is RealRegularization:
+                pk = PROJ_REAL
+            else:
+                return None
         return kind, float(r.lam), slices, pk
 
     def _new_state(self):
@@ -526,8 +531,8 @@ class ADMM(AbstractPrimalDualSolver):
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         regs = _as_list(reg) or [L1Regularization(0.0)]
-        self.proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
-        self.reg = normalize(normalizeReg, [r for r in regs if not isinstance(r, AbstractProjectionRegularization)], self.A, None)
+        self.proj = [r for r in regs if is_projection(r)]
+        self.reg = normalize(normalizeReg, [r for r in regs if not is_projection(r)], self.A, None)
         n = self._op.N
         trafos = _as_list(regTrafo) or [_Identity(n) for _ in self.reg]
         if len(trafos) != len(self.reg):
@@ -631,9 +636,9 @@ class ADMM(AbstractPrimalDualSolver):
             return None
         P.proj_kind = PROJ_NONE
         if self.proj:
-            if isinstance(self.proj[0], PositiveRegularization):
+            if type(self.proj[0]) is PositiveRegularization:
                 P.proj_kind = PROJ_POSITIVE
-            elif isinstance(self.proj[0], RealRegularization):
+            elif type(self.proj[0]) is RealRegularization:
                 P.proj_kind = PROJ_REAL
             else:
                 return None
@@ -855,8 +860,8 @@ def _default_rho(op):
 
 def _split_regs(regs, name):
     regs = _as_list(regs) or [L1Regularization(0.0)]
-    proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
-    rest = [r for r in regs if not isinstance(r, AbstractProjectionRegularization)]
+    proj = [r for r in regs if is_projection(r)]
+    rest = [r for r in regs if not is_projection(r)]
     if len(rest) != 1:
         raise ValueError(f"{name} does not allow for more additional regularization terms, found {len(rest)}")
     return rest[0], proj
@@ -874,9 +879,9 @@ def _fusable_kinds(reg, proj):
         return None
     pk = PROJ_NONE
     if proj:
-        if isinstance(proj[0], PositiveRegularization):
+        if type(proj[0]) is PositiveRegularization:
             pk = PROJ_POSITIVE
-        elif isinstance(proj[0], RealRegularization):
+        elif type(proj[0]) is RealRegularization:
             pk = PROJ_REAL
         else:
             return None
@@ -1286,9 +1291,9 @@ class Kaczmarz(AbstractRowActionSolver):
         self.A_in = A
         self.normalizeReg = normalizeReg or NoNormalization()
         regs = normalize(normalizeReg, _as_list(reg) or [L2Regularization(0.0)], A, None)
-        l2 = [r for r in regs if isinstance(r, L2Regularization)]
-        self.L2 = l2[0] if l2 else L2Regularization(0.0)
-        proj = [r for r in regs if isinstance(r, AbstractProjectionRegularization)]
+        i2 = findsink(L2Regularization, regs)  # src/Kaczmarz.jl:86
+        self.L2 = regs[i2] if i2 is not None else L2Regularization(0.0)
+        proj = [r for r in regs if is_projection(r)]
         rest = [r for r in regs if r is not self.L2 and r not in proj]
         if len(rest) > 1:
             raise ValueError(f"Kaczmarz does not allow for more than one additional regularization term, found {len(rest)}")
@@ -1404,7 +1409,7 @@ class Kaczmarz(AbstractRowActionSolver):
         self._sweep(st, 1)
         for r in self.reg:
             for col in (st._views(st.x) if st.matrix else [st.x]):
-                r.prox_(col) if isinstance(r, AbstractProjectionRegularization) else r.prox_(col, r.lam)
+                r.prox_(col) if is_projection(r) else r.prox_(col, r.lam)
         st.iteration += 1
         return st.x, st
 
@@ -1629,9 +1634,9 @@ def isapplicable(solver, *args):
     if len(args) != 1:
         raise TypeError("isapplicable(solver, reg) | isapplicable(solver, A, x) | isapplicable(solver, A, x, reg)")
     regs = _as_list(args[0])
-    n_param = sum(1 for r in regs if not isinstance(r, AbstractProjectionRegularization) and hasattr(r, "lam"))
+    n_param = len(findsinks(AbstractParameterizedRegularization, regs))
     if issubclass(T, AbstractRowActionSolver):
-        return n_param <= 2 and sum(1 for r in regs if isinstance(r, L2Regularization)) == 1
+        return n_param <= 2 and len(findsinks(L2Regularization, regs)) == 1
     if issubclass(T, AbstractPrimalDualSolver):
         return True
     if issubclass(T, AbstractProximalGradientSolver):

@@ -1221,3 +1221,125 @@ def test_prox_llr_overlapping_randshift_and_denoising(rls, ctx):
     xd = rls.DeviceVector.from_host(noisy)
     rls.prox_(rls.LLRRegularization, xd, 10 * sigma, shape=(32, 32), blockSize=(4, 4), randshift=False)
     assert np.linalg.norm(xd.to_host() - base.reshape(-1, order="F")) < np.linalg.norm(noisy - base.reshape(-1, order="F"))
+
+
+# ---- nested regularisation terms, ProjectionRegularization, plug-and-play prior (device) -------------------------
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_nested_regularization_terms_on_device(rls, ctx, dt):
+    """Masked / Transformed / FixedScaled / FixedParameter / AutoScaled terms: the device composition (rls_gather,
+    rls_scatter, rls_stats + the inner prox kernels) against the oracle's restatement of the reference files"""
+    rng = np.random.default_rng(77)
+    n = 3000
+    x = rng.standard_normal(n).astype(np.float32)
+    if dt == np.complex64:
+        x = (x + 1j * rng.standard_normal(n)).astype(np.complex64)
+    x64 = x.astype(np.complex128 if dt == np.complex64 else np.float64)
+    dev = lambda a: rls.DeviceVector.from_host(a)
+    mask = rng.random(n) < 0.4
+    # docstring example of the reference (MaskedRegularization.jl:8-17)
+    m4 = rls.MaskedRegularization(rls.PositiveRegularization(), [True, False, True, False])
+    assert np.array_equal(rls.prox_(m4, dev(np.full(4, -1, np.float32))).to_host(), [0, -1, 0, -1])
+    for inner_d, inner_o in ((rls.L1Regularization(0.3), O.L1Regularization(0.3)), (rls.PositiveRegularization(), O.PositiveRegularization())):
+        got = rls.prox_(rls.MaskedRegularization(inner_d, mask), dev(x)).to_host()
+        ref = O.MaskedRegularization(inner_o, mask).prox(x64.copy())
+        assert rel(got, ref) < 2e-6
+        assert np.array_equal(got[~mask], x[~mask])  # untouched outside the mask, bit for bit
+    assert np.isclose(rls.norm(rls.MaskedRegularization(rls.L1Regularization(0.3), mask), dev(x)),
+                      O.MaskedRegularization(O.L1Regularization(0.3), mask).norm(x64), rtol=1e-5)
+    l1d, l1o = rls.L1Regularization(0.5), O.L1Regularization(0.5)
+    fs = rls.FixedScaledRegularization(l1d, 4.0)
+    assert rls.lam(fs) == 2.0 and rls.sink(fs) is l1d and rls.sinktype(fs) is rls.L1Regularization
+    assert rel(rls.prox_(fs, dev(x)).to_host(), O.prox_l1(x64.copy(), 2.0)) < 2e-6
+    assert rel(rls.prox_(fs, dev(x), 0.25).to_host(), O.prox_l1(x64.copy(), 0.25)) < 2e-6
+    fp = rls.FixedParameterRegularization(l1d)
+    assert rel(rls.prox_(fp, dev(x), 123.0).to_host(), O.prox_l1(x64.copy(), 0.5)) < 2e-6
+    au_d, au_o = rls.AutoScaledRegularization(l1d), O.AutoScaledRegularization(l1o)
+    for _ in range(2):  # first call fixes the factor (maximum(abs.(x))), the second uses lambda as given
+        assert rel(rls.prox_(au_d, dev(x), 0.05).to_host(), au_o.prox(x64.copy(), 0.05)) < 3e-6
+    assert np.isclose(au_d.factor, au_o.factor, rtol=1e-6) and np.isclose(rls.lam(au_d), O.reg_lambda(au_o), rtol=1e-6)
+    # TransformedRegularization with a dense unitary transform held as a DeviceMatrix
+    k = 96
+    Q = np.linalg.qr(rng.standard_normal((k, k)) + (1j * rng.standard_normal((k, k)) if dt == np.complex64 else 0))[0]
+    Qd = rls.DeviceMatrix.from_host(np.asfortranarray(Q.astype(dt)))
+    w = x[:k]
+    tr_d, tr_o = rls.TransformedRegularization(rls.L1Regularization(0.2), Qd), O.TransformedRegularization(O.L1Regularization(0.2), Q)
+    assert rel(rls.prox_(tr_d, dev(w)).to_host(), tr_o.prox(w.astype(x64.dtype))) < 2e-5
+    assert np.isclose(rls.norm(tr_d, dev(w)), tr_o.norm(w.astype(x64.dtype)), rtol=1e-5)
+    # ... and with the finite-difference operator: soft-thresholding of the gradient
+    tg = rls.TransformedRegularization(rls.L1Regularization(0.1), rls.GradientOp((12, 8)))
+    tg_o = O.TransformedRegularization(O.L1Regularization(0.1), O.GradientTrafo((12, 8)))
+    assert rel(rls.prox_(tg, dev(w)).to_host(), tg_o.prox(w.astype(x64.dtype))) < 2e-5
+    # nested chain: a normalised, masked L2 term is still found as THE L2 term of CGNR (findsink, src/CGNR.jl:69)
+    A, xt, b = O.make_problem(64, 32, dt, 3)
+    nested = rls.FixedScaledRegularization(rls.L2Regularization(0.05), 2.0)
+    S = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A), reg=[nested, rls.RealRegularization()], iterations=20)
+    ref = O.CGNR(A, reg=[O.L2Regularization(0.1), O.RealRegularization()], iterations=20)
+    assert rel(rls.solve_(S, dev(b)).to_host(), O.solve(ref, b)) < 5e-5
+
+
+def test_projection_regularization_reference_test(rls, ctx):
+    """testProj (test/testProxMaps.jl:153-164) with projFunc = x -> real(x) written for device vectors"""
+    rng = np.random.default_rng(1234)
+    x = (rng.standard_normal(1012) + 1j * rng.standard_normal(1012)).astype(np.complex64)
+    proj = lambda v: rls.prox_(rls.RealRegularization, v.copy())
+    xp = rls.prox_(rls.ProjectionRegularization, rls.DeviceVector.from_host(x), projFunc=proj).to_host()
+    assert np.linalg.norm(xp - x.real) / np.linalg.norm(x.real) < 1e-4
+    n_after = rls.norm(rls.ProjectionRegularization, rls.DeviceVector.from_host(xp), projFunc=proj)
+    n_before = rls.norm(rls.ProjectionRegularization, rls.DeviceVector.from_host(x), projFunc=proj)
+    assert n_after == 0.0 and n_before == float("inf")
+    assert 0.5 * np.linalg.norm(x - xp) ** 2 + n_after <= n_before
+    # as a solver constraint: sorted with the projections through its sink type
+    A, xt, b = O.make_problem(48, 24, np.complex64, 4)
+    S = rls.createLinearSolver(rls.FISTA, rls.DeviceMatrix.from_host(A), reg=[rls.L1Regularization(0.01), rls.ProjectionRegularization(proj)],
+                               rho=0.5 / np.linalg.norm(A, 2) ** 2, iterations=12)
+    ref = O.FISTA(A, reg=[O.L1Regularization(0.01), O.RealRegularization()], rho=0.5 / np.linalg.norm(A, 2) ** 2, iterations=12)
+    assert rel(rls.solve_(S, rls.DeviceVector.from_host(b)).to_host(), O.solve(ref, b)) < 5e-5
+
+
+def test_pnp_regularization_reference_tests_on_device(rls, ctx):
+    """test/testRegularization.jl:1-79 on device vectors (constructor, compatibility with Kaczmarz and ADMM, prox on
+    real / complex input, lambda clipping with the reference's warning) + the input transforms against the oracle"""
+    ident = lambda v: v
+    pnp = rls.PnPRegularization(ident, [2])
+    assert pnp.lam == 1.0 and pnp.model is ident and pnp.shape == [2]
+    assert pnp.input_transform is rls.MinMaxTransform and pnp.ignoreIm is False
+    pnp = rls.PnPRegularization(0.1, model=ident, shape=[2], input_transform=lambda v: v, ignoreIm=True, sMtHeLsE=1)
+    assert pnp.ignoreIm is True
+    rng = np.random.default_rng(5)
+    A = rng.random((3, 2)).astype(np.float32)
+    xs = rng.random(2).astype(np.float32)
+    for solver in (rls.Kaczmarz, rls.ADMM):  # "PnP Compatibility"
+        S = rls.createLinearSolver(solver, rls.DeviceMatrix.from_host(np.asfortranarray(A)), iterations=2, reg=[rls.PnPRegularization(ident, [2])])
+        assert np.all(np.isfinite(rls.solve_(S, rls.DeviceVector.from_host(A @ xs)).to_host()))
+    zero = lambda v: v.similar().fill_(0)
+    f32 = np.float32
+    pnp = rls.PnPRegularization(0.1, model=zero, shape=[2], input_transform=rls.IdentityTransform)
+    out = rls.prox_(pnp, rls.DeviceVector.from_host(np.array([1, 2], f32)), 0.1).to_host()
+    assert np.allclose(out, [0.9, 1.8], rtol=2e-7)
+    out = rls.prox_(pnp, rls.DeviceVector.from_host(np.array([1 + 1j, 2 + 2j], np.complex64)), 0.1).to_host()
+    assert np.allclose(out.real, [0.9, 1.8], rtol=2e-7) and np.allclose(out.imag, [0.9, 1.8], rtol=2e-7)
+    pnp_i = rls.PnPRegularization(0.1, model=zero, shape=[2], input_transform=rls.IdentityTransform, ignoreIm=True)
+    out = rls.prox_(pnp_i, rls.DeviceVector.from_host(np.array([1 + 1j, 2 + 2j], np.complex64)), 0.1).to_host()
+    assert np.allclose(out.real, [0.9, 1.8], rtol=2e-7) and np.array_equal(out.imag, [1.0, 2.0])
+    with pytest.warns(UserWarning, match=r"was given λ with value 1.5. Valid range is \[0, 1\]. λ changed to temp"):
+        out = rls.prox_(pnp, rls.DeviceVector.from_host(np.array([1, 2], f32)), 1.5).to_host()
+    assert np.array_equal(out, [0.0, 0.0])
+    with pytest.warns(UserWarning, match="-1.5"):
+        out = rls.prox_(pnp, rls.DeviceVector.from_host(np.array([1, 2], f32)), -1.5).to_host()
+    assert np.array_equal(out, [1.0, 2.0])
+    # a non-trivial model (3-point smoothing, done with device BLAS-1 on shifted views is overkill: scale by 1/2)
+    # and every input transform, against the oracle
+    x = rng.standard_normal(5000).astype(f32) * 3 + 1
+    half_d = lambda v: v.copy().rmul_(0.5)
+    half_o = lambda a: 0.5 * a
+    cases = [(rls.MinMaxTransform, O.MinMaxTransform), (rls.ZTransform, O.ZTransform), (rls.IdentityTransform, O.IdentityTransform),
+             (lambda v: rls.ClampedScalingTransform(v, -2.0, 4.0), lambda a: O.ClampedScalingTransform(a, -2.0, 4.0))]
+    for tf_d, tf_o in cases:
+        got = rls.prox_(rls.PnPRegularization(0.3, model=half_d, shape=[50, 100], input_transform=tf_d), rls.DeviceVector.from_host(x), 0.3).to_host()
+        ref = O.PnPRegularization(0.3, model=half_o, shape=[50, 100], input_transform=tf_o).prox(x.astype(np.float64), 0.3)
+        assert rel(got, ref) < 5e-6
+    st = rls.DeviceVector.from_host(x).stats()
+    assert st[0] == x.min() and st[1] == x.max() and np.isclose(st[2], x.astype(np.float64).sum(), rtol=1e-12)
+    assert np.isclose(st[3], (x.astype(np.float64) ** 2).sum(), rtol=1e-12) and st[4] == np.abs(x).max()

@@ -347,3 +347,62 @@ def test_golden_fista_admm_prox():
         assert np.array_equal(O.prox_l1(x.copy(), 0.35), g[f"l1_{tag}"])
         assert np.array_equal(O.prox_l21(x.copy(), 0.8, 8), g[f"l21_{tag}"])
         assert np.array_equal(O.prox_positive(x.copy()), g[f"pos_{tag}"])
+
+
+# ---- nested regularisation terms, ProjectionRegularization, plug-and-play prior ----------------------------------
+
+
+def test_pnp_reference_known_answers():
+    """test/testRegularization.jl:1-79 replayed on the restatement: constructor defaults, prox on real and complex
+    input (ignoreIm on / off), clipping of lambda to [0, 1] with the reference's warning text"""
+    model = lambda x: x
+    pnp = O.PnPRegularization(model, [2])
+    assert pnp.lam == 1.0 and pnp.model is model and pnp.shape == [2]
+    assert pnp.input_transform is O.MinMaxTransform and pnp.ignoreIm is False
+    pnp = O.PnPRegularization(0.1, model=model, shape=[2], input_transform=lambda x: x, ignoreIm=True, sMtHeLsE=1)
+    assert pnp.ignoreIm is True
+    zero = lambda x: np.zeros_like(x)
+    pnp = O.PnPRegularization(0.1, model=zero, shape=[2], input_transform=O.IdentityTransform)
+    assert np.array_equal(pnp.prox(np.array([1.0, 2.0]), 0.1), [0.9, 1.8])
+    out = pnp.prox(np.array([1.0 + 1.0j, 2.0 + 2.0j]), 0.1)
+    assert np.array_equal(out.real, [0.9, 1.8]) and np.array_equal(out.imag, [0.9, 1.8])
+    pnp_i = O.PnPRegularization(0.1, model=zero, shape=[2], input_transform=O.IdentityTransform, ignoreIm=True)
+    out = pnp_i.prox(np.array([1.0 + 1.0j, 2.0 + 2.0j]), 0.1)
+    assert np.array_equal(out.real, [0.9, 1.8]) and np.array_equal(out.imag, [1.0, 2.0])
+    assert np.array_equal(pnp.prox(np.array([1.0, 2.0]), 1.5), [0.0, 0.0])
+    assert "was given λ with value 1.5. Valid range is [0, 1]. λ changed to temp" in pnp.warnings[-1]
+    assert np.array_equal(pnp.prox(np.array([1.0, 2.0]), -1.5), [1.0, 2.0])
+    assert "-1.5" in pnp.warnings[-1]
+
+
+def test_nested_terms_reference_examples():
+    """docstring example of MaskedRegularization (MaskedRegularization.jl:8-17); testProj (test/testProxMaps.jl:153-164);
+    lambda algebra of the scaled terms (ScaledRegularization.jl:23,35,49,62-70); transforms are exact inverses"""
+    x = np.full(4, -1.0)
+    O.MaskedRegularization(O.PositiveRegularization(), [True, False, True, False]).prox(x)
+    assert np.array_equal(x, [0.0, -1.0, 0.0, -1.0])
+    rng = np.random.default_rng(1234)
+    z = rng.standard_normal(1012) + 1j * rng.standard_normal(1012)
+    pr = O.ProjectionRegularization(lambda v: v.real.astype(v.dtype))
+    zp = pr.prox(z.copy())
+    assert np.linalg.norm(zp - z.real) / np.linalg.norm(z.real) < 1e-4
+    assert 0.5 * np.linalg.norm(z - zp) ** 2 + pr.norm(zp) <= pr.norm(z) and pr.norm(z) == np.inf and pr.norm(zp) == 0.0
+    l1 = O.L1Regularization(0.5)
+    fs = O.FixedScaledRegularization(l1, 4.0)
+    assert O.reg_lambda(fs) == 2.0 and O.sink(fs) is l1
+    v = np.array([3.0, -1.0, 0.5])
+    assert np.array_equal(fs.prox(v.copy()), O.prox_l1(v.copy(), 2.0))           # no lambda given: the nested one
+    assert np.array_equal(fs.prox(v.copy(), 0.25), O.prox_l1(v.copy(), 0.25))     # a given lambda passes through
+    fp = O.FixedParameterRegularization(l1)
+    assert np.array_equal(fp.prox(v.copy(), 123.0), O.prox_l1(v.copy(), 0.5))     # discards what it is given
+    au = O.AutoScaledRegularization(l1)
+    assert np.allclose(au.prox(v.copy(), 0.1), O.prox_l1(v.copy(), 0.3), rtol=1e-14) and au.factor == 3.0
+    assert np.array_equal(au.prox(v.copy(), 0.1), O.prox_l1(v.copy(), 0.1)) and O.reg_lambda(au) == 1.5
+    Q, _ = np.linalg.qr(rng.standard_normal((12, 12)))
+    tr = O.TransformedRegularization(l1, Q)
+    w = rng.standard_normal(12)
+    assert np.allclose(tr.prox(w.copy(), 0.2), Q.T @ O.prox_l1(Q @ w, 0.2))
+    assert np.isclose(tr.norm(w, 0.2), 0.2 * np.abs(Q @ w).sum())
+    for tf in (O.MinMaxTransform(w), O.ZTransform(w), O.IdentityTransform(w), O.ClampedScalingTransform(w, -0.5, 0.7)):
+        assert np.allclose(tf.inverse_transform(tf.transform(w.copy())), w)
+    assert O._is_projection(O.MaskedRegularization(O.PositiveRegularization(), [True])) and not O._is_projection(fs)
