@@ -25,9 +25,25 @@ __device__ unsigned long long g_stamps[16 * 8];
     if (threadIdx.x == 0 && (blockIdx.x % 37) == 5 && blockIdx.x / 37 < 8)                  \
       g_stamps[(blockIdx.x / 37) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();         \
   } while (0)
+// row 7: the reduce kernel's workgroup 0 (slots 0..3) and, copied at the next K_A start, the one before (4..7)
+#define STAMP_R(slot)                                                                    \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[7 * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define STAMP_R_KEEP()                                                                    \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x == 5)                                                \
+      for (int q = 0; q < 4; ++q) g_stamps[7 * 16 + 4 + q] = g_stamps[7 * 16 + q];          \
+  } while (0)
 #else
 #define STAMP(slot) \
   do {              \
+  } while (0)
+#define STAMP_R(slot) \
+  do {                \
+  } while (0)
+#define STAMP_R_KEEP() \
+  do {                 \
   } while (0)
 #endif
 
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
   STAMP(0);
+  STAMP_R_KEEP();
   // First right-hand side: its small loads go out ahead of the slab.  A CU's vector-memory path
   // returns loads in issue order (measured with stamps), so every wave issues them, a workgroup
   // barrier makes sure no wave has slab loads queued in front of another wave's small loads, and only
@@ -437,12 +454,74 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
 
 // K_R: v = sum of the slab rows (fixed order) for 16 columns per workgroup, the partial dots
 // <p, v> and ||p||^2 for those columns, and the commit of the staged scalars.
+// sum of this thread's partial rows for column jc: rows wy, wy+ny, wy+2ny, ...  Four independent loads per trip
+// (none depends on anything but the kernel arguments, so they leave with the first instruction of the kernel);
+// the order of the additions is fixed: s0 takes trips' rows 0 and 2, s1 rows 1 and 3, result s0 + s1.
+template <typename E>
+__device__ static inline E slab_column_sum(const E* __restrict__ slab, int nwg, int64_t N, int64_t jc, int wy, int ny) {
+  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
+  for (int wgi = wy; wgi < nwg; wgi += 4 * ny) {
+    E a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = wgi + q * ny;
+      const int rc = row < nwg ? row : wgi;  // clamped address, masked below
+      a[q] = slab[(int64_t)rc * N + jc];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (wgi + q * ny >= nwg) a[q] = elem<E>::zero();
+    }
+    s0 = elem<E>::add(s0, a[0]);
+    s1 = elem<E>::add(s1, a[1]);
+    s0 = elem<E>::add(s0, a[2]);
+    s1 = elem<E>::add(s1, a[3]);
+  }
+  return elem<E>::add(s0, s1);
+}
+
+// combine the row groups of a workgroup: first the 4 row groups inside each wave (lanes l, l+16, l+32, l+48 hold
+// the same column), then one value per wave through LDS; valid in lanes 0..15 of wave 0.  Fixed order.
+template <typename E>
+__device__ static inline E slab_group_combine(E s, E (*sm)[16]) {
+  const int cx = threadIdx.x % 16, w = threadIdx.x / 64, nw = blockDim.x / 64;
+  float re = elem<E>::re(s), im = elem<E>::im(s);
+  re += __shfl_xor(re, 16, 64);
+  if constexpr (elem<E>::cplx) im += __shfl_xor(im, 16, 64);
+  re += __shfl_xor(re, 32, 64);
+  if constexpr (elem<E>::cplx) im += __shfl_xor(im, 32, 64);
+  if ((threadIdx.x & 63) < 16) sm[w][cx] = elem<E>::make(re, im);
+  __syncthreads();
+  E t = elem<E>::zero();
+  if (threadIdx.x < 16)
+    for (int i = 0; i < nw; ++i) t = elem<E>::add(t, sm[i][cx]);
+  return t;
+}
+
 template <typename E>
 __global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
                                                           E* __restrict__ v, const E* p0, const E* p1,
                                                           double* __restrict__ dots, cgnr_scalars* __restrict__ sc,
                                                           const cgnr_scalars* __restrict__ scn, pipe_rhs_ptrs R) {
   const int b = blockIdx.y;  // right-hand side
+  STAMP_R(0);
+  slab += (int64_t)b * R.slab_stride;
+  v += (int64_t)b * R.vstride;
+  p0 += (int64_t)b * R.vstride;
+  p1 += (int64_t)b * R.vstride;
+  dots += (int64_t)b * 4 * gridDim.x;
+  __shared__ E sm[16][16];
+  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;  // ny row groups
+  const int64_t j = (int64_t)blockIdx.x * 16 + cx;
+  const int64_t jc = j < N ? j : (N - 1);
+  // everything this kernel reads is requested up front: the partial rows, both candidates for p (which one is
+  // current is in the staged scalars) and the scalars themselves -- one memory round trip instead of three
+  const E sum = slab_column_sum<E>(slab, nwg, N, jc, wy, ny);
+  E pa = elem<E>::zero(), pb = elem<E>::zero();
+  if (wy == 0) {
+    pa = p0[jc];
+    pb = p1[jc];
+  }
   const cgnr_scalars Sn = scn[b];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     cgnr_scalars c = Sn;
@@ -450,31 +529,14 @@ __global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__
     sc[b] = c;
   }
   if (!Sn.fresh) return;
-  slab += (int64_t)b * R.slab_stride;
-  v += (int64_t)b * R.vstride;
-  p0 += (int64_t)b * R.vstride;
-  p1 += (int64_t)b * R.vstride;
-  dots += (int64_t)b * 4 * gridDim.x;
-  __shared__ E sm[64][16];
-  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;  // ny row groups
-  const int64_t j = (int64_t)blockIdx.x * 16 + cx;
-  const int64_t jc = j < N ? j : (N - 1);
-  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
-  int wgi = wy;
-  for (; wgi + ny < nwg; wgi += 2 * ny) {
-    s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
-    s1 = elem<E>::add(s1, slab[(int64_t)(wgi + ny) * N + jc]);
-  }
-  if (wgi < nwg) s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
-  sm[wy][cx] = elem<E>::add(s0, s1);
-  __syncthreads();
+  STAMP_R(1);
+  const E t = slab_group_combine<E>(sum, sm);
+  STAMP_R(2);
   if (wy == 0) {
-    E t = elem<E>::zero();
-    for (int i = 0; i < ny; ++i) t = elem<E>::add(t, sm[i][cx]);
     double dre = 0.0, dim_ = 0.0, pp = 0.0;
     if (j < N) {
       v[j] = t;
-      const E pj = (Sn.cur ? p1 : p0)[j];
+      const E pj = Sn.cur ? pb : pa;
       dre = (double)elem<E>::re(pj) * (double)elem<E>::re(t) + (double)elem<E>::im(pj) * (double)elem<E>::im(t);
       dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(t) - (double)elem<E>::im(pj) * (double)elem<E>::re(t);
       pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
@@ -491,6 +553,7 @@ __global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__
       dots[4 * blockIdx.x + 2] = pp;
     }
   }
+  STAMP_R(3);
 }
 
 // K_F: apply a pending update and bring r, p back into the caller's vectors (single workgroup)
@@ -730,6 +793,11 @@ template <typename E>
 __global__ __launch_bounds__(1024) void fista_pipe_r_kernel(const E* __restrict__ slab, int nwg, int64_t N,
                                                             E* __restrict__ res_raw, fista_scalars* __restrict__ sc,
                                                             const fista_scalars* __restrict__ scn) {
+  __shared__ E sm[16][16];
+  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;
+  const int64_t j = (int64_t)blockIdx.x * 16 + cx;
+  const int64_t jc = j < N ? j : (N - 1);
+  const E sum = slab_column_sum<E>(slab, nwg, N, jc, wy, ny);  // requested before the scalars are looked at
   fista_scalars Sn;
   RLS_FISTA_COPY(Sn, *scn);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -739,24 +807,8 @@ __global__ __launch_bounds__(1024) void fista_pipe_r_kernel(const E* __restrict_
     RLS_FISTA_COPY(*sc, c);
   }
   if (!Sn.fresh) return;
-  __shared__ E sm[64][16];
-  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;
-  const int64_t j = (int64_t)blockIdx.x * 16 + cx;
-  const int64_t jc = j < N ? j : (N - 1);
-  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
-  int wgi = wy;
-  for (; wgi + ny < nwg; wgi += 2 * ny) {
-    s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
-    s1 = elem<E>::add(s1, slab[(int64_t)(wgi + ny) * N + jc]);
-  }
-  if (wgi < nwg) s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
-  sm[wy][cx] = elem<E>::add(s0, s1);
-  __syncthreads();
-  if (wy == 0 && j < N) {
-    E t = elem<E>::zero();
-    for (int i = 0; i < ny; ++i) t = elem<E>::add(t, sm[i][cx]);
-    res_raw[j] = t;
-  }
+  const E t = slab_group_combine<E>(sum, sm);
+  if (wy == 0 && j < N) res_raw[j] = t;
 }
 
 // K_F of FISTA: apply a pending update (single workgroup)

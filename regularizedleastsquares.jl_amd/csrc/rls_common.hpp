@@ -193,13 +193,18 @@ __device__ static inline double block_sum(double v, double* smem) {
 // (s_load through the dispatch pointer); the packet lives in the queue ring in host-visible memory, so that
 // read costs microseconds and depends on the XCD -- harmless where it hides under other waits, 15 us per
 // launch where a barrier or an lgkmcnt(0) wait sits right behind it (measured on the Gram-mode FISTA kernel).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding vector-memory
+// load (s_waitcnt vmcnt(0)); in the one-pass kernels that is the whole register slab of A, i.e. the reductions of
+// the CG / FISTA update would sit out the slab's flight instead of running under it.
+__device__ static inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NW>
 __device__ static inline double block_sum_n(double v, double* smem) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   v = wave_sum(v);
-  __syncthreads();
+  lds_barrier();
   if (lane == 0) smem[w] = v;
-  __syncthreads();
+  lds_barrier();
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < NW; ++i) s += smem[i];
@@ -211,13 +216,13 @@ __device__ static inline void block_sum3_n(double& a, double& b, double& c, doub
   a = wave_sum(a);
   b = wave_sum(b);
   c = wave_sum(c);
-  __syncthreads();
+  lds_barrier();
   if (lane == 0) {
     smem[w] = a;
     smem[16 + w] = b;
     smem[32 + w] = c;
   }
-  __syncthreads();
+  lds_barrier();
   double sa = 0.0, sb = 0.0, sc = 0.0;
 #pragma unroll
   for (int i = 0; i < NW; ++i) {

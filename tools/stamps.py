@@ -21,6 +21,11 @@ buf = (C.c_ulonglong * 128)()
 lib.rls_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
 print("status", lib.rls_debug_stamps(buf))
 names = ["start", "loads issued", "scalars", "prologue start", "xs ready+barrier", "t_w done", "v partial in LDS", "end"]
+t00 = buf[0]
 for wg in range(7):
     t = [buf[wg * 16 + i] for i in range(8)]
-    print(f"wg {wg*37+5}: " + "  ".join(f"{names[i]} +{(t[i]-t[0])*10} ns" for i in range(1, 8)))
+    print(f"wg {wg*37+5}: start @{(t[0]-t00)*10:+d} ns  " + "  ".join(f"{names[i]} +{(t[i]-t[0])*10} ns" for i in range(1, 8)))
+r = [buf[7 * 16 + i] for i in range(8)]
+rn = ["start", "partials loaded", "LDS combine", "end"]
+print("K_R before this K_A (wg 0): " + "  ".join(f"{rn[i]} @{(r[4+i]-t00)*10:+d} ns" for i in range(4)))
+print("K_R after  this K_A (wg 0): " + "  ".join(f"{rn[i]} @{(r[i]-t00)*10:+d} ns" for i in range(4)))
