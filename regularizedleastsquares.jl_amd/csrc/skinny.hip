@@ -360,26 +360,41 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
     rr = block_sum(rr, sm);
     if (threadIdx.x == 0) cg_scalars_init(sc, rr, lambda_in, rel_tol, max_iter);
   } else if constexpr (EPT > 0) {
-    if (sc->done) return;  // this column has retired (src/MultiThreading.jl:60-78); its panel entry stays
-    const float lambda = sc->lambda;
-    const double zeta = sc->rr;
+    // Every load of this kernel is requested before anything is waited for: the state vectors, the partial rows of
+    // V in batches of four splits (independent loads; the additions keep the order s = 0, 1, 2, ...) and the
+    // scalars.  Written the obvious way -- scalars, then vectors, then one split after the other -- this was
+    // five dependent memory round trips (8.8 us per launch at K = 16).
+    const cgnr_scalars S0 = *sc;  // one scalar fetch, requested first, used after the vector loads are out
     E pv[EPT], xv[EPT], rv[EPT], vv[EPT];
+    int64_t ic[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
-      const int64_t ic = i < N ? i : N - 1;
-      pv[e] = p[ic];
-      xv[e] = x[ic];
-      rv[e] = r[ic];
-      vv[e] = Vpart[(int64_t)b * N + ic];
+      ic[e] = i < N ? i : N - 1;
+      pv[e] = p[ic[e]];
+      xv[e] = x[ic[e]];
+      rv[e] = r[ic[e]];
+      vv[e] = elem<E>::zero();
     }
-    for (int s = 1; s < S; ++s) {
+    for (int s0 = 0; s0 < S; s0 += 4) {
+      E part[4][EPT];
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
-        vv[e] = elem<E>::add(vv[e], Vpart[((int64_t)s * nrhs_pad + b) * N + (i < N ? i : N - 1)]);
+      for (int q = 0; q < 4; ++q) {
+        const int sq = s0 + q < S ? s0 + q : S - 1;  // clamped address, masked below
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) part[q][e] = Vpart[((int64_t)sq * nrhs_pad + b) * N + ic[e]];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (s0 + q < S) {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) vv[e] = s0 + q == 0 ? part[q][e] : elem<E>::add(vv[e], part[q][e]);
+        }
       }
     }
+    if (S0.done) return;  // this column has retired (src/MultiThreading.jl:60-78); its panel entry stays
+    const float lambda = S0.lambda;
+    const double zeta = S0.rr;
     double nre = 0.0, nim = 0.0, pp = 0.0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -423,7 +438,18 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
         pp_out[16 * i] = pn;
       }
     }
-    if (threadIdx.x == 0) cg_scalars_step(sc, zeta, rr, alpha, beta);
+    if (threadIdx.x == 0) {  // cg_scalars_step on the copy fetched at entry (no second fetch at the tail)
+      sc->zeta = zeta;
+      sc->rr = rr;
+      sc->alpha_re = alpha.re;
+      sc->alpha_im = alpha.im;
+      sc->beta_re = beta;
+      sc->beta_im = 0.0;
+      const int it = S0.iteration + 1;
+      sc->iteration = it;
+      const float ratio = (float)(sqrt(rr) / S0.z0);
+      sc->done = (ratio <= S0.rel_tol) || (it >= S0.max_iter);  // src/CGNR.jl:181-185
+    }
   } else {
     if (sc->done) return;
     const float lambda = sc->lambda;
