@@ -144,6 +144,26 @@ def other_paths(rls, ctx, Ad, A, b):
         rls.solve_(S, b); ctx.sync()
         t0 = time.perf_counter(); rls.solve_(S, b); ctx.sync(); dt = time.perf_counter() - t0
         out["kaczmarz_row_sweeps (one launch per solve)"] = {"us_per_row_step": dt / (4 * M) * 1e6}
+        # BASELINE configs[2]: ADMM + TV, 8192 x 4096 Float32, shape (64, 64), 10 outer x 10 inner cg! iterations --
+        # whole outer iterations enqueued as a device plan (rls_admm_step); wall clock of complete solves, min of 3
+        M3, N3 = 8192, 4096
+        A3 = make_A(M3, N3, 3, np.float32)
+        A3d = rls.DeviceMatrix.from_host(A3, ctx)
+        b3 = rls.DeviceVector.from_host((A3 @ np.ones(N3, np.float32)).astype(np.float32), ctx)
+        S = rls.createLinearSolver(rls.ADMM, A3d, reg=rls.TVRegularization(1e-2, shape=(64, 64)), rho=0.1, iterations=10,
+                                   iterationsCG=10, tolInner=1e-5)
+        rls.solve_(S, b3); rls.solve_(S, b3); ctx.sync()
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(5):
+                rls.solve_(S, b3)
+            ctx.sync(); dts.append((time.perf_counter() - t0) / 50)
+        ms = 1e3 * min(dts)
+        alg = 11 * 2 * M3 * N3 * 4  # 11 normal-operator applies per outer iteration, A read twice each on the reference path
+        out["admm_tv_config3 (BASELINE configs[2], device plan)"] = {
+            "ms_per_outer_iteration": ms, "inner_cg_iterations": S.state.cg_iterations,
+            "algorithmic_GBps": alg / (ms * 1e-3) / 1e9}
     except Exception as e:  # the extras must never take the headline line down
         out["error"] = repr(e)
     return out
