@@ -1343,3 +1343,57 @@ def test_pnp_regularization_reference_tests_on_device(rls, ctx):
     st = rls.DeviceVector.from_host(x).stats()
     assert st[0] == x.min() and st[1] == x.max() and np.isclose(st[2], x.astype(np.float64).sum(), rtol=1e-12)
     assert np.isclose(st[3], (x.astype(np.float64) ** 2).sum(), rtol=1e-12) and st[4] == np.abs(x).max()
+
+
+def test_library_is_reentrant_across_host_threads(rls, ctx):
+    """SURVEY 8b "Threading": solve! may be entered concurrently from several host threads (src/MultiThreading.jl:71,
+    docs multi_threading.jl:14-17), each with its own rls_ctx (own stream, own workspace).  Four threads run CGNR,
+    FISTA (+L1), ADMM (+TV: FGP single-workgroup kernel, device plan) and a batched solve side by side, repeatedly;
+    every result must equal, bit for bit, what the same solver produced alone."""
+    import threading
+
+    A, xt, b = O.make_problem(512, 256, np.complex64, 31)
+    Ar, xr, br = O.make_problem(384, 144, np.float32, 32)
+    _, X, B = O.make_problem(512, 256, np.complex64, 31, n_rhs=16)
+    rho = 0.9 / np.linalg.norm(A.astype(np.complex128), 2) ** 2
+
+    def job_cgnr(c):
+        S = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A, c), reg=rls.L2Regularization(1e-3), iterations=24)
+        return rls.solve_(S, rls.DeviceVector.from_host(b, c)).to_host()
+
+    def job_fista(c):
+        S = rls.createLinearSolver(rls.FISTA, rls.DeviceMatrix.from_host(A, c), reg=rls.L1Regularization(0.02), rho=rho, iterations=30)
+        return rls.solve_(S, rls.DeviceVector.from_host(b, c)).to_host()
+
+    def job_admm(c):
+        S = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(Ar, c), reg=rls.TVRegularization(0.02, shape=(12, 12)),
+                                   rho=0.2, iterations=8, iterationsCG=6)
+        return rls.solve_(S, rls.DeviceVector.from_host(br, c)).to_host()
+
+    def job_batched(c):
+        S = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A, c), iterations=16, relTol=0.0)
+        xs = rls.solve_(S, rls.DeviceMatrix.from_host(np.asfortranarray(B), c), scheduler=rls.BatchedState)
+        return np.stack([x.to_host() for x in xs], axis=1)
+
+    jobs = [job_cgnr, job_fista, job_admm, job_batched]
+    alone = [j(rls.Context(0)) for j in jobs]
+    results, errors = [None] * len(jobs), []
+
+    def worker(k):
+        try:
+            c = rls.Context(0)
+            outs = [jobs[k](c) for _ in range(6)]
+            results[k] = outs
+        except Exception as e:  # surfaced below; a thread must not die silently
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errors, errors
+    for k, outs in enumerate(results):
+        assert outs is not None, f"job {k} did not finish"
+        for o in outs:
+            assert np.array_equal(o, alone[k]), f"job {k} differs under concurrency"
