@@ -1,3 +1,4 @@
+"""host-side cost of the ctypes call sequence of one CGNR iteration (eager launches vs hipGraph replay)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+"""headline CGNR iteration time for the two slab_order modes (small loads waited for before the slab / barrier only)"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""the first LONG host wait of a process returns ~50 ms late, once: wall clock vs hipEvents per repetition (why bench.py warms up outside W)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+"""sweep of the single-workgroup FGP threshold (tv_fused_max_n) against the 2-launches-per-iteration graph path"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
