@@ -140,6 +140,14 @@ def other_paths(rls, ctx, Ad, A, b):
                                 rls._lib.check(h, lib.rls_cgnr_step(st._plan, 32), "step")), 32, reps=4)
             out[f"cgnr_batched_{K}_rhs (BASELINE configs[3] on one GPU, f32 MFMA)"] = {
                 "us_per_batched_iteration": us, "solve_iterations_per_s": K * 1e6 / us}
+        Xf = (rng.standard_normal((N, 16)) + 1j * rng.standard_normal((N, 16))).astype(np.complex64)
+        Bf = rls.DeviceMatrix.from_host(np.asfortranarray((A @ Xf).astype(np.complex64)), ctx)
+        S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
+        rls.solve_(S, Bf, scheduler=rls.BatchedState)
+        stf = S.state
+        us = timed(lambda: (rls._lib.check(h, lib.rls_fista_init_batched(stf._plan, Bf.ptr, Bf.lda, rho, 1.0, 0.0, 48, 0), "init"),
+                            rls._lib.check(h, lib.rls_fista_step(stf._plan, 48), "step")), 48, reps=4)
+        out["fista_l1_batched_16_rhs (solve!(FISTA, B), f32 MFMA)"] = {"us_per_batched_iteration": us, "solve_iterations_per_s": 16 * 1e6 / us}
         S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(1e-3), iterations=4)
         rls.solve_(S, b); ctx.sync()
         t0 = time.perf_counter(); rls.solve_(S, b); ctx.sync(); dt = time.perf_counter() - t0

@@ -263,6 +263,18 @@ typedef struct rls_fista_status {
 /* x, x0, xold, res: caller-owned length-N device vectors.  The plan swaps x/xold internally by
  * pointer as the reference does (:144-146); rls_fista_solution() returns the current x. */
 int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* res, rls_fista** out);
+/* solve!(solver::FISTA, B::AbstractMatrix) (src/MultiThreading.jl:30-79): nrhs columns advance together and share
+ * A -- T = A Y and V = A^H T as skinny GEMMs on the matrix cores, then one workgroup per column for
+ * src/FISTA.jl:153-180 with that column's own scalars (theta, rel_res_norm, done: a column that is done stops
+ * changing, the others go on).  x, x0, xold, res: N x nrhs, columns ldv elements apart; column j's current
+ * solution is in x when its iteration count is even, in xold when odd (the pointer swap of :144-146).
+ * RLS_E_UNSUPPORTED unless the operator is matrix-free with M, N multiples of 16.  rls_fista_set_reg,
+ * rls_fista_step and rls_fista_destroy apply unchanged. */
+int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* x0, void* xold, void* res, int64_t ldv,
+                                 rls_fista** out);
+int32_t rls_fista_init_batched(rls_fista* s, const void* B, int64_t ldb, float rho, float theta, float rel_tol,
+                               int32_t iterations, int32_t restart_gradient);
+int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out_h /* [nrhs] */);
 int32_t rls_fista_destroy(rls_fista* s);
 int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t l21_slices, int32_t proj_kind);
 int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, float rel_tol, int32_t iterations,

@@ -151,6 +151,9 @@ PROTOTYPES = {
     "rls_restore_outside": (_i32, [_vp, _i64, _vp, _vp, _f, _f]),
     "rls_complex_split": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "rls_complex_merge": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "rls_fista_create_batched": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _pvp]),
+    "rls_fista_init_batched": (_i32, [_vp, _vp, _i64, _f, _f, _f, _i32, _i32]),
+    "rls_fista_get_status_batched": (_i32, [_vp, C.POINTER(FistaStatus)]),
     "rls_fista_init_local_a": (_i32, [_vp, _vp]),
     "rls_fista_init_local_b": (_i32, [_vp, _f, _f, _f, _i32, _i32]),
     "rls_fista_step_local_a": (_i32, [_vp]),

@@ -434,6 +434,7 @@ void rls_skinny_sizes(int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_b
 int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb, float lambda,
                         float rel_tol, int max_iter);
 int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which);
+int32_t rls_skinny_atb(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb);
 void rls_skinny_tune(int which, int value);
 void rls_kaczmarz_tune(int v);
 bool rls_gram_tiles_ok(int64_t M, int64_t N);

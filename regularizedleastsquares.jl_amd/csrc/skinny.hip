@@ -609,6 +609,21 @@ int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const 
                           : skinny_init_typed<float2>(ctx, K, B, ldb, lambda, rel_tol, max_iter);
 }
 
+// partial rows of A^H B into K.Vpart (B: M x nrhs column-major): the init product of the batched plans
+int32_t rls_skinny_atb(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb) {
+  const dim3 grid((unsigned)((K.M + 63) / 64), (unsigned)K.ngroups);
+  if (dtype == RLS_F32) {
+    hipLaunchKernelGGL(skinny_pack_rows_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)B, ldb, K.nrhs,
+                       (float*)K.Tpack, K.M, K.ngroups);
+    launch_v<float>(ctx, K);
+  } else {
+    hipLaunchKernelGGL(skinny_pack_rows_kernel<float2>, grid, dim3(256), 0, ctx->stream, (const float2*)B, ldb, K.nrhs,
+                       (float2*)K.Tpack, K.M, K.ngroups);
+    launch_v<float2>(ctx, K);
+  }
+  return sk_status(ctx);
+}
+
 // which: bit 0 = T kernel, bit 1 = V kernel, bit 2 = update kernel
 int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which) {
   if (dtype == RLS_F32) {

@@ -336,25 +336,64 @@ struct rls_fista {
   float lambda;
   int64_t l21_slices;
   bool initialised;
+  // batched plan (rls_fista_create_batched): nrhs columns ldv elements apart, the K extrapolated points as an
+  // MFMA operand panel, T = A Y and the partial rows of A^H T (skinny.hip)
+  int nrhs = 1;
+  int64_t ldv = 0;
+  float *Ypack = nullptr, *Tpack = nullptr;
+  void* Vpart = nullptr;
+  int splits = 1;
+  fista_scalars* scb_h = nullptr;  // pinned [nrhs]
 };
+
+// batched launches: workgroup b = column b.  Vpart non-null: AHA y arrives as `S` partial rows per column and is
+// summed here (fixed order); Yp non-null: the extrapolated point also goes into the operand panel Yp[g][n][j].
+template <typename E>
+struct fista_batch {
+  int64_t ldv;
+  const E* Vpart;
+  int S, nrhs_pad;
+  E* Yp;
+};
+template <typename E>
+__device__ static inline E fista_parts(const fista_batch<E>& B, int b, int64_t N, int64_t i) {
+  E v = B.Vpart[(int64_t)b * N + i];
+  for (int s = 1; s < B.S; ++s) v = elem<E>::add(v, B.Vpart[((int64_t)s * B.nrhs_pad + b) * N + i]);
+  return v;
+}
 
 // x0 = A^H b is already in place.  x = x_init (zero), xold = 0, res = Inf, y = x   (src/FISTA.jl:110-129)
 template <typename E>
 __global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__ b0, E* __restrict__ b1,
-                                                                 const E* __restrict__ x0, E* __restrict__ res,
+                                                                 E* __restrict__ x0, E* __restrict__ res,
                                                                  E* __restrict__ y, int64_t n, fista_scalars* sc,
                                                                  float rho, float theta, float rel_tol, int max_iter,
                                                                  int restart, int reg_kind, int proj_kind,
-                                                                 float lambda, long long slices) {
+                                                                 float lambda, long long slices, fista_batch<E> Bt) {
   __shared__ double sm[16];
+  const int b = blockIdx.x;
+  b0 += b * Bt.ldv;
+  b1 += b * Bt.ldv;
+  x0 += b * Bt.ldv;
+  res += b * Bt.ldv;
+  y += b * Bt.ldv;
+  sc += b;
+  E* yp = Bt.Yp ? Bt.Yp + (int64_t)(b >> 4) * n * 16 + (b & 15) : nullptr;
   double nn = 0.0;
   const float inf = __builtin_huge_valf();
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
-    const E v = x0[i];
+    E v;
+    if (Bt.Vpart) {  // x0 = A^H b from the partial rows of the skinny product
+      v = fista_parts<E>(Bt, b, n, i);
+      x0[i] = v;
+    } else {
+      v = x0[i];
+    }
     nn += (double)elem<E>::re(v) * (double)elem<E>::re(v) + (double)elem<E>::im(v) * (double)elem<E>::im(v);
     b0[i] = elem<E>::zero();
     b1[i] = elem<E>::zero();
     y[i] = elem<E>::zero();
+    if (yp) yp[16 * i] = elem<E>::zero();
     res[i] = elem<E>::make(inf, 0.f);
   }
   nn = block_sum(nn, sm);
@@ -385,8 +424,17 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__
 template <typename E>
 __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict__ b0, E* __restrict__ b1,
                                                                    const E* __restrict__ x0, E* __restrict__ res,
-                                                                   E* __restrict__ y, int64_t n, fista_scalars* sc) {
-  if (sc->done) return;
+                                                                   E* __restrict__ y, int64_t n, fista_scalars* sc,
+                                                                   fista_batch<E> Bt) {
+  const int b = blockIdx.x;
+  b0 += b * Bt.ldv;
+  b1 += b * Bt.ldv;
+  x0 += b * Bt.ldv;
+  res += b * Bt.ldv;
+  y += b * Bt.ldv;
+  sc += b;
+  E* yp = Bt.Yp ? Bt.Yp + (int64_t)(b >> 4) * n * 16 + (b & 15) : nullptr;
+  if (sc->done) return;  // a retired column keeps its panel entry (src/MultiThreading.jl:60-78)
   __shared__ double sm[16];
   const int it = sc->iteration;
   E* xnew = (it & 1) ? b0 : b1;  // after the reference's pointer swap: state.x      :144-146
@@ -396,7 +444,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
   const float thr = rho * sc->lambda;  // prox!(reg, x, rho * lambda(reg))             :164
   double rn = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
-    const E ri = elem<E>::sub(res[i], x0[i]);                       // res .-= x0      :153
+    const E ri = elem<E>::sub(Bt.Vpart ? fista_parts<E>(Bt, b, n, i) : res[i], x0[i]);  // res .-= x0      :153
     res[i] = ri;
     rn += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
     E xi = elem<E>::sub(y[i], elem<E>::scale(rho, ri));             // x .-= rho .* res :154
@@ -437,8 +485,11 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
     // next iteration's Nesterov step, formed out of place in y                         :147-148
     const float c1 = (1.f - theta_old) / theta;
     const float c2 = (theta_old - 1.f) / theta + 1.f;
-    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS)
-      y[i] = elem<E>::add(elem<E>::scale(c1, xold[i]), elem<E>::scale(c2, xnew[i]));
+    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+      const E yi = elem<E>::add(elem<E>::scale(c1, xold[i]), elem<E>::scale(c2, xnew[i]));
+      y[i] = yi;
+      if (yp) yp[16 * i] = yi;
+    }
   }
   if (threadIdx.x == 0) {
     sc->res_norm = res_norm;
@@ -504,11 +555,12 @@ static int32_t fista_enqueue_iteration(rls_fista* s) {
   RLS_TRY(op_normal(op, s->y, s->res, &s->sc->done));
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(fista_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (float*)s->buf[0],
-                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc);
+                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc,
+                       fista_batch<float>{0, nullptr, 1, 0, nullptr});
   else
     hipLaunchKernelGGL(fista_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream,
                        (float2*)s->buf[0], (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y,
-                       op->N, s->sc);
+                       op->N, s->sc, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
   return launch_status(op->ctx);
 }
 
@@ -948,6 +1000,46 @@ __global__ void admm_reset_kernel(admm_scalars* sc, int max_iter, float rho, flo
   sc->rho = rho;
   sc->sigma_abs = sigma_abs;
   sc->rel_tol = rel_tol;
+}
+
+// ---- batched FISTA (shared A, matrix-core products) ----------------------------------------------
+static rls_skinny fista_skinny_desc(const rls_fista* s) {
+  rls_skinny K;
+  K.A = s->op->A;
+  K.lda = s->op->lda;
+  K.M = s->op->M;
+  K.N = s->op->N;
+  K.nrhs = s->nrhs;
+  K.ngroups = (s->nrhs + 15) / 16;
+  K.splits = s->splits;
+  K.X = K.R = K.P = K.V = nullptr;
+  K.ldv = s->ldv;
+  K.Ppack = s->Ypack;  // the T kernel's right operand: the extrapolated points
+  K.Tpack = s->Tpack;
+  K.Vpart = s->Vpart;
+  K.ldvp = s->op->N;
+  K.sc = nullptr;
+  return K;
+}
+
+template <typename E>
+static fista_batch<E> fista_batch_desc(const rls_fista* s) {
+  return fista_batch<E>{s->ldv, (const E*)s->Vpart, s->splits, ((s->nrhs + 15) / 16) * 16, (E*)s->Ypack};
+}
+
+static int32_t fista_enqueue_batched(rls_fista* s) {
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  RLS_TRY(rls_skinny_launch(ctx, op->dtype, fista_skinny_desc(s), 1 | 2));
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(fista_update_kernel<float>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
+                       (float*)s->buf[0], (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N,
+                       s->sc, fista_batch_desc<float>(s));
+  else
+    hipLaunchKernelGGL(fista_update_kernel<float2>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
+                       (float2*)s->buf[0], (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y,
+                       op->N, s->sc, fista_batch_desc<float2>(s));
+  return launch_status(ctx);
 }
 
 // type-erased admm_fuse (null beta_y = plain cg!)
@@ -1558,6 +1650,10 @@ int32_t rls_fista_destroy(rls_fista* s) {
   if (s->res_raw) hipFree(s->res_raw);
   if (s->res_raw1) hipFree(s->res_raw1);
   if (s->scn) hipFree(s->scn);
+  if (s->Ypack) hipFree(s->Ypack);
+  if (s->Tpack) hipFree(s->Tpack);
+  if (s->Vpart) hipFree(s->Vpart);
+  if (s->scb_h) hipHostFree(s->scb_h);
   hipFree(s->sc);
   hipHostFree(s->sc_h);
   delete s;
@@ -1601,14 +1697,14 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(fista_init_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
-                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc, rho, theta,
+                       (float*)s->buf[1], (float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc, rho, theta,
                        rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices);
+                       (long long)s->l21_slices, fista_batch<float>{0, nullptr, 1, 0, nullptr});
   else
     hipLaunchKernelGGL(fista_init_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)s->buf[0],
-                       (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc, rho,
+                       (float2*)s->buf[1], (float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc, rho,
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices);
+                       (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
   s->initialised = true;
   // row-sharded plans exchange `res` between the operator apply and the update: two-half iterations only
   const bool gram = !local && fista_gram_ok(s);
@@ -1650,11 +1746,113 @@ int32_t rls_fista_step_local_b(rls_fista* s) {
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(fista_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
-                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc);
+                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc,
+                       fista_batch<float>{0, nullptr, 1, 0, nullptr});
   else
     hipLaunchKernelGGL(fista_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)s->buf[0],
-                       (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc);
+                       (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc,
+                       fista_batch<float2>{0, nullptr, 1, 0, nullptr});
   return launch_status(ctx);
+}
+
+// K right-hand sides sharing A (solve!(solver, B) of src/MultiThreading.jl:30-79 for FISTA): per-column scalars,
+// per-column retirement, the two products as skinny GEMMs on the matrix cores.
+int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* x0, void* xold, void* res, int64_t ldv,
+                                 rls_fista** out) {
+  if (!op) return RLS_E_INVALID;
+  rls_ctx* ctx = op->ctx;
+  if (!x || !x0 || !xold || !res || !out || nrhs < 1 || ldv < op->N)
+    return rls_fail(ctx, RLS_E_INVALID, "fista_create_batched: bad argument");
+  if (op->G || !op->A || !ctx->tune.batched_mfma || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched FISTA needs a matrix-free operator with 16-aligned M, N (matrix-core path)");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_fista* s = new rls_fista();
+  s->op = op;
+  s->device = ctx->device;
+  s->buf[0] = x;
+  s->buf[1] = xold;
+  s->x0 = x0;
+  s->res = res;
+  s->y = s->y1 = s->res_raw = s->res_raw1 = nullptr;
+  s->scn = nullptr;
+  s->use_pipe = s->use_gram = false;
+  s->reg_kind = RLS_REG_L1;
+  s->proj_kind = RLS_PROJ_NONE;
+  s->lambda = 0.f;
+  s->l21_slices = 1;
+  s->initialised = false;
+  s->nrhs = nrhs;
+  s->ldv = ldv;
+  s->sc = s->sc_h = nullptr;
+  size_t pb, tb, vb;
+  rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+  const size_t yb = (size_t)ldv * nrhs * rls_elem_size(op->dtype);
+  hipError_t e = hipMalloc(&s->y, yb);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->Ypack, pb);
+  if (e == hipSuccess) e = hipMemset(s->Ypack, 0, pb);  // the padding columns of the last group stay zero
+  if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
+  if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->sc, sizeof(fista_scalars) * nrhs);
+  if (e == hipSuccess) e = hipMemset(s->sc, 0, sizeof(fista_scalars) * nrhs);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&s->scb_h, sizeof(fista_scalars) * nrhs, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&s->sc_h, sizeof(fista_scalars), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (s->y) hipFree(s->y);
+    if (s->Ypack) hipFree(s->Ypack);
+    if (s->Tpack) hipFree(s->Tpack);
+    if (s->Vpart) hipFree(s->Vpart);
+    if (s->sc) hipFree(s->sc);
+    if (s->scb_h) hipHostFree(s->scb_h);
+    if (s->sc_h) hipHostFree(s->sc_h);
+    delete s;
+    return rls_fail(ctx, (int32_t)e, "fista_create_batched: allocation failed");
+  }
+  *out = s;
+  return 0;
+}
+
+int32_t rls_fista_init_batched(rls_fista* s, const void* B, int64_t ldb, float rho, float theta, float rel_tol,
+                               int32_t iterations, int32_t restart_gradient) {
+  if (!s) return RLS_E_INVALID;
+  rls_operator* op = s->op;
+  rls_ctx* ctx = op->ctx;
+  if (s->nrhs < 2 && !s->Ypack) return rls_fail(ctx, RLS_E_STATE, "fista_init_batched on a single-column plan");
+  if (!B || ldb < op->M) return rls_fail(ctx, RLS_E_INVALID, "fista_init_batched: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_TRY(rls_skinny_atb(ctx, op->dtype, fista_skinny_desc(s), B, ldb));  // partial rows of A^H B   (src/FISTA.jl:114)
+  if (op->dtype == RLS_F32)
+    hipLaunchKernelGGL(fista_init_kernel<float>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
+                       (float*)s->buf[0], (float*)s->buf[1], (float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc,
+                       rho, theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
+                       (long long)s->l21_slices, fista_batch_desc<float>(s));
+  else
+    hipLaunchKernelGGL(fista_init_kernel<float2>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
+                       (float2*)s->buf[0], (float2*)s->buf[1], (float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N,
+                       s->sc, rho, theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
+                       (long long)s->l21_slices, fista_batch_desc<float2>(s));
+  s->initialised = true;
+  s->use_pipe = s->use_gram = false;
+  return launch_status(ctx);
+}
+
+int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised || !s->scb_h) return rls_fail(ctx, RLS_E_STATE, "fista_get_status_batched: not a batched, initialised plan");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, hipMemcpyAsync(s->scb_h, s->sc, sizeof(fista_scalars) * s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < s->nrhs; ++b) {
+    const fista_scalars& h = s->scb_h[b];
+    out[b].iteration = h.iteration;
+    out[b].done = h.done;
+    out[b].theta = h.theta;
+    out[b].theta_old = h.theta_old;
+    out[b].rel_res_norm = (float)h.rel_res_norm;
+    out[b].residual = (float)h.res_norm;
+    out[b].norm_x0 = (float)h.norm_x0;
+  }
+  return 0;
 }
 
 int32_t rls_fista_set_start(rls_fista* s, const void* x_init) {
@@ -1676,6 +1874,9 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_step before fista_init");
   if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "fista_step: n_steps < 0");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->nrhs > 1) {  // K columns share A: T = A Y, V = A^H T on the matrix cores, then one workgroup per column
+    return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_batched(s); });
+  }
   if (s->use_gram) {
     // explicit AHA: one launch per iteration (two-parity state, see cgnr_gram_kernel); the finish kernel
     // applies the last update and leaves the scalars in both parities, so every call starts at parity 0

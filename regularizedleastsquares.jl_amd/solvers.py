@@ -1477,6 +1477,10 @@ class BatchedState(AbstractMatrixSolverState):
         self._keep = (op, ctx)
         self.iteration = 0
 
+    def _step(self, n):
+        ctx = self.X.ctx
+        check(ctx.handle, ctx.lib.rls_cgnr_step(self._plan, int(n)), "rls_cgnr_step")
+
     def status(self):
         st = (CgnrStatus * self.K)()
         ctx = self.X.ctx
@@ -1498,6 +1502,52 @@ class BatchedState(AbstractMatrixSolverState):
         self._plan = None
 
 
+class FistaBatchedState(BatchedState):
+    """BatchedState for FISTA: the K extrapolated points share one pass over A per product (rls_fista_*_batched);
+    prox, momentum and `done` are per column, exactly as K independent solves."""
+
+    def __init__(self, solver, B: DeviceMatrix):
+        self.states = []
+        self.active = [True] * B.N
+        self.solver = solver
+        self.K = B.N
+        op, ctx, N = solver._op, B.ctx, solver._op.N
+        self.X, self.Xold, self.X0, self.RES = (DeviceMatrix(N, B.N, B.dtype, ctx) for _ in range(4))
+        lib, h = ctx.lib, ctx.handle
+        plan = C.c_void_p()
+        check(h, lib.rls_fista_create_batched(op.handle, B.N, self.X.ptr, self.X0.ptr, self.Xold.ptr, self.RES.ptr, N,
+                                              C.byref(plan)), "rls_fista_create_batched")
+        self._plan = plan
+        self._keep = (op, ctx)
+        self.iteration = 0
+        self._destroy = lib.rls_fista_destroy
+
+    def _step(self, n):
+        ctx = self.X.ctx
+        check(ctx.handle, ctx.lib.rls_fista_step(self._plan, int(n)), "rls_fista_step")
+
+    def status(self):
+        st = (FistaStatus * self.K)()
+        ctx = self.X.ctx
+        check(ctx.handle, ctx.lib.rls_fista_get_status_batched(self._plan, st), "rls_fista_get_status_batched")
+        return list(st)
+
+    def convergence(self):
+        return [{"residual": s.residual} for s in self.status()]
+
+    def solutions(self) -> List[DeviceVector]:
+        # state.x of column j is X when its iteration count is even, Xold when odd (src/FISTA.jl:144-146)
+        return [(self.Xold if s.iteration & 1 else self.X).column(j) for j, s in enumerate(self.status())]
+
+    def __del__(self):
+        try:
+            if self._plan and self.X.ctx.handle:
+                self.X.ctx.lib.rls_fista_destroy(self._plan)
+        except Exception:
+            pass
+        self._plan = None
+
+
 def _columns(b) -> List[DeviceVector]:
     if isinstance(b, DeviceMatrix):
         return [b.column(j) for j in range(b.N)]
@@ -1512,7 +1562,9 @@ def _columns(b) -> List[DeviceVector]:
 def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
     """init!(solver, b; kwargs...)   src/RegularizedLeastSquares.jl:190, src/MultiThreading.jl:30-43"""
     if isinstance(b, DeviceVector):
-        if isinstance(solver.state, BatchedState):
+        if isinstance(solver.state, FistaBatchedState):
+            solver.state = FISTAState(solver.state.rho, 1, solver.state.relTol)
+        elif isinstance(solver.state, BatchedState):
             solver.state = CGNRState(solver.state.relTol)
         elif isinstance(solver.state, AbstractMatrixSolverState):
             solver.state = solver.state.states[0]  # :39-43
@@ -1537,8 +1589,27 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
                 return
             except _lib.RLSError:
                 pass  # shape not covered by the one-pass kernel: independent per-column plans instead
+        if (type(solver) is FISTA and isinstance(b, DeviceMatrix) and b.N > 1 and solver.A is not None
+                and solver._fused_kinds() is not None and not isinstance(solver.normalizeReg, MeasurementBasedNormalization)
+                and "x0" not in kw):
+            try:
+                st = FistaBatchedState(solver, b)
+                lib, h = b.ctx.lib, b.ctx.handle
+                ref = solver.state.states[0] if isinstance(solver.state, AbstractMatrixSolverState) and solver.state.states else solver.state
+                st.rho, st.relTol = ref.rho, ref.relTol
+                kind, lam_, slices, pk = solver._fused_kinds()
+                check(h, lib.rls_fista_set_reg(st._plan, kind, lam_, slices, pk), "rls_fista_set_reg")
+                check(h, lib.rls_fista_init_batched(st._plan, b.ptr, b.lda, float(st.rho), float(kw.get("theta", 1)),
+                                                    float(st.relTol), solver.iterations,
+                                                    1 if solver.restart == "gradient" else 0), "rls_fista_init_batched")
+                solver.state = st
+                return
+            except _lib.RLSError:
+                pass  # e.g. M or N not a multiple of 16: independent per-column plans instead
         scheduler = MultiThreadingState
-    if isinstance(solver.state, BatchedState):
+    if isinstance(solver.state, FistaBatchedState):
+        solver.state = FISTAState(solver.state.rho, 1, solver.state.relTol)
+    elif isinstance(solver.state, BatchedState):
         solver.state = CGNRState(solver.state.relTol)
     cols = _columns(b)
     states = [solver._new_state() for _ in cols]  # deep copies of the state  :45-48
@@ -1557,8 +1628,8 @@ def iterate(solver: AbstractLinearSolver):
         if not any(st.active):
             return None
         if st.iteration > solver.iterations + 1:
-            raise _lib.RLSError("batched CGNR: a column did not reach done() within `iterations` steps")
-        check(st.X.ctx.handle, st.X.ctx.lib.rls_cgnr_step(st._plan, 1), "rls_cgnr_step")
+            raise _lib.RLSError("batched solve: a column did not reach done() within `iterations` steps")
+        st._step(1)
         st.iteration += 1
         return st.active, st
     if isinstance(st, AbstractMatrixSolverState):
@@ -1586,7 +1657,7 @@ def solve_(solver: AbstractLinearSolver, b, callbacks=None, **kw):
         cb(solver, 0)
     if not cbs and isinstance(solver.state, BatchedState):
         st = solver.state
-        check(st.X.ctx.handle, st.X.ctx.lib.rls_cgnr_step(st._plan, min(solver.iterations, solver._op.N)), "rls_cgnr_step")
+        st._step(solver.iterations if isinstance(st, FistaBatchedState) else min(solver.iterations, solver._op.N))
         while iterate(solver) is not None:  # normally returns None at once
             pass
         return solversolution(solver)

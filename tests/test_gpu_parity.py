@@ -1397,3 +1397,51 @@ def test_library_is_reentrant_across_host_threads(rls, ctx):
         assert outs is not None, f"job {k} did not finish"
         for o in outs:
             assert np.array_equal(o, alone[k]), f"job {k} differs under concurrency"
+
+
+@pytest.mark.parametrize("dt,M,N,K,kind", [(np.complex64, 256, 128, 5, "l1"), (np.float32, 320, 96, 20, "l1pos"),
+                                           (np.complex64, 4096, 2048, 16, "l1"), (np.float32, 128, 64, 3, "l21")])
+def test_fista_batched_matrix_solve_equals_column_solves(rls, ctx, dt, M, N, K, kind):
+    """solve!(solver::FISTA, B) with K columns sharing A on the matrix cores (rls_fista_*_batched) against K
+    independent oracle solves and against the MultiThreadingState scheduler; per-column scalars and retirement
+    (columns stop at different iterations under a loose relTol), gradient restart, padding columns (K % 16 != 0)"""
+    A, X, B = O.make_problem(M, N, dt, 41, n_rhs=K)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    A64 = A.astype(dt64)
+    rho = 0.9 / np.linalg.norm(A64, 2) ** 2 if M < 1000 else 0.9 / (np.sqrt(M) + np.sqrt(N)) ** 2
+    B = (B * (4.0 ** (np.arange(K) % 6))[None, :]).astype(dt)  # different scales against a fixed lambda: different stopping iterations
+    lam = 0.02 * np.max(np.abs(A64.conj().T @ B[:, 0].astype(dt64)))
+    its, relTol, restart = 25, (0.02 if M < 1000 else 0.0), "gradient" if kind == "l1pos" else "none"
+
+    def regs(R):
+        if kind == "l1":
+            return R.L1Regularization(lam)
+        if kind == "l1pos":
+            return [R.L1Regularization(lam), R.PositiveRegularization()]
+        return R.L21Regularization(lam, slices=4)
+
+    Ad, Bd = rls.DeviceMatrix.from_host(A), rls.DeviceMatrix.from_host(np.asfortranarray(B))
+    S = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=its, relTol=relTol, restart=restart)
+    xs = rls.solve_(S, Bd, scheduler=rls.BatchedState)
+    assert type(S.state).__name__ == "FistaBatchedState"
+    stat = S.state.status()
+    its_seen = []
+    for j in range(K if M < 1000 else 3):
+        ref = O.FISTA(A64, reg=regs(O), rho=rho, iterations=its, relTol=relTol, restart=restart)
+        O.solve(ref, B[:, j].astype(dt64))
+        assert stat[j].iteration == ref.iteration, (j, stat[j].iteration, ref.iteration)
+        assert rel(xs[j].to_host(), ref.x) < 5e-5, j
+        its_seen.append(ref.iteration)
+    if kind == "l1" and M < 1000:
+        assert len(set(its_seen)) > 1  # the columns really did retire at different iterations
+    # the reference's own scheduler gives the same columns
+    S2 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=its, relTol=relTol, restart=restart)
+    ys = rls.solve_(S2, Bd, scheduler=rls.MultiThreadingState)
+    for j in range(K):
+        assert rel(xs[j].to_host(), ys[j].to_host()) < 2e-5, j
+    # iterating with callbacks reaches the same result; a vector solve still works afterwards
+    seen = []
+    zs = rls.solve_(S, Bd, scheduler=rls.BatchedState, callbacks=lambda s_, it: seen.append(it))
+    assert seen[0] == 0 and all(np.array_equal(z.to_host(), x.to_host()) for z, x in zip(zs, xs))
+    x1 = rls.solve_(S, rls.DeviceVector.from_host(B[:, 1].copy())).to_host()
+    assert rel(x1, xs[1].to_host()) < 2e-5
