@@ -57,7 +57,7 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
           big->exec = nullptr;
         }
         hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
         int32_t st = 0;
         if (e == hipSuccess) {
           for (int i = 0; i < chunk && st == 0; ++i) st = enqueue_one();
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const E* __restrict__ A, int6
 template <typename S>
 static int32_t alloc_scalars(rls_ctx* ctx, S** d, S** h) {
   RLS_HIP(ctx, hipMalloc((void**)d, sizeof(S)));
-  RLS_HIP(ctx, hipMemset(*d, 0, sizeof(S)));
+  RLS_HIP(ctx, hipMemsetAsync(*d, 0, sizeof(S), ctx->stream));
   RLS_HIP(ctx, hipHostMalloc((void**)h, sizeof(S), hipHostMallocDefault));
   memset(*h, 0, sizeof(S));
   return 0;
@@ -1272,7 +1272,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   s->slab_b = nullptr;
   const size_t sb = sizeof(cgnr_scalars) * (size_t)nrhs;
   hipError_t e = hipMalloc((void**)&s->sc, sb);
-  if (e == hipSuccess) e = hipMemset(s->sc, 0, sb);
+  if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sb, ctx->stream);
   if (e == hipSuccess) e = hipHostMalloc((void**)&s->sc_h, sb, hipHostMallocDefault);
   if (e == hipSuccess) memset(s->sc_h, 0, sb);
   if (e == hipSuccess && op->slab) {  // scratch of the fused pipeline
@@ -1280,12 +1280,12 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double) * nrhs;
     e = hipMalloc(&s->r1, vb);
     if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
-    if (e == hipSuccess) e = hipMemset(s->r1, 0, vb);
-    if (e == hipSuccess) e = hipMemset(s->p1, 0, vb);
+    if (e == hipSuccess) e = hipMemsetAsync(s->r1, 0, vb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->p1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&s->dots, nd);
     if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sb);
-    if (e == hipSuccess) e = hipMemset(s->dots, 0, nd);
-    if (e == hipSuccess) e = hipMemset(s->scn, 0, sb);
+    if (e == hipSuccess) e = hipMemsetAsync(s->dots, 0, nd, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
     if (e == hipSuccess && nrhs > 1 && !skinny)
       e = hipMalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
   }
@@ -1297,18 +1297,18 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMalloc(&s->v1, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&s->gdots, nd);
     if (e == hipSuccess && !s->scn) e = hipMalloc((void**)&s->scn, sb);
-    if (e == hipSuccess) e = hipMemset(s->r1, 0, vb);
-    if (e == hipSuccess) e = hipMemset(s->p1, 0, vb);
-    if (e == hipSuccess) e = hipMemset(s->v1, 0, vb);
-    if (e == hipSuccess) e = hipMemset(s->gdots, 0, nd);
-    if (e == hipSuccess) e = hipMemset(s->scn, 0, sb);
+    if (e == hipSuccess) e = hipMemsetAsync(s->r1, 0, vb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->p1, 0, vb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->v1, 0, vb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->gdots, 0, nd, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
     s->gram_pipe = e == hipSuccess;
   }
   if (e == hipSuccess && skinny) {
     size_t pb, tb, vb;
     rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
     e = hipMalloc((void**)&s->Ppack, pb);
-    if (e == hipSuccess) e = hipMemset(s->Ppack, 0, pb);  // the padding columns of the last group stay zero
+    if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
     if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
     if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
   }
@@ -1608,15 +1608,15 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   const bool gram = op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg);
   if (e == hipSuccess && gram) {
     e = hipMalloc(&s->res_raw1, vb);
-    if (e == hipSuccess) e = hipMemset(s->res_raw1, 0, vb);
+    if (e == hipSuccess) e = hipMemsetAsync(s->res_raw1, 0, vb, ctx->stream);
   }
   if (e == hipSuccess && (op->slab || gram)) {
     e = hipMalloc(&s->y1, vb);
     if (e == hipSuccess) e = hipMalloc(&s->res_raw, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sizeof(fista_scalars));
-    if (e == hipSuccess) e = hipMemset(s->y1, 0, vb);
-    if (e == hipSuccess) e = hipMemset(s->res_raw, 0, vb);
-    if (e == hipSuccess) e = hipMemset(s->scn, 0, sizeof(fista_scalars));
+    if (e == hipSuccess) e = hipMemsetAsync(s->y1, 0, vb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->res_raw, 0, vb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sizeof(fista_scalars), ctx->stream);
   }
   if (e != hipSuccess) {
     if (s->y) hipFree(s->y);
@@ -1789,11 +1789,11 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   const size_t yb = (size_t)ldv * nrhs * rls_elem_size(op->dtype);
   hipError_t e = hipMalloc(&s->y, yb);
   if (e == hipSuccess) e = hipMalloc((void**)&s->Ypack, pb);
-  if (e == hipSuccess) e = hipMemset(s->Ypack, 0, pb);  // the padding columns of the last group stay zero
+  if (e == hipSuccess) e = hipMemsetAsync(s->Ypack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
   if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
   if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
   if (e == hipSuccess) e = hipMalloc((void**)&s->sc, sizeof(fista_scalars) * nrhs);
-  if (e == hipSuccess) e = hipMemset(s->sc, 0, sizeof(fista_scalars) * nrhs);
+  if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sizeof(fista_scalars) * nrhs, ctx->stream);
   if (e == hipSuccess) e = hipHostMalloc((void**)&s->scb_h, sizeof(fista_scalars) * nrhs, hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void**)&s->sc_h, sizeof(fista_scalars), hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -1962,11 +1962,11 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
     hipError_t e = hipMalloc(&s->r1, vb);
     if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
     if (e == hipSuccess) e = hipMalloc(&s->v1, vb);
-    if (e == hipSuccess) e = hipMemset(s->v1, 0, vb);
+    if (e == hipSuccess) e = hipMemsetAsync(s->v1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&s->gdots, nd);
-    if (e == hipSuccess) e = hipMemset(s->gdots, 0, nd);
+    if (e == hipSuccess) e = hipMemsetAsync(s->gdots, 0, nd, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&s->pscn, sizeof(cgnr_scalars));
-    if (e == hipSuccess) e = hipMemset(s->pscn, 0, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = hipMemsetAsync(s->pscn, 0, sizeof(cgnr_scalars), ctx->stream);
     if (e != hipSuccess || alloc_scalars(ctx, &s->psc, &s->psc_h) != 0) {
       rls_cg_destroy(s);
       return rls_fail(ctx, (int32_t)e, "cg_create: hipMalloc failed");
@@ -1977,9 +1977,9 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
     hipError_t e = hipMalloc(&s->r1, vb);
     if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&s->dots, nd);
-    if (e == hipSuccess) e = hipMemset(s->dots, 0, nd);
+    if (e == hipSuccess) e = hipMemsetAsync(s->dots, 0, nd, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&s->pscn, sizeof(cgnr_scalars));
-    if (e == hipSuccess) e = hipMemset(s->pscn, 0, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = hipMemsetAsync(s->pscn, 0, sizeof(cgnr_scalars), ctx->stream);
     if (e != hipSuccess || alloc_scalars(ctx, &s->psc, &s->psc_h) != 0) {
       rls_cg_destroy(s);
       return rls_fail(ctx, (int32_t)e, "cg_create: hipMalloc failed");

@@ -506,7 +506,7 @@ int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E*
   }
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  hipError_t err = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+  hipError_t err = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
   int32_t st = 0;
   if (err == hipSuccess) {
     st = enqueue();

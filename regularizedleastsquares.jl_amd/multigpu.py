@@ -68,10 +68,13 @@ class MultiSolve:
     """solve!(solver, B; scheduler = MultiThreadingState) across ranks: every rank owns a replica of A
     (or its own A) and the columns shard_columns() gives it."""
 
-    def __init__(self, rls, solver_factory, dist=None):
+    def __init__(self, rls, solver_factory, dist=None, scheduler=None):
         self.rls = rls
         self.solver_factory = solver_factory
         self.dist = dist
+        # the local columns advance together through one pass over A per product where the solver has a batched plan
+        # (CGNR, FISTA; matrix cores), and column by column otherwise -- same results either way
+        self.scheduler = scheduler if scheduler is not None else rls.BatchedState
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
 
@@ -84,7 +87,7 @@ class MultiSolve:
         local = None
         if len(cols):
             Bd = rls.DeviceMatrix.from_host(np.asfortranarray(B_host[:, cols.start:cols.stop]), ctx)
-            xs = rls.solve_(solver, Bd, scheduler=rls.MultiThreadingState)
+            xs = rls.solve_(solver, Bd, scheduler=self.scheduler)
             local = np.stack([x.to_host() for x in xs], axis=1)
         if self.dist is None:
             return local

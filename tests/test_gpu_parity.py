@@ -784,6 +784,14 @@ def test_multisolve_single_rank(rls, ctx):
     ms = rls.MultiSolve(rls, lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=64))
     got = ms.solve(B)
     assert got.shape == (64, 5) and rel(got, X) < 1e-3
+    # default: the local columns share A (BatchedState); the reference's scheduler gives the same columns
+    seq = rls.MultiSolve(rls, lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=64), scheduler=rls.MultiThreadingState).solve(B)
+    assert rel(got, seq) < 2e-5
+    rho = 0.9 / np.linalg.norm(A.astype(np.complex128), 2) ** 2
+    mk = lambda: rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-3), rho=rho, iterations=30)
+    f_b = rls.MultiSolve(rls, mk).solve(B)
+    f_s = rls.MultiSolve(rls, mk, scheduler=rls.MultiThreadingState).solve(B)
+    assert f_b.shape == (64, 5) and rel(f_b, f_s) < 2e-5
 
 
 @pytest.mark.parametrize("mfma", [1, 0])
