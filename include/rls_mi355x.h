@@ -148,6 +148,8 @@ int32_t rls_operator_destroy(rls_operator* op);
 int32_t rls_operator_mul(rls_operator* op, const void* x, void* y);
 int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x);
 int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v);
+/* the same, as a no-op when the device int32 *skip_d is non-zero at launch time (nullable) */
+int32_t rls_operator_mul_normal_skip(rls_operator* op, const void* p, void* v, const void* skip_d);
 /* setup GEMM AHA = A' * A (src/CGNR.jl:49) on device; G is N x N column-major, ld >= N */
 int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G, int64_t ld);
 /* Singular-value soft-thresholding.
@@ -177,6 +179,18 @@ int32_t rls_pogm_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const
                         void* xold, void* z, void* w, float rho, float c_y, float c_x1, float c_xo, float c_z,
                         int32_t reg_kind, float thr, int32_t proj_kind, int32_t restart, float rho_over_gamma,
                         float* out_h);
+/* Deferred forms: no host read-back.  state_d points at 4 device words {int32 iteration, int32 done, float ||res||,
+ * pad}, zeroed by the caller before the first iteration; each launch is a no-op once `done` is set, increments
+ * `iteration`, stores ||res|| and sets done = (||res|| / norm_x0 < rel_tol) -- the reference's stopping test
+ * (src/OptISTA.jl:206-209, src/POGM.jl:234-237).  Pair with rls_operator_mul_normal_skip(op, x, res, &state->done).
+ * POGM: restart = :none only. */
+int32_t rls_optista_update_async(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* x, void* y,
+                                 void* z, void* zold, float step, int32_t reg_kind, float thr, float c_z, float c_y,
+                                 float c_x, float c_zn, float c_zo, float norm_x0, float rel_tol, void* state_d);
+int32_t rls_pogm_update_async(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                              void* xold, void* z, float rho, float c_y, float c_x1, float c_xo, float c_z,
+                              int32_t reg_kind, float thr, int32_t proj_kind, float norm_x0, float rel_tol,
+                              void* state_d);
 /* At = transpose(A) (no conjugation): N x M column-major, leading dimension ldat >= N.  Row k of A becomes the
  * contiguous column k of At -- the "structure for row access" that the reference's row-action solvers ask for
  * (createLinearSolver(Kaczmarz, transpose(A_T)), src/Kaczmarz.jl:391, dot_with_matrix_row(::Transpose…)

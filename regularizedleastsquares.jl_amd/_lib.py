@@ -111,6 +111,11 @@ PROTOTYPES = {
     "rls_optista_update": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _f, _f, _f, _f, _f, _f, _pf]),
     "rls_pogm_update": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i32, _f, _i32, _i32,
                                _f, _pf]),
+    "rls_optista_update_async": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _f, _f, _f, _f, _f, _f,
+                                        _f, _f, _vp]),
+    "rls_pogm_update_async": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i32, _f, _i32,
+                                     _f, _f, _vp]),
+    "rls_operator_mul_normal_skip": (_i32, [_vp, _vp, _vp, _vp]),
     "rls_transpose": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _i64]),
     "rls_kaczmarz_sweep": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
                                   C.c_float, _i32]),

@@ -7,6 +7,20 @@
 
 constexpr int PGM_THREADS = 1024;
 
+// Deferred mode (rls_*_update_async): the iteration count, ||res|| and the reference's stopping test
+// `rel_res_norm < relTol` (src/OptISTA.jl:206-209, src/POGM.jl:234-237) live in a 4-word device record, every
+// launch of the sequence is a no-op once `done` is set, and the host reads the record once per solve.
+struct pgm_state {
+  int iteration, done;
+  float res_norm, pad;
+};
+__device__ static inline void pgm_state_step(pgm_state* st, float res_norm, float norm_x0, float rel_tol) {
+  if (!st) return;
+  st->iteration += 1;
+  st->res_norm = res_norm;
+  st->done = ((double)res_norm / (double)norm_x0) < (double)rel_tol;  // the host forms this quotient in double
+}
+
 template <typename E>
 __device__ static inline double redot(E a, E b) {  // real(conj(a) * b)
   return (double)elem<E>::re(a) * (double)elem<E>::re(b) + (double)elem<E>::im(a) * (double)elem<E>::im(b);
@@ -20,8 +34,10 @@ __global__ __launch_bounds__(PGM_THREADS) void optista_update_kernel(E* __restri
                                                                      E* __restrict__ z, E* __restrict__ zold, int64_t n,
                                                                      float step, int reg_kind, float thr, float c_z,
                                                                      float c_y, float c_x, float c_zn, float c_zo,
-                                                                     float* __restrict__ out) {
+                                                                     float* __restrict__ out, pgm_state* state,
+                                                                     float norm_x0, float rel_tol) {
   __shared__ double sm[16];
+  if (state && state->done) return;
   double rn = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += PGM_THREADS) {
     const E zo = z[i], ztmp = y[i], xi = x[i];
@@ -40,7 +56,10 @@ __global__ __launch_bounds__(PGM_THREADS) void optista_update_kernel(E* __restri
     x[i] = xn;
   }
   rn = block_sum(rn, sm);
-  if (threadIdx.x == 0) out[0] = (float)sqrt(rn);
+  if (threadIdx.x == 0) {
+    out[0] = (float)sqrt(rn);
+    pgm_state_step(state, out[0], norm_x0, rel_tol);
+  }
 }
 
 // xbuf holds x_k, ybuf holds y_{k-1} on entry; on exit xbuf holds the gradient point (the new y after the
@@ -52,8 +71,10 @@ __global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict_
                                                                   E* __restrict__ w, int64_t n, float rho, float c_y,
                                                                   float c_x1, float c_xo, float c_z, int reg_kind,
                                                                   float thr, int proj_kind, float rg,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, pgm_state* state,
+                                                                  float norm_x0, float rel_tol) {
   __shared__ double sm[48];
+  if (state && state->done) return;
   double rn = 0.0, dwx = 0.0, dwz = 0.0, dwr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += PGM_THREADS) {
     const E xo = xbuf[i], yp = ybuf[i];
@@ -88,6 +109,7 @@ __global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict_
     out[1] = (float)dwx;
     out[2] = (float)dwz;
     out[3] = (float)dwr;
+    pgm_state_step(state, out[0], norm_x0, rel_tol);
   }
 }
 
@@ -100,40 +122,59 @@ static int32_t pgm_fetch(rls_ctx* ctx, float* out_h, int nfloats) {
 
 extern "C" {
 
-int32_t rls_optista_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* x, void* y, void* z,
-                           void* zold, float step, int32_t reg_kind, float thr, float c_z, float c_y, float c_x,
-                           float c_zn, float c_zo, float* res_norm_h) {
+static int32_t optista_launch(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* x, void* y, void* z,
+                              void* zold, float step, int32_t reg_kind, float thr, float c_z, float c_y, float c_x,
+                              float c_zn, float c_zo, pgm_state* state, float norm_x0, float rel_tol) {
   RLS_CHECK_CTX(ctx);
-  if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !x || !y || !z || !zold || !res_norm_h ||
-      reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2)
+  if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !x || !y || !z || !zold || reg_kind < RLS_REG_NONE ||
+      reg_kind > RLS_REG_L2)
     return rls_fail(ctx, RLS_E_INVALID, "optista_update: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(optista_update_kernel<float>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float*)res,
                        (const float*)x0, (float*)x, (float*)y, (float*)z, (float*)zold, n, step, reg_kind, thr, c_z, c_y,
-                       c_x, c_zn, c_zo, ctx->res_d);
+                       c_x, c_zn, c_zo, ctx->res_d, state, norm_x0, rel_tol);
   else
     hipLaunchKernelGGL(optista_update_kernel<float2>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float2*)res,
                        (const float2*)x0, (float2*)x, (float2*)y, (float2*)z, (float2*)zold, n, step, reg_kind, thr, c_z,
-                       c_y, c_x, c_zn, c_zo, ctx->res_d);
+                       c_y, c_x, c_zn, c_zo, ctx->res_d, state, norm_x0, rel_tol);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+int32_t rls_optista_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* x, void* y, void* z,
+                           void* zold, float step, int32_t reg_kind, float thr, float c_z, float c_y, float c_x,
+                           float c_zn, float c_zo, float* res_norm_h) {
+  RLS_CHECK_CTX(ctx);
+  if (!res_norm_h) return rls_fail(ctx, RLS_E_INVALID, "optista_update: null result pointer");
+  RLS_TRY(optista_launch(ctx, dtype, n, res, x0, x, y, z, zold, step, reg_kind, thr, c_z, c_y, c_x, c_zn, c_zo, nullptr,
+                         1.f, 0.f));
   return pgm_fetch(ctx, res_norm_h, 1);
 }
 
-int32_t rls_pogm_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
-                        void* xold, void* z, void* w, float rho, float c_y, float c_x1, float c_xo, float c_z,
-                        int32_t reg_kind, float thr, int32_t proj_kind, int32_t restart, float rho_over_gamma,
-                        float* out_h) {
+int32_t rls_optista_update_async(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* x, void* y,
+                                 void* z, void* zold, float step, int32_t reg_kind, float thr, float c_z, float c_y,
+                                 float c_x, float c_zn, float c_zo, float norm_x0, float rel_tol, void* state_d) {
   RLS_CHECK_CTX(ctx);
-  if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !xbuf || !ybuf || !xold || !z || !out_h || (restart && !w) ||
+  if (!state_d) return rls_fail(ctx, RLS_E_INVALID, "optista_update_async: null state");
+  return optista_launch(ctx, dtype, n, res, x0, x, y, z, zold, step, reg_kind, thr, c_z, c_y, c_x, c_zn, c_zo,
+                        (pgm_state*)state_d, norm_x0, rel_tol);
+}
+
+static int32_t pogm_launch(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                           void* xold, void* z, void* w, float rho, float c_y, float c_x1, float c_xo, float c_z,
+                           int32_t reg_kind, float thr, int32_t proj_kind, int32_t restart, float rho_over_gamma,
+                           pgm_state* state, float norm_x0, float rel_tol) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !xbuf || !ybuf || !xold || !z || (restart && !w) ||
       reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2 || proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE)
     return rls_fail(ctx, RLS_E_INVALID, "pogm_update: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
 #define RLS_POGM(EE, RR)                                                                                             \
   hipLaunchKernelGGL((pogm_update_kernel<EE, RR>), dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (EE*)res, (const EE*)x0, \
                      (EE*)xbuf, (EE*)ybuf, (EE*)xold, (EE*)z, (EE*)w, n, rho, c_y, c_x1, c_xo, c_z, reg_kind, thr,     \
-                     proj_kind, rho_over_gamma, ctx->res_d)
+                     proj_kind, rho_over_gamma, ctx->res_d, state, norm_x0, rel_tol)
   if (dtype == RLS_F32) {
     if (restart) RLS_POGM(float, true);
     else RLS_POGM(float, false);
@@ -144,7 +185,29 @@ int32_t rls_pogm_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const
 #undef RLS_POGM
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+int32_t rls_pogm_update(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                        void* xold, void* z, void* w, float rho, float c_y, float c_x1, float c_xo, float c_z,
+                        int32_t reg_kind, float thr, int32_t proj_kind, int32_t restart, float rho_over_gamma,
+                        float* out_h) {
+  RLS_CHECK_CTX(ctx);
+  if (!out_h) return rls_fail(ctx, RLS_E_INVALID, "pogm_update: null result pointer");
+  RLS_TRY(pogm_launch(ctx, dtype, n, res, x0, xbuf, ybuf, xold, z, w, rho, c_y, c_x1, c_xo, c_z, reg_kind, thr, proj_kind,
+                      restart, rho_over_gamma, nullptr, 1.f, 0.f));
   return pgm_fetch(ctx, out_h, 4);
+}
+
+// restart = :none only (the gradient restart feeds data-dependent theta / sigma back into the next coefficients)
+int32_t rls_pogm_update_async(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                              void* xold, void* z, float rho, float c_y, float c_x1, float c_xo, float c_z,
+                              int32_t reg_kind, float thr, int32_t proj_kind, float norm_x0, float rel_tol,
+                              void* state_d) {
+  RLS_CHECK_CTX(ctx);
+  if (!state_d) return rls_fail(ctx, RLS_E_INVALID, "pogm_update_async: null state");
+  return pogm_launch(ctx, dtype, n, res, x0, xbuf, ybuf, xold, z, nullptr, rho, c_y, c_x1, c_xo, c_z, reg_kind, thr,
+                     proj_kind, 0, 0.f, (pgm_state*)state_d, norm_x0, rel_tol);
 }
 
 }  // extern "C"

@@ -1206,6 +1206,15 @@ int32_t rls_operator_mul_adj(rls_operator* op, const void* y, void* x) {
   if (!op->A) return rls_fail(op->ctx, RLS_E_STATE, "operator_mul_adj: operator has no forward matrix");
   return rls_launch_gemv(op->ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, y, 0.f, 0.f, x, nullptr);
 }
+// the same with a device flag that turns the launches into no-ops (deferred OptISTA / POGM sequences)
+int32_t rls_operator_mul_normal_skip(rls_operator* op, const void* p, void* v, const void* skip_d) {
+  if (!op) return RLS_E_INVALID;
+  rls_ctx* ctx = op->ctx;
+  if (!p || !v) return rls_fail(ctx, RLS_E_INVALID, "operator_mul_normal_skip: null pointer");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  return op_normal(op, p, v, (const int*)skip_d);
+}
+
 int32_t rls_operator_mul_normal(rls_operator* op, const void* p, void* v) {
   if (!op || !p || !v) return RLS_E_INVALID;
   return op_normal(op, p, v, nullptr);

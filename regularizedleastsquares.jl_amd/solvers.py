@@ -952,10 +952,8 @@ class OptISTA(AbstractProximalGradientSolver):
         st.rel_res_norm = math.inf
         st.iteration = 0
 
-    def iterate(self, st=None):
-        st = st or self.state
-        if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
-            return None
+    def _coefficients(self, st):
+        """the index-only scalars of one iteration (src/OptISTA.jl:170-175,196-204), advancing theta"""
         f32 = np.float32
         th, tn, rho = f32(st.theta), f32(st.theta_n), f32(st.rho)
         gamma = f32(2) * th / (tn * tn) * (tn * tn - f32(2) * th * th + th)
@@ -966,15 +964,27 @@ class OptISTA(AbstractProximalGradientSolver):
             thn = (f32(1) + np.sqrt(f32(1) + f32(4) * th * th)) / f32(2)
         st.theta = float(thn)
         alpha, beta = (th - f32(1)) / thn, th / thn
+        return rho, gamma, alpha, beta
+
+    def _update_args(self, st, fus, rho, gamma, alpha, beta):
+        f32 = np.float32
+        return (st.x.ctx.handle, st.x.code, st.x.n, st.res.ptr, st.x0.ptr, st.x.ptr, st.y.ptr, st.z.ptr, st.zold.ptr,
+                float(rho * gamma), fus[0], float(rho * gamma * f32(self.reg.lam)), float(f32(-1) / gamma),
+                float(f32(1) / gamma), float(-beta), float(f32(1) + alpha + beta), float(-alpha))
+
+    def iterate(self, st=None):
+        st = st or self.state
+        if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
+            return None
+        f32 = np.float32
+        rho, gamma, alpha, beta = self._coefficients(st)
         fus = _fusable_kinds(self.reg, [])
         if fus is not None:  # one launch for everything after the operator apply (rls_optista_update)
             _NormalApply(self._op).mul_(st.res, st.x)
             ctx = st.x.ctx
             out = (C.c_float * 1)()
-            check(ctx.handle, ctx.lib.rls_optista_update(
-                ctx.handle, st.x.code, st.x.n, st.res.ptr, st.x0.ptr, st.x.ptr, st.y.ptr, st.z.ptr, st.zold.ptr,
-                float(rho * gamma), fus[0], float(rho * gamma * f32(self.reg.lam)), float(f32(-1) / gamma),
-                float(f32(1) / gamma), float(-beta), float(f32(1) + alpha + beta), float(-alpha), out), "rls_optista_update")
+            check(ctx.handle, ctx.lib.rls_optista_update(*self._update_args(st, fus, rho, gamma, alpha, beta), out),
+                  "rls_optista_update")
             st.rel_res_norm = float(out[0]) / st.norm_x0
             if self.verbose:
                 print(f"Iteration {st.iteration}; rel. residual = {st.rel_res_norm}")
@@ -997,8 +1007,43 @@ class OptISTA(AbstractProximalGradientSolver):
         return st.x, st
 
     def _run(self, st):
-        while self.iterate(st) is not None:
-            pass
+        """no callbacks: every remaining iteration is enqueued at once (the coefficients depend on the index only);
+        `rel_res_norm < relTol` is evaluated on the device, later launches are no-ops, ONE read-back at the end"""
+        fus = _fusable_kinds(self.reg, [])
+        if fus is None or self.verbose or not isinstance(self._op, OperatorHandle) or st.rel_res_norm < st.relTol:
+            while self.iterate(st) is not None:
+                pass
+            return
+        ctx = st.x.ctx
+        lib, h = ctx.lib, ctx.handle
+        rec = _pgm_record(st, ctx)
+        thetas = [(st.theta, st.thetaold)]
+        for _ in range(st.iteration, self.iterations):
+            rho, gamma, alpha, beta = self._coefficients(st)
+            st.iteration += 1
+            thetas.append((st.theta, st.thetaold))
+            check(h, lib.rls_operator_mul_normal_skip(self._op.handle, st.x.ptr, st.res.ptr, rec.ptr + 4), "rls_operator_mul_normal_skip")
+            check(h, lib.rls_optista_update_async(*self._update_args(st, fus, rho, gamma, alpha, beta), float(st.norm_x0),
+                                                  float(st.relTol), rec.ptr), "rls_optista_update_async")
+        done_its, res_norm = _pgm_fetch(rec)
+        first = st.iteration - (len(thetas) - 1)
+        st.iteration = first + done_its
+        st.theta, st.thetaold = thetas[done_its]
+        if done_its:
+            st.rel_res_norm = res_norm / st.norm_x0
+
+
+def _pgm_record(st, ctx):
+    """4 zeroed device words {iteration, done, ||res||, pad} of the deferred OptISTA / POGM sequences"""
+    if getattr(st, "_rec", None) is None or st._rec.ctx is not ctx:
+        st._rec = DeviceVector(4, np.float32, ctx)
+    st._rec.fill_(0)
+    return st._rec
+
+
+def _pgm_fetch(rec):
+    raw = rec.to_host()  # synchronises
+    return int(raw[:1].view(np.int32)[0]), float(raw[2])
 
 
 class POGM(AbstractProximalGradientSolver):
@@ -1130,8 +1175,45 @@ class POGM(AbstractProximalGradientSolver):
         return st.x, st
 
     def _run(self, st):
-        while self.iterate(st) is not None:
-            pass
+        """restart = :none without callbacks: all remaining iterations enqueued at once (index-only coefficients),
+        the stopping test on the device, ONE read-back at the end; otherwise iteration by iteration"""
+        fus = _fusable_kinds(self.reg, self.proj)
+        if (fus is None or self.restart != "none" or self.verbose or not isinstance(self._op, OperatorHandle)
+                or st.rel_res_norm < st.relTol):
+            while self.iterate(st) is not None:
+                pass
+            return
+        f32 = np.float32
+        ctx = st.x.ctx
+        lib, h = ctx.lib, ctx.handle
+        rec = _pgm_record(st, ctx)
+        rho = f32(st.rho)
+        bufs = (st.x, st.y)
+        hist = [(st.theta, st.thetaold, st.gamma)]
+        first = st.iteration
+        for k in range(first, self.iterations):
+            tho = f32(st.theta)
+            st.thetaold = float(tho)
+            th = (f32(1) + np.sqrt(f32(1) + f32(4) * tho * tho)) / f32(2)  # :183-187 (restart == :none)
+            st.theta = float(th)
+            alpha = (tho - f32(1)) / th
+            beta = f32(st.sigma) * tho / th
+            gamma_old = f32(st.gamma)
+            gamma = rho * (f32(2) * tho + th - f32(1)) / th
+            st.gamma = float(gamma)
+            hist.append((st.theta, st.thetaold, st.gamma))
+            xb, yb = bufs if (k - first) % 2 == 0 else bufs[::-1]
+            check(h, lib.rls_operator_mul_normal_skip(self._op.handle, xb.ptr, st.res.ptr, rec.ptr + 4), "rls_operator_mul_normal_skip")
+            check(h, lib.rls_pogm_update_async(
+                h, xb.code, xb.n, st.res.ptr, st.x0.ptr, xb.ptr, yb.ptr, st.xold.ptr, st.z.ptr, float(rho), float(-alpha),
+                float(f32(1) + alpha + beta), -float(beta + rho * alpha / gamma_old), float(rho * alpha / gamma_old), fus[0],
+                float(gamma * f32(self.reg.lam)), fus[1], float(st.norm_x0), float(st.relTol), rec.ptr), "rls_pogm_update_async")
+        done_its, res_norm = _pgm_fetch(rec)
+        st.iteration = first + done_its
+        st.theta, st.thetaold, st.gamma = hist[done_its]
+        st.x, st.y = bufs if done_its % 2 == 0 else bufs[::-1]  # the kernel writes the new x into the old y buffer
+        if done_its:
+            st.rel_res_norm = res_norm / st.norm_x0
 
 
 class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM

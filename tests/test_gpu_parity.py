@@ -1453,3 +1453,29 @@ def test_fista_batched_matrix_solve_equals_column_solves(rls, ctx, dt, M, N, K, 
     assert seen[0] == 0 and all(np.array_equal(z.to_host(), x.to_host()) for z, x in zip(zs, xs))
     x1 = rls.solve_(S, rls.DeviceVector.from_host(B[:, 1].copy())).to_host()
     assert rel(x1, xs[1].to_host()) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["OptISTA", "POGM"])
+def test_optista_pogm_deferred_run_equals_stepwise(rls, ctx, name):
+    """without callbacks every iteration is enqueued at once and `rel_res_norm < relTol` is decided on the device
+    (rls_*_update_async): same stopping iteration as the oracle, same bits as the iteration-by-iteration run, and the
+    state (iteration, theta, rel_res_norm, x/y roles) is consistent afterwards so that a second solve works"""
+    A, xt, b = O.make_problem(300, 100, np.complex64, 37)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    rho = 0.9 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    for relTol, its in ((0.0, 21), (3e-2, 60)):
+        ref = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=relTol)
+        O.solve(ref, b64)
+        sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=relTol)
+        for _ in range(2):
+            x = rls.solve_(sol, bd).to_host()
+            assert sol.state.iteration == ref.iteration, (relTol, sol.state.iteration, ref.iteration)
+            assert rel(x, ref.x) < 3e-5
+            assert np.isclose(sol.state.rel_res_norm, ref.rel_res_norm, rtol=2e-3)
+        if relTol > 0:
+            assert 1 < ref.iteration < its
+        seen = []
+        x_cb = rls.solve_(sol, bd, callbacks=lambda s_, it: seen.append(it)).to_host()
+        assert seen == list(range(ref.iteration + 1)) and np.array_equal(x_cb, x)
