@@ -608,8 +608,8 @@ class ADMM(AbstractPrimalDualSolver):
 
     def _plan_params(self, state):
         """rls_admm_params when the whole outer iteration can run on the device, else None"""
-        if type(self) is not ADMM or not self.use_device_plan or not (self._all_identity() and len(self.reg) == 1 and self.vary_rho == "none"
-                                          and not self.verbose):
+        if type(self) not in (ADMM, SplitBregman) or not self.use_device_plan or not (
+                self._all_identity() and len(self.reg) == 1 and self.vary_rho == "none" and not self.verbose):
             return None
         reg, rho = self.reg[0], np.float32(state.rho[0])
         P = AdmmParams()
@@ -643,12 +643,18 @@ class ADMM(AbstractPrimalDualSolver):
             else:
                 return None
         with np.errstate(divide="ignore"):
-            P.prox_lambda = 0.0 if rho == 0 else float(np.float32(reg.lam) / (np.float32(2) * rho))  # :261
+            P.prox_lambda = 0.0 if rho == 0 else float(self._prox_threshold(np.float32(reg.lam), rho))
         P.x, P.xold, P.beta, P.beta_y = state.x.ptr, state.xold.ptr, state.beta.ptr, state.beta_y.ptr
         P.z0, P.z1, P.u = state._zbufs[0].ptr, state._zbufs[1].ptr, state.u[0].ptr
         P.rho, P.sigma_abs, P.rel_tol = float(rho), float(state.sigma_abs), float(state.relTol)
-        P.iterations, P.iterations_cg, P.tol_inner = self.iterations, self.iterationsCG, float(state.tolInner)
+        P.iterations, P.iterations_cg, P.tol_inner = self._plan_iterations(), self.iterationsCG, float(state.tolInner)
         return P
+
+    def _prox_threshold(self, lam32, rho32):
+        return lam32 / (np.float32(2) * rho32)  # prox!(reg, z, lambda / (2 rho))   src/ADMM.jl:261
+
+    def _plan_iterations(self):
+        return self.iterations
 
     def _init_plan(self, state):
         state._plan_ok = False
@@ -1240,12 +1246,56 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
     def done(self, state):
         return self.converged(state) or (state.iteration == 1 and state.iter_cnt > self.iterations)
 
+    def _prox_threshold(self, lam32, rho32):
+        return lam32 / rho32  # prox!(reg, z, lambda / rho)   src/SplitBregman.jl:235
+
+    def _plan_iterations(self):
+        return self.iterationsInner  # one plan run = one block of inner iterations (:204-262)
+
+    def _bregman_update(self, state):
+        """src/SplitBregman.jl:264-268: beta_y += ybreg - AHA x ; z = Phi x ; u = 0 ; next block"""
+        state.beta_y.axpy_(1.0, state.ybreg)
+        self._op.mul_normal_(state.xold, state.x)
+        state.beta_y.axpy_(-1.0, state.xold)
+        for i, t in enumerate(self.regTrafo):
+            t.mul_(state.z[i], state.x)
+            state.u[i].fill_(0)
+        state.iter_cnt += 1
+        state.iteration = 0
+
+    def _plan_block(self, state, n_inner):
+        """up to n_inner inner iterations of the current block on the device (`converged` or the block length stop
+        it there), one read-back, then the host-side Bregman update if the block ended"""
+        lib, h = state.x.ctx.lib, state.x.ctx.handle
+        if state.iteration == 1:  # a block starts: re-arm the plan with the current z as its first buffer
+            P = self._plan_params(state)
+            cur = state.z[0]
+            other = state._zbufs[1] if cur is state._zbufs[0] else state._zbufs[0]
+            state._zbufs = (cur, other)
+            P.z0, P.z1 = cur.ptr, other.ptr
+            check(h, lib.rls_admm_init(state._admm, C.byref(P)), "rls_admm_init")
+            state._block_done = 0
+        check(h, lib.rls_admm_step(state._admm, int(n_inner)), "rls_admm_step")
+        st = AdmmStatus()
+        cap = max(self.iterationsInner, 1)
+        log = (C.c_float * (8 * cap))()
+        check(h, lib.rls_admm_get_status(state._admm, C.byref(st), log, cap), "rls_admm_get_status")
+        it = int(st.iteration)  # inner iterations completed in this block
+        state.cg_iterations += [int(log[8 * k + 5]) for k in range(state._block_done, it)]
+        state._block_done = it
+        state.sk[0], state.eps_pri[0], state.rk[0], state.eps_dua[0] = st.sk, st.eps_pri, st.rk, st.eps_dua
+        state.z[0], state.zold[0] = (state._zbufs[1], state._zbufs[0]) if it & 1 else state._zbufs
+        state.iteration = it  # == the reference's counter before its end-of-iteration increment
+        if self.converged(state) or state.iteration >= self.iterationsInner:
+            self._bregman_update(state)
+        state.iteration += 1
+
     def iterate(self, state=None):
         state = state or self.state
         if self.done(state):
             return None
         if state._plan_ok:
-            self._plan_advance(state, 1)
+            self._plan_block(state, 1)
             return state.x, state
         f32 = np.float32
         lib, h = state.x.ctx.lib, state.x.ctx.handle
@@ -1298,16 +1348,15 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
             t.mul_adj_(state.xold, state.u[i], float(state.rho[i]), 0.0)
             state.eps_dua[i] = f32(state.xold.norm())
         if self.converged(state) or state.iteration >= self.iterationsInner:
-            state.beta_y.axpy_(1.0, state.ybreg)
-            self._op.mul_normal_(state.xold, state.x)
-            state.beta_y.axpy_(-1.0, state.xold)
-            for i, t in enumerate(self.regTrafo):
-                t.mul_(state.z[i], state.x)
-                state.u[i].fill_(0)
-            state.iter_cnt += 1
-            state.iteration = 0
+            self._bregman_update(state)
         state.iteration += 1
         return state.x, state
+
+    def _run(self, state):
+        while state._plan_ok and not self.done(state):
+            self._plan_block(state, self.iterationsInner - (state.iteration - 1))
+        while self.iterate(state) is not None:
+            pass
 
 
 # --------------------------------------------------------------------------------------------

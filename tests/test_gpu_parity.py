@@ -1479,3 +1479,35 @@ def test_optista_pogm_deferred_run_equals_stepwise(rls, ctx, name):
         seen = []
         x_cb = rls.solve_(sol, bd, callbacks=lambda s_, it: seen.append(it)).to_host()
         assert seen == list(range(ref.iteration + 1)) and np.array_equal(x_cb, x)
+
+
+@pytest.mark.parametrize("dt,M,N,kind", [(np.float32, 128, 64, "tv"), (np.complex64, 120, 48, "l1"), (np.float32, 96, 40, "l1pos")])
+def test_split_bregman_blocks_on_the_device_plan(rls, ctx, dt, M, N, kind):
+    """SplitBregman (src/SplitBregman.jl:204-271): each block of inner iterations runs through rls_admm_step (prox
+    threshold lambda / rho, block length iterationsInner, `converged` on the device), the Bregman update stays on
+    the host: equal to the per-call sequence and to the oracle, in one go and iteration by iteration"""
+    A, xt, b = O.make_problem(M, N, dt, 43)
+    def regs(R):
+        if kind == "tv":
+            return R.TVRegularization(2e-2, shape=(8, 8))
+        if kind == "l1":
+            return R.L1Regularization(0.05)
+        return [R.L1Regularization(0.05), R.PositiveRegularization()]
+    kw = dict(rho=0.3, iterations=3, iterationsInner=4, iterationsCG=5, tolInner=1e-4)
+    ref = O.SplitBregman(A, reg=regs(O), **kw)
+    O.solve(ref, b)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    sol = rls.createLinearSolver(rls.SplitBregman, Ad, reg=regs(rls), **kw)
+    x = rls.solve_(sol, bd).to_host()
+    assert sol.state._plan_ok
+    old = rls.createLinearSolver(rls.SplitBregman, Ad, reg=regs(rls), **kw)
+    old.use_device_plan = False
+    x_old = rls.solve_(old, bd).to_host()
+    assert not old.state._plan_ok
+    assert (sol.state.iter_cnt, sol.state.iteration) == (old.state.iter_cnt, old.state.iteration) == (ref.iter_cnt, ref.iteration)
+    assert rel(x, ref.x) < 3e-5 and rel(x, x_old) < 3e-6
+    assert np.allclose(sol.state.rk, old.state.rk, rtol=1e-4) and np.allclose(sol.state.sk, old.state.sk, rtol=1e-4)
+    seen = []
+    x_cb = rls.solve_(sol, bd, callbacks=lambda s_, it: seen.append(it)).to_host()
+    assert seen == list(range(len(seen))) and len(seen) - 1 == kw["iterations"] * kw["iterationsInner"]
+    assert np.array_equal(x_cb, x)
