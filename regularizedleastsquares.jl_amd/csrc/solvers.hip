@@ -908,6 +908,34 @@ static int32_t fetch_scalars(rls_ctx* ctx, S* d, S* h) {
   return 0;
 }
 
+// G = A^H A is Hermitian with a real diagonal (Julia's A'*A goes through herk).  The generic kernels compute
+// both triangles independently, so the two images of an entry can differ in the last bit: copy the upper triangle
+// over the lower one as its conjugate and clear the imaginary part of the diagonal (the 64 x 64 tile kernel is
+// Hermitian by construction and does not need this).
+template <typename E>
+__global__ void hermitianize_kernel(E* __restrict__ G, int64_t ld, int64_t N) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // column
+  const int64_t i = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;  // row
+  if (i >= N || j >= N || i < j) return;
+  if (i == j) {
+    G[i + j * ld] = elem<E>::make(elem<E>::re(G[i + j * ld]), 0.f);
+  } else {  // i > j: lower triangle <- conj(upper)
+    const E u = G[j + i * ld];
+    G[i + j * ld] = elem<E>::make(elem<E>::re(u), -elem<E>::im(u));
+  }
+}
+
+static int32_t gram_hermitianize(rls_ctx* ctx, int32_t dtype, int64_t N, void* G, int64_t ld) {
+  const dim3 block(32, 8), grid((unsigned)((N + 31) / 32), (unsigned)((N + 7) / 8));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(hermitianize_kernel<float>, grid, block, 0, ctx->stream, (float*)G, ld, N);
+  else
+    hipLaunchKernelGGL(hermitianize_kernel<float2>, grid, block, 0, ctx->stream, (float2*)G, ld, N);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ADMM plan: whole outer iterations without host involvement (one regulariser, identity regTrafo)
 // ---------------------------------------------------------------------------------------------
@@ -1232,6 +1260,7 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
     void* panels = nullptr;
     RLS_HIP(ctx, hipMalloc(&panels, (size_t)M * (size_t)N * rls_elem_size(dtype)));
     int32_t st = rls_skinny_gram(ctx, dtype, M, N, A, lda, G, ld, panels);
+    if (st == 0) st = gram_hermitianize(ctx, dtype, N, G, ld);
     hipError_t e = hipStreamSynchronize(ctx->stream);  // setup path: the scratch is freed before returning
     hipFree(panels);
     if (st == 0 && e != hipSuccess) st = rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
@@ -1242,7 +1271,8 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
     hipLaunchKernelGGL(gram_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)A, lda, M, N, (float*)G, ld);
   else
     hipLaunchKernelGGL(gram_kernel<float2>, grid, dim3(256), 0, ctx->stream, (const float2*)A, lda, M, N, (float2*)G, ld);
-  return launch_status(ctx);
+  RLS_TRY(launch_status(ctx));
+  return gram_hermitianize(ctx, dtype, N, G, ld);
 }
 
 // ---- CGNR -----------------------------------------------------------------------------------

@@ -1511,3 +1511,101 @@ def test_split_bregman_blocks_on_the_device_plan(rls, ctx, dt, M, N, kind):
     x_cb = rls.solve_(sol, bd, callbacks=lambda s_, it: seen.append(it)).to_host()
     assert seen == list(range(len(seen))) and len(seen) - 1 == kw["iterations"] * kw["iterationsInner"]
     assert np.array_equal(x_cb, x)
+
+
+def test_random_shapes_against_oracle(rls, ctx):
+    """shape fuzz across every alignment boundary of the kernels (rows per 16-byte chunk, 16-row slabs, 16-column MFMA
+    tiles, columns per load round, N < one round, M < one slab, M or N = 1): GEMV N / C, the normal operator, a few
+    CGNR and FISTA iterations, each against the float64 oracle.  Deterministic seed; run it under RLS_GUARD_ALLOC=1
+    to turn any read past the end of a buffer into a fault."""
+    rng = np.random.default_rng(20260101)
+    shapes = [(1, 1), (2, 1), (1, 3), (3, 2), (15, 17), (16, 16), (17, 15), (33, 7), (64, 129), (130, 64), (255, 33),
+              (256, 128), (257, 127), (48, 260), (500, 3), (3, 500)]
+    shapes += [(int(rng.integers(1, 700)), int(rng.integers(1, 330))) for _ in range(22)]
+    for k, (M, N) in enumerate(shapes):
+        dt = np.complex64 if k % 2 == 0 else np.float32
+        dt64 = np.complex128 if dt == np.complex64 else np.float64
+        A = rng.standard_normal((M, N)).astype(np.float32)
+        if dt == np.complex64:
+            A = (A + 1j * rng.standard_normal((M, N))).astype(np.complex64)
+        A = np.asfortranarray(A)
+        x = rng.standard_normal(N).astype(dt)
+        y = rng.standard_normal(M).astype(dt)
+        A64 = A.astype(dt64)
+        Ad = rls.DeviceMatrix.from_host(A)
+        xd, yd = rls.DeviceVector.from_host(x), rls.DeviceVector.from_host(y)
+        tag = (M, N, np.dtype(dt).name)
+        assert rel(Ad.mul_(rls.DeviceVector(M, dt, ctx), xd).to_host(), A64 @ x) < 2e-5, tag
+        assert rel(Ad.mul_adj_(rls.DeviceVector(N, dt, ctx), yd).to_host(), A64.conj().T @ y) < 2e-5, tag
+        op = rls.OperatorHandle(Ad)
+        assert rel(op.mul_normal_(rls.DeviceVector(N, dt, ctx), xd).to_host(), A64.conj().T @ (A64 @ x)) < 3e-5, tag
+        b = (A64 @ rng.standard_normal(N)).astype(dt)
+        its = min(4, N, max(M - 1, 1))  # CG past the rank of A only amplifies Float32 rounding
+        ref = O.CGNR(A64, reg=O.L2Regularization(0.1), iterations=its, relTol=0.0)
+        O.solve(ref, b.astype(dt64))
+        S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(0.1), iterations=its, relTol=0.0)
+        assert rel(rls.solve_(S, rls.DeviceVector.from_host(b)).to_host(), ref.x) < 5e-5, tag
+        rho = 0.9 / max(np.linalg.norm(A64, 2) ** 2, 1e-30)
+        reff = O.FISTA(A64, reg=O.L1Regularization(0.05), rho=rho, iterations=4, relTol=0.0)
+        O.solve(reff, b.astype(dt64))
+        Sf = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(0.05), rho=rho, iterations=4, relTol=0.0)
+        got = rls.solve_(Sf, rls.DeviceVector.from_host(b)).to_host()
+        assert np.linalg.norm(got - reff.x) <= 5e-5 * max(np.linalg.norm(reff.x), 1e-3), tag
+
+
+def test_random_shapes_other_paths_against_oracle(rls, ctx):
+    """the same fuzz for the paths around the matrix-free loop: Gram GEMM + Gram-mode CGNR, the shared-A batched
+    solve (matrix cores for multiples of 16, register slab / column plans otherwise), Kaczmarz sweeps, the
+    elementwise prox maps and the TV prox on odd image shapes"""
+    rng = np.random.default_rng(20260102)
+    shapes = [(16, 16), (32, 48), (47, 31), (64, 64), (65, 63), (128, 16), (129, 17), (208, 112), (300, 37), (5, 9)]
+    shapes += [(int(rng.integers(2, 400)), int(rng.integers(2, 200))) for _ in range(8)]
+    for k, (M, N) in enumerate(shapes):
+        dt = np.complex64 if k % 2 == 0 else np.float32
+        dt64 = np.complex128 if dt == np.complex64 else np.float64
+        A = rng.standard_normal((M, N)).astype(np.float32)
+        if dt == np.complex64:
+            A = (A + 1j * rng.standard_normal((M, N))).astype(np.complex64)
+        A = np.asfortranarray(A)
+        A64 = A.astype(dt64)
+        Ad = rls.DeviceMatrix.from_host(A)
+        tag = (M, N, np.dtype(dt).name)
+        G = Ad.gram()
+        Gh = G.to_host()
+        assert rel(Gh, A64.conj().T @ A64) < 2e-5, tag
+        assert np.array_equal(Gh, Gh.conj().T), tag  # Hermitian bit for bit
+        b = (A64 @ rng.standard_normal(N)).astype(dt)
+        its = min(4, N, max(M - 1, 1))
+        ref = O.CGNR(A64, reg=O.L2Regularization(0.2), iterations=its, relTol=0.0, normal="gram")
+        O.solve(ref, b.astype(dt64))
+        S = rls.createLinearSolver(rls.CGNR, Ad, AHA=G, reg=rls.L2Regularization(0.2), iterations=its, relTol=0.0)
+        assert rel(rls.solve_(S, rls.DeviceVector.from_host(b)).to_host(), ref.x) < 5e-5, tag
+        K = int(rng.integers(2, 21))
+        B = np.asfortranarray((A64 @ rng.standard_normal((N, K))).astype(dt))
+        Sb = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(0.2), iterations=its, relTol=0.0)
+        xs = rls.solve_(Sb, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
+        for j in (0, K - 1):
+            refj = O.CGNR(A64, reg=O.L2Regularization(0.2), iterations=its, relTol=0.0)
+            assert rel(xs[j].to_host(), O.solve(refj, B[:, j].astype(dt64))) < 5e-5, (tag, K, j)
+        refk = O.Kaczmarz(A64, reg=O.L2Regularization(0.05), iterations=2)
+        xk = O.solve(refk, b.astype(dt64))
+        Sk = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(0.05), iterations=2)
+        assert rel(rls.solve_(Sk, rls.DeviceVector.from_host(b)).to_host(), xk) < 5e-5, tag
+        # prox maps on a vector of length M * N' (odd lengths included)
+        n = int(rng.integers(1, 3000))
+        v = rng.standard_normal(n).astype(np.float32)
+        if dt == np.complex64:
+            v = (v + 1j * rng.standard_normal(n)).astype(np.complex64)
+        v64 = v.astype(dt64)
+        assert rel(rls.prox_(rls.L1Regularization, rls.DeviceVector.from_host(v), 0.3).to_host(), O.prox_l1(v64.copy(), 0.3)) < 2e-6, (tag, n)
+        assert rel(rls.prox_(rls.L2Regularization, rls.DeviceVector.from_host(v), 0.3).to_host(), O.prox_l2(v64.copy(), 0.3)) < 2e-6, (tag, n)
+        assert np.array_equal(rls.prox_(rls.PositiveRegularization, rls.DeviceVector.from_host(v)).to_host(),
+                              O.prox_positive(v.copy())), (tag, n)
+        nx, ny = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        img = rng.standard_normal(nx * ny).astype(np.float32)
+        if dt == np.complex64:
+            img = (img + 1j * rng.standard_normal(nx * ny)).astype(np.complex64)
+        if nx * ny > 1 and (nx > 1 or ny > 1):
+            want = O.prox_tv_fgp(img.astype(dt64), 0.2, (nx, ny), None, 6)
+            got = rls.prox_(rls.TVRegularization(0.2, shape=(nx, ny), iterationsTV=6), rls.DeviceVector.from_host(img), 0.2).to_host()
+            assert rel(got, want) < 5e-6, (tag, nx, ny)
