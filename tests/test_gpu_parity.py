@@ -1609,3 +1609,42 @@ def test_random_shapes_other_paths_against_oracle(rls, ctx):
             want = O.prox_tv_fgp(img.astype(dt64), 0.2, (nx, ny), None, 6)
             got = rls.prox_(rls.TVRegularization(0.2, shape=(nx, ny), iterationsTV=6), rls.DeviceVector.from_host(img), 0.2).to_host()
             assert rel(got, want) < 5e-6, (tag, nx, ny)
+
+
+def test_random_shapes_solver_plans_against_oracle(rls, ctx):
+    """fuzz of the device plans: ADMM (+L1 / +TV on an odd image shape), SplitBregman, OptISTA / POGM deferred runs and
+    the batched FISTA over shapes that do and do not qualify for the fused paths"""
+    rng = np.random.default_rng(20260103)
+    cases = [(64, 48, (8, 6)), (130, 35, (7, 5)), (256, 128, (16, 8)), (96, 81, (9, 9)), (75, 20, (20,)), (513, 144, (12, 12))]
+    for k, (M, N, shape) in enumerate(cases):
+        dt = np.float32 if k % 2 == 0 else np.complex64
+        dt64 = np.complex128 if dt == np.complex64 else np.float64
+        A, xt, b = O.make_problem(M, N, dt, 100 + k)
+        A64, b64 = A.astype(dt64), b.astype(dt64)
+        Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+        tag = (M, N, np.dtype(dt).name)
+        kw = dict(rho=0.25, iterations=4, iterationsCG=4, tolInner=1e-4)
+        for mk in (lambda R: R.L1Regularization(0.03), lambda R: R.TVRegularization(0.03, shape=shape)):
+            ref = O.ADMM(A, reg=mk(O), **kw)
+            O.solve(ref, b)
+            S = rls.createLinearSolver(rls.ADMM, Ad, reg=mk(rls), **kw)
+            assert rel(rls.solve_(S, bd).to_host(), ref.x) < 5e-5 and S.state._plan_ok and S.state.iteration == ref.iteration, tag
+        refb = O.SplitBregman(A, reg=O.L1Regularization(0.03), rho=0.25, iterations=2, iterationsInner=3, iterationsCG=4, tolInner=1e-4)
+        O.solve(refb, b)
+        Sb = rls.createLinearSolver(rls.SplitBregman, Ad, reg=rls.L1Regularization(0.03), rho=0.25, iterations=2, iterationsInner=3,
+                                    iterationsCG=4, tolInner=1e-4)
+        assert rel(rls.solve_(Sb, bd).to_host(), refb.x) < 5e-5, tag
+        rho = 0.9 / np.linalg.norm(A64, 2) ** 2
+        lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+        for name in ("OptISTA", "POGM"):
+            refp = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=9)
+            O.solve(refp, b64)
+            Sp = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=9)
+            assert rel(rls.solve_(Sp, bd).to_host(), refp.x) < 5e-5, (tag, name)
+        K = int(rng.integers(2, 19))
+        B = np.asfortranarray((A64 @ rng.standard_normal((N, K))).astype(dt))
+        Sf = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=8, relTol=0.0)
+        xs = rls.solve_(Sf, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
+        for j in (0, K - 1):
+            reff = O.FISTA(A64, reg=O.L1Regularization(lam), rho=rho, iterations=8, relTol=0.0)
+            assert rel(xs[j].to_host(), O.solve(reff, B[:, j].astype(dt64))) < 5e-5, (tag, K, j)
