@@ -52,9 +52,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const E* __restrict_
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           if constexpr (CONJ)
-            acc[c] = elem<E>::fmac(a[u].e[i], xr[u].e[i], acc[c]);
+            acc[c] = elem<E>::fmac_pk(a[u].e[i], xr[u].e[i], acc[c]);
           else
-            acc[c] = elem<E>::fma(a[u].e[i], xr[u].e[i], acc[c]);
+            acc[c] = elem<E>::fma_pk(a[u].e[i], xr[u].e[i], acc[c]);
         }
       }
     }
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const E* __restrict_
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           if constexpr (CONJ)
-            acc[c] = elem<E>::fmac(a[u].e[i], xr[u].e[i], acc[c]);
+            acc[c] = elem<E>::fmac_pk(a[u].e[i], xr[u].e[i], acc[c]);
           else
-            acc[c] = elem<E>::fma(a[u].e[i], xr[u].e[i], acc[c]);
+            acc[c] = elem<E>::fma_pk(a[u].e[i], xr[u].e[i], acc[c]);
         }
       }
     }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_n_kernel(const E* __restrict_
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[u].e[i], xv[u], acc[i]);
+        for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a[u].e[i], xv[u], acc[i]);
       }
     }
     const int rounds = (nt + CPR - 1) / CPR;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_n_kernel(const E* __restrict_
         a = zero_chunk<E, NV>();
       }
 #pragma unroll
-      for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a.e[i], xv, acc[i]);
+      for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a.e[i], xv, acc[i]);
     }
   }
 

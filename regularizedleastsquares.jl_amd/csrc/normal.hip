@@ -162,7 +162,7 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
     if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
     const E xv = L.xs[k * C::CPR + slot];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[k].e[i], xv, acc[i]);
+    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a[k].e[i], xv, acc[i]);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -206,7 +206,7 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
     if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
     E q = elem<E>::zero();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) q = elem<E>::fmac(a[k].e[i], tr[i], q);
+    for (int i = 0; i < NV; ++i) q = elem<E>::fmac_pk(a[k].e[i], tr[i], q);
     L.xg[g][k * C::CPR + slot] = q;
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -896,7 +896,7 @@ __device__ static inline void gram_rows(chunk<E, elem<E>::vec> (&a)[K], gram_lds
     if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
     const E xe = L.xs[k * C::CPR + slot];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma(a[k].e[i], xe, acc[i]);
+    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a[k].e[i], xe, acc[i]);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -86,6 +86,8 @@ struct elem<float> {
   __device__ static inline float mulc(float a, float b) { return a * b; }  // conj(a)*b
   __device__ static inline float fma(float a, float b, float c) { return fmaf(a, b, c); }
   __device__ static inline float fmac(float a, float b, float c) { return fmaf(a, b, c); }  // conj(a)*b + c
+  __device__ static inline float fma_pk(float a, float b, float c) { return fmaf(a, b, c); }
+  __device__ static inline float fmac_pk(float a, float b, float c) { return fmaf(a, b, c); }
   __device__ static inline float add(float a, float b) { return a + b; }
   __device__ static inline float sub(float a, float b) { return a - b; }
   __device__ static inline float scale(float s, float a) { return s * a; }
@@ -119,6 +121,24 @@ struct elem<float2> {
     re = fmaf(a.y, b.y, re);
     im = fmaf(-a.y, b.x, im);
     return make_float2(re, im);
+  }
+  // The same two operations as TWO packed FMAs (v_pk_fma_f32, full rate on CDNA3/4) instead of four scalar ones;
+  // op_sel / op_sel_hi pick the halves, neg_lo / neg_hi the sign, so no operand is copied or swizzled and the
+  // four roundings are the ones of fma() / fmac() above, in the same order (bit-identical results).  For the
+  // VALU-bound product loops over the register slab; hipcc's own SLP packing of these loops needed register
+  // copies of the slab and spilled (Makefile: -fno-slp-vectorize).
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  __device__ static inline float2 fma_pk(float2 a, float2 b, float2 c) {  // a*b + c
+    v2f A = {a.x, a.y}, B = {b.x, b.y}, C = {c.x, c.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(C) : "v"(A), "v"(B));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(C) : "v"(A), "v"(B));
+    return make_float2(C.x, C.y);
+  }
+  __device__ static inline float2 fmac_pk(float2 a, float2 b, float2 c) {  // conj(a)*b + c
+    v2f A = {a.x, a.y}, B = {b.x, b.y}, C = {c.x, c.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(C) : "v"(A), "v"(B));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(C) : "v"(A), "v"(B));
+    return make_float2(C.x, C.y);
   }
   __device__ static inline float2 add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
   __device__ static inline float2 sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
