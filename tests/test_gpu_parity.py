@@ -1648,3 +1648,58 @@ def test_random_shapes_solver_plans_against_oracle(rls, ctx):
         for j in (0, K - 1):
             reff = O.FISTA(A64, reg=O.L1Regularization(lam), rho=rho, iterations=8, relTol=0.0)
             assert rel(xs[j].to_host(), O.solve(reff, B[:, j].astype(dt64))) < 5e-5, (tag, K, j)
+
+
+def test_plan_entry_points_reject_misuse(rls, ctx):
+    """error behaviour of the plan-level C ABI: calls out of order return RLS_E_STATE, bad arguments RLS_E_INVALID,
+    shapes / regularisers a fused plan does not cover RLS_E_UNSUPPORTED (so that the host falls back to the per-call
+    sequence) -- each with a message in rls_last_error_string, never a crash and never a silent no-op"""
+    import ctypes as C
+    from rls_amd._lib import AdmmParams, AdmmStatus, FistaStatus
+    lib, h = ctx.lib, ctx.handle
+    A, _, b = O.make_problem(48, 24, np.float32, 2)   # N = 24: not a multiple of 16
+    Ad = rls.DeviceMatrix.from_host(A)
+    op = rls.OperatorHandle(Ad)
+    v = [rls.DeviceVector(24, np.float32, ctx) for _ in range(8)]
+    cg = C.c_void_p()
+    assert lib.rls_cg_create(op.handle, v[0].ptr, v[1].ptr, v[2].ptr, C.byref(cg)) == 0
+    plan = C.c_void_p()
+    assert lib.rls_admm_create(cg, C.byref(plan)) == 0
+    assert lib.rls_admm_step(plan, 1) == -4 and b"admm_init" in lib.rls_last_error_string(h)       # RLS_E_STATE
+    st = AdmmStatus()
+    assert lib.rls_admm_get_status(plan, C.byref(st), None, 0) == -4
+    P = AdmmParams()
+    assert lib.rls_admm_init(plan, C.byref(P)) == -1                                                # null vectors
+    P.x, P.xold, P.beta, P.beta_y, P.z0, P.z1, P.u = (t.ptr for t in v[:7])
+    P.rho, P.iterations, P.iterations_cg, P.reg_kind = 0.1, 3, 2, 3                                  # REG_L21: not fused
+    assert lib.rls_admm_init(plan, C.byref(P)) == -2
+    P.reg_kind, P.proj_kind = 4, 2                                                                   # TV + projection
+    P.tv_ndims, P.tv_ntv, P.tv_iterations = 2, 2, 5
+    P.tv_shape[0], P.tv_shape[1], P.tv_dims[0], P.tv_dims[1] = 6, 4, 0, 1
+    assert lib.rls_admm_init(plan, C.byref(P)) == -2
+    P.proj_kind = 0
+    P.tv_shape[0] = 5                                                                                # 5 * 4 != N
+    assert lib.rls_admm_init(plan, C.byref(P)) == -1
+    P.tv_shape[0] = 6
+    assert lib.rls_admm_init(plan, C.byref(P)) == 0 and lib.rls_admm_step(plan, -1) == -1
+    assert lib.rls_admm_destroy(plan) == 0 and lib.rls_cg_destroy(cg) == 0
+    # batched FISTA needs the matrix-core shape (M, N multiples of 16): the host then uses per-column plans
+    fp = C.c_void_p()
+    X = [rls.DeviceMatrix(24, 4, np.float32, ctx) for _ in range(4)]
+    assert lib.rls_fista_create_batched(op.handle, 4, X[0].ptr, X[1].ptr, X[2].ptr, X[3].ptr, 24, C.byref(fp)) == -2
+    S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(0.01), rho=1e-3, iterations=3)
+    B = np.asfortranarray(np.stack([b, 2 * b], axis=1))
+    xs = rls.solve_(S, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
+    assert type(S.state).__name__ == "MultiThreadingState" and len(xs) == 2
+    # single-column plan: the batched calls are refused
+    f1 = C.c_void_p()
+    assert lib.rls_fista_create(op.handle, v[0].ptr, v[1].ptr, v[2].ptr, v[3].ptr, C.byref(f1)) == 0
+    fs = (FistaStatus * 1)()
+    assert lib.rls_fista_get_status_batched(f1, fs) == -4
+    assert lib.rls_fista_step_local_a(f1) == -4
+    assert lib.rls_fista_destroy(f1) == 0
+    # nested-term helpers
+    d = (C.c_double * 5)()
+    assert lib.rls_stats(h, 0, 0, v[0].ptr, d) == -1 and lib.rls_gather(h, 0, 4, None, v[0].ptr, v[1].ptr) == -1
+    assert lib.rls_optista_update_async(h, 0, 24, v[0].ptr, v[1].ptr, v[2].ptr, v[3].ptr, v[4].ptr, v[5].ptr, 0.1, 1, 0.1,
+                                        1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, None) == -1
