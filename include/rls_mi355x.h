@@ -61,7 +61,8 @@ int32_t rls_device_count(int32_t* out);
 /* kernel-selection knobs for measurement sweeps and for forcing a path in the parity tests; not part of the
  * reference.  Per context: "gemvn_g", "gemvn_waves", "gemvt_cols" (0 = heuristic), "graph_chunk", "use_graph",
  * "fuse_level", "fused_normal" (one-pass normal operator), "cgnr_pipeline" (2-launch CGNR), "gram_pipeline"
- * (1-launch Gram-mode CGNR / cg), "batched_mfma" (matrix-core batched path and Gram GEMM).  Process-wide
+ * (1-launch Gram-mode CGNR / cg), "batched_mfma" (matrix-core batched path and Gram GEMM), "pipe_hint_mode" (0: the
+ * host tells the 2-launch pipeline which (r, p) buffer pair is current, 1: never, 2: deliberately wrong -- tests).  Process-wide
  * (measurement only, set before the plan is created): "slab_g", "slab_wv", "slab_order", "red_threads",
  * "tv_fused_max_n", "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits",
  * "kaczmarz_nt". */

@@ -97,6 +97,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "cgnr_pipeline")) ctx->tune.cgnr_pipeline = value;
   else if (!strcmp(key, "batched_mfma")) ctx->tune.batched_mfma = value;
   else if (!strcmp(key, "gram_pipeline")) ctx->tune.gram_pipeline = value;
+  else if (!strcmp(key, "pipe_hint_mode")) ctx->tune.pipe_hint_mode = value;
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);
   else if (!strcmp(key, "skinny_v_waves")) rls_skinny_tune(1, value);
   else if (!strcmp(key, "skinny_v_splits")) rls_skinny_tune(2, value);

@@ -308,20 +308,34 @@ struct pipe_small {
   double d0, d1, d2;
 };
 
-template <typename E, int EPT, int NT>
+// `hint` >= 0: the host knows which (r, p) pair is current, only that one is loaded (into both slots); x is
+// loaded by the one workgroup that stores it.  27 -> 15 loads per lane: every one of them is issued by all 8
+// waves ahead of the slab, so they cost issue slots as well as latency (0.7 us per iteration at the headline).
+// (A compile-time switch, not a branch on `hint`: loads under a wave-uniform branch make the compiler wait
+// vmcnt(0) at the join.)
+template <typename E, int EPT, int NT, bool HINTED>
 __device__ static inline void pipe_load_small(pipe_small<E, EPT>& s, const E* x, const E* r0, const E* p0, const E* r1,
                                               const E* p1, const E* v, const double* dots, int ndots, int64_t N,
-                                              int64_t vo, int b) {
+                                              int64_t vo, int b, int hint) {
   const int tid = threadIdx.x;
+  const bool writer = blockIdx.x == 0;
+  const E* rh = hint == 1 ? r1 : r0;
+  const E* ph = hint == 1 ? p1 : p0;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int64_t i = tid + (int64_t)e * NT;
     const int64_t ic = vo + (i < N ? i : (N - 1));
-    s.xv[e] = x[ic];  // only workgroup 0 stores x, but a late load would queue behind the slab
-    s.pa[e] = p0[ic];
-    s.pb[e] = p1[ic];
-    s.ra[e] = r0[ic];
-    s.rb[e] = r1[ic];
+    if constexpr (HINTED) {
+      s.xv[e] = writer ? x[ic] : elem<E>::zero();  // only workgroup 0 stores x
+      s.pa[e] = s.pb[e] = ph[ic];
+      s.ra[e] = s.rb[e] = rh[ic];
+    } else {
+      s.xv[e] = x[ic];  // only workgroup 0 stores x, but a late load would queue behind the slab
+      s.pa[e] = p0[ic];
+      s.pb[e] = p1[ic];
+      s.ra[e] = r0[ic];
+      s.rb[e] = r1[ic];
+    }
     s.vv[e] = v[ic];
   }
   const int dtid = tid < ndots ? tid : 0;  // clamped address; dead lanes zeroed by the caller
@@ -333,11 +347,11 @@ __device__ static inline void pipe_load_small(pipe_small<E, EPT>& s, const E* x,
 
 // CG update of one right-hand side (every workgroup redundantly; workgroup 0 stores) followed by the
 // two products from the register slab.  Wave-uniform control flow: every thread reads the same scalars.
-template <typename E, int G, int K, int WV, bool FULL>
+template <typename E, int G, int K, int WV, bool FULL, bool HINTED>
 __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L,
                                                pipe_small<E, slab_cfg<E, G, K, WV>::EPT>& sm, E* x, E* r0, E* p0,
                                                E* r1, E* p1, E* slab_b, const cgnr_scalars* sc_b, cgnr_scalars* scn_b,
-                                               int ndots, int64_t Mc, int64_t N, int64_t vo, int pair) {
+                                               int ndots, int64_t Mc, int64_t N, int64_t vo, int pair, int hint) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int EPT = C::EPT;
   const int tid = threadIdx.x;
@@ -359,6 +373,21 @@ __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], s
     pv[e] = S.cur ? sm.pb[e] : sm.pa[e];
     rv[e] = S.cur ? sm.rb[e] : sm.ra[e];
     if (i >= N) pv[e] = elem<E>::zero();
+  }
+  if constexpr (HINTED) {
+    if (S.cur != hint) {  // wrong hint (never with the host's bookkeeping): fetch the right pair, late
+      const E* rc = (S.cur ? r1 : r0) + vo;
+      const E* pc = (S.cur ? p1 : p0) + vo;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        const int64_t ic = i < N ? i : (N - 1);
+        pv[e] = pc[ic];
+        rv[e] = rc[ic];
+        if (i >= N) pv[e] = elem<E>::zero();
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) HERE, so that the common path has nothing to wait for at the join
+    }
   }
   STAMP(2);
   cgnr_scalars Sn;
@@ -410,9 +439,10 @@ __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], s
 struct pipe_rhs_ptrs {
   int64_t vstride, slab_stride;
   int nrhs;
+  int hint;  // rls_cgnr_pipe::cur_hint
 };
 
-template <typename E, int G, int K, int WV, bool FULL, bool BATCHED>
+template <typename E, int G, int K, int WV, bool FULL, bool BATCHED, bool HINTED>
 __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* __restrict__ x,
                                                                E* r0, E* p0, E* r1, E* p1, const E* __restrict__ v,
                                                                E* __restrict__ slab, const double* __restrict__ dots,
@@ -429,7 +459,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
   // barrier makes sure no wave has slab loads queued in front of another wave's small loads, and only
   // then the 256 KiB slab goes out; the CG update runs under its flight.
   pipe_small<E, C::EPT> sm;
-  pipe_load_small<E, C::EPT, C::NT>(sm, x, r0, p0, r1, p1, v, dots, ndots, N, 0, 0);
+  pipe_load_small<E, C::EPT, C::NT, HINTED>(sm, x, r0, p0, r1, p1, v, dots, ndots, N, 0, 0, R.hint);
   if (order_mode == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
@@ -440,15 +470,15 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   STAMP(1);
-  pipe_process_rhs<E, G, K, WV, FULL>(a, L, sm, x, r0, p0, r1, p1, slab, sc, scn, ndots, Mc, N, 0, pair);
+  pipe_process_rhs<E, G, K, WV, FULL, HINTED>(a, L, sm, x, r0, p0, r1, p1, slab, sc, scn, ndots, Mc, N, 0, pair, R.hint);
   // further right-hand sides reuse the registers (a separate instantiation: with the loop present the
   // compiler hoists per-load address math out of it and the single-RHS kernel spills)
   if constexpr (BATCHED)
   for (int b = 1; b < R.nrhs; ++b) {
     const int64_t vo = (int64_t)b * R.vstride;
-    pipe_load_small<E, C::EPT, C::NT>(sm, x, r0, p0, r1, p1, v, dots, ndots, N, vo, b);
-    pipe_process_rhs<E, G, K, WV, FULL>(a, L, sm, x, r0, p0, r1, p1, slab + (int64_t)b * R.slab_stride, sc + b, scn + b,
-                                         ndots, Mc, N, vo, pair);
+    pipe_load_small<E, C::EPT, C::NT, HINTED>(sm, x, r0, p0, r1, p1, v, dots, ndots, N, vo, b, R.hint);
+    pipe_process_rhs<E, G, K, WV, FULL, HINTED>(a, L, sm, x, r0, p0, r1, p1, slab + (int64_t)b * R.slab_stride, sc + b,
+                                                 scn + b, ndots, Mc, N, vo, pair, R.hint);
   }
 }
 
@@ -1345,6 +1375,7 @@ static pipe_rhs_ptrs rhs_of(const rls_cgnr_pipe& P, int nwg) {
   R.nrhs = P.nrhs > 0 ? P.nrhs : 1;
   R.vstride = P.vstride;
   R.slab_stride = (int64_t)nwg * P.N;
+  R.hint = P.cur_hint;
   return R;
 }
 
@@ -1356,22 +1387,27 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   static bool attr_set = false;
   if (!attr_set) {
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false>, lds);
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false>, lds);
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, true>, lds);
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, true>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, false>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, false>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, true, false>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, true, false>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, true>, lds);
+    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, true>, lds);
     attr_set = true;
   }
   const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
   const bool batched = P.nrhs > 1;
-#define RLS_LAUNCH_A(FULLV, BATCHV)                                                                                  \
-  hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV>), dim3(nwg), dim3(C::NT), lds, ctx->stream,      \
-                     (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, (E*)P.slab, \
+  const bool hinted = !batched && P.cur_hint >= 0;  // single right-hand side: the hinted instantiation
+#define RLS_LAUNCH_A(FULLV, BATCHV, HINTV)                                                                            \
+  hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV, HINTV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, \
+                     (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, (E*)P.slab,   \
                      P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, rhs_of(P, nwg))
-  if (full && !batched) RLS_LAUNCH_A(true, false);
-  else if (!full && !batched) RLS_LAUNCH_A(false, false);
-  else if (full) RLS_LAUNCH_A(true, true);
-  else RLS_LAUNCH_A(false, true);
+  if (full && hinted) RLS_LAUNCH_A(true, false, true);
+  else if (hinted) RLS_LAUNCH_A(false, false, true);
+  else if (full && !batched) RLS_LAUNCH_A(true, false, false);
+  else if (!full && !batched) RLS_LAUNCH_A(false, false, false);
+  else if (full) RLS_LAUNCH_A(true, true, false);
+  else RLS_LAUNCH_A(false, true, false);
 #undef RLS_LAUNCH_A
 }
 

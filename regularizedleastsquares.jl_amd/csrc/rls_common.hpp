@@ -22,6 +22,8 @@ struct rls_tuning {
   int cgnr_pipeline = 1; // 1: CGNR as slab kernel (with the CG update in its prologue) + reduce kernel
   int batched_mfma = 1;  // 1: batched plans run the two skinny products on the matrix cores (skinny.hip)
   int gram_pipeline = 1; // 1: Gram-mode CGNR as one launch per iteration (normal.hip)
+  int pipe_hint_mode = 0; // (r, p) pair hints of the slab pipeline: 0 = host bookkeeping, 1 = always "unknown",
+                          // 2 = deliberately wrong (tests: exercises the kernel's check-and-reload path)
 };
 
 struct rls_ctx {
@@ -406,6 +408,10 @@ struct rls_cgnr_pipe {
   cgnr_scalars *sc, *scn;  // [nrhs]
   int nrhs = 1;            // right-hand sides sharing one pass over A
   int64_t vstride = 0;     // elements between consecutive right-hand sides in x, r, p, v
+  // which (r, p) pair is current when this launch runs, if the host knows (every step call starts at pair 0 and
+  // each launch with a pending update flips it); -1 = unknown: the kernel then loads both candidates.  A hint
+  // only: the kernel checks it against the device scalars and re-loads if it is wrong.
+  int cur_hint = -1;
 };
 int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);

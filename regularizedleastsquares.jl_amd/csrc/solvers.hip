@@ -84,6 +84,19 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
   return 0;
 }
 
+// Which (r, p) pair launch k of a step call finds current (rls_cgnr_pipe::cur_hint): the call starts at pair 0
+// with nothing pending, launch 0 flips nothing, every later launch flips.  Launches at a chunk boundary may be
+// the first node of a REPLAYED graph, whose captured hint belongs to another position in the sequence, so they
+// get "unknown"; so does everything when the chunk length is odd (replays would be out of phase).
+static inline int pipe_cur_hint(const rls_ctx* ctx, int k) {
+  const int chunk = ctx->tune.graph_chunk;
+  if (ctx->tune.pipe_hint_mode == 1) return -1;
+  if (ctx->tune.pipe_hint_mode == 2) return k == 0 ? 1 : (k & 1);  // the opposite of the bookkeeping below
+  if (k == 0) return (ctx->tune.use_graph && chunk > 1) ? -1 : 0;
+  if (ctx->tune.use_graph && chunk > 1 && (chunk % 2 != 0 || k % chunk == 0)) return -1;
+  return (k - 1) & 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // CGNR
 // ---------------------------------------------------------------------------------------------
@@ -1142,7 +1155,7 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
                          (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->psc, rho, reltol,
                          maxiter, Fc);
     RLS_TRY(launch_status(ctx));
-    const rls_cgnr_pipe P = cg_pipe_desc(s, x);
+    rls_cgnr_pipe P = cg_pipe_desc(s, x);
     const int32_t dtype = op->dtype;
     if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 1)) {  // the captured kernels carry x's address
       hipGraphExecDestroy(s->graph.exec);
@@ -1150,7 +1163,11 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     }
     s->graph.x_bound = x;
     s->graph.mode = 1;
-    RLS_TRY(run_steps(ctx, &s->graph, maxiter, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
+    int k = 0;
+    RLS_TRY(run_steps(ctx, &s->graph, maxiter, [ctx, dtype, &P, &k]() {
+      P.cur_hint = pipe_cur_hint(ctx, k++);
+      return rls_cgnr_pipe_iteration(ctx, dtype, P);
+    }));
     return rls_cgnr_pipe_finish(ctx, dtype, P);
   }
   if (op->dtype == RLS_F32)
@@ -1528,14 +1545,18 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
   if (cgnr_use_pipeline(s)) {
     // iteration k = K_A (applies update k-1 in its prologue, then one pass over A) + K_R; the last
     // update of this call is applied by K_F, which also returns r, p to the caller's vectors
-    const rls_cgnr_pipe P = cgnr_pipe_desc(s);
+    rls_cgnr_pipe P = cgnr_pipe_desc(s);
     const int32_t dtype = s->op->dtype;
     if (s->graph.steps && s->graph.mode != 1) {  // graph captured for the other kernel sequence
       hipGraphExecDestroy(s->graph.exec);
       s->graph = step_graph();
     }
     s->graph.mode = 1;
-    RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P]() { return rls_cgnr_pipe_iteration(ctx, dtype, P); }));
+    int k = 0;
+    RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P, &k]() {
+      P.cur_hint = pipe_cur_hint(ctx, k++);
+      return rls_cgnr_pipe_iteration(ctx, dtype, P);
+    }));
     return rls_cgnr_pipe_finish(ctx, dtype, P);
   }
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR: fused pipeline switched off");
@@ -1558,9 +1579,10 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step_profiled before cgnr_init");
   if (!cgnr_use_pipeline(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr_step_profiled: fused pipeline not active");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  const rls_cgnr_pipe P = cgnr_pipe_desc(s);
+  rls_cgnr_pipe P = cgnr_pipe_desc(s);
   const int32_t dtype = s->op->dtype;
   RLS_TRY(rls_cgnr_pipe_iteration(ctx, dtype, P));  // leaves an update pending: K_A then does full work
+  P.cur_hint = 0;  // ... on pair 0, every time (the reduce kernel that would commit the flip is not run in between)
   hipEvent_t ev[3];
   for (auto& e : ev) RLS_HIP(ctx, hipEventCreate(&e));
   int32_t st = 0;

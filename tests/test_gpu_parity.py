@@ -1703,3 +1703,30 @@ def test_plan_entry_points_reject_misuse(rls, ctx):
     assert lib.rls_stats(h, 0, 0, v[0].ptr, d) == -1 and lib.rls_gather(h, 0, 4, None, v[0].ptr, v[1].ptr) == -1
     assert lib.rls_optista_update_async(h, 0, 24, v[0].ptr, v[1].ptr, v[2].ptr, v[3].ptr, v[4].ptr, v[5].ptr, 0.1, 1, 0.1,
                                         1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, None) == -1
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pipeline_pair_hint_is_only_a_hint(rls, ctx, mode):
+    """the 2-launch CGNR / cg! pipeline is told by the host which (r, p) buffer pair is current so that it loads one
+    pair instead of both; the kernel checks the hint against the device scalars: with the hint withheld (mode 1) or
+    deliberately inverted (mode 2: every launch takes the check-and-reload path) the results are bit-identical"""
+    A, xt, b = O.make_problem(4096, 2048, np.complex64, 2)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    Ar, xr, br = O.make_problem(256, 128, np.float32, 3)
+    Ard, brd = rls.DeviceMatrix.from_host(Ar), rls.DeviceVector.from_host(br)
+
+    def run():
+        S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=37, relTol=0.0)
+        x1 = rls.solve_(S, bd).to_host()
+        T = rls.createLinearSolver(rls.ADMM, Ard, reg=rls.L1Regularization(0.02), rho=0.3, iterations=4, iterationsCG=7, tolInner=1e-6)
+        x2 = rls.solve_(T, brd).to_host()
+        return x1, x2, S.state.iteration
+
+    want = run()
+    ctx.tune(pipe_hint_mode=mode)
+    try:
+        got = run()
+    finally:
+        ctx.tune(pipe_hint_mode=0)
+    assert got[2] == want[2] == 37
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
