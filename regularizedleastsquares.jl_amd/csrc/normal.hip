@@ -726,32 +726,40 @@ __device__ static inline bool fista_update_elems(const fista_scalars& S, const E
   return done != 0;
 }
 
-template <typename E, int G, int K, int WV, bool FULL>
+template <typename E, int G, int K, int WV, bool FULL, bool HINTED>
 __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
                                                                 const E* __restrict__ x0, E* __restrict__ res, E* y0,
                                                                 E* y1, const E* __restrict__ res_raw,
                                                                 E* __restrict__ slab,
                                                                 const fista_scalars* __restrict__ sc,
                                                                 fista_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                                int pair) {
+                                                                int pair, int hint) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int EPT = C::EPT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
   const int tid = threadIdx.x;
   const bool writer = blockIdx.x == 0;
-  // small loads first (both candidates of every ping-pong pair), barrier, then the slab: see K_A of CGNR
+  // small loads first, barrier, then the slab: see K_A of CGNR.  Both candidates of each ping-pong pair unless the
+  // host passed the parity of the iteration count (HINTED: 16 loads per lane instead of 24)
   E raw[EPT], x0v[EPT], ya[EPT], yb[EPT], ba[EPT], bb[EPT];
+  const E* yh = hint == 1 ? y1 : y0;
+  const E* bh = hint == 1 ? b1 : b0;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int64_t i = tid + (int64_t)e * C::NT;
     const int64_t ic = i < N ? i : (N - 1);
     raw[e] = res_raw[ic];
     x0v[e] = x0[ic];
-    ya[e] = y0[ic];
-    yb[e] = y1[ic];
-    ba[e] = b0[ic];
-    bb[e] = b1[ic];
+    if constexpr (HINTED) {
+      ya[e] = yb[e] = yh[ic];
+      ba[e] = bb[e] = bh[ic];
+    } else {
+      ya[e] = y0[ic];
+      yb[e] = y1[ic];
+      ba[e] = b0[ic];
+      bb[e] = b1[ic];
+    }
   }
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -776,6 +784,21 @@ __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restri
     yv[e] = S.ycur ? yb[e] : ya[e];
     xk[e] = (S.iteration & 1) ? bb[e] : ba[e];  // state.x == buf[iteration & 1]
     if (i >= N) yv[e] = elem<E>::zero();
+  }
+  if constexpr (HINTED) {
+    if (S.ycur != hint || (S.iteration & 1) != hint) {  // wrong hint (never with the host's bookkeeping): re-load, late
+      const E* yc = S.ycur ? y1 : y0;
+      const E* bc = (S.iteration & 1) ? b1 : b0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        const int64_t ic = i < N ? i : (N - 1);
+        yv[e] = yc[ic];
+        xk[e] = bc[ic];
+        if (i >= N) yv[e] = elem<E>::zero();
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) inside the branch: nothing to wait for at the join otherwise
+    }
   }
   fista_scalars Sn;
   if (S.pending) {
@@ -1474,16 +1497,21 @@ static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg) {
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   static bool attr_set = false;
   if (!attr_set) {
-    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true>, lds);
-    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false>, lds);
+    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, false>, lds);
+    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, false>, lds);
+    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, true>, lds);
+    allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, true>, lds);
     attr_set = true;
   }
-#define RLS_LAUNCH_FA(FULLV)                                                                                       \
-  hipLaunchKernelGGL((fista_pipe_a_kernel<E, G, K, WV, FULLV>), dim3(nwg), dim3(C::NT), lds, ctx->stream,           \
+  const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
+#define RLS_LAUNCH_FA(FULLV, HINTV)                                                                                 \
+  hipLaunchKernelGGL((fista_pipe_a_kernel<E, G, K, WV, FULLV, HINTV>), dim3(nwg), dim3(C::NT), lds, ctx->stream,     \
                      (const E*)P.A, P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1,      \
-                     (const E*)P.res_raw, (E*)P.slab, P.sc, P.scn, Mc, P.N, pair)
-  if (P.N == C::NMAX && (int64_t)nwg * G == Mc) RLS_LAUNCH_FA(true);
-  else RLS_LAUNCH_FA(false);
+                     (const E*)P.res_raw, (E*)P.slab, P.sc, P.scn, Mc, P.N, pair, P.par_hint)
+  if (full && P.par_hint >= 0) RLS_LAUNCH_FA(true, true);
+  else if (P.par_hint >= 0) RLS_LAUNCH_FA(false, true);
+  else if (full) RLS_LAUNCH_FA(true, false);
+  else RLS_LAUNCH_FA(false, false);
 #undef RLS_LAUNCH_FA
 }
 

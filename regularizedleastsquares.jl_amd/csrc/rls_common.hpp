@@ -394,6 +394,8 @@ struct rls_fista_pipe {
   void *y0, *y1;        // extrapolated point, ping-pong (plan scratch)
   void *res_raw, *slab; // AHA y before "- x0" ; per-workgroup partial rows
   fista_scalars *sc, *scn;
+  int par_hint = -1;    // parity of the iteration count (= which y / x buffer is current) at this launch, or -1;
+                        // a hint checked on the device, like rls_cgnr_pipe::cur_hint
 };
 int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
 int32_t rls_fista_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);

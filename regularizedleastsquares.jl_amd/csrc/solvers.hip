@@ -357,6 +357,8 @@ struct rls_fista {
   void* Vpart = nullptr;
   int splits = 1;
   fista_scalars* scb_h = nullptr;  // pinned [nrhs]
+  int enq = 0;           // iterations enqueued since init (== the device's count unless the plan stopped early)
+  int graph_parity = 0;  // parity of `enq` the cached graph's buffer hints were captured with
 };
 
 // batched launches: workgroup b = column b.  Vpart non-null: AHA y arrives as `S` partial rows per column and is
@@ -1766,6 +1768,7 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
                        (float2*)s->buf[1], (float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc, rho,
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
                        (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
+  s->enq = 0;
   s->initialised = true;
   // row-sharded plans exchange `res` between the operator apply and the update: two-half iterations only
   const bool gram = !local && fista_gram_ok(s);
@@ -1959,9 +1962,25 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   if (s->use_pipe) {
     // iteration k = K_A (applies the gradient/prox/momentum update k-1 in its prologue, then one pass
     // over A for AHA y) + K_R (sums the partial rows); the last update of this call is applied by K_F
-    const rls_fista_pipe P = fista_pipe_desc(s);
+    rls_fista_pipe P = fista_pipe_desc(s);
     const int32_t dtype = s->op->dtype;
-    RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P]() { return rls_fista_pipe_iteration(ctx, dtype, P); }));
+    // buffer hints: launch k >= 1 of this call finds iteration count enq + k - 1 (launch 0 applies nothing); the
+    // hints a cached graph carries belong to the parity of `enq` it was captured with
+    const int it0 = s->enq;
+    if (s->graph.exec && s->graph_parity != (it0 & 1)) {
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph_parity = it0 & 1;
+    int k = 0;
+    RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P, &k, it0]() {
+      const int h = pipe_cur_hint(ctx, k);  // -1 where the position may be replayed out of sequence
+      P.par_hint = h < 0 ? -1 : ((it0 + (k > 0 ? k - 1 : 0)) & 1);
+      if (h >= 0 && ctx->tune.pipe_hint_mode == 2) P.par_hint ^= 1;  // tests: exercise the check-and-reload path
+      ++k;
+      return rls_fista_pipe_iteration(ctx, dtype, P);
+    }));
+    s->enq += n_steps;
     return rls_fista_pipe_finish(ctx, dtype, P);
   }
   return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_iteration(s); });

@@ -1720,7 +1720,13 @@ def test_pipeline_pair_hint_is_only_a_hint(rls, ctx, mode):
         x1 = rls.solve_(S, bd).to_host()
         T = rls.createLinearSolver(rls.ADMM, Ard, reg=rls.L1Regularization(0.02), rho=0.3, iterations=4, iterationsCG=7, tolInner=1e-6)
         x2 = rls.solve_(T, brd).to_host()
-        return x1, x2, S.state.iteration
+        F = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=0.9 / (64 + 45.3) ** 2, iterations=35, relTol=0.0)
+        x3 = rls.solve_(F, bd).to_host()
+        rls.init_(F, bd)   # iteration by iteration: every call starts at another parity of the iteration count
+        for _ in range(5):
+            rls.iterate(F)
+        x4 = F.state.x.to_host() if hasattr(F.state, "x") else None
+        return x1, x2, S.state.iteration, x3, x4
 
     want = run()
     ctx.tune(pipe_hint_mode=mode)
@@ -1730,3 +1736,4 @@ def test_pipeline_pair_hint_is_only_a_hint(rls, ctx, mode):
         ctx.tune(pipe_hint_mode=0)
     assert got[2] == want[2] == 37
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4])
