@@ -989,7 +989,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
   for (int e = 0; e < EPT; ++e) {
     const int64_t i = tid + (int64_t)e * C::NT;
     const int64_t ic = i < N ? i : (N - 1);
-    xv[e] = x[ic];
+    xv[e] = writer ? x[ic] : elem<E>::zero();  // only workgroup 0 stores x
     pv[e] = pc[ic];
     rv[e] = rc[ic];
     vv[e] = vc[ic];

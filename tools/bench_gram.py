@@ -19,5 +19,6 @@ for name, kw in (("gram", dict(AHA=G)), ("matrix-free", {})):
     def run(n):
         for _ in range(n):
             rls.init_(S, b); rls._lib.check(h, lib.rls_cgnr_step(S.state._plan, 32), "step")
+    run(60); ctx.sync()  # the first long host wait of a process returns ~50 ms late, once (tools/stall_probe2.py): take it here
     run(5); ctx.sync(); ctx.timer_start(); run(40); us = ctx.timer_stop_ms() * 1e3 / (40 * 32)
     print(f"{name:12s}: {us:6.2f} us per iteration ({1e6/us:7.0f} it/s), err {np.linalg.norm(xs-x)/np.linalg.norm(x):.1e}")
