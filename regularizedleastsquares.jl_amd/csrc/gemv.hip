@@ -148,16 +148,44 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_n_kernel(const E* __restrict_
 
   for (int64_t t0 = 0; t0 < N; t0 += TILE) {
     const int nt = (int)((N - t0) < TILE ? (N - t0) : TILE);
-    __syncthreads();
-    for (int i = tid; i < nt; i += THREADS) xs[i] = x[t0 + i];
-    __syncthreads();
-    // full rounds (every slot of every wave has a valid column) run unpredicated, U loads in
-    // flight per lane; the remainder clamps the column and zeroes x instead of branching
     const E* At = Ab + t0 * lda;
     const int slot = w * S + s;
     const int full_rounds = nt / CPR;
     const int main_rounds = (full_rounds / U) * U;
-    for (int k = 0; k < main_rounds; k += U) {
+    // The x tile goes to registers first and the first U loads of A go out right behind it, BEFORE the tile is
+    // written to LDS: the staging then hides under the first loads' latency instead of preceding it (the barriers
+    // order LDS only -- __syncthreads() would wait for the A loads as well).  Clamped columns, no branch around loads.
+    constexpr int XPT = (TILE + THREADS - 1) / THREADS;
+    E xr[XPT];
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int i = tid + j * THREADS;
+      xr[j] = x[t0 + (i < nt ? i : nt - 1)];
+    }
+    chunk<E, NV> a0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int jl = u * CPR + slot;
+      a0[u] = load_chunk<E, NV>(At + (int64_t)(jl < nt ? jl : nt - 1) * lda);
+    }
+    lds_barrier();  // the previous tile's readers are done
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int i = tid + j * THREADS;
+      if (i < nt) xs[i] = xr[j];
+    }
+    lds_barrier();
+    if (main_rounds > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const E xv = xs[u * CPR + slot];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a0[u].e[i], xv, acc[i]);
+      }
+    }
+    // full rounds (every slot of every wave has a valid column) run unpredicated, U loads in
+    // flight per lane; the remainder clamps the column and zeroes x instead of branching
+    for (int k = U; k < main_rounds; k += U) {
       chunk<E, NV> a[U];
       E xv[U];
 #pragma unroll
