@@ -63,7 +63,7 @@ int32_t rls_ctx_create_on_stream(int32_t device, void* hip_stream, rls_ctx** out
 int32_t rls_ctx_destroy(rls_ctx* ctx) {
   RLS_CHECK_CTX(ctx);
   hipSetDevice(ctx->device);
-  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) rls_stream_wait(ctx->stream);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->red_d) hipFree(ctx->red_d);
@@ -77,7 +77,7 @@ int32_t rls_ctx_destroy(rls_ctx* ctx) {
 int32_t rls_ctx_sync(rls_ctx* ctx) {
   RLS_CHECK_CTX(ctx);
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   return 0;
 }
 
@@ -136,7 +136,7 @@ int32_t rls_free(rls_ctx* ctx, void* p) {
   RLS_CHECK_CTX(ctx);
   if (!p) return 0;
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   RLS_HIP(ctx, hipFree(p));
   return 0;
 }
@@ -148,7 +148,7 @@ int32_t rls_memcpy_h2d(rls_ctx* ctx, void* dst, const void* src_h, size_t bytes)
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   // pageable host memory: the copy is staged, so wait for it before the caller may reuse src_h
   RLS_HIP(ctx, hipMemcpyAsync(dst, src_h, bytes, hipMemcpyHostToDevice, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   return 0;
 }
 
@@ -158,7 +158,7 @@ int32_t rls_memcpy_d2h(rls_ctx* ctx, void* dst_h, const void* src, size_t bytes)
   if (!dst_h || !src) return rls_fail(ctx, RLS_E_INVALID, "memcpy_d2h: null pointer");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   RLS_HIP(ctx, hipMemcpyAsync(dst_h, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   return 0;
 }
 
@@ -183,7 +183,7 @@ int32_t rls_timer_stop_ms(rls_ctx* ctx, float* ms_out) {
   if (!ms_out) return rls_fail(ctx, RLS_E_INVALID, "timer_stop: null out");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   RLS_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  RLS_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  RLS_HIP(ctx, rls_event_wait(ctx->ev1));
   RLS_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
   return 0;
 }

@@ -120,7 +120,7 @@ int32_t reduce_dispatch(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, c
 
 int32_t fetch_result(rls_ctx* ctx, float* result_h, int nfloats) {
   RLS_HIP(ctx, hipMemcpyAsync(ctx->res_h, ctx->res_d, sizeof(float) * 2, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   for (int i = 0; i < nfloats; ++i) result_h[i] = ctx->res_h[i];
   return 0;
 }

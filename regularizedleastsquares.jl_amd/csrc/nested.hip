@@ -191,7 +191,7 @@ int32_t rls_stats(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, double*
   hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_d, nwg, fin);
   RLS_TRY(ns_status(ctx));
   RLS_HIP(ctx, hipMemcpyAsync(out_h, fin, sizeof(double) * NSTAT, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   return 0;
 }
 

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict_
 
 static int32_t pgm_fetch(rls_ctx* ctx, float* out_h, int nfloats) {
   RLS_HIP(ctx, hipMemcpyAsync(ctx->res_h, ctx->res_d, sizeof(float) * (size_t)nfloats, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   for (int i = 0; i < nfloats; ++i) out_h[i] = ctx->res_h[i];
   return 0;
 }

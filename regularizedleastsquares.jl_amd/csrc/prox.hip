@@ -169,7 +169,7 @@ int32_t rls_norm_l21(rls_ctx* ctx, int32_t dtype, int64_t n, int64_t slices, con
   hipLaunchKernelGGL(l21_norm_final, dim3(1), dim3(256), 0, ctx->stream, ctx->red_d, (int)g, lambda, ctx->res_d);
   RLS_TRY(px_status(ctx));
   RLS_HIP(ctx, hipMemcpyAsync(ctx->res_h, ctx->res_d, sizeof(float) * 2, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   result_h[0] = ctx->res_h[0];
   return 0;
 }

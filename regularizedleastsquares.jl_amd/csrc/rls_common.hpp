@@ -39,6 +39,27 @@ struct rls_ctx {
   rls_tuning tune;
 };
 
+// Host-side waits poll (hipStreamQuery / hipEventQuery) instead of blocking.  A blocking wait sleeps on an interrupt and
+// on this stack now and then wakes up tens of milliseconds late (tools/stall_probe2.py: wall 123 ms for 75 ms of
+// events) -- invisible in hipEvent times, but it is wall-clock latency of every status read-back and of the solve
+// as a whole.  Polling is bounded: after ~2 s it falls back to the blocking call.
+static inline hipError_t rls_stream_wait(hipStream_t s) {
+  for (long spins = 0; spins < 400000000L; ++spins) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    __builtin_ia32_pause();
+  }
+  return hipStreamSynchronize(s);
+}
+static inline hipError_t rls_event_wait(hipEvent_t ev) {
+  for (long spins = 0; spins < 400000000L; ++spins) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    __builtin_ia32_pause();
+  }
+  return hipEventSynchronize(ev);
+}
+
 constexpr int RLS_RED_SLOTS = 4096;
 constexpr int RLS_RES_FLOATS = 64;
 

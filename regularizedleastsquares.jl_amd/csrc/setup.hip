@@ -56,7 +56,7 @@ int32_t rls_rownorm2(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const vo
                        partial);
   hipLaunchKernelGGL(rownorm2_sum_kernel, dim3(grid.x), dim3(256), 0, ctx->stream, partial, CS, M, out_d);
   int32_t st = setup_status(ctx);
-  hipError_t e = hipStreamSynchronize(ctx->stream);  // setup path: the scratch is freed before returning
+  hipError_t e = rls_stream_wait(ctx->stream);  // setup path: the scratch is freed before returning
   hipFree(partial);
   if (st == 0 && e != hipSuccess) st = rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
   return st;

@@ -919,7 +919,7 @@ static int32_t alloc_scalars(rls_ctx* ctx, S** d, S** h) {
 template <typename S>
 static int32_t fetch_scalars(rls_ctx* ctx, S* d, S* h) {
   RLS_HIP(ctx, hipMemcpyAsync(h, d, sizeof(S), hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   return 0;
 }
 
@@ -1280,7 +1280,7 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
     RLS_HIP(ctx, hipMalloc(&panels, (size_t)M * (size_t)N * rls_elem_size(dtype)));
     int32_t st = rls_skinny_gram(ctx, dtype, M, N, A, lda, G, ld, panels);
     if (st == 0) st = gram_hermitianize(ctx, dtype, N, G, ld);
-    hipError_t e = hipStreamSynchronize(ctx->stream);  // setup path: the scratch is freed before returning
+    hipError_t e = rls_stream_wait(ctx->stream);  // setup path: the scratch is freed before returning
     hipFree(panels);
     if (st == 0 && e != hipSuccess) st = rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
     return st;
@@ -1488,7 +1488,7 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   RLS_HIP(ctx, hipMemcpyAsync(s->sc_h, s->sc, sizeof(cgnr_scalars) * (size_t)s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   for (int b = 0; b < s->nrhs; ++b) {
     const cgnr_scalars& h = s->sc_h[b];
     out[b].iteration = h.iteration;
@@ -1593,7 +1593,7 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
   RLS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
   for (int i = 0; i < n_steps && st == 0; ++i) st = rls_cgnr_pipe_launch(ctx, dtype, P, 2);
   RLS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-  RLS_HIP(ctx, hipEventSynchronize(ev[2]));
+  RLS_HIP(ctx, rls_event_wait(ev[2]));
   float a = 0.f, r = 0.f;
   RLS_HIP(ctx, hipEventElapsedTime(&a, ev[0], ev[1]));
   RLS_HIP(ctx, hipEventElapsedTime(&r, ev[1], ev[2]));
@@ -1905,7 +1905,7 @@ int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out) {
   if (!s->initialised || !s->scb_h) return rls_fail(ctx, RLS_E_STATE, "fista_get_status_batched: not a batched, initialised plan");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   RLS_HIP(ctx, hipMemcpyAsync(s->scb_h, s->sc, sizeof(fista_scalars) * s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   for (int b = 0; b < s->nrhs; ++b) {
     const fista_scalars& h = s->scb_h[b];
     out[b].iteration = h.iteration;
@@ -2192,7 +2192,7 @@ int32_t rls_admm_post(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, con
                        (const float2*)xold, (const float2*)z, (const float2*)zold, (float2*)u, n, ctx->res_d);
   RLS_TRY(launch_status(ctx));
   RLS_HIP(ctx, hipMemcpyAsync(ctx->res_h, ctx->res_d, sizeof(float) * 6, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   for (int i = 0; i < 6; ++i) out_h[i] = ctx->res_h[i];
   return 0;
 }
