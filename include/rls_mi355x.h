@@ -192,6 +192,14 @@ int32_t rls_pogm_update_async(rls_ctx* ctx, int32_t dtype, int64_t n, void* res,
                               void* xold, void* z, float rho, float c_y, float c_x1, float c_xo, float c_z,
                               int32_t reg_kind, float thr, int32_t proj_kind, float norm_x0, float rel_tol,
                               void* state_d);
+/* POGM with restart = :gradient, deferred: theta, sigma, gamma live in the device record (8 words: int32 iteration,
+ * int32 done, float ||res||, pad, float theta, theta_old, sigma, gamma) and every launch derives its coefficients
+ * from them in Float32 with the host's operation order (src/POGM.jl:183-201), applies the update, evaluates the
+ * restart criterion (:218-232) and the stopping test.  The caller sets theta, sigma, gamma before the first
+ * iteration, alternates xbuf / ybuf between launches, and reads the record back after the last one. */
+int32_t rls_pogm_update_auto(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                             void* xold, void* z, void* w, float rho, float lambda, float sigma_fac, int32_t iterations,
+                             int32_t reg_kind, int32_t proj_kind, float norm_x0, float rel_tol, void* state_d);
 /* At = transpose(A) (no conjugation): N x M column-major, leading dimension ldat >= N.  Row k of A becomes the
  * contiguous column k of At -- the "structure for row access" that the reference's row-action solvers ask for
  * (createLinearSolver(Kaczmarz, transpose(A_T)), src/Kaczmarz.jl:391, dot_with_matrix_row(::Transpose…)

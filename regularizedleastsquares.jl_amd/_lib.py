@@ -115,6 +115,7 @@ PROTOTYPES = {
                                         _f, _f, _vp]),
     "rls_pogm_update_async": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i32, _f, _i32,
                                      _f, _f, _vp]),
+    "rls_pogm_update_auto": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i32, _i32, _i32, _f, _f, _vp]),
     "rls_operator_mul_normal_skip": (_i32, [_vp, _vp, _vp, _vp]),
     "rls_transpose": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _i64]),
     "rls_kaczmarz_sweep": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32,

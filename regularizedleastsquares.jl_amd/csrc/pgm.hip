@@ -64,18 +64,14 @@ __global__ __launch_bounds__(PGM_THREADS) void optista_update_kernel(E* __restri
 
 // xbuf holds x_k, ybuf holds y_{k-1} on entry; on exit xbuf holds the gradient point (the new y after the
 // reference's swap, src/POGM.jl:203) and ybuf the new x, so the caller swaps its two references.
+// Returns (valid in every thread) ||res||^2 and, with RESTART, real <w,x>, <w,z>, <w,res>.
 template <typename E, bool RESTART>
-__global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict__ res, const E* __restrict__ x0,
-                                                                  E* __restrict__ xbuf, E* __restrict__ ybuf,
-                                                                  E* __restrict__ xold, E* __restrict__ z,
-                                                                  E* __restrict__ w, int64_t n, float rho, float c_y,
-                                                                  float c_x1, float c_xo, float c_z, int reg_kind,
-                                                                  float thr, int proj_kind, float rg,
-                                                                  float* __restrict__ out, pgm_state* state,
-                                                                  float norm_x0, float rel_tol) {
-  __shared__ double sm[48];
-  if (state && state->done) return;
-  double rn = 0.0, dwx = 0.0, dwz = 0.0, dwr = 0.0;
+__device__ static inline void pogm_update_body(E* __restrict__ res, const E* __restrict__ x0, E* __restrict__ xbuf,
+                                               E* __restrict__ ybuf, E* __restrict__ xold, E* __restrict__ z,
+                                               E* __restrict__ w, int64_t n, float rho, float c_y, float c_x1,
+                                               float c_xo, float c_z, int reg_kind, float thr, int proj_kind, float rg,
+                                               double* sm /* 48 */, double& rn, double& dwx, double& dwz, double& dwr) {
+  rn = dwx = dwz = dwr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += PGM_THREADS) {
     const E xo = xbuf[i], yp = ybuf[i];
     const E r = elem<E>::sub(res[i], x0[i]);              // res .-= x0                         :178
@@ -104,12 +100,79 @@ __global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict_
   }
   rn = block_sum(rn, sm);
   if constexpr (RESTART) block_sum3(dwx, dwz, dwr, sm);
+}
+
+template <typename E, bool RESTART>
+__global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict__ res, const E* __restrict__ x0,
+                                                                  E* __restrict__ xbuf, E* __restrict__ ybuf,
+                                                                  E* __restrict__ xold, E* __restrict__ z,
+                                                                  E* __restrict__ w, int64_t n, float rho, float c_y,
+                                                                  float c_x1, float c_xo, float c_z, int reg_kind,
+                                                                  float thr, int proj_kind, float rg,
+                                                                  float* __restrict__ out, pgm_state* state,
+                                                                  float norm_x0, float rel_tol) {
+  __shared__ double sm[48];
+  if (state && state->done) return;
+  double rn, dwx, dwz, dwr;
+  pogm_update_body<E, RESTART>(res, x0, xbuf, ybuf, xold, z, w, n, rho, c_y, c_x1, c_xo, c_z, reg_kind, thr, proj_kind, rg,
+                               sm, rn, dwx, dwz, dwr);
   if (threadIdx.x == 0) {
     out[0] = (float)sqrt(rn);
     out[1] = (float)dwx;
     out[2] = (float)dwz;
     out[3] = (float)dwr;
     pgm_state_step(state, out[0], norm_x0, rel_tol);
+  }
+}
+
+// POGM with gradient restart, deferred: theta, sigma and gamma live in the device record and the coefficients of an
+// iteration (src/POGM.jl:183-201) are formed HERE from them, in Float32 with the host's operation order (explicit
+// round-to-nearest intrinsics: no contraction), so that the data-dependent restart decision (:218-232) never has to
+// travel to the host.
+struct pogm_auto_state {
+  int iteration, done;
+  float res_norm, pad;
+  float theta, theta_old, sigma, gamma;
+};
+template <typename E>
+__global__ __launch_bounds__(PGM_THREADS) void pogm_auto_kernel(E* __restrict__ res, const E* __restrict__ x0,
+                                                                E* __restrict__ xbuf, E* __restrict__ ybuf,
+                                                                E* __restrict__ xold, E* __restrict__ z,
+                                                                E* __restrict__ w, int64_t n, float rho, float lam,
+                                                                float sigma_fac, int max_iter, int reg_kind,
+                                                                int proj_kind, pogm_auto_state* st, float norm_x0,
+                                                                float rel_tol) {
+  __shared__ double sm[48];
+  if (st->done) return;
+  float th, alpha, c_x1, gamma, c_z, c_xo, thr, rg;
+  const float tho = st->theta, sigma = st->sigma, gamma_old = st->gamma;
+  {  // one rounding per operation, as NumPy's Float32 scalars on the host (f32_mul / f32_add: never fused)
+    const bool last = st->iteration == max_iter - 1;                     // :183-187
+    const float t2 = f32_mul(f32_mul(last ? 8.f : 4.f, tho), tho);
+    th = f32_add(1.f, sqrtf(f32_add(1.f, t2))) / 2.f;  // sqrtf: correctly rounded (v_sqrt_f32 alone is not)
+    alpha = f32_sub(tho, 1.f) / th;                                      // :189
+    const float beta = f32_mul(sigma, tho) / th;                         // :190
+    c_x1 = f32_add(f32_add(1.f, alpha), beta);
+    gamma = f32_mul(rho, c_x1);                                          // :195  rho (1 + alpha + beta)
+    c_z = f32_mul(rho, alpha) / gamma_old;
+    c_xo = -f32_add(beta, c_z);
+    thr = f32_mul(gamma, lam);
+    rg = rho / gamma;
+  }
+  double rn, dwx, dwz, dwr;
+  pogm_update_body<E, true>(res, x0, xbuf, ybuf, xold, z, w, n, rho, -alpha, c_x1, c_xo, c_z, reg_kind, thr, proj_kind, rg,
+                            sm, rn, dwx, dwz, dwr);
+  if (threadIdx.x == 0) {
+    const float crit = f32_sub(f32_sub((float)dwx, (float)dwz) / gamma, (float)dwr);   // :224
+    const bool restart = crit < 0.f;
+    st->theta_old = tho;
+    st->theta = restart ? 1.f : th;
+    st->sigma = restart ? 1.f : f32_mul(sigma, sigma_fac);
+    st->gamma = gamma;
+    const float rnorm = (float)sqrt(rn);
+    st->res_norm = rnorm;
+    st->iteration += 1;
+    st->done = ((double)rnorm / (double)norm_x0) < (double)rel_tol;
   }
 }
 
@@ -208,6 +271,30 @@ int32_t rls_pogm_update_async(rls_ctx* ctx, int32_t dtype, int64_t n, void* res,
   if (!state_d) return rls_fail(ctx, RLS_E_INVALID, "pogm_update_async: null state");
   return pogm_launch(ctx, dtype, n, res, x0, xbuf, ybuf, xold, z, nullptr, rho, c_y, c_x1, c_xo, c_z, reg_kind, thr,
                      proj_kind, 0, 0.f, (pgm_state*)state_d, norm_x0, rel_tol);
+}
+
+// POGM, restart = :gradient, deferred.  state_d: 8 device words {int32 iteration, int32 done, float ||res||, pad,
+// float theta, theta_old, sigma, gamma}; the caller writes theta, sigma, gamma (and zeroes the rest) before the
+// first iteration and reads all of it back after the last.
+int32_t rls_pogm_update_auto(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
+                             void* xold, void* z, void* w, float rho, float lambda, float sigma_fac, int32_t iterations,
+                             int32_t reg_kind, int32_t proj_kind, float norm_x0, float rel_tol, void* state_d) {
+  RLS_CHECK_CTX(ctx);
+  if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !xbuf || !ybuf || !xold || !z || !w || !state_d ||
+      reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2 || proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE)
+    return rls_fail(ctx, RLS_E_INVALID, "pogm_update_auto: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == RLS_F32)
+    hipLaunchKernelGGL(pogm_auto_kernel<float>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float*)res, (const float*)x0,
+                       (float*)xbuf, (float*)ybuf, (float*)xold, (float*)z, (float*)w, n, rho, lambda, sigma_fac,
+                       iterations, reg_kind, proj_kind, (pogm_auto_state*)state_d, norm_x0, rel_tol);
+  else
+    hipLaunchKernelGGL(pogm_auto_kernel<float2>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float2*)res,
+                       (const float2*)x0, (float2*)xbuf, (float2*)ybuf, (float2*)xold, (float2*)z, (float2*)w, n, rho,
+                       lambda, sigma_fac, iterations, reg_kind, proj_kind, (pogm_auto_state*)state_d, norm_x0, rel_tol);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
 }
 
 }  // extern "C"

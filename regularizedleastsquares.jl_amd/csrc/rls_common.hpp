@@ -172,6 +172,27 @@ struct elem<float2> {
   __device__ static inline float im(float2 a) { return a.y; }
 };
 
+// Float32 multiply / add / subtract that the compiler cannot fuse into an FMA.  The library is built with
+// -ffp-contract=fast, under which the backend fuses a*b + c whatever the source says (`#pragma clang fp contract(off)`
+// and the *_rn intrinsics, which are plain operators to clang, do not stop it).  Where a device scalar must come
+// out bit-identical to the host's Float32 arithmetic (NumPy scalars: one rounding per operation) -- stopping
+// tests, the POGM coefficient recurrences -- the operations go through single instructions.
+__device__ static inline float f32_mul(float a, float b) {
+  float r;
+  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ static inline float f32_add(float a, float b) {
+  float r;
+  asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ static inline float f32_sub(float a, float b) {
+  float r;
+  asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // complex scalar carried in double precision on the device (alpha, beta, dot results)
 struct dcomplex {
   double re, im;

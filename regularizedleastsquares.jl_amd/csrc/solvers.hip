@@ -1013,14 +1013,16 @@ __global__ __launch_bounds__(UPD_THREADS) void admm_zu_kernel(E* __restrict__ x,
   block_sum3(nx, nz, nxz, sm);
   nu = block_sum(nu, sm);
   if (threadIdx.x == 0) {
+    // one rounding per operation, as the host's Float32 arithmetic (f32_mul / f32_add: never fused into an FMA)
     const float rho = sc->rho;
-    const float delta = (float)sqrt(dx) + (float)sqrt(dz) + (float)sqrt(du);
-    const float sk = __fmul_rn(rho, (float)sqrt(dz));
+    const float delta = f32_add(f32_add((float)sqrt(dx), (float)sqrt(dz)), (float)sqrt(du));
+    const float sk = f32_mul(rho, (float)sqrt(dz));
     const float eps_pri = fmaxf((float)sqrt(nx), (float)sqrt(nz));
     const float rk = (float)sqrt(nxz);
-    const float eps_dua = __fmul_rn(rho, (float)sqrt(nu));
-    const bool conv = rk < __fadd_rn(sc->sigma_abs, __fmul_rn(sc->rel_tol, eps_pri)) &&
-                      sk < __fadd_rn(sc->sigma_abs, __fmul_rn(sc->rel_tol, eps_dua));
+    const float eps_dua = f32_mul(rho, (float)sqrt(nu));
+    const float lim_pri = f32_add(sc->sigma_abs, f32_mul(sc->rel_tol, eps_pri));
+    const float lim_dua = f32_add(sc->sigma_abs, f32_mul(sc->rel_tol, eps_dua));
+    const bool conv = rk < lim_pri && sk < lim_dua;
     const int it = sc->iteration;
     float* rec = log + (int64_t)it * ADMM_REC;
     rec[0] = delta;

@@ -1184,14 +1184,37 @@ class POGM(AbstractProximalGradientSolver):
         """restart = :none without callbacks: all remaining iterations enqueued at once (index-only coefficients),
         the stopping test on the device, ONE read-back at the end; otherwise iteration by iteration"""
         fus = _fusable_kinds(self.reg, self.proj)
-        if (fus is None or self.restart != "none" or self.verbose or not isinstance(self._op, OperatorHandle)
-                or st.rel_res_norm < st.relTol):
+        if (fus is None or self.verbose or not isinstance(self._op, OperatorHandle) or st.rel_res_norm < st.relTol):
             while self.iterate(st) is not None:
                 pass
             return
         f32 = np.float32
         ctx = st.x.ctx
         lib, h = ctx.lib, ctx.handle
+        if self.restart == "gradient":
+            # theta, sigma, gamma live in the device record; every launch derives its coefficients from them and
+            # applies the restart rule itself (rls_pogm_update_auto), so nothing is read back until the end
+            if getattr(st, "_rec8", None) is None or st._rec8.ctx is not ctx:
+                st._rec8 = DeviceVector(8, np.float32, ctx)
+            init = np.zeros(8, np.float32)
+            init[4:8] = [f32(st.theta), f32(st.thetaold), f32(st.sigma), f32(st.gamma)]
+            st._rec8.copy_from_host(init)
+            rec, bufs, first = st._rec8, (st.x, st.y), st.iteration
+            for k in range(first, self.iterations):
+                xb, yb = bufs if (k - first) % 2 == 0 else bufs[::-1]
+                check(h, lib.rls_operator_mul_normal_skip(self._op.handle, xb.ptr, st.res.ptr, rec.ptr + 4), "rls_operator_mul_normal_skip")
+                check(h, lib.rls_pogm_update_auto(h, xb.code, xb.n, st.res.ptr, st.x0.ptr, xb.ptr, yb.ptr, st.xold.ptr,
+                                                  st.z.ptr, st.w.ptr, float(f32(st.rho)), float(f32(self.reg.lam)),
+                                                  float(f32(st.sigma_fac)), self.iterations, fus[0], fus[1],
+                                                  float(st.norm_x0), float(st.relTol), rec.ptr), "rls_pogm_update_auto")
+            raw = rec.to_host()  # synchronises
+            done_its = int(raw[:1].view(np.int32)[0])
+            st.iteration = first + done_its
+            st.x, st.y = bufs if done_its % 2 == 0 else bufs[::-1]
+            if done_its:
+                st.rel_res_norm = float(raw[2]) / st.norm_x0
+                st.theta, st.thetaold, st.sigma, st.gamma = (float(v) for v in raw[4:8])
+            return
         rec = _pgm_record(st, ctx)
         rho = f32(st.rho)
         bufs = (st.x, st.y)
