@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void stats_final_kernel(const double* __restri
 // mode 0: x = (x - shift) / scale        transform(::MinMaxTransform / ::ZTransform)          Transforms.jl:11,41
 // mode 1: x = x * scale + shift          inverse_transform                                    Transforms.jl:15,45
 __global__ void shift_scale_kernel(float* x, int64_t n, float shift, float scale, int mode) {
-  NS_STRIDE(i, n) x[i] = mode == 0 ? __fdiv_rn(__fsub_rn(x[i], shift), scale) : __fadd_rn(__fmul_rn(x[i], scale), shift);
+  NS_STRIDE(i, n) x[i] = mode == 0 ? f32_sub(x[i], shift) / scale : f32_add(f32_mul(x[i], scale), shift);  // never fused
 }
 __global__ void clamp_kernel(float* x, int64_t n, float lo, float hi) {
   NS_STRIDE(i, n) x[i] = fminf(fmaxf(x[i], lo), hi);
