@@ -1746,3 +1746,52 @@ def test_pipeline_pair_hint_is_only_a_hint(rls, ctx, mode):
     assert got[2] == want[2] == 37
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4])
+
+
+def test_random_shapes_svt_prox_and_batched_kaczmarz(rls, ctx):
+    """fuzz of the singular-value thresholding prox maps (random image shapes, block sizes, shifts, series lengths;
+    tall, wide and rank-deficient blocks) and of the batched Kaczmarz sweep (one workgroup per right-hand side)"""
+    rng = np.random.default_rng(20260104)
+    for k in range(14):
+        dt = np.complex64 if k % 2 == 0 else np.float32
+        dt64 = np.complex128 if dt == np.complex64 else np.float64
+        nd = int(rng.integers(1, 4))
+        shape = tuple(int(rng.integers(2, 12)) for _ in range(nd))
+        bs = tuple(int(rng.integers(1, min(5, s) + 1)) for s in shape)
+        K = int(rng.integers(1, 9))
+        shift = tuple(int(rng.integers(0, b)) for b in bs)
+        n = int(np.prod(shape)) * K
+        x = rng.standard_normal(n)
+        if dt == np.complex64:
+            x = x + 1j * rng.standard_normal(n)
+        if k % 5 == 0:  # rank-deficient blocks: repeat one frame
+            X = x.reshape(shape + (K,), order="F")
+            X[..., 1:] = X[..., :1]
+            x = X.reshape(-1, order="F")
+        x = x.astype(dt)
+        ref = O.prox_llr(x.astype(dt64), 0.7, shape, bs, shift)
+        reg = rls.LLRRegularization(0.7, shape=shape, blockSize=bs, randshift=False)
+        xd = rls.DeviceVector.from_host(x)
+        reg._call(xd, 0.7, list(shift))
+        assert rel(xd.to_host(), ref) < 5e-5, (shape, bs, K, shift, np.dtype(dt).name)
+        m, c = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        y = rng.standard_normal(m * c).astype(np.float32)
+        if dt == np.complex64:
+            y = (y + 1j * rng.standard_normal(m * c)).astype(np.complex64)
+        refn = O.prox_nuclear(y.astype(dt64), 0.9, (m, c))
+        got = rls.prox_(rls.NuclearRegularization, rls.DeviceVector.from_host(y), 0.9, svtShape=(m, c)).to_host()
+        assert np.linalg.norm(got - refn) <= 5e-5 * max(np.linalg.norm(refn), 1e-2), (m, c, np.dtype(dt).name)
+    for k in range(6):
+        dt = np.complex64 if k % 2 == 0 else np.float32
+        dt64 = np.complex128 if dt == np.complex64 else np.float64
+        M, N, K = int(rng.integers(2, 200)), int(rng.integers(1, 300)), int(rng.integers(2, 12))
+        A = rng.standard_normal((M, N)).astype(np.float32)
+        if dt == np.complex64:
+            A = (A + 1j * rng.standard_normal((M, N))).astype(np.complex64)
+        A = np.asfortranarray(A)
+        B = np.asfortranarray((A.astype(dt64) @ rng.standard_normal((N, K))).astype(dt))
+        S = rls.createLinearSolver(rls.Kaczmarz, rls.DeviceMatrix.from_host(A), reg=rls.L2Regularization(0.02), iterations=2)
+        xs = rls.solve_(S, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
+        for j in (0, K - 1):
+            refk = O.Kaczmarz(A.astype(dt64), reg=O.L2Regularization(0.02), iterations=2)
+            assert rel(xs[j].to_host(), O.solve(refk, B[:, j].astype(dt64))) < 5e-5, (M, N, K, j)
