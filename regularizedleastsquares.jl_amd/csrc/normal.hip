@@ -530,26 +530,32 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
 // sum of this thread's partial rows for column jc: rows wy, wy+ny, wy+2ny, ...  Four independent loads per trip
 // (none depends on anything but the kernel arguments, so they leave with the first instruction of the kernel);
 // the order of the additions is fixed: s0 takes trips' rows 0 and 2, s1 rows 1 and 3, result s0 + s1.
-template <typename E>
-__device__ static inline E slab_column_sum(const E* __restrict__ slab, int nwg, int64_t N, int64_t jc, int wy, int ny) {
-  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
-  for (int wgi = wy; wgi < nwg; wgi += 4 * ny) {
-    E a[4];
+template <typename E, int B>
+__device__ static inline void slab_column_batches(const E* __restrict__ slab, int nwg, int64_t N, int64_t jc, int wy,
+                                                  int ny, E& s0, E& s1) {
+  for (int wgi = wy; wgi < nwg; wgi += B * ny) {
+    E a[B];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < B; ++q) {
       const int row = wgi + q * ny;
       const int rc = row < nwg ? row : wgi;  // clamped address, masked below
       a[q] = slab[(int64_t)rc * N + jc];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < B; ++q) {
       if (wgi + q * ny >= nwg) a[q] = elem<E>::zero();
+      if (q & 1) s1 = elem<E>::add(s1, a[q]);
+      else s0 = elem<E>::add(s0, a[q]);
     }
-    s0 = elem<E>::add(s0, a[0]);
-    s1 = elem<E>::add(s1, a[1]);
-    s0 = elem<E>::add(s0, a[2]);
-    s1 = elem<E>::add(s1, a[3]);
   }
+}
+template <typename E>
+__device__ static inline E slab_column_sum(const E* __restrict__ slab, int nwg, int64_t N, int64_t jc, int wy, int ny) {
+  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
+  // one batch of independent loads whenever it fits: 4 rows per thread at the headline shape (256 partial rows, 64
+  // row groups), 8 at 512 partial rows (8192 x 4096 Float32); the order of the additions is the same either way
+  if (nwg > 4 * ny) slab_column_batches<E, 8>(slab, nwg, N, jc, wy, ny, s0, s1);
+  else slab_column_batches<E, 4>(slab, nwg, N, jc, wy, ny, s0, s1);
   return elem<E>::add(s0, s1);
 }
 
