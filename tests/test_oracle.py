@@ -281,6 +281,25 @@ def test_cg_inplace_solves_spd_system_and_counts_iterations():
     assert it2 <= 10 and rel(x2, np.linalg.solve(Aop, b)) < 1e-6
 
 
+def test_cg_inplace_iterates_equal_an_independent_cg():
+    """`cg!` is third-party (IterativeSolvers, not in the reference tree): the restatement is checked, iterate by
+    iterate, against SciPy's conjugate-gradient implementation (an independent code of the same recurrence) on a
+    Hermitian positive definite system with a warm start"""
+    from scipy.sparse.linalg import cg as scipy_cg, LinearOperator
+    rng = np.random.default_rng(6)
+    B = rng.standard_normal((30, 30)) + 1j * rng.standard_normal((30, 30))
+    Aop = B.conj().T @ B + 0.3 * np.eye(30)
+    b = rng.standard_normal(30) + 1j * rng.standard_normal(30)
+    x0 = 0.1 * (rng.standard_normal(30) + 1j * rng.standard_normal(30))
+    for k in (1, 2, 5, 9):
+        x = x0.copy()
+        it = O.cg_inplace(x, lambda v: Aop @ v, b, maxiter=k, reltol=0.0)
+        assert it == k
+        xs, _ = scipy_cg(LinearOperator((30, 30), matvec=lambda v: Aop @ v, dtype=np.complex128), b, x0=x0.copy(), maxiter=k,
+                         rtol=0.0, atol=0.0)
+        assert rel(x, xs) < 1e-10, k
+
+
 def test_power_iterations_estimates_top_eigenvalue():
     A, _, _ = O.make_problem(80, 30, np.complex128, 4)
     lam = O.power_iterations(O.NormalOp(O.DenseOp(A)), np.ones(30, dtype=np.complex128), rtol=1e-6, maxiter=500)
