@@ -290,6 +290,78 @@ __global__ __launch_bounds__(UPD_THREADS) void cgnr_update_kernel(E* __restrict_
   }
 }
 
+// The same update with the four vectors held in registers (n <= EPT * UPD_THREADS): every load is requested before
+// anything is waited for -- one memory round trip instead of the seven dependent ones of the loop form above
+// (scalars, three passes over the vectors) -- and the same per-thread summation order, so the same bits.
+template <typename E, int EPT>
+__global__ __launch_bounds__(UPD_THREADS) void cgnr_update_reg_kernel(E* __restrict__ x, E* __restrict__ r,
+                                                                      E* __restrict__ p, const E* __restrict__ v,
+                                                                      int64_t n, cgnr_scalars* sc) {
+  __shared__ double sm[48];
+  const cgnr_scalars S = *sc;
+  E pv[EPT], vv[EPT], xv[EPT], rv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * UPD_THREADS;
+    const int64_t ic = i < n ? i : n - 1;
+    pv[e] = p[ic];
+    vv[e] = v[ic];
+    xv[e] = x[ic];
+    rv[e] = r[ic];
+  }
+  if (S.done) return;
+  const float lambda = S.lambda;
+  const double zeta = S.rr;
+  double nre = 0.0, nim = 0.0, pp = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * UPD_THREADS;
+    if (i >= n) pv[e] = vv[e] = rv[e] = elem<E>::zero();
+    nre += (double)elem<E>::re(pv[e]) * (double)elem<E>::re(vv[e]) + (double)elem<E>::im(pv[e]) * (double)elem<E>::im(vv[e]);
+    if constexpr (elem<E>::cplx)
+      nim += (double)elem<E>::re(pv[e]) * (double)elem<E>::im(vv[e]) - (double)elem<E>::im(pv[e]) * (double)elem<E>::re(vv[e]);
+    pp += (double)elem<E>::re(pv[e]) * (double)elem<E>::re(pv[e]) + (double)elem<E>::im(pv[e]) * (double)elem<E>::im(pv[e]);
+  }
+  block_sum3(nre, nim, pp, sm);
+  const dcomplex den = {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim};
+  const dcomplex alpha = dc_div({zeta, 0.0}, den);
+  const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
+  const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
+  double rr = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    xv[e] = elem<E>::fma(pv[e], a, xv[e]);
+    E ri = elem<E>::fma(vv[e], na, rv[e]);
+    if (lambda > 0.f) ri = elem<E>::fma(elem<E>::scale(-lambda, pv[e]), a, ri);
+    rv[e] = ri;
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum(rr, sm);
+  const double beta = rr / zeta;
+  const float bf = (float)beta;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * UPD_THREADS;
+    if (i < n) {
+      x[i] = xv[e];
+      r[i] = rv[e];
+      p[i] = elem<E>::add(elem<E>::scale(bf, pv[e]), rv[e]);
+    }
+  }
+  if (threadIdx.x == 0) {
+    sc->zeta = zeta;
+    sc->rr = rr;
+    sc->alpha_re = alpha.re;
+    sc->alpha_im = alpha.im;
+    sc->beta_re = beta;
+    sc->beta_im = 0.0;
+    const int it = S.iteration + 1;
+    sc->iteration = it;
+    const float ratio = (float)(sqrt(rr) / S.z0);
+    sc->done = (ratio <= S.rel_tol) || (it >= S.max_iter);  // :181-185
+  }
+}
+
 template <typename E>
 static void cgnr_launch_init(rls_cgnr* s, float lambda, float rel_tol, int max_iter) {
   rls_operator* op = s->op;
@@ -299,8 +371,18 @@ static void cgnr_launch_init(rls_cgnr* s, float lambda, float rel_tol, int max_i
 template <typename E>
 static void cgnr_launch_update(rls_cgnr* s) {
   rls_operator* op = s->op;
-  hipLaunchKernelGGL(cgnr_update_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->x, (E*)s->r,
-                     (E*)s->p, (const E*)s->v, op->N, s->sc);
+  const int64_t n = op->N;
+#define RLS_UPD_REG(EE)                                                                                             \
+  hipLaunchKernelGGL((cgnr_update_reg_kernel<E, EE>), dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->x, (E*)s->r, \
+                     (E*)s->p, (const E*)s->v, n, s->sc)
+  if (n <= UPD_THREADS) RLS_UPD_REG(1);
+  else if (n <= 2 * UPD_THREADS) RLS_UPD_REG(2);
+  else if (n <= 4 * UPD_THREADS) RLS_UPD_REG(4);
+  else if (n <= 8 * UPD_THREADS) RLS_UPD_REG(8);
+  else
+    hipLaunchKernelGGL(cgnr_update_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->x, (E*)s->r,
+                       (E*)s->p, (const E*)s->v, n, s->sc);
+#undef RLS_UPD_REG
 }
 
 static int32_t launch_status(rls_ctx* ctx) {
