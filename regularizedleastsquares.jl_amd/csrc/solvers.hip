@@ -598,6 +598,112 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
   }
 }
 
+// fista_update_kernel with the vectors in registers (n <= EPT * UPD_THREADS; every regulariser but L21, whose
+// group norms need the whole new x): all loads requested up front, the same per-thread summation order.
+template <typename E, int EPT>
+__global__ __launch_bounds__(UPD_THREADS) void fista_update_reg_kernel(E* __restrict__ b0, E* __restrict__ b1,
+                                                                       const E* __restrict__ x0, E* __restrict__ res,
+                                                                       E* __restrict__ y, int64_t n, fista_scalars* sc,
+                                                                       fista_batch<E> Bt) {
+  const int b = blockIdx.x;
+  b0 += b * Bt.ldv;
+  b1 += b * Bt.ldv;
+  x0 += b * Bt.ldv;
+  res += b * Bt.ldv;
+  y += b * Bt.ldv;
+  sc += b;
+  E* yp = Bt.Yp ? Bt.Yp + (int64_t)(b >> 4) * n * 16 + (b & 15) : nullptr;
+  __shared__ double sm[16];
+  const int done0 = sc->done, it = sc->iteration, reg_kind = sc->reg_kind, proj_kind = sc->proj_kind;
+  const int restart = sc->restart, max_iter = sc->max_iter;
+  const float rho = sc->rho, lam = sc->lambda, rel_tol = sc->rel_tol, theta0 = sc->theta;
+  const double norm_x0 = sc->norm_x0;
+  E* xnew = (it & 1) ? b0 : b1;  // after the reference's pointer swap: state.x      :144-146
+  E* xold = (it & 1) ? b1 : b0;  // holds x_k
+  E raw[EPT], x0v[EPT], yv[EPT], xo[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * UPD_THREADS;
+    const int64_t ic = i < n ? i : n - 1;
+    raw[e] = Bt.Vpart ? fista_parts<E>(Bt, b, n, ic) : res[ic];
+    x0v[e] = x0[ic];
+    yv[e] = y[ic];
+    xo[e] = xold[ic];
+  }
+  if (done0) return;  // a retired column keeps its panel entry (src/MultiThreading.jl:60-78)
+  const float thr = rho * lam;  // prox!(reg, x, rho * lambda(reg))             :164
+  E ri[EPT], xn[EPT];
+  double rn = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * UPD_THREADS;
+    ri[e] = elem<E>::sub(raw[e], x0v[e]);                                      // res .-= x0      :153
+    E xi = elem<E>::sub(yv[e], elem<E>::scale(rho, ri[e]));                    // x .-= rho .* res :154
+    xn[e] = fista_proj_elem<E>(fista_prox_elem<E>(xi, reg_kind, thr), proj_kind);
+    if (i < n) rn += (double)elem<E>::re(ri[e]) * (double)elem<E>::re(ri[e]) + (double)elem<E>::im(ri[e]) * (double)elem<E>::im(ri[e]);
+  }
+  rn = block_sum(rn, sm);
+  float theta = theta0;
+  if (restart) {  // real(res . (x - xold)) > 0  => theta = 1                       :171-176
+    double d = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = threadIdx.x + (int64_t)e * UPD_THREADS;
+      const E df = elem<E>::sub(xn[e], xo[e]);
+      if (i < n) d += (double)elem<E>::re(ri[e]) * (double)elem<E>::re(df) + (double)elem<E>::im(ri[e]) * (double)elem<E>::im(df);
+    }
+    d = block_sum(d, sm);
+    if (d > 0.0) theta = 1.f;
+  }
+  const float theta_old = theta;                                     // :179
+  theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;    // :180
+  const double res_norm = sqrt(rn);
+  const float rel = (float)(res_norm / norm_x0);                     // :156
+  const int done = (rel < rel_tol) || (it + 1 >= max_iter);          // :187-189
+  const float c1 = (1.f - theta_old) / theta;
+  const float c2 = (theta_old - 1.f) / theta + 1.f;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * UPD_THREADS;
+    if (i < n) {
+      xnew[i] = xn[e];
+      res[i] = ri[e];
+      if (!done) {  // next iteration's Nesterov step, formed out of place in y                         :147-148
+        const E yi = elem<E>::add(elem<E>::scale(c1, xo[e]), elem<E>::scale(c2, xn[e]));
+        y[i] = yi;
+        if (yp) yp[16 * i] = yi;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    sc->res_norm = res_norm;
+    sc->rel_res_norm = (double)rel;
+    sc->theta = theta;
+    sc->theta_old = theta_old;
+    sc->iteration = it + 1;
+    sc->done = done;
+  }
+}
+
+// launch of the update half of an unfused / batched FISTA iteration: the register form when it applies
+template <typename E>
+static void fista_launch_update(rls_fista* s, unsigned nblocks, const fista_batch<E>& Bt) {
+  rls_operator* op = s->op;
+  const int64_t n = op->N;
+#define RLS_FUPD_REG(EE)                                                                                            \
+  hipLaunchKernelGGL((fista_update_reg_kernel<E, EE>), dim3(nblocks), dim3(UPD_THREADS), 0, op->ctx->stream,        \
+                     (E*)s->buf[0], (E*)s->buf[1], (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt)
+  if (s->reg_kind != RLS_REG_L21 && n <= 4 * UPD_THREADS) {
+    if (n <= UPD_THREADS) RLS_FUPD_REG(1);
+    else if (n <= 2 * UPD_THREADS) RLS_FUPD_REG(2);
+    else RLS_FUPD_REG(4);
+  } else {
+    hipLaunchKernelGGL(fista_update_kernel<E>, dim3(nblocks), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->buf[0],
+                       (E*)s->buf[1], (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt);
+  }
+#undef RLS_FUPD_REG
+}
+
 static bool fista_pipe_ok(const rls_fista* s) {
   const rls_ctx* ctx = s->op->ctx;
   return s->y1 && s->op->slab && !s->op->G && ctx->tune.fused_normal && ctx->tune.cgnr_pipeline &&
@@ -651,13 +757,9 @@ static int32_t fista_enqueue_iteration(rls_fista* s) {
   rls_operator* op = s->op;
   RLS_TRY(op_normal(op, s->y, s->res, &s->sc->done));
   if (op->dtype == RLS_F32)
-    hipLaunchKernelGGL(fista_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (float*)s->buf[0],
-                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc,
-                       fista_batch<float>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr});
   else
-    hipLaunchKernelGGL(fista_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream,
-                       (float2*)s->buf[0], (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y,
-                       op->N, s->sc, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
   return launch_status(op->ctx);
 }
 
@@ -1159,13 +1261,9 @@ static int32_t fista_enqueue_batched(rls_fista* s) {
   rls_ctx* ctx = op->ctx;
   RLS_TRY(rls_skinny_launch(ctx, op->dtype, fista_skinny_desc(s), 1 | 2));
   if (op->dtype == RLS_F32)
-    hipLaunchKernelGGL(fista_update_kernel<float>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
-                       (float*)s->buf[0], (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N,
-                       s->sc, fista_batch_desc<float>(s));
+    fista_launch_update<float>(s, (unsigned)s->nrhs, fista_batch_desc<float>(s));
   else
-    hipLaunchKernelGGL(fista_update_kernel<float2>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
-                       (float2*)s->buf[0], (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y,
-                       op->N, s->sc, fista_batch_desc<float2>(s));
+    fista_launch_update<float2>(s, (unsigned)s->nrhs, fista_batch_desc<float2>(s));
   return launch_status(ctx);
 }
 
@@ -1893,13 +1991,9 @@ int32_t rls_fista_step_local_b(rls_fista* s) {
   if (!s->initialised || s->use_pipe || s->use_gram) return rls_fail(ctx, RLS_E_STATE, "fista_step_local before fista_init_local_b");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (op->dtype == RLS_F32)
-    hipLaunchKernelGGL(fista_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
-                       (float*)s->buf[1], (const float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc,
-                       fista_batch<float>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr});
   else
-    hipLaunchKernelGGL(fista_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)s->buf[0],
-                       (float2*)s->buf[1], (const float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc,
-                       fista_batch<float2>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
   return launch_status(ctx);
 }
 
