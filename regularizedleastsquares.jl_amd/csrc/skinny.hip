@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void skinny_pack_rows_kernel(const E* __restri
 // EPT > 0: the column lives in registers (N <= 1024 EPT), every load is issued before the first
 // reduction; EPT == 0: any N, the vectors are re-read between the reductions.
 // ---------------------------------------------------------------------------------------------
-constexpr int SKU_THREADS = 512;
+constexpr int SKU_THREADS = 1024;
 
 template <typename E>
 __device__ static inline double abs2d(E a) {
