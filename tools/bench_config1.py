@@ -1,0 +1,22 @@
+"""BASELINE configs[0] (the reference's CPU-runnable case): CGNR 256 x 128 Float32, lambda = 1e-2, 10 iterations --
+latency-bound on a GPU; us per iteration through the pipeline (hipGraph off: fewer than one chunk) and per solve"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch  # noqa
+import rls_amd as rls
+from bench import make_A
+ctx = rls.Context(0)
+A = make_A(256, 128, 1, np.float32); Ad = rls.DeviceMatrix.from_host(A, ctx)
+b = rls.DeviceVector.from_host((A @ np.ones(128, np.float32)).astype(np.float32), ctx)
+for name, kw in (("matrix-free", {}), ("gram", dict(AHA=Ad.gram()))):
+    S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-2), iterations=10, relTol=0.0, **kw)
+    rls.solve_(S, b)
+    def run(n):
+        for _ in range(n):
+            rls.init_(S, b); ctx.lib.rls_cgnr_step(S.state._plan, 10)
+    run(300); ctx.sync(); ctx.timer_start(); run(300); us = ctx.timer_stop_ms() * 1e3 / 300
+    t0 = time.perf_counter()
+    for _ in range(200): rls.solve_(S, b)
+    ctx.sync(); wall = (time.perf_counter() - t0) / 200 * 1e6
+    print(f"config 1 {name:12s}: {us/10:6.2f} us per iteration on the device ({us:6.1f} us per 10-iteration solve incl. init), "
+          f"{wall:6.1f} us wall clock per solve_() from Python")
