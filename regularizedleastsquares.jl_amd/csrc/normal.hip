@@ -1217,14 +1217,14 @@ __global__ __launch_bounds__(FIN_THREADS) void cgnr_gram_f_kernel(E* __restrict_
 
 // ---- Gram-mode FISTA: the same one-launch scheme (src/FISTA.jl:139-185 with AHA explicit, :58) ----
 // res_raw = AHA y exists in two parities; x / xold and y keep their own ping-pong (iteration parity, ycur).
-template <typename E, int G, int K, int WV, bool FULL>
+template <typename E, int G, int K, int WV, bool FULL, bool HINTED>
 __global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
                                                              const E* __restrict__ x0, E* __restrict__ res, E* y0,
                                                              E* y1, const E* __restrict__ rr_cur,
                                                              E* __restrict__ rr_next,
                                                              const fista_scalars* __restrict__ sc,
                                                              fista_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                             int pair) {
+                                                             int pair, int hint) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT;
   __shared__ gram_lds<E, G, K, WV> L;
@@ -1235,16 +1235,23 @@ __global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict
   fista_scalars S;
   RLS_FISTA_COPY(S, *sc);
   E raw[EPT], x0v[EPT], ya[EPT], yb[EPT], ba[EPT], bb[EPT];
+  const E* yh = hint == 1 ? y1 : y0;  // HINTED: the host passed the parity of the iteration count (16 loads, not 24)
+  const E* bh = hint == 1 ? b1 : b0;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int64_t i = tid + (int64_t)e * C::NT;
     const int64_t ic = i < N ? i : (N - 1);
     raw[e] = rr_cur[ic];
     x0v[e] = x0[ic];
-    ya[e] = y0[ic];
-    yb[e] = y1[ic];
-    ba[e] = b0[ic];
-    bb[e] = b1[ic];
+    if constexpr (HINTED) {
+      ya[e] = yb[e] = yh[ic];
+      ba[e] = bb[e] = bh[ic];
+    } else {
+      ya[e] = y0[ic];
+      yb[e] = y1[ic];
+      ba[e] = b0[ic];
+      bb[e] = b1[ic];
+    }
   }
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -1261,6 +1268,21 @@ __global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict
     yv[e] = S.ycur ? yb[e] : ya[e];
     xk[e] = (S.iteration & 1) ? bb[e] : ba[e];  // state.x == buf[iteration & 1]
     if (i >= N) yv[e] = elem<E>::zero();
+  }
+  if constexpr (HINTED) {
+    if (S.ycur != hint || (S.iteration & 1) != hint) {  // wrong hint (never with the host's bookkeeping): re-load, late
+      const E* yc = S.ycur ? y1 : y0;
+      const E* bc = (S.iteration & 1) ? b1 : b0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * C::NT;
+        const int64_t ic = i < N ? i : (N - 1);
+        yv[e] = yc[ic];
+        xk[e] = bc[ic];
+        if (i >= N) yv[e] = elem<E>::zero();
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) inside the branch
+    }
   }
   fista_scalars Sn;
   if (S.done) {
@@ -1654,12 +1676,14 @@ static void launch_fista_gram(rls_ctx* ctx, const rls_fista_gram& P, int q, int 
   const int64_t Mc = P.N / C::NV;
   const int pair = (nwg % 16 == 0) ? 1 : 0;
   const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
-#define RLS_LAUNCH_FG(FULLV)                                                                                        \
-  hipLaunchKernelGGL((fista_gram_kernel<E, 4, K, 8, FULLV>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,  \
-                     P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (const E*)P.rr[q],     \
-                     (E*)P.rr[q ^ 1], P.sc[q], P.sc[q ^ 1], Mc, P.N, pair)
-  if (full) RLS_LAUNCH_FG(true);
-  else RLS_LAUNCH_FG(false);
+#define RLS_LAUNCH_FG(FULLV, HINTV)                                                                                 \
+  hipLaunchKernelGGL((fista_gram_kernel<E, 4, K, 8, FULLV, HINTV>), dim3(nwg), dim3(C::NT), 0, ctx->stream,          \
+                     (const E*)P.G, P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1,         \
+                     (const E*)P.rr[q], (E*)P.rr[q ^ 1], P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, P.par_hint)
+  if (full && P.par_hint >= 0) RLS_LAUNCH_FG(true, true);
+  else if (P.par_hint >= 0) RLS_LAUNCH_FG(false, true);
+  else if (full) RLS_LAUNCH_FG(true, false);
+  else RLS_LAUNCH_FG(false, false);
 #undef RLS_LAUNCH_FG
 }
 

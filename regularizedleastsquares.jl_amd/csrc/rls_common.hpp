@@ -482,6 +482,7 @@ struct rls_fista_gram {
   void *b0, *b1, *x0, *res, *y0, *y1;
   void* rr[2];              // AHA y before "- x0", two parities
   fista_scalars* sc[2];
+  int par_hint = -1;        // as rls_fista_pipe::par_hint
 };
 int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);
 int32_t rls_fista_gram_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);

@@ -2122,10 +2122,20 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   if (s->use_gram) {
     // explicit AHA: one launch per iteration (two-parity state, see cgnr_gram_kernel); the finish kernel
     // applies the last update and leaves the scalars in both parities, so every call starts at parity 0
-    const rls_fista_gram P = fista_gram_desc(s);
+    rls_fista_gram P = fista_gram_desc(s);
     const int32_t dtype = s->op->dtype;
-    int parity = 0;
-    auto one = [ctx, dtype, &P, &parity]() {
+    const int it0 = s->enq;  // buffer hints as in the slab pipeline below
+    if (s->graph.exec && s->graph_parity != (it0 & 1)) {
+      hipGraphExecDestroy(s->graph.exec);
+      s->graph = step_graph();
+    }
+    s->graph_parity = it0 & 1;
+    int parity = 0, k = 0;
+    auto one = [ctx, dtype, &P, &parity, &k, it0]() {
+      const int hk = pipe_cur_hint(ctx, k);
+      P.par_hint = hk < 0 ? -1 : ((it0 + (k > 0 ? k - 1 : 0)) & 1);
+      if (hk >= 0 && ctx->tune.pipe_hint_mode == 2) P.par_hint ^= 1;
+      ++k;
       const int32_t st = rls_fista_gram_iteration(ctx, dtype, P, parity);
       parity ^= 1;
       return st;
@@ -2135,6 +2145,7 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
     } else {
       RLS_TRY(run_steps(ctx, &s->graph, n_steps, one));
     }
+    s->enq += n_steps;
     return rls_fista_gram_finish(ctx, dtype, P, n_steps & 1);
   }
   if (s->use_pipe) {

@@ -1723,6 +1723,7 @@ def test_pipeline_pair_hint_is_only_a_hint(rls, ctx, mode):
     Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
     Ar, xr, br = O.make_problem(256, 128, np.float32, 3)
     Ard, brd = rls.DeviceMatrix.from_host(Ar), rls.DeviceVector.from_host(br)
+    Gd = Ad.gram()
 
     def run():
         S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=37, relTol=0.0)
@@ -1735,7 +1736,14 @@ def test_pipeline_pair_hint_is_only_a_hint(rls, ctx, mode):
         for _ in range(5):
             rls.iterate(F)
         x4 = F.state.x.to_host() if hasattr(F.state, "x") else None
-        return x1, x2, S.state.iteration, x3, x4
+        Fg = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(1e-2), rho=0.9 / (64 + 45.3) ** 2,
+                                    iterations=35, relTol=0.0)   # the one-launch Gram-mode kernel takes the same hint
+        x5 = rls.solve_(Fg, bd).to_host()
+        rls.init_(Fg, bd)
+        for _ in range(5):
+            rls.iterate(Fg)
+        x6 = Fg.state.x.to_host()
+        return x1, x2, S.state.iteration, x3, x4, x5, x6
 
     want = run()
     ctx.tune(pipe_hint_mode=mode)
@@ -1746,6 +1754,7 @@ def test_pipeline_pair_hint_is_only_a_hint(rls, ctx, mode):
     assert got[2] == want[2] == 37
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4])
+    assert np.array_equal(got[5], want[5]) and np.array_equal(got[6], want[6])
 
 
 def test_random_shapes_svt_prox_and_batched_kaczmarz(rls, ctx):
