@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void skinny_pack_rows_kernel(const E* __restri
 // EPT > 0: the column lives in registers (N <= 1024 EPT), every load is issued before the first
 // reduction; EPT == 0: any N, the vectors are re-read between the reductions.
 // ---------------------------------------------------------------------------------------------
-constexpr int SKU_THREADS = 1024;
+// NT threads per workgroup: 512 where the column fits in 8 elements per thread (N = 2048: 7.0 us per launch against
+// 7.9 with 1024 and 7.6 with 256), 1024 beyond
 
 template <typename E>
 __device__ static inline double abs2d(E a) {
@@ -332,8 +333,8 @@ __device__ static inline void cg_scalars_step(cgnr_scalars* sc, double zeta, dou
   sc->done = (ratio <= sc->rel_tol) || (it >= sc->max_iter);  // src/CGNR.jl:181-185
 }
 
-template <typename E, bool INIT, int EPT>
-__global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X, E* __restrict__ R, E* __restrict__ P,
+template <typename E, bool INIT, int EPT, int NT>
+__global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __restrict__ R, E* __restrict__ P,
                                                                E* __restrict__ V, int64_t ldv,
                                                                const E* __restrict__ Vpart, int S, int nrhs_pad,
                                                                int64_t N, E* __restrict__ Pp, cgnr_scalars* scv,
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
   E* pp_out = Pp + (int64_t)(b >> 4) * N * 16 + (b & 15);  // Pp[g][n][j]: element n at pp_out[16 n]
   if constexpr (INIT) {
     double rr = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+    for (int64_t i = threadIdx.x; i < N; i += NT) {
       const E ri = sum_parts<E>(Vpart, S, nrhs_pad, b, N, i);
       x[i] = elem<E>::zero();
       v[i] = elem<E>::zero();
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
     int64_t ic[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
+      const int64_t i = threadIdx.x + (int64_t)e * NT;
       ic[e] = i < N ? i : N - 1;
       pv[e] = p[ic[e]];
       xv[e] = x[ic[e]];
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
     double nre = 0.0, nim = 0.0, pp = 0.0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
+      const int64_t i = threadIdx.x + (int64_t)e * NT;
       if (i >= N) {
         pv[e] = elem<E>::zero();
         vv[e] = elem<E>::zero();
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
     const float bf = (float)beta;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const int64_t i = threadIdx.x + (int64_t)e * SKU_THREADS;
+      const int64_t i = threadIdx.x + (int64_t)e * NT;
       if (i < N) {
         const E pn = elem<E>::add(elem<E>::scale(bf, pv[e]), rv[e]);
         x[i] = xv[e];
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
     const float lambda = sc->lambda;
     const double zeta = sc->rr;
     double nre = 0.0, nim = 0.0, pp = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+    for (int64_t i = threadIdx.x; i < N; i += NT) {
       const E vi = sum_parts<E>(Vpart, S, nrhs_pad, b, N, i);
       v[i] = vi;
       const E pi = p[i];
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
     const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
     const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
     double rr = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+    for (int64_t i = threadIdx.x; i < N; i += NT) {
       const E pi = p[i];
       x[i] = elem<E>::fma(pi, a, x[i]);
       E ri = elem<E>::fma(v[i], na, r[i]);
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(SKU_THREADS) void skinny_u_kernel(E* __restrict__ X
     rr = block_sum(rr, sm);
     const double beta = rr / zeta;
     const float bf = (float)beta;
-    for (int64_t i = threadIdx.x; i < N; i += SKU_THREADS) {
+    for (int64_t i = threadIdx.x; i < N; i += NT) {
       const E pn = elem<E>::add(elem<E>::scale(bf, p[i]), r[i]);
       p[i] = pn;
       pp_out[16 * i] = pn;
@@ -573,23 +574,25 @@ static void launch_v(rls_ctx* ctx, const rls_skinny& K) {
                      (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16, K.ldvp);
 }
 
-template <typename E, bool INIT, int EPT>
+template <typename E, bool INIT, int EPT, int NT>
 static void launch_u_ept(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_tol, int max_iter) {
-  hipLaunchKernelGGL((skinny_u_kernel<E, INIT, EPT>), dim3((unsigned)K.nrhs), dim3(SKU_THREADS), 0, ctx->stream,
+  hipLaunchKernelGGL((skinny_u_kernel<E, INIT, EPT, NT>), dim3((unsigned)K.nrhs), dim3(NT), 0, ctx->stream,
                      (E*)K.X, (E*)K.R, (E*)K.P, (E*)K.V, K.ldv, (const E*)K.Vpart, K.splits, K.ngroups * 16, K.N,
                      (E*)K.Ppack, K.sc, lambda, rel_tol, max_iter);
 }
 
 template <typename E, bool INIT>
 static void launch_u(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_tol, int max_iter) {
-  if (INIT || K.N > 8 * SKU_THREADS)
-    launch_u_ept<E, INIT, 0>(ctx, K, lambda, rel_tol, max_iter);
-  else if (K.N <= 2 * SKU_THREADS)
-    launch_u_ept<E, INIT, 2>(ctx, K, lambda, rel_tol, max_iter);
-  else if (K.N <= 4 * SKU_THREADS)
-    launch_u_ept<E, INIT, 4>(ctx, K, lambda, rel_tol, max_iter);
+  if (INIT || K.N > 8 * 1024)
+    launch_u_ept<E, INIT, 0, 1024>(ctx, K, lambda, rel_tol, max_iter);
+  else if (K.N <= 2 * 512)
+    launch_u_ept<E, INIT, 2, 512>(ctx, K, lambda, rel_tol, max_iter);
+  else if (K.N <= 4 * 512)
+    launch_u_ept<E, INIT, 4, 512>(ctx, K, lambda, rel_tol, max_iter);
+  else if (K.N <= 8 * 512)
+    launch_u_ept<E, INIT, 8, 512>(ctx, K, lambda, rel_tol, max_iter);
   else
-    launch_u_ept<E, INIT, 8>(ctx, K, lambda, rel_tol, max_iter);
+    launch_u_ept<E, INIT, 8, 1024>(ctx, K, lambda, rel_tol, max_iter);
 }
 
 template <typename E>
