@@ -265,6 +265,11 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out_h /* [nrhs
  * pipeline; average device microseconds per launch of the one-pass normal-operator kernel and of
  * the partial-sum reduce kernel.  RLS_E_UNSUPPORTED when the shape runs on the two-GEMV path. */
 int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, float* us_reduce);
+/* Which kernel sequence the next rls_cgnr_step call of this plan takes (a query; measurement harness and tests):
+ * 0 = two GEMVs + update kernel, 1 = one-pass slab pipeline (two launches per iteration), 2 = Gram-mode pipeline
+ * (one launch per iteration), 3 = batched matrix-core kernels, 4 = resident (the whole call in ONE launch, A held in
+ * registers across iterations; needs A <= the register files, one live context on the device). */
+int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out);
 
 /* ---------------------------------------------------------------------------------------------
  * fused FISTA.   replaces init!/iterate(::FISTA, ::FISTAState) src/FISTA.jl:110-129,139-185.

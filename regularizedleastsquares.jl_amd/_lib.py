@@ -131,6 +131,7 @@ PROTOTYPES = {
     "rls_cgnr_init_batched": (_i32, [_vp, _vp, _i64, _f, _f, _i32]),
     "rls_cgnr_get_status_batched": (_i32, [_vp, C.POINTER(CgnrStatus)]),
     "rls_cgnr_step_profiled": (_i32, [_vp, _i32, _pf, _pf]),
+    "rls_cgnr_path": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "rls_cgnr_init_local_a": (_i32, [_vp, _vp, _f, _f, _i32]),
     "rls_cgnr_init_local_b": (_i32, [_vp]),
     "rls_cgnr_step_local_a": (_i32, [_vp]),

@@ -1,7 +1,13 @@
 // Context, memory and timing entry points of the C ABI (include/rls_mi355x.h).
 #include "rls_common.hpp"
 
+#include <atomic>
 #include <cstdlib>
+
+// contexts alive per device: the resident kernels (normal.hip) need every CU, so they run only while ONE context
+// of this process is using the device (several contexts = several streams whose kernels can interleave on the CUs)
+static std::atomic<int> g_live_ctx[64];
+int rls_ctx_live_count(int device) { return (device >= 0 && device < 64) ? g_live_ctx[device].load() : 2; }
 
 static int32_t ctx_setup(rls_ctx* ctx) {
   RLS_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -39,6 +45,8 @@ static int32_t ctx_create_impl(int32_t device, void* stream, bool borrow, rls_ct
     rls_ctx_destroy(ctx);
     return st;
   }
+  if (device < 64) g_live_ctx[device].fetch_add(1);
+  ctx->counted = true;
   *out = ctx;
   return 0;
 }
@@ -70,6 +78,7 @@ int32_t rls_ctx_destroy(rls_ctx* ctx) {
   if (ctx->res_d) hipFree(ctx->res_d);
   if (ctx->res_h) hipHostFree(ctx->res_h);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  if (ctx->counted && ctx->device < 64) g_live_ctx[ctx->device].fetch_sub(1);
   delete ctx;
   return 0;
 }
@@ -98,6 +107,8 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "batched_mfma")) ctx->tune.batched_mfma = value;
   else if (!strcmp(key, "gram_pipeline")) ctx->tune.gram_pipeline = value;
   else if (!strcmp(key, "pipe_hint_mode")) ctx->tune.pipe_hint_mode = value;
+  else if (!strcmp(key, "resident")) ctx->tune.resident = value;
+  else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);
   else if (!strcmp(key, "skinny_v_waves")) rls_skinny_tune(1, value);
   else if (!strcmp(key, "skinny_v_splits")) rls_skinny_tune(2, value);

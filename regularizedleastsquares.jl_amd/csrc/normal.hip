@@ -135,7 +135,27 @@ __device__ static inline void slab_load(chunk<E, elem<E>::vec> (&a)[K], const E*
 }
 
 // with L.xs holding the input vector (zero beyond N): t_w = A_w xs, partial v = A_w^H t_w -> slab row
-template <typename E, int G, int K, int WV, bool FULL>
+// Write-through (sc1) accesses for data handed to other workgroups INSIDE a launch (the resident kernels below):
+// an sc1 store leaves the XCD's L2 for the memory side at once (no release fence needed), an sc1 load bypasses
+// the CU's L1, which another CU's stores never refresh.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ static inline __amdgpu_buffer_rsrc_t sc1_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ static inline f4 sc1_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));  // aux 16 = sc1
+}
+template <typename E>
+__device__ static inline void sc1_store_elem(E* p, E v) {
+  if constexpr (sizeof(E) == 8)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  else
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename E, int G, int K, int WV, bool FULL, bool SC1 = false>
 __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L, E* __restrict__ slab,
                                           int64_t Mc, int64_t N, int pair) {
   using C = slab_cfg<E, G, K, WV>;
@@ -220,7 +240,11 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
       E sum = L.xg[0][c];
 #pragma unroll
       for (int gg = 1; gg < G; ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
-      if (c < N) out[c] = sum;
+      if constexpr (SC1) {
+        if (c < N) sc1_store_elem<E>(out + c, sum);
+      } else {
+        if (c < N) out[c] = sum;
+      }
     }
   }
 }
@@ -1390,6 +1414,215 @@ __global__ __launch_bounds__(FIN_THREADS) void fista_gram_f_kernel(E* b0, E* b1,
   }
 }
 
+
+// ---- resident CGNR: a whole rls_cgnr_step call in ONE launch, A held in registers across iterations -------
+// At the headline shape A is 64 MiB and the chip's register files hold 128 MiB: with one 512-thread workgroup per
+// CU each workgroup keeps its 16-row slab of A in VGPRs for the WHOLE solve, so an iteration costs no pass over
+// memory at all -- only the two products from registers and two grid-wide exchanges:
+//   1. every workgroup publishes its partial row of v = A^H (A p) (write-through stores)   | grid barrier
+//   2. workgroup j sums 64-byte column chunk j over all partial rows in a fixed order and
+//      publishes that piece of v and its share of <p, v>, ||p||^2                          | grid barrier
+//   3. every workgroup reads v and the partial dots and applies the CG update redundantly
+//      (identical inputs, identical order => identical alpha, beta, done); r, p, x stay in registers.
+// Inter-workgroup visibility follows the guide's rule for in-launch hand-offs: every handed-off byte is stored
+// sc1 (write-through) and drained (s_waitcnt vmcnt(0)) by its storing wave, a workgroup barrier, then ONE lane
+// adds to the (sharded, monotonic) arrival counter; consumers poll the shards with sc1 loads and read the
+// payload with sc1 loads only after a workgroup barrier behind the poll.  Nothing depends on dispatch order
+// or XCD placement; every spin is bounded (`spin_limit`), a timeout leaves x, r, p untouched and raises `fail`.
+struct resident_sync {
+  unsigned cnt[8 * 32];  // 8 shards of the arrival counter, one 128-byte line each (zeroed before every launch)
+  unsigned fail;         // some workgroup gave up waiting
+  unsigned completed;    // workgroup 0 passed the last barrier and wrote the state back
+  unsigned pad[30];
+};
+
+template <typename E, int G, int K, int WV>
+struct resident_lds {
+  slab_lds<E, G, K, WV> L;
+  f4 rp[WV][4];  // per-wave sums of the four 16-byte pieces of a 64-byte column chunk
+  int flag;
+};
+
+// arrive + wait.  Precondition: this workgroup's handed-off stores are sc1, drained by every storing wave, and a
+// workgroup barrier lies between those drains and this call.
+__device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned target, unsigned spin_limit, int* lds_flag) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    if (tid == 0) __hip_atomic_fetch_add(cnt + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 0;
+    for (unsigned spins = 0; spins < spin_limit; ++spins) {
+      unsigned c = __hip_atomic_load(cnt + (tid & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // lanes 0..7 hold the 8 shards:
+      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // butterfly inside the group of 8
+      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xF, 0xF, true);
+      if (__builtin_amdgcn_readfirstlane((int)c) >= (int)target) {
+        ok = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (tid == 0) *lds_flag = ok;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
+template <typename E, int G, int K, int WV>
+__global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* r, E* p,
+                                                                 E* v, E* slab, double* dout, cgnr_scalars* sc,
+                                                                 resident_sync* sync, int64_t Mc, int64_t N, int pair,
+                                                                 int n_steps, unsigned spin_limit) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
+  constexpr int CW = 64 / (int)sizeof(E);  // columns of a 64-byte chunk: 8 complex / 16 real
+  static_assert(EPT % NV == 0, "16-byte ownership layout");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  resident_lds<E, G, K, WV>& R = *reinterpret_cast<resident_lds<E, G, K, WV>*>(smem_raw);
+  slab_lds<E, G, K, WV>& L = R.L;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nwg = gridDim.x;
+  cgnr_scalars S = *sc;
+  // this thread's elements of the length-N vectors, in 16-byte pieces (own_index<.., WIDE = true>)
+  E pv[EPT], rv[EPT], xv[EPT];
+  load_owned_wide<E, EPT, NT>(pv, p, tid);
+  load_owned_wide<E, EPT, NT>(rv, r, tid);
+  load_owned_wide<E, EPT, NT>(xv, x, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, NV> a[K];
+  slab_load<E, G, K, WV, true>(a, A, lda, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  if (S.done || n_steps <= 0) return;  // uniform
+  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(v), d_rs = sc1_rsrc(dout);
+  const int nchunks = (int)(N / CW);
+  unsigned epoch = 0;
+  bool alive = true;
+  for (int it = 0; it < n_steps; ++it) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
+    // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through)
+    slab_finish<E, G, K, WV, true, true>(a, L, slab, Mc, N, pair);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
+    __syncthreads();
+    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+      alive = false;
+      break;
+    }
+    // ---- sum my 64-byte column chunk(s) over all partial rows, fixed order -----------------------------
+    double dre = 0.0, dim_ = 0.0, pp = 0.0;
+    for (int ch = blockIdx.x; ch < nchunks; ch += nwg) {
+      const int piece = lane >> 4, r16 = lane & 15;
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int row0 = 0; row0 < nwg; row0 += 256) {  // two independent loads per trip (one trip at 256 rows)
+        const int ra = row0 + w * 16 + r16, rb = ra + 128;
+        const uint32_t col_off = (uint32_t)ch * 64u + (uint32_t)piece * 16u;
+        const f4 ta = sc1_load16(slab_rs, (uint32_t)(ra < nwg ? ra : 0) * (uint32_t)(N * sizeof(E)) + col_off);
+        const f4 tb = sc1_load16(slab_rs, (uint32_t)(rb < nwg ? rb : 0) * (uint32_t)(N * sizeof(E)) + col_off);
+        if (ra < nwg) acc += ta;
+        if (rb < nwg) acc += tb;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // the 16 rows of this wave: DPP butterfly inside a row of 16 lanes
+        float t = acc[q];
+        t += dpp_f(t, 0xB1);
+        t += dpp_f(t, 0x4E);
+        t += dpp_f(t, 0x141);
+        t += dpp_f(t, 0x140);
+        acc[q] = t;
+      }
+      if (r16 == 0) R.rp[w][piece] = acc;
+      __syncthreads();
+      if (tid < CW) {
+        E sum = elem<E>::zero();
+#pragma unroll
+        for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, reinterpret_cast<const E*>(&R.rp[ww][0])[tid]);
+        const int j = ch * CW + tid;
+        sc1_store_elem<E>(v + j, sum);
+        const E pj = L.xs[j];
+        dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+        dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+        pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+      }
+      __syncthreads();  // rp is reused by the next chunk
+    }
+    if (w == 0) {  // lanes 0..CW-1 hold the terms (zero elsewhere); fixed-order butterfly, lane 0 publishes
+#pragma unroll
+      for (int off = CW / 2; off > 0; off >>= 1) {
+        dre += __shfl_xor(dre, off, 64);
+        dim_ += __shfl_xor(dim_, off, 64);
+        pp += __shfl_xor(pp, off, 64);
+      }
+      if (lane < 3) {
+        const double dv = lane == 0 ? dre : (lane == 1 ? dim_ : pp);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dout + 4 * blockIdx.x + lane),
+                           __builtin_bit_cast(unsigned long long, dv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+      alive = false;
+      break;
+    }
+    // ---- v and the partial dots, then the CG update (src/CGNR.jl:153-176), redundantly in every workgroup ----
+    E vv[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((q * NT * NV + tid * NV) * sizeof(E))));
+#pragma unroll
+      for (int j = 0; j < NV; ++j) vv[q * NV + j] = c.e[j];
+    }
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    {
+      const int dt = tid < nwg ? tid : 0;
+      const f4 lo = sc1_load16(d_rs, (uint32_t)dt * 32u), hi = sc1_load16(d_rs, (uint32_t)dt * 32u + 16u);
+      if (tid < nwg) {
+        d0 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 0, 1));
+        d1 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 2, 3));
+        d2 = __builtin_bit_cast(double, __builtin_shufflevector(hi, hi, 0, 1));
+      }
+    }
+    E pn[EPT], rn[EPT], al;
+    cgnr_scalars Sn;
+    const bool done = cg_update_elems<E, EPT, NT, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      xv[e] = elem<E>::fma(pv[e], al, xv[e]);
+      rv[e] = rn[e];
+      pv[e] = pn[e];
+    }
+    S = Sn;
+    if (done) break;  // uniform: every workgroup derived the same scalars
+  }
+  if (!alive) {
+    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;  // x, r, p and the scalars are untouched: the call was a no-op
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      chunk<E, NV> cx, cr, cp;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        cx.e[j] = xv[q * NV + j];
+        cr.e[j] = rv[q * NV + j];
+        cp.e[j] = pv[q * NV + j];
+      }
+      const int64_t o = (int64_t)q * (NT * NV) + (int64_t)tid * NV;
+      *reinterpret_cast<f4*>(x + o) = __builtin_bit_cast(f4, cx);
+      *reinterpret_cast<f4*>(r + o) = __builtin_bit_cast(f4, cr);
+      *reinterpret_cast<f4*>(p + o) = __builtin_bit_cast(f4, cp);
+    }
+    if (tid == 0) {
+      S.pending = 0;
+      S.cur = 0;
+      S.fresh = 0;
+      *sc = S;
+      sync->completed = 1u;
+    }
+  }
+}
+
 struct fused_cfg {
   int G, K, WV;
 };
@@ -1711,6 +1944,58 @@ static int32_t fista_gram_finish_typed(rls_ctx* ctx, const rls_fista_gram& P, in
   return launch_status(ctx);
 }
 
+
+// ---- resident CGNR host side ------------------------------------------------------------------------
+template <typename E, int G, int K, int WV>
+static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout, void* sync, int nwg, int n_steps,
+                               unsigned spin_limit) {
+  using C = slab_cfg<E, G, K, WV>;
+  // (complex with 64-byte row pieces holds 8 owned elements of x, r, p, v per thread on top of the slab: spills)
+  if constexpr (K == 32 && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
+    const int64_t Mc = P.M / C::NV;
+    const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+    constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
+    static bool attr_set = false;
+    if (!attr_set) {
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV>, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
+                       (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N, pair,
+                       n_steps, spin_limit);
+    return launch_status(ctx);
+  } else {
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident CGNR: slab shape not instantiated");
+  }
+}
+
+template <typename E>
+static bool resident_ok_typed(int device, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!fused_ok<E>(M, N, A, lda)) return false;
+  fused_cfg c;
+  if (!pick_cfg<E>(N, &c) || c.K != 32 || c.WV != 8 || (elem<E>::cplx && c.G == 4)) return false;
+  const int64_t nmax = (int64_t)c.K * c.WV * (64 / c.G), Mc = M / elem<E>::vec;
+  const int64_t nwg = fused_nwg<E>(M, N);
+  if (N != nmax || nwg * c.G != Mc) return false;  // the full-size instantiation only
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
+  // one 512-thread workgroup (256 VGPRs per lane, ~148 KiB of LDS) per CU: the grid is resident iff it fits the CUs
+  return nwg <= cus && nwg * N * (int64_t)sizeof(E) < (int64_t)0xffffffffll;
+}
+
+template <typename E>
+static int32_t resident_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout, void* sync, int n_steps,
+                              unsigned spin_limit) {
+  fused_cfg c;
+  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident CGNR: N too large");
+  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  int32_t st = RLS_E_UNSUPPORTED;
+#define RLS_RES_CASE(GG, KK, WW) \
+  if (c.G == GG && c.K == KK && c.WV == WW) st = launch_resident<E, GG, KK, WW>(ctx, P, dout, sync, nwg, n_steps, spin_limit);
+  RLS_FOR_EACH_CFG(RLS_RES_CASE)
+#undef RLS_RES_CASE
+  return st;
+}
 }  // namespace
 
 int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity) {
@@ -1793,4 +2078,21 @@ int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t 
   if (dtype == RLS_F32)
     return normal_typed<float>(ctx, M, N, (const float*)A, lda, (const float*)p, (float*)v, (float*)slab, skip);
   return normal_typed<float2>(ctx, M, N, (const float2*)A, lda, (const float2*)p, (float2*)v, (float2*)slab, skip);
+}
+
+// resident CGNR (one launch per step call, A in registers across iterations)
+size_t rls_cgnr_resident_sync_bytes() { return sizeof(resident_sync); }
+bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!ctx) return false;
+  if (dtype == RLS_F32) return resident_ok_typed<float>(ctx->device, M, N, A, lda);
+  if (dtype == RLS_C32) return resident_ok_typed<float2>(ctx->device, M, N, A, lda);
+  return false;
+}
+int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N) {
+  return dtype == RLS_F32 ? (int)fused_nwg<float>(M, N) : (int)fused_nwg<float2>(M, N);
+}
+int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
+                                 int n_steps, unsigned spin_limit) {
+  if (dtype == RLS_F32) return resident_typed<float>(ctx, P, dout, sync, n_steps, spin_limit);
+  return resident_typed<float2>(ctx, P, dout, sync, n_steps, spin_limit);
 }

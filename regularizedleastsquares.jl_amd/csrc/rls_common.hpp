@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -24,12 +25,16 @@ struct rls_tuning {
   int gram_pipeline = 1; // 1: Gram-mode CGNR as one launch per iteration (normal.hip)
   int pipe_hint_mode = 0; // (r, p) pair hints of the slab pipeline: 0 = host bookkeeping, 1 = always "unknown",
                           // 2 = deliberately wrong (tests: exercises the kernel's check-and-reload path)
+  int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
+                          // ONE launch (normal.hip, cgnr_resident_kernel); needs the device to itself (one live context)
+  int resident_spin = 400000;  // bound of every in-kernel wait, in polls (~1 us each)
 };
 
 struct rls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool counted = false;  // included in the per-device live-context count (api.hip)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = {0};
   // reduction scratch: partial sums (double) + a few result slots, and a pinned host mirror
@@ -42,22 +47,31 @@ struct rls_ctx {
 // Host-side waits poll (hipStreamQuery / hipEventQuery) instead of blocking.  A blocking wait sleeps on an interrupt and
 // on this stack now and then wakes up tens of milliseconds late (tools/stall_probe2.py: wall 123 ms for 75 ms of
 // events) -- invisible in hipEvent times, but it is wall-clock latency of every status read-back and of the solve
-// as a whole.  Polling is bounded: after ~2 s it falls back to the blocking call.
-static inline hipError_t rls_stream_wait(hipStream_t s) {
-  for (long spins = 0; spins < 400000000L; ++spins) {
-    const hipError_t e = hipStreamQuery(s);
+// as a whole.  The spin is bounded by WALL CLOCK (250 ms: status read-backs and whole solves of the BASELINE configs
+// finish inside it); longer waits hand the core back and block, so a long enqueue cannot pin a host core for minutes.
+static inline void rls_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+}
+template <typename Q, typename B>
+static inline hipError_t rls_bounded_spin(Q&& query, B&& block) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned n = 0;; ++n) {
+    const hipError_t e = query();
     if (e != hipErrorNotReady) return e;
-    __builtin_ia32_pause();
+    rls_cpu_relax();
+    if ((n & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(250)) break;
   }
-  return hipStreamSynchronize(s);
+  return block();
+}
+static inline hipError_t rls_stream_wait(hipStream_t s) {
+  return rls_bounded_spin([s] { return hipStreamQuery(s); }, [s] { return hipStreamSynchronize(s); });
 }
 static inline hipError_t rls_event_wait(hipEvent_t ev) {
-  for (long spins = 0; spins < 400000000L; ++spins) {
-    const hipError_t e = hipEventQuery(ev);
-    if (e != hipErrorNotReady) return e;
-    __builtin_ia32_pause();
-  }
-  return hipEventSynchronize(ev);
+  return rls_bounded_spin([ev] { return hipEventQuery(ev); }, [ev] { return hipEventSynchronize(ev); });
 }
 
 constexpr int RLS_RED_SLOTS = 4096;
@@ -460,6 +474,13 @@ struct rls_cgnr_pipe {
 int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, int which);
+// resident CGNR (normal.hip): the whole step call in one launch with A held in registers across iterations
+size_t rls_cgnr_resident_sync_bytes();
+bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
+int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N);
+int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
+                                 int n_steps, unsigned spin_limit);
+int rls_ctx_live_count(int device);  // api.hip: contexts alive on a device (resident kernels need the device to themselves)
 
 // Gram-mode CGNR pipeline (normal.hip): one launch per iteration, every buffer in two parities
 struct rls_gram_pipe {

@@ -125,6 +125,11 @@ struct rls_cgnr {
   float *Ppack, *Tpack;
   void* Vpart;
   int splits;
+  // resident mode (normal.hip, cgnr_resident_kernel): arrival counters + flags, per-workgroup partial dots
+  void* rsync;
+  double* rdots;
+  unsigned* rsync_h;  // pinned: {fail, completed} of the last resident launch, read with the status
+  bool resident_used;
 };
 
 static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
@@ -174,6 +179,15 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
 static bool cgnr_use_pipeline(const rls_cgnr* s) {
   const rls_ctx* ctx = s->op->ctx;
   return s->r1 && s->op->slab && !s->op->G && ctx->tune.fused_normal && ctx->tune.cgnr_pipeline;
+}
+
+// the whole step call as one launch: single right-hand side, matrix-free, A small enough to stay in the register
+// files (one workgroup per CU), 16-byte aligned state vectors, and this context alone on the device
+static bool cgnr_use_resident(const rls_cgnr* s) {
+  const rls_ctx* ctx = s->op->ctx;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return s->rsync && s->nrhs == 1 && cgnr_use_pipeline(s) && ctx->tune.resident && rls_ctx_live_count(ctx->device) == 1 &&
+         al16(s->x) && al16(s->r) && al16(s->p) && al16(s->v);
 }
 
 static rls_cgnr_pipe cgnr_pipe_desc(const rls_cgnr* s) {
@@ -1510,6 +1524,10 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   s->nrhs = nrhs;
   s->ldv = ldv;
   s->slab_b = nullptr;
+  s->rsync = nullptr;
+  s->rdots = nullptr;
+  s->rsync_h = nullptr;
+  s->resident_used = false;
   const size_t sb = sizeof(cgnr_scalars) * (size_t)nrhs;
   hipError_t e = hipMalloc((void**)&s->sc, sb);
   if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sb, ctx->stream);
@@ -1528,6 +1546,15 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
     if (e == hipSuccess && nrhs > 1 && !skinny)
       e = hipMalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
+  }
+  if (e == hipSuccess && nrhs == 1 && op->slab && op->A && !op->G &&
+      rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
+    const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
+    e = hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes());
+    if (e == hipSuccess) e = hipMalloc((void**)&s->rdots, db);
+    if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->rsync_h, 2 * sizeof(unsigned), hipHostMallocDefault);
+    if (e == hipSuccess) s->rsync_h[0] = s->rsync_h[1] = 0;
   }
   if (e == hipSuccess && nrhs == 1 && op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
@@ -1584,6 +1611,9 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->Ppack) hipFree(s->Ppack);
   if (s->Tpack) hipFree(s->Tpack);
   if (s->Vpart) hipFree(s->Vpart);
+  if (s->rsync) hipFree(s->rsync);
+  if (s->rdots) hipFree(s->rdots);
+  if (s->rsync_h) hipHostFree(s->rsync_h);
   if (s->sc) hipFree(s->sc);
   if (s->sc_h) hipHostFree(s->sc_h);
   delete s;
@@ -1726,6 +1756,15 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
     }
     return rls_gram_pipe_finish(ctx, dtype, P, n_steps & 1);
   }
+  if (cgnr_use_resident(s)) {
+    // ONE launch for the whole call: A stays in the register files, iterations are separated by two in-kernel
+    // grid-wide exchanges (normal.hip).  The arrival counters and flags are zeroed ahead of every launch.
+    if (n_steps == 0) return 0;
+    const rls_cgnr_pipe P = cgnr_pipe_desc(s);
+    RLS_HIP(ctx, hipMemsetAsync(s->rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream));
+    s->resident_used = true;
+    return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+  }
   if (cgnr_use_pipeline(s)) {
     // iteration k = K_A (applies update k-1 in its prologue, then one pass over A) + K_R; the last
     // update of this call is applied by K_F, which also returns r, p to the caller's vectors
@@ -1787,6 +1826,12 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
   return 0;
 }
 
+int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  *out = s->skinny ? 3 : cgnr_use_gram_pipeline(s) ? 2 : cgnr_use_resident(s) ? 4 : cgnr_use_pipeline(s) ? 1 : 0;
+  return 0;
+}
+
 int32_t rls_cgnr_step_local_a(rls_cgnr* s) {
   if (!s) return RLS_E_INVALID;
   if (!s->initialised) return rls_fail(s->op->ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
@@ -1807,7 +1852,14 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   const float lambda = s->sc_h->lambda, rel_tol = s->sc_h->rel_tol;
   const int max_iter = s->sc_h->max_iter;
+  if (s->resident_used)  // {fail, completed} of the last resident launch ride along with the scalars
+    RLS_HIP(ctx, hipMemcpyAsync(s->rsync_h, (const char*)s->rsync + 8 * 32 * sizeof(unsigned), 2 * sizeof(unsigned),
+                                hipMemcpyDeviceToHost, ctx->stream));
   RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  if (s->resident_used && s->rsync_h[0] && !s->rsync_h[1])
+    return rls_fail(ctx, RLS_E_STATE, "resident CGNR launch timed out waiting for its workgroups (is another process or "
+                                      "stream using the device?): the call was a no-op; rls_tune_set(\"resident\", 0) "
+                                      "selects the two-launch pipeline");
   const cgnr_scalars& h = *s->sc_h;
   out->iteration = h.iteration;
   out->done = h.done;

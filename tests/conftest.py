@@ -24,3 +24,52 @@ def rls():
 @pytest.fixture(scope="session")
 def ctx(rls):
     return rls.default_context(0)
+
+
+# ---- the parity gate (BASELINE.json north_star: iterates within 1e-5 relative Float32) -------------------------
+# Every hot-path comparison goes through `parity`: the device result against the FLOAT64 oracle must be within 1e-5;
+# where Float32 conditioning makes that unattainable the bound is twice the error the oracle itself makes when it
+# runs in the working precision (float32 / complex64 = the reference's Float32 path) against its float64 run.
+# Both errors of every call are appended to gpurun_out/parity_errors.jsonl (the table in DESIGN.md section 3b).
+PARITY_TOL = 1e-5
+_PARITY_LOG = os.path.join(ROOT, "gpurun_out", "parity_errors.jsonl")
+
+
+def _rel(a, b, scale=None):
+    import numpy as np
+
+    a = np.asarray(a).astype(np.complex128)
+    b = np.asarray(b).astype(np.complex128)
+    n = np.linalg.norm(b) if scale is None else float(scale)
+    d = np.linalg.norm(a - b)
+    return float(d / n) if n > 0 else float(d)
+
+
+def parity_check(tag, got, ref64, ref32=None, tol=PARITY_TOL, record=True, scale=None):
+    """assert the gate for one result.  `ref32` may be an array or a zero-argument callable (evaluated only when the
+    1e-5 bound alone does not hold; pass an array to have both errors recorded regardless).  `scale`: measure the
+    difference on this scale instead of ||ref64|| (residual-like vectors that shrink geometrically)."""
+    import json
+
+    e = _rel(got, ref64, scale)
+    e32 = None
+    if ref32 is not None and (e > tol or not callable(ref32)):
+        r32 = ref32() if callable(ref32) else ref32
+        e32 = _rel(r32, ref64, scale)
+    if record:
+        try:
+            os.makedirs(os.path.dirname(_PARITY_LOG), exist_ok=True)
+            with open(_PARITY_LOG, "a") as f:
+                f.write(json.dumps({"tag": tag, "err_gpu_vs_f64": e, "err_f32_oracle_vs_f64": e32, "tol": tol}) + "\n")
+        except OSError:
+            pass
+    if e <= tol:
+        return e
+    assert e32 is not None, f"{tag}: device vs float64 oracle {e:.3e} > {tol:.0e} and no Float32 bound given"
+    assert e <= 2 * e32, f"{tag}: device vs float64 oracle {e:.3e} > 2 x (Float32 oracle vs float64 oracle {e32:.3e})"
+    return e
+
+
+@pytest.fixture(scope="session")
+def parity():
+    return parity_check

@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
-inputs.  Tolerances: 1e-5 relative l2 on iterates (BASELINE.json north_star, Float32); elementwise
-kernels 2e-6; reductions 1e-6.  Run on the GPU box with `pytest -m gpu`."""
+inputs.  Tolerances: 1e-5 relative l2 on iterates against the FLOAT64 oracle (BASELINE.json north_star);
+where Float32 conditioning makes 1e-5 unattainable the gate is 2 x the error of the oracle's own Float32
+run against its float64 run (`parity`, tests/conftest.py; both errors are logged per case and tabulated in
+DESIGN.md section 3b); elementwise kernels 2e-6; reductions 1e-6.  Run on the GPU box with `pytest -m gpu`."""
 import math
 
 import numpy as np
@@ -11,6 +13,18 @@ import rls_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL_ITER = 1e-5
+from conftest import parity_check as parity  # noqa: E402  (the gate: <= 1e-5 vs float64, or <= 2 x the Float32 oracle's own error)
+
+
+def hi(dt):
+    return np.complex128 if np.dtype(dt).kind == "c" else np.float64
+
+
+def oracle_pair(make, *arrays):
+    """make(*arrays) runs an oracle solve in the dtype of its inputs and returns the solution.  Returns the float64
+    result and a thunk for the working-precision (Float32 = the reference's path) result."""
+    x64 = make(*[a.astype(hi(a.dtype)) for a in arrays])
+    return x64, (lambda: make(*arrays))
 
 
 def rel(a, b):
@@ -355,18 +369,21 @@ def test_cgnr_gram_pipeline_iterates(rls, ctx, dt, M, N, lam, iters, pipe):
     ctx.tune(gram_pipeline=pipe)
     try:
         ref, sol, b, dt64 = _cgnr_pair(rls, M, N, dt, 7, lam, iters, mode="gram")
+        ref32 = O.CGNR(ref.A.A.astype(dt), reg=O.L2Regularization(lam), iterations=iters, relTol=0.0, normal="gram")
         bd = rls.DeviceVector.from_host(b)
         ref.init(b.astype(dt64))
+        ref32.init(b)
         rls.init_(sol, bd)
         r0 = np.linalg.norm(ref.A.mul_adj(b.astype(dt64)))
+        tag = f"cgnr_gram_{M}x{N}_{np.dtype(dt).name}_pipe{pipe}"
         for it in range(1, iters + 1):
-            assert ref.iterate() is not None and rls.iterate(sol) is not None
+            assert ref.iterate() is not None and rls.iterate(sol) is not None and ref32.iterate() is not None
             if it in (1, 2, 5, iters):
                 st = sol.state
-                assert rel(st.x.to_host(), ref.x) < 2 * TOL_ITER, it
-                assert np.linalg.norm(st.pl.to_host() - ref.p) < 2 * TOL_ITER * r0, it
-                assert np.linalg.norm(st.x0.to_host() - ref.r) < 2 * TOL_ITER * r0, it
-                assert np.linalg.norm(st.vl.to_host() - ref.v) < 2 * TOL_ITER * np.linalg.norm(ref.v) + 1e-30, it
+                parity(f"{tag}_x_it{it}", st.x.to_host(), ref.x, ref32.x)
+                parity(f"{tag}_p_it{it}", st.pl.to_host(), ref.p, ref32.p, scale=r0)
+                parity(f"{tag}_r_it{it}", st.x0.to_host(), ref.r, ref32.r, scale=r0)
+                parity(f"{tag}_v_it{it}", st.vl.to_host(), ref.v, ref32.v)
         assert rls.iterate(sol) is None and sol.state.iteration == iters
         x_steps = sol.state.x.to_host()
         x_once = rls.solve_(sol, bd).to_host()  # all iterations in one call (graph chunks + finish)
@@ -381,7 +398,8 @@ def test_cgnr_gram_pipeline_iterates(rls, ctx, dt, M, N, lam, iters, pipe):
         x2 = rls.solve_(sol2, bd).to_host()
         assert abs(sol2.state.iteration - ref2.iteration) <= 1
         if sol2.state.iteration == ref2.iteration:
-            assert rel(x2, ref2.x) < 2 * TOL_ITER
+            ref2_32 = O.CGNR(ref.A.A.astype(dt), reg=O.L2Regularization(lam), iterations=ref2.iteration, relTol=0.0, normal="gram")
+            parity(f"{tag}_reltol", x2, ref2.x, lambda: O.solve(ref2_32, b))
     finally:
         ctx.tune(gram_pipeline=1)
 
@@ -470,11 +488,10 @@ def test_fista_other_regs(rls, ctx, regname):
         r_o, r_d = O.L2Regularization(0.5), rls.L2Regularization(0.5)
     else:
         r_o, r_d = O.TVRegularization(2.0, shape=(8, 8)), rls.TVRegularization(2.0, shape=(8, 8))
-    ref = O.FISTA(A, reg=r_o, rho=rho, iterations=15)
-    O.solve(ref, b)
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=r_o, rho=rho, iterations=15), b_), A, b)
     sol = rls.createLinearSolver(rls.FISTA, rls.DeviceMatrix.from_host(A), reg=r_d, rho=rho, iterations=15)
     x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
-    assert rel(x, ref.x) < 2e-5
+    parity(f"fista_{regname}_160x64_f32", x, x64, x32)
 
 
 @pytest.mark.parametrize("dt,M,N,shape", [(np.float32, 128, 64, (8, 8)), (np.float32, 8192, 4096, (64, 64)),
@@ -482,13 +499,15 @@ def test_fista_other_regs(rls, ctx, regname):
 def test_admm_tv_matches_oracle(rls, ctx, dt, M, N, shape):
     A, xt, b = O.make_problem(M, N, dt, 3)
     kw = dict(rho=0.1, iterations=10, iterationsCG=10, tolInner=1e-5)
-    ref = O.ADMM(A, reg=O.TVRegularization(1e-2, shape=shape), **kw)
+    ref = O.ADMM(A, reg=O.TVRegularization(1e-2, shape=shape), **kw)  # Float32 oracle = the reference's path: counts
     O.solve(ref, b)
+    ref64 = O.ADMM(A.astype(hi(dt)), reg=O.TVRegularization(1e-2, shape=shape), **kw)  # float64 oracle: the truth for x
+    O.solve(ref64, b.astype(hi(dt)))
     sol = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.TVRegularization(1e-2, shape=shape), **kw)
     x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
     assert sol.state.iteration == ref.iteration
     assert sol.state.cg_iterations == ref.cg_iters
-    assert rel(x, ref.x) < 2e-5
+    parity(f"admm_tv_{M}x{N}_{np.dtype(dt).name}" + (" (BASELINE config 3)" if M == 8192 else ""), x, ref64.x, ref.x)
     assert np.allclose(sol.state.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(sol.state.sk, ref.sk, rtol=2e-3, atol=1e-6)
 
 
@@ -526,10 +545,14 @@ def test_admm_device_plan_equals_per_call_path(rls, ctx, dt, M, N, kind):
     assert not old.state._plan_ok
     assert sol.state.iteration == old.state.iteration == ref.iteration
     assert sol.state.cg_iterations == old.state.cg_iterations == ref.cg_iters
-    assert rel(x, ref.x) < 2e-5 and rel(x, x_old) < 2e-6
+    ref64 = O.ADMM(A.astype(hi(dt)), reg=regs(O), **kw)
+    parity(f"admm_plan_{kind}_{M}x{N}_{np.dtype(dt).name}", x, O.solve(ref64, b.astype(hi(dt))), ref.x)
+    assert rel(x, x_old) < 2e-6
     assert np.allclose(sol.state.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(sol.state.sk, ref.sk, rtol=2e-3, atol=1e-6)
     assert np.allclose(sol.state.eps_pri, old.state.eps_pri, rtol=1e-5) and np.allclose(sol.state.eps_dua, old.state.eps_dua, rtol=1e-5)
     assert rel(sol.state.z[0].to_host(), old.state.z[0].to_host()) < 2e-6
+    # u = sum of (x - z) over the iterations: a difference of nearly equal vectors, so the 2e-6 agreement of x and z
+    # between the two device paths is ~10x larger relative to ||u|| (two device paths against each other, not the gate)
     assert rel(sol.state.u[0].to_host(), old.state.u[0].to_host()) < 2e-5
     # with callbacks: one plan iteration per host iteration, the same bits as the bulk run
     seen = []
@@ -548,11 +571,14 @@ def test_admm_device_plan_stops_when_converged(rls, ctx):
     assert 1 < ref.iteration < 60
     sol = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(1e-3), **kw)
     bd = rls.DeviceVector.from_host(b)
+    # float64 truth with the stop iteration of the Float32 path (the stop test sits on a Float32 threshold)
+    ref64 = O.ADMM(A.astype(np.float64), reg=O.L1Regularization(1e-3), **dict(kw, iterations=ref.iteration, absTol=0.0, relTol=0.0))
+    x64 = O.solve(ref64, b.astype(np.float64))
     for _ in range(2):
         x = rls.solve_(sol, bd).to_host()
         assert sol.state._plan_ok and sol.state.iteration == ref.iteration
         assert sol.converged(sol.state)
-        assert rel(x, ref.x) < 2e-5
+        parity("admm_l1_converged_150x50_f32", x, x64, ref.x)
         assert len(sol.state.cg_iterations) == ref.iteration
 
 
@@ -570,21 +596,25 @@ def test_fista_gram_mode_matches_oracle(rls, ctx, dt, M, N, restart, pipe):
         rho = 0.95 / np.linalg.norm(A64, 2) ** 2
         lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
         its = 25
-        ref = O.FISTA(A64, reg=[O.L1Regularization(lam), O.PositiveRegularization()] if restart == "gradient" else O.L1Regularization(lam),
-                      rho=rho, iterations=its, restart=restart, normal="gram")
+        oreg = [O.L1Regularization(lam), O.PositiveRegularization()] if restart == "gradient" else O.L1Regularization(lam)
+        ref = O.FISTA(A64, reg=oreg, rho=rho, iterations=its, restart=restart, normal="gram")
+        ref32 = O.FISTA(A, reg=oreg, rho=rho, iterations=its, restart=restart, normal="gram")
+        tag = f"fista_gram_{M}x{N}_{np.dtype(dt).name}_pipe{pipe}"
         Ad = rls.DeviceMatrix.from_host(A)
         reg = [rls.L1Regularization(lam), rls.PositiveRegularization()] if restart == "gradient" else rls.L1Regularization(lam)
         sol = rls.createLinearSolver(rls.FISTA, Ad, AHA=Ad.gram(), reg=reg, rho=rho, iterations=its, restart=restart)
         bd = rls.DeviceVector.from_host(b)
         ref.init(b64)
+        ref32.init(b)
         rls.init_(sol, bd)
         for it in range(1, its + 1):
-            assert ref.iterate() is not None and rls.iterate(sol) is not None
+            assert ref.iterate() is not None and rls.iterate(sol) is not None and ref32.iterate() is not None
             if it in (1, 2, 7, its):
-                assert rel(sol.state.x.to_host(), ref.x) < 3e-5, it
+                parity(f"{tag}_it{it}", sol.state.x.to_host(), ref.x, ref32.x)
         assert rls.iterate(sol) is None
         x_once = rls.solve_(sol, bd).to_host()
-        assert rel(x_once, ref.x) < 3e-5 and sol.state.iteration == its
+        parity(f"{tag}_once", x_once, ref.x, ref32.x)
+        assert sol.state.iteration == its
     finally:
         ctx.tune(gram_pipeline=1)
 
@@ -597,15 +627,18 @@ def test_admm_gram_mode_matches_oracle(rls, ctx, dt, M, N, shape):
     kw = dict(rho=0.1, iterations=6, iterationsCG=10, tolInner=1e-5)
     ref = O.ADMM(A, reg=O.TVRegularization(1e-2, shape=shape), normal="gram", **kw)
     O.solve(ref, b)
+    ref64 = O.ADMM(A.astype(hi(dt)), reg=O.TVRegularization(1e-2, shape=shape), normal="gram", **kw)
+    O.solve(ref64, b.astype(hi(dt)))
     Ad = rls.DeviceMatrix.from_host(A)
     sol = rls.createLinearSolver(rls.ADMM, Ad, AHA=Ad.gram(), reg=rls.TVRegularization(1e-2, shape=shape), **kw)
     x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
     assert sol.state.iteration == ref.iteration and sol.state.cg_iterations == ref.cg_iters
-    assert rel(x, ref.x) < 3e-5
+    tag = f"admm_tv_gram_{M}x{N}_{np.dtype(dt).name}"
+    parity(tag, x, ref64.x, ref.x)
     ctx.tune(gram_pipeline=0)
     try:
         sol2 = rls.createLinearSolver(rls.ADMM, Ad, AHA=Ad.gram(), reg=rls.TVRegularization(1e-2, shape=shape), **kw)
-        assert rel(rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host(), ref.x) < 3e-5
+        parity(tag + "_nopipe", rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host(), ref64.x, ref.x)
     finally:
         ctx.tune(gram_pipeline=1)
 
@@ -616,16 +649,19 @@ def test_admm_l1_vary_rho_and_gradient_trafo(rls, ctx, vary):
     kw = dict(rho=0.5, iterations=8, vary_rho=vary)
     ref = O.ADMM(A, reg=O.L1Regularization(0.05), **kw)
     O.solve(ref, b)
+    ref64 = O.ADMM(A.astype(np.float64), reg=O.L1Regularization(0.05), **kw)
+    O.solve(ref64, b.astype(np.float64))
     sol = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05), **kw)
     x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
-    assert rel(x, ref.x) < 5e-5 and np.allclose(sol.state.rho, ref.rho)
+    parity(f"admm_l1_vary_{vary}_100x48_f32", x, ref64.x, ref.x)
+    assert np.allclose(sol.state.rho, ref.rho)
     # TV as L1-of-gradient (src/ADMM.jl:74): regTrafo = GradientOp
-    ref2 = O.ADMM(A, reg=O.L1Regularization(0.05), regTrafo=O.GradientTrafo((8, 6)), rho=0.5, iterations=5)
-    O.solve(ref2, b)
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.ADMM(A_, reg=O.L1Regularization(0.05), regTrafo=O.GradientTrafo((8, 6)),
+                                                        rho=0.5, iterations=5), b_), A, b)
     sol2 = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05),
                                   regTrafo=rls.GradientOp((8, 6)), rho=0.5, iterations=5)
     x2 = rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host()
-    assert rel(x2, ref2.x) < 5e-5
+    parity("admm_l1_gradient_trafo_100x48_f32", x2, x64, x32)
 
 
 @pytest.mark.parametrize("scheduler", ["SequentialState", "MultiThreadingState"])
@@ -735,15 +771,14 @@ def test_row_sharded_fista_two_shards_on_gpu(rls, ctx, dt):
     xs = [s.solution() for s in pair.shards]
     assert np.array_equal(xs[0], xs[1])  # replicated state: bit-identical on both shards
     regs = [O.L1Regularization(lam)] + ([O.PositiveRegularization()] if dt == np.float32 else [])
-    ref = O.FISTA(A.astype(dt64), reg=regs, rho=rho, iterations=30, relTol=0.0, restart="gradient")
-    O.solve(ref, b.astype(dt64))
-    assert rel(xs[0], ref.x) < 5e-5
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=regs, rho=rho, iterations=30, relTol=0.0, restart="gradient"), b_), A, b)
+    parity(f"fista_rowsharded_2shards_768x256_{np.dtype(dt).name}", xs[0], x64, x32)
     assert all(s.status()["iteration"] == 30 for s in pair.shards)
     # world = 1 (no collective) through the same entry points
     one = rls.multigpu.HipFistaOps(rls, A, dev, reg=rls.L1Regularization(lam),
                                    proj=rls.PositiveRegularization() if dt == np.float32 else None)
     x1 = rls.RowShardedFISTA(one, None, rho=rho, iterations=30, relTol=0.0, restart="gradient").solve(b)
-    assert rel(x1, ref.x) < 5e-5
+    parity(f"fista_rowsharded_1shard_768x256_{np.dtype(dt).name}", x1, x64, x32)
     for s in pair.shards + (one,):
         s.close()
 
@@ -771,7 +806,8 @@ def test_row_sharded_admm_two_shards_on_gpu(rls, ctx, kind):
     ref = O.ADMM(A, reg=reg_o, **kw)
     O.solve(ref, b)
     assert a.iteration == ref.iteration and a.cg_iterations == ref.cg_iters
-    assert rel(xs[0], ref.x) < 3e-5
+    ref64 = O.ADMM(A.astype(np.float64), reg=reg_o, **kw)
+    parity(f"admm_rowsharded_2shards_{kind}_640x144_f32", xs[0], O.solve(ref64, b.astype(np.float64)), ref.x)
     assert np.allclose(a.rk, ref.rk, rtol=2e-3, atol=1e-6) and np.allclose(a.sk, ref.sk, rtol=2e-3, atol=1e-6)
     for s in pair.shards:
         s.close()
@@ -786,12 +822,19 @@ def test_multisolve_single_rank(rls, ctx):
     assert got.shape == (64, 5) and rel(got, X) < 1e-3
     # default: the local columns share A (BatchedState); the reference's scheduler gives the same columns
     seq = rls.MultiSolve(rls, lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=64), scheduler=rls.MultiThreadingState).solve(B)
-    assert rel(got, seq) < 2e-5
+    for j in range(5):  # both schedulers against the oracle, column by column
+        x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.CGNR(A_, iterations=64), b_), A, B[:, j])
+        parity(f"multisolve_cgnr_batched_col{j}", got[:, j], x64, x32)
+        parity(f"multisolve_cgnr_threads_col{j}", seq[:, j], x64, x32)
     rho = 0.9 / np.linalg.norm(A.astype(np.complex128), 2) ** 2
     mk = lambda: rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-3), rho=rho, iterations=30)
     f_b = rls.MultiSolve(rls, mk).solve(B)
     f_s = rls.MultiSolve(rls, mk, scheduler=rls.MultiThreadingState).solve(B)
-    assert f_b.shape == (64, 5) and rel(f_b, f_s) < 2e-5
+    assert f_b.shape == (64, 5)
+    for j in range(5):
+        x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=O.L1Regularization(1e-3), rho=rho, iterations=30), b_), A, B[:, j])
+        parity(f"multisolve_fista_batched_col{j}", f_b[:, j], x64, x32)
+        parity(f"multisolve_fista_threads_col{j}", f_s[:, j], x64, x32)
 
 
 @pytest.mark.parametrize("mfma", [1, 0])
@@ -821,15 +864,20 @@ def _batched_case(rls, ctx, dt, M, N, K):
         for j in range(K):
             ref = O.CGNR(A.astype(dt64), reg=O.L2Regularization(1e-3), iterations=iters, relTol=relTol)
             O.solve(ref, B[:, j].astype(dt64))
-            assert rel(xs[j].to_host(), ref.x) < 2e-5, (relTol, j)
+            # Float32 bound: the oracle's Float32 run stopped at the float64 run's iteration (the relTol threshold is
+            # itself a Float32-conditioned decision)
+            x32 = lambda: O.solve(O.CGNR(A, reg=O.L2Regularization(1e-3), iterations=ref.iteration, relTol=0.0), np.ascontiguousarray(B[:, j]))
+            if its is None or its[j] == ref.iteration:
+                parity(f"batched_cgnr_{M}x{N}_{np.dtype(dt).name}_K{K}_reltol{relTol}_col{j}", xs[j].to_host(), ref.x, x32,
+                       record=(j < 2))
             if its is not None:
                 assert abs(its[j] - ref.iteration) <= (1 if relTol > 0 else 0), (its, j, ref.iteration)
     # a vector solve still works afterwards (src/MultiThreading.jl:39-43)
     S2 = rls.createLinearSolver(rls.CGNR, Ad, iterations=iters, relTol=0.0)
     rls.solve_(S2, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
     v = rls.solve_(S2, rls.DeviceVector.from_host(B[:, 1])).to_host()
-    ref = O.CGNR(A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64), iterations=iters, relTol=0.0)
-    assert rel(v, O.solve(ref, B[:, 1].astype(ref.dtype))) < 2e-5
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.CGNR(A_, iterations=iters, relTol=0.0), b_), A, np.ascontiguousarray(B[:, 1]))
+    parity(f"batched_then_vector_{M}x{N}_{np.dtype(dt).name}", v, x64, x32)
 
 
 @pytest.mark.parametrize("name,kw", [("OptISTA", {}), ("POGM", {}), ("POGM", {"restart": "gradient"})])
@@ -842,13 +890,12 @@ def test_optista_pogm_match_oracle(rls, ctx, name, kw, dt, M, N):
     A64, b64 = A.astype(dt64), b.astype(dt64)
     rho = 0.95 / np.linalg.norm(A64, 2) ** 2
     lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
-    ref = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=30, **kw)
-    O.solve(ref, b64)
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(getattr(O, name)(A_, reg=O.L1Regularization(lam), rho=rho, iterations=30, **kw), b_), A, b)
     sol = rls.createLinearSolver(getattr(rls, name), rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(lam),
                                  rho=rho, iterations=30, **kw)
     x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
     assert sol.state.iteration == 30
-    assert rel(x, ref.x) < 3e-5
+    parity(f"{name}{'_restart' if kw else ''}_{M}x{N}_{np.dtype(dt).name}", x, x64, x32)
 
 
 @pytest.mark.parametrize("name,kw", [("OptISTA", {}), ("POGM", {"restart": "gradient"})])
@@ -859,15 +906,16 @@ def test_optista_pogm_generic_path_and_projection(rls, ctx, name, kw):
     A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
     rho = 0.95 / np.linalg.norm(A64, 2) ** 2
     lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
-    ref = getattr(O, name)(A64, reg=O.L21Regularization(lam, slices=4), rho=rho, iterations=20, **kw)
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(getattr(O, name)(A_, reg=O.L21Regularization(lam, slices=4), rho=rho, iterations=20, **kw), b_), A, b)
     sol = rls.createLinearSolver(getattr(rls, name), rls.DeviceMatrix.from_host(A), reg=rls.L21Regularization(lam, slices=4),
                                  rho=rho, iterations=20, **kw)
-    assert rel(rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host(), O.solve(ref, b64)) < 3e-5
+    parity(f"{name}_l21_generic_192x64_c64", rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host(), x64, x32)
     if name == "POGM":
-        ref = O.POGM(A64, reg=[O.L1Regularization(lam), O.PositiveRegularization()], rho=rho, iterations=20, **kw)
+        x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.POGM(A_, reg=[O.L1Regularization(lam), O.PositiveRegularization()], rho=rho,
+                                                            iterations=20, **kw), b_), A, b)
         sol = rls.createLinearSolver(rls.POGM, rls.DeviceMatrix.from_host(A),
                                      reg=[rls.L1Regularization(lam), rls.PositiveRegularization()], rho=rho, iterations=20, **kw)
-        assert rel(rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host(), O.solve(ref, b64)) < 3e-5
+        parity("POGM_l1_positive_192x64_c64", rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host(), x64, x32)
 
 
 def test_split_bregman_matches_oracle(rls, ctx):
@@ -878,13 +926,15 @@ def test_split_bregman_matches_oracle(rls, ctx):
     O.solve(ref, b.astype(np.float64))
     sol = rls.createLinearSolver(rls.SplitBregman, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05), **kw)
     x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
-    assert rel(x, ref.x) < 5e-5 and sol.state.iter_cnt == ref.iter_cnt
+    parity("splitbregman_l1_160x64_f32", x, ref.x, lambda: O.solve(O.SplitBregman(A, reg=O.L1Regularization(0.05), **kw), b))
+    assert sol.state.iter_cnt == ref.iter_cnt
     ref2 = O.SplitBregman(A.astype(np.float64), reg=O.L1Regularization(0.05), regTrafo=O.GradientTrafo((8, 8)), **kw)
     O.solve(ref2, b.astype(np.float64))
     sol2 = rls.createLinearSolver(rls.SplitBregman, rls.DeviceMatrix.from_host(A), reg=rls.L1Regularization(0.05),
                                   regTrafo=rls.GradientOp((8, 8)), **kw)
     x2 = rls.solve_(sol2, rls.DeviceVector.from_host(b)).to_host()
-    assert rel(x2, ref2.x) < 5e-5
+    parity("splitbregman_l1_gradient_trafo_160x64_f32", x2, ref2.x,
+           lambda: O.solve(O.SplitBregman(A, reg=O.L1Regularization(0.05), regTrafo=O.GradientTrafo((8, 8)), **kw), b))
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.complex64])
@@ -905,8 +955,8 @@ def test_normalization_schemes(rls, ctx, dt):
         S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), normalizeReg=scheme, iterations=20)
         x = rls.solve_(S, bd).to_host()
         assert abs(S.L2.lam - lam * f) < 1e-5 * lam * f and rls.scalefactor(S.L2) == pytest.approx(f, rel=1e-5)
-        ref = O.CGNR(A64, reg=O.L2Regularization(lam * f), iterations=20)
-        assert rel(x, O.solve(ref, b64)) < 2e-5
+        x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.CGNR(A_, reg=O.L2Regularization(lam * f), iterations=20), b_), A, b)
+        parity(f"cgnr_normalized_{key}_192x80_{np.dtype(dt).name}", x, x64, x32)
         # solving again re-normalises from the unscaled lambda (NormalizedRegularization.jl:73), it does not compound
         rls.solve_(S, bd)
         assert abs(S.L2.lam - lam * f) < 1e-5 * lam * f
@@ -916,8 +966,8 @@ def test_normalization_schemes(rls, ctx, dt):
     S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-3), normalizeReg=rls.MeasurementBasedNormalization(),
                                rho=rho, iterations=25)
     x = rls.solve_(S, bd).to_host()
-    ref = O.FISTA(A64, reg=O.L1Regularization(1e-3 * f), rho=rho, iterations=25)
-    assert rel(x, O.solve(ref, b64)) < 3e-5
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=O.L1Regularization(1e-3 * f), rho=rho, iterations=25), b_), A, b)
+    parity(f"fista_normalized_192x80_{np.dtype(dt).name}", x, x64, x32)
     with pytest.raises(ValueError):
         rls.createLinearSolver(rls.CGNR, AHA=Ad.gram(), reg=rls.L2Regularization(lam),
                                normalizeReg=rls.SystemMatrixBasedNormalization())
@@ -938,7 +988,8 @@ def test_weighted_operator(rls, ctx, dt):
     S = rls.createLinearSolver(rls.CGNR, WA, AHA=rls.normalOperator(WA), reg=rls.L2Regularization(1e-4), iterations=16)
     x = rls.solve_(S, rls.DeviceVector.from_host((w * b).astype(dt))).to_host()
     ref = O.CGNR(WA64, reg=O.L2Regularization(1e-4), iterations=16)
-    assert rel(x, O.solve(ref, wb64)) < 2e-5
+    parity(f"cgnr_weighted_{A.shape[0]}x{A.shape[1]}_{np.dtype(dt).name}", x, O.solve(ref, wb64),
+           lambda: O.solve(O.CGNR(O.weighted_operator(w, A), reg=O.L2Regularization(1e-4), iterations=16), (w * b).astype(dt)))
     f = O.normalization_factor("systemmatrix", WA64, None)  # weights^2 * rownorm², GPU ext NormalizedRegularization.jl:7-12
     assert abs(WA.rownorm2().norm1() / A.shape[1] - f) < 1e-5 * f
 
@@ -1005,8 +1056,13 @@ def test_kaczmarz_matches_oracle(rls, ctx, dt, M, N, lam, its):
     assert len(S.rowindex) == M - 1
     x = rls.solve_(S, rls.DeviceVector.from_host(b)).to_host()
     assert S.state.iteration == its
-    assert rel(x, xr) < 5e-5
-    assert np.linalg.norm(S.state.vl.to_host() - ref.vl) <= 5e-5 * max(np.linalg.norm(ref.vl), 1e-30) + 1e-12
+    ref32 = O.Kaczmarz(A, reg=O.L2Regularization(lam), iterations=its)
+    x32 = O.solve(ref32, b)
+    parity(f"kaczmarz_{M}x{N}_{np.dtype(dt).name}_x", x, xr, x32)
+    if np.linalg.norm(ref.vl) > 0:
+        parity(f"kaczmarz_{M}x{N}_{np.dtype(dt).name}_vl", S.state.vl.to_host(), ref.vl, ref32.vl)
+    else:
+        assert np.linalg.norm(S.state.vl.to_host()) <= 1e-12
     res = rls.solverconvergence(S)["residual"]
     assert abs(res - np.linalg.norm(A.astype(dt64) @ xr - b.astype(dt64))) < 1e-3 * np.linalg.norm(b) + 1e-6
     # step-by-step with callbacks == the single multi-sweep launch (callback cadence 0..n, test/testCallbacks.jl:6-16)
@@ -1062,7 +1118,9 @@ def test_kaczmarz_reference_test_suite(rls, ctx):
     # projection applied after every sweep (:294-296)
     S = rls.createLinearSolver(rls.Kaczmarz, Ad, iterations=5, reg=[rls.L2Regularization(0.0), rls.RealRegularization()])
     ref = O.Kaczmarz(A64, reg=[O.L2Regularization(0.0), O.RealRegularization()], iterations=5)
-    assert rel(rls.solve_(S, bd).to_host(), O.solve(ref, b.astype(np.complex128))) < 5e-5
+    parity("kaczmarz_real_projection", rls.solve_(S, bd).to_host(), O.solve(ref, b.astype(np.complex128)),
+           lambda: O.solve(O.Kaczmarz(A64.astype(np.complex64), reg=[O.L2Regularization(0.0), O.RealRegularization()], iterations=5),
+                           b.astype(np.complex64)))
 
 
 def test_kaczmarz_matrix_rhs_one_launch(rls, ctx):
@@ -1099,13 +1157,16 @@ def test_config4_all_64_columns_full_size(rls, ctx):
     A64 = A.astype(np.complex128)
     for j in (0, 17, 63):
         ref = O.CGNR(A64, iterations=32, relTol=0.0)
-        assert rel(got[:, j], O.solve(ref, B[:, j].astype(np.complex128))) < 2e-5
-    # linearity: column 0 <- 2 b0 - 0.5i b1 must give 2 x0 - 0.5i x1
+        parity(f"BASELINE config 4: batched CGNR 4096x2048 c64, 64 columns, column {j}", got[:, j],
+               O.solve(ref, B[:, j].astype(np.complex128)), O.solve(O.CGNR(A, iterations=32, relTol=0.0), np.ascontiguousarray(B[:, j])))
+    # linearity: column 0 <- 2 b0 - 0.5i b1 must give 2 x0 - 0.5i x1 (against the float64 solution of that column)
     B2 = np.asfortranarray(B[:, :16]).copy()
     B2[:, 0] = 2 * B[:, 0] - 0.5j * B[:, 1]
     S2 = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
     ys = rls.solve_(S2, rls.DeviceMatrix.from_host(B2), scheduler=rls.BatchedState)
-    assert rel(ys[0].to_host(), 2 * got[:, 0] - 0.5j * got[:, 1]) < 5e-5
+    x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.CGNR(A_, iterations=32, relTol=0.0), b_), A, np.ascontiguousarray(B2[:, 0]))
+    parity("config 4 linearity column", ys[0].to_host(), x64, x32)
+    assert rel(2 * got[:, 0] - 0.5j * got[:, 1], x64) < 1e-5
     assert np.array_equal(ys[5].to_host(), got[:, 5])  # the other columns are untouched, bit for bit
 
 
@@ -1144,8 +1205,32 @@ def test_config5_shard_size_properties(rls, ctx):
     got = rls.solve_(S, rls.DeviceVector.from_host(b),
                      callbacks=lambda s2, it: res.append(rls.solverconvergence(s2)["residual"])).to_host()
     assert all(b2 < a2 for a2, b2 in zip(res[1:], res[2:]))  # CG on a well-conditioned matrix: monotone here
-    ref = O.CGNR(A, iterations=8, relTol=0.0)  # complex64 restatement, same operation order
-    assert rel(got, O.solve(ref, b)) < 1e-4
+    # float64 oracle with A kept in complex64 and widened panel by panel (a complex128 copy would be 1 GiB)
+    ref64 = O.CGNR(_PanelF64Op(A), iterations=8, relTol=0.0)
+    x64 = O.solve(ref64, b.astype(np.complex128))
+    ref32 = O.CGNR(A, iterations=8, relTol=0.0)  # complex64 restatement = the reference's Float32 path
+    parity("BASELINE config 5 shard: CGNR 8192x8192 c64 (square: ill-conditioned), 8 iterations", got, x64, O.solve(ref32, b))
+
+
+class _PanelF64Op:
+    """float64 forward / adjoint products of a complex64 (or float32) matrix, 512 columns at a time (oracle side)"""
+
+    def __init__(self, A, panel=512):
+        self.A, self.panel = A, panel
+        self.dtype = np.dtype(hi(A.dtype))
+        self.shape = A.shape
+
+    def mul(self, x):
+        y = np.zeros(self.shape[0], self.dtype)
+        for j in range(0, self.shape[1], self.panel):
+            y += self.A[:, j:j + self.panel].astype(self.dtype) @ x[j:j + self.panel]
+        return y
+
+    def mul_adj(self, y):
+        out = np.empty(self.shape[1], self.dtype)
+        for j in range(0, self.shape[1], self.panel):
+            out[j:j + self.panel] = self.A[:, j:j + self.panel].astype(self.dtype).conj().T @ y
+        return out
 
 
 def test_golden_next_tier_on_device(rls, ctx):
@@ -1155,8 +1240,9 @@ def test_golden_next_tier_on_device(rls, ctx):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "next_tier_96x40_c64.npz"))
     got = _next_tier_solutions(rls, g, wrap=lambda a: rls.DeviceMatrix.from_host(np.asfortranarray(a)),
                                vec=lambda a: rls.DeviceVector.from_host(a))
+    got32 = _next_tier_solutions(O, g, wrap=lambda a: a.astype(np.complex64), vec=lambda a: a.astype(np.complex64))
     for k, v in got.items():
-        assert rel(v.to_host(), g[k]) < 5e-5, k
+        parity(f"golden_next_tier_{k}", v.to_host(), g[k], np.asarray(got32[k]))
 
 
 # ---- singular-value thresholding prox maps ------------------------------------------
@@ -1176,7 +1262,8 @@ def test_prox_nuclear_matches_svd(rls, ctx, dt, m, n):
     ref = O.prox_nuclear(x.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64), lam, (m, n))
     xd = rls.DeviceVector.from_host(x)
     rls.prox_(rls.NuclearRegularization(lam, svtShape=(m, n)), xd)
-    assert rel(xd.to_host(), ref) < 2e-5
+    # Float32 bound: the oracle (LAPACK svd) in the working precision
+    parity(f"prox_nuclear_{m}x{n}_{np.dtype(dt).name}", xd.to_host(), ref, lambda: O.prox_nuclear(x.copy(), lam, (m, n)), record=False)
     # lambda above the largest singular value: everything is thresholded away
     xd = rls.DeviceVector.from_host(x)
     rls.prox_(rls.NuclearRegularization, xd, 1e6, svtShape=(m, n))
@@ -1203,7 +1290,7 @@ def test_prox_llr_matches_oracle(rls, ctx, dt, shape, bs, K, shift):
         rls.prox_(reg, xd)
     else:
         reg._call(xd, lam, list(shift))
-    assert rel(xd.to_host(), ref) < 2e-5
+    parity(f"prox_llr_{shape}_{np.dtype(dt).name}", xd.to_host(), ref, lambda: O.prox_llr(x.copy(), lam, shape, bs, shift), record=False)
 
 
 def test_prox_llr_overlapping_randshift_and_denoising(rls, ctx):
@@ -1215,12 +1302,13 @@ def test_prox_llr_overlapping_randshift_and_denoising(rls, ctx):
     ref = O.prox_llr_overlapping(x.astype(np.complex128), 0.8, shape, bs)
     xd = rls.DeviceVector.from_host(x)
     rls.prox_(rls.LLRRegularization(0.8, shape=shape, blockSize=bs, fullyOverlapping=True), xd)
-    assert rel(xd.to_host(), ref) < 3e-5
+    parity("prox_llr_overlapping", xd.to_host(), ref, lambda: O.prox_llr_overlapping(x.copy(), 0.8, shape, bs), record=False)
     reg = rls.LLRRegularization(0.8, shape=shape, blockSize=bs, randshift=True, seed=5)
     xd = rls.DeviceVector.from_host(x)
     rls.prox_(reg, xd)
-    cands = [O.prox_llr(x.astype(np.complex128), 0.8, shape, bs, (a, b)) for a in range(1, 5) for b in range(1, 4)]
-    assert min(rel(xd.to_host(), c) for c in cands) < 2e-5
+    cands = [((a, b), O.prox_llr(x.astype(np.complex128), 0.8, shape, bs, (a, b))) for a in range(1, 5) for b in range(1, 4)]
+    sh_best, c_best = min(cands, key=lambda c: rel(xd.to_host(), c[1]))
+    parity("prox_llr_randshift", xd.to_host(), c_best, lambda: O.prox_llr(x.copy(), 0.8, shape, bs, sh_best), record=False)
     # denoising: rank-2 image series + noise
     shp, sigma = (32, 32, 20), 0.05
     base = sum(np.einsum("i,j,k->ijk", rng.random(32), rng.random(32), rng.random(20)) for _ in range(2))
@@ -1433,26 +1521,29 @@ def test_fista_batched_matrix_solve_equals_column_solves(rls, ctx, dt, M, N, K, 
     xs = rls.solve_(S, Bd, scheduler=rls.BatchedState)
     assert type(S.state).__name__ == "FistaBatchedState"
     stat = S.state.status()
-    its_seen = []
+    its_seen, refs = [], {}
+    # the reference's own scheduler must give the same columns: both are gated against the oracle
+    S2 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=its, relTol=relTol, restart=restart)
+    ys = rls.solve_(S2, Bd, scheduler=rls.MultiThreadingState)
     for j in range(K if M < 1000 else 3):
         ref = O.FISTA(A64, reg=regs(O), rho=rho, iterations=its, relTol=relTol, restart=restart)
         O.solve(ref, B[:, j].astype(dt64))
         assert stat[j].iteration == ref.iteration, (j, stat[j].iteration, ref.iteration)
-        assert rel(xs[j].to_host(), ref.x) < 5e-5, j
+        # Float32 bound: the oracle in the working precision, stopped at the same iteration
+        x32 = lambda: O.solve(O.FISTA(A, reg=regs(O), rho=rho, iterations=ref.iteration, relTol=0.0, restart=restart), np.ascontiguousarray(B[:, j]))
+        tag = f"fista_batched_{kind}_{M}x{N}_{np.dtype(dt).name}_K{K}_col{j}"
+        parity(tag, xs[j].to_host(), ref.x, x32, record=(j < 2))
+        parity(tag + "_threads", ys[j].to_host(), ref.x, x32, record=False)
         its_seen.append(ref.iteration)
+        refs[j] = (ref.x, x32)
     if kind == "l1" and M < 1000:
         assert len(set(its_seen)) > 1  # the columns really did retire at different iterations
-    # the reference's own scheduler gives the same columns
-    S2 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=its, relTol=relTol, restart=restart)
-    ys = rls.solve_(S2, Bd, scheduler=rls.MultiThreadingState)
-    for j in range(K):
-        assert rel(xs[j].to_host(), ys[j].to_host()) < 2e-5, j
     # iterating with callbacks reaches the same result; a vector solve still works afterwards
     seen = []
     zs = rls.solve_(S, Bd, scheduler=rls.BatchedState, callbacks=lambda s_, it: seen.append(it))
     assert seen[0] == 0 and all(np.array_equal(z.to_host(), x.to_host()) for z, x in zip(zs, xs))
     x1 = rls.solve_(S, rls.DeviceVector.from_host(B[:, 1].copy())).to_host()
-    assert rel(x1, xs[1].to_host()) < 2e-5
+    parity("fista_vector_after_batched", x1, refs[1][0], refs[1][1], record=False)
 
 
 @pytest.mark.parametrize("name", ["OptISTA", "POGM", "POGM-restart"])
@@ -1476,7 +1567,9 @@ def test_optista_pogm_deferred_run_equals_stepwise(rls, ctx, name):
         for _ in range(2):
             x = rls.solve_(sol, bd).to_host()
             assert sol.state.iteration == ref.iteration, (relTol, sol.state.iteration, ref.iteration)
-            assert rel(x, ref.x) < 3e-5
+            parity(f"{name}{'_restart' if extra else ''}_deferred_reltol{relTol}", x, ref.x,
+                   lambda: O.solve(getattr(O, name)(A, reg=O.L1Regularization(lam), rho=rho, iterations=ref.iteration, relTol=0.0, **extra), b),
+                   record=False)
             assert np.isclose(sol.state.rel_res_norm, ref.rel_res_norm, rtol=2e-3)
         if relTol > 0:
             assert 1 < ref.iteration < its
@@ -1514,7 +1607,9 @@ def test_split_bregman_blocks_on_the_device_plan(rls, ctx, dt, M, N, kind):
     x_old = rls.solve_(old, bd).to_host()
     assert not old.state._plan_ok
     assert (sol.state.iter_cnt, sol.state.iteration) == (old.state.iter_cnt, old.state.iteration) == (ref.iter_cnt, ref.iteration)
-    assert rel(x, ref.x) < 3e-5 and rel(x, x_old) < 3e-6
+    ref64 = O.SplitBregman(A.astype(hi(dt)), reg=regs(O), **kw)
+    parity(f"splitbregman_plan_{kind}_{M}x{N}", x, O.solve(ref64, b.astype(hi(dt))), ref.x, record=False)
+    assert rel(x, x_old) < 3e-6
     assert np.allclose(sol.state.rk, old.state.rk, rtol=1e-4) and np.allclose(sol.state.sk, old.state.sk, rtol=1e-4)
     seen = []
     x_cb = rls.solve_(sol, bd, callbacks=lambda s_, it: seen.append(it)).to_host()
@@ -1544,22 +1639,27 @@ def test_random_shapes_against_oracle(rls, ctx):
         Ad = rls.DeviceMatrix.from_host(A)
         xd, yd = rls.DeviceVector.from_host(x), rls.DeviceVector.from_host(y)
         tag = (M, N, np.dtype(dt).name)
-        assert rel(Ad.mul_(rls.DeviceVector(M, dt, ctx), xd).to_host(), A64 @ x) < 2e-5, tag
-        assert rel(Ad.mul_adj_(rls.DeviceVector(N, dt, ctx), yd).to_host(), A64.conj().T @ y) < 2e-5, tag
+        # single products of random vectors can cancel: the Float32 bound is NumPy's own product in the working precision
+        parity(f"fuzz_gemv_n_{tag}", Ad.mul_(rls.DeviceVector(M, dt, ctx), xd).to_host(), A64 @ x, lambda: A @ x.astype(dt), record=False)
+        parity(f"fuzz_gemv_c_{tag}", Ad.mul_adj_(rls.DeviceVector(N, dt, ctx), yd).to_host(), A64.conj().T @ y,
+               lambda: A.conj().T @ y.astype(dt), record=False)
         op = rls.OperatorHandle(Ad)
-        assert rel(op.mul_normal_(rls.DeviceVector(N, dt, ctx), xd).to_host(), A64.conj().T @ (A64 @ x)) < 3e-5, tag
+        parity(f"fuzz_normal_{tag}", op.mul_normal_(rls.DeviceVector(N, dt, ctx), xd).to_host(), A64.conj().T @ (A64 @ x),
+               lambda: A.conj().T @ (A @ x.astype(dt)), record=False)
         b = (A64 @ rng.standard_normal(N)).astype(dt)
         its = min(4, N, max(M - 1, 1))  # CG past the rank of A only amplifies Float32 rounding
         ref = O.CGNR(A64, reg=O.L2Regularization(0.1), iterations=its, relTol=0.0)
         O.solve(ref, b.astype(dt64))
         S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(0.1), iterations=its, relTol=0.0)
-        assert rel(rls.solve_(S, rls.DeviceVector.from_host(b)).to_host(), ref.x) < 5e-5, tag
+        parity(f"fuzz_cgnr_{tag}", rls.solve_(S, rls.DeviceVector.from_host(b)).to_host(), ref.x,
+               lambda: O.solve(O.CGNR(A, reg=O.L2Regularization(0.1), iterations=its, relTol=0.0), b), record=False)
         rho = 0.9 / max(np.linalg.norm(A64, 2) ** 2, 1e-30)
         reff = O.FISTA(A64, reg=O.L1Regularization(0.05), rho=rho, iterations=4, relTol=0.0)
         O.solve(reff, b.astype(dt64))
         Sf = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(0.05), rho=rho, iterations=4, relTol=0.0)
         got = rls.solve_(Sf, rls.DeviceVector.from_host(b)).to_host()
-        assert np.linalg.norm(got - reff.x) <= 5e-5 * max(np.linalg.norm(reff.x), 1e-3), tag
+        parity(f"fuzz_fista_{tag}", got, reff.x, lambda: O.solve(O.FISTA(A, reg=O.L1Regularization(0.05), rho=rho, iterations=4, relTol=0.0), b),
+               record=False, scale=max(np.linalg.norm(reff.x), 1e-3))
 
 
 def test_random_shapes_other_paths_against_oracle(rls, ctx):
@@ -1581,25 +1681,28 @@ def test_random_shapes_other_paths_against_oracle(rls, ctx):
         tag = (M, N, np.dtype(dt).name)
         G = Ad.gram()
         Gh = G.to_host()
-        assert rel(Gh, A64.conj().T @ A64) < 2e-5, tag
+        parity(f"fuzz_gram_{tag}", Gh, A64.conj().T @ A64, lambda: A.conj().T @ A, record=False)
         assert np.array_equal(Gh, Gh.conj().T), tag  # Hermitian bit for bit
         b = (A64 @ rng.standard_normal(N)).astype(dt)
         its = min(4, N, max(M - 1, 1))
         ref = O.CGNR(A64, reg=O.L2Regularization(0.2), iterations=its, relTol=0.0, normal="gram")
         O.solve(ref, b.astype(dt64))
         S = rls.createLinearSolver(rls.CGNR, Ad, AHA=G, reg=rls.L2Regularization(0.2), iterations=its, relTol=0.0)
-        assert rel(rls.solve_(S, rls.DeviceVector.from_host(b)).to_host(), ref.x) < 5e-5, tag
+        parity(f"fuzz_cgnr_gram_{tag}", rls.solve_(S, rls.DeviceVector.from_host(b)).to_host(), ref.x,
+               lambda: O.solve(O.CGNR(A, reg=O.L2Regularization(0.2), iterations=its, relTol=0.0, normal="gram"), b), record=False)
         K = int(rng.integers(2, 21))
         B = np.asfortranarray((A64 @ rng.standard_normal((N, K))).astype(dt))
         Sb = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(0.2), iterations=its, relTol=0.0)
         xs = rls.solve_(Sb, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
         for j in (0, K - 1):
             refj = O.CGNR(A64, reg=O.L2Regularization(0.2), iterations=its, relTol=0.0)
-            assert rel(xs[j].to_host(), O.solve(refj, B[:, j].astype(dt64))) < 5e-5, (tag, K, j)
+            parity(f"fuzz_batched_{tag}_{K}_{j}", xs[j].to_host(), O.solve(refj, B[:, j].astype(dt64)),
+                   lambda: O.solve(O.CGNR(A, reg=O.L2Regularization(0.2), iterations=its, relTol=0.0), np.ascontiguousarray(B[:, j])), record=False)
         refk = O.Kaczmarz(A64, reg=O.L2Regularization(0.05), iterations=2)
         xk = O.solve(refk, b.astype(dt64))
         Sk = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(0.05), iterations=2)
-        assert rel(rls.solve_(Sk, rls.DeviceVector.from_host(b)).to_host(), xk) < 5e-5, tag
+        parity(f"fuzz_kaczmarz_{tag}", rls.solve_(Sk, rls.DeviceVector.from_host(b)).to_host(), xk,
+               lambda: O.solve(O.Kaczmarz(A, reg=O.L2Regularization(0.05), iterations=2), b), record=False)
         # prox maps on a vector of length M * N' (odd lengths included)
         n = int(rng.integers(1, 3000))
         v = rng.standard_normal(n).astype(np.float32)
@@ -1637,26 +1740,31 @@ def test_random_shapes_solver_plans_against_oracle(rls, ctx):
             ref = O.ADMM(A, reg=mk(O), **kw)
             O.solve(ref, b)
             S = rls.createLinearSolver(rls.ADMM, Ad, reg=mk(rls), **kw)
-            assert rel(rls.solve_(S, bd).to_host(), ref.x) < 5e-5 and S.state._plan_ok and S.state.iteration == ref.iteration, tag
+            r64 = O.ADMM(A64, reg=mk(O), **kw)
+            parity(f"fuzz_admm_{tag}", rls.solve_(S, bd).to_host(), O.solve(r64, b64), ref.x, record=False)
+            assert S.state._plan_ok and S.state.iteration == ref.iteration, tag
         refb = O.SplitBregman(A, reg=O.L1Regularization(0.03), rho=0.25, iterations=2, iterationsInner=3, iterationsCG=4, tolInner=1e-4)
         O.solve(refb, b)
         Sb = rls.createLinearSolver(rls.SplitBregman, Ad, reg=rls.L1Regularization(0.03), rho=0.25, iterations=2, iterationsInner=3,
                                     iterationsCG=4, tolInner=1e-4)
-        assert rel(rls.solve_(Sb, bd).to_host(), refb.x) < 5e-5, tag
+        r64 = O.SplitBregman(A64, reg=O.L1Regularization(0.03), rho=0.25, iterations=2, iterationsInner=3, iterationsCG=4, tolInner=1e-4)
+        parity(f"fuzz_splitbregman_{tag}", rls.solve_(Sb, bd).to_host(), O.solve(r64, b64), refb.x, record=False)
         rho = 0.9 / np.linalg.norm(A64, 2) ** 2
         lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
         for name in ("OptISTA", "POGM"):
             refp = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=9)
             O.solve(refp, b64)
             Sp = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=9)
-            assert rel(rls.solve_(Sp, bd).to_host(), refp.x) < 5e-5, (tag, name)
+            parity(f"fuzz_{name}_{tag}", rls.solve_(Sp, bd).to_host(), refp.x,
+                   lambda: O.solve(getattr(O, name)(A, reg=O.L1Regularization(lam), rho=rho, iterations=9), b), record=False)
         K = int(rng.integers(2, 19))
         B = np.asfortranarray((A64 @ rng.standard_normal((N, K))).astype(dt))
         Sf = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=8, relTol=0.0)
         xs = rls.solve_(Sf, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
         for j in (0, K - 1):
             reff = O.FISTA(A64, reg=O.L1Regularization(lam), rho=rho, iterations=8, relTol=0.0)
-            assert rel(xs[j].to_host(), O.solve(reff, B[:, j].astype(dt64))) < 5e-5, (tag, K, j)
+            parity(f"fuzz_fista_batched_{tag}_{K}_{j}", xs[j].to_host(), O.solve(reff, B[:, j].astype(dt64)),
+                   lambda: O.solve(O.FISTA(A, reg=O.L1Regularization(lam), rho=rho, iterations=8, relTol=0.0), np.ascontiguousarray(B[:, j])), record=False)
 
 
 def test_plan_entry_points_reject_misuse(rls, ctx):
@@ -1782,14 +1890,16 @@ def test_random_shapes_svt_prox_and_batched_kaczmarz(rls, ctx):
         reg = rls.LLRRegularization(0.7, shape=shape, blockSize=bs, randshift=False)
         xd = rls.DeviceVector.from_host(x)
         reg._call(xd, 0.7, list(shift))
-        assert rel(xd.to_host(), ref) < 5e-5, (shape, bs, K, shift, np.dtype(dt).name)
+        parity(f"fuzz_llr_{shape}_{bs}_{K}_{shift}_{np.dtype(dt).name}", xd.to_host(), ref, lambda: O.prox_llr(x.copy(), 0.7, shape, bs, shift),
+               record=False)
         m, c = int(rng.integers(1, 40)), int(rng.integers(1, 40))
         y = rng.standard_normal(m * c).astype(np.float32)
         if dt == np.complex64:
             y = (y + 1j * rng.standard_normal(m * c)).astype(np.complex64)
         refn = O.prox_nuclear(y.astype(dt64), 0.9, (m, c))
         got = rls.prox_(rls.NuclearRegularization, rls.DeviceVector.from_host(y), 0.9, svtShape=(m, c)).to_host()
-        assert np.linalg.norm(got - refn) <= 5e-5 * max(np.linalg.norm(refn), 1e-2), (m, c, np.dtype(dt).name)
+        parity(f"fuzz_nuclear_{m}x{c}_{np.dtype(dt).name}", got, refn, lambda: O.prox_nuclear(y.copy(), 0.9, (m, c)), record=False,
+               scale=max(np.linalg.norm(refn), 1e-2))
     for k in range(6):
         dt = np.complex64 if k % 2 == 0 else np.float32
         dt64 = np.complex128 if dt == np.complex64 else np.float64
@@ -1803,4 +1913,89 @@ def test_random_shapes_svt_prox_and_batched_kaczmarz(rls, ctx):
         xs = rls.solve_(S, rls.DeviceMatrix.from_host(B), scheduler=rls.BatchedState)
         for j in (0, K - 1):
             refk = O.Kaczmarz(A.astype(dt64), reg=O.L2Regularization(0.02), iterations=2)
-            assert rel(xs[j].to_host(), O.solve(refk, B[:, j].astype(dt64))) < 5e-5, (M, N, K, j)
+            parity(f"fuzz_kaczmarz_batched_{M}x{N}_{K}_{j}", xs[j].to_host(), O.solve(refk, B[:, j].astype(dt64)),
+                   lambda: O.solve(O.Kaczmarz(A, reg=O.L2Regularization(0.02), iterations=2), np.ascontiguousarray(B[:, j])), record=False)
+
+
+# ---- resident CGNR: the whole step call in one launch, A in registers across iterations ----------------------
+
+
+def _cgnr_path(rls, sol):
+    import ctypes as C
+    out = C.c_int32(-1)
+    assert rls.load().rls_cgnr_path(sol.state._plan, C.byref(out)) == 0
+    return out.value
+
+
+@pytest.mark.parametrize("dt,M,N,lam", [(np.complex64, 4096, 2048, 0.0), (np.complex64, 4096, 2048, 1e-2), (np.float32, 4096, 4096, 0.0),
+                                       (np.float32, 2048, 4096, 1e-3)])
+def test_cgnr_resident_kernel(rls, ctx, dt, M, N, lam):
+    """rls_cgnr_step as ONE launch (cgnr_resident_kernel: A held in registers, two in-kernel grid exchanges per
+    iteration): iterates against the float64 oracle at iterations 1 / 5 / 10 / 32, bit-identical run to run and
+    identical whether the iterations are enqueued one launch each or all in one launch; relTol stops it at the
+    oracle's iteration; the two-launch pipeline (resident = 0) agrees within the gate"""
+    A, xt, b = O.make_problem(M, N, dt, 77)
+    iters = 32
+    ref = O.CGNR(A.astype(hi(dt)), reg=O.L2Regularization(lam), iterations=iters, relTol=0.0)
+    ref32 = O.CGNR(A, reg=O.L2Regularization(lam), iterations=iters, relTol=0.0)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    sol = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), iterations=iters, relTol=0.0)
+    rls.init_(sol, bd)
+    if _cgnr_path(rls, sol) != 4:
+        pytest.skip("resident mode not available on this device / with other contexts alive")
+    ref.init(b.astype(hi(dt)))
+    ref32.init(b)
+    r0 = np.linalg.norm(ref.A.mul_adj(b.astype(hi(dt))))
+    tag = f"cgnr_resident_{M}x{N}_{np.dtype(dt).name}_lam{lam}"
+    for it in range(1, iters + 1):
+        assert ref.iterate() is not None and ref32.iterate() is not None and rls.iterate(sol) is not None
+        if it in (1, 5, 10, 32):
+            st = sol.state
+            parity(f"{tag}_x_it{it}", st.x.to_host(), ref.x, ref32.x)
+            parity(f"{tag}_r_it{it}", st.x0.to_host(), ref.r, ref32.r, scale=r0)
+            parity(f"{tag}_p_it{it}", st.pl.to_host(), ref.p, ref32.p, scale=r0)
+    assert rls.iterate(sol) is None and sol.state.iteration == iters
+    x_steps = sol.state.x.to_host()
+    x_once = rls.solve_(sol, bd).to_host()      # all 32 iterations in ONE launch
+    x_again = rls.solve_(sol, bd).to_host()
+    assert np.array_equal(x_once, x_steps) and np.array_equal(x_once, x_again)
+    # relTol: stops inside the launch, at the oracle's iteration
+    tol = 1e-3
+    ref2 = O.CGNR(A.astype(hi(dt)), reg=O.L2Regularization(lam), iterations=iters, relTol=tol)
+    O.solve(ref2, b.astype(hi(dt)))
+    sol2 = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), iterations=iters, relTol=tol)
+    x2 = rls.solve_(sol2, bd).to_host()
+    assert 1 < ref2.iteration < iters and abs(sol2.state.iteration - ref2.iteration) <= 1
+    if sol2.state.iteration == ref2.iteration:
+        parity(f"{tag}_reltol", x2, ref2.x, lambda: O.solve(O.CGNR(A, reg=O.L2Regularization(lam), iterations=ref2.iteration, relTol=0.0), b))
+    # the two-launch pipeline of the same plan
+    ctx.tune(resident=0)
+    try:
+        assert _cgnr_path(rls, sol) == 1
+        x_pipe = rls.solve_(sol, bd).to_host()
+    finally:
+        ctx.tune(resident=1)
+    parity(f"{tag}_pipeline", x_pipe, ref.x, ref32.x)
+
+
+def test_cgnr_resident_timeout_is_a_loud_no_op(rls, ctx):
+    """every in-kernel wait is bounded: with the bound forced to ONE poll some workgroup gives up, the launch leaves
+    x, r, p and the scalars untouched and the next status read reports it; the plan keeps working afterwards"""
+    A, xt, b = O.make_problem(4096, 2048, np.complex64, 78)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=8, relTol=0.0)
+    rls.init_(sol, bd)
+    if _cgnr_path(rls, sol) != 4:
+        pytest.skip("resident mode not available")
+    p_before = sol.state.pl.to_host()
+    ctx.tune(resident_spin=1)
+    try:
+        ctx.lib.rls_cgnr_step(sol.state._plan, 4)
+        with pytest.raises(rls.RLSError, match="timed out"):
+            sol.state._refresh(ctx.lib)
+    finally:
+        ctx.tune(resident_spin=400000)
+    assert np.array_equal(sol.state.pl.to_host(), p_before) and np.all(sol.state.x.to_host() == 0)
+    x = rls.solve_(sol, bd).to_host()
+    ref = O.CGNR(A.astype(np.complex128), iterations=8, relTol=0.0)
+    parity("cgnr_resident_after_timeout", x, O.solve(ref, b.astype(np.complex128)), lambda: O.solve(O.CGNR(A, iterations=8, relTol=0.0), b))
