@@ -3,21 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is ONE CGNR iteration (src/CGNR.jl:143-178) of the matrix-free normal operator on a dense
-column-major ComplexF32 4096x2048 A that is already resident in HBM: t = A p, v = A^H t, then the
-fused BLAS-1 update.  lambda = 0, relTol = 0 (SURVEY.md 8d "headline metric run").
+N = 1: a step is ONE CGNR iteration (src/CGNR.jl:143-178) of the matrix-free normal operator on a dense
+column-major ComplexF32 4096x2048 A that is already resident in HBM (lambda = 0, relTol = 0, SURVEY.md 8d
+"headline metric run").  The timed region is EXACTLY K iterations between barrier + synchronize on both sides;
+when that region is shorter than 10 ms it is repeated (>= 50 times, every repetition bracketed the same way) and
+`value` = K / median(elapsed), with the spread reported beside it.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE config 4 -- independent
-solves sharded one per GPU, distinct A per rank, no data-path collective -> weak scaling; the only
-collectives are the barrier and the max-over-ranks of the elapsed time.  `--workload rowsharded`
-runs BASELINE config 5 instead (one tall A row-partitioned, one all-reduce of A^H t per iteration).
+N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE configs[3] -- 64 independent CGNR solves
+on one shared 4096x2048 A sharded 8 right-hand sides per GPU (column k -> GPU k // 8), no data-path collective
+-> weak scaling; a step is one batched iteration (8 solve-iterations per GPU), `value` = solve-iterations/s of the
+whole job.  `--workload single` instead runs the N = 1 workload on every GPU (one independent solve each);
+`--workload rowsharded` runs BASELINE configs[4] (one tall A row-partitioned, one all-reduce per iteration).
 
 Prints ONE JSON line on rank 0 with `roofline` and (N = 1) `cpu_baseline` objects.
 """
 import argparse
+import ctypes as C
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
@@ -26,12 +31,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
-# CG converges geometrically on the well-conditioned randn matrix (hard part 4): left running
-# for hundreds of iterations the recursive residual underflows Float32 and alpha becomes 0/0.  The
-# bench therefore times back-to-back SOLVES of SEGMENT iterations each (BASELINE configs 4/5 use 32);
-# the init! of every solve (one extra GEMV) is inside the timed region but not counted as a step.
+HBM_PEAK_GBS = 8000.0     # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+MFMA_F32_PEAK_TF = 157.3  # dense f32-input MFMA peak, same table
+# CG converges geometrically on the well-conditioned randn matrix (hard part 4): left running for hundreds
+# of iterations the recursive residual underflows Float32 and alpha becomes 0/0.  The bench therefore times
+# back-to-back SOLVES of SEGMENT iterations each (BASELINE configs 4/5 use 32); the init! of every solve after the
+# first (one extra GEMV) is inside the timed region but not counted as a step.
 SEGMENT = 32
+PATH_NAMES = {0: "two GEMVs + update kernel", 1: "one-pass slab pipeline (2 launches per iteration)",
+              2: "Gram-mode pipeline", 3: "batched matrix-core kernels", 4: "resident (one launch per step call, A in registers)"}
 
 
 def make_A(M, N, seed, dtype=np.complex64):
@@ -52,17 +60,24 @@ def bytes_per_cgnr_iteration(M, N, s):
     return 2 * M * N * s + (16 * N + 2 * M) * s
 
 
-def cpu_baseline_cgnr(A, b, budget_s=14.0, max_iters=640):
-    """the oracle's CGNR (NumPy/OpenBLAS restatement of src/CGNR.jl:143-178) timed on the host.  OpenBLAS's
-    cgemv does not scale to every core of a big host, so a short calibration picks the BLAS thread count
-    (reported as `cores`) before the bounded timed sample."""
+def spread(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return {"n": n, "median": statistics.median(xs), "min": xs[0], "max": xs[-1], "p10": xs[int(0.1 * (n - 1))],
+            "p90": xs[int(math.ceil(0.9 * (n - 1)))]}
+
+
+# ---- CPU baselines (rank 0, N = 1 only): the oracle's NumPy restatement and its C++/OpenMP restatement -----------
+def cpu_baseline_numpy(A, b, budget_s=8.0, max_iters=640):
+    """the oracle's CGNR (NumPy/OpenBLAS restatement of src/CGNR.jl:143-178) timed on the host.  OpenBLAS's cgemv does
+    not scale to every core of a big host, so a short calibration picks the BLAS thread count (reported as `cores`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rls_oracle as O
 
     try:
-        from threadpoolctl import threadpool_info, threadpool_limits
+        from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
-        threadpool_info = threadpool_limits = None
+        threadpool_limits = None
 
     def run(n_solves, limit=None):
         s = O.CGNR(A, iterations=SEGMENT, relTol=0.0)
@@ -82,8 +97,8 @@ def cpu_baseline_cgnr(A, b, budget_s=14.0, max_iters=640):
             if nt > ncpu:
                 continue
             with threadpool_limits(limits=nt, user_api="blas"):
-                run(1, 1.0)  # warm
-                n, dt = run(1, 3.0)
+                run(1, 0.5)  # warm
+                n, dt = run(1, 1.5)
             calib[nt] = n / dt
         best_threads = max(calib, key=calib.get)
         ctxmgr = threadpool_limits(limits=best_threads, user_api="blas")
@@ -93,15 +108,68 @@ def cpu_baseline_cgnr(A, b, budget_s=14.0, max_iters=640):
     with ctxmgr:
         n, dt = run(max_iters // SEGMENT, budget_s)
     return {"value": n / dt, "unit": "iterations/s", "cores": int(best_threads), "kind": "port",
-            "sample": f"{n} CGNR iterations of the same {A.shape[0]}x{A.shape[1]} complex64 problem, NumPy/OpenBLAS "
-                      f"restatement (oracle/rls_oracle.py), {dt:.1f} s, BLAS threads chosen by calibration "
+            "implementation": "NumPy/OpenBLAS restatement (oracle/rls_oracle.py)",
+            "sample": f"{n} CGNR iterations of the same {A.shape[0]}x{A.shape[1]} complex64 problem, {dt:.1f} s, BLAS threads chosen "
+                      f"by calibration { {k: round(v, 1) for k, v in calib.items()} } it/s of {ncpu} host CPUs",
+            "GBps_algorithmic": bytes_per_cgnr_iteration(A.shape[0], A.shape[1], 8) * n / dt / 1e9, "ms_per_step": 1e3 * dt / n}
+
+
+def cpu_baseline_openmp(A, b, budget_s=10.0):
+    """oracle/cgnr_omp.cpp: the same iteration in C++ with OpenMP, both products streaming A once with every core
+    (column panels per thread, NUMA-placed copy of A).  Thread count by calibration; checked against the NumPy
+    restatement in tests/test_oracle.py."""
+    so = os.path.join(ROOT, "oracle", "_build", "libcgnr_omp.so")
+    if not os.path.exists(so):
+        return {"error": f"{so} not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    lib = C.CDLL(so)
+    lib.cgnr_omp_run.restype = C.c_int64
+    lib.cgnr_omp_run.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                 C.POINTER(C.c_double)]
+    M, N = A.shape
+    x = np.zeros(N, np.complex64)
+    sec = C.c_double()
+    ncpu = os.cpu_count() or 1
+
+    def run(threads, solves):
+        n = lib.cgnr_omp_run(A.ctypes.data, M, N, b.ctypes.data, SEGMENT, solves, 0.0, threads, x.ctypes.data, C.byref(sec))
+        return n, sec.value
+
+    calib = {}
+    for nt in sorted({8, 16, 32, 64, 128, ncpu}):
+        if nt > ncpu:
+            continue
+        run(nt, 1)
+        n, dt = run(nt, 2)
+        calib[nt] = n / dt
+    best = max(calib, key=calib.get)
+    solves = max(2, int(budget_s * calib[best] / SEGMENT))
+    n, dt = run(best, solves)
+    return {"value": n / dt, "unit": "iterations/s", "cores": int(best), "kind": "port",
+            "implementation": "C++/OpenMP restatement (oracle/cgnr_omp.cpp), x86-64-v3",
+            "sample": f"{n} CGNR iterations of the same {M}x{N} complex64 problem, {dt:.1f} s, OpenMP threads chosen by calibration "
                       f"{ {k: round(v, 1) for k, v in calib.items()} } it/s of {ncpu} host CPUs",
-            "ms_per_step": 1e3 * dt / n}
+            "GBps_algorithmic": bytes_per_cgnr_iteration(M, N, 8) * n / dt / 1e9, "ms_per_step": 1e3 * dt / n}
 
 
-def other_paths(rls, ctx, Ad, A, b):
-    """Untimed extras (N = 1, after the timed region): the other paths of SURVEY 8 on the same operator, a few
-    milliseconds each, so that one bench run shows them all.  None of this enters `value`."""
+def cpu_baselines(A, b):
+    variants = []
+    for fn in (cpu_baseline_openmp, cpu_baseline_numpy):
+        try:
+            variants.append(fn(A, b))
+        except Exception as e:  # a broken baseline must not take the GPU line down, but it must be visible
+            variants.append({"error": f"{fn.__name__}: {e!r}"})
+    ok = [v for v in variants if "value" in v]
+    if not ok:
+        return {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "no CPU baseline ran", "variants": variants}
+    best = dict(max(ok, key=lambda v: v["value"]))
+    best["variants"] = variants
+    return best
+
+
+# ---- the other paths of SURVEY 8 on the same operator (N = 1, untimed extras) --------------------------------------
+def other_paths(rls, ctx, Ad, A, b, errors):
+    """a few milliseconds each, so that one bench run shows them all.  None of this enters `value`.  A failure of one
+    entry is recorded in `errors` (top-level `other_paths_error` of the JSON line), it is never swallowed."""
     M, N = A.shape
     out = {}
     lib, h = ctx.lib, ctx.handle
@@ -117,25 +185,75 @@ def other_paths(rls, ctx, Ad, A, b):
             best = min(best, ctx.timer_stop_ms())
         return best * 1e3 / n_inner
 
-    try:
-        rho = 0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2
+    def entry(name):
+        def deco(fn):
+            try:
+                out[name] = fn()
+            except Exception as e:
+                errors.append(f"{name}: {e!r}")
+            return fn
+        return deco
+
+    rho = 0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2
+    rng = np.random.default_rng(5)
+    state = {}
+
+    @entry("cgnr_two_launch_pipeline (resident = 0: A streamed once per iteration)")
+    def _():
+        ctx.tune(resident=0)
+        try:
+            S = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+            rls.solve_(S, b)
+            us = timed(lambda: (rls.init_(S, b), lib.rls_cgnr_step(S.state._plan, 32)), 32)
+            us_a, us_r = C.c_float(), C.c_float()
+            rls.init_(S, b)
+            rc = lib.rls_cgnr_step_profiled(S.state._plan, 100, C.byref(us_a), C.byref(us_r))
+        finally:
+            ctx.tune(resident=1)
+        s = 8
+        res = {"us_per_iteration": us, "iterations_per_s": 1e6 / us, "algorithmic_GBps": bytes_per_cgnr_iteration(M, N, s) / us / 1e3,
+               "frac_algorithmic": bytes_per_cgnr_iteration(M, N, s) / us / 1e3 / HBM_PEAK_GBS}
+        if rc == 0:
+            nwg = M // 16
+            res["cgnr_pipe_a_kernel_us_back_to_back"] = us_a.value
+            res["cgnr_pipe_a_kernel_min_hbm_bytes"] = M * N * s + nwg * N * s
+            res["cgnr_pipe_a_kernel_frac_hbm"] = (M * N * s + nwg * N * s) / (us_a.value * 1e-6) / 1e9 / HBM_PEAK_GBS
+            res["cgnr_pipe_r_kernel_us_back_to_back"] = us_r.value
+            res["note"] = ("kernel times are back-to-back launches between two hipEvents; in the real sequence the reduce kernel reads "
+                           "partial rows the slab kernel has just written on other XCDs and runs ~4.8 us (rocprofv3, profiles/)")
+        return res
+
+    @entry("fista_l1_matrix_free (BASELINE configs[1])")
+    def _():
         S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
         rls.solve_(S, b)
         us = timed(lambda: (rls.init_(S, b), lib.rls_fista_step(S.state._plan, 48)), 48)
-        out["fista_l1_matrix_free (BASELINE configs[1])"] = {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
+        return {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
+
+    @entry("gram_gemm_AHA (setup, matrix cores)")
+    def _():
         t0 = time.perf_counter(); G = Ad.gram(); ctx.sync(); t_gram = time.perf_counter() - t0
         t0 = time.perf_counter(); G = Ad.gram(); ctx.sync(); t_gram = min(t_gram, time.perf_counter() - t0)
-        out["gram_gemm_AHA (setup, matrix cores)"] = {"ms": 1e3 * t_gram, "TFLOPs_nominal": 8.0 * N * N * M / t_gram / 1e12}
-        S = rls.createLinearSolver(rls.CGNR, Ad, AHA=G, iterations=32, relTol=0.0)
+        state["G"] = G
+        return {"ms": 1e3 * t_gram, "TFLOPs_nominal": 8.0 * N * N * M / t_gram / 1e12}
+
+    @entry("cgnr_gram_mode (AHA explicit, one launch per iteration)")
+    def _():
+        S = rls.createLinearSolver(rls.CGNR, Ad, AHA=state["G"], iterations=32, relTol=0.0)
         rls.solve_(S, b)
         us = timed(lambda: (rls.init_(S, b), lib.rls_cgnr_step(S.state._plan, 32)), 32)
-        out["cgnr_gram_mode (AHA explicit, one launch per iteration)"] = {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
-        S = rls.createLinearSolver(rls.FISTA, Ad, AHA=G, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
+        return {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
+
+    @entry("fista_l1_gram_mode")
+    def _():
+        S = rls.createLinearSolver(rls.FISTA, Ad, AHA=state["G"], reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
         rls.solve_(S, b)
         us = timed(lambda: (rls.init_(S, b), lib.rls_fista_step(S.state._plan, 48)), 48)
-        out["fista_l1_gram_mode"] = {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
-        rng = np.random.default_rng(5)
-        for K in (16, 64):
+        return {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
+
+    for K in (8, 16, 64):
+        @entry(f"cgnr_batched_{K}_rhs (BASELINE configs[3] on one GPU, f32 MFMA)")
+        def _(K=K):
             X = (rng.standard_normal((N, K)) + 1j * rng.standard_normal((N, K))).astype(np.complex64)
             Bd = rls.DeviceMatrix.from_host(np.asfortranarray((A @ X).astype(np.complex64)), ctx)
             S = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
@@ -143,8 +261,11 @@ def other_paths(rls, ctx, Ad, A, b):
             st = S.state
             us = timed(lambda: (rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, 32), "init"),
                                 rls._lib.check(h, lib.rls_cgnr_step(st._plan, 32), "step")), 32, reps=4)
-            out[f"cgnr_batched_{K}_rhs (BASELINE configs[3] on one GPU, f32 MFMA)"] = {
-                "us_per_batched_iteration": us, "solve_iterations_per_s": K * 1e6 / us}
+            return {"us_per_batched_iteration": us, "solve_iterations_per_s": K * 1e6 / us,
+                    "TFLOPs_algorithmic": 16.0 * M * N * K / us / 1e6, "frac_mfma_f32": 16.0 * M * N * K / us / 1e6 / MFMA_F32_PEAK_TF}
+
+    @entry("fista_l1_batched_16_rhs (solve!(FISTA, B), f32 MFMA)")
+    def _():
         Xf = (rng.standard_normal((N, 16)) + 1j * rng.standard_normal((N, 16))).astype(np.complex64)
         Bf = rls.DeviceMatrix.from_host(np.asfortranarray((A @ Xf).astype(np.complex64)), ctx)
         S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
@@ -152,13 +273,19 @@ def other_paths(rls, ctx, Ad, A, b):
         stf = S.state
         us = timed(lambda: (rls._lib.check(h, lib.rls_fista_init_batched(stf._plan, Bf.ptr, Bf.lda, rho, 1.0, 0.0, 48, 0), "init"),
                             rls._lib.check(h, lib.rls_fista_step(stf._plan, 48), "step")), 48, reps=4)
-        out["fista_l1_batched_16_rhs (solve!(FISTA, B), f32 MFMA)"] = {"us_per_batched_iteration": us, "solve_iterations_per_s": 16 * 1e6 / us}
+        return {"us_per_batched_iteration": us, "solve_iterations_per_s": 16 * 1e6 / us}
+
+    @entry("kaczmarz_row_sweeps (one launch per solve)")
+    def _():
         S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(1e-3), iterations=4)
         rls.solve_(S, b); ctx.sync()
         t0 = time.perf_counter(); rls.solve_(S, b); ctx.sync(); dt = time.perf_counter() - t0
-        out["kaczmarz_row_sweeps (one launch per solve)"] = {"us_per_row_step": dt / (4 * M) * 1e6}
-        # BASELINE configs[2]: ADMM + TV, 8192 x 4096 Float32, shape (64, 64), 10 outer x 10 inner cg! iterations --
-        # whole outer iterations enqueued as a device plan (rls_admm_step); wall clock of complete solves, min of 3
+        return {"us_per_row_step": dt / (4 * M) * 1e6}
+
+    @entry("admm_tv_config3 (BASELINE configs[2], device plan)")
+    def _():
+        # ADMM + TV, 8192 x 4096 Float32, shape (64, 64), 10 outer x 10 inner cg! iterations -- whole outer iterations
+        # enqueued as a device plan (rls_admm_step); wall clock of complete solves, min of 3
         M3, N3 = 8192, 4096
         A3 = make_A(M3, N3, 3, np.float32)
         A3d = rls.DeviceMatrix.from_host(A3, ctx)
@@ -174,12 +301,24 @@ def other_paths(rls, ctx, Ad, A, b):
             ctx.sync(); dts.append((time.perf_counter() - t0) / 50)
         ms = 1e3 * min(dts)
         alg = 11 * 2 * M3 * N3 * 4  # 11 normal-operator applies per outer iteration, A read twice each on the reference path
-        out["admm_tv_config3 (BASELINE configs[2], device plan)"] = {
-            "ms_per_outer_iteration": ms, "inner_cg_iterations": S.state.cg_iterations,
-            "algorithmic_GBps": alg / (ms * 1e-3) / 1e9}
-    except Exception as e:  # the extras must never take the headline line down
-        out["error"] = repr(e)
+        return {"ms_per_outer_iteration": ms, "inner_cg_iterations": S.state.cg_iterations, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
+                "frac_algorithmic": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
     return out
+
+
+def load_pmc(kernel_prefix):
+    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+    rocprofv3 --pmc runs; tools/pmc_summarize.py); None if not collected for this kernel"""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            for k, v in pmc["kernels"].items():
+                if k.startswith(kernel_prefix):
+                    return v["hbm_bytes_per_launch"], name
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -187,12 +326,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3200)
     ap.add_argument("--warmup", type=int, default=320)
-    ap.add_argument("--workload", default="cgnr", choices=["cgnr", "rowsharded"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "cgnr", "single", "config4", "rowsharded"])
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=2048)
+    ap.add_argument("--rhs-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--kernel-reps", type=int, default=200)
+    ap.add_argument("--resident", type=int, default=1, help="0: force the two-launch pipeline for the headline run")
     args = ap.parse_args()
 
     import torch  # plumbing: device selection, barrier, max-over-ranks
@@ -200,9 +340,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -219,33 +358,138 @@ def main():
     dt = np.complex64
     s = np.dtype(dt).itemsize
     K, W = args.steps, args.warmup
+    workload = args.workload
+    if workload == "auto":
+        workload = "cgnr" if world == 1 else "config4"
+    if workload == "single":
+        workload = "cgnr"
 
-    if args.workload == "rowsharded":
+    def finish(result=None):
+        if rank == 0 and result is not None:
+            print(json.dumps(result))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    if workload == "rowsharded":
         from importlib import import_module
 
         mg = import_module("rls_amd.multigpu")
-        result = mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W)
-        if rank == 0:
-            print(json.dumps(result))
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return finish(mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W))
 
-    # ---- data: resident in HBM before the timed region ------------------------------------
+    lib, h = ctx.lib, ctx.handle
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    def timed_regions(prepare, run, est_s):
+        """the contract's timed region -- barrier + synchronize, EXACTLY K steps, synchronize + barrier -- repeated
+        when it is short.  Returns wall-clock seconds (max over ranks) and hipEvent seconds of every repetition."""
+        reps = 5 if est_s >= 0.010 else int(min(400, max(50, math.ceil(0.4 / max(est_s, 1e-5)))))
+        walls, evs = [], []
+        for _ in range(reps):
+            prepare()
+            barrier()
+            ctx.timer_start()
+            t0 = time.perf_counter()
+            run()
+            ev_ms = ctx.timer_stop_ms()  # hipEvents on the stream the kernels run on; synchronises that stream
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                dist.barrier()
+                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            walls.append(el)
+            evs.append(ev_ms * 1e-3)
+        return walls, evs
+
+    if workload == "config4":
+        # ---- BASELINE configs[3]: shared A (seed 4), B = A X (X: seed 5, 64 columns), columns 8k..8k+7 on GPU k ----
+        R = args.rhs_per_gpu
+        A = make_A(M, N, seed=4)
+        rng = np.random.default_rng(5)
+        X = ((rng.standard_normal((N, 64)) + 1j * rng.standard_normal((N, 64))) / math.sqrt(2)).astype(dt)
+        cols = [(rank * R + j) % 64 for j in range(R)]
+        B = np.asfortranarray((A @ X[:, cols]).astype(dt))
+        Ad = rls.DeviceMatrix.from_host(A, ctx)
+        Bd = rls.DeviceMatrix.from_host(B, ctx)
+        solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
+        rls.solve_(solver, Bd, scheduler=rls.BatchedState)  # builds the batched plan (and checks it runs)
+        st = solver.state
+        assert isinstance(st, rls.BatchedState), "config 4 needs the shared-A batched plan"
+
+        def init():
+            rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, SEGMENT), "init_batched")
+
+        def step(n, initialised=False):
+            while n > 0:
+                m = min(n, SEGMENT)
+                if not initialised:
+                    init()
+                initialised = False
+                rls._lib.check(h, lib.rls_cgnr_step(st._plan, m), "rls_cgnr_step")
+                n -= m
+
+        step(20 * SEGMENT); ctx.sync()
+        step(W)
+        t0 = time.perf_counter(); init(); step(min(K, 4 * SEGMENT), True); ctx.sync()
+        est = (time.perf_counter() - t0) * K / min(K, 4 * SEGMENT)
+        walls, evs = timed_regions(init, lambda: step(K, True), est)
+        elapsed, ev = statistics.median(walls), statistics.median(evs)
+        stat = st.status()
+        assert all(math.isfinite(s_.residual) for s_ in stat), "batched CGNR residual is not finite"
+        rate = R * K / elapsed
+        rates = [rate]
+        if dist is not None:
+            tt = torch.tensor([R * K / ev], dtype=torch.float64, device="cuda")
+            gathered = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(gathered, tt)
+            rates = [float(g.item()) for g in gathered]
+        flops_iter = 16.0 * M * N * R  # complex: 8 real flops per MAC, two products
+        us_iter = 1e6 * ev / K
+        out = {
+            "metric": "CGNR solve-iterations/sec, 64 independent solves of 4096x2048 CF32 sharded 8 per GPU (BASELINE configs[3])",
+            "value": world * R * K / elapsed, "unit": "solve-iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "c64 (ComplexF32 storage, f32 MFMA arithmetic; scalar reductions accumulated in f64)", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: CGNR {M}x{N} ComplexF32, shared A, {R} right-hand sides per GPU advancing together "
+                                   f"(BatchedState: per-column scalars and done flags), lambda=0, relTol=0, back-to-back solves of {SEGMENT} "
+                                   f"iterations, no data-path collective", "M": M, "N": N, "rhs_per_gpu": R, "step": "one batched iteration"},
+            "timed_region": {"repetitions": len(walls), "wall_s": spread(walls), "hip_events_s": spread(evs),
+                             "value_is": "n_gpus * rhs_per_gpu * steps / median(wall, max over ranks)"},
+            "per_rank_solve_iterations_per_s_hip_events": rates,
+            "roofline": {"bound": "mfma", "kernel": "skinny_t_kernel + skinny_v_kernel (T = A P, V = A^H T on v_mfma_f32_16x16x4_f32) + per-column update",
+                         "achieved": flops_iter / us_iter / 1e6, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops_iter / us_iter / 1e6 / MFMA_F32_PEAK_TF, "traffic": None,
+                         "note": "algorithmic flops = 16*M*N per solve-iteration (complex MAC = 8 flops, two products); with fewer than 16 "
+                                 "right-hand sides per group the MFMA columns beyond them are padding and are not counted",
+                         "us_per_batched_iteration": us_iter},
+        }
+        return finish(out)
+
+    # ---- headline: one CGNR solve per GPU, data resident in HBM before the timed region ---------------------------
     A = make_A(M, N, seed=2 if world == 1 else 100 + rank)
     rng = np.random.default_rng(1000 + rank)
     x_true = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(dt)
     b = (A @ x_true).astype(dt)
     Ad = rls.DeviceMatrix.from_host(A, ctx)
     bd = rls.DeviceVector.from_host(b, ctx)
+    if not args.resident:
+        ctx.tune(resident=0)
     solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
     rls.init_(solver, bd)
     st = solver.state
-    lib, h = ctx.lib, ctx.handle
+    path = C.c_int32(-1)
+    lib.rls_cgnr_path(st._plan, C.byref(path))
 
     def step(n, initialised=False):
         """n CGNR iterations as back-to-back solves of SEGMENT iterations; `initialised`: the first solve's init! has
-        already run (it belongs to the solve's setup, not to its iterations: SURVEY 8d times iterations of a running solve)"""
+        already run (it belongs to the solve's setup: SURVEY 8d times iterations of a running solve)"""
         while n > 0:
             m = min(n, SEGMENT)
             if not initialised:
@@ -254,84 +498,60 @@ def main():
             rls._lib.check(h, lib.rls_cgnr_step(st._plan, m), "rls_cgnr_step")
             n -= m
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        ctx.sync()
-        torch.cuda.synchronize()
-
-    # setup (untimed, not part of W): the first LONG host wait of a process (tens of ms of queued GPU
-    # work) returns ~50 ms late, once (tools/stall_probe2.py: rep 0 wall 123 ms vs 75 ms of events,
-    # every later rep wall == events).  Take that hit here, outside the measurement.
+    # setup (untimed, not part of W): the first LONG host wait of a process returns ~50 ms late, once
+    # (tools/stall_probe2.py); take that hit here, outside the measurement.
     step(150 * SEGMENT)
     ctx.sync()
     step(W)
-    rls.init_(solver, bd)  # the timed region starts on a freshly initialised solve; every later re-init is inside it
-    barrier()
-    ctx.timer_start()
-    t0 = time.perf_counter()
-    step(K, initialised=True)
-    ev_ms = ctx.timer_stop_ms()  # hipEvents on the stream the kernels run on; synchronises
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    ctx.sync()
+    t0 = time.perf_counter(); rls.init_(solver, bd); step(min(K, 4 * SEGMENT), True); ctx.sync()
+    est = (time.perf_counter() - t0) * K / min(K, 4 * SEGMENT)
+    walls, evs = timed_regions(lambda: rls.init_(solver, bd), lambda: step(K, True), est)
+    elapsed, ev = statistics.median(walls), statistics.median(evs)
     st._refresh(lib)
     assert st.iteration == ((K - 1) % SEGMENT) + 1, (st.iteration, K)
     assert math.isfinite(st._residual), "CGNR residual is not finite"
 
-    # ---- per-kernel device time, hipEvents on the ctx stream --------------------------------------
-    import ctypes as C
-
+    # ---- the dominant kernel, timed live with hipEvents on the stream it is launched on ---------------------------
     bytes_iter = bytes_per_cgnr_iteration(M, N, s)
-    iter_gbs = bytes_iter * K / (ev_ms * 1e-3) / 1e9
+    iter_gbs = bytes_iter * K / ev / 1e9
+    nwg = M // 16
     kern = {}
-    us_a, us_r = C.c_float(), C.c_float()
-    rls.init_(solver, bd)
-    rc = lib.rls_cgnr_step_profiled(st._plan, 10, C.byref(us_a), C.byref(us_r))
-    if rc == 0:
+    if path.value == 4:
+        # one launch = a whole step call (here SEGMENT iterations); the memset node that zeroes its arrival counters
+        # (1 KiB) sits inside the event pair
+        rls.init_(solver, bd); lib.rls_cgnr_step(st._plan, SEGMENT); ctx.sync()
+        us = []
+        for _ in range(20):
+            rls.init_(solver, bd)
+            ctx.timer_start()
+            lib.rls_cgnr_step(st._plan, SEGMENT)
+            us.append(1e3 * ctx.timer_stop_ms())
+        us_launch = statistics.median(us)
+        exch = (2 * nwg * N * s + nwg * (N * s + 8 * 1024)) * SEGMENT  # partial rows out + in, v and partial dots read by every workgroup
+        dom = "cgnr_resident_kernel"
+        kern[dom] = {"us_per_launch": us_launch, "iterations_per_launch": SEGMENT, "us_per_iteration_in_kernel": us_launch / SEGMENT,
+                     "algorithmic_bytes_per_launch": bytes_iter * SEGMENT,
+                     "effective_GBps": bytes_iter * SEGMENT / us_launch / 1e3,
+                     "min_hbm_bytes_per_launch": M * N * s, "exchange_bytes_per_launch (L2 / Infinity Cache, not HBM-bound)": exch}
+    elif path.value == 1:
+        us_a, us_r = C.c_float(), C.c_float()
         rls.init_(solver, bd)
-        rls._lib.check(h, lib.rls_cgnr_step_profiled(st._plan, args.kernel_reps, C.byref(us_a), C.byref(us_r)), "profiled")
-        # One launch of the one-pass kernel does BOTH GEMVs of an iteration: its algorithmic bytes are
-        # the reference path's 2*M*N*s; what it actually has to move is A once plus the
-        # per-workgroup partial rows.
-        nwg = M // (2 * 8)
-        alg = 2 * M * N * s
-        kern["cgnr_pipe_a_kernel (one-pass v = A^H A p + fused CG update)"] = {
-            "us_per_launch": us_a.value, "algorithmic_bytes_per_launch": alg, "GBps": alg / (us_a.value * 1e-6) / 1e9,
-            "min_hbm_bytes_per_launch": M * N * s + nwg * N * s, "launches_per_iteration": 1}
-        rb = nwg * N * s + 3 * N * s
-        kern["cgnr_pipe_r_kernel (sum of partial rows + partial dots)"] = {
-            "us_per_launch": us_r.value, "algorithmic_bytes_per_launch": rb, "GBps": rb / (us_r.value * 1e-6) / 1e9,
-            "launches_per_iteration": 1}
-    reps = args.kernel_reps
-    p = rls.DeviceVector.from_host(x_true, ctx)
-    t = rls.DeviceVector(M, dt, ctx)
-    v = rls.DeviceVector(N, dt, ctx)
-    for name, fn in (("gemv_n_kernel (two-pass path, t = A p)", lambda: Ad.gemv_(0, p, t)),
-                     ("gemv_t_kernel (two-pass path, v = A^H t)", lambda: Ad.gemv_(2, t, v))):
-        for _ in range(10):
-            fn()
-        ctx.sync()
-        ctx.timer_start()
-        for _ in range(reps):
-            fn()
-        ms = ctx.timer_stop_ms() / reps
-        by = M * N * s + (M + N) * s
-        kern[name] = {"us_per_launch": 1e3 * ms, "algorithmic_bytes_per_launch": by, "GBps": by / (ms * 1e-3) / 1e9,
-                      "launches_per_iteration": 0 if rc == 0 else 1}
-    used = {k: v_ for k, v_ in kern.items() if v_["launches_per_iteration"] > 0}
-    dom = max(used, key=lambda k: used[k]["us_per_launch"])
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    # separate rocprofv3 --pmc runs of tools/pmc_probe.py; tools/pmc_summarize.py); null if not collected
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        traffic = pmc["kernels"][dom.split(" ")[0]]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+        rls._lib.check(h, lib.rls_cgnr_step_profiled(st._plan, 200, C.byref(us_a), C.byref(us_r)), "profiled")
+        dom = "cgnr_pipe_a_kernel"
+        kern[dom] = {"us_per_launch": us_a.value, "iterations_per_launch": 1, "algorithmic_bytes_per_launch": 2 * M * N * s,
+                     "effective_GBps": 2 * M * N * s / us_a.value / 1e3, "min_hbm_bytes_per_launch": M * N * s + nwg * N * s}
+        kern["cgnr_pipe_r_kernel"] = {"us_per_launch_back_to_back": us_r.value, "note": "in situ ~4.8 us (rocprofv3): it reads partial rows written "
+                                                                                        "on other XCDs"}
+    else:
+        dom = PATH_NAMES.get(path.value, "?")
+        kern[dom] = {"us_per_launch": 1e6 * ev / K, "iterations_per_launch": 1, "algorithmic_bytes_per_launch": bytes_iter,
+                     "effective_GBps": iter_gbs, "min_hbm_bytes_per_launch": 2 * M * N * s}
+    traffic, traffic_src = load_pmc(dom)
+    kd = kern[dom]
+    hbm_bytes = traffic if traffic is not None else kd["min_hbm_bytes_per_launch"]
+    frac_hbm = hbm_bytes / (kd["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    frac_alg = iter_gbs / HBM_PEAK_GBS
 
     if rank == 0:
         out = {
@@ -347,26 +567,43 @@ def main():
             "vs_baseline": None,
             "dtype": "c64 (ComplexF32 storage and arithmetic; scalar reductions accumulated in f64)",
             "data": "synthetic",
-            "config": {"workload": f"CGNR matrix-free normal operator, dense column-major ComplexF32 {M}x{N}, lambda=0, "
-                                   f"relTol=0, back-to-back solves of {SEGMENT} iterations (BASELINE configs[1] shape; configs[3] sharding at N>1: one independent "
-                                   f"solve per GPU, no collectives)",
-                       "M": M, "N": N, "problems_per_gpu": 1},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "achieved = algorithmic bytes (reference path: A read twice per iteration) / device "
-                                 "time per launch; the one-pass kernel reads A once, see min_hbm_bytes_per_launch",
-                         "per_kernel": kern,
-                         "iteration": {"bytes": bytes_iter, "GBps": iter_gbs, "frac": iter_gbs / HBM_PEAK_GBS,
-                                       "us_hip_events": 1e3 * ev_ms / K}},
+            "config": {"workload": f"CGNR matrix-free normal operator, dense column-major ComplexF32 {M}x{N}, lambda=0, relTol=0, back-to-back "
+                                   f"solves of {SEGMENT} iterations (BASELINE configs[1] shape, headline metric run of SURVEY 8d)" +
+                                   ("" if world == 1 else "; one independent solve per GPU, no collectives"),
+                       "M": M, "N": N, "problems_per_gpu": 1, "kernel_path": PATH_NAMES.get(path.value, str(path.value))},
+            "timed_region": {"repetitions": len(walls), "wall_s": spread(walls), "hip_events_s": spread(evs),
+                             "value_is": "n_gpus * steps / median(wall); every repetition is exactly `steps` iterations between "
+                                         "barrier + synchronize on both sides",
+                             "iterations_per_s_hip_events": K / ev},
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # algorithmic basis, the ITERATION as the unit (SURVEY 8d bytes per iteration x iterations / device time of the timed
+                # region): capped at the peak -- a path that no longer moves the algorithm's bytes can exceed it
+                "achieved": min(iter_gbs, HBM_PEAK_GBS), "frac": min(frac_alg, 1.0),
+                "frac_algorithmic": min(frac_alg, 1.0), "algorithmic_GBps_uncapped": iter_gbs,
+                "exceeds_algorithmic_roofline": bool(frac_alg > 1.0),
+                # physical basis: bytes the dominant kernel really moves per launch / its launch time
+                "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src,
+                "hbm_bytes_per_launch_used": hbm_bytes,
+                "note": ("achieved/frac: SURVEY 8d algorithmic bytes per iteration (A read twice) x iterations / hipEvent time of the timed region, "
+                         "capped at the HBM peak; frac_hbm: HBM bytes of the dominant kernel per launch (PMC when collected, else the minimum it "
+                         "must move) / its launch time / peak.  " +
+                         ("The resident kernel keeps A in the register files across the iterations of a launch: per iteration it moves only "
+                          "the partial-row exchange (L2 / Infinity Cache), so it is bound by two in-kernel grid-wide exchanges, not by HBM; the "
+                          "two-launch pipeline that streams A every iteration is reported under other_paths." if path.value == 4 else "")),
+                "per_kernel": kern,
+                "iteration": {"bytes": bytes_iter, "us_hip_events": 1e6 * ev / K, "roofline_us_at_peak": bytes_iter / HBM_PEAK_GBS / 1e3}},
         }
+        errors = []
         if world == 1 and not args.no_extras and (M, N) == (4096, 2048):
-            out["other_paths"] = other_paths(rls, ctx, Ad, A, bd)
+            out["other_paths"] = other_paths(rls, ctx, Ad, A, bd, errors)
+        if errors:
+            out["other_paths_error"] = errors
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_cgnr(A, b)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            out["cpu_baseline"] = cpu_baselines(A, b)
+        finish(out)
+    else:
+        finish()
 
 
 if __name__ == "__main__":

@@ -1,13 +1,7 @@
 // Context, memory and timing entry points of the C ABI (include/rls_mi355x.h).
 #include "rls_common.hpp"
 
-#include <atomic>
 #include <cstdlib>
-
-// contexts alive per device: the resident kernels (normal.hip) need every CU, so they run only while ONE context
-// of this process is using the device (several contexts = several streams whose kernels can interleave on the CUs)
-static std::atomic<int> g_live_ctx[64];
-int rls_ctx_live_count(int device) { return (device >= 0 && device < 64) ? g_live_ctx[device].load() : 2; }
 
 static int32_t ctx_setup(rls_ctx* ctx) {
   RLS_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -45,8 +39,6 @@ static int32_t ctx_create_impl(int32_t device, void* stream, bool borrow, rls_ct
     rls_ctx_destroy(ctx);
     return st;
   }
-  if (device < 64) g_live_ctx[device].fetch_add(1);
-  ctx->counted = true;
   *out = ctx;
   return 0;
 }
@@ -78,7 +70,6 @@ int32_t rls_ctx_destroy(rls_ctx* ctx) {
   if (ctx->res_d) hipFree(ctx->res_d);
   if (ctx->res_h) hipHostFree(ctx->res_h);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
-  if (ctx->counted && ctx->device < 64) g_live_ctx[ctx->device].fetch_sub(1);
   delete ctx;
   return 0;
 }

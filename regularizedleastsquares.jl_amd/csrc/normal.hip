@@ -1498,16 +1498,20 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   unsigned epoch = 0;
   bool alive = true;
   for (int it = 0; it < n_steps; ++it) {
+    STAMP(8);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
     // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through)
     slab_finish<E, G, K, WV, true, true>(a, L, slab, Mc, N, pair);
+    STAMP(9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
+    STAMP(10);
     if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
       alive = false;
       break;
     }
+    STAMP(11);
     // ---- sum my 64-byte column chunk(s) over all partial rows, fixed order -----------------------------
     double dre = 0.0, dim_ = 0.0, pp = 0.0;
     for (int ch = blockIdx.x; ch < nchunks; ch += nwg) {
@@ -1560,10 +1564,12 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP(12);
     if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
       alive = false;
       break;
     }
+    STAMP(13);
     // ---- v and the partial dots, then the CG update (src/CGNR.jl:153-176), redundantly in every workgroup ----
     E vv[EPT];
 #pragma unroll
@@ -1584,6 +1590,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     }
     E pn[EPT], rn[EPT], al;
     cgnr_scalars Sn;
+#ifdef RLS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(14);
+#endif
     const bool done = cg_update_elems<E, EPT, NT, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -1592,6 +1602,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
       pv[e] = pn[e];
     }
     S = Sn;
+    STAMP(15);
     if (done) break;  // uniform: every workgroup derived the same scalars
   }
   if (!alive) {

@@ -26,7 +26,7 @@ struct rls_tuning {
   int pipe_hint_mode = 0; // (r, p) pair hints of the slab pipeline: 0 = host bookkeeping, 1 = always "unknown",
                           // 2 = deliberately wrong (tests: exercises the kernel's check-and-reload path)
   int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
-                          // ONE launch (normal.hip, cgnr_resident_kernel); needs the device to itself (one live context)
+                          // ONE launch (normal.hip, cgnr_resident_kernel)
   int resident_spin = 400000;  // bound of every in-kernel wait, in polls (~1 us each)
 };
 
@@ -34,7 +34,6 @@ struct rls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  bool counted = false;  // included in the per-device live-context count (api.hip)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = {0};
   // reduction scratch: partial sums (double) + a few result slots, and a pinned host mirror
@@ -480,7 +479,6 @@ bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, con
 int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N);
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
                                  int n_steps, unsigned spin_limit);
-int rls_ctx_live_count(int device);  // api.hip: contexts alive on a device (resident kernels need the device to themselves)
 
 // Gram-mode CGNR pipeline (normal.hip): one launch per iteration, every buffer in two parities
 struct rls_gram_pipe {

@@ -10,6 +10,8 @@
 // enqueue iterations in hipGraph-captured chunks.
 #include "rls_common.hpp"
 
+#include <mutex>
+
 // ---------------------------------------------------------------------------------------------
 // operator
 // ---------------------------------------------------------------------------------------------
@@ -182,12 +184,30 @@ static bool cgnr_use_pipeline(const rls_cgnr* s) {
 }
 
 // the whole step call as one launch: single right-hand side, matrix-free, A small enough to stay in the register
-// files (one workgroup per CU), 16-byte aligned state vectors, and this context alone on the device
+// files (one workgroup per CU), 16-byte aligned state vectors
 static bool cgnr_use_resident(const rls_cgnr* s) {
   const rls_ctx* ctx = s->op->ctx;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  return s->rsync && s->nrhs == 1 && cgnr_use_pipeline(s) && ctx->tune.resident && rls_ctx_live_count(ctx->device) == 1 &&
-         al16(s->x) && al16(s->r) && al16(s->p) && al16(s->v);
+  return s->rsync && s->nrhs == 1 && cgnr_use_pipeline(s) && ctx->tune.resident && al16(s->x) && al16(s->r) && al16(s->p) &&
+         al16(s->v);
+}
+
+// A resident kernel needs every one of its workgroups on a CU at the same time.  Other kernels only delay that, but
+// two resident kernels running side by side (two contexts = two streams of this process) could each hold CUs the
+// other is waiting for.  So resident launches on one device form ONE chain across all streams of the process: each
+// waits for the event recorded behind the previous one.  (Another PROCESS on the same device is not covered: its
+// symptom is the bounded-wait timeout reported by rls_cgnr_get_status.)
+static std::mutex g_resident_mu;
+static hipEvent_t g_resident_ev[64];
+static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_pipe& P, int n_steps) {
+  std::lock_guard<std::mutex> lock(g_resident_mu);
+  const int d = ctx->device < 64 ? ctx->device : 63;
+  if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
+  else RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
+  RLS_HIP(ctx, hipMemsetAsync(s->rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream));
+  const int32_t st = rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+  RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], ctx->stream));
+  return st;
 }
 
 static rls_cgnr_pipe cgnr_pipe_desc(const rls_cgnr* s) {
@@ -1761,9 +1781,8 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
     // grid-wide exchanges (normal.hip).  The arrival counters and flags are zeroed ahead of every launch.
     if (n_steps == 0) return 0;
     const rls_cgnr_pipe P = cgnr_pipe_desc(s);
-    RLS_HIP(ctx, hipMemsetAsync(s->rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream));
     s->resident_used = true;
-    return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+    return resident_chain_launch(ctx, s, P, n_steps);
   }
   if (cgnr_use_pipeline(s)) {
     // iteration k = K_A (applies update k-1 in its prologue, then one pass over A) + K_R; the last

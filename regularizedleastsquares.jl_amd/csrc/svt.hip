@@ -56,7 +56,8 @@ __global__ __launch_bounds__(64 * NW) void svt_blocks_kernel(E* __restrict__ x, 
   E* W = reinterpret_cast<E*>(smem_raw);  // W[v * len + t]
   E* V = W + (size_t)nv * len;            // V[u * nv + v]  (column u of V)
   float* fac = reinterpret_cast<float*>(V + (size_t)nv * nv);
-  float* red = fac + nv;                  // [NW] per-wave scratch
+  float* sigv = fac + nv;                 // singular values
+  float* red = sigv + nv;                 // [NW] per-wave scratch
   int64_t b[3] = {0, 0, 0};
   {
     int64_t id = blockIdx.x;
@@ -152,31 +153,43 @@ __global__ __launch_bounds__(64 * NW) void svt_blocks_kernel(E* __restrict__ x, 
     a = wave_sum(a);
     if (lane == 0) {
       const float sig = sqrtf(a);
+      sigv[u] = sig;
       fac[u] = sig > 0.f ? fmaxf(sig - lam, 0.f) / sig : 0.f;
     }
   }
   __syncthreads();
-  // Y[t][v] = sum_u fac_u w_u[t] conj(V[v][u]), scattered back (only elements inside the image)
+  // Y = sum_u fac_u w_u V_u^H.  W and V carry the rounding of every rotation applied to them (about 1e-5 relative
+  // at 96 x 96 in Float32), so the result is assembled from whichever part is SMALLER: the kept part directly, or
+  // the input minus the removed part, Y = X - sum_u (1 - fac_u) w_u V_u^H with X re-read from memory -- the
+  // accumulated rounding then scales with the smaller of the two norms (uniform choice per matrix; the direct form
+  // also gives exact zeros when everything is thresholded away).
+  float kept2 = 0.f, gone2 = 0.f;
+  for (int u = 0; u < nv; ++u) {
+    const float k1 = fac[u] * sigv[u], g1 = (1.f - fac[u]) * sigv[u];
+    kept2 += k1 * k1;
+    gone2 += g1 * g1;
+  }
+  const bool subtract = gone2 < kept2;
   for (int e = tid; e < nv * len; e += NT) {
     const int v = e / len, t = e % len;
+    const int r = tr ? v : t, k = tr ? t : v;
+    const int64_t idx = svt_index(G, b, r, k);
     E y = elem<E>::zero();
     for (int u = 0; u < nv; ++u) {
       const E vc = V[u * nv + v];
-      const E wu = elem<E>::scale(fac[u], W[u * len + t]);
+      const E wu = elem<E>::scale(subtract ? 1.f - fac[u] : fac[u], W[u * len + t]);
       // wu * conj(vc)
       y = elem<E>::add(y, elem<E>::make(elem<E>::re(wu) * elem<E>::re(vc) + elem<E>::im(wu) * elem<E>::im(vc),
                                          elem<E>::im(wu) * elem<E>::re(vc) - elem<E>::re(wu) * elem<E>::im(vc)));
     }
-    const int r = tr ? v : t, k = tr ? t : v;
-    const int64_t idx = svt_index(G, b, r, k);
-    if (idx >= 0) x[idx] = y;
+    if (idx >= 0) x[idx] = subtract ? elem<E>::sub(x[idx], y) : y;
   }
 }
 
 static int32_t svt_launch(rls_ctx* ctx, int32_t dtype, const svt_geom& G, void* x, float lam) {
   const int nv = G.K > G.mb ? G.mb : G.K, len = G.K > G.mb ? G.K : G.mb;
   const size_t es = rls_elem_size(dtype);
-  const size_t lds = ((size_t)nv * len + (size_t)nv * nv) * es + (size_t)(nv + 16) * sizeof(float);
+  const size_t lds = ((size_t)nv * len + (size_t)nv * nv) * es + (size_t)(2 * nv + 16) * sizeof(float);
   if (lds > 150 * 1024)
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "singular-value thresholding: the matrix does not fit one CU's LDS");
   int64_t nb = 1;

@@ -425,3 +425,26 @@ def test_nested_terms_reference_examples():
     for tf in (O.MinMaxTransform(w), O.ZTransform(w), O.IdentityTransform(w), O.ClampedScalingTransform(w, -0.5, 0.7)):
         assert np.allclose(tf.inverse_transform(tf.transform(w.copy())), w)
     assert O._is_projection(O.MaskedRegularization(O.PositiveRegularization(), [True])) and not O._is_projection(fs)
+
+
+def test_openmp_cgnr_baseline_matches_the_oracle():
+    """oracle/cgnr_omp.cpp (the C++/OpenMP `cpu_baseline` leg of bench.py, SURVEY 8d) restates src/CGNR.jl:107-178;
+    it must agree with the NumPy restatement, which the reference's own known answers pin"""
+    import ctypes as C
+    import subprocess
+
+    odir = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    subprocess.run(["make", "-C", odir], check=True, capture_output=True)
+    lib = C.CDLL(os.path.join(odir, "_build", "libcgnr_omp.so"))
+    lib.cgnr_omp_run.restype = C.c_int64
+    lib.cgnr_omp_run.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                 C.POINTER(C.c_double)]
+    for (M, N, lam, its, threads) in ((256, 128, 0.0, 10, 1), (300, 77, 1e-2, 12, 3), (64, 32, 0.5, 5, 2)):
+        A, xt, b = O.make_problem(M, N, np.complex64, 11)
+        A = np.asfortranarray(A)
+        x = np.zeros(N, np.complex64)
+        sec = C.c_double()
+        n = lib.cgnr_omp_run(A.ctypes.data, M, N, b.ctypes.data, its, 2, lam, threads, x.ctypes.data, C.byref(sec))
+        assert n == 2 * its and sec.value > 0
+        ref = O.CGNR(A.astype(np.complex128), reg=O.L2Regularization(lam), iterations=its, relTol=0.0)
+        assert rel(x, O.solve(ref, b.astype(np.complex128))) < 1e-5

@@ -1,0 +1,29 @@
+"""diagnostic: phase timeline of one iteration of cgnr_resident_kernel (needs the -DRLS_STAMPS build,
+tools/build_stamps.sh -> tools/ubench/librls_stamps.so).  Stamps are those of the LAST iteration of the launch."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import rls_amd as rls
+import rls_amd._lib as L
+L.LIB_PATH = os.path.join(ROOT, "tools", "ubench", "librls_stamps.so")
+L._lib = None
+from bench import make_A
+ctx = rls.Context(0)
+lib = ctx.lib
+M, N = 4096, 2048
+A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
+b = rls.DeviceVector.from_host((A @ np.ones(N, np.complex64)).astype(np.complex64), ctx)
+solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+for _ in range(5):
+    rls.init_(solver, b); lib.rls_cgnr_step(solver.state._plan, 20); ctx.sync()
+buf = (C.c_ulonglong * 128)()
+lib.rls_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
+print("status", lib.rls_debug_stamps(buf))
+names = ["iteration start", "products done (partial row stored)", "stores drained + wg barrier", "grid barrier 1 passed",
+         "chunk reduced, v + dots stored, drained", "grid barrier 2 passed", "v + dots loaded", "CG update done"]
+t00 = min(buf[wg * 16 + 8] for wg in range(7))
+for wg in range(7):
+    t = [buf[wg * 16 + 8 + i] for i in range(8)]
+    print(f"wg {wg*37+5}: start @{(t[0]-t00)*10:+5d} ns  " + "  ".join(f"[{i}] +{(t[i]-t[0])*10}" for i in range(1, 8)))
+print("phases: " + "; ".join(f"[{i}] {n}" for i, n in enumerate(names)))
