@@ -310,6 +310,9 @@ int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, floa
 /* optional warm start x0 != 0 (init!(solver, b; x0), src/FISTA.jl:110,120): call right after init */
 int32_t rls_fista_set_start(rls_fista* s, const void* x_init);
 int32_t rls_fista_step(rls_fista* s, int32_t n_steps);
+/* which kernel sequence the next rls_fista_step call takes (as rls_cgnr_path): 0 = two GEMVs + update kernel,
+ * 1 = one-pass slab pipeline, 2 = Gram-mode pipeline, 3 = batched matrix-core kernels, 4 = resident (one launch per call) */
+int32_t rls_fista_path(rls_fista* s, int32_t* out);
 int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out_h);
 int32_t rls_fista_solution(rls_fista* s, void** x_out); /* device pointer currently holding state.x */
 

@@ -142,6 +142,7 @@ PROTOTYPES = {
     "rls_fista_init": (_i32, [_vp, _vp, _f, _f, _f, _i32, _i32]),
     "rls_fista_set_start": (_i32, [_vp, _vp]),
     "rls_fista_step": (_i32, [_vp, _i32]),
+    "rls_fista_path": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "rls_fista_get_status": (_i32, [_vp, C.POINTER(FistaStatus)]),
     "rls_fista_solution": (_i32, [_vp, _pvp]),
     "rls_cg_create": (_i32, [_vp, _vp, _vp, _vp, _pvp]),

@@ -1467,6 +1467,49 @@ __device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned target, u
   return *lds_flag != 0;
 }
 
+
+// workgroup j sums 64-byte column chunk j (and j + nwg, ...) of the partial rows in a fixed order, stores that piece
+// of v write-through and hands every summed column to `per_column(j, sum)` (threads 0..CW-1 of wave 0)
+template <typename E, int G, int K, int WV, typename F>
+__device__ static inline void resident_reduce_chunks(resident_lds<E, G, K, WV>& R, __amdgpu_buffer_rsrc_t slab_rs, E* v,
+                                                     int nwg, int64_t N, F&& per_column) {
+  constexpr int CW = 64 / (int)sizeof(E);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nchunks = (int)(N / CW);
+  for (int ch = blockIdx.x; ch < nchunks; ch += nwg) {
+    const int piece = lane >> 4, r16 = lane & 15;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int row0 = 0; row0 < nwg; row0 += 256) {  // two independent loads per trip (one trip at 256 rows)
+      const int ra = row0 + w * 16 + r16, rb = ra + 128;
+      const uint32_t col_off = (uint32_t)ch * 64u + (uint32_t)piece * 16u;
+      const f4 ta = sc1_load16(slab_rs, (uint32_t)(ra < nwg ? ra : 0) * (uint32_t)(N * sizeof(E)) + col_off);
+      const f4 tb = sc1_load16(slab_rs, (uint32_t)(rb < nwg ? rb : 0) * (uint32_t)(N * sizeof(E)) + col_off);
+      if (ra < nwg) acc += ta;
+      if (rb < nwg) acc += tb;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // the 16 rows of this wave: DPP butterfly inside a row of 16 lanes
+      float t = acc[q];
+      t += dpp_f(t, 0xB1);
+      t += dpp_f(t, 0x4E);
+      t += dpp_f(t, 0x141);
+      t += dpp_f(t, 0x140);
+      acc[q] = t;
+    }
+    if (r16 == 0) R.rp[w][piece] = acc;
+    __syncthreads();
+    if (tid < CW) {
+      E sum = elem<E>::zero();
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, reinterpret_cast<const E*>(&R.rp[ww][0])[tid]);
+      const int j = ch * CW + tid;
+      sc1_store_elem<E>(v + j, sum);
+      per_column(j, sum);
+    }
+    __syncthreads();  // rp is reused by the next chunk
+  }
+}
+
 template <typename E, int G, int K, int WV>
 __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* r, E* p,
                                                                  E* v, E* slab, double* dout, cgnr_scalars* sc,
@@ -1494,7 +1537,6 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   __builtin_amdgcn_sched_barrier(0);
   if (S.done || n_steps <= 0) return;  // uniform
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(v), d_rs = sc1_rsrc(dout);
-  const int nchunks = (int)(N / CW);
   unsigned epoch = 0;
   bool alive = true;
   for (int it = 0; it < n_steps; ++it) {
@@ -1514,41 +1556,12 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     STAMP(11);
     // ---- sum my 64-byte column chunk(s) over all partial rows, fixed order -----------------------------
     double dre = 0.0, dim_ = 0.0, pp = 0.0;
-    for (int ch = blockIdx.x; ch < nchunks; ch += nwg) {
-      const int piece = lane >> 4, r16 = lane & 15;
-      f4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int row0 = 0; row0 < nwg; row0 += 256) {  // two independent loads per trip (one trip at 256 rows)
-        const int ra = row0 + w * 16 + r16, rb = ra + 128;
-        const uint32_t col_off = (uint32_t)ch * 64u + (uint32_t)piece * 16u;
-        const f4 ta = sc1_load16(slab_rs, (uint32_t)(ra < nwg ? ra : 0) * (uint32_t)(N * sizeof(E)) + col_off);
-        const f4 tb = sc1_load16(slab_rs, (uint32_t)(rb < nwg ? rb : 0) * (uint32_t)(N * sizeof(E)) + col_off);
-        if (ra < nwg) acc += ta;
-        if (rb < nwg) acc += tb;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {  // the 16 rows of this wave: DPP butterfly inside a row of 16 lanes
-        float t = acc[q];
-        t += dpp_f(t, 0xB1);
-        t += dpp_f(t, 0x4E);
-        t += dpp_f(t, 0x141);
-        t += dpp_f(t, 0x140);
-        acc[q] = t;
-      }
-      if (r16 == 0) R.rp[w][piece] = acc;
-      __syncthreads();
-      if (tid < CW) {
-        E sum = elem<E>::zero();
-#pragma unroll
-        for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, reinterpret_cast<const E*>(&R.rp[ww][0])[tid]);
-        const int j = ch * CW + tid;
-        sc1_store_elem<E>(v + j, sum);
-        const E pj = L.xs[j];
-        dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
-        dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
-        pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
-      }
-      __syncthreads();  // rp is reused by the next chunk
-    }
+    resident_reduce_chunks<E, G, K, WV>(R, slab_rs, v, nwg, N, [&](int j, E sum) {
+      const E pj = L.xs[j];
+      dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+      dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+      pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+    });
     if (w == 0) {  // lanes 0..CW-1 hold the terms (zero elsewhere); fixed-order butterfly, lane 0 publishes
 #pragma unroll
       for (int off = CW / 2; off > 0; off >>= 1) {
@@ -1629,6 +1642,114 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
       S.cur = 0;
       S.fresh = 0;
       *sc = S;
+      sync->completed = 1u;
+    }
+  }
+}
+
+
+// ---- resident FISTA: the same scheme for src/FISTA.jl:139-185 (BASELINE configs[1] has the headline shape) -------
+// Per iteration: xs = y, partial rows of AHA y, exchange 1, chunk sums -> res_raw, exchange 2, then the gradient step,
+// prox, restart test, theta and the next extrapolated point redundantly in every workgroup (fista_update_elems: its
+// two scalar sums run over full vectors every workgroup holds, so no partial dots travel).
+template <typename E, int G, int K, int WV>
+__global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
+                                                                  const E* __restrict__ x0, E* res, E* y0, E* y1,
+                                                                  E* raw_g, E* slab, fista_scalars* sc,
+                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair,
+                                                                  int n_steps, unsigned spin_limit) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
+  static_assert(EPT % NV == 0, "16-byte ownership layout");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  resident_lds<E, G, K, WV>& R = *reinterpret_cast<resident_lds<E, G, K, WV>*>(smem_raw);
+  slab_lds<E, G, K, WV>& L = R.L;
+  const int tid = threadIdx.x;
+  const int nwg = gridDim.x;
+  fista_scalars S;
+  RLS_FISTA_COPY(S, *sc);
+  E yv[EPT], xk[EPT], xp[EPT], x0v[EPT], ri[EPT];
+  load_owned_wide<E, EPT, NT>(yv, S.ycur ? y1 : y0, tid);
+  load_owned_wide<E, EPT, NT>(xk, (S.iteration & 1) ? b1 : b0, tid);  // state.x == buf[iteration & 1]
+  load_owned_wide<E, EPT, NT>(xp, (S.iteration & 1) ? b0 : b1, tid);
+  load_owned_wide<E, EPT, NT>(x0v, x0, tid);
+  load_owned_wide<E, EPT, NT>(ri, res, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, NV> a[K];
+  slab_load<E, G, K, WV, true>(a, A, lda, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  if (S.done || n_steps <= 0) return;  // uniform
+  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(raw_g);
+  unsigned epoch = 0;
+  bool alive = true;
+  int ycur = S.ycur;
+  for (int it = 0; it < n_steps; ++it) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = yv[e];
+    slab_finish<E, G, K, WV, true, true>(a, L, slab, Mc, N, pair);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+      alive = false;
+      break;
+    }
+    resident_reduce_chunks<E, G, K, WV>(R, slab_rs, raw_g, nwg, N, [](int, E) {});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+      alive = false;
+      break;
+    }
+    E raw[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((q * NT * NV + tid * NV) * sizeof(E))));
+#pragma unroll
+      for (int j = 0; j < NV; ++j) raw[q * NV + j] = c.e[j];
+    }
+    E xn[EPT], yn[EPT];
+    fista_scalars Sn;
+    const bool done = fista_update_elems<E, EPT, NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      xp[e] = xk[e];
+      xk[e] = xn[e];
+      if (!done) yv[e] = yn[e];
+    }
+    if (!done) ycur ^= 1;
+    RLS_FISTA_COPY(S, Sn);
+    if (done) break;  // uniform
+  }
+  if (!alive) {
+    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (blockIdx.x == 0) {
+    E* xw = (S.iteration & 1) ? b1 : b0;   // state.x == buf[iteration & 1] afterwards as well
+    E* xo = (S.iteration & 1) ? b0 : b1;
+    E* yw = ycur ? y1 : y0;
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      chunk<E, NV> c0, c1, c2, c3;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        c0.e[j] = xk[q * NV + j];
+        c1.e[j] = xp[q * NV + j];
+        c2.e[j] = yv[q * NV + j];
+        c3.e[j] = ri[q * NV + j];
+      }
+      const int64_t o = (int64_t)q * (NT * NV) + (int64_t)tid * NV;
+      *reinterpret_cast<f4*>(xw + o) = __builtin_bit_cast(f4, c0);
+      *reinterpret_cast<f4*>(xo + o) = __builtin_bit_cast(f4, c1);
+      *reinterpret_cast<f4*>(yw + o) = __builtin_bit_cast(f4, c2);
+      *reinterpret_cast<f4*>(res + o) = __builtin_bit_cast(f4, c3);
+    }
+    if (tid == 0) {
+      S.ycur = ycur;
+      S.pending = 0;
+      S.fresh = 0;
+      RLS_FISTA_COPY(*sc, S);
       sync->completed = 1u;
     }
   }
@@ -2007,6 +2128,41 @@ static int32_t resident_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout
 #undef RLS_RES_CASE
   return st;
 }
+
+template <typename E, int G, int K, int WV>
+static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void* sync, int nwg, int n_steps,
+                                     unsigned spin_limit) {
+  using C = slab_cfg<E, G, K, WV>;
+  if constexpr (K == 32 && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
+    const int64_t Mc = P.M / C::NV;
+    const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+    constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
+    static bool attr_set = false;
+    if (!attr_set) {
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV>, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
+                       (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab, P.sc,
+                       (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+    return launch_status(ctx);
+  } else {
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident FISTA: slab shape not instantiated");
+  }
+}
+
+template <typename E>
+static int32_t fista_resident_typed(rls_ctx* ctx, const rls_fista_pipe& P, void* sync, int n_steps, unsigned spin_limit) {
+  fused_cfg c;
+  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident FISTA: N too large");
+  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  int32_t st = RLS_E_UNSUPPORTED;
+#define RLS_FRES_CASE(GG, KK, WW) \
+  if (c.G == GG && c.K == KK && c.WV == WW) st = launch_fista_resident<E, GG, KK, WW>(ctx, P, sync, nwg, n_steps, spin_limit);
+  RLS_FOR_EACH_CFG(RLS_FRES_CASE)
+#undef RLS_FRES_CASE
+  return st;
+}
 }  // namespace
 
 int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity) {
@@ -2106,4 +2262,10 @@ int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pip
                                  int n_steps, unsigned spin_limit) {
   if (dtype == RLS_F32) return resident_typed<float>(ctx, P, dout, sync, n_steps, spin_limit);
   return resident_typed<float2>(ctx, P, dout, sync, n_steps, spin_limit);
+}
+
+int32_t rls_fista_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, void* sync, int n_steps,
+                                  unsigned spin_limit) {
+  if (dtype == RLS_F32) return fista_resident_typed<float>(ctx, P, sync, n_steps, spin_limit);
+  return fista_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit);
 }

@@ -454,6 +454,8 @@ struct rls_fista_pipe {
 };
 int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
 int32_t rls_fista_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
+int32_t rls_fista_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, void* sync, int n_steps,
+                                  unsigned spin_limit);
 
 // everything the CGNR pipeline kernels need (normal.hip)
 struct rls_cgnr_pipe {

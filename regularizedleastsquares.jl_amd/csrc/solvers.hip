@@ -199,15 +199,31 @@ static bool cgnr_use_resident(const rls_cgnr* s) {
 // symptom is the bounded-wait timeout reported by rls_cgnr_get_status.)
 static std::mutex g_resident_mu;
 static hipEvent_t g_resident_ev[64];
-static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_pipe& P, int n_steps) {
+template <typename F>
+static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch) {
   std::lock_guard<std::mutex> lock(g_resident_mu);
   const int d = ctx->device < 64 ? ctx->device : 63;
   if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
   else RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
-  RLS_HIP(ctx, hipMemsetAsync(s->rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream));
-  const int32_t st = rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+  RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream));
+  const int32_t st = launch();
   RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], ctx->stream));
   return st;
+}
+static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_pipe& P, int n_steps) {
+  return resident_chain(ctx, s->rsync, [&]() {
+    return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+  });
+}
+// {fail, completed} of the last resident launch, read back with the scalars of a status call
+static int32_t resident_check(rls_ctx* ctx, const unsigned* rsync_h, const char* what) {
+  if (rsync_h[0] && !rsync_h[1]) {
+    snprintf(ctx->err, sizeof(ctx->err),
+             "resident %s launch timed out waiting for its workgroups (is another process using the device?): the call was a "
+             "no-op; rls_tune_set(\"resident\", 0) selects the two-launch pipeline (code %d)", what, (int)RLS_E_STATE);
+    return RLS_E_STATE;
+  }
+  return 0;
 }
 
 static rls_cgnr_pipe cgnr_pipe_desc(const rls_cgnr* s) {
@@ -475,6 +491,10 @@ struct rls_fista {
   fista_scalars* scb_h = nullptr;  // pinned [nrhs]
   int enq = 0;           // iterations enqueued since init (== the device's count unless the plan stopped early)
   int graph_parity = 0;  // parity of `enq` the cached graph's buffer hints were captured with
+  // resident mode (normal.hip, fista_resident_kernel)
+  void* rsync = nullptr;
+  unsigned* rsync_h = nullptr;
+  bool resident_used = false;
 };
 
 // batched launches: workgroup b = column b.  Vpart non-null: AHA y arrives as `S` partial rows per column and is
@@ -1875,10 +1895,7 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
     RLS_HIP(ctx, hipMemcpyAsync(s->rsync_h, (const char*)s->rsync + 8 * 32 * sizeof(unsigned), 2 * sizeof(unsigned),
                                 hipMemcpyDeviceToHost, ctx->stream));
   RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
-  if (s->resident_used && s->rsync_h[0] && !s->rsync_h[1])
-    return rls_fail(ctx, RLS_E_STATE, "resident CGNR launch timed out waiting for its workgroups (is another process or "
-                                      "stream using the device?): the call was a no-op; rls_tune_set(\"resident\", 0) "
-                                      "selects the two-launch pipeline");
+  if (s->resident_used) RLS_TRY(resident_check(ctx, s->rsync_h, "CGNR"));
   const cgnr_scalars& h = *s->sc_h;
   out->iteration = h.iteration;
   out->done = h.done;
@@ -1943,6 +1960,16 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
     delete s;
     return rls_fail(ctx, (int32_t)e, "fista_create: hipMalloc failed");
   }
+  if (op->slab && op->A && !op->G && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
+    if (hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes()) != hipSuccess ||
+        hipHostMalloc((void**)&s->rsync_h, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+      if (s->rsync) hipFree(s->rsync);
+      s->rsync = nullptr;  // resident mode is an optimisation: without its scratch the pipeline runs
+      (void)hipGetLastError();
+    } else {
+      s->rsync_h[0] = s->rsync_h[1] = 0;
+    }
+  }
   int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
   if (st != 0) {
     hipFree(s->y);
@@ -1970,6 +1997,8 @@ int32_t rls_fista_destroy(rls_fista* s) {
   if (s->Tpack) hipFree(s->Tpack);
   if (s->Vpart) hipFree(s->Vpart);
   if (s->scb_h) hipHostFree(s->scb_h);
+  if (s->rsync) hipFree(s->rsync);
+  if (s->rsync_h) hipHostFree(s->rsync_h);
   hipFree(s->sc);
   hipHostFree(s->sc_h);
   delete s;
@@ -2181,6 +2210,8 @@ int32_t rls_fista_set_start(rls_fista* s, const void* x_init) {
   return 0;
 }
 
+static bool fista_use_resident(const rls_fista* s);
+
 int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
@@ -2219,6 +2250,16 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
     s->enq += n_steps;
     return rls_fista_gram_finish(ctx, dtype, P, n_steps & 1);
   }
+  if (fista_use_resident(s)) {
+    // the whole call as ONE launch, A held in registers (normal.hip, fista_resident_kernel)
+    if (n_steps == 0) return 0;
+    const rls_fista_pipe P = fista_pipe_desc(s);
+    s->resident_used = true;
+    s->enq += n_steps;
+    return resident_chain(ctx, s->rsync, [&]() {
+      return rls_fista_resident_launch(ctx, s->op->dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+    });
+  }
   if (s->use_pipe) {
     // iteration k = K_A (applies the gradient/prox/momentum update k-1 in its prologue, then one pass
     // over A for AHA y) + K_R (sums the partial rows); the last update of this call is applied by K_F
@@ -2246,12 +2287,28 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_iteration(s); });
 }
 
+static bool fista_use_resident(const rls_fista* s) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return s->nrhs == 1 && s->use_pipe && s->rsync && s->op->ctx->tune.resident && al16(s->buf[0]) && al16(s->buf[1]) &&
+         al16(s->x0) && al16(s->res);
+}
+
+int32_t rls_fista_path(rls_fista* s, int32_t* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  *out = s->nrhs > 1 ? 3 : s->use_gram ? 2 : fista_use_resident(s) ? 4 : s->use_pipe ? 1 : 0;
+  return 0;
+}
+
 int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_get_status before fista_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->resident_used)
+    RLS_HIP(ctx, hipMemcpyAsync(s->rsync_h, (const char*)s->rsync + 8 * 32 * sizeof(unsigned), 2 * sizeof(unsigned),
+                                hipMemcpyDeviceToHost, ctx->stream));
   RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  if (s->resident_used) RLS_TRY(resident_check(ctx, s->rsync_h, "FISTA"));
   const fista_scalars& h = *s->sc_h;
   out->iteration = h.iteration;
   out->done = h.done;

@@ -2001,3 +2001,50 @@ def test_cgnr_resident_timeout_is_a_loud_no_op(rls, ctx):
     x = rls.solve_(sol, bd).to_host()
     ref = O.CGNR(A.astype(np.complex128), iterations=8, relTol=0.0)
     parity("cgnr_resident_after_timeout", x, O.solve(ref, b.astype(np.complex128)), lambda: O.solve(O.CGNR(A, iterations=8, relTol=0.0), b))
+
+
+@pytest.mark.parametrize("dt,M,N,restart", [(np.complex64, 4096, 2048, "none"), (np.complex64, 4096, 2048, "gradient"),
+                                            (np.float32, 4096, 4096, "gradient")])
+def test_fista_resident_kernel(rls, ctx, dt, M, N, restart):
+    """BASELINE configs[1] shape through fista_resident_kernel (the whole rls_fista_step call in one launch): iterates
+    against the float64 oracle step by step and in one call, bit-identical between the two and run to run, projection
+    + gradient restart included; the two-launch pipeline (resident = 0) passes the same gate"""
+    import ctypes as C
+    A, xt, b = O.make_problem(M, N, dt, 2)
+    A64, b64 = A.astype(hi(dt)), b.astype(hi(dt))
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2 if M > N else 0.9 / (np.sqrt(M) + np.sqrt(N)) ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    its = 30
+    regs = lambda R: [R.L1Regularization(lam), R.PositiveRegularization()] if restart == "gradient" else R.L1Regularization(lam)
+    ref = O.FISTA(A64, reg=regs(O), rho=rho, iterations=its, restart=restart)
+    ref32 = O.FISTA(A, reg=regs(O), rho=rho, iterations=its, restart=restart)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    sol = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=its, restart=restart)
+    rls.init_(sol, bd)
+    path = C.c_int32(-1)
+    assert ctx.lib.rls_fista_path(sol.state._plan, C.byref(path)) == 0
+    if path.value != 4:
+        pytest.skip("resident mode not available on this device")
+    ref.init(b64)
+    ref32.init(b)
+    tag = f"fista_resident_{M}x{N}_{np.dtype(dt).name}_{restart}"
+    for it in range(1, its + 1):
+        assert ref.iterate() is not None and ref32.iterate() is not None and rls.iterate(sol) is not None
+        if it in (1, 2, 7, its):
+            parity(f"{tag}_it{it}", sol.state.x.to_host(), ref.x, ref32.x)
+    assert rls.iterate(sol) is None and sol.state.iteration == its
+    x_steps = sol.state.x.to_host()
+    assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
+    x_once = rls.solve_(sol, bd).to_host()
+    x_again = rls.solve_(sol, bd).to_host()
+    assert np.array_equal(x_once, x_steps) and np.array_equal(x_once, x_again)
+    seen = []
+    x_cb = rls.solve_(sol, bd, callbacks=lambda s_, i: seen.append(i)).to_host()
+    assert seen == list(range(its + 1)) and np.array_equal(x_cb, x_once)
+    ctx.tune(resident=0)
+    try:
+        assert ctx.lib.rls_fista_path(sol.state._plan, C.byref(path)) == 0 and path.value == 1
+        x_pipe = rls.solve_(sol, bd).to_host()
+    finally:
+        ctx.tune(resident=1)
+    parity(f"{tag}_pipeline", x_pipe, ref.x, ref32.x)
