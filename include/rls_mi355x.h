@@ -429,6 +429,37 @@ int32_t rls_cg_local_apply(rls_cg* s, const void* x);
 int32_t rls_cg_local_start(rls_cg* s, const void* x, const void* b, float rho, int32_t maxiter, float reltol);
 int32_t rls_cg_local_update(rls_cg* s, void* x);
 
+/* ---------------------------------------------------------------------------------------------
+ * Communicator: the exchange step of the row-partitioned mode inside the library, for hosts that drive several
+ * GPUs from ONE process (the Julia extension: one task per GPU; fan-out site src/MultiThreading.jl:60-78; the
+ * replicated init / iterate halves are src/CGNR.jl:107-130, :143-178).  Rank r owns context ctxs[r] (pass NULL to
+ * have the communicator create one context per entry of devices[]; rls_comm_ctx returns them) and everything a rank
+ * enqueues -- its local halves and its share of the collective -- goes to that context's stream.
+ *   RLS_COMM_RCCL   : ncclAllReduce over xGMI, one group call per all-reduce; needs one distinct device per rank.
+ *   RLS_COMM_DIRECT : one-shot direct-write all-reduce (peer stores into per-rank slots, stream events, the slots
+ *                     summed in rank order: every rank adds the same numbers in the same order).  Ranks may share
+ *                     a device, which is how the config-5 schedule runs on a one-GPU box.
+ *   RLS_COMM_AUTO   : RCCL when the devices are distinct, DIRECT otherwise.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rls_comm rls_comm;
+enum { RLS_COMM_AUTO = 0, RLS_COMM_RCCL = 1, RLS_COMM_DIRECT = 2 };
+int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* ctxs, int32_t transport, rls_comm** out);
+int32_t rls_comm_destroy(rls_comm* comm);
+int32_t rls_comm_size(rls_comm* comm);
+int32_t rls_comm_transport(rls_comm* comm);
+int32_t rls_comm_ctx(rls_comm* comm, int32_t rank, rls_ctx** out);
+int32_t rls_comm_sync(rls_comm* comm); /* waits for every rank's stream */
+/* in place: rank_bufs[r] (device pointer on rank r's device, n elements of dtype) <- sum over ranks; asynchronous */
+int32_t rls_allreduce_sum(rls_comm* comm, void* const* rank_bufs, int64_t n, int32_t dtype);
+/* CGNR on a row-partitioned A: plans[r] was created on rank r's context over that rank's row shard (repacked
+ * contiguous), b_parts[r] is that rank's slice of b.  init = every rank's rls_cgnr_init_local_a, ONE all-reduce of
+ * A^H b, every rank's rls_cgnr_init_local_b; a step = local_a (t_g = A_g p, v_g = A_g^H t_g), ONE all-reduce of v,
+ * local_b (the replicated update).  Scalars need no collective: every rank reduces identical vectors in the same
+ * order.  `done` is a device flag replicated on every rank, so the collective count never depends on the data. */
+int32_t rls_cgnr_init_rowsharded(rls_comm* comm, rls_cgnr* const* plans, const void* const* b_parts, float lambda,
+                                 float rel_tol, int32_t iterations);
+int32_t rls_cgnr_step_rowsharded(rls_comm* comm, rls_cgnr* const* plans, int32_t n_steps);
+
 #ifdef __cplusplus
 }
 #endif

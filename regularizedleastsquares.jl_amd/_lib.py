@@ -169,6 +169,15 @@ PROTOTYPES = {
     "rls_cg_local_apply": (_i32, [_vp, _vp]),
     "rls_cg_local_start": (_i32, [_vp, _vp, _vp, _f, _i32, _f]),
     "rls_cg_local_update": (_i32, [_vp, _vp]),
+    "rls_comm_create": (_i32, [_i32, C.POINTER(C.c_int32), C.POINTER(_vp), _i32, C.POINTER(_vp)]),
+    "rls_comm_destroy": (_i32, [_vp]),
+    "rls_comm_size": (_i32, [_vp]),
+    "rls_comm_transport": (_i32, [_vp]),
+    "rls_comm_ctx": (_i32, [_vp, _i32, C.POINTER(_vp)]),
+    "rls_comm_sync": (_i32, [_vp]),
+    "rls_allreduce_sum": (_i32, [_vp, C.POINTER(_vp), C.c_int64, _i32]),
+    "rls_cgnr_init_rowsharded": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_float, C.c_float, _i32]),
+    "rls_cgnr_step_rowsharded": (_i32, [_vp, C.POINTER(_vp), _i32]),
     "rls_admm_create": (_i32, [_vp, _pvp]),
     "rls_admm_destroy": (_i32, [_vp]),
     "rls_admm_init": (_i32, [_vp, C.POINTER(AdmmParams)]),

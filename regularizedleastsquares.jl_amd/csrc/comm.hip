@@ -1,0 +1,285 @@
+// Communicator for the row-partitioned mode (BASELINE config 5): one exchange step per operator
+// apply -- the all-reduce(sum) of the length-N partial products A_g^H t_g -- between the ranks of ONE host process
+// (the Julia host drives every GPU of the node from one process, one task per GPU: src/MultiThreading.jl:60-78 is the
+// fan-out site this serves; the Python host of this repository runs one process per GPU and uses torch.distributed).
+//
+// Two transports behind the same entry point:
+//   * RLS_COMM_RCCL   -- ncclAllReduce on every rank's stream inside one group call (RCCL over xGMI).  The library is
+//                        loaded with dlopen at communicator creation, so librls_mi355x.so itself does not link it.
+//                        Needs distinct devices (RCCL rejects two ranks on one GPU).
+//   * RLS_COMM_DIRECT -- the one-shot direct-write all-reduce for the 64 KiB vectors of this path (latency-bound at
+//                        that size: SURVEY 5, last row): every rank stores its vector straight into slot r of every
+//                        peer's receive buffer (peer access: xGMI stores, or plain stores when ranks share a device),
+//                        records an event, waits for the events of all ranks on its own stream and sums the slots
+//                        in RANK ORDER.  Every rank adds the same numbers in the same order, so the replicated state
+//                        of the solvers stays bit-identical across ranks by construction (a ring all-reduce gives
+//                        every rank the same bits too, but not the bits of the unsharded sum order).  Ordering is
+//                        by stream events only -- no in-kernel polling across devices -- and receive buffers
+//                        alternate between two parities so that round k + 1 never overwrites what round k still reads.
+//                        Ranks may share a device: that is how the collective schedule of config 5 runs on a
+//                        one-GPU box (tests/abi_smoke.c, tests/test_gpu_parity.py).
+#include "rls_common.hpp"
+
+#include <dlfcn.h>
+
+#include <vector>
+
+namespace {
+
+constexpr int MAX_RANKS = 16;
+
+struct peer_ptrs {
+  float* p[MAX_RANKS];
+};
+
+// src -> slot `rank` of every rank's receive buffer (blockIdx.y = destination rank)
+__global__ __launch_bounds__(256) void comm_push_kernel(const float* __restrict__ src, peer_ptrs dst, int64_t nf) {
+  float* out = dst.p[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (int64_t)gridDim.x * blockDim.x) out[i] = src[i];
+}
+
+// buf = slot 0 + slot 1 + ... + slot n-1, in that order
+__global__ __launch_bounds__(256) void comm_sum_kernel(float* __restrict__ buf, const float* __restrict__ slots, int n,
+                                                       int64_t stride_f, int64_t nf) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = slots[i];
+    for (int r = 1; r < n; ++r) s += slots[(int64_t)r * stride_f + i];
+    buf[i] = s;
+  }
+}
+
+typedef void* nccl_comm_t;
+struct rccl_api {
+  void* handle = nullptr;
+  int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+}  // namespace
+
+struct rls_comm {
+  int n = 0;
+  int transport = 0;
+  std::vector<rls_ctx*> ctx;
+  bool own_ctx = false;
+  // direct transport
+  size_t cap_f = 0;                  // floats per slot
+  std::vector<float*> recv[2];       // [parity][rank]: n slots of cap_f floats on that rank's device
+  std::vector<hipEvent_t> pushed;    // one per rank
+  int round = 0;
+  // RCCL transport
+  rccl_api rccl;
+  std::vector<nccl_comm_t> comms;
+};
+
+static int32_t comm_fail(rls_comm* c, int32_t code, const char* what) {
+  return rls_fail(c && !c->ctx.empty() ? c->ctx[0] : nullptr, code, what);
+}
+
+static int32_t direct_reserve(rls_comm* c, size_t nf) {
+  if (nf <= c->cap_f) return 0;
+  rls_ctx* c0 = c->ctx[0];
+  for (int r = 0; r < c->n; ++r) {  // growing the receive buffers is a setup step: drain every rank first
+    RLS_HIP(c0, hipSetDevice(c->ctx[r]->device));
+    RLS_HIP(c0, rls_stream_wait(c->ctx[r]->stream));
+  }
+  const size_t cap = (nf + 1023) / 1024 * 1024;
+  for (int q = 0; q < 2; ++q)
+    for (int r = 0; r < c->n; ++r) {
+      RLS_HIP(c0, hipSetDevice(c->ctx[r]->device));
+      if (c->recv[q][r]) RLS_HIP(c0, hipFree(c->recv[q][r]));
+      c->recv[q][r] = nullptr;
+      RLS_HIP(c0, hipMalloc((void**)&c->recv[q][r], sizeof(float) * cap * (size_t)c->n));
+    }
+  c->cap_f = cap;
+  return 0;
+}
+
+static int32_t direct_allreduce(rls_comm* c, void* const* bufs, size_t nf) {
+  RLS_TRY(direct_reserve(c, nf));
+  rls_ctx* c0 = c->ctx[0];
+  const int q = c->round & 1;
+  const unsigned gx = (unsigned)((nf + 255) / 256 < 64 ? (nf + 255) / 256 : 64);
+  for (int r = 0; r < c->n; ++r) {
+    rls_ctx* cr = c->ctx[r];
+    RLS_HIP(c0, hipSetDevice(cr->device));
+    peer_ptrs d;
+    for (int t = 0; t < MAX_RANKS; ++t) d.p[t] = t < c->n ? c->recv[q][t] + (size_t)r * c->cap_f : nullptr;
+    hipLaunchKernelGGL(comm_push_kernel, dim3(gx, (unsigned)c->n), dim3(256), 0, cr->stream, (const float*)bufs[r], d, (int64_t)nf);
+    RLS_HIP(c0, hipEventRecord(c->pushed[r], cr->stream));
+  }
+  for (int r = 0; r < c->n; ++r) {
+    rls_ctx* cr = c->ctx[r];
+    RLS_HIP(c0, hipSetDevice(cr->device));
+    for (int t = 0; t < c->n; ++t)
+      if (t != r) RLS_HIP(c0, hipStreamWaitEvent(cr->stream, c->pushed[t], 0));
+    hipLaunchKernelGGL(comm_sum_kernel, dim3(gx), dim3(256), 0, cr->stream, (float*)bufs[r], (const float*)c->recv[q][r], c->n,
+                       (int64_t)c->cap_f, (int64_t)nf);
+  }
+  c->round++;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return comm_fail(c, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+static int32_t rccl_load(rls_comm* c) {
+  rccl_api& R = c->rccl;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    R.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (R.handle) break;
+  }
+  if (!R.handle) return comm_fail(c, RLS_E_UNSUPPORTED, "rls_comm_create: librccl.so not found (RCCL transport)");
+  R.CommInitAll = (int (*)(nccl_comm_t*, int, const int*))dlsym(R.handle, "ncclCommInitAll");
+  R.CommDestroy = (int (*)(nccl_comm_t))dlsym(R.handle, "ncclCommDestroy");
+  R.GroupStart = (int (*)())dlsym(R.handle, "ncclGroupStart");
+  R.GroupEnd = (int (*)())dlsym(R.handle, "ncclGroupEnd");
+  R.AllReduce = (int (*)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(R.handle, "ncclAllReduce");
+  R.GetErrorString = (const char* (*)(int))dlsym(R.handle, "ncclGetErrorString");
+  if (!R.CommInitAll || !R.CommDestroy || !R.GroupStart || !R.GroupEnd || !R.AllReduce)
+    return comm_fail(c, RLS_E_UNSUPPORTED, "rls_comm_create: librccl.so lacks an expected symbol");
+  return 0;
+}
+
+static int32_t rccl_check(rls_comm* c, int rc, const char* what) {
+  if (rc == 0) return 0;
+  char msg[256];
+  snprintf(msg, sizeof(msg), "%s: %s", what, c->rccl.GetErrorString ? c->rccl.GetErrorString(rc) : "RCCL error");
+  return comm_fail(c, 1000 + rc, msg);
+}
+
+extern "C" {
+
+int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* ctxs, int32_t transport, rls_comm** out) {
+  if (!out) return RLS_E_INVALID;
+  *out = nullptr;
+  if (nranks < 1 || nranks > MAX_RANKS || (!devices && !ctxs)) return RLS_E_INVALID;
+  rls_comm* c = new rls_comm();
+  c->n = nranks;
+  c->own_ctx = ctxs == nullptr;
+  for (int r = 0; r < nranks; ++r) {
+    rls_ctx* x = nullptr;
+    if (ctxs) {
+      x = ctxs[r];
+      if (!x || (devices && devices[r] != x->device)) {
+        delete c;
+        return RLS_E_INVALID;
+      }
+    } else {
+      const int32_t st = rls_ctx_create(devices[r], &x);
+      if (st != 0) {
+        for (rls_ctx* y : c->ctx) rls_ctx_destroy(y);
+        delete c;
+        return st;
+      }
+    }
+    c->ctx.push_back(x);
+  }
+  bool distinct = true;
+  for (int r = 0; r < nranks; ++r)
+    for (int t = 0; t < r; ++t) distinct = distinct && c->ctx[r]->device != c->ctx[t]->device;
+  if (transport == RLS_COMM_AUTO) transport = (distinct && nranks > 1) ? RLS_COMM_RCCL : RLS_COMM_DIRECT;
+  c->transport = transport;
+  int32_t st = 0;
+  if (transport == RLS_COMM_RCCL) {
+    if (!distinct) st = comm_fail(c, RLS_E_UNSUPPORTED, "rls_comm_create: the RCCL transport needs one distinct device per rank");
+    if (st == 0) st = rccl_load(c);
+    if (st == 0) {
+      std::vector<int> devs;
+      for (rls_ctx* x : c->ctx) devs.push_back(x->device);
+      c->comms.resize(nranks);
+      st = rccl_check(c, c->rccl.CommInitAll(c->comms.data(), nranks, devs.data()), "ncclCommInitAll");
+      if (st != 0) c->comms.clear();
+    }
+  } else if (transport == RLS_COMM_DIRECT) {
+    for (int q = 0; q < 2; ++q) c->recv[q].assign(nranks, nullptr);
+    c->pushed.assign(nranks, nullptr);
+    for (int r = 0; r < nranks && st == 0; ++r) {
+      hipError_t e = hipSetDevice(c->ctx[r]->device);
+      for (int t = 0; t < nranks && e == hipSuccess; ++t) {
+        const int da = c->ctx[r]->device, db = c->ctx[t]->device;
+        if (da == db) continue;
+        int can = 0;
+        e = hipDeviceCanAccessPeer(&can, da, db);
+        if (e == hipSuccess && !can) {
+          st = comm_fail(c, RLS_E_UNSUPPORTED, "rls_comm_create: direct transport needs peer access between the ranks' devices");
+          break;
+        }
+        if (e == hipSuccess) {
+          e = hipDeviceEnablePeerAccess(db, 0);
+          if (e == hipErrorPeerAccessAlreadyEnabled) {
+            e = hipSuccess;
+            (void)hipGetLastError();
+          }
+        }
+      }
+      if (st == 0 && e == hipSuccess) e = hipEventCreateWithFlags(&c->pushed[r], hipEventDisableTiming);
+      if (st == 0 && e != hipSuccess) st = comm_fail(c, (int32_t)e, hipGetErrorString(e));
+    }
+  } else {
+    st = comm_fail(c, RLS_E_INVALID, "rls_comm_create: unknown transport");
+  }
+  if (st != 0) {
+    rls_comm_destroy(c);
+    return st;
+  }
+  *out = c;
+  return 0;
+}
+
+int32_t rls_comm_destroy(rls_comm* c) {
+  if (!c) return RLS_E_INVALID;
+  for (int r = 0; r < (int)c->ctx.size(); ++r) {
+    hipSetDevice(c->ctx[r]->device);
+    rls_stream_wait(c->ctx[r]->stream);
+    for (int q = 0; q < 2; ++q)
+      if (r < (int)c->recv[q].size() && c->recv[q][r]) hipFree(c->recv[q][r]);
+    if (r < (int)c->pushed.size() && c->pushed[r]) hipEventDestroy(c->pushed[r]);
+  }
+  for (nccl_comm_t k : c->comms)
+    if (k && c->rccl.CommDestroy) c->rccl.CommDestroy(k);
+  if (c->own_ctx)
+    for (rls_ctx* x : c->ctx) rls_ctx_destroy(x);
+  // the RCCL handle stays loaded: unloading a library with live device state is not safe
+  delete c;
+  return 0;
+}
+
+int32_t rls_comm_size(rls_comm* c) { return c ? c->n : RLS_E_INVALID; }
+int32_t rls_comm_transport(rls_comm* c) { return c ? c->transport : RLS_E_INVALID; }
+
+int32_t rls_comm_ctx(rls_comm* c, int32_t rank, rls_ctx** out) {
+  if (!c || !out || rank < 0 || rank >= c->n) return RLS_E_INVALID;
+  *out = c->ctx[rank];
+  return 0;
+}
+
+int32_t rls_comm_sync(rls_comm* c) {
+  if (!c) return RLS_E_INVALID;
+  for (rls_ctx* x : c->ctx) RLS_TRY(rls_ctx_sync(x));
+  return 0;
+}
+
+// rank_bufs[r]: device pointer on rank r's device, n elements of dtype; in place: every buffer ends up holding the
+// sum over ranks.  Enqueued on the ranks' context streams (asynchronous).
+int32_t rls_allreduce_sum(rls_comm* c, void* const* rank_bufs, int64_t n, int32_t dtype) {
+  if (!c || !rank_bufs) return RLS_E_INVALID;
+  if (!rls_dtype_ok(dtype) || n < 0) return comm_fail(c, RLS_E_INVALID, "rls_allreduce_sum: bad dtype or length");
+  for (int r = 0; r < c->n; ++r)
+    if (!rank_bufs[r]) return comm_fail(c, RLS_E_INVALID, "rls_allreduce_sum: null buffer");
+  if (n == 0 || c->n == 1) return 0;
+  const size_t nf = (size_t)n * (dtype == RLS_C32 ? 2 : 1);
+  if (c->transport == RLS_COMM_DIRECT) return direct_allreduce(c, rank_bufs, nf);
+  RLS_TRY(rccl_check(c, c->rccl.GroupStart(), "ncclGroupStart"));
+  int32_t st = 0;
+  for (int r = 0; r < c->n && st == 0; ++r)
+    st = rccl_check(c, c->rccl.AllReduce(rank_bufs[r], rank_bufs[r], nf, /* ncclFloat32 */ 7, /* ncclSum */ 0, c->comms[r], c->ctx[r]->stream),
+                    "ncclAllReduce");
+  const int32_t st2 = rccl_check(c, c->rccl.GroupEnd(), "ncclGroupEnd");
+  return st != 0 ? st : st2;
+}
+
+}  // extern "C"

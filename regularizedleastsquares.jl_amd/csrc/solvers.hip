@@ -11,6 +11,7 @@
 #include "rls_common.hpp"
 
 #include <mutex>
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------
 // operator
@@ -1862,6 +1863,48 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
   RLS_TRY(rls_cgnr_pipe_finish(ctx, dtype, P));
   *us_normal = 1e3f * a / n_steps;
   *us_reduce = 1e3f * r / n_steps;
+  return 0;
+}
+
+// ---- row-partitioned CGNR through a communicator (comm.hip): the collective lives inside the library ----------
+static int32_t rowsharded_check(rls_comm* comm, rls_cgnr* const* plans, std::vector<void*>* bufs, int which) {
+  if (!comm || !plans) return RLS_E_INVALID;
+  const int n = rls_comm_size(comm);
+  bufs->resize(n);
+  for (int r = 0; r < n; ++r) {
+    rls_ctx* cr = nullptr;
+    RLS_TRY(rls_comm_ctx(comm, r, &cr));
+    if (!plans[r]) return rls_fail(cr, RLS_E_INVALID, "rowsharded: null plan");
+    if (plans[r]->op->ctx != cr) return rls_fail(cr, RLS_E_INVALID, "rowsharded: plan r must live on the communicator's context r");
+    if (plans[r]->nrhs != 1 || plans[r]->op->N != plans[0]->op->N || plans[r]->op->dtype != plans[0]->op->dtype)
+      return rls_fail(cr, RLS_E_INVALID, "rowsharded: the shards must share N and the element type");
+    (*bufs)[r] = which == 0 ? plans[r]->r : plans[r]->v;
+  }
+  return 0;
+}
+
+int32_t rls_cgnr_init_rowsharded(rls_comm* comm, rls_cgnr* const* plans, const void* const* b_parts, float lambda,
+                                 float rel_tol, int32_t iterations) {
+  std::vector<void*> bufs;
+  RLS_TRY(rowsharded_check(comm, plans, &bufs, 0));
+  if (!b_parts) return RLS_E_INVALID;
+  const int n = rls_comm_size(comm);
+  for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_init_local_a(plans[r], b_parts[r], lambda, rel_tol, iterations));
+  RLS_TRY(rls_allreduce_sum(comm, bufs.data(), plans[0]->op->N, plans[0]->op->dtype));  // r = sum_g A_g^H b_g
+  for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_init_local_b(plans[r]));
+  return 0;
+}
+
+int32_t rls_cgnr_step_rowsharded(rls_comm* comm, rls_cgnr* const* plans, int32_t n_steps) {
+  std::vector<void*> bufs;
+  RLS_TRY(rowsharded_check(comm, plans, &bufs, 1));
+  if (n_steps < 0) return RLS_E_INVALID;
+  const int n = rls_comm_size(comm);
+  for (int k = 0; k < n_steps; ++k) {
+    for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_step_local_a(plans[r]));
+    RLS_TRY(rls_allreduce_sum(comm, bufs.data(), plans[0]->op->N, plans[0]->op->dtype));  // v = sum_g A_g^H A_g p
+    for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_step_local_b(plans[r]));
+  }
   return 0;
 }
 

@@ -4,6 +4,7 @@ where Float32 conditioning makes 1e-5 unattainable the gate is 2 x the error of 
 run against its float64 run (`parity`, tests/conftest.py; both errors are logged per case and tabulated in
 DESIGN.md section 3b); elementwise kernels 2e-6; reductions 1e-6.  Run on the GPU box with `pytest -m gpu`."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -2048,3 +2049,18 @@ def test_fista_resident_kernel(rls, ctx, dt, M, N, restart):
     finally:
         ctx.tune(resident=1)
     parity(f"{tag}_pipeline", x_pipe, ref.x, ref32.x)
+
+
+def test_plain_c_program_drives_the_abi(rls, tmp_path):
+    """tests/abi_smoke.c: create -> init -> step -> status for CGNR and FISTA, the headline shape, and row-partitioned
+    CGNR through the library's own communicator, from a plain-C process (gcc; no Python, C++ or torch inside it) --
+    what a host binding include/rls_mi355x.h through its FFI executes"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(rls.LIB_PATH)
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi_smoke.c"),
+                    "-o", exe, "-L", pkg, "-lrls_mi355x", "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_smoke OK" in out.stdout and "row-sharded CGNR, 4 rank(s)" in out.stdout
