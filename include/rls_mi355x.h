@@ -307,8 +307,9 @@ int32_t rls_fista_destroy(rls_fista* s);
 int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t l21_slices, int32_t proj_kind);
 int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, float rel_tol, int32_t iterations,
                        int32_t restart_gradient);
-/* optional warm start x0 != 0 (init!(solver, b; x0), src/FISTA.jl:110,120): call right after init */
-int32_t rls_fista_set_start(rls_fista* s, const void* x_init);
+/* optional warm start x0 != 0 (init!(solver, b; x0), src/FISTA.jl:110,120): call right after init.  x_init: n = N
+ * elements (a scalar x0 is broadcast by the caller, as `state.x .= x0` does); RLS_E_INVALID on any other length */
+int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n);
 int32_t rls_fista_step(rls_fista* s, int32_t n_steps);
 /* which kernel sequence the next rls_fista_step call takes (as rls_cgnr_path): 0 = two GEMVs + update kernel,
  * 1 = one-pass slab pipeline, 2 = Gram-mode pipeline, 3 = batched matrix-core kernels, 4 = resident (one launch per call) */

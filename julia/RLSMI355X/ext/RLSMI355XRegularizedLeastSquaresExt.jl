@@ -2,17 +2,22 @@
 # the same the reference uses for its GPUArrays / CUDA extensions: Project.toml:20-27).
 # It overloads, for RLSVector / RLSMatrix, exactly the methods SURVEY.md 8(b) lists:
 #   * the internal helpers the GPUArrays ext overloads (prox pieces, enfReal!/enfPos!)
-#   * the fused fast paths init!/iterate for CGNR and FISTA (sanctioned: docs/src/solvers.md:85-98,
-#     precedent ext/RegularizedLeastSquaresGPUArraysExt/Kaczmarz.jl:1)
-# Everything else (createLinearSolver, solve!, callbacks, Regularization types, ADMM's outer loop,
-# MultiThreading schedulers) runs UNCHANGED from the reference on top of these methods.
+#   * the fused fast paths init!/iterate for CGNR, FISTA, ADMM and Kaczmarz (sanctioned: docs/src/solvers.md:85-98,
+#     precedent ext/RegularizedLeastSquaresGPUArraysExt/Kaczmarz.jl:1); configurations a fused plan does not
+#     cover (several regularisers, a non-identity regTrafo, vary_rho, L21 / LLR / nuclear terms in ADMM, ...) fall
+#     through to the reference's own generic methods, which run on RLSVector through its BLAS-1 methods and its
+#     broadcast lowering (RLSMI355X.jl: RLSStyle)
+# Everything else (createLinearSolver, solve!, callbacks, Regularization types, MultiThreading schedulers) runs
+# UNCHANGED from the reference on top of these methods.
 module RLSMI355XRegularizedLeastSquaresExt
 
 using RLSMI355X, RegularizedLeastSquares, LinearAlgebra
 using RLSMI355X: RLSVector, RLSMatrix, RLSNormalOp, librls, check, dtypecode
 import RegularizedLeastSquares: prox!, proxL21!, proxTV!, enfReal!, enfPos!, tv_restrictMagnitude!, tv_linearcomb!,
-                                init!, iterate, CGNR, CGNRState, FISTA, FISTAState, L1Regularization, L2Regularization,
-                                TVParams, λ, Kaczmarz, KaczmarzState, normalize, SystemMatrixBasedNormalization, done
+                                init!, iterate, CGNR, CGNRState, FISTA, FISTAState, ADMM, ADMMState, L1Regularization,
+                                L2Regularization, L21Regularization, TVRegularization, PositiveRegularization,
+                                RealRegularization, NoNormalization, TVParams, λ, Kaczmarz, KaczmarzState, normalize,
+                                SystemMatrixBasedNormalization, done
 
 const V{T} = Union{RLSVector{T}, RLSVector{Complex{T}}}
 
@@ -103,6 +108,224 @@ function iterate(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
   check(state.x.ctx, ccall((:rls_cgnr_step, librls[]), Int32, (Ptr{Cvoid}, Int32), plan, 1), "rls_cgnr_step")
   state.iteration += 1
   return state.x, state
+end
+
+# ---- fused FISTA: init! + iterate on device state (src/FISTA.jl:110-129, :139-185) ---------------------------
+const RLS_REG_NONE = Int32(0); const RLS_REG_L1 = Int32(1); const RLS_REG_L2 = Int32(2); const RLS_REG_L21 = Int32(3); const RLS_REG_TV = Int32(4)
+const RLS_PROJ_NONE = Int32(0); const RLS_PROJ_REAL = Int32(1); const RLS_PROJ_POSITIVE = Int32(2)
+
+"(reg_kind, slices) of the elementwise updates the fused kernels apply, or nothing (nested / other terms)"
+fused_reg(r::L1Regularization) = (RLS_REG_L1, 1)
+fused_reg(r::L2Regularization) = (RLS_REG_L2, 1)
+fused_reg(r::L21Regularization) = (RLS_REG_L21, r.slices)
+fused_reg(r) = nothing
+function fused_proj(projs)
+  isempty(projs) && return RLS_PROJ_NONE
+  length(projs) == 1 || return nothing
+  projs[1] isa PositiveRegularization && return RLS_PROJ_POSITIVE
+  projs[1] isa RealRegularization && return RLS_PROJ_REAL
+  nothing
+end
+"the operator handle behind A / AHA when the solver sits on this backend's types (matrix-free or explicit Gram)"
+function operator_of(A, AHA)
+  A isa RLSMatrix && AHA isa RLSNormalOp && AHA.A === A && return A.op
+  nothing
+end
+
+const fista_plans = IdDict{Any,Ptr{Cvoid}}()   # state => rls_fista plan
+
+struct FistaStatus
+  iteration::Int32; done::Int32; theta::Float32; theta_old::Float32; rel_res_norm::Float32; residual::Float32; norm_x0::Float32
+end
+
+function fista_plan_for(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT}
+  haskey(fista_plans, state) && return fista_plans[state]
+  op = operator_of(solver.A, solver.AHA)
+  (op === nothing || fused_reg(solver.reg) === nothing || fused_proj(solver.proj) === nothing) && return C_NULL
+  p = Ref{Ptr{Cvoid}}(C_NULL)
+  check(state.x.ctx, ccall((:rls_fista_create, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                           op, state.x.ptr, state.x₀.ptr, state.xᵒˡᵈ.ptr, state.res.ptr, p), "rls_fista_create")
+  finalizer(_ -> ccall((:rls_fista_destroy, librls[]), Int32, (Ptr{Cvoid},), p[]), state)
+  fista_plans[state] = p[]
+end
+
+function fista_status(state, plan)
+  st = Ref{FistaStatus}()
+  check(state.x.ctx, ccall((:rls_fista_get_status, librls[]), Int32, (Ptr{Cvoid}, Ref{FistaStatus}), plan, st), "rls_fista_get_status")
+  st[]
+end
+
+function init!(solver::FISTA, state::FISTAState{rT,vecT}, b::vecT; x0 = 0, theta = 1) where {rT,vecT<:RLSVector}
+  plan = fista_plan_for(solver, state)
+  # (configurations the fused kernels do not cover run the reference's own method.  `invoke` needs a signature that
+  #  only the generic method matches: V ranges over every vector type, so this method -- V <: RLSVector -- is not it)
+  plan == C_NULL && return invoke(init!, Tuple{FISTA,FISTAState{rT,V},V} where {V<:Union{AbstractVector{rT},AbstractVector{Complex{rT}}}},
+                                  solver, state, b; x0, theta)
+  ctx = state.x.ctx
+  if !(solver.normalizeReg isa NoNormalization)      # the normalisation factor needs x0 = A'b before lambda is fixed (:128)
+    mul!(state.x₀, adjoint(solver.A), b)
+    solver.reg = normalize(solver, solver.normalizeReg, solver.reg, solver.A, state.x₀)
+  end
+  kind, slices = fused_reg(solver.reg)
+  check(ctx, ccall((:rls_fista_set_reg, librls[]), Int32, (Ptr{Cvoid}, Int32, Float32, Int64, Int32),
+                   plan, kind, Float32(λ(solver.reg)), slices, fused_proj(solver.proj)), "rls_fista_set_reg")
+  check(ctx, ccall((:rls_fista_init, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32, Int32, Int32),
+                   plan, b.ptr, state.ρ, Float32(theta), state.relTol, solver.iterations, solver.restart == :gradient), "rls_fista_init")
+  if !all(x0 .== 0)                                   # warm start: state.x .= x0 (:120), scalar or vector
+    xs = x0 isa RLSVector ? x0 : fill!(similar(state.x), x0)
+    length(xs) == length(state.x) || throw(DimensionMismatch("x0 has length $(length(xs)), the solution $(length(state.x))"))
+    check(ctx, ccall((:rls_fista_set_start, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), plan, xs.ptr, length(xs)), "rls_fista_set_start")
+  end
+  st = fista_status(state, plan)
+  state.iteration = 0; state.norm_x₀ = st.norm_x0; state.theta = theta; state.thetaᵒˡᵈ = theta; state.rel_res_norm = rT(Inf)
+  nothing
+end
+
+"host-side scalars and the x / xold roles after the device has advanced"
+function fista_refresh!(state, plan)
+  st = fista_status(state, plan)
+  state.iteration = st.iteration; state.theta = st.theta; state.thetaᵒˡᵈ = st.theta_old
+  st.iteration > 0 && (state.rel_res_norm = st.rel_res_norm)
+  sol = Ref{Ptr{Cvoid}}(C_NULL)                        # the plan swaps x / xold by pointer, as :144-146 does
+  check(state.x.ctx, ccall((:rls_fista_solution, librls[]), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), plan, sol), "rls_fista_solution")
+  if state.x.ptr != sol[]
+    state.x, state.xᵒˡᵈ = state.xᵒˡᵈ, state.x
+  end
+  st
+end
+
+function iterate(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT}
+  plan = get(fista_plans, state, C_NULL)
+  plan == C_NULL && return invoke(iterate, Tuple{FISTA,FISTAState}, solver, state)
+  done(solver, state) && return nothing
+  check(state.x.ctx, ccall((:rls_fista_step, librls[]), Int32, (Ptr{Cvoid}, Int32), plan, 1), "rls_fista_step")
+  fista_refresh!(state, plan)
+  solver.verbose && println("Iteration $(state.iteration); rel. residual = $(state.rel_res_norm)")
+  return state.x, state
+end
+
+# ---- fused ADMM: whole outer iterations as a device plan (src/ADMM.jl:191-220, :230-322) -----------------------
+struct AdmmParams
+  x::Ptr{Cvoid}; xold::Ptr{Cvoid}; beta::Ptr{Cvoid}; beta_y::Ptr{Cvoid}; z0::Ptr{Cvoid}; z1::Ptr{Cvoid}; u::Ptr{Cvoid}
+  rho::Float32; sigma_abs::Float32; rel_tol::Float32
+  iterations::Int32; iterations_cg::Int32
+  tol_inner::Float32
+  reg_kind::Int32
+  prox_lambda::Float32
+  proj_kind::Int32
+  tv_ndims::Int32; tv_ntv::Int32; tv_iterations::Int32
+  tv_dims::NTuple{4,Int32}
+  tv_shape::NTuple{4,Int64}
+end
+struct AdmmStatus
+  iteration::Int32; done::Int32; rk::Float32; sk::Float32; eps_pri::Float32; eps_dua::Float32; delta::Float32; cg_iterations::Int32
+end
+
+const admm_plans = IdDict{Any,Any}()   # state => (cg plan, admm plan, z buffers)
+
+admm_reg(r::L1Regularization) = RLS_REG_L1
+admm_reg(r::L2Regularization) = RLS_REG_L2
+admm_reg(r::TVRegularization) = length(r.shape) <= 4 ? RLS_REG_TV : nothing
+admm_reg(r) = nothing
+"regTrafo == identity (the constructor default opEye, src/ADMM.jl:84), probed through the public `*` only: Phi * (A'b) == A'b"
+function is_identity_trafo(op, probe::RLSVector)
+  size(op) == (length(probe), length(probe)) || return false
+  t = op * probe
+  t isa RLSVector && norm(t .- probe) == 0
+end
+
+function admm_fusable(solver::ADMM, state)
+  length(solver.reg) == 1 && solver.vary_ρ == :none && operator_of(solver.A, solver.AHA) !== nothing &&
+    admm_reg(solver.reg[1]) !== nothing && fused_proj(solver.proj) !== nothing &&
+    !(solver.reg[1] isa TVRegularization && !isempty(solver.proj)) &&
+    is_identity_trafo(solver.regTrafo[1], state.β_y)      # beta_y = A'b is set by the reference's init! just before
+end
+
+function admm_plan_for(solver::ADMM, state::ADMMState)
+  haskey(admm_plans, state) && return admm_plans[state]
+  admm_fusable(solver, state) || return nothing
+  ctx = state.x.ctx
+  cg = Ref{Ptr{Cvoid}}(C_NULL); pl = Ref{Ptr{Cvoid}}(C_NULL)
+  sv = state.cgStateVars                               # CGStateVariables(u, r, c)   src/ADMM.jl:129
+  check(ctx, ccall((:rls_cg_create, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                   operator_of(solver.A, solver.AHA), sv.u.ptr, sv.r.ptr, sv.c.ptr, cg), "rls_cg_create")
+  check(ctx, ccall((:rls_admm_create, librls[]), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), cg[], pl), "rls_admm_create")
+  finalizer(state) do _
+    ccall((:rls_admm_destroy, librls[]), Int32, (Ptr{Cvoid},), pl[])
+    ccall((:rls_cg_destroy, librls[]), Int32, (Ptr{Cvoid},), cg[])
+  end
+  admm_plans[state] = (cg = cg[], plan = pl[], zbuf = (state.z[1], state.zᵒˡᵈ[1]))
+end
+
+function init!(solver::ADMM, state::ADMMState{rT,rvecT,vecT}, b::vecT; x0 = 0) where {rT,rvecT,vecT<:RLSVector}
+  # the reference's own init! (:191-220), selected by a signature this method does not match (see the FISTA init! above)
+  invoke(init!, Tuple{ADMM,ADMMState{rT,rvecT,V},V} where {V<:Union{AbstractVector{rT},AbstractVector{Complex{rT}}}}, solver, state, b; x0)
+  P = admm_plan_for(solver, state)
+  P === nothing && return nothing
+  reg = solver.reg[1]
+  ρ = Float32(state.ρ[1])
+  tv = reg isa TVRegularization
+  nd = tv ? length(reg.shape) : 0
+  dims = tv ? collect(Int32, reg.dims isa Integer ? (reg.dims,) : reg.dims) .- Int32(1) : Int32[]
+  pad4(v, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), 4)
+  prm = AdmmParams(state.x.ptr, state.xᵒˡᵈ.ptr, state.β.ptr, state.β_y.ptr, P.zbuf[1].ptr, P.zbuf[2].ptr, state.u[1].ptr,
+                   ρ, state.σᵃᵇˢ, state.relTol, solver.iterations, solver.iterationsCG, state.tolInner,
+                   ρ == 0 ? RLS_REG_NONE : admm_reg(reg), ρ == 0 ? 0f0 : Float32(λ(reg)) / (2f0 * ρ), fused_proj(solver.proj),
+                   nd, length(dims), tv ? reg.params.iterationsTV : 0, pad4(dims, Int32), pad4(tv ? collect(reg.shape) : Int[], Int64))
+  st = ccall((:rls_admm_init, librls[]), Int32, (Ptr{Cvoid}, Ref{AdmmParams}), P.plan, prm)
+  if st == -2                                           # RLS_E_UNSUPPORTED: this regulariser runs through the generic iterate
+    delete!(admm_plans, state); admm_plans[state] = nothing
+  else
+    check(state.x.ctx, st, "rls_admm_init")
+  end
+  nothing
+end
+
+function iterate(solver::ADMM, state::ADMMState{rT,rvecT,<:RLSVector}) where {rT,rvecT}
+  P = get(admm_plans, state, nothing)
+  P === nothing && return invoke(iterate, Tuple{ADMM,ADMMState}, solver, state)
+  done(solver, state) && return nothing
+  check(state.x.ctx, ccall((:rls_admm_step, librls[]), Int32, (Ptr{Cvoid}, Int32), P.plan, 1), "rls_admm_step")
+  admm_refresh!(state, P)
+  return state.x, state
+end
+
+function admm_refresh!(state, P)
+  st = Ref{AdmmStatus}()
+  check(state.x.ctx, ccall((:rls_admm_get_status, librls[]), Int32, (Ptr{Cvoid}, Ref{AdmmStatus}, Ptr{Cvoid}, Int32), P.plan, st, C_NULL, 0), "rls_admm_get_status")
+  state.iteration = st[].iteration
+  if st[].iteration > 0
+    state.rᵏ[1] = st[].rk; state.sᵏ[1] = st[].sk; state.ɛᵖʳⁱ[1] = st[].eps_pri; state.ɛᵈᵘᵃ[1] = st[].eps_dua; state.Δ[1] = st[].delta
+  end
+  cur = isodd(state.iteration) ? 2 : 1                  # z alternates between the two buffers, as the swap of :252-254
+  state.z[1], state.zᵒˡᵈ[1] = P.zbuf[cur], P.zbuf[3 - cur]
+  st[]
+end
+
+# ---- whole solves without a read-back per iteration ----------------------------------------------------------
+"""
+    solve_fused!(solver, b)
+
+`init!` followed by ALL iterations enqueued in one call (`rls_*_step(plan, iterations)`: the device stops at the
+iteration where `done` holds, exactly as the iterate-by-iterate loop of `solve!` does) and one status read-back.
+For callers that do not register callbacks; `solve!` itself stays the reference's loop.
+"""
+function RLSMI355X.solve_fused!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector)
+  init!(solver, b)
+  state = solver.state
+  if solver isa CGNR
+    check(b.ctx, ccall((:rls_cgnr_step, librls[]), Int32, (Ptr{Cvoid}, Int32), plan_for(solver, state), solver.iterations), "rls_cgnr_step")
+    iterate(solver, state)   # reads the status first: refreshes the host-side scalars, applies `constr`, returns nothing (done)
+  elseif solver isa FISTA && get(fista_plans, state, C_NULL) != C_NULL
+    check(b.ctx, ccall((:rls_fista_step, librls[]), Int32, (Ptr{Cvoid}, Int32), fista_plans[state], solver.iterations), "rls_fista_step")
+    fista_refresh!(state, fista_plans[state])
+  elseif solver isa ADMM && get(admm_plans, state, nothing) !== nothing
+    check(b.ctx, ccall((:rls_admm_step, librls[]), Int32, (Ptr{Cvoid}, Int32), admm_plans[state].plan, solver.iterations), "rls_admm_step")
+    admm_refresh!(state, admm_plans[state])
+  else
+    while iterate(solver, state) !== nothing end
+  end
+  return solver.state.x
 end
 
 # ---- setup path: SystemMatrixBasedNormalization (ext/RegularizedLeastSquaresGPUArraysExt/NormalizedRegularization.jl:1-5)

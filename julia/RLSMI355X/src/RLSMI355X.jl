@@ -3,8 +3,8 @@
 # GPU extensions do (ext/RegularizedLeastSquaresGPUArraysExt/*.jl, loading mechanism Project.toml:20-27).
 #
 # This file cannot be executed in the build container (no Julia); it is kept in lock-step with the
-# Python harness (regularizedleastsquares.jl_amd/*.py), which issues exactly the same ABI call
-# sequences and is what the parity tests run.
+# Python harness (regularizedleastsquares.jl_amd/*.py) and the plain-C driver tests/abi_smoke.c, which issue
+# exactly the same ABI call sequences and are what the parity tests run.
 module RLSMI355X
 
 using LinearAlgebra, Libdl
@@ -105,6 +105,109 @@ function axpy!(a::Number, x::RLSVector{T}, y::RLSVector{T}) where {T}
   y
 end
 
+"z = a x + b y (z may alias x or y): the two-vector form every fused broadcast of the solver loops reduces to"
+function lincomb!(z::RLSVector{T}, a::Number, x::RLSVector{T}, b::Number, y::RLSVector{T}) where {T}
+  za, zb = ComplexF32(a), ComplexF32(b)
+  check(z.ctx, ccall((:rls_lincomb, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Float32, Float32, Ptr{Cvoid}, Float32, Float32, Ptr{Cvoid}, Ptr{Cvoid}),
+                     z.ctx.handle, dtypecode(T), z.n, real(za), imag(za), x.ptr, real(zb), imag(zb), y.ptr, z.ptr), "rls_lincomb")
+  z
+end
+"y = a x + b y"
+function axpby!(a::Number, x::RLSVector{T}, b::Number, y::RLSVector{T}) where {T}
+  za, zb = ComplexF32(a), ComplexF32(b)
+  check(y.ctx, ccall((:rls_axpby, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Float32, Float32, Ptr{Cvoid}, Float32, Float32, Ptr{Cvoid}),
+                     y.ctx.handle, dtypecode(T), y.n, real(za), imag(za), x.ptr, real(zb), imag(zb), y.ptr), "rls_axpby")
+  y
+end
+Base.zero(v::RLSVector{T}) where {T} = fill!(similar(v), zero(T))          # CGStateVariables(zero(x), ...) src/ADMM.jl:129
+Base.copy(v::RLSVector{T}) where {T} = copyto!(similar(v), v)
+Base.dotview(v::RLSVector, ::Colon) = v                                     # state.res[:] .= Inf     src/FISTA.jl:123
+
+# ---- broadcasting -----------------------------------------------------------------------------------
+# The unchanged solver loops update their state with fused broadcasts -- `v .= w`, `v .= 0`, `v .*= c`, `v .+= c .* w`,
+# `v .-= w`, `v .-= rho .* w`, `x .- xold`, `xold .= x .- xold` (src/CGNR.jl:163-174, src/FISTA.jl:147-154,172,
+# src/ADMM.jl:236,243,259-267,282-284; IterativeSolvers.cg! uses the same shapes).  Every one of them is a LINEAR
+# COMBINATION of device vectors with scalar coefficients, so a lazy Broadcasted tree is read off as a list of
+# (coefficient, vector) terms and evaluated with rls_scal / rls_axpy / rls_axpby / rls_lincomb: no scalar indexing,
+# one or two launches per statement.  Anything that is not such a combination raises (use Array(v)).
+struct RLSStyle <: Broadcast.AbstractArrayStyle{1} end
+RLSStyle(::Val{N}) where {N} = RLSStyle()
+Base.BroadcastStyle(::Type{<:RLSVector}) = RLSStyle()
+
+isscalar(x) = x isa Number || (x isa Base.RefValue && x[] isa Number)
+scalar(x) = x isa Base.RefValue ? x[] : x
+unsupported(bc) = error("broadcast over an RLSVector that is not a linear combination of device vectors: $(bc.f); use Array(v)")
+
+terms(v::RLSVector, s) = Any[(ComplexF32(s), v)]
+terms(x, s) = error("broadcast over an RLSVector with a $(typeof(x)) operand; device vectors and scalars only")
+function terms(bc::Broadcast.Broadcasted, s)
+  f, a = bc.f, bc.args
+  if f === identity && length(a) == 1
+    return terms(a[1], s)
+  elseif f === +
+    return reduce(vcat, [terms(x, s) for x in a])
+  elseif f === - && length(a) == 1
+    return terms(a[1], -s)
+  elseif f === - && length(a) == 2
+    return vcat(terms(a[1], s), terms(a[2], -s))
+  elseif f === * && length(a) == 2 && isscalar(a[1])
+    return terms(a[2], s * scalar(a[1]))
+  elseif f === * && length(a) == 2 && isscalar(a[2])
+    return terms(a[1], s * scalar(a[2]))
+  elseif f === / && length(a) == 2 && isscalar(a[2])
+    return terms(a[1], s / scalar(a[2]))
+  end
+  unsupported(bc)
+end
+
+firstvector(v::RLSVector) = v
+firstvector(x) = nothing
+function firstvector(bc::Broadcast.Broadcasted)
+  for x in bc.args
+    v = firstvector(x)
+    v === nothing || return v
+  end
+  nothing
+end
+function Base.similar(bc::Broadcast.Broadcasted{RLSStyle}, ::Type{T}) where {T}
+  v = firstvector(bc)
+  RLSVector{T}(undef, length(axes(bc)[1]); ctx = v.ctx)
+end
+
+"dest = sum of the terms; terms that refer to dest itself are its own coefficient"
+function evaluate!(dest::RLSVector{T}, ts) where {T}
+  cd = ComplexF32(0)
+  others = Any[]
+  for (c, v) in ts
+    length(v) == length(dest) || throw(DimensionMismatch("broadcast over device vectors of lengths $(length(v)) and $(length(dest))"))
+    if v === dest
+      cd += c
+    else
+      k = findfirst(t -> t[2] === v, others)
+      k === nothing ? push!(others, (c, v)) : (others[k] = (others[k][1] + c, v))
+    end
+  end
+  if isempty(others)
+    cd == 1 || (cd == 0 ? fill!(dest, 0) : rmul!(dest, cd))
+    return dest
+  end
+  if length(others) >= 2 && cd == 0                # z = a x + b y
+    lincomb!(dest, others[1][1], others[1][2], others[2][1], others[2][2])
+    rest = others[3:end]
+  else                                             # y = a x + cd y
+    cd == 1 ? axpy!(others[1][1], others[1][2], dest) : axpby!(others[1][1], others[1][2], cd, dest)
+    rest = others[2:end]
+  end
+  for (c, v) in rest
+    axpy!(c, v, dest)
+  end
+  dest
+end
+
+Base.copyto!(dest::RLSVector, bc::Broadcast.Broadcasted{RLSStyle}) = evaluate!(dest, terms(bc, 1f0))
+# `v .= 0`, `v .= x0` with a scalar x0, `res[:] .= Inf`
+Base.copyto!(dest::RLSVector, bc::Broadcast.Broadcasted{<:Broadcast.AbstractArrayStyle{0}}) = fill!(dest, bc[])
+
 # ---- dense operator: the type of A --------------------------------------------------------------
 mutable struct RLSMatrix{T} <: AbstractMatrix{T}
   ptr::Ptr{Cvoid}
@@ -154,5 +257,8 @@ function LinearAlgebra.mul!(v::RLSVector{T}, N::RLSNormalOp{T}, p::RLSVector{T})
   check(N.A.ctx, ccall((:rls_operator_mul_normal, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), N.A.op, p.ptr, v.ptr), "rls_operator_mul_normal")
   v
 end
+
+"whole solve in one enqueue; methods are added by the RegularizedLeastSquares extension"
+function solve_fused! end
 
 end # module

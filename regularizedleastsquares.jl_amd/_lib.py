@@ -140,7 +140,7 @@ PROTOTYPES = {
     "rls_fista_destroy": (_i32, [_vp]),
     "rls_fista_set_reg": (_i32, [_vp, _i32, _f, _i64, _i32]),
     "rls_fista_init": (_i32, [_vp, _vp, _f, _f, _f, _i32, _i32]),
-    "rls_fista_set_start": (_i32, [_vp, _vp]),
+    "rls_fista_set_start": (_i32, [_vp, _vp, C.c_int64]),
     "rls_fista_step": (_i32, [_vp, _i32]),
     "rls_fista_path": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "rls_fista_get_status": (_i32, [_vp, C.POINTER(FistaStatus)]),

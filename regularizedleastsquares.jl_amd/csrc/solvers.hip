@@ -492,6 +492,7 @@ struct rls_fista {
   fista_scalars* scb_h = nullptr;  // pinned [nrhs]
   int enq = 0;           // iterations enqueued since init (== the device's count unless the plan stopped early)
   int graph_parity = 0;  // parity of `enq` the cached graph's buffer hints were captured with
+  float theta0 = 1.f;    // theta given to the last init (rls_fista_set_start needs it)
   // resident mode (normal.hip, fista_resident_kernel)
   void* rsync = nullptr;
   unsigned* rsync_h = nullptr;
@@ -2094,6 +2095,7 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
                        (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
   s->enq = 0;
+  s->theta0 = theta;
   s->initialised = true;
   // row-sharded plans exchange `res` between the operator apply and the update: two-half iterations only
   const bool gram = !local && fista_gram_ok(s);
@@ -2240,17 +2242,20 @@ int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out) {
   return 0;
 }
 
-int32_t rls_fista_set_start(rls_fista* s, const void* x_init) {
+int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n) {
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_set_start before fista_init");
   if (!x_init) return rls_fail(ctx, RLS_E_INVALID, "fista_set_start: null pointer");
+  if (n != s->op->N) return rls_fail(ctx, RLS_E_INVALID, "fista_set_start: x_init must have the solution's length N");
+  if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista_set_start on a batched plan");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)s->op->N * rls_elem_size(s->op->dtype);
-  // iteration 0: state.x == buf[0]; the first extrapolated point is 0*xold + 1*x == x
+  // iteration 0: state.x == buf[0], xold == 0; the first extrapolated point (src/FISTA.jl:147-148 with
+  // thetaold == theta) is ((theta - 1) / theta + 1) x0 -- x0 itself only for the default theta = 1
   RLS_HIP(ctx, hipMemcpyAsync(s->buf[0], x_init, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  RLS_HIP(ctx, hipMemcpyAsync(s->y, x_init, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  return 0;
+  const float c2 = (s->theta0 - 1.f) / s->theta0 + 1.f;
+  return rls_lincomb(ctx, s->op->dtype, n, c2, 0.f, x_init, 0.f, 0.f, x_init, s->y);
 }
 
 static bool fista_use_resident(const rls_fista* s);

@@ -379,9 +379,16 @@ class FISTA(AbstractProximalGradientSolver):
             check(h, lib.rls_fista_set_reg(state._plan, kind, lam_, slices, pk), "rls_fista_set_reg")
             check(h, lib.rls_fista_init(state._plan, b.ptr, state.rho, float(theta), state.relTol, self.iterations,
                                         1 if self.restart == "gradient" else 0), "rls_fista_init")
-            if not (np.isscalar(x0) and x0 == 0):
-                xs = x0 if isinstance(x0, DeviceVector) else DeviceVector.from_host(np.asarray(x0, dtype=b.dtype), b.ctx)
-                check(h, lib.rls_fista_set_start(state._plan, xs.ptr), "rls_fista_set_start")
+            if not (np.ndim(x0) == 0 and not isinstance(x0, DeviceVector) and x0 == 0):
+                if isinstance(x0, DeviceVector):
+                    xs = x0
+                elif np.ndim(x0) == 0:   # `state.x .= x0` broadcasts a scalar (src/FISTA.jl:120)
+                    xs = DeviceVector.from_host(np.full(N, x0, dtype=b.dtype), b.ctx)
+                else:
+                    xs = DeviceVector.from_host(np.ascontiguousarray(np.asarray(x0, dtype=b.dtype).reshape(-1)), b.ctx)
+                if xs.n != N or xs.dtype != b.dtype:
+                    raise ValueError(f"DimensionMismatch: x0 has length {xs.n} ({xs.dtype}), the solution {N} ({b.dtype})")
+                check(h, lib.rls_fista_set_start(state._plan, xs.ptr, xs.n), "rls_fista_set_start")
         else:
             # generic path from primitives (TV prox etc.)
             if self.A is None:
@@ -1729,7 +1736,12 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
         solver.init_(solver.state, b, **kw)  # all columns in one launch, one workgroup per column
         return
     if scheduler is BatchedState:
-        if (isinstance(solver, CGNR) and isinstance(b, DeviceMatrix) and b.N > 1 and not solver.constr
+        # the shared-A plans cover only the keyword arguments listed here; anything else (a warm start x0, ...) goes to
+        # the per-column path below, which forwards **kw to the solver's own init_ (and raises what it does not support)
+        kw_cgnr_ok = all(k == "x0" and np.ndim(v) == 0 and v == 0 for k, v in kw.items())
+        kw_fista_ok = all((k == "theta") or (k == "x0" and np.ndim(v) == 0 and not isinstance(v, DeviceVector) and v == 0)
+                          for k, v in kw.items())
+        if (isinstance(solver, CGNR) and isinstance(b, DeviceMatrix) and b.N > 1 and not solver.constr and kw_cgnr_ok
                 and not isinstance(solver.normalizeReg, MeasurementBasedNormalization)):  # per-column lambda: not batched
             try:
                 st = BatchedState(solver, b)
@@ -1745,7 +1757,7 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
                 pass  # shape not covered by the one-pass kernel: independent per-column plans instead
         if (type(solver) is FISTA and isinstance(b, DeviceMatrix) and b.N > 1 and solver.A is not None
                 and solver._fused_kinds() is not None and not isinstance(solver.normalizeReg, MeasurementBasedNormalization)
-                and "x0" not in kw):
+                and kw_fista_ok):
             try:
                 st = FistaBatchedState(solver, b)
                 lib, h = b.ctx.lib, b.ctx.handle

@@ -2064,3 +2064,28 @@ def test_plain_c_program_drives_the_abi(rls, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_smoke OK" in out.stdout and "row-sharded CGNR, 4 rank(s)" in out.stdout
+
+
+@pytest.mark.parametrize("theta", [1.0, 1.7])
+def test_fista_warm_start_scalar_vector_and_theta(rls, ctx, theta):
+    """init!(solver, b; x0, theta) (src/FISTA.jl:110-129): a scalar x0 is broadcast (`state.x .= x0`), a vector x0 is
+    copied, the first extrapolated point is ((theta - 1) / theta + 1) x0, a wrong length is a DimensionMismatch"""
+    A, xt, b = O.make_problem(192, 64, np.complex64, 91)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    rho = 0.9 / np.linalg.norm(A64, 2) ** 2
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    rng = np.random.default_rng(3)
+    xv = (rng.standard_normal(64) + 1j * rng.standard_normal(64)).astype(np.complex64)
+    for x0 in (0.25, xv):
+        ref = O.FISTA(A64, reg=O.L1Regularization(0.02), rho=rho, iterations=12)
+        ref.init(b64, x0=x0 if np.ndim(x0) == 0 else x0.astype(np.complex128), theta=theta)
+        while ref.iterate() is not None:
+            pass
+        sol = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(0.02), rho=rho, iterations=12)
+        rls.init_(sol, bd, x0=x0, theta=theta)
+        while rls.iterate(sol) is not None:
+            pass
+        parity(f"fista_warm_start_theta{theta}_{'scalar' if np.ndim(x0) == 0 else 'vector'}", sol.state.x.to_host(), ref.x,
+               None, record=False)
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        rls.init_(sol, bd, x0=xv[:10])
