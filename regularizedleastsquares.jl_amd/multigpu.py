@@ -30,6 +30,7 @@ import numpy as np
 
 from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, CgnrStatus, CgStatus,
                    FistaStatus, check)
+from .arrays import Context
 
 
 # --------------------------------------------------------------------------------------------
@@ -195,6 +196,95 @@ class RowShardedCGNR:
         # steps past it are no-ops on the device, and the collective count stays matched
         self.step(min(self.iterations, self.ops.tensor("x").shape[0]))
         return self.ops.solution()
+
+
+class _BorrowedContext(Context):
+    """a Context object around an rls_ctx the communicator owns (never destroyed from here)"""
+
+    def __init__(self, lib, handle, device):  # noqa: super().__init__ would create a new rls_ctx
+        self.lib, self.handle, self.device = lib, handle, device
+
+    def close(self):
+        self.handle = None
+
+
+COMM_AUTO, COMM_RCCL, COMM_DIRECT = 0, 1, 2
+
+
+class CommRowShardedCGNR:
+    """Config 5 driven from ONE host process through the library's own communicator (include/rls_mi355x.h:
+    rls_comm_create, rls_cgnr_init_rowsharded, rls_cgnr_step_rowsharded): rank r owns a context, its row shard of A
+    (repacked contiguous) and a CGNR plan; the all-reduce of A^H t runs inside the library (RCCL between distinct
+    devices, the one-shot direct-write transport when ranks share a device -- the emulation of an 8-GPU node on one
+    GPU).  This is the call sequence the Julia host issues (one process, one task per GPU)."""
+
+    def __init__(self, rls, shards, devices=None, transport=COMM_AUTO, lam=0.0, iterations=10,
+                 relTol=float(np.finfo(np.float32).eps)):
+        self.rls = rls
+        lib = rls.load()
+        n = len(shards)
+        devices = list(devices) if devices is not None else [0] * n
+        devs = (C.c_int32 * n)(*devices)
+        comm = C.c_void_p()
+        st = lib.rls_comm_create(n, devs, None, int(transport), C.byref(comm))
+        if st != 0:
+            raise rls.RLSError(f"rls_comm_create failed with status {st}")
+        self.lib, self.comm, self.n = lib, comm, n
+        self.lam, self.iterations, self.relTol = float(lam), int(iterations), float(relTol)
+        self.ctxs, self.A, self.ops, self.vecs, self.plans = [], [], [], [], []
+        for r in range(n):
+            h = C.c_void_p()
+            check(None, lib.rls_comm_ctx(comm, r, C.byref(h)), "rls_comm_ctx")
+            ctx = _BorrowedContext(lib, h, devices[r])
+            Ar = rls.DeviceMatrix.from_host(np.asfortranarray(shards[r]), ctx)
+            op = rls.OperatorHandle(Ar)
+            v = [rls.DeviceVector(Ar.N, Ar.dtype, ctx) for _ in range(4)]  # x, r, p, v
+            plan = C.c_void_p()
+            check(h, lib.rls_cgnr_create(op.handle, v[0].ptr, v[1].ptr, v[2].ptr, v[3].ptr, C.byref(plan)), "rls_cgnr_create")
+            self.ctxs.append(ctx); self.A.append(Ar); self.ops.append(op); self.vecs.append(v); self.plans.append(plan)
+        self._plans_c = (C.c_void_p * n)(*[p.value for p in self.plans])
+        self._b = None
+
+    @property
+    def transport(self):
+        return self.lib.rls_comm_transport(self.comm)
+
+    def init(self, b_parts):
+        self._b = [self.rls.DeviceVector.from_host(np.ascontiguousarray(bp), c) for bp, c in zip(b_parts, self.ctxs)]
+        ptrs = (C.c_void_p * self.n)(*[b.ptr for b in self._b])
+        check(self.ctxs[0].handle, self.lib.rls_cgnr_init_rowsharded(self.comm, self._plans_c, ptrs, self.lam, self.relTol, self.iterations),
+              "rls_cgnr_init_rowsharded")
+
+    def step(self, n=1):
+        check(self.ctxs[0].handle, self.lib.rls_cgnr_step_rowsharded(self.comm, self._plans_c, int(n)), "rls_cgnr_step_rowsharded")
+
+    def sync(self):
+        check(self.ctxs[0].handle, self.lib.rls_comm_sync(self.comm), "rls_comm_sync")
+
+    def solution(self, rank=0) -> np.ndarray:
+        self.sync()
+        return self.vecs[rank][0].to_host()
+
+    def status(self, rank=0):
+        st = CgnrStatus()
+        check(self.ctxs[rank].handle, self.lib.rls_cgnr_get_status(self.plans[rank], C.byref(st)), "rls_cgnr_get_status")
+        return {"iteration": st.iteration, "done": bool(st.done), "residual": st.residual, "z0": st.z0}
+
+    def solve(self, b_parts):
+        self.init(b_parts)
+        self.step(min(self.iterations, self.A[0].N))
+        return self.solution()
+
+    def close(self):
+        if self.comm:
+            self.sync()
+            for p in self.plans:
+                self.lib.rls_cgnr_destroy(p)
+            self.plans, self._b, self.vecs, self.ops, self.A = [], None, [], [], []
+            self.lib.rls_comm_destroy(self.comm)
+            self.comm = None
+            for c in self.ctxs:
+                c.close()
 
 
 # --------------------------------------------------------------------------------------------

@@ -2089,3 +2089,31 @@ def test_fista_warm_start_scalar_vector_and_theta(rls, ctx, theta):
                None, record=False)
     with pytest.raises(ValueError, match="DimensionMismatch"):
         rls.init_(sol, bd, x0=xv[:10])
+
+
+@pytest.mark.parametrize("nshards", [2, 8])
+def test_config5_schedule_through_the_library_communicator(rls, ctx, nshards):
+    """BASELINE config 5's collective schedule on one GPU: `nshards` row shards of one tall complex A, one context
+    (= one stream) and one CGNR plan per shard, the all-reduce of A^H t inside the library (rls_allreduce_sum, direct
+    transport: ranks share the device).  Replicated state bit-identical on every rank, solution within the gate of the
+    unsharded float64 oracle, same iteration count; unequal shards included"""
+    M, N = 2048 + 64 * nshards, 512
+    A, xt, b = O.make_problem(M, N, np.complex64, 97)
+    cuts = [0] + [int(M * (k + 1) / nshards) // 4 * 4 for k in range(nshards - 1)] + [M]
+    cuts[1] += 8  # unequal shards
+    shards = [np.asfortranarray(A[cuts[k]:cuts[k + 1]]) for k in range(nshards)]
+    parts = [b[cuts[k]:cuts[k + 1]] for k in range(nshards)]
+    s = rls.CommRowShardedCGNR(rls, shards, transport=2, lam=1e-3, iterations=16, relTol=0.0)
+    try:
+        assert s.transport == 2
+        x = s.solve(parts)
+        xs = [s.solution(r) for r in range(nshards)]
+        assert all(np.array_equal(xs[0], xr) for xr in xs[1:])
+        assert all(s.status(r)["iteration"] == 16 for r in range(nshards))
+        x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.CGNR(A_, reg=O.L2Regularization(1e-3), iterations=16, relTol=0.0), b_), A, b)
+        parity(f"config5_schedule_{nshards}_shards_one_gpu", x, x64, x32)
+        # a second solve on the same communicator / plans (the double-buffered receive slots keep alternating)
+        x2 = s.solve(parts)
+        assert np.array_equal(x2, x)
+    finally:
+        s.close()
