@@ -12,8 +12,19 @@ M, N = 4096, 2048
 A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
 b = rls.DeviceVector.from_host((A @ np.ones(N, np.complex64)).astype(np.complex64), ctx)
 solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+for _ in range(3):  # resident path: one launch per call of 32 iterations (where the device offers it)
+    rls.init_(solver, b)
+    ctx.lib.rls_cgnr_step(solver.state._plan, 32)
+ctx.sync()
+ctx.tune(resident=0)  # the two-launch pipeline: K_A + K_R per iteration
 rls.init_(solver, b)
 ctx.lib.rls_cgnr_step(solver.state._plan, 6)
+ctx.sync()
+S2 = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2, iterations=32)
+ctx.tune(resident=1)
+for _ in range(3):
+    rls.init_(S2, b)
+    ctx.lib.rls_fista_step(S2.state._plan, 32)
 ctx.sync()
 p = rls.DeviceVector.from_host(np.ones(N, np.complex64), ctx); t = rls.DeviceVector(M, np.complex64, ctx); v = rls.DeviceVector(N, np.complex64, ctx)
 for _ in range(3):
