@@ -328,6 +328,11 @@ typedef struct rls_cg_status {
   float tol;          /* max(reltol * ||r0||, 0)                                                  */
 } rls_cg_status;
 int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out);
+/* batched plan (shared A; solve!(solver::ADMM, B) with the shared-A scheduler, src/MultiThreading.jl:30-79): U, R, C are
+ * N x nrhs scratch matrices, columns ldv elements apart.  Used through rls_admm_create / rls_admm_step, whose params then
+ * point to N x nrhs matrices with the same ldv; every column keeps its own scalars, inner-iteration count and `done`.
+ * RLS_E_UNSUPPORTED unless the operator is matrix-free with M, N multiples of 16. */
+int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, void* C, int64_t ldv, rls_cg** out);
 int32_t rls_cg_destroy(rls_cg* s);
 /* solves (AHA + rho I) x = b starting from x (warm start); asynchronous */
 int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxiter, float reltol);
@@ -379,6 +384,8 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer); /* asynchronous; stops enqu
 /* synchronises; log_h (nullable) receives min(iteration, log_records) records of 8 floats:
  * Delta, sk, eps_pri, rk, eps_dua, inner cg! iterations, 0, 0 */
 int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out_h, float* log_h, int32_t log_records);
+/* batched plans: out_h[nrhs]; log_h (nullable) = nrhs blocks of log_records records, column after column */
+int32_t rls_admm_get_status_batched(rls_admm* a, rls_admm_status* out_h, float* log_h, int32_t log_records);
 
 /* ---------------------------------------------------------------------------------------------
  * device pieces of the nested regularisation terms and of the plug-and-play input transforms

@@ -146,6 +146,7 @@ PROTOTYPES = {
     "rls_fista_get_status": (_i32, [_vp, C.POINTER(FistaStatus)]),
     "rls_fista_solution": (_i32, [_vp, _pvp]),
     "rls_cg_create": (_i32, [_vp, _vp, _vp, _vp, _pvp]),
+    "rls_cg_create_batched": (_i32, [_vp, _i32, _vp, _vp, _vp, C.c_int64, _pvp]),
     "rls_cg_destroy": (_i32, [_vp]),
     "rls_cg_solve": (_i32, [_vp, _vp, _vp, _f, _i32, _f]),
     "rls_cg_get_status": (_i32, [_vp, C.POINTER(CgStatus)]),
@@ -183,6 +184,7 @@ PROTOTYPES = {
     "rls_admm_init": (_i32, [_vp, C.POINTER(AdmmParams)]),
     "rls_admm_step": (_i32, [_vp, _i32]),
     "rls_admm_get_status": (_i32, [_vp, C.POINTER(AdmmStatus), _pf, _i32]),
+    "rls_admm_get_status_batched": (_i32, [_vp, C.POINTER(AdmmStatus), _pf, _i32]),
 }
 
 _lib = None

@@ -278,6 +278,13 @@ class DeviceMatrix:
     def size(self, i: int) -> int:  # 1-based like Julia's size(A, i)
         return (self.M, self.N)[i - 1]
 
+    def fill_(self, value):
+        """A .= value (every stored element, padding rows of lda included)"""
+        value = complex(value)
+        lib, h = self.ctx.lib, self.ctx.handle
+        check(h, lib.rls_fill(h, dtype_code(self.dtype), self.lda * self.N, self.ptr, value.real, value.imag), "rls_fill")
+        return self
+
     def column(self, j: int) -> DeviceVector:
         """b[:, j] (0-based j) as a fresh vector: the reference copies columns (src/MultiThreading.jl:35)"""
         v = DeviceVector(self.M, self.dtype, self.ctx)

@@ -549,7 +549,7 @@ void rls_tv_set_fused_2d(int on);
 bool rls_tv_single_ok(int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims);
 int32_t rls_tv_single_launch(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
                              const int32_t* dims, const void* xin, const void* add, void* out, float lam, int iters,
-                             const int* skip);
+                             const int* skip, int count = 1, int64_t ldv = 0, int skip_stride = 0);
 void rls_normal_force_group(int g);
 void rls_normal_force_waves(int wv);
 void rls_normal_order_mode(int m);

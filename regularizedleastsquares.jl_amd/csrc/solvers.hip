@@ -844,6 +844,13 @@ struct rls_cg {
   // Gram-mode pipeline: second parity of c (= v) and of the partial dots
   void* v1;
   double* gdots;
+  // batched plan (rls_cg_create_batched): nrhs columns ldv elements apart, operand panel + partial rows of the
+  // skinny matrix-core products (skinny.hip); sc / sc_h hold nrhs structs
+  int nrhs = 1;
+  int64_t ldv = 0;
+  float *Ppack = nullptr, *Tpack = nullptr;
+  void* Vpart = nullptr;
+  int splits = 1;
 };
 
 static bool cg_use_gram_pipeline(const rls_cg* s) {
@@ -906,6 +913,34 @@ struct admm_fuse {
   float rho;
   const int* skip;
 };
+// Batched plans (shared A, rls_cg_create_batched): the per-column kernels below run one workgroup per column
+// (blockIdx.x = column, state matrices N x K with leading dimension ldv, one scalar struct per column); the
+// operator apply in front of them is the pair of skinny matrix-core products, which leaves AHA u as S partial rows
+// per column (summed here in a fixed order) and reads its right operand from the MFMA panel the kernels write.
+// All zero = the single-column plans.
+template <typename E>
+struct col_batch {
+  int64_t ldv = 0;
+  const E* Vpart = nullptr;
+  int S = 1, nrhs_pad = 16;
+  E* panel = nullptr;       // operand panel [group][n][16]: column b -> panel + (b >> 4) * n * 16 + (b & 15), stride 16
+  int skip_stride = 0;      // ints between the columns' skip flags
+  int64_t log_stride = 0;   // floats between the columns' ADMM logs
+};
+template <typename E>
+__device__ static inline E col_parts(const col_batch<E>& B, int b, int64_t N, int64_t i) {
+  E v = B.Vpart[(int64_t)b * N + i];
+  for (int s = 1; s < B.S; ++s) v = elem<E>::add(v, B.Vpart[((int64_t)s * B.nrhs_pad + b) * N + i]);
+  return v;
+}
+// X (N x K) -> operand panel, ahead of the warm-start apply AHA x of every outer iteration
+template <typename E>
+__global__ __launch_bounds__(256) void pack_panel_kernel(const E* __restrict__ X, int64_t ldv, E* __restrict__ panel, int64_t n) {
+  const int b = blockIdx.y;
+  E* up = panel + (int64_t)(b >> 4) * n * 16 + (b & 15);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    up[16 * i] = X[(int64_t)b * ldv + i];
+}
 template <typename E>
 __device__ static inline E admm_rhs(const admm_fuse<E>& F, const E* b, const E* x, int64_t i) {
   if (!F.beta_y) return b[i];
@@ -1017,8 +1052,19 @@ template <typename E>
 __global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restrict__ x, const E* b,
                                                                E* __restrict__ u, E* __restrict__ r,
                                                                const E* __restrict__ c, int64_t n, cg_scalars* sc,
-                                                               float rho, float reltol, int maxiter, admm_fuse<E> F) {
+                                                               float rho, float reltol, int maxiter, admm_fuse<E> F,
+                                                               col_batch<E> B) {
   __shared__ double sm[16];
+  const int bq = blockIdx.x;
+  {
+    const int64_t o = (int64_t)bq * B.ldv;
+    x += o; u += o; r += o; c += o;
+    if (b) b += o;
+    if (F.beta_y) { F.beta_y += o; F.z += o; F.u += o; F.beta += o; F.xold += o; }
+    if (F.skip) F.skip += (int64_t)bq * B.skip_stride;
+    sc += bq;
+  }
+  E* up = B.panel ? B.panel + (int64_t)(bq >> 4) * n * 16 + (bq & 15) : nullptr;
   if (F.skip && *F.skip) {
     if (threadIdx.x == 0) {
       sc->iteration = 0;
@@ -1029,10 +1075,12 @@ __global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restri
   }
   double rr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
-    const E ci = elem<E>::add(c[i], elem<E>::scale(rho, x[i]));
+    const E cv = B.Vpart ? col_parts<E>(B, bq, n, i) : c[i];
+    const E ci = elem<E>::add(cv, elem<E>::scale(rho, x[i]));
     const E ri = elem<E>::sub(admm_rhs<E>(F, b, x, i), ci);
     r[i] = ri;
     u[i] = ri;  // first iteration: beta = residual^2 / 1^2 multiplies u == 0
+    if (up) up[16 * i] = ri;
     rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
   }
   rr = block_sum(rr, sm);
@@ -1055,14 +1103,22 @@ __global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restri
 template <typename E>
 __global__ __launch_bounds__(UPD_THREADS) void cg_update_kernel(E* __restrict__ x, E* __restrict__ u,
                                                                 E* __restrict__ r, E* __restrict__ c, int64_t n,
-                                                                cg_scalars* sc) {
+                                                                cg_scalars* sc, col_batch<E> B) {
+  const int bq = blockIdx.x;
+  {
+    const int64_t o = (int64_t)bq * B.ldv;
+    x += o; u += o; r += o; c += o;
+    sc += bq;
+  }
   if (sc->done) return;
+  E* up = B.panel ? B.panel + (int64_t)(bq >> 4) * n * 16 + (bq & 15) : nullptr;
   __shared__ double sm[16];
   const float rho = sc->rho;
   double dre = 0.0, dim_ = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
     const E ui = u[i];
-    const E ci = elem<E>::add(c[i], elem<E>::scale(rho, ui));
+    const E cv = B.Vpart ? col_parts<E>(B, bq, n, i) : c[i];
+    const E ci = elem<E>::add(cv, elem<E>::scale(rho, ui));
     c[i] = ci;
     dre += (double)elem<E>::re(ui) * (double)elem<E>::re(ci) + (double)elem<E>::im(ui) * (double)elem<E>::im(ci);
     if constexpr (elem<E>::cplx)
@@ -1087,7 +1143,11 @@ __global__ __launch_bounds__(UPD_THREADS) void cg_update_kernel(E* __restrict__ 
   const int done = (it >= sc->maxiter) || ((float)residual <= (float)sc->tol);
   if (!done) {
     const float beta = (float)(rr / (res * res));
-    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) u[i] = elem<E>::add(r[i], elem<E>::scale(beta, u[i]));
+    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
+      const E un = elem<E>::add(r[i], elem<E>::scale(beta, u[i]));
+      u[i] = un;
+      if (up) up[16 * i] = un;
+    }
   }
   if (threadIdx.x == 0) {
     sc->prev = res;
@@ -1149,11 +1209,11 @@ __global__ __launch_bounds__(256) void gram_kernel(const E* __restrict__ A, int6
 // C ABI
 // ---------------------------------------------------------------------------------------------
 template <typename S>
-static int32_t alloc_scalars(rls_ctx* ctx, S** d, S** h) {
-  RLS_HIP(ctx, hipMalloc((void**)d, sizeof(S)));
-  RLS_HIP(ctx, hipMemsetAsync(*d, 0, sizeof(S), ctx->stream));
-  RLS_HIP(ctx, hipHostMalloc((void**)h, sizeof(S), hipHostMallocDefault));
-  memset(*h, 0, sizeof(S));
+static int32_t alloc_scalars(rls_ctx* ctx, S** d, S** h, int n = 1) {
+  RLS_HIP(ctx, hipMalloc((void**)d, sizeof(S) * n));
+  RLS_HIP(ctx, hipMemsetAsync(*d, 0, sizeof(S) * n, ctx->stream));
+  RLS_HIP(ctx, hipHostMalloc((void**)h, sizeof(S) * n, hipHostMallocDefault));
+  memset(*h, 0, sizeof(S) * n);
   return 0;
 }
 template <typename S>
@@ -1209,6 +1269,7 @@ struct rls_admm {
   float *log, *log_h;
   int log_cap;
   int enq;  // outer iterations enqueued since init (== device iteration unless the plan stopped early)
+  int nrhs = 1;  // batched plans: sc / sc_h / log hold one entry per column
 };
 
 // src/ADMM.jl:246-309 in ONE single-workgroup launch: projections on x, z = prox(x + u) (L1 / L2 inline; a TV prox
@@ -1219,8 +1280,17 @@ __global__ __launch_bounds__(UPD_THREADS) void admm_zu_kernel(E* __restrict__ x,
                                                               E* __restrict__ znew, const E* __restrict__ zold,
                                                               E* __restrict__ u, int64_t n, int reg_kind, float lam,
                                                               int proj_kind, int z_ready, admm_scalars* sc,
-                                                              const int* cg_iterations, float* __restrict__ log) {
+                                                              const int* cg_iterations, float* __restrict__ log,
+                                                              col_batch<E> B, const cg_scalars* cgs) {
   __shared__ double sm[48];
+  {
+    const int bq = blockIdx.x;  // batched plans: one workgroup per column
+    const int64_t o = (int64_t)bq * B.ldv;
+    x += o; xold += o; znew += o; zold += o; u += o;
+    sc += bq;
+    log += (int64_t)bq * B.log_stride;
+    if (cgs) cg_iterations = &cgs[bq].iteration;
+  }
   if (sc->done) return;
   double dx = 0, dz = 0, du = 0, nx = 0, nz = 0, nxz = 0, nu = 0;
   auto sq = [](E a) { return (double)elem<E>::re(a) * (double)elem<E>::re(a) + (double)elem<E>::im(a) * (double)elem<E>::im(a); };
@@ -1279,6 +1349,7 @@ __global__ __launch_bounds__(UPD_THREADS) void admm_zu_kernel(E* __restrict__ x,
 
 template <typename E>
 __global__ void admm_reset_kernel(admm_scalars* sc, int max_iter, float rho, float sigma_abs, float rel_tol) {
+  sc += blockIdx.x;
   sc->iteration = 0;
   sc->max_iter = max_iter;
   sc->done = max_iter <= 0;
@@ -1413,23 +1484,105 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
                        (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->sc, rho, reltol, maxiter,
-                       Ff);
+                       Ff, col_batch<float>());
   else
     hipLaunchKernelGGL(cg_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
                        (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, n, s->sc, rho, reltol,
-                       maxiter, Fc);
+                       maxiter, Fc, col_batch<float2>());
   RLS_TRY(launch_status(ctx));
   for (int it = 0; it < maxiter; ++it) {
     RLS_TRY(op_normal(op, s->u, s->c, &s->sc->done));
     if (op->dtype == RLS_F32)
       hipLaunchKernelGGL(cg_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)x, (float*)s->u,
-                         (float*)s->r, (float*)s->c, n, s->sc);
+                         (float*)s->r, (float*)s->c, n, s->sc, col_batch<float>());
     else
       hipLaunchKernelGGL(cg_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)x,
-                         (float2*)s->u, (float2*)s->r, (float2*)s->c, n, s->sc);
+                         (float2*)s->u, (float2*)s->r, (float2*)s->c, n, s->sc, col_batch<float2>());
     RLS_TRY(launch_status(ctx));
   }
   return 0;
+}
+
+// ---- batched ADMM (shared A): every column's outer iteration advances together --------------------------------
+// Per outer iteration: X -> operand panel, T = A X and V = A^H T on the matrix cores (the warm-start apply of every
+// column's cg!), the per-column start kernel (beta = beta_y + rho (z - u), r, u; next operand = u), iterations_cg x
+// {T = A U, V = A^H T, per-column CG update}, the FGP launch with one workgroup per column for a TV term, and the
+// per-column z / u / residual-norm / `done` kernel.  Columns retire independently (per-column device flags), exactly
+// as K independent solves do (src/MultiThreading.jl:60-78).
+static rls_skinny cg_skinny_desc(const rls_cg* s) {
+  rls_skinny K;
+  K.A = s->op->A;
+  K.lda = s->op->lda;
+  K.M = s->op->M;
+  K.N = s->op->N;
+  K.nrhs = s->nrhs;
+  K.ngroups = (s->nrhs + 15) / 16;
+  K.splits = s->splits;
+  K.X = K.R = K.P = K.V = nullptr;
+  K.ldv = s->ldv;
+  K.Ppack = s->Ppack;
+  K.Tpack = s->Tpack;
+  K.Vpart = s->Vpart;
+  K.ldvp = s->op->N;
+  K.sc = nullptr;
+  return K;
+}
+
+template <typename E>
+static int32_t admm_step_batched_typed(rls_admm* a, int32_t n_outer) {
+  rls_cg* cg = a->cg;
+  rls_ctx* ctx = cg->op->ctx;
+  const rls_admm_params& P = a->P;
+  const int32_t dtype = cg->op->dtype;
+  const int64_t n = cg->op->N;
+  const unsigned K = (unsigned)a->nrhs;
+  const rls_skinny SK = cg_skinny_desc(cg);
+  col_batch<E> B;
+  B.ldv = cg->ldv;
+  B.Vpart = (const E*)cg->Vpart;
+  B.S = cg->splits;
+  B.nrhs_pad = ((a->nrhs + 15) / 16) * 16;
+  B.panel = (E*)cg->Ppack;
+  B.skip_stride = (int)(sizeof(admm_scalars) / sizeof(int));
+  B.log_stride = (int64_t)ADMM_REC * a->log_cap;
+  col_batch<E> Bz = B;  // the z / u kernel reads no partial rows and writes no panel
+  Bz.Vpart = nullptr;
+  Bz.panel = nullptr;
+  for (int k = 0; k < n_outer && a->enq < P.iterations; ++k, ++a->enq) {
+    E* zcur = (E*)((a->enq & 1) ? P.z1 : P.z0);
+    E* znew = (E*)((a->enq & 1) ? P.z0 : P.z1);
+    hipLaunchKernelGGL(pack_panel_kernel<E>, dim3((unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64), K), dim3(256), 0,
+                       ctx->stream, (const E*)P.x, cg->ldv, (E*)cg->Ppack, n);
+    RLS_TRY(rls_skinny_launch(ctx, dtype, SK, 1 | 2));  // AHA x of every column  (:244, warm start)
+    admm_fuse<E> F;
+    F.beta_y = (const E*)P.beta_y;
+    F.z = zcur;
+    F.u = (const E*)P.u;
+    F.beta = (E*)P.beta;
+    F.xold = (E*)P.xold;
+    F.rho = P.rho;
+    F.skip = &a->sc->done;
+    hipLaunchKernelGGL(cg_start_kernel<E>, dim3(K), dim3(UPD_THREADS), 0, ctx->stream, (const E*)P.x, (const E*)P.beta,
+                       (E*)cg->u, (E*)cg->r, (const E*)cg->c, n, cg->sc, P.rho, P.tol_inner, P.iterations_cg, F, B);
+    for (int it = 0; it < P.iterations_cg; ++it) {
+      RLS_TRY(rls_skinny_launch(ctx, dtype, SK, 1 | 2));
+      hipLaunchKernelGGL(cg_update_kernel<E>, dim3(K), dim3(UPD_THREADS), 0, ctx->stream, (E*)P.x, (E*)cg->u, (E*)cg->r,
+                         (E*)cg->c, n, cg->sc, B);
+    }
+    const int z_ready = P.reg_kind == RLS_REG_TV;
+    if (z_ready)
+      RLS_TRY(rls_tv_single_launch(ctx, dtype, P.tv_ndims, P.tv_shape, P.tv_ntv, P.tv_dims, P.x, P.u, znew, P.prox_lambda,
+                                   P.tv_iterations, &a->sc->done, (int)K, cg->ldv, B.skip_stride));
+    hipLaunchKernelGGL(admm_zu_kernel<E>, dim3(K), dim3(UPD_THREADS), 0, ctx->stream, (E*)P.x, (const E*)P.xold, znew,
+                       (const E*)zcur, (E*)P.u, n, P.reg_kind, P.prox_lambda, P.proj_kind, z_ready, a->sc,
+                       (const int*)nullptr, a->log, Bz, (const cg_scalars*)cg->sc);
+    RLS_TRY(launch_status(ctx));
+  }
+  return 0;
+}
+
+static int32_t admm_step_batched(rls_admm* a, int32_t n_outer) {
+  return a->cg->op->dtype == RLS_F32 ? admm_step_batched_typed<float>(a, n_outer) : admm_step_batched_typed<float2>(a, n_outer);
 }
 
 extern "C" {
@@ -2434,10 +2587,51 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   return 0;
 }
 
+// K right-hand sides sharing A (solve!(solver::ADMM, B) with the shared-A scheduler; src/MultiThreading.jl:30-79 applies
+// to every solver): U, R, C are N x nrhs scratch matrices (the CGStateVariables of every column, src/ADMM.jl:129)
+int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, void* Cm, int64_t ldv, rls_cg** out) {
+  if (!op) return RLS_E_INVALID;
+  rls_ctx* ctx = op->ctx;
+  if (!U || !R || !Cm || !out || nrhs < 1 || ldv < op->N) return rls_fail(ctx, RLS_E_INVALID, "cg_create_batched: bad argument");
+  if (!op->A || op->G || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "cg_create_batched: needs a matrix-free operator with M, N multiples of 16");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_cg* s = new rls_cg();
+  s->op = op;
+  s->device = ctx->device;
+  s->u = U;
+  s->r = R;
+  s->c = Cm;
+  s->r1 = s->p1 = nullptr;
+  s->dots = nullptr;
+  s->psc = s->pscn = s->psc_h = nullptr;
+  s->used_pipeline = false;
+  s->v1 = nullptr;
+  s->gdots = nullptr;
+  s->sc = s->sc_h = nullptr;
+  s->nrhs = nrhs;
+  s->ldv = ldv;
+  size_t pb, tb, vb;
+  rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+  hipError_t e = hipMalloc((void**)&s->Ppack, pb);
+  if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
+  if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
+  if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
+  if (e != hipSuccess || alloc_scalars(ctx, &s->sc, &s->sc_h, nrhs) != 0) {
+    rls_cg_destroy(s);
+    return rls_fail(ctx, (int32_t)e, "cg_create_batched: allocation failed");
+  }
+  *out = s;
+  return 0;
+}
+
 int32_t rls_cg_destroy(rls_cg* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
+  if (s->Ppack) hipFree(s->Ppack);
+  if (s->Tpack) hipFree(s->Tpack);
+  if (s->Vpart) hipFree(s->Vpart);
   if (s->r1) hipFree(s->r1);
   if (s->p1) hipFree(s->p1);
   if (s->dots) hipFree(s->dots);
@@ -2446,8 +2640,8 @@ int32_t rls_cg_destroy(rls_cg* s) {
   if (s->psc) hipFree(s->psc);
   if (s->pscn) hipFree(s->pscn);
   if (s->psc_h) hipHostFree(s->psc_h);
-  hipFree(s->sc);
-  hipHostFree(s->sc_h);
+  if (s->sc) hipFree(s->sc);
+  if (s->sc_h) hipHostFree(s->sc_h);
   delete s;
   return 0;
 }
@@ -2456,6 +2650,7 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_solve: bad argument");
+  if (s->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "cg_solve on a batched plan: batched cg! runs inside rls_admm_step");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   return cg_solve_impl(s, x, b, rho, maxiter, reltol, admm_fuse_v());
 }
@@ -2482,11 +2677,11 @@ int32_t rls_cg_local_start(rls_cg* s, const void* x, const void* b, float rho, i
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
                        (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, op->N, s->sc, rho, reltol,
-                       maxiter, typed_fuse<float>(admm_fuse_v()));
+                       maxiter, typed_fuse<float>(admm_fuse_v()), col_batch<float>());
   else
     hipLaunchKernelGGL(cg_start_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float2*)x,
                        (const float2*)b, (float2*)s->u, (float2*)s->r, (const float2*)s->c, op->N, s->sc, rho, reltol,
-                       maxiter, typed_fuse<float2>(admm_fuse_v()));
+                       maxiter, typed_fuse<float2>(admm_fuse_v()), col_batch<float2>());
   return launch_status(ctx);
 }
 
@@ -2498,10 +2693,10 @@ int32_t rls_cg_local_update(rls_cg* s, void* x) {
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(cg_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)x, (float*)s->u,
-                       (float*)s->r, (float*)s->c, op->N, s->sc);
+                       (float*)s->r, (float*)s->c, op->N, s->sc, col_batch<float>());
   else
     hipLaunchKernelGGL(cg_update_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)x,
-                       (float2*)s->u, (float2*)s->r, (float2*)s->c, op->N, s->sc);
+                       (float2*)s->u, (float2*)s->r, (float2*)s->c, op->N, s->sc, col_batch<float2>());
   return launch_status(ctx);
 }
 
@@ -2575,7 +2770,8 @@ int32_t rls_admm_create(rls_cg* cg, rls_admm** out) {
   a->log = a->log_h = nullptr;
   a->log_cap = 0;
   a->enq = 0;
-  const int32_t st = alloc_scalars(ctx, &a->sc, &a->sc_h);
+  a->nrhs = cg->nrhs;
+  const int32_t st = alloc_scalars(ctx, &a->sc, &a->sc_h, cg->nrhs);
   if (st != 0) {
     delete a;
     return st;
@@ -2630,14 +2826,14 @@ int32_t rls_admm_init(rls_admm* a, const rls_admm_params* p) {
     if (a->log_h) hipHostFree(a->log_h);
     a->log = a->log_h = nullptr;
     a->log_cap = 0;
-    RLS_HIP(ctx, hipMalloc((void**)&a->log, sizeof(float) * ADMM_REC * cap));
-    RLS_HIP(ctx, hipHostMalloc((void**)&a->log_h, sizeof(float) * ADMM_REC * cap, hipHostMallocDefault));
+    RLS_HIP(ctx, hipMalloc((void**)&a->log, sizeof(float) * ADMM_REC * cap * a->nrhs));
+    RLS_HIP(ctx, hipHostMalloc((void**)&a->log_h, sizeof(float) * ADMM_REC * cap * a->nrhs, hipHostMallocDefault));
     a->log_cap = cap;
   }
   a->P = *p;
   a->enq = 0;
-  hipLaunchKernelGGL(admm_reset_kernel<float>, dim3(1), dim3(1), 0, ctx->stream, a->sc, p->iterations, p->rho,
-                     p->sigma_abs, p->rel_tol);
+  hipLaunchKernelGGL(admm_reset_kernel<float>, dim3((unsigned)a->nrhs), dim3(1), 0, ctx->stream, a->sc, p->iterations,
+                     p->rho, p->sigma_abs, p->rel_tol);
   RLS_TRY(launch_status(ctx));
   a->ready = true;
   return 0;
@@ -2653,6 +2849,7 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer) {
   const rls_admm_params& P = a->P;
   const int32_t dtype = cg->op->dtype;
   const int64_t n = cg->op->N;
+  if (a->nrhs > 1 || cg->Vpart) return admm_step_batched(a, n_outer);
   for (int k = 0; k < n_outer && a->enq < P.iterations; ++k, ++a->enq) {
     void* zcur = (a->enq & 1) ? P.z1 : P.z0;
     void* znew = (a->enq & 1) ? P.z0 : P.z1;
@@ -2673,12 +2870,44 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer) {
     if (dtype == RLS_F32)
       hipLaunchKernelGGL(admm_zu_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)P.x,
                          (const float*)P.xold, (float*)znew, (const float*)zcur, (float*)P.u, n, P.reg_kind,
-                         P.prox_lambda, P.proj_kind, z_ready, a->sc, cg_it, a->log);
+                         P.prox_lambda, P.proj_kind, z_ready, a->sc, cg_it, a->log, col_batch<float>(), nullptr);
     else
       hipLaunchKernelGGL(admm_zu_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)P.x,
                          (const float2*)P.xold, (float2*)znew, (const float2*)zcur, (float2*)P.u, n, P.reg_kind,
-                         P.prox_lambda, P.proj_kind, z_ready, a->sc, cg_it, a->log);
+                         P.prox_lambda, P.proj_kind, z_ready, a->sc, cg_it, a->log, col_batch<float2>(), nullptr);
     RLS_TRY(launch_status(ctx));
+  }
+  return 0;
+}
+
+// batched plans: out_h[nrhs]; log_h (nullable): nrhs blocks of log_records records, column after column
+int32_t rls_admm_get_status_batched(rls_admm* a, rls_admm_status* out, float* log_h, int32_t log_records) {
+  if (!a || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = a->cg->op->ctx;
+  if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_get_status before admm_init");
+  if (log_records < 0 || (log_records > 0 && !log_h)) return rls_fail(ctx, RLS_E_INVALID, "admm_get_status: bad log");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t stride = (size_t)ADMM_REC * a->log_cap;
+  RLS_HIP(ctx, hipMemcpyAsync(a->log_h, a->log, sizeof(float) * stride * a->nrhs, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, hipMemcpyAsync(a->sc_h, a->sc, sizeof(admm_scalars) * a->nrhs, hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  for (int b = 0; b < a->nrhs; ++b) {
+    const int it = a->sc_h[b].iteration;
+    out[b].iteration = it;
+    out[b].done = a->sc_h[b].done;
+    out[b].delta = out[b].sk = out[b].eps_pri = out[b].rk = out[b].eps_dua = 0.f;
+    out[b].cg_iterations = 0;
+    if (it > 0 && it <= a->log_cap) {
+      const float* rec = a->log_h + stride * b + (size_t)(it - 1) * ADMM_REC;
+      out[b].delta = rec[0];
+      out[b].sk = rec[1];
+      out[b].eps_pri = rec[2];
+      out[b].rk = rec[3];
+      out[b].eps_dua = rec[4];
+      out[b].cg_iterations = (int32_t)rec[5];
+    }
+    const int ncopy = it < log_records ? it : log_records;
+    for (int i = 0; i < ncopy * ADMM_REC; ++i) log_h[(size_t)b * log_records * ADMM_REC + i] = a->log_h[stride * b + i];
   }
   return 0;
 }
@@ -2687,6 +2916,7 @@ int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int
   if (!a || !out) return RLS_E_INVALID;
   rls_ctx* ctx = a->cg->op->ctx;
   if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_get_status before admm_init");
+  if (a->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "admm_get_status on a batched plan: use rls_admm_get_status_batched");
   if (log_records < 0 || (log_records > 0 && !log_h)) return rls_fail(ctx, RLS_E_INVALID, "admm_get_status: bad log");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   const int nrec = a->enq < a->log_cap ? a->enq : a->log_cap;

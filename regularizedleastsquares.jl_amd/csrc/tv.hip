@@ -211,14 +211,26 @@ __global__ void fgp_dual_kernel(E* brs, E* bpq, const E* xtmp, tv_geom G, float 
   }
 }
 
+// images processed by one launch of the single-workgroup FGP kernels: workgroup b works on the image that starts
+// b * ldv elements further on and honours the skip flag skip[b * skip_stride]
+struct tv_batch {
+  int count = 1;
+  int64_t ldv = 0;
+  int skip_stride = 0;
+};
+
 // whole FGP loop in one workgroup; the image, xTmp and both dual buffers live in LDS (a global
 // re-read of x in every FGP iteration cost ~6 us of dependent latency per iteration)
 // out = prox_TV(xin [+ add]); `skip` (nullable) is a device flag that turns the launch into a no-op (ADMM plan)
 template <typename E>
 __global__ __launch_bounds__(1024) void fgp_fused_kernel(const E* xin, const E* add, E* x, tv_geom32 G, float lam,
-                                                         int iters, const int* skip) {
+                                                         int iters, const int* skip, tv_batch Bt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (skip && *skip) return;
+  // one workgroup per image (batched plans: image b = column b of N x K matrices, its own skip flag)
+  xin += (int64_t)blockIdx.x * Bt.ldv;
+  if (add) add += (int64_t)blockIdx.x * Bt.ldv;
+  x += (int64_t)blockIdx.x * Bt.ldv;
+  if (skip && skip[(int64_t)blockIdx.x * Bt.skip_stride]) return;
   const unsigned ng = G.goff[G.ntv], n = G.n;
   E* b0 = reinterpret_cast<E*>(smem_raw);
   E* b1 = b0 + ng;
@@ -268,9 +280,12 @@ __global__ __launch_bounds__(1024) void fgp_fused_kernel(const E* xin, const E* 
 template <typename E, int PPT>
 __global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, const E* __restrict__ add,
                                                      E* __restrict__ out, unsigned nx, unsigned ny, int use0, int use1,
-                                                     float lam, int iters, const int* __restrict__ skip) {
+                                                     float lam, int iters, const int* __restrict__ skip, tv_batch Bt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (skip && *skip) return;
+  xin += (int64_t)blockIdx.x * Bt.ldv;  // one workgroup per image (see fgp_fused_kernel)
+  if (add) add += (int64_t)blockIdx.x * Bt.ldv;
+  out += (int64_t)blockIdx.x * Bt.ldv;
+  if (skip && skip[(int64_t)blockIdx.x * Bt.skip_stride]) return;
   const unsigned n = nx * ny, tid = threadIdx.x, nth = blockDim.x;
   E* xt = reinterpret_cast<E*>(smem_raw);
   E* P = xt + n;
@@ -416,7 +431,7 @@ static bool fgp2d_geom(const tv_geom& G, size_t es, unsigned* nx, unsigned* ny, 
 
 template <typename E, int PPT>
 static void fgp2d_launch(rls_ctx* ctx, unsigned nx, unsigned ny, int use0, int use1, const E* xin, const E* add, E* out,
-                         float lam, int iters, const int* skip) {
+                         float lam, int iters, const int* skip, const tv_batch& Bt) {
   const unsigned n = nx * ny;
   const size_t lds = (size_t)3 * n * sizeof(E);
   unsigned nth = (n + PPT - 1) / PPT;
@@ -424,27 +439,27 @@ static void fgp2d_launch(rls_ctx* ctx, unsigned nx, unsigned ny, int use0, int u
   if (nth > 1024) nth = 1024;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp2d_kernel<E, PPT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)lds);
-  hipLaunchKernelGGL((fgp2d_kernel<E, PPT>), dim3(1), dim3(nth), lds, ctx->stream, xin, add, out, nx, ny, use0, use1,
-                     lam, iters, skip);
+  hipLaunchKernelGGL((fgp2d_kernel<E, PPT>), dim3((unsigned)Bt.count), dim3(nth), lds, ctx->stream, xin, add, out, nx, ny,
+                     use0, use1, lam, iters, skip, Bt);
 }
 
 // single-workgroup FGP (either kernel) when the geometry allows: out = prox_TV(xin [+ add]).  Returns false
 // (nothing launched) otherwise.
 template <typename E>
 static bool fgp_single_launch(rls_ctx* ctx, const tv_geom& G, const E* xin, const E* add, E* out, float lam, int iters,
-                              const int* skip) {
+                              const int* skip, const tv_batch& Bt = tv_batch()) {
   unsigned nx, ny;
   int use0, use1;
   if (fgp2d_geom(G, sizeof(E), &nx, &ny, &use0, &use1)) {
     const unsigned n = nx * ny;
     if (n <= 1024)
-      fgp2d_launch<E, 1>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+      fgp2d_launch<E, 1>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
     else if (n <= 2048)
-      fgp2d_launch<E, 2>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+      fgp2d_launch<E, 2>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
     else if (n <= 4096)
-      fgp2d_launch<E, 4>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+      fgp2d_launch<E, 4>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
     else
-      fgp2d_launch<E, 8>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip);
+      fgp2d_launch<E, 8>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
     return true;
   }
   const int64_t ng = G.goff[G.ntv], n = G.n;
@@ -452,8 +467,8 @@ static bool fgp_single_launch(rls_ctx* ctx, const tv_geom& G, const E* xin, cons
   if (lds <= FGP_LDS_BUDGET && n <= g_fused_max_n) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp_fused_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
-    hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3(1), dim3(1024), lds, ctx->stream, xin, add, out, narrow_geom(G), lam,
-                       iters, skip);
+    hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3((unsigned)Bt.count), dim3(1024), lds, ctx->stream, xin, add, out,
+                       narrow_geom(G), lam, iters, skip, Bt);
     return true;
   }
   return false;
@@ -550,14 +565,18 @@ bool rls_tv_single_ok(int32_t dtype, int32_t ndims, const int64_t* shape, int32_
 
 int32_t rls_tv_single_launch(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
                              const int32_t* dims, const void* xin, const void* add, void* out, float lam, int iters,
-                             const int* skip) {
+                             const int* skip, int count, int64_t ldv, int skip_stride) {
   tv_geom G;
-  if (!rls_dtype_ok(dtype) || !make_geom(ndims, shape, ntv, dims, &G))
+  if (!rls_dtype_ok(dtype) || !make_geom(ndims, shape, ntv, dims, &G) || count < 1)
     return rls_fail(ctx, RLS_E_INVALID, "tv_single_launch: bad geometry");
+  tv_batch Bt;
+  Bt.count = count;
+  Bt.ldv = ldv;
+  Bt.skip_stride = skip_stride;
   const bool ok = dtype == RLS_F32
-                      ? fgp_single_launch<float>(ctx, G, (const float*)xin, (const float*)add, (float*)out, lam, iters, skip)
+                      ? fgp_single_launch<float>(ctx, G, (const float*)xin, (const float*)add, (float*)out, lam, iters, skip, Bt)
                       : fgp_single_launch<float2>(ctx, G, (const float2*)xin, (const float2*)add, (float2*)out, lam,
-                                                  iters, skip);
+                                                  iters, skip, Bt);
   if (!ok) return rls_fail(ctx, RLS_E_UNSUPPORTED, "tv_single_launch: image does not fit one workgroup");
   return tv_status(ctx);
 }

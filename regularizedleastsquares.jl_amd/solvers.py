@@ -1709,6 +1709,84 @@ class FistaBatchedState(BatchedState):
         self._plan = None
 
 
+class AdmmBatchedState(BatchedState):
+    """BatchedState for ADMM (one regulariser, identity regTrafo, vary_rho = :none): the K columns' cg! iterations share
+    one pass over A per product (rls_cg_create_batched + rls_admm_step on N x K matrices); prox, z / u updates, the
+    residual norms and `done` are per column, exactly as K independent solves (src/MultiThreading.jl:30-79)."""
+
+    def __init__(self, solver, B: DeviceMatrix):
+        self.states = []
+        self.active = [True] * B.N
+        self.solver = solver
+        self.K = B.N
+        op, ctx, N = solver._op, B.ctx, solver._op.N
+        mk = lambda: DeviceMatrix(N, B.N, B.dtype, ctx)
+        self.x, self.xold, self.beta, self.beta_y, self.u0 = mk(), mk(), mk(), mk(), mk()
+        self._zbufs = (mk(), mk())
+        self.cg_u, self.cg_r, self.cg_c = mk(), mk(), mk()
+        self.u = [self.u0]
+        ref = solver.state.states[0] if isinstance(solver.state, AbstractMatrixSolverState) and solver.state.states else solver.state
+        self.absTol, self.relTol, self.tolInner = ref.absTol, ref.relTol, ref.tolInner
+        self.rho = np.full(1, solver.rho, np.float32)
+        self.sigma_abs = np.float32(np.sqrt(np.float32(B.M))) * self.absTol
+        lib, h = ctx.lib, ctx.handle
+        cg = C.c_void_p()
+        check(h, lib.rls_cg_create_batched(op.handle, B.N, self.cg_u.ptr, self.cg_r.ptr, self.cg_c.ptr, N, C.byref(cg)),
+              "rls_cg_create_batched")
+        self._cg = cg
+        plan = C.c_void_p()
+        check(h, lib.rls_admm_create(cg, C.byref(plan)), "rls_admm_create")
+        self._plan = plan
+        self._keep = (op, ctx)
+        self.iteration = 0
+
+    def init(self, B: DeviceMatrix):
+        solver, ctx = self.solver, self.x.ctx
+        for M_ in (self.x, self.xold, self.u0, self._zbufs[0], self._zbufs[1]):
+            M_.fill_(0)  # x0 = 0: z = Phi x = 0, u = 0   (src/ADMM.jl:192-205)
+        for j in range(self.K):
+            solver.A.mul_adj_(self.beta_y.column_view(j), B.column_view(j))  # beta_y = A' b   (:198)
+        P = solver._plan_params(self)
+        if P is None:
+            raise _lib.RLSError("batched ADMM: this configuration does not run as a device plan")
+        check(ctx.handle, ctx.lib.rls_admm_init(self._plan, C.byref(P)), "rls_admm_init")
+        self.iteration = 0
+
+    def _step(self, n):
+        ctx = self.x.ctx
+        check(ctx.handle, ctx.lib.rls_admm_step(self._plan, int(n)), "rls_admm_step")
+
+    def status(self):
+        st = (AdmmStatus * self.K)()
+        ctx = self.x.ctx
+        check(ctx.handle, ctx.lib.rls_admm_get_status_batched(self._plan, st, None, 0), "rls_admm_get_status_batched")
+        return list(st)
+
+    def cg_iterations(self):
+        """per column: the inner cg! iteration counts of its outer iterations"""
+        cap = max(self.solver.iterations, 1)
+        st = (AdmmStatus * self.K)()
+        log = (C.c_float * (8 * cap * self.K))()
+        ctx = self.x.ctx
+        check(ctx.handle, ctx.lib.rls_admm_get_status_batched(self._plan, st, log, cap), "rls_admm_get_status_batched")
+        return [[int(log[(j * cap + k) * 8 + 5]) for k in range(st[j].iteration)] for j in range(self.K)]
+
+    def convergence(self):
+        return [{"primal": s.rk, "dual": s.sk} for s in self.status()]
+
+    def solutions(self) -> List[DeviceVector]:
+        return [self.x.column(j) for j in range(self.K)]
+
+    def __del__(self):
+        try:
+            if self._plan and self.x.ctx.handle:
+                self.x.ctx.lib.rls_admm_destroy(self._plan)
+                self.x.ctx.lib.rls_cg_destroy(self._cg)
+        except Exception:
+            pass
+        self._plan = None
+
+
 def _columns(b) -> List[DeviceVector]:
     if isinstance(b, DeviceMatrix):
         return [b.column(j) for j in range(b.N)]
@@ -1723,6 +1801,9 @@ def _columns(b) -> List[DeviceVector]:
 def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
     """init!(solver, b; kwargs...)   src/RegularizedLeastSquares.jl:190, src/MultiThreading.jl:30-43"""
     if isinstance(b, DeviceVector):
+        if isinstance(solver.state, AdmmBatchedState):
+            ref = solver.state
+            solver.state = ADMMState(len(solver.reg), solver.rho, ref.absTol, ref.relTol, ref.tolInner)
         if isinstance(solver.state, FistaBatchedState):
             solver.state = FISTAState(solver.state.rho, 1, solver.state.relTol)
         elif isinstance(solver.state, BatchedState):
@@ -1772,7 +1853,21 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
                 return
             except _lib.RLSError:
                 pass  # e.g. M or N not a multiple of 16: independent per-column plans instead
+        if (type(solver) is ADMM and isinstance(b, DeviceMatrix) and b.N > 1 and solver.A is not None and not kw
+                and solver.use_device_plan and solver._all_identity() and len(solver.reg) == 1 and solver.vary_rho == "none"
+                and not isinstance(solver.normalizeReg, (MeasurementBasedNormalization, SystemMatrixBasedNormalization))):
+            try:
+                st = solver.state if isinstance(solver.state, AdmmBatchedState) and solver.state.K == b.N else AdmmBatchedState(solver, b)
+                st.init(b)
+                st.active = [True] * b.N
+                solver.state = st
+                return
+            except _lib.RLSError:
+                pass  # shape or regulariser not covered by the batched plan: independent per-column plans instead
         scheduler = MultiThreadingState
+    if isinstance(solver.state, AdmmBatchedState):
+        ref = solver.state
+        solver.state = ADMMState(len(solver.reg), solver.rho, ref.absTol, ref.relTol, ref.tolInner)
     if isinstance(solver.state, FistaBatchedState):
         solver.state = FISTAState(solver.state.rho, 1, solver.state.relTol)
     elif isinstance(solver.state, BatchedState):

@@ -2117,3 +2117,47 @@ def test_config5_schedule_through_the_library_communicator(rls, ctx, nshards):
         assert np.array_equal(x2, x)
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("dt,M,N,K,kind", [(np.float32, 256, 64, 5, "tv"), (np.complex64, 128, 48, 3, "l1"), (np.float32, 512, 256, 20, "l1pos"),
+                                           (np.complex64, 4096, 2048, 8, "l1"), (np.float32, 320, 144, 4, "l2")])
+def test_admm_batched_matrix_rhs(rls, ctx, dt, M, N, K, kind):
+    """solve!(solver::ADMM, B) with the shared-A scheduler (src/MultiThreading.jl:30-79 applies to every solver): the K
+    columns' cg! iterations share the passes over A (rls_cg_create_batched + rls_admm_step), prox / z / u / `done` per
+    column.  Every column against its own oracle solve (iteration count, inner cg! counts, solution), columns that
+    converge early retire while the others go on, and the reference's scheduler gives the same columns"""
+    A, X, B = O.make_problem(M, N, dt, 61, n_rhs=K)
+    B = np.asfortranarray(B * (3.0 ** (np.arange(K) % 4))[None, :]).astype(dt)  # different scales: different stopping iterations
+    def regs(R):
+        if kind == "tv":
+            return R.TVRegularization(2e-2, shape=(8, 8))
+        if kind == "l1":
+            return R.L1Regularization(0.05)
+        if kind == "l1pos":
+            return [R.L1Regularization(0.05), R.PositiveRegularization()]
+        return R.L2Regularization(0.3)
+    loose = M < 1000
+    kw = dict(rho=0.3, iterations=12 if loose else 4, iterationsCG=6, tolInner=1e-4, **(dict(absTol=1e-3, relTol=5e-2) if loose else {}))
+    Ad, Bd = rls.DeviceMatrix.from_host(A), rls.DeviceMatrix.from_host(B)
+    S = rls.createLinearSolver(rls.ADMM, Ad, reg=regs(rls), **kw)
+    xs = rls.solve_(S, Bd, scheduler=rls.BatchedState)
+    assert type(S.state).__name__ == "AdmmBatchedState"
+    stat, cgits = S.state.status(), S.state.cg_iterations()
+    seen = []
+    for j in range(K if M < 1000 else 2):
+        ref = O.ADMM(A, reg=regs(O), **kw)                 # Float32 oracle = the reference's path: counts
+        O.solve(ref, np.ascontiguousarray(B[:, j]))
+        assert stat[j].iteration == ref.iteration and cgits[j] == ref.cg_iters, (j, stat[j].iteration, ref.iteration, cgits[j], ref.cg_iters)
+        ref64 = O.ADMM(A.astype(hi(dt)), reg=regs(O), **dict(kw, iterations=ref.iteration, absTol=0.0, relTol=0.0))
+        parity(f"admm_batched_{kind}_{M}x{N}_{np.dtype(dt).name}_K{K}_col{j}", xs[j].to_host(), O.solve(ref64, B[:, j].astype(hi(dt))), ref.x,
+               record=(j < 2))
+        seen.append(ref.iteration)
+    if loose and kind != "l2":
+        assert len(set(seen)) > 1 or max(seen) < kw["iterations"]  # some column stopped early
+    S2 = rls.createLinearSolver(rls.ADMM, Ad, reg=regs(rls), **kw)
+    ys = rls.solve_(S2, Bd, scheduler=rls.MultiThreadingState)
+    for j in range(K):
+        assert rel(xs[j].to_host(), ys[j].to_host()) < 2e-5, j  # two device paths, each gated against the oracle above
+    # a vector solve still works afterwards (src/MultiThreading.jl:39-43)
+    v = rls.solve_(S, rls.DeviceVector.from_host(np.ascontiguousarray(B[:, 0]))).to_host()
+    assert rel(v, ys[0].to_host()) < 2e-5
