@@ -275,6 +275,45 @@ def other_paths(rls, ctx, Ad, A, b, errors):
                             rls._lib.check(h, lib.rls_fista_step(stf._plan, 48), "step")), 48, reps=4)
         return {"us_per_batched_iteration": us, "solve_iterations_per_s": 16 * 1e6 / us}
 
+    @entry("admm_l1_batched_16_rhs (solve!(ADMM, B), shared A: cg! on the matrix cores, one workgroup per column for the rest)")
+    def _():
+        Xa = (rng.standard_normal((N, 16)) + 1j * rng.standard_normal((N, 16))).astype(np.complex64)
+        Ba = rls.DeviceMatrix.from_host(np.asfortranarray((A @ Xa).astype(np.complex64)), ctx)
+        S = rls.createLinearSolver(rls.ADMM, Ad, reg=rls.L1Regularization(1e-2), rho=0.1, iterations=4, iterationsCG=10, tolInner=1e-5)
+        rls.solve_(S, Ba, scheduler=rls.BatchedState)
+        st = S.state
+        assert type(st).__name__ == "AdmmBatchedState"
+        us = timed(lambda: (st.init(Ba), st._step(4)), 4, reps=4)
+        S1 = rls.createLinearSolver(rls.ADMM, Ad, reg=rls.L1Regularization(1e-2), rho=0.1, iterations=4, iterationsCG=10, tolInner=1e-5)
+        b1 = Ba.column(0)
+        rls.solve_(S1, b1)
+        us1 = timed(lambda: rls.solve_(S1, b1), 4, reps=4)
+        return {"us_per_batched_outer_iteration": us, "us_per_outer_iteration_one_column": us1, "outer_iterations_per_s_all_columns": 16e6 / us,
+                "speedup_vs_column_by_column": 16 * us1 / us}
+
+    @entry("cgnr_distinct_A_8_problems (BASELINE configs[3], distinct-A flavour on one GPU: 8 matrices, 8 streams)")
+    def _():
+        from rls_amd.multigpu import ConcurrentSolves
+        mats = [A] + [make_A(M, N, 100 + k) for k in range(1, 8)]
+        rhs = [(m_ @ np.ones(N, np.complex64)).astype(np.complex64) for m_ in mats]
+        res = {}
+        for ns in (1, 8):
+            cs = ConcurrentSolves(rls, n_streams=ns)
+            try:
+                dA = cs.upload(mats)
+                mk = lambda Ad_: rls.createLinearSolver(rls.CGNR, Ad_, iterations=32, relTol=0.0)
+                cs.solve(dA, rhs, mk)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    cs.solve(dA, rhs, mk)
+                dt_ = (time.perf_counter() - t0) / 3
+            finally:
+                cs.close()
+            res[f"{ns}_stream(s)"] = {"ms_per_8_solves": 1e3 * dt_, "solve_iterations_per_s": 8 * 32 / dt_}
+        res["note"] = ("whole solve! calls from worker threads (plan creation, upload of b, 32 iterations, download of x); the slab / resident "
+                       "kernels need the whole chip, so only setup and the small kernels overlap")
+        return res
+
     @entry("kaczmarz_row_sweeps (one launch per solve)")
     def _():
         S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(1e-3), iterations=4)

@@ -101,6 +101,65 @@ class MultiSolve:
         return np.concatenate([p[1] for p in parts], axis=1)
 
 
+class ConcurrentSolves:
+    """Config 4, distinct-A flavour inside one GPU: several independent solvers, each with its OWN matrix, solved side
+    by side -- the reference spawns one Julia task per solver (docs/src/literate/howto/multi_threading.jl:8-17); here
+    every worker thread owns a context (= a HIP stream of its own), so uploads, setup kernels and the small kernels
+    of one solve overlap with the large kernels of another.  The library is re-entrant (all mutable state lives in
+    the rls_ctx) and ctypes releases the GIL inside every call.  Kernels that need the whole chip (the one-pass slab
+    kernels, the resident kernels) still run one after another: they are chained on the device."""
+
+    def __init__(self, rls, n_streams: int = 8, device: int = 0):
+        self.rls = rls
+        self.ctxs = [rls.Context(device) for _ in range(int(n_streams))]
+
+    def upload(self, matrices):
+        """A_k -> DeviceMatrix on context k % n_streams (residency before a timed region)"""
+        rls = self.rls
+        return [rls.DeviceMatrix.from_host(A, self.ctxs[k % len(self.ctxs)]) for k, A in enumerate(matrices)]
+
+    def solve(self, device_matrices, rhs, make_solver):
+        """rhs[k]: host vector for problem k; make_solver(Ad) -> solver.  Returns the host solutions in problem order."""
+        import queue
+        import threading
+
+        rls, n = self.rls, len(device_matrices)
+        out, errs = [None] * n, []
+        work = queue.Queue()
+        for k in range(n):
+            work.put(k)
+
+        def worker(slot):
+            while True:
+                try:
+                    k = work.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    Ad = device_matrices[k]
+                    if Ad.ctx is not self.ctxs[slot] and len(self.ctxs) >= n:
+                        pass  # problem k was uploaded on context k % n_streams; any worker may drive it
+                    solver = make_solver(Ad)
+                    x = rls.solve_(solver, rls.DeviceVector.from_host(rhs[k], Ad.ctx))
+                    out[k] = x.to_host()
+                except Exception as e:  # surfaced after the join
+                    errs.append((k, e))
+
+        threads = [threading.Thread(target=worker, args=(s_,)) for s_ in range(min(len(self.ctxs), n))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0][1]
+        return out
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+
 # --------------------------------------------------------------------------------------------
 # config 5: row-sharded CGNR
 # --------------------------------------------------------------------------------------------

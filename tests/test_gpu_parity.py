@@ -2161,3 +2161,35 @@ def test_admm_batched_matrix_rhs(rls, ctx, dt, M, N, K, kind):
     # a vector solve still works afterwards (src/MultiThreading.jl:39-43)
     v = rls.solve_(S, rls.DeviceVector.from_host(np.ascontiguousarray(B[:, 0]))).to_host()
     assert rel(v, ys[0].to_host()) < 2e-5
+
+
+def test_concurrent_solves_with_distinct_matrices(rls, ctx):
+    """config 4, distinct-A flavour on one GPU (docs/src/literate/howto/multi_threading.jl:8-17): 6 solvers with their own
+    matrices on 3 contexts / streams driven from worker threads -- each result is bit-identical to solving that problem
+    alone, and within the gate of its oracle (CGNR at the resident shape and FISTA at a small one, mixed)"""
+    probs = []
+    for k in range(6):
+        M, N = (4096, 2048) if k % 2 == 0 else (192, 64)
+        A, xt, b = O.make_problem(M, N, np.complex64, 200 + k)
+        probs.append((A, b))
+    def mk(Ad):
+        if Ad.M == 4096:
+            return rls.createLinearSolver(rls.CGNR, Ad, iterations=16, relTol=0.0)
+        return rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(0.02), rho=0.9 / (np.sqrt(192) + np.sqrt(64)) ** 2, iterations=20)
+    cs = rls.ConcurrentSolves(rls, n_streams=3)
+    try:
+        dA = cs.upload([p[0] for p in probs])
+        xs = cs.solve(dA, [p[1] for p in probs], mk)
+        xs2 = cs.solve(dA, [p[1] for p in probs], mk)
+    finally:
+        cs.close()
+    for k, (A, b) in enumerate(probs):
+        Ad = rls.DeviceMatrix.from_host(A)
+        alone = rls.solve_(mk(Ad), rls.DeviceVector.from_host(b)).to_host()
+        assert np.array_equal(xs[k], alone) and np.array_equal(xs2[k], alone), k
+        if A.shape[0] == 4096:
+            x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.CGNR(A_, iterations=16, relTol=0.0), b_), A, b)
+        else:
+            x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=O.L1Regularization(0.02), rho=0.9 / (np.sqrt(192) + np.sqrt(64)) ** 2,
+                                                                  iterations=20), b_), A, b)
+        parity(f"concurrent_solves_problem{k}", xs[k], x64, x32, record=False)
