@@ -119,6 +119,8 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
     rls_normal_order_mode(value);
   } else if (!strcmp(key, "red_threads")) {
     rls_normal_red_threads(value);
+  } else if (!strcmp(key, "resident_barrier")) {
+    rls_normal_resident_barrier(value);
   }
   else return rls_fail(ctx, RLS_E_INVALID, "tune_set: unknown key");
   return 0;

@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(FIN_THREADS) void fista_gram_f_kernel(E* b0, E* b1,
 // payload with sc1 loads only after a workgroup barrier behind the poll.  Nothing depends on dispatch order
 // or XCD placement; every spin is bounded (`spin_limit`), a timeout leaves x, r, p untouched and raises `fail`.
 struct resident_sync {
-  unsigned cnt[8 * 32];  // 8 shards of the arrival counter, one 128-byte line each (zeroed before every launch)
+  unsigned cnt[8 * 32];  // arrival words (zeroed before every launch): one flag per workgroup, or 8 counter shards a line apart
   unsigned fail;         // some workgroup gave up waiting
   unsigned completed;    // workgroup 0 passed the last barrier and wrote the state back
   unsigned pad[30];
@@ -1445,28 +1445,51 @@ struct resident_lds {
 
 // arrive + wait.  Precondition: this workgroup's handed-off stores are sc1, drained by every storing wave, and a
 // workgroup barrier lies between those drains and this call.
-__device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned target, unsigned spin_limit, int* lds_flag) {
+// MODE 1 (default): arrival = one returning-free atomic add to one of 8 counter shards (a 128-byte line each), waiting =
+// lanes 0..7 of one wave re-reading the 8 shards until their sum reaches nwg * epoch.
+// MODE 0 (`rls_tune_set("resident_barrier", 0)`): arrival = ONE sc1 store of the epoch into this workgroup's own flag
+// word, waiting = one wave re-reading all nwg <= 256 flags (1 KiB, one 16-byte load per lane).  Measured SLOWER on
+// MI355X (18.3 vs 15.9 us per iteration at the headline shape: 256 pollers each pulling 8 lines that 32 writers share
+// cost more than the atomic round trip they save); kept as a switch so the comparison can be re-run.
+template <int MODE>
+__device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned epoch, unsigned nwg, unsigned spin_limit, int* lds_flag) {
   const int tid = threadIdx.x;
   if (tid < 64) {
-    if (tid == 0) __hip_atomic_fetch_add(cnt + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 0;
-    for (unsigned spins = 0; spins < spin_limit; ++spins) {
-      unsigned c = __hip_atomic_load(cnt + (tid & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // lanes 0..7 hold the 8 shards:
-      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // butterfly inside the group of 8
-      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xF, 0xF, true);
-      if (__builtin_amdgcn_readfirstlane((int)c) >= (int)target) {
-        ok = 1;
-        break;
+    if constexpr (MODE == 0) {
+      if (tid == 0) __hip_atomic_store(cnt + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const __amdgpu_buffer_rsrc_t rs = sc1_rsrc(cnt);
+      for (unsigned spins = 0; spins < spin_limit; ++spins) {
+        const u4 f = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)tid * 16u, 0, 16);
+        bool mine = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine = mine && ((unsigned)(tid * 4 + q) >= nwg || f[q] >= epoch);
+        if (__all(mine)) {
+          ok = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(1);
+    } else {
+      const unsigned target = nwg * epoch;
+      if (tid == 0) __hip_atomic_fetch_add(cnt + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned spins = 0; spins < spin_limit; ++spins) {
+        unsigned c = __hip_atomic_load(cnt + (tid & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // lanes 0..7 hold the 8 shards:
+        c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // butterfly inside the group of 8
+        c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xF, 0xF, true);
+        if (__builtin_amdgcn_readfirstlane((int)c) >= (int)target) {
+          ok = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
     if (tid == 0) *lds_flag = ok;
   }
   __syncthreads();
   return *lds_flag != 0;
 }
-
 
 // workgroup j sums 64-byte column chunk j (and j + nwg, ...) of the partial rows in a fixed order, stores that piece
 // of v write-through and hands every summed column to `per_column(j, sum)` (threads 0..CW-1 of wave 0)
@@ -1510,7 +1533,7 @@ __device__ static inline void resident_reduce_chunks(resident_lds<E, G, K, WV>& 
   }
 }
 
-template <typename E, int G, int K, int WV>
+template <typename E, int G, int K, int WV, int BAR>
 __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* r, E* p,
                                                                  E* v, E* slab, double* dout, cgnr_scalars* sc,
                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair,
@@ -1549,7 +1572,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
     STAMP(10);
-    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
       alive = false;
       break;
     }
@@ -1578,7 +1601,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STAMP(12);
-    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
       alive = false;
       break;
     }
@@ -1652,7 +1675,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
 // Per iteration: xs = y, partial rows of AHA y, exchange 1, chunk sums -> res_raw, exchange 2, then the gradient step,
 // prox, restart test, theta and the next extrapolated point redundantly in every workgroup (fista_update_elems: its
 // two scalar sums run over full vectors every workgroup holds, so no partial dots travel).
-template <typename E, int G, int K, int WV>
+template <typename E, int G, int K, int WV, int BAR>
 __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
                                                                   const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                   E* raw_g, E* slab, fista_scalars* sc,
@@ -1690,14 +1713,14 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     slab_finish<E, G, K, WV, true, true>(a, L, slab, Mc, N, pair);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
       alive = false;
       break;
     }
     resident_reduce_chunks<E, G, K, WV>(R, slab_rs, raw_g, nwg, N, [](int, E) {});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!grid_arrive_wait(sync->cnt, (unsigned)nwg * ++epoch, spin_limit, &R.flag)) {
+    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
       alive = false;
       break;
     }
@@ -1762,6 +1785,7 @@ struct fused_cfg {
 static int g_force_g = 0;   // measurement overrides (rls_tune_set "slab_g" / "slab_wv"): 0 = heuristic
 static int g_force_wv = 0;
 static int g_order_mode = 1;  // 0: wait for the small loads, 1: barrier only (rls_tune_set "slab_order")
+static int g_resident_barrier = 1;  // resident kernels: 1 = sharded atomic counter (default), 0 = per-workgroup flag words (measured slower)
 static int g_red_threads = 1024;  // reduce kernel: 16 columns x 64 row groups per workgroup (-1.0 us vs 256)
 
 // candidate slab shapes, smallest column capacity first; NMAX = K * WV * (64 / G)
@@ -2089,12 +2113,18 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
     constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
     static bool attr_set = false;
     if (!attr_set) {
-      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 0>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1>, lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
-                       (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N, pair,
-                       n_steps, spin_limit);
+    if (g_resident_barrier == 0)
+      hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, 0>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
+                         (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N, pair,
+                         n_steps, spin_limit);
+    else
+      hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, 1>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
+                         (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N, pair,
+                         n_steps, spin_limit);
     return launch_status(ctx);
   } else {
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident CGNR: slab shape not instantiated");
@@ -2139,12 +2169,18 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
     constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
     static bool attr_set = false;
     if (!attr_set) {
-      allow_big_lds(&fista_resident_kernel<E, G, K, WV>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 0>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1>, lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
-                       (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab, P.sc,
-                       (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+    if (g_resident_barrier == 0)
+      hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, 0>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
+                         (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab, P.sc,
+                         (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+    else
+      hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, 1>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
+                         (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab, P.sc,
+                         (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
     return launch_status(ctx);
   } else {
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident FISTA: slab shape not instantiated");
@@ -2209,6 +2245,7 @@ void rls_normal_force_group(int g) { g_force_g = g; }
 void rls_normal_force_waves(int wv) { g_force_wv = wv; }
 void rls_normal_order_mode(int m) { g_order_mode = m; }
 void rls_normal_red_threads(int t) { g_red_threads = t; }
+void rls_normal_resident_barrier(int m) { g_resident_barrier = m ? 1 : 0; }
 
 #ifdef RLS_STAMPS
 extern "C" int32_t rls_debug_stamps(unsigned long long* out_h) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -71,6 +72,16 @@ static inline hipError_t rls_stream_wait(hipStream_t s) {
 }
 static inline hipError_t rls_event_wait(hipEvent_t ev) {
   return rls_bounded_spin([ev] { return hipEventQuery(ev); }, [ev] { return hipEventSynchronize(ev); });
+}
+
+// One process-wide lock around (a) every hipGraph capture of the library (begin ... end capture: host-side recording
+// of a few dozen launches) and (b) the cross-stream event chain of the resident kernels.  While ANY stream of the
+// process is capturing, hipStreamWaitEvent from another thread on an event recorded outside that capture can fail
+// with hipErrorStreamCaptureIsolation (seen with one context capturing a FISTA graph while another chained a
+// resident launch: 1 run in 6); both sections are short and host-only, so serialising them costs nothing measurable.
+inline std::mutex& rls_capture_mutex() {
+  static std::mutex m;
+  return m;
 }
 
 constexpr int RLS_RED_SLOTS = 4096;
@@ -554,6 +565,7 @@ void rls_normal_force_group(int g);
 void rls_normal_force_waves(int wv);
 void rls_normal_order_mode(int m);
 void rls_normal_red_threads(int t);
+void rls_normal_resident_barrier(int m);
 size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,
                                 const void* p, void* v, void* slab, const int* skip);

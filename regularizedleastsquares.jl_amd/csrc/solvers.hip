@@ -60,12 +60,14 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
           big->exec = nullptr;
         }
         hipGraph_t graph = nullptr;
+        std::unique_lock<std::mutex> capture_lock(rls_capture_mutex());
         hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
         int32_t st = 0;
         if (e == hipSuccess) {
           for (int i = 0; i < chunk && st == 0; ++i) st = enqueue_one();
           e = hipStreamEndCapture(ctx->stream, &graph);
         }
+        capture_lock.unlock();
         if (e != hipSuccess || st != 0 || !graph ||
             hipGraphInstantiate(&big->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
           big->failed = true;  // fall back to eager launches (still the HIP kernels)
@@ -198,11 +200,10 @@ static bool cgnr_use_resident(const rls_cgnr* s) {
 // other is waiting for.  So resident launches on one device form ONE chain across all streams of the process: each
 // waits for the event recorded behind the previous one.  (Another PROCESS on the same device is not covered: its
 // symptom is the bounded-wait timeout reported by rls_cgnr_get_status.)
-static std::mutex g_resident_mu;
 static hipEvent_t g_resident_ev[64];
 template <typename F>
 static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch) {
-  std::lock_guard<std::mutex> lock(g_resident_mu);
+  std::lock_guard<std::mutex> lock(rls_capture_mutex());
   const int d = ctx->device < 64 ? ctx->device : 63;
   if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
   else RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));

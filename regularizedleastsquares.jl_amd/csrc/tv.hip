@@ -521,12 +521,14 @@ int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E*
   }
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  std::unique_lock<std::mutex> capture_lock(rls_capture_mutex());
   hipError_t err = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
   int32_t st = 0;
   if (err == hipSuccess) {
     st = enqueue();
     err = hipStreamEndCapture(ctx->stream, &graph);
   }
+  capture_lock.unlock();
   if (err != hipSuccess || st != 0 || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
     if (graph) hipGraphDestroy(graph);
     (void)hipGetLastError();

@@ -120,32 +120,26 @@ class ConcurrentSolves:
 
     def solve(self, device_matrices, rhs, make_solver):
         """rhs[k]: host vector for problem k; make_solver(Ad) -> solver.  Returns the host solutions in problem order."""
-        import queue
         import threading
 
         rls, n = self.rls, len(device_matrices)
         out, errs = [None] * n, []
-        work = queue.Queue()
-        for k in range(n):
-            work.put(k)
 
         def worker(slot):
-            while True:
+            # a context (its stream, its graph captures) is driven by ONE thread at a time: worker `slot` takes exactly
+            # the problems that live on context `slot`
+            for k in range(n):
+                Ad = device_matrices[k]
+                if Ad.ctx is not self.ctxs[slot]:
+                    continue
                 try:
-                    k = work.get_nowait()
-                except queue.Empty:
-                    return
-                try:
-                    Ad = device_matrices[k]
-                    if Ad.ctx is not self.ctxs[slot] and len(self.ctxs) >= n:
-                        pass  # problem k was uploaded on context k % n_streams; any worker may drive it
                     solver = make_solver(Ad)
                     x = rls.solve_(solver, rls.DeviceVector.from_host(rhs[k], Ad.ctx))
                     out[k] = x.to_host()
                 except Exception as e:  # surfaced after the join
                     errs.append((k, e))
 
-        threads = [threading.Thread(target=worker, args=(s_,)) for s_ in range(min(len(self.ctxs), n))]
+        threads = [threading.Thread(target=worker, args=(s_,)) for s_ in range(len(self.ctxs))]
         for t in threads:
             t.start()
         for t in threads:

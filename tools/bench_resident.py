@@ -15,9 +15,9 @@ xt = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).ast
 b = (A @ xt).astype(np.complex64)
 Ad, bd = rls.DeviceMatrix.from_host(A, ctx), rls.DeviceVector.from_host(b, ctx)
 S = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
-for mode in (1, 0):
-    ctx.tune(resident=mode)
-    for seg in (32, 8, 1):
+for mode, bar in ((1, 0), (1, 1), (0, 0)):
+    ctx.tune(resident=mode, resident_barrier=bar)
+    for seg in (32, 8):
         def run(nsolves):
             for _ in range(nsolves):
                 rls.init_(S, bd)
@@ -28,4 +28,4 @@ for mode in (1, 0):
         for _ in range(5):
             ctx.timer_start(); run(50); best = min(best, ctx.timer_stop_ms())
         S.state._refresh(lib)
-        print(f"resident={mode} step calls of {seg:2d}: {best * 1e3 / (50 * 32):7.2f} us/iteration (incl. init! GEMV per 32)  it={S.state.iteration} res={S.state._residual:.3e}", flush=True)
+        print(f"resident={mode} barrier={bar} step calls of {seg:2d}: {best * 1e3 / (50 * 32):7.2f} us/iteration (incl. init! GEMV per 32)  it={S.state.iteration} res={S.state._residual:.3e}", flush=True)
