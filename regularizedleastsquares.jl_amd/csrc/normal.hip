@@ -221,29 +221,36 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
   // The sum over the G lanes that share a column goes through LDS, not DPP: per column a lane does
   // one store here and the G-term sum below costs G reads per OUTPUT column, against 2*log2(G)
   // cross-lane adds per lane per load with shuffles (that phase was VALU-bound at 3 us).
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
-    E q = elem<E>::zero();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) q = elem<E>::fmac_pk(a[k].e[i], tr[i], q);
-    L.xg[g][k * C::CPR + slot] = q;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
-  STAMP(6);
   E* out = slab + (int64_t)blockIdx.x * N;
+  // The resident kernels (SC1) drain these write-through stores before they may signal: the columns go out in two
+  // halves, so that the first half's stores are already on their way while the second half is still being formed.
+  constexpr int HALVES = (SC1 && K % 2 == 0 && C::EPT % 2 == 0 && C::NMAX == C::EPT * C::NT) ? 2 : 1;
 #pragma unroll
-  for (int e = 0; e < C::EPT; ++e) {
-    const int c = tid + e * C::NT;
-    if (c < C::NMAX) {
-      E sum = L.xg[0][c];
+  for (int h = 0; h < HALVES; ++h) {
 #pragma unroll
-      for (int gg = 1; gg < G; ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
-      if constexpr (SC1) {
-        if (c < N) sc1_store_elem<E>(out + c, sum);
-      } else {
-        if (c < N) out[c] = sum;
+    for (int k = h * (K / HALVES); k < (h + 1) * (K / HALVES); ++k) {
+      if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+      E q = elem<E>::zero();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) q = elem<E>::fmac_pk(a[k].e[i], tr[i], q);
+      L.xg[g][k * C::CPR + slot] = q;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HALVES == 2) lds_barrier();  // LDS only: the first half's stores stay in flight
+    else __syncthreads();
+    if (h == 0) STAMP(6);
+#pragma unroll
+    for (int e = h * (C::EPT / HALVES); e < (h + 1) * (C::EPT / HALVES); ++e) {
+      const int c = tid + e * C::NT;
+      if (c < C::NMAX) {
+        E sum = L.xg[0][c];
+#pragma unroll
+        for (int gg = 1; gg < G; ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
+        if constexpr (SC1) {
+          if (c < N) sc1_store_elem<E>(out + c, sum);
+        } else {
+          if (c < N) out[c] = sum;
+        }
       }
     }
   }
