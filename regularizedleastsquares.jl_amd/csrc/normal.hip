@@ -222,9 +222,9 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
   // one store here and the G-term sum below costs G reads per OUTPUT column, against 2*log2(G)
   // cross-lane adds per lane per load with shuffles (that phase was VALU-bound at 3 us).
   E* out = slab + (int64_t)blockIdx.x * N;
-  // The resident kernels (SC1) drain these write-through stores before they may signal: the columns go out in two
-  // halves, so that the first half's stores are already on their way while the second half is still being formed.
-  constexpr int HALVES = (SC1 && K % 2 == 0 && C::EPT % 2 == 0 && C::NMAX == C::EPT * C::NT) ? 2 : 1;
+  // The resident kernels (SC1) drain these write-through stores before they may signal: the columns go out in parts
+  // (4, or 2), so that the earlier parts' stores are already on their way while the later ones are still being formed.
+  constexpr int HALVES = !(SC1 && C::NMAX == C::EPT * C::NT) ? 1 : (K % 4 == 0 && C::EPT % 4 == 0) ? 4 : (K % 2 == 0 && C::EPT % 2 == 0) ? 2 : 1;
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) {
 #pragma unroll
@@ -236,7 +236,7 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
       L.xg[g][k * C::CPR + slot] = q;
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (HALVES == 2) lds_barrier();  // LDS only: the first half's stores stay in flight
+    if constexpr (HALVES > 1) lds_barrier();  // LDS only: the earlier parts' stores stay in flight
     else __syncthreads();
     if (h == 0) STAMP(6);
 #pragma unroll
@@ -1458,6 +1458,9 @@ struct resident_lds {
 // word, waiting = one wave re-reading all nwg <= 256 flags (1 KiB, one 16-byte load per lane).  Measured SLOWER on
 // MI355X (18.3 vs 15.9 us per iteration at the headline shape: 256 pollers each pulling 8 lines that 32 writers share
 // cost more than the atomic round trip they save); kept as a switch so the comparison can be re-run.
+#ifndef RLS_POLL_SLEEP
+#define RLS_POLL_SLEEP 1
+#endif
 template <int MODE>
 __device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned epoch, unsigned nwg, unsigned spin_limit, int* lds_flag) {
   const int tid = threadIdx.x;
@@ -1480,6 +1483,9 @@ __device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned epoch, un
     } else {
       const unsigned target = nwg * epoch;
       if (tid == 0) __hip_atomic_fetch_add(cnt + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ONE poll in flight, a short sleep between polls: the pollers of 256 workgroups share the memory-side path
+      // with the arrivals they are waiting for.  Measured at the headline shape (us per iteration, one run): sleep 1
+      // 14.3, sleep 8 14.7, sleep 32 15.4; two polls in flight (the next requested before the previous is examined) 16.2.
       for (unsigned spins = 0; spins < spin_limit; ++spins) {
         unsigned c = __hip_atomic_load(cnt + (tid & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // lanes 0..7 hold the 8 shards:
@@ -1489,7 +1495,7 @@ __device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned epoch, un
           ok = 1;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(RLS_POLL_SLEEP);
       }
     }
     if (tid == 0) *lds_flag = ok;
