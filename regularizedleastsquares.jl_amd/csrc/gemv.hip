@@ -265,6 +265,9 @@ static void dispatch_t(rls_ctx* ctx, const E* A, int64_t lda, const E* x, E* y, 
   if (cols == 0) {
     // keep >= ~2 workgroups per CU while amortising the x loads over several columns
     cols = N >= 4096 ? 8 : (N >= 2048 ? 4 : (N >= 1024 ? 2 : 1));
+    // a matrix beyond the Infinity Cache streams from HBM: there two columns per workgroup are faster (8192 x 8192
+    // CF32, the config-5 shard: 86.9 us at 2 columns, 93.7 at 4, 100.8 at 8; tools/tune_gemv.py)
+    if ((double)M * (double)N * (double)sizeof(E) > 256.0 * 1024 * 1024 && cols > 2) cols = 2;
   }
   switch (cols) {
     case 8: launch_t<E, CONJ, NV, 8>(ctx, A, lda, x, y, M, N, alpha, beta, skip); break;
@@ -311,6 +314,9 @@ static void dispatch_n(rls_ctx* ctx, const E* A, int64_t lda, const E* x, E* y, 
   }
   const int64_t rb = (Mc + G - 1) / G;
   if (waves == 0) waves = rb <= 256 ? 16 : (rb <= 512 ? 8 : 4);
+  // out-of-cache matrices (see dispatch_t): 4 waves per workgroup stream best (8192 x 8192 CF32, G = 16: 87.8 us at 4
+  // waves, 92.7 at 8, 96.1 at 16)
+  if (ctx->tune.gemvn_waves == 0 && (double)M * (double)N * (double)sizeof(E) > 256.0 * 1024 * 1024) waves = 4;
   if constexpr (NV == 1) {
     dispatch_n_w<E, NV, 64>(ctx, waves, A, lda, x, y, M, N, alpha, beta, skip);
   } else {
