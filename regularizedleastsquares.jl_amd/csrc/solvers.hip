@@ -852,7 +852,22 @@ struct rls_cg {
   float *Ppack = nullptr, *Tpack = nullptr;
   void* Vpart = nullptr;
   int splits = 1;
+  // resident mode: cg! on (AHA + rho I) IS the CGNR recurrence, so after the start kernel the whole inner solve runs as
+  // ONE launch of cgnr_resident_kernel with A in registers (normal.hip)
+  void* rsync = nullptr;
+  double* rdots = nullptr;
+  bool resident_used = false;
 };
+
+// {fail, completed} of the plan's last resident launch (synchronises the stream)
+static int32_t cg_resident_check(rls_cg* s) {
+  if (!s->resident_used) return 0;
+  rls_ctx* ctx = s->op->ctx;
+  unsigned flags[2] = {0, 0};
+  RLS_HIP(ctx, hipMemcpyAsync(flags, (const char*)s->rsync + 8 * 32 * sizeof(unsigned), sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  return resident_check(ctx, flags, "cg!");
+}
 
 static bool cg_use_gram_pipeline(const rls_cg* s) {
   return s->gdots && s->op->G && s->op->ctx->tune.gram_pipeline;
@@ -1469,6 +1484,15 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     RLS_TRY(launch_status(ctx));
     rls_cgnr_pipe P = cg_pipe_desc(s, x);
     const int32_t dtype = op->dtype;
+    {
+      auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+      if (s->rsync && ctx->tune.resident && maxiter > 0 && al16(x) && al16(s->r) && al16(s->u) && al16(s->c)) {
+        s->resident_used = true;
+        return resident_chain(ctx, s->rsync, [&]() {
+          return rls_cgnr_resident_launch(ctx, dtype, P, s->rdots, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin);
+        });
+      }
+    }
     if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 1)) {  // the captured kernels carry x's address
       hipGraphExecDestroy(s->graph.exec);
       s->graph = step_graph();
@@ -2571,6 +2595,14 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
       return rls_fail(ctx, (int32_t)e, "cg_create: hipMalloc failed");
     }
   } else if (op->slab) {
+    if (op->A && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
+      const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
+      if (hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes()) != hipSuccess || hipMalloc((void**)&s->rdots, db) != hipSuccess) {
+        if (s->rsync) hipFree(s->rsync);
+        s->rsync = nullptr;  // an optimisation only: the two-launch pipeline runs without it
+        (void)hipGetLastError();
+      }
+    }
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
     const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double);
     hipError_t e = hipMalloc(&s->r1, vb);
@@ -2633,6 +2665,8 @@ int32_t rls_cg_destroy(rls_cg* s) {
   if (s->Ppack) hipFree(s->Ppack);
   if (s->Tpack) hipFree(s->Tpack);
   if (s->Vpart) hipFree(s->Vpart);
+  if (s->rsync) hipFree(s->rsync);
+  if (s->rdots) hipFree(s->rdots);
   if (s->r1) hipFree(s->r1);
   if (s->p1) hipFree(s->p1);
   if (s->dots) hipFree(s->dots);
@@ -2705,6 +2739,7 @@ int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_TRY(cg_resident_check(s));
   if (s->used_pipeline) {
     RLS_TRY(fetch_scalars(ctx, s->psc, s->psc_h));
     out->iterations = s->psc_h->iteration;
@@ -2918,6 +2953,7 @@ int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int
   rls_ctx* ctx = a->cg->op->ctx;
   if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_get_status before admm_init");
   if (a->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "admm_get_status on a batched plan: use rls_admm_get_status_batched");
+  RLS_TRY(cg_resident_check(a->cg));
   if (log_records < 0 || (log_records > 0 && !log_h)) return rls_fail(ctx, RLS_E_INVALID, "admm_get_status: bad log");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   const int nrec = a->enq < a->log_cap ? a->enq : a->log_cap;

@@ -2193,3 +2193,31 @@ def test_concurrent_solves_with_distinct_matrices(rls, ctx):
             x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=O.L1Regularization(0.02), rho=0.9 / (np.sqrt(192) + np.sqrt(64)) ** 2,
                                                                   iterations=20), b_), A, b)
         parity(f"concurrent_solves_problem{k}", xs[k], x64, x32, record=False)
+
+
+@pytest.mark.parametrize("kind", ["l1", "tv"])
+def test_admm_inner_cg_on_the_resident_kernel(rls, ctx, kind):
+    """cg! on (AHA + rho I) is the CGNR recurrence: at a shape whose A fits the register files the whole
+    inner solve of every ADMM outer iteration is ONE resident launch.  Same outer iteration count, same inner cg!
+    counts and the same solution gate as the two-launch pipeline (resident = 0), which the oracle pins"""
+    M, N = 4096, 2048
+    A, xt, b = O.make_problem(M, N, np.complex64, 87)
+    regs = (lambda R: R.L1Regularization(0.05)) if kind == "l1" else (lambda R: R.TVRegularization(2e-2, shape=(64, 32)))
+    kw = dict(rho=0.3, iterations=5, iterationsCG=6, tolInner=1e-4)
+    ref = O.ADMM(A, reg=regs(O), **kw)
+    O.solve(ref, b)
+    ref64 = O.ADMM(A.astype(np.complex128), reg=regs(O), **kw)
+    O.solve(ref64, b.astype(np.complex128))
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    out = {}
+    for res_on in (1, 0):
+        ctx.tune(resident=res_on)
+        try:
+            sol = rls.createLinearSolver(rls.ADMM, Ad, reg=regs(rls), **kw)
+            out[res_on] = rls.solve_(sol, bd).to_host()
+            assert sol.state._plan_ok and sol.state.iteration == ref.iteration and sol.state.cg_iterations == ref.cg_iters
+            again = rls.solve_(sol, bd).to_host()
+            assert np.array_equal(again, out[res_on])
+        finally:
+            ctx.tune(resident=1)
+        parity(f"admm_{kind}_4096x2048_c64_resident{res_on}", out[res_on], ref64.x, ref.x)
