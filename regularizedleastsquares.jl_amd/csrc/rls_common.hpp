@@ -519,19 +519,49 @@ struct rls_fista_gram {
 int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);
 int32_t rls_fista_gram_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);
 
+// One right-hand side's slot in an MFMA operand panel (skinny.hip).  Full layout: panel[g][n][16] elements, column b in
+// group b >> 4 at slot b & 15.  Half layout (complex, <= 8 columns): panel[n][16] floats = (re of 8 columns | im of 8).
+#ifdef __HIPCC__
+template <typename E>
+struct panel_col {
+  E* full;
+  float* half;
+  __device__ inline void put(int64_t i, E v) const {
+    if (half) {
+      half[16 * i] = elem<E>::re(v);
+      half[16 * i + 8] = elem<E>::im(v);
+    } else {
+      full[16 * i] = v;
+    }
+  }
+};
+template <typename E>
+__device__ static inline panel_col<E> panel_column(E* panel, int64_t n, int b, int half) {
+  panel_col<E> c;
+  c.full = half ? nullptr : panel + (int64_t)(b >> 4) * n * 16 + (b & 15);
+  c.half = half ? reinterpret_cast<float*>(panel) + (b & 7) : nullptr;
+  return c;
+}
+#endif
+
 // everything the matrix-core batched kernels need (skinny.hip)
 struct rls_skinny {
   const void* A;
   int64_t lda, M, N;
   int nrhs, ngroups, splits;  // ngroups = ceil(nrhs / 16); splits = row splits of the A^H T product
+  int half = 0;               // 1: complex, nrhs <= 8: ONE group whose 16 operand columns are (8 re | 8 im) floats
   void *X, *R, *P, *V;        // N x nrhs, columns ldv elements apart (caller's)
   int64_t ldv;
   float *Ppack, *Tpack;       // MFMA-operand layouts of P (N x 16 ngroups) and T (M x 16 ngroups)
-  void* Vpart;                // [splits][16 ngroups][ldvp] partial A^H T
+  void* Vpart;                // [splits][16 ngroups (8 when half)][ldvp] partial A^H T
   int64_t ldvp;               // elements between right-hand sides in Vpart (N for the solver plans)
   cgnr_scalars* sc;           // [nrhs]
 };
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
+// complex with at most 8 right-hand sides: the (re | im) operand packing (two MFMAs per complex block instead of four)
+int rls_skinny_half(int32_t dtype, int nrhs);
+static inline int rls_skinny_groups(int nrhs, int half) { return half ? 1 : (nrhs + 15) / 16; }
+static inline int rls_skinny_pad(int nrhs, int half) { return half ? 8 : ((nrhs + 15) / 16) * 16; }
 void rls_skinny_sizes(int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes, size_t* v_bytes,
                       int* splits);
 int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb, float lambda,

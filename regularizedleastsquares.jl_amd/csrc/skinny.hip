@@ -19,6 +19,7 @@
 // the loads with the MFMAs, two waves per SIMD do not (21.6 vs 13.6 us for T = A P); small load
 // batches beat deep ones (U = 4: 12.6 us, U = 16: 17.0 us); the MFMAs alone take 11.2 us.
 #include "rls_common.hpp"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -31,9 +32,11 @@ __device__ static inline f32x4 mfma4(float a, float b, f32x4 c) {
 // workgroup = 16 rows of A x all columns; wave w takes the 4-column blocks nb = w, w + WV, ...
 // lane l: A operand = A[16 mb + (l & 15)][4 nb + (l >> 4)], B operand = Pp[g][4 nb + (l >> 4)][l & 15]
 // ---------------------------------------------------------------------------------------------
-template <typename E, int WV, int U>
-__device__ static inline void t_load(E (&a)[U], E (&p)[U], const E* __restrict__ Ap, int64_t lda,
-                                     const E* __restrict__ Pg, int w, int64_t i0) {
+// PE = element type of the operand panel: E, or float for the half layout (lane l reads float
+// Pp[4 nb + (l >> 4)][l & 15] = re (slots 0..7) or im (slots 8..15) of right-hand side l & 7)
+template <typename E, typename PE, int WV, int U>
+__device__ static inline void t_load(E (&a)[U], PE (&p)[U], const E* __restrict__ Ap, int64_t lda,
+                                     const PE* __restrict__ Pg, int w, int64_t i0) {
   // no predication here: a select on a wave-uniform condition becomes a branch around the load, and the
   // compiler then waits vmcnt(0) instead of counting (the callers only pass in-range steps)
 #pragma unroll
@@ -44,11 +47,15 @@ __device__ static inline void t_load(E (&a)[U], E (&p)[U], const E* __restrict__
   }
 }
 
-template <typename E, int U>
-__device__ static inline void t_mma(f32x4 (&acc)[4], const E (&a)[U], const E (&p)[U]) {
+template <typename E, typename PE, int U>
+__device__ static inline void t_mma(f32x4 (&acc)[4], const E (&a)[U], const PE (&p)[U]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    if constexpr (elem<E>::cplx) {
+    if constexpr (!std::is_same<E, PE>::value) {
+      // half layout: ar x (pr | pi) and ai x (pr | pi) -- the same four FMA chains as below, in two instructions
+      acc[0] = mfma4(elem<E>::re(a[u]), p[u], acc[0]);
+      acc[1] = mfma4(elem<E>::im(a[u]), p[u], acc[1]);
+    } else if constexpr (elem<E>::cplx) {
       const float ar = elem<E>::re(a[u]), ai = elem<E>::im(a[u]);
       const float pr = elem<E>::re(p[u]), pi = elem<E>::im(p[u]);
       acc[0] = mfma4(ar, pr, acc[0]);
@@ -61,17 +68,19 @@ __device__ static inline void t_mma(f32x4 (&acc)[4], const E (&a)[U], const E (&
   }
 }
 
-template <typename E, int WV, int U>
+template <typename E, int WV, int U, bool H>
 __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__ A, int64_t lda,
                                                             const E* __restrict__ Pp, E* __restrict__ Tp, int64_t M,
                                                             int64_t N) {
   constexpr bool CX = elem<E>::cplx;
+  static_assert(!H || CX, "the half layout is a complex layout");
+  using PE = typename std::conditional<H, float, E>::type;
   __shared__ float red[WV][2][4][64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t mb = blockIdx.x, NB = N / 4;
   const int g = blockIdx.y;
-  const E* Pg = Pp + (int64_t)g * N * 16 + lane;
+  const PE* Pg = reinterpret_cast<const PE*>(Pp) + (int64_t)g * N * 16 + lane;
   const E* Ap = A + mb * 16 + (lane & 15) + (int64_t)(lane >> 4) * lda;
   f32x4 acc[4];
 #pragma unroll
@@ -81,36 +90,41 @@ __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__
   // a load, so the waits are counted (vmcnt(N)) and the next batch stays in flight under the MFMAs
   const int64_t nfull = ns / U;
   if (nfull > 0) {
-    E a0[U], a1[U], p0[U], p1[U];
-    t_load<E, WV, U>(a0, p0, Ap, lda, Pg, w, 0);
+    E a0[U], a1[U];
+    PE p0[U], p1[U];
+    t_load<E, PE, WV, U>(a0, p0, Ap, lda, Pg, w, 0);
     int64_t b = 0;
     for (; b + 2 < nfull; b += 2) {
       // sched_barrier: keep the whole next batch of loads AHEAD of this batch's MFMAs (the scheduler
       // otherwise sinks the loads towards their uses and the prefetch distance collapses)
-      t_load<E, WV, U>(a1, p1, Ap, lda, Pg, w, (b + 1) * U);
+      t_load<E, PE, WV, U>(a1, p1, Ap, lda, Pg, w, (b + 1) * U);
       __builtin_amdgcn_sched_barrier(0);
-      t_mma<E, U>(acc, a0, p0);
+      t_mma<E, PE, U>(acc, a0, p0);
       __builtin_amdgcn_sched_barrier(0);
-      t_load<E, WV, U>(a0, p0, Ap, lda, Pg, w, (b + 2) * U);
+      t_load<E, PE, WV, U>(a0, p0, Ap, lda, Pg, w, (b + 2) * U);
       __builtin_amdgcn_sched_barrier(0);
-      t_mma<E, U>(acc, a1, p1);
+      t_mma<E, PE, U>(acc, a1, p1);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (b + 1 < nfull) {
-      t_load<E, WV, U>(a1, p1, Ap, lda, Pg, w, (b + 1) * U);
-      t_mma<E, U>(acc, a0, p0);
-      t_mma<E, U>(acc, a1, p1);
+      t_load<E, PE, WV, U>(a1, p1, Ap, lda, Pg, w, (b + 1) * U);
+      t_mma<E, PE, U>(acc, a0, p0);
+      t_mma<E, PE, U>(acc, a1, p1);
     } else {
-      t_mma<E, U>(acc, a0, p0);
+      t_mma<E, PE, U>(acc, a0, p0);
     }
   }
   for (int64_t i = nfull * U; i < ns; ++i) {  // remainder steps, one at a time
-    E a2[1], p2[1];
-    t_load<E, WV, 1>(a2, p2, Ap, lda, Pg, w, i);
-    t_mma<E, 1>(acc, a2, p2);
+    E a2[1];
+    PE p2[1];
+    t_load<E, PE, WV, 1>(a2, p2, Ap, lda, Pg, w, i);
+    t_mma<E, PE, 1>(acc, a2, p2);
   }
   f32x4 tre, tim;
-  if constexpr (CX) {
+  if constexpr (H) {
+    tre = acc[0];  // combined across the (re | im) slots below
+    tim = acc[1];
+  } else if constexpr (CX) {
     tre = acc[0] - acc[1];
     tim = acc[2] + acc[3];
   } else {
@@ -124,6 +138,21 @@ __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__
     if constexpr (CX) red[w][1][t][lane] = tim[t];
   }
   __syncthreads();
+  if constexpr (H) {
+    // slot j < 8: re = ar pr - ai pi = acc0[j] - acc1[j + 8]; slot j >= 8: im = ar pi + ai pr = acc0[j] + acc1[j - 8]
+    // (per wave first, then over the waves: the same additions in the same order as the full layout)
+    float* out = reinterpret_cast<float*>(Tp) + mb * 16 * 16;
+    for (int idx = threadIdx.x; idx < 256; idx += WV * 64) {  // idx = row * 16 + slot
+      const int row = idx >> 4, j = idx & 15;
+      const int l = (row >> 2) * 16 + j, t = row & 3;
+      float val = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww)
+        val += j < 8 ? red[ww][0][t][l] - red[ww][1][t][l + 8] : red[ww][0][t][l] + red[ww][1][t][l - 8];
+      out[idx] = val;
+    }
+    return;
+  }
   E* out = Tp + ((int64_t)g * M + mb * 16) * 16;
   for (int idx = threadIdx.x; idx < 256; idx += WV * 64) {  // idx = row * 16 + j
     const int row = idx >> 4, j = idx & 15;
@@ -144,14 +173,14 @@ __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__
 // lane l (q = l >> 4): A operand of step register t = conj(A[16 mb + 4 q + t][n0 + (l & 15)]) (one 32-byte
 // piece of the column per lane), B operand = Tp[g][16 mb + 4 q + t][l & 15]
 // ---------------------------------------------------------------------------------------------
-template <typename E>
+template <typename E, typename PE>
 struct v_regs {
   float4 x0, x1;  // complex: rows (0,1), (2,3) as (re, im) pairs; real: x0 = rows 0..3
-  E t[4];
+  PE t[4];        // PE = E, or float for the half layout (slots 0..7 = re, 8..15 = im of 8 right-hand sides)
 };
 
-template <typename E, int WV, int U>
-__device__ static inline void v_load(v_regs<E> (&q)[U], const E* __restrict__ Ap, const E* __restrict__ Tg, int w,
+template <typename E, typename PE, int WV, int U>
+__device__ static inline void v_load(v_regs<E, PE> (&q)[U], const E* __restrict__ Ap, const PE* __restrict__ Tg, int w,
                                      int64_t lo, int64_t i0) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -159,17 +188,25 @@ __device__ static inline void v_load(v_regs<E> (&q)[U], const E* __restrict__ Ap
     const float4* ap = reinterpret_cast<const float4*>(Ap + mb * 16);
     q[u].x0 = ap[0];
     if constexpr (elem<E>::cplx) q[u].x1 = ap[1];
-    const E* tp = Tg + mb * 256;
+    const PE* tp = Tg + mb * 256;
 #pragma unroll
     for (int t = 0; t < 4; ++t) q[u].t[t] = tp[t * 16];
   }
 }
 
-template <typename E, int U>
-__device__ static inline void v_mma(f32x4 (&acc)[4], const v_regs<E> (&q)[U]) {
+template <typename E, typename PE, int U>
+__device__ static inline void v_mma(f32x4 (&acc)[4], const v_regs<E, PE> (&q)[U]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    if constexpr (elem<E>::cplx) {
+    if constexpr (!std::is_same<E, PE>::value) {
+      const float ar[4] = {q[u].x0.x, q[u].x0.z, q[u].x1.x, q[u].x1.z};
+      const float ai[4] = {q[u].x0.y, q[u].x0.w, q[u].x1.y, q[u].x1.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0] = mfma4(ar[t], q[u].t[t], acc[0]);  // ar x (tr | ti)
+        acc[1] = mfma4(ai[t], q[u].t[t], acc[1]);  // ai x (tr | ti)
+      }
+    } else if constexpr (elem<E>::cplx) {
       const float ar[4] = {q[u].x0.x, q[u].x0.z, q[u].x1.x, q[u].x1.z};
       const float ai[4] = {q[u].x0.y, q[u].x0.w, q[u].x1.y, q[u].x1.w};
 #pragma unroll
@@ -188,11 +225,13 @@ __device__ static inline void v_mma(f32x4 (&acc)[4], const v_regs<E> (&q)[U]) {
   }
 }
 
-template <typename E, int WV, int U>
+template <typename E, int WV, int U, bool H>
 __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__ A, int64_t lda,
                                                             const E* __restrict__ Tp, E* __restrict__ Vpart,
                                                             int64_t M, int64_t N, int nrhs_pad, int64_t ldvp) {
   constexpr bool CX = elem<E>::cplx;
+  static_assert(!H || CX, "the half layout is a complex layout");
+  using PE = typename std::conditional<H, float, E>::type;
   __shared__ float red[WV][2][4][64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -200,41 +239,44 @@ __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__
   const int s = blockIdx.y, S = gridDim.y, g = blockIdx.z;
   const int64_t lo = s * MB / S, hi = (s + 1) * MB / S;
   const E* Ap = A + (n0 + (lane & 15)) * lda + 4 * (lane >> 4);
-  const E* Tg = Tp + (int64_t)g * M * 16 + (lane >> 4) * 64 + (lane & 15);
+  const PE* Tg = reinterpret_cast<const PE*>(Tp) + (int64_t)g * M * 16 + (lane >> 4) * 64 + (lane & 15);
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int64_t ns = hi - lo > w ? (hi - lo - w + WV - 1) / WV : 0;
   const int64_t nfull = ns / U;
   if (nfull > 0) {
-    v_regs<E> q0[U], q1[U];
-    v_load<E, WV, U>(q0, Ap, Tg, w, lo, 0);
+    v_regs<E, PE> q0[U], q1[U];
+    v_load<E, PE, WV, U>(q0, Ap, Tg, w, lo, 0);
     int64_t b = 0;
     for (; b + 2 < nfull; b += 2) {
-      v_load<E, WV, U>(q1, Ap, Tg, w, lo, (b + 1) * U);
+      v_load<E, PE, WV, U>(q1, Ap, Tg, w, lo, (b + 1) * U);
       __builtin_amdgcn_sched_barrier(0);
-      v_mma<E, U>(acc, q0);
+      v_mma<E, PE, U>(acc, q0);
       __builtin_amdgcn_sched_barrier(0);
-      v_load<E, WV, U>(q0, Ap, Tg, w, lo, (b + 2) * U);
+      v_load<E, PE, WV, U>(q0, Ap, Tg, w, lo, (b + 2) * U);
       __builtin_amdgcn_sched_barrier(0);
-      v_mma<E, U>(acc, q1);
+      v_mma<E, PE, U>(acc, q1);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (b + 1 < nfull) {
-      v_load<E, WV, U>(q1, Ap, Tg, w, lo, (b + 1) * U);
-      v_mma<E, U>(acc, q0);
-      v_mma<E, U>(acc, q1);
+      v_load<E, PE, WV, U>(q1, Ap, Tg, w, lo, (b + 1) * U);
+      v_mma<E, PE, U>(acc, q0);
+      v_mma<E, PE, U>(acc, q1);
     } else {
-      v_mma<E, U>(acc, q0);
+      v_mma<E, PE, U>(acc, q0);
     }
   }
   for (int64_t i = nfull * U; i < ns; ++i) {
-    v_regs<E> q2[1];
-    v_load<E, WV, 1>(q2, Ap, Tg, w, lo, i);
-    v_mma<E, 1>(acc, q2);
+    v_regs<E, PE> q2[1];
+    v_load<E, PE, WV, 1>(q2, Ap, Tg, w, lo, i);
+    v_mma<E, PE, 1>(acc, q2);
   }
   f32x4 vre, vim;
-  if constexpr (CX) {
+  if constexpr (H) {
+    vre = acc[0];  // combined across the (re | im) slots below
+    vim = acc[1];
+  } else if constexpr (CX) {
     vre = acc[0] + acc[1];
     vim = acc[2] - acc[3];
   } else {
@@ -247,6 +289,21 @@ __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__
     if constexpr (CX) red[w][1][u][lane] = vim[u];
   }
   __syncthreads();
+  if constexpr (H) {
+    // re = ar tr + ai ti = acc0[j] + acc1[j + 8], im = ar ti - ai tr = acc0[j + 8] - acc1[j]   (j < 8)
+    for (int idx = threadIdx.x; idx < 128; idx += WV * 64) {  // idx = j * 16 + column
+      const int j = idx >> 4, c = idx & 15;
+      const int l = (c >> 2) * 16 + j, u = c & 3;
+      float re = 0.f, im = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) {
+        re += red[ww][0][u][l] + red[ww][1][u][l + 8];
+        im += red[ww][0][u][l + 8] - red[ww][1][u][l];
+      }
+      Vpart[((int64_t)s * nrhs_pad + j) * ldvp + n0 + c] = elem<E>::make(re, im);
+    }
+    return;
+  }
   // accumulator register u of lane (q, j) is V[n0 + 4 q + u][j]; stored per right-hand side (16 columns
   // = one 128-byte line each) so that the update kernel reads its column contiguously
   for (int idx = threadIdx.x; idx < 256; idx += WV * 64) {  // idx = j * 16 + column
@@ -265,7 +322,7 @@ __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__
 // ---------------------------------------------------------------------------------------------
 // B (M x nrhs, column-major) -> Tp panels, so that the init product A^H B runs on skinny_v_kernel
 // ---------------------------------------------------------------------------------------------
-template <typename E>
+template <typename E, bool H>
 __global__ __launch_bounds__(256) void skinny_pack_rows_kernel(const E* __restrict__ B, int64_t ldb, int nrhs,
                                                                E* __restrict__ Tp, int64_t M, int ngroups) {
   __shared__ E tile[16][65];
@@ -280,7 +337,13 @@ __global__ __launch_bounds__(256) void skinny_pack_rows_kernel(const E* __restri
   __syncthreads();
   for (int idx = threadIdx.x; idx < 1024; idx += 256) {
     const int r = idx >> 4, j = idx & 15;
-    if (m0 + r < M) Tp[((int64_t)g * M + m0 + r) * 16 + j] = tile[j][r];
+    if (m0 + r >= M) continue;
+    if constexpr (H) {  // slots 0..7 = re, 8..15 = im of right-hand side j & 7
+      const E t = tile[j & 7][r];
+      reinterpret_cast<float*>(Tp)[(m0 + r) * 16 + j] = j < 8 ? elem<E>::re(t) : elem<E>::im(t);
+    } else {
+      Tp[((int64_t)g * M + m0 + r) * 16 + j] = tile[j][r];
+    }
   }
 }
 
@@ -337,8 +400,9 @@ template <typename E, bool INIT, int EPT, int NT>
 __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __restrict__ R, E* __restrict__ P,
                                                                E* __restrict__ V, int64_t ldv,
                                                                const E* __restrict__ Vpart, int S, int nrhs_pad,
-                                                               int64_t N, E* __restrict__ Pp, cgnr_scalars* scv,
-                                                               float lambda_in, float rel_tol, int max_iter) {
+                                                               int64_t N, E* __restrict__ Pp, int half,
+                                                               cgnr_scalars* scv, float lambda_in, float rel_tol,
+                                                               int max_iter) {
   __shared__ double sm[48];
   const int b = blockIdx.x;
   cgnr_scalars* sc = scv + b;
@@ -346,7 +410,7 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
   E* r = R + (int64_t)b * ldv;
   E* p = P + (int64_t)b * ldv;
   E* v = V + (int64_t)b * ldv;
-  E* pp_out = Pp + (int64_t)(b >> 4) * N * 16 + (b & 15);  // Pp[g][n][j]: element n at pp_out[16 n]
+  const panel_col<E> pp_out = panel_column<E>(Pp, N, b, half);
   if constexpr (INIT) {
     double rr = 0.0;
     for (int64_t i = threadIdx.x; i < N; i += NT) {
@@ -355,7 +419,7 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
       v[i] = elem<E>::zero();
       r[i] = ri;
       p[i] = ri;
-      pp_out[16 * i] = ri;
+      pp_out.put(i, ri);
       rr += abs2d<E>(ri);
     }
     rr = block_sum(rr, sm);
@@ -436,7 +500,7 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
         r[i] = rv[e];
         v[i] = vv[e];
         p[i] = pn;
-        pp_out[16 * i] = pn;
+        pp_out.put(i, pn);
       }
     }
     if (threadIdx.x == 0) {  // cg_scalars_step on the copy fetched at entry (no second fetch at the tail)
@@ -485,7 +549,7 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
     for (int64_t i = threadIdx.x; i < N; i += NT) {
       const E pn = elem<E>::add(elem<E>::scale(bf, p[i]), r[i]);
       p[i] = pn;
-      pp_out[16 * i] = pn;
+      pp_out.put(i, pn);
     }
     if (threadIdx.x == 0) cg_scalars_step(sc, zeta, rr, alpha, beta);
   }
@@ -496,6 +560,7 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
 // ---------------------------------------------------------------------------------------------
 // measurement overrides (rls_tune_set "skinny_*"); defaults from tools/skinny_probe.py on MI355X
 static int g_t_waves = 4, g_t_u = 4, g_v_waves = 4, g_v_u = 1, g_v_splits = 0;
+static int g_half = 1;  // rls_tune_set "skinny_half": the (re | im) operand packing for <= 8 complex right-hand sides
 // dynamic LDS requested by the Gram tile kernel purely as an occupancy limiter: one workgroup (one wave per SIMD)
 // per CU keeps the MFMA pipe fed by a single instruction stream (0.92 ms vs 1.05 ms with three co-resident
 // workgroups at 4096 x 2048 CF32); rls_tune_set "gram_lds_kib"
@@ -507,6 +572,7 @@ void rls_skinny_tune(int which, int value) {
   if (which == 4) g_t_u = value;
   if (which == 5) g_v_u = value;
   if (which == 6) g_gram_lds = value * 1024;
+  if (which == 7) g_half = value;
 }
 
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
@@ -528,10 +594,15 @@ static int skinny_splits(int64_t M, int64_t N, int /*ngroups*/) {
   return (int)S;
 }
 
+int rls_skinny_half(int32_t dtype, int nrhs) { return g_half && dtype == RLS_C32 && nrhs <= 8; }
+
 void rls_skinny_sizes(int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes, size_t* v_bytes,
                       int* splits) {
-  const int G = (nrhs + 15) / 16;
+  const int half = rls_skinny_half(dtype, nrhs);
+  const int G = rls_skinny_groups(nrhs, half);
   const int S = skinny_splits(M, N, G);
+  // the half layout holds 16 floats (8 re | 8 im) per row where the full one holds 16 elements; sized for the
+  // full layout either way so that the switch can be flipped on a live plan by the measurement tools
   *p_bytes = (size_t)G * N * 16 * rls_elem_size(dtype);
   *t_bytes = (size_t)G * M * 16 * rls_elem_size(dtype);
   *v_bytes = (size_t)S * G * 16 * N * rls_elem_size(dtype);
@@ -547,38 +618,56 @@ static int32_t sk_status(rls_ctx* ctx) {
 template <typename E>
 static void launch_t(rls_ctx* ctx, const rls_skinny& K) {
   const dim3 grid((unsigned)(K.M / 16), (unsigned)K.ngroups);
-#define SK_T(W, UU)                                                                                                \
+#define SK_T(W, UU, HH)                                                                                            \
   if (g_t_waves == W && g_t_u == UU) {                                                                             \
-    hipLaunchKernelGGL((skinny_t_kernel<E, W, UU>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda,     \
+    hipLaunchKernelGGL((skinny_t_kernel<E, W, UU, HH>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda, \
                        (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);                                                  \
     return;                                                                                                        \
   }
-  SK_T(8, 4) SK_T(8, 8) SK_T(4, 8) SK_T(4, 2) SK_T(4, 16) SK_T(2, 4)
+  if constexpr (elem<E>::cplx) {
+    if (K.half) {
+      SK_T(8, 4, true) SK_T(8, 8, true) SK_T(4, 8, true) SK_T(4, 2, true) SK_T(4, 16, true) SK_T(2, 4, true)
+      SK_T(8, 2, true) SK_T(8, 16, true)
+      hipLaunchKernelGGL((skinny_t_kernel<E, 4, 4, true>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
+                         (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);
+      return;
+    }
+  }
+  SK_T(8, 4, false) SK_T(8, 8, false) SK_T(4, 8, false) SK_T(4, 2, false) SK_T(4, 16, false) SK_T(2, 4, false)
 #undef SK_T
-  hipLaunchKernelGGL((skinny_t_kernel<E, 4, 4>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
+  hipLaunchKernelGGL((skinny_t_kernel<E, 4, 4, false>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
                      (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);
 }
 
 template <typename E>
 static void launch_v(rls_ctx* ctx, const rls_skinny& K) {
   const dim3 grid((unsigned)(K.N / 16), (unsigned)K.splits, (unsigned)K.ngroups);
-#define SK_V(W, UU)                                                                                                \
+  const int pad = rls_skinny_pad(K.nrhs, K.half);
+#define SK_V(W, UU, HH)                                                                                            \
   if (g_v_waves == W && g_v_u == UU) {                                                                             \
-    hipLaunchKernelGGL((skinny_v_kernel<E, W, UU>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda,     \
-                       (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16, K.ldvp);                                  \
+    hipLaunchKernelGGL((skinny_v_kernel<E, W, UU, HH>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda, \
+                       (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);                                     \
     return;                                                                                                        \
   }
-  SK_V(8, 1) SK_V(8, 2) SK_V(4, 2) SK_V(4, 4) SK_V(2, 1) SK_V(2, 2)
+  if constexpr (elem<E>::cplx) {
+    if (K.half) {
+      SK_V(8, 1, true) SK_V(8, 2, true) SK_V(4, 2, true) SK_V(4, 4, true) SK_V(2, 1, true) SK_V(2, 2, true)
+      hipLaunchKernelGGL((skinny_v_kernel<E, 4, 1, true>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
+                         (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);
+      return;
+    }
+  }
+  SK_V(8, 1, false) SK_V(8, 2, false) SK_V(4, 2, false) SK_V(4, 4, false) SK_V(2, 1, false) SK_V(2, 2, false)
 #undef SK_V
-  hipLaunchKernelGGL((skinny_v_kernel<E, 4, 1>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
-                     (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, K.ngroups * 16, K.ldvp);
+  hipLaunchKernelGGL((skinny_v_kernel<E, 4, 1, false>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda,
+                     (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);
 }
 
 template <typename E, bool INIT, int EPT, int NT>
 static void launch_u_ept(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_tol, int max_iter) {
   hipLaunchKernelGGL((skinny_u_kernel<E, INIT, EPT, NT>), dim3((unsigned)K.nrhs), dim3(NT), 0, ctx->stream,
-                     (E*)K.X, (E*)K.R, (E*)K.P, (E*)K.V, K.ldv, (const E*)K.Vpart, K.splits, K.ngroups * 16, K.N,
-                     (E*)K.Ppack, K.sc, lambda, rel_tol, max_iter);
+                     (E*)K.X, (E*)K.R, (E*)K.P, (E*)K.V, K.ldv, (const E*)K.Vpart, K.splits,
+                     rls_skinny_pad(K.nrhs, K.half), K.N, (E*)K.Ppack, K.half, K.sc, lambda, rel_tol, max_iter);
 }
 
 template <typename E, bool INIT>
@@ -596,11 +685,23 @@ static void launch_u(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_
 }
 
 template <typename E>
+static void launch_pack_rows(rls_ctx* ctx, const rls_skinny& K, const E* B, int64_t ldb) {
+  const dim3 grid((unsigned)((K.M + 63) / 64), (unsigned)K.ngroups);
+  if constexpr (elem<E>::cplx) {
+    if (K.half) {
+      hipLaunchKernelGGL((skinny_pack_rows_kernel<E, true>), grid, dim3(256), 0, ctx->stream, B, ldb, K.nrhs,
+                         (E*)K.Tpack, K.M, K.ngroups);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((skinny_pack_rows_kernel<E, false>), grid, dim3(256), 0, ctx->stream, B, ldb, K.nrhs, (E*)K.Tpack,
+                     K.M, K.ngroups);
+}
+
+template <typename E>
 static int32_t skinny_init_typed(rls_ctx* ctx, const rls_skinny& K, const void* B, int64_t ldb, float lambda,
                                  float rel_tol, int max_iter) {
-  const dim3 grid((unsigned)((K.M + 63) / 64), (unsigned)K.ngroups);
-  hipLaunchKernelGGL(skinny_pack_rows_kernel<E>, grid, dim3(256), 0, ctx->stream, (const E*)B, ldb, K.nrhs,
-                     (E*)K.Tpack, K.M, K.ngroups);
+  launch_pack_rows<E>(ctx, K, (const E*)B, ldb);
   launch_v<E>(ctx, K);
   launch_u<E, true>(ctx, K, lambda, rel_tol, max_iter);
   return sk_status(ctx);
@@ -614,14 +715,11 @@ int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const 
 
 // partial rows of A^H B into K.Vpart (B: M x nrhs column-major): the init product of the batched plans
 int32_t rls_skinny_atb(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb) {
-  const dim3 grid((unsigned)((K.M + 63) / 64), (unsigned)K.ngroups);
   if (dtype == RLS_F32) {
-    hipLaunchKernelGGL(skinny_pack_rows_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)B, ldb, K.nrhs,
-                       (float*)K.Tpack, K.M, K.ngroups);
+    launch_pack_rows<float>(ctx, K, (const float*)B, ldb);
     launch_v<float>(ctx, K);
   } else {
-    hipLaunchKernelGGL(skinny_pack_rows_kernel<float2>, grid, dim3(256), 0, ctx->stream, (const float2*)B, ldb, K.nrhs,
-                       (float2*)K.Tpack, K.M, K.ngroups);
+    launch_pack_rows<float2>(ctx, K, (const float2*)B, ldb);
     launch_v<float2>(ctx, K);
   }
   return sk_status(ctx);
@@ -781,7 +879,8 @@ static int32_t skinny_gram_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A,
   K.Vpart = G;
   K.ldvp = ldg;
   const dim3 grid((unsigned)((M + 63) / 64), (unsigned)K.ngroups);
-  hipLaunchKernelGGL(skinny_pack_rows_kernel<E>, grid, dim3(256), 0, ctx->stream, A, lda, (int)N, panels, M, K.ngroups);
+  hipLaunchKernelGGL((skinny_pack_rows_kernel<E, false>), grid, dim3(256), 0, ctx->stream, A, lda, (int)N, panels, M,
+                     K.ngroups);
   launch_v<E>(ctx, K);
   return sk_status(ctx);
 }

@@ -130,6 +130,7 @@ struct rls_cgnr {
   float *Ppack, *Tpack;
   void* Vpart;
   int splits;
+  int half;  // operand-panel layout, fixed at creation (rls_skinny_half)
   // resident mode (normal.hip, cgnr_resident_kernel): arrival counters + flags, per-workgroup partial dots
   void* rsync;
   double* rdots;
@@ -166,7 +167,8 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
   K.M = s->op->M;
   K.N = s->op->N;
   K.nrhs = s->nrhs;
-  K.ngroups = (s->nrhs + 15) / 16;
+  K.half = s->half;
+  K.ngroups = rls_skinny_groups(s->nrhs, s->half);
   K.splits = s->splits;
   K.X = s->x;
   K.R = s->r;
@@ -490,6 +492,7 @@ struct rls_fista {
   float *Ypack = nullptr, *Tpack = nullptr;
   void* Vpart = nullptr;
   int splits = 1;
+  int half = 0;  // operand-panel layout, fixed at creation (rls_skinny_half)
   fista_scalars* scb_h = nullptr;  // pinned [nrhs]
   int enq = 0;           // iterations enqueued since init (== the device's count unless the plan stopped early)
   int graph_parity = 0;  // parity of `enq` the cached graph's buffer hints were captured with
@@ -508,6 +511,7 @@ struct fista_batch {
   const E* Vpart;
   int S, nrhs_pad;
   E* Yp;
+  int half;  // operand-panel layout (rls_common.hpp, panel_col)
 };
 template <typename E>
 __device__ static inline E fista_parts(const fista_batch<E>& B, int b, int64_t N, int64_t i) {
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__
   res += b * Bt.ldv;
   y += b * Bt.ldv;
   sc += b;
-  E* yp = Bt.Yp ? Bt.Yp + (int64_t)(b >> 4) * n * 16 + (b & 15) : nullptr;
+  const panel_col<E> yp = panel_column<E>(Bt.Yp, n, b, Bt.half);
   double nn = 0.0;
   const float inf = __builtin_huge_valf();
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__
     b0[i] = elem<E>::zero();
     b1[i] = elem<E>::zero();
     y[i] = elem<E>::zero();
-    if (yp) yp[16 * i] = elem<E>::zero();
+    if (Bt.Yp) yp.put(i, elem<E>::zero());
     res[i] = elem<E>::make(inf, 0.f);
   }
   nn = block_sum(nn, sm);
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
   res += b * Bt.ldv;
   y += b * Bt.ldv;
   sc += b;
-  E* yp = Bt.Yp ? Bt.Yp + (int64_t)(b >> 4) * n * 16 + (b & 15) : nullptr;
+  const panel_col<E> yp = panel_column<E>(Bt.Yp, n, b, Bt.half);
   if (sc->done) return;  // a retired column keeps its panel entry (src/MultiThreading.jl:60-78)
   __shared__ double sm[16];
   const int it = sc->iteration;
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
     for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
       const E yi = elem<E>::add(elem<E>::scale(c1, xold[i]), elem<E>::scale(c2, xnew[i]));
       y[i] = yi;
-      if (yp) yp[16 * i] = yi;
+      if (Bt.Yp) yp.put(i, yi);
     }
   }
   if (threadIdx.x == 0) {
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_reg_kernel(E* __rest
   res += b * Bt.ldv;
   y += b * Bt.ldv;
   sc += b;
-  E* yp = Bt.Yp ? Bt.Yp + (int64_t)(b >> 4) * n * 16 + (b & 15) : nullptr;
+  const panel_col<E> yp = panel_column<E>(Bt.Yp, n, b, Bt.half);
   __shared__ double sm[16];
   const int done0 = sc->done, it = sc->iteration, reg_kind = sc->reg_kind, proj_kind = sc->proj_kind;
   const int restart = sc->restart, max_iter = sc->max_iter;
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_reg_kernel(E* __rest
       if (!done) {  // next iteration's Nesterov step, formed out of place in y                         :147-148
         const E yi = elem<E>::add(elem<E>::scale(c1, xo[e]), elem<E>::scale(c2, xn[e]));
         y[i] = yi;
-        if (yp) yp[16 * i] = yi;
+        if (Bt.Yp) yp.put(i, yi);
       }
     }
   }
@@ -814,9 +818,9 @@ static int32_t fista_enqueue_iteration(rls_fista* s) {
   rls_operator* op = s->op;
   RLS_TRY(op_normal(op, s->y, s->res, &s->sc->done));
   if (op->dtype == RLS_F32)
-    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0});
   else
-    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0});
   return launch_status(op->ctx);
 }
 
@@ -850,6 +854,7 @@ struct rls_cg {
   int nrhs = 1;
   int64_t ldv = 0;
   float *Ppack = nullptr, *Tpack = nullptr;
+  int half = 0;  // operand-panel layout, fixed at creation (rls_skinny_half)
   void* Vpart = nullptr;
   int splits = 1;
   // resident mode: cg! on (AHA + rho I) IS the CGNR recurrence, so after the start kernel the whole inner solve runs as
@@ -940,6 +945,7 @@ struct col_batch {
   const E* Vpart = nullptr;
   int S = 1, nrhs_pad = 16;
   E* panel = nullptr;       // operand panel [group][n][16]: column b -> panel + (b >> 4) * n * 16 + (b & 15), stride 16
+  int half = 0;             // ... or the (8 re | 8 im) layout of at most 8 complex columns (rls_common.hpp, panel_col)
   int skip_stride = 0;      // ints between the columns' skip flags
   int64_t log_stride = 0;   // floats between the columns' ADMM logs
 };
@@ -951,11 +957,12 @@ __device__ static inline E col_parts(const col_batch<E>& B, int b, int64_t N, in
 }
 // X (N x K) -> operand panel, ahead of the warm-start apply AHA x of every outer iteration
 template <typename E>
-__global__ __launch_bounds__(256) void pack_panel_kernel(const E* __restrict__ X, int64_t ldv, E* __restrict__ panel, int64_t n) {
+__global__ __launch_bounds__(256) void pack_panel_kernel(const E* __restrict__ X, int64_t ldv, E* __restrict__ panel, int64_t n,
+                                                         int half) {
   const int b = blockIdx.y;
-  E* up = panel + (int64_t)(b >> 4) * n * 16 + (b & 15);
+  const panel_col<E> up = panel_column<E>(panel, n, b, half);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    up[16 * i] = X[(int64_t)b * ldv + i];
+    up.put(i, X[(int64_t)b * ldv + i]);
 }
 template <typename E>
 __device__ static inline E admm_rhs(const admm_fuse<E>& F, const E* b, const E* x, int64_t i) {
@@ -1080,7 +1087,7 @@ __global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restri
     if (F.skip) F.skip += (int64_t)bq * B.skip_stride;
     sc += bq;
   }
-  E* up = B.panel ? B.panel + (int64_t)(bq >> 4) * n * 16 + (bq & 15) : nullptr;
+  const panel_col<E> up = panel_column<E>(B.panel, n, bq, B.half);
   if (F.skip && *F.skip) {
     if (threadIdx.x == 0) {
       sc->iteration = 0;
@@ -1096,7 +1103,7 @@ __global__ __launch_bounds__(UPD_THREADS) void cg_start_kernel(const E* __restri
     const E ri = elem<E>::sub(admm_rhs<E>(F, b, x, i), ci);
     r[i] = ri;
     u[i] = ri;  // first iteration: beta = residual^2 / 1^2 multiplies u == 0
-    if (up) up[16 * i] = ri;
+    if (B.panel) up.put(i, ri);
     rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
   }
   rr = block_sum(rr, sm);
@@ -1127,7 +1134,7 @@ __global__ __launch_bounds__(UPD_THREADS) void cg_update_kernel(E* __restrict__ 
     sc += bq;
   }
   if (sc->done) return;
-  E* up = B.panel ? B.panel + (int64_t)(bq >> 4) * n * 16 + (bq & 15) : nullptr;
+  const panel_col<E> up = panel_column<E>(B.panel, n, bq, B.half);
   __shared__ double sm[16];
   const float rho = sc->rho;
   double dre = 0.0, dim_ = 0.0;
@@ -1162,7 +1169,7 @@ __global__ __launch_bounds__(UPD_THREADS) void cg_update_kernel(E* __restrict__ 
     for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
       const E un = elem<E>::add(r[i], elem<E>::scale(beta, u[i]));
       u[i] = un;
-      if (up) up[16 * i] = un;
+      if (B.panel) up.put(i, un);
     }
   }
   if (threadIdx.x == 0) {
@@ -1382,7 +1389,8 @@ static rls_skinny fista_skinny_desc(const rls_fista* s) {
   K.M = s->op->M;
   K.N = s->op->N;
   K.nrhs = s->nrhs;
-  K.ngroups = (s->nrhs + 15) / 16;
+  K.half = s->half;
+  K.ngroups = rls_skinny_groups(s->nrhs, s->half);
   K.splits = s->splits;
   K.X = K.R = K.P = K.V = nullptr;
   K.ldv = s->ldv;
@@ -1396,7 +1404,7 @@ static rls_skinny fista_skinny_desc(const rls_fista* s) {
 
 template <typename E>
 static fista_batch<E> fista_batch_desc(const rls_fista* s) {
-  return fista_batch<E>{s->ldv, (const E*)s->Vpart, s->splits, ((s->nrhs + 15) / 16) * 16, (E*)s->Ypack};
+  return fista_batch<E>{s->ldv, (const E*)s->Vpart, s->splits, rls_skinny_pad(s->nrhs, s->half), (E*)s->Ypack, s->half};
 }
 
 static int32_t fista_enqueue_batched(rls_fista* s) {
@@ -1541,7 +1549,8 @@ static rls_skinny cg_skinny_desc(const rls_cg* s) {
   K.M = s->op->M;
   K.N = s->op->N;
   K.nrhs = s->nrhs;
-  K.ngroups = (s->nrhs + 15) / 16;
+  K.half = s->half;
+  K.ngroups = rls_skinny_groups(s->nrhs, s->half);
   K.splits = s->splits;
   K.X = K.R = K.P = K.V = nullptr;
   K.ldv = s->ldv;
@@ -1566,8 +1575,9 @@ static int32_t admm_step_batched_typed(rls_admm* a, int32_t n_outer) {
   B.ldv = cg->ldv;
   B.Vpart = (const E*)cg->Vpart;
   B.S = cg->splits;
-  B.nrhs_pad = ((a->nrhs + 15) / 16) * 16;
+  B.nrhs_pad = rls_skinny_pad(a->nrhs, cg->half);
   B.panel = (E*)cg->Ppack;
+  B.half = cg->half;
   B.skip_stride = (int)(sizeof(admm_scalars) / sizeof(int));
   B.log_stride = (int64_t)ADMM_REC * a->log_cap;
   col_batch<E> Bz = B;  // the z / u kernel reads no partial rows and writes no panel
@@ -1577,7 +1587,7 @@ static int32_t admm_step_batched_typed(rls_admm* a, int32_t n_outer) {
     E* zcur = (E*)((a->enq & 1) ? P.z1 : P.z0);
     E* znew = (E*)((a->enq & 1) ? P.z0 : P.z1);
     hipLaunchKernelGGL(pack_panel_kernel<E>, dim3((unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64), K), dim3(256), 0,
-                       ctx->stream, (const E*)P.x, cg->ldv, (E*)cg->Ppack, n);
+                       ctx->stream, (const E*)P.x, cg->ldv, (E*)cg->Ppack, n, cg->half);
     RLS_TRY(rls_skinny_launch(ctx, dtype, SK, 1 | 2));  // AHA x of every column  (:244, warm start)
     admm_fuse<E> F;
     F.beta_y = (const E*)P.beta_y;
@@ -1794,6 +1804,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   if (e == hipSuccess && skinny) {
     size_t pb, tb, vb;
     rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+    s->half = rls_skinny_half(op->dtype, nrhs);
     e = hipMalloc((void**)&s->Ppack, pb);
     if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
     if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
@@ -2266,12 +2277,12 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
     hipLaunchKernelGGL(fista_init_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
                        (float*)s->buf[1], (float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc, rho, theta,
                        rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices, fista_batch<float>{0, nullptr, 1, 0, nullptr});
+                       (long long)s->l21_slices, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0});
   else
     hipLaunchKernelGGL(fista_init_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)s->buf[0],
                        (float2*)s->buf[1], (float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc, rho,
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
+                       (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0});
   s->enq = 0;
   s->theta0 = theta;
   s->initialised = true;
@@ -2314,9 +2325,9 @@ int32_t rls_fista_step_local_b(rls_fista* s) {
   if (!s->initialised || s->use_pipe || s->use_gram) return rls_fail(ctx, RLS_E_STATE, "fista_step_local before fista_init_local_b");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (op->dtype == RLS_F32)
-    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0});
   else
-    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr});
+    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0});
   return launch_status(ctx);
 }
 
@@ -2351,6 +2362,7 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   s->sc = s->sc_h = nullptr;
   size_t pb, tb, vb;
   rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+  s->half = rls_skinny_half(op->dtype, nrhs);
   const size_t yb = (size_t)ldv * nrhs * rls_elem_size(op->dtype);
   hipError_t e = hipMalloc(&s->y, yb);
   if (e == hipSuccess) e = hipMalloc((void**)&s->Ypack, pb);
@@ -2646,6 +2658,7 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
   s->ldv = ldv;
   size_t pb, tb, vb;
   rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+  s->half = rls_skinny_half(op->dtype, nrhs);
   hipError_t e = hipMalloc((void**)&s->Ppack, pb);
   if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
   if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);

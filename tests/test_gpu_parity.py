@@ -881,6 +881,38 @@ def _batched_case(rls, ctx, dt, M, N, K):
     parity(f"batched_then_vector_{M}x{N}_{np.dtype(dt).name}", v, x64, x32)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 8), (272, 144, 3), (1040, 208, 7)])
+def test_batched_half_operand_panels_change_no_bit(rls, ctx, M, N, K):
+    """Up to 8 ComplexF32 right-hand sides ride the matrix cores as (8 re | 8 im) operand columns -- two MFMAs per
+    complex block instead of four (csrc/skinny.hip, H = true).  The four FMA chains per output element are the same
+    chains in the same order as in the 16-column layout, so CGNR, FISTA and ADMM batched solves must agree with the
+    full layout bit for bit (and a column's result must not depend on the layout its batch happened to get)."""
+    A, X, B = O.make_problem(M, N, np.complex64, 41, n_rhs=K)
+    B = np.asfortranarray(B)
+    Ad = rls.DeviceMatrix.from_host(A)
+    Bd = rls.DeviceMatrix.from_host(B)
+    makers = {
+        "cgnr": lambda: rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=9, relTol=0.0),
+        # explicit step size: the default is a power iteration from a random start (src/FISTA.jl:76), new per solver
+        "fista": lambda: rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-3), iterations=9, relTol=0.0,
+                                                rho=float(8.0 / np.linalg.norm(A) ** 2)),
+        "admm": lambda: rls.createLinearSolver(rls.ADMM, Ad, reg=rls.L1Regularization(1e-3), rho=0.1, iterations=4,
+                                               iterationsCG=5, absTol=0.0, relTol=0.0),
+    }
+    for name, make in makers.items():
+        got = {}
+        for half in (1, 0):
+            ctx.tune(skinny_half=half)
+            try:
+                S = make()
+                xs = rls.solve_(S, Bd, scheduler=rls.BatchedState)
+                got[half] = np.stack([x.to_host() for x in xs], axis=1)
+            finally:
+                ctx.tune(skinny_half=1)
+        assert np.isfinite(got[1]).all() and np.abs(got[1]).max() > 0
+        assert np.array_equal(got[1], got[0]), (name, np.abs(got[1] - got[0]).max())
+
+
 @pytest.mark.parametrize("name,kw", [("OptISTA", {}), ("POGM", {}), ("POGM", {"restart": "gradient"})])
 @pytest.mark.parametrize("dt,M,N", [(np.complex64, 256, 96), (np.float32, 4096, 2048)])
 def test_optista_pogm_match_oracle(rls, ctx, name, kw, dt, M, N):
