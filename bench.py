@@ -68,6 +68,29 @@ def spread(xs):
 
 
 # ---- CPU baselines (rank 0, N = 1 only): the oracle's NumPy restatement and its C++/OpenMP restatement -----------
+def usable_cpus():
+    """CPUs this process can really keep busy: the affinity mask capped by the cgroup CPU quota (the GPU boxes give a
+    container 16 CPUs' worth of time on a 256-CPU host; more threads than that run in bursts and are then throttled,
+    which a short calibration does not see)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline_numpy(A, b, budget_s=8.0, max_iters=640):
     """the oracle's CGNR (NumPy/OpenBLAS restatement of src/CGNR.jl:143-178) timed on the host.  OpenBLAS's cgemv does
     not scale to every core of a big host, so a short calibration picks the BLAS thread count (reported as `cores`)."""
@@ -90,7 +113,7 @@ def cpu_baseline_numpy(A, b, budget_s=8.0, max_iters=640):
             done += 1
         return done * SEGMENT, time.perf_counter() - t0
 
-    ncpu = os.cpu_count() or 1
+    ncpu, quota = usable_cpus()
     best_threads, calib = ncpu, {}
     if threadpool_limits is not None:
         for nt in sorted({1, 4, 8, 16, 32, ncpu}):
@@ -110,7 +133,8 @@ def cpu_baseline_numpy(A, b, budget_s=8.0, max_iters=640):
     return {"value": n / dt, "unit": "iterations/s", "cores": int(best_threads), "kind": "port",
             "implementation": "NumPy/OpenBLAS restatement (oracle/rls_oracle.py)",
             "sample": f"{n} CGNR iterations of the same {A.shape[0]}x{A.shape[1]} complex64 problem, {dt:.1f} s, BLAS threads chosen "
-                      f"by calibration { {k: round(v, 1) for k, v in calib.items()} } it/s of {ncpu} host CPUs",
+                      f"by calibration { {k: round(v, 1) for k, v in calib.items()} } it/s; {ncpu} usable CPUs (cgroup quota "
+                      f"{quota}) of {os.cpu_count()} on the host",
             "GBps_algorithmic": bytes_per_cgnr_iteration(A.shape[0], A.shape[1], 8) * n / dt / 1e9, "ms_per_step": 1e3 * dt / n}
 
 
@@ -128,26 +152,35 @@ def cpu_baseline_openmp(A, b, budget_s=10.0):
     M, N = A.shape
     x = np.zeros(N, np.complex64)
     sec = C.c_double()
-    ncpu = os.cpu_count() or 1
+    ncpu, quota = usable_cpus()
 
     def run(threads, solves):
         n = lib.cgnr_omp_run(A.ctypes.data, M, N, b.ctypes.data, SEGMENT, solves, 0.0, threads, x.ctypes.data, C.byref(sec))
         return n, sec.value
 
     calib = {}
-    for nt in sorted({8, 16, 32, 64, 128, ncpu}):
+    for nt in sorted({4, 8, 16, 32, 64, 128, ncpu}):
         if nt > ncpu:
             continue
         run(nt, 1)
-        n, dt = run(nt, 2)
-        calib[nt] = n / dt
+        n, dt = run(nt, 4)
+        n2, dt2 = run(nt, max(4, int(0.4 * n / dt / SEGMENT)))  # ~0.4 s: long enough to run into a CPU quota
+        calib[nt] = n2 / dt2
     best = max(calib, key=calib.get)
-    solves = max(2, int(budget_s * calib[best] / SEGMENT))
-    n, dt = run(best, solves)
+    # the sample: chunks of about a second until the budget is used (bounded by time, not by a count sized from the
+    # calibration -- a host that slows down must not stretch the bench run)
+    n = 0
+    dt = 0.0
+    chunk = max(2, int(calib[best] / SEGMENT))
+    while dt < budget_s:
+        ni, di = run(best, chunk)
+        n += ni
+        dt += di
     return {"value": n / dt, "unit": "iterations/s", "cores": int(best), "kind": "port",
             "implementation": "C++/OpenMP restatement (oracle/cgnr_omp.cpp), x86-64-v3",
             "sample": f"{n} CGNR iterations of the same {M}x{N} complex64 problem, {dt:.1f} s, OpenMP threads chosen by calibration "
-                      f"{ {k: round(v, 1) for k, v in calib.items()} } it/s of {ncpu} host CPUs",
+                      f"{ {k: round(v, 1) for k, v in calib.items()} } it/s; {ncpu} usable CPUs (cgroup quota {quota}) of "
+                      f"{os.cpu_count()} on the host",
             "GBps_algorithmic": bytes_per_cgnr_iteration(M, N, 8) * n / dt / 1e9, "ms_per_step": 1e3 * dt / n}
 
 

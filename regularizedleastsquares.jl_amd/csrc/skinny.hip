@@ -68,7 +68,7 @@ __device__ static inline void t_mma(f32x4 (&acc)[4], const E (&a)[U], const PE (
   }
 }
 
-template <typename E, int WV, int U, bool H>
+template <typename E, int WV, int U, bool H, int D = 0>
 __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__ A, int64_t lda,
                                                             const E* __restrict__ Pp, E* __restrict__ Tp, int64_t M,
                                                             int64_t N) {
@@ -86,9 +86,46 @@ __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int64_t ns = NB > w ? (NB - w + WV - 1) / WV : 0;
+  bool rolled = false;
+  if constexpr (D > 0) {
+    // rolling window: D steps always in flight -- step i's MFMAs are followed at once by the loads of step i + D
+    // into the registers they have just freed, so the waits are vmcnt(2 (D - 1)) throughout and there is no bubble
+    // between batches (the two-set pipeline below drains one set before it refills it).  ns a multiple of D.
+    if (ns >= 2 * D && ns % D == 0) {
+      rolled = true;
+      E a[D];
+      PE p[D];
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int64_t nb = w + WV * (int64_t)u;
+        a[u] = Ap[nb * 4 * lda];
+        p[u] = Pg[nb * 64];
+        // same issue order as in the loop: the wait counts at the loop head are the minimum over both ways in
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int64_t i = D; i < ns; i += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          E a1[1] = {a[u]};
+          PE p1[1] = {p[u]};
+          t_mma<E, PE, 1>(acc, a1, p1);
+          const int64_t nb = w + WV * (i + u);
+          a[u] = Ap[nb * 4 * lda];
+          p[u] = Pg[nb * 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        E a1[1] = {a[u]};
+        PE p1[1] = {p[u]};
+        t_mma<E, PE, 1>(acc, a1, p1);
+      }
+    }
+  }
   // software pipeline over batches of U steps, two register sets; the loop body has no branch around
   // a load, so the waits are counted (vmcnt(N)) and the next batch stays in flight under the MFMAs
-  const int64_t nfull = ns / U;
+  const int64_t nfull = rolled ? 0 : ns / U;
   if (nfull > 0) {
     E a0[U], a1[U];
     PE p0[U], p1[U];
@@ -114,7 +151,7 @@ __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__
       t_mma<E, PE, U>(acc, a0, p0);
     }
   }
-  for (int64_t i = nfull * U; i < ns; ++i) {  // remainder steps, one at a time
+  for (int64_t i = rolled ? ns : nfull * U; i < ns; ++i) {  // remainder steps, one at a time
     E a2[1];
     PE p2[1];
     t_load<E, PE, WV, 1>(a2, p2, Ap, lda, Pg, w, i);
@@ -225,7 +262,7 @@ __device__ static inline void v_mma(f32x4 (&acc)[4], const v_regs<E, PE> (&q)[U]
   }
 }
 
-template <typename E, int WV, int U, bool H>
+template <typename E, int WV, int U, bool H, int D = 0>
 __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__ A, int64_t lda,
                                                             const E* __restrict__ Tp, E* __restrict__ Vpart,
                                                             int64_t M, int64_t N, int nrhs_pad, int64_t ldvp) {
@@ -244,7 +281,36 @@ __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int64_t ns = hi - lo > w ? (hi - lo - w + WV - 1) / WV : 0;
-  const int64_t nfull = ns / U;
+  bool rolled = false;
+  if constexpr (D > 0) {  // rolling window of D steps, as in skinny_t_kernel
+    if (ns >= 2 * D && ns % D == 0) {
+      rolled = true;
+      v_regs<E, PE> q[D];
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        v_regs<E, PE> q1[1];
+        v_load<E, PE, WV, 1>(q1, Ap, Tg, w, lo, u);
+        q[u] = q1[0];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int64_t i = D; i < ns; i += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          v_regs<E, PE> q1[1] = {q[u]};
+          v_mma<E, PE, 1>(acc, q1);
+          v_load<E, PE, WV, 1>(q1, Ap, Tg, w, lo, i + u);
+          q[u] = q1[0];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        v_regs<E, PE> q1[1] = {q[u]};
+        v_mma<E, PE, 1>(acc, q1);
+      }
+    }
+  }
+  const int64_t nfull = rolled ? 0 : ns / U;
   if (nfull > 0) {
     v_regs<E, PE> q0[U], q1[U];
     v_load<E, PE, WV, U>(q0, Ap, Tg, w, lo, 0);
@@ -267,7 +333,7 @@ __global__ __launch_bounds__(WV * 64) void skinny_v_kernel(const E* __restrict__
       v_mma<E, PE, U>(acc, q0);
     }
   }
-  for (int64_t i = nfull * U; i < ns; ++i) {
+  for (int64_t i = rolled ? ns : nfull * U; i < ns; ++i) {
     v_regs<E, PE> q2[1];
     v_load<E, PE, WV, 1>(q2, Ap, Tg, w, lo, i);
     v_mma<E, PE, 1>(acc, q2);
@@ -560,6 +626,10 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
 // ---------------------------------------------------------------------------------------------
 // measurement overrides (rls_tune_set "skinny_*"); defaults from tools/skinny_probe.py on MI355X
 static int g_t_waves = 4, g_t_u = 4, g_v_waves = 4, g_v_u = 1, g_v_splits = 0;
+// rolling-window depth of the complex T / V kernels (0 = two-set batch pipeline).  MI355X, 4096 x 2048 CF32,
+// (8, 2) against (0, 0): K = 8 32.7 -> 31.6 us, K = 16 36.6 -> 33.9 us, K = 64 120.3 -> 98.7 us per batched iteration;
+// (16, 2), (8, 4) and deeper windows measure within noise or worse: the kernels are not short of loads in flight
+static int g_t_roll = 8, g_v_roll = 2;
 static int g_half = 1;  // rls_tune_set "skinny_half": the (re | im) operand packing for <= 8 complex right-hand sides
 // dynamic LDS requested by the Gram tile kernel purely as an occupancy limiter: one workgroup (one wave per SIMD)
 // per CU keeps the MFMA pipe fed by a single instruction stream (0.92 ms vs 1.05 ms with three co-resident
@@ -573,6 +643,8 @@ void rls_skinny_tune(int which, int value) {
   if (which == 5) g_v_u = value;
   if (which == 6) g_gram_lds = value * 1024;
   if (which == 7) g_half = value;
+  if (which == 8) g_t_roll = value;
+  if (which == 9) g_v_roll = value;
 }
 
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
@@ -624,6 +696,20 @@ static void launch_t(rls_ctx* ctx, const rls_skinny& K) {
                        (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);                                                  \
     return;                                                                                                        \
   }
+#define SK_TR(HH, DD)                                                                                              \
+  if (g_t_roll == DD && (K.half != 0) == HH) {                                                                     \
+    if (g_t_waves == 8)                                                                                            \
+      hipLaunchKernelGGL((skinny_t_kernel<E, 8, 4, HH, DD>), grid, dim3(512), 0, ctx->stream, (const E*)K.A, K.lda, \
+                         (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);                                                \
+    else                                                                                                           \
+      hipLaunchKernelGGL((skinny_t_kernel<E, 4, 4, HH, DD>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda, \
+                         (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);                                                \
+    return;                                                                                                        \
+  }
+  if constexpr (elem<E>::cplx) {
+    SK_TR(true, 8) SK_TR(true, 16) SK_TR(true, 32) SK_TR(false, 8) SK_TR(false, 16)
+  }
+#undef SK_TR
   if constexpr (elem<E>::cplx) {
     if (K.half) {
       SK_T(8, 4, true) SK_T(8, 8, true) SK_T(4, 8, true) SK_T(4, 2, true) SK_T(4, 16, true) SK_T(2, 4, true)
@@ -649,6 +735,20 @@ static void launch_v(rls_ctx* ctx, const rls_skinny& K) {
                        (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);                                     \
     return;                                                                                                        \
   }
+#define SK_VR(HH, DD)                                                                                              \
+  if (g_v_roll == DD && (K.half != 0) == HH) {                                                                     \
+    if (g_v_waves == 8)                                                                                            \
+      hipLaunchKernelGGL((skinny_v_kernel<E, 8, 1, HH, DD>), grid, dim3(512), 0, ctx->stream, (const E*)K.A, K.lda, \
+                         (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);                                   \
+    else                                                                                                           \
+      hipLaunchKernelGGL((skinny_v_kernel<E, 4, 1, HH, DD>), grid, dim3(256), 0, ctx->stream, (const E*)K.A, K.lda, \
+                         (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);                                   \
+    return;                                                                                                        \
+  }
+  if constexpr (elem<E>::cplx) {
+    SK_VR(true, 2) SK_VR(true, 4) SK_VR(true, 8) SK_VR(false, 2) SK_VR(false, 4) SK_VR(false, 8)
+  }
+#undef SK_VR
   if constexpr (elem<E>::cplx) {
     if (K.half) {
       SK_V(8, 1, true) SK_V(8, 2, true) SK_V(4, 2, true) SK_V(4, 4, true) SK_V(2, 1, true) SK_V(2, 2, true)

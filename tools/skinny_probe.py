@@ -32,5 +32,5 @@ for var in variants:
     us = ctx.timer_stop_ms() * 1e3 / (reps * 32)
     print(f"{var:40s} K={K}: {us:7.2f} us per batched iteration", flush=True)
     for k in kv:
-        ctx.tune(**{k: {"skinny_t_waves": 4, "skinny_v_waves": 4, "skinny_t_u": 4, "skinny_v_u": 1, "skinny_half": 1}.get(k, 0)})
+        ctx.tune(**{k: {"skinny_t_waves": 4, "skinny_v_waves": 4, "skinny_t_u": 4, "skinny_v_u": 1, "skinny_half": 1, "skinny_t_roll": 8, "skinny_v_roll": 2}.get(k, 0)})
     del S, st
