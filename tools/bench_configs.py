@@ -7,7 +7,11 @@ import torch  # noqa
 import rls_amd as rls
 from bench import make_A
 ctx = rls.Context(0)
-which = sys.argv[1:] or ["fista", "admm"]
+args = sys.argv[1:]
+for a in [a for a in args if "=" in a]:  # tuning switches, e.g. slab_g=2
+    k, v = a.split("=")
+    ctx.tune(**{k: int(v)})
+which = [a for a in args if "=" not in a] or ["fista", "admm"]
 if "fista" in which:
     M, N = 4096, 2048
     A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
