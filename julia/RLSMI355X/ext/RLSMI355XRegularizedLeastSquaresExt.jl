@@ -362,7 +362,7 @@ function iterate(solver::Kaczmarz, state::KaczmarzState{T,<:RLSVector}) where {T
   end
   key = (objectid(solver.denom), copy(state.usedIndices))
   if aux.key[] != key   # upload the processing order: 0-based rows and their denominators
-    aux.rows[] = RLSVector(reinterpret(Float32, Int32.(solver.rowindex[state.usedIndices] .- 1)); ctx = state.x.ctx)
+    aux.rows[] = RLSVector(collect(reinterpret(Float32, Int32.(solver.rowindex[state.usedIndices] .- 1))); ctx = state.x.ctx)  # a Vector: 0-based Int32 row numbers, bit-cast
     aux.den[] = RLSVector(Float32.(solver.denom[state.usedIndices]); ctx = state.x.ctx)
     aux.key[] = key
   end
