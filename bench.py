@@ -196,6 +196,11 @@ def cpu_baselines(A, b):
         return {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "no CPU baseline ran", "variants": variants}
     best = dict(max(ok, key=lambda v: v["value"]))
     best["variants"] = variants
+    # the reference's own CPU path would be the baseline of choice if a Julia runtime with the package were
+    # on this host; it is probed for, never installed (kind stays "port")
+    import shutil
+    jl = shutil.which("julia")
+    best["reference_runtime"] = f"julia found at {jl} but RegularizedLeastSquares.jl is not installed offline" if jl else "julia not found on this host"
     return best
 
 

@@ -268,7 +268,8 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
 /* Which kernel sequence the next rls_cgnr_step call of this plan takes (a query; measurement harness and tests):
  * 0 = two GEMVs + update kernel, 1 = one-pass slab pipeline (two launches per iteration), 2 = Gram-mode pipeline
  * (one launch per iteration), 3 = batched matrix-core kernels, 4 = resident (the whole call in ONE launch, A held in
- * registers across iterations; needs A <= the register files, one live context on the device). */
+ * registers across iterations; needs A <= the register files), 5 = resident Gram mode (the same with AHA explicit and
+ * held in registers: one in-kernel grid exchange per iteration). */
 int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out);
 
 /* ---------------------------------------------------------------------------------------------

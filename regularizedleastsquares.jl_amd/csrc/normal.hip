@@ -1684,6 +1684,144 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
 }
 
 
+// ---- resident Gram-mode CGNR: a whole rls_cgnr_step call (or a whole cg! solve) in ONE launch, AHA in registers --------
+// With AHA explicit a workgroup's rows of v = AHA p are complete (no partial rows), so an iteration needs ONE grid-wide
+// exchange instead of the two of cgnr_resident_kernel: every workgroup publishes its 8 (complex) / 16 (real) entries of
+// v and its share of <p, v>, ||p||^2 (write-through), one barrier, then every workgroup reads v and the partial dots and
+// applies the CG update redundantly.  v and the dots alternate between two parities: a workgroup that has passed
+// barrier k publishes iteration k + 1 into the other buffer while a slower one still reads iteration k.  Same
+// visibility protocol, bounded spins and fail-as-a-no-op behaviour as the matrix-free resident kernel; same element
+// ownership and summation orders as cgnr_gram_kernel.
+template <typename E>
+__device__ static inline E sc1_load_elem(const E* p) {
+  if constexpr (sizeof(E) == 8)
+    return __builtin_bit_cast(E, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+  else
+    return __builtin_bit_cast(E, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <typename E, int K, int BAR>
+__global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* x, E* r, E* p,
+                                                                  E* v0, E* v1, double* dots, cgnr_scalars* sc0,
+                                                                  cgnr_scalars* sc1, resident_sync* sync, int64_t Mc,
+                                                                  int64_t N, int pair, int n_steps, unsigned spin_limit) {
+  constexpr int G = 4, WV = 8;
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
+  __shared__ gram_lds<E, G, K, WV> L;
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nwg = gridDim.x;
+  cgnr_scalars S = *sc0;
+  E pv[EPT], rv[EPT], xv[EPT], vv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {  // N == EPT * NT (full-size instantiation only): every index is valid
+    const int64_t i = tid + (int64_t)e * NT;
+    pv[e] = p[i];
+    rv[e] = r[i];
+    xv[e] = x[i];
+    vv[e] = elem<E>::zero();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, NV> a[K];
+  slab_load<E, G, K, WV, true>(a, Gm, ldg, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  if (S.done || n_steps <= 0) return;  // uniform
+  const __amdgpu_buffer_rsrc_t d_rs = sc1_rsrc(dots);
+  unsigned epoch = 0;
+  bool alive = true;
+  int it = 0;
+  for (; it < n_steps; ++it) {
+    const int q = it & 1;
+    E* vq = q ? v1 : v0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = pv[e];
+    gram_rows<E, G, K, WV, true>(a, L, Mc, N, pair);
+    double dre = 0.0, dim_ = 0.0, pp = 0.0;
+    if (tid < G * NV) {
+      const int gg = tid / NV, i = tid % NV;
+      E sum = elem<E>::zero();
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+      const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
+      sc1_store_elem<E>(vq + row, sum);
+      const E pj = L.xs[row];
+      dre = (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+      dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+      pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+    }
+    if (w == 0) {  // G*NV <= 16 lanes of wave 0 hold the terms; fixed-order butterfly
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        dre += __shfl_xor(dre, off, 64);
+        dim_ += __shfl_xor(dim_, off, 64);
+        pp += __shfl_xor(pp, off, 64);
+      }
+      if (lane < 3) {
+        const double dv = lane == 0 ? dre : (lane == 1 ? dim_ : pp);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dots + (size_t)q * 4 * nwg + 4 * blockIdx.x + lane),
+                           __builtin_bit_cast(unsigned long long, dv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
+    __syncthreads();
+    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
+      alive = false;
+      break;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) vv[e] = sc1_load_elem<E>(vq + tid + (int64_t)e * NT);
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    {
+      const int dt = tid < nwg ? tid : 0;
+      const uint32_t base = (uint32_t)((size_t)q * 4 * nwg * sizeof(double));
+      const f4 lo = sc1_load16(d_rs, base + (uint32_t)dt * 32u), hi = sc1_load16(d_rs, base + (uint32_t)dt * 32u + 16u);
+      if (tid < nwg) {
+        d0 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 0, 1));
+        d1 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 2, 3));
+        d2 = __builtin_bit_cast(double, __builtin_shufflevector(hi, hi, 0, 1));
+      }
+    }
+    E pn[EPT], rn[EPT], al;
+    cgnr_scalars Sn;
+    const bool done = cg_update_elems<E, EPT, NT, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      xv[e] = elem<E>::fma(pv[e], al, xv[e]);
+      rv[e] = rn[e];
+      pv[e] = pn[e];
+    }
+    S = Sn;
+    if (done) break;  // uniform: every workgroup derived the same scalars
+  }
+  if (!alive) {
+    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;  // x, r, p, v and the scalars are untouched: the call was a no-op
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * NT;
+      x[i] = xv[e];
+      r[i] = rv[e];
+      p[i] = pv[e];
+      v0[i] = vv[e];  // the last v (a workgroup still reading parity 0 reads the same values)
+    }
+    if (tid == 0) {
+      S.pending = 0;
+      S.cur = 0;
+      S.fresh = 0;
+      *sc0 = S;
+      *sc1 = S;
+      sync->completed = 1u;
+    }
+  }
+}
+
+
 // ---- resident FISTA: the same scheme for src/FISTA.jl:139-185 (BASELINE configs[1] has the headline shape) -------
 // Per iteration: xs = y, partial rows of AHA y, exchange 1, chunk sums -> res_raw, exchange 2, then the gradient step,
 // prox, restart test, theta and the next extrapolated point redundantly in every workgroup (fista_update_elems: its
@@ -2212,6 +2350,45 @@ static int32_t fista_resident_typed(rls_ctx* ctx, const rls_fista_pipe& P, void*
 #undef RLS_FRES_CASE
   return st;
 }
+template <typename E, int K>
+static int32_t launch_gram_resident(rls_ctx* ctx, const rls_gram_pipe& P, void* sync, int nwg, int n_steps,
+                                    unsigned spin_limit) {
+  using C = slab_cfg<E, 4, K, 8>;
+  const int64_t Mc = P.N / C::NV;
+  const int pair = (nwg % 16 == 0) ? 1 : 0;
+  if (g_resident_barrier == 0)
+    hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, 0>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
+                       (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],
+                       (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+  else
+    hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, 1>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
+                       (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],
+                       (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+  return launch_status(ctx);
+}
+
+// full-size Gram slabs only (N = 128 K, every row chunk valid), one workgroup per CU
+template <typename E>
+static bool gram_resident_ok_typed(int device, int64_t N) {
+  int K = 0;
+  if (!gram_pick<E>(N, &K)) return false;
+  const int64_t Mc = N / elem<E>::vec;
+  const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, N);
+  if (N != (int64_t)K * 128 || (int64_t)nwg * 4 != Mc) return false;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
+  return nwg <= cus;
+}
+
+template <typename E>
+static int32_t gram_resident_typed(rls_ctx* ctx, const rls_gram_pipe& P, void* sync, int n_steps, unsigned spin_limit) {
+  int K = 0;
+  if (!gram_pick<E>(P.N, &K)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram CGNR: N too large");
+  const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
+  if (K == 8) return launch_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit);
+  if (K == 16) return launch_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit);
+  return launch_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
+}
 }  // namespace
 
 int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity) {
@@ -2242,6 +2419,16 @@ int32_t rls_gram_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe
 int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity) {
   if (dtype == RLS_F32) return gram_finish_typed<float>(ctx, P, parity & 1);
   return gram_finish_typed<float2>(ctx, P, parity & 1);
+}
+
+bool rls_gram_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, const void* G, int64_t ldg) {
+  if (!rls_gram_pipe_ok(dtype, N, G, ldg)) return false;
+  return dtype == RLS_F32 ? gram_resident_ok_typed<float>(ctx->device, N) : gram_resident_ok_typed<float2>(ctx->device, N);
+}
+int32_t rls_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, void* sync, int n_steps,
+                                 unsigned spin_limit) {
+  if (dtype == RLS_F32) return gram_resident_typed<float>(ctx, P, sync, n_steps, spin_limit);
+  return gram_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit);
 }
 
 

@@ -136,6 +136,7 @@ struct rls_cgnr {
   double* rdots;
   unsigned* rsync_h;  // pinned: {fail, completed} of the last resident launch, read with the status
   bool resident_used;
+  bool gram_resident;  // Gram mode: AHA fits the register files (rls_gram_resident_ok)
 };
 
 static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
@@ -181,6 +182,10 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
   K.ldvp = s->op->N;
   K.sc = s->sc;
   return K;
+}
+
+static bool cgnr_use_gram_resident(const rls_cgnr* s) {
+  return s->gram_resident && s->rsync && s->nrhs == 1 && cgnr_use_gram_pipeline(s) && s->op->ctx->tune.resident;
 }
 
 static bool cgnr_use_pipeline(const rls_cgnr* s) {
@@ -1758,6 +1763,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   s->rdots = nullptr;
   s->rsync_h = nullptr;
   s->resident_used = false;
+  s->gram_resident = false;
   const size_t sb = sizeof(cgnr_scalars) * (size_t)nrhs;
   hipError_t e = hipMalloc((void**)&s->sc, sb);
   if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sb, ctx->stream);
@@ -1800,6 +1806,12 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMemsetAsync(s->gdots, 0, nd, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
     s->gram_pipe = e == hipSuccess;
+    if (e == hipSuccess && !s->rsync && rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg)) {
+      e = hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes());
+      if (e == hipSuccess) e = hipHostMalloc((void**)&s->rsync_h, 2 * sizeof(unsigned), hipHostMallocDefault);
+      if (e == hipSuccess) s->rsync_h[0] = s->rsync_h[1] = 0;
+      s->gram_resident = e == hipSuccess;
+    }
   }
   if (e == hipSuccess && skinny) {
     size_t pb, tb, vb;
@@ -1969,6 +1981,13 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
     // are always the right ones
     const rls_gram_pipe P = cgnr_gram_desc(s);
     const int32_t dtype = s->op->dtype;
+    if (cgnr_use_gram_resident(s)) {  // the whole call as ONE launch, AHA in registers, one grid exchange per iteration
+      if (n_steps == 0) return 0;
+      s->resident_used = true;
+      return resident_chain(ctx, s->rsync, [&]() {
+        return rls_gram_resident_launch(ctx, dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+      });
+    }
     if (s->graph.steps && s->graph.mode != 3) {
       hipGraphExecDestroy(s->graph.exec);
       s->graph = step_graph();
@@ -2100,7 +2119,7 @@ int32_t rls_cgnr_step_rowsharded(rls_comm* comm, rls_cgnr* const* plans, int32_t
 
 int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out) {
   if (!s || !out) return RLS_E_INVALID;
-  *out = s->skinny ? 3 : cgnr_use_gram_pipeline(s) ? 2 : cgnr_use_resident(s) ? 4 : cgnr_use_pipeline(s) ? 1 : 0;
+  *out = s->skinny ? 3 : cgnr_use_gram_resident(s) ? 5 : cgnr_use_gram_pipeline(s) ? 2 : cgnr_use_resident(s) ? 4 : cgnr_use_pipeline(s) ? 1 : 0;
   return 0;
 }
 

@@ -360,16 +360,26 @@ def test_cgnr_gram_mode_and_float32_oracle(rls, ctx):
     assert rel(x, ref32.x) < TOL_ITER
 
 
-@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("pipe", [2, 1, 0])
 @pytest.mark.parametrize("dt,M,N,lam,iters", [(np.complex64, 4096, 2048, 0.0, 32), (np.float32, 600, 256, 1e-2, 12),
-                                              (np.complex64, 90, 46, 0.1, 9), (np.float32, 5000, 4096, 0.0, 6)])
+                                              (np.complex64, 90, 46, 0.1, 9), (np.float32, 5000, 4096, 0.0, 6),
+                                              (np.complex64, 1500, 1024, 1e-3, 12), (np.float32, 3000, 2048, 0.0, 10)])
 def test_cgnr_gram_pipeline_iterates(rls, ctx, dt, M, N, lam, iters, pipe):
-    """Gram mode (AHA = A' * A explicit, the constructor default for a dense Matrix, src/CGNR.jl:49): one launch per
-    iteration.  Step-by-step iterates, a single n-step call, relTol retirement, and the unfused path all agree with
-    the float64 oracle in Gram mode."""
-    ctx.tune(gram_pipeline=pipe)
+    """Gram mode (AHA = A' * A explicit, the constructor default for a dense Matrix, src/CGNR.jl:49).  pipe 2: the
+    resident kernel where AHA fits the register files (N = 1024 / 2048 CF32, 1024 / 2048 / 4096 F32: the whole step call
+    in one launch, one in-kernel grid exchange per iteration), the one-launch-per-iteration pipeline elsewhere; pipe 1:
+    that pipeline everywhere; pipe 0: the unfused path.  Step-by-step iterates, a single n-step call and relTol
+    retirement all agree with the float64 oracle in Gram mode."""
+    ctx.tune(gram_pipeline=1 if pipe else 0, resident=1 if pipe == 2 else 0)
     try:
         ref, sol, b, dt64 = _cgnr_pair(rls, M, N, dt, 7, lam, iters, mode="gram")
+        if pipe:
+            import ctypes
+            rls.init_(sol, rls.DeviceVector.from_host(b))
+            pth = ctypes.c_int32(-1)
+            ctx.lib.rls_cgnr_path(sol.state._plan, ctypes.byref(pth))
+            fits = N in ((1024, 2048) if np.dtype(dt).kind == "c" else (1024, 2048, 4096))
+            assert pth.value == (5 if pipe == 2 and fits else 2), pth.value
         ref32 = O.CGNR(ref.A.A.astype(dt), reg=O.L2Regularization(lam), iterations=iters, relTol=0.0, normal="gram")
         bd = rls.DeviceVector.from_host(b)
         ref.init(b.astype(dt64))
@@ -402,7 +412,7 @@ def test_cgnr_gram_pipeline_iterates(rls, ctx, dt, M, N, lam, iters, pipe):
             ref2_32 = O.CGNR(ref.A.A.astype(dt), reg=O.L2Regularization(lam), iterations=ref2.iteration, relTol=0.0, normal="gram")
             parity(f"{tag}_reltol", x2, ref2.x, lambda: O.solve(ref2_32, b))
     finally:
-        ctx.tune(gram_pipeline=1)
+        ctx.tune(gram_pipeline=1, resident=1)
 
 
 def test_cgnr_callbacks_cadence_and_lstsq(rls, ctx):
