@@ -867,6 +867,7 @@ struct rls_cg {
   void* rsync = nullptr;
   double* rdots = nullptr;
   bool resident_used = false;
+  bool gram_resident = false;  // Gram mode with AHA small enough for the register files (rls_gram_resident_ok)
 };
 
 // {fail, completed} of the plan's last resident launch (synchronises the stream)
@@ -1465,6 +1466,13 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     RLS_TRY(launch_status(ctx));
     const rls_gram_pipe P = cg_gram_desc(s, x);
     const int32_t dtype = op->dtype;
+    if (s->gram_resident && s->rsync && ctx->tune.resident && maxiter > 0) {
+      // the whole inner solve as ONE launch with AHA in registers (cgnr_gram_resident_kernel, normal.hip)
+      s->resident_used = true;
+      return resident_chain(ctx, s->rsync, [&]() {
+        return rls_gram_resident_launch(ctx, dtype, P, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin);
+      });
+    }
     if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 3)) {  // the captured kernels carry x's address
       hipGraphExecDestroy(s->graph.exec);
       s->graph = step_graph();
@@ -2624,6 +2632,14 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
     if (e != hipSuccess || alloc_scalars(ctx, &s->psc, &s->psc_h) != 0) {
       rls_cg_destroy(s);
       return rls_fail(ctx, (int32_t)e, "cg_create: hipMalloc failed");
+    }
+    if (rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg)) {
+      if (hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes()) == hipSuccess) {
+        s->gram_resident = true;
+      } else {
+        s->rsync = nullptr;  // an optimisation only: the one-launch-per-iteration pipeline runs without it
+        (void)hipGetLastError();
+      }
     }
   } else if (op->slab) {
     if (op->A && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
