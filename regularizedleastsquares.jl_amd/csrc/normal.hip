@@ -1929,6 +1929,110 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   }
 }
 
+// ---- resident Gram-mode FISTA: as cgnr_gram_resident_kernel, for src/FISTA.jl:139-185 with AHA explicit ---------------
+// Per iteration: xs = y, this workgroup's rows of AHA y published (two parities), ONE grid exchange, then the gradient
+// step, prox, restart test, theta and the next extrapolated point redundantly in every workgroup.
+template <typename E, int K, int BAR>
+__global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
+                                                                   const E* __restrict__ x0, E* res, E* y0, E* y1,
+                                                                   E* rr0, E* rr1, fista_scalars* sc0, fista_scalars* sc1,
+                                                                   resident_sync* sync, int64_t Mc, int64_t N, int pair,
+                                                                   int n_steps, unsigned spin_limit) {
+  constexpr int G = 4, WV = 8;
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
+  __shared__ gram_lds<E, G, K, WV> L;
+  __shared__ int flag;
+  const int tid = threadIdx.x;
+  const int nwg = gridDim.x;
+  fista_scalars S;
+  RLS_FISTA_COPY(S, *sc0);
+  E yv[EPT], xk[EPT], xp[EPT], x0v[EPT], ri[EPT];
+  {
+    const E* yc = S.ycur ? y1 : y0;
+    const E* xc = (S.iteration & 1) ? b1 : b0;  // state.x == buf[iteration & 1]
+    const E* xo = (S.iteration & 1) ? b0 : b1;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {  // N == EPT * NT (full-size instantiation only)
+      const int64_t i = tid + (int64_t)e * NT;
+      yv[e] = yc[i];
+      xk[e] = xc[i];
+      xp[e] = xo[i];
+      x0v[e] = x0[i];
+      ri[e] = res[i];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, NV> a[K];
+  slab_load<E, G, K, WV, true>(a, Gm, ldg, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  if (S.done || n_steps <= 0) return;  // uniform
+  unsigned epoch = 0;
+  bool alive = true;
+  int ycur = S.ycur;
+  for (int it = 0; it < n_steps; ++it) {
+    E* rq = (it & 1) ? rr1 : rr0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = yv[e];
+    gram_rows<E, G, K, WV, true>(a, L, Mc, N, pair);
+    if (tid < G * NV) {
+      const int gg = tid / NV, i = tid % NV;
+      E sum = elem<E>::zero();
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+      sc1_store_elem<E>(rq + (row_block_of(blockIdx.x, pair) * G + gg) * NV + i, sum);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
+      alive = false;
+      break;
+    }
+    E raw[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) raw[e] = sc1_load_elem<E>(rq + tid + (int64_t)e * NT);
+    E xn[EPT], yn[EPT];
+    fista_scalars Sn;
+    const bool done = fista_update_elems<E, EPT, NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      xp[e] = xk[e];
+      xk[e] = xn[e];
+      if (!done) yv[e] = yn[e];
+    }
+    if (!done) ycur ^= 1;
+    RLS_FISTA_COPY(S, Sn);
+    if (done) break;  // uniform
+  }
+  if (!alive) {
+    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (blockIdx.x == 0) {
+    E* xw = (S.iteration & 1) ? b1 : b0;  // state.x == buf[iteration & 1] afterwards as well
+    E* xo = (S.iteration & 1) ? b0 : b1;
+    E* yw = ycur ? y1 : y0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * NT;
+      xw[i] = xk[e];
+      xo[i] = xp[e];
+      yw[i] = yv[e];
+      res[i] = ri[e];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      S.ycur = ycur;
+      S.pending = 0;
+      S.fresh = 0;
+      RLS_FISTA_COPY(*sc0, S);
+      RLS_FISTA_COPY(*sc1, S);
+      sync->completed = 1u;
+    }
+  }
+}
+
 struct fused_cfg {
   int G, K, WV;
 };
@@ -2389,6 +2493,33 @@ static int32_t gram_resident_typed(rls_ctx* ctx, const rls_gram_pipe& P, void* s
   if (K == 16) return launch_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit);
   return launch_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
 }
+template <typename E, int K>
+static int32_t launch_fista_gram_resident(rls_ctx* ctx, const rls_fista_gram& P, void* sync, int nwg, int n_steps,
+                                          unsigned spin_limit) {
+  using C = slab_cfg<E, 4, K, 8>;
+  const int64_t Mc = P.N / C::NV;
+  const int pair = (nwg % 16 == 0) ? 1 : 0;
+  if (g_resident_barrier == 0)
+    hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, 0>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
+                       (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.rr[0], (E*)P.rr[1], P.sc[0],
+                       P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+  else
+    hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, 1>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
+                       (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.rr[0], (E*)P.rr[1], P.sc[0],
+                       P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+  return launch_status(ctx);
+}
+
+template <typename E>
+static int32_t fista_gram_resident_typed(rls_ctx* ctx, const rls_fista_gram& P, void* sync, int n_steps,
+                                         unsigned spin_limit) {
+  int K = 0;
+  if (!gram_pick<E>(P.N, &K)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram FISTA: N too large");
+  const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
+  if (K == 8) return launch_fista_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit);
+  if (K == 16) return launch_fista_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit);
+  return launch_fista_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
+}
 }  // namespace
 
 int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity) {
@@ -2421,6 +2552,11 @@ int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P
   return gram_finish_typed<float2>(ctx, P, parity & 1);
 }
 
+int32_t rls_fista_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, void* sync, int n_steps,
+                                       unsigned spin_limit) {
+  if (dtype == RLS_F32) return fista_gram_resident_typed<float>(ctx, P, sync, n_steps, spin_limit);
+  return fista_gram_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit);
+}
 bool rls_gram_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, const void* G, int64_t ldg) {
   if (!rls_gram_pipe_ok(dtype, N, G, ldg)) return false;
   return dtype == RLS_F32 ? gram_resident_ok_typed<float>(ctx->device, N) : gram_resident_ok_typed<float2>(ctx->device, N);

@@ -2220,7 +2220,8 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
     delete s;
     return rls_fail(ctx, (int32_t)e, "fista_create: hipMalloc failed");
   }
-  if (op->slab && op->A && !op->G && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
+  if ((op->slab && op->A && !op->G && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) ||
+      (gram && rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg))) {
     if (hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes()) != hipSuccess ||
         hipHostMalloc((void**)&s->rsync_h, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
       if (s->rsync) hipFree(s->rsync);
@@ -2476,6 +2477,9 @@ int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n) {
 }
 
 static bool fista_use_resident(const rls_fista* s);
+static bool fista_use_gram_resident(const rls_fista* s) {
+  return s->nrhs == 1 && s->use_gram && s->rsync && s->op->ctx->tune.resident;
+}
 
 int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   if (!s) return RLS_E_INVALID;
@@ -2491,6 +2495,14 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
     // applies the last update and leaves the scalars in both parities, so every call starts at parity 0
     rls_fista_gram P = fista_gram_desc(s);
     const int32_t dtype = s->op->dtype;
+    if (fista_use_gram_resident(s)) {  // the whole call as ONE launch, AHA in registers (fista_gram_resident_kernel)
+      if (n_steps == 0) return 0;
+      s->resident_used = true;
+      s->enq += n_steps;
+      return resident_chain(ctx, s->rsync, [&]() {
+        return rls_fista_gram_resident_launch(ctx, dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+      });
+    }
     const int it0 = s->enq;  // buffer hints as in the slab pipeline below
     if (s->graph.exec && s->graph_parity != (it0 & 1)) {
       hipGraphExecDestroy(s->graph.exec);
@@ -2560,7 +2572,7 @@ static bool fista_use_resident(const rls_fista* s) {
 
 int32_t rls_fista_path(rls_fista* s, int32_t* out) {
   if (!s || !out) return RLS_E_INVALID;
-  *out = s->nrhs > 1 ? 3 : s->use_gram ? 2 : fista_use_resident(s) ? 4 : s->use_pipe ? 1 : 0;
+  *out = s->nrhs > 1 ? 3 : fista_use_gram_resident(s) ? 5 : s->use_gram ? 2 : fista_use_resident(s) ? 4 : s->use_pipe ? 1 : 0;
   return 0;
 }
 

@@ -593,13 +593,15 @@ def test_admm_device_plan_stops_when_converged(rls, ctx):
         assert len(sol.state.cg_iterations) == ref.iteration
 
 
-@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("pipe", [2, 1, 0])
 @pytest.mark.parametrize("dt,M,N,restart", [(np.complex64, 4096, 2048, "none"), (np.float32, 300, 120, "gradient"),
-                                            (np.complex64, 70, 34, "none")])
+                                            (np.complex64, 70, 34, "none"), (np.float32, 2500, 2048, "gradient"),
+                                            (np.complex64, 1100, 1024, "gradient")])
 def test_fista_gram_mode_matches_oracle(rls, ctx, dt, M, N, restart, pipe):
-    """FISTA(A; AHA = A'*A) (src/FISTA.jl:58, explicit Gram = the constructor default for a dense Matrix): one launch
-    per iteration; iterates step by step and in one call, with and without the pipeline, against the oracle"""
-    ctx.tune(gram_pipeline=pipe)
+    """FISTA(A; AHA = A'*A) (src/FISTA.jl:58, explicit Gram = the constructor default for a dense Matrix).  pipe 2: the
+    resident kernel where AHA fits the register files (fista_gram_resident_kernel: one launch per step call), pipe 1: one
+    launch per iteration, pipe 0: the unfused path; iterates step by step and in one call against the oracle"""
+    ctx.tune(gram_pipeline=1 if pipe else 0, resident=1 if pipe == 2 else 0)
     try:
         A, xt, b = O.make_problem(M, N, dt, 9)
         dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
@@ -626,8 +628,14 @@ def test_fista_gram_mode_matches_oracle(rls, ctx, dt, M, N, restart, pipe):
         x_once = rls.solve_(sol, bd).to_host()
         parity(f"{tag}_once", x_once, ref.x, ref32.x)
         assert sol.state.iteration == its
+        if pipe:
+            import ctypes
+            pth = ctypes.c_int32(-1)
+            ctx.lib.rls_fista_path(sol.state._plan, ctypes.byref(pth))
+            fits = N in ((1024, 2048) if np.dtype(dt).kind == "c" else (1024, 2048, 4096))
+            assert pth.value == (5 if pipe == 2 and fits else 2), pth.value
     finally:
-        ctx.tune(gram_pipeline=1)
+        ctx.tune(gram_pipeline=1, resident=1)
 
 
 @pytest.mark.parametrize("dt,M,N,shape", [(np.float32, 8192, 4096, (64, 64)), (np.complex64, 96, 36, (6, 6))])
