@@ -299,8 +299,11 @@ def other_paths(rls, ctx, Ad, A, b, errors):
             st = S.state
             us = timed(lambda: (rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, 32), "init"),
                                 rls._lib.check(h, lib.rls_cgnr_step(st._plan, 32), "step")), 32, reps=4)
+            groups = 1 if K <= 8 else (K + 15) // 16  # passes over A per product: one per group of 16 (<= 8: the half layout)
             return {"us_per_batched_iteration": us, "solve_iterations_per_s": K * 1e6 / us,
-                    "TFLOPs_algorithmic": 16.0 * M * N * K / us / 1e6, "frac_mfma_f32": 16.0 * M * N * K / us / 1e6 / MFMA_F32_PEAK_TF}
+                    "TFLOPs_algorithmic": 16.0 * M * N * K / us / 1e6, "frac_mfma_f32": 16.0 * M * N * K / us / 1e6 / MFMA_F32_PEAK_TF,
+                    "A_stream_GBps (2 passes per group of 16, out of the Infinity Cache)": 2.0 * groups * M * N * 8 / us / 1e3,
+                    "binding_roof": "hbm (8 flop/B at 8 right-hand sides, ridge ~20)" if K < 20 else "mfma"}
 
     @entry("fista_l1_batched_16_rhs (solve!(FISTA, B), f32 MFMA)")
     def _():
@@ -540,13 +543,20 @@ def main():
             "timed_region": {"repetitions": len(walls), "wall_s": spread(walls), "hip_events_s": spread(evs),
                              "value_is": "n_gpus * rhs_per_gpu * steps / median(wall, max over ranks)"},
             "per_rank_solve_iterations_per_s_hip_events": rates,
-            "roofline": {"bound": "mfma", "kernel": "skinny_t_kernel + skinny_v_kernel (T = A P, V = A^H T on v_mfma_f32_16x16x4_f32) + per-column update",
-                         "achieved": flops_iter / us_iter / 1e6, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": flops_iter / us_iter / 1e6 / MFMA_F32_PEAK_TF, "traffic": None,
-                         "note": "algorithmic flops = 16*M*N per solve-iteration (complex MAC = 8 flops, two products); with fewer than 16 "
-                                 "right-hand sides per group the MFMA columns beyond them are padding and are not counted",
-                         "us_per_batched_iteration": us_iter},
         }
+        # which roof binds a batched iteration: the two passes over the shared A (2*M*N*s bytes, whatever the
+        # number of right-hand sides) against 16*M*N*R flops on the f32 matrix cores -- 8 right-hand sides are 8 flop/B,
+        # under the ~20 flop/B ridge, i.e. bandwidth-bound; from ~20 right-hand sides on the MFMA rate binds
+        bytes_iter = 2.0 * M * N * 8
+        t_hbm, t_mfma = bytes_iter / (HBM_PEAK_GBS * 1e9), flops_iter / (MFMA_F32_PEAK_TF * 1e12)
+        kern = "skinny_t_kernel + skinny_v_kernel (T = A P, V = A^H T on v_mfma_f32_16x16x4_f32) + per-column update"
+        mf = {"achieved": flops_iter / us_iter / 1e6, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops_iter / us_iter / 1e6 / MFMA_F32_PEAK_TF}
+        hb = {"achieved": bytes_iter / us_iter / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_iter / us_iter / 1e3 / HBM_PEAK_GBS}
+        out["roofline"] = dict(bound="hbm" if t_hbm >= t_mfma else "mfma", kernel=kern, **(hb if t_hbm >= t_mfma else mf), traffic=None,
+                               us_per_batched_iteration=us_iter, other_roof=(mf if t_hbm >= t_mfma else hb),
+                               note="hbm basis: A streamed twice per batched iteration (2*M*N*s bytes, shared by the right-hand sides; it "
+                                    "comes out of the Infinity Cache, so the memory-side counters see less); mfma basis: 16*M*N flops per "
+                                    "solve-iteration (complex MAC = 8 flops, two products), padding columns not counted")
         return finish(out)
 
     # ---- headline: one CGNR solve per GPU, data resident in HBM before the timed region ---------------------------
