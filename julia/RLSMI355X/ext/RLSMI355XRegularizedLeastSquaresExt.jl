@@ -74,9 +74,10 @@ end
 function plan_for(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
   get!(cgnr_plans, state) do
     A = solver.A::RLSMatrix
+    op = something(operator_of(A, solver.AHA), A.op)   # matrix-free (A' * A lazy) or Gram mode (AHA = gram(A))
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(A.ctx, ccall((:rls_cgnr_create, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
-                       A.op, state.x.ptr, state.x₀.ptr, state.pl.ptr, state.vl.ptr, p), "rls_cgnr_create")
+                       op, state.x.ptr, state.x₀.ptr, state.pl.ptr, state.vl.ptr, p), "rls_cgnr_create")
     finalizer(_ -> ccall((:rls_cgnr_destroy, librls[]), Int32, (Ptr{Cvoid},), p[]), state)
     p[]
   end
@@ -129,6 +130,8 @@ end
 "the operator handle behind A / AHA when the solver sits on this backend's types (matrix-free or explicit Gram)"
 function operator_of(A, AHA)
   A isa RLSMatrix && AHA isa RLSNormalOp && AHA.A === A && return A.op
+  # explicit Gram matrix from RLSMI355X.gram(A): its operator handle carries A and AHA (rls_operator_set_gram)
+  A isa RLSMatrix && AHA isa RLSMatrix && size(AHA) == (A.N, A.N) && return AHA.op
   nothing
 end
 

@@ -258,6 +258,31 @@ function LinearAlgebra.mul!(v::RLSVector{T}, N::RLSNormalOp{T}, p::RLSVector{T})
   v
 end
 
+"""
+    gram(A::RLSMatrix) -> RLSMatrix
+
+The explicit Gram matrix `A' * A` on the device (Hermitian rank-M update on the matrix cores, `rls_gram`).  Passing it as
+`CGNR(A; AHA = gram(A))` (likewise FISTA, ADMM) selects Gram mode: the per-iteration operator apply is one N x N GEMV, and
+where AHA fits the register files the whole `step` call runs as one resident launch (DESIGN.md 4.3).  `A' * A` itself stays
+lazy (matrix-free), so the unchanged constructor default keeps the reference's matrix-free arithmetic.
+"""
+function gram(A::RLSMatrix{T}) where {T}
+  N = A.N
+  p = Ref{Ptr{Cvoid}}(C_NULL)
+  check(A.ctx, ccall((:rls_malloc, librls[]), Int32, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), A.ctx.handle, N * N * sizeof(T), p), "rls_malloc")
+  check(A.ctx, ccall((:rls_gram, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+                     A.ctx.handle, dtypecode(T), A.M, A.N, A.ptr, A.lda, p[], N), "rls_gram")
+  o = Ref{Ptr{Cvoid}}(C_NULL)   # the operator of the pair (A, AHA): rls_operator_set_gram switches its plans to Gram mode
+  check(A.ctx, ccall((:rls_operator_create, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}),
+                     A.ctx.handle, dtypecode(T), A.M, A.N, A.ptr, A.lda, o), "rls_operator_create")
+  check(A.ctx, ccall((:rls_operator_set_gram, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), o[], p[], N), "rls_operator_set_gram")
+  G = RLSMatrix{T}(p[], N, N, N, A.ctx, o[])
+  finalizer(G) do x
+    ccall((:rls_operator_destroy, librls[]), Int32, (Ptr{Cvoid},), x.op)
+    ccall((:rls_free, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, x.ptr)
+  end
+end
+
 "whole solve in one enqueue; methods are added by the RegularizedLeastSquares extension"
 function solve_fused! end
 
