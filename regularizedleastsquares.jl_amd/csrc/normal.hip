@@ -1702,7 +1702,7 @@ __device__ static inline E sc1_load_elem(const E* p) {
                                                    __HIP_MEMORY_SCOPE_AGENT));
 }
 
-template <typename E, int K, int BAR>
+template <typename E, int K, int BAR, bool FULL>
 __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* x, E* r, E* p,
                                                                   E* v0, E* v1, double* dots, cgnr_scalars* sc0,
                                                                   cgnr_scalars* sc1, resident_sync* sync, int64_t Mc,
@@ -1717,17 +1717,19 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
   cgnr_scalars S = *sc0;
   E pv[EPT], rv[EPT], xv[EPT], vv[EPT];
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {  // N == EPT * NT (full-size instantiation only): every index is valid
+  for (int e = 0; e < EPT; ++e) {  // FULL: N == EPT * NT, every index is valid; else clamped loads, zeroed tails
     const int64_t i = tid + (int64_t)e * NT;
-    pv[e] = p[i];
-    rv[e] = r[i];
-    xv[e] = x[i];
+    const int64_t ic = FULL || i < N ? i : (N - 1);
+    pv[e] = p[ic];
+    rv[e] = r[ic];
+    xv[e] = x[ic];
     vv[e] = elem<E>::zero();
+    if (!FULL && i >= N) pv[e] = rv[e] = xv[e] = elem<E>::zero();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, NV> a[K];
-  slab_load<E, G, K, WV, true>(a, Gm, ldg, Mc, N, pair);
+  slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (S.done || n_steps <= 0) return;  // uniform
   const __amdgpu_buffer_rsrc_t d_rs = sc1_rsrc(dots);
@@ -1739,7 +1741,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     E* vq = q ? v1 : v0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = pv[e];
-    gram_rows<E, G, K, WV, true>(a, L, Mc, N, pair);
+    gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
     double dre = 0.0, dim_ = 0.0, pp = 0.0;
     if (tid < G * NV) {
       const int gg = tid / NV, i = tid % NV;
@@ -1747,11 +1749,13 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
 #pragma unroll
       for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
       const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
-      sc1_store_elem<E>(vq + row, sum);
-      const E pj = L.xs[row];
-      dre = (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
-      dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
-      pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+      if (FULL || row < N) {
+        sc1_store_elem<E>(vq + row, sum);
+        const E pj = L.xs[row];
+        dre = (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+        dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+        pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+      }
     }
     if (w == 0) {  // G*NV <= 16 lanes of wave 0 hold the terms; fixed-order butterfly
 #pragma unroll
@@ -1773,7 +1777,11 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
       break;
     }
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) vv[e] = sc1_load_elem<E>(vq + tid + (int64_t)e * NT);
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * NT;
+      vv[e] = sc1_load_elem<E>(vq + (FULL || i < N ? i : (N - 1)));
+      if (!FULL && i >= N) vv[e] = elem<E>::zero();
+    }
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
     {
       const int dt = tid < nwg ? tid : 0;
@@ -1787,7 +1795,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     }
     E pn[EPT], rn[EPT], al;
     cgnr_scalars Sn;
-    const bool done = cg_update_elems<E, EPT, NT, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    const bool done = cg_update_elems<E, EPT, NT, FULL>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       xv[e] = elem<E>::fma(pv[e], al, xv[e]);
@@ -1805,10 +1813,12 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int64_t i = tid + (int64_t)e * NT;
-      x[i] = xv[e];
-      r[i] = rv[e];
-      p[i] = pv[e];
-      v0[i] = vv[e];  // the last v (a workgroup still reading parity 0 reads the same values)
+      if (FULL || i < N) {
+        x[i] = xv[e];
+        r[i] = rv[e];
+        p[i] = pv[e];
+        v0[i] = vv[e];  // the last v (a workgroup still reading parity 0 reads the same values)
+      }
     }
     if (tid == 0) {
       S.pending = 0;
@@ -1932,7 +1942,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
 // ---- resident Gram-mode FISTA: as cgnr_gram_resident_kernel, for src/FISTA.jl:139-185 with AHA explicit ---------------
 // Per iteration: xs = y, this workgroup's rows of AHA y published (two parities), ONE grid exchange, then the gradient
 // step, prox, restart test, theta and the next extrapolated point redundantly in every workgroup.
-template <typename E, int K, int BAR>
+template <typename E, int K, int BAR, bool FULL>
 __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
                                                                    const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                    E* rr0, E* rr1, fista_scalars* sc0, fista_scalars* sc1,
@@ -1953,19 +1963,21 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     const E* xc = (S.iteration & 1) ? b1 : b0;  // state.x == buf[iteration & 1]
     const E* xo = (S.iteration & 1) ? b0 : b1;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {  // N == EPT * NT (full-size instantiation only)
+    for (int e = 0; e < EPT; ++e) {  // FULL: N == EPT * NT; else clamped loads, zeroed tails
       const int64_t i = tid + (int64_t)e * NT;
-      yv[e] = yc[i];
-      xk[e] = xc[i];
-      xp[e] = xo[i];
-      x0v[e] = x0[i];
-      ri[e] = res[i];
+      const int64_t ic = FULL || i < N ? i : (N - 1);
+      yv[e] = yc[ic];
+      xk[e] = xc[ic];
+      xp[e] = xo[ic];
+      x0v[e] = x0[ic];
+      ri[e] = res[ic];
+      if (!FULL && i >= N) yv[e] = xk[e] = xp[e] = x0v[e] = ri[e] = elem<E>::zero();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, NV> a[K];
-  slab_load<E, G, K, WV, true>(a, Gm, ldg, Mc, N, pair);
+  slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (S.done || n_steps <= 0) return;  // uniform
   unsigned epoch = 0;
@@ -1975,13 +1987,14 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     E* rq = (it & 1) ? rr1 : rr0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = yv[e];
-    gram_rows<E, G, K, WV, true>(a, L, Mc, N, pair);
+    gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
     if (tid < G * NV) {
       const int gg = tid / NV, i = tid % NV;
       E sum = elem<E>::zero();
 #pragma unroll
       for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
-      sc1_store_elem<E>(rq + (row_block_of(blockIdx.x, pair) * G + gg) * NV + i, sum);
+      const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
+      if (FULL || row < N) sc1_store_elem<E>(rq + row, sum);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1991,7 +2004,11 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     }
     E raw[EPT];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) raw[e] = sc1_load_elem<E>(rq + tid + (int64_t)e * NT);
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * NT;
+      raw[e] = sc1_load_elem<E>(rq + (FULL || i < N ? i : (N - 1)));
+      if (!FULL && i >= N) raw[e] = elem<E>::zero();
+    }
     E xn[EPT], yn[EPT];
     fista_scalars Sn;
     const bool done = fista_update_elems<E, EPT, NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
@@ -2016,10 +2033,12 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int64_t i = tid + (int64_t)e * NT;
-      xw[i] = xk[e];
-      xo[i] = xp[e];
-      yw[i] = yv[e];
-      res[i] = ri[e];
+      if (FULL || i < N) {
+        xw[i] = xk[e];
+        xo[i] = xp[e];
+        yw[i] = yv[e];
+        res[i] = ri[e];
+      }
     }
     __syncthreads();
     if (tid == 0) {
@@ -2460,25 +2479,29 @@ static int32_t launch_gram_resident(rls_ctx* ctx, const rls_gram_pipe& P, void* 
   using C = slab_cfg<E, 4, K, 8>;
   const int64_t Mc = P.N / C::NV;
   const int pair = (nwg % 16 == 0) ? 1 : 0;
-  if (g_resident_barrier == 0)
-    hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, 0>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
-                       (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],
-                       (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
-  else
-    hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, 1>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
-                       (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],
-                       (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+  const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
+#define RLS_LAUNCH_GR(BB, FF)                                                                                          \
+  hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, BB, FF>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,  \
+                     P.ldg, (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],         \
+                     (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
+  if (g_resident_barrier == 0) {
+    if (full) RLS_LAUNCH_GR(0, true);
+    else RLS_LAUNCH_GR(0, false);
+  } else {
+    if (full) RLS_LAUNCH_GR(1, true);
+    else RLS_LAUNCH_GR(1, false);
+  }
+#undef RLS_LAUNCH_GR
   return launch_status(ctx);
 }
 
-// full-size Gram slabs only (N = 128 K, every row chunk valid), one workgroup per CU
+// every Gram-pipeline shape whose workgroups (8 / 16 rows of AHA each) fit the CUs at one per CU: N <= 2048 CF32,
+// N <= 4096 F32 on 256 CUs; ragged N runs the masked instantiation
 template <typename E>
 static bool gram_resident_ok_typed(int device, int64_t N) {
   int K = 0;
   if (!gram_pick<E>(N, &K)) return false;
-  const int64_t Mc = N / elem<E>::vec;
   const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, N);
-  if (N != (int64_t)K * 128 || (int64_t)nwg * 4 != Mc) return false;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
   return nwg <= cus;
@@ -2499,14 +2522,19 @@ static int32_t launch_fista_gram_resident(rls_ctx* ctx, const rls_fista_gram& P,
   using C = slab_cfg<E, 4, K, 8>;
   const int64_t Mc = P.N / C::NV;
   const int pair = (nwg % 16 == 0) ? 1 : 0;
-  if (g_resident_barrier == 0)
-    hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, 0>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
-                       (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.rr[0], (E*)P.rr[1], P.sc[0],
-                       P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
-  else
-    hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, 1>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, P.ldg,
-                       (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.rr[0], (E*)P.rr[1], P.sc[0],
-                       P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+  const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
+#define RLS_LAUNCH_FGR(BB, FF)                                                                                         \
+  hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, BB, FF>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, \
+                     P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.rr[0], (E*)P.rr[1], \
+                     P.sc[0], P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
+  if (g_resident_barrier == 0) {
+    if (full) RLS_LAUNCH_FGR(0, true);
+    else RLS_LAUNCH_FGR(0, false);
+  } else {
+    if (full) RLS_LAUNCH_FGR(1, true);
+    else RLS_LAUNCH_FGR(1, false);
+  }
+#undef RLS_LAUNCH_FGR
   return launch_status(ctx);
 }
 
