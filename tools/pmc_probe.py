@@ -26,6 +26,21 @@ for _ in range(3):
     rls.init_(S2, b)
     ctx.lib.rls_fista_step(S2.state._plan, 32)
 ctx.sync()
+# Gram mode (AHA explicit): the resident Gram kernel, one launch per call of 32 iterations
+G = Ad.gram()
+S3 = rls.createLinearSolver(rls.CGNR, Ad, AHA=G, iterations=32, relTol=0.0)
+for _ in range(3):
+    rls.init_(S3, b)
+    ctx.lib.rls_cgnr_step(S3.state._plan, 32)
+ctx.sync()
+# shared-A batched solves on the matrix cores: 8 right-hand sides (half operand layout) and 16
+rng = np.random.default_rng(5)
+for K in (8, 16):
+    X = (rng.standard_normal((N, K)) + 1j * rng.standard_normal((N, K))).astype(np.complex64)
+    Bd = rls.DeviceMatrix.from_host(np.asfortranarray((A @ X).astype(np.complex64)), ctx)
+    S4 = rls.createLinearSolver(rls.CGNR, Ad, iterations=6, relTol=0.0)
+    rls.solve_(S4, Bd, scheduler=rls.BatchedState)
+    ctx.sync()
 p = rls.DeviceVector.from_host(np.ones(N, np.complex64), ctx); t = rls.DeviceVector(M, np.complex64, ctx); v = rls.DeviceVector(N, np.complex64, ctx)
 for _ in range(3):
     Ad.gemv_(0, p, t); Ad.gemv_(2, t, v)
