@@ -24,7 +24,7 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE x1", "kernels": {}}
 for k in fetch:
     short = k.replace("void ", "").replace("(anonymous namespace)::", "").split("<")[0].split("(")[0].strip()
-    if short.startswith("skinny_"):  # the half (<= 8 right-hand sides) and full operand layouts are different kernels
+    if short in ("skinny_t_kernel", "skinny_v_kernel", "skinny_pack_rows_kernel"):  # half (<= 8 right-hand sides) / full operand layout
         short += " [half layout]" if ", true" in k.split("(")[0] else " [full layout]"
     out["kernels"][short] = {"fetch_size_raw_bytes": fetch[k], "write_size_bytes": write.get(k, 0.0),
                              "hbm_bytes_per_launch": 2.0 * fetch[k] + write.get(k, 0.0)}
