@@ -62,10 +62,13 @@ int32_t rls_device_count(int32_t* out);
  * reference.  Per context: "gemvn_g", "gemvn_waves", "gemvt_cols" (0 = heuristic), "graph_chunk", "use_graph",
  * "fuse_level", "fused_normal" (one-pass normal operator), "cgnr_pipeline" (2-launch CGNR), "gram_pipeline"
  * (1-launch Gram-mode CGNR / cg), "batched_mfma" (matrix-core batched path and Gram GEMM), "pipe_hint_mode" (0: the
- * host tells the 2-launch pipeline which (r, p) buffer pair is current, 1: never, 2: deliberately wrong -- tests).  Process-wide
- * (measurement only, set before the plan is created): "slab_g", "slab_wv", "slab_order", "red_threads",
- * "tv_fused_max_n", "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits",
- * "kaczmarz_nt". */
+ * host tells the 2-launch pipeline which (r, p) buffer pair is current, 1: never, 2: deliberately wrong -- tests),
+ * "resident" (1: a whole step call as ONE launch with A / AHA held in registers where the shape allows, 0: the per-iteration
+ * pipelines), "resident_spin" (bound of the in-kernel waits, in polls).  Process-wide (measurement only, set before the
+ * plan is created): "slab_g", "slab_wv", "slab_order", "red_threads", "resident_barrier", "tv_fused_max_n",
+ * "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits", "skinny_half"
+ * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll" (rolling-window
+ * depth of the batched kernels' load pipelines), "gram_lds_kib", "kaczmarz_nt". */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
 
 int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out);  /* similar(b, dims...)  src/CGNR.jl:92-95 */
