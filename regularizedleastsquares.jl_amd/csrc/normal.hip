@@ -343,6 +343,19 @@ __device__ static inline int64_t own_index(int tid, int e) {
     return tid + (int64_t)e * NT;
   }
 }
+// the same for a vector of any length n (a multiple of the piece size): pieces at or beyond n come back as zeros (clamped
+// address, no branch around the load)
+template <typename E, int EPT, int NT>
+__device__ static inline void load_owned_wide_masked(E (&dst)[EPT], const E* __restrict__ src, int tid, int64_t n) {
+  constexpr int V = elem<E>::vec;
+#pragma unroll
+  for (int q = 0; q < EPT / V; ++q) {
+    const int64_t o = (int64_t)q * (NT * V) + (int64_t)tid * V;
+    const chunk<E, V> c = load_chunk<E, V>(src + (o < n ? o : 0));
+#pragma unroll
+    for (int j = 0; j < V; ++j) dst[q * V + j] = o < n ? c.e[j] : elem<E>::zero();
+  }
+}
 template <typename E, int EPT, int NT>
 __device__ static inline void load_owned_wide(E (&dst)[EPT], const E* __restrict__ src, int tid) {
   constexpr int V = elem<E>::vec;
@@ -762,7 +775,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const E* __restrict__ 
 // ---- FISTA pipeline: iteration = K_A (previous gradient/prox/momentum update + one pass over A) + K_R --
 // src/FISTA.jl:153-180 for the elements one thread owns, plus the NEXT iteration's Nesterov step (:144-148).
 // Every workgroup runs it redundantly (same inputs, same summation order => identical scalars).
-template <typename E, int EPT, int NT>
+// NOMASK: the caller's ownership layout is not the strided one and its elements beyond N are zeros already (they stay
+// zeros: the elementwise prox maps and projections map 0 to 0)
+template <typename E, int EPT, int NT, bool NOMASK = false>
 __device__ static inline bool fista_update_elems(const fista_scalars& S, const E (&raw)[EPT], const E (&x0v)[EPT],
                                                  const E (&yv)[EPT], const E (&xk)[EPT], int64_t N, double* red,
                                                  E (&ri)[EPT], E (&xn)[EPT], E (&yn)[EPT], fista_scalars& Sn) {
@@ -775,7 +790,7 @@ __device__ static inline bool fista_update_elems(const fista_scalars& S, const E
     E r = elem<E>::sub(raw[e], x0v[e]);                                   // res .-= x0      :153
     E xv = elem<E>::sub(yv[e], elem<E>::scale(rho, r));                   // x .-= rho .* res :154
     xv = fista_proj_elem<E>(fista_prox_elem<E>(xv, S.reg_kind, thr), S.proj_kind);
-    if (i >= N) {
+    if (!NOMASK && i >= N) {
       r = elem<E>::zero();
       xv = elem<E>::zero();
     }
@@ -1506,22 +1521,23 @@ __device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned epoch, un
 
 // workgroup j sums 64-byte column chunk j (and j + nwg, ...) of the partial rows in a fixed order, stores that piece
 // of v write-through and hands every summed column to `per_column(j, sum)` (threads 0..CW-1 of wave 0)
-template <typename E, int G, int K, int WV, typename F>
+template <typename E, int G, int K, int WV, bool FULL = true, typename F>
 __device__ static inline void resident_reduce_chunks(resident_lds<E, G, K, WV>& R, __amdgpu_buffer_rsrc_t slab_rs, E* v,
                                                      int nwg, int64_t N, F&& per_column) {
   constexpr int CW = 64 / (int)sizeof(E);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nchunks = (int)(N / CW);
+  const int nchunks = (int)((N + CW - 1) / CW);  // !FULL: the last chunk may be short (N is a multiple of the 16-byte piece)
   for (int ch = blockIdx.x; ch < nchunks; ch += nwg) {
     const int piece = lane >> 4, r16 = lane & 15;
     f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool piece_ok = FULL || (int64_t)ch * 64 + piece * 16 < N * (int64_t)sizeof(E);
     for (int row0 = 0; row0 < nwg; row0 += 256) {  // two independent loads per trip (one trip at 256 rows)
       const int ra = row0 + w * 16 + r16, rb = ra + 128;
-      const uint32_t col_off = (uint32_t)ch * 64u + (uint32_t)piece * 16u;
+      const uint32_t col_off = piece_ok ? (uint32_t)ch * 64u + (uint32_t)piece * 16u : 0u;
       const f4 ta = sc1_load16(slab_rs, (uint32_t)(ra < nwg ? ra : 0) * (uint32_t)(N * sizeof(E)) + col_off);
       const f4 tb = sc1_load16(slab_rs, (uint32_t)(rb < nwg ? rb : 0) * (uint32_t)(N * sizeof(E)) + col_off);
-      if (ra < nwg) acc += ta;
-      if (rb < nwg) acc += tb;
+      if (ra < nwg && piece_ok) acc += ta;
+      if (rb < nwg && piece_ok) acc += tb;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // the 16 rows of this wave: DPP butterfly inside a row of 16 lanes
@@ -1539,14 +1555,16 @@ __device__ static inline void resident_reduce_chunks(resident_lds<E, G, K, WV>& 
 #pragma unroll
       for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, reinterpret_cast<const E*>(&R.rp[ww][0])[tid]);
       const int j = ch * CW + tid;
-      sc1_store_elem<E>(v + j, sum);
-      per_column(j, sum);
+      if (FULL || j < N) {
+        sc1_store_elem<E>(v + j, sum);
+        per_column(j, sum);
+      }
     }
     __syncthreads();  // rp is reused by the next chunk
   }
 }
 
-template <typename E, int G, int K, int WV, int BAR>
+template <typename E, int G, int K, int WV, int BAR, bool FULL>
 __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* r, E* p,
                                                                  E* v, E* slab, double* dout, cgnr_scalars* sc,
                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair,
@@ -1563,13 +1581,19 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   cgnr_scalars S = *sc;
   // this thread's elements of the length-N vectors, in 16-byte pieces (own_index<.., WIDE = true>)
   E pv[EPT], rv[EPT], xv[EPT];
-  load_owned_wide<E, EPT, NT>(pv, p, tid);
-  load_owned_wide<E, EPT, NT>(rv, r, tid);
-  load_owned_wide<E, EPT, NT>(xv, x, tid);
+  if constexpr (FULL) {
+    load_owned_wide<E, EPT, NT>(pv, p, tid);
+    load_owned_wide<E, EPT, NT>(rv, r, tid);
+    load_owned_wide<E, EPT, NT>(xv, x, tid);
+  } else {  // ragged N (a multiple of the 16-byte piece): zeros beyond N, and they stay zeros through the update
+    load_owned_wide_masked<E, EPT, NT>(pv, p, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(rv, r, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(xv, x, tid, N);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, NV> a[K];
-  slab_load<E, G, K, WV, true>(a, A, lda, Mc, N, pair);
+  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (S.done || n_steps <= 0) return;  // uniform
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(v), d_rs = sc1_rsrc(dout);
@@ -1580,7 +1604,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
     // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through)
-    slab_finish<E, G, K, WV, true, true>(a, L, slab, Mc, N, pair);
+    slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
     STAMP(9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
@@ -1592,7 +1616,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     STAMP(11);
     // ---- sum my 64-byte column chunk(s) over all partial rows, fixed order -----------------------------
     double dre = 0.0, dim_ = 0.0, pp = 0.0;
-    resident_reduce_chunks<E, G, K, WV>(R, slab_rs, v, nwg, N, [&](int j, E sum) {
+    resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, v, nwg, N, [&](int j, E sum) {
       const E pj = L.xs[j];
       dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
       dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
@@ -1623,9 +1647,11 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     E vv[EPT];
 #pragma unroll
     for (int q = 0; q < EPT / NV; ++q) {
-      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((q * NT * NV + tid * NV) * sizeof(E))));
+      const int o = q * NT * NV + tid * NV;
+      const bool ok = FULL || o < N;
+      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((ok ? o : 0) * sizeof(E))));
 #pragma unroll
-      for (int j = 0; j < NV; ++j) vv[q * NV + j] = c.e[j];
+      for (int j = 0; j < NV; ++j) vv[q * NV + j] = ok ? c.e[j] : elem<E>::zero();
     }
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
     {
@@ -1669,9 +1695,11 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
         cp.e[j] = pv[q * NV + j];
       }
       const int64_t o = (int64_t)q * (NT * NV) + (int64_t)tid * NV;
-      *reinterpret_cast<f4*>(x + o) = __builtin_bit_cast(f4, cx);
-      *reinterpret_cast<f4*>(r + o) = __builtin_bit_cast(f4, cr);
-      *reinterpret_cast<f4*>(p + o) = __builtin_bit_cast(f4, cp);
+      if (FULL || o < N) {
+        *reinterpret_cast<f4*>(x + o) = __builtin_bit_cast(f4, cx);
+        *reinterpret_cast<f4*>(r + o) = __builtin_bit_cast(f4, cr);
+        *reinterpret_cast<f4*>(p + o) = __builtin_bit_cast(f4, cp);
+      }
     }
     if (tid == 0) {
       S.pending = 0;
@@ -1836,7 +1864,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
 // Per iteration: xs = y, partial rows of AHA y, exchange 1, chunk sums -> res_raw, exchange 2, then the gradient step,
 // prox, restart test, theta and the next extrapolated point redundantly in every workgroup (fista_update_elems: its
 // two scalar sums run over full vectors every workgroup holds, so no partial dots travel).
-template <typename E, int G, int K, int WV, int BAR>
+template <typename E, int G, int K, int WV, int BAR, bool FULL>
 __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
                                                                   const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                   E* raw_g, E* slab, fista_scalars* sc,
@@ -1853,15 +1881,23 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   fista_scalars S;
   RLS_FISTA_COPY(S, *sc);
   E yv[EPT], xk[EPT], xp[EPT], x0v[EPT], ri[EPT];
-  load_owned_wide<E, EPT, NT>(yv, S.ycur ? y1 : y0, tid);
-  load_owned_wide<E, EPT, NT>(xk, (S.iteration & 1) ? b1 : b0, tid);  // state.x == buf[iteration & 1]
-  load_owned_wide<E, EPT, NT>(xp, (S.iteration & 1) ? b0 : b1, tid);
-  load_owned_wide<E, EPT, NT>(x0v, x0, tid);
-  load_owned_wide<E, EPT, NT>(ri, res, tid);
+  if constexpr (FULL) {
+    load_owned_wide<E, EPT, NT>(yv, S.ycur ? y1 : y0, tid);
+    load_owned_wide<E, EPT, NT>(xk, (S.iteration & 1) ? b1 : b0, tid);  // state.x == buf[iteration & 1]
+    load_owned_wide<E, EPT, NT>(xp, (S.iteration & 1) ? b0 : b1, tid);
+    load_owned_wide<E, EPT, NT>(x0v, x0, tid);
+    load_owned_wide<E, EPT, NT>(ri, res, tid);
+  } else {
+    load_owned_wide_masked<E, EPT, NT>(yv, S.ycur ? y1 : y0, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(xk, (S.iteration & 1) ? b1 : b0, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(xp, (S.iteration & 1) ? b0 : b1, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(ri, res, tid, N);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, NV> a[K];
-  slab_load<E, G, K, WV, true>(a, A, lda, Mc, N, pair);
+  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (S.done || n_steps <= 0) return;  // uniform
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(raw_g);
@@ -1871,14 +1907,14 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   for (int it = 0; it < n_steps; ++it) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = yv[e];
-    slab_finish<E, G, K, WV, true, true>(a, L, slab, Mc, N, pair);
+    slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
       alive = false;
       break;
     }
-    resident_reduce_chunks<E, G, K, WV>(R, slab_rs, raw_g, nwg, N, [](int, E) {});
+    resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, raw_g, nwg, N, [](int, E) {});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
@@ -1888,13 +1924,15 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     E raw[EPT];
 #pragma unroll
     for (int q = 0; q < EPT / NV; ++q) {
-      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((q * NT * NV + tid * NV) * sizeof(E))));
+      const int o = q * NT * NV + tid * NV;
+      const bool ok = FULL || o < N;
+      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((ok ? o : 0) * sizeof(E))));
 #pragma unroll
-      for (int j = 0; j < NV; ++j) raw[q * NV + j] = c.e[j];
+      for (int j = 0; j < NV; ++j) raw[q * NV + j] = ok ? c.e[j] : elem<E>::zero();
     }
     E xn[EPT], yn[EPT];
     fista_scalars Sn;
-    const bool done = fista_update_elems<E, EPT, NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    const bool done = fista_update_elems<E, EPT, NT, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       xp[e] = xk[e];
@@ -1924,10 +1962,12 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
         c3.e[j] = ri[q * NV + j];
       }
       const int64_t o = (int64_t)q * (NT * NV) + (int64_t)tid * NV;
-      *reinterpret_cast<f4*>(xw + o) = __builtin_bit_cast(f4, c0);
-      *reinterpret_cast<f4*>(xo + o) = __builtin_bit_cast(f4, c1);
-      *reinterpret_cast<f4*>(yw + o) = __builtin_bit_cast(f4, c2);
-      *reinterpret_cast<f4*>(res + o) = __builtin_bit_cast(f4, c3);
+      if (FULL || o < N) {
+        *reinterpret_cast<f4*>(xw + o) = __builtin_bit_cast(f4, c0);
+        *reinterpret_cast<f4*>(xo + o) = __builtin_bit_cast(f4, c1);
+        *reinterpret_cast<f4*>(yw + o) = __builtin_bit_cast(f4, c2);
+        *reinterpret_cast<f4*>(res + o) = __builtin_bit_cast(f4, c3);
+      }
     }
     if (tid == 0) {
       S.ycur = ycur;
@@ -2384,21 +2424,28 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
   if constexpr (K == 32 && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
     const int64_t Mc = P.M / C::NV;
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+    const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
     constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
     static bool attr_set = false;
     if (!attr_set) {
-      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 0>, lds);
-      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 0, true>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, true>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 0, false>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, false>, lds);
       attr_set = true;
     }
-    if (g_resident_barrier == 0)
-      hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, 0>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
-                         (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N, pair,
-                         n_steps, spin_limit);
-    else
-      hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, 1>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
-                         (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N, pair,
-                         n_steps, spin_limit);
+#define RLS_LAUNCH_RES(BB, FF)                                                                                          \
+  hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
+                     P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N,  \
+                     pair, n_steps, spin_limit)
+    if (g_resident_barrier == 0) {
+      if (full) RLS_LAUNCH_RES(0, true);
+      else RLS_LAUNCH_RES(0, false);
+    } else {
+      if (full) RLS_LAUNCH_RES(1, true);
+      else RLS_LAUNCH_RES(1, false);
+    }
+#undef RLS_LAUNCH_RES
     return launch_status(ctx);
   } else {
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident CGNR: slab shape not instantiated");
@@ -2410,9 +2457,10 @@ static bool resident_ok_typed(int device, int64_t M, int64_t N, const void* A, i
   if (!fused_ok<E>(M, N, A, lda)) return false;
   fused_cfg c;
   if (!pick_cfg<E>(N, &c) || c.K != 32 || c.WV != 8 || (elem<E>::cplx && c.G == 4)) return false;
-  const int64_t nmax = (int64_t)c.K * c.WV * (64 / c.G), Mc = M / elem<E>::vec;
+  // the K = 32 slab shapes: N in (NMAX / 2, NMAX], N a multiple of the 16-byte piece; ragged M and N run the masked
+  // instantiation (the full-size one has no clamps at all)
   const int64_t nwg = fused_nwg<E>(M, N);
-  if (N != nmax || nwg * c.G != Mc) return false;  // the full-size instantiation only
+  if (N % elem<E>::vec) return false;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
   // one 512-thread workgroup (256 VGPRs per lane, ~148 KiB of LDS) per CU: the grid is resident iff it fits the CUs
@@ -2440,21 +2488,28 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
   if constexpr (K == 32 && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
     const int64_t Mc = P.M / C::NV;
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+    const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
     constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
     static bool attr_set = false;
     if (!attr_set) {
-      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 0>, lds);
-      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 0, true>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, true>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 0, false>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, false>, lds);
       attr_set = true;
     }
-    if (g_resident_barrier == 0)
-      hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, 0>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
-                         (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab, P.sc,
-                         (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
-    else
-      hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, 1>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, P.lda,
-                         (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab, P.sc,
-                         (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit);
+#define RLS_LAUNCH_FRES(BB, FF)                                                                                          \
+  hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
+                     P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab,  \
+                     P.sc, (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
+    if (g_resident_barrier == 0) {
+      if (full) RLS_LAUNCH_FRES(0, true);
+      else RLS_LAUNCH_FRES(0, false);
+    } else {
+      if (full) RLS_LAUNCH_FRES(1, true);
+      else RLS_LAUNCH_FRES(1, false);
+    }
+#undef RLS_LAUNCH_FRES
     return launch_status(ctx);
   } else {
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident FISTA: slab shape not instantiated");
