@@ -2421,7 +2421,7 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
                                unsigned spin_limit) {
   using C = slab_cfg<E, G, K, WV>;
   // (complex with 64-byte row pieces holds 8 owned elements of x, r, p, v per thread on top of the slab: spills)
-  if constexpr (K == 32 && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
+  if constexpr ((K == 32 || K == 16) && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
     const int64_t Mc = P.M / C::NV;
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
@@ -2456,7 +2456,8 @@ template <typename E>
 static bool resident_ok_typed(int device, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (!fused_ok<E>(M, N, A, lda)) return false;
   fused_cfg c;
-  if (!pick_cfg<E>(N, &c) || c.K != 32 || c.WV != 8 || (elem<E>::cplx && c.G == 4)) return false;
+  if (!pick_cfg<E>(N, &c) || (c.K != 32 && c.K != 16) || c.WV != 8 || (elem<E>::cplx && c.G == 4)) return false;
+  if (((int64_t)c.K * c.WV * (64 / c.G) / (c.WV * 64)) % elem<E>::vec) return false;  // 16-byte ownership pieces: EPT % V == 0
   // the K = 32 slab shapes: N in (NMAX / 2, NMAX], N a multiple of the 16-byte piece; ragged M and N run the masked
   // instantiation (the full-size one has no clamps at all)
   const int64_t nwg = fused_nwg<E>(M, N);
@@ -2485,7 +2486,7 @@ template <typename E, int G, int K, int WV>
 static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void* sync, int nwg, int n_steps,
                                      unsigned spin_limit) {
   using C = slab_cfg<E, G, K, WV>;
-  if constexpr (K == 32 && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
+  if constexpr ((K == 32 || K == 16) && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
     const int64_t Mc = P.M / C::NV;
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;

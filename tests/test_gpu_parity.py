@@ -1981,7 +1981,8 @@ def _cgnr_path(rls, sol):
 @pytest.mark.parametrize("dt,M,N,lam", [(np.complex64, 4096, 2048, 0.0), (np.complex64, 4096, 2048, 1e-2), (np.float32, 4096, 4096, 0.0),
                                        (np.float32, 2048, 4096, 1e-3),
                                        # ragged M and N: the masked instantiation (N in (NMAX / 2, NMAX], fewer workgroups than CUs)
-                                       (np.complex64, 4000, 2000, 1e-3), (np.complex64, 3000, 1502, 0.0), (np.float32, 4000, 2200, 0.0)])
+                                       (np.complex64, 4000, 2000, 1e-3), (np.complex64, 3000, 1502, 0.0), (np.float32, 4000, 2200, 0.0),
+                                       (np.complex64, 2048, 1024, 0.0), (np.complex64, 1800, 900, 1e-3), (np.float32, 3000, 1600, 0.0)])
 def test_cgnr_resident_kernel(rls, ctx, dt, M, N, lam):
     """rls_cgnr_step as ONE launch (cgnr_resident_kernel: A held in registers, two in-kernel grid exchanges per
     iteration): iterates against the float64 oracle at iterations 1 / 5 / 10 / 32, bit-identical run to run and
