@@ -49,8 +49,10 @@ struct step_graph {
   bool failed = false;
 };
 
-template <typename F>
-static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue_one) {
+// `rewind(c)`: a capture that fails has already called enqueue_one c times WITHOUT any of those launches running; a
+// caller whose callback keeps a position (parity, launch index) gets the chance to step it back before the eager retry.
+template <typename F, typename R>
+static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue_one, R&& rewind) {
   const int chunk = ctx->tune.graph_chunk;
   while (n_steps > 0) {
     if (ctx->tune.use_graph && chunk > 1 && n_steps >= chunk && !big->failed) {
@@ -63,8 +65,9 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
         std::unique_lock<std::mutex> capture_lock(rls_capture_mutex());
         hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
         int32_t st = 0;
+        int calls = 0;
         if (e == hipSuccess) {
-          for (int i = 0; i < chunk && st == 0; ++i) st = enqueue_one();
+          for (int i = 0; i < chunk && st == 0; ++i, ++calls) st = enqueue_one();
           e = hipStreamEndCapture(ctx->stream, &graph);
         }
         capture_lock.unlock();
@@ -73,6 +76,7 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
           big->failed = true;  // fall back to eager launches (still the HIP kernels)
           big->exec = nullptr;
           (void)hipGetLastError();
+          rewind(calls);
         } else {
           big->steps = chunk;
         }
@@ -87,6 +91,11 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
     }
   }
   return 0;
+}
+
+template <typename F>
+static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue_one) {
+  return run_steps(ctx, big, n_steps, enqueue_one, [](int) {});
 }
 
 // Which (r, p) pair launch k of a step call finds current (rls_cgnr_pipe::cur_hint): the call starts at pair 0
@@ -1488,7 +1497,7 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     if (ctx->tune.graph_chunk % 2) {
       for (int i = 0; i < maxiter; ++i) RLS_TRY(one());
     } else {
-      RLS_TRY(run_steps(ctx, &s->graph, maxiter, one));
+      RLS_TRY(run_steps(ctx, &s->graph, maxiter, one, [&parity](int c) { parity ^= c & 1; }));
     }
     return rls_gram_pipe_finish(ctx, dtype, P, maxiter & 1);
   }
@@ -1524,7 +1533,7 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     RLS_TRY(run_steps(ctx, &s->graph, maxiter, [ctx, dtype, &P, &k]() {
       P.cur_hint = pipe_cur_hint(ctx, k++);
       return rls_cgnr_pipe_iteration(ctx, dtype, P);
-    }));
+    }, [&k](int c) { k -= c; }));
     return rls_cgnr_pipe_finish(ctx, dtype, P);
   }
   if (op->dtype == RLS_F32)
@@ -2010,7 +2019,7 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
     if (ctx->tune.graph_chunk % 2) {  // an odd chunk would replay the captured parities out of phase
       for (int i = 0; i < n_steps; ++i) RLS_TRY(one());
     } else {
-      RLS_TRY(run_steps(ctx, &s->graph, n_steps, one));
+      RLS_TRY(run_steps(ctx, &s->graph, n_steps, one, [&parity](int c) { parity ^= c & 1; }));
     }
     return rls_gram_pipe_finish(ctx, dtype, P, n_steps & 1);
   }
@@ -2036,7 +2045,7 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
     RLS_TRY(run_steps(ctx, &s->graph, n_steps, [ctx, dtype, &P, &k]() {
       P.cur_hint = pipe_cur_hint(ctx, k++);
       return rls_cgnr_pipe_iteration(ctx, dtype, P);
-    }));
+    }, [&k](int c) { k -= c; }));
     return rls_cgnr_pipe_finish(ctx, dtype, P);
   }
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR: fused pipeline switched off");
@@ -2522,7 +2531,7 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
     if (ctx->tune.graph_chunk % 2) {
       for (int i = 0; i < n_steps; ++i) RLS_TRY(one());
     } else {
-      RLS_TRY(run_steps(ctx, &s->graph, n_steps, one));
+      RLS_TRY(run_steps(ctx, &s->graph, n_steps, one, [&parity, &k](int c) { parity ^= c & 1; k -= c; }));
     }
     s->enq += n_steps;
     return rls_fista_gram_finish(ctx, dtype, P, n_steps & 1);
@@ -2557,7 +2566,7 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
       if (h >= 0 && ctx->tune.pipe_hint_mode == 2) P.par_hint ^= 1;  // tests: exercise the check-and-reload path
       ++k;
       return rls_fista_pipe_iteration(ctx, dtype, P);
-    }));
+    }, [&k](int c) { k -= c; }));
     s->enq += n_steps;
     return rls_fista_pipe_finish(ctx, dtype, P);
   }
