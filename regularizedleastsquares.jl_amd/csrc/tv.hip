@@ -311,40 +311,71 @@ __global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, 
   __syncthreads();
   float t = 1.f;
   const float step = 1.f / (8.f * lam);
+  // Neighbour addresses, clamped once (a masked-out neighbour is read from the pixel itself and its value discarded): the
+  // loop body then has no branch around an LDS access and the 2 PPT neighbour reads of a phase go out back to back.
+  // Measured: 64 x 64 Float32, 10 iterations 20.6 -> 20.1 us -- little, because the kernel is bound by the VALU rate of
+  // the ONE CU it runs on (time per FGP iteration scales with the pixels per thread: 0.36 us at one, 1.5 us at four),
+  // not by LDS latency.  The arithmetic is unchanged: a masked-out term is +0 under a subtraction and -0 under an
+  // addition, which leave every value -- and the sign of a zero -- as it was.
+  unsigned kc[PPT], kPm[PPT], kQm[PPT], kPp[PPT], kQp[PPT];
+#pragma unroll
+  for (int m = 0; m < PPT; ++m) {
+    const unsigned k = tid + m * nth;
+    kc[m] = (mIn >> m & 1) ? k : 0u;
+    kPm[m] = (mPm >> m & 1) ? k - 1 : kc[m];
+    kQm[m] = (mQm >> m & 1) ? k - nx : kc[m];
+    kPp[m] = (mP >> m & 1) ? k + 1 : kc[m];
+    kQp[m] = (mQ >> m & 1) ? k + nx : kc[m];
+  }
+  const E pz = elem<E>::zero(), nz = elem<E>::make(-0.f, -0.f);
   for (int it = 0; it < iters; ++it) {
+    E nP[PPT], nQ[PPT];
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
-      const unsigned k = tid + m * nth;
-      if (mIn >> m & 1) {
-        E s = elem<E>::zero();
-        if (mP >> m & 1) s = elem<E>::add(s, rp[m]);
-        if (mPm >> m & 1) s = elem<E>::sub(s, P[k - 1]);
-        if (mQ >> m & 1) s = elem<E>::add(s, rq[m]);
-        if (mQm >> m & 1) s = elem<E>::sub(s, Q[k - nx]);
-        xv[m] = elem<E>::add(xl[m], elem<E>::scale(-lam, s));
-        xt[k] = xv[m];
-      }
+      nP[m] = P[kPm[m]];
+      nQ[m] = Q[kQm[m]];
+    }
+#pragma unroll
+    for (int m = 0; m < PPT; ++m) {
+      E s = elem<E>::zero();
+      s = elem<E>::add(s, (mP >> m & 1) ? rp[m] : nz);
+      s = elem<E>::sub(s, (mPm >> m & 1) ? nP[m] : pz);
+      s = elem<E>::add(s, (mQ >> m & 1) ? rq[m] : nz);
+      s = elem<E>::sub(s, (mQm >> m & 1) ? nQ[m] : pz);
+      xv[m] = elem<E>::add(xl[m], elem<E>::scale(-lam, s));
+      if (mIn >> m & 1) xt[kc[m]] = xv[m];
     }
     __syncthreads();
     const float tOld = t;
     t = (1.f + sqrtf(1.f + 4.f * tOld * tOld)) / 2.f;
     const float t2 = (tOld - 1.f) / t, t3 = 1.f + t2;
+    E xP[PPT], xQ[PPT];
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
-      const unsigned k = tid + m * nth;
-      if (mP >> m & 1) {
-        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xt[k + 1])), rp[m]);
+      xP[m] = xt[kPp[m]];
+      xQ[m] = xt[kQp[m]];
+    }
+#pragma unroll
+    for (int m = 0; m < PPT; ++m) {
+      {
+        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xP[m])), rp[m]);
         q = tv_clip<E>(q);
-        rp[m] = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pp[m]));
-        pp[m] = q;
-        P[k] = rp[m];
+        const E rn = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pp[m]));
+        const bool on = mP >> m & 1;
+        rp[m] = on ? rn : rp[m];
+        pp[m] = on ? q : pp[m];
       }
-      if (mQ >> m & 1) {
-        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xt[k + nx])), rq[m]);
+      {
+        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xQ[m])), rq[m]);
         q = tv_clip<E>(q);
-        rq[m] = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pq[m]));
-        pq[m] = q;
-        Q[k] = rq[m];
+        const E rn = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pq[m]));
+        const bool on = mQ >> m & 1;
+        rq[m] = on ? rn : rq[m];
+        pq[m] = on ? q : pq[m];
+      }
+      if (mIn >> m & 1) {  // masked-out duals stay zero, so the unconditional store writes what is there already
+        P[kc[m]] = rp[m];
+        Q[kc[m]] = rq[m];
       }
     }
     __syncthreads();
