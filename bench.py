@@ -381,8 +381,23 @@ def other_paths(rls, ctx, Ad, A, b, errors):
             ctx.sync(); dts.append((time.perf_counter() - t0) / 50)
         ms = 1e3 * min(dts)
         alg = 11 * 2 * M3 * N3 * 4  # 11 normal-operator applies per outer iteration, A read twice each on the reference path
-        return {"ms_per_outer_iteration": ms, "inner_cg_iterations": S.state.cg_iterations, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
-                "frac_algorithmic": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        res = {"ms_per_outer_iteration": ms, "inner_cg_iterations": S.state.cg_iterations, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
+               "frac_algorithmic": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # the same solver built the way the reference constructor builds it for a dense matrix (AHA = A'*A explicit,
+        # src/ADMM.jl:82): cg! on the 64 MiB Gram matrix, resident in the register files
+        t0 = time.perf_counter(); G3 = A3d.gram(); ctx.sync(); tg = time.perf_counter() - t0
+        Sg = rls.createLinearSolver(rls.ADMM, A3d, AHA=G3, reg=rls.TVRegularization(1e-2, shape=(64, 64)), rho=0.1, iterations=10,
+                                    iterationsCG=10, tolInner=1e-5)
+        rls.solve_(Sg, b3); rls.solve_(Sg, b3); ctx.sync()
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(5):
+                rls.solve_(Sg, b3)
+            ctx.sync(); dts.append((time.perf_counter() - t0) / 50)
+        res["gram_mode (AHA = A'*A explicit, the reference constructor's default for a dense matrix)"] = {
+            "ms_per_outer_iteration": 1e3 * min(dts), "setup_gram_gemm_ms": 1e3 * tg, "inner_cg_iterations": Sg.state.cg_iterations}
+        return res
 
     return out
 

@@ -1734,7 +1734,8 @@ template <typename E, int K, int BAR, bool FULL>
 __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* x, E* r, E* p,
                                                                   E* v0, E* v1, double* dots, cgnr_scalars* sc0,
                                                                   cgnr_scalars* sc1, resident_sync* sync, int64_t Mc,
-                                                                  int64_t N, int pair, int n_steps, unsigned spin_limit) {
+                                                                  int64_t N, int pair, int n_steps, unsigned spin_limit,
+                                                                  rls_cg_start St) {
   constexpr int G = 4, WV = 8;
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
@@ -1742,6 +1743,21 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nwg = gridDim.x;
+  if (St.enabled && St.skip && *St.skip) {  // the ADMM plan is done: this cg! is a no-op (uniform: every workgroup reads the flag)
+    if (blockIdx.x == 0 && tid == 0) {
+      cgnr_scalars Z = *sc0;
+      Z.iteration = 0;
+      Z.max_iter = St.maxiter;
+      Z.pending = 0;
+      Z.cur = 0;
+      Z.fresh = 0;
+      Z.done = 1;
+      *sc0 = Z;
+      *sc1 = Z;
+      sync->completed = 1u;
+    }
+    return;
+  }
   cgnr_scalars S = *sc0;
   E pv[EPT], rv[EPT], xv[EPT], vv[EPT];
 #pragma unroll
@@ -1759,10 +1775,74 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
   chunk<E, NV> a[K];
   slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
-  if (S.done || n_steps <= 0) return;  // uniform
+  if (!St.enabled && (S.done || n_steps <= 0)) return;  // uniform
   const __amdgpu_buffer_rsrc_t d_rs = sc1_rsrc(dots);
   unsigned epoch = 0;
   bool alive = true;
+  if (St.enabled) {
+    // ---- cg! entry: c = AHA x (one more product + exchange, parity-1 buffer), r = b - (c + rho x), p = r ------------------
+    // (cg_pipe_start_kernel of solvers.hip, folded in: no separate operator apply, no start kernel, no reload of r and p)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = xv[e];
+    gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
+    if (tid < G * NV) {
+      const int gg = tid / NV, i = tid % NV;
+      E sum = elem<E>::zero();
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+      const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
+      if (FULL || row < N) sc1_store_elem<E>(v1 + row, sum);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
+      if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    const E* bb = reinterpret_cast<const E*>(St.b);
+    const E* by = reinterpret_cast<const E*>(St.beta_y);
+    const E* zz = reinterpret_cast<const E*>(St.z);
+    const E* uu = reinterpret_cast<const E*>(St.u);
+    double rr = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = tid + (int64_t)e * NT;
+      const bool ok = FULL || i < N;
+      const int64_t ic = ok ? i : (N - 1);
+      const E ci = elem<E>::add(sc1_load_elem<E>(v1 + ic), elem<E>::scale(St.rho, xv[e]));
+      E bi;
+      if (by) {  // beta = beta_y + rho (z - u)   (src/ADMM.jl:236-241), stored with xold = x by workgroup 0
+        bi = by[ic];
+        bi = elem<E>::add(bi, elem<E>::scale(St.rho_admm, zz[ic]));
+        bi = elem<E>::add(bi, elem<E>::scale(-St.rho_admm, uu[ic]));
+        if (blockIdx.x == 0 && ok) {
+          reinterpret_cast<E*>(St.beta)[i] = bi;
+          reinterpret_cast<E*>(St.xold)[i] = xv[e];
+        }
+      } else {
+        bi = bb[ic];
+      }
+      E ri = elem<E>::sub(bi, ci);
+      if (!ok) ri = elem<E>::zero();
+      rv[e] = ri;
+      pv[e] = ri;
+      rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+    }
+    rr = block_sum_n<NT / 64>(rr, L.red);
+    S.rr = rr;
+    S.z0 = sqrt(rr);
+    S.zeta = 0.0;
+    S.alpha_re = S.alpha_im = S.beta_re = S.beta_im = 0.0;
+    S.lambda = St.rho;
+    S.rel_tol = St.reltol;
+    S.iteration = 0;
+    S.max_iter = St.maxiter;
+    S.pending = 0;
+    S.cur = 0;
+    S.fresh = 0;
+    S.done = (St.maxiter <= 0) || (rr == 0.0) || (1.0f <= St.reltol);
+    if (S.done) n_steps = 0;  // uniform: nothing to iterate; the state below is written back as it stands
+  }
   int it = 0;
   for (; it < n_steps; ++it) {
     const int q = it & 1;
@@ -2531,7 +2611,7 @@ static int32_t fista_resident_typed(rls_ctx* ctx, const rls_fista_pipe& P, void*
 }
 template <typename E, int K>
 static int32_t launch_gram_resident(rls_ctx* ctx, const rls_gram_pipe& P, void* sync, int nwg, int n_steps,
-                                    unsigned spin_limit) {
+                                    unsigned spin_limit, const rls_cg_start& St) {
   using C = slab_cfg<E, 4, K, 8>;
   const int64_t Mc = P.N / C::NV;
   const int pair = (nwg % 16 == 0) ? 1 : 0;
@@ -2539,7 +2619,7 @@ static int32_t launch_gram_resident(rls_ctx* ctx, const rls_gram_pipe& P, void* 
 #define RLS_LAUNCH_GR(BB, FF)                                                                                          \
   hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, BB, FF>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,  \
                      P.ldg, (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],         \
-                     (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
+                     (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, St)
   if (g_resident_barrier == 0) {
     if (full) RLS_LAUNCH_GR(0, true);
     else RLS_LAUNCH_GR(0, false);
@@ -2564,13 +2644,14 @@ static bool gram_resident_ok_typed(int device, int64_t N) {
 }
 
 template <typename E>
-static int32_t gram_resident_typed(rls_ctx* ctx, const rls_gram_pipe& P, void* sync, int n_steps, unsigned spin_limit) {
+static int32_t gram_resident_typed(rls_ctx* ctx, const rls_gram_pipe& P, void* sync, int n_steps, unsigned spin_limit,
+                                   const rls_cg_start& St) {
   int K = 0;
   if (!gram_pick<E>(P.N, &K)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram CGNR: N too large");
   const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
-  if (K == 8) return launch_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit);
-  if (K == 16) return launch_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit);
-  return launch_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
+  if (K == 8) return launch_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit, St);
+  if (K == 16) return launch_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit, St);
+  return launch_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit, St);
 }
 template <typename E, int K>
 static int32_t launch_fista_gram_resident(rls_ctx* ctx, const rls_fista_gram& P, void* sync, int nwg, int n_steps,
@@ -2646,9 +2727,9 @@ bool rls_gram_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, const void* G,
   return dtype == RLS_F32 ? gram_resident_ok_typed<float>(ctx->device, N) : gram_resident_ok_typed<float2>(ctx->device, N);
 }
 int32_t rls_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, void* sync, int n_steps,
-                                 unsigned spin_limit) {
-  if (dtype == RLS_F32) return gram_resident_typed<float>(ctx, P, sync, n_steps, spin_limit);
-  return gram_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit);
+                                 unsigned spin_limit, const rls_cg_start& St) {
+  if (dtype == RLS_F32) return gram_resident_typed<float>(ctx, P, sync, n_steps, spin_limit, St);
+  return gram_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit, St);
 }
 
 

@@ -1460,6 +1460,29 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
   const int64_t n = op->N;
   const admm_fuse<float> Ff = typed_fuse<float>(FV);
   const admm_fuse<float2> Fc = typed_fuse<float2>(FV);
+  if (cg_use_gram_pipeline(s) && s->gram_resident && s->rsync && ctx->tune.resident && maxiter > 0) {
+    // Gram mode, AHA in the register files: the whole cg! -- warm-start apply, r = b - (AHA + rho I) x (with beta formed on
+    // the way for ADMM), every iteration -- is ONE launch of cgnr_gram_resident_kernel (normal.hip)
+    s->used_pipeline = true;
+    s->resident_used = true;
+    const rls_gram_pipe P = cg_gram_desc(s, x);
+    rls_cg_start St;
+    St.enabled = 1;
+    St.b = b;
+    St.beta_y = FV.beta_y;
+    St.z = FV.z;
+    St.u = FV.u;
+    St.beta = FV.beta;
+    St.xold = FV.xold;
+    St.rho_admm = FV.rho;
+    St.rho = rho;
+    St.reltol = reltol;
+    St.maxiter = maxiter;
+    St.skip = FV.skip;
+    return resident_chain(ctx, s->rsync, [&]() {
+      return rls_gram_resident_launch(ctx, op->dtype, P, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin, St);
+    });
+  }
   // warm start: one operator apply for r = b - (AHA + rho I) x
   RLS_TRY(op_normal(op, x, s->c, FV.skip));
   if (cg_use_gram_pipeline(s)) {
@@ -1475,13 +1498,6 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     RLS_TRY(launch_status(ctx));
     const rls_gram_pipe P = cg_gram_desc(s, x);
     const int32_t dtype = op->dtype;
-    if (s->gram_resident && s->rsync && ctx->tune.resident && maxiter > 0) {
-      // the whole inner solve as ONE launch with AHA in registers (cgnr_gram_resident_kernel, normal.hip)
-      s->resident_used = true;
-      return resident_chain(ctx, s->rsync, [&]() {
-        return rls_gram_resident_launch(ctx, dtype, P, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin);
-      });
-    }
     if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 3)) {  // the captured kernels carry x's address
       hipGraphExecDestroy(s->graph.exec);
       s->graph = step_graph();
