@@ -1568,7 +1568,7 @@ template <typename E, int G, int K, int WV, int BAR, bool FULL>
 __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* r, E* p,
                                                                  E* v, E* slab, double* dout, cgnr_scalars* sc,
                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair,
-                                                                 int n_steps, unsigned spin_limit) {
+                                                                 int n_steps, unsigned spin_limit, rls_cg_start St) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
   constexpr int CW = 64 / (int)sizeof(E);  // columns of a 64-byte chunk: 8 complex / 16 real
@@ -1578,6 +1578,20 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   slab_lds<E, G, K, WV>& L = R.L;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nwg = gridDim.x;
+  if (St.enabled && St.skip && *St.skip) {  // the ADMM plan is done: this cg! is a no-op (uniform: every workgroup reads the flag)
+    if (blockIdx.x == 0 && tid == 0) {
+      cgnr_scalars Z = *sc;
+      Z.iteration = 0;
+      Z.max_iter = St.maxiter;
+      Z.pending = 0;
+      Z.cur = 0;
+      Z.fresh = 0;
+      Z.done = 1;
+      *sc = Z;
+      sync->completed = 1u;
+    }
+    return;
+  }
   cgnr_scalars S = *sc;
   // this thread's elements of the length-N vectors, in 16-byte pieces (own_index<.., WIDE = true>)
   E pv[EPT], rv[EPT], xv[EPT];
@@ -1595,10 +1609,80 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   chunk<E, NV> a[K];
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
-  if (S.done || n_steps <= 0) return;  // uniform
+  if (!St.enabled && (S.done || n_steps <= 0)) return;  // uniform
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(v), d_rs = sc1_rsrc(dout);
   unsigned epoch = 0;
   bool alive = true;
+  if (St.enabled) {
+    // ---- cg! entry (cg_pipe_start_kernel of solvers.hip, folded in): c = AHA x through the same two exchanges, then
+    // r = b - (c + rho x), p = r and the scalars of the solve, redundantly in every workgroup ----------------------------
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = xv[e];
+    slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool ok_sync = grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag);
+    if (ok_sync) {
+      resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, v, nwg, N, [](int, E) {});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      ok_sync = grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag);
+    }
+    if (!ok_sync) {
+      if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    double rr = 0.0;
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      const int o = q * NT * NV + tid * NV;
+      const bool ok = FULL || o < N;
+      const int oc = ok ? o : 0;
+      const chunk<E, NV> cc = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)(oc * sizeof(E))));
+      chunk<E, NV> bi;
+      if (St.beta_y) {  // beta = beta_y + rho (z - u)   (src/ADMM.jl:236-241), stored with xold = x by workgroup 0
+        bi = load_chunk<E, NV>(reinterpret_cast<const E*>(St.beta_y) + oc);
+        const chunk<E, NV> zc = load_chunk<E, NV>(reinterpret_cast<const E*>(St.z) + oc);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) bi.e[j] = elem<E>::add(bi.e[j], elem<E>::scale(St.rho_admm, zc.e[j]));
+        const chunk<E, NV> uc = load_chunk<E, NV>(reinterpret_cast<const E*>(St.u) + oc);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) bi.e[j] = elem<E>::add(bi.e[j], elem<E>::scale(-St.rho_admm, uc.e[j]));
+        if (blockIdx.x == 0 && ok) {
+          chunk<E, NV> xc;
+#pragma unroll
+          for (int j = 0; j < NV; ++j) xc.e[j] = xv[q * NV + j];
+          *reinterpret_cast<f4*>(reinterpret_cast<E*>(St.beta) + o) = __builtin_bit_cast(f4, bi);
+          *reinterpret_cast<f4*>(reinterpret_cast<E*>(St.xold) + o) = __builtin_bit_cast(f4, xc);
+        }
+      } else {
+        bi = load_chunk<E, NV>(reinterpret_cast<const E*>(St.b) + oc);
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const E ci = elem<E>::add(cc.e[j], elem<E>::scale(St.rho, xv[q * NV + j]));
+        E ri = elem<E>::sub(bi.e[j], ci);
+        if (!ok) ri = elem<E>::zero();
+        rv[q * NV + j] = ri;
+        pv[q * NV + j] = ri;
+        rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+      }
+    }
+    rr = block_sum_n<NT / 64>(rr, L.red);
+    S.rr = rr;
+    S.z0 = sqrt(rr);
+    S.zeta = 0.0;
+    S.alpha_re = S.alpha_im = S.beta_re = S.beta_im = 0.0;
+    S.lambda = St.rho;
+    S.rel_tol = St.reltol;
+    S.iteration = 0;
+    S.max_iter = St.maxiter;
+    S.pending = 0;
+    S.cur = 0;
+    S.fresh = 0;
+    S.done = (St.maxiter <= 0) || (rr == 0.0) || (1.0f <= St.reltol);
+    if (S.done) n_steps = 0;  // uniform
+  }
   for (int it = 0; it < n_steps; ++it) {
     STAMP(8);
 #pragma unroll
@@ -2498,7 +2582,7 @@ static int32_t fista_gram_finish_typed(rls_ctx* ctx, const rls_fista_gram& P, in
 // ---- resident CGNR host side ------------------------------------------------------------------------
 template <typename E, int G, int K, int WV>
 static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout, void* sync, int nwg, int n_steps,
-                               unsigned spin_limit) {
+                               unsigned spin_limit, const rls_cg_start& St) {
   using C = slab_cfg<E, G, K, WV>;
   // (complex with 64-byte row pieces holds 8 owned elements of x, r, p, v per thread on top of the slab: spills)
   if constexpr ((K == 32 || K == 16) && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
@@ -2517,7 +2601,7 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
 #define RLS_LAUNCH_RES(BB, FF)                                                                                          \
   hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N,  \
-                     pair, n_steps, spin_limit)
+                     pair, n_steps, spin_limit, St)
     if (g_resident_barrier == 0) {
       if (full) RLS_LAUNCH_RES(0, true);
       else RLS_LAUNCH_RES(0, false);
@@ -2550,13 +2634,13 @@ static bool resident_ok_typed(int device, int64_t M, int64_t N, const void* A, i
 
 template <typename E>
 static int32_t resident_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout, void* sync, int n_steps,
-                              unsigned spin_limit) {
+                              unsigned spin_limit, const rls_cg_start& St) {
   fused_cfg c;
   if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident CGNR: N too large");
   const int nwg = (int)fused_nwg<E>(P.M, P.N);
   int32_t st = RLS_E_UNSUPPORTED;
 #define RLS_RES_CASE(GG, KK, WW) \
-  if (c.G == GG && c.K == KK && c.WV == WW) st = launch_resident<E, GG, KK, WW>(ctx, P, dout, sync, nwg, n_steps, spin_limit);
+  if (c.G == GG && c.K == KK && c.WV == WW) st = launch_resident<E, GG, KK, WW>(ctx, P, dout, sync, nwg, n_steps, spin_limit, St);
   RLS_FOR_EACH_CFG(RLS_RES_CASE)
 #undef RLS_RES_CASE
   return st;
@@ -2797,9 +2881,9 @@ int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N) {
   return dtype == RLS_F32 ? (int)fused_nwg<float>(M, N) : (int)fused_nwg<float2>(M, N);
 }
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
-                                 int n_steps, unsigned spin_limit) {
-  if (dtype == RLS_F32) return resident_typed<float>(ctx, P, dout, sync, n_steps, spin_limit);
-  return resident_typed<float2>(ctx, P, dout, sync, n_steps, spin_limit);
+                                 int n_steps, unsigned spin_limit, const rls_cg_start& St) {
+  if (dtype == RLS_F32) return resident_typed<float>(ctx, P, dout, sync, n_steps, spin_limit, St);
+  return resident_typed<float2>(ctx, P, dout, sync, n_steps, spin_limit, St);
 }
 
 int32_t rls_fista_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, void* sync, int n_steps,

@@ -490,8 +490,20 @@ int32_t rls_cgnr_pipe_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P
 size_t rls_cgnr_resident_sync_bytes();
 bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N);
+// cg! entry folded into a resident launch (src/ADMM.jl:236-244): r = b - (AHA + rho I) x with the warm start x, p = r,
+// the scalars of the solve; with beta_y non-null b = beta_y + rho_admm (z - u) is formed on the way (and stored, with a
+// copy of x in xold, by workgroup 0).  enabled = 0: the kernel continues an initialised solve (rls_cgnr_step).
+struct rls_cg_start {
+  int enabled = 0;
+  const void* b = nullptr;
+  const void *beta_y = nullptr, *z = nullptr, *u = nullptr;
+  void *beta = nullptr, *xold = nullptr;
+  float rho_admm = 0.f, rho = 0.f, reltol = 0.f;
+  int maxiter = 0;
+  const int* skip = nullptr;
+};
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
-                                 int n_steps, unsigned spin_limit);
+                                 int n_steps, unsigned spin_limit, const rls_cg_start& start = rls_cg_start());
 
 // Gram-mode CGNR pipeline (normal.hip): one launch per iteration, every buffer in two parities
 struct rls_gram_pipe {
@@ -506,18 +518,6 @@ bool rls_gram_pipe_ok(int32_t dtype, int64_t N, const void* G, int64_t ldg);
 int rls_gram_pipe_nwg(int32_t dtype, int64_t N);
 int32_t rls_gram_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity);
 int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity);
-// cg! entry folded into a resident launch (src/ADMM.jl:236-244): r = b - (AHA + rho I) x with the warm start x, p = r,
-// the scalars of the solve; with beta_y non-null b = beta_y + rho_admm (z - u) is formed on the way (and stored, with a
-// copy of x in xold, by workgroup 0).  enabled = 0: the kernel continues an initialised solve (rls_cgnr_step).
-struct rls_cg_start {
-  int enabled = 0;
-  const void* b = nullptr;
-  const void *beta_y = nullptr, *z = nullptr, *u = nullptr;
-  void *beta = nullptr, *xold = nullptr;
-  float rho_admm = 0.f, rho = 0.f, reltol = 0.f;
-  int maxiter = 0;
-  const int* skip = nullptr;
-};
 // resident Gram-mode CGNR / cg!: the whole step call as one launch, AHA held in registers (normal.hip)
 bool rls_gram_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, const void* G, int64_t ldg);
 int32_t rls_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, void* sync, int n_steps,

@@ -1483,8 +1483,12 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
       return rls_gram_resident_launch(ctx, op->dtype, P, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin, St);
     });
   }
-  // warm start: one operator apply for r = b - (AHA + rho I) x
-  RLS_TRY(op_normal(op, x, s->c, FV.skip));
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool resident_mf = cg_use_pipeline(s) && !cg_use_gram_pipeline(s) && s->rsync && ctx->tune.resident && maxiter > 0 &&
+                           al16(x) && al16(s->r) && al16(s->u) && al16(s->c) && al16(b) && al16(FV.beta_y) && al16(FV.z) &&
+                           al16(FV.u) && al16(FV.beta) && al16(FV.xold);
+  // warm start: one operator apply for r = b - (AHA + rho I) x   (inside the resident launch where that runs)
+  if (!resident_mf) RLS_TRY(op_normal(op, x, s->c, FV.skip));
   if (cg_use_gram_pipeline(s)) {
     s->used_pipeline = true;
     if (op->dtype == RLS_F32)
@@ -1519,6 +1523,28 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
   }
   s->used_pipeline = cg_use_pipeline(s);
   if (s->used_pipeline) {
+    if (resident_mf) {
+      // matrix-free, A in the register files: warm-start apply, residual (ADMM's beta formed on the way) and every
+      // iteration in ONE launch of cgnr_resident_kernel (normal.hip)
+      s->resident_used = true;
+      const rls_cgnr_pipe P = cg_pipe_desc(s, x);
+      rls_cg_start St;
+      St.enabled = 1;
+      St.b = b;
+      St.beta_y = FV.beta_y;
+      St.z = FV.z;
+      St.u = FV.u;
+      St.beta = FV.beta;
+      St.xold = FV.xold;
+      St.rho_admm = FV.rho;
+      St.rho = rho;
+      St.reltol = reltol;
+      St.maxiter = maxiter;
+      St.skip = FV.skip;
+      return resident_chain(ctx, s->rsync, [&]() {
+        return rls_cgnr_resident_launch(ctx, op->dtype, P, s->rdots, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin, St);
+      });
+    }
     if (op->dtype == RLS_F32)
       hipLaunchKernelGGL(cg_pipe_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
                          (const float*)b, (float*)s->u, (float*)s->r, (const float*)s->c, n, s->psc, rho, reltol,
@@ -1530,15 +1556,6 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     RLS_TRY(launch_status(ctx));
     rls_cgnr_pipe P = cg_pipe_desc(s, x);
     const int32_t dtype = op->dtype;
-    {
-      auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-      if (s->rsync && ctx->tune.resident && maxiter > 0 && al16(x) && al16(s->r) && al16(s->u) && al16(s->c)) {
-        s->resident_used = true;
-        return resident_chain(ctx, s->rsync, [&]() {
-          return rls_cgnr_resident_launch(ctx, dtype, P, s->rdots, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin);
-        });
-      }
-    }
     if (s->graph.exec && (s->graph.x_bound != x || s->graph.mode != 1)) {  // the captured kernels carry x's address
       hipGraphExecDestroy(s->graph.exec);
       s->graph = step_graph();
