@@ -28,7 +28,10 @@ for c in range(cases):
     rho = 0.9 / (math.sqrt(M) + math.sqrt(N)) ** 2
     for name, make in (("cgnr", lambda: rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), iterations=its, relTol=0.0, **kw)),
                        ("fista", lambda: rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0,
-                                                                 restart="gradient" if c % 2 else "none", **kw))):
+                                                                 restart="gradient" if c % 2 else "none", **kw)),
+                       # ADMM: the inner cg! (warm start, entry folded into the resident launch) -- 3 outer x `its` inner iterations
+                       ("admm", lambda: rls.createLinearSolver(rls.ADMM, Ad, reg=rls.L1Regularization(max(lam, 1e-3)), rho=0.1, iterations=3,
+                                                                iterationsCG=min(its, 10), tolInner=1e-6, absTol=0.0, relTol=0.0, **kw))):
         S = make()
         got = {}
         for res in (1, 0):
@@ -36,7 +39,8 @@ for c in range(cases):
             got[res] = rls.solve_(S, bd).to_host()
             if res == 1:
                 pth = ctypes.c_int32(-1)
-                (lib.rls_cgnr_path if name == "cgnr" else lib.rls_fista_path)(S.state._plan, ctypes.byref(pth))
+                if name != "admm":
+                    (lib.rls_cgnr_path if name == "cgnr" else lib.rls_fista_path)(S.state._plan, ctypes.byref(pth))
         ctx.tune(resident=1)
         err = float(np.linalg.norm(got[1] - got[0]) / max(np.linalg.norm(got[0]), 1e-30))
         worst = max(worst, err)
