@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 1
+#define RLS_ABI_VERSION 2
 
 typedef struct rls_ctx rls_ctx;           /* device + stream + workspace                           */
 typedef struct rls_operator rls_operator; /* dense forward operator A (+ optional Gram matrix)     */
@@ -70,6 +70,10 @@ int32_t rls_device_count(int32_t* out);
  * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll" (rolling-window
  * depth of the batched kernels' load pipelines), "gram_lds_kib", "kaczmarz_nt". */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
+/* test utility (tests/test_gpu_parity.py, the co-tenancy test): enqueue on ctx's stream a kernel of n_workgroups
+ * workgroups that each hold a whole CU (1024 threads, all of its LDS) for `microseconds` of wall clock and do nothing
+ * else -- what another tenant of the device looks like to a kernel that needs every CU at once.  Bounded: <= 2 s. */
+int32_t rls_debug_hold_cus(rls_ctx* ctx, int32_t n_workgroups, int32_t microseconds);
 
 int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out);  /* similar(b, dims...)  src/CGNR.jl:92-95 */
 int32_t rls_free(rls_ctx* ctx, void* p);
@@ -245,6 +249,8 @@ typedef struct rls_cgnr_status {
   float zeta;     /* ||r||^2 at the start of the last iteration                                  */
   float residual; /* ||r|| now: solverconvergence(state).residual  src/CGNR.jl:136               */
   float z0;       /* ||A^H b||                                                                   */
+  int32_t fallbacks; /* resident launches that timed out (no-ops) and were re-run on the per-iteration pipeline
+                      * by this or an earlier status call; 0 in normal operation                                  */
 } rls_cgnr_status;
 
 int32_t rls_cgnr_create(rls_operator* op, void* x, void* r, void* p, void* v, rls_cgnr** out);
@@ -253,7 +259,15 @@ int32_t rls_cgnr_destroy(rls_cgnr* s);
 int32_t rls_cgnr_init(rls_cgnr* s, const void* b, float lambda, float rel_tol, int32_t iterations);
 /* enqueue n_steps iterations (no-ops once done); asynchronous, graph-replayed */
 int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps);
-int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h); /* synchronises */
+/* synchronises.  If a resident launch of this plan (rls_cgnr_path 4 / 5) could not get all its workgroups onto the chip
+ * within its wait bound -- another process on the device, a long kernel on another stream -- that launch was a no-op;
+ * this call then re-runs the missing iterations on the per-iteration pipeline before it reports (state and result are
+ * those of an undisturbed run), counts the event in `fallbacks`, and the plan stays on the pipeline.  The reference's
+ * solve! has no such failure mode (src/RegularizedLeastSquares.jl:103-117), so none is surfaced here either. */
+int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h);
+/* rls_cgnr_step(s, n_steps) followed by rls_cgnr_get_status(s, out_h) in one call: what one `iterate` of the reference's
+ * solve! loop needs (advance, then `done` / the convergence record for the callbacks) with ONE host synchronisation */
+int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out_h);
 /* Batched plan (BASELINE config 4, shared-A flavour; semantics of solve!(solver, B; scheduler =
  * MultiThreadingState), src/MultiThreading.jl:30-79): nrhs independent CGNR solves that share ONE pass over A
  * per iteration.  X, R, P, V: caller-owned N x nrhs column-major device matrices, leading dimension ldv;
@@ -290,6 +304,7 @@ typedef struct rls_fista_status {
   float rel_res_norm; /* ||res|| / ||x0||   src/FISTA.jl:156                                      */
   float residual;     /* ||res||: solverconvergence  src/FISTA.jl:131                             */
   float norm_x0;
+  int32_t fallbacks; /* as rls_cgnr_status.fallbacks */
 } rls_fista_status;
 
 /* x, x0, xold, res: caller-owned length-N device vectors.  The plan swaps x/xold internally by
@@ -315,10 +330,12 @@ int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, floa
  * elements (a scalar x0 is broadcast by the caller, as `state.x .= x0` does); RLS_E_INVALID on any other length */
 int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n);
 int32_t rls_fista_step(rls_fista* s, int32_t n_steps);
-/* which kernel sequence the next rls_fista_step call takes (as rls_cgnr_path): 0 = two GEMVs + update kernel,
- * 1 = one-pass slab pipeline, 2 = Gram-mode pipeline, 3 = batched matrix-core kernels, 4 = resident (one launch per call) */
+/* which kernel sequence the next rls_fista_step call takes (the codes of rls_cgnr_path): 0 = two GEMVs + update kernel,
+ * 1 = one-pass slab pipeline, 2 = Gram-mode pipeline, 3 = batched matrix-core kernels, 4 = resident (one launch per
+ * call, A in registers), 5 = resident Gram mode (one launch per call, AHA in registers) */
 int32_t rls_fista_path(rls_fista* s, int32_t* out);
-int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out_h);
+int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out_h); /* synchronises; recovers lost resident launches as rls_cgnr_get_status */
+int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out_h); /* step + status, one synchronisation */
 int32_t rls_fista_solution(rls_fista* s, void** x_out); /* device pointer currently holding state.x */
 
 /* ---------------------------------------------------------------------------------------------
@@ -330,6 +347,7 @@ typedef struct rls_cg_status {
   int32_t iterations; /* CG iterations actually performed                                        */
   float residual;     /* ||r|| at exit                                                            */
   float tol;          /* max(reltol * ||r0||, 0)                                                  */
+  int32_t fallbacks;  /* as rls_cgnr_status.fallbacks                                                 */
 } rls_cg_status;
 int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out);
 /* batched plan (shared A; solve!(solver::ADMM, B) with the shared-A scheduler, src/MultiThreading.jl:30-79): U, R, C are
@@ -340,7 +358,13 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
 int32_t rls_cg_destroy(rls_cg* s);
 /* solves (AHA + rho I) x = b starting from x (warm start); asynchronous */
 int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxiter, float reltol);
+/* synchronises.  When the solve ran as ONE resident launch (rls_cg_path 4 / 5) and that launch timed out, x still holds the
+ * warm start: this call then repeats the solve on the per-iteration pipeline (`fallbacks`).  A caller that consumes x
+ * asynchronously therefore calls this first whenever rls_cg_path reports 4 or 5; inside an ADMM plan (rls_admm_*) the
+ * library does the equivalent itself. */
 int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out_h);
+/* which kernel sequence the next rls_cg_solve of this plan takes (the codes of rls_cgnr_path) */
+int32_t rls_cg_path(rls_cg* s, int32_t* out);
 
 /* ADMM elementwise steps for an identity regTrafo (the default opEye, src/ADMM.jl:84), fused:
  *   rls_admm_pre :  beta = (accumulate ? beta : beta_y) + rho (z - u) ; xold = x            src/ADMM.jl:236-243
@@ -380,6 +404,7 @@ typedef struct rls_admm_status {
   int32_t iteration, done;
   float rk, sk, eps_pri, eps_dua, delta; /* of the last completed iteration */
   int32_t cg_iterations;
+  int32_t fallbacks; /* resident cg! launches lost; the outer iterations behind them were re-run (rls_admm_get_status) */
 } rls_admm_status;
 int32_t rls_admm_create(rls_cg* cg, rls_admm** out);
 int32_t rls_admm_destroy(rls_admm* a);
@@ -388,6 +413,8 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer); /* asynchronous; stops enqu
 /* synchronises; log_h (nullable) receives min(iteration, log_records) records of 8 floats:
  * Delta, sk, eps_pri, rk, eps_dua, inner cg! iterations, 0, 0 */
 int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out_h, float* log_h, int32_t log_records);
+/* rls_admm_step(a, n_outer) followed by rls_admm_get_status in one call (one synchronisation) */
+int32_t rls_admm_step_status(rls_admm* a, int32_t n_outer, rls_admm_status* out_h, float* log_h, int32_t log_records);
 /* batched plans: out_h[nrhs]; log_h (nullable) = nrhs blocks of log_records records, column after column */
 int32_t rls_admm_get_status_batched(rls_admm* a, rls_admm_status* out_h, float* log_h, int32_t log_records);
 
@@ -471,6 +498,27 @@ int32_t rls_allreduce_sum(rls_comm* comm, void* const* rank_bufs, int64_t n, int
 int32_t rls_cgnr_init_rowsharded(rls_comm* comm, rls_cgnr* const* plans, const void* const* b_parts, float lambda,
                                  float rel_tol, int32_t iterations);
 int32_t rls_cgnr_step_rowsharded(rls_comm* comm, rls_cgnr* const* plans, int32_t n_steps);
+/* The row-sharded calls fan out inside the library: one host worker thread per rank (the Threads.@threads of
+ * src/MultiThreading.jl:60-78) walks that rank's share of the whole call, the ranks meeting at a host barrier between the
+ * two halves of each all-reduce, so the host side of an iteration costs ONE rank's launches.  on = 0: the calling thread
+ * drives every rank in turn (also: environment RLS_COMM_THREADS=0 at communicator creation).  Results are identical. */
+int32_t rls_comm_set_threads(rls_comm* comm, int32_t on);
+/* FISTA on a row-partitioned A (src/FISTA.jl:110-185; call sites of the distributed step :114, :152): plans[r] =
+ * rls_fista_create (+ rls_fista_set_reg) on rank r's shard operator.  init: x0 = sum_g A_g^H b_g (ONE all-reduce), then
+ * every rank's rls_fista_init_local_b; a step: res_g = A_g^H A_g y, ONE all-reduce of res, the replicated gradient step /
+ * prox / momentum / `done`.  Status and solution through any rank's plan (rls_fista_get_status, rls_fista_solution). */
+int32_t rls_fista_init_rowsharded(rls_comm* comm, rls_fista* const* plans, const void* const* b_parts, float rho, float theta,
+                                  float rel_tol, int32_t iterations, int32_t restart_gradient);
+int32_t rls_fista_step_rowsharded(rls_comm* comm, rls_fista* const* plans, int32_t n_steps);
+/* ADMM on a row-partitioned A (src/ADMM.jl:191-330, distributed step = the operator applies inside cg!, :244): plans[r] =
+ * rls_cg_create + rls_admm_create + rls_admm_init on rank r's shard operator, the same parameters on every rank
+ * (sigma_abs from the length of the whole b; the caller has set x, z0, u as init! does, :199-206).
+ * init_rowsharded: beta_y = sum_g A_g^H b_g (ONE all-reduce, :198).  step_rowsharded: n_outer outer iterations, each
+ * iterations_cg + 1 all-reduces of the cg! scratch c (the inner solve always runs its iterations_cg half-step pairs; its
+ * convergence and the plan's `done` are replicated device flags, so the collective count never depends on the data);
+ * z / u / prox / `converged` are the single-GPU plan's kernels, replicated.  Status through rls_admm_get_status. */
+int32_t rls_admm_init_rowsharded(rls_comm* comm, rls_admm* const* plans, const void* const* b_parts);
+int32_t rls_admm_step_rowsharded(rls_comm* comm, rls_admm* const* plans, int32_t n_outer);
 
 #ifdef __cplusplus
 }

@@ -25,16 +25,16 @@ class RLSError(RuntimeError):
 class CgnrStatus(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("done", C.c_int32), ("alpha_re", C.c_float), ("alpha_im", C.c_float),
                 ("beta_re", C.c_float), ("beta_im", C.c_float), ("zeta", C.c_float), ("residual", C.c_float),
-                ("z0", C.c_float)]
+                ("z0", C.c_float), ("fallbacks", C.c_int32)]
 
 
 class FistaStatus(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("done", C.c_int32), ("theta", C.c_float), ("theta_old", C.c_float),
-                ("rel_res_norm", C.c_float), ("residual", C.c_float), ("norm_x0", C.c_float)]
+                ("rel_res_norm", C.c_float), ("residual", C.c_float), ("norm_x0", C.c_float), ("fallbacks", C.c_int32)]
 
 
 class CgStatus(C.Structure):
-    _fields_ = [("iterations", C.c_int32), ("residual", C.c_float), ("tol", C.c_float)]
+    _fields_ = [("iterations", C.c_int32), ("residual", C.c_float), ("tol", C.c_float), ("fallbacks", C.c_int32)]
 
 
 class AdmmParams(C.Structure):
@@ -48,7 +48,8 @@ class AdmmParams(C.Structure):
 
 class AdmmStatus(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("done", C.c_int32), ("rk", C.c_float), ("sk", C.c_float),
-                ("eps_pri", C.c_float), ("eps_dua", C.c_float), ("delta", C.c_float), ("cg_iterations", C.c_int32)]
+                ("eps_pri", C.c_float), ("eps_dua", C.c_float), ("delta", C.c_float), ("cg_iterations", C.c_int32),
+                ("fallbacks", C.c_int32)]
 
 
 _vp, _i32, _i64, _f, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "rls_last_error_string": (C.c_char_p, [_vp]),
     "rls_device_count": (_i32, [_pi32]),
     "rls_tune_set": (_i32, [_vp, C.c_char_p, _i32]),
+    "rls_debug_hold_cus": (_i32, [_vp, _i32, _i32]),
     "rls_malloc": (_i32, [_vp, _sz, _pvp]),
     "rls_free": (_i32, [_vp, _vp]),
     "rls_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
@@ -127,6 +129,7 @@ PROTOTYPES = {
     "rls_cgnr_init": (_i32, [_vp, _vp, _f, _f, _i32]),
     "rls_cgnr_step": (_i32, [_vp, _i32]),
     "rls_cgnr_get_status": (_i32, [_vp, C.POINTER(CgnrStatus)]),
+    "rls_cgnr_step_status": (_i32, [_vp, _i32, C.POINTER(CgnrStatus)]),
     "rls_cgnr_create_batched": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _pvp]),
     "rls_cgnr_init_batched": (_i32, [_vp, _vp, _i64, _f, _f, _i32]),
     "rls_cgnr_get_status_batched": (_i32, [_vp, C.POINTER(CgnrStatus)]),
@@ -144,12 +147,14 @@ PROTOTYPES = {
     "rls_fista_step": (_i32, [_vp, _i32]),
     "rls_fista_path": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "rls_fista_get_status": (_i32, [_vp, C.POINTER(FistaStatus)]),
+    "rls_fista_step_status": (_i32, [_vp, _i32, C.POINTER(FistaStatus)]),
     "rls_fista_solution": (_i32, [_vp, _pvp]),
     "rls_cg_create": (_i32, [_vp, _vp, _vp, _vp, _pvp]),
     "rls_cg_create_batched": (_i32, [_vp, _i32, _vp, _vp, _vp, C.c_int64, _pvp]),
     "rls_cg_destroy": (_i32, [_vp]),
     "rls_cg_solve": (_i32, [_vp, _vp, _vp, _f, _i32, _f]),
     "rls_cg_get_status": (_i32, [_vp, C.POINTER(CgStatus)]),
+    "rls_cg_path": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "rls_admm_pre": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32]),
     "rls_admm_post": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _pf]),
     "rls_gather": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
@@ -179,11 +184,17 @@ PROTOTYPES = {
     "rls_allreduce_sum": (_i32, [_vp, C.POINTER(_vp), C.c_int64, _i32]),
     "rls_cgnr_init_rowsharded": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_float, C.c_float, _i32]),
     "rls_cgnr_step_rowsharded": (_i32, [_vp, C.POINTER(_vp), _i32]),
+    "rls_comm_set_threads": (_i32, [_vp, _i32]),
+    "rls_fista_init_rowsharded": (_i32, [_vp, _pvp, _pvp, _f, _f, _f, _i32, _i32]),
+    "rls_fista_step_rowsharded": (_i32, [_vp, _pvp, _i32]),
+    "rls_admm_init_rowsharded": (_i32, [_vp, _pvp, _pvp]),
+    "rls_admm_step_rowsharded": (_i32, [_vp, _pvp, _i32]),
     "rls_admm_create": (_i32, [_vp, _pvp]),
     "rls_admm_destroy": (_i32, [_vp]),
     "rls_admm_init": (_i32, [_vp, C.POINTER(AdmmParams)]),
     "rls_admm_step": (_i32, [_vp, _i32]),
     "rls_admm_get_status": (_i32, [_vp, C.POINTER(AdmmStatus), _pf, _i32]),
+    "rls_admm_step_status": (_i32, [_vp, _i32, C.POINTER(AdmmStatus), _pf, _i32]),
     "rls_admm_get_status_batched": (_i32, [_vp, C.POINTER(AdmmStatus), _pf, _i32]),
 }
 

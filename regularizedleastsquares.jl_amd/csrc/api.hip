@@ -98,7 +98,10 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "batched_mfma")) ctx->tune.batched_mfma = value;
   else if (!strcmp(key, "gram_pipeline")) ctx->tune.gram_pipeline = value;
   else if (!strcmp(key, "pipe_hint_mode")) ctx->tune.pipe_hint_mode = value;
-  else if (!strcmp(key, "resident")) ctx->tune.resident = value;
+  else if (!strcmp(key, "resident")) {
+    ctx->tune.resident = value;
+    ctx->resident_failures = 0;  // an explicit switch also forgets earlier timeouts (solvers.hip, resident_lost)
+  }
   else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);
   else if (!strcmp(key, "skinny_v_waves")) rls_skinny_tune(1, value);
@@ -126,6 +129,26 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
     rls_normal_resident_barrier(value);
   }
   else return rls_fail(ctx, RLS_E_INVALID, "tune_set: unknown key");
+  return 0;
+}
+
+// test utility: workgroups that sit on whole CUs for a given wall-clock time (s_memrealtime ticks at 100 MHz)
+__global__ __launch_bounds__(1024) void hold_cus_kernel(unsigned long long ticks, unsigned* sink) {
+  extern __shared__ char hold_lds[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (ticks == ~0ull) sink[threadIdx.x] = (unsigned)hold_lds[threadIdx.x];  // never: keeps the LDS allocation alive
+}
+
+int32_t rls_debug_hold_cus(rls_ctx* ctx, int32_t n_workgroups, int32_t microseconds) {
+  RLS_CHECK_CTX(ctx);
+  if (n_workgroups <= 0 || microseconds < 0 || microseconds > 2000000) return rls_fail(ctx, RLS_E_INVALID, "hold_cus: bad argument");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t lds = 160 * 1024;
+  RLS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(hold_cus_kernel, dim3((unsigned)n_workgroups), dim3(1024), lds, ctx->stream,
+                     (unsigned long long)microseconds * 100ull, reinterpret_cast<unsigned*>(ctx->res_d));
+  RLS_HIP(ctx, hipGetLastError());
   return 0;
 }
 

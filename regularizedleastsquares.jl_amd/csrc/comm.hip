@@ -22,6 +22,11 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -61,6 +66,23 @@ struct rccl_api {
 
 }  // namespace
 
+// One host worker thread per rank (the fan-out of src/MultiThreading.jl:60-78, `Threads.@threads`, inside the library):
+// a row-sharded solver call hands every worker the WHOLE loop of its rank -- phases separated by a spinning host barrier
+// -- so that the host side of an iteration costs what ONE rank's launches cost, not the sum over ranks.
+struct comm_pool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t gen = 0;
+  bool quit = false;
+  const std::vector<rls_comm_phase>* phases = nullptr;
+  int reps = 0;
+  std::atomic<int> arrived{0};
+  std::atomic<unsigned> sense{0};
+  std::atomic<int> finished{0};
+  std::atomic<int32_t> status{0};
+};
+
 struct rls_comm {
   int n = 0;
   int transport = 0;
@@ -69,12 +91,17 @@ struct rls_comm {
   // direct transport
   size_t cap_f = 0;                  // floats per slot
   std::vector<float*> recv[2];       // [parity][rank]: n slots of cap_f floats on that rank's device
-  std::vector<hipEvent_t> pushed;    // one per rank
+  std::vector<hipEvent_t> pushed[2]; // [parity][rank]
   int round = 0;
+  // host fan-out
+  int use_threads = 1;
+  comm_pool* pool = nullptr;
   // RCCL transport
   rccl_api rccl;
   std::vector<nccl_comm_t> comms;
 };
+
+static void pool_stop(rls_comm* c);
 
 static int32_t comm_fail(rls_comm* c, int32_t code, const char* what) {
   return rls_fail(c && !c->ctx.empty() ? c->ctx[0] : nullptr, code, what);
@@ -99,30 +126,40 @@ static int32_t direct_reserve(rls_comm* c, size_t nf) {
   return 0;
 }
 
+// rank r's half-steps of the direct all-reduce for round `round` (parity round & 1):
+//   publish: r's vector into slot r of EVERY rank's receive buffer, then r's "pushed" event;
+//   collect: wait for every other rank's "pushed" event of this round on r's stream, then sum the slots in rank order.
+// Every rank's publish (the event record) must have been CALLED before any rank's collect is called: a host barrier
+// between the two when the ranks run on worker threads, the loop structure when one thread drives them all.
+static int32_t direct_publish(rls_comm* c, int r, const void* buf, size_t nf, int round) {
+  rls_ctx* cr = c->ctx[r];
+  const int q = round & 1;
+  const unsigned gx = (unsigned)((nf + 255) / 256 < 64 ? (nf + 255) / 256 : 64);
+  RLS_HIP(cr, hipSetDevice(cr->device));
+  peer_ptrs d;
+  for (int t = 0; t < MAX_RANKS; ++t) d.p[t] = t < c->n ? c->recv[q][t] + (size_t)r * c->cap_f : nullptr;
+  hipLaunchKernelGGL(comm_push_kernel, dim3(gx, (unsigned)c->n), dim3(256), 0, cr->stream, (const float*)buf, d, (int64_t)nf);
+  RLS_HIP(cr, hipEventRecord(c->pushed[q][r], cr->stream));
+  return 0;
+}
+static int32_t direct_collect(rls_comm* c, int r, void* buf, size_t nf, int round) {
+  rls_ctx* cr = c->ctx[r];
+  const int q = round & 1;
+  const unsigned gx = (unsigned)((nf + 255) / 256 < 64 ? (nf + 255) / 256 : 64);
+  RLS_HIP(cr, hipSetDevice(cr->device));
+  for (int t = 0; t < c->n; ++t)
+    if (t != r) RLS_HIP(cr, hipStreamWaitEvent(cr->stream, c->pushed[q][t], 0));
+  hipLaunchKernelGGL(comm_sum_kernel, dim3(gx), dim3(256), 0, cr->stream, (float*)buf, (const float*)c->recv[q][r], c->n,
+                     (int64_t)c->cap_f, (int64_t)nf);
+  RLS_HIP(cr, hipGetLastError());
+  return 0;
+}
+
 static int32_t direct_allreduce(rls_comm* c, void* const* bufs, size_t nf) {
   RLS_TRY(direct_reserve(c, nf));
-  rls_ctx* c0 = c->ctx[0];
-  const int q = c->round & 1;
-  const unsigned gx = (unsigned)((nf + 255) / 256 < 64 ? (nf + 255) / 256 : 64);
-  for (int r = 0; r < c->n; ++r) {
-    rls_ctx* cr = c->ctx[r];
-    RLS_HIP(c0, hipSetDevice(cr->device));
-    peer_ptrs d;
-    for (int t = 0; t < MAX_RANKS; ++t) d.p[t] = t < c->n ? c->recv[q][t] + (size_t)r * c->cap_f : nullptr;
-    hipLaunchKernelGGL(comm_push_kernel, dim3(gx, (unsigned)c->n), dim3(256), 0, cr->stream, (const float*)bufs[r], d, (int64_t)nf);
-    RLS_HIP(c0, hipEventRecord(c->pushed[r], cr->stream));
-  }
-  for (int r = 0; r < c->n; ++r) {
-    rls_ctx* cr = c->ctx[r];
-    RLS_HIP(c0, hipSetDevice(cr->device));
-    for (int t = 0; t < c->n; ++t)
-      if (t != r) RLS_HIP(c0, hipStreamWaitEvent(cr->stream, c->pushed[t], 0));
-    hipLaunchKernelGGL(comm_sum_kernel, dim3(gx), dim3(256), 0, cr->stream, (float*)bufs[r], (const float*)c->recv[q][r], c->n,
-                       (int64_t)c->cap_f, (int64_t)nf);
-  }
-  c->round++;
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return comm_fail(c, (int32_t)e, hipGetErrorString(e));
+  const int round = c->round++;
+  for (int r = 0; r < c->n; ++r) RLS_TRY(direct_publish(c, r, bufs[r], nf, round));
+  for (int r = 0; r < c->n; ++r) RLS_TRY(direct_collect(c, r, bufs[r], nf, round));
   return 0;
 }
 
@@ -151,7 +188,137 @@ static int32_t rccl_check(rls_comm* c, int rc, const char* what) {
   return comm_fail(c, 1000 + rc, msg);
 }
 
+// ---- host fan-out -----------------------------------------------------------------------------------------------------
+static void pool_barrier(comm_pool* P, int n, unsigned* my_sense) {
+  *my_sense ^= 1u;
+  if (P->arrived.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+    P->arrived.store(0, std::memory_order_relaxed);
+    P->sense.store(*my_sense, std::memory_order_release);
+  } else {
+    for (unsigned spins = 0; P->sense.load(std::memory_order_acquire) != *my_sense; ++spins) {
+      rls_cpu_relax();
+      if ((spins & 1023u) == 1023u) std::this_thread::yield();  // oversubscribed hosts: let the others run
+    }
+  }
+}
+
+static void pool_worker(rls_comm* c, int r) {
+  comm_pool* P = c->pool;
+  uint64_t seen = 0;
+  (void)hipSetDevice(c->ctx[r]->device);
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(P->m);
+      P->cv.wait(lk, [&] { return P->quit || P->gen != seen; });
+      if (P->quit) return;
+      seen = P->gen;
+    }
+    unsigned my_sense = P->sense.load(std::memory_order_acquire);
+    const std::vector<rls_comm_phase>& ph = *P->phases;
+    for (int k = 0; k < P->reps; ++k) {
+      for (size_t i = 0; i < ph.size(); ++i) {
+        if (P->status.load(std::memory_order_relaxed) == 0) {  // after a failure the ranks only keep each other company
+          const int32_t st = ph[i].run(r, k);
+          if (st != 0) {
+            int32_t zero = 0;
+            P->status.compare_exchange_strong(zero, st);
+          }
+        }
+        if (ph[i].barrier_after) pool_barrier(P, c->n, &my_sense);
+      }
+    }
+    if (P->finished.fetch_add(1, std::memory_order_acq_rel) == c->n - 1) {
+      std::lock_guard<std::mutex> lk(P->m);
+      P->cv.notify_all();
+    }
+  }
+}
+
+static void pool_stop(rls_comm* c) {
+  comm_pool* P = c->pool;
+  if (!P) return;
+  {
+    std::lock_guard<std::mutex> lk(P->m);
+    P->quit = true;
+  }
+  P->cv.notify_all();
+  for (std::thread& t : P->th) t.join();
+  delete P;
+  c->pool = nullptr;
+}
+
+// reps x (the phases in order) for every rank.  Threads: each rank's worker runs the whole sequence, meeting the others
+// at the host barrier behind every phase that asks for one.  One thread (single rank, or threads switched off): phase by
+// phase over all ranks, which orders everything a barrier would.
+int32_t rls_comm_run(rls_comm* c, const std::vector<rls_comm_phase>& phases, int reps) {
+  if (!c) return RLS_E_INVALID;
+  if (reps <= 0 || phases.empty()) return 0;
+  if (c->n == 1 || !c->use_threads) {
+    for (int k = 0; k < reps; ++k)
+      for (const rls_comm_phase& ph : phases)
+        for (int r = 0; r < c->n; ++r) RLS_TRY(ph.run(r, k));
+    return 0;
+  }
+  if (!c->pool) {
+    c->pool = new comm_pool();
+    for (int r = 0; r < c->n; ++r) c->pool->th.emplace_back(pool_worker, c, r);
+  }
+  comm_pool* P = c->pool;
+  {
+    std::lock_guard<std::mutex> lk(P->m);
+    P->phases = &phases;
+    P->reps = reps;
+    P->finished.store(0);
+    P->status.store(0);
+    P->arrived.store(0);
+    ++P->gen;
+  }
+  P->cv.notify_all();
+  {
+    std::unique_lock<std::mutex> lk(P->m);
+    P->cv.wait(lk, [&] { return P->finished.load(std::memory_order_acquire) == c->n; });
+  }
+  return P->status.load();
+}
+
+// the collective as two per-rank half-steps (see direct_publish / direct_collect); `round` = rls_comm_next_rounds() + k.
+// RCCL: each rank's ncclAllReduce on its own communicator from its own thread (no group needed), collect is a no-op;
+// when ONE thread drives all ranks the calls of a round sit inside one group (rank 0 opens it, the last rank closes it).
+int32_t rls_comm_publish(rls_comm* c, int r, void* buf, int64_t n, int32_t dtype, int round) {
+  const size_t nf = (size_t)n * (dtype == RLS_C32 ? 2 : 1);
+  if (c->n == 1 || n == 0) return 0;
+  if (c->transport == RLS_COMM_DIRECT) return direct_publish(c, r, buf, nf, round);
+  const bool grouped = !c->use_threads;
+  if (grouped && r == 0) RLS_TRY(rccl_check(c, c->rccl.GroupStart(), "ncclGroupStart"));
+  const int32_t st = rccl_check(c, c->rccl.AllReduce(buf, buf, nf, /* ncclFloat32 */ 7, /* ncclSum */ 0, c->comms[r], c->ctx[r]->stream),
+                                "ncclAllReduce");
+  if (grouped && r == c->n - 1) {
+    const int32_t st2 = rccl_check(c, c->rccl.GroupEnd(), "ncclGroupEnd");
+    return st != 0 ? st : st2;
+  }
+  return st;
+}
+int32_t rls_comm_collect(rls_comm* c, int r, void* buf, int64_t n, int32_t dtype, int round) {
+  const size_t nf = (size_t)n * (dtype == RLS_C32 ? 2 : 1);
+  if (c->n == 1 || n == 0 || c->transport != RLS_COMM_DIRECT) return 0;
+  return direct_collect(c, r, buf, nf, round);
+}
+// reserve `count` consecutive round numbers (and the receive buffers for vectors of n elements) ahead of a run
+int32_t rls_comm_next_rounds(rls_comm* c, int count, int64_t n, int32_t dtype, int* first) {
+  if (c->transport == RLS_COMM_DIRECT && c->n > 1) RLS_TRY(direct_reserve(c, (size_t)n * (dtype == RLS_C32 ? 2 : 1)));
+  *first = c->round;
+  c->round += count;
+  return 0;
+}
+
 extern "C" {
+
+int32_t rls_comm_set_threads(rls_comm* c, int32_t on) {
+  if (!c) return RLS_E_INVALID;
+  if (!on) pool_stop(c);
+  c->use_threads = on ? 1 : 0;
+  return 0;
+}
 
 int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* ctxs, int32_t transport, rls_comm** out) {
   if (!out) return RLS_E_INVALID;
@@ -160,6 +327,7 @@ int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* 
   rls_comm* c = new rls_comm();
   c->n = nranks;
   c->own_ctx = ctxs == nullptr;
+  if (const char* e = getenv("RLS_COMM_THREADS")) c->use_threads = atoi(e) != 0;
   for (int r = 0; r < nranks; ++r) {
     rls_ctx* x = nullptr;
     if (ctxs) {
@@ -196,7 +364,7 @@ int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* 
     }
   } else if (transport == RLS_COMM_DIRECT) {
     for (int q = 0; q < 2; ++q) c->recv[q].assign(nranks, nullptr);
-    c->pushed.assign(nranks, nullptr);
+    for (int q = 0; q < 2; ++q) c->pushed[q].assign(nranks, nullptr);
     for (int r = 0; r < nranks && st == 0; ++r) {
       hipError_t e = hipSetDevice(c->ctx[r]->device);
       for (int t = 0; t < nranks && e == hipSuccess; ++t) {
@@ -216,7 +384,8 @@ int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* 
           }
         }
       }
-      if (st == 0 && e == hipSuccess) e = hipEventCreateWithFlags(&c->pushed[r], hipEventDisableTiming);
+      for (int q = 0; q < 2; ++q)
+        if (st == 0 && e == hipSuccess) e = hipEventCreateWithFlags(&c->pushed[q][r], hipEventDisableTiming);
       if (st == 0 && e != hipSuccess) st = comm_fail(c, (int32_t)e, hipGetErrorString(e));
     }
   } else {
@@ -232,12 +401,14 @@ int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* 
 
 int32_t rls_comm_destroy(rls_comm* c) {
   if (!c) return RLS_E_INVALID;
+  pool_stop(c);
   for (int r = 0; r < (int)c->ctx.size(); ++r) {
     hipSetDevice(c->ctx[r]->device);
     rls_stream_wait(c->ctx[r]->stream);
     for (int q = 0; q < 2; ++q)
       if (r < (int)c->recv[q].size() && c->recv[q][r]) hipFree(c->recv[q][r]);
-    if (r < (int)c->pushed.size() && c->pushed[r]) hipEventDestroy(c->pushed[r]);
+    for (int q = 0; q < 2; ++q)
+      if (r < (int)c->pushed[q].size() && c->pushed[q][r]) hipEventDestroy(c->pushed[q][r]);
   }
   for (nccl_comm_t k : c->comms)
     if (k && c->rccl.CommDestroy) c->rccl.CommDestroy(k);

@@ -1452,11 +1452,32 @@ __global__ __launch_bounds__(FIN_THREADS) void fista_gram_f_kernel(E* b0, E* b1,
 // payload with sc1 loads only after a workgroup barrier behind the poll.  Nothing depends on dispatch order
 // or XCD placement; every spin is bounded (`spin_limit`), a timeout leaves x, r, p untouched and raises `fail`.
 struct resident_sync {
-  unsigned cnt[8 * 32];  // arrival words (zeroed before every launch): one flag per workgroup, or 8 counter shards a line apart
-  unsigned fail;         // some workgroup gave up waiting
-  unsigned completed;    // workgroup 0 passed the last barrier and wrote the state back
-  unsigned pad[30];
+  unsigned cnt[8 * 32];  // grid arrival counter (zeroed before every launch): 8 shards a 128-byte line apart
+  unsigned gcnt[8 * 32]; // group arrival counters of the two-level exchange: one word per group, a line apart
+  unsigned fail;         // some workgroup gave up waiting (last launch)
+  unsigned completed;    // workgroup 0 passed the last barrier and wrote the state back (last launch)
+  // ---- everything above is zeroed ahead of every launch (rls_resident_sync_clear_bytes); what follows is STICKY ----
+  unsigned failed;       // launches of this plan that were no-ops because workgroup 0 gave up: only workgroup 0 writes the
+                         // state back, so "workgroup 0 timed out" is exactly "the launch changed nothing".  Zeroed by the
+                         // plan's init and by the host once it has re-run the lost work on the per-iteration pipeline.
+  unsigned pad[29];
 };
+static_assert(sizeof(resident_sync) == (2 * 8 * 32 + 32) * sizeof(unsigned), "resident_sync layout");
+// behind the sync block (same allocation): the group-partial vectors of the two-level exchange, [2 parities][8 groups][N]
+constexpr int RES_GROUPS = 8;
+
+// a workgroup gave up waiting.  Workgroup 0 is the only one that writes x, r, p and the scalars back, so its giving up
+// is what makes the launch a no-op: it counts the lost launch in the sticky word and, inside an ADMM plan, poisons the
+// plan's `done` flag (value 2) so that the z / u kernels queued behind this cg! do not consume a stale x.
+__device__ static inline void resident_give_up(resident_sync* sync, int* poison) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0) {
+      __hip_atomic_fetch_add(&sync->failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (poison) __hip_atomic_store(poison, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 template <typename E, int G, int K, int WV>
 struct resident_lds {
@@ -1465,53 +1486,53 @@ struct resident_lds {
   int flag;
 };
 
-// arrive + wait.  Precondition: this workgroup's handed-off stores are sc1, drained by every storing wave, and a
-// workgroup barrier lies between those drains and this call.
-// MODE 1 (default): arrival = one returning-free atomic add to one of 8 counter shards (a 128-byte line each), waiting =
-// lanes 0..7 of one wave re-reading the 8 shards until their sum reaches nwg * epoch.
-// MODE 0 (`rls_tune_set("resident_barrier", 0)`): arrival = ONE sc1 store of the epoch into this workgroup's own flag
-// word, waiting = one wave re-reading all nwg <= 256 flags (1 KiB, one 16-byte load per lane).  Measured SLOWER on
-// MI355X (18.3 vs 15.9 us per iteration at the headline shape: 256 pollers each pulling 8 lines that 32 writers share
-// cost more than the atomic round trip they save); kept as a switch so the comparison can be re-run.
+// arrive + wait on the grid counter.  Precondition: this workgroup's handed-off stores are sc1, drained by every storing
+// wave, and a workgroup barrier lies between those drains and this call.  Arrival = one returning-free atomic add to one
+// of 8 counter shards (a 128-byte line each), waiting = lanes 0..7 of one wave re-reading the 8 shards until their sum
+// reaches nwg * epoch.  (Round 2 also carried a variant with one flag word per workgroup; measured slower -- 18.3 vs 15.9 us
+// per iteration: 256 pollers each pulling 8 lines that 32 writers share -- and removed in round 3.)
 #ifndef RLS_POLL_SLEEP
 #define RLS_POLL_SLEEP 1
 #endif
-template <int MODE>
 __device__ static inline bool grid_arrive_wait(unsigned* cnt, unsigned epoch, unsigned nwg, unsigned spin_limit, int* lds_flag) {
   const int tid = threadIdx.x;
   if (tid < 64) {
     int ok = 0;
-    if constexpr (MODE == 0) {
-      if (tid == 0) __hip_atomic_store(cnt + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const __amdgpu_buffer_rsrc_t rs = sc1_rsrc(cnt);
-      for (unsigned spins = 0; spins < spin_limit; ++spins) {
-        const u4 f = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)tid * 16u, 0, 16);
-        bool mine = true;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mine = mine && ((unsigned)(tid * 4 + q) >= nwg || f[q] >= epoch);
-        if (__all(mine)) {
-          ok = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
+    const unsigned target = nwg * epoch;
+    if (tid == 0) __hip_atomic_fetch_add(cnt + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE poll in flight, a short sleep between polls: the pollers of 256 workgroups share the memory-side path
+    // with the arrivals they are waiting for.  Measured at the headline shape (us per iteration, one run): sleep 1
+    // 14.3, sleep 8 14.7, sleep 32 15.4; two polls in flight (the next requested before the previous is examined) 16.2.
+    for (unsigned spins = 0; spins < spin_limit; ++spins) {
+      unsigned c = __hip_atomic_load(cnt + (tid & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // lanes 0..7 hold the 8 shards:
+      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // butterfly inside the group of 8
+      c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xF, 0xF, true);
+      if (__builtin_amdgcn_readfirstlane((int)c) >= (int)target) {
+        ok = 1;
+        break;
       }
-    } else {
-      const unsigned target = nwg * epoch;
-      if (tid == 0) __hip_atomic_fetch_add(cnt + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // ONE poll in flight, a short sleep between polls: the pollers of 256 workgroups share the memory-side path
-      // with the arrivals they are waiting for.  Measured at the headline shape (us per iteration, one run): sleep 1
-      // 14.3, sleep 8 14.7, sleep 32 15.4; two polls in flight (the next requested before the previous is examined) 16.2.
-      for (unsigned spins = 0; spins < spin_limit; ++spins) {
-        unsigned c = __hip_atomic_load(cnt + (tid & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // lanes 0..7 hold the 8 shards:
-        c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // butterfly inside the group of 8
-        c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xF, 0xF, true);
-        if (__builtin_amdgcn_readfirstlane((int)c) >= (int)target) {
-          ok = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(RLS_POLL_SLEEP);
+      __builtin_amdgcn_s_sleep(RLS_POLL_SLEEP);
+    }
+    if (tid == 0) *lds_flag = ok;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+// the same on ONE word: the members of a group (RES_GROUPS groups, workgroups with equal blockIdx % RES_GROUPS -- under the
+// observed round-robin dispatch one XCD each, which only makes it faster) wait for each other
+__device__ static inline bool group_arrive_wait(unsigned* word, unsigned target, unsigned spin_limit, int* lds_flag) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    int ok = 0;
+    if (tid == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spins = 0; spins < spin_limit; ++spins) {
+      const unsigned c = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__builtin_amdgcn_readfirstlane((int)c) >= (int)target) {
+        ok = 1;
+        break;
       }
+      __builtin_amdgcn_s_sleep(RLS_POLL_SLEEP);
     }
     if (tid == 0) *lds_flag = ok;
   }
@@ -1564,6 +1585,104 @@ __device__ static inline void resident_reduce_chunks(resident_lds<E, G, K, WV>& 
   }
 }
 
+// The grid-wide sum of the workgroups' partial rows (slab[nwg][N]: just stored write-through and drained by every storing
+// wave, a workgroup barrier behind the drains), delivered to EVERY workgroup as the 16-byte pieces vv[] its threads own.
+//   EXCH 1 (any grid): grid barrier | workgroup j sums 64-byte column chunk j over all nwg rows, publishes it to v (plus
+//     whatever `publish` adds: CGNR's partial dots) | grid barrier | every workgroup reads v.
+//   EXCH 2 (two levels; nwg a multiple of RES_GROUPS, the row a power-of-two number of 16-byte pieces per group member):
+//     group barrier (the nwg / 8 workgroups with equal blockIdx % 8) | member l sums slice l of the row over its group's
+//     rows and publishes that group-partial slice | ONE grid barrier | every workgroup reads the 8 group-partial vectors
+//     and adds them in group order.  One full-grid barrier per exchange instead of two at the price of an 8x larger final
+//     read (128 KiB per workgroup at the headline shape).  tools/ubench/grid_barrier.hip, arithmetic stripped, 256
+//     workgroups, 16 KiB rows: EXCH 1 10.4 us, EXCH 2 7.4 us per exchange (groups of 32 strided by 8; 9.5 us with
+//     contiguous groups, 8.4 / 8.5 us with 4 / 16 groups; the bare grid barrier 1.56 us).
+// Everything handed over is sc1-stored and sc1-loaded in both variants, so which workgroups share an XCD changes speed
+// only; the group partials alternate between two buffers (a fast group's members may publish exchange k + 1 while a slow
+// group still reads exchange k; k + 2 cannot start before every workgroup has passed the grid barrier of k + 1).
+// Summation orders are functions of (nwg, N) alone: bit-reproducible.  Returns false when a wait ran into its bound.
+template <typename E, int G, int K, int WV, int EXCH, bool FULL, typename PC, typename PUB>
+__device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, resident_sync* sync,
+                                                 __amdgpu_buffer_rsrc_t slab_rs, E* v, int nwg, int64_t N, unsigned& epoch,
+                                                 unsigned& xchg, unsigned spin_limit,
+                                                 E (&vv)[slab_cfg<E, G, K, WV>::EPT], PC&& per_column, PUB&& publish) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
+  const int tid = threadIdx.x;
+  if constexpr (EXCH == 1) {
+    if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) return false;
+    STAMP(11);
+    resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, v, nwg, N, per_column);
+    publish();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(12);
+    if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) return false;
+    STAMP(13);
+    const __amdgpu_buffer_rsrc_t v_rs = sc1_rsrc(v);
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      const int o = q * NT * NV + tid * NV;
+      const bool ok = FULL || o < N;
+      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((ok ? o : 0) * sizeof(E))));
+#pragma unroll
+      for (int j = 0; j < NV; ++j) vv[q * NV + j] = ok ? c.e[j] : elem<E>::zero();
+    }
+    return true;
+  } else {
+    const unsigned per = (unsigned)nwg / RES_GROUPS, grp = blockIdx.x % RES_GROUPS, mem = blockIdx.x / RES_GROUPS;
+    const uint32_t rowb = (uint32_t)(N * sizeof(E));
+    const unsigned q = (rowb / 16u) / per;                   // 16-byte pieces of the row per group member: a power of two
+    const unsigned lq = (unsigned)__builtin_ctz(q), nrg = (unsigned)NT >> lq;
+    const unsigned par = xchg & 1u;
+    ++xchg;
+    char* xpart = reinterpret_cast<char*>(sync) + sizeof(resident_sync) + (size_t)par * RES_GROUPS * rowb;
+    const __amdgpu_buffer_rsrc_t xp_rs = sc1_rsrc(xpart);
+    if (!group_arrive_wait(sync->gcnt + grp * 32, per * xchg, spin_limit, &R.flag)) return false;
+    STAMP(11);
+    {
+      const unsigned piece = (unsigned)tid & (q - 1u), rg = (unsigned)tid >> lq;
+      const uint32_t col = (mem * q + piece) * 16u;
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (unsigned row = rg; row < per; row += 2u * nrg) {  // two loads in flight per trip (one trip at 32 rows, q = 32)
+        const unsigned rb = row + nrg;
+        const f4 ta = sc1_load16(slab_rs, (grp + RES_GROUPS * row) * rowb + col);
+        const f4 tb = sc1_load16(slab_rs, (grp + RES_GROUPS * (rb < per ? rb : row)) * rowb + col);
+        acc += ta;
+        if (rb < per) acc += tb;
+      }
+      f4* ex = reinterpret_cast<f4*>(&R.L.xg[0][0]);  // the exchange planes of the second product are idle here
+      ex[tid] = acc;                                  // [rg][piece]
+      __syncthreads();
+      if ((unsigned)tid < q) {
+        f4 sum = ex[tid];
+        for (unsigned g = 1; g < nrg; ++g) sum += ex[(g << lq) + tid];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, sum), xp_rs, grp * rowb + (mem * q + (unsigned)tid) * 16u, 0, 16);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(12);
+    if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) return false;
+    STAMP(13);
+#pragma unroll
+    for (int qq = 0; qq < EPT / NV; ++qq) {
+      const int o = qq * NT * NV + tid * NV;
+      const bool ok = FULL || o < N;
+      const uint32_t off = (uint32_t)((ok ? o : 0) * sizeof(E));
+      f4 t[RES_GROUPS];
+#pragma unroll
+      for (int g = 0; g < RES_GROUPS; ++g) t[g] = sc1_load16(xp_rs, (uint32_t)g * rowb + off);
+      f4 sum = t[0];
+#pragma unroll
+      for (int g = 1; g < RES_GROUPS; ++g) sum += t[g];
+      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sum);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) vv[qq * NV + j] = ok ? c.e[j] : elem<E>::zero();
+    }
+    return true;
+  }
+}
+
 template <typename E, int G, int K, int WV, int BAR, bool FULL>
 __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* r, E* p,
                                                                  E* v, E* slab, double* dout, cgnr_scalars* sc,
@@ -1610,8 +1729,9 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (!St.enabled && (S.done || n_steps <= 0)) return;  // uniform
-  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(v), d_rs = sc1_rsrc(dout);
-  unsigned epoch = 0;
+  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), d_rs = sc1_rsrc(dout);
+  (void)d_rs;
+  unsigned epoch = 0, xchg = 0;
   bool alive = true;
   if (St.enabled) {
     // ---- cg! entry (cg_pipe_start_kernel of solvers.hip, folded in): c = AHA x through the same two exchanges, then
@@ -1621,15 +1741,9 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    bool ok_sync = grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag);
-    if (ok_sync) {
-      resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, v, nwg, N, [](int, E) {});
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      ok_sync = grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag);
-    }
-    if (!ok_sync) {
-      if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    E cv[EPT];
+    if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, cv, [](int, E) {}, []() {})) {
+      resident_give_up(sync, St.enabled ? St.poison : nullptr);
       return;
     }
     double rr = 0.0;
@@ -1638,7 +1752,9 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
       const int o = q * NT * NV + tid * NV;
       const bool ok = FULL || o < N;
       const int oc = ok ? o : 0;
-      const chunk<E, NV> cc = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)(oc * sizeof(E))));
+      chunk<E, NV> cc;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) cc.e[j] = cv[q * NV + j];
       chunk<E, NV> bi;
       if (St.beta_y) {  // beta = beta_y + rho (z - u)   (src/ADMM.jl:236-241), stored with xold = x by workgroup 0
         bi = load_chunk<E, NV>(reinterpret_cast<const E*>(St.beta_y) + oc);
@@ -1693,58 +1809,52 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
     STAMP(10);
-    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
-      alive = false;
-      break;
-    }
-    STAMP(11);
-    // ---- sum my 64-byte column chunk(s) over all partial rows, fixed order -----------------------------
-    double dre = 0.0, dim_ = 0.0, pp = 0.0;
-    resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, v, nwg, N, [&](int j, E sum) {
-      const E pj = L.xs[j];
-      dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
-      dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
-      pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
-    });
-    if (w == 0) {  // lanes 0..CW-1 hold the terms (zero elsewhere); fixed-order butterfly, lane 0 publishes
-#pragma unroll
-      for (int off = CW / 2; off > 0; off >>= 1) {
-        dre += __shfl_xor(dre, off, 64);
-        dim_ += __shfl_xor(dim_, off, 64);
-        pp += __shfl_xor(pp, off, 64);
-      }
-      if (lane < 3) {
-        const double dv = lane == 0 ? dre : (lane == 1 ? dim_ : pp);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dout + 4 * blockIdx.x + lane),
-                           __builtin_bit_cast(unsigned long long, dv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    STAMP(12);
-    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
-      alive = false;
-      break;
-    }
-    STAMP(13);
-    // ---- v and the partial dots, then the CG update (src/CGNR.jl:153-176), redundantly in every workgroup ----
+    // ---- v = the sum of the partial rows, in every workgroup; <p, v> and ||p||^2 ---------------------------------------
     E vv[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT / NV; ++q) {
-      const int o = q * NT * NV + tid * NV;
-      const bool ok = FULL || o < N;
-      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((ok ? o : 0) * sizeof(E))));
-#pragma unroll
-      for (int j = 0; j < NV; ++j) vv[q * NV + j] = ok ? c.e[j] : elem<E>::zero();
-    }
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    {
+    double dre = 0.0, dim_ = 0.0, pp = 0.0;  // EXCH 1: this workgroup's share of the dots over its column chunk
+    const bool ok_x = resident_allreduce<E, G, K, WV, BAR, FULL>(
+        R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, vv,
+        [&](int j, E sum) {
+          const E pj = L.xs[j];
+          dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+          dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+          pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+        },
+        [&]() {
+          if (w == 0) {  // lanes 0..CW-1 hold the terms (zero elsewhere); fixed-order butterfly, lane 0 publishes
+#pragma unroll
+            for (int off = CW / 2; off > 0; off >>= 1) {
+              dre += __shfl_xor(dre, off, 64);
+              dim_ += __shfl_xor(dim_, off, 64);
+              pp += __shfl_xor(pp, off, 64);
+            }
+            if (lane < 3) {
+              const double dv = lane == 0 ? dre : (lane == 1 ? dim_ : pp);
+              __hip_atomic_store(reinterpret_cast<unsigned long long*>(dout + 4 * blockIdx.x + lane),
+                                 __builtin_bit_cast(unsigned long long, dv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        });
+    if (!ok_x) {
+      alive = false;
+      break;
+    }
+    if constexpr (BAR == 1) {  // the 256 partial dots, one per thread; cg_update_elems sums them over the workgroup
       const int dt = tid < nwg ? tid : 0;
       const f4 lo = sc1_load16(d_rs, (uint32_t)dt * 32u), hi = sc1_load16(d_rs, (uint32_t)dt * 32u + 16u);
       if (tid < nwg) {
         d0 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 0, 1));
         d1 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 2, 3));
         d2 = __builtin_bit_cast(double, __builtin_shufflevector(hi, hi, 0, 1));
+      }
+    } else {  // every workgroup holds all of p and v: the dots over this thread's elements (summed by cg_update_elems)
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const E pj = pv[e], vj = vv[e];
+        d0 += (double)elem<E>::re(pj) * (double)elem<E>::re(vj) + (double)elem<E>::im(pj) * (double)elem<E>::im(vj);
+        d1 += (double)elem<E>::re(pj) * (double)elem<E>::im(vj) - (double)elem<E>::im(pj) * (double)elem<E>::re(vj);
+        d2 += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
       }
     }
     E pn[EPT], rn[EPT], al;
@@ -1765,7 +1875,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     if (done) break;  // uniform: every workgroup derived the same scalars
   }
   if (!alive) {
-    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    resident_give_up(sync, St.enabled ? St.poison : nullptr);
     return;  // x, r, p and the scalars are untouched: the call was a no-op
   }
   if (blockIdx.x == 0) {
@@ -1879,8 +1989,8 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
-      if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
+      resident_give_up(sync, St.enabled ? St.poison : nullptr);
       return;
     }
     const E* bb = reinterpret_cast<const E*>(St.b);
@@ -1964,7 +2074,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
-    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
+    if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
       alive = false;
       break;
     }
@@ -1998,7 +2108,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     if (done) break;  // uniform: every workgroup derived the same scalars
   }
   if (!alive) {
-    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    resident_give_up(sync, St.enabled ? St.poison : nullptr);
     return;  // x, r, p, v and the scalars are untouched: the call was a no-op
   }
   if (blockIdx.x == 0) {
@@ -2064,8 +2174,8 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (S.done || n_steps <= 0) return;  // uniform
-  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), v_rs = sc1_rsrc(raw_g);
-  unsigned epoch = 0;
+  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab);
+  unsigned epoch = 0, xchg = 0;
   bool alive = true;
   int ycur = S.ycur;
   for (int it = 0; it < n_steps; ++it) {
@@ -2074,25 +2184,10 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
-      alive = false;
-      break;
-    }
-    resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, raw_g, nwg, N, [](int, E) {});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
-      alive = false;
-      break;
-    }
     E raw[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT / NV; ++q) {
-      const int o = q * NT * NV + tid * NV;
-      const bool ok = FULL || o < N;
-      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(v_rs, (uint32_t)((ok ? o : 0) * sizeof(E))));
-#pragma unroll
-      for (int j = 0; j < NV; ++j) raw[q * NV + j] = ok ? c.e[j] : elem<E>::zero();
+    if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
+      alive = false;
+      break;
     }
     E xn[EPT], yn[EPT];
     fista_scalars Sn;
@@ -2108,7 +2203,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     if (done) break;  // uniform
   }
   if (!alive) {
-    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    resident_give_up(sync, nullptr);
     return;
   }
   if (blockIdx.x == 0) {
@@ -2202,7 +2297,7 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!grid_arrive_wait<BAR>(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
+    if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &flag)) {
       alive = false;
       break;
     }
@@ -2227,7 +2322,7 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     if (done) break;  // uniform
   }
   if (!alive) {
-    if (tid == 0) __hip_atomic_store(&sync->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    resident_give_up(sync, nullptr);
     return;
   }
   if (blockIdx.x == 0) {
@@ -2263,7 +2358,7 @@ struct fused_cfg {
 static int g_force_g = 0;   // measurement overrides (rls_tune_set "slab_g" / "slab_wv"): 0 = heuristic
 static int g_force_wv = 0;
 static int g_order_mode = 1;  // 0: wait for the small loads, 1: barrier only (rls_tune_set "slab_order")
-static int g_resident_barrier = 1;  // resident kernels: 1 = sharded atomic counter (default), 0 = per-workgroup flag words (measured slower)
+static int g_resident_barrier = 2;  // matrix-free resident kernels' exchange: 2 = two-level where the grid allows (default), 1 = flat
 static int g_red_threads = 1024;  // reduce kernel: 16 columns x 64 row groups per workgroup (-1.0 us vs 256)
 
 // candidate slab shapes, smallest column capacity first; NMAX = K * WV * (64 / G)
@@ -2317,11 +2412,10 @@ static void launch_slab(rls_ctx* ctx, const E* A, int64_t lda, const E* p, E* sl
   const int64_t Mc = M / C::NV;
   const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
-  static bool attr_set = false;  // per template instantiation
-  if (!attr_set) {
+  static rls_device_once attr_once;  // per template instantiation and device
+  if (attr_once.first(ctx->device)) {
     allow_big_lds(&normal_slab_kernel<E, G, K, WV, true>, lds);
     allow_big_lds(&normal_slab_kernel<E, G, K, WV, false>, lds);
-    attr_set = true;
   }
   if (N == C::NMAX && (int64_t)nwg * G == Mc)
     hipLaunchKernelGGL((normal_slab_kernel<E, G, K, WV, true>), dim3(nwg), dim3(C::NT), lds, ctx->stream, A, lda, p,
@@ -2346,15 +2440,14 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   const int64_t Mc = P.M / C::NV;
   const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static rls_device_once attr_once;
+  if (attr_once.first(ctx->device)) {
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, false>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, false>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, true, false>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, true, false>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, true>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, true>, lds);
-    attr_set = true;
   }
   const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
   const bool batched = P.nrhs > 1;
@@ -2435,13 +2528,12 @@ static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg) {
   const int64_t Mc = P.M / C::NV;
   const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static rls_device_once attr_once;
+  if (attr_once.first(ctx->device)) {
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, false>, lds);
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, false>, lds);
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, true>, lds);
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, true>, lds);
-    attr_set = true;
   }
   const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
 #define RLS_LAUNCH_FA(FULLV, HINTV)                                                                                 \
@@ -2580,6 +2672,17 @@ static int32_t fista_gram_finish_typed(rls_ctx* ctx, const rls_fista_gram& P, in
 
 
 // ---- resident CGNR host side ------------------------------------------------------------------------
+// the two-level exchange (resident_allreduce, EXCH 2): 8 equal groups, the row split into a power-of-two number of
+// 16-byte pieces per group member, at most one piece per thread.  Other grids (ragged M) take the flat exchange.
+template <typename E>
+static bool resident_two_level_ok(int nwg, int64_t N, int nt) {
+  if (g_resident_barrier != 2 || nwg % RES_GROUPS != 0) return false;
+  const int64_t pieces = N * (int64_t)sizeof(E) / 16, per = nwg / RES_GROUPS;
+  if (N * (int64_t)sizeof(E) % 16 != 0 || pieces % per != 0) return false;
+  const int64_t q = pieces / per;
+  return q >= 1 && q <= nt && (q & (q - 1)) == 0;
+}
+
 template <typename E, int G, int K, int WV>
 static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout, void* sync, int nwg, int n_steps,
                                unsigned spin_limit, const rls_cg_start& St) {
@@ -2590,21 +2693,20 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
     constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
-    static bool attr_set = false;
-    if (!attr_set) {
-      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 0, true>, lds);
+    static rls_device_once attr_once;
+    if (attr_once.first(ctx->device)) {
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, true>, lds);
-      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 0, false>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 2, true>, lds);
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, false>, lds);
-      attr_set = true;
-    }
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 2, false>, lds);
+      }
 #define RLS_LAUNCH_RES(BB, FF)                                                                                          \
   hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N,  \
                      pair, n_steps, spin_limit, St)
-    if (g_resident_barrier == 0) {
-      if (full) RLS_LAUNCH_RES(0, true);
-      else RLS_LAUNCH_RES(0, false);
+    if (resident_two_level_ok<E>(nwg, P.N, C::NT)) {
+      if (full) RLS_LAUNCH_RES(2, true);
+      else RLS_LAUNCH_RES(2, false);
     } else {
       if (full) RLS_LAUNCH_RES(1, true);
       else RLS_LAUNCH_RES(1, false);
@@ -2628,8 +2730,26 @@ static bool resident_ok_typed(int device, int64_t M, int64_t N, const void* A, i
   if (N % elem<E>::vec) return false;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
-  // one 512-thread workgroup (256 VGPRs per lane, ~148 KiB of LDS) per CU: the grid is resident iff it fits the CUs
-  return nwg <= cus && nwg * N * (int64_t)sizeof(E) < (int64_t)0xffffffffll;
+  // one 512-thread workgroup (256 VGPRs per lane, ~148 KiB of LDS) per CU: the grid is resident iff it fits the CUs;
+  // the arrival words of the barrier (resident_sync::cnt, per-workgroup flags in mode 0) hold 256 workgroups
+  if (!(nwg <= cus && nwg <= 256 && nwg * N * (int64_t)sizeof(E) < (int64_t)0xffffffffll)) return false;
+  // ... and the runtime must agree that a workgroup of this instantiation fits a CU at all (the occupancy query is
+  // advisory upwards -- it can over-report by one -- but "0" is a firm no: e.g. a device with less LDS per CU)
+  int blocks = 0;
+#define RLS_OCC_CASE(GG, KK, WW)                                                                                        \
+  if (c.G == GG && c.K == KK && c.WV == WW) {                                                                            \
+    if constexpr ((KK == 32 || KK == 16) && WW == 8 && slab_cfg<E, GG, KK, WW>::EPT % elem<E>::vec == 0 &&               \
+                  !(elem<E>::cplx && GG == 4)) {                                                                         \
+      allow_big_lds(&cgnr_resident_kernel<E, GG, KK, WW, 1, false>, sizeof(resident_lds<E, GG, KK, WW>));                \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cgnr_resident_kernel<E, GG, KK, WW, 1, false>, WW * 64,  \
+                                                       sizeof(resident_lds<E, GG, KK, WW>)) != hipSuccess)               \
+        blocks = 0;                                                                                                      \
+    }                                                                                                                    \
+  }
+  RLS_FOR_EACH_CFG(RLS_OCC_CASE)
+#undef RLS_OCC_CASE
+  (void)hipGetLastError();
+  return blocks >= 1;
 }
 
 template <typename E>
@@ -2655,21 +2775,20 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
     constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
-    static bool attr_set = false;
-    if (!attr_set) {
-      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 0, true>, lds);
+    static rls_device_once attr_once;
+    if (attr_once.first(ctx->device)) {
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, true>, lds);
-      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 0, false>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 2, true>, lds);
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, false>, lds);
-      attr_set = true;
-    }
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 2, false>, lds);
+      }
 #define RLS_LAUNCH_FRES(BB, FF)                                                                                          \
   hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab,  \
                      P.sc, (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
-    if (g_resident_barrier == 0) {
-      if (full) RLS_LAUNCH_FRES(0, true);
-      else RLS_LAUNCH_FRES(0, false);
+    if (resident_two_level_ok<E>(nwg, P.N, C::NT)) {
+      if (full) RLS_LAUNCH_FRES(2, true);
+      else RLS_LAUNCH_FRES(2, false);
     } else {
       if (full) RLS_LAUNCH_FRES(1, true);
       else RLS_LAUNCH_FRES(1, false);
@@ -2704,13 +2823,8 @@ static int32_t launch_gram_resident(rls_ctx* ctx, const rls_gram_pipe& P, void* 
   hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, BB, FF>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,  \
                      P.ldg, (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],         \
                      (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, St)
-  if (g_resident_barrier == 0) {
-    if (full) RLS_LAUNCH_GR(0, true);
-    else RLS_LAUNCH_GR(0, false);
-  } else {
-    if (full) RLS_LAUNCH_GR(1, true);
-    else RLS_LAUNCH_GR(1, false);
-  }
+  if (full) RLS_LAUNCH_GR(1, true);
+  else RLS_LAUNCH_GR(1, false);
 #undef RLS_LAUNCH_GR
   return launch_status(ctx);
 }
@@ -2724,7 +2838,15 @@ static bool gram_resident_ok_typed(int device, int64_t N) {
   const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, N);
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
-  return nwg <= cus;
+  if (!(nwg <= cus && nwg <= 256)) return false;
+  int blocks = 0;
+  hipError_t e = hipSuccess;
+  if (K == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cgnr_gram_resident_kernel<E, 8, 1, false>, 512, 0);
+  else if (K == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cgnr_gram_resident_kernel<E, 16, 1, false>, 512, 0);
+  else if constexpr (!elem<E>::cplx)  // complex K = 32 would be N > 2048: more than 256 workgroups, never resident
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cgnr_gram_resident_kernel<E, 32, 1, false>, 512, 0);
+  (void)hipGetLastError();
+  return e == hipSuccess && blocks >= 1;
 }
 
 template <typename E>
@@ -2735,7 +2857,8 @@ static int32_t gram_resident_typed(rls_ctx* ctx, const rls_gram_pipe& P, void* s
   const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
   if (K == 8) return launch_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit, St);
   if (K == 16) return launch_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit, St);
-  return launch_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit, St);
+  if constexpr (!elem<E>::cplx) return launch_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit, St);
+  return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram CGNR: shape not resident");
 }
 template <typename E, int K>
 static int32_t launch_fista_gram_resident(rls_ctx* ctx, const rls_fista_gram& P, void* sync, int nwg, int n_steps,
@@ -2748,13 +2871,8 @@ static int32_t launch_fista_gram_resident(rls_ctx* ctx, const rls_fista_gram& P,
   hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, BB, FF>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, \
                      P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.rr[0], (E*)P.rr[1], \
                      P.sc[0], P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
-  if (g_resident_barrier == 0) {
-    if (full) RLS_LAUNCH_FGR(0, true);
-    else RLS_LAUNCH_FGR(0, false);
-  } else {
-    if (full) RLS_LAUNCH_FGR(1, true);
-    else RLS_LAUNCH_FGR(1, false);
-  }
+  if (full) RLS_LAUNCH_FGR(1, true);
+  else RLS_LAUNCH_FGR(1, false);
 #undef RLS_LAUNCH_FGR
   return launch_status(ctx);
 }
@@ -2767,7 +2885,8 @@ static int32_t fista_gram_resident_typed(rls_ctx* ctx, const rls_fista_gram& P, 
   const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
   if (K == 8) return launch_fista_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit);
   if (K == 16) return launch_fista_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit);
-  return launch_fista_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
+  if constexpr (!elem<E>::cplx) return launch_fista_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
+  return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram FISTA: shape not resident");
 }
 }  // namespace
 
@@ -2830,7 +2949,7 @@ void rls_normal_force_group(int g) { g_force_g = g; }
 void rls_normal_force_waves(int wv) { g_force_wv = wv; }
 void rls_normal_order_mode(int m) { g_order_mode = m; }
 void rls_normal_red_threads(int t) { g_red_threads = t; }
-void rls_normal_resident_barrier(int m) { g_resident_barrier = m ? 1 : 0; }
+void rls_normal_resident_barrier(int m) { g_resident_barrier = m == 1 ? 1 : 2; }
 
 #ifdef RLS_STAMPS
 extern "C" int32_t rls_debug_stamps(unsigned long long* out_h) {
@@ -2871,6 +2990,11 @@ int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t 
 
 // resident CGNR (one launch per step call, A in registers across iterations)
 size_t rls_cgnr_resident_sync_bytes() { return sizeof(resident_sync); }
+size_t rls_resident_sync_alloc_bytes(int32_t dtype, int64_t N) {  // + [2 parities][RES_GROUPS][N] group-partial vectors
+  return sizeof(resident_sync) + (size_t)2 * RES_GROUPS * (size_t)N * rls_elem_size(dtype);
+}
+size_t rls_resident_sync_clear_bytes() { return offsetof(resident_sync, failed); }
+size_t rls_resident_sync_flags_offset() { return offsetof(resident_sync, fail); }
 bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (!ctx) return false;
   if (dtype == RLS_F32) return resident_ok_typed<float>(ctx->device, M, N, A, lda);

@@ -28,7 +28,9 @@ struct rls_tuning {
                           // 2 = deliberately wrong (tests: exercises the kernel's check-and-reload path)
   int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
                           // ONE launch (normal.hip, cgnr_resident_kernel)
-  int resident_spin = 400000;  // bound of every in-kernel wait, in polls (~1 us each)
+  int resident_spin = 100000;  // bound of every in-kernel wait, in polls (~1 us each: a wall-clock bound of ~0.1 s per
+                               // wait); a launch that runs into it is a no-op and the host re-runs its iterations on the
+                               // per-iteration pipeline (solvers.hip, *_recover)
 };
 
 struct rls_ctx {
@@ -42,6 +44,7 @@ struct rls_ctx {
   float* res_d = nullptr;   // small float result block on device
   float* res_h = nullptr;   // pinned host mirror
   rls_tuning tune;
+  int resident_failures = 0;  // resident launches of this context that timed out; at 2 the context stops using them
 };
 
 // Host-side waits poll (hipStreamQuery / hipEventQuery) instead of blocking.  A blocking wait sleeps on an interrupt and
@@ -83,6 +86,17 @@ inline std::mutex& rls_capture_mutex() {
   static std::mutex m;
   return m;
 }
+
+// "done once per device" guard for per-function attributes (hipFuncSetAttribute applies to the function on the CURRENT
+// device: a process that drives several GPUs, rls_comm_*, must set it on each of them); race-free across host threads
+#include <atomic>
+struct rls_device_once {
+  std::atomic<uint64_t> mask{0};
+  bool first(int device) {  // true exactly when this device has not been seen (the caller then does the work: idempotent)
+    const uint64_t bit = 1ull << (device & 63);
+    return !(mask.fetch_or(bit, std::memory_order_acq_rel) & bit);
+  }
+};
 
 constexpr int RLS_RED_SLOTS = 4096;
 constexpr int RLS_RES_FLOATS = 64;
@@ -488,6 +502,11 @@ int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P
 int32_t rls_cgnr_pipe_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, int which);
 // resident CGNR (normal.hip): the whole step call in one launch with A held in registers across iterations
 size_t rls_cgnr_resident_sync_bytes();
+// layout of the resident kernels' sync block: [0, clear_bytes) is zeroed ahead of every launch (arrival counters and the
+// {fail, completed} words of that launch, which start at flags_offset); the sticky count of lost launches follows
+size_t rls_resident_sync_alloc_bytes(int32_t dtype, int64_t N);  // sync block + the two-level exchange's group partials
+size_t rls_resident_sync_clear_bytes();
+size_t rls_resident_sync_flags_offset();   // {fail, completed, failed}: three consecutive unsigned words
 bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N);
 // cg! entry folded into a resident launch (src/ADMM.jl:236-244): r = b - (AHA + rho I) x with the warm start x, p = r,
@@ -501,6 +520,8 @@ struct rls_cg_start {
   float rho_admm = 0.f, rho = 0.f, reltol = 0.f;
   int maxiter = 0;
   const int* skip = nullptr;
+  int* poison = nullptr;  // ADMM plans: set to 2 by a launch that gives up (resident_give_up), so that the kernels queued
+                          // behind this cg! skip; the host re-runs the lost outer iterations from rls_admm_get_status
 };
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
                                  int n_steps, unsigned spin_limit, const rls_cg_start& start = rls_cg_start());
@@ -593,6 +614,20 @@ int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const 
                        int64_t ldg);
 int32_t rls_skinny_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
                         int64_t ldg, void* panels);
+
+// ---------------------------------------------------------------------------------------------
+// comm.hip internals used by the row-sharded solver loops (solvers.hip)
+// ---------------------------------------------------------------------------------------------
+#include <functional>
+#include <vector>
+struct rls_comm_phase {
+  std::function<int32_t(int rank, int rep)> run;  // rank's share of the phase in repetition `rep`
+  bool barrier_after = true;                      // every rank must have CALLED this phase before any starts the next
+};
+int32_t rls_comm_run(rls_comm* c, const std::vector<rls_comm_phase>& phases, int reps);
+int32_t rls_comm_publish(rls_comm* c, int rank, void* buf, int64_t n, int32_t dtype, int round);
+int32_t rls_comm_collect(rls_comm* c, int rank, void* buf, int64_t n, int32_t dtype, int round);
+int32_t rls_comm_next_rounds(rls_comm* c, int count, int64_t n, int32_t dtype, int* first);
 
 // ---------------------------------------------------------------------------------------------
 // host-side launch entry points implemented in the .hip files (all enqueue on ctx->stream)

@@ -10,6 +10,7 @@
 // enqueue iterations in hipGraph-captured chunks.
 #include "rls_common.hpp"
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -143,9 +144,14 @@ struct rls_cgnr {
   // resident mode (normal.hip, cgnr_resident_kernel): arrival counters + flags, per-workgroup partial dots
   void* rsync;
   double* rdots;
-  unsigned* rsync_h;  // pinned: {fail, completed} of the last resident launch, read with the status
+  unsigned* rsync_h;  // pinned: {fail, completed, failed} (resident_sync), read with the status
   bool resident_used;
   bool gram_resident;  // Gram mode: AHA fits the register files (rls_gram_resident_ok)
+  // a resident launch whose workgroups were not all on the chip in time is a no-op (normal.hip); the status call re-runs
+  // what was lost on the per-iteration pipeline and the plan stays there
+  bool resident_off;
+  int fallbacks;        // resident launches lost and recovered so far
+  long long requested;  // iterations asked for since init
 };
 
 static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
@@ -194,7 +200,8 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
 }
 
 static bool cgnr_use_gram_resident(const rls_cgnr* s) {
-  return s->gram_resident && s->rsync && s->nrhs == 1 && cgnr_use_gram_pipeline(s) && s->op->ctx->tune.resident;
+  return s->gram_resident && s->rsync && !s->resident_off && s->nrhs == 1 && cgnr_use_gram_pipeline(s) &&
+         s->op->ctx->tune.resident;
 }
 
 static bool cgnr_use_pipeline(const rls_cgnr* s) {
@@ -207,8 +214,8 @@ static bool cgnr_use_pipeline(const rls_cgnr* s) {
 static bool cgnr_use_resident(const rls_cgnr* s) {
   const rls_ctx* ctx = s->op->ctx;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  return s->rsync && s->nrhs == 1 && cgnr_use_pipeline(s) && ctx->tune.resident && al16(s->x) && al16(s->r) && al16(s->p) &&
-         al16(s->v);
+  return s->rsync && !s->resident_off && s->nrhs == 1 && cgnr_use_pipeline(s) && ctx->tune.resident && al16(s->x) &&
+         al16(s->r) && al16(s->p) && al16(s->v);
 }
 
 // A resident kernel needs every one of its workgroups on a CU at the same time.  Other kernels only delay that, but
@@ -223,7 +230,8 @@ static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch) {
   const int d = ctx->device < 64 ? ctx->device : 63;
   if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
   else RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
-  RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream));
+  // arrival counters and the {fail, completed} words of THIS launch; the count of lost launches behind them is sticky
+  RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_resident_sync_clear_bytes(), ctx->stream));
   const int32_t st = launch();
   RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], ctx->stream));
   return st;
@@ -233,15 +241,36 @@ static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_p
     return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
   });
 }
-// {fail, completed} of the last resident launch, read back with the scalars of a status call
-static int32_t resident_check(rls_ctx* ctx, const unsigned* rsync_h, const char* what) {
-  if (rsync_h[0] && !rsync_h[1]) {
-    snprintf(ctx->err, sizeof(ctx->err),
-             "resident %s launch timed out waiting for its workgroups (is another process using the device?): the call was a "
-             "no-op; rls_tune_set(\"resident\", 0) selects the two-launch pipeline (code %d)", what, (int)RLS_E_STATE);
-    return RLS_E_STATE;
+// the sync block of a plan (zeroed once: the sticky word starts at 0) and the pinned mirror of its three flag words
+static hipError_t resident_alloc(rls_ctx* ctx, const rls_operator* op, void** rsync, unsigned** rsync_h) {
+  hipError_t e = hipMalloc(rsync, rls_resident_sync_alloc_bytes(op->dtype, op->N));
+  if (e == hipSuccess) e = hipMemsetAsync(*rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream);
+  if (e == hipSuccess && rsync_h && !*rsync_h) {
+    e = hipHostMalloc((void**)rsync_h, 4 * sizeof(unsigned), hipHostMallocDefault);
+    if (e == hipSuccess) memset(*rsync_h, 0, 4 * sizeof(unsigned));
   }
+  return e;
+}
+// enqueue the read-back of {fail, completed, failed}; the caller synchronises (normally with its scalar read-back)
+static int32_t resident_fetch_flags(rls_ctx* ctx, const void* rsync, unsigned* rsync_h) {
+  RLS_HIP(ctx, hipMemcpyAsync(rsync_h, (const char*)rsync + rls_resident_sync_flags_offset(), 3 * sizeof(unsigned),
+                              hipMemcpyDeviceToHost, ctx->stream));
   return 0;
+}
+// Launches lost since the last call (0 = none).  A lost launch changed nothing (x, r, p and the scalars are written back by
+// workgroup 0 only after its last barrier), so the caller re-runs the missing iterations on the per-iteration pipeline.
+// The plan stays off the resident kernels from here on, and a context that has lost two launches stops using them at all:
+// whatever keeps the grid from being resident (another process on the device, a long kernel on another stream) would
+// cost every later attempt its full wait bound.
+static unsigned resident_lost(rls_ctx* ctx, void* rsync, unsigned* rsync_h, bool* off, int* fallbacks) {
+  const unsigned lost = rsync_h[2];
+  if (!lost) return 0;
+  (void)hipMemsetAsync((char*)rsync + rls_resident_sync_flags_offset() + 2 * sizeof(unsigned), 0, sizeof(unsigned), ctx->stream);
+  rsync_h[2] = 0;
+  *off = true;
+  *fallbacks += (int)lost;
+  if (++ctx->resident_failures >= 2) ctx->tune.resident = 0;
+  return lost;
 }
 
 static rls_cgnr_pipe cgnr_pipe_desc(const rls_cgnr* s) {
@@ -515,6 +544,9 @@ struct rls_fista {
   void* rsync = nullptr;
   unsigned* rsync_h = nullptr;
   bool resident_used = false;
+  bool resident_off = false;  // a resident launch was lost: the plan stays on the per-iteration pipeline (cgnr plan, above)
+  int fallbacks = 0;
+  long long requested = 0;    // iterations asked for since init
 };
 
 // batched launches: workgroup b = column b.  Vpart non-null: AHA y arrives as `S` partial rows per column and is
@@ -875,19 +907,21 @@ struct rls_cg {
   // ONE launch of cgnr_resident_kernel with A in registers (normal.hip)
   void* rsync = nullptr;
   double* rdots = nullptr;
+  unsigned* rsync_h = nullptr;  // pinned {fail, completed, failed}
   bool resident_used = false;
   bool gram_resident = false;  // Gram mode with AHA small enough for the register files (rls_gram_resident_ok)
+  bool resident_off = false;   // a resident launch was lost: the plan stays on the per-iteration pipeline
+  int fallbacks = 0;
+  // the last rls_cg_solve, kept so that rls_cg_get_status can repeat it on the pipeline if its resident launch was lost
+  // (a lost launch is a no-op: x still holds the warm start)
+  struct {
+    void* x = nullptr;
+    const void* b = nullptr;
+    float rho = 0.f, reltol = 0.f;
+    int32_t maxiter = 0;
+    bool valid = false;
+  } last;
 };
-
-// {fail, completed} of the plan's last resident launch (synchronises the stream)
-static int32_t cg_resident_check(rls_cg* s) {
-  if (!s->resident_used) return 0;
-  rls_ctx* ctx = s->op->ctx;
-  unsigned flags[2] = {0, 0};
-  RLS_HIP(ctx, hipMemcpyAsync(flags, (const char*)s->rsync + 8 * 32 * sizeof(unsigned), sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
-  return resident_check(ctx, flags, "cg!");
-}
 
 static bool cg_use_gram_pipeline(const rls_cg* s) {
   return s->gdots && s->op->G && s->op->ctx->tune.gram_pipeline;
@@ -1308,6 +1342,8 @@ struct rls_admm {
   int log_cap;
   int enq;  // outer iterations enqueued since init (== device iteration unless the plan stopped early)
   int nrhs = 1;  // batched plans: sc / sc_h / log hold one entry per column
+  int requested = 0;  // outer iterations asked for since init (capped at P.iterations)
+  int fallbacks = 0;  // resident cg! launches lost and recovered (rls_admm_get_status)
 };
 
 // src/ADMM.jl:246-309 in ONE single-workgroup launch: projections on x, z = prox(x + u) (L1 / L2 inline; a TV prox
@@ -1439,6 +1475,7 @@ struct admm_fuse_v {
   void *beta = nullptr, *xold = nullptr;
   float rho = 0.f;
   const int* skip = nullptr;
+  int* poison = nullptr;  // rls_cg_start::poison
 };
 template <typename E>
 static admm_fuse<E> typed_fuse(const admm_fuse_v& V) {
@@ -1460,7 +1497,7 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
   const int64_t n = op->N;
   const admm_fuse<float> Ff = typed_fuse<float>(FV);
   const admm_fuse<float2> Fc = typed_fuse<float2>(FV);
-  if (cg_use_gram_pipeline(s) && s->gram_resident && s->rsync && ctx->tune.resident && maxiter > 0) {
+  if (cg_use_gram_pipeline(s) && s->gram_resident && s->rsync && !s->resident_off && ctx->tune.resident && maxiter > 0) {
     // Gram mode, AHA in the register files: the whole cg! -- warm-start apply, r = b - (AHA + rho I) x (with beta formed on
     // the way for ADMM), every iteration -- is ONE launch of cgnr_gram_resident_kernel (normal.hip)
     s->used_pipeline = true;
@@ -1479,12 +1516,14 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
     St.reltol = reltol;
     St.maxiter = maxiter;
     St.skip = FV.skip;
+    St.poison = FV.poison;
     return resident_chain(ctx, s->rsync, [&]() {
       return rls_gram_resident_launch(ctx, op->dtype, P, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin, St);
     });
   }
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const bool resident_mf = cg_use_pipeline(s) && !cg_use_gram_pipeline(s) && s->rsync && ctx->tune.resident && maxiter > 0 &&
+  const bool resident_mf = cg_use_pipeline(s) && !cg_use_gram_pipeline(s) && s->rsync && !s->resident_off &&
+                           ctx->tune.resident && maxiter > 0 &&
                            al16(x) && al16(s->r) && al16(s->u) && al16(s->c) && al16(b) && al16(FV.beta_y) && al16(FV.z) &&
                            al16(FV.u) && al16(FV.beta) && al16(FV.xold);
   // warm start: one operator apply for r = b - (AHA + rho I) x   (inside the resident launch where that runs)
@@ -1541,6 +1580,8 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
       St.reltol = reltol;
       St.maxiter = maxiter;
       St.skip = FV.skip;
+      St.poison = FV.poison;
+    St.poison = FV.poison;
       return resident_chain(ctx, s->rsync, [&]() {
         return rls_cgnr_resident_launch(ctx, op->dtype, P, s->rdots, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin, St);
       });
@@ -1673,6 +1714,49 @@ static int32_t admm_step_batched_typed(rls_admm* a, int32_t n_outer) {
 
 static int32_t admm_step_batched(rls_admm* a, int32_t n_outer) {
   return a->cg->op->dtype == RLS_F32 ? admm_step_batched_typed<float>(a, n_outer) : admm_step_batched_typed<float2>(a, n_outer);
+}
+
+// ---- helpers of the row-sharded entry points (templates: C++ linkage) --------------------------------------------------
+template <typename PlanT>
+static int32_t rowsharded_check(rls_comm* comm, PlanT* const* plans, rls_operator* (*op_of)(PlanT*), bool (*single)(PlanT*)) {
+  if (!comm || !plans) return RLS_E_INVALID;
+  const int n = rls_comm_size(comm);
+  for (int r = 0; r < n; ++r) {
+    rls_ctx* cr = nullptr;
+    RLS_TRY(rls_comm_ctx(comm, r, &cr));
+    if (!plans[r]) return rls_fail(cr, RLS_E_INVALID, "rowsharded: null plan");
+    rls_operator* op = op_of(plans[r]);
+    if (op->ctx != cr) return rls_fail(cr, RLS_E_INVALID, "rowsharded: plan r must live on the communicator's context r");
+    if (!single(plans[r]) || op->N != op_of(plans[0])->N || op->dtype != op_of(plans[0])->dtype)
+      return rls_fail(cr, RLS_E_INVALID, "rowsharded: the shards must share N and the element type (single right-hand side)");
+    if (!op->A) return rls_fail(cr, RLS_E_INVALID, "rowsharded: a row shard needs its matrix (no Gram-only operators)");
+  }
+  return 0;
+}
+static rls_operator* cgnr_op(rls_cgnr* s) { return s->op; }
+static bool cgnr_single(rls_cgnr* s) { return s->nrhs == 1; }
+static rls_operator* fista_op(rls_fista* s) { return s->op; }
+static bool fista_single(rls_fista* s) { return s->nrhs == 1; }
+static rls_operator* admm_op(rls_admm* a) { return a->cg->op; }
+static bool admm_single(rls_admm* a) { return a->nrhs == 1 && !a->cg->Vpart; }
+
+template <typename E>
+static void admm_local_start(rls_admm* a, const admm_fuse_v& F) {
+  rls_cg* cg = a->cg;
+  rls_ctx* ctx = cg->op->ctx;
+  const rls_admm_params& P = a->P;
+  hipLaunchKernelGGL(cg_start_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const E*)P.x, (const E*)P.beta, (E*)cg->u,
+                     (E*)cg->r, (const E*)cg->c, cg->op->N, cg->sc, P.rho, P.tol_inner, P.iterations_cg, typed_fuse<E>(F),
+                     col_batch<E>());
+}
+template <typename E>
+static void admm_local_finish(rls_admm* a, void* zcur, void* znew) {
+  rls_cg* cg = a->cg;
+  rls_ctx* ctx = cg->op->ctx;
+  const rls_admm_params& P = a->P;
+  hipLaunchKernelGGL(admm_zu_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (E*)P.x, (const E*)P.xold, (E*)znew,
+                     (const E*)zcur, (E*)P.u, cg->op->N, P.reg_kind, P.prox_lambda, P.proj_kind,
+                     P.reg_kind == RLS_REG_TV ? 1 : 0, a->sc, &cg->sc->iteration, a->log, col_batch<E>(), nullptr);
 }
 
 extern "C" {
@@ -1814,6 +1898,9 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   s->rsync_h = nullptr;
   s->resident_used = false;
   s->gram_resident = false;
+  s->resident_off = false;
+  s->fallbacks = 0;
+  s->requested = 0;
   const size_t sb = sizeof(cgnr_scalars) * (size_t)nrhs;
   hipError_t e = hipMalloc((void**)&s->sc, sb);
   if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sb, ctx->stream);
@@ -1836,11 +1923,9 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   if (e == hipSuccess && nrhs == 1 && op->slab && op->A && !op->G &&
       rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
     const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
-    e = hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes());
+    e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
     if (e == hipSuccess) e = hipMalloc((void**)&s->rdots, db);
     if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s->rsync_h, 2 * sizeof(unsigned), hipHostMallocDefault);
-    if (e == hipSuccess) s->rsync_h[0] = s->rsync_h[1] = 0;
   }
   if (e == hipSuccess && nrhs == 1 && op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
@@ -1857,9 +1942,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
     s->gram_pipe = e == hipSuccess;
     if (e == hipSuccess && !s->rsync && rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg)) {
-      e = hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes());
-      if (e == hipSuccess) e = hipHostMalloc((void**)&s->rsync_h, 2 * sizeof(unsigned), hipHostMallocDefault);
-      if (e == hipSuccess) s->rsync_h[0] = s->rsync_h[1] = 0;
+      e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
       s->gram_resident = e == hipSuccess;
     }
   }
@@ -1940,6 +2023,7 @@ int32_t rls_cgnr_init_local_b(rls_cgnr* s) {
   else
     cgnr_launch_init<float2>(s, s->sc_h->lambda, s->sc_h->rel_tol, s->sc_h->max_iter);
   s->initialised = true;
+  s->requested = 0;
   return launch_status(ctx);
 }
 
@@ -2005,16 +2089,13 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
     out[b].zeta = (float)h.zeta;
     out[b].residual = (float)sqrt(h.rr);
     out[b].z0 = (float)h.z0;
+    out[b].fallbacks = 0;
   }
   return 0;
 }
 
-int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
-  if (!s) return RLS_E_INVALID;
+static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps) {
   rls_ctx* ctx = s->op->ctx;
-  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
-  if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr_step: n_steps < 0");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (s->skinny) {
     const rls_skinny K = cgnr_skinny_desc(s);
     const int32_t dtype = s->op->dtype;
@@ -2090,6 +2171,16 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
   return run_steps(ctx, &s->graph, n_steps, [s]() { return cgnr_enqueue_iteration(s); });
 }
 
+int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
+  if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr_step: n_steps < 0");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  s->requested += n_steps;
+  return cgnr_step_impl(s, n_steps);
+}
+
 // measurement only: the two kernels of the fused pipeline timed separately.  Each is idempotent
 // when repeated (K_A reads the committed scalars and writes the staged ones, K_R the reverse), so
 // after one ordinary iteration the normal-operator kernel is launched n_steps times back to back
@@ -2125,46 +2216,89 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
   return 0;
 }
 
-// ---- row-partitioned CGNR through a communicator (comm.hip): the collective lives inside the library ----------
-static int32_t rowsharded_check(rls_comm* comm, rls_cgnr* const* plans, std::vector<void*>* bufs, int which) {
-  if (!comm || !plans) return RLS_E_INVALID;
-  const int n = rls_comm_size(comm);
-  bufs->resize(n);
-  for (int r = 0; r < n; ++r) {
-    rls_ctx* cr = nullptr;
-    RLS_TRY(rls_comm_ctx(comm, r, &cr));
-    if (!plans[r]) return rls_fail(cr, RLS_E_INVALID, "rowsharded: null plan");
-    if (plans[r]->op->ctx != cr) return rls_fail(cr, RLS_E_INVALID, "rowsharded: plan r must live on the communicator's context r");
-    if (plans[r]->nrhs != 1 || plans[r]->op->N != plans[0]->op->N || plans[r]->op->dtype != plans[0]->op->dtype)
-      return rls_fail(cr, RLS_E_INVALID, "rowsharded: the shards must share N and the element type");
-    (*bufs)[r] = which == 0 ? plans[r]->r : plans[r]->v;
-  }
-  return 0;
-}
-
+// ---- row-partitioned solvers through a communicator (comm.hip): the collective lives inside the library ----------------
+// Every loop below is a list of PHASES run by rls_comm_run: each rank's worker thread walks the whole list for its rank
+// (src/MultiThreading.jl:60-78's Threads.@threads, inside the library), meeting the others at a host barrier wherever
+// one rank's stream must not wait on an event another rank has not recorded yet -- i.e. between "publish" and "collect"
+// of an all-reduce round.  The host side of an iteration therefore costs one rank's launches, not n ranks'.
 int32_t rls_cgnr_init_rowsharded(rls_comm* comm, rls_cgnr* const* plans, const void* const* b_parts, float lambda,
                                  float rel_tol, int32_t iterations) {
-  std::vector<void*> bufs;
-  RLS_TRY(rowsharded_check(comm, plans, &bufs, 0));
+  RLS_TRY(rowsharded_check<rls_cgnr>(comm, plans, cgnr_op, cgnr_single));
   if (!b_parts) return RLS_E_INVALID;
-  const int n = rls_comm_size(comm);
-  for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_init_local_a(plans[r], b_parts[r], lambda, rel_tol, iterations));
-  RLS_TRY(rls_allreduce_sum(comm, bufs.data(), plans[0]->op->N, plans[0]->op->dtype));  // r = sum_g A_g^H b_g
-  for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_init_local_b(plans[r]));
-  return 0;
+  const int64_t N = plans[0]->op->N;
+  const int32_t dtype = plans[0]->op->dtype;
+  int round0 = 0;
+  RLS_TRY(rls_comm_next_rounds(comm, 1, N, dtype, &round0));
+  const std::vector<rls_comm_phase> phases = {
+      {[&](int r, int) {  // r_g = A_g^H b_g
+         RLS_TRY(rls_cgnr_init_local_a(plans[r], b_parts[r], lambda, rel_tol, iterations));
+         return rls_comm_publish(comm, r, plans[r]->r, N, dtype, round0);
+       }, true},
+      {[&](int r, int) {  // r = sum_g r_g, then the replicated rest of initCGNR
+         RLS_TRY(rls_comm_collect(comm, r, plans[r]->r, N, dtype, round0));
+         return rls_cgnr_init_local_b(plans[r]);
+       }, false}};
+  return rls_comm_run(comm, phases, 1);
 }
 
 int32_t rls_cgnr_step_rowsharded(rls_comm* comm, rls_cgnr* const* plans, int32_t n_steps) {
-  std::vector<void*> bufs;
-  RLS_TRY(rowsharded_check(comm, plans, &bufs, 1));
+  RLS_TRY(rowsharded_check<rls_cgnr>(comm, plans, cgnr_op, cgnr_single));
   if (n_steps < 0) return RLS_E_INVALID;
-  const int n = rls_comm_size(comm);
-  for (int k = 0; k < n_steps; ++k) {
-    for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_step_local_a(plans[r]));
-    RLS_TRY(rls_allreduce_sum(comm, bufs.data(), plans[0]->op->N, plans[0]->op->dtype));  // v = sum_g A_g^H A_g p
-    for (int r = 0; r < n; ++r) RLS_TRY(rls_cgnr_step_local_b(plans[r]));
-  }
-  return 0;
+  const int64_t N = plans[0]->op->N;
+  const int32_t dtype = plans[0]->op->dtype;
+  int round0 = 0;
+  RLS_TRY(rls_comm_next_rounds(comm, n_steps, N, dtype, &round0));
+  const std::vector<rls_comm_phase> phases = {
+      {[&](int r, int k) {  // t_g = A_g p, v_g = A_g^H t_g
+         RLS_TRY(rls_cgnr_step_local_a(plans[r]));
+         return rls_comm_publish(comm, r, plans[r]->v, N, dtype, round0 + k);
+       }, true},
+      {[&](int r, int k) {  // v = sum_g v_g, the replicated update.  No barrier behind it: a rank can run at most one round
+         RLS_TRY(rls_comm_collect(comm, r, plans[r]->v, N, dtype, round0 + k));  // ahead, and the rounds alternate buffers
+         return rls_cgnr_step_local_b(plans[r]);
+       }, false}};
+  return rls_comm_run(comm, phases, n_steps);
+}
+
+// FISTA on a row-partitioned A (src/FISTA.jl:110-185): x0 = sum_g A_g^H b_g at init, res_g = A_g^H A_g y per iteration;
+// gradient step, prox, momentum and `done` replicated.  plans[r]: rls_fista_create on rank r's shard operator (+ set_reg).
+int32_t rls_fista_init_rowsharded(rls_comm* comm, rls_fista* const* plans, const void* const* b_parts, float rho, float theta,
+                                  float rel_tol, int32_t iterations, int32_t restart_gradient) {
+  RLS_TRY(rowsharded_check<rls_fista>(comm, plans, fista_op, fista_single));
+  if (!b_parts) return RLS_E_INVALID;
+  const int64_t N = plans[0]->op->N;
+  const int32_t dtype = plans[0]->op->dtype;
+  int round0 = 0;
+  RLS_TRY(rls_comm_next_rounds(comm, 1, N, dtype, &round0));
+  const std::vector<rls_comm_phase> phases = {
+      {[&](int r, int) {
+         RLS_TRY(rls_fista_init_local_a(plans[r], b_parts[r]));
+         return rls_comm_publish(comm, r, plans[r]->x0, N, dtype, round0);
+       }, true},
+      {[&](int r, int) {
+         RLS_TRY(rls_comm_collect(comm, r, plans[r]->x0, N, dtype, round0));
+         return rls_fista_init_local_b(plans[r], rho, theta, rel_tol, iterations, restart_gradient);
+       }, false}};
+  return rls_comm_run(comm, phases, 1);
+}
+
+int32_t rls_fista_step_rowsharded(rls_comm* comm, rls_fista* const* plans, int32_t n_steps) {
+  RLS_TRY(rowsharded_check<rls_fista>(comm, plans, fista_op, fista_single));
+  if (n_steps < 0) return RLS_E_INVALID;
+  const int64_t N = plans[0]->op->N;
+  const int32_t dtype = plans[0]->op->dtype;
+  int round0 = 0;
+  RLS_TRY(rls_comm_next_rounds(comm, n_steps, N, dtype, &round0));
+  const std::vector<rls_comm_phase> phases = {
+      {[&](int r, int k) {
+         RLS_TRY(rls_fista_step_local_a(plans[r]));
+         return rls_comm_publish(comm, r, plans[r]->res, N, dtype, round0 + k);
+       }, true},
+      {[&](int r, int k) {
+         RLS_TRY(rls_comm_collect(comm, r, plans[r]->res, N, dtype, round0 + k));
+         return rls_fista_step_local_b(plans[r]);
+       }, false}};
+  return rls_comm_run(comm, phases, n_steps);
 }
 
 int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out) {
@@ -2186,18 +2320,27 @@ int32_t rls_cgnr_step_local_b(rls_cgnr* s) {
   return cgnr_enqueue_update(s);
 }
 
+// status read-back of a single-RHS plan; re-runs on the per-iteration pipeline whatever a lost resident launch left undone
+static int32_t cgnr_fetch_status(rls_cgnr* s) {
+  rls_ctx* ctx = s->op->ctx;
+  if (s->resident_used) RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
+  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  if (s->resident_used && resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks)) {
+    const long long missing = s->requested - (long long)s->sc_h->iteration;
+    if (!s->sc_h->done && missing > 0) {
+      RLS_TRY(cgnr_step_impl(s, (int32_t)(missing > 0x7fffffff ? 0x7fffffff : missing)));
+      RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+    }
+  }
+  return 0;
+}
+
 int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  const float lambda = s->sc_h->lambda, rel_tol = s->sc_h->rel_tol;
-  const int max_iter = s->sc_h->max_iter;
-  if (s->resident_used)  // {fail, completed} of the last resident launch ride along with the scalars
-    RLS_HIP(ctx, hipMemcpyAsync(s->rsync_h, (const char*)s->rsync + 8 * 32 * sizeof(unsigned), 2 * sizeof(unsigned),
-                                hipMemcpyDeviceToHost, ctx->stream));
-  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
-  if (s->resident_used) RLS_TRY(resident_check(ctx, s->rsync_h, "CGNR"));
+  RLS_TRY(cgnr_fetch_status(s));
   const cgnr_scalars& h = *s->sc_h;
   out->iteration = h.iteration;
   out->done = h.done;
@@ -2208,10 +2351,13 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
   out->zeta = (float)h.zeta;
   out->residual = (float)sqrt(h.rr);
   out->z0 = (float)h.z0;
-  (void)lambda;
-  (void)rel_tol;
-  (void)max_iter;
+  out->fallbacks = s->fallbacks;
   return 0;
+}
+
+int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out) {
+  RLS_TRY(rls_cgnr_step(s, n_steps));
+  return rls_cgnr_get_status(s, out);
 }
 
 // ---- FISTA ----------------------------------------------------------------------------------
@@ -2264,13 +2410,10 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   }
   if ((op->slab && op->A && !op->G && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) ||
       (gram && rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg))) {
-    if (hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes()) != hipSuccess ||
-        hipHostMalloc((void**)&s->rsync_h, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+    if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) != hipSuccess) {
       if (s->rsync) hipFree(s->rsync);
       s->rsync = nullptr;  // resident mode is an optimisation: without its scratch the pipeline runs
       (void)hipGetLastError();
-    } else {
-      s->rsync_h[0] = s->rsync_h[1] = 0;
     }
   }
   int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
@@ -2354,6 +2497,7 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
                        (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0});
   s->enq = 0;
+  s->requested = 0;
   s->theta0 = theta;
   s->initialised = true;
   // row-sharded plans exchange `res` between the operator apply and the update: two-half iterations only
@@ -2498,6 +2642,7 @@ int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out) {
     out[b].rel_res_norm = (float)h.rel_res_norm;
     out[b].residual = (float)h.res_norm;
     out[b].norm_x0 = (float)h.norm_x0;
+    out[b].fallbacks = 0;
   }
   return 0;
 }
@@ -2520,15 +2665,11 @@ int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n) {
 
 static bool fista_use_resident(const rls_fista* s);
 static bool fista_use_gram_resident(const rls_fista* s) {
-  return s->nrhs == 1 && s->use_gram && s->rsync && s->op->ctx->tune.resident;
+  return s->nrhs == 1 && s->use_gram && s->rsync && !s->resident_off && s->op->ctx->tune.resident;
 }
 
-int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
-  if (!s) return RLS_E_INVALID;
+static int32_t fista_step_impl(rls_fista* s, int32_t n_steps) {
   rls_ctx* ctx = s->op->ctx;
-  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_step before fista_init");
-  if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "fista_step: n_steps < 0");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (s->nrhs > 1) {  // K columns share A: T = A Y, V = A^H T on the matrix cores, then one workgroup per column
     return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_batched(s); });
   }
@@ -2606,10 +2747,37 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_iteration(s); });
 }
 
+int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_step before fista_init");
+  if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "fista_step: n_steps < 0");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  s->requested += n_steps;
+  return fista_step_impl(s, n_steps);
+}
+
 static bool fista_use_resident(const rls_fista* s) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  return s->nrhs == 1 && s->use_pipe && s->rsync && s->op->ctx->tune.resident && al16(s->buf[0]) && al16(s->buf[1]) &&
-         al16(s->x0) && al16(s->res);
+  return s->nrhs == 1 && s->use_pipe && s->rsync && !s->resident_off && s->op->ctx->tune.resident && al16(s->buf[0]) &&
+         al16(s->buf[1]) && al16(s->x0) && al16(s->res);
+}
+
+// status read-back of a single-column plan; re-runs on the per-iteration pipeline whatever a lost resident launch left
+// undone (cgnr_fetch_status)
+static int32_t fista_fetch_status(rls_fista* s) {
+  rls_ctx* ctx = s->op->ctx;
+  if (s->resident_used) RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
+  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  if (s->resident_used && resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks)) {
+    const long long missing = s->requested - (long long)s->sc_h->iteration;
+    s->enq = s->sc_h->iteration;  // the buffer-parity hints of the pipeline follow the device's count
+    if (!s->sc_h->done && missing > 0) {
+      RLS_TRY(fista_step_impl(s, (int32_t)(missing > 0x7fffffff ? 0x7fffffff : missing)));
+      RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+    }
+  }
+  return 0;
 }
 
 int32_t rls_fista_path(rls_fista* s, int32_t* out) {
@@ -2623,11 +2791,7 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_get_status before fista_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  if (s->resident_used)
-    RLS_HIP(ctx, hipMemcpyAsync(s->rsync_h, (const char*)s->rsync + 8 * 32 * sizeof(unsigned), 2 * sizeof(unsigned),
-                                hipMemcpyDeviceToHost, ctx->stream));
-  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
-  if (s->resident_used) RLS_TRY(resident_check(ctx, s->rsync_h, "FISTA"));
+  RLS_TRY(fista_fetch_status(s));
   const fista_scalars& h = *s->sc_h;
   out->iteration = h.iteration;
   out->done = h.done;
@@ -2636,7 +2800,13 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
   out->rel_res_norm = (float)h.rel_res_norm;
   out->residual = (float)h.res_norm;
   out->norm_x0 = (float)h.norm_x0;
+  out->fallbacks = s->fallbacks;
   return 0;
+}
+
+int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out) {
+  RLS_TRY(rls_fista_step(s, n_steps));
+  return rls_fista_get_status(s, out);
 }
 
 int32_t rls_fista_solution(rls_fista* s, void** x_out) {
@@ -2644,7 +2814,7 @@ int32_t rls_fista_solution(rls_fista* s, void** x_out) {
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_solution before fista_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+  RLS_TRY(fista_fetch_status(s));
   *x_out = s->buf[s->sc_h->iteration & 1];
   return 0;
 }
@@ -2688,9 +2858,10 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
       return rls_fail(ctx, (int32_t)e, "cg_create: hipMalloc failed");
     }
     if (rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg)) {
-      if (hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes()) == hipSuccess) {
+      if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) == hipSuccess) {
         s->gram_resident = true;
       } else {
+        if (s->rsync) hipFree(s->rsync);
         s->rsync = nullptr;  // an optimisation only: the one-launch-per-iteration pipeline runs without it
         (void)hipGetLastError();
       }
@@ -2698,7 +2869,7 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   } else if (op->slab) {
     if (op->A && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
       const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
-      if (hipMalloc(&s->rsync, rls_cgnr_resident_sync_bytes()) != hipSuccess || hipMalloc((void**)&s->rdots, db) != hipSuccess) {
+      if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) != hipSuccess || hipMalloc((void**)&s->rdots, db) != hipSuccess) {
         if (s->rsync) hipFree(s->rsync);
         s->rsync = nullptr;  // an optimisation only: the two-launch pipeline runs without it
         (void)hipGetLastError();
@@ -2769,6 +2940,7 @@ int32_t rls_cg_destroy(rls_cg* s) {
   if (s->Vpart) hipFree(s->Vpart);
   if (s->rsync) hipFree(s->rsync);
   if (s->rdots) hipFree(s->rdots);
+  if (s->rsync_h) hipHostFree(s->rsync_h);
   if (s->r1) hipFree(s->r1);
   if (s->p1) hipFree(s->p1);
   if (s->dots) hipFree(s->dots);
@@ -2789,6 +2961,12 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
   if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_solve: bad argument");
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "cg_solve on a batched plan: batched cg! runs inside rls_admm_step");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  s->last.x = x;
+  s->last.b = b;
+  s->last.rho = rho;
+  s->last.reltol = reltol;
+  s->last.maxiter = maxiter;
+  s->last.valid = true;
   return cg_solve_impl(s, x, b, rho, maxiter, reltol, admm_fuse_v());
 }
 
@@ -2837,11 +3015,30 @@ int32_t rls_cg_local_update(rls_cg* s, void* x) {
   return launch_status(ctx);
 }
 
+int32_t rls_cg_path(rls_cg* s, int32_t* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  const rls_ctx* ctx = s->op->ctx;
+  const bool res = s->rsync && !s->resident_off && ctx->tune.resident;
+  if (s->nrhs > 1 || s->Vpart) *out = 3;
+  else if (cg_use_gram_pipeline(s)) *out = (res && s->gram_resident) ? 5 : 2;
+  else if (cg_use_pipeline(s)) *out = res ? 4 : 1;
+  else *out = 0;
+  return 0;
+}
+
 int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  RLS_TRY(cg_resident_check(s));
+  out->fallbacks = s->fallbacks;
+  if (s->resident_used) {
+    // a lost resident launch left x at its warm start: repeat the solve on the per-iteration pipeline
+    RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
+    RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+    if (resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks) && s->last.valid)
+      RLS_TRY(cg_solve_impl(s, s->last.x, s->last.b, s->last.rho, s->last.maxiter, s->last.reltol, admm_fuse_v()));
+    out->fallbacks = s->fallbacks;
+  }
   if (s->used_pipeline) {
     RLS_TRY(fetch_scalars(ctx, s->psc, s->psc_h));
     out->iterations = s->psc_h->iteration;
@@ -2970,6 +3167,7 @@ int32_t rls_admm_init(rls_admm* a, const rls_admm_params* p) {
   }
   a->P = *p;
   a->enq = 0;
+  a->requested = 0;
   hipLaunchKernelGGL(admm_reset_kernel<float>, dim3((unsigned)a->nrhs), dim3(1), 0, ctx->stream, a->sc, p->iterations,
                      p->rho, p->sigma_abs, p->rel_tol);
   RLS_TRY(launch_status(ctx));
@@ -2988,6 +3186,7 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer) {
   const int32_t dtype = cg->op->dtype;
   const int64_t n = cg->op->N;
   if (a->nrhs > 1 || cg->Vpart) return admm_step_batched(a, n_outer);
+  a->requested = (int)std::min<long long>((long long)a->requested + n_outer, (long long)P.iterations);
   for (int k = 0; k < n_outer && a->enq < P.iterations; ++k, ++a->enq) {
     void* zcur = (a->enq & 1) ? P.z1 : P.z0;
     void* znew = (a->enq & 1) ? P.z0 : P.z1;
@@ -2999,6 +3198,7 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer) {
     F.xold = P.xold;
     F.rho = P.rho;
     F.skip = &a->sc->done;
+    F.poison = &a->sc->done;  // a resident cg! that gives up sets done = 2: the z / u kernels behind it skip
     RLS_TRY(cg_solve_impl(cg, P.x, P.beta, P.rho, P.iterations_cg, P.tol_inner, F));  // :236-244
     const int* cg_it = cg->used_pipeline ? &cg->psc->iteration : &cg->sc->iteration;
     const int z_ready = P.reg_kind == RLS_REG_TV;
@@ -3018,6 +3218,109 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer) {
   return 0;
 }
 
+// ---- ADMM on a row-partitioned A (src/ADMM.jl:191-330; one regulariser, identity regTrafo, vary_rho = :none) --------------
+// plans[r]: rls_cg_create + rls_admm_create + rls_admm_init on rank r's shard operator, every rank with the same
+// parameters (sigma_abs from the length of the WHOLE b, :214).  The x-update's cg! is the distributed part: its operator
+// applies are per-shard products followed by ONE all-reduce of c each; it always runs its `iterations_cg` half-step
+// pairs -- its own convergence and the plan's `done` are device flags replicated on every rank (identical inputs,
+// identical order), so the collective count never depends on the data.  Everything else of the outer iteration is the
+// single-GPU plan's kernels, replicated: beta = beta_y + rho (z - u) inside the start kernel, the FGP launch for a TV
+// term, admm_zu_kernel (projections, z, u, the norms, `converged`).
+int32_t rls_admm_init_rowsharded(rls_comm* comm, rls_admm* const* plans, const void* const* b_parts) {
+  RLS_TRY(rowsharded_check<rls_admm>(comm, plans, admm_op, admm_single));
+  if (!b_parts) return RLS_E_INVALID;
+  const int n = rls_comm_size(comm);
+  for (int r = 0; r < n; ++r)
+    if (!plans[r]->ready || !b_parts[r]) return rls_fail(plans[r]->cg->op->ctx, RLS_E_STATE, "admm_init_rowsharded before admm_init");
+  const int64_t N = plans[0]->cg->op->N;
+  const int32_t dtype = plans[0]->cg->op->dtype;
+  int round0 = 0;
+  RLS_TRY(rls_comm_next_rounds(comm, 1, N, dtype, &round0));
+  const std::vector<rls_comm_phase> phases = {
+      {[&](int r, int) {  // beta_y = A^H b   (:198), per shard
+         rls_operator* op = plans[r]->cg->op;
+         RLS_HIP(op->ctx, hipSetDevice(op->ctx->device));
+         RLS_TRY(rls_launch_gemv(op->ctx, dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, b_parts[r], 0.f, 0.f,
+                                 plans[r]->P.beta_y, nullptr));
+         return rls_comm_publish(comm, r, plans[r]->P.beta_y, N, dtype, round0);
+       }, true},
+      {[&](int r, int) { return rls_comm_collect(comm, r, plans[r]->P.beta_y, N, dtype, round0); }, false}};
+  return rls_comm_run(comm, phases, 1);
+}
+
+int32_t rls_admm_step_rowsharded(rls_comm* comm, rls_admm* const* plans, int32_t n_outer) {
+  RLS_TRY(rowsharded_check<rls_admm>(comm, plans, admm_op, admm_single));
+  if (n_outer < 0) return RLS_E_INVALID;
+  const int n = rls_comm_size(comm);
+  for (int r = 0; r < n; ++r) {
+    if (!plans[r]->ready) return rls_fail(plans[r]->cg->op->ctx, RLS_E_STATE, "admm_step_rowsharded before admm_init");
+    if (plans[r]->enq != plans[0]->enq || plans[r]->P.iterations != plans[0]->P.iterations ||
+        plans[r]->P.iterations_cg != plans[0]->P.iterations_cg)
+      return rls_fail(plans[r]->cg->op->ctx, RLS_E_INVALID, "admm_step_rowsharded: the ranks' plans are out of step");
+  }
+  const int64_t N = plans[0]->cg->op->N;
+  const int32_t dtype = plans[0]->cg->op->dtype;
+  const int icg = plans[0]->P.iterations_cg;
+  const int todo = std::min<int>(n_outer, plans[0]->P.iterations - plans[0]->enq);
+  if (todo <= 0) return 0;
+  const int per_outer = icg + 1;  // all-reduce rounds of one outer iteration: the warm-start apply + one per inner step
+  int round0 = 0;
+  RLS_TRY(rls_comm_next_rounds(comm, todo * per_outer, N, dtype, &round0));
+  auto zbufs = [&](rls_admm* a, void** zcur, void** znew) {
+    *zcur = (a->enq & 1) ? a->P.z1 : a->P.z0;
+    *znew = (a->enq & 1) ? a->P.z0 : a->P.z1;
+  };
+  std::vector<rls_comm_phase> phases;
+  phases.push_back({[&](int r, int k) {  // c_g = A_g^H A_g x   (warm start of cg!, src/ADMM.jl:244)
+                      rls_admm* a = plans[r];
+                      rls_cg* cg = a->cg;
+                      RLS_HIP(cg->op->ctx, hipSetDevice(cg->op->ctx->device));
+                      cg->used_pipeline = false;
+                      RLS_TRY(op_normal(cg->op, a->P.x, cg->c, &a->sc->done));
+                      return rls_comm_publish(comm, r, cg->c, N, dtype, round0 + k * per_outer);
+                    }, true});
+  for (int j = 0; j <= icg; ++j) {
+    phases.push_back({[&, j](int r, int k) {
+                        rls_admm* a = plans[r];
+                        rls_cg* cg = a->cg;
+                        rls_ctx* ctx = cg->op->ctx;
+                        RLS_HIP(ctx, hipSetDevice(ctx->device));
+                        RLS_TRY(rls_comm_collect(comm, r, cg->c, N, dtype, round0 + k * per_outer + j));
+                        void *zcur, *znew;
+                        zbufs(a, &zcur, &znew);
+                        if (j == 0) {  // beta = beta_y + rho (z - u), xold = x, r = beta - (c + rho x), u = r   (:236-243)
+                          admm_fuse_v F;
+                          F.beta_y = a->P.beta_y;
+                          F.z = zcur;
+                          F.u = a->P.u;
+                          F.beta = a->P.beta;
+                          F.xold = a->P.xold;
+                          F.rho = a->P.rho;
+                          F.skip = &a->sc->done;
+                          if (dtype == RLS_F32) admm_local_start<float>(a, F);
+                          else admm_local_start<float2>(a, F);
+                        } else {
+                          RLS_TRY(rls_cg_local_update(cg, a->P.x));
+                        }
+                        RLS_TRY(launch_status(ctx));
+                        if (j < icg) {  // next inner step's operator apply on the direction u
+                          RLS_TRY(op_normal(cg->op, cg->u, cg->c, &cg->sc->done));
+                          return rls_comm_publish(comm, r, cg->c, N, dtype, round0 + k * per_outer + j + 1);
+                        }
+                        // the rest of the outer iteration, replicated (:246-309)
+                        if (a->P.reg_kind == RLS_REG_TV)
+                          RLS_TRY(rls_tv_single_launch(ctx, dtype, a->P.tv_ndims, a->P.tv_shape, a->P.tv_ntv, a->P.tv_dims, a->P.x,
+                                                       a->P.u, znew, a->P.prox_lambda, a->P.tv_iterations, &a->sc->done));
+                        if (dtype == RLS_F32) admm_local_finish<float>(a, zcur, znew);
+                        else admm_local_finish<float2>(a, zcur, znew);
+                        ++a->enq;
+                        a->requested = a->enq;
+                        return launch_status(ctx);
+                      }, j < icg});
+  }
+  return rls_comm_run(comm, phases, todo);
+}
+
 // batched plans: out_h[nrhs]; log_h (nullable): nrhs blocks of log_records records, column after column
 int32_t rls_admm_get_status_batched(rls_admm* a, rls_admm_status* out, float* log_h, int32_t log_records) {
   if (!a || !out) return RLS_E_INVALID;
@@ -3033,6 +3336,7 @@ int32_t rls_admm_get_status_batched(rls_admm* a, rls_admm_status* out, float* lo
     const int it = a->sc_h[b].iteration;
     out[b].iteration = it;
     out[b].done = a->sc_h[b].done;
+    out[b].fallbacks = 0;
     out[b].delta = out[b].sk = out[b].eps_pri = out[b].rk = out[b].eps_dua = 0.f;
     out[b].cg_iterations = 0;
     if (it > 0 && it <= a->log_cap) {
@@ -3055,17 +3359,37 @@ int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int
   rls_ctx* ctx = a->cg->op->ctx;
   if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_get_status before admm_init");
   if (a->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "admm_get_status on a batched plan: use rls_admm_get_status_batched");
-  RLS_TRY(cg_resident_check(a->cg));
   if (log_records < 0 || (log_records > 0 && !log_h)) return rls_fail(ctx, RLS_E_INVALID, "admm_get_status: bad log");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  const int nrec = a->enq < a->log_cap ? a->enq : a->log_cap;
+  rls_cg* cg = a->cg;
+  int nrec = a->enq < a->log_cap ? a->enq : a->log_cap;
   if (nrec > 0)
     RLS_HIP(ctx, hipMemcpyAsync(a->log_h, a->log, sizeof(float) * ADMM_REC * nrec, hipMemcpyDeviceToHost, ctx->stream));
+  if (cg->resident_used) RLS_TRY(resident_fetch_flags(ctx, cg->rsync, cg->rsync_h));
   RLS_TRY(fetch_scalars(ctx, a->sc, a->sc_h));  // synchronises the stream
+  if (cg->resident_used && resident_lost(ctx, cg->rsync, cg->rsync_h, &cg->resident_off, &cg->fallbacks)) {
+    // A resident cg! gave up: it was a no-op and poisoned `done` (= 2), so everything queued behind it skipped.  The
+    // outer iteration it belonged to has changed nothing that its repetition does not rewrite (beta, xold), so clear the
+    // poison and run the missing outer iterations again; the inner solves now take the per-iteration pipeline.
+    a->fallbacks = cg->fallbacks;
+    if (a->sc_h->done == 2) {
+      const int it_done = a->sc_h->iteration;
+      RLS_HIP(ctx, hipMemsetAsync(&a->sc->done, 0, sizeof(int), ctx->stream));
+      a->enq = it_done;
+      const int missing = a->requested - it_done;
+      a->requested = it_done;
+      if (missing > 0) RLS_TRY(rls_admm_step(a, missing));
+      nrec = a->enq < a->log_cap ? a->enq : a->log_cap;
+      if (nrec > 0)
+        RLS_HIP(ctx, hipMemcpyAsync(a->log_h, a->log, sizeof(float) * ADMM_REC * nrec, hipMemcpyDeviceToHost, ctx->stream));
+      RLS_TRY(fetch_scalars(ctx, a->sc, a->sc_h));
+    }
+  }
   const int it = a->sc_h->iteration;
   a->enq = it;  // a plan that stopped early continues (after a re-init only) from the device's count
   out->iteration = it;
   out->done = a->sc_h->done;
+  out->fallbacks = a->fallbacks;
   out->delta = out->sk = out->eps_pri = out->rk = out->eps_dua = 0.f;
   out->cg_iterations = 0;
   if (it > 0 && it <= nrec) {
@@ -3080,6 +3404,11 @@ int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int
   const int ncopy = it < log_records ? it : log_records;
   for (int i = 0; i < ncopy * ADMM_REC; ++i) log_h[i] = a->log_h[i];
   return 0;
+}
+
+int32_t rls_admm_step_status(rls_admm* a, int32_t n_outer, rls_admm_status* out, float* log_h, int32_t log_records) {
+  RLS_TRY(rls_admm_step(a, n_outer));
+  return rls_admm_get_status(a, out, log_h, log_records);
 }
 
 }  // extern "C"

@@ -61,6 +61,15 @@ def _resolve_operator(A, AHA):
     return A, OperatorHandle(A, gram)
 
 
+
+def _cg_is_resident(lib, plan) -> bool:
+    """a cg! that runs as ONE resident launch can time out as a no-op (another tenant on the device); its status call
+    repeats the solve on the per-iteration pipeline then, so x must not be consumed before that call (include/rls_mi355x.h,
+    rls_cg_get_status)"""
+    path = C.c_int32(-1)
+    return lib.rls_cg_path(plan, C.byref(path)) == 0 and path.value in (4, 5)
+
+
 class AbstractLinearSolver:
     state = None
 
@@ -141,6 +150,7 @@ class CGNRState(AbstractSolverState):
         self.z0 = st.z0
         self._done = bool(st.done)
         self._residual = st.residual
+        self.fallbacks = int(st.fallbacks)  # resident launches lost to a co-tenant and re-run on the pipeline
         return st
 
     def convergence(self):
@@ -276,6 +286,7 @@ class FISTAState(AbstractSolverState):
         self.norm_x0 = st.norm_x0
         self._residual = st.residual
         self._done = bool(st.done)
+        self.fallbacks = int(st.fallbacks)
         # the reference swaps x / xold by pointer every iteration (src/FISTA.jl:144-146)
         self.x, self.xold = (self._bufs[st.iteration & 1], self._bufs[(st.iteration + 1) & 1])
         return st
@@ -687,6 +698,7 @@ class ADMM(AbstractPrimalDualSolver):
         cap = max(self.iterations, 1)
         log = (C.c_float * (8 * cap))()
         check(h, lib.rls_admm_get_status(state._admm, C.byref(st), log, cap), "rls_admm_get_status")
+        state.fallbacks = int(st.fallbacks)
         it = int(st.iteration)
         if it > 0:
             state.Delta[0], state.sk[0], state.eps_pri[0] = st.delta, st.sk, st.eps_pri
@@ -769,7 +781,7 @@ class ADMM(AbstractPrimalDualSolver):
             rho_sum = float(np.sum(state.rho, dtype=np.float32))
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, rho_sum, self.iterationsCG,
                                       float(state.tolInner)), "rls_cg_solve")
-            if not fused or self.verbose or self._track_cg:
+            if not fused or self.verbose or self._track_cg or _cg_is_resident(lib, state._cg):
                 st = CgStatus()
                 check(h, lib.rls_cg_get_status(state._cg, C.byref(st)), "rls_cg_get_status")
                 state.cg_iterations.append(int(st.iterations))
@@ -1310,6 +1322,7 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
         cap = max(self.iterationsInner, 1)
         log = (C.c_float * (8 * cap))()
         check(h, lib.rls_admm_get_status(state._admm, C.byref(st), log, cap), "rls_admm_get_status")
+        state.fallbacks = int(st.fallbacks)
         it = int(st.iteration)  # inner iterations completed in this block
         state.cg_iterations += [int(log[8 * k + 5]) for k in range(state._block_done, it)]
         state._block_done = it
@@ -1341,6 +1354,8 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
         if self._all_identity():
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, float(np.sum(state.rho, dtype=np.float32)),
                                       self.iterationsCG, float(state.tolInner)), "rls_cg_solve")
+            if _cg_is_resident(lib, state._cg):
+                check(h, lib.rls_cg_get_status(state._cg, C.byref(CgStatus())), "rls_cg_get_status")
         else:
             self._cg_generic(state)
         for pr in self.proj:

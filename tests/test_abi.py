@@ -42,7 +42,7 @@ def test_binding_covers_exactly_the_header(rls):
 
 def test_abi_version_and_status_codes(rls):
     lib = rls.load()
-    assert lib.rls_abi_version() == 1
+    assert lib.rls_abi_version() == 2
     assert lib.rls_ctx_sync(None) == -1          # RLS_E_INVALID on a null context
     assert lib.rls_cgnr_step(None, 1) == -1
     assert lib.rls_last_error_string(None) == b"null context"

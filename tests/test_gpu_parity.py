@@ -2034,27 +2034,94 @@ def test_cgnr_resident_kernel(rls, ctx, dt, M, N, lam):
     parity(f"{tag}_pipeline", x_pipe, ref.x, ref32.x)
 
 
-def test_cgnr_resident_timeout_is_a_loud_no_op(rls, ctx):
-    """every in-kernel wait is bounded: with the bound forced to ONE poll some workgroup gives up, the launch leaves
-    x, r, p and the scalars untouched and the next status read reports it; the plan keeps working afterwards"""
+def _fresh_resident_ctx(ctx):
+    """forget earlier timeouts (a context that lost two resident launches stops using the resident kernels)"""
+    ctx.tune(resident=1)
+
+
+def test_cgnr_resident_timeout_falls_back_to_the_pipeline(rls, ctx):
+    """every in-kernel wait is bounded: with the bound forced to ONE poll workgroup 0 gives up and the launch changes
+    nothing.  The next status read re-runs the lost iterations on the two-launch pipeline: no exception, the iteration
+    count and the solution are those of an undisturbed run, `fallbacks` counts the event, and a lost launch stays
+    visible (sticky) even when a later resident launch of the same plan succeeds before the status is read"""
+    import ctypes as C
     A, xt, b = O.make_problem(4096, 2048, np.complex64, 78)
     Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
-    sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=8, relTol=0.0)
-    rls.init_(sol, bd)
-    if _cgnr_path(rls, sol) != 4:
-        pytest.skip("resident mode not available")
-    p_before = sol.state.pl.to_host()
-    ctx.tune(resident_spin=1)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    ref = {n: O.solve(O.CGNR(A64, iterations=n, relTol=0.0), b64) for n in (4, 8)}
+    _fresh_resident_ctx(ctx)
     try:
-        ctx.lib.rls_cgnr_step(sol.state._plan, 4)
-        with pytest.raises(rls.RLSError, match="timed out"):
-            sol.state._refresh(ctx.lib)
+        for lost_then_ok in (False, True):
+            sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=8, relTol=0.0)
+            rls.init_(sol, bd)
+            if _cgnr_path(rls, sol) != 4:
+                pytest.skip("resident mode not available")
+            ctx.tune(resident_spin=1)
+            assert ctx.lib.rls_cgnr_step(sol.state._plan, 4) == 0       # lost: a no-op
+            ctx.tune(resident_spin=100000)
+            if lost_then_ok:
+                assert ctx.lib.rls_cgnr_step(sol.state._plan, 4) == 0   # runs, and clears the per-launch flags
+            st = sol.state._refresh(ctx.lib)
+            want = 8 if lost_then_ok else 4
+            assert st.iteration == want and st.fallbacks >= 1
+            assert _cgnr_path(rls, sol) == 1                             # the plan stays on the pipeline
+            parity(f"cgnr_resident_fallback_{want}", sol.state.x.to_host(), ref[want],
+                   lambda: O.solve(O.CGNR(A, iterations=want, relTol=0.0), b))
+            _fresh_resident_ctx(ctx)
     finally:
-        ctx.tune(resident_spin=400000)
-    assert np.array_equal(sol.state.pl.to_host(), p_before) and np.all(sol.state.x.to_host() == 0)
+        ctx.tune(resident_spin=100000)
+        _fresh_resident_ctx(ctx)
+    sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=8, relTol=0.0)
     x = rls.solve_(sol, bd).to_host()
-    ref = O.CGNR(A.astype(np.complex128), iterations=8, relTol=0.0)
-    parity("cgnr_resident_after_timeout", x, O.solve(ref, b.astype(np.complex128)), lambda: O.solve(O.CGNR(A, iterations=8, relTol=0.0), b))
+    assert _cgnr_path(rls, sol) == 4 and sol.state._refresh(ctx.lib).fallbacks == 0
+    parity("cgnr_resident_after_timeout", x, ref[8], lambda: O.solve(O.CGNR(A, iterations=8, relTol=0.0), b))
+
+
+def test_resident_solvers_survive_a_co_tenant(rls, ctx):
+    """a kernel on ANOTHER stream sits on 64 whole CUs for longer than the resident kernels' wait bound while a resident
+    CGNR step, a resident FISTA step and an ADMM plan (one resident cg! per outer iteration) are issued: the resident
+    launches cannot get their 256 workgroups onto the chip and give up; the results still equal the oracle's, nothing
+    raises, and every plan reports the fallback"""
+    import ctypes as C
+    A, xt, b = O.make_problem(4096, 2048, np.complex64, 79)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    other = rls.Context(0)  # own stream
+    lam = 1e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    rho_f = 0.95 / np.linalg.norm(A64, 2) ** 2
+    cases = {
+        "cgnr": (lambda R, Am: R.CGNR(Am, iterations=8, relTol=0.0) if R is O else R.createLinearSolver(R.CGNR, Am, iterations=8, relTol=0.0)),
+        "fista": (lambda R, Am: R.FISTA(Am, reg=R.L1Regularization(lam), rho=rho_f, iterations=8) if R is O
+                  else R.createLinearSolver(R.FISTA, Am, reg=R.L1Regularization(lam), rho=rho_f, iterations=8)),
+        "admm": (lambda R, Am: R.ADMM(Am, reg=R.L1Regularization(lam), rho=0.1, iterations=4, iterationsCG=5, tolInner=1e-5) if R is O
+                 else R.createLinearSolver(R.ADMM, Am, reg=R.L1Regularization(lam), rho=0.1, iterations=4, iterationsCG=5, tolInner=1e-5)),
+    }
+    try:
+        for name, make in cases.items():
+            _fresh_resident_ctx(ctx)
+            ctx.tune(resident_spin=20000)  # ~20 ms per wait
+            ref = make(O, A64)
+            O.solve(ref, b64)
+            sol = make(rls, Ad)
+            rls.init_(sol, bd)
+            ctx.sync()
+            assert other.lib.rls_debug_hold_cus(other.handle, 64, 400000) == 0   # 0.4 s on 64 CUs, other stream
+            x = rls.solve_(sol, bd).to_host()
+            other.sync()
+            st = sol.state._refresh(ctx.lib) if name != "admm" else None
+            if name == "admm":
+                ast = rls._lib.AdmmStatus()
+                assert ctx.lib.rls_admm_get_status(sol.state._admm, C.byref(ast), None, 0) == 0
+                fallbacks, iteration = ast.fallbacks, ast.iteration
+            else:
+                fallbacks, iteration = st.fallbacks, st.iteration
+            assert fallbacks >= 1, f"{name}: the co-tenant did not displace the resident launch"
+            assert iteration == ref.iteration
+            parity(f"co_tenant_{name}", x, ref.x, lambda: (lambda o: (O.solve(o, b), o.x)[1])(make(O, A)))
+    finally:
+        ctx.tune(resident_spin=100000)
+        _fresh_resident_ctx(ctx)
+        other.close()
 
 
 @pytest.mark.parametrize("dt,M,N,restart", [(np.complex64, 4096, 2048, "none"), (np.complex64, 4096, 2048, "gradient"),

@@ -15,7 +15,7 @@ xt = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).ast
 b = (A @ xt).astype(np.complex64)
 Ad, bd = rls.DeviceMatrix.from_host(A, ctx), rls.DeviceVector.from_host(b, ctx)
 S = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
-for mode, bar in ((1, 0), (1, 1), (0, 0)):
+for mode, bar in ((1, 2), (1, 1), (0, 2)):  # resident two-level exchange, resident flat exchange, two-launch pipeline
     ctx.tune(resident=mode, resident_barrier=bar)
     for seg in (32, 8):
         def run(nsolves):
