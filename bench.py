@@ -9,11 +9,13 @@ column-major ComplexF32 4096x2048 A that is already resident in HBM (lambda = 0,
 when that region is shorter than 10 ms it is repeated (>= 50 times, every repetition bracketed the same way) and
 `value` = K / median(elapsed), with the spread reported beside it.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE configs[3] -- 64 independent CGNR solves
-on one shared 4096x2048 A sharded 8 right-hand sides per GPU (column k -> GPU k // 8), no data-path collective
--> weak scaling; a step is one batched iteration (8 solve-iterations per GPU), `value` = solve-iterations/s of the
-whole job.  `--workload single` instead runs the N = 1 workload on every GPU (one independent solve each);
-`--workload rowsharded` runs BASELINE configs[4] (one tall A row-partitioned, one all-reduce per iteration).
+N > 1 (launched by torch.distributed.run, one process per GPU): the SAME workload and unit on every GPU -- one
+independent headline solve per GPU (the path shards by independent problems, src/MultiThreading.jl:30-79: no data-path
+collective, weak scaling), `value` = iterations/s summed over the GPUs, so value(N) / (N * value(1)) is an efficiency.
+Every N > 1 line also carries `n1_same_workload_value` (rank 0 running the same steps alone while the other ranks wait)
+and the quotient, plus `config4_batched`: BASELINE configs[3]'s shared-A flavour (8 right-hand sides per GPU advancing
+together on the matrix cores, solve-iterations/s) measured the same way.  `--workload config4` makes that the line's
+workload; `--workload rowsharded` runs BASELINE configs[4] (one tall A row-partitioned, one all-reduce per iteration).
 
 Prints ONE JSON line on rank 0 with `roofline` and (N = 1) `cpu_baseline` objects.
 """
@@ -39,7 +41,30 @@ MFMA_F32_PEAK_TF = 157.3  # dense f32-input MFMA peak, same table
 # first (one extra GEMV) is inside the timed region but not counted as a step.
 SEGMENT = 32
 PATH_NAMES = {0: "two GEMVs + update kernel", 1: "one-pass slab pipeline (2 launches per iteration)",
-              2: "Gram-mode pipeline", 3: "batched matrix-core kernels", 4: "resident (one launch per step call, A in registers)"}
+              2: "Gram-mode pipeline", 3: "batched matrix-core kernels", 4: "resident (one launch per step call, A in registers)",
+              5: "resident Gram mode (one launch per step call, AHA in registers)"}
+
+
+def grid_exchange_floor():
+    """the resident kernels' in-kernel exchange measured with the arithmetic stripped (tools/ubench/grid_barrier, built by
+    __graft_entry__.build()): us per round of the bare grid barrier, of the flat two-hop all-reduce and of the two-level
+    one.  Run live (about a second); None when the binary is missing."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench", "grid_barrier")
+    if not os.path.exists(exe):
+        return None
+    try:
+        txt = subprocess.run([exe, "1000", "2048"], capture_output=True, text=True, timeout=60).stdout
+    except Exception:
+        return None
+    best = {}
+    for line in txt.splitlines():
+        f = line.split()
+        if len(f) >= 2 and f[0] in ("bar", "flat") and "fail 0" in line and "wrong sums 0" in line:
+            best[f[0]] = min(best.get(f[0], 1e9), float(f[1]))
+        if line.startswith("group GN= 8 strided") and "fail 0" in line and "wrong sums 0" in line:
+            best["two_level"] = min(best.get("two_level", 1e9), float(f[4]))
+    return best or None
 
 
 def make_A(M, N, seed, dtype=np.complex64):
@@ -261,6 +286,47 @@ def other_paths(rls, ctx, Ad, A, b, errors):
                            "partial rows the slab kernel has just written on other XCDs and runs ~4.8 us (rocprofv3, profiles/)")
         return res
 
+    @entry("iterate_per_call_cadence (the reference's solve! loop: one iterate + one `done` check per iteration, "
+           "src/RegularizedLeastSquares.jl:103-117; rls_*_step_status(plan, 1) = one host synchronisation per iteration)")
+    def _():
+        res = {}
+
+        def cadence(make, step_status, status_t, n_it):
+            S = make()
+            rls.solve_(S, b)
+            st_ = status_t()
+            plan = S.state._admm if hasattr(S.state, "_admm") and S.state._admm else S.state._plan
+            def run():
+                rls.init_(S, b)
+                for _ in range(n_it):
+                    step_status(plan, st_)
+            run(); ctx.sync()
+            best = float("inf")
+            for _ in range(5):
+                t0 = time.perf_counter(); run(); best = min(best, time.perf_counter() - t0)
+            assert st_.iteration == n_it, (st_.iteration, n_it)
+            return 1e6 * best / n_it
+
+        L = rls._lib
+        for tag, res_on in (("", 1), ("_pipeline (resident = 0)", 0)):
+            ctx.tune(resident=res_on)
+            try:
+                us = cadence(lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0),
+                             lambda p, st_: L.check(h, lib.rls_cgnr_step_status(p, 1, C.byref(st_)), "cgnr_step_status"), L.CgnrStatus, 32)
+                res["cgnr" + tag] = {"us_per_iterate_call_wall": us, "iterations_per_s": 1e6 / us}
+                us = cadence(lambda: rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=32, relTol=0.0),
+                             lambda p, st_: L.check(h, lib.rls_fista_step_status(p, 1, C.byref(st_)), "fista_step_status"), L.FistaStatus, 32)
+                res["fista_l1" + tag] = {"us_per_iterate_call_wall": us, "iterations_per_s": 1e6 / us}
+                us = cadence(lambda: rls.createLinearSolver(rls.ADMM, Ad, reg=rls.L1Regularization(1e-2), rho=0.1, iterations=8, iterationsCG=10,
+                                                            tolInner=1e-5, absTol=0.0, relTol=0.0),
+                             lambda p, st_: L.check(h, lib.rls_admm_step_status(p, 1, C.byref(st_), None, 0), "admm_step_status"), L.AdmmStatus, 8)
+                res["admm_l1_outer" + tag] = {"us_per_iterate_call_wall": us, "outer_iterations_per_s": 1e6 / us}
+            finally:
+                ctx.tune(resident=1)
+        res["note"] = ("wall clock of init! + n x (step one iteration, read the status back) driven from Python through ctypes; the headline "
+                       "`value` enqueues a whole solve per call instead (solve! without callbacks)")
+        return res
+
     @entry("fista_l1_matrix_free (BASELINE configs[1])")
     def _():
         S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
@@ -454,9 +520,7 @@ def main():
     s = np.dtype(dt).itemsize
     K, W = args.steps, args.warmup
     workload = args.workload
-    if workload == "auto":
-        workload = "cgnr" if world == 1 else "config4"
-    if workload == "single":
+    if workload in ("auto", "single"):
         workload = "cgnr"
 
     def finish(result=None):
@@ -503,7 +567,29 @@ def main():
             evs.append(ev_ms * 1e-3)
         return walls, evs
 
-    if workload == "config4":
+    def solo_rate(prepare, run, units):
+        """units / wall time of `run` on rank 0 ALONE (the other ranks wait at the barrier): the N = 1 figure of the same
+        workload, measured in the same job; broadcast to every rank.  None at N = 1 (the line's value is that figure)."""
+        if dist is None:
+            return None
+        barrier()
+        rate = 0.0
+        if rank == 0:
+            els, t_all = [], time.perf_counter()
+            while len(els) < 5 or (len(els) < 200 and time.perf_counter() - t_all < 0.3):
+                prepare()
+                ctx.sync()
+                t0 = time.perf_counter()
+                run()
+                ctx.sync()
+                els.append(time.perf_counter() - t0)
+            rate = units / statistics.median(els)
+        tt = torch.tensor([rate], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        barrier()
+        return float(tt.item())
+
+    def config4_measure(K, W):
         # ---- BASELINE configs[3]: shared A (seed 4), B = A X (X: seed 5, 64 columns), columns 8k..8k+7 on GPU k ----
         R = args.rhs_per_gpu
         A = make_A(M, N, seed=4)
@@ -572,7 +658,14 @@ def main():
                                note="hbm basis: A streamed twice per batched iteration (2*M*N*s bytes, shared by the right-hand sides; it "
                                     "comes out of the Infinity Cache, so the memory-side counters see less); mfma basis: 16*M*N flops per "
                                     "solve-iteration (complex MAC = 8 flops, two products), padding columns not counted")
-        return finish(out)
+        n1 = solo_rate(init, lambda: step(K, True), R * K)
+        if n1 is not None:
+            out["n1_same_workload_value"] = n1
+            out["efficiency_vs_n1_same_workload"] = out["value"] / (world * n1)
+        return out
+
+    if workload == "config4":
+        return finish(config4_measure(K, W))
 
     # ---- headline: one CGNR solve per GPU, data resident in HBM before the timed region ---------------------------
     A = make_A(M, N, seed=2 if world == 1 else 100 + rank)
@@ -630,7 +723,8 @@ def main():
             lib.rls_cgnr_step(st._plan, SEGMENT)
             us.append(1e3 * ctx.timer_stop_ms())
         us_launch = statistics.median(us)
-        exch = (2 * nwg * N * s + nwg * (N * s + 8 * 1024)) * SEGMENT  # partial rows out + in, v and partial dots read by every workgroup
+        # two-level exchange: partial rows out + in (slices over the group), 8 group partials out, all of them read by every workgroup
+        exch = (2 * nwg * N * s + 8 * N * s + nwg * 8 * N * s) * SEGMENT
         dom = "cgnr_resident_kernel"
         kern[dom] = {"us_per_launch": us_launch, "iterations_per_launch": SEGMENT, "us_per_iteration_in_kernel": us_launch / SEGMENT,
                      "algorithmic_bytes_per_launch": bytes_iter * SEGMENT,
@@ -649,6 +743,30 @@ def main():
         dom = PATH_NAMES.get(path.value, "?")
         kern[dom] = {"us_per_launch": 1e6 * ev / K, "iterations_per_launch": 1, "algorithmic_bytes_per_launch": bytes_iter,
                      "effective_GBps": iter_gbs, "min_hbm_bytes_per_launch": 2 * M * N * s}
+    floor = None
+    if path.value == 4 and rank == 0:
+        # A roof for the resident kernel (its HBM fraction says nothing: A never moves): per iteration it must at least run
+        # its two products on the VALU (16 M N flops at the packed-f32 FMA peak: 256 CUs x 128 lanes x 2 (v_pk_fma) x 2 flop
+        # x 2.4 GHz = 314.6 TFLOP/s) and ONE grid-wide all-reduce of the partial rows, whose cost with the arithmetic
+        # stripped is measured live by tools/ubench/grid_barrier (same protocol, same shapes, nothing else in the kernel).
+        ge = grid_exchange_floor()
+        if ge and "two_level" in ge:
+            valu_us = 16.0 * M * N / 314.6e12 * 1e6
+            floor_us = valu_us + ge["two_level"]
+            it_us = kern[dom]["us_per_iteration_in_kernel"]
+            floor = {"bound": "grid-exchange", "unit": "us per iteration", "floor": floor_us, "measured": it_us, "frac_of_floor": floor_us / it_us,
+                     "components": {"products_on_the_VALU_at_peak": valu_us, "all_reduce_two_level_arithmetic_stripped": ge["two_level"],
+                                    "for_comparison": {"bare_grid_barrier_256_workgroups": ge.get("bar"),
+                                                       "all_reduce_flat_two_hops (round 2's exchange)": ge.get("flat")}},
+                     "source": "tools/ubench/grid_barrier (run live by bench.py); profiles/r03_grid_barrier.txt holds a committed run"}
+    n1_value = solo_rate(lambda: rls.init_(solver, bd), lambda: step(K, True), K)
+    c4 = None
+    if world > 1:
+        # BASELINE configs[3], shared-A flavour, on the same job: 8 right-hand sides per GPU advancing together (matrix cores)
+        c4_full = config4_measure(max(SEGMENT, min(K, 20 * SEGMENT)), SEGMENT)
+        c4 = {k: c4_full[k] for k in ("metric", "value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
+                                      "per_rank_solve_iterations_per_s_hip_events") if k in c4_full}
+        c4["roofline"] = {k: c4_full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
     traffic, traffic_src = load_pmc(dom)
     kd = kern[dom]
     hbm_bytes = traffic if traffic is not None else kd["min_hbm_bytes_per_launch"]
@@ -691,11 +809,19 @@ def main():
                          "capped at the HBM peak; frac_hbm: HBM bytes of the dominant kernel per launch (PMC when collected, else the minimum it "
                          "must move) / its launch time / peak.  " +
                          ("The resident kernel keeps A in the register files across the iterations of a launch: per iteration it moves only "
-                          "the partial-row exchange (L2 / Infinity Cache), so it is bound by two in-kernel grid-wide exchanges, not by HBM; the "
+                          "the partial-row exchange (L2 / Infinity Cache), so it is bound by its in-kernel grid-wide all-reduce, not by HBM: "
+                          "`resident_floor` is its roof (VALU time of the products + the all-reduce measured with the arithmetic stripped); the "
                           "two-launch pipeline that streams A every iteration is reported under other_paths." if path.value == 4 else "")),
                 "per_kernel": kern,
                 "iteration": {"bytes": bytes_iter, "us_hip_events": 1e6 * ev / K, "roofline_us_at_peak": bytes_iter / HBM_PEAK_GBS / 1e3}},
         }
+        if floor is not None:
+            out["roofline"]["resident_floor"] = floor
+        if n1_value is not None:
+            out["n1_same_workload_value"] = n1_value
+            out["efficiency_vs_n1_same_workload"] = out["value"] / (world * n1_value)
+        if c4 is not None:
+            out["config4_batched"] = c4
         errors = []
         if world == 1 and not args.no_extras and (M, N) == (4096, 2048):
             out["other_paths"] = other_paths(rls, ctx, Ad, A, bd, errors)

@@ -503,6 +503,9 @@ int32_t rls_cgnr_step_rowsharded(rls_comm* comm, rls_cgnr* const* plans, int32_t
  * two halves of each all-reduce, so the host side of an iteration costs ONE rank's launches.  on = 0: the calling thread
  * drives every rank in turn (also: environment RLS_COMM_THREADS=0 at communicator creation).  Results are identical. */
 int32_t rls_comm_set_threads(rls_comm* comm, int32_t on);
+/* measurement only: seconds each rank's worker thread has spent enqueueing (inside the phases of the row-sharded calls,
+ * host barriers and idle time excluded) since the previous call; out_h[nranks] */
+int32_t rls_comm_debug_busy_seconds(rls_comm* comm, double* out_h);
 /* FISTA on a row-partitioned A (src/FISTA.jl:110-185; call sites of the distributed step :114, :152): plans[r] =
  * rls_fista_create (+ rls_fista_set_reg) on rank r's shard operator.  init: x0 = sum_g A_g^H b_g (ONE all-reduce), then
  * every rank's rls_fista_init_local_b; a step: res_g = A_g^H A_g y, ONE all-reduce of res, the replicated gradient step /

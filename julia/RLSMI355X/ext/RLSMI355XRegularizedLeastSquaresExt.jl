@@ -12,12 +12,13 @@
 module RLSMI355XRegularizedLeastSquaresExt
 
 using RLSMI355X, RegularizedLeastSquares, LinearAlgebra
-using RLSMI355X: RLSVector, RLSMatrix, RLSNormalOp, librls, check, dtypecode
+using RLSMI355X: RLSVector, RLSMatrix, RLSNormalOp, librls, check, dtypecode, Comm, colptr
 import RegularizedLeastSquares: prox!, proxL21!, proxTV!, enfReal!, enfPos!, tv_restrictMagnitude!, tv_linearcomb!,
                                 init!, iterate, CGNR, CGNRState, FISTA, FISTAState, ADMM, ADMMState, L1Regularization,
                                 L2Regularization, L21Regularization, TVRegularization, PositiveRegularization,
                                 RealRegularization, NoNormalization, TVParams, λ, Kaczmarz, KaczmarzState, normalize,
-                                SystemMatrixBasedNormalization, done
+                                SystemMatrixBasedNormalization, done, AbstractSolverState, AbstractLinearSolver,
+                                AbstractMatrixSolverState, solversolution, solverconvergence
 
 const V{T} = Union{RLSVector{T}, RLSVector{Complex{T}}}
 
@@ -66,9 +67,9 @@ end
 # ---- fused CGNR: init! + iterate on device state --------------------------------------------------
 const cgnr_plans = IdDict{Any,Ptr{Cvoid}}()   # state => rls_cgnr plan (destroyed with the state)
 
-struct CgnrStatus
+struct CgnrStatus   # rls_cgnr_status (include/rls_mi355x.h), field for field
   iteration::Int32; done::Int32; alpha_re::Float32; alpha_im::Float32; beta_re::Float32; beta_im::Float32
-  zeta::Float32; residual::Float32; z0::Float32
+  zeta::Float32; residual::Float32; z0::Float32; fallbacks::Int32
 end
 
 function plan_for(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
@@ -90,24 +91,37 @@ function init!(solver::CGNR, state::CGNRState{T,Tc,vecTc}, b::vecTc; x0 = 0) whe
   check(b.ctx, ccall((:rls_cgnr_init, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int32),
                      plan, b.ptr, Float32(λ(solver.L2)), state.relTol, solver.iterations), "rls_cgnr_init")
   state.iteration = 0
+  delete!(cgnr_done, state)    # the device's `done` of this solve is not known yet
+  nothing
 end
 
-# src/CGNR.jl:143-178
+"the scalars of the device plan into the host-side state (after a status read-back)"
+function cgnr_take!(state::CGNRState{T,Tc}, st::CgnrStatus) where {T,Tc}
+  state.iteration = st.iteration; state.z0 = st.z0
+  state.αl = Tc <: Complex ? Tc(st.alpha_re, st.alpha_im) : Tc(st.alpha_re)
+  state.βl = Tc(st.beta_re); state.ζl = Tc(st.zeta)
+  cgnr_done[state] = st.done != 0
+  st
+end
+const cgnr_done = IdDict{Any,Bool}()   # state => `done` as the device last reported it
+
+# src/CGNR.jl:143-178.  One library call per iteration: the step and the status read-back (`done`, the convergence record
+# the callbacks read) travel together (rls_cgnr_step_status: one host synchronisation).
 function iterate(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
   plan = plan_for(solver, state)
   st = Ref{CgnrStatus}()
-  check(state.x.ctx, ccall((:rls_cgnr_get_status, librls[]), Int32, (Ptr{Cvoid}, Ref{CgnrStatus}), plan, st), "rls_cgnr_get_status")
-  state.iteration = st[].iteration; state.z0 = st[].z0
-  state.αl = Tc <: Complex ? Tc(st[].alpha_re, st[].alpha_im) : Tc(st[].alpha_re)
-  state.βl = Tc(st[].beta_re); state.ζl = Tc(st[].zeta)
-  if st[].done != 0
+  if !haskey(cgnr_done, state)   # first call after init!: is the solve done before it starts (iterations == 0, r == 0)?
+    check(state.x.ctx, ccall((:rls_cgnr_get_status, librls[]), Int32, (Ptr{Cvoid}, Ref{CgnrStatus}), plan, st), "rls_cgnr_get_status")
+    cgnr_take!(state, st[])
+  end
+  if cgnr_done[state]
     for r in solver.constr
       prox!(r, state.x)
     end
     return nothing
   end
-  check(state.x.ctx, ccall((:rls_cgnr_step, librls[]), Int32, (Ptr{Cvoid}, Int32), plan, 1), "rls_cgnr_step")
-  state.iteration += 1
+  check(state.x.ctx, ccall((:rls_cgnr_step_status, librls[]), Int32, (Ptr{Cvoid}, Int32, Ref{CgnrStatus}), plan, 1, st), "rls_cgnr_step_status")
+  cgnr_take!(state, st[])
   return state.x, state
 end
 
@@ -137,8 +151,9 @@ end
 
 const fista_plans = IdDict{Any,Ptr{Cvoid}}()   # state => rls_fista plan
 
-struct FistaStatus
+struct FistaStatus   # rls_fista_status, field for field
   iteration::Int32; done::Int32; theta::Float32; theta_old::Float32; rel_res_norm::Float32; residual::Float32; norm_x0::Float32
+  fallbacks::Int32
 end
 
 function fista_plan_for(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT}
@@ -179,14 +194,15 @@ function init!(solver::FISTA, state::FISTAState{rT,vecT}, b::vecT; x0 = 0, theta
     length(xs) == length(state.x) || throw(DimensionMismatch("x0 has length $(length(xs)), the solution $(length(state.x))"))
     check(ctx, ccall((:rls_fista_set_start, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), plan, xs.ptr, length(xs)), "rls_fista_set_start")
   end
-  st = fista_status(state, plan)
+  # the plan starts every solve with state.x in the vector it was created with; after a solve that ended on an odd
+  # iteration count the host-side x / xold are swapped, so bring the roles back in line with the device (rls_fista_solution)
+  st = fista_refresh!(state, plan)
   state.iteration = 0; state.norm_x₀ = st.norm_x0; state.theta = theta; state.thetaᵒˡᵈ = theta; state.rel_res_norm = rT(Inf)
   nothing
 end
 
-"host-side scalars and the x / xold roles after the device has advanced"
-function fista_refresh!(state, plan)
-  st = fista_status(state, plan)
+"host-side scalars and the x / xold roles after the device has advanced (`st`: a status already read, else read now)"
+function fista_refresh!(state, plan, st = fista_status(state, plan))
   state.iteration = st.iteration; state.theta = st.theta; state.thetaᵒˡᵈ = st.theta_old
   st.iteration > 0 && (state.rel_res_norm = st.rel_res_norm)
   sol = Ref{Ptr{Cvoid}}(C_NULL)                        # the plan swaps x / xold by pointer, as :144-146 does
@@ -201,8 +217,9 @@ function iterate(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT}
   plan = get(fista_plans, state, C_NULL)
   plan == C_NULL && return invoke(iterate, Tuple{FISTA,FISTAState}, solver, state)
   done(solver, state) && return nothing
-  check(state.x.ctx, ccall((:rls_fista_step, librls[]), Int32, (Ptr{Cvoid}, Int32), plan, 1), "rls_fista_step")
-  fista_refresh!(state, plan)
+  st = Ref{FistaStatus}()   # step + status in one call: one host synchronisation per iteration
+  check(state.x.ctx, ccall((:rls_fista_step_status, librls[]), Int32, (Ptr{Cvoid}, Int32, Ref{FistaStatus}), plan, 1, st), "rls_fista_step_status")
+  fista_refresh!(state, plan, st[])
   solver.verbose && println("Iteration $(state.iteration); rel. residual = $(state.rel_res_norm)")
   return state.x, state
 end
@@ -220,8 +237,9 @@ struct AdmmParams
   tv_dims::NTuple{4,Int32}
   tv_shape::NTuple{4,Int64}
 end
-struct AdmmStatus
+struct AdmmStatus   # rls_admm_status, field for field
   iteration::Int32; done::Int32; rk::Float32; sk::Float32; eps_pri::Float32; eps_dua::Float32; delta::Float32; cg_iterations::Int32
+  fallbacks::Int32
 end
 
 const admm_plans = IdDict{Any,Any}()   # state => (cg plan, admm plan, z buffers)
@@ -265,6 +283,11 @@ function init!(solver::ADMM, state::ADMMState{rT,rvecT,vecT}, b::vecT; x0 = 0) w
   invoke(init!, Tuple{ADMM,ADMMState{rT,rvecT,V},V} where {V<:Union{AbstractVector{rT},AbstractVector{Complex{rT}}}}, solver, state, b; x0)
   P = admm_plan_for(solver, state)
   P === nothing && return nothing
+  # The reference's init! has just written z = Phi x0 into state.z[1] -- whichever of the two buffers that is after the
+  # previous solve (a solve that stopped on an odd outer-iteration count leaves the roles swapped).  The device plan
+  # starts at parity 0 = z0, so z0 must be the buffer init! wrote: rebuild the pair from the CURRENT roles every time.
+  P = merge(P, (zbuf = (state.z[1], state.zᵒˡᵈ[1]),))
+  admm_plans[state] = P
   reg = solver.reg[1]
   ρ = Float32(state.ρ[1])
   tv = reg isa TVRegularization
@@ -288,14 +311,17 @@ function iterate(solver::ADMM, state::ADMMState{rT,rvecT,<:RLSVector}) where {rT
   P = get(admm_plans, state, nothing)
   P === nothing && return invoke(iterate, Tuple{ADMM,ADMMState}, solver, state)
   done(solver, state) && return nothing
-  check(state.x.ctx, ccall((:rls_admm_step, librls[]), Int32, (Ptr{Cvoid}, Int32), P.plan, 1), "rls_admm_step")
-  admm_refresh!(state, P)
+  st = Ref{AdmmStatus}()   # step + status in one call
+  check(state.x.ctx, ccall((:rls_admm_step_status, librls[]), Int32, (Ptr{Cvoid}, Int32, Ref{AdmmStatus}, Ptr{Cvoid}, Int32), P.plan, 1, st, C_NULL, 0), "rls_admm_step_status")
+  admm_refresh!(state, P, st)
   return state.x, state
 end
 
-function admm_refresh!(state, P)
-  st = Ref{AdmmStatus}()
-  check(state.x.ctx, ccall((:rls_admm_get_status, librls[]), Int32, (Ptr{Cvoid}, Ref{AdmmStatus}, Ptr{Cvoid}, Int32), P.plan, st, C_NULL, 0), "rls_admm_get_status")
+function admm_refresh!(state, P, st = nothing)
+  if st === nothing
+    st = Ref{AdmmStatus}()
+    check(state.x.ctx, ccall((:rls_admm_get_status, librls[]), Int32, (Ptr{Cvoid}, Ref{AdmmStatus}, Ptr{Cvoid}, Int32), P.plan, st, C_NULL, 0), "rls_admm_get_status")
+  end
   state.iteration = st[].iteration
   if st[].iteration > 0
     state.rᵏ[1] = st[].rk; state.sᵏ[1] = st[].sk; state.ɛᵖʳⁱ[1] = st[].eps_pri; state.ɛᵈᵘᵃ[1] = st[].eps_dua; state.Δ[1] = st[].delta
@@ -317,8 +343,10 @@ function RLSMI355X.solve_fused!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector)
   init!(solver, b)
   state = solver.state
   if solver isa CGNR
-    check(b.ctx, ccall((:rls_cgnr_step, librls[]), Int32, (Ptr{Cvoid}, Int32), plan_for(solver, state), solver.iterations), "rls_cgnr_step")
-    iterate(solver, state)   # reads the status first: refreshes the host-side scalars, applies `constr`, returns nothing (done)
+    st = Ref{CgnrStatus}()
+    check(b.ctx, ccall((:rls_cgnr_step_status, librls[]), Int32, (Ptr{Cvoid}, Int32, Ref{CgnrStatus}), plan_for(solver, state), solver.iterations, st), "rls_cgnr_step_status")
+    cgnr_take!(state, st[])
+    iterate(solver, state)   # done: applies `constr`, returns nothing
   elseif solver isa FISTA && get(fista_plans, state, C_NULL) != C_NULL
     check(b.ctx, ccall((:rls_fista_step, librls[]), Int32, (Ptr{Cvoid}, Int32), fista_plans[state], solver.iterations), "rls_fista_step")
     fista_refresh!(state, fista_plans[state])
@@ -329,6 +357,157 @@ function RLSMI355X.solve_fused!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector)
     while iterate(solver, state) !== nothing end
   end
   return solver.state.x
+end
+
+
+# ---- matrix right-hand sides: the shared-A scheduler (BASELINE configs[3]; src/MultiThreading.jl:30-79) -------------------
+# `solve!(solver, B; scheduler = RLSMI355X.BatchedState)` with B an RLSMatrix (RLSMI355X.rhs(b)): the K columns advance
+# TOGETHER through one plan (rls_cgnr_create_batched: both products of an iteration as skinny GEMMs on the matrix cores,
+# A streamed once per product for all columns), each column with its own scalars and its own `done` -- the reference's
+# per-column `active` retirement (src/MultiThreading.jl:60-78).  SequentialState / MultiThreadingState keep working on a
+# device matrix through b[:, i], deepcopy(state) and hcat (RLSMI355X.jl): one plan per column.
+mutable struct CgnrBatchedState{S, ST <: AbstractSolverState{S}} <: AbstractMatrixSolverState{S}
+  states::Vector{ST}        # the single-column state this was built from (a later vector solve goes back to it)
+  active::Vector{Bool}
+  X::RLSMatrix; R::RLSMatrix; P::RLSMatrix; V::RLSMatrix    # N x K
+  plan::Ptr{Cvoid}
+  iteration::Int
+end
+"`scheduler = RLSMI355X.BatchedState`: the marker the matrix init! below looks for"
+RLSMI355X.BatchedState(states::Vector) = error("BatchedState is selected with solve!(solver, B::RLSMatrix; scheduler = RLSMI355X.BatchedState)")
+
+function init!(solver::CGNR, state::AbstractSolverState, B::RLSMatrix{Tc}; scheduler = RegularizedLeastSquares.SequentialState, x0 = 0, kwargs...) where {Tc}
+  if scheduler !== RLSMI355X.BatchedState
+    # the reference's own matrix init! (src/MultiThreading.jl:30-38), selected by a signature this method does not match
+    return invoke(init!, Tuple{AbstractLinearSolver,AbstractSolverState,AbstractMatrix}, solver, state, B; scheduler, x0, kwargs...)
+  end
+  all(x0 .== 0) || error("CGNR: x0 != 0 is unsupported (src/CGNR.jl:119)")
+  single = state isa AbstractMatrixSolverState ? first(state.states) : state
+  A = solver.A::RLSMatrix
+  op = something(operator_of(A, solver.AHA), A.op)
+  K, N, ctx = size(B, 2), A.N, A.ctx
+  bs = state isa CgnrBatchedState && size(state.X) == (N, K) ? state : nothing
+  if bs === nothing
+    X, R, P, V = (RLSMatrix{Tc}(undef, N, K; ctx) for _ in 1:4)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, ccall((:rls_cgnr_create_batched, librls[]), Int32,
+                     (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}),
+                     op, K, X.ptr, R.ptr, P.ptr, V.ptr, N, p), "rls_cgnr_create_batched")
+    bs = CgnrBatchedState{typeof(single).parameters[1], typeof(single)}([single], fill(true, K), X, R, P, V, p[], 0)
+    finalizer(s -> ccall((:rls_cgnr_destroy, librls[]), Int32, (Ptr{Cvoid},), s.plan), bs)
+  end
+  check(ctx, ccall((:rls_cgnr_init_batched, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float32, Float32, Int32),
+                   bs.plan, B.ptr, B.lda, Float32(λ(solver.L2)), single.relTol, solver.iterations), "rls_cgnr_init_batched")
+  bs.active .= true
+  bs.iteration = 0
+  solver.state = bs
+  nothing
+end
+
+function iterate(solver::CGNR, state::CgnrBatchedState, activeIdx)
+  K = length(state.active)
+  st = Vector{CgnrStatus}(undef, K)
+  ctx = state.X.ctx
+  if state.iteration == 0   # columns that are done before they start (iterations == 0, a zero right-hand side)
+    check(ctx, ccall((:rls_cgnr_get_status_batched, librls[]), Int32, (Ptr{Cvoid}, Ptr{CgnrStatus}), state.plan, st), "rls_cgnr_get_status_batched")
+    for i in activeIdx
+      st[i].done != 0 && (state.active[i] = false)
+    end
+    any(state.active) || return finish_batched!(solver, state)
+  end
+  check(ctx, ccall((:rls_cgnr_step, librls[]), Int32, (Ptr{Cvoid}, Int32), state.plan, 1), "rls_cgnr_step")
+  check(ctx, ccall((:rls_cgnr_get_status_batched, librls[]), Int32, (Ptr{Cvoid}, Ptr{CgnrStatus}), state.plan, st), "rls_cgnr_get_status_batched")
+  state.iteration += 1
+  for i in activeIdx   # a column retires at the iteration where ITS `done` holds; the device skips it from then on
+    st[i].done != 0 && (state.active[i] = false)
+  end
+  any(state.active) || finish_batched!(solver, state)
+  return state.active, state
+end
+"constraints applied once, at exit, column by column (src/CGNR.jl:145-147)"
+function finish_batched!(solver::CGNR, state::CgnrBatchedState)
+  for r in solver.constr, j in 1:size(state.X, 2)
+    # prox! on a column in place: a non-owning vector over the column's memory (kept alive by `state`)
+    prox!(r, RLSMI355X.column_view(state.X, j))
+  end
+  nothing
+end
+solversolution(state::CgnrBatchedState) = state.X
+iterate(solver::CGNR, state::CgnrBatchedState) = (idx = findall(state.active); isempty(idx) ? nothing : iterate(solver, state, idx))
+
+# ---- a single oversized A, row-partitioned over the GPUs of one node (BASELINE configs[4]) ---------------------------------
+"""
+    RowSharded(comm, solvers)
+
+`solvers[r]`: a CGNR / FISTA / ADMM built on rank r's row shard of A (`RLSMI355X.shard_operator(comm, a)`), all with the same
+parameters.  `solve!(rs, b_parts)` runs the solver with the one distributed step of each operator apply -- the all-reduce of
+the length-N partial product -- inside the library (rls_*_rowsharded: one host worker thread per rank); state vectors and
+scalars are replicated, so any rank's solution is the solution.
+"""
+struct RowSharded{S}
+  comm::Comm
+  solvers::Vector{S}
+end
+
+function RegularizedLeastSquares.solve!(rs::RowSharded{<:CGNR}, b_parts::Vector{<:RLSVector})
+  n = length(rs.comm)
+  length(b_parts) == n == length(rs.solvers) || throw(DimensionMismatch("one solver and one slice of b per rank"))
+  plans = Ptr{Cvoid}[plan_for(s, s.state) for s in rs.solvers]
+  s1 = rs.solvers[1]
+  ctx = rs.comm.ctxs[1]
+  check(ctx, ccall((:rls_cgnr_init_rowsharded, librls[]), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Float32, Float32, Int32),
+                   rs.comm.handle, plans, Ptr{Cvoid}[b.ptr for b in b_parts], Float32(λ(s1.L2)), s1.state.relTol, s1.iterations), "rls_cgnr_init_rowsharded")
+  check(ctx, ccall((:rls_cgnr_step_rowsharded, librls[]), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int32), rs.comm.handle, plans, s1.iterations), "rls_cgnr_step_rowsharded")
+  for s in rs.solvers
+    delete!(cgnr_done, s.state)
+    while iterate(s, s.state) !== nothing end   # status read-back (done at once), constraints at exit
+  end
+  return s1.state.x
+end
+
+function RegularizedLeastSquares.solve!(rs::RowSharded{<:FISTA}, b_parts::Vector{<:RLSVector}; theta = 1)
+  n = length(rs.comm)
+  length(b_parts) == n == length(rs.solvers) || throw(DimensionMismatch("one solver and one slice of b per rank"))
+  s1 = rs.solvers[1]
+  plans = Ptr{Cvoid}[]
+  for s in rs.solvers
+    p = fista_plan_for(s, s.state)
+    p == C_NULL && error("row-sharded FISTA: L1 / L2 / L21 regularisation with at most one projection")
+    kind, slices = fused_reg(s.reg)
+    check(s.state.x.ctx, ccall((:rls_fista_set_reg, librls[]), Int32, (Ptr{Cvoid}, Int32, Float32, Int64, Int32),
+                               p, kind, Float32(λ(s.reg)), slices, fused_proj(s.proj)), "rls_fista_set_reg")
+    push!(plans, p)
+  end
+  ctx = rs.comm.ctxs[1]
+  check(ctx, ccall((:rls_fista_init_rowsharded, librls[]), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Float32, Float32, Float32, Int32, Int32),
+                   rs.comm.handle, plans, Ptr{Cvoid}[b.ptr for b in b_parts], s1.state.ρ, Float32(theta), s1.state.relTol, s1.iterations,
+                   s1.restart == :gradient), "rls_fista_init_rowsharded")
+  check(ctx, ccall((:rls_fista_step_rowsharded, librls[]), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int32), rs.comm.handle, plans, s1.iterations), "rls_fista_step_rowsharded")
+  for (s, p) in zip(rs.solvers, plans)
+    fista_refresh!(s.state, p)
+  end
+  return s1.state.x
+end
+
+"ADMM: every rank's solver has been through the reference's init! with ITS slice of b first (x, z, u, sigma_abs from the length of the whole b)"
+function RegularizedLeastSquares.solve!(rs::RowSharded{<:ADMM}, b_parts::Vector{<:RLSVector}; M_total::Integer)
+  n = length(rs.comm)
+  length(b_parts) == n == length(rs.solvers) || throw(DimensionMismatch("one solver and one slice of b per rank"))
+  for (s, b) in zip(rs.solvers, b_parts)
+    s.state.σᵃᵇˢ = sqrt(eltype(s.state.ρ)(M_total)) * s.state.absTol   # sqrt(length(b)) of the WHOLE b   (src/ADMM.jl:214)
+    init!(s, s.state, b)                                             # x = 0, z = Phi x, u = 0, the device plan's parameters
+    get(admm_plans, s.state, nothing) === nothing && error("row-sharded ADMM: one L1 / L2 / TV term, identity regTrafo, vary_rho = :none")
+  end
+  plans = Ptr{Cvoid}[admm_plans[s.state].plan for s in rs.solvers]
+  ctx = rs.comm.ctxs[1]
+  check(ctx, ccall((:rls_admm_init_rowsharded, librls[]), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), rs.comm.handle, plans,
+                   Ptr{Cvoid}[b.ptr for b in b_parts]), "rls_admm_init_rowsharded")
+  s1 = rs.solvers[1]
+  check(ctx, ccall((:rls_admm_step_rowsharded, librls[]), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int32), rs.comm.handle, plans, s1.iterations), "rls_admm_step_rowsharded")
+  for s in rs.solvers
+    admm_refresh!(s.state, admm_plans[s.state])
+  end
+  return s1.state.x
 end
 
 # ---- setup path: SystemMatrixBasedNormalization (ext/RegularizedLeastSquaresGPUArraysExt/NormalizedRegularization.jl:1-5)

@@ -29,6 +29,8 @@ mutable struct Context
     ctx = new(h[], Int32(device))
     finalizer(c -> ccall((:rls_ctx_destroy, librls[]), Int32, (Ptr{Cvoid},), c.handle), ctx)
   end
+  # a context owned by a communicator (rls_comm_ctx): wrapped, never destroyed from here
+  Context(handle::Ptr{Cvoid}, device::Integer, ::Val{:borrowed}) = new(handle, Int32(device))
 end
 
 function check(ctx::Context, st::Int32, what)
@@ -56,6 +58,8 @@ mutable struct RLSVector{T} <: AbstractVector{T}
     v = new{T}(p[], n, ctx)
     finalizer(x -> ccall((:rls_free, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, x.ptr), v)
   end
+  # a NON-owning vector over memory that something else owns and keeps alive (a column of a device matrix)
+  RLSVector{T}(ptr::Ptr{Cvoid}, n::Integer, ctx::Context, ::Val{:view}) where {T} = new{T}(ptr, n, ctx)
 end
 Base.size(v::RLSVector) = (v.n,)
 Base.similar(v::RLSVector{T}, ::Type{S}, dims::Dims{1}) where {T,S} = RLSVector{S}(undef, dims[1]; ctx = v.ctx)
@@ -121,6 +125,14 @@ function axpby!(a::Number, x::RLSVector{T}, b::Number, y::RLSVector{T}) where {T
 end
 Base.zero(v::RLSVector{T}) where {T} = fill!(similar(v), zero(T))          # CGStateVariables(zero(x), ...) src/ADMM.jl:129
 Base.copy(v::RLSVector{T}) where {T} = copyto!(similar(v), v)
+# prepareMatrixStates deep-copies the solver state once per column of B (src/MultiThreading.jl:43-46): a field-wise copy
+# of the struct would alias the device memory of every column, so a deep copy is a new device vector with the same content
+function Base.deepcopy_internal(v::RLSVector{T}, dict::IdDict) where {T}
+  haskey(dict, v) && return dict[v]
+  w = copyto!(similar(v), v)
+  dict[v] = w
+  w
+end
 Base.dotview(v::RLSVector, ::Colon) = v                                     # state.res[:] .= Inf     src/FISTA.jl:123
 
 # ---- broadcasting -----------------------------------------------------------------------------------
@@ -215,9 +227,63 @@ mutable struct RLSMatrix{T} <: AbstractMatrix{T}
   N::Int
   lda::Int
   ctx::Context
-  op::Ptr{Cvoid}      # rls_operator handle
+  op::Ptr{Cvoid}      # rls_operator handle (C_NULL for plain data matrices: right-hand sides, solutions)
 end
 Base.size(A::RLSMatrix) = (A.M, A.N)
+Base.getindex(::RLSMatrix, ::Int, ::Int) = error("scalar indexing of a device matrix is disabled; use Array(A)")
+
+"an M x N device matrix without an operator handle: the type of a matrix right-hand side B and of a matrix of solutions"
+function RLSMatrix{T}(::UndefInitializer, M::Integer, N::Integer; ctx = context()) where {T}
+  dtypecode(T)
+  p = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ctx, ccall((:rls_malloc, librls[]), Int32, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, max(M * N, 1) * sizeof(T), p), "rls_malloc")
+  A = RLSMatrix{T}(p[], M, N, M, ctx, C_NULL)
+  finalizer(x -> ccall((:rls_free, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, x.ptr), A)
+end
+"upload a host matrix as plain data (no operator): `solve!(solver, rhs(B))` for a matrix of right-hand sides"
+function rhs(b::Matrix{T}; ctx = context()) where {T}
+  B = RLSMatrix{T}(undef, size(b, 1), size(b, 2); ctx)
+  check(ctx, ccall((:rls_memcpy_h2d, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{T}, Csize_t), ctx.handle, B.ptr, b, sizeof(b)), "rls_memcpy_h2d")
+  B
+end
+function Base.Array(A::RLSMatrix{T}) where {T}
+  A.lda == A.M || error("Array(::RLSMatrix) needs a contiguous matrix")
+  a = Matrix{T}(undef, A.M, A.N)
+  check(A.ctx, ccall((:rls_memcpy_d2h, librls[]), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{Cvoid}, Csize_t), A.ctx.handle, a, A.ptr, sizeof(a)), "rls_memcpy_d2h")
+  a
+end
+"device pointer of column j (1-based)"
+colptr(A::RLSMatrix{T}, j::Integer) where {T} = A.ptr + (j - 1) * A.lda * sizeof(T)
+# b[:, i] (src/MultiThreading.jl:35): indexing copies in Julia, so this is a new device vector holding column i
+function Base.getindex(B::RLSMatrix{T}, ::Colon, j::Integer) where {T}
+  1 <= j <= B.N || throw(BoundsError(B, (:, j)))
+  v = RLSVector{T}(undef, B.M; ctx = B.ctx)
+  check(B.ctx, ccall((:rls_memcpy_d2d, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), B.ctx.handle, v.ptr, colptr(B, j), B.M * sizeof(T)), "rls_memcpy_d2d")
+  v
+end
+# hcat of the columns' solutions (src/MultiThreading.jl:79: mapreduce(solversolution, hcat, states) folds pairwise)
+ncols(v::RLSVector) = 1
+ncols(A::RLSMatrix) = A.N
+nrows(v::RLSVector) = v.n
+nrows(A::RLSMatrix) = A.M
+function Base.hcat(xs::Union{RLSVector{T},RLSMatrix{T}}...) where {T}
+  M = nrows(xs[1])
+  all(x -> nrows(x) == M, xs) || throw(DimensionMismatch("hcat of device arrays with different numbers of rows"))
+  ctx = xs[1].ctx
+  out = RLSMatrix{T}(undef, M, sum(ncols, xs); ctx)
+  j = 1
+  for x in xs
+    if x isa RLSMatrix && x.lda != x.M
+      for c in 1:x.N   # padded leading dimension: column by column
+        check(ctx, ccall((:rls_memcpy_d2d, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), ctx.handle, colptr(out, j + c - 1), colptr(x, c), M * sizeof(T)), "rls_memcpy_d2d")
+      end
+    else
+      check(ctx, ccall((:rls_memcpy_d2d, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), ctx.handle, colptr(out, j), x.ptr, M * ncols(x) * sizeof(T)), "rls_memcpy_d2d")
+    end
+    j += ncols(x)
+  end
+  out
+end
 function RLSMatrix(a::Matrix{T}; ctx = context()) where {T}
   p = Ref{Ptr{Cvoid}}(C_NULL)
   check(ctx, ccall((:rls_malloc, librls[]), Int32, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, sizeof(a), p), "rls_malloc")
@@ -231,6 +297,8 @@ function RLSMatrix(a::Matrix{T}; ctx = context()) where {T}
     ccall((:rls_free, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, x.ptr)
   end
 end
+"the operator constructor on a context other than the default one (row shards: one context per GPU)"
+RLSMatrix(a::Matrix, ctx::Context) = RLSMatrix(a; ctx)
 
 "5-arg mul!: y = alpha * op(A) * x + beta * y"
 function gemv!(op::Int32, A::RLSMatrix{T}, x::RLSVector{T}, y::RLSVector{T}, alpha::Number, beta::Number) where {T}
@@ -285,5 +353,58 @@ end
 
 "whole solve in one enqueue; methods are added by the RegularizedLeastSquares extension"
 function solve_fused! end
+"`scheduler = RLSMI355X.BatchedState` for `solve!(solver, B::RLSMatrix)`: the columns share every pass over A (matrix cores); defined by the extension"
+function BatchedState end
+
+"a NON-owning device vector over column j of a device matrix (the matrix must outlive it)"
+column_view(A::RLSMatrix{T}, j::Integer) where {T} = RLSVector{T}(colptr(A, j), A.M, A.ctx, Val(:view))
+
+# ---- single-process multi-GPU: the library's communicator (include/rls_mi355x.h, rls_comm_*) ------------------------
+# One Julia process drives every GPU of the node (BASELINE config 5: one tall A row-partitioned, one all-reduce of the
+# length-N partial product per operator apply).  The fan-out over the ranks happens INSIDE the library (one host worker
+# thread per rank, the Threads.@threads of src/MultiThreading.jl:60-78), so these calls are made from one task.
+const RLS_COMM_AUTO = Int32(0); const RLS_COMM_RCCL = Int32(1); const RLS_COMM_DIRECT = Int32(2)
+
+mutable struct Comm
+  handle::Ptr{Cvoid}
+  ctxs::Vector{Context}
+  function Comm(devices::AbstractVector{<:Integer}; transport::Integer = RLS_COMM_AUTO, threads::Bool = true)
+    devs = collect(Int32, devices)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = ccall((:rls_comm_create, librls[]), Int32, (Int32, Ptr{Int32}, Ptr{Ptr{Cvoid}}, Int32, Ref{Ptr{Cvoid}}), length(devs), devs, C_NULL, transport, h)
+    st == 0 || throw(RLSError(st, "rls_comm_create failed (RCCL needs one distinct device per rank; the direct transport needs peer access)"))
+    ctxs = Context[]
+    for r in 0:length(devs)-1
+      c = Ref{Ptr{Cvoid}}(C_NULL)
+      ccall((:rls_comm_ctx, librls[]), Int32, (Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), h[], r, c) == 0 || throw(RLSError(Int32(-1), "rls_comm_ctx"))
+      push!(ctxs, Context(c[], devs[r+1], Val(:borrowed)))
+    end
+    ccall((:rls_comm_set_threads, librls[]), Int32, (Ptr{Cvoid}, Int32), h[], threads ? 1 : 0)
+    comm = new(h[], ctxs)
+    finalizer(c -> ccall((:rls_comm_destroy, librls[]), Int32, (Ptr{Cvoid},), c.handle), comm)
+  end
+end
+Base.length(c::Comm) = Int(ccall((:rls_comm_size, librls[]), Int32, (Ptr{Cvoid},), c.handle))
+transport(c::Comm) = ccall((:rls_comm_transport, librls[]), Int32, (Ptr{Cvoid},), c.handle)
+synchronize(c::Comm) = check(c.ctxs[1], ccall((:rls_comm_sync, librls[]), Int32, (Ptr{Cvoid},), c.handle), "rls_comm_sync")
+
+"in place: every rank's vector becomes the sum over the ranks (asynchronous, on the ranks' streams)"
+function allreduce_sum!(c::Comm, vs::Vector{RLSVector{T}}) where {T}
+  length(vs) == length(c) || throw(DimensionMismatch("one vector per rank"))
+  ptrs = Ptr{Cvoid}[v.ptr for v in vs]
+  check(c.ctxs[1], ccall((:rls_allreduce_sum, librls[]), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int64, Int32), c.handle, ptrs, length(vs[1]), dtypecode(T)), "rls_allreduce_sum")
+  vs
+end
+
+"row blocks [lo, hi] (1-based, multiples of 4 rows) of an M-row matrix for `n` ranks"
+function shard_rows(M::Integer, n::Integer, r::Integer)
+  lo = (M * (r - 1) ÷ n) ÷ 4 * 4
+  hi = r == n ? M : (M * r ÷ n) ÷ 4 * 4
+  (lo + 1, hi)
+end
+
+"upload the row shards of a host matrix, one operator per rank's context"
+shard_operator(c::Comm, a::Matrix{T}) where {T} =
+  [RLSMatrix(a[first(shard_rows(size(a, 1), length(c), r)):last(shard_rows(size(a, 1), length(c), r)), :], c.ctxs[r]) for r in 1:length(c)]
 
 end # module

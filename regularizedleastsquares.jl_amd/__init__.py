@@ -27,5 +27,5 @@ from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA,
                       iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,
                       solverstate)
 from . import multigpu  # noqa: F401,E402
-from .multigpu import (CommRowShardedCGNR, ConcurrentSolves, MultiSolve, RowShardedADMM, RowShardedCGNR, RowShardedFISTA,  # noqa: F401,E402
+from .multigpu import (CommRowShardedADMM, CommRowShardedCGNR, CommRowShardedFISTA, ConcurrentSolves, MultiSolve, RowShardedADMM, RowShardedCGNR, RowShardedFISTA,  # noqa: F401,E402
                        shard_columns, shard_rows)

@@ -185,6 +185,7 @@ PROTOTYPES = {
     "rls_cgnr_init_rowsharded": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_float, C.c_float, _i32]),
     "rls_cgnr_step_rowsharded": (_i32, [_vp, C.POINTER(_vp), _i32]),
     "rls_comm_set_threads": (_i32, [_vp, _i32]),
+    "rls_comm_debug_busy_seconds": (_i32, [_vp, C.POINTER(C.c_double)]),
     "rls_fista_init_rowsharded": (_i32, [_vp, _pvp, _pvp, _f, _f, _f, _i32, _i32]),
     "rls_fista_step_rowsharded": (_i32, [_vp, _pvp, _i32]),
     "rls_admm_init_rowsharded": (_i32, [_vp, _pvp, _pvp]),

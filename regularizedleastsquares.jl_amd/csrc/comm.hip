@@ -81,6 +81,7 @@ struct comm_pool {
   std::atomic<unsigned> sense{0};
   std::atomic<int> finished{0};
   std::atomic<int32_t> status{0};
+  double busy_s[16] = {0};  // per rank: wall clock spent INSIDE phase bodies (enqueueing), barriers and idling excluded
 };
 
 struct rls_comm {
@@ -218,7 +219,9 @@ static void pool_worker(rls_comm* c, int r) {
     for (int k = 0; k < P->reps; ++k) {
       for (size_t i = 0; i < ph.size(); ++i) {
         if (P->status.load(std::memory_order_relaxed) == 0) {  // after a failure the ranks only keep each other company
+          const auto t0 = std::chrono::steady_clock::now();
           const int32_t st = ph[i].run(r, k);
+          P->busy_s[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           if (st != 0) {
             int32_t zero = 0;
             P->status.compare_exchange_strong(zero, st);
@@ -312,6 +315,17 @@ int32_t rls_comm_next_rounds(rls_comm* c, int count, int64_t n, int32_t dtype, i
 }
 
 extern "C" {
+
+// measurement (tools/host_overhead_rowsharded.py): seconds each rank's worker has spent enqueueing since the last call
+// (out[nranks]); what the host side of the row-sharded loops would cost on a node where every rank has its own GPU
+int32_t rls_comm_debug_busy_seconds(rls_comm* c, double* out) {
+  if (!c || !out) return RLS_E_INVALID;
+  for (int r = 0; r < c->n; ++r) {
+    out[r] = c->pool ? c->pool->busy_s[r] : 0.0;
+    if (c->pool) c->pool->busy_s[r] = 0.0;
+  }
+  return 0;
+}
 
 int32_t rls_comm_set_threads(rls_comm* c, int32_t on) {
   if (!c) return RLS_E_INVALID;

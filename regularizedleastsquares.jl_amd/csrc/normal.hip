@@ -1684,7 +1684,7 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
 }
 
 template <typename E, int G, int K, int WV, int BAR, bool FULL>
-__global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* r, E* p,
+__global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* xw, E* r, E* p,
                                                                  E* v, E* slab, double* dout, cgnr_scalars* sc,
                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair,
                                                                  int n_steps, unsigned spin_limit, rls_cg_start St) {
@@ -1799,6 +1799,34 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     S.done = (St.maxiter <= 0) || (rr == 0.0) || (1.0f <= St.reltol);
     if (S.done) n_steps = 0;  // uniform
   }
+  // x is not part of the recurrence (only x += alpha p touches it) and only workgroup 0 writes it back: it lives in plan
+  // scratch `xw` between iterations -- read behind the products, advanced by workgroup 0 -- instead of in 8 registers that
+  // would be live across the products (the kernel sat at 256 VGPRs and spilled without this).  The caller's x is written
+  // once, at the end, so a launch that gives up still leaves it untouched.
+  auto store_owned = [&](E* dst, const E (&src)[EPT]) {
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      chunk<E, NV> c;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) c.e[j] = src[q * NV + j];
+      const int64_t o = (int64_t)q * (NT * NV) + (int64_t)tid * NV;
+      if (FULL || o < N) *reinterpret_cast<f4*>(dst + o) = __builtin_bit_cast(f4, c);
+    }
+  };
+  // read back with L1-bypassing loads: the thread re-reads what IT stored an iteration earlier (drained long since), and an
+  // L1 line of this CU must not stand in for it
+  const __amdgpu_buffer_rsrc_t xw_rs = sc1_rsrc(xw);
+  auto load_owned_sc1 = [&](E (&dst)[EPT], const E*) {
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      const int o = q * NT * NV + tid * NV;
+      const bool ok = FULL || o < N;
+      const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(xw_rs, (uint32_t)((ok ? o : 0) * sizeof(E))));
+#pragma unroll
+      for (int j = 0; j < NV; ++j) dst[q * NV + j] = ok ? c.e[j] : elem<E>::zero();
+    }
+  };
+  if (blockIdx.x == 0) store_owned(xw, xv);
   for (int it = 0; it < n_steps; ++it) {
     STAMP(8);
 #pragma unroll
@@ -1809,6 +1837,8 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
     STAMP(10);
+    E xq[EPT];  // x, requested here and consumed behind the exchange (every workgroup: no branch around a load)
+    load_owned_sc1(xq, xw);
     // ---- v = the sum of the partial rows, in every workgroup; <p, v> and ||p||^2 ---------------------------------------
     E vv[EPT];
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
@@ -1840,6 +1870,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
       alive = false;
       break;
     }
+    // p of this iteration, back from its LDS copy (L.xs, staged for the products and untouched since): it need not occupy
+    // registers across the products and the exchange
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) pv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
     if constexpr (BAR == 1) {  // the 256 partial dots, one per thread; cg_update_elems sums them over the workgroup
       const int dt = tid < nwg ? tid : 0;
       const f4 lo = sc1_load16(d_rs, (uint32_t)dt * 32u), hi = sc1_load16(d_rs, (uint32_t)dt * 32u + 16u);
@@ -1866,11 +1900,22 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     const bool done = cg_update_elems<E, EPT, NT, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      xv[e] = elem<E>::fma(pv[e], al, xv[e]);
+      xq[e] = elem<E>::fma(pv[e], al, xq[e]);
       rv[e] = rn[e];
       pv[e] = pn[e];
     }
+    if (blockIdx.x == 0) {  // buffer stores: the 32-bit offsets of the loads above, no 64-bit address pairs kept across the loop
+#pragma unroll
+      for (int q = 0; q < EPT / NV; ++q) {
+        chunk<E, NV> c;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) c.e[j] = xq[q * NV + j];
+        const int o = q * NT * NV + tid * NV;
+        if (FULL || o < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, c), xw_rs, (uint32_t)(o * sizeof(E)), 0, 0);
+      }
+    }
     S = Sn;
+    RLS_CGNR_UNIFORM(S);
     STAMP(15);
     if (done) break;  // uniform: every workgroup derived the same scalars
   }
@@ -1879,22 +1924,23 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     return;  // x, r, p and the scalars are untouched: the call was a no-op
   }
   if (blockIdx.x == 0) {
+    E xf[EPT];
+    load_owned_sc1(xf, xw);
+    // buffer stores (a descriptor in SGPRs + a 32-bit lane offset): nothing per-lane has to survive the loop for them
+    auto store_buf = [&](E* dst, const E (&src)[EPT]) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0xffffffff, 0x00020000);
 #pragma unroll
-    for (int q = 0; q < EPT / NV; ++q) {
-      chunk<E, NV> cx, cr, cp;
+      for (int q = 0; q < EPT / NV; ++q) {
+        chunk<E, NV> c;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        cx.e[j] = xv[q * NV + j];
-        cr.e[j] = rv[q * NV + j];
-        cp.e[j] = pv[q * NV + j];
+        for (int j = 0; j < NV; ++j) c.e[j] = src[q * NV + j];
+        const int o = q * NT * NV + tid * NV;
+        if (FULL || o < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, c), rs, (uint32_t)(o * sizeof(E)), 0, 0);
       }
-      const int64_t o = (int64_t)q * (NT * NV) + (int64_t)tid * NV;
-      if (FULL || o < N) {
-        *reinterpret_cast<f4*>(x + o) = __builtin_bit_cast(f4, cx);
-        *reinterpret_cast<f4*>(r + o) = __builtin_bit_cast(f4, cr);
-        *reinterpret_cast<f4*>(p + o) = __builtin_bit_cast(f4, cp);
-      }
-    }
+    };
+    store_buf(x, xf);
+    store_buf(r, rv);
+    store_buf(p, pv);
     if (tid == 0) {
       S.pending = 0;
       S.cur = 0;
@@ -2154,19 +2200,18 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   const int nwg = gridDim.x;
   fista_scalars S;
   RLS_FISTA_COPY(S, *sc);
-  E yv[EPT], xk[EPT], xp[EPT], x0v[EPT], ri[EPT];
+  // Loop-carried in registers: y, x, xold (the recurrence).  NOT carried: x0 = A^H b (read-only: re-read every iteration
+  // behind the products, so that it is not live while the slab's 128 registers and the product's temporaries are) and res
+  // (output only: workgroup 0 stores it every iteration) -- 16 registers less across the products, no spill.
+  E yv[EPT], xk[EPT], xp[EPT];
   if constexpr (FULL) {
     load_owned_wide<E, EPT, NT>(yv, S.ycur ? y1 : y0, tid);
     load_owned_wide<E, EPT, NT>(xk, (S.iteration & 1) ? b1 : b0, tid);  // state.x == buf[iteration & 1]
     load_owned_wide<E, EPT, NT>(xp, (S.iteration & 1) ? b0 : b1, tid);
-    load_owned_wide<E, EPT, NT>(x0v, x0, tid);
-    load_owned_wide<E, EPT, NT>(ri, res, tid);
   } else {
     load_owned_wide_masked<E, EPT, NT>(yv, S.ycur ? y1 : y0, tid, N);
     load_owned_wide_masked<E, EPT, NT>(xk, (S.iteration & 1) ? b1 : b0, tid, N);
     load_owned_wide_masked<E, EPT, NT>(xp, (S.iteration & 1) ? b0 : b1, tid, N);
-    load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
-    load_owned_wide_masked<E, EPT, NT>(ri, res, tid, N);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -2184,14 +2229,31 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    E x0v[EPT];  // requested here, consumed behind the exchange
+    if constexpr (FULL) load_owned_wide<E, EPT, NT>(x0v, x0, tid);
+    else load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
     E raw[EPT];
     if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
       alive = false;
       break;
     }
-    E xn[EPT], yn[EPT];
+    // y of this iteration, back from its LDS copy (L.xs): not carried in registers across the products and the exchange
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) yv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
+    E xn[EPT], yn[EPT], ri[EPT];
     fista_scalars Sn;
     const bool done = fista_update_elems<E, EPT, NT, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    if (blockIdx.x == 0) {  // state.res of this iteration (nothing reads it back: a launch that gives up later loses nothing)
+      const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(res, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < EPT / NV; ++q) {
+        chunk<E, NV> c3;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) c3.e[j] = ri[q * NV + j];
+        const int o = q * NT * NV + tid * NV;
+        if (FULL || o < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, c3), res_rs, (uint32_t)(o * sizeof(E)), 0, 0);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       xp[e] = xk[e];
@@ -2200,6 +2262,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     }
     if (!done) ycur ^= 1;
     RLS_FISTA_COPY(S, Sn);
+    RLS_FISTA_UNIFORM(S);
     if (done) break;  // uniform
   }
   if (!alive) {
@@ -2212,20 +2275,18 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     E* yw = ycur ? y1 : y0;
 #pragma unroll
     for (int q = 0; q < EPT / NV; ++q) {
-      chunk<E, NV> c0, c1, c2, c3;
+      chunk<E, NV> c0, c1, c2;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         c0.e[j] = xk[q * NV + j];
         c1.e[j] = xp[q * NV + j];
         c2.e[j] = yv[q * NV + j];
-        c3.e[j] = ri[q * NV + j];
       }
       const int64_t o = (int64_t)q * (NT * NV) + (int64_t)tid * NV;
       if (FULL || o < N) {
         *reinterpret_cast<f4*>(xw + o) = __builtin_bit_cast(f4, c0);
         *reinterpret_cast<f4*>(xo + o) = __builtin_bit_cast(f4, c1);
         *reinterpret_cast<f4*>(yw + o) = __builtin_bit_cast(f4, c2);
-        *reinterpret_cast<f4*>(res + o) = __builtin_bit_cast(f4, c3);
       }
     }
     if (tid == 0) {
@@ -2361,8 +2422,10 @@ static int g_order_mode = 1;  // 0: wait for the small loads, 1: barrier only (r
 static int g_resident_barrier = 2;  // matrix-free resident kernels' exchange: 2 = two-level where the grid allows (default), 1 = flat
 static int g_red_threads = 1024;  // reduce kernel: 16 columns x 64 row groups per workgroup (-1.0 us vs 256)
 
-// candidate slab shapes, smallest column capacity first; NMAX = K * WV * (64 / G)
-static const fused_cfg kCfgs[] = {{8, 8, 8}, {8, 16, 8}, {8, 32, 8}, {4, 32, 8}, {8, 16, 16}, {4, 16, 16}};
+// candidate slab shapes, smallest column capacity first; NMAX = K * WV * (64 / G).  (Rounds 1-2 also instantiated 16-wave
+// workgroups -- {8, 16, 16}, {4, 16, 16} -- for the measurement switch "slab_wv": at 128 VGPRs per lane every one of them
+// spilled, none was ever selected by this table's default, and they were a quarter of the library's code: removed.)
+static const fused_cfg kCfgs[] = {{8, 8, 8}, {8, 16, 8}, {8, 32, 8}, {4, 32, 8}};
 
 template <typename E>
 static bool pick_cfg(int64_t N, fused_cfg* c) {
@@ -2444,8 +2507,6 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   if (attr_once.first(ctx->device)) {
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, false>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, false>, lds);
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, true, false>, lds);
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, true, false>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, true>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, true>, lds);
   }
@@ -2458,16 +2519,18 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV, HINTV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, \
                      (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, (E*)P.slab,   \
                      P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, rhs_of(P, nwg))
+  // (a BATCHED = true instantiation -- the slab kernel looping over several right-hand sides on the VALU -- existed until
+  //  round 3 as the fallback of the matrix-core batched path; it spilled up to 528 bytes per lane and was four times slower
+  //  per solve-iteration than the skinny kernels: shapes those do not cover now run one plan per column)
+  (void)batched;
   if (full && hinted) RLS_LAUNCH_A(true, false, true);
   else if (hinted) RLS_LAUNCH_A(false, false, true);
-  else if (full && !batched) RLS_LAUNCH_A(true, false, false);
-  else if (!full && !batched) RLS_LAUNCH_A(false, false, false);
-  else if (full) RLS_LAUNCH_A(true, true, false);
-  else RLS_LAUNCH_A(false, true, false);
+  else if (full) RLS_LAUNCH_A(true, false, false);
+  else RLS_LAUNCH_A(false, false, false);
 #undef RLS_LAUNCH_A
 }
 
-#define RLS_FOR_EACH_CFG(X) X(8, 8, 8) X(8, 16, 8) X(8, 32, 8) X(4, 32, 8) X(8, 16, 16) X(4, 16, 16)
+#define RLS_FOR_EACH_CFG(X) X(8, 8, 8) X(8, 16, 8) X(8, 32, 8) X(4, 32, 8)
 
 static int32_t launch_status(rls_ctx* ctx) {
   hipError_t e = hipGetLastError();
@@ -2702,7 +2765,7 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
       }
 #define RLS_LAUNCH_RES(BB, FF)                                                                                          \
   hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
-                     P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N,  \
+                     P.lda, (E*)P.x, (E*)P.r1, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N,  \
                      pair, n_steps, spin_limit, St)
     if (resident_two_level_ok<E>(nwg, P.N, C::NT)) {
       if (full) RLS_LAUNCH_RES(2, true);

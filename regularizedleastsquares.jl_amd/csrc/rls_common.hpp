@@ -465,6 +465,48 @@ struct fista_scalars {
     (dst).fresh = (src).fresh;          \
   } while (0)
 
+// Wave-uniform scalars into SGPRs.  The solver scalars that a resident kernel carries from one iteration to the next come
+// out of block reductions (LDS reads: VGPRs), and the compiler does not know they are uniform: left alone they sit in ~20
+// vector registers per lane for the whole loop, beside a 128-register slab.  One v_readfirstlane per dword per iteration
+// moves them to the scalar file.
+#ifdef __HIPCC__
+__device__ static inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ static inline float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ static inline double uni(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ static inline long long uni(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (long long)lo;
+}
+#define RLS_CGNR_UNIFORM(S)                                                       \
+  do {                                                                            \
+    (S).rr = uni((S).rr); (S).z0 = uni((S).z0); (S).zeta = uni((S).zeta);         \
+    (S).alpha_re = uni((S).alpha_re); (S).alpha_im = uni((S).alpha_im);           \
+    (S).beta_re = uni((S).beta_re); (S).beta_im = uni((S).beta_im);               \
+    (S).lambda = uni((S).lambda); (S).rel_tol = uni((S).rel_tol);                 \
+    (S).iteration = uni((S).iteration); (S).max_iter = uni((S).max_iter);         \
+    (S).done = uni((S).done); (S).pending = uni((S).pending);                     \
+    (S).cur = uni((S).cur); (S).fresh = uni((S).fresh);                           \
+  } while (0)
+#define RLS_FISTA_UNIFORM(S)                                                      \
+  do {                                                                            \
+    (S).norm_x0 = uni((S).norm_x0); (S).res_norm = uni((S).res_norm);             \
+    (S).rel_res_norm = uni((S).rel_res_norm); (S).rho = uni((S).rho);             \
+    (S).theta = uni((S).theta); (S).theta_old = uni((S).theta_old);               \
+    (S).rel_tol = uni((S).rel_tol); (S).lambda = uni((S).lambda);                 \
+    (S).iteration = uni((S).iteration); (S).max_iter = uni((S).max_iter);         \
+    (S).done = uni((S).done); (S).restart = uni((S).restart);                     \
+    (S).reg_kind = uni((S).reg_kind); (S).proj_kind = uni((S).proj_kind);         \
+    (S).l21_slices = uni((S).l21_slices); (S).pending = uni((S).pending);         \
+    (S).ycur = uni((S).ycur); (S).fresh = uni((S).fresh);                         \
+  } while (0)
+#endif
+
 // everything the FISTA pipeline kernels need (normal.hip)
 struct rls_fista_pipe {
   const void* A;

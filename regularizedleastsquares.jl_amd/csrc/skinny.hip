@@ -780,8 +780,10 @@ static void launch_u(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_
     launch_u_ept<E, INIT, 4, 512>(ctx, K, lambda, rel_tol, max_iter);
   else if (K.N <= 8 * 512)
     launch_u_ept<E, INIT, 8, 512>(ctx, K, lambda, rel_tol, max_iter);
-  else
+  else if constexpr (!elem<E>::cplx)
     launch_u_ept<E, INIT, 8, 1024>(ctx, K, lambda, rel_tol, max_iter);
+  else  // complex columns of more than 4096 elements: 8 per thread at 1024 threads (128 VGPRs) spilled 148 bytes per lane
+    launch_u_ept<E, INIT, 0, 1024>(ctx, K, lambda, rel_tol, max_iter);
 }
 
 template <typename E>

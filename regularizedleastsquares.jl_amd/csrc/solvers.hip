@@ -1868,8 +1868,9 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     return rls_fail(ctx, RLS_E_INVALID, "cgnr_create: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   const bool skinny = nrhs > 1 && !op->G && ctx->tune.batched_mfma && rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda);
-  if (nrhs > 1 && !skinny && !(op->slab && !op->G))
-    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR needs 16-aligned M, N (matrix-core path) or the one-pass register-slab operator");
+  if (nrhs > 1 && !skinny)
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR runs on the matrix cores: a matrix-free operator with M, N multiples of 16 "
+                                            "(other shapes: one plan per column)");
   rls_cgnr* s = new rls_cgnr();
   s->skinny = skinny;
   s->gram_pipe = false;

@@ -28,7 +28,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, CgnrStatus, CgStatus,
+from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, AdmmStatus, CgnrStatus, CgStatus,
                    FistaStatus, check)
 from .arrays import Context
 
@@ -338,6 +338,189 @@ class CommRowShardedCGNR:
             self.comm = None
             for c in self.ctxs:
                 c.close()
+
+
+class _CommHost:
+    """shared plumbing of the single-process row-sharded hosts: the communicator, one borrowed context, one shard operator
+    and a set of named device vectors per rank"""
+
+    def __init__(self, rls, shards, names, devices=None, transport=COMM_AUTO, threads=True):
+        self.rls = rls
+        lib = rls.load()
+        n = len(shards)
+        devices = list(devices) if devices is not None else [0] * n
+        devs = (C.c_int32 * n)(*devices)
+        comm = C.c_void_p()
+        st = lib.rls_comm_create(n, devs, None, int(transport), C.byref(comm))
+        if st != 0:
+            raise rls.RLSError(f"rls_comm_create failed with status {st}")
+        self.lib, self.comm, self.n = lib, comm, n
+        check(None, lib.rls_comm_set_threads(comm, 1 if threads else 0), "rls_comm_set_threads")
+        self.ctxs, self.A, self.ops, self.v = [], [], [], []
+        for r in range(n):
+            h = C.c_void_p()
+            check(None, lib.rls_comm_ctx(comm, r, C.byref(h)), "rls_comm_ctx")
+            ctx = _BorrowedContext(lib, h, devices[r])
+            Ar = rls.DeviceMatrix.from_host(np.asfortranarray(shards[r]), ctx)
+            self.ctxs.append(ctx)
+            self.A.append(Ar)
+            self.ops.append(rls.OperatorHandle(Ar))
+            self.v.append({k: rls.DeviceVector(Ar.N, Ar.dtype, ctx) for k in names})
+        self.plans = []
+        self._b = None
+
+    @property
+    def transport(self):
+        return self.lib.rls_comm_transport(self.comm)
+
+    def _upload_b(self, b_parts):
+        self._b = [self.rls.DeviceVector.from_host(np.ascontiguousarray(bp), c) for bp, c in zip(b_parts, self.ctxs)]
+        return (C.c_void_p * self.n)(*[b.ptr for b in self._b])
+
+    def sync(self):
+        check(self.ctxs[0].handle, self.lib.rls_comm_sync(self.comm), "rls_comm_sync")
+
+    def _destroy_plans(self):
+        raise NotImplementedError
+
+    def close(self):
+        if self.comm:
+            self.sync()
+            self._destroy_plans()
+            self.plans, self._b, self.v, self.ops, self.A = [], None, [], [], []
+            self.lib.rls_comm_destroy(self.comm)
+            self.comm = None
+            for c in self.ctxs:
+                c.close()
+
+
+class CommRowShardedFISTA(_CommHost):
+    """FISTA on a row-partitioned A from ONE host process through the library (rls_fista_init_rowsharded /
+    rls_fista_step_rowsharded): what the Julia host issues for SURVEY 8e's last row (src/FISTA.jl:114,152)."""
+
+    def __init__(self, rls, shards, reg=None, proj=None, devices=None, transport=COMM_AUTO, rho=1.0, theta=1.0, iterations=50,
+                 relTol=float(np.finfo(np.float32).eps), restart="none", threads=True):
+        super().__init__(rls, shards, ("x", "x0", "xold", "res"), devices, transport, threads)
+        self.rho, self.theta, self.iterations, self.relTol, self.restart = float(rho), float(theta), int(iterations), float(relTol), restart
+        kind, lam, slices, pk = _reg_codes(rls, reg, proj)  # proj: one projection term or None
+        for r in range(self.n):
+            v, h = self.v[r], self.ctxs[r].handle
+            plan = C.c_void_p()
+            check(h, self.lib.rls_fista_create(self.ops[r].handle, v["x"].ptr, v["x0"].ptr, v["xold"].ptr, v["res"].ptr, C.byref(plan)),
+                  "rls_fista_create")
+            check(h, self.lib.rls_fista_set_reg(plan, kind, lam, slices, pk), "rls_fista_set_reg")
+            self.plans.append(plan)
+        self._plans_c = (C.c_void_p * self.n)(*[p.value for p in self.plans])
+
+    def init(self, b_parts):
+        ptrs = self._upload_b(b_parts)
+        check(self.ctxs[0].handle, self.lib.rls_fista_init_rowsharded(self.comm, self._plans_c, ptrs, self.rho, self.theta, self.relTol,
+                                                                      self.iterations, int(self.restart == "gradient")),
+              "rls_fista_init_rowsharded")
+
+    def step(self, n=1):
+        check(self.ctxs[0].handle, self.lib.rls_fista_step_rowsharded(self.comm, self._plans_c, int(n)), "rls_fista_step_rowsharded")
+
+    def status(self, rank=0):
+        st = FistaStatus()
+        check(self.ctxs[rank].handle, self.lib.rls_fista_get_status(self.plans[rank], C.byref(st)), "rls_fista_get_status")
+        return {"iteration": st.iteration, "done": bool(st.done), "rel_res_norm": st.rel_res_norm, "residual": st.residual}
+
+    def solution(self, rank=0) -> np.ndarray:
+        self.sync()
+        p = C.c_void_p()
+        check(self.ctxs[rank].handle, self.lib.rls_fista_solution(self.plans[rank], C.byref(p)), "rls_fista_solution")
+        for k in ("x", "xold"):  # the plan swaps x / xold by pointer (src/FISTA.jl:144-146)
+            if self.v[rank][k].ptr == p.value:
+                return self.v[rank][k].to_host()
+        raise RuntimeError("rls_fista_solution returned a foreign pointer")
+
+    def solve(self, b_parts):
+        self.init(b_parts)
+        self.step(self.iterations)
+        return self.solution()
+
+    def _destroy_plans(self):
+        for p in self.plans:
+            self.lib.rls_fista_destroy(p)
+
+
+class CommRowShardedADMM(_CommHost):
+    """ADMM (one regulariser: L1 / L2 / TV, identity regTrafo, vary_rho = :none) on a row-partitioned A from ONE host
+    process: the single-GPU device plan's kernels replicated per rank, the operator applies of the inner cg! per shard
+    with one all-reduce each (rls_admm_init_rowsharded / rls_admm_step_rowsharded; src/ADMM.jl:198,244)."""
+
+    NAMES = ("x", "xold", "beta", "beta_y", "z0", "z1", "u", "cg_u", "cg_r", "cg_c")
+
+    def __init__(self, rls, shards, reg, M_total, proj=None, devices=None, transport=COMM_AUTO, rho=0.1, iterations=10,
+                 iterationsCG=10, absTol=float(np.finfo(np.float32).eps), relTol=float(np.finfo(np.float32).eps), tolInner=1e-5,
+                 threads=True):
+        super().__init__(rls, shards, self.NAMES, devices, transport, threads)
+        from .solvers import ADMM
+        self.iterations = int(iterations)
+        # the parameter block of the device plan, filled exactly as the single-GPU host fills it
+        host = ADMM(self.A[0], reg=([reg] + list(proj or ())), rho=rho, iterations=iterations, iterationsCG=iterationsCG,
+                    absTol=absTol, relTol=relTol, tolInner=tolInner)
+        self._host = host
+        self.cgs = []
+        f32 = np.float32
+        for r in range(self.n):
+            v, h = self.v[r], self.ctxs[r].handle
+            cg = C.c_void_p()
+            check(h, self.lib.rls_cg_create(self.ops[r].handle, v["cg_u"].ptr, v["cg_r"].ptr, v["cg_c"].ptr, C.byref(cg)), "rls_cg_create")
+            plan = C.c_void_p()
+            check(h, self.lib.rls_admm_create(cg, C.byref(plan)), "rls_admm_create")
+            self.cgs.append(cg)
+            self.plans.append(plan)
+        self._plans_c = (C.c_void_p * self.n)(*[p.value for p in self.plans])
+        self._sigma_abs = f32(np.sqrt(f32(M_total))) * f32(absTol)   # sqrt(length(b)) of the WHOLE b   (src/ADMM.jl:214)
+        self._rho, self._relTol, self._tolInner, self._icg = f32(rho), f32(relTol), f32(tolInner), int(iterationsCG)
+
+    def _params(self, r):
+        from types import SimpleNamespace
+        v = self.v[r]
+        st = SimpleNamespace(rho=np.array([self._rho], np.float32), x=v["x"], xold=v["xold"], beta=v["beta"], beta_y=v["beta_y"],
+                             _zbufs=(v["z0"], v["z1"]), u=[v["u"]], sigma_abs=self._sigma_abs, relTol=self._relTol,
+                             tolInner=self._tolInner)
+        P = self._host._plan_params(st)
+        if P is None:
+            raise self.rls.RLSError("CommRowShardedADMM: this regulariser is not covered by the device plan")
+        return P
+
+    def init(self, b_parts):
+        ptrs = self._upload_b(b_parts)
+        for r in range(self.n):
+            for k in ("x", "z0", "z1", "u"):   # x0 = 0, z = Phi x, u = 0   (src/ADMM.jl:199-206)
+                self.v[r][k].fill_(0)
+            P = self._params(r)
+            check(self.ctxs[r].handle, self.lib.rls_admm_init(self.plans[r], C.byref(P)), "rls_admm_init")
+        check(self.ctxs[0].handle, self.lib.rls_admm_init_rowsharded(self.comm, self._plans_c, ptrs), "rls_admm_init_rowsharded")
+
+    def step(self, n=1):
+        check(self.ctxs[0].handle, self.lib.rls_admm_step_rowsharded(self.comm, self._plans_c, int(n)), "rls_admm_step_rowsharded")
+
+    def status(self, rank=0):
+        st = AdmmStatus()
+        cap = max(self.iterations, 1)
+        log = (C.c_float * (8 * cap))()
+        check(self.ctxs[rank].handle, self.lib.rls_admm_get_status(self.plans[rank], C.byref(st), log, cap), "rls_admm_get_status")
+        return {"iteration": st.iteration, "done": bool(st.done), "rk": st.rk, "sk": st.sk,
+                "cg_iterations": [int(log[8 * i + 5]) for i in range(st.iteration)]}
+
+    def solution(self, rank=0) -> np.ndarray:
+        self.sync()
+        return self.v[rank]["x"].to_host()
+
+    def solve(self, b_parts):
+        self.init(b_parts)
+        self.step(self.iterations)
+        return self.solution()
+
+    def _destroy_plans(self):
+        for p in self.plans:
+            self.lib.rls_admm_destroy(p)
+        for c in self.cgs:
+            self.lib.rls_cg_destroy(c)
 
 
 # --------------------------------------------------------------------------------------------

@@ -142,6 +142,15 @@ class CGNRState(AbstractSolverState):
     def _refresh(self, lib):
         st = CgnrStatus()
         check(self.x.ctx.handle, lib.rls_cgnr_get_status(self._plan, C.byref(st)), "rls_cgnr_get_status")
+        return self._take(st)
+
+    def _step_status(self, lib, n):
+        """advance n iterations and read the status back in ONE call (one host synchronisation): rls_cgnr_step_status"""
+        st = CgnrStatus()
+        check(self.x.ctx.handle, lib.rls_cgnr_step_status(self._plan, int(n), C.byref(st)), "rls_cgnr_step_status")
+        return self._take(st)
+
+    def _take(self, st):
         cplx = self.x.dtype.kind == "c"
         self.alphal = complex(st.alpha_re, st.alpha_im) if cplx else st.alpha_re
         self.betal = complex(st.beta_re, st.beta_im) if cplx else st.beta_re
@@ -151,6 +160,7 @@ class CGNRState(AbstractSolverState):
         self._done = bool(st.done)
         self._residual = st.residual
         self.fallbacks = int(st.fallbacks)  # resident launches lost to a co-tenant and re-run on the pipeline
+        self._status_valid = True
         return st
 
     def convergence(self):
@@ -215,26 +225,29 @@ class CGNR(AbstractKrylovSolver):
         state.iteration = 0
         state._done = False
         state._finalised = False
+        state._status_valid = False
 
     def iterate(self, state: Optional[CGNRState] = None):
-        """iterate(solver, state)  src/CGNR.jl:143-178; returns None when done"""
+        """iterate(solver, state)  src/CGNR.jl:143-178; returns None when done.  One library call per iteration: the step
+        and the status read-back (`done`, the convergence record) travel together (rls_cgnr_step_status)"""
         state = state or self.state
         lib = state.x.ctx.lib
-        state._refresh(lib)
+        if not getattr(state, "_status_valid", False):
+            state._refresh(lib)  # first call after init! (or after work enqueued behind the host's back): is it done already?
         if state._done:
             if not getattr(state, "_finalised", False):
                 for r in self.constr:  # constraints applied once, at exit  :145-147
                     r.prox_(state.x)
                 state._finalised = True
             return None
-        check(state.x.ctx.handle, lib.rls_cgnr_step(state._plan, 1), "rls_cgnr_step")
+        state._step_status(lib, 1)
         return state.x, state
 
     def _run(self, state: CGNRState):
         """no callbacks: enqueue every remaining iteration (no-ops once done) and finalise"""
         lib = state.x.ctx.lib
         n = max(min(self.iterations, self._op.N) - state.iteration, 0)
-        check(state.x.ctx.handle, lib.rls_cgnr_step(state._plan, n), "rls_cgnr_step")
+        state._step_status(lib, n)
         while self.iterate(state) is not None:  # normally returns None at once
             pass
 
@@ -280,6 +293,15 @@ class FISTAState(AbstractSolverState):
         st = FistaStatus()
         h = self._bufs[0].ctx.handle
         check(h, lib.rls_fista_get_status(self._plan, C.byref(st)), "rls_fista_get_status")
+        return self._take(st)
+
+    def _step_status(self, lib, n):
+        """advance n iterations and read the status back in ONE call (rls_fista_step_status)"""
+        st = FistaStatus()
+        check(self._bufs[0].ctx.handle, lib.rls_fista_step_status(self._plan, int(n), C.byref(st)), "rls_fista_step_status")
+        return self._take(st)
+
+    def _take(self, st):
         self.theta, self.thetaold = st.theta, st.theta_old
         self.iteration = st.iteration
         self.rel_res_norm = st.rel_res_norm
@@ -289,6 +311,7 @@ class FISTAState(AbstractSolverState):
         self.fallbacks = int(st.fallbacks)
         # the reference swaps x / xold by pointer every iteration (src/FISTA.jl:144-146)
         self.x, self.xold = (self._bufs[st.iteration & 1], self._bufs[(st.iteration + 1) & 1])
+        self._status_valid = True
         return st
 
     def convergence(self):
@@ -414,6 +437,7 @@ class FISTA(AbstractProximalGradientSolver):
             state.xold.fill_(0)
             state.res.fill_(math.inf)
             state.rel_res_norm = math.inf
+        state._status_valid = False
         state.iteration = 0
         state.theta = state.thetaold = float(theta)
         state._done = False
@@ -422,12 +446,11 @@ class FISTA(AbstractProximalGradientSolver):
         state = state or self.state
         if state._plan:
             lib = state.x.ctx.lib
-            state._refresh(lib)
+            if not getattr(state, "_status_valid", False):
+                state._refresh(lib)  # first call after init!: done already?
             if state._done:
                 return None
-            check(state.x.ctx.handle, lib.rls_fista_step(state._plan, 1), "rls_fista_step")
-            state.iteration += 1
-            state.x, state.xold = state.xold, state.x
+            state._step_status(lib, 1)  # one library call per iteration: step + status (one host synchronisation)
             return state.x, state
         return self._iterate_generic(state)
 
@@ -462,9 +485,7 @@ class FISTA(AbstractProximalGradientSolver):
     def _run(self, state: FISTAState):
         if state._plan:
             lib = state.x.ctx.lib
-            check(state.x.ctx.handle, lib.rls_fista_step(state._plan, max(self.iterations - state.iteration, 0)),
-                  "rls_fista_step")
-            state._refresh(lib)
+            state._step_status(lib, max(self.iterations - state.iteration, 0))
         while self.iterate(state) is not None:
             pass
 

@@ -2240,6 +2240,126 @@ def test_config5_schedule_through_the_library_communicator(rls, ctx, nshards):
         s.close()
 
 
+def _row_cuts(M, nshards, unequal=True):
+    cuts = [0] + [int(M * (k + 1) / nshards) // 4 * 4 for k in range(nshards - 1)] + [M]
+    if unequal and nshards > 1:
+        cuts[1] += 8
+    return cuts
+
+
+@pytest.mark.parametrize("threads", [True, False])
+@pytest.mark.parametrize("nshards", [2, 8])
+def test_rowsharded_fista_through_the_library_communicator(rls, ctx, nshards, threads):
+    """SURVEY 8e last row: FISTA on a row-partitioned A driven from ONE host process through the library
+    (rls_fista_init_rowsharded / rls_fista_step_rowsharded, direct transport: the ranks share the device): replicated
+    state bit-identical on every rank, iteration count and solution those of the unsharded oracle; with one host worker
+    thread per rank and with the calling thread driving every rank the same bits"""
+    M, N = 1536 + 64 * nshards, 384
+    A, xt, b = O.make_problem(M, N, np.complex64, 131)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 2e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    cuts = _row_cuts(M, nshards)
+    shards = [np.asfortranarray(A[cuts[k]:cuts[k + 1]]) for k in range(nshards)]
+    parts = [b[cuts[k]:cuts[k + 1]] for k in range(nshards)]
+    regs = lambda R: [R.L1Regularization(lam), R.PositiveRegularization()]
+    s = rls.CommRowShardedFISTA(rls, shards, reg=rls.L1Regularization(lam), proj=rls.PositiveRegularization(), transport=2,
+                                rho=rho, iterations=20, restart="gradient", threads=threads)
+    try:
+        x = s.solve(parts)
+        xs = [s.solution(r) for r in range(nshards)]
+        assert all(np.array_equal(xs[0], xr) for xr in xs[1:])
+        ref = O.FISTA(A64, reg=regs(O), rho=rho, iterations=20, restart="gradient")
+        x64 = O.solve(ref, b64)
+        assert all(s.status(r)["iteration"] == ref.iteration for r in range(nshards))
+        parity(f"rowsharded_fista_comm_{nshards}_shards_threads{int(threads)}", x, x64,
+               lambda: O.solve(O.FISTA(A, reg=regs(O), rho=rho, iterations=20, restart="gradient"), b))
+        assert np.array_equal(s.solve(parts), x)   # a second solve on the same plans and communicator
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("kind,dt", [("l1", np.complex64), ("tv", np.float32)])
+@pytest.mark.parametrize("nshards", [2, 8])
+def test_rowsharded_admm_through_the_library_communicator(rls, ctx, nshards, kind, dt):
+    """ADMM on a row-partitioned A from ONE host process through the library (rls_admm_init_rowsharded /
+    rls_admm_step_rowsharded): iterations_cg + 1 all-reduces per outer iteration whatever the data; outer iteration count,
+    inner cg! counts and solution those of the unsharded oracle; replicated state bit-identical on every rank"""
+    N = 256
+    M = 1024 + 64 * nshards
+    A, xt, b = O.make_problem(M, N, dt, 137)
+    hdt = hi(dt)
+    regs = (lambda R: R.L1Regularization(0.05)) if kind == "l1" else (lambda R: R.TVRegularization(2e-2, shape=(16, 16)))
+    kw = dict(rho=0.3, iterations=6, iterationsCG=5, tolInner=1e-4)
+    cuts = _row_cuts(M, nshards)
+    shards = [np.asfortranarray(A[cuts[k]:cuts[k + 1]]) for k in range(nshards)]
+    parts = [b[cuts[k]:cuts[k + 1]] for k in range(nshards)]
+    s = rls.CommRowShardedADMM(rls, shards, regs(rls), M, transport=2, **kw)
+    try:
+        x = s.solve(parts)
+        xs = [s.solution(r) for r in range(nshards)]
+        assert all(np.array_equal(xs[0], xr) for xr in xs[1:])
+        ref = O.ADMM(A, reg=regs(O), **kw)   # Float32 oracle = the reference's path: the counts
+        O.solve(ref, b)
+        st = s.status()
+        assert st["iteration"] == ref.iteration and st["cg_iterations"] == list(ref.cg_iters), (st, ref.iteration, ref.cg_iters)
+        ref64 = O.ADMM(A.astype(hdt), reg=regs(O), **dict(kw, iterations=ref.iteration, absTol=0.0, relTol=0.0))
+        parity(f"rowsharded_admm_comm_{kind}_{nshards}_shards", x, O.solve(ref64, b.astype(hdt)), ref.x)
+    finally:
+        s.close()
+
+
+class _ShardedPanelF64Op:
+    """float64 forward / adjoint products of a row-sharded complex64 matrix, 512 columns of one shard at a time (oracle side)"""
+
+    def __init__(self, shards, panel=512):
+        self.shards, self.panel = shards, panel
+        self.dtype = np.dtype(hi(shards[0].dtype))
+        self.shape = (sum(a.shape[0] for a in shards), shards[0].shape[1])
+
+    def mul(self, x):
+        return np.concatenate([_PanelF64Op(a, self.panel).mul(x) for a in self.shards])
+
+    def mul_adj(self, y):
+        out = np.zeros(self.shape[1], self.dtype)
+        lo = 0
+        for a in self.shards:
+            out += _PanelF64Op(a, self.panel).mul_adj(y[lo:lo + a.shape[0]])
+            lo += a.shape[0]
+        return out
+
+
+def test_config5_full_size_eight_shards_on_one_gpu(rls, ctx):
+    """BASELINE configs[4] at FULL size under the gate: one 65536 x 8192 ComplexF32 CGNR (4 GiB of A) as 8 row shards of
+    512 MiB on one GPU, the library's own communicator between them (rls_comm_*, direct transport, one host worker
+    thread per rank), 8 iterations, against the float64 oracle applied shard- and panel-wise; replicated state
+    bit-identical across the 8 ranks"""
+    from rls_amd.multigpu import make_row_shard
+    M, N, nshards, its = 65536, 8192, 8, 8
+    shards, cuts = [], [0]
+    for r in range(nshards):
+        A_r, lo, hi_ = make_row_shard(M, N, r, nshards)
+        shards.append(A_r)
+        cuts.append(hi_)
+    rng = np.random.default_rng(7)
+    x_true = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(np.complex64)
+    parts = [(a @ x_true).astype(np.complex64) for a in shards]
+    b = np.concatenate(parts)
+    s = rls.CommRowShardedCGNR(rls, shards, transport=2, iterations=its, relTol=0.0)
+    try:
+        x = s.solve(parts)
+        xs = [s.solution(r) for r in range(nshards)]
+        assert all(np.array_equal(xs[0], xr) for xr in xs[1:])
+        assert all(s.status(r)["iteration"] == its for r in range(nshards))
+    finally:
+        s.close()
+    op64 = _ShardedPanelF64Op(shards)
+    x64 = O.solve(O.CGNR(op64, iterations=its, relTol=0.0), b.astype(np.complex128))
+    # the Float32 bound (needed only if the 1e-5 gate alone fails): the complex64 restatement on the concatenated matrix
+    parity("BASELINE config 5 full size: CGNR 65536x8192 c64 as 8 shards on one GPU, 8 iterations", x, x64,
+           lambda: O.solve(O.CGNR(np.concatenate(shards), iterations=its, relTol=0.0), b))
+
+
 @pytest.mark.parametrize("dt,M,N,K,kind", [(np.float32, 256, 64, 5, "tv"), (np.complex64, 128, 48, 3, "l1"), (np.float32, 512, 256, 20, "l1pos"),
                                            (np.complex64, 4096, 2048, 8, "l1"), (np.float32, 320, 144, 4, "l2")])
 def test_admm_batched_matrix_rhs(rls, ctx, dt, M, N, K, kind):

@@ -1,0 +1,90 @@
+"""CPU gate on the kernels' register budget, read from the code objects INSIDE the shipped librls_mi355x.so
+(tools/kernel_metadata.py: clang offload bundles -> AMDGPU metadata notes; no compiler and no GPU needed):
+
+* every kernel a BASELINE config launches uses NO scratch (a spill inside an iteration loop is a memory round trip per
+  iteration on kernels that are tuned to the microsecond);
+* the kernels that do spill are exactly the known ones below, each with the shape that reaches it -- a new spill anywhere
+  else fails here instead of showing up as an unexplained slowdown on the GPU box."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    import kernel_metadata
+
+    if not os.path.exists(kernel_metadata.LIB):
+        pytest.skip("library not built")
+    ks = kernel_metadata.kernels()
+    assert len(ks) > 300, "the metadata parser lost the kernels"
+    return ks
+
+
+# (config, regular expression on the demangled instantiation) -- what each BASELINE config launches on its default path
+BASELINE = [
+    ("headline / configs[3] single solves: resident CGNR 4096x2048 CF32", r"cgnr_resident_kernel<c32, 8, 32, 8, 2, true>"),
+    ("headline on the two-launch pipeline", r"cgnr_pipe_a_kernel<c32, 8, 32, 8, true, false, (true|false)>"),
+    ("headline on the two-launch pipeline", r"cgnr_pipe_r_kernel<c32>"),
+    ("headline on the two-launch pipeline", r"cgnr_pipe_f_kernel<c32, \d+>"),
+    ("configs[0]: CGNR 256x128 F32", r"cgnr_pipe_a_kernel<float, 8, 8, 8, (true|false), false, (true|false)>"),
+    ("configs[1]: FISTA + L1 4096x2048 CF32, resident", r"fista_resident_kernel<c32, 8, 32, 8, 2, true>"),
+    ("configs[1] on the pipeline", r"fista_pipe_a_kernel<c32, 8, 32, 8, true, (true|false)>"),
+    ("configs[1] on the pipeline", r"fista_pipe_r_kernel<c32>"),
+    ("configs[2]: ADMM + TV 8192x4096 F32: cg! on the pipeline", r"cgnr_pipe_a_kernel<float, 4, 32, 8, true, false, (true|false)>"),
+    ("configs[2]: cg! entry, z / u update", r"cg_pipe_start_kernel<float>"),
+    ("configs[2]: cg! entry, z / u update", r"admm_zu_kernel<float>"),
+    ("configs[2]: TV prox of a 64 x 64 image", r"fgp2d_kernel<float, 4>"),
+    ("configs[3]: 8 right-hand sides per GPU on the matrix cores", r"skinny_t_kernel<c32, 4, 4, true, 8>"),
+    ("configs[3]", r"skinny_v_kernel<c32, 4, 1, true, 2>"),
+    ("configs[3]", r"skinny_u_kernel<c32, false, 4, 512>"),
+    ("configs[4]: row shards 8192x8192 CF32, two GEMVs + update", r"gemv_n_kernel<c32.*>"),
+    ("configs[4]", r"gemv_t_kernel<c32.*>"),
+    ("configs[4]", r"cgnr_update_(reg_)?kernel<c32.*>"),
+    ("configs[4]: the direct all-reduce", r"comm_(push|sum)_kernel"),
+]
+
+# kernels that are allowed to spill, with the shape that reaches them (none is on a BASELINE config's path)
+KNOWN_SPILLS = {
+    r"fgp2d_kernel<(float|c32), 8>": "register-resident 2-D TV prox of images with 4097..8192 pixels (8 pixels per thread at 128 VGPRs)",
+    r"cgnr_gram_kernel<c32, 4, 32, 8, (true|false)>": "Gram-mode CGNR, ComplexF32 N in (2048, 4096]: 8 owned elements of 4 vectors beside the slab",
+    r"cgnr_pipe_a_kernel<c32, 4, 32, 8, (true|false), false, false>": "slab pipeline, ComplexF32 N in (2048, 4096], launch without a buffer hint "
+                                                                       "(first node of a graph chunk): both (r, p) candidates in registers",
+    r"cgnr_resident_kernel<c32, 8, 32, 8, 1, false>": "resident CGNR, ragged ComplexF32 shape on the flat exchange (M not a multiple of 128)",
+    r"fista_resident_kernel<c32, 8, 32, 8, 2, false>": "resident FISTA, ragged ComplexF32 shape",
+    r"fista_resident_kernel<float, 4, 32, 8, 2, (true|false)>": "resident FISTA, Float32 N in (2048, 4096]",
+}
+
+
+def test_baseline_kernels_use_no_scratch(kernels):
+    bad = []
+    for cfg, pat in BASELINE:
+        hit = [k for k in kernels if re.fullmatch(pat, k)]
+        assert hit, f"{cfg}: no kernel matches {pat} (renamed? update this table)"
+        bad += [f"{cfg}: {k} spills {kernels[k]['scratch']} B/lane" for k in hit if kernels[k]["scratch"] > 0]
+    assert not bad, "\n".join(bad)
+
+
+def test_spills_are_only_the_known_ones(kernels):
+    spill = {k: v["scratch"] for k, v in kernels.items() if v["scratch"] > 0}
+    unknown = [f"{k}: {b} B/lane" for k, b in spill.items() if not any(re.fullmatch(p, k) for p in KNOWN_SPILLS)]
+    assert not unknown, "new spilling kernels:\n" + "\n".join(unknown)
+    for p, why in KNOWN_SPILLS.items():   # the table must not rot either: an entry nothing matches any more goes
+        assert any(re.fullmatch(p, k) for k in spill), f"KNOWN_SPILLS entry no longer spills (remove it): {p} ({why})"
+    assert all(b <= 400 for b in spill.values())
+    for cfg, pat in BASELINE:
+        assert not any(re.fullmatch(p, k) for k in kernels if re.fullmatch(pat, k) for p in KNOWN_SPILLS), cfg
+
+
+def test_register_budgets_admit_the_intended_occupancy(kernels):
+    """the resident kernels need ONE 512-thread workgroup per CU: at most 256 VGPRs; the batched matrix-core kernels run one
+    wave per SIMD by design (skinny.hip) and must stay under 512"""
+    for k, v in kernels.items():
+        if "resident_kernel" in k:
+            assert v["vgprs"] <= 256, (k, v)
+        assert v["vgprs"] <= 512, (k, v)
