@@ -2,6 +2,86 @@
 #include "rls_common.hpp"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <set>
+#include <vector>
+
+// ---- memory (rls_common.hpp) -------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_mem_mutex;
+std::set<const rls_ctx*> g_live_ctx;
+std::map<size_t, std::vector<void*>> g_pinned_free;   // size class -> blocks
+constexpr size_t PIN_HDR = 64;                        // the block's size class sits in front of it (keeps 64-byte alignment)
+thread_local rls_ctx* tl_alloc_ctx = nullptr;
+
+bool device_pools_ok(int device) {
+  static std::mutex m;
+  static std::map<int, bool> known;
+  std::lock_guard<std::mutex> lk(m);
+  auto it = known.find(device);
+  if (it != known.end()) return it->second;
+  bool ok = false;
+  const char* env = getenv("RLS_ALLOC");
+  if (!(env && !strcmp(env, "sync"))) {
+    int supported = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
+        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+      uint64_t keep = ~0ull;  // never hand cached blocks back to the driver at synchronisation points
+      ok = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
+    }
+    (void)hipGetLastError();
+  }
+  known[device] = ok;
+  return ok;
+}
+}  // namespace
+
+bool rls_ctx_alive(const rls_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  return ctx && g_live_ctx.count(ctx) != 0;
+}
+
+hipError_t rls_dev_alloc(rls_ctx* ctx, void** p, size_t bytes) {
+  if (ctx && ctx->pools) return hipMallocAsync(p, bytes ? bytes : 1, ctx->stream);
+  return hipMalloc(p, bytes ? bytes : 1);
+}
+hipError_t rls_dev_free(rls_ctx* ctx, void* p) {
+  if (!p) return hipSuccess;
+  if (ctx && ctx->pools) return hipFreeAsync(p, ctx->stream);
+  return hipFree(p);
+}
+
+hipError_t rls_pinned_alloc(void** p, size_t bytes) {
+  const size_t cls = (bytes + 255) / 256 * 256;
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    auto& fl = g_pinned_free[cls];
+    if (!fl.empty()) {
+      *p = fl.back();
+      fl.pop_back();
+      return hipSuccess;
+    }
+  }
+  char* raw = nullptr;
+  const hipError_t e = hipHostMalloc((void**)&raw, cls + PIN_HDR, hipHostMallocDefault);
+  if (e != hipSuccess) return e;
+  *reinterpret_cast<size_t*>(raw) = cls;
+  *p = raw + PIN_HDR;
+  return hipSuccess;
+}
+void rls_pinned_free(void* p) {
+  if (!p) return;
+  const size_t cls = *reinterpret_cast<size_t*>(static_cast<char*>(p) - PIN_HDR);
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  g_pinned_free[cls].push_back(p);   // kept for the next plan; the process returns it to the driver at exit
+}
+
+rls_alloc_scope::rls_alloc_scope(rls_ctx* ctx) : prev(tl_alloc_ctx) { tl_alloc_ctx = ctx; }
+rls_alloc_scope::~rls_alloc_scope() { tl_alloc_ctx = prev; }
+hipError_t rls_scoped_malloc(void** p, size_t bytes) { return rls_dev_alloc(tl_alloc_ctx, p, bytes); }
+hipError_t rls_scoped_free(void* p) { return rls_dev_free(tl_alloc_ctx, p); }
 
 static int32_t ctx_setup(rls_ctx* ctx) {
   RLS_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -23,6 +103,7 @@ static int32_t ctx_create_impl(int32_t device, void* stream, bool borrow, rls_ct
   if (e != hipSuccess) return (int32_t)e;
   rls_ctx* ctx = new rls_ctx();
   ctx->device = device;
+  ctx->pools = device_pools_ok(device);
   if (borrow) {
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
@@ -38,6 +119,10 @@ static int32_t ctx_create_impl(int32_t device, void* stream, bool borrow, rls_ct
   if (st != 0) {
     rls_ctx_destroy(ctx);
     return st;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    g_live_ctx.insert(ctx);
   }
   *out = ctx;
   return 0;
@@ -62,6 +147,10 @@ int32_t rls_ctx_create_on_stream(int32_t device, void* hip_stream, rls_ctx** out
 
 int32_t rls_ctx_destroy(rls_ctx* ctx) {
   RLS_CHECK_CTX(ctx);
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    g_live_ctx.erase(ctx);
+  }
   hipSetDevice(ctx->device);
   if (ctx->stream) rls_stream_wait(ctx->stream);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -158,7 +247,7 @@ int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out) {
   *out = nullptr;
   if (bytes == 0) return 0;
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  RLS_HIP(ctx, hipMalloc(out, bytes));
+  RLS_HIP(ctx, rls_dev_alloc(ctx, out, bytes));
   return 0;
 }
 
@@ -166,8 +255,8 @@ int32_t rls_free(rls_ctx* ctx, void* p) {
   RLS_CHECK_CTX(ctx);
   if (!p) return 0;
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
-  RLS_HIP(ctx, hipFree(p));
+  if (!ctx->pools) RLS_HIP(ctx, rls_stream_wait(ctx->stream));  // (hipFree synchronises the whole device anyway)
+  RLS_HIP(ctx, rls_dev_free(ctx, p));   // pooled: ordered behind everything enqueued on the context's stream
   return 0;
 }
 

@@ -83,6 +83,13 @@ struct slab_cfg {
   static constexpr int EPT = NMAX >= NT ? NMAX / NT : 1;  // vector elements per thread
 };
 
+// resident kernels: may the slab be re-arranged into the column-owner layout (owner_cfg below)?
+template <typename E, int G, int K, int WV>
+constexpr bool owner_cfg_ok() {
+  using C = slab_cfg<E, G, K, WV>;
+  return (K % 16 == 0) && (C::EPT % C::NV == 0) && (C::EPT / C::NV == K / 16);
+}
+
 // LDS image of one workgroup (dynamic LDS: > 64 KiB).  xg is the exchange area of the second product:
 // every lane stores its two-row (four-row for real) contribution to a column, one padded plane per
 // row chunk g (pad = 64 B so the G planes start on different banks: 2-way at worst on the store,
@@ -290,13 +297,15 @@ __global__ __launch_bounds__(WV * 64) void normal_slab_kernel(const E* __restric
 // The BLAS-1 part of src/CGNR.jl:153-176 for the elements one thread owns.  Every workgroup runs it
 // redundantly (same inputs, same summation order => identical alpha, beta, done); `writer` says
 // whether this workgroup also stores x, r, p.  Returns p_new in pn[].
-template <typename E, int EPT, int NT, bool NOMASK = false>
+// LEADFREE: the resident kernels' calling pattern (see block_sum3_nolead): two workgroup barriers per update instead of four
+template <typename E, int EPT, int NT, bool NOMASK = false, bool LEADFREE = false>
 __device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre, double nim, double pp,
                                               const E (&pv)[EPT], const E (&rv)[EPT], const E (&vv)[EPT], int64_t N,
                                               double* red, E (&pn)[EPT], E (&rn)[EPT], E& a_out,
                                               cgnr_scalars& Sn) {
   const int tid = threadIdx.x;
-  block_sum3_n<NT / 64>(nre, nim, pp, red);
+  if constexpr (LEADFREE) block_sum3_nolead<NT / 64>(nre, nim, pp, red);
+  else block_sum3_n<NT / 64>(nre, nim, pp, red);
   const float lambda = S.lambda;
   const double zeta = S.rr;
   const dcomplex alpha = dc_div({zeta, 0.0}, {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim});
@@ -312,7 +321,8 @@ __device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre,
     rn[e] = ri;
     rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
   }
-  rr = block_sum_n<NT / 64>(rr, red);
+  if constexpr (LEADFREE) rr = block_sum_nolead<NT / 64>(rr, red);
+  else rr = block_sum_n<NT / 64>(rr, red);
   const double beta = rr / zeta;
   const float bf = (float)beta;
 #pragma unroll
@@ -777,7 +787,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const E* __restrict__ 
 // Every workgroup runs it redundantly (same inputs, same summation order => identical scalars).
 // NOMASK: the caller's ownership layout is not the strided one and its elements beyond N are zeros already (they stay
 // zeros: the elementwise prox maps and projections map 0 to 0)
-template <typename E, int EPT, int NT, bool NOMASK = false>
+template <typename E, int EPT, int NT, bool NOMASK = false, bool LEADFREE = false>
 __device__ static inline bool fista_update_elems(const fista_scalars& S, const E (&raw)[EPT], const E (&x0v)[EPT],
                                                  const E (&yv)[EPT], const E (&xk)[EPT], int64_t N, double* red,
                                                  E (&ri)[EPT], E (&xn)[EPT], E (&yn)[EPT], fista_scalars& Sn) {
@@ -800,7 +810,8 @@ __device__ static inline bool fista_update_elems(const fista_scalars& S, const E
     const E df = elem<E>::sub(xv, xk[e]);
     d += (double)elem<E>::re(r) * (double)elem<E>::re(df) + (double)elem<E>::im(r) * (double)elem<E>::im(df);
   }
-  block_sum3_n<NT / 64>(rn, d, zero, red);
+  if constexpr (LEADFREE) block_sum3_nolead<NT / 64>(rn, d, zero, red);  // resident kernels: barriers of the exchange in between
+  else block_sum3_n<NT / 64>(rn, d, zero, red);
   float theta = S.theta;
   if (S.restart && d > 0.0) theta = 1.f;                                  // gradient restart  :171-176
   const float theta_old = theta;                                          // :179
@@ -1484,7 +1495,13 @@ struct resident_lds {
   slab_lds<E, G, K, WV> L;
   f4 rp[WV][4];  // per-wave sums of the four 16-byte pieces of a 64-byte column chunk
   int flag;
+  float ored[(WV + 1) * 32];  // owner layout: per-wave sums of t_w, then t_w
 };
+// dynamic LDS of a resident kernel: its struct, or the 128 KiB staging area of the one-off slab transposition
+template <typename E, int G, int K, int WV>
+constexpr size_t resident_lds_bytes() {
+  return sizeof(resident_lds<E, G, K, WV>) > 131072 || !owner_cfg_ok<E, G, K, WV>() ? sizeof(resident_lds<E, G, K, WV>) : 131072;
+}
 
 // arrive + wait on the grid counter.  Precondition: this workgroup's handed-off stores are sc1, drained by every storing
 // wave, and a workgroup barrier lies between those drains and this call.  Arrival = one returning-free atomic add to one
@@ -1582,6 +1599,200 @@ __device__ static inline void resident_reduce_chunks(resident_lds<E, G, K, WV>& 
       }
     }
     __syncthreads();  // rp is reused by the next chunk
+  }
+}
+
+// ---- column-owner layout of the resident slab (round 3) ----------------------------------------------------------------
+// The streaming kernels load the slab so that a lane holds NV rows x K columns (coalesced 16-byte pieces of a column); the
+// first product then sums over a lane's own columns, but the second needs a sum ACROSS the G lanes that share a column: K
+// values per lane through LDS exchange planes, 256 KiB of LDS traffic per iteration -- 2 of the ~3.9 us the products cost.
+// A resident kernel loads its slab once per LAUNCH, so it can afford to re-arrange it once: after the transposition below
+// thread t holds ALL G * NV rows of the EPT columns it also owns of p, r, x, v (the 16-byte ownership pieces of
+// own_index<.., WIDE>).  Per iteration then
+//   * t_w = A_w p: the multiplier p[c] is the thread's own register (no staging of p in LDS), G * NV row sums per thread,
+//     reduced over the workgroup by a halving butterfly in registers (DPP / bpermute: ~110 instructions per wave) and one
+//     small LDS round for the 8 waves;
+//   * A_w^H t_w: every column's sum is complete inside its owner thread -- no exchange at all -- and is stored straight into
+//     the partial row at the thread's own pieces.
+// Same FMA count as before; what disappears is the LDS traffic and four workgroup barriers.  Applies where a thread's
+// ownership pieces match the 16-round passes of the transposition (EPT / NV == K / 16): the ComplexF32 shapes and Float32
+// N in (2048, 4096]; Float32 N <= 2048 (32 rows x 4 columns per thread in ONE piece) keeps the exchange-plane products.
+template <typename E, int G, int K, int WV>
+struct owner_cfg {
+  using C = slab_cfg<E, G, K, WV>;
+  static constexpr bool ok = owner_cfg_ok<E, G, K, WV>();
+  static constexpr int RF = G * C::NV * (elem<E>::cplx ? 2 : 1);  // floats of t_w: 32 (16 complex rows / 32 real rows) or 16
+};
+
+// once per launch: a[k] (rows NV g.., column (k WV + w) S + s) -> a[16 q + j G + i] = rows NV i.. of owned column (piece q, j).
+// Pass q moves the 16 rounds whose columns are piece q through LDS (128 KiB), in place: the 16 registers it empties are
+// the 16 it fills.  Slot swizzle: a column's G slots are permuted by its owner's index so that the reads (stride 256 B
+// between lanes) spread over G bank groups.
+template <typename E, int G, int K, int WV, bool FULL>
+__device__ static inline void owner_transpose(chunk<E, elem<E>::vec> (&a)[K], char* lds, int64_t Mc, int64_t N, int pair) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, S = C::S, CPR = C::CPR, NT = C::NT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane % G, s = lane / G, slot = w * S + s;
+  if constexpr (!FULL) {
+    const bool row_ok = row_block_of(blockIdx.x, pair) * G + g < Mc;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k * CPR + slot >= N || !row_ok) a[k] = zero_chunk<E, NV>();
+  }
+  f4* st = reinterpret_cast<f4*>(lds);
+#pragma unroll
+  for (int q = 0; q < K / 16; ++q) {
+    __syncthreads();  // the previous pass has been read
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int cl = kk * CPR + slot;              // column inside the piece
+      const int owner = cl / NV;                   // its owner thread
+      st[cl * G + (g ^ (owner % G))] = __builtin_bit_cast(f4, a[16 * q + kk]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+        a[16 * q + j * G + i] = __builtin_bit_cast(chunk<E, NV>, st[(tid * NV + j) * G + (i ^ (tid % G))]);
+  }
+  __syncthreads();
+  (void)NT;
+}
+
+// Sum of v[0..NVAL) over the 64 lanes of a wave by halving: after the step with partner lane ^ 2^b a lane keeps the half
+// selected by its bit b (0: lower), so after log2(NVAL) steps it holds ONE value -- the sum over 2^steps lanes of element
+//   idx = sum_b bit_b(lane) * NVAL / 2^(b+1)
+// -- and the remaining steps are plain adds.  Returns that value (complete over the wave); *idx_out = its element index.
+template <int NVAL>
+__device__ static inline float wave_reduce_scatter(float (&v)[NVAL], int lane, int* idx_out) {
+  static_assert(NVAL == 32 || NVAL == 16, "16 or 32 values");
+  int idx = 0;
+  // xor 1 and xor 2: DPP quad permutes (full rate)
+  {
+    constexpr int H = NVAL / 2;
+    const bool up = lane & 1;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const float lo = v[j] + dpp_f(v[j], 0xB1), hi = v[H + j] + dpp_f(v[H + j], 0xB1);
+      v[j] = up ? hi : lo;
+    }
+    idx += up ? H : 0;
+  }
+  {
+    constexpr int H = NVAL / 4;
+    const bool up = lane & 2;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const float lo = v[j] + dpp_f(v[j], 0x4E), hi = v[H + j] + dpp_f(v[H + j], 0x4E);
+      v[j] = up ? hi : lo;
+    }
+    idx += up ? H : 0;
+  }
+  // xor 4, 8, (16): few values left -- bpermute shuffles
+  {
+    constexpr int H = NVAL / 8;
+    const bool up = lane & 4;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const float lo = v[j] + __shfl_xor(v[j], 4, 64), hi = v[H + j] + __shfl_xor(v[H + j], 4, 64);
+      v[j] = up ? hi : lo;
+    }
+    idx += up ? H : 0;
+  }
+  {
+    constexpr int H = NVAL / 16;
+    const bool up = lane & 8;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const float lo = v[j] + __shfl_xor(v[j], 8, 64), hi = v[H + j] + __shfl_xor(v[H + j], 8, 64);
+      v[j] = up ? hi : lo;
+    }
+    idx += up ? H : 0;
+  }
+  float r;
+  if constexpr (NVAL == 32) {
+    const bool up = lane & 16;
+    const float lo = v[0] + __shfl_xor(v[0], 16, 64), hi = v[1] + __shfl_xor(v[1], 16, 64);
+    r = up ? hi : lo;
+    idx += up ? 1 : 0;
+  } else {
+    r = v[0] + __shfl_xor(v[0], 16, 64);
+  }
+  r += __shfl_xor(r, 32, 64);
+  *idx_out = idx;
+  return r;
+}
+
+// one application of the slab in the owner layout: partial row of A_w^H (A_w pin) -> slab[blockIdx] (write-through, the
+// thread's own 16-byte pieces).  pin[]: the thread's owned elements of the input vector (zero beyond N).
+// `red`: WV x RF floats + RF floats of LDS scratch.
+template <typename E, int G, int K, int WV, bool FULL>
+__device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K], const E (&pin)[slab_cfg<E, G, K, WV>::EPT],
+                                             float* red, __amdgpu_buffer_rsrc_t slab_rs, int64_t N) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT, RF = owner_cfg<E, G, K, WV>::RF;
+  constexpr bool CX = elem<E>::cplx;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // ---- t_w = A_w p: this thread's columns ----
+  E acc[G * NV];
+#pragma unroll
+  for (int i = 0; i < G * NV; ++i) acc[i] = elem<E>::zero();
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int q = e / NV, j = e % NV;
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int r = 0; r < NV; ++r) acc[i * NV + r] = elem<E>::fma_pk(a[16 * q + j * G + i].e[r], pin[e], acc[i * NV + r]);
+  }
+  float v[RF];
+#pragma unroll
+  for (int i = 0; i < G * NV; ++i) {
+    if constexpr (CX) {
+      v[2 * i] = elem<E>::re(acc[i]);
+      v[2 * i + 1] = elem<E>::im(acc[i]);
+    } else {
+      v[i] = elem<E>::re(acc[i]);
+    }
+  }
+  int idx;
+  const float part = wave_reduce_scatter<RF>(v, lane, &idx);
+  // (no barrier in front: the previous reader of `red` is the previous application's second product, and an exchange with
+  //  several workgroup barriers lies between)
+  if (lane < 32) red[w * RF + idx] = part;   // lanes l and l + 32 hold the same element (RF = 16: l, l + 16, ... likewise)
+  lds_barrier();
+  if (tid < RF) {
+    float sum = red[tid];
+#pragma unroll
+    for (int ww = 1; ww < WV; ++ww) sum += red[ww * RF + tid];
+    red[WV * RF + tid] = sum;
+  }
+  lds_barrier();
+  // ---- A_w^H t_w: complete inside the owner thread ----
+  E tr[G * NV];
+#pragma unroll
+  for (int i = 0; i < G * NV; ++i) {
+    if constexpr (CX) tr[i] = elem<E>::make(red[WV * RF + 2 * i], red[WV * RF + 2 * i + 1]);
+    else tr[i] = elem<E>::make(red[WV * RF + i], 0.f);
+  }
+#pragma unroll
+  for (int q = 0; q < EPT / NV; ++q) {
+    chunk<E, NV> out;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      E sum = elem<E>::zero();
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int r = 0; r < NV; ++r) sum = elem<E>::fmac_pk(a[16 * q + j * G + i].e[r], tr[i * NV + r], sum);
+      out.e[j] = sum;
+    }
+    const int o = q * NT * NV + tid * NV;
+    if (FULL || o < N)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), slab_rs,
+                                             (uint32_t)blockIdx.x * (uint32_t)(N * sizeof(E)) + (uint32_t)(o * sizeof(E)), 0, 16);
   }
 }
 
@@ -1729,6 +1940,8 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (!St.enabled && (S.done || n_steps <= 0)) return;  // uniform
+  constexpr bool OWN = owner_cfg<E, G, K, WV>::ok;  // the slab re-arranged once so that a thread holds whole columns
+  if constexpr (OWN) owner_transpose<E, G, K, WV, FULL>(a, smem_raw, Mc, N, pair);
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), d_rs = sc1_rsrc(dout);
   (void)d_rs;
   unsigned epoch = 0, xchg = 0;
@@ -1736,9 +1949,13 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   if (St.enabled) {
     // ---- cg! entry (cg_pipe_start_kernel of solvers.hip, folded in): c = AHA x through the same two exchanges, then
     // r = b - (c + rho x), p = r and the scalars of the solve, redundantly in every workgroup ----------------------------
+    if constexpr (OWN) {
+      owner_products<E, G, K, WV, FULL>(a, xv, R.ored, slab_rs, N);
+    } else {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = xv[e];
-    slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+      for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = xv[e];
+      slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     E cv[EPT];
@@ -1829,10 +2046,14 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   if (blockIdx.x == 0) store_owned(xw, xv);
   for (int it = 0; it < n_steps; ++it) {
     STAMP(8);
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
     // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through)
-    slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+    if constexpr (OWN) {
+      owner_products<E, G, K, WV, FULL>(a, pv, R.ored, slab_rs, N);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
+      slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+    }
     STAMP(9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
@@ -1843,38 +2064,45 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     E vv[EPT];
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
     double dre = 0.0, dim_ = 0.0, pp = 0.0;  // EXCH 1: this workgroup's share of the dots over its column chunk
-    const bool ok_x = resident_allreduce<E, G, K, WV, BAR, FULL>(
-        R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, vv,
-        [&](int j, E sum) {
-          const E pj = L.xs[j];
-          dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
-          dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
-          pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
-        },
-        [&]() {
-          if (w == 0) {  // lanes 0..CW-1 hold the terms (zero elsewhere); fixed-order butterfly, lane 0 publishes
-#pragma unroll
-            for (int off = CW / 2; off > 0; off >>= 1) {
-              dre += __shfl_xor(dre, off, 64);
-              dim_ += __shfl_xor(dim_, off, 64);
-              pp += __shfl_xor(pp, off, 64);
+    bool ok_x;
+    if constexpr (OWN) {  // p is not staged in LDS in the owner layout: the dots are formed from the full vectors below
+      ok_x = resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, vv, [](int, E) {}, []() {});
+    } else {
+    ok_x = resident_allreduce<E, G, K, WV, BAR, FULL>(
+          R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, vv,
+          [&](int j, E sum) {
+            const E pj = L.xs[j];
+            dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+            dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+            pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+          },
+          [&]() {
+            if (w == 0) {  // lanes 0..CW-1 hold the terms (zero elsewhere); fixed-order butterfly, lane 0 publishes
+  #pragma unroll
+              for (int off = CW / 2; off > 0; off >>= 1) {
+                dre += __shfl_xor(dre, off, 64);
+                dim_ += __shfl_xor(dim_, off, 64);
+                pp += __shfl_xor(pp, off, 64);
+              }
+              if (lane < 3) {
+                const double dv = lane == 0 ? dre : (lane == 1 ? dim_ : pp);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dout + 4 * blockIdx.x + lane),
+                                   __builtin_bit_cast(unsigned long long, dv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
             }
-            if (lane < 3) {
-              const double dv = lane == 0 ? dre : (lane == 1 ? dim_ : pp);
-              __hip_atomic_store(reinterpret_cast<unsigned long long*>(dout + 4 * blockIdx.x + lane),
-                                 __builtin_bit_cast(unsigned long long, dv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-        });
+          });
+    }
     if (!ok_x) {
       alive = false;
       break;
     }
     // p of this iteration, back from its LDS copy (L.xs, staged for the products and untouched since): it need not occupy
     // registers across the products and the exchange
+    if constexpr (!OWN) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) pv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
-    if constexpr (BAR == 1) {  // the 256 partial dots, one per thread; cg_update_elems sums them over the workgroup
+      for (int e = 0; e < EPT; ++e) pv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
+    }
+    if constexpr (BAR == 1 && !OWN) {  // the 256 partial dots, one per thread; cg_update_elems sums them over the workgroup
       const int dt = tid < nwg ? tid : 0;
       const f4 lo = sc1_load16(d_rs, (uint32_t)dt * 32u), hi = sc1_load16(d_rs, (uint32_t)dt * 32u + 16u);
       if (tid < nwg) {
@@ -1897,7 +2125,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(14);
 #endif
-    const bool done = cg_update_elems<E, EPT, NT, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    const bool done = cg_update_elems<E, EPT, NT, true, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       xq[e] = elem<E>::fma(pv[e], al, xq[e]);
@@ -2219,14 +2447,20 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   if (S.done || n_steps <= 0) return;  // uniform
+  constexpr bool OWN = owner_cfg<E, G, K, WV>::ok;
+  if constexpr (OWN) owner_transpose<E, G, K, WV, FULL>(a, smem_raw, Mc, N, pair);
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab);
   unsigned epoch = 0, xchg = 0;
   bool alive = true;
   int ycur = S.ycur;
   for (int it = 0; it < n_steps; ++it) {
+    if constexpr (OWN) {
+      owner_products<E, G, K, WV, FULL>(a, yv, R.ored, slab_rs, N);
+    } else {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = yv[e];
-    slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+      for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = yv[e];
+      slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     E x0v[EPT];  // requested here, consumed behind the exchange
@@ -2238,11 +2472,13 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
       break;
     }
     // y of this iteration, back from its LDS copy (L.xs): not carried in registers across the products and the exchange
+    if constexpr (!OWN) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) yv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
+      for (int e = 0; e < EPT; ++e) yv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
+    }
     E xn[EPT], yn[EPT], ri[EPT];
     fista_scalars Sn;
-    const bool done = fista_update_elems<E, EPT, NT, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    const bool done = fista_update_elems<E, EPT, NT, true, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
     if (blockIdx.x == 0) {  // state.res of this iteration (nothing reads it back: a launch that gives up later loses nothing)
       const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(res, 0, 0xffffffff, 0x00020000);
 #pragma unroll
@@ -2294,6 +2530,147 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
       S.pending = 0;
       S.fresh = 0;
       RLS_FISTA_COPY(*sc, S);
+      sync->completed = 1u;
+    }
+  }
+}
+
+// ---- resident OptISTA / POGM: a whole block of iterations in ONE launch ------------------------------------
+// Same skeleton as fista_resident_kernel on the column-owner layout: per iteration res_raw = AHA x from registers (one
+// grid-wide all-reduce), then the elementwise half of iterate (src/OptISTA.jl:176-204 / src/POGM.jl:176-212: the bodies of
+// optista_update_kernel / pogm_update_body in pgm.hip) redundantly in every workgroup.  The momentum coefficients depend on
+// the iteration index only: the host computes them in Float32 as the reference does and hands the block's worth over as a
+// kernel argument.  Loop-carried in registers: three vectors (x, y, z); zold / xold and res are written every iteration by
+// workgroup 0 and never read (a launch that gives up loses nothing: x, y, z and the record are written once, at the end).
+// POGM swaps its x / y references every iteration (:203): the launch leaves the operator input of the NEXT iteration in the
+// buffer the host's reference `x` points to after as many swaps as iterations ran.
+template <typename E, int G, int K, int WV, int BAR, bool FULL, int KIND>
+__global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1, E* b2, E* o0,
+                                                                E* res, const E* __restrict__ x0, E* raw_g, E* slab,
+                                                                pgm_state* st, rls_pgm_coefs CF, float norm_x0, float rel_tol,
+                                                                int reg_kind, int proj_kind, resident_sync* sync, int64_t Mc,
+                                                                int64_t N, int pair, int n_steps, unsigned spin_limit) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
+  static_assert(owner_cfg<E, G, K, WV>::ok, "column-owner layout only");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  resident_lds<E, G, K, WV>& R = *reinterpret_cast<resident_lds<E, G, K, WV>*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int nwg = gridDim.x;
+  int iteration = st->iteration;
+  int done = st->done;
+  float res_norm = st->res_norm;
+  E xv[EPT], yv[EPT], zv[EPT];
+  if constexpr (FULL) {
+    load_owned_wide<E, EPT, NT>(xv, b0, tid);
+    load_owned_wide<E, EPT, NT>(yv, b1, tid);
+    load_owned_wide<E, EPT, NT>(zv, b2, tid);
+  } else {
+    load_owned_wide_masked<E, EPT, NT>(xv, b0, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(yv, b1, tid, N);
+    load_owned_wide_masked<E, EPT, NT>(zv, b2, tid, N);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  chunk<E, NV> a[K];
+  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
+  __builtin_amdgcn_sched_barrier(0);
+  if (done || n_steps <= 0) return;  // uniform
+  owner_transpose<E, G, K, WV, FULL>(a, smem_raw, Mc, N, pair);
+  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab);
+  const __amdgpu_buffer_rsrc_t o0_rs = __builtin_amdgcn_make_buffer_rsrc(o0, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(res, 0, 0xffffffff, 0x00020000);
+  auto store_buf = [&](__amdgpu_buffer_rsrc_t rs, const E (&src)[EPT]) {
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      chunk<E, NV> c;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) c.e[j] = src[q * NV + j];
+      const int o = q * NT * NV + tid * NV;
+      if (FULL || o < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, c), rs, (uint32_t)(o * sizeof(E)), 0, 0);
+    }
+  };
+  unsigned epoch = 0, xchg = 0;
+  bool alive = true;
+  int ran = 0;
+  for (int it = 0; it < n_steps; ++it) {
+    owner_products<E, G, K, WV, FULL>(a, xv, R.ored, slab_rs, N);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    E x0v[EPT];  // requested here, consumed behind the exchange
+    if constexpr (FULL) load_owned_wide<E, EPT, NT>(x0v, x0, tid);
+    else load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
+    E raw[EPT];
+    if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
+      alive = false;
+      break;
+    }
+    const float c0 = CF.c[it][0], c1 = CF.c[it][1], c2 = CF.c[it][2], c3 = CF.c[it][3], c4 = CF.c[it][4], c5 = CF.c[it][5],
+                c6 = CF.c[it][6];
+    E ri[EPT], ov[EPT];
+    double rn = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = own_index<E, EPT, NT, true>(tid, e);
+      E r = elem<E>::sub(raw[e], x0v[e]);
+      if (!FULL && i >= N) r = elem<E>::zero();
+      ri[e] = r;
+      rn += (double)elem<E>::re(r) * (double)elem<E>::re(r) + (double)elem<E>::im(r) * (double)elem<E>::im(r);
+      if constexpr (KIND == 0) {  // OptISTA: {step, thr, c_z, c_y, c_x, c_zn, c_zo}   (optista_update_kernel, pgm.hip)
+        const E zo = zv[e], ztmp = yv[e], xi = xv[e];
+        E yn = elem<E>::add(ztmp, elem<E>::scale(-c0, r));
+        yn = fista_prox_elem<E>(yn, reg_kind, c1);
+        E zn = elem<E>::add(elem<E>::scale(c2, ztmp), xi);
+        zn = elem<E>::add(zn, elem<E>::scale(c3, yn));
+        E xn = elem<E>::add(elem<E>::scale(c4, xi), elem<E>::scale(c5, zn));
+        xn = elem<E>::add(xn, elem<E>::scale(c6, zo));
+        if (!FULL && i >= N) yn = zn = xn = elem<E>::zero();
+        ov[e] = zo;   // zold
+        yv[e] = yn;
+        zv[e] = zn;
+        xv[e] = xn;
+      } else {  // POGM: {rho, thr, c_y, c_x1, c_xo, c_z}   (pogm_update_body, pgm.hip)
+        const E xo = xv[e], yp = yv[e];
+        const E x1 = elem<E>::add(xo, elem<E>::scale(-c0, r));
+        E xn = elem<E>::add(elem<E>::scale(c2, yp), elem<E>::scale(c3, x1));
+        xn = elem<E>::add(xn, elem<E>::scale(c4, xo));
+        xn = elem<E>::add(xn, elem<E>::scale(c5, zv[e]));
+        E zn = xn;
+        xn = fista_proj_elem<E>(fista_prox_elem<E>(xn, reg_kind, c1), proj_kind);
+        E y1 = x1;
+        if (!FULL && i >= N) xn = zn = y1 = elem<E>::zero();
+        ov[e] = xo;   // xold
+        zv[e] = zn;
+        yv[e] = y1;   // the gradient point: the reference's y after its swap
+        xv[e] = xn;   // the next operator input
+      }
+    }
+    if (blockIdx.x == 0) {
+      store_buf(o0_rs, ov);
+      store_buf(res_rs, ri);
+    }
+    rn = block_sum_nolead<NT / 64>(rn, R.L.red);
+    res_norm = uni((float)sqrt(rn));
+    iteration += 1;
+    ran += 1;
+    done = uni((int)(((double)res_norm / (double)norm_x0) < (double)rel_tol));
+    if (done) break;  // uniform: every workgroup derived the same scalar
+  }
+  if (!alive) {
+    resident_give_up(sync, nullptr);
+    return;
+  }
+  if (blockIdx.x == 0) {
+    // POGM: an odd number of iterations leaves the roles of the two buffers swapped (the host swaps its references as often)
+    E* xd = (KIND == 1 && (ran & 1)) ? b1 : b0;
+    E* yd = (KIND == 1 && (ran & 1)) ? b0 : b1;
+    store_buf(__builtin_amdgcn_make_buffer_rsrc(xd, 0, 0xffffffff, 0x00020000), xv);
+    store_buf(__builtin_amdgcn_make_buffer_rsrc(yd, 0, 0xffffffff, 0x00020000), yv);
+    store_buf(__builtin_amdgcn_make_buffer_rsrc(b2, 0, 0xffffffff, 0x00020000), zv);
+    if (tid == 0) {
+      st->iteration = iteration;
+      st->done = done;
+      st->res_norm = res_norm;
       sync->completed = 1u;
     }
   }
@@ -2755,7 +3132,7 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
     const int64_t Mc = P.M / C::NV;
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
-    constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
+    constexpr size_t lds = resident_lds_bytes<E, G, K, WV>();
     static rls_device_once attr_once;
     if (attr_once.first(ctx->device)) {
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, true>, lds);
@@ -2803,9 +3180,9 @@ static bool resident_ok_typed(int device, int64_t M, int64_t N, const void* A, i
   if (c.G == GG && c.K == KK && c.WV == WW) {                                                                            \
     if constexpr ((KK == 32 || KK == 16) && WW == 8 && slab_cfg<E, GG, KK, WW>::EPT % elem<E>::vec == 0 &&               \
                   !(elem<E>::cplx && GG == 4)) {                                                                         \
-      allow_big_lds(&cgnr_resident_kernel<E, GG, KK, WW, 1, false>, sizeof(resident_lds<E, GG, KK, WW>));                \
+      allow_big_lds(&cgnr_resident_kernel<E, GG, KK, WW, 1, false>, resident_lds_bytes<E, GG, KK, WW>());                \
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cgnr_resident_kernel<E, GG, KK, WW, 1, false>, WW * 64,  \
-                                                       sizeof(resident_lds<E, GG, KK, WW>)) != hipSuccess)               \
+                                                       resident_lds_bytes<E, GG, KK, WW>()) != hipSuccess)               \
         blocks = 0;                                                                                                      \
     }                                                                                                                    \
   }
@@ -2837,7 +3214,7 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
     const int64_t Mc = P.M / C::NV;
     const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
-    constexpr size_t lds = sizeof(resident_lds<E, G, K, WV>);
+    constexpr size_t lds = resident_lds_bytes<E, G, K, WV>();
     static rls_device_once attr_once;
     if (attr_once.first(ctx->device)) {
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, true>, lds);
@@ -2950,6 +3327,67 @@ static int32_t fista_gram_resident_typed(rls_ctx* ctx, const rls_fista_gram& P, 
   if (K == 16) return launch_fista_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit);
   if constexpr (!elem<E>::cplx) return launch_fista_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
   return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram FISTA: shape not resident");
+}
+template <typename E, int G, int K, int WV>
+static int32_t launch_pgm_resident(rls_ctx* ctx, const rls_pgm_desc& D, const rls_pgm_coefs& CF, void* sync, int nwg, int n_steps,
+                                   unsigned spin_limit) {
+  using C = slab_cfg<E, G, K, WV>;
+  if constexpr ((K == 32 || K == 16) && WV == 8 && owner_cfg_ok<E, G, K, WV>() && !(elem<E>::cplx && G == 4)) {
+    const int64_t Mc = D.M / C::NV;
+    const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+    const bool full = D.N == C::NMAX && (int64_t)nwg * G == Mc;
+    constexpr size_t lds = resident_lds_bytes<E, G, K, WV>();
+    static rls_device_once attr_once;
+    if (attr_once.first(ctx->device)) {
+#define RLS_PGM_ATTR(BB, FF, KK2) allow_big_lds(&pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>, lds);
+      RLS_PGM_ATTR(1, true, 0) RLS_PGM_ATTR(2, true, 0) RLS_PGM_ATTR(1, false, 0) RLS_PGM_ATTR(2, false, 0)
+      RLS_PGM_ATTR(1, true, 1) RLS_PGM_ATTR(2, true, 1) RLS_PGM_ATTR(1, false, 1) RLS_PGM_ATTR(2, false, 1)
+#undef RLS_PGM_ATTR
+    }
+#define RLS_LAUNCH_PGM(BB, FF, KK2)                                                                                              \
+  hipLaunchKernelGGL((pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)D.A,    \
+                     D.lda, (E*)D.v0, (E*)D.v1, (E*)D.v2, (E*)D.o0, (E*)D.res, (const E*)D.x0, (E*)D.raw, (E*)D.slab, D.st, CF,  \
+                     D.norm_x0, D.rel_tol, D.reg_kind, D.proj_kind, (resident_sync*)sync, Mc, D.N, pair, n_steps, spin_limit)
+    const bool two = resident_two_level_ok<E>(nwg, D.N, C::NT);
+    if (D.kind == 0) {
+      if (two) { if (full) RLS_LAUNCH_PGM(2, true, 0); else RLS_LAUNCH_PGM(2, false, 0); }
+      else { if (full) RLS_LAUNCH_PGM(1, true, 0); else RLS_LAUNCH_PGM(1, false, 0); }
+    } else {
+      if (two) { if (full) RLS_LAUNCH_PGM(2, true, 1); else RLS_LAUNCH_PGM(2, false, 1); }
+      else { if (full) RLS_LAUNCH_PGM(1, true, 1); else RLS_LAUNCH_PGM(1, false, 1); }
+    }
+#undef RLS_LAUNCH_PGM
+    return launch_status(ctx);
+  } else {
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident OptISTA / POGM: slab shape not instantiated");
+  }
+}
+
+template <typename E>
+static int32_t pgm_resident_typed(rls_ctx* ctx, const rls_pgm_desc& D, const rls_pgm_coefs& CF, void* sync, int n_steps,
+                                  unsigned spin_limit) {
+  fused_cfg c;
+  if (!pick_cfg<E>(D.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident OptISTA / POGM: N too large");
+  const int nwg = (int)fused_nwg<E>(D.M, D.N);
+  int32_t st = RLS_E_UNSUPPORTED;
+#define RLS_PGM_CASE(GG, KK, WW) \
+  if (c.G == GG && c.K == KK && c.WV == WW) st = launch_pgm_resident<E, GG, KK, WW>(ctx, D, CF, sync, nwg, n_steps, spin_limit);
+  RLS_FOR_EACH_CFG(RLS_PGM_CASE)
+#undef RLS_PGM_CASE
+  return st;
+}
+
+template <typename E>
+static bool pgm_resident_ok_typed(int device, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!resident_ok_typed<E>(device, M, N, A, lda)) return false;
+  fused_cfg c;
+  if (!pick_cfg<E>(N, &c)) return false;
+  bool ok = false;
+#define RLS_PGM_OK(GG, KK, WW) \
+  if (c.G == GG && c.K == KK && c.WV == WW) ok = owner_cfg_ok<E, GG, KK, WW>() && (KK == 16 || KK == 32);
+  RLS_FOR_EACH_CFG(RLS_PGM_OK)
+#undef RLS_PGM_OK
+  return ok;
 }
 }  // namespace
 
@@ -3077,4 +3515,17 @@ int32_t rls_fista_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_p
                                   unsigned spin_limit) {
   if (dtype == RLS_F32) return fista_resident_typed<float>(ctx, P, sync, n_steps, spin_limit);
   return fista_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit);
+}
+
+bool rls_pgm_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!ctx) return false;
+  if (dtype == RLS_F32) return pgm_resident_ok_typed<float>(ctx->device, M, N, A, lda);
+  if (dtype == RLS_C32) return pgm_resident_ok_typed<float2>(ctx->device, M, N, A, lda);
+  return false;
+}
+int32_t rls_pgm_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_pgm_desc& D, const rls_pgm_coefs& C, void* sync,
+                                int n_steps, unsigned spin_limit) {
+  if (n_steps > RLS_PGM_MAX_IT) return rls_fail(ctx, RLS_E_INVALID, "pgm_resident: more iterations than coefficient slots");
+  if (dtype == RLS_F32) return pgm_resident_typed<float>(ctx, D, C, sync, n_steps, spin_limit);
+  return pgm_resident_typed<float2>(ctx, D, C, sync, n_steps, spin_limit);
 }

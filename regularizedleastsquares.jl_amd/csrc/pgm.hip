@@ -10,10 +10,7 @@ constexpr int PGM_THREADS = 1024;
 // Deferred mode (rls_*_update_async): the iteration count, ||res|| and the reference's stopping test
 // `rel_res_norm < relTol` (src/OptISTA.jl:206-209, src/POGM.jl:234-237) live in a 4-word device record, every
 // launch of the sequence is a no-op once `done` is set, and the host reads the record once per solve.
-struct pgm_state {
-  int iteration, done;
-  float res_norm, pad;
-};
+// (struct pgm_state: rls_common.hpp)
 __device__ static inline void pgm_state_step(pgm_state* st, float res_norm, float norm_x0, float rel_tol) {
   if (!st) return;
   st->iteration += 1;

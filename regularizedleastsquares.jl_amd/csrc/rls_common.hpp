@@ -45,7 +45,33 @@ struct rls_ctx {
   float* res_h = nullptr;   // pinned host mirror
   rls_tuning tune;
   int resident_failures = 0;  // resident launches of this context that timed out; at 2 the context stops using them
+  bool pools = false;         // device memory comes from the device's stream-ordered pool (rls_dev_alloc)
 };
+
+// ---- memory ------------------------------------------------------------------------------------------------------------
+// Device memory of the library (plan scratch, rls_malloc) is STREAM-ORDERED on the context's stream: hipMallocAsync /
+// hipFreeAsync on the device's default memory pool, whose release threshold is raised once so that freed blocks stay
+// cached.  A whole solve! creates and drops a dozen scratch vectors; with hipMalloc / hipFree that was a dozen driver
+// calls plus a device-wide synchronisation per free (hipFree waits for EVERY stream of the device -- eight solver threads
+// serialised each other through it: bench.py cgnr_distinct_A_8_problems, 8 streams slower than 1).  Reuse is ordered by
+// the stream, as with any stream-ordered allocator: memory handed to ANOTHER context's stream must be synchronised by the
+// caller before it is freed.  Devices without memory pools (or RLS_ALLOC=sync) fall back to hipMalloc / hipFree.
+// Small pinned host blocks (the status mirrors of the plans) come from a process-wide free list: hipHostMalloc costs
+// ~100 us a call.
+hipError_t rls_dev_alloc(rls_ctx* ctx, void** p, size_t bytes);
+hipError_t rls_dev_free(rls_ctx* ctx, void* p);   // ctx may be null (or destroyed: pass null): synchronous hipFree
+hipError_t rls_pinned_alloc(void** p, size_t bytes);
+void rls_pinned_free(void* p);
+bool rls_ctx_alive(const rls_ctx* ctx);
+// The allocation calls of a plan's create / destroy function go to the context named by the innermost live scope on
+// this thread (null: the synchronous calls).
+struct rls_alloc_scope {
+  rls_ctx* prev;
+  explicit rls_alloc_scope(rls_ctx* ctx);
+  ~rls_alloc_scope();
+};
+hipError_t rls_scoped_malloc(void** p, size_t bytes);
+hipError_t rls_scoped_free(void* p);
 
 // Host-side waits poll (hipStreamQuery / hipEventQuery) instead of blocking.  A blocking wait sleeps on an interrupt and
 // on this stack now and then wakes up tens of milliseconds late (tools/stall_probe2.py: wall 123 ms for 75 ms of
@@ -337,6 +363,44 @@ __device__ static inline void block_sum3_n(double& a, double& b, double& c, doub
   c = sc;
 }
 
+// The same two reductions WITHOUT their leading barrier, for callers that alternate between two disjoint scratch areas and
+// have a workgroup barrier between any read of an area and the next write to it (the resident kernels: sum3 in slots
+// [0,8) [16,24) [32,40) of `smem`, the single sum in slots [8,16) -- each is rewritten only after the OTHER one's barrier).
+template <int NW>
+__device__ static inline void block_sum3_nolead(double& a, double& b, double& c, double* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  if (lane == 0) {
+    smem[w] = a;
+    smem[16 + w] = b;
+    smem[32 + w] = c;
+  }
+  lds_barrier();
+  double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    sa += smem[i];
+    sb += smem[16 + i];
+    sc += smem[32 + i];
+  }
+  a = sa;
+  b = sb;
+  c = sc;
+}
+template <int NW>
+__device__ static inline double block_sum_nolead(double v, double* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = wave_sum(v);
+  if (lane == 0) smem[8 + w] = v;
+  lds_barrier();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) s += smem[8 + i];
+  return s;
+}
+
 // three sums with one barrier pair; `smem` needs 48 doubles
 __device__ static inline void block_sum3(double& a, double& b, double& c, double* smem) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -567,6 +631,35 @@ struct rls_cg_start {
 };
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
                                  int n_steps, unsigned spin_limit, const rls_cg_start& start = rls_cg_start());
+
+// ---- OptISTA / POGM as resident launches (normal.hip, pgm_resident_kernel; host side pgm.hip) ----------------------------
+// the 4-word device record of the deferred OptISTA / POGM sequences (rls_*_update_async): iteration count, `done`, ||res||
+struct pgm_state {
+  int iteration, done;
+  float res_norm, pad;
+};
+constexpr int RLS_PGM_MAX_IT = 48;  // iterations per resident launch: their coefficients travel as a kernel argument
+struct rls_pgm_coefs {
+  // per iteration, index-only scalars computed by the host in Float32 exactly as the reference does:
+  //   OptISTA (src/OptISTA.jl:170-204): {rho gamma, rho gamma lambda, -1/gamma, 1/gamma, -beta, 1 + alpha + beta, -alpha, 0}
+  //   POGM    (src/POGM.jl:183-210):    {rho, gamma lambda, c_y, c_x1, c_xo, c_z, 0, 0}
+  float c[RLS_PGM_MAX_IT][8];
+};
+struct rls_pgm_desc {
+  const void* A;
+  int64_t lda, M, N;
+  int kind;                 // 0 = OptISTA, 1 = POGM (restart = :none)
+  void *v0, *v1, *v2;       // loop-carried state: OptISTA x, y, z ; POGM x (operator input), y, z
+  void *o0, *res;           // written every iteration, never read: OptISTA zold ; POGM xold ; and state.res
+  const void* x0;
+  void *slab, *raw;         // partial rows [nwg][N]; N-vector scratch of the flat exchange
+  pgm_state* st;
+  float norm_x0, rel_tol;
+  int reg_kind, proj_kind;
+};
+bool rls_pgm_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
+int32_t rls_pgm_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_pgm_desc& D, const rls_pgm_coefs& C, void* sync,
+                                int n_steps, unsigned spin_limit);
 
 // Gram-mode CGNR pipeline (normal.hip): one launch per iteration, every buffer in two parities
 struct rls_gram_pipe {

@@ -14,6 +14,18 @@
 #include <mutex>
 #include <vector>
 
+
+// ---- allocation: the plans' scratch comes from the stream-ordered pool of the context named by the innermost
+// rls_alloc_scope of the calling thread; the pinned status mirrors from the process-wide free list (rls_common.hpp) ----
+template <typename T>
+static hipError_t dmalloc(T** p, size_t bytes) { return rls_scoped_malloc(reinterpret_cast<void**>(p), bytes); }
+static hipError_t dfree(void* p) { return rls_scoped_free(p); }
+template <typename T>
+static hipError_t hmalloc(T** p, size_t bytes) { return rls_pinned_alloc(reinterpret_cast<void**>(p), bytes); }
+static void hfree(void* p) { rls_pinned_free(p); }
+// the context a plan allocated from, if it still exists (plans may outlive their context in a garbage-collected host)
+static rls_ctx* alloc_ctx_of(rls_ctx* ctx) { return rls_ctx_alive(ctx) ? ctx : nullptr; }
+
 // ---------------------------------------------------------------------------------------------
 // operator
 // ---------------------------------------------------------------------------------------------
@@ -117,6 +129,7 @@ static inline int pipe_cur_hint(const rls_ctx* ctx, int k) {
 // ---------------------------------------------------------------------------------------------
 struct rls_cgnr {
   rls_operator* op;
+  rls_ctx* actx;  // the context whose pool the plan's scratch came from (checked alive before it is used in destroy)
   int device;
   void *x, *r, *p, *v;
   cgnr_scalars* sc;    // device
@@ -243,10 +256,10 @@ static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_p
 }
 // the sync block of a plan (zeroed once: the sticky word starts at 0) and the pinned mirror of its three flag words
 static hipError_t resident_alloc(rls_ctx* ctx, const rls_operator* op, void** rsync, unsigned** rsync_h) {
-  hipError_t e = hipMalloc(rsync, rls_resident_sync_alloc_bytes(op->dtype, op->N));
+  hipError_t e = dmalloc(rsync, rls_resident_sync_alloc_bytes(op->dtype, op->N));
   if (e == hipSuccess) e = hipMemsetAsync(*rsync, 0, rls_cgnr_resident_sync_bytes(), ctx->stream);
   if (e == hipSuccess && rsync_h && !*rsync_h) {
-    e = hipHostMalloc((void**)rsync_h, 4 * sizeof(unsigned), hipHostMallocDefault);
+    e = hmalloc(rsync_h, 4 * sizeof(unsigned));
     if (e == hipSuccess) memset(*rsync_h, 0, 4 * sizeof(unsigned));
   }
   return e;
@@ -512,6 +525,7 @@ static int32_t cgnr_effective_iterations(rls_cgnr* s, int32_t iterations) {
 // ---------------------------------------------------------------------------------------------
 struct rls_fista {
   rls_operator* op;
+  rls_ctx* actx;
   int device;
   void* buf[2];  // x / xold, swapped by iteration parity: state.x == buf[iteration & 1]
   void *x0, *res;
@@ -881,6 +895,7 @@ struct cg_scalars {
 
 struct rls_cg {
   rls_operator* op;
+  rls_ctx* actx;
   int device;
   void *u, *r, *c;
   cg_scalars* sc;
@@ -1282,9 +1297,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const E* __restrict__ A, int6
 // ---------------------------------------------------------------------------------------------
 template <typename S>
 static int32_t alloc_scalars(rls_ctx* ctx, S** d, S** h, int n = 1) {
-  RLS_HIP(ctx, hipMalloc((void**)d, sizeof(S) * n));
+  RLS_HIP(ctx, dmalloc((void**)d, sizeof(S) * n));
   RLS_HIP(ctx, hipMemsetAsync(*d, 0, sizeof(S) * n, ctx->stream));
-  RLS_HIP(ctx, hipHostMalloc((void**)h, sizeof(S) * n, hipHostMallocDefault));
+  RLS_HIP(ctx, hmalloc(h, sizeof(S) * n));
   memset(*h, 0, sizeof(S) * n);
   return 0;
 }
@@ -1334,6 +1349,7 @@ constexpr int ADMM_REC = 8;  // floats per log record: Delta, sk, eps_pri, rk, e
 
 struct rls_admm {
   rls_cg* cg;
+  rls_ctx* actx;
   int device;
   rls_admm_params P;
   bool ready;
@@ -1767,6 +1783,7 @@ int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, c
   if (!out || !rls_dtype_ok(dtype) || M < 0 || N <= 0) return rls_fail(ctx, RLS_E_INVALID, "operator_create: bad argument");
   if (A && (M <= 0 || lda < M)) return rls_fail(ctx, RLS_E_INVALID, "operator_create: bad shape/lda");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_alloc_scope alloc_scope(ctx);
   rls_operator* op = new rls_operator();
   op->ctx = ctx;
   op->dtype = dtype;
@@ -1779,11 +1796,11 @@ int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, c
   op->t = nullptr;
   op->slab = nullptr;
   if (A) {
-    hipError_t e = hipMalloc(&op->t, (size_t)M * rls_elem_size(dtype));
+    hipError_t e = dmalloc(&op->t, (size_t)M * rls_elem_size(dtype));
     const size_t ws = rls_normal_fused_workspace(dtype, M, N, A, lda);
-    if (e == hipSuccess && ws > 0) e = hipMalloc(&op->slab, ws);
+    if (e == hipSuccess && ws > 0) e = dmalloc(&op->slab, ws);
     if (e != hipSuccess) {
-      if (op->t) hipFree(op->t);
+      if (op->t) dfree(op->t);
       delete op;
       return rls_fail(ctx, (int32_t)e, "operator_create: hipMalloc failed");
     }
@@ -1802,8 +1819,9 @@ int32_t rls_operator_set_gram(rls_operator* op, const void* AHA, int64_t ld) {
 
 int32_t rls_operator_destroy(rls_operator* op) {
   if (!op) return RLS_E_INVALID;
-  if (op->slab) hipFree(op->slab);
-  if (op->t) hipFree(op->t);  // hipFree resolves the owning device from the pointer
+  rls_alloc_scope alloc_scope(alloc_ctx_of(op->ctx));
+  if (op->slab) dfree(op->slab);
+  if (op->t) dfree(op->t);  // hipFree resolves the owning device from the pointer
   delete op;
   return 0;
 }
@@ -1842,11 +1860,12 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
   if (ctx->tune.batched_mfma && N <= 65535 * 16 && rls_skinny_ok(dtype, M, N, A, lda)) {
     // matrix cores: A^H T with T = A in 16-column panels (skinny.hip); M x N scratch for the panels
     void* panels = nullptr;
-    RLS_HIP(ctx, hipMalloc(&panels, (size_t)M * (size_t)N * rls_elem_size(dtype)));
+    rls_alloc_scope alloc_scope(ctx);
+    RLS_HIP(ctx, dmalloc(&panels, (size_t)M * (size_t)N * rls_elem_size(dtype)));
     int32_t st = rls_skinny_gram(ctx, dtype, M, N, A, lda, G, ld, panels);
     if (st == 0) st = gram_hermitianize(ctx, dtype, N, G, ld);
     hipError_t e = rls_stream_wait(ctx->stream);  // setup path: the scratch is freed before returning
-    hipFree(panels);
+    dfree(panels);
     if (st == 0 && e != hipSuccess) st = rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
     return st;
   }
@@ -1871,7 +1890,9 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   if (nrhs > 1 && !skinny)
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR runs on the matrix cores: a matrix-free operator with M, N multiples of 16 "
                                             "(other shapes: one plan per column)");
+  rls_alloc_scope alloc_scope(ctx);
   rls_cgnr* s = new rls_cgnr();
+  s->actx = ctx;
   s->skinny = skinny;
   s->gram_pipe = false;
   s->v1 = nullptr;
@@ -1903,39 +1924,39 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   s->fallbacks = 0;
   s->requested = 0;
   const size_t sb = sizeof(cgnr_scalars) * (size_t)nrhs;
-  hipError_t e = hipMalloc((void**)&s->sc, sb);
+  hipError_t e = dmalloc(&s->sc, sb);
   if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sb, ctx->stream);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&s->sc_h, sb, hipHostMallocDefault);
+  if (e == hipSuccess) e = hmalloc(&s->sc_h, sb);
   if (e == hipSuccess) memset(s->sc_h, 0, sb);
   if (e == hipSuccess && op->slab) {  // scratch of the fused pipeline
     const size_t vb = (size_t)ldv * nrhs * rls_elem_size(op->dtype);
     const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double) * nrhs;
-    e = hipMalloc(&s->r1, vb);
-    if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
+    e = dmalloc(&s->r1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->p1, vb);
     if (e == hipSuccess) e = hipMemsetAsync(s->r1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->p1, 0, vb, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->dots, nd);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sb);
+    if (e == hipSuccess) e = dmalloc(&s->dots, nd);
+    if (e == hipSuccess) e = dmalloc(&s->scn, sb);
     if (e == hipSuccess) e = hipMemsetAsync(s->dots, 0, nd, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
     if (e == hipSuccess && nrhs > 1 && !skinny)
-      e = hipMalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
+      e = dmalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
   }
   if (e == hipSuccess && nrhs == 1 && op->slab && op->A && !op->G &&
       rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
     const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
     e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->rdots, db);
+    if (e == hipSuccess) e = dmalloc(&s->rdots, db);
     if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
   }
   if (e == hipSuccess && nrhs == 1 && op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
     const size_t nd = (size_t)2 * rls_gram_pipe_nwg(op->dtype, op->N) * 4 * sizeof(double);
-    if (!s->r1) e = hipMalloc(&s->r1, vb);
-    if (e == hipSuccess && !s->p1) e = hipMalloc(&s->p1, vb);
-    if (e == hipSuccess) e = hipMalloc(&s->v1, vb);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->gdots, nd);
-    if (e == hipSuccess && !s->scn) e = hipMalloc((void**)&s->scn, sb);
+    if (!s->r1) e = dmalloc(&s->r1, vb);
+    if (e == hipSuccess && !s->p1) e = dmalloc(&s->p1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->v1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->gdots, nd);
+    if (e == hipSuccess && !s->scn) e = dmalloc(&s->scn, sb);
     if (e == hipSuccess) e = hipMemsetAsync(s->r1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->p1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->v1, 0, vb, ctx->stream);
@@ -1951,10 +1972,10 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     size_t pb, tb, vb;
     rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
     s->half = rls_skinny_half(op->dtype, nrhs);
-    e = hipMalloc((void**)&s->Ppack, pb);
+    e = dmalloc(&s->Ppack, pb);
     if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
-    if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
-    if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
+    if (e == hipSuccess) e = dmalloc(&s->Tpack, tb);
+    if (e == hipSuccess) e = dmalloc(&s->Vpart, vb);
   }
   if (e != hipSuccess) {
     rls_cgnr_destroy(s);
@@ -1977,22 +1998,23 @@ int32_t rls_cgnr_create_batched(rls_operator* op, int32_t nrhs, void* X, void* R
 int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
-  if (s->r1) hipFree(s->r1);
-  if (s->p1) hipFree(s->p1);
-  if (s->dots) hipFree(s->dots);
-  if (s->scn) hipFree(s->scn);
-  if (s->slab_b) hipFree(s->slab_b);
-  if (s->v1) hipFree(s->v1);
-  if (s->gdots) hipFree(s->gdots);
-  if (s->Ppack) hipFree(s->Ppack);
-  if (s->Tpack) hipFree(s->Tpack);
-  if (s->Vpart) hipFree(s->Vpart);
-  if (s->rsync) hipFree(s->rsync);
-  if (s->rdots) hipFree(s->rdots);
-  if (s->rsync_h) hipHostFree(s->rsync_h);
-  if (s->sc) hipFree(s->sc);
-  if (s->sc_h) hipHostFree(s->sc_h);
+  if (s->r1) dfree(s->r1);
+  if (s->p1) dfree(s->p1);
+  if (s->dots) dfree(s->dots);
+  if (s->scn) dfree(s->scn);
+  if (s->slab_b) dfree(s->slab_b);
+  if (s->v1) dfree(s->v1);
+  if (s->gdots) dfree(s->gdots);
+  if (s->Ppack) dfree(s->Ppack);
+  if (s->Tpack) dfree(s->Tpack);
+  if (s->Vpart) dfree(s->Vpart);
+  if (s->rsync) dfree(s->rsync);
+  if (s->rdots) dfree(s->rdots);
+  if (s->rsync_h) hfree(s->rsync_h);
+  if (s->sc) dfree(s->sc);
+  if (s->sc_h) hfree(s->sc_h);
   delete s;
   return 0;
 }
@@ -2138,9 +2160,12 @@ static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps) {
     }
     return rls_gram_pipe_finish(ctx, dtype, P, n_steps & 1);
   }
-  if (cgnr_use_resident(s)) {
-    // ONE launch for the whole call: A stays in the register files, iterations are separated by two in-kernel
-    // grid-wide exchanges (normal.hip).  The arrival counters and flags are zeroed ahead of every launch.
+  // A resident launch pays for loading its slab of A (~10 us at the headline shape) before its first iteration: a call of
+  // ONE iteration -- the reference's solve! loop with callbacks, one iterate per call -- is cheaper on the two-launch
+  // pipeline (bench.py other_paths, iterate_per_call_cadence: 40 us against 52 us per call, host synchronisation included)
+  if (cgnr_use_resident(s) && n_steps != 1) {
+    // ONE launch for the whole call: A stays in the register files, iterations are separated by an in-kernel
+    // grid-wide all-reduce (normal.hip).  The arrival counters and flags are zeroed ahead of every launch.
     if (n_steps == 0) return 0;
     const rls_cgnr_pipe P = cgnr_pipe_desc(s);
     s->resident_used = true;
@@ -2367,8 +2392,10 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   rls_ctx* ctx = op->ctx;
   if (!x || !x0 || !xold || !res || !out) return rls_fail(ctx, RLS_E_INVALID, "fista_create: null pointer");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_alloc_scope alloc_scope(ctx);
   rls_fista* s = new rls_fista();
   s->op = op;
+  s->actx = ctx;
   s->device = op->ctx->device;
   s->buf[0] = x;
   s->buf[1] = xold;
@@ -2386,44 +2413,44 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   s->res_raw1 = nullptr;
   s->use_gram = false;
   const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
-  hipError_t e = hipMalloc(&s->y, vb);
+  hipError_t e = dmalloc(&s->y, vb);
   const bool gram = op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg);
   if (e == hipSuccess && gram) {
-    e = hipMalloc(&s->res_raw1, vb);
+    e = dmalloc(&s->res_raw1, vb);
     if (e == hipSuccess) e = hipMemsetAsync(s->res_raw1, 0, vb, ctx->stream);
   }
   if (e == hipSuccess && (op->slab || gram)) {
-    e = hipMalloc(&s->y1, vb);
-    if (e == hipSuccess) e = hipMalloc(&s->res_raw, vb);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->scn, sizeof(fista_scalars));
+    e = dmalloc(&s->y1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->res_raw, vb);
+    if (e == hipSuccess) e = dmalloc(&s->scn, sizeof(fista_scalars));
     if (e == hipSuccess) e = hipMemsetAsync(s->y1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->res_raw, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sizeof(fista_scalars), ctx->stream);
   }
   if (e != hipSuccess) {
-    if (s->y) hipFree(s->y);
-    if (s->y1) hipFree(s->y1);
-    if (s->res_raw) hipFree(s->res_raw);
-    if (s->res_raw1) hipFree(s->res_raw1);
-    if (s->scn) hipFree(s->scn);
+    if (s->y) dfree(s->y);
+    if (s->y1) dfree(s->y1);
+    if (s->res_raw) dfree(s->res_raw);
+    if (s->res_raw1) dfree(s->res_raw1);
+    if (s->scn) dfree(s->scn);
     delete s;
     return rls_fail(ctx, (int32_t)e, "fista_create: hipMalloc failed");
   }
   if ((op->slab && op->A && !op->G && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) ||
       (gram && rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg))) {
     if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) != hipSuccess) {
-      if (s->rsync) hipFree(s->rsync);
+      if (s->rsync) dfree(s->rsync);
       s->rsync = nullptr;  // resident mode is an optimisation: without its scratch the pipeline runs
       (void)hipGetLastError();
     }
   }
   int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
   if (st != 0) {
-    hipFree(s->y);
-    if (s->y1) hipFree(s->y1);
-    if (s->res_raw) hipFree(s->res_raw);
-    if (s->res_raw1) hipFree(s->res_raw1);
-    if (s->scn) hipFree(s->scn);
+    dfree(s->y);
+    if (s->y1) dfree(s->y1);
+    if (s->res_raw) dfree(s->res_raw);
+    if (s->res_raw1) dfree(s->res_raw1);
+    if (s->scn) dfree(s->scn);
     delete s;
     return st;
   }
@@ -2434,20 +2461,21 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
 int32_t rls_fista_destroy(rls_fista* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
-  hipFree(s->y);
-  if (s->y1) hipFree(s->y1);
-  if (s->res_raw) hipFree(s->res_raw);
-  if (s->res_raw1) hipFree(s->res_raw1);
-  if (s->scn) hipFree(s->scn);
-  if (s->Ypack) hipFree(s->Ypack);
-  if (s->Tpack) hipFree(s->Tpack);
-  if (s->Vpart) hipFree(s->Vpart);
-  if (s->scb_h) hipHostFree(s->scb_h);
-  if (s->rsync) hipFree(s->rsync);
-  if (s->rsync_h) hipHostFree(s->rsync_h);
-  hipFree(s->sc);
-  hipHostFree(s->sc_h);
+  dfree(s->y);
+  if (s->y1) dfree(s->y1);
+  if (s->res_raw) dfree(s->res_raw);
+  if (s->res_raw1) dfree(s->res_raw1);
+  if (s->scn) dfree(s->scn);
+  if (s->Ypack) dfree(s->Ypack);
+  if (s->Tpack) dfree(s->Tpack);
+  if (s->Vpart) dfree(s->Vpart);
+  if (s->scb_h) hfree(s->scb_h);
+  if (s->rsync) dfree(s->rsync);
+  if (s->rsync_h) hfree(s->rsync_h);
+  dfree(s->sc);
+  hfree(s->sc_h);
   delete s;
   return 0;
 }
@@ -2557,8 +2585,10 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   if (op->G || !op->A || !ctx->tune.batched_mfma || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda))
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched FISTA needs a matrix-free operator with 16-aligned M, N (matrix-core path)");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_alloc_scope alloc_scope(ctx);
   rls_fista* s = new rls_fista();
   s->op = op;
+  s->actx = ctx;
   s->device = ctx->device;
   s->buf[0] = x;
   s->buf[1] = xold;
@@ -2579,23 +2609,23 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
   s->half = rls_skinny_half(op->dtype, nrhs);
   const size_t yb = (size_t)ldv * nrhs * rls_elem_size(op->dtype);
-  hipError_t e = hipMalloc(&s->y, yb);
-  if (e == hipSuccess) e = hipMalloc((void**)&s->Ypack, pb);
+  hipError_t e = dmalloc(&s->y, yb);
+  if (e == hipSuccess) e = dmalloc(&s->Ypack, pb);
   if (e == hipSuccess) e = hipMemsetAsync(s->Ypack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
-  if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
-  if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
-  if (e == hipSuccess) e = hipMalloc((void**)&s->sc, sizeof(fista_scalars) * nrhs);
+  if (e == hipSuccess) e = dmalloc(&s->Tpack, tb);
+  if (e == hipSuccess) e = dmalloc(&s->Vpart, vb);
+  if (e == hipSuccess) e = dmalloc(&s->sc, sizeof(fista_scalars) * nrhs);
   if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sizeof(fista_scalars) * nrhs, ctx->stream);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&s->scb_h, sizeof(fista_scalars) * nrhs, hipHostMallocDefault);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&s->sc_h, sizeof(fista_scalars), hipHostMallocDefault);
+  if (e == hipSuccess) e = hmalloc(&s->scb_h, sizeof(fista_scalars) * nrhs);
+  if (e == hipSuccess) e = hmalloc(&s->sc_h, sizeof(fista_scalars));
   if (e != hipSuccess) {
-    if (s->y) hipFree(s->y);
-    if (s->Ypack) hipFree(s->Ypack);
-    if (s->Tpack) hipFree(s->Tpack);
-    if (s->Vpart) hipFree(s->Vpart);
-    if (s->sc) hipFree(s->sc);
-    if (s->scb_h) hipHostFree(s->scb_h);
-    if (s->sc_h) hipHostFree(s->sc_h);
+    if (s->y) dfree(s->y);
+    if (s->Ypack) dfree(s->Ypack);
+    if (s->Tpack) dfree(s->Tpack);
+    if (s->Vpart) dfree(s->Vpart);
+    if (s->sc) dfree(s->sc);
+    if (s->scb_h) hfree(s->scb_h);
+    if (s->sc_h) hfree(s->sc_h);
     delete s;
     return rls_fail(ctx, (int32_t)e, "fista_create_batched: allocation failed");
   }
@@ -2711,7 +2741,7 @@ static int32_t fista_step_impl(rls_fista* s, int32_t n_steps) {
     s->enq += n_steps;
     return rls_fista_gram_finish(ctx, dtype, P, n_steps & 1);
   }
-  if (fista_use_resident(s)) {
+  if (fista_use_resident(s) && n_steps != 1) {  // (a single iteration: the pipeline, as in rls_cgnr_step)
     // the whole call as ONE launch, A held in registers (normal.hip, fista_resident_kernel)
     if (n_steps == 0) return 0;
     const rls_fista_pipe P = fista_pipe_desc(s);
@@ -2826,8 +2856,10 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   rls_ctx* ctx = op->ctx;
   if (!u || !r || !c || !out) return rls_fail(ctx, RLS_E_INVALID, "cg_create: null pointer");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_alloc_scope alloc_scope(ctx);
   rls_cg* s = new rls_cg();
   s->op = op;
+  s->actx = ctx;
   s->device = op->ctx->device;
   s->u = u;
   s->r = r;
@@ -2846,13 +2878,13 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   if (op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
     const size_t nd = (size_t)2 * rls_gram_pipe_nwg(op->dtype, op->N) * 4 * sizeof(double);
-    hipError_t e = hipMalloc(&s->r1, vb);
-    if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
-    if (e == hipSuccess) e = hipMalloc(&s->v1, vb);
+    hipError_t e = dmalloc(&s->r1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->p1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->v1, vb);
     if (e == hipSuccess) e = hipMemsetAsync(s->v1, 0, vb, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->gdots, nd);
+    if (e == hipSuccess) e = dmalloc(&s->gdots, nd);
     if (e == hipSuccess) e = hipMemsetAsync(s->gdots, 0, nd, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->pscn, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = dmalloc(&s->pscn, sizeof(cgnr_scalars));
     if (e == hipSuccess) e = hipMemsetAsync(s->pscn, 0, sizeof(cgnr_scalars), ctx->stream);
     if (e != hipSuccess || alloc_scalars(ctx, &s->psc, &s->psc_h) != 0) {
       rls_cg_destroy(s);
@@ -2862,7 +2894,7 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
       if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) == hipSuccess) {
         s->gram_resident = true;
       } else {
-        if (s->rsync) hipFree(s->rsync);
+        if (s->rsync) dfree(s->rsync);
         s->rsync = nullptr;  // an optimisation only: the one-launch-per-iteration pipeline runs without it
         (void)hipGetLastError();
       }
@@ -2870,19 +2902,19 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   } else if (op->slab) {
     if (op->A && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
       const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
-      if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) != hipSuccess || hipMalloc((void**)&s->rdots, db) != hipSuccess) {
-        if (s->rsync) hipFree(s->rsync);
+      if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) != hipSuccess || dmalloc(&s->rdots, db) != hipSuccess) {
+        if (s->rsync) dfree(s->rsync);
         s->rsync = nullptr;  // an optimisation only: the two-launch pipeline runs without it
         (void)hipGetLastError();
       }
     }
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
     const size_t nd = (size_t)((op->N + 15) / 16) * 4 * sizeof(double);
-    hipError_t e = hipMalloc(&s->r1, vb);
-    if (e == hipSuccess) e = hipMalloc(&s->p1, vb);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->dots, nd);
+    hipError_t e = dmalloc(&s->r1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->p1, vb);
+    if (e == hipSuccess) e = dmalloc(&s->dots, nd);
     if (e == hipSuccess) e = hipMemsetAsync(s->dots, 0, nd, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->pscn, sizeof(cgnr_scalars));
+    if (e == hipSuccess) e = dmalloc(&s->pscn, sizeof(cgnr_scalars));
     if (e == hipSuccess) e = hipMemsetAsync(s->pscn, 0, sizeof(cgnr_scalars), ctx->stream);
     if (e != hipSuccess || alloc_scalars(ctx, &s->psc, &s->psc_h) != 0) {
       rls_cg_destroy(s);
@@ -2902,8 +2934,10 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
   if (!op->A || op->G || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda))
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "cg_create_batched: needs a matrix-free operator with M, N multiples of 16");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_alloc_scope alloc_scope(ctx);
   rls_cg* s = new rls_cg();
   s->op = op;
+  s->actx = ctx;
   s->device = ctx->device;
   s->u = U;
   s->r = R;
@@ -2920,10 +2954,10 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
   size_t pb, tb, vb;
   rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
   s->half = rls_skinny_half(op->dtype, nrhs);
-  hipError_t e = hipMalloc((void**)&s->Ppack, pb);
+  hipError_t e = dmalloc(&s->Ppack, pb);
   if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
-  if (e == hipSuccess) e = hipMalloc((void**)&s->Tpack, tb);
-  if (e == hipSuccess) e = hipMalloc(&s->Vpart, vb);
+  if (e == hipSuccess) e = dmalloc(&s->Tpack, tb);
+  if (e == hipSuccess) e = dmalloc(&s->Vpart, vb);
   if (e != hipSuccess || alloc_scalars(ctx, &s->sc, &s->sc_h, nrhs) != 0) {
     rls_cg_destroy(s);
     return rls_fail(ctx, (int32_t)e, "cg_create_batched: allocation failed");
@@ -2935,23 +2969,24 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
 int32_t rls_cg_destroy(rls_cg* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
-  if (s->Ppack) hipFree(s->Ppack);
-  if (s->Tpack) hipFree(s->Tpack);
-  if (s->Vpart) hipFree(s->Vpart);
-  if (s->rsync) hipFree(s->rsync);
-  if (s->rdots) hipFree(s->rdots);
-  if (s->rsync_h) hipHostFree(s->rsync_h);
-  if (s->r1) hipFree(s->r1);
-  if (s->p1) hipFree(s->p1);
-  if (s->dots) hipFree(s->dots);
-  if (s->v1) hipFree(s->v1);
-  if (s->gdots) hipFree(s->gdots);
-  if (s->psc) hipFree(s->psc);
-  if (s->pscn) hipFree(s->pscn);
-  if (s->psc_h) hipHostFree(s->psc_h);
-  if (s->sc) hipFree(s->sc);
-  if (s->sc_h) hipHostFree(s->sc_h);
+  if (s->Ppack) dfree(s->Ppack);
+  if (s->Tpack) dfree(s->Tpack);
+  if (s->Vpart) dfree(s->Vpart);
+  if (s->rsync) dfree(s->rsync);
+  if (s->rdots) dfree(s->rdots);
+  if (s->rsync_h) hfree(s->rsync_h);
+  if (s->r1) dfree(s->r1);
+  if (s->p1) dfree(s->p1);
+  if (s->dots) dfree(s->dots);
+  if (s->v1) dfree(s->v1);
+  if (s->gdots) dfree(s->gdots);
+  if (s->psc) dfree(s->psc);
+  if (s->pscn) dfree(s->pscn);
+  if (s->psc_h) hfree(s->psc_h);
+  if (s->sc) dfree(s->sc);
+  if (s->sc_h) hfree(s->sc_h);
   delete s;
   return 0;
 }
@@ -3099,8 +3134,10 @@ int32_t rls_admm_create(rls_cg* cg, rls_admm** out) {
   rls_ctx* ctx = cg->op->ctx;
   if (!out) return rls_fail(ctx, RLS_E_INVALID, "admm_create: null out");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_alloc_scope alloc_scope(ctx);
   rls_admm* a = new rls_admm();
   a->cg = cg;
+  a->actx = ctx;
   a->device = ctx->device;
   a->ready = false;
   a->log = a->log_h = nullptr;
@@ -3119,10 +3156,11 @@ int32_t rls_admm_create(rls_cg* cg, rls_admm** out) {
 int32_t rls_admm_destroy(rls_admm* a) {
   if (!a) return RLS_E_INVALID;
   hipSetDevice(a->device);
-  if (a->log) hipFree(a->log);
-  if (a->log_h) hipHostFree(a->log_h);
-  hipFree(a->sc);
-  hipHostFree(a->sc_h);
+  rls_alloc_scope alloc_scope(alloc_ctx_of(a->actx));
+  if (a->log) dfree(a->log);
+  if (a->log_h) hfree(a->log_h);
+  dfree(a->sc);
+  hfree(a->sc_h);
   delete a;
   return 0;
 }
@@ -3156,14 +3194,15 @@ int32_t rls_admm_init(rls_admm* a, const rls_admm_params* p) {
   if (p->proj_kind != RLS_PROJ_NONE && p->proj_kind != RLS_PROJ_REAL && p->proj_kind != RLS_PROJ_POSITIVE)
     return rls_fail(ctx, RLS_E_INVALID, "admm_init: bad proj_kind");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_alloc_scope alloc_scope(ctx);
   const int cap = p->iterations > 0 ? p->iterations : 1;
   if (cap > a->log_cap) {
-    if (a->log) hipFree(a->log);
-    if (a->log_h) hipHostFree(a->log_h);
+    if (a->log) dfree(a->log);
+    if (a->log_h) hfree(a->log_h);
     a->log = a->log_h = nullptr;
     a->log_cap = 0;
-    RLS_HIP(ctx, hipMalloc((void**)&a->log, sizeof(float) * ADMM_REC * cap * a->nrhs));
-    RLS_HIP(ctx, hipHostMalloc((void**)&a->log_h, sizeof(float) * ADMM_REC * cap * a->nrhs, hipHostMallocDefault));
+    RLS_HIP(ctx, dmalloc(&a->log, sizeof(float) * ADMM_REC * cap * a->nrhs));
+    RLS_HIP(ctx, hmalloc(&a->log_h, sizeof(float) * ADMM_REC * cap * a->nrhs));
     a->log_cap = cap;
   }
   a->P = *p;

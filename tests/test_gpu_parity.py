@@ -363,7 +363,10 @@ def test_cgnr_gram_mode_and_float32_oracle(rls, ctx):
 @pytest.mark.parametrize("pipe", [2, 1, 0])
 @pytest.mark.parametrize("dt,M,N,lam,iters", [(np.complex64, 4096, 2048, 0.0, 32), (np.float32, 600, 256, 1e-2, 12),
                                               (np.complex64, 90, 46, 0.1, 9), (np.float32, 5000, 4096, 0.0, 6),
-                                              (np.complex64, 1500, 1024, 1e-3, 12), (np.float32, 3000, 2048, 0.0, 10)])
+                                              (np.complex64, 1500, 1024, 1e-3, 12), (np.float32, 3000, 2048, 0.0, 10),
+                                              # ComplexF32 N in (2048, 4096]: cgnr_gram_kernel<c32, 4, 32, 8> (32 rows of AHA per
+                                              # lane beside 8 owned elements of four vectors: the one Gram kernel that spills)
+                                              (np.complex64, 3200, 3072, 1e-3, 8)])
 def test_cgnr_gram_pipeline_iterates(rls, ctx, dt, M, N, lam, iters, pipe):
     """Gram mode (AHA = A' * A explicit, the constructor default for a dense Matrix, src/CGNR.jl:49).  pipe 2: the
     resident kernel where AHA fits the register files (N <= 2048 CF32, N <= 4096 F32, ragged N included: the whole step
@@ -2009,9 +2012,17 @@ def test_cgnr_resident_kernel(rls, ctx, dt, M, N, lam):
             parity(f"{tag}_r_it{it}", st.x0.to_host(), ref.r, ref32.r, scale=r0)
             parity(f"{tag}_p_it{it}", st.pl.to_host(), ref.p, ref32.p, scale=r0)
     assert rls.iterate(sol) is None and sol.state.iteration == iters
-    x_steps = sol.state.x.to_host()
+    # (a step call of ONE iteration -- what iterate() issues -- takes the two-launch pipeline since round 3: the gate above
+    #  covered that path; the resident kernel proper is what the calls below reach)
     x_once = rls.solve_(sol, bd).to_host()      # all 32 iterations in ONE launch
     x_again = rls.solve_(sol, bd).to_host()
+    parity(f"{tag}_one_launch", x_once, ref.x, ref32.x)
+    rls.init_(sol, bd)
+    for _ in range(4):                          # the same 32 iterations as four launches of 8
+        assert ctx.lib.rls_cgnr_step(sol.state._plan, 8) == 0
+    sol.state._refresh(ctx.lib)
+    x_steps = sol.state.x.to_host()
+    assert sol.state.iteration == iters
     assert np.array_equal(x_once, x_steps) and np.array_equal(x_once, x_again)
     # relTol: stops inside the launch, at the oracle's iteration
     tol = 1e-3
@@ -2155,14 +2166,22 @@ def test_fista_resident_kernel(rls, ctx, dt, M, N, restart):
         if it in (1, 2, 7, its):
             parity(f"{tag}_it{it}", sol.state.x.to_host(), ref.x, ref32.x)
     assert rls.iterate(sol) is None and sol.state.iteration == its
-    x_steps = sol.state.x.to_host()
     assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
+    # (iterate() = a step call of ONE iteration = the two-launch pipeline since round 3; the resident kernel proper below)
     x_once = rls.solve_(sol, bd).to_host()
     x_again = rls.solve_(sol, bd).to_host()
+    parity(f"{tag}_one_launch", x_once, ref.x, ref32.x)
+    rls.init_(sol, bd)
+    for n in (its // 3, its // 3, its - 2 * (its // 3)):   # the same iterations as three resident launches
+        assert ctx.lib.rls_fista_step(sol.state._plan, n) == 0
+    sol.state._refresh(ctx.lib)
+    x_steps = sol.state.x.to_host()
+    assert sol.state.iteration == its
     assert np.array_equal(x_once, x_steps) and np.array_equal(x_once, x_again)
     seen = []
     x_cb = rls.solve_(sol, bd, callbacks=lambda s_, i: seen.append(i)).to_host()
-    assert seen == list(range(its + 1)) and np.array_equal(x_cb, x_once)
+    assert seen == list(range(its + 1))
+    parity(f"{tag}_callbacks", x_cb, ref.x, ref32.x)
     ctx.tune(resident=0)
     try:
         assert ctx.lib.rls_fista_path(sol.state._plan, C.byref(path)) == 0 and path.value == 1

@@ -55,9 +55,6 @@ KNOWN_SPILLS = {
     r"cgnr_gram_kernel<c32, 4, 32, 8, (true|false)>": "Gram-mode CGNR, ComplexF32 N in (2048, 4096]: 8 owned elements of 4 vectors beside the slab",
     r"cgnr_pipe_a_kernel<c32, 4, 32, 8, (true|false), false, false>": "slab pipeline, ComplexF32 N in (2048, 4096], launch without a buffer hint "
                                                                        "(first node of a graph chunk): both (r, p) candidates in registers",
-    r"cgnr_resident_kernel<c32, 8, 32, 8, 1, false>": "resident CGNR, ragged ComplexF32 shape on the flat exchange (M not a multiple of 128)",
-    r"fista_resident_kernel<c32, 8, 32, 8, 2, false>": "resident FISTA, ragged ComplexF32 shape",
-    r"fista_resident_kernel<float, 4, 32, 8, 2, (true|false)>": "resident FISTA, Float32 N in (2048, 4096]",
 }
 
 
