@@ -199,6 +199,28 @@ int32_t rls_pogm_update_async(rls_ctx* ctx, int32_t dtype, int64_t n, void* res,
                               void* xold, void* z, float rho, float c_y, float c_x1, float c_xo, float c_z,
                               int32_t reg_kind, float thr, int32_t proj_kind, float norm_x0, float rel_tol,
                               void* state_d);
+/* OptISTA / POGM (restart = :none) with a whole block of iterations in ONE launch (A in the register files, the elementwise
+ * half of iterate redundantly in every workgroup -- the layout of rls_fista_step on its resident path).  The caller keeps
+ * the solver state exactly as for rls_optista_update_async / rls_pogm_update_async (vectors, the 4-word record state_d);
+ * the plan owns the launch's own scratch.  rls_pgm_create returns RLS_E_UNSUPPORTED (no error recorded) when the operator
+ * does not fit the resident form (not a dense matrix held in the register files, another dtype): the caller stays on the
+ * per-iteration entry points.
+ *   kind 0 = OptISTA: v0, v1, v2 = x, y, z; o0 = zold; coefs row = {step, thr, c_z, c_y, c_x, c_zn, c_zo, 0}
+ *   kind 1 = POGM:    v0, v1, v2 = xbuf, ybuf, z; o0 = xold; coefs row = {rho, thr, c_y, c_x1, c_xo, c_z, 0, 0}
+ * (the float arguments of the *_update_async calls, one row of 8 per iteration, n_steps <= 48 rows).  POGM swaps the roles
+ * of xbuf / ybuf once per iteration run, as the sequence of rls_pogm_update_async calls does: after an odd number of
+ * iterations the current x is in ybuf.  first_iteration = the count state_d holds when this launch starts; a launch that
+ * finds another count (an earlier launch of the sequence gave up) does nothing.  A launch that cannot get all its workgroups
+ * resident within the bounded wait changes nothing either: rls_pgm_lost (synchronises) reports such launches, the record
+ * shows fewer iterations than requested and the caller runs the rest through the per-iteration entry points; the plan
+ * answers RLS_E_UNSUPPORTED from then on. */
+typedef struct rls_pgm rls_pgm;
+int32_t rls_pgm_create(rls_operator* op, rls_pgm** out);
+int32_t rls_pgm_destroy(rls_pgm* plan);
+int32_t rls_pgm_step_resident(rls_pgm* plan, int32_t kind, int32_t n_steps, int32_t first_iteration, const float* coefs, void* v0,
+                              void* v1, void* v2, void* o0, void* res, const void* x0, int32_t reg_kind, int32_t proj_kind,
+                              float norm_x0, float rel_tol, void* state_d);
+int32_t rls_pgm_lost(rls_pgm* plan, int32_t* lost, int32_t* fallbacks_total);
 /* POGM with restart = :gradient, deferred: theta, sigma, gamma live in the device record (8 words: int32 iteration,
  * int32 done, float ||res||, pad, float theta, theta_old, sigma, gamma) and every launch derives its coefficients
  * from them in Float32 with the host's operation order (src/POGM.jl:183-201), applies the update, evaluates the

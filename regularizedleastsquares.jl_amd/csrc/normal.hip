@@ -2549,7 +2549,8 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
                                                                 E* res, const E* __restrict__ x0, E* raw_g, E* slab,
                                                                 pgm_state* st, rls_pgm_coefs CF, float norm_x0, float rel_tol,
                                                                 int reg_kind, int proj_kind, resident_sync* sync, int64_t Mc,
-                                                                int64_t N, int pair, int n_steps, unsigned spin_limit) {
+                                                                int64_t N, int pair, int n_steps, int first_it,
+                                                                unsigned spin_limit) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
   static_assert(owner_cfg<E, G, K, WV>::ok, "column-owner layout only");
@@ -2575,7 +2576,9 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
   chunk<E, NV> a[K];
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
-  if (done || n_steps <= 0) return;  // uniform
+  // uniform.  `iteration != first_it`: an earlier launch of this sequence was lost -- the coefficients of this one belong
+  // to later iterations, so it must not run (the host finishes the sequence launch by launch, pgm.hip)
+  if (done || n_steps <= 0 || iteration != first_it) return;
   owner_transpose<E, G, K, WV, FULL>(a, smem_raw, Mc, N, pair);
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab);
   const __amdgpu_buffer_rsrc_t o0_rs = __builtin_amdgcn_make_buffer_rsrc(o0, 0, 0xffffffff, 0x00020000);
@@ -3347,7 +3350,7 @@ static int32_t launch_pgm_resident(rls_ctx* ctx, const rls_pgm_desc& D, const rl
 #define RLS_LAUNCH_PGM(BB, FF, KK2)                                                                                              \
   hipLaunchKernelGGL((pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)D.A,    \
                      D.lda, (E*)D.v0, (E*)D.v1, (E*)D.v2, (E*)D.o0, (E*)D.res, (const E*)D.x0, (E*)D.raw, (E*)D.slab, D.st, CF,  \
-                     D.norm_x0, D.rel_tol, D.reg_kind, D.proj_kind, (resident_sync*)sync, Mc, D.N, pair, n_steps, spin_limit)
+                     D.norm_x0, D.rel_tol, D.reg_kind, D.proj_kind, (resident_sync*)sync, Mc, D.N, pair, n_steps, D.first_it, spin_limit)
     const bool two = resident_two_level_ok<E>(nwg, D.N, C::NT);
     if (D.kind == 0) {
       if (two) { if (full) RLS_LAUNCH_PGM(2, true, 0); else RLS_LAUNCH_PGM(2, false, 0); }
@@ -3384,7 +3387,7 @@ static bool pgm_resident_ok_typed(int device, int64_t M, int64_t N, const void* 
   if (!pick_cfg<E>(N, &c)) return false;
   bool ok = false;
 #define RLS_PGM_OK(GG, KK, WW) \
-  if (c.G == GG && c.K == KK && c.WV == WW) ok = owner_cfg_ok<E, GG, KK, WW>() && (KK == 16 || KK == 32);
+  if (c.G == GG && c.K == KK && c.WV == WW) ok = owner_cfg_ok<E, GG, KK, WW>() && (KK == 16 || KK == 32) && WW == 8 && !(elem<E>::cplx && GG == 4);
   RLS_FOR_EACH_CFG(RLS_PGM_OK)
 #undef RLS_PGM_OK
   return ok;

@@ -656,6 +656,7 @@ struct rls_pgm_desc {
   pgm_state* st;
   float norm_x0, rel_tol;
   int reg_kind, proj_kind;
+  int first_it;             // st->iteration this launch expects (it does nothing otherwise)
 };
 bool rls_pgm_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_pgm_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_pgm_desc& D, const rls_pgm_coefs& C, void* sync,

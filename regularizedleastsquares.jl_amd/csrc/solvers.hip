@@ -3051,6 +3051,114 @@ int32_t rls_cg_local_update(rls_cg* s, void* x) {
   return launch_status(ctx);
 }
 
+// ---------------------------------------------------------------------------------------------
+// OptISTA / POGM (restart = :none) as resident launches (kernel: normal.hip, pgm_resident_kernel)
+// ---------------------------------------------------------------------------------------------
+// The solver state (x, y, z, zold / xold, res, x0 and the 4-word record) belongs to the caller, as with the per-iteration
+// entry points rls_optista_update_async / rls_pogm_update_async; the plan owns what a resident launch needs on top: the
+// arrival counters and the N-vector of the flat exchange.
+struct rls_pgm {
+  rls_operator* op;
+  rls_ctx* actx;
+  int device;
+  void* rsync = nullptr;
+  unsigned* rsync_h = nullptr;
+  void* raw = nullptr;
+  bool resident_off = false;
+  int fallbacks = 0;
+};
+
+int32_t rls_pgm_create(rls_operator* op, rls_pgm** out) {
+  if (!op || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = op->ctx;
+  *out = nullptr;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(op->slab && op->A && !op->G && rls_pgm_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)))
+    return RLS_E_UNSUPPORTED;  // (not an error state: the caller keeps its launch-per-iteration sequence)
+  rls_alloc_scope alloc_scope(ctx);
+  rls_pgm* s = new rls_pgm();
+  s->op = op;
+  s->actx = ctx;
+  s->device = ctx->device;
+  hipError_t e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
+  if (e == hipSuccess) e = dmalloc(&s->raw, (size_t)op->N * rls_elem_size(op->dtype));
+  if (e != hipSuccess) {
+    if (s->rsync) dfree(s->rsync);
+    if (s->rsync_h) hfree(s->rsync_h);
+    if (s->raw) dfree(s->raw);
+    delete s;
+    (void)hipGetLastError();
+    return rls_fail(ctx, (int32_t)e, "pgm_create: hipMalloc failed");
+  }
+  *out = s;
+  return 0;
+}
+
+int32_t rls_pgm_destroy(rls_pgm* s) {
+  if (!s) return RLS_E_INVALID;
+  hipSetDevice(s->device);
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
+  dfree(s->rsync);
+  dfree(s->raw);
+  hfree(s->rsync_h);
+  delete s;
+  return 0;
+}
+
+int32_t rls_pgm_step_resident(rls_pgm* s, int32_t kind, int32_t n_steps, int32_t first_iteration, const float* coefs, void* v0,
+                              void* v1, void* v2, void* o0, void* res, const void* x0, int32_t reg_kind, int32_t proj_kind,
+                              float norm_x0, float rel_tol, void* state_d) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if ((kind != 0 && kind != 1) || n_steps < 0 || n_steps > RLS_PGM_MAX_IT || first_iteration < 0 || !coefs || !v0 || !v1 || !v2 ||
+      !o0 || !res || !x0 || !state_d || reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2 || proj_kind < RLS_PROJ_NONE ||
+      proj_kind > RLS_PROJ_POSITIVE || (kind == 0 && proj_kind != RLS_PROJ_NONE))
+    return rls_fail(ctx, RLS_E_INVALID, "pgm_step_resident: bad argument");
+  if (!(al16(v0) && al16(v1) && al16(v2) && al16(o0) && al16(res) && al16(x0)))
+    return rls_fail(ctx, RLS_E_INVALID, "pgm_step_resident: vectors must be 16-byte aligned");
+  if (s->resident_off || !ctx->tune.resident) return RLS_E_UNSUPPORTED;  // lost a launch earlier: per-iteration launches
+  if (n_steps == 0) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_pgm_coefs C;
+  memcpy(C.c, coefs, sizeof(float) * 8 * (size_t)n_steps);
+  rls_pgm_desc D;
+  D.A = s->op->A;
+  D.lda = s->op->lda;
+  D.M = s->op->M;
+  D.N = s->op->N;
+  D.kind = kind;
+  D.v0 = v0;
+  D.v1 = v1;
+  D.v2 = v2;
+  D.o0 = o0;
+  D.res = res;
+  D.x0 = x0;
+  D.slab = s->op->slab;
+  D.raw = s->raw;
+  D.st = (pgm_state*)state_d;
+  D.norm_x0 = norm_x0;
+  D.rel_tol = rel_tol;
+  D.reg_kind = reg_kind;
+  D.proj_kind = proj_kind;
+  D.first_it = first_iteration;
+  return resident_chain(ctx, s->rsync, [&]() {
+    return rls_pgm_resident_launch(ctx, s->op->dtype, D, C, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+  });
+}
+
+// after the launches of a sequence: how many of them gave up (bounded wait; they changed nothing).  Synchronises.
+int32_t rls_pgm_lost(rls_pgm* s, int32_t* lost, int32_t* fallbacks_total) {
+  if (!s || !lost) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
+  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  *lost = (int32_t)resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks);
+  if (fallbacks_total) *fallbacks_total = s->fallbacks;
+  return 0;
+}
+
 int32_t rls_cg_path(rls_cg* s, int32_t* out) {
   if (!s || !out) return RLS_E_INVALID;
   const rls_ctx* ctx = s->op->ctx;

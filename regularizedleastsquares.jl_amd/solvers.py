@@ -1062,6 +1062,14 @@ class OptISTA(AbstractProximalGradientSolver):
             return
         ctx = st.x.ctx
         lib, h = ctx.lib, ctx.handle
+        if _pgm_plan(self) is not None:
+            # whole blocks of iterations as single launches, A in the register files (rls_pgm_step_resident)
+            def row(st):
+                a = self._update_args(st, fus, *self._coefficients(st))
+                return (a[9], a[11]) + a[12:17], (st.theta, st.thetaold)
+            _pgm_resident(self, st, 0, row, ("theta", "thetaold"), (st.x, st.y, st.z, st.zold), fus)
+            if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
+                return
         rec = _pgm_record(st, ctx)
         thetas = [(st.theta, st.thetaold)]
         for _ in range(st.iteration, self.iterations):
@@ -1090,6 +1098,97 @@ def _pgm_record(st, ctx):
 def _pgm_fetch(rec):
     raw = rec.to_host()  # synchronises
     return int(raw[:1].view(np.int32)[0]), float(raw[2])
+
+
+_PGM_BLOCK = 48   # iterations per resident launch (RLS_PGM_MAX_IT; even, so POGM's buffer roles are the same at every block start)
+
+
+def _pgm_plan(solver):
+    """the resident-launch plan of an OptISTA / POGM solver over a dense operator (None: the operator does not fit, or a launch
+    was lost earlier and the plan retired itself)"""
+    op = solver._op
+    if not isinstance(op, OperatorHandle):
+        return None
+    cached = getattr(solver, "_pgm", None)
+    if cached is None or cached[0] is not op:
+        ctx = op.ctx
+        out = C.c_void_p()
+        rc = ctx.lib.rls_pgm_create(op.handle, C.byref(out))
+        if rc == -2:
+            plan = None
+        else:
+            check(ctx.handle, rc, "rls_pgm_create")
+            plan = _PgmPlan(ctx, out)
+        solver._pgm = cached = (op, plan)
+    plan = cached[1]
+    return plan if plan is not None and not plan.off else None
+
+
+class _PgmPlan:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle, self.off, self.fallbacks = ctx, handle, False, 0
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ctx.lib.rls_pgm_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+def _pgm_resident(solver, st, kind, row, names, vecs, fus):
+    """Run the remaining iterations of `st` as resident launches of up to _PGM_BLOCK iterations.  `row(st)` advances the
+    index-only scalars of `st` by one iteration and returns (the 7 / 6 coefficient floats of the per-iteration entry point,
+    the values of `names` after it).  On return st.iteration, rel_res_norm, the `names` scalars and (POGM) the x / y
+    references describe what the device actually did: everything requested, fewer because the stopping test fired, or fewer
+    because a launch could not become resident (then the plan retires and the caller continues launch by launch)."""
+    plan = _pgm_plan(solver)
+    ctx = st.x.ctx
+    lib = ctx.lib
+    first = st.iteration
+    start = tuple(getattr(st, n) for n in names)
+    # the table depends on the iteration index and the scalars below only: a repeated solve reuses it
+    key = (kind, first, solver.iterations, start, float(st.rho), float(solver.reg.lam), getattr(st, "sigma", None),
+           getattr(st, "theta_n", None))
+    cached = getattr(solver, "_pgm_table", None)
+    if cached is not None and cached[0] == key:
+        coefs, hist = cached[1], cached[2]
+    else:
+        hist, rows = [start], []
+        for _ in range(first, solver.iterations):
+            r, after = row(st)
+            st.iteration += 1
+            rows.append(tuple(r) + (0.0,) * (8 - len(r)))
+            hist.append(after)
+        coefs = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, 8)
+        solver._pgm_table = (key, coefs, hist)
+    rows = coefs
+    rec = _pgm_record(st, ctx)
+    v0, v1, v2, o0 = vecs
+    done_launch = 0
+    for off in range(0, len(rows), _PGM_BLOCK):
+        n = min(_PGM_BLOCK, len(rows) - off)
+        rc = lib.rls_pgm_step_resident(plan.handle, kind, n, off, coefs[off:].ctypes.data_as(C.POINTER(C.c_float)), v0.ptr, v1.ptr,
+                                       v2.ptr, o0.ptr, st.res.ptr, st.x0.ptr, fus[0], fus[1] if kind == 1 else 0,
+                                       float(st.norm_x0), float(st.relTol), rec.ptr)
+        if rc == -2:
+            break
+        check(ctx.handle, rc, "rls_pgm_step_resident")
+        done_launch += 1
+    lost, total = C.c_int32(0), C.c_int32(0)
+    if done_launch:
+        check(ctx.handle, lib.rls_pgm_lost(plan.handle, C.byref(lost), C.byref(total)), "rls_pgm_lost")
+    if lost.value:   # (RLS_E_UNSUPPORTED without a lost launch: resident mode is switched off on the context, nothing to retire)
+        plan.off = True
+        plan.fallbacks = total.value
+    done_its, res_norm = _pgm_fetch(rec)
+    st.iteration = first + done_its
+    for n, v in zip(names, hist[done_its]):
+        setattr(st, n, v)
+    if done_its:
+        st.rel_res_norm = res_norm / st.norm_x0
+    return done_its
 
 
 class POGM(AbstractProximalGradientSolver):
@@ -1255,28 +1354,44 @@ class POGM(AbstractProximalGradientSolver):
                 st.rel_res_norm = float(raw[2]) / st.norm_x0
                 st.theta, st.thetaold, st.sigma, st.gamma = (float(v) for v in raw[4:8])
             return
-        rec = _pgm_record(st, ctx)
         rho = f32(st.rho)
-        bufs = (st.x, st.y)
-        hist = [(st.theta, st.thetaold, st.gamma)]
-        first = st.iteration
-        for k in range(first, self.iterations):
+
+        def coefficients(st):
+            """(rho, c_y, c_x1, c_xo, c_z, thr) of one iteration, advancing theta / gamma   (src/POGM.jl:183-201, restart == :none)"""
             tho = f32(st.theta)
             st.thetaold = float(tho)
-            th = (f32(1) + np.sqrt(f32(1) + f32(4) * tho * tho)) / f32(2)  # :183-187 (restart == :none)
+            th = (f32(1) + np.sqrt(f32(1) + f32(4) * tho * tho)) / f32(2)
             st.theta = float(th)
             alpha = (tho - f32(1)) / th
             beta = f32(st.sigma) * tho / th
             gamma_old = f32(st.gamma)
             gamma = rho * (f32(2) * tho + th - f32(1)) / th
             st.gamma = float(gamma)
+            return (float(rho), float(-alpha), float(f32(1) + alpha + beta), -float(beta + rho * alpha / gamma_old),
+                    float(rho * alpha / gamma_old), float(gamma * f32(self.reg.lam)))
+
+        if _pgm_plan(self) is not None:
+            # whole blocks of iterations as single launches, A in the register files (rls_pgm_step_resident)
+            def row(st):
+                c = coefficients(st)
+                return (c[0], c[5]) + c[1:5], (st.theta, st.thetaold, st.gamma)
+            bufs = (st.x, st.y)
+            done_its = _pgm_resident(self, st, 1, row, ("theta", "thetaold", "gamma"), (st.x, st.y, st.z, st.xold), fus)
+            st.x, st.y = bufs if done_its % 2 == 0 else bufs[::-1]
+            if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
+                return
+        rec = _pgm_record(st, ctx)
+        bufs = (st.x, st.y)
+        hist = [(st.theta, st.thetaold, st.gamma)]
+        first = st.iteration
+        for k in range(first, self.iterations):
+            c = coefficients(st)
             hist.append((st.theta, st.thetaold, st.gamma))
             xb, yb = bufs if (k - first) % 2 == 0 else bufs[::-1]
             check(h, lib.rls_operator_mul_normal_skip(self._op.handle, xb.ptr, st.res.ptr, rec.ptr + 4), "rls_operator_mul_normal_skip")
             check(h, lib.rls_pogm_update_async(
-                h, xb.code, xb.n, st.res.ptr, st.x0.ptr, xb.ptr, yb.ptr, st.xold.ptr, st.z.ptr, float(rho), float(-alpha),
-                float(f32(1) + alpha + beta), -float(beta + rho * alpha / gamma_old), float(rho * alpha / gamma_old), fus[0],
-                float(gamma * f32(self.reg.lam)), fus[1], float(st.norm_x0), float(st.relTol), rec.ptr), "rls_pogm_update_async")
+                h, xb.code, xb.n, st.res.ptr, st.x0.ptr, xb.ptr, yb.ptr, st.xold.ptr, st.z.ptr, c[0], c[1], c[2], c[3], c[4],
+                fus[0], c[5], fus[1], float(st.norm_x0), float(st.relTol), rec.ptr), "rls_pogm_update_async")
         done_its, res_norm = _pgm_fetch(rec)
         st.iteration = first + done_its
         st.theta, st.thetaold, st.gamma = hist[done_its]

@@ -1633,6 +1633,8 @@ def test_optista_pogm_deferred_run_equals_stepwise(rls, ctx, name):
         assert seen == list(range(ref.iteration + 1))
         if extra:  # two different kernels evaluate the same update: the compiler may fuse a*b + c*d either way round
             assert rel(x_cb, x) < 2e-6 and sol.state.theta == th_deferred
+        elif getattr(sol, "_pgm", (None, None))[1] is not None:  # resident launches sum AHA x in another order
+            assert rel(x_cb, x) < 2e-5
         else:
             assert np.array_equal(x_cb, x)
 
@@ -2129,6 +2131,116 @@ def test_resident_solvers_survive_a_co_tenant(rls, ctx):
             assert fallbacks >= 1, f"{name}: the co-tenant did not displace the resident launch"
             assert iteration == ref.iteration
             parity(f"co_tenant_{name}", x, ref.x, lambda: (lambda o: (O.solve(o, b), o.x)[1])(make(O, A)))
+    finally:
+        ctx.tune(resident_spin=100000)
+        _fresh_resident_ctx(ctx)
+        other.close()
+
+
+@pytest.mark.parametrize("name", ["OptISTA", "POGM"])
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 4096, 4096), (np.complex64, 4000, 2002), (np.float32, 4000, 2200)])
+def test_optista_pogm_resident_launch(rls, ctx, name, dt, M, N):
+    """SURVEY 8f-1 / BASELINE configs[1] shape: the remaining iterations of OptISTA / POGM as resident launches of up to 48
+    iterations (pgm_resident_kernel through rls_pgm_step_resident).  Against the float64 oracle at 30, 49 (an odd count: POGM's
+    x / y roles end swapped; two launches) and 100 iterations (three launches); the stopping test inside a launch stops at
+    the oracle's iteration; solver state consistent afterwards (second solve, iterate-by-iterate run from the same state);
+    run to run identical; and the launch-per-iteration sequence (resident = 0) passes the same gate"""
+    A, xt, b = O.make_problem(M, N, dt, 5)
+    A64, b64 = A.astype(hi(dt)), b.astype(hi(dt))
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    regs = lambda R: [R.L1Regularization(lam), R.PositiveRegularization()] if (name == "POGM" and N == 2002) else R.L1Regularization(lam)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    tag = f"{name}_resident_{M}x{N}_{np.dtype(dt).name}"
+    for its in (30, 49, 100):
+        ref = getattr(O, name)(A64, reg=regs(O), rho=rho, iterations=its, relTol=0.0)
+        O.solve(ref, b64)
+        ref32 = lambda: O.solve(getattr(O, name)(A, reg=regs(O), rho=rho, iterations=its, relTol=0.0), b)
+        sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=regs(rls), rho=rho, iterations=its, relTol=0.0)
+        x = rls.solve_(sol, bd).to_host()
+        plan = sol._pgm[1]
+        if plan is None:
+            pytest.skip("resident mode not available on this device")
+        assert not plan.off and plan.fallbacks == 0 and sol.state.iteration == its
+        parity(f"{tag}_its{its}", x, ref.x, ref32, record=its == 30)
+        assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
+        assert np.array_equal(rls.solve_(sol, bd).to_host(), x)
+        if its == 49:
+            ctx.tune(resident=0)
+            try:
+                x_seq = rls.solve_(sol, bd).to_host()
+            finally:
+                ctx.tune(resident=1)
+            parity(f"{tag}_sequence", x_seq, ref.x, ref32, record=False)
+            assert rel(x_seq, x) < 2e-5
+            names = ("zold", "res", "y", "z") if name == "OptISTA" else ("xold", "res", "y", "z")   # every vector of the state
+            seq = {v: getattr(sol.state, v).to_host() for v in names}
+            assert np.array_equal(rls.solve_(sol, bd).to_host(), x) and not plan.off    # resident again
+            for v in names:
+                assert rel(getattr(sol.state, v).to_host(), seq[v]) < 1e-4, v
+    # the stopping test inside a launch
+    probe = getattr(O, name)(A64, reg=regs(O), rho=rho, iterations=90, relTol=0.0)
+    probe.init(b64)
+    rr = []
+    while probe.iterate() is not None:
+        rr.append(probe.rel_res_norm)
+    k = next(k for k in range(60, 2, -1) if min(rr[:k]) > 1.001 * rr[k])   # a threshold first crossed at iteration k, with margin
+    tol = 1.0005 * rr[k]
+    ref = getattr(O, name)(A64, reg=regs(O), rho=rho, iterations=90, relTol=tol)
+    O.solve(ref, b64)
+    assert ref.iteration == k + 1
+    sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=regs(rls), rho=rho, iterations=90, relTol=tol)
+    for _ in range(2):
+        x = rls.solve_(sol, bd).to_host()
+        assert sol.state.iteration == ref.iteration
+        parity(f"{tag}_reltol", x, ref.x, lambda: O.solve(getattr(O, name)(A, reg=regs(O), rho=rho, iterations=ref.iteration, relTol=0.0), b),
+               record=False)
+        assert np.isclose(sol.state.rel_res_norm, ref.rel_res_norm, rtol=2e-3)
+    # part of the iterations step by step (callbacks), then the state is what a resident run continues from
+    sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=regs(rls), rho=rho, iterations=30, relTol=0.0)
+    rls.init_(sol, bd)
+    for _ in range(7):
+        assert rls.iterate(sol) is not None
+    sol._run(sol.state)
+    ref = getattr(O, name)(A64, reg=regs(O), rho=rho, iterations=30, relTol=0.0)
+    O.solve(ref, b64)
+    assert sol.state.iteration == 30
+    parity(f"{tag}_continued", sol.state.x.to_host(), ref.x,
+           lambda: O.solve(getattr(O, name)(A, reg=regs(O), rho=rho, iterations=30, relTol=0.0), b), record=False)
+
+
+@pytest.mark.parametrize("name", ["OptISTA", "POGM"])
+def test_optista_pogm_resident_lost_launch(rls, ctx, name):
+    """a co-tenant holds 64 CUs for longer than the wait bound: the first resident launch gives up having changed nothing,
+    the later launches of the sequence see a stale iteration count and do nothing, the host finishes launch by launch;
+    the result equals the oracle's and the plan reports the fallback and retires"""
+    A, xt, b = O.make_problem(4096, 2048, np.complex64, 83)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    other = rls.Context(0)
+    its = 60   # two launches
+    try:
+        _fresh_resident_ctx(ctx)
+        ctx.tune(resident_spin=20000)
+        ref = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0)
+        O.solve(ref, b64)
+        sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0)
+        rls.init_(sol, bd)
+        ctx.sync()
+        assert other.lib.rls_debug_hold_cus(other.handle, 64, 400000) == 0
+        sol._run(sol.state)
+        other.sync()
+        plan = sol._pgm[1]
+        if plan is None:
+            pytest.skip("resident mode not available on this device")
+        assert plan.off and plan.fallbacks >= 1, "the co-tenant did not displace the resident launch"
+        assert sol.state.iteration == its
+        parity(f"co_tenant_{name}", sol.state.x.to_host(), ref.x,
+               lambda: O.solve(getattr(O, name)(A, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0), b), record=False)
+        x2 = rls.solve_(sol, bd).to_host()   # the retired plan: launch by launch
+        assert rel(x2, sol.state.x.to_host()) == 0 and sol.state.iteration == its
     finally:
         ctx.tune(resident_spin=100000)
         _fresh_resident_ctx(ctx)

@@ -11,7 +11,7 @@ args = sys.argv[1:]
 for a in [a for a in args if "=" in a]:  # tuning switches, e.g. slab_g=2
     k, v = a.split("=")
     ctx.tune(**{k: int(v)})
-which = [a for a in args if "=" not in a] or ["fista", "admm"]
+which = [a for a in args if "=" not in a] or ["fista", "pgm", "admm"]
 if "fista" in which:
     M, N = 4096, 2048
     A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
@@ -22,6 +22,22 @@ if "fista" in which:
     for _ in range(20): rls.init_(S, b); ctx.lib.rls_fista_step(S.state._plan, 50)
     us = ctx.timer_stop_ms() * 1e3 / 1000
     print(f"config 2: FISTA+L1 4096x2048 CF32: {us:.2f} us/iteration ({1e6/us:.0f} it/s)")
+if "pgm" in which:   # OptISTA / POGM on the configs[1] problem, 48 iterations = one resident launch
+    M, N = 4096, 2048
+    A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
+    b = rls.DeviceVector.from_host((A @ np.ones(N, np.complex64)).astype(np.complex64), ctx)
+    for name in ("OptISTA", "POGM"):
+        for res in (1, 0):
+            ctx.tune(resident=res)
+            S = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(1e-2), rho=0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2,
+                                       iterations=48, relTol=0.0)
+            for _ in range(5): rls.solve_(S, b)
+            ctx.sync(); t0 = time.perf_counter(); ctx.timer_start()
+            for _ in range(20): rls.init_(S, b); S._run(S.state)
+            us = ctx.timer_stop_ms() * 1e3 / (20 * 48); wall = (time.perf_counter() - t0) * 1e6 / (20 * 48)
+            print(f"{name} + L1 4096x2048 CF32, {'resident launches' if res else 'launch per iteration'}: {us:.2f} us/iteration "
+                  f"(incl. init!; host wall {wall:.2f})")
+    ctx.tune(resident=1)
 if "admm" in which:
     M, N = 8192, 4096
     A = make_A(M, N, 3, np.float32); Ad = rls.DeviceMatrix.from_host(A, ctx)
