@@ -540,7 +540,9 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
         nim += (double)elem<E>::re(pv[e]) * (double)elem<E>::im(vv[e]) - (double)elem<E>::im(pv[e]) * (double)elem<E>::re(vv[e]);
       pp += abs2d<E>(pv[e]);
     }
-    block_sum3(nre, nim, pp, sm);
+    // (wave count as a constant: blockDim.x would be a scalar load from the dispatch packet in host-visible memory)
+    if constexpr (NT == 512) block_sum3_nolead<8>(nre, nim, pp, sm);
+    else block_sum3_n<NT / 64>(nre, nim, pp, sm);
     const dcomplex den = {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim};
     const dcomplex alpha = dc_div({zeta, 0.0}, den);
     const E a = elem<E>::make((float)alpha.re, (float)alpha.im);
@@ -554,7 +556,8 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
       rv[e] = ri;
       rr += abs2d<E>(ri);
     }
-    rr = block_sum(rr, sm);
+    if constexpr (NT == 512) rr = block_sum_nolead<8>(rr, sm);
+    else rr = block_sum_n<NT / 64>(rr, sm);
     const double beta = rr / zeta;
     const float bf = (float)beta;
 #pragma unroll

@@ -10,6 +10,8 @@ M, N = 4096, 2048
 A = make_A(M, N, 4); Ad = rls.DeviceMatrix.from_host(A, ctx)
 rng = np.random.default_rng(5)
 Ks = tuple(int(k) for k in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1, 2, 4, 8, 16, 32, 64)
+for kv in sys.argv[2:]:  # tuning switches, e.g. skinny_tu=0 skinny_tu_window=8
+    k, v = kv.split('='); ctx.tune(**{k: int(v)})
 for K in Ks:
     X = (rng.standard_normal((N, K)) + 1j * rng.standard_normal((N, K))).astype(np.complex64)
     B = np.asfortranarray((A @ X).astype(np.complex64))
