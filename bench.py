@@ -334,6 +334,21 @@ def other_paths(rls, ctx, Ad, A, b, errors):
         us = timed(lambda: (rls.init_(S, b), lib.rls_fista_step(S.state._plan, 48)), 48)
         return {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
 
+    @entry("optista_pogm_l1 (SURVEY 8f-1: blocks of 48 iterations as ONE resident launch, rls_pgm_step_resident)")
+    def _():
+        res = {}
+        for name in ("OptISTA", "POGM"):
+            for tag, res_on in (("resident_launches", 1), ("launch_per_iteration", 0)):
+                ctx.tune(resident=res_on)
+                try:
+                    S = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=48, relTol=0.0)
+                    rls.solve_(S, b)
+                    us = timed(lambda: (rls.init_(S, b), S._run(S.state)), 48, reps=4)
+                finally:
+                    ctx.tune(resident=1)
+                res[f"{name}_{tag}"] = {"us_per_iteration_incl_init": us, "iterations_per_s": 1e6 / us}
+        return res
+
     @entry("gram_gemm_AHA (setup, matrix cores)")
     def _():
         t0 = time.perf_counter(); G = Ad.gram(); ctx.sync(); t_gram = time.perf_counter() - t0
