@@ -351,6 +351,56 @@ function gram(A::RLSMatrix{T}) where {T}
   end
 end
 
+"""
+    PgmPlan(A::RLSMatrix) -> PgmPlan or nothing
+
+Launch scratch of the resident OptISTA / POGM (restart = :none) iteration blocks (`rls_pgm_create`); `nothing` when the
+operator does not fit the resident form (the caller then stays on `rls_optista_update_async` / `rls_pogm_update_async`).
+"""
+mutable struct PgmPlan
+  handle::Ptr{Cvoid}
+  ctx::Context
+  function PgmPlan(handle::Ptr{Cvoid}, ctx::Context)
+    p = new(handle, ctx)
+    finalizer(x -> ccall((:rls_pgm_destroy, librls[]), Int32, (Ptr{Cvoid},), x.handle), p)
+  end
+end
+function PgmPlan(A::RLSMatrix)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  st = ccall((:rls_pgm_create, librls[]), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), A.op, h)
+  st == Int32(-2) && return nothing   # RLS_E_UNSUPPORTED: not an error
+  check(A.ctx, st, "rls_pgm_create")
+  PgmPlan(h[], A.ctx)
+end
+
+"""
+    pgm_step_resident!(plan, kind, coefs, first_iteration, v0, v1, v2, o0, res, x0, reg_kind, proj_kind, norm_x0, rel_tol, state) -> Bool
+
+Up to 48 iterations (`size(coefs, 2)`; `coefs` is 8 x n Float32, one column per iteration: the float arguments of the
+per-iteration `*_update_async` entry points) as ONE launch.  kind 0 = OptISTA (x, y, z, zold), 1 = POGM (xbuf, ybuf, z, xold).
+Returns false when the plan has retired (a launch was lost earlier): continue launch by launch.
+"""
+function pgm_step_resident!(plan::PgmPlan, kind::Integer, coefs::Matrix{Float32}, first_iteration::Integer, v0::RLSVector{T},
+                            v1::RLSVector{T}, v2::RLSVector{T}, o0::RLSVector{T}, res::RLSVector{T}, x0::RLSVector{T},
+                            reg_kind::Integer, proj_kind::Integer, norm_x0::Real, rel_tol::Real, state::RLSVector{Float32}) where {T}
+  size(coefs, 1) == 8 || error("coefs must be 8 x n")
+  st = ccall((:rls_pgm_step_resident, librls[]), Int32,
+             (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32,
+              Float32, Float32, Ptr{Cvoid}),
+             plan.handle, Int32(kind), Int32(size(coefs, 2)), Int32(first_iteration), coefs, v0.ptr, v1.ptr, v2.ptr, o0.ptr, res.ptr, x0.ptr,
+             Int32(reg_kind), Int32(proj_kind), Float32(norm_x0), Float32(rel_tol), state.ptr)
+  st == Int32(-2) && return false
+  check(plan.ctx, st, "rls_pgm_step_resident")
+  true
+end
+
+"launches of the sequence that gave up (they changed nothing); synchronises"
+function pgm_lost(plan::PgmPlan)
+  lost = Ref{Int32}(0); total = Ref{Int32}(0)
+  check(plan.ctx, ccall((:rls_pgm_lost, librls[]), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), plan.handle, lost, total), "rls_pgm_lost")
+  Int(lost[])
+end
+
 "whole solve in one enqueue; methods are added by the RegularizedLeastSquares extension"
 function solve_fused! end
 "`scheduler = RLSMI355X.BatchedState` for `solve!(solver, B::RLSMatrix)`: the columns share every pass over A (matrix cores); defined by the extension"

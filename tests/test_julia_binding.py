@@ -203,7 +203,8 @@ def test_julia_package_reaches_configs_4_and_5():
     for sym in ("rls_cgnr_create_batched", "rls_cgnr_init_batched", "rls_cgnr_get_status_batched", "rls_comm_create", "rls_comm_ctx",
                 "rls_comm_set_threads", "rls_allreduce_sum", "rls_cgnr_init_rowsharded", "rls_cgnr_step_rowsharded",
                 "rls_fista_init_rowsharded", "rls_fista_step_rowsharded", "rls_admm_init_rowsharded", "rls_admm_step_rowsharded",
-                "rls_cgnr_step_status", "rls_fista_step_status", "rls_admm_step_status"):
+                "rls_cgnr_step_status", "rls_fista_step_status", "rls_admm_step_status", "rls_pgm_create", "rls_pgm_step_resident",
+                "rls_pgm_lost", "rls_pgm_destroy"):
         assert sym in bound, f"{sym} is not called anywhere in julia/RLSMI355X"
 
 
