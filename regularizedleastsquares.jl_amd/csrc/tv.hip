@@ -162,8 +162,17 @@ __device__ static inline E gradt_at32(const E* g, const tv_geom32& G, unsigned x
 // tv_restrictMagnitude!: q /= max(1, |q|)   (ProxTV.jl:135-139)
 template <typename E>
 __device__ static inline E tv_clip(E q) {
-  const float m = fmaxf(1.f, elem<E>::absv(q));
-  return elem<E>::make(elem<E>::re(q) / m, elem<E>::im(q) / m);
+  if constexpr (!elem<E>::cplx) {
+    // real: q / max(1, |q|) IS clamp(q, -1, 1), bit for bit (|q| <= 1: q / 1; otherwise q / |q| = +-1 exactly; a NaN stays a
+    // NaN) -- three instructions instead of an IEEE division (~12), twice per pixel and FGP iteration on kernels that are
+    // bound by the VALU rate of the one CU they run on
+    const float v = elem<E>::re(q);
+    const float c = fminf(fmaxf(v, -1.f), 1.f);
+    return elem<E>::make(v == v ? c : v, 0.f);
+  } else {
+    const float m = fmaxf(1.f, elem<E>::absv(q));
+    return elem<E>::make(elem<E>::re(q) / m, elem<E>::im(q) / m);
+  }
 }
 
 #define GRID_STRIDE(i, n) \
