@@ -7,7 +7,8 @@
 #     cover (several regularisers, a non-identity regTrafo, vary_rho, L21 / LLR / nuclear terms in ADMM, ...) fall
 #     through to the reference's own generic methods, which run on RLSVector through its BLAS-1 methods and its
 #     broadcast lowering (RLSMI355X.jl: RLSStyle)
-# Everything else (createLinearSolver, solve!, callbacks, Regularization types, MultiThreading schedulers) runs
+#   * solve! without callbacks on a device right-hand side = the whole solve in one enqueue (solve_fused!)
+# Everything else (createLinearSolver, solve! with callbacks, Regularization types, MultiThreading schedulers) runs
 # UNCHANGED from the reference on top of these methods.
 module RLSMI355XRegularizedLeastSquaresExt
 
@@ -337,7 +338,7 @@ end
 
 `init!` followed by ALL iterations enqueued in one call (`rls_*_step(plan, iterations)`: the device stops at the
 iteration where `done` holds, exactly as the iterate-by-iterate loop of `solve!` does) and one status read-back.
-For callers that do not register callbacks; `solve!` itself stays the reference's loop.
+`solve!(solver, b::RLSVector)` without callbacks lands here; with callbacks it stays the reference's loop.
 """
 function RLSMI355X.solve_fused!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector)
   init!(solver, b)
@@ -361,6 +362,24 @@ end
 
 
 # ---- matrix right-hand sides: the shared-A scheduler (BASELINE configs[3]; src/MultiThreading.jl:30-79) -------------------
+# `solve!` on a device right-hand side WITHOUT callbacks: nothing observes the iterates, so the whole solve is enqueued at once
+# (the reference's loop, src/RegularizedLeastSquares.jl:103-117, would synchronise with the host once per iteration for a
+# `done` nobody else reads: 44 us against 11.7 us per CGNR iteration at 4096 x 2048 ComplexF32).  With callbacks, or with
+# init! keywords (x0, ...), the reference's loop runs as written.
+function RegularizedLeastSquares.solve!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector; callbacks = nothing, kwargs...)
+  if callbacks === nothing && isempty(kwargs)
+    RLSMI355X.solve_fused!(solver, b)
+    return solversolution(solver)
+  end
+  cbs = callbacks === nothing ? Any[] : (callbacks isa Vector ? callbacks : Any[callbacks])
+  init!(solver, b; kwargs...)
+  foreach(cb -> cb(solver, 0), cbs)
+  for (iteration, _) = enumerate(solver)
+    foreach(cb -> cb(solver, iteration), cbs)
+  end
+  return solversolution(solver)
+end
+
 # `solve!(solver, B; scheduler = RLSMI355X.BatchedState)` with B an RLSMatrix (RLSMI355X.rhs(b)): the K columns advance
 # TOGETHER through one plan (rls_cgnr_create_batched: both products of an iteration as skinny GEMMs on the matrix cores,
 # A streamed once per product for all columns), each column with its own scalars and its own `done` -- the reference's
