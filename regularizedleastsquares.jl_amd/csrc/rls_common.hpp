@@ -28,6 +28,7 @@ struct rls_tuning {
                           // 2 = deliberately wrong (tests: exercises the kernel's check-and-reload path)
   int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
                           // ONE launch (normal.hip, cgnr_resident_kernel)
+  int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
   int resident_spin = 100000;  // bound of every in-kernel wait, in polls (~1 us each: a wall-clock bound of ~0.1 s per
                                // wait); a launch that runs into it is a no-op and the host re-runs its iterations on the
                                // per-iteration pipeline (solvers.hip, *_recover)

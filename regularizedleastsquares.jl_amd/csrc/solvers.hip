@@ -165,6 +165,7 @@ struct rls_cgnr {
   bool resident_off;
   int fallbacks;        // resident launches lost and recovered so far
   long long requested;  // iterations asked for since init
+  bool rsync_clean = false;  // the init kernel has just zeroed the arrival counters (resident_chain)
 };
 
 static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
@@ -237,14 +238,17 @@ static bool cgnr_use_resident(const rls_cgnr* s) {
 // waits for the event recorded behind the previous one.  (Another PROCESS on the same device is not covered: its
 // symptom is the bounded-wait timeout reported by rls_cgnr_get_status.)
 static hipEvent_t g_resident_ev[64];
+// `clean` (nullable): the plan's init kernel has zeroed the counters itself and nothing has used them since -- the memset
+// (a launch of its own: ~4 us on the stream between init! and the resident kernel of every solve) is skipped, once
 template <typename F>
-static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch) {
+static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch, bool* clean = nullptr) {
   std::lock_guard<std::mutex> lock(rls_capture_mutex());
   const int d = ctx->device < 64 ? ctx->device : 63;
   if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
   else RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
   // arrival counters and the {fail, completed} words of THIS launch; the count of lost launches behind them is sticky
-  RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_resident_sync_clear_bytes(), ctx->stream));
+  if (clean && *clean && ctx->tune.resident_preclear) *clean = false;
+  else RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_resident_sync_clear_bytes(), ctx->stream));
   const int32_t st = launch();
   RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], ctx->stream));
   return st;
@@ -252,7 +256,7 @@ static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch) {
 static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_pipe& P, int n_steps) {
   return resident_chain(ctx, s->rsync, [&]() {
     return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
-  });
+  }, &s->rsync_clean);
 }
 // the sync block of a plan (zeroed once: the sticky word starts at 0) and the pinned mirror of its three flag words
 static hipError_t resident_alloc(rls_ctx* ctx, const rls_operator* op, void** rsync, unsigned** rsync_h) {
@@ -315,8 +319,11 @@ template <typename E>
 __global__ __launch_bounds__(UPD_THREADS) void cgnr_init_kernel(E* __restrict__ x, const E* __restrict__ r,
                                                                 E* __restrict__ p, E* __restrict__ v, int64_t n,
                                                                 cgnr_scalars* sc, float lambda, float rel_tol,
-                                                                int max_iter) {
+                                                                int max_iter, unsigned* clear_words = nullptr,
+                                                                int n_clear = 0) {
   __shared__ double sm[16];
+  // the arrival counters of the plan's resident kernel (resident_chain: saves the memset launch ahead of it)
+  for (int i = threadIdx.x; i < n_clear; i += UPD_THREADS) clear_words[i] = 0u;
   double rr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
     const E ri = r[i];
@@ -475,8 +482,11 @@ __global__ __launch_bounds__(UPD_THREADS) void cgnr_update_reg_kernel(E* __restr
 template <typename E>
 static void cgnr_launch_init(rls_cgnr* s, float lambda, float rel_tol, int max_iter) {
   rls_operator* op = s->op;
+  const bool clr = s->rsync && s->nrhs == 1;
   hipLaunchKernelGGL(cgnr_init_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->x, (const E*)s->r,
-                     (E*)s->p, (E*)s->v, op->N, s->sc, lambda, rel_tol, max_iter);
+                     (E*)s->p, (E*)s->v, op->N, s->sc, lambda, rel_tol, max_iter, clr ? (unsigned*)s->rsync : nullptr,
+                     clr ? (int)(rls_resident_sync_clear_bytes() / sizeof(unsigned)) : 0);
+  s->rsync_clean = clr;
 }
 template <typename E>
 static void cgnr_launch_update(rls_cgnr* s) {
@@ -561,6 +571,7 @@ struct rls_fista {
   bool resident_off = false;  // a resident launch was lost: the plan stays on the per-iteration pipeline (cgnr plan, above)
   int fallbacks = 0;
   long long requested = 0;    // iterations asked for since init
+  bool rsync_clean = false;   // the init kernel has just zeroed the arrival counters (resident_chain)
 };
 
 // batched launches: workgroup b = column b.  Vpart non-null: AHA y arrives as `S` partial rows per column and is
@@ -587,8 +598,10 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__
                                                                  E* __restrict__ y, int64_t n, fista_scalars* sc,
                                                                  float rho, float theta, float rel_tol, int max_iter,
                                                                  int restart, int reg_kind, int proj_kind,
-                                                                 float lambda, long long slices, fista_batch<E> Bt) {
+                                                                 float lambda, long long slices, fista_batch<E> Bt,
+                                                                 unsigned* clear_words = nullptr, int n_clear = 0) {
   __shared__ double sm[16];
+  for (int i = threadIdx.x; i < n_clear; i += UPD_THREADS) clear_words[i] = 0u;  // (cgnr_init_kernel)
   const int b = blockIdx.x;
   b0 += b * Bt.ldv;
   b1 += b * Bt.ldv;
@@ -1597,7 +1610,6 @@ static int32_t cg_solve_impl(rls_cg* s, void* x, const void* b, float rho, int32
       St.maxiter = maxiter;
       St.skip = FV.skip;
       St.poison = FV.poison;
-    St.poison = FV.poison;
       return resident_chain(ctx, s->rsync, [&]() {
         return rls_cgnr_resident_launch(ctx, op->dtype, P, s->rdots, s->rsync, maxiter, (unsigned)ctx->tune.resident_spin, St);
       });
@@ -2140,7 +2152,7 @@ static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps) {
       s->resident_used = true;
       return resident_chain(ctx, s->rsync, [&]() {
         return rls_gram_resident_launch(ctx, dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
-      });
+      }, &s->rsync_clean);
     }
     if (s->graph.steps && s->graph.mode != 3) {
       hipGraphExecDestroy(s->graph.exec);
@@ -2519,12 +2531,15 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
     hipLaunchKernelGGL(fista_init_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
                        (float*)s->buf[1], (float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc, rho, theta,
                        rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0});
+                       (long long)s->l21_slices, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0}, (unsigned*)s->rsync,
+                       s->rsync ? (int)(rls_resident_sync_clear_bytes() / sizeof(unsigned)) : 0);
   else
     hipLaunchKernelGGL(fista_init_kernel<float2>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float2*)s->buf[0],
                        (float2*)s->buf[1], (float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N, s->sc, rho,
                        theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0});
+                       (long long)s->l21_slices, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0}, (unsigned*)s->rsync,
+                       s->rsync ? (int)(rls_resident_sync_clear_bytes() / sizeof(unsigned)) : 0);
+  s->rsync_clean = s->rsync != nullptr;
   s->enq = 0;
   s->requested = 0;
   s->theta0 = theta;
@@ -2715,7 +2730,7 @@ static int32_t fista_step_impl(rls_fista* s, int32_t n_steps) {
       s->enq += n_steps;
       return resident_chain(ctx, s->rsync, [&]() {
         return rls_fista_gram_resident_launch(ctx, dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
-      });
+      }, &s->rsync_clean);
     }
     const int it0 = s->enq;  // buffer hints as in the slab pipeline below
     if (s->graph.exec && s->graph_parity != (it0 & 1)) {
@@ -2749,7 +2764,7 @@ static int32_t fista_step_impl(rls_fista* s, int32_t n_steps) {
     s->enq += n_steps;
     return resident_chain(ctx, s->rsync, [&]() {
       return rls_fista_resident_launch(ctx, s->op->dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
-    });
+    }, &s->rsync_clean);
   }
   if (s->use_pipe) {
     // iteration k = K_A (applies the gradient/prox/momentum update k-1 in its prologue, then one pass
