@@ -153,6 +153,7 @@ int32_t rls_ctx_destroy(rls_ctx* ctx) {
   }
   hipSetDevice(ctx->device);
   if (ctx->stream) rls_stream_wait(ctx->stream);
+  rls_resident_forget(ctx->device, ctx->stream);  // (after the wait: nothing of this stream is in flight any more)
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->red_d) hipFree(ctx->red_d);

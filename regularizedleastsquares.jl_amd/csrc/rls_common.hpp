@@ -109,6 +109,7 @@ static inline hipError_t rls_event_wait(hipEvent_t ev) {
 // process is capturing, hipStreamWaitEvent from another thread on an event recorded outside that capture can fail
 // with hipErrorStreamCaptureIsolation (seen with one context capturing a FISTA graph while another chained a
 // resident launch: 1 run in 6); both sections are short and host-only, so serialising them costs nothing measurable.
+void rls_resident_forget(int device, hipStream_t stream);  // solvers.hip: a stream is going away (resident launch chain)
 inline std::mutex& rls_capture_mutex() {
   static std::mutex m;
   return m;

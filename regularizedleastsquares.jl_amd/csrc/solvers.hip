@@ -234,10 +234,18 @@ static bool cgnr_use_resident(const rls_cgnr* s) {
 
 // A resident kernel needs every one of its workgroups on a CU at the same time.  Other kernels only delay that, but
 // two resident kernels running side by side (two contexts = two streams of this process) could each hold CUs the
-// other is waiting for.  So resident launches on one device form ONE chain across all streams of the process: each
-// waits for the event recorded behind the previous one.  (Another PROCESS on the same device is not covered: its
-// symptom is the bounded-wait timeout reported by rls_cgnr_get_status.)
+// other is waiting for.  So resident launches on one device form ONE chain across all streams of the process.  A launch
+// on the stream that issued the previous one is ordered by the stream itself (no event traffic at all: the common
+// single-context case); only when the stream CHANGES is an event recorded on the previous stream -- now, i.e. behind
+// everything it has queued since: conservative -- and waited for by the new one.  (Another PROCESS on the same device
+// is not covered: its symptom is the bounded-wait timeout reported by rls_cgnr_get_status.)
 static hipEvent_t g_resident_ev[64];
+static hipStream_t g_resident_last[64];  // guarded by rls_capture_mutex(); cleared by rls_resident_forget (context teardown)
+void rls_resident_forget(int device, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(rls_capture_mutex());
+  const int d = device < 64 ? (device < 0 ? 0 : device) : 63;
+  if (g_resident_last[d] == stream) g_resident_last[d] = nullptr;
+}
 // `clean` (nullable): the plan's init kernel has zeroed the counters itself and nothing has used them since -- the memset
 // (a launch of its own: ~4 us on the stream between init! and the resident kernel of every solve) is skipped, once
 template <typename F>
@@ -245,12 +253,15 @@ static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch, bool* clean
   std::lock_guard<std::mutex> lock(rls_capture_mutex());
   const int d = ctx->device < 64 ? ctx->device : 63;
   if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
-  else RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
+  if (g_resident_last[d] && g_resident_last[d] != ctx->stream) {
+    RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], g_resident_last[d]));
+    RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
+  }
   // arrival counters and the {fail, completed} words of THIS launch; the count of lost launches behind them is sticky
   if (clean && *clean && ctx->tune.resident_preclear) *clean = false;
   else RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_resident_sync_clear_bytes(), ctx->stream));
   const int32_t st = launch();
-  RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], ctx->stream));
+  g_resident_last[d] = ctx->stream;
   return st;
 }
 static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_pipe& P, int n_steps) {
