@@ -81,7 +81,7 @@ struct comm_pool {
   std::atomic<unsigned> sense{0};
   std::atomic<int> finished{0};
   std::atomic<int32_t> status{0};
-  double busy_s[16] = {0};  // per rank: wall clock spent INSIDE phase bodies (enqueueing), barriers and idling excluded
+  double busy_s[MAX_RANKS] = {0};  // per rank: wall clock spent INSIDE phase bodies (enqueueing), barriers and idling excluded
 };
 
 struct rls_comm {
