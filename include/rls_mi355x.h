@@ -64,7 +64,8 @@ int32_t rls_device_count(int32_t* out);
  * (1-launch Gram-mode CGNR / cg), "batched_mfma" (matrix-core batched path and Gram GEMM), "pipe_hint_mode" (0: the
  * host tells the 2-launch pipeline which (r, p) buffer pair is current, 1: never, 2: deliberately wrong -- tests),
  * "resident" (1: a whole step call as ONE launch with A / AHA held in registers where the shape allows, 0: the per-iteration
- * pipelines), "resident_spin" (bound of the in-kernel waits, in polls).  Process-wide (measurement only, set before the
+ * pipelines), "resident_spin" (bound of the in-kernel waits, in polls), "resident_preclear" (1: a plan's init kernel zeroes its
+ * resident kernel's arrival counters, saving the memset launch ahead of the first step call).  Process-wide (measurement only, set before the
  * plan is created): "slab_g", "slab_wv", "slab_order", "red_threads", "resident_barrier", "tv_fused_max_n",
  * "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits", "skinny_half"
  * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll" (rolling-window
