@@ -42,9 +42,20 @@ __device__ static inline int64_t svt_index(const svt_geom& G, const int64_t (&b)
   return lin + (int64_t)k * G.sstride;
 }
 
-// NW waves per matrix: the pairs of one round of the round-robin tournament are disjoint, so the waves rotate
-// different pairs at the same time and meet at a barrier after every round (NW = 1: many small blocks, one wave
-// each; NW up to 16: a single larger matrix, e.g. the nuclear-norm prox).
+// NW waves per matrix: the pairs of one round of the round-robin tournament are disjoint, so they are rotated at the same
+// time -- one pair per group of SVT_SG = 16 lanes (a DPP row: its sums need no cross-row traffic), four pairs per wave,
+// 4 NW per matrix -- and the waves meet at a barrier after every round (NW = 1: many small blocks, one wave each; NW up to
+// 16: a single larger matrix, e.g. the nuclear-norm prox).  Round 3: a pair used to occupy a whole wave (64 lanes for
+// vectors of 16-96 elements, every lane repeating the rotation's scalar arithmetic); a 96 x 96 nuclear-norm prox ran
+// three pairs per wave one after the other, 4.9 ms against 3-4 ms for LAPACK on the host.
+constexpr int SVT_SG = 16;
+__device__ static inline float svt_row_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane of the row
+  v += dpp_f(v, 0xB1);
+  v += dpp_f(v, 0x4E);
+  v += dpp_f(v, 0x141);
+  v += dpp_f(v, 0x140);
+  return v;
+}
 template <typename E, int NW>
 __global__ __launch_bounds__(64 * NW) void svt_blocks_kernel(E* __restrict__ x, svt_geom G, float lam) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -89,7 +100,8 @@ __global__ __launch_bounds__(64 * NW) void svt_blocks_kernel(E* __restrict__ x, 
   for (int sweep = 0; sweep < SVT_MAX_SWEEPS; ++sweep) {
     float off = 0.f;
     for (int round = 0; round < m - 1; ++round) {
-      for (int i = w; i < m / 2; i += NW) {  // wave-uniform loop
+      const int sl = lane % SVT_SG;                                     // lane inside its group of 16
+      for (int i = w * (64 / SVT_SG) + lane / SVT_SG; i < m / 2; i += NW * (64 / SVT_SG)) {  // uniform per group of 16 lanes
         int p = i == 0 ? m - 1 : (round + i) % (m - 1);
         int q = i == 0 ? round : (round - i + (m - 1)) % (m - 1);
         if (p > q) {
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(64 * NW) void svt_blocks_kernel(E* __restrict__ x, 
         }
         if (q >= nv) continue;  // the dummy player
         float a = 0.f, bb = 0.f, gr = 0.f, gi = 0.f;
-        for (int t = lane; t < len; t += 64) {
+        for (int t = sl; t < len; t += SVT_SG) {
           const E wp = W[p * len + t], wq = W[q * len + t];
           a += elem<E>::abs2(wp);
           bb += elem<E>::abs2(wq);
@@ -107,28 +119,28 @@ __global__ __launch_bounds__(64 * NW) void svt_blocks_kernel(E* __restrict__ x, 
           gr += elem<E>::re(g);
           gi += elem<E>::im(g);
         }
-        a = wave_sum(a);
-        bb = wave_sum(bb);
-        gr = wave_sum(gr);
-        if constexpr (elem<E>::cplx) gi = wave_sum(gi);
+        a = svt_row_sum(a);
+        bb = svt_row_sum(bb);
+        gr = svt_row_sum(gr);
+        if constexpr (elem<E>::cplx) gi = svt_row_sum(gi);
         // |g| and the phase without squaring g (g*g underflows for nearly-null vectors and the "unit" phase
         // g/sqrt(g*g) then is not of modulus one, which breaks X = W V^H); vectors that have been rotated down to
         // rounding level (rank-deficient blocks: zero-padded edge blocks, K > voxels) are left alone
         const float gabs = elem<E>::cplx ? hypotf(gr, gi) : fabsf(gr);
         const float na = sqrtf(a), nb = sqrtf(bb);
-        if (gabs > tol * na * nb && na > null_tol && nb > null_tol) {  // wave-uniform: every lane holds the same sums
+        if (gabs > tol * na * nb && na > null_tol && nb > null_tol) {  // uniform per group: its 16 lanes hold the same sums
           const float er = gr / gabs, ei = gi / gabs;       // e^{i phi}
           const float zeta = (bb - a) / (2.f * gabs);
           const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
           const float c = 1.f / sqrtf(1.f + tt * tt), s = c * tt;
           const E ph = elem<E>::make(er, ei);
-          for (int t = lane; t < len; t += 64) {
+          for (int t = sl; t < len; t += SVT_SG) {
             const E wp = W[p * len + t];
             const E qt = elem<E>::mulc(ph, W[q * len + t]);  // e^{-i phi} w_q
             W[p * len + t] = elem<E>::sub(elem<E>::scale(c, wp), elem<E>::scale(s, qt));
             W[q * len + t] = elem<E>::add(elem<E>::scale(s, wp), elem<E>::scale(c, qt));
           }
-          for (int v = lane; v < nv; v += 64) {
+          for (int v = sl; v < nv; v += SVT_SG) {
             const E vp = V[p * nv + v];
             const E qt = elem<E>::mulc(ph, V[q * nv + v]);
             V[p * nv + v] = elem<E>::sub(elem<E>::scale(c, vp), elem<E>::scale(s, qt));
@@ -139,6 +151,8 @@ __global__ __launch_bounds__(64 * NW) void svt_blocks_kernel(E* __restrict__ x, 
       }
       __syncthreads();  // the pairs of a round are disjoint; the next round re-pairs the vectors
     }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) off = fmaxf(off, __shfl_xor(off, sh, 64));  // over the wave's groups
     if (lane == 0) red[w] = off;
     __syncthreads();
     float offm = 0.f;
