@@ -209,12 +209,15 @@ static int32_t svt_launch(rls_ctx* ctx, int32_t dtype, const svt_geom& G, void* 
   int64_t nb = 1;
   for (int d = 0; d < G.ndims; ++d) nb *= G.nblk[d];
   if (nb <= 0 || nb > 0x7fffffff) return rls_fail(ctx, RLS_E_INVALID, "singular-value thresholding: bad block count");
-  // waves per matrix: one when there are enough blocks to fill the chip, up to 16 for a single matrix
+  // waves per matrix: one when there are blocks enough to keep every CU's wave slots busy, otherwise as many as give a CU
+  // ~16 waves over the blocks it holds -- but no more than the pairs of a round need at four pairs per wave
+  const int pairs = (nv + 1) / 2;
+  int cap = 1;
+  while (cap * 4 < pairs && cap < 16) cap *= 2;
+  const int64_t blocks_per_cu = nb > 256 ? (nb + 255) / 256 : 1;
+  const int want = (int)(16 / blocks_per_cu > 1 ? 16 / blocks_per_cu : 1);
   int nw = 1;
-  if (nb < 1024) {
-    const int64_t want = 1024 / nb;  // ~4 waves per CU over all blocks
-    while (nw < 16 && nw * 2 <= want && nw * 2 <= (nv + 1) / 2) nw *= 2;
-  }
+  while (nw * 2 <= want && nw * 2 <= cap) nw *= 2;
 #define RLS_SVT_LAUNCH(EE, NWV)                                                                                        \
   do {                                                                                                                 \
     RLS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_blocks_kernel<EE, NWV>),                       \
