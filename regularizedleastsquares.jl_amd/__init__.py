@@ -22,7 +22,7 @@ from .regularization import (AbstractParameterizedRegularization, AbstractProjec
                              findfirst, findsink, findsinks, is_projection, sink, sinktype)
 from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractKrylovSolver,
                       AbstractPrimalDualSolver, AbstractProximalGradientSolver, AbstractRowActionSolver,
-                      applicableSolverList, isapplicable, AbstractLinearSolver, BatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
+                      applicableSolverList, isapplicable, AbstractLinearSolver, AdmmBatchedState, BatchedState, FistaBatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
                       SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,
                       iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,
                       solverstate)

@@ -203,6 +203,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "skinny_half")) rls_skinny_tune(7, value);
   else if (!strcmp(key, "skinny_t_roll")) rls_skinny_tune(8, value);
   else if (!strcmp(key, "skinny_v_roll")) rls_skinny_tune(9, value);
+  else if (!strcmp(key, "skinny_g_roll")) rls_skinny_tune(10, value);
   else if (!strcmp(key, "gram_lds_kib")) rls_skinny_tune(6, value);
   else if (!strcmp(key, "slab_g")) {  // process-wide; must be set before the operator is created
     rls_normal_force_group(value);

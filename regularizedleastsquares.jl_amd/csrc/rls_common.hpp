@@ -725,6 +725,8 @@ __device__ static inline panel_col<E> panel_column(E* panel, int64_t n, int b, i
 struct rls_skinny {
   const void* A;
   int64_t lda, M, N;
+  const void* G = nullptr;    // explicit AHA (N x N, leading dimension ldg): V = G P is ONE product, same row splits
+  int64_t ldg = 0;
   int nrhs, ngroups, splits;  // ngroups = ceil(nrhs / 16); splits = row splits of the A^H T product
   int half = 0;               // 1: complex, nrhs <= 8: ONE group whose 16 operand columns are (8 re | 8 im) floats
   void *X, *R, *P, *V;        // N x nrhs, columns ldv elements apart (caller's)

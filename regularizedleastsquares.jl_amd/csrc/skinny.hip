@@ -68,20 +68,25 @@ __device__ static inline void t_mma(f32x4 (&acc)[4], const E (&a)[U], const PE (
   }
 }
 
-template <typename E, int WV, int U, bool H, int D = 0>
+// VOUT (Gram mode, V = AHA P with the explicit N x N matrix as `A`: the reference constructors' default operator,
+// src/CGNR.jl:49,151): the contraction is split over blockIdx.z and the result goes out as partial rows in the layout
+// of skinny_v_kernel (Vpart[split][right-hand side][row]), so that the per-column update kernels read it unchanged.
+template <typename E, int WV, int U, bool H, int D = 0, bool VOUT = false>
 __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__ A, int64_t lda,
                                                             const E* __restrict__ Pp, E* __restrict__ Tp, int64_t M,
-                                                            int64_t N) {
+                                                            int64_t N, int nrhs_pad = 0, int64_t ldvp = 0) {
   constexpr bool CX = elem<E>::cplx;
   static_assert(!H || CX, "the half layout is a complex layout");
   using PE = typename std::conditional<H, float, E>::type;
   __shared__ float red[WV][2][4][64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t mb = blockIdx.x, NB = N / 4;
+  const int64_t mb = blockIdx.x;
   const int g = blockIdx.y;
-  const PE* Pg = reinterpret_cast<const PE*>(Pp) + (int64_t)g * N * 16 + lane;
-  const E* Ap = A + mb * 16 + (lane & 15) + (int64_t)(lane >> 4) * lda;
+  const int sp = VOUT ? (int)blockIdx.z : 0, SP = VOUT ? (int)gridDim.z : 1;
+  const int64_t nb_lo = sp * (N / 4) / SP, NB = (sp + 1) * (N / 4) / SP - nb_lo;  // this split's 4-column blocks
+  const PE* Pg = reinterpret_cast<const PE*>(Pp) + (int64_t)g * N * 16 + nb_lo * 64 + lane;
+  const E* Ap = A + mb * 16 + (lane & 15) + ((int64_t)(lane >> 4) + nb_lo * 4) * lda;
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -175,6 +180,26 @@ __global__ __launch_bounds__(WV * 64) void skinny_t_kernel(const E* __restrict__
     if constexpr (CX) red[w][1][t][lane] = tim[t];
   }
   __syncthreads();
+  if constexpr (VOUT) {  // idx = right-hand side * 16 + row: a right-hand side's 16 rows are one contiguous piece
+    constexpr int NJ = H ? 8 : 16;
+    for (int idx = threadIdx.x; idx < NJ * 16; idx += WV * 64) {
+      const int j = idx >> 4, row = idx & 15;
+      const int l = (row >> 2) * 16 + j, t = row & 3;
+      float re = 0.f, im = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) {
+        if constexpr (H) {  // re = acc0[j] - acc1[j + 8], im = acc0[j + 8] + acc1[j]
+          re += red[ww][0][t][l] - red[ww][1][t][l + 8];
+          im += red[ww][0][t][l + 8] + red[ww][1][t][l];
+        } else {
+          re += red[ww][0][t][l];
+          if constexpr (CX) im += red[ww][1][t][l];
+        }
+      }
+      Tp[((int64_t)sp * nrhs_pad + 16 * g + j) * ldvp + mb * 16 + row] = elem<E>::make(re, im);
+    }
+    return;
+  }
   if constexpr (H) {
     // slot j < 8: re = ar pr - ai pi = acc0[j] - acc1[j + 8]; slot j >= 8: im = ar pi + ai pr = acc0[j] + acc1[j - 8]
     // (per wave first, then over the waves: the same additions in the same order as the full layout)
@@ -633,6 +658,7 @@ static int g_t_waves = 4, g_t_u = 4, g_v_waves = 4, g_v_u = 1, g_v_splits = 0;
 // (8, 2) against (0, 0): K = 8 32.7 -> 31.6 us, K = 16 36.6 -> 33.9 us, K = 64 120.3 -> 98.7 us per batched iteration;
 // (16, 2), (8, 4) and deeper windows measure within noise or worse: the kernels are not short of loads in flight
 static int g_t_roll = 8, g_v_roll = 2;
+static int g_g_roll = 8;  // the Gram-mode product (skinny_t_kernel<..., VOUT>): rls_tune_set "skinny_g_roll"
 static int g_half = 1;  // rls_tune_set "skinny_half": the (re | im) operand packing for <= 8 complex right-hand sides
 // dynamic LDS requested by the Gram tile kernel purely as an occupancy limiter: one workgroup (one wave per SIMD)
 // per CU keeps the MFMA pipe fed by a single instruction stream (0.92 ms vs 1.05 ms with three co-resident
@@ -648,6 +674,7 @@ void rls_skinny_tune(int which, int value) {
   if (which == 7) g_half = value;
   if (which == 8) g_t_roll = value;
   if (which == 9) g_v_roll = value;
+  if (which == 10) g_g_roll = value;
 }
 
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
@@ -766,6 +793,30 @@ static void launch_v(rls_ctx* ctx, const rls_skinny& K) {
                      (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);
 }
 
+// Gram mode: V = AHA P as ONE product over the explicit N x N matrix (K.G), the contraction split K.splits ways
+template <typename E>
+static void launch_g(rls_ctx* ctx, const rls_skinny& K) {
+  const dim3 grid((unsigned)(K.N / 16), (unsigned)K.ngroups, (unsigned)K.splits);
+  const int pad = rls_skinny_pad(K.nrhs, K.half);
+#define SK_G(HH, DD)                                                                                                   \
+  hipLaunchKernelGGL((skinny_t_kernel<E, 4, 4, HH, DD, true>), grid, dim3(256), 0, ctx->stream, (const E*)K.G, K.ldg, \
+                     (const E*)K.Ppack, (E*)K.Vpart, K.N, K.N, pad, K.ldvp)
+  if constexpr (elem<E>::cplx) {
+    if (K.half) {
+      if (g_g_roll == 16) SK_G(true, 16);
+      else if (g_g_roll == 0) SK_G(true, 0);
+      else SK_G(true, 8);
+    } else {
+      if (g_g_roll == 16) SK_G(false, 16);
+      else if (g_g_roll == 0) SK_G(false, 0);
+      else SK_G(false, 8);
+    }
+  } else {
+    SK_G(false, 0);
+  }
+#undef SK_G
+}
+
 template <typename E, bool INIT, int EPT, int NT>
 static void launch_u_ept(rls_ctx* ctx, const rls_skinny& K, float lambda, float rel_tol, int max_iter) {
   hipLaunchKernelGGL((skinny_u_kernel<E, INIT, EPT, NT>), dim3((unsigned)K.nrhs), dim3(NT), 0, ctx->stream,
@@ -832,6 +883,11 @@ int32_t rls_skinny_atb(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const v
 
 // which: bit 0 = T kernel, bit 1 = V kernel, bit 2 = update kernel
 int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which) {
+  if (K.G && (which & 3)) {  // explicit AHA: the two products over A are one product over the Gram matrix
+    if (dtype == RLS_F32) launch_g<float>(ctx, K);
+    else launch_g<float2>(ctx, K);
+    which &= ~3;
+  }
   if (dtype == RLS_F32) {
     if (which & 1) launch_t<float>(ctx, K);
     if (which & 2) launch_v<float>(ctx, K);

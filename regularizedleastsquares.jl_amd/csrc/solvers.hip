@@ -196,6 +196,8 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
   K.lda = s->op->lda;
   K.M = s->op->M;
   K.N = s->op->N;
+  K.G = s->op->G;  // explicit AHA (src/CGNR.jl:49): every operator apply of the batched loop is ONE product over it
+  K.ldg = s->op->ldg;
   K.nrhs = s->nrhs;
   K.half = s->half;
   K.ngroups = rls_skinny_groups(s->nrhs, s->half);
@@ -1498,6 +1500,8 @@ static rls_skinny fista_skinny_desc(const rls_fista* s) {
   K.lda = s->op->lda;
   K.M = s->op->M;
   K.N = s->op->N;
+  K.G = s->op->G;  // explicit AHA (src/CGNR.jl:49): every operator apply of the batched loop is ONE product over it
+  K.ldg = s->op->ldg;
   K.nrhs = s->nrhs;
   K.half = s->half;
   K.ngroups = rls_skinny_groups(s->nrhs, s->half);
@@ -1702,6 +1706,8 @@ static rls_skinny cg_skinny_desc(const rls_cg* s) {
   K.lda = s->op->lda;
   K.M = s->op->M;
   K.N = s->op->N;
+  K.G = s->op->G;  // explicit AHA (src/CGNR.jl:49): every operator apply of the batched loop is ONE product over it
+  K.ldg = s->op->ldg;
   K.nrhs = s->nrhs;
   K.half = s->half;
   K.ngroups = rls_skinny_groups(s->nrhs, s->half);
@@ -1928,10 +1934,13 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   if (!x || !r || !p || !v || !out || nrhs < 1 || ldv < op->N)
     return rls_fail(ctx, RLS_E_INVALID, "cgnr_create: bad argument");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
-  const bool skinny = nrhs > 1 && !op->G && ctx->tune.batched_mfma && rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda);
+  // the columns share solver.AHA (src/MultiThreading.jl:30-48): an explicit Gram matrix when the operator has one -- the
+  // reference constructors' default for a dense matrix, src/CGNR.jl:49 --, otherwise the two products over A
+  const bool skinny = nrhs > 1 && ctx->tune.batched_mfma && rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda) &&
+                      (!op->G || rls_skinny_ok(op->dtype, op->N, op->N, op->G, op->ldg));
   if (nrhs > 1 && !skinny)
-    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR runs on the matrix cores: a matrix-free operator with M, N multiples of 16 "
-                                            "(other shapes: one plan per column)");
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR runs on the matrix cores: A (and AHA, when explicit) with M, N multiples "
+                                            "of 16 and 16-byte aligned columns (other shapes: one plan per column)");
   rls_alloc_scope alloc_scope(ctx);
   rls_cgnr* s = new rls_cgnr();
   s->actx = ctx;
@@ -2627,8 +2636,9 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   rls_ctx* ctx = op->ctx;
   if (!x || !x0 || !xold || !res || !out || nrhs < 1 || ldv < op->N)
     return rls_fail(ctx, RLS_E_INVALID, "fista_create_batched: bad argument");
-  if (op->G || !op->A || !ctx->tune.batched_mfma || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda))
-    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched FISTA needs a matrix-free operator with 16-aligned M, N (matrix-core path)");
+  if (!op->A || !ctx->tune.batched_mfma || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda) ||
+      (op->G && !rls_skinny_ok(op->dtype, op->N, op->N, op->G, op->ldg)))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched FISTA needs A (and AHA, when explicit) with 16-aligned M, N (matrix-core path)");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   rls_alloc_scope alloc_scope(ctx);
   rls_fista* s = new rls_fista();
@@ -2976,8 +2986,9 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
   if (!op) return RLS_E_INVALID;
   rls_ctx* ctx = op->ctx;
   if (!U || !R || !Cm || !out || nrhs < 1 || ldv < op->N) return rls_fail(ctx, RLS_E_INVALID, "cg_create_batched: bad argument");
-  if (!op->A || op->G || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda))
-    return rls_fail(ctx, RLS_E_UNSUPPORTED, "cg_create_batched: needs a matrix-free operator with M, N multiples of 16");
+  if (!op->A || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda) ||
+      (op->G && !rls_skinny_ok(op->dtype, op->N, op->N, op->G, op->ldg)))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "cg_create_batched: needs A (and AHA, when explicit) with M, N multiples of 16");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   rls_alloc_scope alloc_scope(ctx);
   rls_cg* s = new rls_cg();

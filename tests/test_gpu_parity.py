@@ -902,6 +902,62 @@ def _batched_case(rls, ctx, dt, M, N, K):
     parity(f"batched_then_vector_{M}x{N}_{np.dtype(dt).name}", v, x64, x32)
 
 
+@pytest.mark.parametrize("resident", [1, 0])
+@pytest.mark.parametrize("dt,M,N,K", [(np.complex64, 4096, 2048, 8), (np.float32, 512, 256, 3), (np.complex64, 272, 144, 20),
+                                      (np.complex64, 1040, 208, 7), (np.float32, 1040, 208, 33)])
+def test_batched_gram_mode_matrix_rhs(rls, ctx, dt, M, N, K, resident):
+    """Matrix right-hand sides on the reference constructors' DEFAULT operator for a dense matrix, AHA = A' * A explicit
+    (src/CGNR.jl:49, src/FISTA.jl:58, src/ADMM.jl:81): every column's state shares that one solver.AHA
+    (src/MultiThreading.jl:30-48), so a batched iteration is ONE skinny product V = AHA P over N x N elements instead of two
+    passes over A.  CGNR (with per-column relTol retirement), FISTA + L1 and ADMM + L1 columns against the float64
+    oracle's Gram-mode solves; resident = 1 additionally lets <= 8 ComplexF32 columns run on the register-resident form."""
+    if resident == 0 and not (np.dtype(dt).kind == "c" and K <= 8):
+        pytest.skip("same kernels as resident = 1 for this case")
+    ctx.tune(resident=resident)
+    try:
+        A, X, B = O.make_problem(M, N, dt, 29, n_rhs=K)
+        B = np.asfortranarray(B)
+        B[:, 0] *= 1e-3
+        dt64 = hi(dt)
+        Ad = rls.DeviceMatrix.from_host(A)
+        Gd = Ad.gram()
+        Bd = rls.DeviceMatrix.from_host(B)
+        iters = 12
+        tag = f"batched_gram_{M}x{N}_{np.dtype(dt).name}_K{K}_res{resident}"
+        for relTol in (0.0, 1e-4):
+            S = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=relTol)
+            xs = rls.solve_(S, Bd, scheduler=rls.BatchedState)
+            assert isinstance(S.state, rls.BatchedState), "Gram-mode matrix solves must take the shared-AHA plan"
+            its = [s_.iteration for s_ in S.state.status()]
+            for j in range(K):
+                ref = O.CGNR(A.astype(dt64), reg=O.L2Regularization(1e-3), iterations=iters, relTol=relTol, normal="gram")
+                O.solve(ref, B[:, j].astype(dt64))
+                x32 = lambda: O.solve(O.CGNR(A, reg=O.L2Regularization(1e-3), iterations=ref.iteration, relTol=0.0, normal="gram"),
+                                      np.ascontiguousarray(B[:, j]))
+                assert abs(its[j] - ref.iteration) <= (1 if relTol > 0 else 0), (its, j, ref.iteration)
+                if its[j] == ref.iteration:
+                    parity(f"{tag}_cgnr_reltol{relTol}_col{j}", xs[j].to_host(), ref.x, x32, record=(j < 2))
+        rho = float(0.9 / np.linalg.norm(A.astype(dt64), 2) ** 2)
+        lam = 1e-3 * float(np.abs(A.conj().T @ B[:, 1]).max())
+        F = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(lam), rho=rho, iterations=15, relTol=0.0)
+        fs = rls.solve_(F, Bd, scheduler=rls.BatchedState)
+        assert isinstance(F.state, rls.FistaBatchedState)
+        for j in (0, 1, K - 1):
+            x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=O.L1Regularization(lam), rho=rho, iterations=15, relTol=0.0,
+                                                                 normal="gram"), b_), A, np.ascontiguousarray(B[:, j]))
+            parity(f"{tag}_fista_col{j}", fs[j].to_host(), x64, x32, record=(j < 2))
+        kw = dict(rho=0.1, iterations=4, iterationsCG=5, absTol=0.0, relTol=0.0, tolInner=1e-5)
+        D = rls.createLinearSolver(rls.ADMM, Ad, AHA=Gd, reg=rls.L1Regularization(1e-3), **kw)
+        ds = rls.solve_(D, Bd, scheduler=rls.BatchedState)
+        assert isinstance(D.state, rls.AdmmBatchedState)
+        for j in (0, K - 1):
+            x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.ADMM(A_, reg=O.L1Regularization(1e-3), normal="gram", **kw), b_), A,
+                                   np.ascontiguousarray(B[:, j]))
+            parity(f"{tag}_admm_col{j}", ds[j].to_host(), x64, x32, record=(j < 1))
+    finally:
+        ctx.tune(resident=1)
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 2048, 8), (272, 144, 3), (1040, 208, 7)])
 def test_batched_half_operand_panels_change_no_bit(rls, ctx, M, N, K):
     """Up to 8 ComplexF32 right-hand sides ride the matrix cores as (8 re | 8 im) operand columns -- two MFMAs per
