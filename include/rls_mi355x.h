@@ -309,7 +309,9 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
  * 0 = two GEMVs + update kernel, 1 = one-pass slab pipeline (two launches per iteration), 2 = Gram-mode pipeline
  * (one launch per iteration), 3 = batched matrix-core kernels, 4 = resident (the whole call in ONE launch, A held in
  * registers across iterations; needs A <= the register files), 5 = resident Gram mode (the same with AHA explicit and
- * held in registers: one in-kernel grid exchange per iteration). */
+ * held in registers: one in-kernel grid exchange per iteration), 6 = batched on an explicit AHA (ONE matrix-core product
+ * V = AHA P per iteration), 7 = the same as ONE resident launch per step call (<= 8 ComplexF32 columns, N <= 2048: AHA in
+ * the register files, the operand panel in LDS; calls of a single iteration take path 6). */
 int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out);
 
 /* ---------------------------------------------------------------------------------------------

@@ -755,6 +755,24 @@ int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const 
 int32_t rls_skinny_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
                         int64_t ldg, void* panels);
 
+// Batched CGNR on an explicit Gram matrix as ONE resident launch per step call (gramk.hip): up to 8 ComplexF32 right-hand
+// sides, AHA (N <= 2048) held in the register files, the operand panel replicated in every workgroup's LDS
+struct rls_gramk {
+  const void* G;
+  int64_t ldg, N;
+  int nrhs;
+  void *X, *R, *P, *V;  // N x nrhs, columns ldv elements apart (caller's)
+  int64_t ldv;
+  cgnr_scalars* sc;     // [nrhs]
+  float* Vx;            // exchanged rows of V = AHA P, two parities (rls_gramk_sizes)
+  void* Xx;             // x gathered at the end of the launch
+  double* dots;         // per-workgroup partial <p, v>, ||p||^2, two parities
+  float* Ppack;         // the streaming kernels' operand panel, kept in step (nullable)
+};
+void rls_gramk_sizes(int64_t N, size_t* vx_bytes, size_t* xx_bytes, size_t* dots_bytes);
+bool rls_gramk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, const void* G, int64_t ldg);
+int32_t rls_gramk_resident_launch(rls_ctx* ctx, const rls_gramk& D, void* sync, int n_steps, unsigned spin_limit);
+
 // ---------------------------------------------------------------------------------------------
 // comm.hip internals used by the row-sharded solver loops (solvers.hip)
 // ---------------------------------------------------------------------------------------------

@@ -166,6 +166,11 @@ struct rls_cgnr {
   int fallbacks;        // resident launches lost and recovered so far
   long long requested;  // iterations asked for since init
   bool rsync_clean = false;  // the init kernel has just zeroed the arrival counters (resident_chain)
+  // batched plan on an explicit Gram matrix, <= 8 ComplexF32 columns, AHA in the register files (gramk.hip): exchange scratch
+  bool gramk = false;
+  float* gk_vx = nullptr;
+  void* gk_xx = nullptr;
+  double* gk_dots = nullptr;
 };
 
 static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
@@ -213,6 +218,32 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
   K.ldvp = s->op->N;
   K.sc = s->sc;
   return K;
+}
+
+// batched Gram mode as ONE resident launch per step call (a call of one iteration -- the callback cadence -- is cheaper on
+// the streaming kernels: a resident launch loads its rows of AHA and gathers x once per call)
+static bool cgnr_use_gramk(const rls_cgnr* s, int n_steps) {
+  return s->gramk && s->rsync && !s->resident_off && s->op->ctx->tune.resident &&
+         (n_steps != 1 || s->op->ctx->tune.resident == 2);  // resident = 2 (tools, tests): single-iteration calls too
+}
+
+static rls_gramk cgnr_gramk_desc(const rls_cgnr* s) {
+  rls_gramk D;
+  D.G = s->op->G;
+  D.ldg = s->op->ldg;
+  D.N = s->op->N;
+  D.nrhs = s->nrhs;
+  D.X = s->x;
+  D.R = s->r;
+  D.P = s->p;
+  D.V = s->v;
+  D.ldv = s->ldv;
+  D.sc = s->sc;
+  D.Vx = s->gk_vx;
+  D.Xx = s->gk_xx;
+  D.dots = s->gk_dots;
+  D.Ppack = s->half ? s->Ppack : nullptr;  // (<= 8 complex columns: the half layout, unless switched off by the tools)
+  return D;
 }
 
 static bool cgnr_use_gram_resident(const rls_cgnr* s) {
@@ -2027,6 +2058,17 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
     if (e == hipSuccess) e = dmalloc(&s->Tpack, tb);
     if (e == hipSuccess) e = dmalloc(&s->Vpart, vb);
+    if (e == hipSuccess && op->G && s->half && rls_gramk_resident_ok(ctx, op->dtype, op->N, nrhs, op->G, op->ldg)) {
+      size_t xb, xxb, db;
+      rls_gramk_sizes(op->N, &xb, &xxb, &db);
+      e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
+      if (e == hipSuccess) e = dmalloc(&s->gk_vx, xb);
+      if (e == hipSuccess) e = hipMemsetAsync(s->gk_vx, 0, xb, ctx->stream);  // rows >= N are read, never written
+      if (e == hipSuccess) e = dmalloc(&s->gk_xx, xxb);
+      if (e == hipSuccess) e = dmalloc(&s->gk_dots, db);
+      if (e == hipSuccess) e = hipMemsetAsync(s->gk_dots, 0, db, ctx->stream);  // slots of absent workgroups add 0.0
+      s->gramk = e == hipSuccess;
+    }
   }
   if (e != hipSuccess) {
     rls_cgnr_destroy(s);
@@ -2061,6 +2103,9 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->Ppack) dfree(s->Ppack);
   if (s->Tpack) dfree(s->Tpack);
   if (s->Vpart) dfree(s->Vpart);
+  if (s->gk_vx) dfree(s->gk_vx);
+  if (s->gk_xx) dfree(s->gk_xx);
+  if (s->gk_dots) dfree(s->gk_dots);
   if (s->rsync) dfree(s->rsync);
   if (s->rdots) dfree(s->rdots);
   if (s->rsync_h) hfree(s->rsync_h);
@@ -2121,6 +2166,7 @@ int32_t rls_cgnr_init_batched(rls_cgnr* s, const void* B, int64_t ldb, float lam
     s->sc_h->rel_tol = rel_tol;
     s->sc_h->max_iter = max_iter;
     s->initialised = true;
+    s->requested = 0;
     return 0;
   }
   if (!cgnr_use_pipeline(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr_init_batched: fused pipeline not active");
@@ -2145,13 +2191,31 @@ int32_t rls_cgnr_init_batched(rls_cgnr* s, const void* B, int64_t ldb, float lam
   return launch_status(ctx);
 }
 
+static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps);
 int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->resident_used) RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
   RLS_HIP(ctx, hipMemcpyAsync(s->sc_h, s->sc, sizeof(cgnr_scalars) * (size_t)s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
   RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  if (s->resident_used && resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks)) {
+    // a lost resident launch changed nothing: the live columns are all at the same count (they advance in lockstep since
+    // init; retired ones stay behind), so what is missing is requested - that count, re-run on the streaming kernels
+    long long at = 0;
+    bool live = false;
+    for (int b = 0; b < s->nrhs; ++b) {
+      if (s->sc_h[b].iteration > at) at = s->sc_h[b].iteration;
+      live = live || !s->sc_h[b].done;
+    }
+    const long long missing = s->requested - at;
+    if (live && missing > 0) {
+      RLS_TRY(cgnr_step_impl(s, (int32_t)(missing > 0x7fffffff ? 0x7fffffff : missing)));
+      RLS_HIP(ctx, hipMemcpyAsync(s->sc_h, s->sc, sizeof(cgnr_scalars) * (size_t)s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
+      RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+    }
+  }
   for (int b = 0; b < s->nrhs; ++b) {
     const cgnr_scalars& h = s->sc_h[b];
     out[b].iteration = h.iteration;
@@ -2163,13 +2227,21 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
     out[b].zeta = (float)h.zeta;
     out[b].residual = (float)sqrt(h.rr);
     out[b].z0 = (float)h.z0;
-    out[b].fallbacks = 0;
+    out[b].fallbacks = s->fallbacks;
   }
   return 0;
 }
 
 static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps) {
   rls_ctx* ctx = s->op->ctx;
+  if (s->skinny && cgnr_use_gramk(s, n_steps)) {
+    if (n_steps == 0) return 0;
+    const rls_gramk D = cgnr_gramk_desc(s);
+    s->resident_used = true;
+    return resident_chain(ctx, s->rsync, [&]() {
+      return rls_gramk_resident_launch(ctx, D, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+    }, &s->rsync_clean);
+  }
   if (s->skinny) {
     const rls_skinny K = cgnr_skinny_desc(s);
     const int32_t dtype = s->op->dtype;
@@ -2380,7 +2452,7 @@ int32_t rls_fista_step_rowsharded(rls_comm* comm, rls_fista* const* plans, int32
 
 int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out) {
   if (!s || !out) return RLS_E_INVALID;
-  *out = s->skinny ? 3 : cgnr_use_gram_resident(s) ? 5 : cgnr_use_gram_pipeline(s) ? 2 : cgnr_use_resident(s) ? 4 : cgnr_use_pipeline(s) ? 1 : 0;
+  *out = s->skinny ? (cgnr_use_gramk(s, 0) ? 7 : s->op->G ? 6 : 3) : cgnr_use_gram_resident(s) ? 5 : cgnr_use_gram_pipeline(s) ? 2 : cgnr_use_resident(s) ? 4 : cgnr_use_pipeline(s) ? 1 : 0;
   return 0;
 }
 
