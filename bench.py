@@ -9,7 +9,10 @@ column-major ComplexF32 4096x2048 A that is already resident in HBM (lambda = 0,
 when that region is shorter than 10 ms it is repeated (>= 50 times, every repetition bracketed the same way) and
 `value` = K / median(elapsed), with the spread reported beside it.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): the SAME workload and unit on every GPU -- one
+N > 1: one process per GPU.  `python bench.py --gpus N` from a plain shell starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` itself, as a CHILD process, before anything has
+touched torch or HIP, relays its output and exit code (`--dry-launch` prints that command line and exits); under an external
+torchrun (RANK / WORLD_SIZE set) it runs as a rank.  The SAME workload and unit on every GPU -- one
 independent headline solve per GPU (the path shards by independent problems, src/MultiThreading.jl:30-79: no data-path
 collective, weak scaling), `value` = iterations/s summed over the GPUs, so value(N) / (N * value(1)) is an efficiency.
 Every N > 1 line also carries `n1_same_workload_value` (rank 0 running the same steps alone while the other ranks wait)
@@ -483,6 +486,31 @@ def other_paths(rls, ctx, Ad, A, b, errors):
     return out
 
 
+def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32):
+    """the config-5 block of the default N > 1 line: a short `--workload rowsharded` run (it/s, the per-rank step_local_a time
+    and HBM fraction, the all-reduce time, the backend and world size the collective saw) and the one-process host."""
+    from importlib import import_module
+
+    mg = import_module("rls_amd.multigpu")
+    out = {}
+    try:
+        full = mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W)
+        dom = full["roofline"]["kernel"]
+        out = {"metric": full["metric"], "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"], "scaling": "strong",
+               "rows_per_gpu": full["config"]["rows_per_gpu"], "collective": full["config"]["collective"],
+               "step_local_a_us": full["roofline"]["per_kernel"][dom]["us_per_call"],
+               "step_local_a_frac_hbm": full["roofline"]["per_kernel"][dom]["frac_hbm"], "residual": full["residual"]}
+    except Exception as e:  # a leg of its own: it must not cost the headline line
+        out = {"error": f"{type(e).__name__}: {e}"}
+    barrier()
+    try:
+        out["one_process_host"] = mg.bench_rowsharded_one_process(rls, rank, world, K, W)
+    except Exception as e:
+        out["one_process_host"] = {"error": f"{type(e).__name__}: {e}"}
+    barrier()
+    return out
+
+
 def load_pmc(kernel_prefix):
     """HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
     rocprofv3 --pmc runs; tools/pmc_summarize.py); None if not collected for this kernel"""
@@ -497,6 +525,21 @@ def load_pmc(kernel_prefix):
     return None, None
 
 
+def self_launch_command(gpus, argv, env):
+    """the torch.distributed.run command line `python bench.py --gpus N` starts when it is NOT already a rank (no WORLD_SIZE
+    / RANK in the environment) and N > 1; None otherwise.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env:
+        return None
+    import socket
+
+    with socket.socket() as so:  # a free port for the rendezvous
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    child_args = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + child_args
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -509,15 +552,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--resident", type=int, default=1, help="0: force the two-launch pipeline for the headline run")
+    ap.add_argument("--dry-launch", action="store_true", help="N > 1 from a plain shell: print the launch command as JSON and exit")
     args = ap.parse_args()
+
+    launch = self_launch_command(args.gpus, sys.argv[1:], os.environ)
+    if launch is not None:
+        # The parent of the N ranks.  Nothing here may import torch or touch HIP: the ranks are child processes (a process
+        # that has initialised the GPU must not replace itself with another program on this pool).
+        if args.dry_launch:
+            print(json.dumps({"launch": launch, "torch_imported": "torch" in sys.modules}))
+            return 0
+        import subprocess
+
+        return subprocess.run(launch).returncode  # rank 0's JSON line goes straight to our stdout
+    if args.dry_launch:
+        print(json.dumps({"launch": None, "torch_imported": "torch" in sys.modules}))
+        return 0
 
     import torch  # plumbing: device selection, barrier, max-over-ranks
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: start with `python bench.py --gpus N` (it launches the ranks) "
+                         "or under torch.distributed.run with --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -782,6 +841,12 @@ def main():
         c4 = {k: c4_full[k] for k in ("metric", "value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
                                       "per_rank_solve_iterations_per_s_hip_events") if k in c4_full}
         c4["roofline"] = {k: c4_full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
+    c5 = None
+    if world > 1:
+        # BASELINE configs[4] on the same job: the 65536 x 8192 problem row-partitioned over the ranks, one all-reduce of
+        # A^H t per iteration through torch.distributed (RCCL); then the one-process host of the same problem -- rank 0 alone
+        # driving every GPU through the library's own communicator (the Julia host's call sequence) -- while the others wait
+        c5 = config5_leg(rls, ctx, dist, rank, world, barrier)
     traffic, traffic_src = load_pmc(dom)
     kd = kern[dom]
     hbm_bytes = traffic if traffic is not None else kd["min_hbm_bytes_per_launch"]
@@ -837,6 +902,8 @@ def main():
             out["efficiency_vs_n1_same_workload"] = out["value"] / (world * n1_value)
         if c4 is not None:
             out["config4_batched"] = c4
+        if c5 is not None:
+            out["config5_rowsharded"] = c5
         errors = []
         if world == 1 and not args.no_extras and (M, N) == (4096, 2048):
             out["other_paths"] = other_paths(rls, ctx, Ad, A, bd, errors)
@@ -850,4 +917,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -50,7 +50,6 @@ constexpr int GK_WV = 8, GK_NT = GK_WV * 64;
 constexpr int GK_SPW = 64;                  // MFMA steps (4 columns of AHA each) per wave at N = GK_NMAX
 constexpr int GK_NMAX = GK_WV * GK_SPW * 4; // 2048
 constexpr int GK_ROWS = 8, GK_KB = 8;       // complex rows of AHA per workgroup; right-hand sides per launch
-constexpr int GK_EPTU = GK_NMAX * 2 / GK_NT; // 4-column units (one row x 4 right-hand sides) per thread: 8
 #ifndef GK_VB_EARLY
 #define GK_VB_EARLY 1  // all of a thread's V loads requested right behind the grid barrier (0: the second half when alpha is known)
 #endif
@@ -202,10 +201,10 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t vx_rs = sc1_rsrc(D.Vx);
-  const __amdgpu_buffer_rsrc_t d_rs = sc1_rsrc(D.dots);
-  // exchanged V: [parity][h][row][(re, im) of columns 4 h, 4 h + 1 | of 4 h + 2, 4 h + 3]: 32 bytes per (row, h)
-  const uint32_t vx_half = (uint32_t)npad * 32u, vx_par = 2u * vx_half;
-  const uint32_t vx_lane = (uint32_t)h * vx_half + (uint32_t)nl * 32u;
+  // exchanged V: [parity][column half h][piece][row][16 bytes]; piece 0 = the (re, im) pairs of columns 4 h, 4 h + 1, piece 1 =
+  // of columns 4 h + 2, 4 h + 3 (operands of the update's FMAs as they come); a wave's load of one piece is 1 KiB contiguous
+  const uint32_t vx_piece = (uint32_t)npad * 16u, vx_par = 4u * vx_piece;
+  const uint32_t vx_lane = (uint32_t)(2 * h) * vx_piece + (uint32_t)nl * 16u;
   // this lane's B-operand address inside a step: rows 4 s' + (lane >> 4), operand column lane & 15
   const uint32_t jq = (uint32_t)(lane >> 4), jj = (uint32_t)(lane & 15);
   const uint32_t lane_const = (2u * (jj >> 3) + ((jj >> 2) & 1u)) * GK_REG + jq * 16u + (jj & 3u) * 4u;
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
         const int i = tl - 32, hh = i >> 4, r = (i >> 1) & 7, pp = i & 1;
         const float* sp = T.stage + r * 16 + hh * 4 + pp * 2;
         const f4 val = {sp[0], sp[8], sp[1], sp[9]};
-        gk_sc1_store16(vx_rs, (uint32_t)q * vx_par + (uint32_t)hh * vx_half + (uint32_t)(row0 + r) * 32u + (uint32_t)pp * 16u, val);
+        gk_sc1_store16(vx_rs, (uint32_t)q * vx_par + (uint32_t)(2 * hh + pp) * vx_piece + (uint32_t)(row0 + r) * 16u, val);
       }
       if (tl == 0) {  // every column had retired before this iteration: it is not applied (uniform: replicated scalars)
         int all = 1;
@@ -307,18 +306,28 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
       // 16 bg .. 16 bg + 15 in that order
       const uint32_t voff = (uint32_t)(tl >> 5) * 16u * 256u + (uint32_t)(tl & 31) * 8u;
       const uint32_t qoff = (uint32_t)q * 256u * 256u;
+      // The partial dots are wanted first and the 16 KiB of V behind them should stay in flight meanwhile -- but with all 32
+      // loads written as builtins hipcc waits vmcnt(0) in front of the first addition (seen in the ISA).  So the 16 small loads
+      // are issued by hand and waited for by hand: vmcnt(2 NE) = "everything but the V loads behind them" (loads return in order).
       double part[16];
+      const unsigned long long da = (unsigned long long)D.dots;  // raw buffer descriptor: base, stride 0, no bound, dword format
+      const u4 d_desc = {(unsigned)da, (unsigned)(da >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
 #pragma unroll
       for (int i = 0; i < 16; ++i)
-        part[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(d_rs, voff, qoff + (uint32_t)i * 256u, 16));
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(part[i]) : "v"(voff), "s"(d_desc), "s"(qoff + (uint32_t)i * 256u) : "memory");
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         {  // rows >= N hold zeros in r, p and (never written) Vx: they stay zero
-          v01[e] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(vx_rs, vx_lane, (uint32_t)q * vx_par + e * 8192u, 16));
-          v23[e] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(vx_rs, vx_lane, (uint32_t)q * vx_par + e * 8192u + 16u, 16));
+          v01[e] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(vx_rs, vx_lane, (uint32_t)q * vx_par + e * 4096u, 16));
+          v23[e] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(vx_rs, vx_lane, (uint32_t)q * vx_par + vx_piece + e * 4096u, 16));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%16)"
+                   : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7]),
+                     "+v"(part[8]), "+v"(part[9]), "+v"(part[10]), "+v"(part[11]), "+v"(part[12]), "+v"(part[13]), "+v"(part[14]),
+                     "+v"(part[15])
+                   : "n"(2 * NE));
       double s = 0.0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) s += part[i];

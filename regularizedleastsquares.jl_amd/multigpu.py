@@ -890,3 +890,57 @@ def bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=65536, N=8192):
                          "note": "achieved = whole-job algorithmic bytes (A read twice per iteration) / wall time; the shard (512 MiB at 8 "
                                  "ranks) exceeds the 256 MiB Infinity Cache, so both GEMVs stream from HBM"},
             "residual": st["residual"]}
+
+
+def bench_rowsharded_one_process(rls, rank, world, K, W, M=65536, N=8192):
+    """BASELINE config 5 from ONE host process (the Julia host's shape): rank 0 of the job drives `world` GPUs through the library's
+    own communicator (rls_comm_*: per-rank worker threads, the one-shot direct-write all-reduce over xGMI, then RCCL inside the
+    library) while the other ranks of the job wait.  Returns (rank 0) iterations/s per transport and the host time the busiest
+    worker spent enqueueing per iteration (rls_comm_debug_busy_seconds); None on the other ranks."""
+    if rank != 0:
+        return None
+    out = {}
+    shards, parts = [], []
+    rng = np.random.default_rng(7)
+    x_true = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(np.complex64)
+    for r in range(world):
+        A, lo, hi = make_row_shard(M, N, r, world)
+        shards.append(A)
+        parts.append((A @ x_true).astype(np.complex64))
+    seg = 32
+    for name, transport in (("direct", COMM_DIRECT), ("rccl", COMM_RCCL)):
+        try:
+            s = CommRowShardedCGNR(rls, shards, devices=list(range(world)), transport=transport, iterations=seg, relTol=0.0)
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        try:
+            def run(n):
+                while n > 0:
+                    m = min(n, seg)
+                    s.init(parts)
+                    s.step(m)
+                    n -= m
+
+            run(W)
+            s.sync()
+            busy0 = (C.c_double * world)()
+            s.lib.rls_comm_debug_busy_seconds(s.comm, busy0)
+            t0 = time.perf_counter()
+            run(K)
+            s.sync()
+            el = time.perf_counter() - t0
+            busy1 = (C.c_double * world)()
+            s.lib.rls_comm_debug_busy_seconds(s.comm, busy1)
+            st = s.status(0)
+            out[name] = {"iterations_per_s": K / el, "us_per_iteration": 1e6 * el / K, "transport_code": int(s.transport), "ranks": world,
+                         "host_busy_us_per_iteration_per_rank": [1e6 * (b1 - b0) / K for b0, b1 in zip(busy0, busy1)],
+                         "residual": st["residual"]}
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            try:
+                s.close()
+            except Exception:
+                pass
+    return out

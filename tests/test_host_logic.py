@@ -73,3 +73,36 @@ def test_dtype_guard(rls):
     assert dtype_code(np.float32) == 0 and dtype_code(np.complex64) == 1
     with pytest.raises(TypeError, match="Float32 / ComplexF32"):
         dtype_code(np.float64)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` from a plain shell (no RANK / WORLD_SIZE) must start torch.distributed.run itself, as a
+    CHILD process and before torch or HIP is touched, relay the child's exit code, and stay launchable under an external
+    torchrun (the first 8-GPU node would otherwise have recorded a usage message)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = d["launch"]
+    assert d["torch_imported"] is False  # the parent decides before importing torch (nothing of it may initialise the GPU)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(bench):]
+    assert tail == [bench, "--gpus", "8", "--steps", "20", "--warmup", "5"]  # the ranks get the same arguments, minus --dry-launch
+    # a rank (or N = 1) does not launch anything
+    for extra_env, args in (({"WORLD_SIZE": "8", "RANK": "3"}, ["--gpus", "8"]), ({}, ["--gpus", "1"]), ({}, [])):
+        r = subprocess.run([sys.executable, bench, *args, "--dry-launch"], env={**env, **extra_env}, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["launch"] is None
+    # exit code of the ranks comes back: without a GPU every rank stops with "bench.py needs an MI355X"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in (r.stderr + r.stdout)
