@@ -71,11 +71,6 @@ int32_t rls_device_count(int32_t* out);
  * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll" (rolling-window
  * depth of the batched kernels' load pipelines), "gram_lds_kib", "kaczmarz_nt". */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
-/* test utility (tests/test_gpu_parity.py, the co-tenancy test): enqueue on ctx's stream a kernel of n_workgroups
- * workgroups that each hold a whole CU (1024 threads, all of its LDS) for `microseconds` of wall clock and do nothing
- * else -- what another tenant of the device looks like to a kernel that needs every CU at once.  Bounded: <= 2 s. */
-int32_t rls_debug_hold_cus(rls_ctx* ctx, int32_t n_workgroups, int32_t microseconds);
-
 int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out);  /* similar(b, dims...)  src/CGNR.jl:92-95 */
 int32_t rls_free(rls_ctx* ctx, void* p);
 int32_t rls_memcpy_h2d(rls_ctx* ctx, void* dst, const void* src_h, size_t bytes);

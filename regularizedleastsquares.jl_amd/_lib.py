@@ -69,7 +69,6 @@ PROTOTYPES = {
     "rls_last_error_string": (C.c_char_p, [_vp]),
     "rls_device_count": (_i32, [_pi32]),
     "rls_tune_set": (_i32, [_vp, C.c_char_p, _i32]),
-    "rls_debug_hold_cus": (_i32, [_vp, _i32, _i32]),
     "rls_malloc": (_i32, [_vp, _sz, _pvp]),
     "rls_free": (_i32, [_vp, _vp]),
     "rls_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),

@@ -224,26 +224,6 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   return 0;
 }
 
-// test utility: workgroups that sit on whole CUs for a given wall-clock time (s_memrealtime ticks at 100 MHz)
-__global__ __launch_bounds__(1024) void hold_cus_kernel(unsigned long long ticks, unsigned* sink) {
-  extern __shared__ char hold_lds[];
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-  if (ticks == ~0ull) sink[threadIdx.x] = (unsigned)hold_lds[threadIdx.x];  // never: keeps the LDS allocation alive
-}
-
-int32_t rls_debug_hold_cus(rls_ctx* ctx, int32_t n_workgroups, int32_t microseconds) {
-  RLS_CHECK_CTX(ctx);
-  if (n_workgroups <= 0 || microseconds < 0 || microseconds > 2000000) return rls_fail(ctx, RLS_E_INVALID, "hold_cus: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t lds = 160 * 1024;
-  RLS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(hold_cus_kernel, dim3((unsigned)n_workgroups), dim3(1024), lds, ctx->stream,
-                     (unsigned long long)microseconds * 100ull, reinterpret_cast<unsigned*>(ctx->res_d));
-  RLS_HIP(ctx, hipGetLastError());
-  return 0;
-}
-
 int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out) {
   RLS_CHECK_CTX(ctx);
   if (!out) return rls_fail(ctx, RLS_E_INVALID, "malloc: null out");

@@ -28,8 +28,9 @@ typedef float gk_f32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_gk_stamps[16 * 8];
 #define GK_STAMP(slot)                                                                           \
   do {                                                                                           \
-    if (threadIdx.x == 0 && (blockIdx.x % 37) == 5 && blockIdx.x / 37 < 8)                       \
+    if (threadIdx.x == 0 && (blockIdx.x % 37) == 5 && blockIdx.x / 37 < 7)                       \
       g_gk_stamps[(blockIdx.x / 37) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();           \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_gk_stamps[7 * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); /* row 7: workgroup 0 */ \
   } while (0)
 extern "C" int32_t rls_debug_gk_stamps(unsigned long long* out_h) {
   return (int32_t)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_gk_stamps), sizeof(unsigned long long) * 16 * 8);
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
                                                                     unsigned spin_limit) {
   extern __shared__ __align__(16) char gk_lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  GK_STAMP(8);
   const int N = FULL ? 256 * NE : (int)D.N;
   const int nwg = gridDim.x, b = blockIdx.x, row0 = b * GK_ROWS;
   // MFMA steps (4 columns of AHA) per wave, a multiple of 8 = one 32-row group of the panel: wave w takes steps
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
     }
   }
   __syncthreads();
+  GK_STAMP(9);
   const __amdgpu_buffer_rsrc_t vx_rs = sc1_rsrc(D.Vx);
   // exchanged V: [parity][column half h][piece][row][16 bytes]; piece 0 = the (re, im) pairs of columns 4 h, 4 h + 1, piece 1 =
   // of columns 4 h + 2, 4 h + 3 (operands of the update's FMAs as they come); a wave's load of one piece is 1 KiB contiguous
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
     GK_STAMP(7);
   }
   gk_lds_tail& T = T0;
+  GK_STAMP(10);
   if (alive) {
     // ---- gather x: every workgroup publishes its rows, one more barrier, workgroup 0 writes the caller's state -------------
     float2* Xx = reinterpret_cast<float2*>(D.Xx);
@@ -474,15 +478,32 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
     resident_give_up(sync, nullptr);
     return;  // x, r, p and the scalars are untouched: the call was a no-op (V's rows may hold products of the lost launch)
   }
+  GK_STAMP(11);
   if (b != 0) return;
   {
     float2* Xo = reinterpret_cast<float2*>(D.X);
     float2* Ro = reinterpret_cast<float2*>(D.R);
     float2* Po = reinterpret_cast<float2*>(D.P);
     const float2* Xx = reinterpret_cast<const float2*>(D.Xx);
-    for (int idx = tid; idx < N * nrhs; idx += GK_NT) {
-      const int k = idx / N, n = idx - k * N;
-      Xo[(int64_t)k * D.ldv + n] = sc1_load_elem<float2>(Xx + (size_t)n * GK_KB + k);
+    // x: 8 gathered elements in flight per thread (one load, one store at a time was 32 dependent round trips: 48 us)
+    const int total = N * nrhs;
+    for (int i0 = 0; i0 < total; i0 += GK_NT * 8) {
+      float2 xg[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + u * GK_NT + tid;
+        const int ic = idx < total ? idx : 0;
+        const int k = ic / N, n = ic - k * N;
+        xg[u] = sc1_load_elem<float2>(Xx + (size_t)n * GK_KB + k);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + u * GK_NT + tid;
+        if (idx < total) {
+          const int k = idx / N, n = idx - k * N;
+          Xo[(int64_t)k * D.ldv + n] = xg[u];
+        }
+      }
     }
     float* pp = D.Ppack;  // the streaming kernels' operand panel ([n][8 re | 8 im]) kept in step
     int nl2 = nl;
@@ -523,6 +544,7 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
       s->fresh = 0;
     }
     if (tid == 0) sync->completed = 1u;
+    GK_STAMP(12);
   }
 }
 

@@ -902,17 +902,16 @@ def _batched_case(rls, ctx, dt, M, N, K):
     parity(f"batched_then_vector_{M}x{N}_{np.dtype(dt).name}", v, x64, x32)
 
 
-@pytest.mark.parametrize("resident", [1, 0])
-@pytest.mark.parametrize("dt,M,N,K", [(np.complex64, 4096, 2048, 8), (np.float32, 512, 256, 3), (np.complex64, 272, 144, 20),
-                                      (np.complex64, 1040, 208, 7), (np.float32, 1040, 208, 33)])
+@pytest.mark.parametrize("dt,M,N,K,resident", [(np.complex64, 4096, 2048, 8, 1), (np.complex64, 4096, 2048, 8, 0), (np.float32, 512, 256, 3, 1),
+                                               (np.complex64, 272, 144, 20, 1), (np.complex64, 1040, 208, 7, 1), (np.complex64, 1040, 208, 7, 0),
+                                               (np.complex64, 2000, 1936, 5, 1), (np.float32, 1040, 208, 33, 1)])
 def test_batched_gram_mode_matrix_rhs(rls, ctx, dt, M, N, K, resident):
     """Matrix right-hand sides on the reference constructors' DEFAULT operator for a dense matrix, AHA = A' * A explicit
     (src/CGNR.jl:49, src/FISTA.jl:58, src/ADMM.jl:81): every column's state shares that one solver.AHA
     (src/MultiThreading.jl:30-48), so a batched iteration is ONE skinny product V = AHA P over N x N elements instead of two
     passes over A.  CGNR (with per-column relTol retirement), FISTA + L1 and ADMM + L1 columns against the float64
-    oracle's Gram-mode solves; resident = 1 additionally lets <= 8 ComplexF32 columns run on the register-resident form."""
-    if resident == 0 and not (np.dtype(dt).kind == "c" and K <= 8):
-        pytest.skip("same kernels as resident = 1 for this case")
+    oracle's Gram-mode solves.  resident = 1: <= 8 ComplexF32 columns with N <= 2048 run the whole step call as ONE launch
+    (csrc/gramk.hip: AHA in the register files, the operand panel in LDS, path 7); resident = 0 and every other case: path 6."""
     ctx.tune(resident=resident)
     try:
         A, X, B = O.make_problem(M, N, dt, 29, n_rhs=K)
@@ -928,7 +927,11 @@ def test_batched_gram_mode_matrix_rhs(rls, ctx, dt, M, N, K, resident):
             S = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=relTol)
             xs = rls.solve_(S, Bd, scheduler=rls.BatchedState)
             assert isinstance(S.state, rls.BatchedState), "Gram-mode matrix solves must take the shared-AHA plan"
-            its = [s_.iteration for s_ in S.state.status()]
+            fits = resident == 1 and np.dtype(dt).kind == "c" and K <= 8 and N <= 2048
+            assert _cgnr_path(rls, S) == (7 if fits else 6), _cgnr_path(rls, S)
+            stat = S.state.status()
+            assert all(s_.fallbacks == 0 for s_ in stat)
+            its = [s_.iteration for s_ in stat]
             for j in range(K):
                 ref = O.CGNR(A.astype(dt64), reg=O.L2Regularization(1e-3), iterations=iters, relTol=relTol, normal="gram")
                 O.solve(ref, B[:, j].astype(dt64))
@@ -2032,6 +2035,31 @@ def test_random_shapes_svt_prox_and_batched_kaczmarz(rls, ctx):
 # ---- resident CGNR: the whole step call in one launch, A in registers across iterations ----------------------
 
 
+def _hold_cus(rls, ctx, n_workgroups, microseconds):
+    """the CU-parking kernel of the co-tenancy tests: a TEST hook in its own shared object (csrc/test_hooks.hip), not a symbol
+    of the product library"""
+    import ctypes as C
+    import os
+
+    lib = C.CDLL(os.path.join(os.path.dirname(rls.LIB_PATH), "librls_test_hooks.so"))
+    lib.rls_test_hold_cus.restype = C.c_int32
+    lib.rls_test_hold_cus.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    ctx.lib.rls_ctx_stream.restype = C.c_void_p
+    return lib.rls_test_hold_cus(ctx.lib.rls_ctx_stream(ctx.handle), 0, int(n_workgroups), int(microseconds))
+
+
+def _resident_unavailable():
+    """A resident kernel needs one workgroup per CU on up to 256 CUs.  On the device these tests are written for (MI355X: 256
+    CUs) a plan that is not resident is a REGRESSION of the headline kernel's eligibility, not a reason to skip its parity gate;
+    only a smaller device may skip."""
+    import torch
+
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus >= 256:
+        pytest.fail(f"resident mode not available on a {cus}-CU device: the headline kernels' parity gate would not run")
+    pytest.skip(f"resident kernels need 256 CUs; this device has {cus}")
+
+
 def _cgnr_path(rls, sol):
     import ctypes as C
     out = C.c_int32(-1)
@@ -2057,7 +2085,7 @@ def test_cgnr_resident_kernel(rls, ctx, dt, M, N, lam):
     sol = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), iterations=iters, relTol=0.0)
     rls.init_(sol, bd)
     if _cgnr_path(rls, sol) != 4:
-        pytest.skip("resident mode not available on this device / with other contexts alive")
+        _resident_unavailable()
     ref.init(b.astype(hi(dt)))
     ref32.init(b)
     r0 = np.linalg.norm(ref.A.mul_adj(b.astype(hi(dt))))
@@ -2124,7 +2152,7 @@ def test_cgnr_resident_timeout_falls_back_to_the_pipeline(rls, ctx):
             sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=8, relTol=0.0)
             rls.init_(sol, bd)
             if _cgnr_path(rls, sol) != 4:
-                pytest.skip("resident mode not available")
+                _resident_unavailable()
             ctx.tune(resident_spin=1)
             assert ctx.lib.rls_cgnr_step(sol.state._plan, 4) == 0       # lost: a no-op
             ctx.tune(resident_spin=100000)
@@ -2144,6 +2172,35 @@ def test_cgnr_resident_timeout_falls_back_to_the_pipeline(rls, ctx):
     x = rls.solve_(sol, bd).to_host()
     assert _cgnr_path(rls, sol) == 4 and sol.state._refresh(ctx.lib).fallbacks == 0
     parity("cgnr_resident_after_timeout", x, ref[8], lambda: O.solve(O.CGNR(A, iterations=8, relTol=0.0), b))
+
+
+def test_batched_gram_resident_lost_launch_is_recovered(rls, ctx):
+    """the batched resident launch (csrc/gramk.hip) under the same contract as the single-column ones: with the wait bound forced
+    to one poll the launch gives up having changed nothing (only workgroup 0 writes the caller's state, after its last
+    barrier), the status call re-runs the missing iterations on the streaming kernels (path 6), reports `fallbacks`, and the
+    columns are those of an undisturbed solve"""
+    M, N, K = 4096, 2048, 8
+    A, X, B = O.make_problem(M, N, np.complex64, 31, n_rhs=K)
+    B = np.asfortranarray(B)
+    Ad = rls.DeviceMatrix.from_host(A)
+    Gd, Bd = Ad.gram(), rls.DeviceMatrix.from_host(B)
+    _fresh_resident_ctx(ctx)
+    try:
+        S = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, iterations=10, relTol=0.0)
+        rls.init_(S, Bd, scheduler=rls.BatchedState)
+        assert _cgnr_path(rls, S) == 7
+        ctx.tune(resident_spin=1)
+        S.state._step(10)  # lost: a no-op
+        ctx.tune(resident_spin=100000)
+        stat = S.state.status()
+        assert [s_.iteration for s_ in stat] == [10] * K and all(s_.fallbacks >= 1 for s_ in stat)
+        assert _cgnr_path(rls, S) == 6  # the plan stays on the streaming kernels
+        for j in (0, K - 1):
+            x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.CGNR(A_, iterations=10, relTol=0.0, normal="gram"), b_), A, np.ascontiguousarray(B[:, j]))
+            parity(f"batched_gram_resident_recovered_col{j}", S.state.solutions()[j].to_host(), x64, x32)
+    finally:
+        ctx.tune(resident_spin=100000)
+        _fresh_resident_ctx(ctx)
 
 
 def test_resident_solvers_survive_a_co_tenant(rls, ctx):
@@ -2174,7 +2231,7 @@ def test_resident_solvers_survive_a_co_tenant(rls, ctx):
             sol = make(rls, Ad)
             rls.init_(sol, bd)
             ctx.sync()
-            assert other.lib.rls_debug_hold_cus(other.handle, 64, 400000) == 0   # 0.4 s on 64 CUs, other stream
+            assert _hold_cus(rls, other, 64, 400000) == 0   # 0.4 s on 64 CUs, other stream
             x = rls.solve_(sol, bd).to_host()
             other.sync()
             st = sol.state._refresh(ctx.lib) if name != "admm" else None
@@ -2216,7 +2273,7 @@ def test_optista_pogm_resident_launch(rls, ctx, name, dt, M, N):
         x = rls.solve_(sol, bd).to_host()
         plan = sol._pgm[1]
         if plan is None:
-            pytest.skip("resident mode not available on this device")
+            _resident_unavailable()
         assert not plan.off and plan.fallbacks == 0 and sol.state.iteration == its
         parity(f"{tag}_its{its}", x, ref.x, ref32, record=its == 30)
         assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
@@ -2285,12 +2342,12 @@ def test_optista_pogm_resident_lost_launch(rls, ctx, name):
         sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0)
         rls.init_(sol, bd)
         ctx.sync()
-        assert other.lib.rls_debug_hold_cus(other.handle, 64, 400000) == 0
+        assert _hold_cus(rls, other, 64, 400000) == 0
         sol._run(sol.state)
         other.sync()
         plan = sol._pgm[1]
         if plan is None:
-            pytest.skip("resident mode not available on this device")
+            _resident_unavailable()
         assert plan.off and plan.fallbacks >= 1, "the co-tenant did not displace the resident launch"
         assert sol.state.iteration == its
         parity(f"co_tenant_{name}", sol.state.x.to_host(), ref.x,
@@ -2325,7 +2382,7 @@ def test_fista_resident_kernel(rls, ctx, dt, M, N, restart):
     path = C.c_int32(-1)
     assert ctx.lib.rls_fista_path(sol.state._plan, C.byref(path)) == 0
     if path.value != 4:
-        pytest.skip("resident mode not available on this device")
+        _resident_unavailable()
     ref.init(b64)
     ref32.init(b)
     tag = f"fista_resident_{M}x{N}_{np.dtype(dt).name}_{restart}"

@@ -44,3 +44,6 @@ if hasattr(lib, "rls_debug_gk_stamps"):
         t = [buf[wg * 16 + i] for i in range(8)]
         print(f"wg {wg*37+5}: start @{(t[0]-t00)*10:+5d} ns  " + "  ".join(f"[{i}] +{(t[i]-t[0])*10}" for i in range(1, 8)))
     print("phases: " + "; ".join(f"[{i}] {n}" for i, n in enumerate(names)))
+    t = [buf[7 * 16 + i] for i in range(16)]
+    print(f"workgroup 0, whole launch of 20 iterations (us): kernel start -> state loaded (AHA rows, r, p) {(t[9]-t[8])/100:.1f}; iterations "
+          f"{(t[10]-t[9])/100:.1f}; x published + final barrier {(t[11]-t[10])/100:.1f}; workgroup 0 writes the caller's state {(t[12]-t[11])/100:.1f}")
