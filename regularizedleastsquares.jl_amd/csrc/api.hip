@@ -65,7 +65,8 @@ hipError_t rls_pinned_alloc(void** p, size_t bytes) {
     }
   }
   char* raw = nullptr;
-  const hipError_t e = hipHostMalloc((void**)&raw, cls + PIN_HDR, hipHostMallocDefault);
+  // mapped + coherent: the status kernels store into these blocks directly (rls_fetch_wait)
+  const hipError_t e = hipHostMalloc((void**)&raw, cls + PIN_HDR, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
   if (e != hipSuccess) return e;
   *reinterpret_cast<size_t*>(raw) = cls;
   *p = raw + PIN_HDR;
@@ -76,6 +77,64 @@ void rls_pinned_free(void* p) {
   const size_t cls = *reinterpret_cast<size_t*>(static_cast<char*>(p) - PIN_HDR);
   std::lock_guard<std::mutex> lk(g_mem_mutex);
   g_pinned_free[cls].push_back(p);   // kept for the next plan; the process returns it to the driver at exit
+}
+
+// ---- status mailbox --------------------------------------------------------------------------------------------------------
+struct fetch_args {
+  const unsigned* src[4];
+  unsigned* dst[4];
+  unsigned n[4];
+  int count;
+};
+// one wave: every queued block, dword by dword, straight into pinned host memory (system-scope stores), then -- released
+// behind them -- the sequence word the host is spinning on
+__global__ __launch_bounds__(64) void mailbox_publish_kernel(fetch_args A, unsigned* seq_h, unsigned seq) {
+  for (int k = 0; k < A.count; ++k)
+    for (unsigned i = threadIdx.x; i < A.n[k]; i += 64)
+      __hip_atomic_store(A.dst[k] + i, A.src[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // the wave's stores above are complete and visible to the host ...
+  if (threadIdx.x == 0) __hip_atomic_store(seq_h, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // ... before this one
+}
+
+int32_t rls_fetch_add(rls_ctx* ctx, const void* src_d, void* dst_pinned, size_t bytes) {
+  if (!ctx->tune.status_mailbox || (bytes & 3) || ctx->nfq >= 4) {
+    RLS_HIP(ctx, hipMemcpyAsync(dst_pinned, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+  }
+  ctx->fq[ctx->nfq++] = {src_d, dst_pinned, (unsigned)(bytes / 4)};
+  return 0;
+}
+
+int32_t rls_fetch_wait(rls_ctx* ctx) {
+  if (ctx->nfq == 0) {
+    RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+    return 0;
+  }
+  fetch_args A;
+  A.count = ctx->nfq;
+  for (int k = 0; k < 4; ++k) {
+    A.src[k] = k < ctx->nfq ? reinterpret_cast<const unsigned*>(ctx->fq[k].src) : nullptr;
+    A.dst[k] = k < ctx->nfq ? reinterpret_cast<unsigned*>(ctx->fq[k].dst) : nullptr;
+    A.n[k] = k < ctx->nfq ? ctx->fq[k].dwords : 0u;
+  }
+  ctx->nfq = 0;
+  const unsigned seq = ++ctx->mb_seq;
+  hipLaunchKernelGGL(mailbox_publish_kernel, dim3(1), dim3(64), 0, ctx->stream, A, ctx->mb_h, seq);
+  RLS_HIP(ctx, hipGetLastError());
+  volatile unsigned* p = ctx->mb_h;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned n = 0;; ++n) {
+    if (*p == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return 0;
+    }
+    rls_cpu_relax();
+    if ((n & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(250)) break;
+  }
+  // a long queue in front of the kernel, or a fault: block on the stream (which reports the error) and look again
+  RLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return *p == seq ? 0 : rls_fail(ctx, RLS_E_STATE, "status mailbox: the publishing kernel did not run");
 }
 
 rls_alloc_scope::rls_alloc_scope(rls_ctx* ctx) : prev(tl_alloc_ctx) { tl_alloc_ctx = ctx; }
@@ -89,6 +148,8 @@ static int32_t ctx_setup(rls_ctx* ctx) {
   RLS_HIP(ctx, hipMalloc((void**)&ctx->red_d, sizeof(double) * RLS_RED_SLOTS));
   RLS_HIP(ctx, hipMalloc((void**)&ctx->res_d, sizeof(float) * RLS_RES_FLOATS));
   RLS_HIP(ctx, hipHostMalloc((void**)&ctx->res_h, sizeof(float) * RLS_RES_FLOATS, hipHostMallocDefault));
+  RLS_HIP(ctx, hipHostMalloc((void**)&ctx->mb_h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+  ctx->mb_h[0] = 0;
   return 0;
 }
 
@@ -159,6 +220,7 @@ int32_t rls_ctx_destroy(rls_ctx* ctx) {
   if (ctx->red_d) hipFree(ctx->red_d);
   if (ctx->res_d) hipFree(ctx->res_d);
   if (ctx->res_h) hipHostFree(ctx->res_h);
+  if (ctx->mb_h) hipHostFree(ctx->mb_h);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
@@ -192,6 +254,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
     ctx->tune.resident = value;
     ctx->resident_failures = 0;  // an explicit switch also forgets earlier timeouts (solvers.hip, resident_lost)
   }
+  else if (!strcmp(key, "status_mailbox")) ctx->tune.status_mailbox = value;
   else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "resident_preclear")) ctx->tune.resident_preclear = value;
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);

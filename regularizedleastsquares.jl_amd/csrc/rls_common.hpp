@@ -29,6 +29,8 @@ struct rls_tuning {
   int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
                           // ONE launch (normal.hip, cgnr_resident_kernel)
   int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
+  int status_mailbox = 1;      // 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
+                               // sequence word (rls_fetch_*); 0: hipMemcpyAsync + stream wait
   int resident_spin = 100000;  // bound of every in-kernel wait, in polls (~1 us each: a wall-clock bound of ~0.1 s per
                                // wait); a launch that runs into it is a no-op and the host re-runs its iterations on the
                                // per-iteration pipeline (solvers.hip, *_recover)
@@ -47,7 +49,24 @@ struct rls_ctx {
   rls_tuning tune;
   int resident_failures = 0;  // resident launches of this context that timed out; at 2 the context stops using them
   bool pools = false;         // device memory comes from the device's stream-ordered pool (rls_dev_alloc)
+  // status mailbox (rls_fetch_add / rls_fetch_wait): device -> pinned copies queued for ONE publishing launch
+  struct fetch_item {
+    const void* src;
+    void* dst;
+    unsigned dwords;
+  } fq[4];
+  int nfq = 0;
+  unsigned* mb_h = nullptr;  // pinned, host-mapped sequence word the publishing kernel stores last (system scope)
+  unsigned mb_seq = 0;
 };
+
+// Status read-backs without a D2H copy engine in the way: the reference's solve! loop evaluates done() and fires callbacks
+// after EVERY iterate (src/RegularizedLeastSquares.jl:103-117), so one read-back per iteration is on the critical path of a
+// solve with callbacks.  rls_fetch_add queues "copy `bytes` (a multiple of 4) from device memory to this PINNED host block";
+// rls_fetch_wait enqueues ONE small kernel that stores everything queued straight into the host blocks and then a sequence
+// word, and spins on that word (bounded; falls back to a stream wait).  With tune.status_mailbox = 0: hipMemcpyAsync + wait.
+int32_t rls_fetch_add(rls_ctx* ctx, const void* src_d, void* dst_pinned, size_t bytes);
+int32_t rls_fetch_wait(rls_ctx* ctx);
 
 // ---- memory ------------------------------------------------------------------------------------------------------------
 // Device memory of the library (plan scratch, rls_malloc) is STREAM-ORDERED on the context's stream: hipMallocAsync /

@@ -314,9 +314,7 @@ static hipError_t resident_alloc(rls_ctx* ctx, const rls_operator* op, void** rs
 }
 // enqueue the read-back of {fail, completed, failed}; the caller synchronises (normally with its scalar read-back)
 static int32_t resident_fetch_flags(rls_ctx* ctx, const void* rsync, unsigned* rsync_h) {
-  RLS_HIP(ctx, hipMemcpyAsync(rsync_h, (const char*)rsync + rls_resident_sync_flags_offset(), 3 * sizeof(unsigned),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  return 0;
+  return rls_fetch_add(ctx, (const char*)rsync + rls_resident_sync_flags_offset(), rsync_h, 3 * sizeof(unsigned));
 }
 // Launches lost since the last call (0 = none).  A lost launch changed nothing (x, r, p and the scalars are written back by
 // workgroup 0 only after its last barrier), so the caller re-runs the missing iterations on the per-iteration pipeline.
@@ -1362,9 +1360,9 @@ static int32_t alloc_scalars(rls_ctx* ctx, S** d, S** h, int n = 1) {
 }
 template <typename S>
 static int32_t fetch_scalars(rls_ctx* ctx, S* d, S* h) {
-  RLS_HIP(ctx, hipMemcpyAsync(h, d, sizeof(S), hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
-  return 0;
+  static_assert(sizeof(S) % 4 == 0, "status structs are copied dword by dword");
+  RLS_TRY(rls_fetch_add(ctx, d, h, sizeof(S)));
+  return rls_fetch_wait(ctx);  // one publishing launch for everything queued (resident flags, logs), then the host sees it
 }
 
 // G = A^H A is Hermitian with a real diagonal (Julia's A'*A goes through herk).  The generic kernels compute
@@ -2198,8 +2196,8 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (s->resident_used) RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
-  RLS_HIP(ctx, hipMemcpyAsync(s->sc_h, s->sc, sizeof(cgnr_scalars) * (size_t)s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  RLS_TRY(rls_fetch_add(ctx, s->sc, s->sc_h, sizeof(cgnr_scalars) * (size_t)s->nrhs));
+  RLS_TRY(rls_fetch_wait(ctx));
   if (s->resident_used && resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks)) {
     // a lost resident launch changed nothing: the live columns are all at the same count (they advance in lockstep since
     // init; retired ones stay behind), so what is missing is requested - that count, re-run on the streaming kernels
@@ -2212,8 +2210,8 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
     const long long missing = s->requested - at;
     if (live && missing > 0) {
       RLS_TRY(cgnr_step_impl(s, (int32_t)(missing > 0x7fffffff ? 0x7fffffff : missing)));
-      RLS_HIP(ctx, hipMemcpyAsync(s->sc_h, s->sc, sizeof(cgnr_scalars) * (size_t)s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
-      RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+      RLS_TRY(rls_fetch_add(ctx, s->sc, s->sc_h, sizeof(cgnr_scalars) * (size_t)s->nrhs));
+      RLS_TRY(rls_fetch_wait(ctx));
     }
   }
   for (int b = 0; b < s->nrhs; ++b) {
@@ -3281,7 +3279,7 @@ int32_t rls_pgm_lost(rls_pgm* s, int32_t* lost, int32_t* fallbacks_total) {
   rls_ctx* ctx = s->op->ctx;
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
-  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  RLS_TRY(rls_fetch_wait(ctx));
   *lost = (int32_t)resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks);
   if (fallbacks_total) *fallbacks_total = s->fallbacks;
   return 0;
@@ -3306,7 +3304,7 @@ int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {
   if (s->resident_used) {
     // a lost resident launch left x at its warm start: repeat the solve on the per-iteration pipeline
     RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
-    RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+    RLS_TRY(rls_fetch_wait(ctx));
     if (resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks) && s->last.valid)
       RLS_TRY(cg_solve_impl(s, s->last.x, s->last.b, s->last.rho, s->last.maxiter, s->last.reltol, admm_fuse_v()));
     out->fallbacks = s->fallbacks;
@@ -3639,8 +3637,7 @@ int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   rls_cg* cg = a->cg;
   int nrec = a->enq < a->log_cap ? a->enq : a->log_cap;
-  if (nrec > 0)
-    RLS_HIP(ctx, hipMemcpyAsync(a->log_h, a->log, sizeof(float) * ADMM_REC * nrec, hipMemcpyDeviceToHost, ctx->stream));
+  if (nrec > 0) RLS_TRY(rls_fetch_add(ctx, a->log, a->log_h, sizeof(float) * ADMM_REC * nrec));
   if (cg->resident_used) RLS_TRY(resident_fetch_flags(ctx, cg->rsync, cg->rsync_h));
   RLS_TRY(fetch_scalars(ctx, a->sc, a->sc_h));  // synchronises the stream
   if (cg->resident_used && resident_lost(ctx, cg->rsync, cg->rsync_h, &cg->resident_off, &cg->fallbacks)) {
@@ -3656,8 +3653,7 @@ int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int
       a->requested = it_done;
       if (missing > 0) RLS_TRY(rls_admm_step(a, missing));
       nrec = a->enq < a->log_cap ? a->enq : a->log_cap;
-      if (nrec > 0)
-        RLS_HIP(ctx, hipMemcpyAsync(a->log_h, a->log, sizeof(float) * ADMM_REC * nrec, hipMemcpyDeviceToHost, ctx->stream));
+      if (nrec > 0) RLS_TRY(rls_fetch_add(ctx, a->log, a->log_h, sizeof(float) * ADMM_REC * nrec));
       RLS_TRY(fetch_scalars(ctx, a->sc, a->sc_h));
     }
   }
