@@ -38,6 +38,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
 MFMA_F32_PEAK_TF = 157.3  # dense f32-input MFMA peak, same table
+VALU_F32_PEAK_TF = 157.3  # "Peak FP32 (vector)", same table: 64 FLOP/clk/SIMD, packed FMAs included (round 3 used twice that)
+L2_SHARED_TBS = 16.8      # rows shared by every workgroup of an XCD, out of its L2 (guide, L2 section: 16.8-18.8 TB/s)
+INF_CACHE_TBS = 8.6       # Infinity Cache (guide, same table): what crosses XCDs travels at this rate at best
 # CG converges geometrically on the well-conditioned randn matrix (hard part 4): left running for hundreds
 # of iterations the recursive residual underflows Float32 and alpha becomes 0/0.  The bench therefore times
 # back-to-back SOLVES of SEGMENT iterations each (BASELINE configs 4/5 use 32); the init! of every solve after the
@@ -63,7 +66,7 @@ def grid_exchange_floor():
     best = {}
     for line in txt.splitlines():
         f = line.split()
-        if len(f) >= 2 and f[0] in ("bar", "flat") and "fail 0" in line and "wrong sums 0" in line:
+        if len(f) >= 2 and f[0] in ("bar", "flat", "gbar") and "fail 0" in line and "wrong sums 0" in line:
             best[f[0]] = min(best.get(f[0], 1e9), float(f[1]))
         if line.startswith("group GN= 8 strided") and "fail 0" in line and "wrong sums 0" in line:
             best["two_level"] = min(best.get("two_level", 1e9), float(f[4]))
@@ -357,6 +360,7 @@ def other_paths(rls, ctx, Ad, A, b, errors):
         t0 = time.perf_counter(); G = Ad.gram(); ctx.sync(); t_gram = time.perf_counter() - t0
         t0 = time.perf_counter(); G = Ad.gram(); ctx.sync(); t_gram = min(t_gram, time.perf_counter() - t0)
         state["G"] = G
+        state["gram_ms"] = 1e3 * t_gram
         return {"ms": 1e3 * t_gram, "TFLOPs_nominal": 8.0 * N * N * M / t_gram / 1e12}
 
     @entry("cgnr_gram_mode (AHA explicit, one launch per iteration)")
@@ -388,6 +392,46 @@ def other_paths(rls, ctx, Ad, A, b, errors):
                     "TFLOPs_algorithmic": 16.0 * M * N * K / us / 1e6, "frac_mfma_f32": 16.0 * M * N * K / us / 1e6 / MFMA_F32_PEAK_TF,
                     "A_stream_GBps (2 passes per group of 16, out of the Infinity Cache)": 2.0 * groups * M * N * 8 / us / 1e3,
                     "binding_roof": "hbm (8 flop/B at 8 right-hand sides, ridge ~20)" if K < 20 else "mfma"}
+
+    for K in (8, 16, 64):
+        @entry(f"cgnr_batched_{K}_rhs_gram_mode (BASELINE configs[3] on the reference's DEFAULT operator: AHA = A' * A explicit, shared by "
+               f"all columns -- src/CGNR.jl:49,151, src/MultiThreading.jl:30-48)")
+        def _(K=K):
+            X = (rng.standard_normal((N, K)) + 1j * rng.standard_normal((N, K))).astype(np.complex64)
+            Bd = rls.DeviceMatrix.from_host(np.asfortranarray((A @ X).astype(np.complex64)), ctx)
+            res = {}
+            for tag, res_on in (("", 1), ("_streaming (resident = 0)", 0)) if K <= 8 else (("", 1),):
+                ctx.tune(resident=res_on)
+                try:
+                    S = rls.createLinearSolver(rls.CGNR, Ad, AHA=state["G"], iterations=32, relTol=0.0)
+                    rls.solve_(S, Bd, scheduler=rls.BatchedState)
+                    st = S.state
+                    pth = C.c_int32(-1)
+                    lib.rls_cgnr_path(st._plan, C.byref(pth))
+                    us = timed(lambda: (rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, 32), "init"),
+                                        rls._lib.check(h, lib.rls_cgnr_step(st._plan, 32), "step")), 32, reps=4)
+                    us_long = None
+                    if pth.value == 7:  # the resident launch amortises its load of AHA and the gather of x over the call: 128 iterations
+                        rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, 4096), "init")
+                        us_long = timed(lambda: rls._lib.check(h, lib.rls_cgnr_step(st._plan, 128), "step"), 128, reps=4)
+                finally:
+                    ctx.tune(resident=1)
+                # bytes a batched iteration must move: AHA once (N^2 s), whatever the number of right-hand sides; flops 8 N^2 K
+                gb = N * N * 8 / us / 1e3
+                r = {"us_per_batched_iteration_incl_init": us, "solve_iterations_per_s": K * 1e6 / us, "kernel_path": pth.value,
+                     "roofline": {"bound": "hbm" if K < 20 else "mfma",
+                                  **({"achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                                      "bytes_per_batched_iteration": N * N * 8} if K < 20 else
+                                     {"achieved": 8.0 * N * N * K / us / 1e6, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                      "frac": 8.0 * N * N * K / us / 1e6 / MFMA_F32_PEAK_TF}),
+                                  "note": ("path 7: AHA lives in the register files for the whole step call, so per iteration it moves only the "
+                                           "all-gather of V = AHA P (N x K values) -- the HBM figure is the algorithm's bytes / time, not traffic"
+                                           if pth.value == 7 else "path 6: one matrix-core product over AHA per batched iteration + the per-column update")}}
+                if us_long is not None:
+                    r["us_per_batched_iteration_128_iteration_call"] = us_long
+                res["gram" + tag] = r
+            res["gram_setup_ms (A' * A on the matrix cores, once per operator)"] = state.get("gram_ms")
+            return res
 
     @entry("fista_l1_batched_16_rhs (solve!(FISTA, B), f32 MFMA)")
     def _():
@@ -819,20 +863,39 @@ def main():
                      "effective_GBps": iter_gbs, "min_hbm_bytes_per_launch": 2 * M * N * s}
     floor = None
     if path.value == 4 and rank == 0:
-        # A roof for the resident kernel (its HBM fraction says nothing: A never moves): per iteration it must at least run
-        # its two products on the VALU (16 M N flops at the packed-f32 FMA peak: 256 CUs x 128 lanes x 2 (v_pk_fma) x 2 flop
-        # x 2.4 GHz = 314.6 TFLOP/s) and ONE grid-wide all-reduce of the partial rows, whose cost with the arithmetic
-        # stripped is measured live by tools/ubench/grid_barrier (same protocol, same shapes, nothing else in the kernel).
+        # The roof of the resident kernel (its HBM fraction says nothing: A never moves).  Per iteration it must at least
+        # (a) run its two products on the VALU: 16 M N flops at the guide's FP32 vector peak (157.3 TF, packed FMAs included), and
+        # (b) all-reduce the 256 partial rows of v.  Two figures for (b):
+        #   * protocol-independent: any all-reduce over 256 workgroups in 8 XCDs needs at least one synchronisation inside
+        #     the XCD-sized groups and one across the grid -- the bare group and grid barriers of tools/ubench/grid_barrier --
+        #     plus its payload at the guide's rates: every partial row leaves its XCD and is read once (Infinity Cache rate),
+        #     and every workgroup reads the N-vector result (an XCD's L2, shared rows);
+        #   * this design's: the two-level exchange with the arithmetic stripped, measured live by the same micro-benchmark
+        #     (same protocol, same shapes, nothing else in the kernel) -- it bounds the protocol, not the machine.
         ge = grid_exchange_floor()
         if ge and "two_level" in ge:
-            valu_us = 16.0 * M * N / 314.6e12 * 1e6
+            valu_us = 16.0 * M * N / (VALU_F32_PEAK_TF * 1e12) * 1e6
             floor_us = valu_us + ge["two_level"]
             it_us = kern[dom]["us_per_iteration_in_kernel"]
+            row_bytes = N * s
+            payload_us = (2.0 * nwg * row_bytes / (INF_CACHE_TBS * 1e12) + nwg * row_bytes / (L2_SHARED_TBS * 1e12)) * 1e6
+            indep = None
+            if "bar" in ge and "gbar" in ge:
+                indep = valu_us + ge["gbar"] + ge["bar"] + payload_us
             floor = {"bound": "grid-exchange", "unit": "us per iteration", "floor": floor_us, "measured": it_us, "frac_of_floor": floor_us / it_us,
-                     "components": {"products_on_the_VALU_at_peak": valu_us, "all_reduce_two_level_arithmetic_stripped": ge["two_level"],
+                     "components": {"products_on_the_VALU_at_peak": valu_us, "valu_peak_TFLOPs": VALU_F32_PEAK_TF,
+                                    "all_reduce_two_level_arithmetic_stripped": ge["two_level"],
                                     "for_comparison": {"bare_grid_barrier_256_workgroups": ge.get("bar"),
+                                                       "bare_group_barrier_8_groups_of_32": ge.get("gbar"),
                                                        "all_reduce_flat_two_hops (round 2's exchange)": ge.get("flat")}},
-                     "source": "tools/ubench/grid_barrier (run live by bench.py); profiles/r03_grid_barrier.txt holds a committed run"}
+                     "protocol_independent_floor": (None if indep is None else {
+                         "us_per_iteration": indep, "frac": indep / it_us,
+                         "components": {"products_on_the_VALU_at_peak": valu_us, "bare_group_barrier": ge["gbar"], "bare_grid_barrier": ge["bar"],
+                                        "payload_at_guide_rates": payload_us,
+                                        "payload_bytes": {"partial_rows_out_and_in (Infinity Cache rate)": 2 * nwg * row_bytes,
+                                                          "result_read_by_every_workgroup (L2 rate)": nwg * row_bytes},
+                                        "rates_TBps": {"infinity_cache": INF_CACHE_TBS, "l2_shared_rows": L2_SHARED_TBS}}}),
+                     "source": "tools/ubench/grid_barrier (run live by bench.py); profiles/ holds a committed run"}
     n1_value = solo_rate(lambda: rls.init_(solver, bd), lambda: step(K, True), K)
     c4 = None
     if world > 1:
@@ -875,28 +938,39 @@ def main():
                              "value_is": "n_gpus * steps / median(wall); every repetition is exactly `steps` iterations between "
                                          "barrier + synchronize on both sides",
                              "iterations_per_s_hip_events": K / ev},
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                # algorithmic basis, the ITERATION as the unit (SURVEY 8d bytes per iteration x iterations / device time of the timed
-                # region): capped at the peak -- a path that no longer moves the algorithm's bytes can exceed it
-                "achieved": min(iter_gbs, HBM_PEAK_GBS), "frac": min(frac_alg, 1.0),
-                "frac_algorithmic": min(frac_alg, 1.0), "algorithmic_GBps_uncapped": iter_gbs,
-                "exceeds_algorithmic_roofline": bool(frac_alg > 1.0),
-                # physical basis: bytes the dominant kernel really moves per launch / its launch time
-                "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src,
-                "hbm_bytes_per_launch_used": hbm_bytes,
-                "note": ("achieved/frac: SURVEY 8d algorithmic bytes per iteration (A read twice) x iterations / hipEvent time of the timed region, "
-                         "capped at the HBM peak; frac_hbm: HBM bytes of the dominant kernel per launch (PMC when collected, else the minimum it "
-                         "must move) / its launch time / peak.  " +
-                         ("The resident kernel keeps A in the register files across the iterations of a launch: per iteration it moves only "
-                          "the partial-row exchange (L2 / Infinity Cache), so it is bound by its in-kernel grid-wide all-reduce, not by HBM: "
-                          "`resident_floor` is its roof (VALU time of the products + the all-reduce measured with the arithmetic stripped); the "
-                          "two-launch pipeline that streams A every iteration is reported under other_paths." if path.value == 4 else "")),
-                "per_kernel": kern,
-                "iteration": {"bytes": bytes_iter, "us_hip_events": 1e6 * ev / K, "roofline_us_at_peak": bytes_iter / HBM_PEAK_GBS / 1e3}},
+            "roofline": {},
         }
+        hbm_view = {
+            # algorithmic basis, the ITERATION as the unit (SURVEY 8d bytes per iteration x iterations / device time of the timed region)
+            "peak_GBps": HBM_PEAK_GBS, "algorithmic_GBps": iter_gbs, "frac_algorithmic": frac_alg,
+            # physical basis: bytes the dominant kernel really moves per launch / its launch time
+            "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "hbm_bytes_per_launch_used": hbm_bytes,
+            "note": "frac_algorithmic: SURVEY 8d algorithmic bytes per iteration (A read twice) x iterations / hipEvent time of the timed region / peak; "
+                    "frac_hbm: HBM bytes of the dominant kernel per launch (PMC when collected, else the minimum it must move) / its launch time / peak"}
         if floor is not None:
-            out["roofline"]["resident_floor"] = floor
+            # the resident kernel keeps A in the register files: the algorithm's bytes are not moved (frac_algorithmic > 1), so the HBM
+            # roof does not bound it and is reported beside the roof that does -- its in-kernel grid-wide all-reduce.  `frac` is a
+            # division: floor / measured, both in us per iteration
+            out["roofline"] = {"bound": "grid-exchange", "kernel": dom, "unit": "iterations/s inside the dominant kernel",
+                               "achieved": 1e6 / floor["measured"], "peak": 1e6 / floor["floor"],
+                               "frac": (1e6 / floor["measured"]) / (1e6 / floor["floor"]),
+                               "us_per_iteration": {"measured": floor["measured"], "floor": floor["floor"]},
+                               "traffic": traffic, "traffic_source": traffic_src,
+                               "protocol_independent": floor["protocol_independent_floor"],
+                               "hbm": dict(hbm_view, hbm_algorithmic_uncapped=iter_gbs,
+                                           note=hbm_view["note"] + ".  A lives in VGPRs for the whole launch: per iteration only the partial-row "
+                                                "exchange moves (L2 / Infinity Cache); the two-launch pipeline that streams A every iteration is under other_paths"),
+                               "resident_floor": floor}
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": iter_gbs, "frac": frac_alg,
+                               "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "hbm_bytes_per_launch_used": hbm_bytes,
+                               "note": hbm_view["note"]}
+        out["roofline"]["per_kernel"] = kern
+        out["roofline"]["iteration"] = {"bytes": bytes_iter, "us_hip_events": 1e6 * ev / K, "roofline_us_at_peak": bytes_iter / HBM_PEAK_GBS / 1e3}
+        # which regime `value` is in: a resident launch pays its slab load once per step call, and the first solve's init! lies
+        # outside the timed region when the region is a single launch
+        out["config"]["iterations_per_launch"] = (min(K, SEGMENT) if path.value in (4, 5) else 1)
+        out["config"]["init_inside_region"] = bool(K > SEGMENT)
         if n1_value is not None:
             out["n1_same_workload_value"] = n1_value
             out["efficiency_vs_n1_same_workload"] = out["value"] / (world * n1_value)

@@ -98,6 +98,18 @@ __global__ __launch_bounds__(NT) void bar_kernel(sync_block* S, int rounds) {
   }
 }
 
+// the bare GROUP barrier of the two-level exchange: 8 groups (blockIdx % 8), one counter word per group, members wait for each other
+__global__ __launch_bounds__(NT) void gbar_kernel(sync_block* S, int rounds) {
+  int* flag = reinterpret_cast<int*>(smem);
+  const unsigned members = gridDim.x / 8, g = blockIdx.x & 7;
+  for (int r = 1; r <= rounds; ++r) {
+    if (!arrive_wait<1>(S->xcnt + g * 32, 0, members * (unsigned)r, flag)) {
+      if (threadIdx.x == 0) S->fail = 1;
+      return;
+    }
+  }
+}
+
 // rows: [nwg][nb] bytes; v: [nb]; dots: [nwg][4] doubles.  nb = bytes of the vector (16 KiB at N = 2048 complex)
 __global__ __launch_bounds__(NT) void flat_kernel(sync_block* S, float* rows, float* v, double* dots, int nb, int rounds) {
   int* flag = reinterpret_cast<int*>(smem);
@@ -399,6 +411,21 @@ int main(int argc, char** argv) {
       }
       printf("\n");
     }
+  }
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gbar_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipMemset(S, 0, sizeof(sync_block)));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(gbar_kernel, dim3(nwg), dim3(NT), lds, 0, S, rounds);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    sync_block h;
+    CK(hipMemcpy(&h, S, sizeof(h), hipMemcpyDeviceToHost));
+    printf("gbar   %8.3f us per round   fail %u  wrong sums %u   (bare group barrier: 8 strided groups of %d)\n", ms * 1e3 / rounds, h.fail, h.bad, nwg / 8);
   }
   run_group<2, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
   run_group<4, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
