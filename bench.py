@@ -412,8 +412,8 @@ def other_paths(rls, ctx, Ad, A, b, errors):
                                         rls._lib.check(h, lib.rls_cgnr_step(st._plan, 32), "step")), 32, reps=4)
                     us_long = None
                     if pth.value == 7:  # the resident launch amortises its load of AHA and the gather of x over the call: 128 iterations
-                        rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, 4096), "init")
-                        us_long = timed(lambda: rls._lib.check(h, lib.rls_cgnr_step(st._plan, 128), "step"), 128, reps=4)
+                        us_long = timed(lambda: (rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, 128), "init"),
+                                                 rls._lib.check(h, lib.rls_cgnr_step(st._plan, 128), "step")), 128, reps=4)
                 finally:
                     ctx.tune(resident=1)
                 # bytes a batched iteration must move: AHA once (N^2 s), whatever the number of right-hand sides; flops 8 N^2 K
@@ -428,7 +428,7 @@ def other_paths(rls, ctx, Ad, A, b, errors):
                                            "all-gather of V = AHA P (N x K values) -- the HBM figure is the algorithm's bytes / time, not traffic"
                                            if pth.value == 7 else "path 6: one matrix-core product over AHA per batched iteration + the per-column update")}}
                 if us_long is not None:
-                    r["us_per_batched_iteration_128_iteration_call"] = us_long
+                    r["us_per_batched_iteration_128_iteration_call_incl_init"] = us_long
                 res["gram" + tag] = r
             res["gram_setup_ms (A' * A on the matrix cores, once per operator)"] = state.get("gram_ms")
             return res
