@@ -306,7 +306,8 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
  * registers across iterations; needs A <= the register files), 5 = resident Gram mode (the same with AHA explicit and
  * held in registers: one in-kernel grid exchange per iteration), 6 = batched on an explicit AHA (ONE matrix-core product
  * V = AHA P per iteration), 7 = the same as ONE resident launch per step call (<= 8 ComplexF32 columns, N <= 2048: AHA in
- * the register files, the operand panel in LDS; calls of a single iteration take path 6). */
+ * the register files, the operand panel in LDS; calls of a single iteration take path 6), 8 = small system (M N s <= ~128 KiB,
+ * matrix-free, single right-hand side): the whole step call as ONE single-workgroup launch with A in one CU's registers. */
 int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out);
 
 /* ---------------------------------------------------------------------------------------------

@@ -29,6 +29,7 @@ struct rls_tuning {
   int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
                           // ONE launch (normal.hip, cgnr_resident_kernel)
   int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
+  int small = 1;               // 1: systems that fit ONE CU's registers run a whole step call as a single-workgroup launch (small.hip)
   int status_mailbox = 1;      // 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
                                // sequence word (rls_fetch_*); 0: hipMemcpyAsync + stream wait
   int resident_spin = 100000;  // bound of every in-kernel wait, in polls (~1 us each: a wall-clock bound of ~0.1 s per
@@ -773,6 +774,16 @@ int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const 
                        int64_t ldg);
 int32_t rls_skinny_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
                         int64_t ldg, void* panels);
+
+// Small systems (M N s <= ~128 KiB): a whole rls_cgnr_step call as ONE single-workgroup launch, A in one CU's registers (small.hip)
+struct rls_small {
+  const void* A;
+  int64_t lda, M, N;
+  void *x, *r, *p, *v;
+  cgnr_scalars* sc;
+};
+bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
+int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps);
 
 // Batched CGNR on an explicit Gram matrix as ONE resident launch per step call (gramk.hip): up to 8 ComplexF32 right-hand
 // sides, AHA (N <= 2048) held in the register files, the operand panel replicated in every workgroup's LDS

@@ -1,0 +1,243 @@
+// Small systems: a whole rls_cgnr_step call as ONE single-workgroup launch, A held in one CU's registers.
+//
+// The reference's own test and documentation sizes (test/testSolvers.jl:3-43, docs/src/literate/howto/gpu_acceleration.jl:12-23:
+// 32 x 16; BASELINE configs[0]: 256 x 128 Float32) are launch-bound on the per-iteration kernels: two launches per iteration cost
+// more than the arithmetic (8.9 us per iteration at 256 x 128).  Here M N s <= 128 KiB fits the register file of ONE CU, so one
+// workgroup of 512 threads runs every iteration of a step call (src/CGNR.jl:143-178) with workgroup barriers only -- no grid
+// exchange, no co-residency requirement, nothing to time out:
+//   * thread (row block rb = tid / 16, column block cb = tid % 16) keeps the R x C tile A[rb R .. +R][cb C .. +C]: the 16 column
+//     blocks of a row block are the 16 lanes of one DPP row, so t = A p is C FMAs per row and a 4-step DPP butterfly (every lane
+//     of the row ends up with its R entries of t);
+//   * v = A^H t: R FMAs per column, two cross-row shuffles inside the wave, the 8 waves' partials through LDS;
+//   * wave 0 alone applies the CG update (alpha, x, r, beta, p; Float64 dots as a wave reduction) and leaves p in LDS: two
+//     workgroup barriers per iteration.
+// State (x, r, p, v, scalars) is read at entry and written back at the end, in the layout every other path uses, so step calls
+// of this kernel and of the pipelines can follow each other.
+#include "rls_common.hpp"
+
+namespace {
+
+constexpr int SM_NT = 512, SM_WV = SM_NT / 64, SM_RB = SM_NT / 16;  // 32 row blocks x 16 column blocks
+
+template <typename E>
+__device__ static inline E row16_sum(E v) {  // all-reduce over the 16 lanes of a DPP row, result in every lane, fixed order
+  if constexpr (elem<E>::cplx) {
+    float re = v.x, im = v.y;
+    re += dpp_f(re, 0xB1); im += dpp_f(im, 0xB1);
+    re += dpp_f(re, 0x4E); im += dpp_f(im, 0x4E);
+    re += dpp_f(re, 0x141); im += dpp_f(im, 0x141);
+    re += dpp_f(re, 0x140); im += dpp_f(im, 0x140);
+    return make_float2(re, im);
+  } else {
+    v += dpp_f(v, 0xB1);
+    v += dpp_f(v, 0x4E);
+    v += dpp_f(v, 0x141);
+    v += dpp_f(v, 0x140);
+    return v;
+  }
+}
+template <typename E>
+__device__ static inline E shfl_xor_e(E v, int m) {
+  if constexpr (elem<E>::cplx) return make_float2(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64));
+  else return __shfl_xor(v, m, 64);
+}
+
+template <typename E, int R, int C>
+__global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* x, E* r, E* p, E* v,
+                                                           cgnr_scalars* sc, int n_steps) {
+  constexpr int NP = 16 * C;              // padded vector length
+  constexpr int EPT = (NP + 63) / 64;     // vector elements per lane of wave 0
+  __shared__ E ps[NP];                    // p, zero beyond N
+  __shared__ E vpart[SM_WV][NP];          // per-wave partial rows of v
+  __shared__ int sdone;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cb = lane & 15, rb = tid >> 4;
+  // ---- A tile into registers (zero outside the matrix) -------------------------------------------------------------------------
+  E a[R][C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const int col = cb * C + j;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int row = rb * R + i;
+      const bool ok = row < M && col < N;
+      const E val = A[(int64_t)(ok ? col : 0) * lda + (ok ? row : 0)];
+      a[i][j] = ok ? val : elem<E>::zero();
+    }
+  }
+  // ---- state: wave 0 owns the vectors (elements lane, lane + 64, ...) -----------------------------------------------------------
+  E xv[EPT], rv[EPT], pv[EPT], vv[EPT];
+  cgnr_scalars S;
+  if (w == 0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = lane + 64 * e;
+      const bool ok = i < N;
+      xv[e] = ok ? x[i] : elem<E>::zero();
+      rv[e] = ok ? r[i] : elem<E>::zero();
+      pv[e] = ok ? p[i] : elem<E>::zero();
+      vv[e] = ok ? v[i] : elem<E>::zero();
+      if (i < NP) ps[i] = pv[e];
+    }
+    S.rr = sc->rr; S.z0 = sc->z0; S.zeta = sc->zeta;
+    S.alpha_re = sc->alpha_re; S.alpha_im = sc->alpha_im; S.beta_re = sc->beta_re; S.beta_im = sc->beta_im;
+    S.lambda = sc->lambda; S.rel_tol = sc->rel_tol;
+    S.iteration = sc->iteration; S.max_iter = sc->max_iter; S.done = sc->done;
+    if (lane == 0) sdone = S.done;
+  }
+  __syncthreads();
+  for (int it = 0; it < n_steps; ++it) {
+    if (sdone) break;  // uniform
+    // ---- t = A p: this thread's R rows over its C columns, then over the 16 column blocks ---------------------------------------
+    E pj[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) pj[j] = ps[cb * C + j];
+    E t[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      E s = elem<E>::zero();
+#pragma unroll
+      for (int j = 0; j < C; ++j) s = elem<E>::fma(a[i][j], pj[j], s);
+      t[i] = row16_sum<E>(s);
+    }
+    // ---- v = A^H t: this thread's C columns over its R rows, then over the 4 row blocks of the wave, then over the waves ---------
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      E s = elem<E>::zero();
+#pragma unroll
+      for (int i = 0; i < R; ++i) s = elem<E>::fmac(a[i][j], t[i], s);  // conj(a) t
+      s = elem<E>::add(s, shfl_xor_e<E>(s, 16));
+      s = elem<E>::add(s, shfl_xor_e<E>(s, 32));
+      if (lane < 16) vpart[w][cb * C + j] = s;
+    }
+    __syncthreads();
+    // ---- the CG update, wave 0 alone (src/CGNR.jl:153-176) -----------------------------------------------------------------------
+    if (w == 0) {
+      double nre = 0.0, nim = 0.0, pp = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int i = lane + 64 * e;
+        E s = elem<E>::zero();
+        if (i < NP) {
+#pragma unroll
+          for (int ww = 0; ww < SM_WV; ++ww) s = elem<E>::add(s, vpart[ww][i]);
+        }
+        vv[e] = s;
+        nre += (double)elem<E>::re(pv[e]) * (double)elem<E>::re(s) + (double)elem<E>::im(pv[e]) * (double)elem<E>::im(s);
+        if constexpr (elem<E>::cplx)
+          nim += (double)elem<E>::re(pv[e]) * (double)elem<E>::im(s) - (double)elem<E>::im(pv[e]) * (double)elem<E>::re(s);
+        pp += (double)elem<E>::re(pv[e]) * (double)elem<E>::re(pv[e]) + (double)elem<E>::im(pv[e]) * (double)elem<E>::im(pv[e]);
+      }
+      nre = wave_sum(nre);
+      if constexpr (elem<E>::cplx) nim = wave_sum(nim);
+      const float lambda = S.lambda;
+      if (lambda > 0.f) pp = wave_sum(pp);
+      const double zeta = S.rr;
+      const dcomplex alpha = dc_div({zeta, 0.0}, {nre + (lambda > 0.f ? (double)lambda * pp : 0.0), nim});
+      const E al = elem<E>::make((float)alpha.re, (float)alpha.im);
+      const E na = elem<E>::make(-(float)alpha.re, -(float)alpha.im);
+      double rr = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        xv[e] = elem<E>::fma(pv[e], al, xv[e]);
+        E ri = elem<E>::fma(vv[e], na, rv[e]);
+        if (lambda > 0.f) ri = elem<E>::fma(elem<E>::scale(-lambda, pv[e]), al, ri);
+        rv[e] = ri;
+        rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+      }
+      rr = wave_sum(rr);
+      const double beta = rr / zeta;
+      const float bf = (float)beta;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        pv[e] = elem<E>::add(elem<E>::scale(bf, pv[e]), rv[e]);
+        const int i = lane + 64 * e;
+        if (i < NP) ps[i] = pv[e];
+      }
+      S.zeta = zeta;
+      S.rr = rr;
+      S.alpha_re = alpha.re;
+      S.alpha_im = alpha.im;
+      S.beta_re = beta;
+      S.beta_im = 0.0;
+      S.iteration += 1;
+      const float ratio = (float)(sqrt(rr) / S.z0);
+      S.done = (ratio <= S.rel_tol) || (S.iteration >= S.max_iter);  // src/CGNR.jl:181-185
+      if (lane == 0) sdone = S.done;
+    }
+    __syncthreads();
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = lane + 64 * e;
+      if (i < N) {
+        x[i] = xv[e];
+        r[i] = rv[e];
+        p[i] = pv[e];
+        v[i] = vv[e];
+      }
+    }
+    if (lane == 0) {
+      sc->rr = S.rr; sc->zeta = S.zeta;
+      sc->alpha_re = S.alpha_re; sc->alpha_im = S.alpha_im; sc->beta_re = S.beta_re; sc->beta_im = S.beta_im;
+      sc->iteration = S.iteration; sc->done = S.done;
+      sc->pending = 0; sc->cur = 0; sc->fresh = 0;
+    }
+  }
+}
+
+struct small_tile {
+  int R, C;
+};
+// tiles (rows per row block x columns per column block); the matrix is padded to 32 R x 16 C.  R C s / 4 registers per lane.
+template <typename E>
+static bool small_pick(int64_t M, int64_t N, small_tile* t) {
+  constexpr small_tile real_tiles[] = {{1, 1}, {2, 2}, {4, 2}, {4, 4}, {8, 4}, {8, 8}, {16, 4}};
+  constexpr small_tile cplx_tiles[] = {{1, 1}, {2, 2}, {4, 2}, {4, 4}, {8, 4}};
+  const small_tile* tiles = elem<E>::cplx ? cplx_tiles : real_tiles;
+  const int n = elem<E>::cplx ? 5 : 7;
+  for (int i = 0; i < n; ++i)
+    if (M <= (int64_t)SM_RB * tiles[i].R && N <= (int64_t)16 * tiles[i].C) {
+      *t = tiles[i];
+      return true;
+    }
+  return false;
+}
+
+template <typename E, int R, int C>
+static void small_launch(rls_ctx* ctx, const rls_small& D, int n_steps) {
+  hipLaunchKernelGGL((cgnr_small_kernel<E, R, C>), dim3(1), dim3(SM_NT), 0, ctx->stream, (const E*)D.A, D.lda, (int)D.M, (int)D.N, (E*)D.x,
+                     (E*)D.r, (E*)D.p, (E*)D.v, D.sc, n_steps);
+}
+
+template <typename E>
+static int32_t small_typed(rls_ctx* ctx, const rls_small& D, int n_steps) {
+  small_tile t;
+  if (!small_pick<E>(D.M, D.N, &t)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "small-system kernel: shape too large");
+#define SM_CASE(RR, CC)          \
+  if (t.R == RR && t.C == CC) {  \
+    small_launch<E, RR, CC>(ctx, D, n_steps); \
+  } else
+  SM_CASE(1, 1) SM_CASE(2, 2) SM_CASE(4, 2) SM_CASE(4, 4) SM_CASE(8, 4) {
+    if constexpr (!elem<E>::cplx) {
+      SM_CASE(8, 8) SM_CASE(16, 4) {}
+    }
+  }
+#undef SM_CASE
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace
+
+bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!A || M < 1 || N < 1 || lda < M) return false;
+  small_tile t;
+  return dtype == RLS_F32 ? small_pick<float>(M, N, &t) : small_pick<float2>(M, N, &t);
+}
+
+int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps) {
+  return dtype == RLS_F32 ? small_typed<float>(ctx, D, n_steps) : small_typed<float2>(ctx, D, n_steps);
+}

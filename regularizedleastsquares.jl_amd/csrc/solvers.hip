@@ -166,6 +166,7 @@ struct rls_cgnr {
   int fallbacks;        // resident launches lost and recovered so far
   long long requested;  // iterations asked for since init
   bool rsync_clean = false;  // the init kernel has just zeroed the arrival counters (resident_chain)
+  bool small = false;  // the system fits one CU's registers: a step call is ONE single-workgroup launch (small.hip)
   // batched plan on an explicit Gram matrix, <= 8 ComplexF32 columns, AHA in the register files (gramk.hip): exchange scratch
   bool gramk = false;
   float* gk_vx = nullptr;
@@ -218,6 +219,12 @@ static rls_skinny cgnr_skinny_desc(const rls_cgnr* s) {
   K.ldvp = s->op->N;
   K.sc = s->sc;
   return K;
+}
+
+// small systems: single right-hand side, matrix-free, A in ONE CU's registers for the whole step call (no grid exchange, no
+// co-residency requirement: always available)
+static bool cgnr_use_small(const rls_cgnr* s) {
+  return s->small && s->nrhs == 1 && !s->op->G && s->op->ctx->tune.small && s->op->ctx->tune.resident;
 }
 
 // batched Gram mode as ONE resident launch per step call (a call of one iteration -- the callback cadence -- is cheaper on
@@ -2022,6 +2029,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess && nrhs > 1 && !skinny)
       e = dmalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
   }
+  s->small = nrhs == 1 && op->A && !op->G && rls_small_ok(op->dtype, op->M, op->N, op->A, op->lda);
   if (e == hipSuccess && nrhs == 1 && op->slab && op->A && !op->G &&
       rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
     const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
@@ -2232,6 +2240,20 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
 
 static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps) {
   rls_ctx* ctx = s->op->ctx;
+  if (cgnr_use_small(s)) {
+    if (n_steps == 0) return 0;
+    rls_small D;
+    D.A = s->op->A;
+    D.lda = s->op->lda;
+    D.M = s->op->M;
+    D.N = s->op->N;
+    D.x = s->x;
+    D.r = s->r;
+    D.p = s->p;
+    D.v = s->v;
+    D.sc = s->sc;
+    return rls_small_launch(ctx, s->op->dtype, D, n_steps);
+  }
   if (s->skinny && cgnr_use_gramk(s, n_steps)) {
     if (n_steps == 0) return 0;
     const rls_gramk D = cgnr_gramk_desc(s);
@@ -2450,7 +2472,7 @@ int32_t rls_fista_step_rowsharded(rls_comm* comm, rls_fista* const* plans, int32
 
 int32_t rls_cgnr_path(rls_cgnr* s, int32_t* out) {
   if (!s || !out) return RLS_E_INVALID;
-  *out = s->skinny ? (cgnr_use_gramk(s, 0) ? 7 : s->op->G ? 6 : 3) : cgnr_use_gram_resident(s) ? 5 : cgnr_use_gram_pipeline(s) ? 2 : cgnr_use_resident(s) ? 4 : cgnr_use_pipeline(s) ? 1 : 0;
+  *out = cgnr_use_small(s) ? 8 : s->skinny ? (cgnr_use_gramk(s, 0) ? 7 : s->op->G ? 6 : 3) : cgnr_use_gram_resident(s) ? 5 : cgnr_use_gram_pipeline(s) ? 2 : cgnr_use_resident(s) ? 4 : cgnr_use_pipeline(s) ? 1 : 0;
   return 0;
 }
 

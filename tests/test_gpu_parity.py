@@ -2174,6 +2174,52 @@ def test_cgnr_resident_timeout_falls_back_to_the_pipeline(rls, ctx):
     parity("cgnr_resident_after_timeout", x, ref[8], lambda: O.solve(O.CGNR(A, iterations=8, relTol=0.0), b))
 
 
+@pytest.mark.parametrize("dt,M,N,lam,iters", [(np.float32, 256, 128, 1e-2, 10), (np.float32, 32, 16, 1e-4, 16), (np.complex64, 64, 32, 0.0, 12),
+                                              (np.complex64, 250, 61, 1e-3, 9), (np.float32, 37, 5, 0.0, 5), (np.float32, 500, 60, 1e-2, 8),
+                                              (np.complex64, 1, 1, 0.0, 1)])
+def test_cgnr_small_system_kernel(rls, ctx, dt, M, N, lam, iters):
+    """Systems that fit ONE CU's register file (BASELINE configs[0] 256 x 128 Float32; the reference's own test and documentation
+    sizes, test/testSolvers.jl:3-43, docs/src/literate/howto/gpu_acceleration.jl:12-23: 32 x 16) run a whole rls_cgnr_step call as a
+    single-workgroup launch (csrc/small.hip, path 8).  Iterates against the float64 oracle step by step, one n-step call = n
+    one-step calls bit for bit, relTol retirement, and agreement with the per-iteration pipeline (small = 0)."""
+    A, xt, b = O.make_problem(M, N, dt, 61)
+    dt64 = hi(dt)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    reg = rls.L2Regularization(lam)
+    ref = O.CGNR(A.astype(dt64), reg=O.L2Regularization(lam), iterations=iters, relTol=0.0)
+    ref32 = O.CGNR(A, reg=O.L2Regularization(lam), iterations=iters, relTol=0.0)
+    ref.init(b.astype(dt64)); ref32.init(b)
+    sol = rls.createLinearSolver(rls.CGNR, Ad, reg=reg, iterations=iters, relTol=0.0)
+    rls.init_(sol, bd)
+    assert _cgnr_path(rls, sol) == 8
+    tag = f"cgnr_small_{M}x{N}_{np.dtype(dt).name}"
+    r0 = max(float(np.linalg.norm(ref.r)), 1e-30)
+    n_it = min(iters, N)
+    for it in range(1, n_it + 1):
+        assert ref.iterate() is not None and ref32.iterate() is not None and rls.iterate(sol) is not None
+        if it in (1, 2, 5, n_it):
+            parity(f"{tag}_x_it{it}", sol.state.x.to_host(), ref.x, ref32.x)
+            parity(f"{tag}_r_it{it}", sol.state.x0.to_host(), ref.r, ref32.r, scale=r0)
+    assert rls.iterate(sol) is None and sol.state.iteration == n_it
+    x_steps = sol.state.x.to_host()
+    x_once = rls.solve_(sol, bd).to_host()  # all iterations in ONE launch
+    assert np.array_equal(x_once, x_steps)
+    ctx.tune(small=0)
+    try:
+        sol0 = rls.createLinearSolver(rls.CGNR, Ad, reg=reg, iterations=iters, relTol=0.0)
+        x_pipe = rls.solve_(sol0, bd).to_host()
+        assert _cgnr_path(rls, sol0) != 8
+    finally:
+        ctx.tune(small=1)
+    assert rel(x_once, x_pipe) < 1e-5
+    if N > 4:  # early retirement on relTol: the oracle's iteration count (+-1 at the threshold)
+        ref2 = O.CGNR(A.astype(dt64), reg=O.L2Regularization(lam), iterations=iters, relTol=1e-2)
+        O.solve(ref2, b.astype(dt64))
+        sol2 = rls.createLinearSolver(rls.CGNR, Ad, reg=reg, iterations=iters, relTol=1e-2)
+        rls.solve_(sol2, bd)
+        assert abs(sol2.state.iteration - ref2.iteration) <= 1
+
+
 def test_batched_gram_resident_lost_launch_is_recovered(rls, ctx):
     """the batched resident launch (csrc/gramk.hip) under the same contract as the single-column ones: with the wait bound forced
     to one poll the launch gives up having changed nothing (only workgroup 0 writes the caller's state, after its last

@@ -32,7 +32,8 @@ BASELINE = [
     ("headline on the two-launch pipeline", r"cgnr_pipe_a_kernel<c32, 8, 32, 8, true, false, (true|false)>"),
     ("headline on the two-launch pipeline", r"cgnr_pipe_r_kernel<c32>"),
     ("headline on the two-launch pipeline", r"cgnr_pipe_f_kernel<c32, \d+>"),
-    ("configs[0]: CGNR 256x128 F32", r"cgnr_pipe_a_kernel<float, 8, 8, 8, (true|false), false, (true|false)>"),
+    ("configs[0]: CGNR 256x128 F32, single-workgroup kernel", r"cgnr_small_kernel<float, 8, 8>"),
+    ("configs[0] on the pipeline (small = 0)", r"cgnr_pipe_a_kernel<float, 8, 8, 8, (true|false), false, (true|false)>"),
     ("configs[1]: FISTA + L1 4096x2048 CF32, resident", r"fista_resident_kernel<c32, 8, 32, 8, 2, true>"),
     ("configs[1] on the pipeline", r"fista_pipe_a_kernel<c32, 8, 32, 8, true, (true|false)>"),
     ("configs[1] shape, SURVEY 8f-1: OptISTA / POGM blocks of iterations as resident launches", r"pgm_resident_kernel<c32, 8, 32, 8, 2, true, (0|1)>"),

@@ -20,3 +20,14 @@ for name, kw in (("matrix-free", {}), ("gram", dict(AHA=Ad.gram()))):
     ctx.sync(); wall = (time.perf_counter() - t0) / 200 * 1e6
     print(f"config 1 {name:12s}: {us/10:6.2f} us per iteration on the device ({us:6.1f} us per 10-iteration solve incl. init), "
           f"{wall:6.1f} us wall clock per solve_() from Python")
+# in-kernel cost per iteration of the single-workgroup kernel: slope between step calls of 10 and of 110 iterations
+S = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-2), iterations=128, relTol=0.0)
+rls.solve_(S, b)
+ts = {}
+for n in (10, 110):
+    def run(k):
+        for _ in range(k):
+            rls.init_(S, b); ctx.lib.rls_cgnr_step(S.state._plan, n)
+    run(100); ctx.sync(); ctx.timer_start(); run(200); ts[n] = ctx.timer_stop_ms() * 1e3 / 200
+print(f"config 1 matrix-free: step(10) {ts[10]:.1f} us, step(110) {ts[110]:.1f} us incl. init -> {(ts[110] - ts[10]) / 100:.2f} us per iteration in the kernel, "
+      f"{ts[10] - 10 * (ts[110] - ts[10]) / 100:.1f} us fixed (init! = GEMV + init kernel, launch, load of A, write-back)")
