@@ -10,9 +10,8 @@
 // ---- memory (rls_common.hpp) -------------------------------------------------------------------------------------------
 namespace {
 std::mutex g_mem_mutex;
-std::set<const rls_ctx*> g_live_ctx;
-std::map<size_t, std::vector<void*>> g_pinned_free;   // size class -> blocks
-constexpr size_t PIN_HDR = 64;                        // the block's size class sits in front of it (keeps 64-byte alignment)
+std::map<const rls_ctx*, uint64_t> g_live_ctx;  // live contexts and their generation ids
+uint64_t g_next_ctx_id = 1;
 thread_local rls_ctx* tl_alloc_ctx = nullptr;
 
 bool device_pools_ok(int device) {
@@ -38,9 +37,11 @@ bool device_pools_ok(int device) {
 }
 }  // namespace
 
-bool rls_ctx_alive(const rls_ctx* ctx) {
+bool rls_ctx_alive(const rls_ctx* ctx, uint64_t id) {
   std::lock_guard<std::mutex> lk(g_mem_mutex);
-  return ctx && g_live_ctx.count(ctx) != 0;
+  if (!ctx) return false;
+  const auto it = g_live_ctx.find(ctx);
+  return it != g_live_ctx.end() && it->second == id;
 }
 
 hipError_t rls_dev_alloc(rls_ctx* ctx, void** p, size_t bytes) {
@@ -53,30 +54,20 @@ hipError_t rls_dev_free(rls_ctx* ctx, void* p) {
   return hipFree(p);
 }
 
+// small pinned host blocks: the process-wide cache of host_pool.hpp (keeps blocks <= 4 KiB, returns larger ones to the driver).
+// mapped + coherent: the status kernels store into these blocks directly (rls_fetch_wait)
+static pinned_cache g_pinned;
 hipError_t rls_pinned_alloc(void** p, size_t bytes) {
-  const size_t cls = (bytes + 255) / 256 * 256;
-  {
-    std::lock_guard<std::mutex> lk(g_mem_mutex);
-    auto& fl = g_pinned_free[cls];
-    if (!fl.empty()) {
-      *p = fl.back();
-      fl.pop_back();
-      return hipSuccess;
-    }
-  }
-  char* raw = nullptr;
-  // mapped + coherent: the status kernels store into these blocks directly (rls_fetch_wait)
-  const hipError_t e = hipHostMalloc((void**)&raw, cls + PIN_HDR, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
-  if (e != hipSuccess) return e;
-  *reinterpret_cast<size_t*>(raw) = cls;
-  *p = raw + PIN_HDR;
-  return hipSuccess;
+  hipError_t err = hipSuccess;
+  *p = g_pinned.get(bytes, [&err](size_t n) -> void* {
+    void* raw = nullptr;
+    err = hipHostMalloc(&raw, n, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+    return err == hipSuccess ? raw : nullptr;
+  });
+  return *p ? hipSuccess : (err != hipSuccess ? err : hipErrorOutOfMemory);
 }
 void rls_pinned_free(void* p) {
-  if (!p) return;
-  const size_t cls = *reinterpret_cast<size_t*>(static_cast<char*>(p) - PIN_HDR);
-  std::lock_guard<std::mutex> lk(g_mem_mutex);
-  g_pinned_free[cls].push_back(p);   // kept for the next plan; the process returns it to the driver at exit
+  g_pinned.put(p, [](void* raw) { (void)hipHostFree(raw); });
 }
 
 // ---- status mailbox --------------------------------------------------------------------------------------------------------
@@ -183,7 +174,8 @@ static int32_t ctx_create_impl(int32_t device, void* stream, bool borrow, rls_ct
   }
   {
     std::lock_guard<std::mutex> lk(g_mem_mutex);
-    g_live_ctx.insert(ctx);
+    ctx->id = g_next_ctx_id++;
+    g_live_ctx[ctx] = ctx->id;
   }
   *out = ctx;
   return 0;

@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int MAX_RANKS = 16;
+constexpr int MAX_RANKS = RLS_POOL_MAX_RANKS;
 
 struct peer_ptrs {
   float* p[MAX_RANKS];
@@ -66,24 +66,6 @@ struct rccl_api {
 
 }  // namespace
 
-// One host worker thread per rank (the fan-out of src/MultiThreading.jl:60-78, `Threads.@threads`, inside the library):
-// a row-sharded solver call hands every worker the WHOLE loop of its rank -- phases separated by a spinning host barrier
-// -- so that the host side of an iteration costs what ONE rank's launches cost, not the sum over ranks.
-struct comm_pool {
-  std::vector<std::thread> th;
-  std::mutex m;
-  std::condition_variable cv;
-  uint64_t gen = 0;
-  bool quit = false;
-  const std::vector<rls_comm_phase>* phases = nullptr;
-  int reps = 0;
-  std::atomic<int> arrived{0};
-  std::atomic<unsigned> sense{0};
-  std::atomic<int> finished{0};
-  std::atomic<int32_t> status{0};
-  double busy_s[MAX_RANKS] = {0};  // per rank: wall clock spent INSIDE phase bodies (enqueueing), barriers and idling excluded
-};
-
 struct rls_comm {
   int n = 0;
   int transport = 0;
@@ -100,9 +82,9 @@ struct rls_comm {
   // RCCL transport
   rccl_api rccl;
   std::vector<nccl_comm_t> comms;
+  bool group_open = false;  // single-thread path: rank 0 opened an RCCL group that the last rank has not closed yet
 };
 
-static void pool_stop(rls_comm* c);
 
 static int32_t comm_fail(rls_comm* c, int32_t code, const char* what) {
   return rls_fail(c && !c->ctx.empty() ? c->ctx[0] : nullptr, code, what);
@@ -189,67 +171,7 @@ static int32_t rccl_check(rls_comm* c, int rc, const char* what) {
   return comm_fail(c, 1000 + rc, msg);
 }
 
-// ---- host fan-out -----------------------------------------------------------------------------------------------------
-static void pool_barrier(comm_pool* P, int n, unsigned* my_sense) {
-  *my_sense ^= 1u;
-  if (P->arrived.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
-    P->arrived.store(0, std::memory_order_relaxed);
-    P->sense.store(*my_sense, std::memory_order_release);
-  } else {
-    for (unsigned spins = 0; P->sense.load(std::memory_order_acquire) != *my_sense; ++spins) {
-      rls_cpu_relax();
-      if ((spins & 1023u) == 1023u) std::this_thread::yield();  // oversubscribed hosts: let the others run
-    }
-  }
-}
-
-static void pool_worker(rls_comm* c, int r) {
-  comm_pool* P = c->pool;
-  uint64_t seen = 0;
-  (void)hipSetDevice(c->ctx[r]->device);
-  for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(P->m);
-      P->cv.wait(lk, [&] { return P->quit || P->gen != seen; });
-      if (P->quit) return;
-      seen = P->gen;
-    }
-    unsigned my_sense = P->sense.load(std::memory_order_acquire);
-    const std::vector<rls_comm_phase>& ph = *P->phases;
-    for (int k = 0; k < P->reps; ++k) {
-      for (size_t i = 0; i < ph.size(); ++i) {
-        if (P->status.load(std::memory_order_relaxed) == 0) {  // after a failure the ranks only keep each other company
-          const auto t0 = std::chrono::steady_clock::now();
-          const int32_t st = ph[i].run(r, k);
-          P->busy_s[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-          if (st != 0) {
-            int32_t zero = 0;
-            P->status.compare_exchange_strong(zero, st);
-          }
-        }
-        if (ph[i].barrier_after) pool_barrier(P, c->n, &my_sense);
-      }
-    }
-    if (P->finished.fetch_add(1, std::memory_order_acq_rel) == c->n - 1) {
-      std::lock_guard<std::mutex> lk(P->m);
-      P->cv.notify_all();
-    }
-  }
-}
-
-static void pool_stop(rls_comm* c) {
-  comm_pool* P = c->pool;
-  if (!P) return;
-  {
-    std::lock_guard<std::mutex> lk(P->m);
-    P->quit = true;
-  }
-  P->cv.notify_all();
-  for (std::thread& t : P->th) t.join();
-  delete P;
-  c->pool = nullptr;
-}
-
+// ---- host fan-out: the worker pool and its barrier live in host_pool.hpp (device-free: also built under the sanitizers) ----
 // reps x (the phases in order) for every rank.  Threads: each rank's worker runs the whole sequence, meeting the others
 // at the host barrier behind every phase that asks for one.  One thread (single rank, or threads switched off): phase by
 // phase over all ranks, which orders everything a barrier would.
@@ -259,29 +181,22 @@ int32_t rls_comm_run(rls_comm* c, const std::vector<rls_comm_phase>& phases, int
   if (c->n == 1 || !c->use_threads) {
     for (int k = 0; k < reps; ++k)
       for (const rls_comm_phase& ph : phases)
-        for (int r = 0; r < c->n; ++r) RLS_TRY(ph.run(r, k));
+        for (int r = 0; r < c->n; ++r) {
+          const int32_t st = ph.run(r, k);
+          if (st != 0) {
+            // a phase body failed between rank 0's ncclGroupStart and the last rank's ncclGroupEnd: close the group, or every
+            // later RCCL call of this thread would be queued into it
+            if (c->group_open) {
+              (void)c->rccl.GroupEnd();
+              c->group_open = false;
+            }
+            return st;
+          }
+        }
     return 0;
   }
-  if (!c->pool) {
-    c->pool = new comm_pool();
-    for (int r = 0; r < c->n; ++r) c->pool->th.emplace_back(pool_worker, c, r);
-  }
-  comm_pool* P = c->pool;
-  {
-    std::lock_guard<std::mutex> lk(P->m);
-    P->phases = &phases;
-    P->reps = reps;
-    P->finished.store(0);
-    P->status.store(0);
-    P->arrived.store(0);
-    ++P->gen;
-  }
-  P->cv.notify_all();
-  {
-    std::unique_lock<std::mutex> lk(P->m);
-    P->cv.wait(lk, [&] { return P->finished.load(std::memory_order_acquire) == c->n; });
-  }
-  return P->status.load();
+  rls_comm* cc = c;
+  return pool_run(c->pool, c->n, phases, reps, [cc](int r) { (void)hipSetDevice(cc->ctx[r]->device); });
 }
 
 // the collective as two per-rank half-steps (see direct_publish / direct_collect); `round` = rls_comm_next_rounds() + k.
@@ -292,11 +207,15 @@ int32_t rls_comm_publish(rls_comm* c, int r, void* buf, int64_t n, int32_t dtype
   if (c->n == 1 || n == 0) return 0;
   if (c->transport == RLS_COMM_DIRECT) return direct_publish(c, r, buf, nf, round);
   const bool grouped = !c->use_threads;
-  if (grouped && r == 0) RLS_TRY(rccl_check(c, c->rccl.GroupStart(), "ncclGroupStart"));
+  if (grouped && r == 0) {
+    RLS_TRY(rccl_check(c, c->rccl.GroupStart(), "ncclGroupStart"));
+    c->group_open = true;
+  }
   const int32_t st = rccl_check(c, c->rccl.AllReduce(buf, buf, nf, /* ncclFloat32 */ 7, /* ncclSum */ 0, c->comms[r], c->ctx[r]->stream),
                                 "ncclAllReduce");
   if (grouped && r == c->n - 1) {
     const int32_t st2 = rccl_check(c, c->rccl.GroupEnd(), "ncclGroupEnd");
+    c->group_open = false;
     return st != 0 ? st : st2;
   }
   return st;
@@ -329,7 +248,7 @@ int32_t rls_comm_debug_busy_seconds(rls_comm* c, double* out) {
 
 int32_t rls_comm_set_threads(rls_comm* c, int32_t on) {
   if (!c) return RLS_E_INVALID;
-  if (!on) pool_stop(c);
+  if (!on) pool_stop(c->pool);
   c->use_threads = on ? 1 : 0;
   return 0;
 }
@@ -415,7 +334,7 @@ int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* 
 
 int32_t rls_comm_destroy(rls_comm* c) {
   if (!c) return RLS_E_INVALID;
-  pool_stop(c);
+  pool_stop(c->pool);
   for (int r = 0; r < (int)c->ctx.size(); ++r) {
     hipSetDevice(c->ctx[r]->device);
     rls_stream_wait(c->ctx[r]->stream);

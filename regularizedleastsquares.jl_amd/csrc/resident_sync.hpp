@@ -42,8 +42,10 @@ struct resident_sync {
   unsigned completed;    // workgroup 0 passed the last barrier and wrote the state back (last launch)
   // ---- everything above is zeroed ahead of every launch (rls_resident_sync_clear_bytes); what follows is STICKY ----
   unsigned failed;       // launches of this plan that were no-ops because workgroup 0 gave up: only workgroup 0 writes the
-                         // state back, so "workgroup 0 timed out" is exactly "the launch changed nothing".  Zeroed by the
-                         // plan's init and by the host once it has re-run the lost work on the per-iteration pipeline.
+                         // state back, so "workgroup 0 timed out" is exactly "the launch changed nothing".  Zeroed at plan
+                         // creation and by the HOST once a status call has seen it (resident_lost: it re-runs what the current
+                         // solve is missing and retires the plan from the resident kernels); init! does NOT clear it, so a loss
+                         // nobody asked about is still reported -- by the next status call, of whichever solve.
   unsigned pad[29];
 };
 static_assert(sizeof(resident_sync) == (2 * 8 * 32 + 32) * sizeof(unsigned), "resident_sync layout");

@@ -39,6 +39,7 @@ struct rls_tuning {
 
 struct rls_ctx {
   int device = 0;
+  uint64_t id = 0;  // unique per context ever created in this process (a plan that outlives its context compares it: rls_ctx_alive)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -83,7 +84,7 @@ hipError_t rls_dev_alloc(rls_ctx* ctx, void** p, size_t bytes);
 hipError_t rls_dev_free(rls_ctx* ctx, void* p);   // ctx may be null (or destroyed: pass null): synchronous hipFree
 hipError_t rls_pinned_alloc(void** p, size_t bytes);
 void rls_pinned_free(void* p);
-bool rls_ctx_alive(const rls_ctx* ctx);
+bool rls_ctx_alive(const rls_ctx* ctx, uint64_t id);  // this very context (same address AND same generation id) still exists
 // The allocation calls of a plan's create / destroy function go to the context named by the innermost live scope on
 // this thread (null: the synchronous calls).
 struct rls_alloc_scope {
@@ -806,12 +807,7 @@ int32_t rls_gramk_resident_launch(rls_ctx* ctx, const rls_gramk& D, void* sync, 
 // ---------------------------------------------------------------------------------------------
 // comm.hip internals used by the row-sharded solver loops (solvers.hip)
 // ---------------------------------------------------------------------------------------------
-#include <functional>
-#include <vector>
-struct rls_comm_phase {
-  std::function<int32_t(int rank, int rep)> run;  // rank's share of the phase in repetition `rep`
-  bool barrier_after = true;                      // every rank must have CALLED this phase before any starts the next
-};
+#include "host_pool.hpp"  // rls_comm_phase, the worker pool, the pinned cache, the resident-chain bookkeeping (device-free)
 int32_t rls_comm_run(rls_comm* c, const std::vector<rls_comm_phase>& phases, int reps);
 int32_t rls_comm_publish(rls_comm* c, int rank, void* buf, int64_t n, int32_t dtype, int round);
 int32_t rls_comm_collect(rls_comm* c, int rank, void* buf, int64_t n, int32_t dtype, int round);

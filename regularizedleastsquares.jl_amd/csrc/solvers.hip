@@ -24,13 +24,15 @@ template <typename T>
 static hipError_t hmalloc(T** p, size_t bytes) { return rls_pinned_alloc(reinterpret_cast<void**>(p), bytes); }
 static void hfree(void* p) { rls_pinned_free(p); }
 // the context a plan allocated from, if it still exists (plans may outlive their context in a garbage-collected host)
-static rls_ctx* alloc_ctx_of(rls_ctx* ctx) { return rls_ctx_alive(ctx) ? ctx : nullptr; }
+// (pointer AND generation id: a destroyed context's address can be handed out again to a new one, possibly on another device)
+static rls_ctx* alloc_ctx_of(rls_ctx* ctx, uint64_t id) { return rls_ctx_alive(ctx, id) ? ctx : nullptr; }
 
 // ---------------------------------------------------------------------------------------------
 // operator
 // ---------------------------------------------------------------------------------------------
 struct rls_operator {
   rls_ctx* ctx;
+  uint64_t ctx_id = 0;  // ctx->id at creation (alloc_ctx_of)
   int32_t dtype;
   int64_t M, N;
   const void* A;  // may be null (Gram-only operator)
@@ -130,6 +132,7 @@ static inline int pipe_cur_hint(const rls_ctx* ctx, int k) {
 struct rls_cgnr {
   rls_operator* op;
   rls_ctx* actx;  // the context whose pool the plan's scratch came from (checked alive before it is used in destroy)
+  uint64_t actx_id = 0;
   int device;
   void *x, *r, *p, *v;
   cgnr_scalars* sc;    // device
@@ -280,29 +283,29 @@ static bool cgnr_use_resident(const rls_cgnr* s) {
 // everything it has queued since: conservative -- and waited for by the new one.  (Another PROCESS on the same device
 // is not covered: its symptom is the bounded-wait timeout reported by rls_cgnr_get_status.)
 static hipEvent_t g_resident_ev[64];
-static hipStream_t g_resident_last[64];  // guarded by rls_capture_mutex(); cleared by rls_resident_forget (context teardown)
+static resident_chain_state g_resident_chain;  // guarded by rls_capture_mutex(); cleared by rls_resident_forget (context teardown)
 void rls_resident_forget(int device, hipStream_t stream) {
-  std::lock_guard<std::mutex> lock(rls_capture_mutex());
-  const int d = device < 64 ? (device < 0 ? 0 : device) : 63;
-  if (g_resident_last[d] == stream) g_resident_last[d] = nullptr;
+  resident_chain_forget(rls_capture_mutex(), g_resident_chain, device, (void*)stream);
 }
 // `clean` (nullable): the plan's init kernel has zeroed the counters itself and nothing has used them since -- the memset
 // (a launch of its own: ~4 us on the stream between init! and the resident kernel of every solve) is skipped, once
 template <typename F>
 static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch, bool* clean = nullptr) {
-  std::lock_guard<std::mutex> lock(rls_capture_mutex());
   const int d = ctx->device < 64 ? ctx->device : 63;
-  if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
-  if (g_resident_last[d] && g_resident_last[d] != ctx->stream) {
-    RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], g_resident_last[d]));
-    RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
-  }
-  // arrival counters and the {fail, completed} words of THIS launch; the count of lost launches behind them is sticky
-  if (clean && *clean && ctx->tune.resident_preclear) *clean = false;
-  else RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_resident_sync_clear_bytes(), ctx->stream));
-  const int32_t st = launch();
-  g_resident_last[d] = ctx->stream;
-  return st;
+  return resident_chain_step(
+      rls_capture_mutex(), g_resident_chain, ctx->device, (void*)ctx->stream,
+      [&](void* prev) -> int32_t {  // the chain changes streams: order this launch behind everything the previous stream has queued
+        if (!g_resident_ev[d]) RLS_HIP(ctx, hipEventCreateWithFlags(&g_resident_ev[d], hipEventDisableTiming));
+        RLS_HIP(ctx, hipEventRecord(g_resident_ev[d], (hipStream_t)prev));
+        RLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_resident_ev[d], 0));
+        return 0;
+      },
+      [&]() -> int32_t {
+        // arrival counters and the {fail, completed} words of THIS launch; the count of lost launches behind them is sticky
+        if (clean && *clean && ctx->tune.resident_preclear) *clean = false;
+        else RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_resident_sync_clear_bytes(), ctx->stream));
+        return launch();
+      });
 }
 static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_pipe& P, int n_steps) {
   return resident_chain(ctx, s->rsync, [&]() {
@@ -585,6 +588,7 @@ static int32_t cgnr_effective_iterations(rls_cgnr* s, int32_t iterations) {
 struct rls_fista {
   rls_operator* op;
   rls_ctx* actx;
+  uint64_t actx_id = 0;
   int device;
   void* buf[2];  // x / xold, swapped by iteration parity: state.x == buf[iteration & 1]
   void *x0, *res;
@@ -958,6 +962,7 @@ struct cg_scalars {
 struct rls_cg {
   rls_operator* op;
   rls_ctx* actx;
+  uint64_t actx_id = 0;
   int device;
   void *u, *r, *c;
   cg_scalars* sc;
@@ -1412,6 +1417,7 @@ constexpr int ADMM_REC = 8;  // floats per log record: Delta, sk, eps_pri, rk, e
 struct rls_admm {
   rls_cg* cg;
   rls_ctx* actx;
+  uint64_t actx_id = 0;
   int device;
   rls_admm_params P;
   bool ready;
@@ -1870,6 +1876,7 @@ int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, c
   rls_alloc_scope alloc_scope(ctx);
   rls_operator* op = new rls_operator();
   op->ctx = ctx;
+  op->ctx_id = ctx->id;
   op->dtype = dtype;
   op->M = M;
   op->N = N;
@@ -1903,7 +1910,7 @@ int32_t rls_operator_set_gram(rls_operator* op, const void* AHA, int64_t ld) {
 
 int32_t rls_operator_destroy(rls_operator* op) {
   if (!op) return RLS_E_INVALID;
-  rls_alloc_scope alloc_scope(alloc_ctx_of(op->ctx));
+  rls_alloc_scope alloc_scope(alloc_ctx_of(op->ctx, op->ctx_id));
   if (op->slab) dfree(op->slab);
   if (op->t) dfree(op->t);  // hipFree resolves the owning device from the pointer
   delete op;
@@ -1980,6 +1987,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   rls_alloc_scope alloc_scope(ctx);
   rls_cgnr* s = new rls_cgnr();
   s->actx = ctx;
+  s->actx_id = ctx->id;
   s->skinny = skinny;
   s->gram_pipe = false;
   s->v1 = nullptr;
@@ -2097,7 +2105,7 @@ int32_t rls_cgnr_create_batched(rls_operator* op, int32_t nrhs, void* X, void* R
 int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
-  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx, s->actx_id));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
   if (s->r1) dfree(s->r1);
   if (s->p1) dfree(s->p1);
@@ -2539,6 +2547,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   rls_fista* s = new rls_fista();
   s->op = op;
   s->actx = ctx;
+  s->actx_id = ctx->id;
   s->device = op->ctx->device;
   s->buf[0] = x;
   s->buf[1] = xold;
@@ -2604,7 +2613,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
 int32_t rls_fista_destroy(rls_fista* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
-  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx, s->actx_id));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
   dfree(s->y);
   if (s->y1) dfree(s->y1);
@@ -2736,6 +2745,7 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   rls_fista* s = new rls_fista();
   s->op = op;
   s->actx = ctx;
+  s->actx_id = ctx->id;
   s->device = ctx->device;
   s->buf[0] = x;
   s->buf[1] = xold;
@@ -3007,6 +3017,7 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   rls_cg* s = new rls_cg();
   s->op = op;
   s->actx = ctx;
+  s->actx_id = ctx->id;
   s->device = op->ctx->device;
   s->u = u;
   s->r = r;
@@ -3086,6 +3097,7 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
   rls_cg* s = new rls_cg();
   s->op = op;
   s->actx = ctx;
+  s->actx_id = ctx->id;
   s->device = ctx->device;
   s->u = U;
   s->r = R;
@@ -3117,7 +3129,7 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
 int32_t rls_cg_destroy(rls_cg* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
-  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx, s->actx_id));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
   if (s->Ppack) dfree(s->Ppack);
   if (s->Tpack) dfree(s->Tpack);
@@ -3208,6 +3220,7 @@ int32_t rls_cg_local_update(rls_cg* s, void* x) {
 struct rls_pgm {
   rls_operator* op;
   rls_ctx* actx;
+  uint64_t actx_id = 0;
   int device;
   void* rsync = nullptr;
   unsigned* rsync_h = nullptr;
@@ -3227,6 +3240,7 @@ int32_t rls_pgm_create(rls_operator* op, rls_pgm** out) {
   rls_pgm* s = new rls_pgm();
   s->op = op;
   s->actx = ctx;
+  s->actx_id = ctx->id;
   s->device = ctx->device;
   hipError_t e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
   if (e == hipSuccess) e = dmalloc(&s->raw, (size_t)op->N * rls_elem_size(op->dtype));
@@ -3245,7 +3259,7 @@ int32_t rls_pgm_create(rls_operator* op, rls_pgm** out) {
 int32_t rls_pgm_destroy(rls_pgm* s) {
   if (!s) return RLS_E_INVALID;
   hipSetDevice(s->device);
-  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx));
+  rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx, s->actx_id));
   dfree(s->rsync);
   dfree(s->raw);
   hfree(s->rsync_h);
@@ -3394,6 +3408,7 @@ int32_t rls_admm_create(rls_cg* cg, rls_admm** out) {
   rls_admm* a = new rls_admm();
   a->cg = cg;
   a->actx = ctx;
+  a->actx_id = ctx->id;
   a->device = ctx->device;
   a->ready = false;
   a->log = a->log_h = nullptr;
@@ -3412,7 +3427,7 @@ int32_t rls_admm_create(rls_cg* cg, rls_admm** out) {
 int32_t rls_admm_destroy(rls_admm* a) {
   if (!a) return RLS_E_INVALID;
   hipSetDevice(a->device);
-  rls_alloc_scope alloc_scope(alloc_ctx_of(a->actx));
+  rls_alloc_scope alloc_scope(alloc_ctx_of(a->actx, a->actx_id));
   if (a->log) dfree(a->log);
   if (a->log_h) hfree(a->log_h);
   dfree(a->sc);
