@@ -68,9 +68,16 @@ int32_t rls_device_count(int32_t* out);
  * resident kernel's arrival counters, saving the memset launch ahead of the first step call).  Process-wide (measurement only, set before the
  * plan is created): "slab_g", "slab_wv", "slab_order", "red_threads", "resident_barrier", "tv_fused_max_n",
  * "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits", "skinny_half"
- * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll" (rolling-window
- * depth of the batched kernels' load pipelines), "gram_lds_kib", "kaczmarz_nt". */
+ * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll", "skinny_g_roll" (rolling-window
+ * depth of the batched kernels' load pipelines), "gram_lds_kib", "kaczmarz_nt".  Per context again: "small" (1: systems that
+ * fit one CU's registers run a step call as a single-workgroup launch), "status_mailbox" (1: status read-backs through a kernel
+ * that stores into pinned host memory + a host spin; 0: hipMemcpyAsync + stream wait). */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
+/* Device memory is STREAM-ORDERED on the context's stream (a private hipMemPool per device; RLS_ALLOC=sync or a device without
+ * memory pools: hipMalloc / hipFree): rls_free does not wait for the stream, the block is reused behind everything enqueued on
+ * this context so far.  Memory that ANOTHER context's stream (or another library's) still uses must be synchronised by the
+ * caller before it is freed.  rls_free with a handle that is not a live context -- a finalizer that runs after its context was
+ * destroyed -- does not dereference the handle and frees synchronously. */
 int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out);  /* similar(b, dims...)  src/CGNR.jl:92-95 */
 int32_t rls_free(rls_ctx* ctx, void* p);
 int32_t rls_memcpy_h2d(rls_ctx* ctx, void* dst, const void* src_h, size_t bytes);

@@ -22,15 +22,16 @@ end
 mutable struct Context
   handle::Ptr{Cvoid}
   device::Int32
+  owner::Any  # a borrowed context keeps its communicator reachable: arrays allocated on it hold the context, hence the Comm
   function Context(device::Integer = 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     st = ccall((:rls_ctx_create, librls[]), Int32, (Int32, Ref{Ptr{Cvoid}}), device, h)
     st == 0 || throw(RLSError(st, "rls_ctx_create failed: no usable MI355X (there is no CPU fallback)"))
-    ctx = new(h[], Int32(device))
+    ctx = new(h[], Int32(device), nothing)
     finalizer(c -> ccall((:rls_ctx_destroy, librls[]), Int32, (Ptr{Cvoid},), c.handle), ctx)
   end
   # a context owned by a communicator (rls_comm_ctx): wrapped, never destroyed from here
-  Context(handle::Ptr{Cvoid}, device::Integer, ::Val{:borrowed}) = new(handle, Int32(device))
+  Context(handle::Ptr{Cvoid}, device::Integer, ::Val{:borrowed}) = new(handle, Int32(device), nothing)
 end
 
 function check(ctx::Context, st::Int32, what)
@@ -431,6 +432,13 @@ mutable struct Comm
     end
     ccall((:rls_comm_set_threads, librls[]), Int32, (Ptr{Cvoid}, Int32), h[], threads ? 1 : 0)
     comm = new(h[], ctxs)
+    # Arrays and plans allocated on a rank's context reference that Context, and through `owner` this Comm: the communicator
+    # (which owns the contexts) stays reachable as long as anything allocated on it is.  Julia still runs the finalizers of
+    # objects that die TOGETHER in no particular order (always so at exit): for that case rls_free never dereferences a handle
+    # that is not a live context (csrc/api.hip) and plans check rls_ctx_alive before they free through their context.
+    for c in ctxs
+      c.owner = comm
+    end
     finalizer(c -> ccall((:rls_comm_destroy, librls[]), Int32, (Ptr{Cvoid},), c.handle), comm)
   end
 end

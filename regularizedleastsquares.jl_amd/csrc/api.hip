@@ -14,28 +14,48 @@ std::map<const rls_ctx*, uint64_t> g_live_ctx;  // live contexts and their gener
 uint64_t g_next_ctx_id = 1;
 thread_local rls_ctx* tl_alloc_ctx = nullptr;
 
-bool device_pools_ok(int device) {
+// One PRIVATE stream-ordered pool per device (release threshold raised so that freed blocks stay cached).  The device's default
+// pool is shared with every other hipMallocAsync user of the process (PyTorch, AMDGPU.jl): its settings are not ours to change.
+std::map<int, hipMemPool_t> g_pools;
+hipMemPool_t device_pool(int device) {
   static std::mutex m;
-  static std::map<int, bool> known;
   std::lock_guard<std::mutex> lk(m);
-  auto it = known.find(device);
-  if (it != known.end()) return it->second;
-  bool ok = false;
+  auto it = g_pools.find(device);
+  if (it != g_pools.end()) return it->second;
+  hipMemPool_t pool = nullptr;
   const char* env = getenv("RLS_ALLOC");
   if (!(env && !strcmp(env, "sync"))) {
     int supported = 0;
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
-        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
-      uint64_t keep = ~0ull;  // never hand cached blocks back to the driver at synchronisation points
-      ok = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported) {
+      hipMemPoolProps props;
+      memset(&props, 0, sizeof(props));
+      props.allocType = hipMemAllocationTypePinned;
+      props.handleTypes = hipMemHandleTypeNone;
+      props.location.type = hipMemLocationTypeDevice;
+      props.location.id = device;
+      if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+        uint64_t keep = ~0ull;  // never hand cached blocks back to the driver at synchronisation points
+        if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) {
+          (void)hipMemPoolDestroy(pool);
+          pool = nullptr;
+        }
+      } else {
+        pool = nullptr;
+      }
     }
     (void)hipGetLastError();
   }
-  known[device] = ok;
-  return ok;
+  g_pools[device] = pool;
+  return pool;
 }
+bool device_pools_ok(int device) { return device_pool(device) != nullptr; }
 }  // namespace
+
+// by address only: for entry points that receive nothing but the handle (rls_free from a garbage-collected host's finalizer)
+static bool ctx_alive_by_address(const rls_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  return ctx && g_live_ctx.find(ctx) != g_live_ctx.end();
+}
 
 bool rls_ctx_alive(const rls_ctx* ctx, uint64_t id) {
   std::lock_guard<std::mutex> lk(g_mem_mutex);
@@ -45,7 +65,7 @@ bool rls_ctx_alive(const rls_ctx* ctx, uint64_t id) {
 }
 
 hipError_t rls_dev_alloc(rls_ctx* ctx, void** p, size_t bytes) {
-  if (ctx && ctx->pools) return hipMallocAsync(p, bytes ? bytes : 1, ctx->stream);
+  if (ctx && ctx->pools) return hipMallocFromPoolAsync(p, bytes ? bytes : 1, device_pool(ctx->device), ctx->stream);
   return hipMalloc(p, bytes ? bytes : 1);
 }
 hipError_t rls_dev_free(rls_ctx* ctx, void* p) {
@@ -291,8 +311,14 @@ int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out) {
 }
 
 int32_t rls_free(rls_ctx* ctx, void* p) {
-  RLS_CHECK_CTX(ctx);
   if (!p) return 0;
+  // A garbage-collected host runs finalizers in no particular order: an array allocated on a communicator's context can be
+  // freed after rls_comm_destroy has destroyed that context (julia/RLSMI355X: Comm and the arrays of its shards).  A handle that
+  // is not a LIVE context is never dereferenced: the block goes back synchronously (hipFree resolves the device from the pointer).
+  if (!ctx_alive_by_address(ctx)) {
+    const hipError_t e = hipFree(p);
+    return e == hipSuccess ? 0 : (int32_t)e;
+  }
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->pools) RLS_HIP(ctx, rls_stream_wait(ctx->stream));  // (hipFree synchronises the whole device anyway)
   RLS_HIP(ctx, rls_dev_free(ctx, p));   // pooled: ordered behind everything enqueued on the context's stream

@@ -448,3 +448,19 @@ def test_openmp_cgnr_baseline_matches_the_oracle():
         assert n == 2 * its and sec.value > 0
         ref = O.CGNR(A.astype(np.complex128), reg=O.L2Regularization(lam), iterations=its, relTol=0.0)
         assert rel(x, O.solve(ref, b.astype(np.complex128))) < 1e-5
+
+
+def test_adjoint_product_forms_are_bit_identical():
+    """the oracle forms A' y through a cached conjugate transpose (or, for very large matrices and in the GPU tests' panel-wise
+    float64 operator, as conj(conj(y) A)): both must give the bits of the plain expression A.conj().T @ y"""
+    rng = np.random.default_rng(5)
+    for dt in (np.complex128, np.complex64, np.float32, np.float64):
+        A = rng.standard_normal((257, 96))
+        y = rng.standard_normal(257)
+        if np.dtype(dt).kind == "c":
+            A = A + 1j * rng.standard_normal((257, 96))
+            y = y + 1j * rng.standard_normal(257)
+        A, y = np.asfortranarray(A.astype(dt)), y.astype(dt)
+        want = A.conj().T @ y
+        assert np.array_equal(O.DenseOp(A).mul_adj(y), want)
+        assert np.array_equal(np.conj(np.conj(y) @ A), want)
