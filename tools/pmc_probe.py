@@ -41,6 +41,23 @@ for K in (8, 16):
     S4 = rls.createLinearSolver(rls.CGNR, Ad, iterations=6, relTol=0.0)
     rls.solve_(S4, Bd, scheduler=rls.BatchedState)
     ctx.sync()
+# the same on the reference's default operator (AHA explicit): the resident batched launch (8 columns) and the streaming product
+for K, res in ((8, 1), (8, 0), (16, 1)):
+    ctx.tune(resident=res)
+    X = (rng.standard_normal((N, K)) + 1j * rng.standard_normal((N, K))).astype(np.complex64)
+    Bd = rls.DeviceMatrix.from_host(np.asfortranarray((A @ X).astype(np.complex64)), ctx)
+    S5 = rls.createLinearSolver(rls.CGNR, Ad, AHA=G, iterations=32 if res else 6, relTol=0.0)
+    for _ in range(2):
+        rls.solve_(S5, Bd, scheduler=rls.BatchedState)
+    ctx.sync()
+ctx.tune(resident=1)
+# BASELINE configs[0] on the single-workgroup kernel
+A1 = make_A(256, 128, 1, np.float32); A1d = rls.DeviceMatrix.from_host(A1, ctx)
+b1 = rls.DeviceVector.from_host((A1 @ np.ones(128, np.float32)).astype(np.float32), ctx)
+S6 = rls.createLinearSolver(rls.CGNR, A1d, reg=rls.L2Regularization(1e-2), iterations=10, relTol=0.0)
+for _ in range(3):
+    rls.solve_(S6, b1)
+ctx.sync()
 p = rls.DeviceVector.from_host(np.ones(N, np.complex64), ctx); t = rls.DeviceVector(M, np.complex64, ctx); v = rls.DeviceVector(N, np.complex64, ctx)
 for _ in range(3):
     Ad.gemv_(0, p, t); Ad.gemv_(2, t, v)

@@ -25,7 +25,13 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
 for k in fetch:
     short = k.replace("void ", "").replace("(anonymous namespace)::", "").split("<")[0].split("(")[0].strip()
     if short in ("skinny_t_kernel", "skinny_v_kernel", "skinny_pack_rows_kernel"):  # half (<= 8 right-hand sides) / full operand layout
-        short += " [half layout]" if ", true" in k.split("(")[0] else " [full layout]"
+        targs = [a.strip() for a in k.split("(")[0].split("<", 1)[1].rsplit(">", 1)[0].replace("HIP_vector_type<float, 2u>", "c32").split(",")]
+        half = (targs[3] if short != "skinny_pack_rows_kernel" else targs[1]) == "true"
+        short += " [half layout]" if half else " [full layout]"
+        if short.startswith("skinny_t_kernel") and len(targs) > 5 and targs[5] == "true":
+            short += " [V = AHA P: the Gram-mode product]"
+    if short == "cgnr_gramk_resident_kernel":
+        short += " [32 iterations per launch]"
     out["kernels"][short] = {"fetch_size_raw_bytes": fetch[k], "write_size_bytes": write.get(k, 0.0),
                              "hbm_bytes_per_launch": 2.0 * fetch[k] + write.get(k, 0.0)}
 g = out["kernels"].get("gemv_t_kernel")
