@@ -25,9 +25,9 @@ cp $(find /tmp/prof_cfg -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_con
 cp $(find /tmp/prof_batched -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_batched_kernel_stats.csv
 # the same on the reference's default operator (AHA explicit, shared by the columns): streaming product and resident launch
 rm -rf /tmp/prof_bg /tmp/prof_bgs
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bg -o b -- python3 "$GRAFT_REPO_ROOT/tools/bench_batched.py" 8,16,64 gram=1 > gpurun_out/${R}_batched_gram.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bg -o b -- python3 "$GRAFT_REPO_ROOT/tools/bench_batched.py" 8,16,64 gram=1 > "$GRAFT_REPO_ROOT/gpurun_out/${R}_batched_gram.log" 2>&1)
 cp $(find /tmp/prof_bg -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_batched_gram_kernel_stats.csv
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bgs -o b -- python3 "$GRAFT_REPO_ROOT/tools/bench_batched.py" 8 gram=1 resident=0 > gpurun_out/${R}_batched_gram_streaming.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bgs -o b -- python3 "$GRAFT_REPO_ROOT/tools/bench_batched.py" 8 gram=1 resident=0 > "$GRAFT_REPO_ROOT/gpurun_out/${R}_batched_gram_streaming.log" 2>&1)
 cp $(find /tmp/prof_bgs -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_batched_gram_streaming_kernel_stats.csv
 # in-kernel primitives (bare group / grid barriers, the exchanges with the arithmetic stripped), cadence, config 1
 tools/ubench/grid_barrier 2000 2048 > gpurun_out/${R}_grid_barrier.txt 2>&1
