@@ -70,8 +70,9 @@ int32_t rls_device_count(int32_t* out);
  * "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits", "skinny_half"
  * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll", "skinny_g_roll" (rolling-window
  * depth of the batched kernels' load pipelines), "gram_lds_kib", "kaczmarz_nt".  Per context again: "small" (1: systems that
- * fit one CU's registers run a step call as a single-workgroup launch), "status_mailbox" (1: status read-backs through a kernel
- * that stores into pinned host memory + a host spin; 0: hipMemcpyAsync + stream wait). */
+ * fit one CU's registers run a step call as a single-workgroup launch), "status_mailbox" (>= 1: status read-backs through a kernel
+ * that stores into pinned host memory + a host spin; 2, the default: rls_*_step_status has the call's last kernel do that store where
+ * it can; 0: hipMemcpyAsync + stream wait). */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
 /* Device memory is STREAM-ORDERED on the context's stream (a private hipMemPool per device; RLS_ALLOC=sync or a device without
  * memory pools: hipMalloc / hipFree): rls_free does not wait for the stream, the block is reused behind everything enqueued on

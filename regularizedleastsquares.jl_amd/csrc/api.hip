@@ -103,8 +103,8 @@ __global__ __launch_bounds__(64) void mailbox_publish_kernel(fetch_args A, unsig
   for (int k = 0; k < A.count; ++k)
     for (unsigned i = threadIdx.x; i < A.n[k]; i += 64)
       __hip_atomic_store(A.dst[k] + i, A.src[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // the wave's stores above are complete and visible to the host ...
-  if (threadIdx.x == 0) __hip_atomic_store(seq_h, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // ... before this one
+  rls_system_stores_done();  // the wave's stores above are acknowledged ...
+  if (threadIdx.x == 0) __hip_atomic_store(seq_h, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ... before this one goes out
 }
 
 int32_t rls_fetch_add(rls_ctx* ctx, const void* src_d, void* dst_pinned, size_t bytes) {
@@ -132,6 +132,19 @@ int32_t rls_fetch_wait(rls_ctx* ctx) {
   const unsigned seq = ++ctx->mb_seq;
   hipLaunchKernelGGL(mailbox_publish_kernel, dim3(1), dim3(64), 0, ctx->stream, A, ctx->mb_h, seq);
   RLS_HIP(ctx, hipGetLastError());
+  return rls_mailbox_wait(ctx, seq);
+}
+
+rls_mailbox_slot rls_mailbox_arm(rls_ctx* ctx, void* dst_pinned) {
+  rls_mailbox_slot mb;
+  if (ctx->tune.status_mailbox < 2) return mb;
+  mb.dst = dst_pinned;
+  mb.seq_h = ctx->mb_h;
+  mb.seq = ++ctx->mb_seq;
+  return mb;
+}
+
+int32_t rls_mailbox_wait(rls_ctx* ctx, unsigned seq) {
   volatile unsigned* p = ctx->mb_h;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned n = 0;; ++n) {

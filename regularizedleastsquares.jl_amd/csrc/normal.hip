@@ -676,7 +676,7 @@ __global__ __launch_bounds__(FIN_THREADS) void cgnr_pipe_f_kernel(E* __restrict_
                                                                const E* __restrict__ v,
                                                                const double* __restrict__ dots, int ndots,
                                                                cgnr_scalars* __restrict__ sc, int64_t N,
-                                                               pipe_rhs_ptrs R) {
+                                                               pipe_rhs_ptrs R, rls_mailbox_slot mb) {
   __shared__ double red[48];
   const int b = blockIdx.x;  // right-hand side
   sc += b;
@@ -689,7 +689,10 @@ __global__ __launch_bounds__(FIN_THREADS) void cgnr_pipe_f_kernel(E* __restrict_
   dots += (int64_t)b * 4 * ndots;
   const cgnr_scalars S = *sc;
   const int tid = threadIdx.x;
-  if (!S.pending && S.cur == 0) return;
+  if (!S.pending && S.cur == 0) {
+    if (tid < 64) rls_mailbox_publish(mb, S, tid);  // (single right-hand side plans only arm the slot)
+    return;
+  }
   const E* rc = S.cur ? r1 : r0;
   const E* pc = S.cur ? p1 : p0;
   E pv[EPT], rv[EPT], vv[EPT];
@@ -735,6 +738,7 @@ __global__ __launch_bounds__(FIN_THREADS) void cgnr_pipe_f_kernel(E* __restrict_
   Sn.fresh = 0;
   __syncthreads();
   if (tid == 0) *sc = Sn;
+  if (tid < 64) rls_mailbox_publish(mb, Sn, tid);
 }
 
 // v[j] = sum_w slab[w][j] in a fixed order: 16 columns per workgroup, 16 row groups per column
@@ -956,11 +960,14 @@ template <typename E, int EPT>
 __global__ __launch_bounds__(FIN_THREADS) void fista_pipe_f_kernel(E* b0, E* b1, const E* __restrict__ x0,
                                                                     E* __restrict__ res, E* y0, E* y1,
                                                                     const E* __restrict__ res_raw,
-                                                                    fista_scalars* __restrict__ sc, int64_t N) {
+                                                                    fista_scalars* __restrict__ sc, int64_t N, rls_mailbox_slot mb) {
   __shared__ double red[48];
   fista_scalars S;
   RLS_FISTA_COPY(S, *sc);
-  if (!S.pending || S.done) return;
+  if (!S.pending || S.done) {
+    if (threadIdx.x < 64) rls_mailbox_publish(mb, S, (int)threadIdx.x);
+    return;
+  }
   const int tid = threadIdx.x;
   const E* yc = S.ycur ? y1 : y0;
   const E* xc = (S.iteration & 1) ? b1 : b0;
@@ -993,6 +1000,7 @@ __global__ __launch_bounds__(FIN_THREADS) void fista_pipe_f_kernel(E* b0, E* b1,
   Sn.fresh = 0;
   __syncthreads();
   if (tid == 0) RLS_FISTA_COPY(*sc, Sn);
+  if (tid < 64) rls_mailbox_publish(mb, Sn, tid);
 }
 
 // ---- Gram-mode CGNR pipeline: ONE launch per iteration -----------------------------------------
@@ -2846,7 +2854,7 @@ static int32_t pipe_finish_typed(rls_ctx* ctx, const rls_cgnr_pipe& P) {
 #define RLS_FIN_CASE(EE)                                                                                         \
   hipLaunchKernelGGL((cgnr_pipe_f_kernel<E, EE>), dim3((unsigned)(P.nrhs > 0 ? P.nrhs : 1)), dim3(FIN_THREADS), 0, \
                      ctx->stream, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, P.dots, P.ndots, P.sc, \
-                     P.N, rhs_of(P, 0))
+                     P.N, rhs_of(P, 0), P.mb)
   if (ept <= 1) RLS_FIN_CASE(1);
   else if (ept <= 2) RLS_FIN_CASE(2);
   else RLS_FIN_CASE(4);
@@ -2898,7 +2906,7 @@ static int32_t fista_finish_typed(rls_ctx* ctx, const rls_fista_pipe& P) {
   const int ept = (int)((P.N + FIN_THREADS - 1) / FIN_THREADS);
 #define RLS_FFIN_CASE(EE)                                                                                        \
   hipLaunchKernelGGL((fista_pipe_f_kernel<E, EE>), dim3(1), dim3(FIN_THREADS), 0, ctx->stream, (E*)P.b0, (E*)P.b1, \
-                     (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (const E*)P.res_raw, P.sc, P.N)
+                     (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (const E*)P.res_raw, P.sc, P.N, P.mb)
   if (ept <= 1) RLS_FFIN_CASE(1);
   else if (ept <= 2) RLS_FFIN_CASE(2);
   else RLS_FFIN_CASE(4);

@@ -30,8 +30,9 @@ struct rls_tuning {
                           // ONE launch (normal.hip, cgnr_resident_kernel)
   int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
   int small = 1;               // 1: systems that fit ONE CU's registers run a whole step call as a single-workgroup launch (small.hip)
-  int status_mailbox = 1;      // 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
-                               // sequence word (rls_fetch_*); 0: hipMemcpyAsync + stream wait
+  int status_mailbox = 2;      // >= 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
+                               // sequence word (rls_fetch_*); 2: and rls_*_step_status has the call's LAST kernel do that
+                               // store where it can (rls_mailbox_slot); 0: hipMemcpyAsync + stream wait
   int resident_spin = 100000;  // bound of every in-kernel wait, in polls (~1 us each: a wall-clock bound of ~0.1 s per
                                // wait); a launch that runs into it is a no-op and the host re-runs its iterations on the
                                // per-iteration pipeline (solvers.hip, *_recover)
@@ -69,6 +70,40 @@ struct rls_ctx {
 // word, and spins on that word (bounded; falls back to a stream wait).  With tune.status_mailbox = 0: hipMemcpyAsync + wait.
 int32_t rls_fetch_add(rls_ctx* ctx, const void* src_d, void* dst_pinned, size_t bytes);
 int32_t rls_fetch_wait(rls_ctx* ctx);
+// The last kernel of a step call can publish the plan's scalars itself (one launch and one launch boundary less on the per-iterate
+// path): the host arms a slot -- where to store (the plan's pinned mirror), the context's sequence word and the value to put there --,
+// hands it to that kernel and waits for the sequence value.  dst == nullptr: not armed.
+struct rls_mailbox_slot {
+  void* dst = nullptr;
+  unsigned* seq_h = nullptr;
+  unsigned seq = 0;
+};
+rls_mailbox_slot rls_mailbox_arm(rls_ctx* ctx, void* dst_pinned);
+int32_t rls_mailbox_wait(rls_ctx* ctx, unsigned seq);
+#ifdef __HIPCC__
+// Orders this wave's system-scope (write-through, sc0 sc1) stores ahead of its next one: their acknowledgements are back.  A release
+// FENCE at system scope would also write back every dirty line of this XCD's L2 (buffer_wbl2) -- the vectors the kernel has just
+// written -- before the sequence word may go out: 2.5 us per status on the critical path for data the host does not read
+// (tools/bench_cadence.py: 27.0 -> 24.3 us per call at 256 x 128).  The mailbox payload itself never sits in L2 dirty: every dword of
+// it is a system-scope atomic store to fine-grained host memory.
+__device__ static inline void rls_system_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Called by ALL 64 lanes of ONE wave of the call's last kernel, behind its last update of the struct, every lane holding the same
+// v: lane i stores dword i into pinned host memory (system scope; ONE store instruction -- twenty single-lane stores are twenty
+// PCIe writes and cost 2.3 us more per status), then lane 0 -- behind their acknowledgements -- the sequence word.
+template <typename S>
+__device__ static inline void rls_mailbox_publish(const rls_mailbox_slot& mb, const S& v, int lane) {
+  constexpr unsigned ND = sizeof(S) / 4;
+  static_assert(sizeof(S) % 4 == 0 && ND <= 64, "status structs are published dword by dword by one wave");
+  if (!mb.dst) return;
+  const unsigned* src = reinterpret_cast<const unsigned*>(&v);
+  unsigned mine = 0;
+#pragma unroll
+  for (unsigned i = 0; i < ND; ++i) mine = lane == (int)i ? src[i] : mine;
+  if (lane < (int)ND) __hip_atomic_store(reinterpret_cast<unsigned*>(mb.dst) + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  rls_system_stores_done();
+  if (lane == 0) __hip_atomic_store(mb.seq_h, mb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 
 // ---- memory ------------------------------------------------------------------------------------------------------------
 // Device memory of the library (plan scratch, rls_malloc) is STREAM-ORDERED on the context's stream: hipMallocAsync /
@@ -605,6 +640,7 @@ struct rls_fista_pipe {
   fista_scalars *sc, *scn;
   int par_hint = -1;    // parity of the iteration count (= which y / x buffer is current) at this launch, or -1;
                         // a hint checked on the device, like rls_cgnr_pipe::cur_hint
+  rls_mailbox_slot mb;  // as rls_cgnr_pipe::mb
 };
 int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
 int32_t rls_fista_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
@@ -625,6 +661,7 @@ struct rls_cgnr_pipe {
   // each launch with a pending update flips it); -1 = unknown: the kernel then loads both candidates.  A hint
   // only: the kernel checks it against the device scalars and re-loads if it is wrong.
   int cur_hint = -1;
+  rls_mailbox_slot mb;  // armed: the finish kernel publishes the scalars to the host itself (rls_cgnr_step_status)
 };
 int32_t rls_cgnr_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
 int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P);
@@ -782,6 +819,7 @@ struct rls_small {
   int64_t lda, M, N;
   void *x, *r, *p, *v;
   cgnr_scalars* sc;
+  rls_mailbox_slot mb;  // as rls_cgnr_pipe::mb
 };
 bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps);

@@ -44,7 +44,7 @@ __device__ static inline E shfl_xor_e(E v, int m) {
 
 template <typename E, int R, int C>
 __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* x, E* r, E* p, E* v,
-                                                           cgnr_scalars* sc, int n_steps) {
+                                                           cgnr_scalars* sc, int n_steps, rls_mailbox_slot mb) {
   constexpr int NP = 16 * C;              // padded vector length
   constexpr int EPT = (NP + 63) / 64;     // vector elements per lane of wave 0
   __shared__ E ps[NP];                    // p, zero beyond N
@@ -184,6 +184,8 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__
       sc->iteration = S.iteration; sc->done = S.done;
       sc->pending = 0; sc->cur = 0; sc->fresh = 0;
     }
+    S.pending = 0; S.cur = 0; S.fresh = 0;
+    rls_mailbox_publish(mb, S, lane);
   }
 }
 
@@ -208,7 +210,7 @@ static bool small_pick(int64_t M, int64_t N, small_tile* t) {
 template <typename E, int R, int C>
 static void small_launch(rls_ctx* ctx, const rls_small& D, int n_steps) {
   hipLaunchKernelGGL((cgnr_small_kernel<E, R, C>), dim3(1), dim3(SM_NT), 0, ctx->stream, (const E*)D.A, D.lda, (int)D.M, (int)D.N, (E*)D.x,
-                     (E*)D.r, (E*)D.p, (E*)D.v, D.sc, n_steps);
+                     (E*)D.r, (E*)D.p, (E*)D.v, D.sc, n_steps, D.mb);
 }
 
 template <typename E>

@@ -162,6 +162,8 @@ struct rls_cgnr {
   double* rdots;
   unsigned* rsync_h;  // pinned: {fail, completed, failed} (resident_sync), read with the status
   bool resident_used;
+  rls_mailbox_slot mb_arm;  // step_status: the call's last kernel publishes the scalars (pipeline and small-system paths)
+  bool mb_sent = false;     // ... and this call's path did take the slot
   bool gram_resident;  // Gram mode: AHA fits the register files (rls_gram_resident_ok)
   // a resident launch whose workgroups were not all on the chip in time is a no-op (normal.hip); the status call re-runs
   // what was lost on the per-iteration pipeline and the plan stays there
@@ -621,6 +623,8 @@ struct rls_fista {
   void* rsync = nullptr;
   unsigned* rsync_h = nullptr;
   bool resident_used = false;
+  rls_mailbox_slot mb_arm;    // as the cgnr plan's
+  bool mb_sent = false;
   bool resident_off = false;  // a resident launch was lost: the plan stays on the per-iteration pipeline (cgnr plan, above)
   int fallbacks = 0;
   long long requested = 0;    // iterations asked for since init
@@ -2206,6 +2210,7 @@ int32_t rls_cgnr_init_batched(rls_cgnr* s, const void* B, int64_t ldb, float lam
 }
 
 static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps);
+static void cgnr_status_out(const rls_cgnr* s, const cgnr_scalars& h, rls_cgnr_status* out);
 int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
@@ -2230,6 +2235,7 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
       RLS_TRY(rls_fetch_wait(ctx));
     }
   }
+  s->resident_used = false;
   for (int b = 0; b < s->nrhs; ++b) {
     const cgnr_scalars& h = s->sc_h[b];
     out[b].iteration = h.iteration;
@@ -2260,6 +2266,8 @@ static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps) {
     D.p = s->p;
     D.v = s->v;
     D.sc = s->sc;
+    D.mb = s->mb_arm;
+    s->mb_sent = s->mb_arm.dst != nullptr;
     return rls_small_launch(ctx, s->op->dtype, D, n_steps);
   }
   if (s->skinny && cgnr_use_gramk(s, n_steps)) {
@@ -2337,6 +2345,10 @@ static int32_t cgnr_step_impl(rls_cgnr* s, int32_t n_steps) {
       P.cur_hint = pipe_cur_hint(ctx, k++);
       return rls_cgnr_pipe_iteration(ctx, dtype, P);
     }, [&k](int c) { k -= c; }));
+    if (s->nrhs == 1) {
+      P.mb = s->mb_arm;
+      s->mb_sent = s->mb_arm.dst != nullptr;
+    }
     return rls_cgnr_pipe_finish(ctx, dtype, P);
   }
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched CGNR: fused pipeline switched off");
@@ -2509,6 +2521,7 @@ static int32_t cgnr_fetch_status(rls_cgnr* s) {
       RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
     }
   }
+  s->resident_used = false;  // every resident launch up to here is accounted for (the lost count is sticky until it is read)
   return 0;
 }
 
@@ -2518,7 +2531,11 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
   RLS_HIP(ctx, hipSetDevice(ctx->device));
   RLS_TRY(cgnr_fetch_status(s));
-  const cgnr_scalars& h = *s->sc_h;
+  cgnr_status_out(s, *s->sc_h, out);
+  return 0;
+}
+
+static void cgnr_status_out(const rls_cgnr* s, const cgnr_scalars& h, rls_cgnr_status* out) {
   out->iteration = h.iteration;
   out->done = h.done;
   out->alpha_re = (float)h.alpha_re;
@@ -2529,12 +2546,27 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
   out->residual = (float)sqrt(h.rr);
   out->z0 = (float)h.z0;
   out->fallbacks = s->fallbacks;
-  return 0;
 }
 
+// One iterate per call is the reference's solve! loop with callbacks (src/RegularizedLeastSquares.jl:161-176): step and read-back
+// as ONE entry point, and on the per-iteration pipeline and the small-system kernel the call's last kernel stores the scalars into
+// the plan's pinned mirror itself -- no publishing launch behind it.
 int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out) {
-  RLS_TRY(rls_cgnr_step(s, n_steps));
-  return rls_cgnr_get_status(s, out);
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (s->initialised && s->nrhs == 1 && n_steps > 0 && !s->resident_used) {
+    RLS_HIP(ctx, hipSetDevice(ctx->device));
+    s->mb_arm = rls_mailbox_arm(ctx, s->sc_h);
+  }
+  s->mb_sent = false;
+  const int32_t st = rls_cgnr_step(s, n_steps);
+  const rls_mailbox_slot mb = s->mb_arm;
+  s->mb_arm = rls_mailbox_slot();
+  if (st != 0) return st;
+  if (!s->mb_sent) return rls_cgnr_get_status(s, out);
+  RLS_TRY(rls_mailbox_wait(ctx, mb.seq));
+  cgnr_status_out(s, *s->sc_h, out);
+  return 0;
 }
 
 // ---- FISTA ----------------------------------------------------------------------------------
@@ -2930,6 +2962,8 @@ static int32_t fista_step_impl(rls_fista* s, int32_t n_steps) {
       return rls_fista_pipe_iteration(ctx, dtype, P);
     }, [&k](int c) { k -= c; }));
     s->enq += n_steps;
+    P.mb = s->mb_arm;
+    s->mb_sent = s->mb_arm.dst != nullptr;
     return rls_fista_pipe_finish(ctx, dtype, P);
   }
   return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_iteration(s); });
@@ -2965,6 +2999,7 @@ static int32_t fista_fetch_status(rls_fista* s) {
       RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
     }
   }
+  s->resident_used = false;
   return 0;
 }
 
@@ -2974,13 +3009,7 @@ int32_t rls_fista_path(rls_fista* s, int32_t* out) {
   return 0;
 }
 
-int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
-  if (!s || !out) return RLS_E_INVALID;
-  rls_ctx* ctx = s->op->ctx;
-  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_get_status before fista_init");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
-  RLS_TRY(fista_fetch_status(s));
-  const fista_scalars& h = *s->sc_h;
+static void fista_status_out(const rls_fista* s, const fista_scalars& h, rls_fista_status* out) {
   out->iteration = h.iteration;
   out->done = h.done;
   out->theta = h.theta;
@@ -2989,12 +3018,34 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
   out->residual = (float)h.res_norm;
   out->norm_x0 = (float)h.norm_x0;
   out->fallbacks = s->fallbacks;
+}
+
+int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_get_status before fista_init");
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_TRY(fista_fetch_status(s));
+  fista_status_out(s, *s->sc_h, out);
   return 0;
 }
 
-int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out) {
-  RLS_TRY(rls_fista_step(s, n_steps));
-  return rls_fista_get_status(s, out);
+int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out) {  // as rls_cgnr_step_status
+  if (!s || !out) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (s->initialised && s->nrhs == 1 && n_steps > 0 && !s->resident_used) {
+    RLS_HIP(ctx, hipSetDevice(ctx->device));
+    s->mb_arm = rls_mailbox_arm(ctx, s->sc_h);
+  }
+  s->mb_sent = false;
+  const int32_t st = rls_fista_step(s, n_steps);
+  const rls_mailbox_slot mb = s->mb_arm;
+  s->mb_arm = rls_mailbox_slot();
+  if (st != 0) return st;
+  if (!s->mb_sent) return rls_fista_get_status(s, out);
+  RLS_TRY(rls_mailbox_wait(ctx, mb.seq));
+  fista_status_out(s, *s->sc_h, out);
+  return 0;
 }
 
 int32_t rls_fista_solution(rls_fista* s, void** x_out) {

@@ -436,6 +436,38 @@ def test_cgnr_callbacks_cadence_and_lstsq(rls, ctx):
     assert rel(xs, xl) < 1e-4
 
 
+@pytest.mark.parametrize("solver,dt,M,N", [("cgnr", np.complex64, 1024, 512), ("cgnr", np.float32, 256, 128), ("cgnr", np.complex64, 32, 16),
+                                           ("fista", np.complex64, 1024, 512), ("fista", np.float32, 300, 120)])
+def test_step_status_published_by_the_last_kernel(rls, ctx, solver, dt, M, N):
+    """One iterate per call (the reference's solve! loop, src/RegularizedLeastSquares.jl:161-176): rls_*_step_status has the
+    call's last kernel store the scalars into pinned host memory.  The stream of statuses -- through the stopping test and for
+    calls after it -- is the one step + get_status gives with the mailbox switched off (hipMemcpyAsync), field for field."""
+    A, xt, b = O.make_problem(M, N, dt, 9)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    A64 = A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
+    rho = float(0.9 / np.linalg.norm(A64, 2) ** 2)
+    streams = []
+    try:
+        for mb in (2, 1, 0):
+            ctx.tune(status_mailbox=mb)
+            if solver == "cgnr":
+                S = rls.createLinearSolver(rls.CGNR, Ad, iterations=24, relTol=1e-4)
+            else:
+                S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=24, relTol=1e-3)
+            rls.init_(S, bd)
+            rec = []
+            for _ in range(28):  # past `done`: the finish kernel's nothing-to-apply path publishes too
+                st = S.state._step_status(ctx.lib, 1)
+                rec.append(tuple(getattr(st, f) for f, _ in st._fields_))
+            assert rec[-1][1] == 1 and rec[-1][0] <= 24  # done, and the count stopped
+            streams.append((rec, rls.solversolution(S).to_host().copy()))
+    finally:
+        ctx.tune(status_mailbox=2)
+    assert streams[0][0] == streams[1][0] == streams[2][0]
+    assert np.array_equal(streams[0][1], streams[1][1]) and np.array_equal(streams[0][1], streams[2][1])
+    assert 1 < streams[0][0][-1][0]
+
+
 def test_cgnr_reltol_stops_early_and_constraints(rls, ctx):
     A, xt, b = O.make_problem(128, 64, np.complex64, 6)
     ref = O.CGNR(A, reg=[O.PositiveRegularization()], iterations=64, relTol=1e-3)

@@ -30,7 +30,20 @@ def cadence(make, step_status, status_t, n_it):
     assert st_.iteration == n_it, (st_.iteration, n_it)
     return 1e6 * best / n_it
 
-for mb in (1, 0):
+# the floor of a one-kernel call: BASELINE configs[0] (256 x 128 Float32) on the small-system kernel (one launch, ~2 us of work)
+from bench import make_A as _mk
+As = np.asfortranarray(np.random.default_rng(5).standard_normal((256, 128)).astype(np.float32))
+Asd = rls.DeviceMatrix.from_host(As, ctx)
+bs = rls.DeviceVector.from_host((As @ np.random.default_rng(6).standard_normal(128).astype(np.float32)).astype(np.float32), ctx)
+_b = b
+for mb in (2, 1, 0):
+    ctx.tune(status_mailbox=mb)
+    b = bs
+    c = cadence(lambda: rls.createLinearSolver(rls.CGNR, Asd, iterations=32, relTol=0.0),
+                lambda p, st_: L.check(h, lib.rls_cgnr_step_status(p, 1, C.byref(st_)), "cgnr"), L.CgnrStatus, 32)
+    print(f"status_mailbox={mb}: CGNR 256 x 128 Float32 (single-workgroup kernel) {c:6.1f} us per iterate call", flush=True)
+b = _b
+for mb in (2, 1, 0):
     ctx.tune(status_mailbox=mb)
     c = cadence(lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0),
                 lambda p, st_: L.check(h, lib.rls_cgnr_step_status(p, 1, C.byref(st_)), "cgnr"), L.CgnrStatus, 32)
