@@ -593,6 +593,7 @@ def main():
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=2048)
     ap.add_argument("--rhs-per-gpu", type=int, default=8)
+    ap.add_argument("--config4-gram", action="store_true", help="--workload config4 on the explicit Gram matrix (the reference's default operator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--resident", type=int, default=1, help="0: force the two-launch pipeline for the headline run")
@@ -707,8 +708,10 @@ def main():
         barrier()
         return float(tt.item())
 
-    def config4_measure(K, W):
+    def config4_measure(K, W, gram=False):
         # ---- BASELINE configs[3]: shared A (seed 4), B = A X (X: seed 5, 64 columns), columns 8k..8k+7 on GPU k ----
+        # gram: the operator the reference constructor builds for a dense matrix (AHA = A' * A explicit, src/CGNR.jl:49), shared
+        # by the columns (src/MultiThreading.jl:30-48); the Gram GEMM is setup, outside the timed region, and reported
         R = args.rhs_per_gpu
         A = make_A(M, N, seed=4)
         rng = np.random.default_rng(5)
@@ -717,7 +720,13 @@ def main():
         B = np.asfortranarray((A @ X[:, cols]).astype(dt))
         Ad = rls.DeviceMatrix.from_host(A, ctx)
         Bd = rls.DeviceMatrix.from_host(B, ctx)
-        solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
+        setup_ms = None
+        if gram:
+            Ad.gram(); ctx.sync()
+            t0 = time.perf_counter(); Gd = Ad.gram(); ctx.sync(); setup_ms = 1e3 * (time.perf_counter() - t0)
+            solver = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, iterations=SEGMENT, relTol=0.0)
+        else:
+            solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
         rls.solve_(solver, Bd, scheduler=rls.BatchedState)  # builds the batched plan (and checks it runs)
         st = solver.state
         assert isinstance(st, rls.BatchedState), "config 4 needs the shared-A batched plan"
@@ -767,15 +776,27 @@ def main():
         # number of right-hand sides) against 16*M*N*R flops on the f32 matrix cores -- 8 right-hand sides are 8 flop/B,
         # under the ~20 flop/B ridge, i.e. bandwidth-bound; from ~20 right-hand sides on the MFMA rate binds
         bytes_iter = 2.0 * M * N * 8
-        t_hbm, t_mfma = bytes_iter / (HBM_PEAK_GBS * 1e9), flops_iter / (MFMA_F32_PEAK_TF * 1e12)
         kern = "skinny_t_kernel + skinny_v_kernel (T = A P, V = A^H T on v_mfma_f32_16x16x4_f32) + per-column update"
+        if gram:
+            pth = C.c_int32(-1)
+            lib.rls_cgnr_path(st._plan, C.byref(pth))
+            flops_iter = 8.0 * N * N * R   # one product over the N x N matrix
+            bytes_iter = 1.0 * N * N * 8   # AHA once per batched iteration (the streaming form reads it; the resident form holds it
+                                           # in registers and moves only the N x R panel -- priced on the same basis)
+            kern = ("cgnr_gramk_resident_kernel (AHA in registers, one launch per step call)" if pth.value == 7 else
+                    "skinny_t_kernel<VOUT> (V = AHA P, one product) + per-column update")
+            out["config"]["operator"] = "AHA = A' * A explicit (the reference constructor's default), shared by the columns"
+            out["config"]["path"] = pth.value
+            out["setup_gram_gemm_ms"] = setup_ms
+        t_hbm, t_mfma = bytes_iter / (HBM_PEAK_GBS * 1e9), flops_iter / (MFMA_F32_PEAK_TF * 1e12)
         mf = {"achieved": flops_iter / us_iter / 1e6, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops_iter / us_iter / 1e6 / MFMA_F32_PEAK_TF}
         hb = {"achieved": bytes_iter / us_iter / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_iter / us_iter / 1e3 / HBM_PEAK_GBS}
         out["roofline"] = dict(bound="hbm" if t_hbm >= t_mfma else "mfma", kernel=kern, **(hb if t_hbm >= t_mfma else mf), traffic=None,
                                us_per_batched_iteration=us_iter, other_roof=(mf if t_hbm >= t_mfma else hb),
-                               note="hbm basis: A streamed twice per batched iteration (2*M*N*s bytes, shared by the right-hand sides; it "
-                                    "comes out of the Infinity Cache, so the memory-side counters see less); mfma basis: 16*M*N flops per "
-                                    "solve-iteration (complex MAC = 8 flops, two products), padding columns not counted")
+                               note=("hbm basis: AHA once per batched iteration (N*N*s bytes); mfma basis: 8*N*N flops per solve-iteration" if gram else
+                                     "hbm basis: A streamed twice per batched iteration (2*M*N*s bytes, shared by the right-hand sides; it "
+                                     "comes out of the Infinity Cache, so the memory-side counters see less); mfma basis: 16*M*N flops per "
+                                     "solve-iteration (complex MAC = 8 flops, two products), padding columns not counted"))
         n1 = solo_rate(init, lambda: step(K, True), R * K)
         if n1 is not None:
             out["n1_same_workload_value"] = n1
@@ -783,7 +804,7 @@ def main():
         return out
 
     if workload == "config4":
-        return finish(config4_measure(K, W))
+        return finish(config4_measure(K, W, gram=args.config4_gram))
 
     # ---- headline: one CGNR solve per GPU, data resident in HBM before the timed region ---------------------------
     A = make_A(M, N, seed=2 if world == 1 else 100 + rank)
@@ -904,6 +925,15 @@ def main():
         c4 = {k: c4_full[k] for k in ("metric", "value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
                                       "per_rank_solve_iterations_per_s_hip_events") if k in c4_full}
         c4["roofline"] = {k: c4_full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
+        try:  # the same job on the reference constructor's default operator (explicit AHA)
+            g4 = config4_measure(max(SEGMENT, min(K, 20 * SEGMENT)), SEGMENT, gram=True)
+            c4["gram_mode"] = {k: g4[k] for k in ("value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
+                                                  "per_rank_solve_iterations_per_s_hip_events", "setup_gram_gemm_ms") if k in g4}
+            c4["gram_mode"]["operator"] = g4["config"]["operator"]
+            c4["gram_mode"]["path"] = g4["config"]["path"]
+            c4["gram_mode"]["roofline"] = {k: g4["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
+        except Exception as e:  # noqa: BLE001 -- an extra block must not lose the line
+            c4["gram_mode"] = {"error": repr(e)}
     c5 = None
     if world > 1:
         # BASELINE configs[4] on the same job: the 65536 x 8192 problem row-partitioned over the ranks, one all-reduce of
