@@ -233,6 +233,15 @@ int32_t rls_pgm_lost(rls_pgm* plan, int32_t* lost, int32_t* fallbacks_total);
 int32_t rls_pogm_update_auto(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, const void* x0, void* xbuf, void* ybuf,
                              void* xold, void* z, void* w, float rho, float lambda, float sigma_fac, int32_t iterations,
                              int32_t reg_kind, int32_t proj_kind, float norm_x0, float rel_tol, void* state_d);
+/* The same as resident launches of a rls_pgm plan (A in the register files, n_steps <= any count per launch: the coefficients
+ * are formed in the kernel from the record's theta, sigma, gamma, so no table travels): xbuf / ybuf swap roles once per
+ * iteration run as in rls_pgm_step_resident (kind 1); w is loop-carried beside x, y, z.  `iterations` = the solve's iteration
+ * count MINUS the count the record started from (the last iteration's theta rule, src/POGM.jl:185, compares the record's
+ * count); first_iteration, lost launches and RLS_E_UNSUPPORTED as for rls_pgm_step_resident. */
+int32_t rls_pogm_step_resident_restart(rls_pgm* plan, int32_t n_steps, int32_t first_iteration, float rho, float lambda, float sigma_fac,
+                                       int32_t iterations, void* xbuf, void* ybuf, void* z, void* w, void* xold, void* res,
+                                       const void* x0, int32_t reg_kind, int32_t proj_kind, float norm_x0, float rel_tol,
+                                       void* state_d);
 /* At = transpose(A) (no conjugation): N x M column-major, leading dimension ldat >= N.  Row k of A becomes the
  * contiguous column k of At -- the "structure for row access" that the reference's row-action solvers ask for
  * (createLinearSolver(Kaczmarz, transpose(A_T)), src/Kaczmarz.jl:391, dot_with_matrix_row(::Transpose…)

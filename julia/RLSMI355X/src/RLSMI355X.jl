@@ -395,6 +395,29 @@ function pgm_step_resident!(plan::PgmPlan, kind::Integer, coefs::Matrix{Float32}
   true
 end
 
+"""
+    pogm_step_resident_restart!(plan, n_steps, first_iteration, rho, lambda, sigma_fac, iterations, xbuf, ybuf, z, w, xold, res, x0,
+                                reg_kind, proj_kind, norm_x0, rel_tol, state) -> Bool
+
+POGM with `restart = :gradient` as ONE launch of `n_steps` iterations: theta, sigma, gamma live in the 8-word device record
+`state` and the kernel forms every iteration's coefficients from them (src/POGM.jl:183-232).  `iterations` = the solve's
+iteration count minus the count the record started from.  Returns false when the plan has retired.
+"""
+function pogm_step_resident_restart!(plan::PgmPlan, n_steps::Integer, first_iteration::Integer, rho::Real, lambda::Real, sigma_fac::Real,
+                                     iterations::Integer, xbuf::RLSVector{T}, ybuf::RLSVector{T}, z::RLSVector{T}, w::RLSVector{T},
+                                     xold::RLSVector{T}, res::RLSVector{T}, x0::RLSVector{T}, reg_kind::Integer, proj_kind::Integer,
+                                     norm_x0::Real, rel_tol::Real, state::RLSVector{Float32}) where {T}
+  st = ccall((:rls_pogm_step_resident_restart, librls[]), Int32,
+             (Ptr{Cvoid}, Int32, Int32, Float32, Float32, Float32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+              Ptr{Cvoid}, Int32, Int32, Float32, Float32, Ptr{Cvoid}),
+             plan.handle, Int32(n_steps), Int32(first_iteration), Float32(rho), Float32(lambda), Float32(sigma_fac), Int32(iterations),
+             xbuf.ptr, ybuf.ptr, z.ptr, w.ptr, xold.ptr, res.ptr, x0.ptr, Int32(reg_kind), Int32(proj_kind), Float32(norm_x0),
+             Float32(rel_tol), state.ptr)
+  st == Int32(-2) && return false
+  check(plan.ctx, st, "rls_pogm_step_resident_restart")
+  true
+end
+
 "launches of the sequence that gave up (they changed nothing); synchronises"
 function pgm_lost(plan::PgmPlan)
   lost = Ref{Int32}(0); total = Ref{Int32}(0)

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "rls_pgm_step_resident": (_i32, [_vp, _i32, _i32, _i32, _pf, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _f, _vp]),
     "rls_pgm_lost": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "rls_pogm_update_auto": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i32, _i32, _i32, _f, _f, _vp]),
+    "rls_pogm_step_resident_restart": (_i32, [_vp, _i32, _i32, _f, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _f, _vp]),
     "rls_operator_mul_normal_skip": (_i32, [_vp, _vp, _vp, _vp]),
     "rls_transpose": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _i64]),
     "rls_kaczmarz_sweep": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32,

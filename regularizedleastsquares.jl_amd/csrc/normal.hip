@@ -2442,7 +2442,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
 // POGM swaps its x / y references every iteration (:203): the launch leaves the operator input of the NEXT iteration in the
 // buffer the host's reference `x` points to after as many swaps as iterations ran.
 template <typename E, int G, int K, int WV, int BAR, bool FULL, int KIND>
-__global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1, E* b2, E* o0,
+__global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1, E* b2, E* b3, E* o0,
                                                                 E* res, const E* __restrict__ x0, E* raw_g, E* slab,
                                                                 pgm_state* st, rls_pgm_coefs CF, float norm_x0, float rel_tol,
                                                                 int reg_kind, int proj_kind, resident_sync* sync, int64_t Mc,
@@ -2459,14 +2459,26 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
   int done = st->done;
   float res_norm = st->res_norm;
   E xv[EPT], yv[EPT], zv[EPT];
+  E wv[KIND == 2 ? EPT : 1];  // POGM's w (gradient restart), loop-carried like x, y, z
+  // KIND 2: theta, sigma, gamma of src/POGM.jl:183-232 are loop-carried uniform scalars (the record's words 4..7)
+  float theta = 1.f, theta_old = 1.f, sigma = 1.f, gamma = 1.f;
+  if constexpr (KIND == 2) {
+    const pogm_auto_state* ast = reinterpret_cast<const pogm_auto_state*>(st);
+    theta = ast->theta;
+    theta_old = ast->theta_old;
+    sigma = ast->sigma;
+    gamma = ast->gamma;
+  }
   if constexpr (FULL) {
     load_owned_wide<E, EPT, NT>(xv, b0, tid);
     load_owned_wide<E, EPT, NT>(yv, b1, tid);
     load_owned_wide<E, EPT, NT>(zv, b2, tid);
+    if constexpr (KIND == 2) load_owned_wide<E, EPT, NT>(wv, b3, tid);
   } else {
     load_owned_wide_masked<E, EPT, NT>(xv, b0, tid, N);
     load_owned_wide_masked<E, EPT, NT>(yv, b1, tid, N);
     load_owned_wide_masked<E, EPT, NT>(zv, b2, tid, N);
+    if constexpr (KIND == 2) load_owned_wide_masked<E, EPT, NT>(wv, b3, tid, N);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -2497,18 +2509,44 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
     owner_products<E, G, K, WV, FULL>(a, xv, R.ored, slab_rs, N);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    E x0v[EPT];  // requested here, consumed behind the exchange
-    if constexpr (FULL) load_owned_wide<E, EPT, NT>(x0v, x0, tid);
-    else load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
+    // x0: requested here, consumed behind the exchange -- except in the masked restart instantiation, which has no registers
+    // to hold it across the exchange (12 B per lane of scratch otherwise) and asks for it afterwards
+    constexpr bool X0_LATE = KIND == 2 && !FULL;
+    E x0v[EPT];
+    if constexpr (!X0_LATE) {
+      if constexpr (FULL) load_owned_wide<E, EPT, NT>(x0v, x0, tid);
+      else load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
+    }
     E raw[EPT];
     if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
       alive = false;
       break;
     }
-    const float c0 = CF.c[it][0], c1 = CF.c[it][1], c2 = CF.c[it][2], c3 = CF.c[it][3], c4 = CF.c[it][4], c5 = CF.c[it][5],
-                c6 = CF.c[it][6];
+    if constexpr (X0_LATE) load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
+    float c0, c1, c2, c3, c4, c5, c6 = 0.f, rg = 0.f, th = 1.f, gamma_n = 1.f;
+    if constexpr (KIND == 2) {
+      // the coefficients of this iteration from theta, sigma, gamma: Float32, one rounding per operation, the host's order
+      // (pogm_auto_kernel, pgm.hip; src/POGM.jl:183-201)
+      const float rho = CF.c[0][0], lam = CF.c[0][1];
+      const bool last = iteration == (int)CF.c[0][3] - 1;
+      const float t2 = f32_mul(f32_mul(last ? 8.f : 4.f, theta), theta);
+      th = f32_add(1.f, sqrtf(f32_add(1.f, t2))) / 2.f;
+      const float alpha = f32_sub(theta, 1.f) / th;
+      const float beta = f32_mul(sigma, theta) / th;
+      c3 = f32_add(f32_add(1.f, alpha), beta);
+      gamma_n = f32_mul(rho, c3);
+      c5 = f32_mul(rho, alpha) / gamma;
+      c4 = -f32_add(beta, c5);
+      c1 = f32_mul(gamma_n, lam);
+      c2 = -alpha;
+      c0 = rho;
+      rg = rho / gamma_n;
+    } else {
+      c0 = CF.c[it][0]; c1 = CF.c[it][1]; c2 = CF.c[it][2]; c3 = CF.c[it][3]; c4 = CF.c[it][4]; c5 = CF.c[it][5];
+      c6 = CF.c[it][6];
+    }
     E ri[EPT], ov[EPT];
-    double rn = 0.0;
+    double rn = 0.0, dwx = 0.0, dwz = 0.0, dwr = 0.0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int64_t i = own_index<E, EPT, NT, true>(tid, e);
@@ -2543,6 +2581,16 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
         zv[e] = zn;
         yv[e] = y1;   // the gradient point: the reference's y after its swap
         xv[e] = xn;   // the next operator input
+        if constexpr (KIND == 2) {  // gradient restart, src/POGM.jl:218-232 (pogm_update_body<E, true>, pgm.hip)
+          E wi = elem<E>::add(wv[e], y1);
+          wi = elem<E>::add(wi, elem<E>::scale(rg, xn));
+          wi = elem<E>::add(wi, elem<E>::scale(-rg, zn));
+          dwx += (double)elem<E>::re(wi) * (double)elem<E>::re(xn) + (double)elem<E>::im(wi) * (double)elem<E>::im(xn);
+          dwz += (double)elem<E>::re(wi) * (double)elem<E>::re(zn) + (double)elem<E>::im(wi) * (double)elem<E>::im(zn);
+          dwr += (double)elem<E>::re(wi) * (double)elem<E>::re(r) + (double)elem<E>::im(wi) * (double)elem<E>::im(r);
+          const E wn = elem<E>::add(elem<E>::scale(rg, zn), elem<E>::scale(-rg, xn));
+          wv[e] = elem<E>::sub(wn, y1);
+        }
       }
     }
     if (blockIdx.x == 0) {
@@ -2551,6 +2599,15 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
     }
     rn = block_sum_nolead<NT / 64>(rn, R.L.red);
     res_norm = uni((float)sqrt(rn));
+    if constexpr (KIND == 2) {
+      block_sum3(dwx, dwz, dwr, R.L.red);
+      const float crit = f32_sub(f32_sub((float)dwx, (float)dwz) / gamma_n, (float)dwr);   // :224
+      const bool restart = crit < 0.f;
+      theta_old = theta;
+      theta = uni(restart ? 1.f : th);
+      sigma = uni(restart ? 1.f : f32_mul(sigma, CF.c[0][2]));
+      gamma = uni(gamma_n);
+    }
     iteration += 1;
     ran += 1;
     done = uni((int)(((double)res_norm / (double)norm_x0) < (double)rel_tol));
@@ -2562,12 +2619,20 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
   }
   if (blockIdx.x == 0) {
     // POGM: an odd number of iterations leaves the roles of the two buffers swapped (the host swaps its references as often)
-    E* xd = (KIND == 1 && (ran & 1)) ? b1 : b0;
-    E* yd = (KIND == 1 && (ran & 1)) ? b0 : b1;
+    E* xd = (KIND >= 1 && (ran & 1)) ? b1 : b0;
+    E* yd = (KIND >= 1 && (ran & 1)) ? b0 : b1;
     store_buf(__builtin_amdgcn_make_buffer_rsrc(xd, 0, 0xffffffff, 0x00020000), xv);
     store_buf(__builtin_amdgcn_make_buffer_rsrc(yd, 0, 0xffffffff, 0x00020000), yv);
     store_buf(__builtin_amdgcn_make_buffer_rsrc(b2, 0, 0xffffffff, 0x00020000), zv);
+    if constexpr (KIND == 2) store_buf(__builtin_amdgcn_make_buffer_rsrc(b3, 0, 0xffffffff, 0x00020000), wv);
     if (tid == 0) {
+      if constexpr (KIND == 2) {
+        pogm_auto_state* ast = reinterpret_cast<pogm_auto_state*>(st);
+        ast->theta = theta;
+        ast->theta_old = theta_old;
+        ast->sigma = sigma;
+        ast->gamma = gamma;
+      }
       st->iteration = iteration;
       st->done = done;
       st->res_norm = res_norm;
@@ -3242,19 +3307,23 @@ static int32_t launch_pgm_resident(rls_ctx* ctx, const rls_pgm_desc& D, const rl
 #define RLS_PGM_ATTR(BB, FF, KK2) allow_big_lds(&pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>, lds);
       RLS_PGM_ATTR(1, true, 0) RLS_PGM_ATTR(2, true, 0) RLS_PGM_ATTR(1, false, 0) RLS_PGM_ATTR(2, false, 0)
       RLS_PGM_ATTR(1, true, 1) RLS_PGM_ATTR(2, true, 1) RLS_PGM_ATTR(1, false, 1) RLS_PGM_ATTR(2, false, 1)
+      RLS_PGM_ATTR(1, true, 2) RLS_PGM_ATTR(2, true, 2) RLS_PGM_ATTR(1, false, 2) RLS_PGM_ATTR(2, false, 2)
 #undef RLS_PGM_ATTR
     }
 #define RLS_LAUNCH_PGM(BB, FF, KK2)                                                                                              \
   hipLaunchKernelGGL((pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)D.A,    \
-                     D.lda, (E*)D.v0, (E*)D.v1, (E*)D.v2, (E*)D.o0, (E*)D.res, (const E*)D.x0, (E*)D.raw, (E*)D.slab, D.st, CF,  \
+                     D.lda, (E*)D.v0, (E*)D.v1, (E*)D.v2, (E*)D.v3, (E*)D.o0, (E*)D.res, (const E*)D.x0, (E*)D.raw, (E*)D.slab, D.st, CF,  \
                      D.norm_x0, D.rel_tol, D.reg_kind, D.proj_kind, (resident_sync*)sync, Mc, D.N, pair, n_steps, D.first_it, spin_limit)
     const bool two = resident_two_level_ok<E>(nwg, D.N, C::NT);
     if (D.kind == 0) {
       if (two) { if (full) RLS_LAUNCH_PGM(2, true, 0); else RLS_LAUNCH_PGM(2, false, 0); }
       else { if (full) RLS_LAUNCH_PGM(1, true, 0); else RLS_LAUNCH_PGM(1, false, 0); }
-    } else {
+    } else if (D.kind == 1) {
       if (two) { if (full) RLS_LAUNCH_PGM(2, true, 1); else RLS_LAUNCH_PGM(2, false, 1); }
       else { if (full) RLS_LAUNCH_PGM(1, true, 1); else RLS_LAUNCH_PGM(1, false, 1); }
+    } else {
+      if (two) { if (full) RLS_LAUNCH_PGM(2, true, 2); else RLS_LAUNCH_PGM(2, false, 2); }
+      else { if (full) RLS_LAUNCH_PGM(1, true, 2); else RLS_LAUNCH_PGM(1, false, 2); }
     }
 #undef RLS_LAUNCH_PGM
     return launch_status(ctx);

@@ -126,11 +126,7 @@ __global__ __launch_bounds__(PGM_THREADS) void pogm_update_kernel(E* __restrict_
 // iteration (src/POGM.jl:183-201) are formed HERE from them, in Float32 with the host's operation order (explicit
 // round-to-nearest intrinsics: no contraction), so that the data-dependent restart decision (:218-232) never has to
 // travel to the host.
-struct pogm_auto_state {
-  int iteration, done;
-  float res_norm, pad;
-  float theta, theta_old, sigma, gamma;
-};
+// (struct pogm_auto_state: rls_common.hpp)
 template <typename E>
 __global__ __launch_bounds__(PGM_THREADS) void pogm_auto_kernel(E* __restrict__ res, const E* __restrict__ x0,
                                                                 E* __restrict__ xbuf, E* __restrict__ ybuf,

@@ -698,18 +698,27 @@ struct pgm_state {
   int iteration, done;
   float res_norm, pad;
 };
+// POGM with restart = :gradient (src/POGM.jl:183-232): theta, sigma, gamma travel in the device record behind pgm_state's words
+struct pogm_auto_state {
+  int iteration, done;
+  float res_norm, pad;
+  float theta, theta_old, sigma, gamma;
+};
 constexpr int RLS_PGM_MAX_IT = 48;  // iterations per resident launch: their coefficients travel as a kernel argument
 struct rls_pgm_coefs {
   // per iteration, index-only scalars computed by the host in Float32 exactly as the reference does:
   //   OptISTA (src/OptISTA.jl:170-204): {rho gamma, rho gamma lambda, -1/gamma, 1/gamma, -beta, 1 + alpha + beta, -alpha, 0}
   //   POGM    (src/POGM.jl:183-210):    {rho, gamma lambda, c_y, c_x1, c_xo, c_z, 0, 0}
+  // POGM with restart = :gradient (kind 2): the coefficients depend on the data (the restart decision), the kernel forms them
+  // from the record (pogm_auto_state) as pogm_auto_kernel does; c[0] = {rho, lambda, sigma_fac, iterations of the solve}
   float c[RLS_PGM_MAX_IT][8];
 };
 struct rls_pgm_desc {
   const void* A;
   int64_t lda, M, N;
-  int kind;                 // 0 = OptISTA, 1 = POGM (restart = :none)
+  int kind;                 // 0 = OptISTA, 1 = POGM (restart = :none), 2 = POGM (restart = :gradient)
   void *v0, *v1, *v2;       // loop-carried state: OptISTA x, y, z ; POGM x (operator input), y, z
+  void* v3 = nullptr;       // kind 2: w (loop-carried as well)
   void *o0, *res;           // written every iteration, never read: OptISTA zold ; POGM xold ; and state.res
   const void* x0;
   void *slab, *raw;         // partial rows [nwg][N]; N-vector scratch of the flat exchange

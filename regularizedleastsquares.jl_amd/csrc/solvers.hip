@@ -3360,6 +3360,55 @@ int32_t rls_pgm_step_resident(rls_pgm* s, int32_t kind, int32_t n_steps, int32_t
   });
 }
 
+// POGM with restart = :gradient as resident launches: theta, sigma, gamma live in the record (pogm_auto_state) and the kernel
+// forms every iteration's coefficients from them (src/POGM.jl:183-232), so a block needs no table -- only rho, lambda, sigma_fac
+// and the iteration count of the solve (the last iteration's theta rule, :185).
+int32_t rls_pogm_step_resident_restart(rls_pgm* s, int32_t n_steps, int32_t first_iteration, float rho, float lambda, float sigma_fac,
+                                       int32_t iterations, void* xbuf, void* ybuf, void* z, void* w, void* xold, void* res,
+                                       const void* x0, int32_t reg_kind, int32_t proj_kind, float norm_x0, float rel_tol,
+                                       void* state_d) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (n_steps < 0 || first_iteration < 0 || iterations < 1 || iterations >= (1 << 24) || !xbuf || !ybuf || !z || !w || !xold || !res ||
+      !x0 || !state_d || reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2 || proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE)
+    return rls_fail(ctx, RLS_E_INVALID, "pogm_step_resident_restart: bad argument");
+  if (!(al16(xbuf) && al16(ybuf) && al16(z) && al16(w) && al16(xold) && al16(res) && al16(x0)))
+    return rls_fail(ctx, RLS_E_INVALID, "pogm_step_resident_restart: vectors must be 16-byte aligned");
+  if (s->resident_off || !ctx->tune.resident) return RLS_E_UNSUPPORTED;
+  if (n_steps == 0) return 0;
+  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  rls_pgm_coefs C;
+  C.c[0][0] = rho;
+  C.c[0][1] = lambda;
+  C.c[0][2] = sigma_fac;
+  C.c[0][3] = (float)iterations;  // (exact: < 2^24)
+  rls_pgm_desc D;
+  D.A = s->op->A;
+  D.lda = s->op->lda;
+  D.M = s->op->M;
+  D.N = s->op->N;
+  D.kind = 2;
+  D.v0 = xbuf;
+  D.v1 = ybuf;
+  D.v2 = z;
+  D.v3 = w;
+  D.o0 = xold;
+  D.res = res;
+  D.x0 = x0;
+  D.slab = s->op->slab;
+  D.raw = s->raw;
+  D.st = (pgm_state*)state_d;
+  D.norm_x0 = norm_x0;
+  D.rel_tol = rel_tol;
+  D.reg_kind = reg_kind;
+  D.proj_kind = proj_kind;
+  D.first_it = first_iteration;
+  return resident_chain(ctx, s->rsync, [&]() {
+    return rls_pgm_resident_launch(ctx, s->op->dtype, D, C, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+  });
+}
+
 // after the launches of a sequence: how many of them gave up (bounded wait; they changed nothing).  Synchronises.
 int32_t rls_pgm_lost(rls_pgm* s, int32_t* lost, int32_t* fallbacks_total) {
   if (!s || !lost) return RLS_E_INVALID;

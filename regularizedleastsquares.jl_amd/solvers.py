@@ -1339,12 +1339,40 @@ class POGM(AbstractProximalGradientSolver):
             init[4:8] = [f32(st.theta), f32(st.thetaold), f32(st.sigma), f32(st.gamma)]
             st._rec8.copy_from_host(init)
             rec, bufs, first = st._rec8, (st.x, st.y), st.iteration
-            for k in range(first, self.iterations):
-                xb, yb = bufs if (k - first) % 2 == 0 else bufs[::-1]
+            todo = self.iterations - first  # (the record counts from 0: the last iteration's theta rule, :185, compares with this)
+            start = 0
+            plan = _pgm_plan(self)
+            if plan is not None and todo > 0:
+                # whole blocks of iterations as single launches, A in the register files: the kernel forms the coefficients
+                # from the record and applies the restart rule itself (rls_pogm_step_resident_restart)
+                launched = 0
+                for off in range(0, todo, _PGM_BLOCK):
+                    n = min(_PGM_BLOCK, todo - off)
+                    xb, yb = bufs if off % 2 == 0 else bufs[::-1]
+                    rc = lib.rls_pogm_step_resident_restart(plan.handle, n, off, float(f32(st.rho)), float(f32(self.reg.lam)),
+                                                            float(f32(st.sigma_fac)), todo, xb.ptr, yb.ptr, st.z.ptr, st.w.ptr,
+                                                            st.xold.ptr, st.res.ptr, st.x0.ptr, fus[0], fus[1], float(st.norm_x0),
+                                                            float(st.relTol), rec.ptr)
+                    if rc == -2:
+                        break
+                    check(h, rc, "rls_pogm_step_resident_restart")
+                    launched += 1
+                if launched:
+                    lost, total = C.c_int32(0), C.c_int32(0)
+                    check(h, lib.rls_pgm_lost(plan.handle, C.byref(lost), C.byref(total)), "rls_pgm_lost")
+                    if lost.value:
+                        plan.off = True
+                        plan.fallbacks = total.value
+                    raw = rec.to_host()
+                    start = int(raw[:1].view(np.int32)[0])
+                    if int(raw[1:2].view(np.int32)[0]):  # the stopping test fired inside a launch
+                        todo = start
+            for k in range(start, todo):  # what no resident launch did (no plan, or one was lost): launch by launch
+                xb, yb = bufs if k % 2 == 0 else bufs[::-1]
                 check(h, lib.rls_operator_mul_normal_skip(self._op.handle, xb.ptr, st.res.ptr, rec.ptr + 4), "rls_operator_mul_normal_skip")
                 check(h, lib.rls_pogm_update_auto(h, xb.code, xb.n, st.res.ptr, st.x0.ptr, xb.ptr, yb.ptr, st.xold.ptr,
                                                   st.z.ptr, st.w.ptr, float(f32(st.rho)), float(f32(self.reg.lam)),
-                                                  float(f32(st.sigma_fac)), self.iterations, fus[0], fus[1],
+                                                  float(f32(st.sigma_fac)), self.iterations - first, fus[0], fus[1],
                                                   float(st.norm_x0), float(st.relTol), rec.ptr), "rls_pogm_update_auto")
             raw = rec.to_host()  # synchronises
             done_its = int(raw[:1].view(np.int32)[0])

@@ -2401,7 +2401,81 @@ def test_optista_pogm_resident_launch(rls, ctx, name, dt, M, N):
            lambda: O.solve(getattr(O, name)(A, reg=regs(O), rho=rho, iterations=30, relTol=0.0), b), record=False)
 
 
-@pytest.mark.parametrize("name", ["OptISTA", "POGM"])
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 4000, 2200)])
+def test_pogm_gradient_restart_resident_launch(rls, ctx, dt, M, N):
+    """POGM with restart = :gradient (src/POGM.jl:183-232) as resident launches (pgm_resident_kernel KIND 2 through
+    rls_pogm_step_resident_restart): theta, sigma, gamma and the restart decision stay on the device and the kernel forms every
+    iteration's coefficients itself.  Against the float64 oracle at 30, 49 (two launches, x / y roles swapped) and 100 iterations
+    with sigma_fac < 1; the recurrence scalars equal those of the launch-per-iteration sequence (resident = 0) and of the oracle;
+    the stopping test inside a launch; a run continued after iterate-by-iterate steps (the last iteration's theta rule counts
+    from the solve's start, :185)."""
+    A, xt, b = O.make_problem(M, N, dt, 5)
+    A64, b64 = A.astype(hi(dt)), b.astype(hi(dt))
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * np.max(np.abs(A64.conj().T @ b64))
+    kw = dict(restart="gradient", sigma_fac=0.97)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    tag = f"POGM_restart_resident_{M}x{N}_{np.dtype(dt).name}"
+    for its in (30, 49, 100):
+        ref = O.POGM(A64, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0, **kw)
+        O.solve(ref, b64)
+        ref32 = lambda: O.solve(O.POGM(A, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0, **kw), b)
+        sol = rls.createLinearSolver(rls.POGM, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0, **kw)
+        x = rls.solve_(sol, bd).to_host()
+        plan = sol._pgm[1]
+        if plan is None:
+            _resident_unavailable()
+        assert not plan.off and plan.fallbacks == 0 and sol.state.iteration == its
+        parity(f"{tag}_its{its}", x, ref.x, ref32, record=its == 30)
+        assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
+        scal = (sol.state.theta, sol.state.thetaold, sol.state.sigma, sol.state.gamma)
+        if its < 100:  # (once the iterate has converged the restart criterion is rounding noise: past ~60 iterations the Float32 and
+            # Float64 oracles themselves restart at different iterations -- tools/debug_pogm_restart.py -- and only x is compared)
+            assert np.allclose(scal, (ref.theta, ref.theta_old, ref.sigma, ref.gamma), rtol=1e-5), (scal, (ref.theta, ref.theta_old, ref.sigma, ref.gamma))
+        assert np.array_equal(rls.solve_(sol, bd).to_host(), x)   # run to run identical
+        if its == 49:
+            ctx.tune(resident=0)
+            try:
+                x_seq = rls.solve_(sol, bd).to_host()
+                scal_seq = (sol.state.theta, sol.state.thetaold, sol.state.sigma, sol.state.gamma)
+                w_seq = sol.state.w.to_host()
+            finally:
+                ctx.tune(resident=1)
+            assert rel(x_seq, x) < 2e-5 and scal_seq == scal
+            assert np.array_equal(rls.solve_(sol, bd).to_host(), x) and not plan.off
+            assert rel(sol.state.w.to_host(), w_seq) < 1e-4
+    # the stopping test inside a launch
+    probe = O.POGM(A64, reg=O.L1Regularization(lam), rho=rho, iterations=90, relTol=0.0, **kw)
+    probe.init(b64)
+    rr = []
+    while probe.iterate() is not None:
+        rr.append(probe.rel_res_norm)
+    k = next(k for k in range(60, 2, -1) if min(rr[:k]) > 1.001 * rr[k])
+    tol = 1.0005 * rr[k]
+    ref = O.POGM(A64, reg=O.L1Regularization(lam), rho=rho, iterations=90, relTol=tol, **kw)
+    O.solve(ref, b64)
+    assert ref.iteration == k + 1
+    sol = rls.createLinearSolver(rls.POGM, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=90, relTol=tol, **kw)
+    for _ in range(2):
+        x = rls.solve_(sol, bd).to_host()
+        assert sol.state.iteration == ref.iteration
+        parity(f"{tag}_reltol", x, ref.x,
+               lambda: O.solve(O.POGM(A, reg=O.L1Regularization(lam), rho=rho, iterations=ref.iteration, relTol=0.0, **kw), b), record=False)
+    # part of the iterations step by step (callbacks), then resident launches continue from that state
+    sol = rls.createLinearSolver(rls.POGM, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=30, relTol=0.0, **kw)
+    rls.init_(sol, bd)
+    for _ in range(7):
+        assert rls.iterate(sol) is not None
+    sol._run(sol.state)
+    ref = O.POGM(A64, reg=O.L1Regularization(lam), rho=rho, iterations=30, relTol=0.0, **kw)
+    O.solve(ref, b64)
+    assert sol.state.iteration == 30
+    parity(f"{tag}_continued", sol.state.x.to_host(), ref.x,
+           lambda: O.solve(O.POGM(A, reg=O.L1Regularization(lam), rho=rho, iterations=30, relTol=0.0, **kw), b), record=False)
+    assert np.isclose(sol.state.theta, ref.theta, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["OptISTA", "POGM", "POGM-restart"])
 def test_optista_pogm_resident_lost_launch(rls, ctx, name):
     """a co-tenant holds 64 CUs for longer than the wait bound: the first resident launch gives up having changed nothing,
     the later launches of the sequence see a stale iteration count and do nothing, the host finishes launch by launch;
@@ -2413,12 +2487,15 @@ def test_optista_pogm_resident_lost_launch(rls, ctx, name):
     Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
     other = rls.Context(0)
     its = 60   # two launches
+    kw = {}
+    if name == "POGM-restart":  # (restart = :gradient: rls_pogm_step_resident_restart, then rls_pogm_update_auto launch by launch)
+        name, kw = "POGM", dict(restart="gradient", sigma_fac=0.97)
     try:
         _fresh_resident_ctx(ctx)
         ctx.tune(resident_spin=20000)
-        ref = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0)
+        ref = getattr(O, name)(A64, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0, **kw)
         O.solve(ref, b64)
-        sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0)
+        sol = rls.createLinearSolver(getattr(rls, name), Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0, **kw)
         rls.init_(sol, bd)
         ctx.sync()
         assert _hold_cus(rls, other, 64, 400000) == 0
@@ -2429,8 +2506,8 @@ def test_optista_pogm_resident_lost_launch(rls, ctx, name):
             _resident_unavailable()
         assert plan.off and plan.fallbacks >= 1, "the co-tenant did not displace the resident launch"
         assert sol.state.iteration == its
-        parity(f"co_tenant_{name}", sol.state.x.to_host(), ref.x,
-               lambda: O.solve(getattr(O, name)(A, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0), b), record=False)
+        parity(f"co_tenant_{name}{'_restart' if kw else ''}", sol.state.x.to_host(), ref.x,
+               lambda: O.solve(getattr(O, name)(A, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0, **kw), b), record=False)
         x2 = rls.solve_(sol, bd).to_host()   # the retired plan: launch by launch
         assert rel(x2, sol.state.x.to_host()) == 0 and sol.state.iteration == its
     finally:

@@ -36,7 +36,7 @@ BASELINE = [
     ("configs[0] on the pipeline (small = 0)", r"cgnr_pipe_a_kernel<float, 8, 8, 8, (true|false), false, (true|false)>"),
     ("configs[1]: FISTA + L1 4096x2048 CF32, resident", r"fista_resident_kernel<c32, 8, 32, 8, 2, true>"),
     ("configs[1] on the pipeline", r"fista_pipe_a_kernel<c32, 8, 32, 8, true, (true|false)>"),
-    ("configs[1] shape, SURVEY 8f-1: OptISTA / POGM blocks of iterations as resident launches", r"pgm_resident_kernel<c32, 8, 32, 8, 2, true, (0|1)>"),
+    ("configs[1] shape, SURVEY 8f-1: OptISTA / POGM (2: with gradient restart) blocks of iterations as resident launches", r"pgm_resident_kernel<c32, 8, 32, 8, 2, true, (0|1|2)>"),
     ("configs[1] on the pipeline", r"fista_pipe_r_kernel<c32>"),
     ("configs[2]: ADMM + TV 8192x4096 F32: cg! on the pipeline", r"cgnr_pipe_a_kernel<float, 4, 32, 8, true, false, (true|false)>"),
     ("configs[2]: cg! entry, z / u update", r"cg_pipe_start_kernel<float>"),
