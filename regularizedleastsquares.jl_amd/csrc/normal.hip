@@ -1079,12 +1079,15 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bool writer = blockIdx.x == 0;
   // the small loads go out ahead of the slab (a CU's vector-memory path returns loads in issue order)
-  E pv[EPT], rv[EPT], vv[EPT], xv[EPT];
+  // X_LATE (ComplexF32, 16 rows of 32 columns per workgroup: 8 owned elements of four vectors beside a 128-register slab spilled
+  // 36 B per lane): x is not held across the slab load; workgroup 0 -- the only one that stores it -- reads it where it updates it
+  constexpr bool X_LATE = elem<E>::cplx && G == 4 && K == 32;
+  E pv[EPT], rv[EPT], vv[EPT], xv[X_LATE ? 1 : EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int64_t i = tid + (int64_t)e * C::NT;
     const int64_t ic = i < N ? i : (N - 1);
-    xv[e] = writer ? x[ic] : elem<E>::zero();  // only workgroup 0 stores x
+    if constexpr (!X_LATE) xv[e] = writer ? x[ic] : elem<E>::zero();  // only workgroup 0 stores x
     pv[e] = pc[ic];
     rv[e] = rc[ic];
     vv[e] = vc[ic];
@@ -1132,7 +1135,8 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
       for (int e = 0; e < EPT; ++e) {
         const int64_t i = tid + (int64_t)e * C::NT;
         if (i < N) {
-          x[i] = elem<E>::fma(pv[e], al, xv[e]);
+          if constexpr (X_LATE) x[i] = elem<E>::fma(pv[e], al, x[i]);
+          else x[i] = elem<E>::fma(pv[e], al, xv[e]);
           rn_out[i] = rn[e];
           pn_out[i] = pn[e];
           if (done) vn[i] = vv[e];
@@ -2845,10 +2849,17 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   const int64_t Mc = P.M / C::NV;
   const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
+  // ComplexF32 with 16 rows x 32 columns per workgroup (N in (2048, 4096]): the instantiation that loads BOTH (r, p) candidates
+  // holds 6 x 8 owned elements beside a 128-register slab and spilled 28-36 B per lane.  It is not instantiated: a launch that
+  // does not know which pair is current (the first node of a graph chunk) runs the hinted kernel on a guess -- that kernel
+  // checks the hint on the device and re-loads the right pair, late, when it was wrong.
+  constexpr bool ALWAYS_HINTED = elem<E>::cplx && G == 4 && K == 32;
   static rls_device_once attr_once;
   if (attr_once.first(ctx->device)) {
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, false>, lds);
-    allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, false>, lds);
+    if constexpr (!ALWAYS_HINTED) {
+      allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, false>, lds);
+      allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, false>, lds);
+    }
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, true>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, true>, lds);
   }
@@ -2856,19 +2867,27 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   const bool batched = P.nrhs > 1;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   // single right-hand side: the hinted instantiation (its full-size form loads the vectors in 16-byte pieces)
-  const bool hinted = !batched && P.cur_hint >= 0 && al16(P.r0) && al16(P.p0) && al16(P.r1) && al16(P.p1) && al16(P.v);
+  const bool aligned = al16(P.r0) && al16(P.p0) && al16(P.r1) && al16(P.p1) && al16(P.v);
+  const bool hinted = !batched && P.cur_hint >= 0 && aligned;
+  pipe_rhs_ptrs R = rhs_of(P, nwg);
 #define RLS_LAUNCH_A(FULLV, BATCHV, HINTV)                                                                            \
   hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV, HINTV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, \
                      (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, (E*)P.slab,   \
-                     P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, rhs_of(P, nwg))
+                     P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, R)
   // (a BATCHED = true instantiation -- the slab kernel looping over several right-hand sides on the VALU -- existed until
   //  round 3 as the fallback of the matrix-core batched path; it spilled up to 528 bytes per lane and was four times slower
   //  per solve-iteration than the skinny kernels: shapes those do not cover now run one plan per column)
   (void)batched;
-  if (full && hinted) RLS_LAUNCH_A(true, false, true);
-  else if (hinted) RLS_LAUNCH_A(false, false, true);
-  else if (full) RLS_LAUNCH_A(true, false, false);
-  else RLS_LAUNCH_A(false, false, false);
+  if constexpr (ALWAYS_HINTED) {
+    if (R.hint < 0) R.hint = 0;
+    if (full && aligned) RLS_LAUNCH_A(true, false, true);   // (the full-size hinted form loads 16-byte pieces)
+    else RLS_LAUNCH_A(false, false, true);
+  } else {
+    if (full && hinted) RLS_LAUNCH_A(true, false, true);
+    else if (hinted) RLS_LAUNCH_A(false, false, true);
+    else if (full) RLS_LAUNCH_A(true, false, false);
+    else RLS_LAUNCH_A(false, false, false);
+  }
 #undef RLS_LAUNCH_A
 }
 

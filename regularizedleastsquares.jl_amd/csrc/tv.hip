@@ -299,7 +299,11 @@ __global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, 
   E* xt = reinterpret_cast<E*>(smem_raw);
   E* P = xt + n;
   E* Q = P + n;
-  E xl[PPT], rp[PPT], rq[PPT], pp[PPT], pq[PPT], xv[PPT];
+  // LEAN (8 pixels per thread at 1024 threads = 128 VGPRs; the full form spilled 64 B per lane): xTmp is not kept across the
+  // barrier but read back from LDS, where the neighbours read it anyway, and the four clamped neighbour indices are formed
+  // from the masks where they are used (pixel index -/+ mask bit x stride) instead of being held in 4 x 8 registers
+  constexpr bool LEAN = PPT >= 8;
+  E xl[PPT], rp[PPT], rq[PPT], pp[PPT], pq[PPT], xv[LEAN ? 1 : PPT];
   unsigned mIn = 0, mP = 0, mPm = 0, mQ = 0, mQm = 0;
 #pragma unroll
   for (int m = 0; m < PPT; ++m) {
@@ -326,23 +330,34 @@ __global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, 
   // the ONE CU it runs on (time per FGP iteration scales with the pixels per thread: 0.36 us at one, 1.5 us at four),
   // not by LDS latency.  The arithmetic is unchanged: a masked-out term is +0 under a subtraction and -0 under an
   // addition, which leave every value -- and the sign of a zero -- as it was.
-  unsigned kc[PPT], kPm[PPT], kQm[PPT], kPp[PPT], kQp[PPT];
+  constexpr int NI = LEAN ? 1 : PPT;
+  unsigned kc[PPT], kPm_[NI], kQm_[NI], kPp_[NI], kQp_[NI];
 #pragma unroll
   for (int m = 0; m < PPT; ++m) {
     const unsigned k = tid + m * nth;
     kc[m] = (mIn >> m & 1) ? k : 0u;
-    kPm[m] = (mPm >> m & 1) ? k - 1 : kc[m];
-    kQm[m] = (mQm >> m & 1) ? k - nx : kc[m];
-    kPp[m] = (mP >> m & 1) ? k + 1 : kc[m];
-    kQp[m] = (mQ >> m & 1) ? k + nx : kc[m];
+    if constexpr (!LEAN) {
+      kPm_[m] = (mPm >> m & 1) ? k - 1 : kc[m];
+      kQm_[m] = (mQm >> m & 1) ? k - nx : kc[m];
+      kPp_[m] = (mP >> m & 1) ? k + 1 : kc[m];
+      kQp_[m] = (mQ >> m & 1) ? k + nx : kc[m];
+    }
   }
+  // (a set mask bit implies the pixel is inside the image, i.e. kc[m] == k)
+  auto kPm = [&](int m) { if constexpr (LEAN) return kc[m] - (mPm >> m & 1u); else return kPm_[m]; };
+  auto kQm = [&](int m) { if constexpr (LEAN) return kc[m] - (mQm >> m & 1u) * nx; else return kQm_[m]; };
+  auto kPp = [&](int m) { if constexpr (LEAN) return kc[m] + (mP >> m & 1u); else return kPp_[m]; };
+  auto kQp = [&](int m) { if constexpr (LEAN) return kc[m] + (mQ >> m & 1u) * nx; else return kQp_[m]; };
   const E pz = elem<E>::zero(), nz = elem<E>::make(-0.f, -0.f);
   for (int it = 0; it < iters; ++it) {
+    if constexpr (LEAN) {  // the neighbour indices are loop invariants: without this they are hoisted back into 32 registers
+      asm volatile("" : "+v"(mPm), "+v"(mQm), "+v"(mP), "+v"(mQ));
+    }
     E nP[PPT], nQ[PPT];
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
-      nP[m] = P[kPm[m]];
-      nQ[m] = Q[kQm[m]];
+      nP[m] = P[kPm(m)];
+      nQ[m] = Q[kQm(m)];
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
@@ -351,8 +366,9 @@ __global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, 
       s = elem<E>::sub(s, (mPm >> m & 1) ? nP[m] : pz);
       s = elem<E>::add(s, (mQ >> m & 1) ? rq[m] : nz);
       s = elem<E>::sub(s, (mQm >> m & 1) ? nQ[m] : pz);
-      xv[m] = elem<E>::add(xl[m], elem<E>::scale(-lam, s));
-      if (mIn >> m & 1) xt[kc[m]] = xv[m];
+      const E xm = elem<E>::add(xl[m], elem<E>::scale(-lam, s));
+      if constexpr (!LEAN) xv[m] = xm;
+      if (mIn >> m & 1) xt[kc[m]] = xm;
     }
     __syncthreads();
     const float tOld = t;
@@ -361,13 +377,16 @@ __global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, 
     E xP[PPT], xQ[PPT];
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
-      xP[m] = xt[kPp[m]];
-      xQ[m] = xt[kQp[m]];
+      xP[m] = xt[kPp(m)];
+      xQ[m] = xt[kQp(m)];
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
+      E xc;  // xTmp of this pixel (a pixel outside the image reads xt[0]: its updates below are masked too)
+      if constexpr (LEAN) xc = xt[kc[m]];
+      else xc = xv[m];
       {
-        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xP[m])), rp[m]);
+        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xc, xP[m])), rp[m]);
         q = tv_clip<E>(q);
         const E rn = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pp[m]));
         const bool on = mP >> m & 1;
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(1024) void fgp2d_kernel(const E* __restrict__ xin, 
         pp[m] = on ? q : pp[m];
       }
       {
-        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xv[m], xQ[m])), rq[m]);
+        E q = elem<E>::add(elem<E>::scale(step, elem<E>::sub(xc, xQ[m])), rq[m]);
         q = tv_clip<E>(q);
         const E rn = elem<E>::sub(elem<E>::scale(t3, q), elem<E>::scale(t2, pq[m]));
         const bool on = mQ >> m & 1;
@@ -498,7 +517,7 @@ static bool fgp_single_launch(rls_ctx* ctx, const tv_geom& G, const E* xin, cons
       fgp2d_launch<E, 2>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
     else if (n <= 4096)
       fgp2d_launch<E, 4>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
-    else
+    else if constexpr (sizeof(E) == 4)  // (fgp2d_geom: complex images stop at 4 pixels per thread)
       fgp2d_launch<E, 8>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
     return true;
   }

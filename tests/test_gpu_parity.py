@@ -255,7 +255,8 @@ def test_prox_l21_zero_group_lambda_zero_is_nan(rls, ctx):
 
 
 TV_CASES = [((16, 16), None), ((64, 64), None), ((8, 8), (1,)), ((8, 8), (2,)), ((5, 4, 3), None), ((300,), None),
-            ((7, 9), (2, 1)), ((256, 256), None)]
+            ((7, 9), (2, 1)), ((256, 256), None),
+            ((96, 80), None), ((90, 91), None), ((128, 64), (1,))]   # 4097..8192 pixels: 8 per thread in the register-resident kernel (Float32)
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.complex64])
@@ -324,7 +325,10 @@ def _cgnr_pair(rls, M, N, dt, seed, lam, iters, mode="matrixfree"):
 
 
 @pytest.mark.parametrize("dt,M,N,lam", [(np.float32, 256, 128, 1e-2), (np.complex64, 64, 32, 0.0),
-                                       (np.complex64, 4096, 2048, 0.0), (np.float32, 1000, 300, 0.5)])
+                                       (np.complex64, 4096, 2048, 0.0), (np.float32, 1000, 300, 0.5),
+                                       # ComplexF32 N in (2048, 4096]: 16 rows x 32 columns per workgroup -- the slab pipeline's
+                                       # hinted kernel only (an unhinted launch runs it on a guess, normal.hip launch_pipe_a)
+                                       (np.complex64, 3200, 3072, 1e-3)])
 def test_cgnr_iterates_match_oracle(rls, ctx, dt, M, N, lam):
     """per-iteration x, r, p and alpha, beta against the float64 oracle (SURVEY 8d parity gate)"""
     iters = 32 if M >= 1000 else 10
@@ -347,6 +351,15 @@ def test_cgnr_iterates_match_oracle(rls, ctx, dt, M, N, lam):
             assert abs(st.betal - ref.beta) < 1e-4 * abs(ref.beta)
     assert rls.iterate(sol) is None and ref.iterate() is None
     assert sol.state.iteration == iters
+    if M >= 1000:  # the same solve as ONE step call (graph chunks: their first launch carries no buffer hint), both hint modes
+        x_steps = sol.state.x.to_host()
+        for mode in (0, 1, 2):  # host bookkeeping / always "unknown" / always wrong (the kernel re-loads the right pair)
+            ctx.tune(pipe_hint_mode=mode, resident=0)
+            try:
+                x_once = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+            finally:
+                ctx.tune(pipe_hint_mode=0, resident=1)
+            assert rel(x_once, x_steps) < 1e-6, mode
 
 
 def test_cgnr_gram_mode_and_float32_oracle(rls, ctx):

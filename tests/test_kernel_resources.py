@@ -53,13 +53,11 @@ BASELINE = [
     ("configs[4]: the direct all-reduce", r"comm_(push|sum)_kernel"),
 ]
 
-# kernels that are allowed to spill, with the shape that reaches them (none is on a BASELINE config's path)
-KNOWN_SPILLS = {
-    r"fgp2d_kernel<(float|c32), 8>": "register-resident 2-D TV prox of images with 4097..8192 pixels (8 pixels per thread at 128 VGPRs)",
-    r"cgnr_gram_kernel<c32, 4, 32, 8, (true|false)>": "Gram-mode CGNR, ComplexF32 N in (2048, 4096]: 8 owned elements of 4 vectors beside the slab",
-    r"cgnr_pipe_a_kernel<c32, 4, 32, 8, (true|false), false, false>": "slab pipeline, ComplexF32 N in (2048, 4096], launch without a buffer hint "
-                                                                       "(first node of a graph chunk): both (r, p) candidates in registers",
-}
+# kernels that are allowed to spill, with the shape that reaches them.  Empty since round 4: the three entries of round 3 went
+# (fgp2d_kernel<float, 8> forms its neighbour indices from the masks and reads xTmp back from LDS, fgp2d_kernel<c32, 8> was
+# never launched and is no longer instantiated; cgnr_gram_kernel<c32, 4, 32, 8, *> reads x where workgroup 0 updates it;
+# cgnr_pipe_a_kernel<c32, 4, 32, 8, *, false, false> is not instantiated -- an unhinted launch runs the hinted kernel on a guess).
+KNOWN_SPILLS = {}
 
 
 def test_baseline_kernels_use_no_scratch(kernels):
@@ -72,6 +70,7 @@ def test_baseline_kernels_use_no_scratch(kernels):
 
 
 def test_spills_are_only_the_known_ones(kernels):
+    """no kernel of the shipped library uses scratch memory (KNOWN_SPILLS is the place to argue an exception)"""
     spill = {k: v["scratch"] for k, v in kernels.items() if v["scratch"] > 0}
     unknown = [f"{k}: {b} B/lane" for k, b in spill.items() if not any(re.fullmatch(p, k) for p in KNOWN_SPILLS)]
     assert not unknown, "new spilling kernels:\n" + "\n".join(unknown)
