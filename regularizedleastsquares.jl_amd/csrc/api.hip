@@ -281,7 +281,6 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   }
   else if (!strcmp(key, "status_mailbox")) ctx->tune.status_mailbox = value;
   else if (!strcmp(key, "small")) ctx->tune.small = value;
-  else if (!strcmp(key, "resident_2d")) ctx->tune.resident_2d = value;
   else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "resident_preclear")) ctx->tune.resident_preclear = value;
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);

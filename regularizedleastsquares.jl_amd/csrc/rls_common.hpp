@@ -29,7 +29,6 @@ struct rls_tuning {
   int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
                           // ONE launch (normal.hip, cgnr_resident_kernel)
   int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
-  int resident_2d = 1;         // 1: resident CGNR of the shapes resident2d.hip covers runs on its 16 x 16 tile grid
   int small = 1;               // 1: systems that fit ONE CU's registers run a whole step call as a single-workgroup launch (small.hip)
   int status_mailbox = 2;      // >= 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
                                // sequence word (rls_fetch_*); 2: and rls_*_step_status has the call's LAST kernel do that
@@ -833,11 +832,6 @@ struct rls_small {
 };
 bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps);
-// resident CGNR on a 16 x 16 grid of tiles (resident2d.hip): three light hand-offs per iteration; ComplexF32, M in {2048, 4096},
-// N in {1024, 2048}.  xb = rls_resident2d_bytes(M, N) bytes of exchange space; sync = the plan's resident_sync block.
-size_t rls_resident2d_bytes(int64_t M, int64_t N);
-bool rls_resident2d_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
-int32_t rls_resident2d_launch(rls_ctx* ctx, const rls_cgnr_pipe& P, void* sync, void* xb, int n_steps, unsigned spin_limit);
 
 // Batched CGNR on an explicit Gram matrix as ONE resident launch per step call (gramk.hip): up to 8 ComplexF32 right-hand
 // sides, AHA (N <= 2048) held in the register files, the operand panel replicated in every workgroup's LDS

@@ -177,7 +177,6 @@ struct rls_cgnr {
   float* gk_vx = nullptr;
   void* gk_xx = nullptr;
   double* gk_dots = nullptr;
-  void* r2_xb = nullptr;  // exchange space of the 16 x 16 tile-grid resident kernel (resident2d.hip), or null
 };
 
 static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
@@ -311,10 +310,6 @@ static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch, bool* clean
       });
 }
 static int32_t resident_chain_launch(rls_ctx* ctx, rls_cgnr* s, const rls_cgnr_pipe& P, int n_steps) {
-  if (s->r2_xb && ctx->tune.resident_2d)  // the 16 x 16 tile grid: three light hand-offs per iteration (resident2d.hip)
-    return resident_chain(ctx, s->rsync, [&]() {
-      return rls_resident2d_launch(ctx, P, s->rsync, s->r2_xb, n_steps, (unsigned)ctx->tune.resident_spin);
-    }, &s->rsync_clean);
   return resident_chain(ctx, s->rsync, [&]() {
     return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
   }, &s->rsync_clean);
@@ -2053,10 +2048,6 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
     if (e == hipSuccess) e = dmalloc(&s->rdots, db);
     if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
-    if (e == hipSuccess && rls_resident2d_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
-      e = dmalloc(&s->r2_xb, rls_resident2d_bytes(op->M, op->N));
-      if (e == hipSuccess) e = hipMemsetAsync(s->r2_xb, 0, rls_resident2d_bytes(op->M, op->N), ctx->stream);
-    }
   }
   if (e == hipSuccess && nrhs == 1 && op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
@@ -2133,7 +2124,6 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->gk_vx) dfree(s->gk_vx);
   if (s->gk_xx) dfree(s->gk_xx);
   if (s->gk_dots) dfree(s->gk_dots);
-  if (s->r2_xb) dfree(s->r2_xb);
   if (s->rsync) dfree(s->rsync);
   if (s->rdots) dfree(s->rdots);
   if (s->rsync_h) hfree(s->rsync_h);
