@@ -44,7 +44,7 @@ __device__ static inline E shfl_xor_e(E v, int m) {
 
 template <typename E, int R, int C>
 __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* x, E* r, E* p, E* v,
-                                                           cgnr_scalars* sc, int n_steps, rls_mailbox_slot mb) {
+                                                           cgnr_scalars* sc, int n_steps, rls_mailbox_slot mb, int vec16) {
   constexpr int NP = 16 * C;              // padded vector length
   constexpr int EPT = (NP + 63) / 64;     // vector elements per lane of wave 0
   __shared__ E ps[NP];                    // p, zero beyond N
@@ -53,16 +53,42 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int cb = lane & 15, rb = tid >> 4;
   // ---- A tile into registers (zero outside the matrix) -------------------------------------------------------------------------
+  // A thread's R rows of a column are contiguous: with a 16-byte aligned A (vec16) they come in as 16-byte pieces -- R C s / 16
+  // loads per lane instead of R C element loads that each touch a cache line of their own (a one-iteration call of the
+  // 256 x 128 Float32 system spent ~8 of its ~11 us of kernel time on them).  Pieces that stick out of the matrix are read
+  // element by element (ragged M only).
   E a[R][C];
+  constexpr int NVE = 16 / (int)sizeof(E);
+  if (R % NVE == 0 && vec16) {
+    constexpr int NQ = R % NVE == 0 ? R / NVE : 1;
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    const int col = cb * C + j;
+    for (int j = 0; j < C; ++j) {
+      const int col = cb * C + j;
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int row = rb * R + i;
-      const bool ok = row < M && col < N;
-      const E val = A[(int64_t)(ok ? col : 0) * lda + (ok ? row : 0)];
-      a[i][j] = ok ? val : elem<E>::zero();
+      for (int q = 0; q < NQ; ++q) {
+        const int row0 = rb * R + q * NVE;
+        const bool full = row0 + NVE <= M && col < N;
+        const chunk<E, NVE> piece = load_chunk<E, NVE>(A + (full ? (int64_t)col * lda + row0 : 0));
+#pragma unroll
+        for (int k = 0; k < NVE; ++k) a[(q * NVE + k) % R][j] = full ? piece.e[k] : elem<E>::zero();
+        if (!full && col < N && row0 < M) {
+#pragma unroll
+          for (int k = 0; k < NVE; ++k)
+            if (row0 + k < M) a[(q * NVE + k) % R][j] = A[(int64_t)col * lda + row0 + k];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const int col = cb * C + j;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int row = rb * R + i;
+        const bool ok = row < M && col < N;
+        const E val = A[(int64_t)(ok ? col : 0) * lda + (ok ? row : 0)];
+        a[i][j] = ok ? val : elem<E>::zero();
+      }
     }
   }
   // ---- state: wave 0 owns the vectors (elements lane, lane + 64, ...) -----------------------------------------------------------
@@ -210,7 +236,8 @@ static bool small_pick(int64_t M, int64_t N, small_tile* t) {
 template <typename E, int R, int C>
 static void small_launch(rls_ctx* ctx, const rls_small& D, int n_steps) {
   hipLaunchKernelGGL((cgnr_small_kernel<E, R, C>), dim3(1), dim3(SM_NT), 0, ctx->stream, (const E*)D.A, D.lda, (int)D.M, (int)D.N, (E*)D.x,
-                     (E*)D.r, (E*)D.p, (E*)D.v, D.sc, n_steps, D.mb);
+                     (E*)D.r, (E*)D.p, (E*)D.v, D.sc, n_steps, D.mb,
+                     (int)((reinterpret_cast<uintptr_t>(D.A) & 15) == 0 && (D.lda * (int64_t)sizeof(E)) % 16 == 0));
 }
 
 template <typename E>
