@@ -370,7 +370,8 @@ int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n);
 int32_t rls_fista_step(rls_fista* s, int32_t n_steps);
 /* which kernel sequence the next rls_fista_step call takes (the codes of rls_cgnr_path): 0 = two GEMVs + update kernel,
  * 1 = one-pass slab pipeline, 2 = Gram-mode pipeline, 3 = batched matrix-core kernels, 4 = resident (one launch per
- * call, A in registers), 5 = resident Gram mode (one launch per call, AHA in registers) */
+ * call, A in registers), 5 = resident Gram mode (one launch per call, AHA in registers), 8 = small system (one single-workgroup
+ * launch per call, A in one CU's registers: fista_small_kernel) */
 int32_t rls_fista_path(rls_fista* s, int32_t* out);
 int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out_h); /* synchronises; recovers lost resident launches as rls_cgnr_get_status */
 int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out_h); /* step + status, one synchronisation */

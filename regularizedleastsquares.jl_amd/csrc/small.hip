@@ -42,22 +42,14 @@ __device__ static inline E shfl_xor_e(E v, int m) {
   else return __shfl_xor(v, m, 64);
 }
 
+// this thread's R x C tile of A (zero outside the matrix)
 template <typename E, int R, int C>
-__global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* x, E* r, E* p, E* v,
-                                                           cgnr_scalars* sc, int n_steps, rls_mailbox_slot mb, int vec16) {
-  constexpr int NP = 16 * C;              // padded vector length
-  constexpr int EPT = (NP + 63) / 64;     // vector elements per lane of wave 0
-  __shared__ E ps[NP];                    // p, zero beyond N
-  __shared__ E vpart[SM_WV][NP];          // per-wave partial rows of v
-  __shared__ int sdone;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int cb = lane & 15, rb = tid >> 4;
-  // ---- A tile into registers (zero outside the matrix) -------------------------------------------------------------------------
+__device__ static inline void small_tile_load(E (&a)[R][C], const E* __restrict__ A, int64_t lda, int M, int N, int vec16, int cb,
+                                              int rb) {
   // A thread's R rows of a column are contiguous: with a 16-byte aligned A (vec16) they come in as 16-byte pieces -- R C s / 16
   // loads per lane instead of R C element loads that each touch a cache line of their own (a one-iteration call of the
   // 256 x 128 Float32 system spent ~8 of its ~11 us of kernel time on them).  Pieces that stick out of the matrix are read
   // element by element (ragged M only).
-  E a[R][C];
   constexpr int NVE = 16 / (int)sizeof(E);
   if (R % NVE == 0 && vec16) {
     constexpr int NQ = R % NVE == 0 ? R / NVE : 1;
@@ -91,6 +83,50 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__
       }
     }
   }
+}
+
+// one application of the normal operator to the vector in `ps`: the per-wave partial rows of A^H (A ps) in vpart, complete
+// behind the workgroup barrier this ends with
+template <typename E, int R, int C>
+__device__ static inline void small_normal_partials(const E (&a)[R][C], const E* ps, E (*vpart)[16 * C], int cb, int lane, int w) {
+  // ---- t = A p: this thread's R rows over its C columns, then over the 16 column blocks ---------------------------------------
+  E pj[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) pj[j] = ps[cb * C + j];
+  E t[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    E s = elem<E>::zero();
+#pragma unroll
+    for (int j = 0; j < C; ++j) s = elem<E>::fma(a[i][j], pj[j], s);
+    t[i] = row16_sum<E>(s);
+  }
+  // ---- v = A^H t: this thread's C columns over its R rows, then over the 4 row blocks of the wave, then over the waves ---------
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    E s = elem<E>::zero();
+#pragma unroll
+    for (int i = 0; i < R; ++i) s = elem<E>::fmac(a[i][j], t[i], s);  // conj(a) t
+    s = elem<E>::add(s, shfl_xor_e<E>(s, 16));
+    s = elem<E>::add(s, shfl_xor_e<E>(s, 32));
+    if (lane < 16) vpart[w][cb * C + j] = s;
+  }
+  __syncthreads();
+}
+
+template <typename E, int R, int C>
+__global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* x, E* r, E* p, E* v,
+                                                           cgnr_scalars* sc, int n_steps, rls_mailbox_slot mb, int vec16) {
+  constexpr int NP = 16 * C;              // padded vector length
+  constexpr int EPT = (NP + 63) / 64;     // vector elements per lane of wave 0
+  __shared__ E ps[NP];                    // p, zero beyond N
+  __shared__ E vpart[SM_WV][NP];          // per-wave partial rows of v
+  __shared__ int sdone;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cb = lane & 15, rb = tid >> 4;
+  // ---- A tile into registers (zero outside the matrix) -------------------------------------------------------------------------
+  E a[R][C];
+  small_tile_load<E, R, C>(a, A, lda, M, N, vec16, cb, rb);
   // ---- state: wave 0 owns the vectors (elements lane, lane + 64, ...) -----------------------------------------------------------
   E xv[EPT], rv[EPT], pv[EPT], vv[EPT];
   cgnr_scalars S;
@@ -114,29 +150,7 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__
   __syncthreads();
   for (int it = 0; it < n_steps; ++it) {
     if (sdone) break;  // uniform
-    // ---- t = A p: this thread's R rows over its C columns, then over the 16 column blocks ---------------------------------------
-    E pj[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) pj[j] = ps[cb * C + j];
-    E t[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      E s = elem<E>::zero();
-#pragma unroll
-      for (int j = 0; j < C; ++j) s = elem<E>::fma(a[i][j], pj[j], s);
-      t[i] = row16_sum<E>(s);
-    }
-    // ---- v = A^H t: this thread's C columns over its R rows, then over the 4 row blocks of the wave, then over the waves ---------
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
-      E s = elem<E>::zero();
-#pragma unroll
-      for (int i = 0; i < R; ++i) s = elem<E>::fmac(a[i][j], t[i], s);  // conj(a) t
-      s = elem<E>::add(s, shfl_xor_e<E>(s, 16));
-      s = elem<E>::add(s, shfl_xor_e<E>(s, 32));
-      if (lane < 16) vpart[w][cb * C + j] = s;
-    }
-    __syncthreads();
+    small_normal_partials<E, R, C>(a, ps, vpart, cb, lane, w);
     // ---- the CG update, wave 0 alone (src/CGNR.jl:153-176) -----------------------------------------------------------------------
     if (w == 0) {
       double nre = 0.0, nim = 0.0, pp = 0.0;
@@ -215,6 +229,130 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__
   }
 }
 
+// ---- FISTA (src/FISTA.jl:139-185) on the same tile layout -----------------------------------------------------------------------
+// A whole rls_fista_step call: per iteration res_raw = A^H (A y) from the registers, then -- wave 0 alone, as above -- the
+// gradient step, prox, restart test, theta, the stopping test and the next extrapolated point (fista_update_elems of normal.hip
+// for one wave).  State in and out in the pipeline's layout: x_k in buf[k & 1], x_{k-1} in the other buffer, the extrapolated
+// point in y0 / y1 by `ycur`, nothing pending.
+template <typename E, int R, int C>
+__global__ __launch_bounds__(SM_NT) void fista_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* b0, E* b1,
+                                                            const E* __restrict__ x0, E* res, E* y0, E* y1, fista_scalars* sc,
+                                                            int n_steps, rls_mailbox_slot mb, int vec16) {
+  constexpr int NP = 16 * C;
+  constexpr int EPT = (NP + 63) / 64;
+  __shared__ E ps[NP];             // the extrapolated point y, zero beyond N
+  __shared__ E vpart[SM_WV][NP];
+  __shared__ int sdone;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cb = lane & 15, rb = tid >> 4;
+  E a[R][C];
+  small_tile_load<E, R, C>(a, A, lda, M, N, vec16, cb, rb);
+  E xk[EPT], xo[EPT], yv[EPT], x0v[EPT], ri[EPT];
+  fista_scalars S;
+  int ran = 0;
+  if (w == 0) {
+    RLS_FISTA_COPY(S, *sc);
+    const E* xc = (S.iteration & 1) ? b1 : b0;   // state.x == buf[iteration & 1]
+    const E* xp = (S.iteration & 1) ? b0 : b1;
+    const E* yc = S.ycur ? y1 : y0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = lane + 64 * e;
+      const bool ok = i < N;
+      xk[e] = ok ? xc[i] : elem<E>::zero();
+      xo[e] = ok ? xp[i] : elem<E>::zero();
+      yv[e] = ok ? yc[i] : elem<E>::zero();
+      x0v[e] = ok ? x0[i] : elem<E>::zero();
+      ri[e] = ok ? res[i] : elem<E>::zero();
+      if (i < NP) ps[i] = yv[e];
+    }
+    if (lane == 0) sdone = S.done;
+  }
+  __syncthreads();
+  for (int it = 0; it < n_steps; ++it) {
+    if (sdone) break;  // uniform
+    small_normal_partials<E, R, C>(a, ps, vpart, cb, lane, w);
+    if (w == 0) {
+      const float rho = S.rho, thr = S.rho * S.lambda;  // prox!(reg, x, rho * lambda(reg))        :164
+      E xn[EPT];
+      double rn = 0.0, d = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int i = lane + 64 * e;
+        E raw = elem<E>::zero();
+        if (i < NP) {
+#pragma unroll
+          for (int ww = 0; ww < SM_WV; ++ww) raw = elem<E>::add(raw, vpart[ww][i]);
+        }
+        E rr = elem<E>::sub(raw, x0v[e]);                                   // res .-= x0      :153
+        E xv = elem<E>::sub(yv[e], elem<E>::scale(rho, rr));                // x .-= rho .* res :154
+        xv = fista_proj_elem<E>(fista_prox_elem<E>(xv, S.reg_kind, thr), S.proj_kind);
+        if (i >= N) {
+          rr = elem<E>::zero();
+          xv = elem<E>::zero();
+        }
+        ri[e] = rr;
+        xn[e] = xv;
+        rn += (double)elem<E>::re(rr) * (double)elem<E>::re(rr) + (double)elem<E>::im(rr) * (double)elem<E>::im(rr);
+        const E df = elem<E>::sub(xv, xk[e]);
+        d += (double)elem<E>::re(rr) * (double)elem<E>::re(df) + (double)elem<E>::im(rr) * (double)elem<E>::im(df);
+      }
+      rn = wave_sum(rn);
+      d = wave_sum(d);
+      float theta = S.theta;
+      if (S.restart && d > 0.0) theta = 1.f;                                  // gradient restart  :171-176
+      const float theta_old = theta;                                          // :179
+      theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;         // :180
+      const double res_norm = sqrt(rn);
+      const float rel = (float)(res_norm / S.norm_x0);                        // :156
+      const int done = (rel < S.rel_tol) || (S.iteration + 1 >= S.max_iter);  // :187-189
+      const float c1 = (1.f - theta_old) / theta, c2 = (theta_old - 1.f) / theta + 1.f;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const E yn = elem<E>::add(elem<E>::scale(c1, xk[e]), elem<E>::scale(c2, xn[e]));
+        xo[e] = xk[e];
+        xk[e] = xn[e];
+        if (!done) {  // (a plan that stops keeps the point its last iteration was taken at, as the pipeline does)
+          yv[e] = yn;
+          const int i = lane + 64 * e;
+          if (i < NP) ps[i] = yn;
+        }
+      }
+      S.res_norm = res_norm;
+      S.rel_res_norm = (double)rel;
+      S.theta = theta;
+      S.theta_old = theta_old;
+      S.iteration += 1;
+      S.done = done;
+      if (!done) S.ycur = 1 - S.ycur;
+      ran += 1;
+      if (lane == 0) sdone = done;
+    }
+    __syncthreads();
+  }
+  if (w == 0) {
+    if (ran > 0) {
+      E* xw = (S.iteration & 1) ? b1 : b0;
+      E* xp = (S.iteration & 1) ? b0 : b1;
+      E* yw = S.ycur ? y1 : y0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int i = lane + 64 * e;
+        if (i < N) {
+          xw[i] = xk[e];
+          xp[i] = xo[e];
+          yw[i] = yv[e];
+          res[i] = ri[e];
+        }
+      }
+      S.pending = 0;
+      S.fresh = 0;
+      if (lane == 0) RLS_FISTA_COPY(*sc, S);
+    }
+    rls_mailbox_publish(mb, S, lane);
+  }
+}
+
 struct small_tile {
   int R, C;
 };
@@ -260,6 +398,32 @@ static int32_t small_typed(rls_ctx* ctx, const rls_small& D, int n_steps) {
 }
 
 }  // namespace
+
+template <typename E>
+static int32_t fista_small_typed(rls_ctx* ctx, const rls_fista_pipe& P, int n_steps) {
+  small_tile t;
+  if (!small_pick<E>(P.M, P.N, &t)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "small-system kernel: shape too large");
+  const int vec16 = (int)((reinterpret_cast<uintptr_t>(P.A) & 15) == 0 && (P.lda * (int64_t)sizeof(E)) % 16 == 0);
+#define SM_CASE(RR, CC)                                                                                                        \
+  if (t.R == RR && t.C == CC) {                                                                                                \
+    hipLaunchKernelGGL((fista_small_kernel<E, RR, CC>), dim3(1), dim3(SM_NT), 0, ctx->stream, (const E*)P.A, P.lda, (int)P.M,  \
+                       (int)P.N, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, P.sc, n_steps, P.mb, vec16); \
+  } else
+  SM_CASE(1, 1) SM_CASE(2, 2) SM_CASE(4, 2) SM_CASE(4, 4) SM_CASE(8, 4) {
+    if constexpr (!elem<E>::cplx) {
+      SM_CASE(8, 8) SM_CASE(16, 4) {}
+    }
+  }
+#undef SM_CASE
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+// a whole rls_fista_step call of a system rls_small_ok accepts (plan state in the pipeline's layout: P.b0 / b1, y0 / y1, sc)
+int32_t rls_fista_small_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, int n_steps) {
+  return dtype == RLS_F32 ? fista_small_typed<float>(ctx, P, n_steps) : fista_small_typed<float2>(ctx, P, n_steps);
+}
 
 bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (!A || M < 1 || N < 1 || lda < M) return false;

@@ -623,6 +623,7 @@ struct rls_fista {
   void* rsync = nullptr;
   unsigned* rsync_h = nullptr;
   bool resident_used = false;
+  bool small = false;         // dense A that fits ONE CU's registers: whole step calls on fista_small_kernel (small.hip)
   rls_mailbox_slot mb_arm;    // as the cgnr plan's
   bool mb_sent = false;
   bool resident_off = false;  // a resident launch was lost: the plan stays on the per-iteration pipeline (cgnr plan, above)
@@ -2596,6 +2597,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   s->use_pipe = false;
   s->res_raw1 = nullptr;
   s->use_gram = false;
+  s->small = op->A && !op->G && rls_small_ok(op->dtype, op->M, op->N, op->A, op->lda);
   const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
   hipError_t e = dmalloc(&s->y, vb);
   const bool gram = op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg);
@@ -2888,8 +2890,26 @@ static bool fista_use_gram_resident(const rls_fista* s) {
   return s->nrhs == 1 && s->use_gram && s->rsync && !s->resident_off && s->op->ctx->tune.resident;
 }
 
+// small systems: the whole step call as a single-workgroup launch, A in ONE CU's registers (as cgnr_use_small), for the
+// regularisers the fused updates cover elementwise.  The kernel keeps the plan's state in the pipeline's layout (y0 / y1 by
+// `ycur`); a plan without the pipeline's second buffer (shapes the slab kernels do not take) hands it y0 twice, which is the
+// two-GEMV path's layout.
+static bool fista_use_small(const rls_fista* s) {
+  return s->small && s->nrhs == 1 && !s->use_gram && s->op->ctx->tune.small && s->op->ctx->tune.resident &&
+         (s->reg_kind == RLS_REG_NONE || s->reg_kind == RLS_REG_L1 || s->reg_kind == RLS_REG_L2);
+}
+
 static int32_t fista_step_impl(rls_fista* s, int32_t n_steps) {
   rls_ctx* ctx = s->op->ctx;
+  if (fista_use_small(s)) {
+    if (n_steps == 0) return 0;
+    rls_fista_pipe P = fista_pipe_desc(s);
+    if (!P.y1) P.y1 = P.y0;
+    P.mb = s->mb_arm;
+    s->mb_sent = s->mb_arm.dst != nullptr;
+    s->enq += n_steps;
+    return rls_fista_small_launch(ctx, s->op->dtype, P, n_steps);
+  }
   if (s->nrhs > 1) {  // K columns share A: T = A Y, V = A^H T on the matrix cores, then one workgroup per column
     return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_batched(s); });
   }
@@ -3005,7 +3025,7 @@ static int32_t fista_fetch_status(rls_fista* s) {
 
 int32_t rls_fista_path(rls_fista* s, int32_t* out) {
   if (!s || !out) return RLS_E_INVALID;
-  *out = s->nrhs > 1 ? 3 : fista_use_gram_resident(s) ? 5 : s->use_gram ? 2 : fista_use_resident(s) ? 4 : s->use_pipe ? 1 : 0;
+  *out = fista_use_small(s) ? 8 : s->nrhs > 1 ? 3 : fista_use_gram_resident(s) ? 5 : s->use_gram ? 2 : fista_use_resident(s) ? 4 : s->use_pipe ? 1 : 0;
   return 0;
 }
 

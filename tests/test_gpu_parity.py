@@ -2266,6 +2266,71 @@ def test_cgnr_small_system_kernel(rls, ctx, dt, M, N, lam, iters):
         assert abs(sol2.state.iteration - ref2.iteration) <= 1
 
 
+@pytest.mark.parametrize("restart", ["none", "gradient"])
+@pytest.mark.parametrize("dt,M,N,kind", [(np.float32, 256, 128, "l1"), (np.float32, 32, 16, "l1"), (np.complex64, 64, 32, "l1"),
+                                         (np.complex64, 250, 61, "l1pos"), (np.float32, 37, 5, "l2"), (np.float32, 500, 60, "none")])
+def test_fista_small_system_kernel(rls, ctx, dt, M, N, kind, restart):
+    """FISTA (src/FISTA.jl:139-185) on systems that fit ONE CU's register file: a whole rls_fista_step call as a single-workgroup
+    launch (fista_small_kernel, path 8).  Iterates against the float64 oracle step by step (x, xold, res, theta, the residual
+    norm), one n-step call = n one-step calls bit for bit, the stopping test inside a launch, agreement with the slab pipeline
+    (small = 0), and a second solve on the same plan."""
+    import ctypes as C
+    A, xt, b = O.make_problem(M, N, dt, 67)
+    dt64 = hi(dt)
+    A64, b64 = A.astype(dt64), b.astype(dt64)
+    rho = 0.9 / np.linalg.norm(A64, 2) ** 2
+    lam = 2e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    def regs(R):
+        return {"l1": R.L1Regularization(lam), "l2": R.L2Regularization(lam), "none": None,
+                "l1pos": [R.L1Regularization(lam), R.PositiveRegularization()]}[kind]
+    iters = 25
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    ref = O.FISTA(A64, reg=regs(O), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    ref32 = O.FISTA(A, reg=regs(O), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    ref.init(b64); ref32.init(b)
+    sol = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    rls.init_(sol, bd)
+    path = C.c_int32(-1)
+    assert ctx.lib.rls_fista_path(sol.state._plan, C.byref(path)) == 0 and path.value == 8
+    tag = f"fista_small_{M}x{N}_{np.dtype(dt).name}_{kind}_{restart}"
+    for it in range(1, iters + 1):
+        assert ref.iterate() is not None and ref32.iterate() is not None and rls.iterate(sol) is not None
+        if it in (1, 2, 7, iters):
+            st = sol.state
+            parity(f"{tag}_x_it{it}", st.x.to_host(), ref.x, ref32.x, record=it == iters)
+            parity(f"{tag}_xold_it{it}", st.xold.to_host(), ref.xold, ref32.xold, record=False)
+            parity(f"{tag}_res_it{it}", st.res.to_host(), ref.res, ref32.res, scale=float(np.linalg.norm(ref.x0)), record=False)
+            assert abs(st.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 2e-6   # (a converged residual is Float32 noise)
+    assert rls.iterate(sol) is None and sol.state.iteration == iters
+    x_steps = sol.state.x.to_host()
+    x_once = rls.solve_(sol, bd).to_host()   # all iterations in ONE launch
+    assert np.array_equal(x_once, x_steps)
+    assert np.array_equal(rls.solve_(sol, bd).to_host(), x_once)
+    ctx.tune(small=0)
+    try:
+        sol0 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+        x_pipe = rls.solve_(sol0, bd).to_host()
+        assert ctx.lib.rls_fista_path(sol0.state._plan, C.byref(path)) == 0 and path.value != 8
+    finally:
+        ctx.tune(small=1)
+    assert rel(x_once, x_pipe) < 1e-5
+    # the stopping test inside the launch: the oracle's iteration count (+-1 at the threshold)
+    rr = []
+    probe = O.FISTA(A64, reg=regs(O), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    probe.init(b64)
+    while probe.iterate() is not None:
+        rr.append(probe.rel_res_norm)
+    tol = float(np.sqrt(rr[5] * rr[6])) if rr[6] < rr[5] else None
+    if tol is not None and min(rr[:6]) > tol:
+        ref2 = O.FISTA(A64, reg=regs(O), rho=rho, iterations=iters, relTol=tol, restart=restart)
+        O.solve(ref2, b64)
+        sol2 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=iters, relTol=tol, restart=restart)
+        x2 = rls.solve_(sol2, bd).to_host()
+        assert sol2.state.iteration == ref2.iteration == 7
+        parity(f"{tag}_reltol", x2, ref2.x, lambda: O.solve(O.FISTA(A, reg=regs(O), rho=rho, iterations=7, relTol=0.0, restart=restart), b), record=False)
+        assert np.array_equal(rls.solve_(sol2, bd).to_host(), x2)
+
+
 def test_batched_gram_resident_lost_launch_is_recovered(rls, ctx):
     """the batched resident launch (csrc/gramk.hip) under the same contract as the single-column ones: with the wait bound forced
     to one poll the launch gives up having changed nothing (only workgroup 0 writes the caller's state, after its last

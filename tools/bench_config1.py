@@ -31,3 +31,18 @@ for n in (10, 110):
     run(100); ctx.sync(); ctx.timer_start(); run(200); ts[n] = ctx.timer_stop_ms() * 1e3 / 200
 print(f"config 1 matrix-free: step(10) {ts[10]:.1f} us, step(110) {ts[110]:.1f} us incl. init -> {(ts[110] - ts[10]) / 100:.2f} us per iteration in the kernel, "
       f"{ts[10] - 10 * (ts[110] - ts[10]) / 100:.1f} us fixed (init! = GEMV + init kernel, launch, load of A, write-back)")
+# FISTA + L1 on the same system: the single-workgroup kernel (fista_small_kernel) against the slab pipeline (small = 0)
+rho = float(0.9 / np.linalg.norm(A.astype(np.float64), 2) ** 2)
+for small in (1, 0):
+    ctx.tune(small=small)
+    F = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=50, relTol=0.0)
+    rls.solve_(F, b)
+    def runf(k):
+        for _ in range(k):
+            rls.init_(F, b); ctx.lib.rls_fista_step(F.state._plan, 50)
+    runf(50); ctx.sync(); ctx.timer_start(); runf(100); us = ctx.timer_stop_ms() * 1e3 / 100
+    t0 = time.perf_counter()
+    for _ in range(100): rls.solve_(F, b)
+    ctx.sync(); wall = (time.perf_counter() - t0) / 100 * 1e6
+    print(f"FISTA + L1 256 x 128 Float32, 50 iterations, small = {small}: {us / 50:6.2f} us per iteration on the device incl. init, {wall:6.1f} us wall clock per solve_()")
+ctx.tune(small=1)
