@@ -237,7 +237,7 @@ int32_t rls_ctx_destroy(rls_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_mem_mutex);
     g_live_ctx.erase(ctx);
   }
-  hipSetDevice(ctx->device);
+  rls_enter(ctx);
   if (ctx->stream) rls_stream_wait(ctx->stream);
   rls_resident_forget(ctx->device, ctx->stream);  // (after the wait: nothing of this stream is in flight any more)
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -253,7 +253,7 @@ int32_t rls_ctx_destroy(rls_ctx* ctx) {
 
 int32_t rls_ctx_sync(rls_ctx* ctx) {
   RLS_CHECK_CTX(ctx);
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   return 0;
 }
@@ -264,6 +264,7 @@ const char* rls_last_error_string(rls_ctx* ctx) { return ctx ? ctx->err : "null 
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   RLS_CHECK_CTX(ctx);
   if (!key) return RLS_E_INVALID;
+  if (ctx->server) rls_server_stop(ctx);  // (a kernel left listening was launched under the old settings)
   if (!strcmp(key, "gemvn_g")) ctx->tune.gemvn_g = value;
   else if (!strcmp(key, "gemvn_waves")) ctx->tune.gemvn_waves = value;
   else if (!strcmp(key, "gemvt_cols")) ctx->tune.gemvt_cols = value;
@@ -281,6 +282,8 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   }
   else if (!strcmp(key, "status_mailbox")) ctx->tune.status_mailbox = value;
   else if (!strcmp(key, "small")) ctx->tune.small = value;
+  else if (!strcmp(key, "resident_server")) ctx->tune.resident_server = value;
+  else if (!strcmp(key, "resident_server_idle_us")) ctx->tune.resident_server_idle_us = value;
   else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "resident_preclear")) ctx->tune.resident_preclear = value;
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);
@@ -318,7 +321,7 @@ int32_t rls_malloc(rls_ctx* ctx, size_t bytes, void** out) {
   if (!out) return rls_fail(ctx, RLS_E_INVALID, "malloc: null out");
   *out = nullptr;
   if (bytes == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_HIP(ctx, rls_dev_alloc(ctx, out, bytes));
   return 0;
 }
@@ -332,7 +335,7 @@ int32_t rls_free(rls_ctx* ctx, void* p) {
     const hipError_t e = hipFree(p);
     return e == hipSuccess ? 0 : (int32_t)e;
   }
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (!ctx->pools) RLS_HIP(ctx, rls_stream_wait(ctx->stream));  // (hipFree synchronises the whole device anyway)
   RLS_HIP(ctx, rls_dev_free(ctx, p));   // pooled: ordered behind everything enqueued on the context's stream
   return 0;
@@ -342,7 +345,7 @@ int32_t rls_memcpy_h2d(rls_ctx* ctx, void* dst, const void* src_h, size_t bytes)
   RLS_CHECK_CTX(ctx);
   if (bytes == 0) return 0;
   if (!dst || !src_h) return rls_fail(ctx, RLS_E_INVALID, "memcpy_h2d: null pointer");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   // pageable host memory: the copy is staged, so wait for it before the caller may reuse src_h
   RLS_HIP(ctx, hipMemcpyAsync(dst, src_h, bytes, hipMemcpyHostToDevice, ctx->stream));
   RLS_HIP(ctx, rls_stream_wait(ctx->stream));
@@ -353,7 +356,7 @@ int32_t rls_memcpy_d2h(rls_ctx* ctx, void* dst_h, const void* src, size_t bytes)
   RLS_CHECK_CTX(ctx);
   if (bytes == 0) return 0;
   if (!dst_h || !src) return rls_fail(ctx, RLS_E_INVALID, "memcpy_d2h: null pointer");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_HIP(ctx, hipMemcpyAsync(dst_h, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   return 0;
@@ -363,14 +366,14 @@ int32_t rls_memcpy_d2d(rls_ctx* ctx, void* dst, const void* src, size_t bytes) {
   RLS_CHECK_CTX(ctx);
   if (bytes == 0) return 0;
   if (!dst || !src) return rls_fail(ctx, RLS_E_INVALID, "memcpy_d2d: null pointer");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }
 
 int32_t rls_timer_start(rls_ctx* ctx) {
   RLS_CHECK_CTX(ctx);
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return 0;
 }
@@ -378,7 +381,7 @@ int32_t rls_timer_start(rls_ctx* ctx) {
 int32_t rls_timer_stop_ms(rls_ctx* ctx, float* ms_out) {
   RLS_CHECK_CTX(ctx);
   if (!ms_out) return rls_fail(ctx, RLS_E_INVALID, "timer_stop: null out");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   RLS_HIP(ctx, rls_event_wait(ctx->ev1));
   RLS_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));

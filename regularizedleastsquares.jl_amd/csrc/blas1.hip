@@ -113,7 +113,7 @@ int32_t reduce_dispatch(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, c
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && (!x || (OP == RED_DOTC && !y))) || !out_d)
     return rls_fail(ctx, RLS_E_INVALID, "reduction: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32) return reduce_launch<float, OP>(ctx, n, (const float*)x, (const float*)y, out_d);
   return reduce_launch<float2, OP>(ctx, n, (const float2*)x, (const float2*)y, out_d);
 }
@@ -129,7 +129,7 @@ int32_t fetch_result(rls_ctx* ctx, float* result_h, int nfloats) {
   RLS_CHECK_CTX(ctx);                                                                        \
   if (!rls_dtype_ok(dtype) || n < 0) return rls_fail(ctx, RLS_E_INVALID, name ": bad argument"); \
   if (n == 0) return 0;                                                                      \
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
 
 static int32_t ew_status(rls_ctx* ctx) {
   hipError_t e = hipGetLastError();

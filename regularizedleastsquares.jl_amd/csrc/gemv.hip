@@ -374,7 +374,7 @@ int32_t rls_launch_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int6
     extern int32_t rls_launch_scale_or_zero(rls_ctx*, int32_t, int64_t, float, float, void*);
     return rls_launch_scale_or_zero(ctx, dtype, ny, br, bi, y);
   }
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     return gemv_typed<float>(ctx, op, M, N, ar, br, (const float*)A, lda, (const float*)x, (float*)y, skip);
   return gemv_typed<float2>(ctx, op, M, N, make_float2(ar, ai), make_float2(br, bi), (const float2*)A, lda,

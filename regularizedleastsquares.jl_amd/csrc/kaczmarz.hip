@@ -334,7 +334,7 @@ int32_t rls_transpose(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const v
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !At || lda < M || ldat < N)
     return rls_fail(ctx, RLS_E_INVALID, "transpose: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)A, lda, (float*)At, ldat,
@@ -353,7 +353,7 @@ int32_t rls_kaczmarz_sweep(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, co
       ldu < M || ldvl < M || nused < 0 || n_sweeps < 0 || (nused > 0 && (!rows_d || !denom_d)))
     return rls_fail(ctx, RLS_E_INVALID, "kaczmarz_sweep: bad argument");
   if (nused == 0 || n_sweeps == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const int V = dtype == RLS_C32 ? 2 : 4;
   const bool vec = (N % V == 0) && (ldat % V == 0) && (ldx % V == 0) && ((uintptr_t)At % 16 == 0) &&
                    ((uintptr_t)X % 16 == 0);

@@ -156,7 +156,7 @@ int32_t rls_gather(rls_ctx* ctx, int32_t dtype, int64_t m, const int32_t* idx, c
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || m < 0 || (m > 0 && (!idx || !x || !out))) return rls_fail(ctx, RLS_E_INVALID, "gather: bad argument");
   if (m == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(gather_kernel<float>, dim3(ns_grid(m)), dim3(NS_THREADS), 0, ctx->stream, idx, m, (const float*)x, (float*)out);
   else
@@ -168,7 +168,7 @@ int32_t rls_scatter(rls_ctx* ctx, int32_t dtype, int64_t m, const int32_t* idx, 
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || m < 0 || (m > 0 && (!idx || !x || !in))) return rls_fail(ctx, RLS_E_INVALID, "scatter: bad argument");
   if (m == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(scatter_kernel<float>, dim3(ns_grid(m)), dim3(NS_THREADS), 0, ctx->stream, idx, m, (const float*)in, (float*)x);
   else
@@ -179,7 +179,7 @@ int32_t rls_scatter(rls_ctx* ctx, int32_t dtype, int64_t m, const int32_t* idx, 
 int32_t rls_stats(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, double* out_h) {
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || n <= 0 || !x || !out_h) return rls_fail(ctx, RLS_E_INVALID, "stats: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   int nwg = (int)((n + 8191) / 8192);
   const int cap = RLS_RED_SLOTS / NSTAT - 1;
   if (nwg > cap) nwg = cap;
@@ -199,7 +199,7 @@ int32_t rls_shift_scale(rls_ctx* ctx, int64_t n, float* x, float shift, float sc
   RLS_CHECK_CTX(ctx);
   if (n < 0 || (n > 0 && !x)) return rls_fail(ctx, RLS_E_INVALID, "shift_scale: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   hipLaunchKernelGGL(shift_scale_kernel, dim3(ns_grid(n)), dim3(NS_THREADS), 0, ctx->stream, x, n, shift, scale, inverse ? 1 : 0);
   return ns_status(ctx);
 }
@@ -208,7 +208,7 @@ int32_t rls_clamp(rls_ctx* ctx, int64_t n, float* x, float lo, float hi) {
   RLS_CHECK_CTX(ctx);
   if (n < 0 || (n > 0 && !x)) return rls_fail(ctx, RLS_E_INVALID, "clamp: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   hipLaunchKernelGGL(clamp_kernel, dim3(ns_grid(n)), dim3(NS_THREADS), 0, ctx->stream, x, n, lo, hi);
   return ns_status(ctx);
 }
@@ -217,7 +217,7 @@ int32_t rls_restore_outside(rls_ctx* ctx, int64_t n, float* out, const float* or
   RLS_CHECK_CTX(ctx);
   if (n < 0 || (n > 0 && (!out || !orig))) return rls_fail(ctx, RLS_E_INVALID, "restore_outside: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   hipLaunchKernelGGL(restore_outside_kernel, dim3(ns_grid(n)), dim3(NS_THREADS), 0, ctx->stream, out, orig, n, lo, hi);
   return ns_status(ctx);
 }
@@ -226,7 +226,7 @@ int32_t rls_complex_split(rls_ctx* ctx, int64_t n, const void* z, float* re, flo
   RLS_CHECK_CTX(ctx);
   if (n < 0 || (n > 0 && (!z || !re || !im))) return rls_fail(ctx, RLS_E_INVALID, "complex_split: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   hipLaunchKernelGGL(split_kernel, dim3(ns_grid(n)), dim3(NS_THREADS), 0, ctx->stream, (const float2*)z, n, re, im);
   return ns_status(ctx);
 }
@@ -235,7 +235,7 @@ int32_t rls_complex_merge(rls_ctx* ctx, int64_t n, const float* re, const float*
   RLS_CHECK_CTX(ctx);
   if (n < 0 || (n > 0 && (!z || !re || !im))) return rls_fail(ctx, RLS_E_INVALID, "complex_merge: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   hipLaunchKernelGGL(merge_kernel, dim3(ns_grid(n)), dim3(NS_THREADS), 0, ctx->stream, re, im, n, (float2*)z);
   return ns_status(ctx);
 }

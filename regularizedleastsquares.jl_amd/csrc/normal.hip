@@ -1955,7 +1955,11 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     }
   };
   if (blockIdx.x == 0) store_owned(xw, xv);
+  rls_mailbox_slot srv_mb = St.srv_mb;
+  unsigned srv_seq = St.srv_seq0;  // the command being served; the host's next one carries srv_seq + 1
+  for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = 0; it < n_steps; ++it) {
+    if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
     STAMP(8);
     // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through)
     if constexpr (OWN) {
@@ -2060,6 +2064,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   }
   if (!alive) {
     resident_give_up(sync, St.enabled ? St.poison : nullptr);
+    if (St.srv_ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;  // x, r, p and the scalars are untouched: the call was a no-op
   }
   if (blockIdx.x == 0) {
@@ -2080,13 +2085,56 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     store_buf(x, xf);
     store_buf(r, rv);
     store_buf(p, pv);
+    S.pending = 0;
+    S.cur = 0;
+    S.fresh = 0;
     if (tid == 0) {
-      S.pending = 0;
-      S.cur = 0;
-      S.fresh = 0;
       *sc = S;
       sync->completed = 1u;
     }
+    if (St.srv_ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
+  }
+  if (!St.srv_ctl) break;  // uniform
+  // ---- server mode: listen for the next command (workgroup 0 polls the host's control block; the grid waits at a barrier) ----
+  if (blockIdx.x == 0 && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back above is out before anything else is announced)
+    unsigned* ctl = St.srv_ctl;
+    const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)St.srv_idle_us * 100ull;  // 100 MHz
+    unsigned n = RLS_SRV_EXIT, seq;
+    for (;;) {
+      seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seq != srv_seq) break;
+      if (wall_clock64() - t0 > idle) {
+        // leave -- unless a command slips in: "leaving" goes out, THEN the sequence word is read once more (the host posts
+        // its command and THEN reads "leaving": one of the two sees the other)
+        __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&sync->srv_n, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sync->srv_mb, __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
+    resident_give_up(sync, nullptr);
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const unsigned cmd = __hip_atomic_load(&sync->srv_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (cmd == RLS_SRV_EXIT) {  // uniform
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  n_steps = (int)cmd;
+  srv_mb.seq = __hip_atomic_load(&sync->srv_mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  srv_seq += 1;
   }
 }
 
@@ -3471,7 +3519,7 @@ int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t 
                                 const void* p, void* v, void* slab, const int* skip) {
   RLS_CHECK_CTX(ctx);
   if (!A || !p || !v || !slab) return rls_fail(ctx, RLS_E_INVALID, "normal_fused: null pointer");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     return normal_typed<float>(ctx, M, N, (const float*)A, lda, (const float*)p, (float*)v, (float*)slab, skip);
   return normal_typed<float2>(ctx, M, N, (const float2*)A, lda, (const float2*)p, (float2*)v, (float2*)slab, skip);

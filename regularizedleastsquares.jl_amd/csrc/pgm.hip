@@ -185,7 +185,7 @@ static int32_t optista_launch(rls_ctx* ctx, int32_t dtype, int64_t n, void* res,
   if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !x || !y || !z || !zold || reg_kind < RLS_REG_NONE ||
       reg_kind > RLS_REG_L2)
     return rls_fail(ctx, RLS_E_INVALID, "optista_update: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(optista_update_kernel<float>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float*)res,
                        (const float*)x0, (float*)x, (float*)y, (float*)z, (float*)zold, n, step, reg_kind, thr, c_z, c_y,
@@ -226,7 +226,7 @@ static int32_t pogm_launch(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, co
   if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !xbuf || !ybuf || !xold || !z || (restart && !w) ||
       reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2 || proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE)
     return rls_fail(ctx, RLS_E_INVALID, "pogm_update: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
 #define RLS_POGM(EE, RR)                                                                                             \
   hipLaunchKernelGGL((pogm_update_kernel<EE, RR>), dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (EE*)res, (const EE*)x0, \
                      (EE*)xbuf, (EE*)ybuf, (EE*)xold, (EE*)z, (EE*)w, n, rho, c_y, c_x1, c_xo, c_z, reg_kind, thr,     \
@@ -276,7 +276,7 @@ int32_t rls_pogm_update_auto(rls_ctx* ctx, int32_t dtype, int64_t n, void* res, 
   if (!rls_dtype_ok(dtype) || n <= 0 || !res || !x0 || !xbuf || !ybuf || !xold || !z || !w || !state_d ||
       reg_kind < RLS_REG_NONE || reg_kind > RLS_REG_L2 || proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE)
     return rls_fail(ctx, RLS_E_INVALID, "pogm_update_auto: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(pogm_auto_kernel<float>, dim3(1), dim3(PGM_THREADS), 0, ctx->stream, (float*)res, (const float*)x0,
                        (float*)xbuf, (float*)ybuf, (float*)xold, (float*)z, (float*)w, n, rho, lambda, sigma_fac,

@@ -97,7 +97,7 @@ static int32_t px_status(rls_ctx* ctx) {
   RLS_CHECK_CTX(ctx);                                                                              \
   if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && !x)) return rls_fail(ctx, RLS_E_INVALID, name ": bad argument"); \
   if (n == 0) return 0;                                                                            \
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
 
 }  // namespace
 
@@ -156,7 +156,7 @@ int32_t rls_norm_l21(rls_ctx* ctx, int32_t dtype, int64_t n, int64_t slices, con
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || n <= 0 || !x || !result_h || slices <= 0 || n / slices == 0)
     return rls_fail(ctx, RLS_E_INVALID, "norm_l21: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const int64_t slen = n / slices;
   unsigned g = px_grid(slen);
   if (g > RLS_RED_SLOTS / 2) g = RLS_RED_SLOTS / 2;

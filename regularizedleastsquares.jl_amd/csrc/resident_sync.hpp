@@ -46,7 +46,8 @@ struct resident_sync {
                          // creation and by the HOST once a status call has seen it (resident_lost: it re-runs what the current
                          // solve is missing and retires the plan from the resident kernels); init! does NOT clear it, so a loss
                          // nobody asked about is still reported -- by the next status call, of whichever solve.
-  unsigned pad[29];
+  unsigned srv_n, srv_mb;  // server mode: the command workgroup 0 relays to the grid (n_steps or RLS_SRV_EXIT, mailbox sequence)
+  unsigned pad[27];
 };
 static_assert(sizeof(resident_sync) == (2 * 8 * 32 + 32) * sizeof(unsigned), "resident_sync layout");
 // behind the sync block (same allocation): the group-partial vectors of the two-level exchange, [2 parities][8 groups][N]

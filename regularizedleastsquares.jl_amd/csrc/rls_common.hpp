@@ -29,6 +29,8 @@ struct rls_tuning {
   int resident = 1;       // 1: single-RHS matrix-free CGNR whose A fits the register files runs a whole step call as
                           // ONE launch (normal.hip, cgnr_resident_kernel)
   int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
+  int resident_server = 1;     // 1: rls_cgnr_step_status leaves the resident kernel listening for the next call (rls_cg_start::srv_ctl)
+  int resident_server_idle_us = 300;  // ... for this long
   int small = 1;               // 1: systems that fit ONE CU's registers run a whole step call as a single-workgroup launch (small.hip)
   int status_mailbox = 2;      // >= 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
                                // sequence word (rls_fetch_*); 2: and rls_*_step_status has the call's LAST kernel do that
@@ -40,6 +42,7 @@ struct rls_tuning {
 
 struct rls_ctx {
   int device = 0;
+  void* server = nullptr;  // the plan whose resident kernel is alive in server mode on this context's stream (rls_server_stop)
   uint64_t id = 0;  // unique per context ever created in this process (a plan that outlives its context compares it: rls_ctx_alive)
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -119,6 +122,14 @@ hipError_t rls_dev_alloc(rls_ctx* ctx, void** p, size_t bytes);
 hipError_t rls_dev_free(rls_ctx* ctx, void* p);   // ctx may be null (or destroyed: pass null): synchronous hipFree
 hipError_t rls_pinned_alloc(void** p, size_t bytes);
 void rls_pinned_free(void* p);
+// Every entry point that is about to put work on the context's stream (or to tear something down) comes through here: a resident
+// kernel left listening in server mode (rls_cgnr_step_status) is asked to leave first -- anything queued behind it would otherwise
+// wait for its idle timeout.
+void rls_server_stop(rls_ctx* ctx);
+static inline hipError_t rls_enter(rls_ctx* ctx) {
+  if (ctx->server) rls_server_stop(ctx);
+  return hipSetDevice(ctx->device);
+}
 bool rls_ctx_alive(const rls_ctx* ctx, uint64_t id);  // this very context (same address AND same generation id) still exists
 // The allocation calls of a plan's create / destroy function go to the context named by the innermost live scope on
 // this thread (null: the synchronous calls).
@@ -688,7 +699,19 @@ struct rls_cg_start {
   const int* skip = nullptr;
   int* poison = nullptr;  // ADMM plans: set to 2 by a launch that gives up (resident_give_up), so that the kernels queued
                           // behind this cg! skip; the host re-runs the lost outer iterations from rls_admm_get_status
+  // ---- server mode (rls_cgnr_step_status, the reference's solve! loop with callbacks: one iterate per call) ----------------------
+  // srv_ctl != nullptr: after its step call the kernel does not end; workgroup 0 publishes the status (srv_mb), then LISTENS on a
+  // control block in pinned host memory for the next command -- {sequence number, n_steps, mailbox sequence} -- and the grid runs
+  // it from the registers it already holds: no launch, no load of A per call.  It leaves when nothing arrives for srv_idle_us
+  // (or on an EXIT command: every other entry point of the library sends one before it touches the stream, rls_enter).
+  // Layout (32-bit words): [0] command sequence  [1] n_steps  [2] mailbox sequence   (host writes)
+  //                        [16] leaving  [17] exited: 1 = left idle / on EXIT, 2 = gave up inside a command   (device writes)
+  unsigned* srv_ctl = nullptr;
+  unsigned srv_seq0 = 0;      // the command sequence number this launch starts with (its n_steps is the launch argument)
+  unsigned srv_idle_us = 0;
+  rls_mailbox_slot srv_mb;
 };
+constexpr unsigned RLS_SRV_EXIT = 0xffffffffu;
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
                                  int n_steps, unsigned spin_limit, const rls_cg_start& start = rls_cg_start());
 

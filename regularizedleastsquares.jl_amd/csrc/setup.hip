@@ -44,7 +44,7 @@ int32_t rls_rownorm2(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const vo
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !out_d || lda < M)
     return rls_fail(ctx, RLS_E_INVALID, "rownorm2: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const int CS = (int)(N < 64 ? N : 64);
   float* partial = nullptr;
   RLS_HIP(ctx, hipMalloc((void**)&partial, sizeof(float) * (size_t)CS * (size_t)M));
@@ -67,7 +67,7 @@ int32_t rls_scale_rows(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const 
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || M <= 0 || N <= 0 || !w || !A || !B || lda < M || ldb < M)
     return rls_fail(ctx, RLS_E_INVALID, "scale_rows: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const dim3 grid((unsigned)((M + 255) / 256), (unsigned)(N < 256 ? N : 256));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(scale_rows_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)w, (const float*)A, lda,

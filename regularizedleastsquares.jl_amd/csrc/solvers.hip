@@ -163,6 +163,13 @@ struct rls_cgnr {
   unsigned* rsync_h;  // pinned: {fail, completed, failed} (resident_sync), read with the status
   bool resident_used;
   rls_mailbox_slot mb_arm;  // step_status: the call's last kernel publishes the scalars (pipeline and small-system paths)
+  // server mode of the resident kernel (rls_cg_start::srv_ctl): the control block in pinned host memory and what the host knows
+  unsigned* srv_ctl = nullptr;
+  bool srv_alive = false;   // a kernel of this plan was left listening (it may have left on its own since: srv_ctl[17])
+  bool srv_fresh = false;   // ... and the status mirror holds the status of its last command
+  bool srv_off = false;     // lives that served fewer than three commands, twice in a row (the caller touches the device between
+  int srv_served = 0, srv_short = 0;  // iterates: a listening kernel only stands in its way): per-iteration pipeline until init!
+  unsigned srv_seq = 0;
   bool mb_sent = false;     // ... and this call's path did take the slot
   bool gram_resident;  // Gram mode: AHA fits the register files (rls_gram_resident_ok)
   // a resident launch whose workgroups were not all on the chip in time is a no-op (normal.hip); the status call re-runs
@@ -1877,7 +1884,7 @@ int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, c
   RLS_CHECK_CTX(ctx);
   if (!out || !rls_dtype_ok(dtype) || M < 0 || N <= 0) return rls_fail(ctx, RLS_E_INVALID, "operator_create: bad argument");
   if (A && (M <= 0 || lda < M)) return rls_fail(ctx, RLS_E_INVALID, "operator_create: bad shape/lda");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_alloc_scope alloc_scope(ctx);
   rls_operator* op = new rls_operator();
   op->ctx = ctx;
@@ -1937,7 +1944,7 @@ int32_t rls_operator_mul_normal_skip(rls_operator* op, const void* p, void* v, c
   if (!op) return RLS_E_INVALID;
   rls_ctx* ctx = op->ctx;
   if (!p || !v) return rls_fail(ctx, RLS_E_INVALID, "operator_mul_normal_skip: null pointer");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   return op_normal(op, p, v, (const int*)skip_d);
 }
 
@@ -1950,7 +1957,7 @@ int32_t rls_gram(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* 
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !G || lda < M || ld < N)
     return rls_fail(ctx, RLS_E_INVALID, "gram: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (ctx->tune.batched_mfma && rls_gram_tiles_ok(M, N) && rls_skinny_ok(dtype, M, N, A, lda))
     return rls_gram_tiles(ctx, dtype, M, N, A, lda, G, ld);  // Hermitian 64 x 64 tiles, no scratch
   if (ctx->tune.batched_mfma && N <= 65535 * 16 && rls_skinny_ok(dtype, M, N, A, lda)) {
@@ -1981,7 +1988,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   rls_ctx* ctx = op->ctx;
   if (!x || !r || !p || !v || !out || nrhs < 1 || ldv < op->N)
     return rls_fail(ctx, RLS_E_INVALID, "cgnr_create: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   // the columns share solver.AHA (src/MultiThreading.jl:30-48): an explicit Gram matrix when the operator has one -- the
   // reference constructors' default for a dense matrix, src/CGNR.jl:49 --, otherwise the two products over A
   const bool skinny = nrhs > 1 && ctx->tune.batched_mfma && rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda) &&
@@ -2049,6 +2056,8 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
     if (e == hipSuccess) e = dmalloc(&s->rdots, db);
     if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
+    if (e == hipSuccess) e = hmalloc(&s->srv_ctl, 32 * sizeof(unsigned));
+    if (e == hipSuccess) memset(s->srv_ctl, 0, 32 * sizeof(unsigned));
   }
   if (e == hipSuccess && nrhs == 1 && op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
@@ -2109,6 +2118,7 @@ int32_t rls_cgnr_create_batched(rls_operator* op, int32_t nrhs, void* X, void* R
 
 int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (!s) return RLS_E_INVALID;
+  if (rls_ctx_alive(s->actx, s->actx_id) && s->actx->server == s) rls_server_stop(s->actx);  // (a kernel of this plan left listening)
   hipSetDevice(s->device);
   rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx, s->actx_id));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
@@ -2128,6 +2138,7 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->rsync) dfree(s->rsync);
   if (s->rdots) dfree(s->rdots);
   if (s->rsync_h) hfree(s->rsync_h);
+  if (s->srv_ctl) hfree(s->srv_ctl);
   if (s->sc) dfree(s->sc);
   if (s->sc_h) hfree(s->sc_h);
   delete s;
@@ -2140,7 +2151,7 @@ int32_t rls_cgnr_init_local_a(rls_cgnr* s, const void* b, float lambda, float re
   rls_ctx* ctx = op->ctx;
   if (!b) return rls_fail(ctx, RLS_E_INVALID, "cgnr_init: null b");
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "cgnr_init on a batched plan: use rls_cgnr_init_batched");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   // r = A^H b   (initCGNR, src/CGNR.jl:132) ; without A, b already is A^H b (:134)
   if (op->A)
     RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, b, 0.f, 0.f, s->r, nullptr));
@@ -2155,13 +2166,15 @@ int32_t rls_cgnr_init_local_a(rls_cgnr* s, const void* b, float lambda, float re
 int32_t rls_cgnr_init_local_b(rls_cgnr* s) {
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (s->op->dtype == RLS_F32)
     cgnr_launch_init<float>(s, s->sc_h->lambda, s->sc_h->rel_tol, s->sc_h->max_iter);
   else
     cgnr_launch_init<float2>(s, s->sc_h->lambda, s->sc_h->rel_tol, s->sc_h->max_iter);
   s->initialised = true;
   s->requested = 0;
+  s->srv_off = false;  // (a new solve: the caller's pattern between iterates is judged afresh)
+  s->srv_short = 0;
   return launch_status(ctx);
 }
 
@@ -2175,7 +2188,7 @@ int32_t rls_cgnr_init_batched(rls_cgnr* s, const void* B, int64_t ldb, float lam
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
   if (!B || !op->A || ldb < op->M) return rls_fail(ctx, RLS_E_INVALID, "cgnr_init_batched: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const size_t es = rls_elem_size(op->dtype);
   const int max_iter = cgnr_effective_iterations(s, iterations);
   if (s->skinny) {
@@ -2216,7 +2229,7 @@ int32_t rls_cgnr_get_status_batched(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (s->resident_used) RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
   RLS_TRY(rls_fetch_add(ctx, s->sc, s->sc_h, sizeof(cgnr_scalars) * (size_t)s->nrhs));
   RLS_TRY(rls_fetch_wait(ctx));
@@ -2366,7 +2379,7 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step before cgnr_init");
   if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr_step: n_steps < 0");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   s->requested += n_steps;
   return cgnr_step_impl(s, n_steps);
 }
@@ -2381,7 +2394,7 @@ int32_t rls_cgnr_step_profiled(rls_cgnr* s, int32_t n_steps, float* us_normal, f
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_step_profiled before cgnr_init");
   if (!cgnr_use_pipeline(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr_step_profiled: fused pipeline not active");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_cgnr_pipe P = cgnr_pipe_desc(s);
   const int32_t dtype = s->op->dtype;
   RLS_TRY(rls_cgnr_pipe_iteration(ctx, dtype, P));  // leaves an update pending: K_A then does full work
@@ -2530,7 +2543,11 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->server == s && s->srv_alive && s->srv_fresh) {  // a kernel left listening: the mirror holds its last command's status
+    cgnr_status_out(s, *s->sc_h, out);
+    return 0;
+  }
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_TRY(cgnr_fetch_status(s));
   cgnr_status_out(s, *s->sc_h, out);
   return 0;
@@ -2549,14 +2566,140 @@ static void cgnr_status_out(const rls_cgnr* s, const cgnr_scalars& h, rls_cgnr_s
   out->fallbacks = s->fallbacks;
 }
 
+// ---- the resident kernel in server mode (rls_cg_start::srv_ctl) ---------------------------------------------------------------
+// rls_cgnr_step_status on a plan whose A lives in the register files does not let the kernel end: the next call posts
+// {n_steps, mailbox sequence, command sequence} into the pinned control block the kernel listens on and spins on the mailbox --
+// no launch, no load of A per call.  Everything else that wants the stream sends EXIT first (rls_enter -> rls_server_stop).
+static bool cgnr_use_server(const rls_cgnr* s) {
+  const rls_ctx* ctx = s->op->ctx;
+  return ctx->tune.resident_server && ctx->tune.status_mailbox && s->srv_ctl && !s->srv_off && cgnr_use_resident(s) &&
+         (ctx->server == nullptr || ctx->server == s);
+}
+
+// the life of a listening kernel is over (it was told to leave, left idle, or gave up): bookkeeping, and the verdict on lives
+// too short to pay for their launch
+static void server_life_over(rls_ctx* ctx, rls_cgnr* s) {
+  if (s->srv_alive) {
+    if (s->srv_served < 3) {
+      if (++s->srv_short >= 2) s->srv_off = true;
+    } else {
+      s->srv_short = 0;
+    }
+  }
+  s->srv_alive = false;
+  s->srv_fresh = false;
+  s->resident_used = true;  // the next status call reads the flags of the sync block (a launch lost inside that life is re-run)
+  if (ctx->server == s) ctx->server = nullptr;
+}
+
+extern "C++" void rls_server_stop(rls_ctx* ctx) {
+  rls_cgnr* s = static_cast<rls_cgnr*>(ctx->server);
+  if (!s) return;
+  if (s->srv_alive) {
+    volatile unsigned* ctl = s->srv_ctl;
+    if (!ctl[17]) {
+      ctl[1] = RLS_SRV_EXIT;
+      std::atomic_thread_fence(std::memory_order_release);
+      ctl[0] = ++s->srv_seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned n = 0; !ctl[17]; ++n) {
+        rls_cpu_relax();
+        if ((n & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) {
+          (void)hipSetDevice(ctx->device);
+          (void)hipStreamSynchronize(ctx->stream);  // (its idle timeout or its wait bounds end it at the latest)
+          break;
+        }
+      }
+    }
+  }
+  server_life_over(ctx, s);
+}
+
+// 0: the command was served (status in the mirror); 1: the kernel had left before it saw the command; 2: it gave up inside it
+static int server_wait(rls_ctx* ctx, rls_cgnr* s, unsigned mbseq) {
+  volatile unsigned* mb = ctx->mb_h;
+  volatile unsigned* ctl = s->srv_ctl;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned n = 0;; ++n) {
+    if (*mb == mbseq) break;
+    const unsigned ex = ctl[17];
+    if (ex) {  // (the status of a served command is published before the kernel can leave: look once more)
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (*mb == mbseq) break;
+      return (int)ex;
+    }
+    rls_cpu_relax();
+    if ((n & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      (void)hipStreamSynchronize(ctx->stream);
+      if (*mb == mbseq) break;
+      return ctl[17] == 1 ? 1 : 2;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
+extern "C" int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out);
+static int32_t cgnr_step_status_server(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out) {
+  rls_ctx* ctx = s->op->ctx;
+  RLS_HIP(ctx, hipSetDevice(s->device));
+  s->requested += n_steps;
+  volatile unsigned* ctl = s->srv_ctl;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const unsigned mbseq = ++ctx->mb_seq;
+    if (s->srv_alive) {  // post the command: payload, then the sequence word
+      ctl[1] = (unsigned)n_steps;
+      ctl[2] = mbseq;
+      std::atomic_thread_fence(std::memory_order_release);
+      ctl[0] = ++s->srv_seq;
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+    } else {
+      ctl[16] = ctl[17] = 0;
+      ctl[0] = s->srv_seq;
+      rls_cg_start St;
+      St.srv_ctl = s->srv_ctl;
+      St.srv_seq0 = s->srv_seq;
+      St.srv_idle_us = (unsigned)(ctx->tune.resident_server_idle_us > 0 ? ctx->tune.resident_server_idle_us : 1);
+      St.srv_mb.dst = s->sc_h;
+      St.srv_mb.seq_h = ctx->mb_h;
+      St.srv_mb.seq = mbseq;
+      const rls_cgnr_pipe P = cgnr_pipe_desc(s);
+      RLS_TRY(resident_chain(ctx, s->rsync, [&]() {
+        return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, St);
+      }, &s->rsync_clean));
+      s->srv_alive = true;
+      s->srv_served = 0;
+      ctx->server = s;
+    }
+    const int r = server_wait(ctx, s, mbseq);
+    if (r == 0) {
+      s->srv_served += 1;
+      s->srv_fresh = true;
+      cgnr_status_out(s, *s->sc_h, out);
+      return 0;
+    }
+    server_life_over(ctx, s);
+    if (r == 2) break;  // gave up inside the command: the lost-launch recovery below re-runs it
+    // r == 1: it had left (idle) before it saw the command -- nothing ran.  Once more with a launch, or -- this plan's lives
+    // keep ending early -- on the ordinary path
+    if (attempt == 1 || !cgnr_use_server(s)) {
+      s->requested -= n_steps;
+      s->srv_off = true;
+      return rls_cgnr_step_status(s, n_steps, out);
+    }
+  }
+  return rls_cgnr_get_status(s, out);  // (reads the sync block's flags: iterations a lost launch did not run are re-run here)
+}
+
 // One iterate per call is the reference's solve! loop with callbacks (src/RegularizedLeastSquares.jl:161-176): step and read-back
 // as ONE entry point, and on the per-iteration pipeline and the small-system kernel the call's last kernel stores the scalars into
 // the plan's pinned mirror itself -- no publishing launch behind it.
 int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
+  if (s->initialised && n_steps > 0 && !s->resident_used && cgnr_use_server(s)) return cgnr_step_status_server(s, n_steps, out);
   if (s->initialised && s->nrhs == 1 && n_steps > 0 && !s->resident_used) {
-    RLS_HIP(ctx, hipSetDevice(ctx->device));
+    RLS_HIP(ctx, rls_enter(ctx));
     s->mb_arm = rls_mailbox_arm(ctx, s->sc_h);
   }
   s->mb_sent = false;
@@ -2575,7 +2718,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   if (!op) return RLS_E_INVALID;
   rls_ctx* ctx = op->ctx;
   if (!x || !x0 || !xold || !res || !out) return rls_fail(ctx, RLS_E_INVALID, "fista_create: null pointer");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_alloc_scope alloc_scope(ctx);
   rls_fista* s = new rls_fista();
   s->op = op;
@@ -2688,7 +2831,7 @@ int32_t rls_fista_init_local_a(rls_fista* s, const void* b) {
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
   if (!b) return rls_fail(ctx, RLS_E_INVALID, "fista_init: null b");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (op->A)
     RLS_TRY(rls_launch_gemv(ctx, op->dtype, RLS_OP_C, op->M, op->N, 1.f, 0.f, op->A, op->lda, b, 0.f, 0.f, s->x0, nullptr));
   else
@@ -2700,7 +2843,7 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
                                  int32_t restart_gradient, bool local) {
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(fista_init_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)s->buf[0],
                        (float*)s->buf[1], (float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc, rho, theta,
@@ -2747,7 +2890,7 @@ int32_t rls_fista_step_local_a(rls_fista* s) {
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised || s->use_pipe || s->use_gram) return rls_fail(ctx, RLS_E_STATE, "fista_step_local before fista_init_local_b");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   return op_normal(s->op, s->y, s->res, &s->sc->done);
 }
 int32_t rls_fista_step_local_b(rls_fista* s) {
@@ -2755,7 +2898,7 @@ int32_t rls_fista_step_local_b(rls_fista* s) {
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
   if (!s->initialised || s->use_pipe || s->use_gram) return rls_fail(ctx, RLS_E_STATE, "fista_step_local before fista_init_local_b");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (op->dtype == RLS_F32)
     fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0});
   else
@@ -2774,7 +2917,7 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   if (!op->A || !ctx->tune.batched_mfma || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda) ||
       (op->G && !rls_skinny_ok(op->dtype, op->N, op->N, op->G, op->ldg)))
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "batched FISTA needs A (and AHA, when explicit) with 16-aligned M, N (matrix-core path)");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_alloc_scope alloc_scope(ctx);
   rls_fista* s = new rls_fista();
   s->op = op;
@@ -2831,7 +2974,7 @@ int32_t rls_fista_init_batched(rls_fista* s, const void* B, int64_t ldb, float r
   rls_ctx* ctx = op->ctx;
   if (s->nrhs < 2 && !s->Ypack) return rls_fail(ctx, RLS_E_STATE, "fista_init_batched on a single-column plan");
   if (!B || ldb < op->M) return rls_fail(ctx, RLS_E_INVALID, "fista_init_batched: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_TRY(rls_skinny_atb(ctx, op->dtype, fista_skinny_desc(s), B, ldb));  // partial rows of A^H B   (src/FISTA.jl:114)
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(fista_init_kernel<float>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
@@ -2852,7 +2995,7 @@ int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised || !s->scb_h) return rls_fail(ctx, RLS_E_STATE, "fista_get_status_batched: not a batched, initialised plan");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_HIP(ctx, hipMemcpyAsync(s->scb_h, s->sc, sizeof(fista_scalars) * s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
   RLS_HIP(ctx, rls_stream_wait(ctx->stream));
   for (int b = 0; b < s->nrhs; ++b) {
@@ -2876,7 +3019,7 @@ int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n) {
   if (!x_init) return rls_fail(ctx, RLS_E_INVALID, "fista_set_start: null pointer");
   if (n != s->op->N) return rls_fail(ctx, RLS_E_INVALID, "fista_set_start: x_init must have the solution's length N");
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista_set_start on a batched plan");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const size_t bytes = (size_t)s->op->N * rls_elem_size(s->op->dtype);
   // iteration 0: state.x == buf[0], xold == 0; the first extrapolated point (src/FISTA.jl:147-148 with
   // thetaold == theta) is ((theta - 1) / theta + 1) x0 -- x0 itself only for the default theta = 1
@@ -2994,7 +3137,7 @@ int32_t rls_fista_step(rls_fista* s, int32_t n_steps) {
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_step before fista_init");
   if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "fista_step: n_steps < 0");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   s->requested += n_steps;
   return fista_step_impl(s, n_steps);
 }
@@ -3044,7 +3187,7 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_get_status before fista_init");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_TRY(fista_fetch_status(s));
   fista_status_out(s, *s->sc_h, out);
   return 0;
@@ -3054,7 +3197,7 @@ int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* o
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (s->initialised && s->nrhs == 1 && n_steps > 0 && !s->resident_used) {
-    RLS_HIP(ctx, hipSetDevice(ctx->device));
+    RLS_HIP(ctx, rls_enter(ctx));
     s->mb_arm = rls_mailbox_arm(ctx, s->sc_h);
   }
   s->mb_sent = false;
@@ -3072,7 +3215,7 @@ int32_t rls_fista_solution(rls_fista* s, void** x_out) {
   if (!s || !x_out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_solution before fista_init");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_TRY(fista_fetch_status(s));
   *x_out = s->buf[s->sc_h->iteration & 1];
   return 0;
@@ -3083,7 +3226,7 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
   if (!op) return RLS_E_INVALID;
   rls_ctx* ctx = op->ctx;
   if (!u || !r || !c || !out) return rls_fail(ctx, RLS_E_INVALID, "cg_create: null pointer");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_alloc_scope alloc_scope(ctx);
   rls_cg* s = new rls_cg();
   s->op = op;
@@ -3163,7 +3306,7 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
   if (!op->A || !rls_skinny_ok(op->dtype, op->M, op->N, op->A, op->lda) ||
       (op->G && !rls_skinny_ok(op->dtype, op->N, op->N, op->G, op->ldg)))
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "cg_create_batched: needs A (and AHA, when explicit) with M, N multiples of 16");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_alloc_scope alloc_scope(ctx);
   rls_cg* s = new rls_cg();
   s->op = op;
@@ -3227,7 +3370,7 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
   rls_ctx* ctx = s->op->ctx;
   if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_solve: bad argument");
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "cg_solve on a batched plan: batched cg! runs inside rls_admm_step");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   s->last.x = x;
   s->last.b = b;
   s->last.rho = rho;
@@ -3245,7 +3388,7 @@ int32_t rls_cg_solve(rls_cg* s, void* x, const void* b, float rho, int32_t maxit
 int32_t rls_cg_local_apply(rls_cg* s, const void* x) {
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   return x ? op_normal(s->op, x, s->c, nullptr) : op_normal(s->op, s->u, s->c, &s->sc->done);
 }
 
@@ -3254,7 +3397,7 @@ int32_t rls_cg_local_start(rls_cg* s, const void* x, const void* b, float rho, i
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
   if (!x || !b || maxiter < 0) return rls_fail(ctx, RLS_E_INVALID, "cg_local_start: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   s->used_pipeline = false;
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(cg_start_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
@@ -3272,7 +3415,7 @@ int32_t rls_cg_local_update(rls_cg* s, void* x) {
   rls_operator* op = s->op;
   rls_ctx* ctx = op->ctx;
   if (!x) return rls_fail(ctx, RLS_E_INVALID, "cg_local_update: null x");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(cg_update_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (float*)x, (float*)s->u,
                        (float*)s->r, (float*)s->c, op->N, s->sc, col_batch<float>());
@@ -3304,7 +3447,7 @@ int32_t rls_pgm_create(rls_operator* op, rls_pgm** out) {
   if (!op || !out) return RLS_E_INVALID;
   rls_ctx* ctx = op->ctx;
   *out = nullptr;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (!(op->slab && op->A && !op->G && rls_pgm_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)))
     return RLS_E_UNSUPPORTED;  // (not an error state: the caller keeps its launch-per-iteration sequence)
   rls_alloc_scope alloc_scope(ctx);
@@ -3352,7 +3495,7 @@ int32_t rls_pgm_step_resident(rls_pgm* s, int32_t kind, int32_t n_steps, int32_t
     return rls_fail(ctx, RLS_E_INVALID, "pgm_step_resident: vectors must be 16-byte aligned");
   if (s->resident_off || !ctx->tune.resident) return RLS_E_UNSUPPORTED;  // lost a launch earlier: per-iteration launches
   if (n_steps == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_pgm_coefs C;
   memcpy(C.c, coefs, sizeof(float) * 8 * (size_t)n_steps);
   rls_pgm_desc D;
@@ -3397,7 +3540,7 @@ int32_t rls_pogm_step_resident_restart(rls_pgm* s, int32_t n_steps, int32_t firs
     return rls_fail(ctx, RLS_E_INVALID, "pogm_step_resident_restart: vectors must be 16-byte aligned");
   if (s->resident_off || !ctx->tune.resident) return RLS_E_UNSUPPORTED;
   if (n_steps == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_pgm_coefs C;
   C.c[0][0] = rho;
   C.c[0][1] = lambda;
@@ -3433,7 +3576,7 @@ int32_t rls_pogm_step_resident_restart(rls_pgm* s, int32_t n_steps, int32_t firs
 int32_t rls_pgm_lost(rls_pgm* s, int32_t* lost, int32_t* fallbacks_total) {
   if (!s || !lost) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
   RLS_TRY(rls_fetch_wait(ctx));
   *lost = (int32_t)resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks);
@@ -3455,7 +3598,7 @@ int32_t rls_cg_path(rls_cg* s, int32_t* out) {
 int32_t rls_cg_get_status(rls_cg* s, rls_cg_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   out->fallbacks = s->fallbacks;
   if (s->resident_used) {
     // a lost resident launch left x at its warm start: repeat the solve on the per-iteration pipeline
@@ -3486,7 +3629,7 @@ int32_t rls_admm_pre(rls_ctx* ctx, int32_t dtype, int64_t n, void* beta, const v
   if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && (!beta || !beta_y || !z || !u || !x || !xold)))
     return rls_fail(ctx, RLS_E_INVALID, "admm_pre: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   unsigned grid = (unsigned)((n + 255) / 256);
   if (grid > 2048) grid = 2048;
   if (dtype == RLS_F32)
@@ -3504,7 +3647,7 @@ int32_t rls_admm_post(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, con
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || n <= 0 || !x || !xold || !z || !zold || !u || !out_h)
     return rls_fail(ctx, RLS_E_INVALID, "admm_post: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(admm_post_kernel<float>, dim3(1), dim3(UPD_THREADS), 0, ctx->stream, (const float*)x,
                        (const float*)xold, (const float*)z, (const float*)zold, (float*)u, n, ctx->res_d);
@@ -3523,7 +3666,7 @@ int32_t rls_admm_create(rls_cg* cg, rls_admm** out) {
   if (!cg) return RLS_E_INVALID;
   rls_ctx* ctx = cg->op->ctx;
   if (!out) return rls_fail(ctx, RLS_E_INVALID, "admm_create: null out");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_alloc_scope alloc_scope(ctx);
   rls_admm* a = new rls_admm();
   a->cg = cg;
@@ -3584,7 +3727,7 @@ int32_t rls_admm_init(rls_admm* a, const rls_admm_params* p) {
   }
   if (p->proj_kind != RLS_PROJ_NONE && p->proj_kind != RLS_PROJ_REAL && p->proj_kind != RLS_PROJ_POSITIVE)
     return rls_fail(ctx, RLS_E_INVALID, "admm_init: bad proj_kind");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_alloc_scope alloc_scope(ctx);
   const int cap = p->iterations > 0 ? p->iterations : 1;
   if (cap > a->log_cap) {
@@ -3612,7 +3755,7 @@ int32_t rls_admm_step(rls_admm* a, int32_t n_outer) {
   rls_ctx* ctx = cg->op->ctx;
   if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_step before admm_init");
   if (n_outer < 0) return rls_fail(ctx, RLS_E_INVALID, "admm_step: n_outer < 0");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const rls_admm_params& P = a->P;
   const int32_t dtype = cg->op->dtype;
   const int64_t n = cg->op->N;
@@ -3715,7 +3858,7 @@ int32_t rls_admm_step_rowsharded(rls_comm* comm, rls_admm* const* plans, int32_t
                         rls_admm* a = plans[r];
                         rls_cg* cg = a->cg;
                         rls_ctx* ctx = cg->op->ctx;
-                        RLS_HIP(ctx, hipSetDevice(ctx->device));
+                        RLS_HIP(ctx, rls_enter(ctx));
                         RLS_TRY(rls_comm_collect(comm, r, cg->c, N, dtype, round0 + k * per_outer + j));
                         void *zcur, *znew;
                         zbufs(a, &zcur, &znew);
@@ -3758,7 +3901,7 @@ int32_t rls_admm_get_status_batched(rls_admm* a, rls_admm_status* out, float* lo
   rls_ctx* ctx = a->cg->op->ctx;
   if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_get_status before admm_init");
   if (log_records < 0 || (log_records > 0 && !log_h)) return rls_fail(ctx, RLS_E_INVALID, "admm_get_status: bad log");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   const size_t stride = (size_t)ADMM_REC * a->log_cap;
   RLS_HIP(ctx, hipMemcpyAsync(a->log_h, a->log, sizeof(float) * stride * a->nrhs, hipMemcpyDeviceToHost, ctx->stream));
   RLS_HIP(ctx, hipMemcpyAsync(a->sc_h, a->sc, sizeof(admm_scalars) * a->nrhs, hipMemcpyDeviceToHost, ctx->stream));
@@ -3791,7 +3934,7 @@ int32_t rls_admm_get_status(rls_admm* a, rls_admm_status* out, float* log_h, int
   if (!a->ready) return rls_fail(ctx, RLS_E_STATE, "admm_get_status before admm_init");
   if (a->nrhs != 1) return rls_fail(ctx, RLS_E_STATE, "admm_get_status on a batched plan: use rls_admm_get_status_batched");
   if (log_records < 0 || (log_records > 0 && !log_h)) return rls_fail(ctx, RLS_E_INVALID, "admm_get_status: bad log");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   rls_cg* cg = a->cg;
   int nrec = a->enq < a->log_cap ? a->enq : a->log_cap;
   if (nrec > 0) RLS_TRY(rls_fetch_add(ctx, a->log, a->log_h, sizeof(float) * ADMM_REC * nrec));

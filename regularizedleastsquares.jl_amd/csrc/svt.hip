@@ -249,7 +249,7 @@ int32_t rls_prox_nuclear(rls_ctx* ctx, int32_t dtype, int64_t m, int64_t n, void
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || m <= 0 || n <= 0 || !x || m > 0x7fffffff || n > 0x7fffffff)
     return rls_fail(ctx, RLS_E_INVALID, "prox_nuclear: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   svt_geom G{};
   G.ndims = 1;
   G.shape[0] = G.block[0] = m;
@@ -265,7 +265,7 @@ int32_t rls_prox_llr(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* 
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || ndims < 1 || ndims > 3 || !shape || !block || !x || n <= 0)
     return rls_fail(ctx, RLS_E_INVALID, "prox_llr: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   svt_geom G{};
   G.ndims = ndims;
   int64_t ns = 1, mb = 1;

@@ -664,7 +664,7 @@ int32_t rls_tv_grad(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* s
   if (!rls_dtype_ok(dtype) || !x || !g || !make_geom(ndims, shape, ntv, dims, &G))
     return rls_fail(ctx, RLS_E_INVALID, "tv_grad: bad argument");
   if (G.goff[G.ntv] == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(grad_kernel<float>, dim3(tv_grid(G.goff[G.ntv])), dim3(256), 0, ctx->stream, (const float*)x,
                        (float*)g, G, alpha, beta);
@@ -680,7 +680,7 @@ int32_t rls_tv_grad_t(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t*
   tv_geom G;
   if (!rls_dtype_ok(dtype) || !x || !g || !make_geom(ndims, shape, ntv, dims, &G))
     return rls_fail(ctx, RLS_E_INVALID, "tv_grad_t: bad argument");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(gradt_kernel<float>, dim3(tv_grid(G.n)), dim3(256), 0, ctx->stream, (const float*)g,
                        (const float*)x, (float*)x, G, alpha, beta);
@@ -694,7 +694,7 @@ int32_t rls_tv_restrict(rls_ctx* ctx, int32_t dtype, int64_t n, void* pq) {
   RLS_CHECK_CTX(ctx);
   if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && !pq)) return rls_fail(ctx, RLS_E_INVALID, "tv_restrict: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(restrict_kernel<float>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, (float*)pq, n);
   else
@@ -708,7 +708,7 @@ int32_t rls_tv_lincomb(rls_ctx* ctx, int32_t dtype, int64_t n, void* rs, float t
   if (!rls_dtype_ok(dtype) || n < 0 || (n > 0 && (!rs || !pq || !pqOld)))
     return rls_fail(ctx, RLS_E_INVALID, "tv_lincomb: bad argument");
   if (n == 0) return 0;
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32)
     hipLaunchKernelGGL(tv_lincomb_kernel<float>, dim3(tv_grid(n)), dim3(256), 0, ctx->stream, (float*)rs, t3,
                        (const float*)pq, t2, (const float*)pqOld, n);
@@ -729,7 +729,7 @@ int32_t rls_prox_tv_fgp(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_
   const bool fused = tv_single_ok(G, rls_elem_size(dtype));
   if (!fused && (!workspace || workspace_bytes < need))
     return rls_fail(ctx, RLS_E_WORKSPACE, "prox_tv_fgp: workspace too small");
-  RLS_HIP(ctx, hipSetDevice(ctx->device));
+  RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F32) return fgp_typed<float>(ctx, G, (float*)x, lambda, iterations, (float*)workspace);
   return fgp_typed<float2>(ctx, G, (float2*)x, lambda, iterations, (float2*)workspace);
 }

@@ -2407,6 +2407,124 @@ def test_resident_solvers_survive_a_co_tenant(rls, ctx):
         other.close()
 
 
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 4000, 2200)])
+def test_cgnr_resident_server_mode(rls, ctx, dt, M, N):
+    """The reference's solve! loop with callbacks is one iterate + one `done` check per call (src/RegularizedLeastSquares.jl:161-176):
+    rls_cgnr_step_status leaves the resident kernel LISTENING between calls (server mode, rls_cg_start::srv_ctl) -- the next call
+    posts a command into pinned host memory instead of launching.  32 one-iterate calls back to back are the bits of ONE
+    32-iteration launch, with the oracle's status stream; the stopping test ends the stream (later calls change nothing);
+    anything else that touches the stream -- a download, a new init!, a destroy -- makes the kernel leave first; a kernel that
+    left on its idle timeout is replaced; a caller that touches the device between iterates ends up on the per-iteration
+    pipeline (same results within the gate); resident_server = 0 never listens."""
+    import time
+    A, xt, b = O.make_problem(M, N, dt, 91)
+    A64, b64 = A.astype(hi(dt)), b.astype(hi(dt))
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    iters = 32
+    ref = O.CGNR(A64, iterations=iters, relTol=0.0)
+    ref.init(b64)
+    res = []
+    while ref.iterate() is not None:
+        res.append(float(np.linalg.norm(ref.r)))
+    sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=iters, relTol=0.0)
+    rls.init_(sol, bd)
+    if _cgnr_path(rls, sol) != 4:
+        _resident_unavailable()
+    x_once = rls.solve_(sol, bd).to_host()            # ONE launch of 32 iterations
+    rls.init_(sol, bd)
+    seen = []
+    while rls.iterate(sol) is not None:               # 32 calls: one launch, then 31 commands
+        seen.append(sol.state.iteration)
+    assert sol.state.iteration == iters and sol.state.fallbacks == 0
+    plan = sol.state._plan
+    st = sol.state._refresh(ctx.lib)                  # (answered from the mirror: the kernel is still listening)
+    assert st.iteration == iters and abs(st.residual - res[-1]) < 1e-4 * res[0]
+    assert np.array_equal(sol.state.x.to_host(), x_once)     # the download makes it leave first
+    assert _cgnr_path(rls, sol) == 4
+    # a pause longer than the idle timeout between calls: the kernel leaves on its own and is replaced
+    ctx.tune(resident_server_idle_us=50)
+    try:
+        rls.init_(sol, bd)
+        for k in range(iters):
+            assert rls.iterate(sol) is not None
+            if k in (3, 9):
+                time.sleep(2e-3)
+        assert rls.iterate(sol) is None and sol.state.iteration == iters
+        parity(f"cgnr_server_idle_{M}x{N}", sol.state.x.to_host(), ref.x, lambda: O.solve(O.CGNR(A, iterations=iters, relTol=0.0), b), record=False)
+    finally:
+        ctx.tune(resident_server_idle_us=300)
+    # a caller that reads x after every iterate: the listening kernel only stands in its way -- pipeline after two short lives
+    rls.init_(sol, bd)
+    k = 0
+    while rls.iterate(sol) is not None:
+        k += 1
+        xk = sol.state.x.to_host()
+        if k == 1:
+            ref1 = O.CGNR(A64, iterations=1, relTol=0.0)
+            O.solve(ref1, b64)
+            assert rel(xk, ref1.x) < 1e-5
+    assert k == iters
+    parity(f"cgnr_server_downloads_{M}x{N}", sol.state.x.to_host(), ref.x, lambda: O.solve(O.CGNR(A, iterations=iters, relTol=0.0), b), record=False)
+    # the stopping test inside a served command: the stream ends at the oracle's iteration, later commands change nothing
+    tol = 1e-3
+    ref2 = O.CGNR(A64, iterations=iters, relTol=tol)
+    O.solve(ref2, b64)
+    sol2 = rls.createLinearSolver(rls.CGNR, Ad, iterations=iters, relTol=tol)
+    rls.init_(sol2, bd)
+    n = 0
+    while rls.iterate(sol2) is not None:
+        n += 1
+    assert abs(n - ref2.iteration) <= 1 and sol2.state.iteration == n
+    import ctypes as C
+    stt = rls._lib.CgnrStatus()
+    for _ in range(3):
+        assert ctx.lib.rls_cgnr_step_status(sol2.state._plan, 1, C.byref(stt)) == 0
+        assert stt.iteration == n and stt.done == 1
+    x2 = sol2.state.x.to_host()
+    if n == ref2.iteration:
+        parity(f"cgnr_server_reltol_{M}x{N}", x2, ref2.x, lambda: O.solve(O.CGNR(A, iterations=n, relTol=0.0), b), record=False)
+    del sol2                                          # destroy with (possibly) a kernel still listening
+    # switched off: the per-iteration pipeline, as before
+    ctx.tune(resident_server=0)
+    try:
+        rls.init_(sol, bd)
+        while rls.iterate(sol) is not None:
+            pass
+        x_pipe = sol.state.x.to_host()
+    finally:
+        ctx.tune(resident_server=1)
+    assert rel(x_pipe, x_once) < 2e-5 and not np.array_equal(x_pipe, x_once)
+
+
+def test_cgnr_resident_server_survives_a_co_tenant(rls, ctx):
+    """a listening launch that cannot get its 256 workgroups onto the chip gives up like every resident launch: the call
+    re-runs its iterate on the per-iteration pipeline, reports the fallback, and the solve ends at the oracle's iterate"""
+    A, xt, b = O.make_problem(4096, 2048, np.complex64, 93)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    other = rls.Context(0)
+    try:
+        _fresh_resident_ctx(ctx)
+        ctx.tune(resident_spin=20000)
+        ref = O.CGNR(A64, iterations=8, relTol=0.0)
+        O.solve(ref, b64)
+        sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=8, relTol=0.0)
+        rls.init_(sol, bd)
+        ctx.sync()
+        assert _hold_cus(rls, other, 64, 400000) == 0
+        k = 0
+        while rls.iterate(sol) is not None:
+            k += 1
+        other.sync()
+        assert k == 8 and sol.state.iteration == 8
+        assert sol.state._refresh(ctx.lib).fallbacks >= 1, "the co-tenant did not displace the listening launch"
+        parity("co_tenant_cgnr_server", sol.state.x.to_host(), ref.x, lambda: O.solve(O.CGNR(A, iterations=8, relTol=0.0), b), record=False)
+    finally:
+        ctx.tune(resident_spin=100000)
+        _fresh_resident_ctx(ctx)
+        other.close()
+
+
 @pytest.mark.parametrize("name", ["OptISTA", "POGM"])
 @pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 4096, 4096), (np.complex64, 4000, 2002), (np.float32, 4000, 2200)])
 def test_optista_pogm_resident_launch(rls, ctx, name, dt, M, N):
