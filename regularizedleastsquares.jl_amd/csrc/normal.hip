@@ -2095,46 +2095,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     if (St.srv_ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
   }
   if (!St.srv_ctl) break;  // uniform
-  // ---- server mode: listen for the next command (workgroup 0 polls the host's control block; the grid waits at a barrier) ----
-  if (blockIdx.x == 0 && tid == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back above is out before anything else is announced)
-    unsigned* ctl = St.srv_ctl;
-    const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)St.srv_idle_us * 100ull;  // 100 MHz
-    unsigned n = RLS_SRV_EXIT, seq;
-    for (;;) {
-      seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (seq != srv_seq) break;
-      if (wall_clock64() - t0 > idle) {
-        // leave -- unless a command slips in: "leaving" goes out, THEN the sequence word is read once more (the host posts
-        // its command and THEN reads "leaving": one of the two sees the other)
-        __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&sync->srv_n, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sync->srv_mb, __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) {
-    resident_give_up(sync, nullptr);
-    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
-  const unsigned cmd = __hip_atomic_load(&sync->srv_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (cmd == RLS_SRV_EXIT) {  // uniform
-    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
+  // ---- server mode: listen for the next command (resident_listen, resident_sync.hpp) ----------------------------------------
+  const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb);
+  if (cmd == RLS_SRV_EXIT) return;  // uniform (told to leave, left idle, or a wait ran out: the control block says which)
   n_steps = (int)cmd;
-  srv_mb.seq = __hip_atomic_load(&sync->srv_mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  srv_seq += 1;
   }
 }
 
@@ -2366,7 +2330,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
                                                                   const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                   E* raw_g, E* slab, fista_scalars* sc,
                                                                   resident_sync* sync, int64_t Mc, int64_t N, int pair,
-                                                                  int n_steps, unsigned spin_limit) {
+                                                                  int n_steps, unsigned spin_limit, rls_srv_args Sv) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
   static_assert(EPT % NV == 0, "16-byte ownership layout");
@@ -2402,7 +2366,11 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   unsigned epoch = 0, xchg = 0;
   bool alive = true;
   int ycur = S.ycur;
+  rls_mailbox_slot srv_mb = Sv.mb;
+  unsigned srv_seq = Sv.seq0;  // server mode (rls_fista_step_status): the command being served
+  for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = 0; it < n_steps; ++it) {
+    if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
     if constexpr (OWN) {
       owner_products<E, G, K, WV, FULL>(a, yv, R.ored, slab_rs, N);
     } else {
@@ -2452,6 +2420,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   }
   if (!alive) {
     resident_give_up(sync, nullptr);
+    if (Sv.ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(Sv.ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   if (blockIdx.x == 0) {
@@ -2474,13 +2443,19 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
         *reinterpret_cast<f4*>(yw + o) = __builtin_bit_cast(f4, c2);
       }
     }
+    S.ycur = ycur;
+    S.pending = 0;
+    S.fresh = 0;
     if (tid == 0) {
-      S.ycur = ycur;
-      S.pending = 0;
-      S.fresh = 0;
       RLS_FISTA_COPY(*sc, S);
       sync->completed = 1u;
     }
+    if (Sv.ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
+  }
+  if (!Sv.ctl) break;  // uniform
+  const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb);
+  if (cmd == RLS_SRV_EXIT) return;  // uniform
+  n_steps = (int)cmd;
   }
 }
 
@@ -3240,7 +3215,7 @@ static int32_t resident_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout
 
 template <typename E, int G, int K, int WV>
 static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void* sync, int nwg, int n_steps,
-                                     unsigned spin_limit) {
+                                     unsigned spin_limit, const rls_srv_args& Sv) {
   using C = slab_cfg<E, G, K, WV>;
   if constexpr ((K == 32 || K == 16) && WV == 8 && C::EPT % C::NV == 0 && !(elem<E>::cplx && G == 4)) {
     const int64_t Mc = P.M / C::NV;
@@ -3257,7 +3232,7 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
 #define RLS_LAUNCH_FRES(BB, FF)                                                                                          \
   hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab,  \
-                     P.sc, (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
+                     P.sc, (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, Sv)
     if (resident_two_level_ok<E>(nwg, P.N, C::NT)) {
       if (full) RLS_LAUNCH_FRES(2, true);
       else RLS_LAUNCH_FRES(2, false);
@@ -3273,13 +3248,14 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
 }
 
 template <typename E>
-static int32_t fista_resident_typed(rls_ctx* ctx, const rls_fista_pipe& P, void* sync, int n_steps, unsigned spin_limit) {
+static int32_t fista_resident_typed(rls_ctx* ctx, const rls_fista_pipe& P, void* sync, int n_steps, unsigned spin_limit,
+                                    const rls_srv_args& Sv) {
   fused_cfg c;
   if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident FISTA: N too large");
   const int nwg = (int)fused_nwg<E>(P.M, P.N);
   int32_t st = RLS_E_UNSUPPORTED;
 #define RLS_FRES_CASE(GG, KK, WW) \
-  if (c.G == GG && c.K == KK && c.WV == WW) st = launch_fista_resident<E, GG, KK, WW>(ctx, P, sync, nwg, n_steps, spin_limit);
+  if (c.G == GG && c.K == KK && c.WV == WW) st = launch_fista_resident<E, GG, KK, WW>(ctx, P, sync, nwg, n_steps, spin_limit, Sv);
   RLS_FOR_EACH_CFG(RLS_FRES_CASE)
 #undef RLS_FRES_CASE
   return st;
@@ -3548,9 +3524,9 @@ int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pip
 }
 
 int32_t rls_fista_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, void* sync, int n_steps,
-                                  unsigned spin_limit) {
-  if (dtype == RLS_F32) return fista_resident_typed<float>(ctx, P, sync, n_steps, spin_limit);
-  return fista_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit);
+                                  unsigned spin_limit, const rls_srv_args& Sv) {
+  if (dtype == RLS_F32) return fista_resident_typed<float>(ctx, P, sync, n_steps, spin_limit, Sv);
+  return fista_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit, Sv);
 }
 
 bool rls_pgm_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {

@@ -126,3 +126,51 @@ __device__ static inline bool group_arrive_wait(unsigned* word, unsigned target,
   return *lds_flag != 0;
 }
 
+// ---- server mode (rls_cg_start::srv_ctl, rls_srv_args): a resident kernel that has finished a step call LISTENS for the next one ----
+// Workgroup 0 polls the control block in pinned host memory -- [0] command sequence, [1] n_steps, [2] mailbox sequence; it writes
+// [16] leaving, [17] exited (1 = left idle or on EXIT, 2 = a wait ran out) -- while the rest of the grid waits at a grid barrier
+// whose bound (spin_limit polls) lies far beyond the idle time.  Returns the command's n_steps, or RLS_SRV_EXIT when the grid is
+// to leave (then the control block already says why); srv_seq advances to the command now being served, mb.seq to its mailbox
+// sequence number.  Called by every thread of every workgroup; the caller's write-back of the previous command lies before it.
+__device__ static inline unsigned resident_listen(unsigned* ctl, unsigned& srv_seq, unsigned idle_us, resident_sync* sync, unsigned& epoch,
+                                                  unsigned nwg, unsigned spin_limit, int* lds_flag, rls_mailbox_slot& mb) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back above is out before anything else is announced)
+    const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)idle_us * 100ull;  // 100 MHz
+    unsigned n = RLS_SRV_EXIT, seq;
+    for (;;) {
+      seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seq != srv_seq) break;
+      if (wall_clock64() - t0 > idle) {
+        // leave -- unless a command slips in: "leaving" goes out, THEN the sequence word is read once more (the host posts
+        // its command and THEN reads "exited": one of the two sees the other)
+        __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&sync->srv_n, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sync->srv_mb, __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (!grid_arrive_wait(sync->cnt, ++epoch, nwg, spin_limit, lds_flag)) {
+    resident_give_up(sync, nullptr);
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return RLS_SRV_EXIT;
+  }
+  const unsigned cmd = __hip_atomic_load(&sync->srv_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (cmd == RLS_SRV_EXIT) {  // uniform
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(ctl + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return RLS_SRV_EXIT;
+  }
+  mb.seq = __hip_atomic_load(&sync->srv_mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  srv_seq += 1;
+  return cmd;
+}

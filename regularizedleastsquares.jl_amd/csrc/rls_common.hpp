@@ -82,6 +82,13 @@ struct rls_mailbox_slot {
   unsigned seq = 0;
 };
 rls_mailbox_slot rls_mailbox_arm(rls_ctx* ctx, void* dst_pinned);
+// server mode of the resident kernels (see rls_cg_start::srv_ctl for the protocol): what a launch that is to stay and LISTEN gets
+constexpr unsigned RLS_SRV_EXIT = 0xffffffffu;
+struct rls_srv_args {
+  unsigned* ctl = nullptr;  // control block in pinned host memory (null: an ordinary launch)
+  unsigned seq0 = 0, idle_us = 0;
+  rls_mailbox_slot mb;
+};
 int32_t rls_mailbox_wait(rls_ctx* ctx, unsigned seq);
 #ifdef __HIPCC__
 // Orders this wave's system-scope (write-through, sc0 sc1) stores ahead of its next one: their acknowledgements are back.  A release
@@ -656,7 +663,7 @@ struct rls_fista_pipe {
 int32_t rls_fista_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
 int32_t rls_fista_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P);
 int32_t rls_fista_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, void* sync, int n_steps,
-                                  unsigned spin_limit);
+                                  unsigned spin_limit, const rls_srv_args& Sv = rls_srv_args());
 
 // everything the CGNR pipeline kernels need (normal.hip)
 struct rls_cgnr_pipe {
@@ -711,7 +718,7 @@ struct rls_cg_start {
   unsigned srv_idle_us = 0;
   rls_mailbox_slot srv_mb;
 };
-constexpr unsigned RLS_SRV_EXIT = 0xffffffffu;
+
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
                                  int n_steps, unsigned spin_limit, const rls_cg_start& start = rls_cg_start());
 

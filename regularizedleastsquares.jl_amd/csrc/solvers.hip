@@ -129,6 +129,18 @@ static inline int pipe_cur_hint(const rls_ctx* ctx, int k) {
 // ---------------------------------------------------------------------------------------------
 // CGNR
 // ---------------------------------------------------------------------------------------------
+// server mode of a plan's resident kernel (rls_cg_start::srv_ctl / rls_srv_args): the control block in pinned host memory and what
+// the host knows about the kernel it left listening.  rls_ctx::server points at the one that is alive on the context's stream.
+struct srv_state {
+  unsigned* ctl = nullptr;
+  bool alive = false;   // a kernel was left listening (it may have left on its own since: ctl[17])
+  bool fresh = false;   // ... and the plan's status mirror holds the status of its last command
+  bool off = false;     // lives that served fewer than three commands, twice in a row (the caller touches the device between
+  int served = 0, short_lives = 0;  // iterates: a listening kernel only stands in its way): per-iteration pipeline until init!
+  unsigned seq = 0;
+  bool* resident_used = nullptr;  // the plan's flag: "a status call must read the sync block's flags" (set when a life ends)
+};
+
 struct rls_cgnr {
   rls_operator* op;
   rls_ctx* actx;  // the context whose pool the plan's scratch came from (checked alive before it is used in destroy)
@@ -163,13 +175,7 @@ struct rls_cgnr {
   unsigned* rsync_h;  // pinned: {fail, completed, failed} (resident_sync), read with the status
   bool resident_used;
   rls_mailbox_slot mb_arm;  // step_status: the call's last kernel publishes the scalars (pipeline and small-system paths)
-  // server mode of the resident kernel (rls_cg_start::srv_ctl): the control block in pinned host memory and what the host knows
-  unsigned* srv_ctl = nullptr;
-  bool srv_alive = false;   // a kernel of this plan was left listening (it may have left on its own since: srv_ctl[17])
-  bool srv_fresh = false;   // ... and the status mirror holds the status of its last command
-  bool srv_off = false;     // lives that served fewer than three commands, twice in a row (the caller touches the device between
-  int srv_served = 0, srv_short = 0;  // iterates: a listening kernel only stands in its way): per-iteration pipeline until init!
-  unsigned srv_seq = 0;
+  srv_state srv;  // server mode of the resident kernel (rls_cgnr_step_status)
   bool mb_sent = false;     // ... and this call's path did take the slot
   bool gram_resident;  // Gram mode: AHA fits the register files (rls_gram_resident_ok)
   // a resident launch whose workgroups were not all on the chip in time is a no-op (normal.hip); the status call re-runs
@@ -631,6 +637,7 @@ struct rls_fista {
   unsigned* rsync_h = nullptr;
   bool resident_used = false;
   bool small = false;         // dense A that fits ONE CU's registers: whole step calls on fista_small_kernel (small.hip)
+  srv_state srv;              // server mode of the resident kernel (rls_fista_step_status)
   rls_mailbox_slot mb_arm;    // as the cgnr plan's
   bool mb_sent = false;
   bool resident_off = false;  // a resident launch was lost: the plan stays on the per-iteration pipeline (cgnr plan, above)
@@ -2056,8 +2063,9 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
     if (e == hipSuccess) e = dmalloc(&s->rdots, db);
     if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
-    if (e == hipSuccess) e = hmalloc(&s->srv_ctl, 32 * sizeof(unsigned));
-    if (e == hipSuccess) memset(s->srv_ctl, 0, 32 * sizeof(unsigned));
+    if (e == hipSuccess) e = hmalloc(&s->srv.ctl, 32 * sizeof(unsigned));
+    if (e == hipSuccess) memset(s->srv.ctl, 0, 32 * sizeof(unsigned));
+    s->srv.resident_used = &s->resident_used;
   }
   if (e == hipSuccess && nrhs == 1 && op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg)) {
     const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
@@ -2118,7 +2126,7 @@ int32_t rls_cgnr_create_batched(rls_operator* op, int32_t nrhs, void* X, void* R
 
 int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (!s) return RLS_E_INVALID;
-  if (rls_ctx_alive(s->actx, s->actx_id) && s->actx->server == s) rls_server_stop(s->actx);  // (a kernel of this plan left listening)
+  if (rls_ctx_alive(s->actx, s->actx_id) && s->actx->server == &s->srv) rls_server_stop(s->actx);  // (a kernel of this plan left listening)
   hipSetDevice(s->device);
   rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx, s->actx_id));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
@@ -2138,7 +2146,7 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->rsync) dfree(s->rsync);
   if (s->rdots) dfree(s->rdots);
   if (s->rsync_h) hfree(s->rsync_h);
-  if (s->srv_ctl) hfree(s->srv_ctl);
+  if (s->srv.ctl) hfree(s->srv.ctl);
   if (s->sc) dfree(s->sc);
   if (s->sc_h) hfree(s->sc_h);
   delete s;
@@ -2173,8 +2181,8 @@ int32_t rls_cgnr_init_local_b(rls_cgnr* s) {
     cgnr_launch_init<float2>(s, s->sc_h->lambda, s->sc_h->rel_tol, s->sc_h->max_iter);
   s->initialised = true;
   s->requested = 0;
-  s->srv_off = false;  // (a new solve: the caller's pattern between iterates is judged afresh)
-  s->srv_short = 0;
+  s->srv.off = false;  // (a new solve: the caller's pattern between iterates is judged afresh)
+  s->srv.short_lives = 0;
   return launch_status(ctx);
 }
 
@@ -2543,7 +2551,7 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
-  if (ctx->server == s && s->srv_alive && s->srv_fresh) {  // a kernel left listening: the mirror holds its last command's status
+  if (ctx->server == &s->srv && s->srv.alive && s->srv.fresh) {  // a kernel left listening: the mirror holds its last command's status
     cgnr_status_out(s, *s->sc_h, out);
     return 0;
   }
@@ -2566,41 +2574,41 @@ static void cgnr_status_out(const rls_cgnr* s, const cgnr_scalars& h, rls_cgnr_s
   out->fallbacks = s->fallbacks;
 }
 
-// ---- the resident kernel in server mode (rls_cg_start::srv_ctl) ---------------------------------------------------------------
-// rls_cgnr_step_status on a plan whose A lives in the register files does not let the kernel end: the next call posts
-// {n_steps, mailbox sequence, command sequence} into the pinned control block the kernel listens on and spins on the mailbox --
-// no launch, no load of A per call.  Everything else that wants the stream sends EXIT first (rls_enter -> rls_server_stop).
-static bool cgnr_use_server(const rls_cgnr* s) {
-  const rls_ctx* ctx = s->op->ctx;
-  return ctx->tune.resident_server && ctx->tune.status_mailbox && s->srv_ctl && !s->srv_off && cgnr_use_resident(s) &&
-         (ctx->server == nullptr || ctx->server == s);
+// ---- resident kernels in server mode (rls_cg_start::srv_ctl, rls_srv_args) ---------------------------------------------------------
+// rls_cgnr_step_status / rls_fista_step_status on a plan whose A lives in the register files do not let the kernel end: the next
+// call posts {n_steps, mailbox sequence, command sequence} into the pinned control block the kernel listens on and spins on the
+// mailbox -- no launch, no load of A per call.  Everything else that wants the stream sends EXIT first (rls_enter -> rls_server_stop).
+extern "C++" {
+static bool server_usable(const rls_ctx* ctx, const srv_state* v) {
+  return ctx->tune.resident_server && ctx->tune.status_mailbox && v->ctl && !v->off && (ctx->server == nullptr || ctx->server == v);
 }
+static bool cgnr_use_server(const rls_cgnr* s) { return server_usable(s->op->ctx, &s->srv) && cgnr_use_resident(s); }
 
 // the life of a listening kernel is over (it was told to leave, left idle, or gave up): bookkeeping, and the verdict on lives
 // too short to pay for their launch
-static void server_life_over(rls_ctx* ctx, rls_cgnr* s) {
-  if (s->srv_alive) {
-    if (s->srv_served < 3) {
-      if (++s->srv_short >= 2) s->srv_off = true;
+static void server_life_over(rls_ctx* ctx, srv_state* v) {
+  if (v->alive) {
+    if (v->served < 3) {
+      if (++v->short_lives >= 2) v->off = true;
     } else {
-      s->srv_short = 0;
+      v->short_lives = 0;
     }
   }
-  s->srv_alive = false;
-  s->srv_fresh = false;
-  s->resident_used = true;  // the next status call reads the flags of the sync block (a launch lost inside that life is re-run)
-  if (ctx->server == s) ctx->server = nullptr;
+  v->alive = false;
+  v->fresh = false;
+  if (v->resident_used) *v->resident_used = true;  // the next status call reads the sync block's flags (a launch lost inside that life)
+  if (ctx->server == v) ctx->server = nullptr;
 }
 
-extern "C++" void rls_server_stop(rls_ctx* ctx) {
-  rls_cgnr* s = static_cast<rls_cgnr*>(ctx->server);
-  if (!s) return;
-  if (s->srv_alive) {
-    volatile unsigned* ctl = s->srv_ctl;
+void rls_server_stop(rls_ctx* ctx) {
+  srv_state* v = static_cast<srv_state*>(ctx->server);
+  if (!v) return;
+  if (v->alive) {
+    volatile unsigned* ctl = v->ctl;
     if (!ctl[17]) {
       ctl[1] = RLS_SRV_EXIT;
       std::atomic_thread_fence(std::memory_order_release);
-      ctl[0] = ++s->srv_seq;
+      ctl[0] = ++v->seq;
       const auto t0 = std::chrono::steady_clock::now();
       for (unsigned n = 0; !ctl[17]; ++n) {
         rls_cpu_relax();
@@ -2612,13 +2620,13 @@ extern "C++" void rls_server_stop(rls_ctx* ctx) {
       }
     }
   }
-  server_life_over(ctx, s);
+  server_life_over(ctx, v);
 }
 
 // 0: the command was served (status in the mirror); 1: the kernel had left before it saw the command; 2: it gave up inside it
-static int server_wait(rls_ctx* ctx, rls_cgnr* s, unsigned mbseq) {
+static int server_wait(rls_ctx* ctx, srv_state* v, unsigned mbseq) {
   volatile unsigned* mb = ctx->mb_h;
-  volatile unsigned* ctl = s->srv_ctl;
+  volatile unsigned* ctl = v->ctl;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned n = 0;; ++n) {
     if (*mb == mbseq) break;
@@ -2639,57 +2647,82 @@ static int server_wait(rls_ctx* ctx, rls_cgnr* s, unsigned mbseq) {
   return 0;
 }
 
+// One command: posted to the listening kernel, or carried by a launch (`launch(args)`, through the resident chain).
+// Returns 0 = served (mirror current), 1 = nothing ran and the plan should take its ordinary path, 2 = a launch gave up inside
+// the command (the caller's lost-launch recovery re-runs it), < 0 = error.
+template <typename L>
+static int32_t server_command(rls_ctx* ctx, srv_state* v, void* mirror, int32_t n_steps, bool usable_again, L&& launch) {
+  volatile unsigned* ctl = v->ctl;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const unsigned mbseq = ++ctx->mb_seq;
+    if (v->alive) {  // post the command: payload, then the sequence word
+      ctl[1] = (unsigned)n_steps;
+      ctl[2] = mbseq;
+      std::atomic_thread_fence(std::memory_order_release);
+      ctl[0] = ++v->seq;
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+    } else {
+      ctl[16] = ctl[17] = 0;
+      ctl[0] = v->seq;
+      rls_srv_args a;
+      a.ctl = v->ctl;
+      a.seq0 = v->seq;
+      a.idle_us = (unsigned)(ctx->tune.resident_server_idle_us > 0 ? ctx->tune.resident_server_idle_us : 1);
+      a.mb.dst = mirror;
+      a.mb.seq_h = ctx->mb_h;
+      a.mb.seq = mbseq;
+      const int32_t st = launch(a);
+      if (st != 0) return st < 0 ? st : -1;
+      v->alive = true;
+      v->served = 0;
+      ctx->server = v;
+    }
+    const int r = server_wait(ctx, v, mbseq);
+    if (r == 0) {
+      v->served += 1;
+      v->fresh = true;
+      return 0;
+    }
+    server_life_over(ctx, v);
+    if (r == 2) return 2;
+    // r == 1: it had left (idle) before it saw the command -- nothing ran.  Once more with a launch, or -- this plan's lives
+    // keep ending early -- on the ordinary path
+    if (attempt == 1 || !usable_again || v->off) {
+      v->off = true;
+      return 1;
+    }
+  }
+  return 1;
+}
+
 extern "C" int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out);
 static int32_t cgnr_step_status_server(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out) {
   rls_ctx* ctx = s->op->ctx;
   RLS_HIP(ctx, hipSetDevice(s->device));
   s->requested += n_steps;
-  volatile unsigned* ctl = s->srv_ctl;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    const unsigned mbseq = ++ctx->mb_seq;
-    if (s->srv_alive) {  // post the command: payload, then the sequence word
-      ctl[1] = (unsigned)n_steps;
-      ctl[2] = mbseq;
-      std::atomic_thread_fence(std::memory_order_release);
-      ctl[0] = ++s->srv_seq;
-      std::atomic_thread_fence(std::memory_order_seq_cst);
-    } else {
-      ctl[16] = ctl[17] = 0;
-      ctl[0] = s->srv_seq;
-      rls_cg_start St;
-      St.srv_ctl = s->srv_ctl;
-      St.srv_seq0 = s->srv_seq;
-      St.srv_idle_us = (unsigned)(ctx->tune.resident_server_idle_us > 0 ? ctx->tune.resident_server_idle_us : 1);
-      St.srv_mb.dst = s->sc_h;
-      St.srv_mb.seq_h = ctx->mb_h;
-      St.srv_mb.seq = mbseq;
-      const rls_cgnr_pipe P = cgnr_pipe_desc(s);
-      RLS_TRY(resident_chain(ctx, s->rsync, [&]() {
-        return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, St);
-      }, &s->rsync_clean));
-      s->srv_alive = true;
-      s->srv_served = 0;
-      ctx->server = s;
-    }
-    const int r = server_wait(ctx, s, mbseq);
-    if (r == 0) {
-      s->srv_served += 1;
-      s->srv_fresh = true;
-      cgnr_status_out(s, *s->sc_h, out);
-      return 0;
-    }
-    server_life_over(ctx, s);
-    if (r == 2) break;  // gave up inside the command: the lost-launch recovery below re-runs it
-    // r == 1: it had left (idle) before it saw the command -- nothing ran.  Once more with a launch, or -- this plan's lives
-    // keep ending early -- on the ordinary path
-    if (attempt == 1 || !cgnr_use_server(s)) {
-      s->requested -= n_steps;
-      s->srv_off = true;
-      return rls_cgnr_step_status(s, n_steps, out);
-    }
+  const int32_t r = server_command(ctx, &s->srv, s->sc_h, n_steps, true, [&](const rls_srv_args& a) {
+    rls_cg_start St;
+    St.srv_ctl = a.ctl;
+    St.srv_seq0 = a.seq0;
+    St.srv_idle_us = a.idle_us;
+    St.srv_mb = a.mb;
+    const rls_cgnr_pipe P = cgnr_pipe_desc(s);
+    return resident_chain(ctx, s->rsync, [&]() {
+      return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, St);
+    }, &s->rsync_clean);
+  });
+  if (r < 0) return r;
+  if (r == 0) {
+    cgnr_status_out(s, *s->sc_h, out);
+    return 0;
+  }
+  if (r == 1) {  // nothing ran: the ordinary path
+    s->requested -= n_steps;
+    return rls_cgnr_step_status(s, n_steps, out);
   }
   return rls_cgnr_get_status(s, out);  // (reads the sync block's flags: iterations a lost launch did not run are re-run here)
 }
+}  // extern "C++"
 
 // One iterate per call is the reference's solve! loop with callbacks (src/RegularizedLeastSquares.jl:161-176): step and read-back
 // as ONE entry point, and on the per-iteration pipeline and the small-system kernel the call's last kernel stores the scalars into
@@ -2771,6 +2804,9 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
       if (s->rsync) dfree(s->rsync);
       s->rsync = nullptr;  // resident mode is an optimisation: without its scratch the pipeline runs
       (void)hipGetLastError();
+    } else if (!gram && hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess) {
+      memset(s->srv.ctl, 0, 32 * sizeof(unsigned));
+      s->srv.resident_used = &s->resident_used;
     }
   }
   int32_t st = alloc_scalars(ctx, &s->sc, &s->sc_h);
@@ -2789,7 +2825,9 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
 
 int32_t rls_fista_destroy(rls_fista* s) {
   if (!s) return RLS_E_INVALID;
+  if (rls_ctx_alive(s->actx, s->actx_id) && s->actx->server == &s->srv) rls_server_stop(s->actx);  // (a kernel of this plan left listening)
   hipSetDevice(s->device);
+  if (s->srv.ctl) hfree(s->srv.ctl);
   rls_alloc_scope alloc_scope(alloc_ctx_of(s->actx, s->actx_id));
   if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
   dfree(s->y);
@@ -2860,6 +2898,8 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
   s->enq = 0;
   s->requested = 0;
   s->theta0 = theta;
+  s->srv.off = false;  // (a new solve: the caller's pattern between iterates is judged afresh)
+  s->srv.short_lives = 0;
   s->initialised = true;
   // row-sharded plans exchange `res` between the operator apply and the update: two-half iterations only
   const bool gram = !local && fista_gram_ok(s);
@@ -3187,6 +3227,10 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "fista_get_status before fista_init");
+  if (ctx->server == &s->srv && s->srv.alive && s->srv.fresh) {  // a kernel left listening: the mirror holds its last command's status
+    fista_status_out(s, *s->sc_h, out);
+    return 0;
+  }
   RLS_HIP(ctx, rls_enter(ctx));
   RLS_TRY(fista_fetch_status(s));
   fista_status_out(s, *s->sc_h, out);
@@ -3196,6 +3240,29 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
 int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out) {  // as rls_cgnr_step_status
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
+  if (s->initialised && n_steps > 0 && !s->resident_used && server_usable(ctx, &s->srv) && !fista_use_small(s) && fista_use_resident(s)) {
+    // the resident kernel in server mode (cgnr_step_status_server): posted to the kernel left listening, or carried by a launch
+    RLS_HIP(ctx, hipSetDevice(s->device));
+    s->requested += n_steps;
+    s->enq += n_steps;
+    const int32_t r = server_command(ctx, &s->srv, s->sc_h, n_steps, true, [&](const rls_srv_args& a) {
+      const rls_fista_pipe P = fista_pipe_desc(s);
+      return resident_chain(ctx, s->rsync, [&]() {
+        return rls_fista_resident_launch(ctx, s->op->dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, a);
+      }, &s->rsync_clean);
+    });
+    if (r < 0) return r;
+    if (r == 0) {
+      fista_status_out(s, *s->sc_h, out);
+      return 0;
+    }
+    if (r == 1) {  // nothing ran: the ordinary path
+      s->requested -= n_steps;
+      s->enq -= n_steps;
+      return rls_fista_step_status(s, n_steps, out);
+    }
+    return rls_fista_get_status(s, out);  // a launch gave up inside the command: the lost-launch recovery re-runs it
+  }
   if (s->initialised && s->nrhs == 1 && n_steps > 0 && !s->resident_used) {
     RLS_HIP(ctx, rls_enter(ctx));
     s->mb_arm = rls_mailbox_arm(ctx, s->sc_h);

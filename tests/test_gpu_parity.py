@@ -2496,6 +2496,76 @@ def test_cgnr_resident_server_mode(rls, ctx, dt, M, N):
     assert rel(x_pipe, x_once) < 2e-5 and not np.array_equal(x_pipe, x_once)
 
 
+@pytest.mark.parametrize("restart", ["none", "gradient"])
+def test_fista_resident_server_mode(rls, ctx, restart):
+    """rls_fista_step_status with the resident kernel left listening (as test_cgnr_resident_server_mode): 40 one-iterate calls
+    back to back are the bits of ONE 40-iteration launch and the oracle's iterate; a download in between makes the kernel leave
+    first; the stopping test ends the stream; resident_server = 0 is the per-iteration pipeline."""
+    import ctypes as C
+    M, N, dt = 4096, 2048, np.complex64
+    A, xt, b = O.make_problem(M, N, dt, 95)
+    A64, b64 = A.astype(np.complex128), b.astype(np.complex128)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    iters = 40
+    ref = O.FISTA(A64, reg=O.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    O.solve(ref, b64)
+    sol = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    rls.init_(sol, bd)
+    path = C.c_int32(-1)
+    assert ctx.lib.rls_fista_path(sol.state._plan, C.byref(path)) == 0
+    if path.value != 4:
+        _resident_unavailable()
+    x_once = rls.solve_(sol, bd).to_host()
+    rls.init_(sol, bd)
+    k = 0
+    while rls.iterate(sol) is not None:      # one launch, then 39 commands
+        k += 1
+    assert k == iters and sol.state.iteration == iters and sol.state.fallbacks == 0
+    assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
+    x_srv = sol.state.x.to_host()
+    assert np.array_equal(x_srv, x_once)
+    parity(f"fista_server_{restart}", x_srv, ref.x,
+           lambda: O.solve(O.FISTA(A, reg=O.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart), b), record=False)
+    # downloads between iterates at 3, 4, 5: the kernel leaves, comes back, and the caller ends up where it should
+    rls.init_(sol, bd)
+    k = 0
+    while rls.iterate(sol) is not None:
+        k += 1
+        if k in (3, 4, 5):
+            sol.state.x.to_host()
+    assert k == iters
+    parity(f"fista_server_downloads_{restart}", sol.state.x.to_host(), ref.x,
+           lambda: O.solve(O.FISTA(A, reg=O.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart), b), record=False)
+    # the stopping test inside a served command
+    probe = O.FISTA(A64, reg=O.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    probe.init(b64)
+    rr = []
+    while probe.iterate() is not None:
+        rr.append(probe.rel_res_norm)
+    kk = next(i for i in range(20, 2, -1) if min(rr[:i]) > 1.001 * rr[i])
+    tol = 1.0005 * rr[kk]
+    sol2 = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=iters, relTol=tol, restart=restart)
+    rls.init_(sol2, bd)
+    n = 0
+    while rls.iterate(sol2) is not None:
+        n += 1
+    assert n == kk + 1 and sol2.state.iteration == n
+    stt = rls._lib.FistaStatus()
+    for _ in range(2):
+        assert ctx.lib.rls_fista_step_status(sol2.state._plan, 1, C.byref(stt)) == 0 and stt.iteration == n and stt.done == 1
+    ctx.tune(resident_server=0)
+    try:
+        rls.init_(sol, bd)
+        while rls.iterate(sol) is not None:
+            pass
+        x_pipe = sol.state.x.to_host()
+    finally:
+        ctx.tune(resident_server=1)
+    assert rel(x_pipe, x_once) < 2e-5
+
+
 def test_cgnr_resident_server_survives_a_co_tenant(rls, ctx):
     """a listening launch that cannot get its 256 workgroups onto the chip gives up like every resident launch: the call
     re-runs its iterate on the per-iteration pipeline, reports the fallback, and the solve ends at the oracle's iterate"""
