@@ -70,7 +70,8 @@ int32_t rls_device_count(int32_t* out);
  * "tv_fused_2d", "skinny_t_waves", "skinny_t_u", "skinny_v_waves", "skinny_v_u", "skinny_v_splits", "skinny_half"
  * (the (8 re | 8 im) operand layout for <= 8 complex right-hand sides), "skinny_t_roll", "skinny_v_roll", "skinny_g_roll" (rolling-window
  * depth of the batched kernels' load pipelines), "gram_lds_kib", "kaczmarz_nt".  Per context again: "small" (1: systems that
- * fit one CU's registers run a step call as a single-workgroup launch), "status_mailbox" (>= 1: status read-backs through a kernel
+ * fit one CU's registers run a step call as a single-workgroup launch), "resident_server" (1: rls_cgnr_step_status / rls_fista_step_status leave the resident kernel listening for the
+ * next call, see there), "resident_server_idle_us", "status_mailbox" (>= 1: status read-backs through a kernel
  * that stores into pinned host memory + a host spin; 2, the default: rls_*_step_status has the call's last kernel do that store where
  * it can; 0: hipMemcpyAsync + stream wait). */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
@@ -301,7 +302,15 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps);
  * solve! has no such failure mode (src/RegularizedLeastSquares.jl:103-117), so none is surfaced here either. */
 int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h);
 /* rls_cgnr_step(s, n_steps) followed by rls_cgnr_get_status(s, out_h) in one call: what one `iterate` of the reference's
- * solve! loop needs (advance, then `done` / the convergence record for the callbacks) with ONE host synchronisation */
+ * solve! loop needs (advance, then `done` / the convergence record for the callbacks) with ONE host synchronisation.
+ * On a plan whose A lives in the register files (path 4) the kernel of this call is left LISTENING on a control block in
+ * pinned host memory ("server mode"): the next rls_cgnr_step_status posts its command there instead of launching -- no launch
+ * and no load of A per call -- and reads the status from the mailbox the kernel publishes into.  The kernel leaves when
+ * nothing arrives for "resident_server_idle_us" (300), and EVERY other entry point of this library that touches the context
+ * (a download, init, another plan, destroy, rls_sync ...) asks it to leave first, so nothing the caller does through the
+ * library waits behind it; work the caller puts on the same stream by other means waits for the idle timeout at most.
+ * A caller that touches the device between iterates twice in a row is served by the per-iteration pipeline until the next
+ * init.  rls_tune_set("resident_server", 0) switches the mode off.  rls_fista_step_status: the same. */
 int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out_h);
 /* Batched plan (BASELINE config 4, shared-A flavour; semantics of solve!(solver, B; scheduler =
  * MultiThreadingState), src/MultiThreading.jl:30-79): nrhs independent CGNR solves that share ONE pass over A
