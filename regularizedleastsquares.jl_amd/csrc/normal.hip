@@ -2096,7 +2096,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   }
   if (!St.srv_ctl) break;  // uniform
   // ---- server mode: listen for the next command (resident_listen, resident_sync.hpp) ----------------------------------------
-  const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb);
+  const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb, srv_seq - St.srv_seq0 + 1u);
   if (cmd == RLS_SRV_EXIT) return;  // uniform (told to leave, left idle, or a wait ran out: the control block says which)
   n_steps = (int)cmd;
   }
@@ -2453,7 +2453,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     if (Sv.ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
   }
   if (!Sv.ctl) break;  // uniform
-  const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb);
+  const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb, srv_seq - Sv.seq0 + 1u);
   if (cmd == RLS_SRV_EXIT) return;  // uniform
   n_steps = (int)cmd;
   }

@@ -132,14 +132,19 @@ __device__ static inline bool group_arrive_wait(unsigned* word, unsigned target,
 // whose bound (spin_limit polls) lies far beyond the idle time.  Returns the command's n_steps, or RLS_SRV_EXIT when the grid is
 // to leave (then the control block already says why); srv_seq advances to the command now being served, mb.seq to its mailbox
 // sequence number.  Called by every thread of every workgroup; the caller's write-back of the previous command lies before it.
+// A kernel also leaves once it has served RLS_SRV_MAX_COMMANDS, command posted or not (a caller iterating for seconds must not
+// turn into one kernel that runs for seconds: ~40 ms of one-iterate calls): the host finds `exited` instead of its status and
+// re-issues the command with a launch, as for a kernel that left idle.
+constexpr unsigned RLS_SRV_MAX_COMMANDS = 2048u;
 __device__ static inline unsigned resident_listen(unsigned* ctl, unsigned& srv_seq, unsigned idle_us, resident_sync* sync, unsigned& epoch,
-                                                  unsigned nwg, unsigned spin_limit, int* lds_flag, rls_mailbox_slot& mb) {
+                                                  unsigned nwg, unsigned spin_limit, int* lds_flag, rls_mailbox_slot& mb,
+                                                  unsigned served) {
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back above is out before anything else is announced)
     const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)idle_us * 100ull;  // 100 MHz
-    unsigned n = RLS_SRV_EXIT, seq;
-    for (;;) {
+    unsigned n = RLS_SRV_EXIT, seq = srv_seq;
+    for (; served < RLS_SRV_MAX_COMMANDS;) {
       seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (seq != srv_seq) break;
       if (wall_clock64() - t0 > idle) {

@@ -2587,6 +2587,7 @@ static bool cgnr_use_server(const rls_cgnr* s) { return server_usable(s->op->ctx
 // the life of a listening kernel is over (it was told to leave, left idle, or gave up): bookkeeping, and the verdict on lives
 // too short to pay for their launch
 static void server_life_over(rls_ctx* ctx, srv_state* v) {
+  const bool gave_up = v->ctl[17] == 2;
   if (v->alive) {
     if (v->served < 3) {
       if (++v->short_lives >= 2) v->off = true;
@@ -2596,7 +2597,7 @@ static void server_life_over(rls_ctx* ctx, srv_state* v) {
   }
   v->alive = false;
   v->fresh = false;
-  if (v->resident_used) *v->resident_used = true;  // the next status call reads the sync block's flags (a launch lost inside that life)
+  if (gave_up && v->resident_used) *v->resident_used = true;  // a wait ran out in that life: the next status call reads the sync block's flags
   if (ctx->server == v) ctx->server = nullptr;
 }
 
@@ -2684,7 +2685,10 @@ static int32_t server_command(rls_ctx* ctx, srv_state* v, void* mirror, int32_t 
       return 0;
     }
     server_life_over(ctx, v);
-    if (r == 2) return 2;
+    if (r == 2) {
+      if (v->resident_used) *v->resident_used = true;  // (the status call that follows reads the sync block's flags)
+      return 2;
+    }
     // r == 1: it had left (idle) before it saw the command -- nothing ran.  Once more with a launch, or -- this plan's lives
     // keep ending early -- on the ordinary path
     if (attempt == 1 || !usable_again || v->off) {

@@ -2484,6 +2484,18 @@ def test_cgnr_resident_server_mode(rls, ctx, dt, M, N):
     if n == ref2.iteration:
         parity(f"cgnr_server_reltol_{M}x{N}", x2, ref2.x, lambda: O.solve(O.CGNR(A, iterations=n, relTol=0.0), b), record=False)
     del sol2                                          # destroy with (possibly) a kernel still listening
+    if M == 4096:
+        # more calls than one kernel life serves (RLS_SRV_MAX_COMMANDS = 2048): it leaves with a command posted, the host
+        # re-issues it with a launch -- still the bits of ONE launch
+        n_long = 2300
+        sol3 = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=n_long, relTol=0.0)
+        x_long = rls.solve_(sol3, bd).to_host()
+        it_long = sol3.state.iteration     # (Float32 CG reaches a residual of exactly 0 after a few hundred iterations and stops)
+        rls.init_(sol3, bd)
+        for _ in range(n_long):            # every call is a served command, iterating or not
+            assert ctx.lib.rls_cgnr_step_status(sol3.state._plan, 1, C.byref(stt)) == 0
+        assert stt.iteration == it_long and stt.fallbacks == 0
+        assert np.array_equal(sol3.state.x.to_host(), x_long, equal_nan=True)
     # switched off: the per-iteration pipeline, as before
     ctx.tune(resident_server=0)
     try:
