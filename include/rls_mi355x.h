@@ -312,6 +312,15 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h);
  * A caller that touches the device between iterates twice in a row is served by the per-iteration pipeline until the next
  * init.  rls_tune_set("resident_server", 0) switches the mode off.  rls_fista_step_status: the same. */
 int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out_h);
+/* K independent SMALL systems -- each with its own A: the distinct-A flavour of a multi-solve, one solver per problem under
+ * Threads.@threads in the reference (docs/src/literate/howto/multi_threading.jl:8-17) -- advanced together in ONE launch, one
+ * workgroup per plan.  Every plan is an ordinary single right-hand-side plan on rls_cgnr_path 8 (same context, same element type;
+ * shapes may differ: the group runs on the tile of its largest member, so a member's bits may differ from its solo run's in the last
+ * place); status, solution and further rls_cgnr_step calls per plan as usual.  rls_cgnr_init_step_group also runs every plan's
+ * init (r = A^H b[k], x = 0, p = r: src/CGNR.jl:107-130) inside the same launch: a whole solve of K problems is ONE launch. */
+int32_t rls_cgnr_step_group(rls_cgnr* const* plans, int32_t count, int32_t n_steps);
+int32_t rls_cgnr_init_step_group(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol,
+                                 int32_t iterations, int32_t n_steps);
 /* Batched plan (BASELINE config 4, shared-A flavour; semantics of solve!(solver, B; scheduler =
  * MultiThreadingState), src/MultiThreading.jl:30-79): nrhs independent CGNR solves that share ONE pass over A
  * per iteration.  X, R, P, V: caller-owned N x nrhs column-major device matrices, leading dimension ldv;

@@ -361,6 +361,41 @@ function RLSMI355X.solve_fused!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector)
 end
 
 
+# ---- K solvers, each with its own matrix, small enough for one CU each: ONE launch ---------------------------------------------
+"""
+    solve_group!(solvers::Vector{<:CGNR}, bs::Vector{<:RLSVector})
+
+The reference's other multi-solve flavour (docs/src/literate/howto/multi_threading.jl:8-17: one solver and one A per problem under
+`Threads.@threads`) for problems that each fit one CU's registers: `init!` and every iteration of all K problems as ONE launch, one
+workgroup per problem (`rls_cgnr_init_step_group`).  The solvers must share the L2 weight, relTol and iteration count and sit on
+`rls_cgnr_path` 8; otherwise (RLS_E_UNSUPPORTED) they are solved one after the other.
+"""
+function RLSMI355X.solve_group!(solvers::Vector{<:CGNR}, bs::Vector{<:RLSVector})
+  length(solvers) == length(bs) || error("one right-hand side per solver")
+  states = [s.state for s in solvers]
+  plans = Ptr{Cvoid}[]
+  for (s, st, b) in zip(solvers, states, bs)
+    push!(plans, plan_for(s, st))         # (the plan is created on first use; init! itself runs inside the group launch)
+    st.iteration = 0
+    delete!(cgnr_done, st)
+  end
+  first_ = solvers[1]
+  lam = Float32(λ(first_.L2)); tol = Float32(states[1].relTol)
+  rc = ccall((:rls_cgnr_init_step_group, librls[]), Int32, (Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Float32, Float32, Int32, Int32),
+             plans, Ptr{Cvoid}[b.ptr for b in bs], Int32(length(plans)), lam, tol, Int32(first_.iterations), Int32(first_.iterations))
+  if rc == Int32(-2)
+    return [RLSMI355X.solve_fused!(s, b) for (s, b) in zip(solvers, bs)]
+  end
+  check(bs[1].ctx, rc, "rls_cgnr_init_step_group")
+  for (s, st) in zip(solvers, states)
+    stt = Ref{CgnrStatus}()
+    check(bs[1].ctx, ccall((:rls_cgnr_get_status, librls[]), Int32, (Ptr{Cvoid}, Ref{CgnrStatus}), plan_for(s, st), stt), "rls_cgnr_get_status")
+    cgnr_take!(st, stt[])
+    iterate(s, st)                        # done: applies `constr`, returns nothing
+  end
+  return [st.x for st in states]
+end
+
 # ---- matrix right-hand sides: the shared-A scheduler (BASELINE configs[3]; src/MultiThreading.jl:30-79) -------------------
 # `solve!` on a device right-hand side WITHOUT callbacks: nothing observes the iterates, so the whole solve is enqueued at once
 # (the reference's loop, src/RegularizedLeastSquares.jl:103-117, would synchronise with the host once per iteration for a

@@ -427,6 +427,8 @@ end
 
 "whole solve in one enqueue; methods are added by the RegularizedLeastSquares extension"
 function solve_fused! end
+"K solvers with their own small matrices as ONE launch (defined by the RegularizedLeastSquares extension)"
+function solve_group! end
 "`scheduler = RLSMI355X.BatchedState` for `solve!(solver, B::RLSMatrix)`: the columns share every pass over A (matrix cores); defined by the extension"
 function BatchedState end
 

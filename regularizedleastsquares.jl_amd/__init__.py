@@ -24,7 +24,7 @@ from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA,
                       AbstractPrimalDualSolver, AbstractProximalGradientSolver, AbstractRowActionSolver,
                       applicableSolverList, isapplicable, AbstractLinearSolver, AdmmBatchedState, BatchedState, FistaBatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
                       SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,
-                      iterate, linearSolverList, power_iterations, solve_, solverconvergence, solversolution,
+                      iterate, linearSolverList, power_iterations, solve_, solve_group_, solverconvergence, solversolution,
                       solverstate)
 from . import multigpu  # noqa: F401,E402
 from .multigpu import (CommRowShardedADMM, CommRowShardedCGNR, CommRowShardedFISTA, ConcurrentSolves, MultiSolve, RowShardedADMM, RowShardedCGNR, RowShardedFISTA,  # noqa: F401,E402

@@ -859,7 +859,19 @@ struct rls_small {
   void *x, *r, *p, *v;
   cgnr_scalars* sc;
   rls_mailbox_slot mb;  // as rls_cgnr_pipe::mb
+  // init! in the same launch (src/CGNR.jl:107-130): b != nullptr -> r = A^H b from the registers, x = v = 0, p = r, the scalars
+  const void* b = nullptr;
+  float lambda = 0.f, rel_tol = 0.f;
+  int max_iter = 0;
 };
+// K independent small systems, one workgroup each, in ONE launch (the distinct-A flavour of a multi-solve,
+// docs/src/literate/howto/multi_threading.jl:8-17): the descriptors travel as a kernel argument
+constexpr int RLS_SMALL_GROUP_MAX = 24;
+struct rls_small_group {
+  int count = 0;
+  rls_small d[RLS_SMALL_GROUP_MAX];
+};
+int32_t rls_small_group_launch(rls_ctx* ctx, int32_t dtype, const rls_small_group& G, int n_steps);
 bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps);
 struct rls_fista_pipe;

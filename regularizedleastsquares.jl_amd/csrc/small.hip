@@ -88,6 +88,8 @@ __device__ static inline void small_tile_load(E (&a)[R][C], const E* __restrict_
 // one application of the normal operator to the vector in `ps`: the per-wave partial rows of A^H (A ps) in vpart, complete
 // behind the workgroup barrier this ends with
 template <typename E, int R, int C>
+__device__ static inline void small_adjoint_partials(const E (&a)[R][C], const E (&t)[R], E (*vpart)[16 * C], int cb, int lane, int w);
+template <typename E, int R, int C>
 __device__ static inline void small_normal_partials(const E (&a)[R][C], const E* ps, E (*vpart)[16 * C], int cb, int lane, int w) {
   // ---- t = A p: this thread's R rows over its C columns, then over the 16 column blocks ---------------------------------------
   E pj[C];
@@ -101,6 +103,13 @@ __device__ static inline void small_normal_partials(const E (&a)[R][C], const E*
     for (int j = 0; j < C; ++j) s = elem<E>::fma(a[i][j], pj[j], s);
     t[i] = row16_sum<E>(s);
   }
+  small_adjoint_partials<E, R, C>(a, t, vpart, cb, lane, w);
+}
+
+// the per-wave partial rows of A^H t (t: this thread's R rows, the same in the 16 lanes of its row block), complete behind the
+// workgroup barrier this ends with
+template <typename E, int R, int C>
+__device__ static inline void small_adjoint_partials(const E (&a)[R][C], const E (&t)[R], E (*vpart)[16 * C], int cb, int lane, int w) {
   // ---- v = A^H t: this thread's C columns over its R rows, then over the 4 row blocks of the wave, then over the waves ---------
 #pragma unroll
   for (int j = 0; j < C; ++j) {
@@ -114,9 +123,17 @@ __device__ static inline void small_normal_partials(const E (&a)[R][C], const E*
   __syncthreads();
 }
 
+// One workgroup per system of the group (blockIdx.x): K independent small problems -- each with its own A -- advance in ONE launch.
 template <typename E, int R, int C>
-__global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* x, E* r, E* p, E* v,
-                                                           cgnr_scalars* sc, int n_steps, rls_mailbox_slot mb, int vec16) {
+__global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group G, int n_steps) {
+  const rls_small& D = G.d[blockIdx.x];
+  const E* __restrict__ A = (const E*)D.A;
+  const int64_t lda = D.lda;
+  const int M = (int)D.M, N = (int)D.N;
+  E *x = (E*)D.x, *r = (E*)D.r, *p = (E*)D.p, *v = (E*)D.v;
+  cgnr_scalars* sc = D.sc;
+  const rls_mailbox_slot mb = D.mb;
+  const int vec16 = (int)((reinterpret_cast<uintptr_t>(D.A) & 15) == 0 && (lda * (int64_t)sizeof(E)) % 16 == 0);
   constexpr int NP = 16 * C;              // padded vector length
   constexpr int EPT = (NP + 63) / 64;     // vector elements per lane of wave 0
   __shared__ E ps[NP];                    // p, zero beyond N
@@ -130,21 +147,64 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__
   // ---- state: wave 0 owns the vectors (elements lane, lane + 64, ...) -----------------------------------------------------------
   E xv[EPT], rv[EPT], pv[EPT], vv[EPT];
   cgnr_scalars S;
-  if (w == 0) {
+  const bool init = D.b != nullptr;  // uniform: init! in this launch (src/CGNR.jl:107-130)
+  if (init) {
+    // r = A^H b: the thread's R entries of b are its t, then the second product alone
+    const E* bb = (const E*)D.b;
+    E t[R];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int i = lane + 64 * e;
-      const bool ok = i < N;
-      xv[e] = ok ? x[i] : elem<E>::zero();
-      rv[e] = ok ? r[i] : elem<E>::zero();
-      pv[e] = ok ? p[i] : elem<E>::zero();
-      vv[e] = ok ? v[i] : elem<E>::zero();
-      if (i < NP) ps[i] = pv[e];
+    for (int i = 0; i < R; ++i) {
+      const int row = rb * R + i;
+      t[i] = row < M ? bb[row] : elem<E>::zero();
     }
-    S.rr = sc->rr; S.z0 = sc->z0; S.zeta = sc->zeta;
-    S.alpha_re = sc->alpha_re; S.alpha_im = sc->alpha_im; S.beta_re = sc->beta_re; S.beta_im = sc->beta_im;
-    S.lambda = sc->lambda; S.rel_tol = sc->rel_tol;
-    S.iteration = sc->iteration; S.max_iter = sc->max_iter; S.done = sc->done;
+    small_adjoint_partials<E, R, C>(a, t, vpart, cb, lane, w);
+  }
+  if (w == 0) {
+    if (init) {
+      double rr = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int i = lane + 64 * e;
+        E s = elem<E>::zero();
+        if (i < NP) {
+#pragma unroll
+          for (int ww = 0; ww < SM_WV; ++ww) s = elem<E>::add(s, vpart[ww][i]);
+        }
+        if (i >= N) s = elem<E>::zero();
+        xv[e] = elem<E>::zero();
+        vv[e] = elem<E>::zero();
+        rv[e] = s;
+        pv[e] = s;
+        if (i < NP) ps[i] = s;
+        rr += (double)elem<E>::re(s) * (double)elem<E>::re(s) + (double)elem<E>::im(s) * (double)elem<E>::im(s);
+      }
+      rr = wave_sum(rr);
+      S.rr = rr;                      // cgnr_init_kernel (solvers.hip)
+      S.z0 = sqrt(rr);
+      S.zeta = 0.0;
+      S.alpha_re = S.alpha_im = S.beta_re = S.beta_im = 0.0;
+      S.lambda = D.lambda;
+      S.rel_tol = D.rel_tol;
+      S.iteration = 0;
+      S.max_iter = D.max_iter;
+      const float ratio = (float)(sqrt(rr) / sqrt(rr));  // NaN when r == 0, as in the reference
+      S.done = (ratio <= D.rel_tol) || (0 >= D.max_iter);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int i = lane + 64 * e;
+        const bool ok = i < N;
+        xv[e] = ok ? x[i] : elem<E>::zero();
+        rv[e] = ok ? r[i] : elem<E>::zero();
+        pv[e] = ok ? p[i] : elem<E>::zero();
+        vv[e] = ok ? v[i] : elem<E>::zero();
+        if (i < NP) ps[i] = pv[e];
+      }
+      S.rr = sc->rr; S.z0 = sc->z0; S.zeta = sc->zeta;
+      S.alpha_re = sc->alpha_re; S.alpha_im = sc->alpha_im; S.beta_re = sc->beta_re; S.beta_im = sc->beta_im;
+      S.lambda = sc->lambda; S.rel_tol = sc->rel_tol;
+      S.iteration = sc->iteration; S.max_iter = sc->max_iter; S.done = sc->done;
+    }
     if (lane == 0) sdone = S.done;
   }
   __syncthreads();
@@ -223,6 +283,9 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const E* __restrict__
       sc->alpha_re = S.alpha_re; sc->alpha_im = S.alpha_im; sc->beta_re = S.beta_re; sc->beta_im = S.beta_im;
       sc->iteration = S.iteration; sc->done = S.done;
       sc->pending = 0; sc->cur = 0; sc->fresh = 0;
+      if (init) {
+        sc->z0 = S.z0; sc->lambda = S.lambda; sc->rel_tol = S.rel_tol; sc->max_iter = S.max_iter;
+      }
     }
     S.pending = 0; S.cur = 0; S.fresh = 0;
     rls_mailbox_publish(mb, S, lane);
@@ -372,19 +435,24 @@ static bool small_pick(int64_t M, int64_t N, small_tile* t) {
 }
 
 template <typename E, int R, int C>
-static void small_launch(rls_ctx* ctx, const rls_small& D, int n_steps) {
-  hipLaunchKernelGGL((cgnr_small_kernel<E, R, C>), dim3(1), dim3(SM_NT), 0, ctx->stream, (const E*)D.A, D.lda, (int)D.M, (int)D.N, (E*)D.x,
-                     (E*)D.r, (E*)D.p, (E*)D.v, D.sc, n_steps, D.mb,
-                     (int)((reinterpret_cast<uintptr_t>(D.A) & 15) == 0 && (D.lda * (int64_t)sizeof(E)) % 16 == 0));
+static void small_launch(rls_ctx* ctx, const rls_small_group& G, int n_steps) {
+  hipLaunchKernelGGL((cgnr_small_kernel<E, R, C>), dim3((unsigned)G.count), dim3(SM_NT), 0, ctx->stream, G, n_steps);
 }
 
+// one tile shape for the whole group: the smallest that holds its largest system
 template <typename E>
-static int32_t small_typed(rls_ctx* ctx, const rls_small& D, int n_steps) {
+static int32_t small_typed(rls_ctx* ctx, const rls_small_group& G, int n_steps) {
+  int64_t Mx = 0, Nx = 0;
+  for (int k = 0; k < G.count; ++k) {
+    Mx = G.d[k].M > Mx ? G.d[k].M : Mx;
+    Nx = G.d[k].N > Nx ? G.d[k].N : Nx;
+  }
   small_tile t;
-  if (!small_pick<E>(D.M, D.N, &t)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "small-system kernel: shape too large");
+  if (G.count < 1 || G.count > RLS_SMALL_GROUP_MAX || !small_pick<E>(Mx, Nx, &t))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "small-system kernel: shape too large (or an empty / oversized group)");
 #define SM_CASE(RR, CC)          \
   if (t.R == RR && t.C == CC) {  \
-    small_launch<E, RR, CC>(ctx, D, n_steps); \
+    small_launch<E, RR, CC>(ctx, G, n_steps); \
   } else
   SM_CASE(1, 1) SM_CASE(2, 2) SM_CASE(4, 2) SM_CASE(4, 4) SM_CASE(8, 4) {
     if constexpr (!elem<E>::cplx) {
@@ -431,6 +499,12 @@ bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t ld
   return dtype == RLS_F32 ? small_pick<float>(M, N, &t) : small_pick<float2>(M, N, &t);
 }
 
+int32_t rls_small_group_launch(rls_ctx* ctx, int32_t dtype, const rls_small_group& G, int n_steps) {
+  return dtype == RLS_F32 ? small_typed<float>(ctx, G, n_steps) : small_typed<float2>(ctx, G, n_steps);
+}
 int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps) {
-  return dtype == RLS_F32 ? small_typed<float>(ctx, D, n_steps) : small_typed<float2>(ctx, D, n_steps);
+  rls_small_group G;
+  G.count = 1;
+  G.d[0] = D;
+  return rls_small_group_launch(ctx, dtype, G, n_steps);
 }

@@ -2392,6 +2392,67 @@ int32_t rls_cgnr_step(rls_cgnr* s, int32_t n_steps) {
   return cgnr_step_impl(s, n_steps);
 }
 
+// ---- K independent small systems in ONE launch (small.hip, rls_small_group) -----------------------------------------------------
+// The distinct-A flavour of a multi-solve (docs/src/literate/howto/multi_threading.jl:8-17: one solver and one A per problem) for
+// problems that each fit one CU's registers: every plan is an ordinary single-column plan on rls_cgnr_path 8; the group call
+// advances them together, one workgroup per plan, optionally with their init! in the same launch.
+static int32_t cgnr_group(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol, int32_t iterations,
+                          int32_t n_steps) {
+  if (!plans || count < 1 || !plans[0]) return RLS_E_INVALID;
+  rls_ctx* ctx = plans[0]->op->ctx;
+  if (n_steps < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr group: n_steps < 0");
+  const int32_t dtype = plans[0]->op->dtype;
+  RLS_HIP(ctx, rls_enter(ctx));
+  for (int32_t k = 0; k < count; ++k) {
+    rls_cgnr* s = plans[k];
+    if (!s || s->op->ctx != ctx || s->op->dtype != dtype) return rls_fail(ctx, RLS_E_INVALID, "cgnr group: plans of one context and one element type");
+    if (!cgnr_use_small(s)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr group: a plan is not on the small-system path (rls_cgnr_path 8)");
+    if (!b && !s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr group: step before init");
+    if (b && !b[k]) return rls_fail(ctx, RLS_E_INVALID, "cgnr group: null right-hand side");
+  }
+  for (int32_t k0 = 0; k0 < count; k0 += RLS_SMALL_GROUP_MAX) {
+    rls_small_group G;
+    G.count = count - k0 < RLS_SMALL_GROUP_MAX ? count - k0 : RLS_SMALL_GROUP_MAX;
+    for (int j = 0; j < G.count; ++j) {
+      rls_cgnr* s = plans[k0 + j];
+      rls_small& D = G.d[j];
+      D.A = s->op->A;
+      D.lda = s->op->lda;
+      D.M = s->op->M;
+      D.N = s->op->N;
+      D.x = s->x;
+      D.r = s->r;
+      D.p = s->p;
+      D.v = s->v;
+      D.sc = s->sc;
+      if (b) {
+        D.b = b[k0 + j];
+        D.lambda = lambda;
+        D.rel_tol = rel_tol;
+        D.max_iter = cgnr_effective_iterations(s, iterations);
+        s->sc_h->lambda = lambda;
+        s->sc_h->rel_tol = rel_tol;
+        s->sc_h->max_iter = D.max_iter;
+        s->initialised = true;
+        s->requested = 0;
+      }
+      s->requested += n_steps;
+    }
+    if (b || n_steps > 0) RLS_TRY(rls_small_group_launch(ctx, dtype, G, n_steps));
+  }
+  return 0;
+}
+
+int32_t rls_cgnr_step_group(rls_cgnr* const* plans, int32_t count, int32_t n_steps) {
+  return cgnr_group(plans, nullptr, count, 0.f, 0.f, 0, n_steps);
+}
+
+int32_t rls_cgnr_init_step_group(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol,
+                                 int32_t iterations, int32_t n_steps) {
+  if (!b) return RLS_E_INVALID;
+  return cgnr_group(plans, b, count, lambda, rel_tol, iterations, n_steps);
+}
+
 // measurement only: the two kernels of the fused pipeline timed separately.  Each is idempotent
 // when repeated (K_A reads the committed scalars and writes the staged ones, K_R the reverse), so
 // after one ordinary iteration the normal-operator kernel is launched n_steps times back to back
@@ -2734,7 +2795,8 @@ static int32_t cgnr_step_status_server(rls_cgnr* s, int32_t n_steps, rls_cgnr_st
 int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
-  if (s->initialised && n_steps > 0 && !s->resident_used && cgnr_use_server(s)) return cgnr_step_status_server(s, n_steps, out);
+  // (whole-solve calls gain nothing from a kernel that stays: server mode is for the per-iterate calls of a solve! loop with callbacks)
+  if (s->initialised && n_steps > 0 && n_steps <= 8 && !s->resident_used && cgnr_use_server(s)) return cgnr_step_status_server(s, n_steps, out);
   if (s->initialised && s->nrhs == 1 && n_steps > 0 && !s->resident_used) {
     RLS_HIP(ctx, rls_enter(ctx));
     s->mb_arm = rls_mailbox_arm(ctx, s->sc_h);
@@ -3244,7 +3306,7 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
 int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out) {  // as rls_cgnr_step_status
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
-  if (s->initialised && n_steps > 0 && !s->resident_used && server_usable(ctx, &s->srv) && !fista_use_small(s) && fista_use_resident(s)) {
+  if (s->initialised && n_steps > 0 && n_steps <= 8 && !s->resident_used && server_usable(ctx, &s->srv) && !fista_use_small(s) && fista_use_resident(s)) {
     // the resident kernel in server mode (cgnr_step_status_server): posted to the kernel left listening, or carried by a launch
     RLS_HIP(ctx, hipSetDevice(s->device));
     s->requested += n_steps;

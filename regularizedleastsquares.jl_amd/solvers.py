@@ -205,6 +205,14 @@ class CGNR(AbstractKrylovSolver):
         if not (np.isscalar(x0) and x0 == 0):
             # the reference's x0 != 0 branch reads a field that does not exist (src/CGNR.jl:119)
             raise NotImplementedError("CGNR: x0 != 0 is unsupported (it throws in the reference as well)")
+        lib = b.ctx.lib
+        self._prepare(state, b)
+        check(b.ctx.handle, lib.rls_cgnr_init(state._plan, b.ptr, float(self.L2.lam), state.relTol, self.iterations),
+              "rls_cgnr_init")
+        self._after_init(state)
+
+    def _prepare(self, state: CGNRState, b: DeviceVector):
+        """everything of init! ahead of the device work: the normalised L2 weight, the state vectors and the plan"""
         N = self._op.N
         lib = b.ctx.lib
         self.L2 = normalize(self.normalizeReg, self.L2, self.A, b, in_solver=True)  # :129
@@ -220,8 +228,9 @@ class CGNR(AbstractKrylovSolver):
         expect = self._op.M if self.A is not None else N
         if b.n != expect:
             raise ValueError(f"DimensionMismatch: b has length {b.n}, expected {expect}")
-        check(b.ctx.handle, lib.rls_cgnr_init(state._plan, b.ptr, float(self.L2.lam), state.relTol, self.iterations),
-              "rls_cgnr_init")
+
+    @staticmethod
+    def _after_init(state: CGNRState):
         state.iteration = 0
         state._done = False
         state._finalised = False
@@ -250,6 +259,49 @@ class CGNR(AbstractKrylovSolver):
         state._step_status(lib, n)
         while self.iterate(state) is not None:  # normally returns None at once
             pass
+
+
+def solve_group_(solvers, rhs):
+    """K independent solves, each solver with its OWN matrix -- the reference's other multi-solve flavour, one solver per problem
+    under `Threads.@threads` (docs/src/literate/howto/multi_threading.jl:8-17).  CGNR solvers of small systems (every plan on the
+    single-workgroup kernel, `rls_cgnr_path` 8) with the same L2 weight, relTol and iteration count run as ONE launch: init! and all
+    iterations of all K problems, one workgroup per problem (rls_cgnr_init_step_group).  Anything else: solve_ one after the other.
+    Returns the solutions in order."""
+    from .arrays import DeviceVector
+    solvers, rhs = list(solvers), list(rhs)
+    if len(solvers) != len(rhs):
+        raise ValueError("solve_group_: one right-hand side per solver")
+    ok = len(solvers) > 1 and all(isinstance(s_, CGNR) and isinstance(s_._op, OperatorHandle) and s_.A is not None and
+                                  isinstance(s_.state, CGNRState) for s_ in solvers)
+    if ok:
+        ctx = rhs[0].ctx
+        ok = all(isinstance(b, DeviceVector) and b.ctx is ctx and b.dtype == rhs[0].dtype for b in rhs)
+    if ok:
+        for s_, b in zip(solvers, rhs):
+            s_._prepare(s_.state, b)
+        first = solvers[0]
+        ok = all(s_.L2.lam == first.L2.lam and s_.state.relTol == first.state.relTol and s_.iterations == first.iterations
+                 for s_ in solvers)
+    if ok:
+        lib, K = ctx.lib, len(solvers)
+        path = C.c_int32(-1)
+        for s_ in solvers:
+            check(ctx.handle, lib.rls_cgnr_path(s_.state._plan, C.byref(path)), "rls_cgnr_path")
+            ok = ok and path.value == 8
+    if not ok:
+        return [solve_(s_, b) for s_, b in zip(solvers, rhs)]
+    plans = (C.c_void_p * K)(*[s_.state._plan for s_ in solvers])
+    bptr = (C.c_void_p * K)(*[b.ptr for b in rhs])
+    n = min(first.iterations, max(s_._op.N for s_ in solvers))  # (each plan stops at its own min(iterations, N): src/CGNR.jl:185)
+    check(ctx.handle, lib.rls_cgnr_init_step_group(plans, bptr, K, float(first.L2.lam), float(first.state.relTol), first.iterations, n),
+          "rls_cgnr_init_step_group")
+    out = []
+    for s_ in solvers:
+        CGNR._after_init(s_.state)
+        while s_.iterate(s_.state) is not None:   # (returns None at once: refreshes the status, applies the constraints)
+            pass
+        out.append(s_.state.x)
+    return out
 
 
 # --------------------------------------------------------------------------------------------

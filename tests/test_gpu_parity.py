@@ -2331,6 +2331,50 @@ def test_fista_small_system_kernel(rls, ctx, dt, M, N, kind, restart):
         assert np.array_equal(rls.solve_(sol2, bd).to_host(), x2)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_small_problem_group_one_launch(rls, ctx, dt):
+    """The reference's other multi-solve flavour -- one solver AND one matrix per problem (docs/src/literate/howto/multi_threading.jl:8-17)
+    -- for problems that each fit one CU: solve_group_ runs init! and every iteration of all K problems as ONE launch, one workgroup
+    per problem (rls_cgnr_init_step_group).  30 problems of differing shapes (two launches: 24 + 6) against the float64 oracle and
+    against the solo solves; the group step entry point continues a started group; a group that does not qualify falls back."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    K = 30
+    cplx = np.dtype(dt).kind == "c"   # (tall systems: a random square one is too ill-conditioned for a 1e-5 gate after 12 iterations)
+    shapes = [(lambda N: (int(rng.integers(2 * N + 8, 129 if cplx else 257)), N))(int(rng.integers(4, 33 if cplx else 65))) for _ in range(K)]
+    probs = [O.make_problem(M, N, dt, 200 + k) for k, (M, N) in enumerate(shapes)]
+    lam, iters = 1e-2, 12
+    mats = [rls.DeviceMatrix.from_host(A) for A, _, _ in probs]
+    rhs = [rls.DeviceVector.from_host(b) for _, _, b in probs]
+    make = lambda Ad: rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), iterations=iters, relTol=0.0)
+    group = [make(Ad) for Ad in mats]
+    xs = rls.solve_group_(group, rhs)
+    for k, ((A, xt, b), x) in enumerate(zip(probs, xs)):
+        ref = O.CGNR(A.astype(hi(dt)), reg=O.L2Regularization(lam), iterations=iters, relTol=0.0)
+        O.solve(ref, b.astype(hi(dt)))
+        assert group[k].state.iteration == ref.iteration == min(iters, shapes[k][1])
+        parity(f"small_group_{np.dtype(dt).name}_{k}", x.to_host(), ref.x,
+               lambda A=A, b=b: O.solve(O.CGNR(A, reg=O.L2Regularization(lam), iterations=iters, relTol=0.0), b), record=k < 2)
+        solo = rls.solve_(make(mats[k]), rhs[k]).to_host()
+        assert rel(x.to_host(), solo) < 1e-4   # (the group runs on the tile of its largest member: another summation order)
+    # a started group continues through the group step entry point: init + 5 iterations, then 7 more
+    plans = (C.c_void_p * K)()
+    bptr = (C.c_void_p * K)(*[b.ptr for b in rhs])
+    again = [make(Ad) for Ad in mats]
+    for k, (s_, b) in enumerate(zip(again, rhs)):
+        s_._prepare(s_.state, b)
+        plans[k] = s_.state._plan
+    L = rls._lib
+    L.check(ctx.handle, ctx.lib.rls_cgnr_init_step_group(plans, bptr, K, lam, 0.0, iters, 5), "init_step_group")
+    L.check(ctx.handle, ctx.lib.rls_cgnr_step_group(plans, K, 7), "step_group")
+    for k, s_ in enumerate(again):
+        assert np.array_equal(s_.state.x.to_host(), xs[k].to_host()), k   # 5 + 7 in two launches == 12 in one
+    # relTol differs between the solvers: not one launch -- the solves still come out
+    odd = [make(mats[0]), rls.createLinearSolver(rls.CGNR, mats[1], reg=rls.L2Regularization(lam), iterations=iters, relTol=1e-3)]
+    ys = rls.solve_group_(odd, rhs[:2])
+    assert np.array_equal(ys[0].to_host(), rls.solve_(make(mats[0]), rhs[0]).to_host())
+
+
 def test_batched_gram_resident_lost_launch_is_recovered(rls, ctx):
     """the batched resident launch (csrc/gramk.hip) under the same contract as the single-column ones: with the wait bound forced
     to one poll the launch gives up having changed nothing (only workgroup 0 writes the caller's state, after its last
