@@ -122,7 +122,7 @@ def usable_cpus():
     return n, quota
 
 
-def cpu_baseline_numpy(A, b, budget_s=8.0, max_iters=640):
+def cpu_baseline_numpy(A, b, budget_s=8.0, max_iters=1 << 30):  # (time-bounded: whole solves until budget_s is spent)
     """the oracle's CGNR (NumPy/OpenBLAS restatement of src/CGNR.jl:143-178) timed on the host.  OpenBLAS's cgemv does
     not scale to every core of a big host, so a short calibration picks the BLAS thread count (reported as `cores`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -151,8 +151,8 @@ def cpu_baseline_numpy(A, b, budget_s=8.0, max_iters=640):
             if nt > ncpu:
                 continue
             with threadpool_limits(limits=nt, user_api="blas"):
-                run(1, 0.5)  # warm
-                n, dt = run(1, 1.5)
+                run(1 << 20, 0.3)  # warm
+                n, dt = run(1 << 20, 0.8)
             calib[nt] = n / dt
         best_threads = max(calib, key=calib.get)
         ctxmgr = threadpool_limits(limits=best_threads, user_api="blas")

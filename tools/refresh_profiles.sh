@@ -33,5 +33,8 @@ cp $(find /tmp/prof_bgs -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_bat
 tools/ubench/grid_barrier 2000 2048 > gpurun_out/${R}_grid_barrier.txt 2>&1
 python3 tools/bench_cadence.py > gpurun_out/${R}_cadence.txt 2>&1
 python3 tools/bench_config1.py > gpurun_out/${R}_config1.txt 2>&1
+tools/ubench/launch_floor > gpurun_out/${R}_launch_floor.txt 2>&1
+python3 tools/bench_small_group.py > gpurun_out/${R}_small_group.txt 2>&1
+python3 tools/bench_tv_prox.py > gpurun_out/${R}_tv_prox.txt 2>&1
 cp gpurun_out/parity_errors.jsonl gpurun_out/${R}_parity_errors.jsonl 2>/dev/null
 head -c 900 gpurun_out/${R}_bench_kernel_stats.csv
