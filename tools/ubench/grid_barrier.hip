@@ -342,6 +342,145 @@ __global__ __launch_bounds__(NT) void group_kernel(sync_block* S, float* rows, f
   if (bad) atomicAdd(&S->bad, bad);
 }
 
+// The grouped two-level all-reduce WITHOUT barriers: every 8 bytes handed over are {one float of payload, a 32-bit tag = the round
+// number as a float}, written in 16-byte pieces (two items) and polled by the reader with 8-byte atomic loads (a buffer-load
+// intrinsic in a polling loop is hoisted out of it by the optimiser; 8-byte granules are atomic, so a torn 16-byte store shows at
+// worst one stale tag and is read again).  A reader polls the data itself: no "stores drained -> arrive -> poll -> load" chain, at
+// twice the bytes.
+//   publish my row (tagged) | member l re-reads slice l of its group's rows until every tag is this round's, sums in row order,
+//   publishes the group-partial slice (tagged, parity r & 1) | everyone re-reads the 8 group partials until tagged, sums in group order
+// Reuse is safe for the reasons the barriered form is: nobody can be two rounds ahead of anybody.
+__device__ static inline f4 ll_poll16(const float* base, uint32_t off, unsigned tag, unsigned* fail) {
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + off);
+  unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned n = 0; (unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag; ++n) {
+    if (n > SPIN) {
+      *fail = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  f4 t;
+  t.x = __builtin_bit_cast(float, (unsigned)a);
+  t.y = __builtin_bit_cast(float, (unsigned)(a >> 32));
+  t.z = __builtin_bit_cast(float, (unsigned)b);
+  t.w = __builtin_bit_cast(float, (unsigned)(b >> 32));
+  return t;
+}
+__global__ __launch_bounds__(NT) void ll_kernel(sync_block* S, float* rows, float* xpart, int nb, int rounds) {
+  float* ex = reinterpret_cast<float*>(smem + 1024);
+  const int tid = threadIdx.x;
+  constexpr unsigned GN = 8;
+  const unsigned nwg = gridDim.x, per = nwg / GN;
+  const unsigned grp = blockIdx.x % GN, mem = blockIdx.x / GN;
+  const unsigned slot = grp * per + mem;
+  const uint32_t llb = 2u * (uint32_t)nb;                 // bytes of a tagged row
+  const __amdgpu_buffer_rsrc_t rows_rs = sc1_rsrc(rows), x_rs = sc1_rsrc(xpart);
+  const int pieces_row = (int)(llb / 16u);                // 16-byte pieces (2 floats each) per row: 2048 at 16 KiB
+  const int per_thread = pieces_row / NT;                 // 4
+  const int pieces_slice = pieces_row / (int)per;         // 64
+  const int nrg = NT / pieces_slice;                      // 8 row groups
+  unsigned bad = 0, fail = 0;
+  float want0 = 0.f;
+  for (unsigned b = 0; b < nwg; ++b) want0 += (float)(b % 7);
+  for (int r = 1; r <= rounds && !fail; ++r) {
+    const float tf = (float)r;  // (a NORMAL float as the tag)
+    const unsigned tag = __builtin_bit_cast(unsigned, tf);
+    const float val = (float)((slot % 7) + (r % 5));
+    for (int q = 0; q < per_thread; ++q)
+      sc1_store16(rows_rs, slot * llb + (uint32_t)(q * NT + tid) * 16u, f4{val, tf, val, tf});
+    {
+      const int piece = tid % pieces_slice, rg = tid / pieces_slice;
+      float a0 = 0.f, a1 = 0.f;
+      {  // all four rows requested at once (per / nrg = 4 at the default shape), stale ones polled again one by one
+        unsigned long long lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned row = rg + (unsigned)k * nrg;
+          const unsigned long long* p = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(rows) + (grp * per + (row < per ? row : rg)) * llb + (mem * (uint32_t)pieces_slice + (uint32_t)piece) * 16u);
+          lo[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi[k] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned row = rg + (unsigned)k * nrg;
+          if (row >= per) continue;
+          f4 t;
+          if ((unsigned)(lo[k] >> 32) != tag || (unsigned)(hi[k] >> 32) != tag) {
+            t = ll_poll16(rows, (grp * per + row) * llb + (mem * (uint32_t)pieces_slice + (uint32_t)piece) * 16u, tag, &fail);
+          } else {
+            t.x = __builtin_bit_cast(float, (unsigned)lo[k]);
+            t.z = __builtin_bit_cast(float, (unsigned)hi[k]);
+          }
+          a0 += t.x;
+          a1 += t.z;
+        }
+      }
+      __syncthreads();  // (the previous round's readers of `ex` are done)
+      ex[2 * (rg * pieces_slice + piece)] = a0;
+      ex[2 * (rg * pieces_slice + piece) + 1] = a1;
+      __syncthreads();
+      if (tid < pieces_slice) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int g = 0; g < nrg; ++g) {
+          s0 += ex[2 * (g * pieces_slice + tid)];
+          s1 += ex[2 * (g * pieces_slice + tid) + 1];
+        }
+        sc1_store16(x_rs, ((uint32_t)(r & 1) * GN + grp) * llb + (mem * (uint32_t)pieces_slice + (uint32_t)tid) * 16u, f4{s0, tf, s1, tf});
+      }
+    }
+    const float want = want0 + (float)nwg * (float)(r % 5);
+    for (int q = 0; q < per_thread; ++q) {
+      float c0 = 0.f, c1 = 0.f;
+      unsigned long long lo[GN], hi[GN];
+#pragma unroll
+      for (unsigned x = 0; x < GN; ++x) {
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(xpart) + ((uint32_t)(r & 1) * GN + x) * llb + (uint32_t)(q * NT + tid) * 16u);
+        lo[x] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hi[x] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (unsigned x = 0; x < GN; ++x) {
+        f4 t;
+        if ((unsigned)(lo[x] >> 32) != tag || (unsigned)(hi[x] >> 32) != tag) {
+          t = ll_poll16(xpart, ((uint32_t)(r & 1) * GN + x) * llb + (uint32_t)(q * NT + tid) * 16u, tag, &fail);
+        } else {
+          t.x = __builtin_bit_cast(float, (unsigned)lo[x]);
+          t.z = __builtin_bit_cast(float, (unsigned)hi[x]);
+        }
+        c0 += t.x;
+        c1 += t.z;
+      }
+      if (c0 != want || c1 != want) ++bad;
+    }
+  }
+  if (fail && tid == 0) S->fail = 1;
+  if (bad) atomicAdd(&S->bad, bad);
+}
+
+static void run_ll(sync_block* S, float* rows, float* xpart, int nb, int rounds, int nwg, size_t lds, hipEvent_t e0, hipEvent_t e1) {
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemset(S, 0, sizeof(sync_block)));
+    CK(hipMemset(rows, 0, (size_t)nwg * nb * 2));
+    CK(hipMemset(xpart, 0, (size_t)32 * nb * 2));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(ll_kernel, dim3(nwg), dim3(NT), lds, 0, S, rows, xpart, nb, rounds);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    sync_block h;
+    CK(hipMemcpy(&h, S, sizeof(h), hipMemcpyDeviceToHost));
+    printf("ll     %8.3f us per round   fail %u  wrong sums %u   (tagged items polled by the reader, no barriers: 8 strided groups)\n", ms * 1e3 / rounds, h.fail, h.bad);
+  }
+}
+
 template <int GN, bool CONTIG>
 static void run_group(sync_block* S, float* rows, float* xpart, int nb, int rounds, int nwg, size_t lds, hipEvent_t e0, hipEvent_t e1) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel<GN, CONTIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -373,8 +512,8 @@ int main(int argc, char** argv) {
   float *rows, *xpart, *v;
   double* dots;
   CK(hipMalloc(&S, sizeof(sync_block)));
-  CK(hipMalloc(&rows, (size_t)nwg * nb));
-  CK(hipMalloc(&xpart, (size_t)32 * nb));
+  CK(hipMalloc(&rows, (size_t)nwg * nb * 2));   // (twice: the tagged variant hands over {float, tag} pairs)
+  CK(hipMalloc(&xpart, (size_t)32 * nb * 2));
   CK(hipMalloc(&v, nb));
   CK(hipMalloc(&dots, (size_t)nwg * 4 * sizeof(double)));
   const size_t lds = 148 * 1024;  // one workgroup per CU, as the product's kernels
@@ -427,6 +566,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(&h, S, sizeof(h), hipMemcpyDeviceToHost));
     printf("gbar   %8.3f us per round   fail %u  wrong sums %u   (bare group barrier: 8 strided groups of %d)\n", ms * 1e3 / rounds, h.fail, h.bad, nwg / 8);
   }
+  run_ll(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
   run_group<2, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
   run_group<4, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
   run_group<8, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
