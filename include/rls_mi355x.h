@@ -319,6 +319,8 @@ int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out_
  * place); status, solution and further rls_cgnr_step calls per plan as usual.  rls_cgnr_init_step_group also runs every plan's
  * init (r = A^H b[k], x = 0, p = r: src/CGNR.jl:107-130) inside the same launch: a whole solve of K problems is ONE launch. */
 int32_t rls_cgnr_step_group(rls_cgnr* const* plans, int32_t count, int32_t n_steps);
+/* the statuses of `count` single right-hand-side plans of one context in one read-back (out_h: count structs) */
+int32_t rls_cgnr_get_status_group(rls_cgnr* const* plans, int32_t count, rls_cgnr_status* out_h);
 int32_t rls_cgnr_init_step_group(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol,
                                  int32_t iterations, int32_t n_steps);
 /* Batched plan (BASELINE config 4, shared-A flavour; semantics of solve!(solver, B; scheduler =

@@ -92,9 +92,9 @@ void rls_pinned_free(void* p) {
 
 // ---- status mailbox --------------------------------------------------------------------------------------------------------
 struct fetch_args {
-  const unsigned* src[4];
-  unsigned* dst[4];
-  unsigned n[4];
+  const unsigned* src[RLS_FETCH_MAX];
+  unsigned* dst[RLS_FETCH_MAX];
+  unsigned n[RLS_FETCH_MAX];
   int count;
 };
 // one wave: every queued block, dword by dword, straight into pinned host memory (system-scope stores), then -- released
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void mailbox_publish_kernel(fetch_args A, unsig
 }
 
 int32_t rls_fetch_add(rls_ctx* ctx, const void* src_d, void* dst_pinned, size_t bytes) {
-  if (!ctx->tune.status_mailbox || (bytes & 3) || ctx->nfq >= 4) {
+  if (!ctx->tune.status_mailbox || (bytes & 3) || ctx->nfq >= RLS_FETCH_MAX) {
     RLS_HIP(ctx, hipMemcpyAsync(dst_pinned, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return 0;
   }
@@ -123,7 +123,7 @@ int32_t rls_fetch_wait(rls_ctx* ctx) {
   }
   fetch_args A;
   A.count = ctx->nfq;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < RLS_FETCH_MAX; ++k) {
     A.src[k] = k < ctx->nfq ? reinterpret_cast<const unsigned*>(ctx->fq[k].src) : nullptr;
     A.dst[k] = k < ctx->nfq ? reinterpret_cast<unsigned*>(ctx->fq[k].dst) : nullptr;
     A.n[k] = k < ctx->nfq ? ctx->fq[k].dwords : 0u;

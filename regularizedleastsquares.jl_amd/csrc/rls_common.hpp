@@ -40,6 +40,7 @@ struct rls_tuning {
                                // per-iteration pipeline (solvers.hip, *_recover)
 };
 
+constexpr int RLS_FETCH_MAX = 24;  // blocks one publishing kernel moves (the statuses of a group of small problems: rls_cgnr_get_status_group)
 struct rls_ctx {
   int device = 0;
   void* server = nullptr;  // the plan whose resident kernel is alive in server mode on this context's stream (rls_server_stop)
@@ -60,7 +61,7 @@ struct rls_ctx {
     const void* src;
     void* dst;
     unsigned dwords;
-  } fq[4];
+  } fq[RLS_FETCH_MAX];
   int nfq = 0;
   unsigned* mb_h = nullptr;  // pinned, host-mapped sequence word the publishing kernel stores last (system scope)
   unsigned mb_seq = 0;

@@ -2443,6 +2443,26 @@ static int32_t cgnr_group(rls_cgnr* const* plans, const void* const* b, int32_t 
   return 0;
 }
 
+// the statuses of a group in ONE read-back (one publishing kernel + one host spin per 24 plans instead of one per plan)
+int32_t rls_cgnr_get_status_group(rls_cgnr* const* plans, int32_t count, rls_cgnr_status* out) {
+  if (!plans || !out || count < 1 || !plans[0]) return RLS_E_INVALID;
+  rls_ctx* ctx = plans[0]->op->ctx;
+  RLS_HIP(ctx, rls_enter(ctx));
+  for (int32_t k = 0; k < count; ++k) {
+    rls_cgnr* s = plans[k];
+    if (!s || s->op->ctx != ctx || s->nrhs != 1) return rls_fail(ctx, RLS_E_INVALID, "cgnr status group: single-column plans of one context");
+    if (!s->initialised) return rls_fail(ctx, RLS_E_STATE, "cgnr_get_status before cgnr_init");
+    if (s->resident_used) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr status group: a plan has resident launches to account for (use rls_cgnr_get_status)");
+  }
+  for (int32_t k0 = 0; k0 < count; k0 += RLS_FETCH_MAX) {
+    const int32_t k1 = k0 + RLS_FETCH_MAX < count ? k0 + RLS_FETCH_MAX : count;
+    for (int32_t k = k0; k < k1; ++k) RLS_TRY(rls_fetch_add(ctx, plans[k]->sc, plans[k]->sc_h, sizeof(cgnr_scalars)));
+    RLS_TRY(rls_fetch_wait(ctx));
+  }
+  for (int32_t k = 0; k < count; ++k) cgnr_status_out(plans[k], *plans[k]->sc_h, out + k);
+  return 0;
+}
+
 int32_t rls_cgnr_step_group(rls_cgnr* const* plans, int32_t count, int32_t n_steps) {
   return cgnr_group(plans, nullptr, count, 0.f, 0.f, 0, n_steps);
 }

@@ -295,10 +295,14 @@ def solve_group_(solvers, rhs):
     n = min(first.iterations, max(s_._op.N for s_ in solvers))  # (each plan stops at its own min(iterations, N): src/CGNR.jl:185)
     check(ctx.handle, lib.rls_cgnr_init_step_group(plans, bptr, K, float(first.L2.lam), float(first.state.relTol), first.iterations, n),
           "rls_cgnr_init_step_group")
+    sts = (CgnrStatus * K)()
+    check(ctx.handle, lib.rls_cgnr_get_status_group(plans, K, sts), "rls_cgnr_get_status_group")   # ONE read-back for the group
     out = []
-    for s_ in solvers:
+    for s_, st in zip(solvers, sts):
         CGNR._after_init(s_.state)
-        while s_.iterate(s_.state) is not None:   # (returns None at once: refreshes the status, applies the constraints)
+        s_.state._take(st)
+        s_.state._status_valid = True
+        while s_.iterate(s_.state) is not None:   # (returns None at once where the solve is done: applies the constraints)
             pass
         out.append(s_.state.x)
     return out
