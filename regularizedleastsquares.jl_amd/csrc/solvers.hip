@@ -2186,7 +2186,12 @@ int32_t rls_cgnr_init_local_b(rls_cgnr* s) {
   return launch_status(ctx);
 }
 
+static int32_t cgnr_group(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol, int32_t iterations,
+                          int32_t n_steps);
 int32_t rls_cgnr_init(rls_cgnr* s, const void* b, float lambda, float rel_tol, int32_t iterations) {
+  // small systems: init! is the single-workgroup kernel's own (r = A^H b from the registers: ONE launch instead of a GEMV and an
+  // init kernel, and the same bits whether a solve is init + steps or one fused launch, rls_cgnr_init_step_group)
+  if (s && b && s->nrhs == 1 && s->op->A && cgnr_use_small(s)) return cgnr_group(&s, &b, 1, lambda, rel_tol, iterations, 0);
   RLS_TRY(rls_cgnr_init_local_a(s, b, lambda, rel_tol, iterations));
   return rls_cgnr_init_local_b(s);
 }

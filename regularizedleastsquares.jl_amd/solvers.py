@@ -271,7 +271,7 @@ def solve_group_(solvers, rhs):
     solvers, rhs = list(solvers), list(rhs)
     if len(solvers) != len(rhs):
         raise ValueError("solve_group_: one right-hand side per solver")
-    ok = len(solvers) > 1 and all(isinstance(s_, CGNR) and isinstance(s_._op, OperatorHandle) and s_.A is not None and
+    ok = len(solvers) >= 1 and all(isinstance(s_, CGNR) and isinstance(s_._op, OperatorHandle) and s_.A is not None and
                                   isinstance(s_.state, CGNRState) for s_ in solvers)
     if ok:
         ctx = rhs[0].ctx
@@ -289,7 +289,7 @@ def solve_group_(solvers, rhs):
             check(ctx.handle, lib.rls_cgnr_path(s_.state._plan, C.byref(path)), "rls_cgnr_path")
             ok = ok and path.value == 8
     if not ok:
-        return [solve_(s_, b) for s_, b in zip(solvers, rhs)]
+        return [solve_(s_, b, _no_group=True) for s_, b in zip(solvers, rhs)]
     plans = (C.c_void_p * K)(*[s_.state._plan for s_ in solvers])
     bptr = (C.c_void_p * K)(*[b.ptr for b in rhs])
     n = min(first.iterations, max(s_._op.N for s_ in solvers))  # (each plan stops at its own min(iterations, N): src/CGNR.jl:185)
@@ -2148,6 +2148,12 @@ def solve_(solver: AbstractLinearSolver, b, callbacks=None, **kw):
         cbs = [callbacks]
     else:
         cbs = list(callbacks)
+    no_group = kw.pop("_no_group", False)
+    if (not cbs and not kw and not no_group and isinstance(solver, CGNR) and isinstance(solver.state, CGNRState) and
+            isinstance(b, DeviceVector) and isinstance(solver._op, OperatorHandle) and solver.A is not None and
+            solver._op.M * solver._op.N * b.dtype.itemsize <= 128 * 1024):
+        # a system small enough for ONE CU: init! and every iteration as one launch (a group of one; the same bits as init_ + steps)
+        return solve_group_([solver], [b])[0]
     init_(solver, b, **kw)
     for cb in cbs:
         cb(solver, 0)
