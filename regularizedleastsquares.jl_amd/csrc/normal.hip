@@ -2111,7 +2111,9 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
 // barrier k publishes iteration k + 1 into the other buffer while a slower one still reads iteration k.  Same
 // visibility protocol, bounded spins and fail-as-a-no-op behaviour as the matrix-free resident kernel; same element
 // ownership and summation orders as cgnr_gram_kernel.
-template <typename E, int K, int BAR, bool FULL>
+// SRV: the instantiation that can stay and listen (server mode, rls_cgnr_step_status); not built for Float32 K = 32, which
+// has no registers to spare for it (it spilled 148-316 B per lane)
+template <typename E, int K, int BAR, bool FULL, bool SRV = false>
 __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* x, E* r, E* p,
                                                                   E* v0, E* v1, double* dots, cgnr_scalars* sc0,
                                                                   cgnr_scalars* sc1, resident_sync* sync, int64_t Mc,
@@ -2224,9 +2226,13 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     S.done = (St.maxiter <= 0) || (rr == 0.0) || (1.0f <= St.reltol);
     if (S.done) n_steps = 0;  // uniform: nothing to iterate; the state below is written back as it stands
   }
-  int it = 0;
-  for (; it < n_steps; ++it) {
-    const int q = it & 1;
+  rls_mailbox_slot srv_mb = St.srv_mb;
+  unsigned srv_seq = St.srv_seq0;  // server mode (rls_cgnr_step_status): the command being served
+  unsigned itg = 0;                // iterations run by this launch, over all its commands: the parity of v and of the dots
+  for (;;) {  // (server mode: one pass per command; otherwise one pass)
+  for (int it = 0; it < n_steps; ++it) {
+    if (SRV && S.done) break;  // uniform (a command behind the one that reached the stopping test)
+    const int q = (int)(itg++ & 1u);
     E* vq = q ? v1 : v0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = pv[e];
@@ -2296,6 +2302,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
   }
   if (!alive) {
     resident_give_up(sync, St.enabled ? St.poison : nullptr);
+    if (SRV && St.srv_ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;  // x, r, p, v and the scalars are untouched: the call was a no-op
   }
   if (blockIdx.x == 0) {
@@ -2306,17 +2313,34 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
         x[i] = xv[e];
         r[i] = rv[e];
         p[i] = pv[e];
-        v0[i] = vv[e];  // the last v (a workgroup still reading parity 0 reads the same values)
+        // the last v (a workgroup still reading parity 0 reads the same values).  A kernel that stays and listens must not leave
+        // these lines DIRTY in this XCD's L2: v0 is an exchange buffer, a later command's write-through rows from other XCDs
+        // would be overwritten whenever the stale lines are evicted
+        if constexpr (SRV) sc1_store_elem<E>(v0 + i, vv[e]);
+        else v0[i] = vv[e];
       }
     }
+    S.pending = 0;
+    S.cur = 0;
+    S.fresh = 0;
     if (tid == 0) {
-      S.pending = 0;
-      S.cur = 0;
-      S.fresh = 0;
       *sc0 = S;
       *sc1 = S;
       sync->completed = 1u;
     }
+    if constexpr (SRV) {
+      if (St.srv_ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
+    }
+  }
+  if constexpr (SRV) {
+    if (!St.srv_ctl) break;  // uniform
+    const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &flag, srv_mb,
+                                         srv_seq - St.srv_seq0 + 1u);
+    if (cmd == RLS_SRV_EXIT) return;  // uniform
+    n_steps = (int)cmd;
+  } else {
+    break;
+  }
   }
 }
 
@@ -3271,6 +3295,20 @@ static int32_t launch_gram_resident(rls_ctx* ctx, const rls_gram_pipe& P, void* 
   hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, BB, FF>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,  \
                      P.ldg, (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],         \
                      (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, St)
+  if constexpr (K != 32) {
+    if (St.srv_ctl) {  // the instantiation that can stay and listen
+#define RLS_LAUNCH_GRS(FF)                                                                                                \
+  hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, 1, FF, true>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, \
+                     P.ldg, (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],            \
+                     (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, St)
+      if (full) RLS_LAUNCH_GRS(true);
+      else RLS_LAUNCH_GRS(false);
+#undef RLS_LAUNCH_GRS
+      return launch_status(ctx);
+    }
+  } else if (St.srv_ctl) {
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram CGNR: no listening instantiation for this shape");
+  }
   if (full) RLS_LAUNCH_GR(1, true);
   else RLS_LAUNCH_GR(1, false);
 #undef RLS_LAUNCH_GR
@@ -3441,6 +3479,12 @@ int32_t rls_fista_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fi
 bool rls_gram_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, const void* G, int64_t ldg) {
   if (!rls_gram_pipe_ok(dtype, N, G, ldg)) return false;
   return dtype == RLS_F32 ? gram_resident_ok_typed<float>(ctx->device, N) : gram_resident_ok_typed<float2>(ctx->device, N);
+}
+// shapes whose resident Gram kernel has a listening (server mode) instantiation: every one but the 32-columns-per-row-piece slabs
+bool rls_gram_resident_server_ok(int32_t dtype, int64_t N) {
+  int K = 0;
+  const bool ok = dtype == RLS_F32 ? gram_pick<float>(N, &K) : gram_pick<float2>(N, &K);
+  return ok && K != 32;
 }
 int32_t rls_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, void* sync, int n_steps,
                                  unsigned spin_limit, const rls_cg_start& St) {

@@ -777,6 +777,7 @@ int32_t rls_gram_pipe_iteration(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe
 int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, int parity);
 // resident Gram-mode CGNR / cg!: the whole step call as one launch, AHA held in registers (normal.hip)
 bool rls_gram_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, const void* G, int64_t ldg);
+bool rls_gram_resident_server_ok(int32_t dtype, int64_t N);
 int32_t rls_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P, void* sync, int n_steps,
                                  unsigned spin_limit, const rls_cg_start& start = rls_cg_start());
 

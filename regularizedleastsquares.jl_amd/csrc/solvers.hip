@@ -2084,6 +2084,11 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess && !s->rsync && rls_gram_resident_ok(ctx, op->dtype, op->N, op->G, op->ldg)) {
       e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
       s->gram_resident = e == hipSuccess;
+      if (e == hipSuccess && !s->srv.ctl && rls_gram_resident_server_ok(op->dtype, op->N) &&
+          hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess) {
+        memset(s->srv.ctl, 0, 32 * sizeof(unsigned));
+        s->srv.resident_used = &s->resident_used;
+      }
     }
   }
   if (e == hipSuccess && skinny) {
@@ -2668,7 +2673,9 @@ extern "C++" {
 static bool server_usable(const rls_ctx* ctx, const srv_state* v) {
   return ctx->tune.resident_server && ctx->tune.status_mailbox && v->ctl && !v->off && (ctx->server == nullptr || ctx->server == v);
 }
-static bool cgnr_use_server(const rls_cgnr* s) { return server_usable(s->op->ctx, &s->srv) && cgnr_use_resident(s); }
+static bool cgnr_use_server(const rls_cgnr* s) {
+  return server_usable(s->op->ctx, &s->srv) && (cgnr_use_resident(s) || (cgnr_use_gram_resident(s) && s->nrhs == 1));
+}
 
 // the life of a listening kernel is over (it was told to leave, left idle, or gave up): bookkeeping, and the verdict on lives
 // too short to pay for their launch
@@ -2796,6 +2803,12 @@ static int32_t cgnr_step_status_server(rls_cgnr* s, int32_t n_steps, rls_cgnr_st
     St.srv_seq0 = a.seq0;
     St.srv_idle_us = a.idle_us;
     St.srv_mb = a.mb;
+    if (cgnr_use_gram_resident(s)) {  // AHA explicit, held in the register files
+      const rls_gram_pipe G = cgnr_gram_desc(s);
+      return resident_chain(ctx, s->rsync, [&]() {
+        return rls_gram_resident_launch(ctx, s->op->dtype, G, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, St);
+      }, &s->rsync_clean);
+    }
     const rls_cgnr_pipe P = cgnr_pipe_desc(s);
     return resident_chain(ctx, s->rsync, [&]() {
       return rls_cgnr_resident_launch(ctx, s->op->dtype, P, s->rdots, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, St);

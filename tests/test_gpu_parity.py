@@ -2622,6 +2622,42 @@ def test_fista_resident_server_mode(rls, ctx, restart):
     assert rel(x_pipe, x_once) < 2e-5
 
 
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 3000, 1500)])
+def test_cgnr_gram_resident_server_mode(rls, ctx, dt, M, N):
+    """server mode on the reference constructor's default operator (AHA = A' * A explicit, held in the register files: rls_cgnr_path 5):
+    32 one-iterate calls back to back are the bits of ONE 32-iteration launch and the Gram-mode oracle's iterate; a download in
+    between makes the kernel leave first; the stopping test ends the stream"""
+    import ctypes as C
+    iters = 32
+    ref, sol, b, dt64 = _cgnr_pair(rls, M, N, dt, 97, 1e-3, iters, mode="gram")
+    O.solve(ref, b.astype(dt64))
+    bd = rls.DeviceVector.from_host(b)
+    rls.init_(sol, bd)
+    if _cgnr_path(rls, sol) != 5:
+        _resident_unavailable()
+    x_once = rls.solve_(sol, bd).to_host()
+    rls.init_(sol, bd)
+    k = 0
+    while rls.iterate(sol) is not None:
+        k += 1
+    assert k == iters and sol.state.iteration == iters and sol.state.fallbacks == 0
+    x_srv = sol.state.x.to_host()
+    assert np.array_equal(x_srv, x_once)
+    ref32 = O.CGNR(ref.A.A.astype(dt), reg=O.L2Regularization(1e-3), iterations=iters, relTol=0.0, normal="gram")
+    parity(f"cgnr_gram_server_{M}x{N}", x_srv, ref.x, lambda: O.solve(ref32, b), record=False)
+    rls.init_(sol, bd)
+    k = 0
+    while rls.iterate(sol) is not None:
+        k += 1
+        if k in (3, 4, 5):
+            sol.state.x.to_host()
+    assert k == iters
+    parity(f"cgnr_gram_server_downloads_{M}x{N}", sol.state.x.to_host(), ref.x, lambda: O.solve(ref32, b), record=False)
+    stt = rls._lib.CgnrStatus()
+    for _ in range(2):   # past the end: served, nothing changes
+        assert ctx.lib.rls_cgnr_step_status(sol.state._plan, 1, C.byref(stt)) == 0 and stt.iteration == iters and stt.done == 1
+
+
 def test_cgnr_resident_server_survives_a_co_tenant(rls, ctx):
     """a listening launch that cannot get its 256 workgroups onto the chip gives up like every resident launch: the call
     re-runs its iterate on the per-iteration pipeline, reports the fallback, and the solve ends at the oracle's iterate"""

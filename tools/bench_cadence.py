@@ -53,3 +53,11 @@ for mb in (2, 1, 0):
                                                tolInner=1e-5, absTol=0.0, relTol=0.0),
                 lambda p, st_: L.check(h, lib.rls_admm_step_status(p, 1, C.byref(st_), None, 0), "admm"), L.AdmmStatus, 8)
     print(f"status_mailbox={mb}: CGNR {c:6.1f} us per iterate call, FISTA + L1 {f:6.1f}, ADMM + L1 {a:6.1f} us per outer iteration", flush=True)
+# the reference constructor's default operator (AHA = A' * A explicit): resident Gram kernel, with and without server mode
+G = Ad.gram()
+for srv in (1, 0):
+    ctx.tune(status_mailbox=2, resident_server=srv)
+    c = cadence(lambda: rls.createLinearSolver(rls.CGNR, Ad, AHA=G, iterations=32, relTol=0.0),
+                lambda p, st_: L.check(h, lib.rls_cgnr_step_status(p, 1, C.byref(st_)), "cgnr"), L.CgnrStatus, 32)
+    print(f"CGNR on the explicit Gram matrix, resident_server={srv}: {c:6.1f} us per iterate call", flush=True)
+ctx.tune(resident_server=1)
