@@ -865,6 +865,7 @@ struct rls_small {
   const void* b = nullptr;
   float lambda = 0.f, rel_tol = 0.f;
   int max_iter = 0;
+  rls_srv_args srv;  // server mode (groups of one): the workgroup stays and listens for the next step call (rls_cg_start::srv_ctl)
 };
 // K independent small systems, one workgroup each, in ONE launch (the distinct-A flavour of a multi-solve,
 // docs/src/literate/howto/multi_threading.jl:8-17): the descriptors travel as a kernel argument

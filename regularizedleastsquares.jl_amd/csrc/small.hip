@@ -208,6 +208,11 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group
     if (lane == 0) sdone = S.done;
   }
   __syncthreads();
+  __shared__ unsigned srv_cmd, srv_mbseq;
+  rls_mailbox_slot mbs = mb;
+  unsigned srv_seq = D.srv.seq0;
+  bool first = true;
+  for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = 0; it < n_steps; ++it) {
     if (sdone) break;  // uniform
     small_normal_partials<E, R, C>(a, ps, vpart, cb, lane, w);
@@ -283,12 +288,45 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group
       sc->alpha_re = S.alpha_re; sc->alpha_im = S.alpha_im; sc->beta_re = S.beta_re; sc->beta_im = S.beta_im;
       sc->iteration = S.iteration; sc->done = S.done;
       sc->pending = 0; sc->cur = 0; sc->fresh = 0;
-      if (init) {
+      if (init && first) {
         sc->z0 = S.z0; sc->lambda = S.lambda; sc->rel_tol = S.rel_tol; sc->max_iter = S.max_iter;
       }
     }
     S.pending = 0; S.cur = 0; S.fresh = 0;
-    rls_mailbox_publish(mb, S, lane);
+    rls_mailbox_publish(mbs, S, lane);
+    // ---- server mode: this workgroup stays and listens for the next step call (one CU; nothing else waits for it) ----------------
+    if (D.srv.ctl && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back is out before anything else is announced)
+      unsigned* ctl = D.srv.ctl;
+      const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)D.srv.idle_us * 100ull;
+      unsigned n = RLS_SRV_EXIT, seq = srv_seq;
+      for (; srv_seq - D.srv.seq0 + 1u < 2048u;) {  // (as resident_listen: idle timeout, "leaving" handshake, a bounded life)
+        seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (seq != srv_seq) break;
+        if (wall_clock64() - t0 > idle) {
+          __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      srv_cmd = n;
+      srv_mbseq = __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (n == RLS_SRV_EXIT) __hip_atomic_store(ctl + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (!D.srv.ctl) break;  // uniform
+  __syncthreads();
+  const unsigned cmd = srv_cmd;
+  if (cmd == RLS_SRV_EXIT) return;  // uniform
+  n_steps = (int)cmd;
+  mbs.seq = srv_mbseq;
+  srv_seq += 1;
+  first = false;
+  __syncthreads();  // (srv_cmd is read before the next pass can overwrite it)
   }
 }
 

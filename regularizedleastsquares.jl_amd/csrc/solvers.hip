@@ -2057,13 +2057,17 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
       e = dmalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
   }
   s->small = nrhs == 1 && op->A && !op->G && rls_small_ok(op->dtype, op->M, op->N, op->A, op->lda);
+  if (e == hipSuccess && s->small && !s->srv.ctl && hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess) {
+    memset(s->srv.ctl, 0, 32 * sizeof(unsigned));  // (the single-workgroup kernel can stay and listen as well: rls_cgnr_step_status)
+    s->srv.resident_used = nullptr;                // (no co-residency requirement, nothing to give up: no flags to read)
+  }
   if (e == hipSuccess && nrhs == 1 && op->slab && op->A && !op->G &&
       rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
     const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
     e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
     if (e == hipSuccess) e = dmalloc(&s->rdots, db);
     if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
-    if (e == hipSuccess) e = hmalloc(&s->srv.ctl, 32 * sizeof(unsigned));
+    if (e == hipSuccess && !s->srv.ctl) e = hmalloc(&s->srv.ctl, 32 * sizeof(unsigned));
     if (e == hipSuccess) memset(s->srv.ctl, 0, 32 * sizeof(unsigned));
     s->srv.resident_used = &s->resident_used;
   }
@@ -2674,7 +2678,8 @@ static bool server_usable(const rls_ctx* ctx, const srv_state* v) {
   return ctx->tune.resident_server && ctx->tune.status_mailbox && v->ctl && !v->off && (ctx->server == nullptr || ctx->server == v);
 }
 static bool cgnr_use_server(const rls_cgnr* s) {
-  return server_usable(s->op->ctx, &s->srv) && (cgnr_use_resident(s) || (cgnr_use_gram_resident(s) && s->nrhs == 1));
+  return server_usable(s->op->ctx, &s->srv) &&
+         (cgnr_use_small(s) || cgnr_use_resident(s) || (cgnr_use_gram_resident(s) && s->nrhs == 1));
 }
 
 // the life of a listening kernel is over (it was told to leave, left idle, or gave up): bookkeeping, and the verdict on lives
@@ -2803,6 +2808,21 @@ static int32_t cgnr_step_status_server(rls_cgnr* s, int32_t n_steps, rls_cgnr_st
     St.srv_seq0 = a.seq0;
     St.srv_idle_us = a.idle_us;
     St.srv_mb = a.mb;
+    if (cgnr_use_small(s)) {  // the single-workgroup kernel: one CU stays, nothing to chain
+      rls_small D;
+      D.A = s->op->A;
+      D.lda = s->op->lda;
+      D.M = s->op->M;
+      D.N = s->op->N;
+      D.x = s->x;
+      D.r = s->r;
+      D.p = s->p;
+      D.v = s->v;
+      D.sc = s->sc;
+      D.mb = a.mb;
+      D.srv = a;
+      return rls_small_launch(ctx, s->op->dtype, D, n_steps);
+    }
     if (cgnr_use_gram_resident(s)) {  // AHA explicit, held in the register files
       const rls_gram_pipe G = cgnr_gram_desc(s);
       return resident_chain(ctx, s->rsync, [&]() {
