@@ -878,7 +878,8 @@ int32_t rls_small_group_launch(rls_ctx* ctx, int32_t dtype, const rls_small_grou
 bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps);
 struct rls_fista_pipe;
-int32_t rls_fista_small_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, int n_steps);
+int32_t rls_fista_small_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, int n_steps,
+                               const rls_srv_args& Sv = rls_srv_args());
 
 // Batched CGNR on an explicit Gram matrix as ONE resident launch per step call (gramk.hip): up to 8 ComplexF32 right-hand
 // sides, AHA (N <= 2048) held in the register files, the operand panel replicated in every workgroup's LDS

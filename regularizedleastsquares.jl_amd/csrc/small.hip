@@ -123,6 +123,31 @@ __device__ static inline void small_adjoint_partials(const E (&a)[R][C], const E
   __syncthreads();
 }
 
+// server mode of the single-workgroup kernels: ONE thread polls the control block (protocol of resident_listen, resident_sync.hpp:
+// idle timeout, the "leaving" handshake, a bounded life) and leaves the command for the workgroup in LDS
+__device__ static inline void small_listen(const rls_srv_args& srv, unsigned srv_seq, unsigned* cmd_out, unsigned* mbseq_out) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back is out before anything else is announced)
+  unsigned* ctl = srv.ctl;
+  const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)srv.idle_us * 100ull;
+  unsigned n = RLS_SRV_EXIT, seq = srv_seq;
+  for (; srv_seq - srv.seq0 + 1u < 2048u;) {
+    seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seq != srv_seq) break;
+    if (wall_clock64() - t0 > idle) {
+      __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  *cmd_out = n;
+  *mbseq_out = __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (n == RLS_SRV_EXIT) __hip_atomic_store(ctl + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One workgroup per system of the group (blockIdx.x): K independent small problems -- each with its own A -- advance in ONE launch.
 template <typename E, int R, int C>
 __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group G, int n_steps) {
@@ -295,28 +320,7 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group
     S.pending = 0; S.cur = 0; S.fresh = 0;
     rls_mailbox_publish(mbs, S, lane);
     // ---- server mode: this workgroup stays and listens for the next step call (one CU; nothing else waits for it) ----------------
-    if (D.srv.ctl && lane == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back is out before anything else is announced)
-      unsigned* ctl = D.srv.ctl;
-      const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)D.srv.idle_us * 100ull;
-      unsigned n = RLS_SRV_EXIT, seq = srv_seq;
-      for (; srv_seq - D.srv.seq0 + 1u < 2048u;) {  // (as resident_listen: idle timeout, "leaving" handshake, a bounded life)
-        seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (seq != srv_seq) break;
-        if (wall_clock64() - t0 > idle) {
-          __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
-      if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      srv_cmd = n;
-      srv_mbseq = __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (n == RLS_SRV_EXIT) __hip_atomic_store(ctl + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (D.srv.ctl && lane == 0) small_listen(D.srv, srv_seq, &srv_cmd, &srv_mbseq);
   }
   if (!D.srv.ctl) break;  // uniform
   __syncthreads();
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group
 template <typename E, int R, int C>
 __global__ __launch_bounds__(SM_NT) void fista_small_kernel(const E* __restrict__ A, int64_t lda, int M, int N, E* b0, E* b1,
                                                             const E* __restrict__ x0, E* res, E* y0, E* y1, fista_scalars* sc,
-                                                            int n_steps, rls_mailbox_slot mb, int vec16) {
+                                                            int n_steps, rls_mailbox_slot mb, int vec16, rls_srv_args srv) {
   constexpr int NP = 16 * C;
   constexpr int EPT = (NP + 63) / 64;
   __shared__ E ps[NP];             // the extrapolated point y, zero beyond N
@@ -370,6 +374,10 @@ __global__ __launch_bounds__(SM_NT) void fista_small_kernel(const E* __restrict_
     if (lane == 0) sdone = S.done;
   }
   __syncthreads();
+  __shared__ unsigned srv_cmd, srv_mbseq;
+  rls_mailbox_slot mbs = mb;
+  unsigned srv_seq = srv.seq0;
+  for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = 0; it < n_steps; ++it) {
     if (sdone) break;  // uniform
     small_normal_partials<E, R, C>(a, ps, vpart, cb, lane, w);
@@ -450,7 +458,17 @@ __global__ __launch_bounds__(SM_NT) void fista_small_kernel(const E* __restrict_
       S.fresh = 0;
       if (lane == 0) RLS_FISTA_COPY(*sc, S);
     }
-    rls_mailbox_publish(mb, S, lane);
+    rls_mailbox_publish(mbs, S, lane);
+    if (srv.ctl && lane == 0) small_listen(srv, srv_seq, &srv_cmd, &srv_mbseq);
+  }
+  if (!srv.ctl) break;  // uniform
+  __syncthreads();
+  const unsigned cmd = srv_cmd;
+  if (cmd == RLS_SRV_EXIT) return;  // uniform
+  n_steps = (int)cmd;
+  mbs.seq = srv_mbseq;
+  srv_seq += 1;
+  __syncthreads();
   }
 }
 
@@ -506,14 +524,14 @@ static int32_t small_typed(rls_ctx* ctx, const rls_small_group& G, int n_steps) 
 }  // namespace
 
 template <typename E>
-static int32_t fista_small_typed(rls_ctx* ctx, const rls_fista_pipe& P, int n_steps) {
+static int32_t fista_small_typed(rls_ctx* ctx, const rls_fista_pipe& P, int n_steps, const rls_srv_args& Sv) {
   small_tile t;
   if (!small_pick<E>(P.M, P.N, &t)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "small-system kernel: shape too large");
   const int vec16 = (int)((reinterpret_cast<uintptr_t>(P.A) & 15) == 0 && (P.lda * (int64_t)sizeof(E)) % 16 == 0);
 #define SM_CASE(RR, CC)                                                                                                        \
   if (t.R == RR && t.C == CC) {                                                                                                \
     hipLaunchKernelGGL((fista_small_kernel<E, RR, CC>), dim3(1), dim3(SM_NT), 0, ctx->stream, (const E*)P.A, P.lda, (int)P.M,  \
-                       (int)P.N, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, P.sc, n_steps, P.mb, vec16); \
+                       (int)P.N, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, P.sc, n_steps, P.mb, vec16, Sv); \
   } else
   SM_CASE(1, 1) SM_CASE(2, 2) SM_CASE(4, 2) SM_CASE(4, 4) SM_CASE(8, 4) {
     if constexpr (!elem<E>::cplx) {
@@ -527,8 +545,8 @@ static int32_t fista_small_typed(rls_ctx* ctx, const rls_fista_pipe& P, int n_st
 }
 
 // a whole rls_fista_step call of a system rls_small_ok accepts (plan state in the pipeline's layout: P.b0 / b1, y0 / y1, sc)
-int32_t rls_fista_small_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, int n_steps) {
-  return dtype == RLS_F32 ? fista_small_typed<float>(ctx, P, n_steps) : fista_small_typed<float2>(ctx, P, n_steps);
+int32_t rls_fista_small_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe& P, int n_steps, const rls_srv_args& Sv) {
+  return dtype == RLS_F32 ? fista_small_typed<float>(ctx, P, n_steps, Sv) : fista_small_typed<float2>(ctx, P, n_steps, Sv);
 }
 
 bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {

@@ -2898,6 +2898,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   s->res_raw1 = nullptr;
   s->use_gram = false;
   s->small = op->A && !op->G && rls_small_ok(op->dtype, op->M, op->N, op->A, op->lda);
+  if (s->small && hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess) memset(s->srv.ctl, 0, 32 * sizeof(unsigned));  // (server mode of the single-workgroup kernel)
   const size_t vb = (size_t)op->N * rls_elem_size(op->dtype);
   hipError_t e = dmalloc(&s->y, vb);
   const bool gram = op->G && rls_gram_pipe_ok(op->dtype, op->N, op->G, op->ldg);
@@ -2928,7 +2929,7 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
       if (s->rsync) dfree(s->rsync);
       s->rsync = nullptr;  // resident mode is an optimisation: without its scratch the pipeline runs
       (void)hipGetLastError();
-    } else if (!gram && hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess) {
+    } else if (!gram && (s->srv.ctl || hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess)) {
       memset(s->srv.ctl, 0, 32 * sizeof(unsigned));
       s->srv.resident_used = &s->resident_used;
     }
@@ -3364,13 +3365,19 @@ int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out) {
 int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* out) {  // as rls_cgnr_step_status
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
-  if (s->initialised && n_steps > 0 && n_steps <= 8 && !s->resident_used && server_usable(ctx, &s->srv) && !fista_use_small(s) && fista_use_resident(s)) {
+  if (s->initialised && n_steps > 0 && n_steps <= 8 && !s->resident_used && server_usable(ctx, &s->srv) &&
+      (fista_use_small(s) || fista_use_resident(s))) {
     // the resident kernel in server mode (cgnr_step_status_server): posted to the kernel left listening, or carried by a launch
     RLS_HIP(ctx, hipSetDevice(s->device));
     s->requested += n_steps;
     s->enq += n_steps;
     const int32_t r = server_command(ctx, &s->srv, s->sc_h, n_steps, true, [&](const rls_srv_args& a) {
-      const rls_fista_pipe P = fista_pipe_desc(s);
+      rls_fista_pipe P = fista_pipe_desc(s);
+      if (fista_use_small(s)) {  // the single-workgroup kernel: one CU stays, nothing to chain
+        if (!P.y1) P.y1 = P.y0;
+        P.mb = a.mb;
+        return rls_fista_small_launch(ctx, s->op->dtype, P, n_steps, a);
+      }
       return resident_chain(ctx, s->rsync, [&]() {
         return rls_fista_resident_launch(ctx, s->op->dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, a);
       }, &s->rsync_clean);
