@@ -2658,6 +2658,43 @@ def test_cgnr_gram_resident_server_mode(rls, ctx, dt, M, N):
         assert ctx.lib.rls_cgnr_step_status(sol.state._plan, 1, C.byref(stt)) == 0 and stt.iteration == iters and stt.done == 1
 
 
+def test_server_mode_with_four_contexts_at_once(rls, ctx):
+    """four threads, each with its own context (= stream), each driving a resident CGNR plan one iterate per call: every listening
+    kernel holds the whole chip, so they take turns (the resident chain orders the launches; a kernel that is kept waiting leaves on
+    its idle timeout) -- nobody deadlocks, nobody gets a wrong iterate"""
+    import threading
+    M, N = 4096, 2048
+    A, xt, b = O.make_problem(M, N, np.complex64, 99)
+    S0 = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A), iterations=24, relTol=0.0)
+    x_ref = rls.solve_(S0, rls.DeviceVector.from_host(b)).to_host()
+    errs = []
+
+    def worker(k):
+        try:
+            c = rls.Context(0)
+            Ad, bd = rls.DeviceMatrix.from_host(A, c), rls.DeviceVector.from_host(b, c)
+            S = rls.createLinearSolver(rls.CGNR, Ad, iterations=24, relTol=0.0)
+            for rep in range(3):
+                rls.init_(S, bd)
+                n = 0
+                while rls.iterate(S) is not None:
+                    n += 1
+                x = S.state.x.to_host()
+                assert n == 24 and rel(x, x_ref) < 2e-5, (k, rep, n, rel(x, x_ref))
+            del S
+            c.close()
+        except Exception as e:  # noqa: BLE001 -- surfaced after the join
+            errs.append((k, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(120)
+    assert not any(t.is_alive() for t in ths), "a worker is stuck"
+    assert not errs, errs
+
+
 def test_cgnr_resident_server_survives_a_co_tenant(rls, ctx):
     """a listening launch that cannot get its 256 workgroups onto the chip gives up like every resident launch: the call
     re-runs its iterate on the per-iteration pipeline, reports the fallback, and the solve ends at the oracle's iterate"""
