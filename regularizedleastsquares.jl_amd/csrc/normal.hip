@@ -2068,6 +2068,12 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     return;  // x, r, p and the scalars are untouched: the call was a no-op
   }
   if (blockIdx.x == 0) {
+    S.pending = 0;
+    S.cur = 0;
+    S.fresh = 0;
+    // server mode: the status of this command goes to the host FIRST -- the write-back below then runs under the host's turnaround.
+    // (Whoever wants x, r, p from memory asks the kernel to leave first, rls_enter, and it leaves behind its write-back.)
+    if (St.srv_ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);
     E xf[EPT];
     load_owned_sc1(xf, xw);
     // buffer stores (a descriptor in SGPRs + a 32-bit lane offset): nothing per-lane has to survive the loop for them
@@ -2085,14 +2091,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     store_buf(x, xf);
     store_buf(r, rv);
     store_buf(p, pv);
-    S.pending = 0;
-    S.cur = 0;
-    S.fresh = 0;
     if (tid == 0) {
       *sc = S;
       sync->completed = 1u;
     }
-    if (St.srv_ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
   }
   if (!St.srv_ctl) break;  // uniform
   // ---- server mode: listen for the next command (resident_listen, resident_sync.hpp) ----------------------------------------
@@ -2448,6 +2450,10 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     return;
   }
   if (blockIdx.x == 0) {
+    S.ycur = ycur;
+    S.pending = 0;
+    S.fresh = 0;
+    if (Sv.ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // (server mode: status first, write-back under the host's turnaround)
     E* xw = (S.iteration & 1) ? b1 : b0;   // state.x == buf[iteration & 1] afterwards as well
     E* xo = (S.iteration & 1) ? b0 : b1;
     E* yw = ycur ? y1 : y0;
@@ -2467,14 +2473,10 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
         *reinterpret_cast<f4*>(yw + o) = __builtin_bit_cast(f4, c2);
       }
     }
-    S.ycur = ycur;
-    S.pending = 0;
-    S.fresh = 0;
     if (tid == 0) {
       RLS_FISTA_COPY(*sc, S);
       sync->completed = 1u;
     }
-    if (Sv.ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
   }
   if (!Sv.ctl) break;  // uniform
   const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb, srv_seq - Sv.seq0 + 1u);
