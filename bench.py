@@ -433,6 +433,34 @@ def other_paths(rls, ctx, Ad, A, b, errors):
             res["gram_setup_ms (A' * A on the matrix cores, once per operator)"] = state.get("gram_ms")
             return res
 
+    @entry("fista_l1_batched_8_rhs_gram_mode (solve!(FISTA, B) on the reference's DEFAULT operator, AHA explicit and shared by the columns -- "
+           "src/FISTA.jl:58,151, src/MultiThreading.jl:30-48)")
+    def _():
+        Xf = (rng.standard_normal((N, 8)) + 1j * rng.standard_normal((N, 8))).astype(np.complex64)
+        Bf = rls.DeviceMatrix.from_host(np.asfortranarray((A @ Xf).astype(np.complex64)), ctx)
+        res = {}
+        for tag, res_on in (("", 1), ("_streaming (resident = 0)", 0)):
+            ctx.tune(resident=res_on)
+            try:
+                S = rls.createLinearSolver(rls.FISTA, Ad, AHA=state["G"], reg=rls.L1Regularization(1e-2), rho=rho, iterations=32, relTol=0.0)
+                rls.solve_(S, Bf, scheduler=rls.BatchedState)
+                stf = S.state
+                pth = C.c_int32(-1)
+                lib.rls_fista_path(stf._plan, C.byref(pth))
+                us = {n: timed(lambda n=n: (rls._lib.check(h, lib.rls_fista_init_batched(stf._plan, Bf.ptr, Bf.lda, rho, 1.0, 0.0, n, 0), "init"),
+                                            rls._lib.check(h, lib.rls_fista_step(stf._plan, n), "step")), n, reps=4) for n in (32, 128)}
+            finally:
+                ctx.tune(resident=1)
+            gb = N * N * 8 / us[32] / 1e3
+            res["gram" + tag] = {"us_per_batched_iteration_incl_init": us[32], "us_per_batched_iteration_128_iteration_call_incl_init": us[128],
+                                 "solve_iterations_per_s": 8e6 / us[32], "kernel_path": pth.value,
+                                 "roofline": {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                                              "bytes_per_batched_iteration": N * N * 8,
+                                              "note": ("path 7: AHA in the register files for the whole step call; per iteration only the rows of the next "
+                                                       "extrapolated point travel (N x K values, ONE grid barrier) -- bytes / time, not traffic"
+                                                       if pth.value == 7 else "path 3: one matrix-core product over AHA + the per-column update launch")}}
+        return res
+
     @entry("fista_l1_batched_16_rhs (solve!(FISTA, B), f32 MFMA)")
     def _():
         Xf = (rng.standard_normal((N, 16)) + 1j * rng.standard_normal((N, 16))).astype(np.complex64)

@@ -374,7 +374,13 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
  * changing, the others go on).  x, x0, xold, res: N x nrhs, columns ldv elements apart; column j's current
  * solution is in x when its iteration count is even, in xold when odd (the pointer swap of :144-146).
  * RLS_E_UNSUPPORTED unless the operator is matrix-free with M, N multiples of 16.  rls_fista_set_reg,
- * rls_fista_step and rls_fista_destroy apply unchanged. */
+ * rls_fista_step and rls_fista_destroy apply unchanged.
+ * With an explicit AHA on the operator (the constructors' default for a dense matrix, src/FISTA.jl:58) every product is
+ * ONE pass over AHA; with <= 8 ComplexF32 columns, N <= 2048 (a multiple of 16), no gradient restart and an elementwise
+ * regulariser (none, L1, L2) a whole rls_fista_step call of more than one iteration is ONE resident launch -- AHA in the
+ * register files, every workgroup advancing its own 8 rows of all columns, the rows of the next extrapolated point
+ * the only exchange (rls_fista_path 7).  A launch that cannot get its grid onto the chip changes nothing;
+ * rls_fista_get_status_batched re-runs what it left undone on the streaming kernels and counts it in `fallbacks`. */
 int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* x0, void* xold, void* res, int64_t ldv,
                                  rls_fista** out);
 int32_t rls_fista_init_batched(rls_fista* s, const void* B, int64_t ldb, float rho, float theta, float rel_tol,
@@ -390,7 +396,8 @@ int32_t rls_fista_set_start(rls_fista* s, const void* x_init, int64_t n);
 int32_t rls_fista_step(rls_fista* s, int32_t n_steps);
 /* which kernel sequence the next rls_fista_step call takes (the codes of rls_cgnr_path): 0 = two GEMVs + update kernel,
  * 1 = one-pass slab pipeline, 2 = Gram-mode pipeline, 3 = batched matrix-core kernels, 4 = resident (one launch per
- * call, A in registers), 5 = resident Gram mode (one launch per call, AHA in registers), 8 = small system (one single-workgroup
+ * call, A in registers), 5 = resident Gram mode (one launch per call, AHA in registers), 7 = batched resident Gram mode
+ * (rls_fista_create_batched), 8 = small system (one single-workgroup
  * launch per call, A in one CU's registers: fista_small_kernel) */
 int32_t rls_fista_path(rls_fista* s, int32_t* out);
 int32_t rls_fista_get_status(rls_fista* s, rls_fista_status* out_h); /* synchronises; recovers lost resident launches as rls_cgnr_get_status */

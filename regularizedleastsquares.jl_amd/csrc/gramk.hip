@@ -548,19 +548,376 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
   }
 }
 
-static size_t gk_lds_bytes(int64_t N) { return gk_panel_bytes(N) + sizeof(gk_lds_tail); }
+// ---- batched FISTA on the explicit Gram matrix (src/FISTA.jl:141-189 per column, src/MultiThreading.jl:30-79) ---------------
+// FISTA without gradient restart has NO global scalar on its critical path: theta follows a data-independent recursion and
+// ||res|| only decides retirement.  So nothing is replicated here: workgroup b forms res = AHA y - x0, the prox and the NEXT
+// extrapolated point for ITS 8 rows (wave 0, one element per lane), publishes those rows of y (512 bytes) and its 8 partial
+// ||res||^2, and behind the ONE grid barrier of the iteration every workgroup gathers the new panel straight into LDS (two
+// 16-byte pieces per slot, already in the panel's layout) while the 2048 partial norms are summed for the retirement flags.
+// A column that retires in an iteration still gets its next extrapolated point into the plan-owned y (the streaming update
+// leaves y alone then); nothing reads y of a retired column.
+struct fk_col {
+  double norm_x0, res_norm, rel;
+  float rho, theta, theta_old, rel_tol, lambda;
+  int iteration, max_iter, done, active, reg_kind, proj_kind;
+};
+struct fk_lds_tail {
+  float red[GK_WV][256];
+  double dsum[64 * 8];
+  fk_col cs[GK_KB];
+  float stage[GK_ROWS * 16];
+  int flag, alld;
+};
 
-template <int NE>
-static void gk_allow_lds() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgnr_gramk_resident_kernel<NE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)gk_lds_bytes(256 * NE));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgnr_gramk_resident_kernel<NE, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)gk_lds_bytes(256 * NE));
+template <int NE, bool FULL>
+__global__ __launch_bounds__(GK_NT) void fista_gramk_resident_kernel(rls_fgramk D, resident_sync* sync, int n_steps,
+                                                                     unsigned spin_limit) {
+  extern __shared__ __align__(16) char gk_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  GK_STAMP(8);
+  const int N = FULL ? 256 * NE : (int)D.N;
+  const int nwg = gridDim.x, b = blockIdx.x, row0 = b * GK_ROWS;
+  constexpr int spw = 8 * NE, npad = 256 * NE;
+  char* pl = gk_lds;
+  const uint32_t tail0 = (uint32_t)(npad / 32) * GK_GRP;
+  fk_lds_tail& T = *reinterpret_cast<fk_lds_tail*>(gk_lds + tail0);
+  const int nrhs = D.nrhs;
+  const int h = w & 1;
+  const int nl = (w >> 1) * 64 + lane;
+
+  // ---- state in: scalars, AHA rows (registers), y (LDS panel), own rows of x, xold, x0, res (wave 0: lane = (row, column)) ----
+  if (tid < GK_KB) {
+    fk_col& c = T.cs[tid];
+    const bool real_col = tid < nrhs;
+    const fista_scalars* s = D.sc + (real_col ? tid : 0);
+    c.norm_x0 = real_col ? s->norm_x0 : 1.0;
+    c.res_norm = real_col ? s->res_norm : 0.0;
+    c.rel = real_col ? s->rel_res_norm : 0.0;
+    c.rho = real_col ? s->rho : 0.f;
+    c.theta = real_col ? s->theta : 1.f;
+    c.theta_old = real_col ? s->theta_old : 1.f;
+    c.rel_tol = real_col ? s->rel_tol : 0.f;
+    c.lambda = real_col ? s->lambda : 0.f;
+    c.iteration = real_col ? s->iteration : 0;
+    c.max_iter = real_col ? s->max_iter : 0;
+    c.done = real_col ? s->done : 1;  // padding columns never take part
+    c.active = real_col ? !s->done : 0;
+    c.reg_kind = real_col ? s->reg_kind : RLS_REG_NONE;
+    c.proj_kind = real_col ? s->proj_kind : RLS_PROJ_NONE;
+    const unsigned long long alld = __ballot(c.done != 0);
+    if (tid == 0) T.alld = (alld & 0xffull) == 0xffull;
+  }
+  const uint32_t pc_lo = (uint32_t)(2 * (w >> 1) + (lane >> 5)) * GK_GRP + (uint32_t)h * GK_REG + (uint32_t)(lane & 31) * 16u;
+  const uint32_t pc_hi = pc_lo + (NE > 4 ? 4u * 8u * GK_GRP : 0u);
+  {
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(D.y), 0, 0xffffffff, 0x00020000);
+    const uint32_t ldvb = (uint32_t)D.ldv * 8u;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int n = nl + 256 * e;
+      const bool rowok = FULL || n < N;
+      const uint32_t voff = (uint32_t)(FULL ? nl : (rowok ? n : 0)) * 8u;
+      f4 yr4, yi4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * h + j;
+        const bool ok = rowok && k < nrhs;
+        const uint32_t so = (uint32_t)(k < nrhs ? k : 0) * ldvb + (FULL ? (uint32_t)e * 2048u : 0u);
+        const float2 yv = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(y_rs, voff, so, 0));
+        yr4[j] = ok ? yv.x : 0.f;
+        yi4[j] = ok ? yv.y : 0.f;
+      }
+      *reinterpret_cast<f4*>(GK_PC(e, 0)) = yr4;
+      *reinterpret_cast<f4*>(GK_PC(e, 1)) = yi4;
+    }
+  }
+  // wave 0, lane (xr = lane >> 3, xk = lane & 7): element (row0 + xr, column xk).  state.x of a column is buf[iteration & 1]
+  // seen from the update that produced it: the update of iteration count `it` wrote (it & 1) ? b0 : b1.
+  float2 xcur = make_float2(0.f, 0.f), xprev = xcur, x0own = xcur, resown = xcur;
+  if (w == 0) {
+    const int xr = lane >> 3, xk = lane & 7;
+    if (xk < nrhs) {
+      const int itk = D.sc[xk].iteration;
+      const int64_t at = (int64_t)xk * D.ldv + row0 + xr;
+      const float2* cur = reinterpret_cast<const float2*>(((itk - 1) & 1) ? D.b0 : D.b1);
+      const float2* prv = reinterpret_cast<const float2*>(((itk - 1) & 1) ? D.b1 : D.b0);
+      xcur = cur[at];
+      xprev = prv[at];
+      x0own = reinterpret_cast<const float2*>(D.x0)[at];
+      resown = reinterpret_cast<const float2*>(D.res)[at];
+    }
+  }
+  float ga[spw];
+  {
+    const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(D.G), 0, 0xffffffff, 0x00020000);
+    const uint32_t colb = (uint32_t)D.ldg * 8u;
+    const uint32_t voff = (uint32_t)row0 * 8u + (uint32_t)(lane & 15) * 4u + (uint32_t)(lane >> 4) * colb;
+#pragma unroll
+    for (int s = 0; s < spw; ++s) {
+      const int c0 = 4 * (w * spw + s);
+      const bool ok = FULL || c0 < N;
+      const float g = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, voff, (uint32_t)(ok ? c0 : 0) * colb, 0));
+      ga[s] = ok ? g : 0.f;
+    }
+  }
+  __syncthreads();
+  GK_STAMP(9);
+  const __amdgpu_buffer_rsrc_t yx_rs = sc1_rsrc(D.Yx);
+  // exchanged rows of y: [parity][part (re | im)][column half][row][16 bytes] -- a thread's gather is the panel piece it stores
+  const uint32_t yx_piece = (uint32_t)npad * 16u, yx_par = 4u * yx_piece;
+  const uint32_t yx_lane = (uint32_t)h * yx_piece + (uint32_t)nl * 16u;
+  const uint32_t jq = (uint32_t)(lane >> 4), jj = (uint32_t)(lane & 15);
+  const uint32_t lane_const = (2u * (jj >> 3) + ((jj >> 2) & 1u)) * GK_REG + jq * 16u + (jj & 3u) * 4u;
+  unsigned epoch = 0;
+  bool alive = true;
+  for (int it = 0; it < n_steps; ++it) {
+    const int q = it & 1;
+    GK_STAMP(0);
+    // ---- (AHA y) rows of this workgroup on the matrix cores ------------------------------------------------------------------
+    gk_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const char* bp = pl + (uint32_t)(w * (spw >> 3)) * GK_GRP + lane_const;
+#pragma unroll
+      for (int s = 0; s < spw; ++s) {
+        const float bv = *reinterpret_cast<const float*>(bp + (s >> 3) * (int)GK_GRP + (s & 7) * 64);
+        if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], bv, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], bv, acc0, 0, 0, 0);
+        if ((s & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    acc0 += acc1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) T.red[w][(4 * (int)jq + t) * 16 + (int)jj] = acc0[t];
+    lds_barrier();
+    GK_STAMP(1);
+    // every column had retired before this iteration (replicated scalars: every workgroup leaves in the same iteration; wave 0
+    // set the flag ahead of ITS products -- the barrier above orders it -- and the products just formed are dropped)
+    if (T.alld) break;
+    // ---- wave 0: the whole update of this workgroup's 8 x 8 elements, then the hand-off ----------------------------------------
+    if (w == 0) {
+      const int xr = lane >> 3, xk = lane & 7;
+      float vre = 0.f, vim = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < GK_WV; ++ww) {
+        vre += T.red[ww][(2 * xr) * 16 + xk] - T.red[ww][(2 * xr + 1) * 16 + xk + 8];
+        vim += T.red[ww][(2 * xr) * 16 + xk + 8] + T.red[ww][(2 * xr + 1) * 16 + xk];
+      }
+      const fk_col& c = T.cs[xk];
+      const bool on = c.active != 0;
+      const float yr = *reinterpret_cast<const float*>(pl + gk_elem_off((uint32_t)(row0 + xr), (uint32_t)xk));
+      const float yi = *reinterpret_cast<const float*>(pl + gk_elem_off((uint32_t)(row0 + xr), (uint32_t)xk + 8u));
+      const float2 ri = make_float2(vre - x0own.x, vim - x0own.y);                                   // res .-= x0       :153
+      float2 xi = elem<float2>::sub(make_float2(yr, yi), elem<float2>::scale(c.rho, ri));            // x .-= rho .* res :154
+      xi = fista_proj_elem<float2>(fista_prox_elem<float2>(xi, c.reg_kind, c.rho * c.lambda), c.proj_kind);  //         :164
+      const float theta_old = c.theta;                                                               // :179
+      const float theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;                    // :180
+      const float c1 = (1.f - theta_old) / theta, c2 = (theta_old - 1.f) / theta + 1.f;
+      const float2 yn = elem<float2>::add(elem<float2>::scale(c1, xcur), elem<float2>::scale(c2, xi));  // :147-148 of the next one
+      double rn = 0.0;
+      float2 yout = make_float2(yr, yi);
+      if (on) {
+        rn = (double)ri.x * (double)ri.x + (double)ri.y * (double)ri.y;
+        xprev = xcur;
+        xcur = xi;
+        resown = ri;
+        yout = yn;
+      }
+      T.stage[xr * 16 + xk] = yout.x;
+      T.stage[xr * 16 + 8 + xk] = yout.y;
+      T.dsum[xr * 8 + xk] = rn;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < GK_KB) {  // ||res||^2 of column `lane` over the 8 rows, fixed order
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < GK_ROWS; ++r) s += T.dsum[r * 8 + lane];
+        gk_sc1_store_f64(D.dots + ((size_t)q * 256 + b) * 8 + lane, s);
+      } else if (lane >= 32) {  // the 8 rows of y as panel pieces: (part, column half, row)
+        const int i = lane - 32, hh = i >> 4, r = (i >> 1) & 7, part = i & 1;
+        const float* sp = T.stage + r * 16 + part * 8 + hh * 4;
+        const f4 val = {sp[0], sp[1], sp[2], sp[3]};
+        gk_sc1_store16(yx_rs, (uint32_t)q * yx_par + (uint32_t)(2 * part + hh) * yx_piece + (uint32_t)(row0 + r) * 16u, val);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the storing wave drains its own stores
+    }
+    GK_STAMP(2);
+    if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &T.flag)) {
+      alive = false;
+      break;
+    }
+    GK_STAMP(3);
+    // ---- behind the barrier: partial norms (wanted first) and the new panel, all requested at once -----------------------------
+    {
+      // partial norms [256 slots][8] per parity (slots >= nwg stay zero): thread (bg = tid >> 3, j = tid & 7) sums slots 4 bg .. 4 bg + 3
+      const double* dp = D.dots + ((size_t)q * 256 + (size_t)(tid >> 3) * 4) * 8 + (tid & 7);
+      double part[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        part[i] = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(dp + i * 8), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+      f4 yre[NE], yim[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        yre[e] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(yx_rs, yx_lane, (uint32_t)q * yx_par + e * 4096u, 16));
+        yim[e] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(yx_rs, yx_lane, (uint32_t)q * yx_par + 2u * yx_piece + e * 4096u, 16));
+      }
+      T.dsum[tid] = (part[0] + part[1]) + (part[2] + part[3]);  // [bg][j]
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        *reinterpret_cast<f4*>(GK_PC(e, 0)) = yre[e];
+        *reinterpret_cast<f4*>(GK_PC(e, 1)) = yim[e];
+      }
+    }
+    lds_barrier();
+    GK_STAMP(4);
+    if (w == 0) {  // lane (g8 = lane >> 3, j = lane & 7): groups 8 g8 .. 8 g8 + 7, then a fixed butterfly over g8
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += T.dsum[((lane >> 3) * 8 + i) * 8 + (lane & 7)];
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      int done = 1;
+      if (lane < GK_KB) {
+        fk_col& c = T.cs[lane];
+        if (c.active) {
+          const float theta_old = c.theta;
+          c.theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;
+          c.theta_old = theta_old;
+          c.res_norm = sqrt(s);
+          const float rel = (float)(c.res_norm / c.norm_x0);                  // :156
+          c.rel = (double)rel;
+          c.iteration += 1;
+          c.done = (rel < c.rel_tol) || (c.iteration >= c.max_iter);          // :187-189
+          c.active = !c.done;
+        }
+        done = c.done;
+      }
+      const unsigned long long nd = __ballot(done == 0);
+      if (lane == 0) T.alld = nd == 0ull;
+    }
+    // no barrier here: the scalars are wave 0's own business until its update phase, `alld` is read behind the next
+    // iteration's product barrier -- the other seven waves are already multiplying
+    GK_STAMP(5);
+  }
+  GK_STAMP(10);
+  if (alive) {
+    // ---- gather: every workgroup publishes its rows of x, xold and res; one more barrier; workgroup 0 writes the caller's state
+    if (w == 0) {
+      float2* Xx = reinterpret_cast<float2*>(D.Xx);
+      const int xr = lane >> 3, xk = lane & 7;
+      const size_t at = (size_t)(row0 + xr) * GK_KB + xk, plane = (size_t)N * GK_KB;
+      sc1_store_elem<float2>(Xx + at, xcur);
+      sc1_store_elem<float2>(Xx + plane + at, xprev);
+      sc1_store_elem<float2>(Xx + 2 * plane + at, resown);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    alive = grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &T.flag);
+  }
+  if (!alive) {
+    resident_give_up(sync, nullptr);
+    return;  // the plan's vectors and scalars are untouched: the call was a no-op
+  }
+  GK_STAMP(11);
+  if (b != 0) return;
+  {
+    // 16 bytes (two columns of a row) per load, 16 loads in flight per thread: the three gathered arrays are 3 x 128 KiB read by
+    // ONE workgroup -- element by element, 8 in flight, they cost ~30 us per launch
+    const __amdgpu_buffer_rsrc_t xx_rs = sc1_rsrc(D.Xx);
+    const int items = N * (GK_KB / 2);
+    const uint32_t plane_b = (uint32_t)N * GK_KB * 8u;
+    // (N <= 2048: items <= 16 per thread -- ONE round of loads for all three arrays, then the stores)
+    f4 xg[3][16];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = u * GK_NT + tid;
+        const int ic = idx < items ? idx : 0;
+        const int kp = FULL ? ic >> (8 + (NE == 8 ? 3 : NE == 4 ? 2 : NE == 2 ? 1 : 0)) : ic / N, n = ic - kp * N;
+        xg[a][u] = sc1_load16(xx_rs, (uint32_t)a * plane_b + (uint32_t)n * 64u + (uint32_t)kp * 16u);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = u * GK_NT + tid;
+        if (idx < items) {
+          const int kp = FULL ? idx >> (8 + (NE == 8 ? 3 : NE == 4 ? 2 : NE == 2 ? 1 : 0)) : idx / N, n = idx - kp * N;
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int k = 2 * kp + c2;
+            if (k < nrhs) {
+              const int odd = (T.cs[k].iteration - 1) & 1;  // where the column's last update wrote state.x
+              float2* dst = a == 2 ? reinterpret_cast<float2*>(D.res)
+                                   : reinterpret_cast<float2*>((a == 0) == (odd != 0) ? D.b0 : D.b1);
+              dst[(int64_t)k * D.ldv + n] = c2 ? make_float2(xg[a][u][2], xg[a][u][3]) : make_float2(xg[a][u][0], xg[a][u][1]);
+            }
+          }
+        }
+      }
+    }
+    float2* Yo = reinterpret_cast<float2*>(D.y);
+    float* pp = D.Ypack;  // the streaming kernels' operand panel ([n][8 re | 8 im]) kept in step
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int n = nl + 256 * e;
+      if (FULL || n < N) {
+        const f4 yr4 = *reinterpret_cast<const f4*>(GK_PC(e, 0));
+        const f4 yi4 = *reinterpret_cast<const f4*>(GK_PC(e, 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 4 * h + j;
+          if (k < nrhs) Yo[(int64_t)k * D.ldv + n] = make_float2(yr4[j], yi4[j]);
+        }
+        if (pp) {
+          *reinterpret_cast<f4*>(pp + (size_t)n * 16 + 4 * h) = yr4;
+          *reinterpret_cast<f4*>(pp + (size_t)n * 16 + 8 + 4 * h) = yi4;
+        }
+      }
+    }
+    if (tid < nrhs) {
+      const fk_col& c = T.cs[tid];
+      fista_scalars* s = D.sc + tid;
+      s->res_norm = c.res_norm;
+      s->rel_res_norm = c.rel;
+      s->theta = c.theta;
+      s->theta_old = c.theta_old;
+      s->iteration = c.iteration;
+      s->done = c.done;
+    }
+    if (tid == 0) sync->completed = 1u;
+    GK_STAMP(12);
+  }
 }
-template <int NE>
+
+static size_t gk_lds_bytes(int64_t N) { return gk_panel_bytes(N) + sizeof(gk_lds_tail); }
+static size_t fk_lds_bytes(int64_t N) { return gk_panel_bytes(N) + sizeof(fk_lds_tail); }
+
+// KIND 0: CGNR, 1: FISTA
+template <int KIND, int NE, bool FULL>
+static const void* gk_kernel() {
+  if constexpr (KIND == 0) return reinterpret_cast<const void*>(&cgnr_gramk_resident_kernel<NE, FULL>);
+  else return reinterpret_cast<const void*>(&fista_gramk_resident_kernel<NE, FULL>);
+}
+template <int KIND>
+static size_t gk_kind_lds(int64_t N) { return KIND == 0 ? gk_lds_bytes(N) : fk_lds_bytes(N); }
+
+template <int KIND, int NE>
+static void gk_allow_lds() {
+  (void)hipFuncSetAttribute(gk_kernel<KIND, NE, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gk_kind_lds<KIND>(256 * NE));
+  (void)hipFuncSetAttribute(gk_kernel<KIND, NE, false>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gk_kind_lds<KIND>(256 * NE));
+}
+template <int KIND, int NE>
 static hipError_t gk_occupancy(int* blocks, bool full) {
-  return full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, cgnr_gramk_resident_kernel<NE, true>, GK_NT, gk_lds_bytes(256 * NE))
-              : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, cgnr_gramk_resident_kernel<NE, false>, GK_NT, gk_lds_bytes(256 * NE));
+  if constexpr (KIND == 0)
+    return full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, cgnr_gramk_resident_kernel<NE, true>, GK_NT, gk_lds_bytes(256 * NE))
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, cgnr_gramk_resident_kernel<NE, false>, GK_NT, gk_lds_bytes(256 * NE));
+  else
+    return full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fista_gramk_resident_kernel<NE, true>, GK_NT, fk_lds_bytes(256 * NE))
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fista_gramk_resident_kernel<NE, false>, GK_NT, fk_lds_bytes(256 * NE));
 }
 template <int NE>
 static void gk_launch(rls_ctx* ctx, const rls_gramk& D, void* sync, int n_steps, unsigned spin_limit) {
@@ -572,6 +929,42 @@ static void gk_launch(rls_ctx* ctx, const rls_gramk& D, void* sync, int n_steps,
   else
     hipLaunchKernelGGL((cgnr_gramk_resident_kernel<NE, false>), dim3(nwg), dim3(GK_NT), lds, ctx->stream, D, (resident_sync*)sync, n_steps,
                        spin_limit);
+}
+template <int NE>
+static void fk_launch(rls_ctx* ctx, const rls_fgramk& D, void* sync, int n_steps, unsigned spin_limit) {
+  const int nwg = (int)(D.N / GK_ROWS);
+  const size_t lds = fk_lds_bytes(D.N);
+  if (D.N == 256 * NE)
+    hipLaunchKernelGGL((fista_gramk_resident_kernel<NE, true>), dim3(nwg), dim3(GK_NT), lds, ctx->stream, D, (resident_sync*)sync, n_steps,
+                       spin_limit);
+  else
+    hipLaunchKernelGGL((fista_gramk_resident_kernel<NE, false>), dim3(nwg), dim3(GK_NT), lds, ctx->stream, D, (resident_sync*)sync, n_steps,
+                       spin_limit);
+}
+
+// shapes both kernels take, and whether one workgroup of kernel KIND fits a CU
+template <int KIND>
+static bool gk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, const void* G, int64_t ldg) {
+  if (dtype != RLS_C32 || !G || nrhs < 1 || nrhs > GK_KB || N < 16 || N % 16 || N > GK_NMAX) return false;
+  if (((uintptr_t)G & 15) || (ldg % 2) || ldg * 8 * N >= (int64_t)0xffffffffll) return false;
+  const int nwg = (int)(N / GK_ROWS);
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return false;
+  if (!(nwg <= cus && nwg <= 256)) return false;
+  static rls_device_once attr_once;
+  if (attr_once.first(ctx->device)) {
+    gk_allow_lds<KIND, 1>();
+    gk_allow_lds<KIND, 2>();
+    gk_allow_lds<KIND, 4>();
+    gk_allow_lds<KIND, 8>();
+  }
+  int blocks = 0;
+  const int ne = gk_ne(N);
+  const bool full = N == 256 * ne;
+  const hipError_t e = ne == 1 ? gk_occupancy<KIND, 1>(&blocks, full) : ne == 2 ? gk_occupancy<KIND, 2>(&blocks, full)
+                       : ne == 4 ? gk_occupancy<KIND, 4>(&blocks, full) : gk_occupancy<KIND, 8>(&blocks, full);
+  (void)hipGetLastError();
+  return e == hipSuccess && blocks >= 1;
 }
 
 }  // namespace
@@ -585,26 +978,7 @@ void rls_gramk_sizes(int64_t N, size_t* vx_bytes, size_t* xx_bytes, size_t* dots
 }
 
 bool rls_gramk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, const void* G, int64_t ldg) {
-  if (dtype != RLS_C32 || !G || nrhs < 1 || nrhs > GK_KB || N < 16 || N % 16 || N > GK_NMAX) return false;
-  if (((uintptr_t)G & 15) || (ldg % 2) || ldg * 8 * N >= (int64_t)0xffffffffll) return false;
-  const int nwg = (int)(N / GK_ROWS);
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return false;
-  if (!(nwg <= cus && nwg <= 256)) return false;
-  static rls_device_once attr_once;
-  if (attr_once.first(ctx->device)) {
-    gk_allow_lds<1>();
-    gk_allow_lds<2>();
-    gk_allow_lds<4>();
-    gk_allow_lds<8>();
-  }
-  int blocks = 0;
-  const int ne = gk_ne(N);
-  const bool full = N == 256 * ne;
-  const hipError_t e = ne == 1 ? gk_occupancy<1>(&blocks, full) : ne == 2 ? gk_occupancy<2>(&blocks, full)
-                       : ne == 4 ? gk_occupancy<4>(&blocks, full) : gk_occupancy<8>(&blocks, full);
-  (void)hipGetLastError();
-  return e == hipSuccess && blocks >= 1;
+  return gk_resident_ok<0>(ctx, dtype, N, nrhs, G, ldg);
 }
 
 int32_t rls_gramk_resident_launch(rls_ctx* ctx, const rls_gramk& D, void* sync, int n_steps, unsigned spin_limit) {
@@ -613,6 +987,29 @@ int32_t rls_gramk_resident_launch(rls_ctx* ctx, const rls_gramk& D, void* sync, 
   else if (ne == 2) gk_launch<2>(ctx, D, sync, n_steps, spin_limit);
   else if (ne == 4) gk_launch<4>(ctx, D, sync, n_steps, spin_limit);
   else gk_launch<8>(ctx, D, sync, n_steps, spin_limit);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
+  return 0;
+}
+
+// FISTA: exchanged rows of y [2 parities][re | im][2 column halves][rows][16 bytes], gathered x / xold / res [3][N][8] complex,
+// partial norms [2][256 slots][8] f64
+void rls_fgramk_sizes(int64_t N, size_t* yx_bytes, size_t* xx_bytes, size_t* dots_bytes) {
+  *yx_bytes = (size_t)2 * 4 * gk_ne(N) * 256 * 16;  // zero-filled by the plan: rows >= N are read (as zeros), never written
+  *xx_bytes = (size_t)3 * N * GK_KB * sizeof(float2);
+  *dots_bytes = (size_t)2 * 256 * 8 * sizeof(double);  // zero-filled by the plan: slots of absent workgroups add 0.0
+}
+
+bool rls_fgramk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, const void* G, int64_t ldg) {
+  return gk_resident_ok<1>(ctx, dtype, N, nrhs, G, ldg);
+}
+
+int32_t rls_fgramk_resident_launch(rls_ctx* ctx, const rls_fgramk& D, void* sync, int n_steps, unsigned spin_limit) {
+  const int ne = gk_ne(D.N);
+  if (ne == 1) fk_launch<1>(ctx, D, sync, n_steps, spin_limit);
+  else if (ne == 2) fk_launch<2>(ctx, D, sync, n_steps, spin_limit);
+  else if (ne == 4) fk_launch<4>(ctx, D, sync, n_steps, spin_limit);
+  else fk_launch<8>(ctx, D, sync, n_steps, spin_limit);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
   return 0;

@@ -898,6 +898,23 @@ struct rls_gramk {
 void rls_gramk_sizes(int64_t N, size_t* vx_bytes, size_t* xx_bytes, size_t* dots_bytes);
 bool rls_gramk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, const void* G, int64_t ldg);
 int32_t rls_gramk_resident_launch(rls_ctx* ctx, const rls_gramk& D, void* sync, int n_steps, unsigned spin_limit);
+// the same for batched FISTA (no gradient restart; elementwise regularisers): rows of the next extrapolated point are what
+// travels, the update itself is distributed (gramk.hip, fista_gramk_resident_kernel)
+struct rls_fgramk {
+  const void* G;
+  int64_t ldg, N;
+  int nrhs;
+  void *b0, *b1, *x0, *res, *y;  // N x nrhs, columns ldv elements apart (x / xold by iteration parity, A^H b, residual, plan's y)
+  int64_t ldv;
+  fista_scalars* sc;    // [nrhs]
+  float* Yx;            // exchanged rows of y, two parities (rls_fgramk_sizes)
+  void* Xx;             // x, xold and res gathered at the end of the launch
+  double* dots;         // per-workgroup partial ||res||^2, two parities
+  float* Ypack;         // the streaming kernels' operand panel, kept in step (nullable)
+};
+void rls_fgramk_sizes(int64_t N, size_t* yx_bytes, size_t* xx_bytes, size_t* dots_bytes);
+bool rls_fgramk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, const void* G, int64_t ldg);
+int32_t rls_fgramk_resident_launch(rls_ctx* ctx, const rls_fgramk& D, void* sync, int n_steps, unsigned spin_limit);
 
 // ---------------------------------------------------------------------------------------------
 // comm.hip internals used by the row-sharded solver loops (solvers.hip)

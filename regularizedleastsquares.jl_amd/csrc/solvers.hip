@@ -644,6 +644,12 @@ struct rls_fista {
   int fallbacks = 0;
   long long requested = 0;    // iterations asked for since init
   bool rsync_clean = false;   // the init kernel has just zeroed the arrival counters (resident_chain)
+  // batched plan on an explicit Gram matrix, <= 8 ComplexF32 columns, AHA in the register files (gramk.hip): exchange scratch
+  bool fgramk = false;
+  int restart_b = 0;          // gradient restart asked for at init (the resident batched kernel does not carry it)
+  float* fk_yx = nullptr;
+  void* fk_xx = nullptr;
+  double* fk_dots = nullptr;
 };
 
 // batched launches: workgroup b = column b.  Vpart non-null: AHA y arrives as `S` partial rows per column and is
@@ -2966,6 +2972,9 @@ int32_t rls_fista_destroy(rls_fista* s) {
   if (s->scb_h) hfree(s->scb_h);
   if (s->rsync) dfree(s->rsync);
   if (s->rsync_h) hfree(s->rsync_h);
+  if (s->fk_yx) dfree(s->fk_yx);
+  if (s->fk_xx) dfree(s->fk_xx);
+  if (s->fk_dots) dfree(s->fk_dots);
   dfree(s->sc);
   hfree(s->sc_h);
   delete s;
@@ -3117,7 +3126,23 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sizeof(fista_scalars) * nrhs, ctx->stream);
   if (e == hipSuccess) e = hmalloc(&s->scb_h, sizeof(fista_scalars) * nrhs);
   if (e == hipSuccess) e = hmalloc(&s->sc_h, sizeof(fista_scalars));
+  if (e == hipSuccess && op->G && s->half && rls_fgramk_resident_ok(ctx, op->dtype, op->N, nrhs, op->G, op->ldg)) {
+    size_t yxb, xxb, db;
+    rls_fgramk_sizes(op->N, &yxb, &xxb, &db);
+    e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
+    if (e == hipSuccess) e = dmalloc(&s->fk_yx, yxb);
+    if (e == hipSuccess) e = hipMemsetAsync(s->fk_yx, 0, yxb, ctx->stream);  // rows >= N are read, never written
+    if (e == hipSuccess) e = dmalloc(&s->fk_xx, xxb);
+    if (e == hipSuccess) e = dmalloc(&s->fk_dots, db);
+    if (e == hipSuccess) e = hipMemsetAsync(s->fk_dots, 0, db, ctx->stream);  // slots of absent workgroups add 0.0
+    s->fgramk = e == hipSuccess;
+  }
   if (e != hipSuccess) {
+    if (s->rsync) dfree(s->rsync);
+    if (s->rsync_h) hfree(s->rsync_h);
+    if (s->fk_yx) dfree(s->fk_yx);
+    if (s->fk_xx) dfree(s->fk_xx);
+    if (s->fk_dots) dfree(s->fk_dots);
     if (s->y) dfree(s->y);
     if (s->Ypack) dfree(s->Ypack);
     if (s->Tpack) dfree(s->Tpack);
@@ -3141,28 +3166,54 @@ int32_t rls_fista_init_batched(rls_fista* s, const void* B, int64_t ldb, float r
   if (!B || ldb < op->M) return rls_fail(ctx, RLS_E_INVALID, "fista_init_batched: bad argument");
   RLS_HIP(ctx, rls_enter(ctx));
   RLS_TRY(rls_skinny_atb(ctx, op->dtype, fista_skinny_desc(s), B, ldb));  // partial rows of A^H B   (src/FISTA.jl:114)
+  // (the resident launch's arrival counters are zeroed by the init kernel: every workgroup writes the same zeros)
+  const int n_clear = s->rsync ? (int)(rls_resident_sync_clear_bytes() / sizeof(unsigned)) : 0;
   if (op->dtype == RLS_F32)
     hipLaunchKernelGGL(fista_init_kernel<float>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
                        (float*)s->buf[0], (float*)s->buf[1], (float*)s->x0, (float*)s->res, (float*)s->y, op->N, s->sc,
                        rho, theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices, fista_batch_desc<float>(s));
+                       (long long)s->l21_slices, fista_batch_desc<float>(s), (unsigned*)s->rsync, n_clear);
   else
     hipLaunchKernelGGL(fista_init_kernel<float2>, dim3((unsigned)s->nrhs), dim3(UPD_THREADS), 0, ctx->stream,
                        (float2*)s->buf[0], (float2*)s->buf[1], (float2*)s->x0, (float2*)s->res, (float2*)s->y, op->N,
                        s->sc, rho, theta, rel_tol, iterations, restart_gradient, s->reg_kind, s->proj_kind, s->lambda,
-                       (long long)s->l21_slices, fista_batch_desc<float2>(s));
+                       (long long)s->l21_slices, fista_batch_desc<float2>(s), (unsigned*)s->rsync, n_clear);
   s->initialised = true;
   s->use_pipe = s->use_gram = false;
+  s->restart_b = restart_gradient;
+  s->rsync_clean = s->rsync != nullptr;
+  s->requested = 0;
+  s->enq = 0;
+  s->resident_used = false;
   return launch_status(ctx);
 }
 
+static int32_t fista_step_impl(rls_fista* s, int32_t n_steps);
 int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out) {
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (!s->initialised || !s->scb_h) return rls_fail(ctx, RLS_E_STATE, "fista_get_status_batched: not a batched, initialised plan");
   RLS_HIP(ctx, rls_enter(ctx));
-  RLS_HIP(ctx, hipMemcpyAsync(s->scb_h, s->sc, sizeof(fista_scalars) * s->nrhs, hipMemcpyDeviceToHost, ctx->stream));
-  RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  if (s->resident_used) RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
+  RLS_TRY(rls_fetch_add(ctx, s->sc, s->scb_h, sizeof(fista_scalars) * (size_t)s->nrhs));
+  RLS_TRY(rls_fetch_wait(ctx));
+  if (s->resident_used && resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks)) {
+    // a lost resident launch changed nothing (rls_cgnr_get_status_batched): the live columns are in lockstep, what is missing
+    // is re-run on the streaming kernels
+    long long at = 0;
+    bool live = false;
+    for (int b = 0; b < s->nrhs; ++b) {
+      if (s->scb_h[b].iteration > at) at = s->scb_h[b].iteration;
+      live = live || !s->scb_h[b].done;
+    }
+    const long long missing = s->requested - at;
+    if (live && missing > 0) {
+      RLS_TRY(fista_step_impl(s, (int32_t)(missing > 0x7fffffff ? 0x7fffffff : missing)));
+      RLS_TRY(rls_fetch_add(ctx, s->sc, s->scb_h, sizeof(fista_scalars) * (size_t)s->nrhs));
+      RLS_TRY(rls_fetch_wait(ctx));
+    }
+  }
+  s->resident_used = false;
   for (int b = 0; b < s->nrhs; ++b) {
     const fista_scalars& h = s->scb_h[b];
     out[b].iteration = h.iteration;
@@ -3172,7 +3223,7 @@ int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out) {
     out[b].rel_res_norm = (float)h.rel_res_norm;
     out[b].residual = (float)h.res_norm;
     out[b].norm_x0 = (float)h.norm_x0;
-    out[b].fallbacks = 0;
+    out[b].fallbacks = s->fallbacks;
   }
   return 0;
 }
@@ -3202,6 +3253,14 @@ static bool fista_use_gram_resident(const rls_fista* s) {
 // regularisers the fused updates cover elementwise.  The kernel keeps the plan's state in the pipeline's layout (y0 / y1 by
 // `ycur`); a plan without the pipeline's second buffer (shapes the slab kernels do not take) hands it y0 twice, which is the
 // two-GEMV path's layout.
+// batched Gram mode as ONE resident launch per step call (cgnr_use_gramk): no gradient restart -- its theta is the one global
+// scalar the distributed update would have to wait for -- and the elementwise regularisers
+static bool fista_use_gramk(const rls_fista* s, int n_steps) {
+  return s->fgramk && s->rsync && !s->resident_off && s->op->ctx->tune.resident && !s->restart_b &&
+         (s->reg_kind == RLS_REG_NONE || s->reg_kind == RLS_REG_L1 || s->reg_kind == RLS_REG_L2) &&
+         (n_steps != 1 || s->op->ctx->tune.resident == 2);
+}
+
 static bool fista_use_small(const rls_fista* s) {
   return s->small && s->nrhs == 1 && !s->use_gram && s->op->ctx->tune.small && s->op->ctx->tune.resident &&
          (s->reg_kind == RLS_REG_NONE || s->reg_kind == RLS_REG_L1 || s->reg_kind == RLS_REG_L2);
@@ -3217,6 +3276,29 @@ static int32_t fista_step_impl(rls_fista* s, int32_t n_steps) {
     s->mb_sent = s->mb_arm.dst != nullptr;
     s->enq += n_steps;
     return rls_fista_small_launch(ctx, s->op->dtype, P, n_steps);
+  }
+  if (fista_use_gramk(s, n_steps)) {  // AHA explicit, <= 8 columns: the whole call as ONE launch (fista_gramk_resident_kernel)
+    if (n_steps == 0) return 0;
+    rls_fgramk D;
+    D.G = s->op->G;
+    D.ldg = s->op->ldg;
+    D.N = s->op->N;
+    D.nrhs = s->nrhs;
+    D.b0 = s->buf[0];
+    D.b1 = s->buf[1];
+    D.x0 = s->x0;
+    D.res = s->res;
+    D.y = s->y;
+    D.ldv = s->ldv;
+    D.sc = s->sc;
+    D.Yx = s->fk_yx;
+    D.Xx = s->fk_xx;
+    D.dots = s->fk_dots;
+    D.Ypack = s->Ypack;
+    s->resident_used = true;
+    return resident_chain(ctx, s->rsync, [&]() {
+      return rls_fgramk_resident_launch(ctx, D, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin);
+    }, &s->rsync_clean);
   }
   if (s->nrhs > 1) {  // K columns share A: T = A Y, V = A^H T on the matrix cores, then one workgroup per column
     return run_steps(ctx, &s->graph, n_steps, [s]() { return fista_enqueue_batched(s); });
@@ -3333,7 +3415,7 @@ static int32_t fista_fetch_status(rls_fista* s) {
 
 int32_t rls_fista_path(rls_fista* s, int32_t* out) {
   if (!s || !out) return RLS_E_INVALID;
-  *out = fista_use_small(s) ? 8 : s->nrhs > 1 ? 3 : fista_use_gram_resident(s) ? 5 : s->use_gram ? 2 : fista_use_resident(s) ? 4 : s->use_pipe ? 1 : 0;
+  *out = fista_use_small(s) ? 8 : s->nrhs > 1 ? (fista_use_gramk(s, 0) ? 7 : 3) : fista_use_gram_resident(s) ? 5 : s->use_gram ? 2 : fista_use_resident(s) ? 4 : s->use_pipe ? 1 : 0;
   return 0;
 }
 

@@ -990,6 +990,7 @@ def test_batched_gram_mode_matrix_rhs(rls, ctx, dt, M, N, K, resident):
         F = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(lam), rho=rho, iterations=15, relTol=0.0)
         fs = rls.solve_(F, Bd, scheduler=rls.BatchedState)
         assert isinstance(F.state, rls.FistaBatchedState)
+        assert _fista_path(ctx, F) == (7 if fits else 3), _fista_path(ctx, F)
         for j in (0, 1, K - 1):
             x64, x32 = oracle_pair(lambda A_, b_: O.solve(O.FISTA(A_, reg=O.L1Regularization(lam), rho=rho, iterations=15, relTol=0.0,
                                                                  normal="gram"), b_), A, np.ascontiguousarray(B[:, j]))
@@ -2106,6 +2107,13 @@ def _resident_unavailable():
     pytest.skip(f"resident kernels need 256 CUs; this device has {cus}")
 
 
+def _fista_path(ctx, sol):
+    import ctypes as C
+    out = C.c_int32(-1)
+    assert ctx.lib.rls_fista_path(sol.state._plan, C.byref(out)) == 0
+    return out.value
+
+
 def _cgnr_path(rls, sol):
     import ctypes as C
     out = C.c_int32(-1)
@@ -2401,6 +2409,81 @@ def test_batched_gram_resident_lost_launch_is_recovered(rls, ctx):
             parity(f"batched_gram_resident_recovered_col{j}", S.state.solutions()[j].to_host(), x64, x32)
     finally:
         ctx.tune(resident_spin=100000)
+        _fresh_resident_ctx(ctx)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 8), (1040, 208, 7), (2000, 1936, 5), (320, 16, 2)])
+@pytest.mark.parametrize("kind", ["l1", "l2", "none"])
+def test_batched_fista_gram_resident_launch(rls, ctx, M, N, K, kind):
+    """batched FISTA on the explicit Gram matrix as ONE resident launch per step call (csrc/gramk.hip,
+    fista_gramk_resident_kernel; rls_fista_path 7): every workgroup advances ITS 8 rows of every column and the rows of the
+    next extrapolated point are what is exchanged.  Against the float64 oracle's Gram-mode FISTA per column
+    (src/FISTA.jl:141-189, src/MultiThreading.jl:30-79), against the streaming kernels of the same plan (path 3), with
+    per-column relTol retirement, and split into several step calls (same bits as one call)."""
+    if M == 4096 and kind != "l1":
+        pytest.skip("full size: the L1 case")
+    A, X, B = O.make_problem(M, N, np.complex64, 53, n_rhs=K)
+    B = np.asfortranarray(B)
+    B[:, 0] *= 1e-3
+    A64 = A.astype(np.complex128)
+    smooth = A64 @ (A64.conj().T @ (A64 @ (A64.conj().T @ B[:, K - 1].astype(np.complex128))))  # in the span of the leading singular vectors:
+    B[:, K - 1] = (smooth / np.linalg.norm(smooth) * np.linalg.norm(B[:, 1])).astype(np.complex64)  # this column retires earlier
+    Ad = rls.DeviceMatrix.from_host(A)
+    Gd, Bd = Ad.gram(), rls.DeviceMatrix.from_host(B)
+    rho = float(0.9 / np.linalg.norm(A64, 2) ** 2)
+    lam = 1e-3 * float(np.abs(A64.conj().T @ B[:, 1]).max())
+    reg = lambda R: {"l1": R.L1Regularization(lam), "l2": R.L2Regularization(lam), "none": R.L2Regularization(0.0)}[kind]
+    iters = 15
+    tag = f"batched_fista_gramk_{M}x{N}_K{K}_{kind}"
+    _fresh_resident_ctx(ctx)
+    try:
+        for relTol in (0.0, 2e-2):
+            F = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=reg(rls), rho=rho, iterations=iters, relTol=relTol)
+            xs = [x.to_host() for x in rls.solve_(F, Bd, scheduler=rls.BatchedState)]
+            assert _fista_path(ctx, F) == 7, _fista_path(ctx, F)
+            stat = F.state.status()
+            assert all(s_.fallbacks == 0 for s_ in stat)
+            ctx.tune(resident=0)
+            F0 = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=reg(rls), rho=rho, iterations=iters, relTol=relTol)
+            x0s = [x.to_host() for x in rls.solve_(F0, Bd, scheduler=rls.BatchedState)]
+            assert _fista_path(ctx, F0) == 3
+            stat0 = F0.state.status()
+            ctx.tune(resident=1)
+            for j in range(K):
+                ref = O.FISTA(A64, reg=reg(O), rho=rho, iterations=iters, relTol=relTol, normal="gram")
+                O.solve(ref, B[:, j].astype(np.complex128))
+                assert abs(stat[j].iteration - ref.iteration) <= (1 if relTol > 0 else 0), (j, stat[j].iteration, ref.iteration)
+                assert abs(stat[j].iteration - stat0[j].iteration) <= (1 if relTol > 0 else 0)
+                if stat[j].iteration == stat0[j].iteration:
+                    assert rel(xs[j], x0s[j]) < 2e-5, (j, rel(xs[j], x0s[j]))
+                    assert abs(stat[j].rel_res_norm - stat0[j].rel_res_norm) <= 1e-4 * abs(stat0[j].rel_res_norm) + 1e-12
+                if stat[j].iteration == ref.iteration and j in (0, 1, K - 1):
+                    x32 = lambda: O.solve(O.FISTA(A, reg=reg(O), rho=rho, iterations=ref.iteration, relTol=0.0, normal="gram"),
+                                          np.ascontiguousarray(B[:, j]))
+                    parity(f"{tag}_reltol{relTol}_col{j}", xs[j], ref.x, x32, record=(j < 2 and relTol == 0.0))
+        # several step calls (4 + 7 + 4 iterations) leave the bits of one call
+        F1 = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=reg(rls), rho=rho, iterations=iters, relTol=0.0)
+        x_once = [x.to_host() for x in rls.solve_(F1, Bd, scheduler=rls.BatchedState)]
+        rls.init_(F1, Bd, scheduler=rls.BatchedState)
+        for n in (4, 7, 4):
+            F1.state._step(n)
+        st = F1.state.status()
+        assert [s_.iteration for s_ in st] == [iters] * K and all(s_.fallbacks == 0 for s_ in st)
+        for j, x in enumerate(F1.state.solutions()):
+            assert np.array_equal(x.to_host(), x_once[j]), j
+        # a lost launch (wait bound of one poll) changes nothing and is re-run on the streaming kernels
+        if N >= 128:
+            rls.init_(F1, Bd, scheduler=rls.BatchedState)
+            ctx.tune(resident_spin=1)
+            F1.state._step(iters)
+            ctx.tune(resident_spin=100000)
+            st = F1.state.status()
+            assert [s_.iteration for s_ in st] == [iters] * K and all(s_.fallbacks >= 1 for s_ in st)
+            assert _fista_path(ctx, F1) == 3
+            for j, x in enumerate(F1.state.solutions()):
+                assert rel(x.to_host(), x_once[j]) < 2e-5
+    finally:
+        ctx.tune(resident=1, resident_spin=100000)
         _fresh_resident_ctx(ctx)
 
 

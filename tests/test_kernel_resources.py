@@ -45,6 +45,7 @@ BASELINE = [
     ("configs[3]: 8 right-hand sides per GPU on the matrix cores", r"skinny_t_kernel<c32, 4, 4, true, 8, false>"),
     ("configs[3] on the reference's default operator (AHA explicit): one product per iteration", r"skinny_t_kernel<c32, 4, 4, true, 8, true>"),
     ("configs[3], AHA explicit, register-resident", r"cgnr_gramk_resident_kernel<\d, (true|false)>"),
+    ("configs[3], AHA explicit, register-resident, FISTA columns", r"fista_gramk_resident_kernel<\d, (true|false)>"),
     ("configs[3]", r"skinny_v_kernel<c32, 4, 1, true, 2>"),
     ("configs[3]", r"skinny_u_kernel<c32, false, 4, 512>"),
     ("configs[4]: row shards 8192x8192 CF32, two GEMVs + update", r"gemv_n_kernel<c32.*>"),

@@ -36,5 +36,6 @@ python3 tools/bench_config1.py > gpurun_out/${R}_config1.txt 2>&1
 tools/ubench/launch_floor > gpurun_out/${R}_launch_floor.txt 2>&1
 python3 tools/bench_small_group.py > gpurun_out/${R}_small_group.txt 2>&1
 python3 tools/bench_tv_prox.py > gpurun_out/${R}_tv_prox.txt 2>&1
+python3 tools/bench_batched_fista.py > gpurun_out/${R}_batched_fista.txt 2>&1
 cp gpurun_out/parity_errors.jsonl gpurun_out/${R}_parity_errors.jsonl 2>/dev/null
 head -c 900 gpurun_out/${R}_bench_kernel_stats.csv
