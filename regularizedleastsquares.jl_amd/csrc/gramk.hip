@@ -466,7 +466,7 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
     float2* Xx = reinterpret_cast<float2*>(D.Xx);
     if (tid < GK_ROWS * GK_KB) {
       const int xr = tid >> 3, xk = tid & 7;
-      sc1_store_elem<float2>(Xx + (size_t)(row0 + xr) * GK_KB + xk, T.xown[tid]);
+      sc1_store_elem<float2>(Xx + (size_t)xk * N + row0 + xr, T.xown[tid]);  // [column][row]: workgroup 0's gather reads contiguously
       // V = AHA P of the last applied iteration: a workgroup's own rows are final
       if (xk < nrhs && it > 0) reinterpret_cast<float2*>(D.V)[(int64_t)xk * D.ldv + row0 + xr] = T.vown[tid];
     }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(GK_NT) void cgnr_gramk_resident_kernel(rls_gramk D,
         const int idx = i0 + u * GK_NT + tid;
         const int ic = idx < total ? idx : 0;
         const int k = ic / N, n = ic - k * N;
-        xg[u] = sc1_load_elem<float2>(Xx + (size_t)n * GK_KB + k);
+        xg[u] = sc1_load_elem<float2>(Xx + (size_t)k * N + n);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(GK_NT) void fista_gramk_resident_kernel(rls_fgramk 
     if (w == 0) {
       float2* Xx = reinterpret_cast<float2*>(D.Xx);
       const int xr = lane >> 3, xk = lane & 7;
-      const size_t at = (size_t)(row0 + xr) * GK_KB + xk, plane = (size_t)N * GK_KB;
+      const size_t at = (size_t)xk * N + row0 + xr, plane = (size_t)N * GK_KB;  // [array][column][row]: contiguous for the gather
       sc1_store_elem<float2>(Xx + at, xcur);
       sc1_store_elem<float2>(Xx + plane + at, xprev);
       sc1_store_elem<float2>(Xx + 2 * plane + at, resown);
@@ -822,21 +822,19 @@ __global__ __launch_bounds__(GK_NT) void fista_gramk_resident_kernel(rls_fgramk 
   GK_STAMP(11);
   if (b != 0) return;
   {
-    // 16 bytes (two columns of a row) per load, 16 loads in flight per thread: the three gathered arrays are 3 x 128 KiB read by
-    // ONE workgroup -- element by element, 8 in flight, they cost ~30 us per launch
+    // [array][column][row] planes: 16 bytes (two rows of a column) per load and per store, contiguous across the lanes; all
+    // 48 loads of a thread in flight.  (Row-major planes read with a 64-byte lane stride cost 13.5 us here: every wave load
+    // touched 64 cache lines.)
     const __amdgpu_buffer_rsrc_t xx_rs = sc1_rsrc(D.Xx);
-    const int items = N * (GK_KB / 2);
+    const int half_n = N >> 1, items = GK_KB * half_n;
     const uint32_t plane_b = (uint32_t)N * GK_KB * 8u;
-    // (N <= 2048: items <= 16 per thread -- ONE round of loads for all three arrays, then the stores)
     f4 xg[3][16];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int idx = u * GK_NT + tid;
-        const int ic = idx < items ? idx : 0;
-        const int kp = FULL ? ic >> (8 + (NE == 8 ? 3 : NE == 4 ? 2 : NE == 2 ? 1 : 0)) : ic / N, n = ic - kp * N;
-        xg[a][u] = sc1_load16(xx_rs, (uint32_t)a * plane_b + (uint32_t)n * 64u + (uint32_t)kp * 16u);
+        xg[a][u] = sc1_load16(xx_rs, (uint32_t)a * plane_b + (uint32_t)(idx < items ? idx : 0) * 16u);
       }
     }
 #pragma unroll
@@ -844,21 +842,16 @@ __global__ __launch_bounds__(GK_NT) void fista_gramk_resident_kernel(rls_fgramk 
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int idx = u * GK_NT + tid;
-        if (idx < items) {
-          const int kp = FULL ? idx >> (8 + (NE == 8 ? 3 : NE == 4 ? 2 : NE == 2 ? 1 : 0)) : idx / N, n = idx - kp * N;
-#pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            const int k = 2 * kp + c2;
-            if (k < nrhs) {
-              const int odd = (T.cs[k].iteration - 1) & 1;  // where the column's last update wrote state.x
-              float2* dst = a == 2 ? reinterpret_cast<float2*>(D.res)
-                                   : reinterpret_cast<float2*>((a == 0) == (odd != 0) ? D.b0 : D.b1);
-              dst[(int64_t)k * D.ldv + n] = c2 ? make_float2(xg[a][u][2], xg[a][u][3]) : make_float2(xg[a][u][0], xg[a][u][1]);
-            }
-          }
+        const int k = FULL ? idx >> (7 + (NE == 8 ? 3 : NE == 4 ? 2 : NE == 2 ? 1 : 0)) : idx / half_n, i = idx - k * half_n;
+        if (idx < items && k < nrhs) {
+          const int odd = (T.cs[k].iteration - 1) & 1;  // where the column's last update wrote state.x
+          float2* dst = a == 2 ? reinterpret_cast<float2*>(D.res)
+                               : reinterpret_cast<float2*>((a == 0) == (odd != 0) ? D.b0 : D.b1);
+          *reinterpret_cast<f4*>(dst + (int64_t)k * D.ldv + 2 * i) = xg[a][u];  // (host: ldv even, 16-byte aligned vectors)
         }
       }
     }
+    GK_STAMP(13);
     float2* Yo = reinterpret_cast<float2*>(D.y);
     float* pp = D.Ypack;  // the streaming kernels' operand panel ([n][8 re | 8 im]) kept in step
 #pragma unroll
@@ -878,6 +871,7 @@ __global__ __launch_bounds__(GK_NT) void fista_gramk_resident_kernel(rls_fgramk 
         }
       }
     }
+    GK_STAMP(14);
     if (tid < nrhs) {
       const fk_col& c = T.cs[tid];
       fista_scalars* s = D.sc + tid;
@@ -1001,7 +995,7 @@ void rls_fgramk_sizes(int64_t N, size_t* yx_bytes, size_t* xx_bytes, size_t* dot
 }
 
 bool rls_fgramk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, const void* G, int64_t ldg) {
-  return gk_resident_ok<1>(ctx, dtype, N, nrhs, G, ldg);
+  return gk_resident_ok<1>(ctx, dtype, N, nrhs, G, ldg);  // (the plan also checks its vectors: 16-byte aligned, ldv even)
 }
 
 int32_t rls_fgramk_resident_launch(rls_ctx* ctx, const rls_fgramk& D, void* sync, int n_steps, unsigned spin_limit) {

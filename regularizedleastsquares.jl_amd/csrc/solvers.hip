@@ -3126,7 +3126,8 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   if (e == hipSuccess) e = hipMemsetAsync(s->sc, 0, sizeof(fista_scalars) * nrhs, ctx->stream);
   if (e == hipSuccess) e = hmalloc(&s->scb_h, sizeof(fista_scalars) * nrhs);
   if (e == hipSuccess) e = hmalloc(&s->sc_h, sizeof(fista_scalars));
-  if (e == hipSuccess && op->G && s->half && rls_fgramk_resident_ok(ctx, op->dtype, op->N, nrhs, op->G, op->ldg)) {
+  const bool vec16 = ldv % 2 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xold) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+  if (e == hipSuccess && op->G && s->half && vec16 && rls_fgramk_resident_ok(ctx, op->dtype, op->N, nrhs, op->G, op->ldg)) {
     size_t yxb, xxb, db;
     rls_fgramk_sizes(op->N, &yxb, &xxb, &db);
     e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);

@@ -47,7 +47,7 @@ if "fista" in sys.argv:
         print("phases: " + "; ".join(f"[{i}] {n}" for i, n in enumerate(names)))
         t = [buf[7 * 16 + i] for i in range(16)]
         print(f"workgroup 0, whole launch of 20 iterations (us): kernel start -> state loaded (AHA rows, y, own rows) {(t[9]-t[8])/100:.1f}; iterations "
-              f"{(t[10]-t[9])/100:.1f}; rows published + final barrier {(t[11]-t[10])/100:.1f}; workgroup 0 writes the caller's state {(t[12]-t[11])/100:.1f}")
+              f"{(t[10]-t[9])/100:.1f}; rows published + final barrier {(t[11]-t[10])/100:.1f}; workgroup 0 writes the caller's state {(t[12]-t[11])/100:.1f} (x / xold / res gathered and stored {(t[13]-t[11])/100:.1f}, y + operand panel {(t[14]-t[13])/100:.1f})")
     sys.exit(0)
 S = rls.createLinearSolver(rls.CGNR, Ad, AHA=Ad.gram(), iterations=2000, relTol=0.0)
 rls.init_(S, Bd, scheduler=rls.BatchedState)
