@@ -2697,12 +2697,13 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
 // ---- resident Gram-mode FISTA: as cgnr_gram_resident_kernel, for src/FISTA.jl:139-185 with AHA explicit ---------------
 // Per iteration: xs = y, this workgroup's rows of AHA y published (two parities), ONE grid exchange, then the gradient
 // step, prox, restart test, theta and the next extrapolated point redundantly in every workgroup.
-template <typename E, int K, int BAR, bool FULL>
+// SRV: the instantiation that can stay and listen (server mode, rls_fista_step_status); not built for Float32 K = 32 (it spilled)
+template <typename E, int K, int BAR, bool FULL, bool SRV = false>
 __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
                                                                    const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                    E* rr0, E* rr1, fista_scalars* sc0, fista_scalars* sc1,
                                                                    resident_sync* sync, int64_t Mc, int64_t N, int pair,
-                                                                   int n_steps, unsigned spin_limit) {
+                                                                   int n_steps, unsigned spin_limit, rls_srv_args Sv) {
   constexpr int G = 4, WV = 8;
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
@@ -2738,8 +2739,13 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
   unsigned epoch = 0;
   bool alive = true;
   int ycur = S.ycur;
+  rls_mailbox_slot srv_mb = Sv.mb;
+  unsigned srv_seq = Sv.seq0;  // server mode (rls_fista_step_status): the command being served
+  unsigned itg = 0;            // iterations run by this launch, over all its commands: the parity of the exchanged rows
+  for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = 0; it < n_steps; ++it) {
-    E* rq = (it & 1) ? rr1 : rr0;
+    if (SRV && S.done) break;  // uniform (a command behind the one that reached the stopping test)
+    E* rq = (itg++ & 1u) ? rr1 : rr0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = yv[e];
     gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
@@ -2779,9 +2785,16 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
   }
   if (!alive) {
     resident_give_up(sync, nullptr);
+    if (SRV && Sv.ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(Sv.ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   if (blockIdx.x == 0) {
+    S.ycur = ycur;
+    S.pending = 0;
+    S.fresh = 0;
+    if constexpr (SRV) {
+      if (Sv.ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // (server mode: status first, write-back under the host's turnaround)
+    }
     E* xw = (S.iteration & 1) ? b1 : b0;  // state.x == buf[iteration & 1] afterwards as well
     E* xo = (S.iteration & 1) ? b0 : b1;
     E* yw = ycur ? y1 : y0;
@@ -2797,13 +2810,19 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     }
     __syncthreads();
     if (tid == 0) {
-      S.ycur = ycur;
-      S.pending = 0;
-      S.fresh = 0;
       RLS_FISTA_COPY(*sc0, S);
       RLS_FISTA_COPY(*sc1, S);
       sync->completed = 1u;
     }
+  }
+  if constexpr (SRV) {
+    if (!Sv.ctl) break;  // uniform
+    const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &flag, srv_mb, srv_seq - Sv.seq0 + 1u);
+    if (cmd == RLS_SRV_EXIT) return;  // uniform
+    n_steps = (int)cmd;
+  } else {
+    break;
+  }
   }
 }
 
@@ -3350,30 +3369,39 @@ static int32_t gram_resident_typed(rls_ctx* ctx, const rls_gram_pipe& P, void* s
 }
 template <typename E, int K>
 static int32_t launch_fista_gram_resident(rls_ctx* ctx, const rls_fista_gram& P, void* sync, int nwg, int n_steps,
-                                          unsigned spin_limit) {
+                                          unsigned spin_limit, const rls_srv_args& Sv) {
   using C = slab_cfg<E, 4, K, 8>;
   const int64_t Mc = P.N / C::NV;
   const int pair = (nwg % 16 == 0) ? 1 : 0;
   const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
-#define RLS_LAUNCH_FGR(BB, FF)                                                                                         \
-  hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, BB, FF>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, \
+#define RLS_LAUNCH_FGR(BB, FF, SS)                                                                                         \
+  hipLaunchKernelGGL((fista_gram_resident_kernel<E, K, BB, FF, SS>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, \
                      P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.rr[0], (E*)P.rr[1], \
-                     P.sc[0], P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit)
-  if (full) RLS_LAUNCH_FGR(1, true);
-  else RLS_LAUNCH_FGR(1, false);
+                     P.sc[0], P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, Sv)
+  if constexpr (K != 32) {
+    if (Sv.ctl) {  // the listening instantiation (the host asks rls_gram_resident_server_ok first)
+      if (full) RLS_LAUNCH_FGR(1, true, true);
+      else RLS_LAUNCH_FGR(1, false, true);
+      return launch_status(ctx);
+    }
+  } else if (Sv.ctl) {
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram FISTA: no listening instantiation for this shape");
+  }
+  if (full) RLS_LAUNCH_FGR(1, true, false);
+  else RLS_LAUNCH_FGR(1, false, false);
 #undef RLS_LAUNCH_FGR
   return launch_status(ctx);
 }
 
 template <typename E>
 static int32_t fista_gram_resident_typed(rls_ctx* ctx, const rls_fista_gram& P, void* sync, int n_steps,
-                                         unsigned spin_limit) {
+                                         unsigned spin_limit, const rls_srv_args& Sv) {
   int K = 0;
   if (!gram_pick<E>(P.N, &K)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram FISTA: N too large");
   const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
-  if (K == 8) return launch_fista_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit);
-  if (K == 16) return launch_fista_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit);
-  if constexpr (!elem<E>::cplx) return launch_fista_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit);
+  if (K == 8) return launch_fista_gram_resident<E, 8>(ctx, P, sync, nwg, n_steps, spin_limit, Sv);
+  if (K == 16) return launch_fista_gram_resident<E, 16>(ctx, P, sync, nwg, n_steps, spin_limit, Sv);
+  if constexpr (!elem<E>::cplx) return launch_fista_gram_resident<E, 32>(ctx, P, sync, nwg, n_steps, spin_limit, Sv);
   return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram FISTA: shape not resident");
 }
 template <typename E, int G, int K, int WV>
@@ -3474,9 +3502,9 @@ int32_t rls_gram_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_gram_pipe& P
 }
 
 int32_t rls_fista_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, void* sync, int n_steps,
-                                       unsigned spin_limit) {
-  if (dtype == RLS_F32) return fista_gram_resident_typed<float>(ctx, P, sync, n_steps, spin_limit);
-  return fista_gram_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit);
+                                       unsigned spin_limit, const rls_srv_args& Sv) {
+  if (dtype == RLS_F32) return fista_gram_resident_typed<float>(ctx, P, sync, n_steps, spin_limit, Sv);
+  return fista_gram_resident_typed<float2>(ctx, P, sync, n_steps, spin_limit, Sv);
 }
 bool rls_gram_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, const void* G, int64_t ldg) {
   if (!rls_gram_pipe_ok(dtype, N, G, ldg)) return false;

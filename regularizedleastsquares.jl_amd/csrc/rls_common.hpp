@@ -793,7 +793,7 @@ struct rls_fista_gram {
 int32_t rls_fista_gram_iteration(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);
 int32_t rls_fista_gram_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, int parity);
 int32_t rls_fista_gram_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_gram& P, void* sync, int n_steps,
-                                       unsigned spin_limit);
+                                       unsigned spin_limit, const rls_srv_args& Sv = rls_srv_args());
 
 // One right-hand side's slot in an MFMA operand panel (skinny.hip).  Full layout: panel[g][n][16] elements, column b in
 // group b >> 4 at slot b & 15.  Half layout (complex, <= 8 columns): panel[n][16] floats = (re of 8 columns | im of 8).

@@ -2935,7 +2935,8 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
       if (s->rsync) dfree(s->rsync);
       s->rsync = nullptr;  // resident mode is an optimisation: without its scratch the pipeline runs
       (void)hipGetLastError();
-    } else if (!gram && (s->srv.ctl || hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess)) {
+    } else if ((!gram || rls_gram_resident_server_ok(op->dtype, op->N)) &&
+               (s->srv.ctl || hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess)) {  // (both resident kernels can stay and listen)
       memset(s->srv.ctl, 0, 32 * sizeof(unsigned));
       s->srv.resident_used = &s->resident_used;
     }
@@ -3449,7 +3450,7 @@ int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* o
   if (!s || !out) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
   if (s->initialised && n_steps > 0 && n_steps <= 8 && !s->resident_used && server_usable(ctx, &s->srv) &&
-      (fista_use_small(s) || fista_use_resident(s))) {
+      (fista_use_small(s) || fista_use_gram_resident(s) || fista_use_resident(s))) {
     // the resident kernel in server mode (cgnr_step_status_server): posted to the kernel left listening, or carried by a launch
     RLS_HIP(ctx, hipSetDevice(s->device));
     s->requested += n_steps;
@@ -3460,6 +3461,12 @@ int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* o
         if (!P.y1) P.y1 = P.y0;
         P.mb = a.mb;
         return rls_fista_small_launch(ctx, s->op->dtype, P, n_steps, a);
+      }
+      if (fista_use_gram_resident(s)) {  // AHA explicit, in the register files (fista_gram_resident_kernel)
+        const rls_fista_gram Pg = fista_gram_desc(s);
+        return resident_chain(ctx, s->rsync, [&]() {
+          return rls_fista_gram_resident_launch(ctx, s->op->dtype, Pg, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, a);
+        }, &s->rsync_clean);
       }
       return resident_chain(ctx, s->rsync, [&]() {
         return rls_fista_resident_launch(ctx, s->op->dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, a);

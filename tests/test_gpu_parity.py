@@ -2703,6 +2703,74 @@ def test_fista_resident_server_mode(rls, ctx, restart):
     assert rel(x_pipe, x_once) < 2e-5
 
 
+@pytest.mark.parametrize("dt,M,N,restart", [(np.complex64, 4096, 2048, "none"), (np.complex64, 4096, 2048, "gradient"), (np.float32, 3000, 1500, "none")])
+def test_fista_gram_resident_server_mode(rls, ctx, dt, M, N, restart):
+    """server mode on the reference constructor's default operator for FISTA (AHA = A' * A explicit, src/FISTA.jl:58; in the register
+    files: rls_fista_path 5): 32 one-iterate calls back to back are the bits of ONE 32-iteration launch and the Gram-mode oracle's
+    iterate; a download in between makes the kernel leave first; the stopping test ends the stream"""
+    import ctypes as C
+    A, xt, b = O.make_problem(M, N, dt, 96)
+    dt64 = hi(dt)
+    A64, b64 = A.astype(dt64), b.astype(dt64)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    Gd = Ad.gram()
+    iters = 32
+    mk_ref = lambda A_, it=iters, tol=0.0: O.FISTA(A_, reg=O.L1Regularization(lam), rho=rho, iterations=it, relTol=tol, restart=restart, normal="gram")
+    ref = mk_ref(A64)
+    O.solve(ref, b64)
+    sol = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+    rls.init_(sol, bd)
+    if _fista_path(ctx, sol) != 5:
+        _resident_unavailable()
+    x_once = rls.solve_(sol, bd).to_host()
+    rls.init_(sol, bd)
+    k = 0
+    while rls.iterate(sol) is not None:      # one launch, then 31 commands
+        k += 1
+    assert k == iters and sol.state.iteration == iters and sol.state.fallbacks == 0
+    assert abs(sol.state.rel_res_norm - ref.rel_res_norm) < 1e-4 * ref.rel_res_norm + 1e-7
+    x_srv = sol.state.x.to_host()
+    assert np.array_equal(x_srv, x_once)
+    tag = f"fista_gram_server_{M}x{N}_{restart}"
+    parity(tag, x_srv, ref.x, lambda: O.solve(mk_ref(A), b), record=False)
+    rls.init_(sol, bd)
+    k = 0
+    while rls.iterate(sol) is not None:
+        k += 1
+        if k in (3, 4, 5):
+            sol.state.x.to_host()
+    assert k == iters
+    parity(tag + "_downloads", sol.state.x.to_host(), ref.x, lambda: O.solve(mk_ref(A), b), record=False)
+    # the stopping test inside a served command
+    probe = mk_ref(A64)
+    probe.init(b64)
+    rr = []
+    while probe.iterate() is not None:
+        rr.append(probe.rel_res_norm)
+    kk = next(i for i in range(20, 2, -1) if min(rr[:i]) > 1.001 * rr[i])
+    sol2 = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(lam), rho=rho, iterations=iters, relTol=1.0005 * rr[kk],
+                                  restart=restart)
+    rls.init_(sol2, bd)
+    n = 0
+    while rls.iterate(sol2) is not None:
+        n += 1
+    assert n == kk + 1 and sol2.state.iteration == n
+    stt = rls._lib.FistaStatus()
+    for _ in range(2):   # past the end: served, nothing changes
+        assert ctx.lib.rls_fista_step_status(sol2.state._plan, 1, C.byref(stt)) == 0 and stt.iteration == n and stt.done == 1
+    ctx.tune(resident_server=0)
+    try:
+        rls.init_(sol, bd)
+        while rls.iterate(sol) is not None:
+            pass
+        x_pipe = sol.state.x.to_host()
+    finally:
+        ctx.tune(resident_server=1)
+    assert rel(x_pipe, x_once) < 2e-5
+
+
 @pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 3000, 1500)])
 def test_cgnr_gram_resident_server_mode(rls, ctx, dt, M, N):
     """server mode on the reference constructor's default operator (AHA = A' * A explicit, held in the register files: rls_cgnr_path 5):

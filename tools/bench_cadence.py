@@ -59,5 +59,7 @@ for srv in (1, 0):
     ctx.tune(status_mailbox=2, resident_server=srv)
     c = cadence(lambda: rls.createLinearSolver(rls.CGNR, Ad, AHA=G, iterations=32, relTol=0.0),
                 lambda p, st_: L.check(h, lib.rls_cgnr_step_status(p, 1, C.byref(st_)), "cgnr"), L.CgnrStatus, 32)
-    print(f"CGNR on the explicit Gram matrix, resident_server={srv}: {c:6.1f} us per iterate call", flush=True)
+    f = cadence(lambda: rls.createLinearSolver(rls.FISTA, Ad, AHA=G, reg=rls.L1Regularization(1e-2), rho=rho, iterations=32, relTol=0.0),
+                lambda p, st_: L.check(h, lib.rls_fista_step_status(p, 1, C.byref(st_)), "fista"), L.FistaStatus, 32)
+    print(f"on the explicit Gram matrix, resident_server={srv}: CGNR {c:6.1f} us per iterate call, FISTA + L1 {f:6.1f}", flush=True)
 ctx.tune(resident_server=1)
