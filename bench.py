@@ -377,6 +377,41 @@ def other_paths(rls, ctx, Ad, A, b, errors):
         us = timed(lambda: (rls.init_(S, b), lib.rls_fista_step(S.state._plan, 48)), 48)
         return {"us_per_iteration": us, "iterations_per_s": 1e6 / us}
 
+    @entry("iterate_per_call_cadence_gram_mode (the same loop on the reference constructors' DEFAULT operator, AHA = A' * A explicit -- "
+           "src/CGNR.jl:49, src/FISTA.jl:58, src/ADMM.jl:81; the resident Gram kernels listen between calls)")
+    def _():
+        L = rls._lib
+        res = {}
+
+        def cadence(make, step_status, status_t, n_it):
+            S = make()
+            rls.solve_(S, b)
+            st_ = status_t()
+            plan = S.state._admm if hasattr(S.state, "_admm") and S.state._admm else S.state._plan
+            def run():
+                rls.init_(S, b)
+                for _ in range(n_it):
+                    step_status(plan, st_)
+            run(); ctx.sync()
+            best = float("inf")
+            for _ in range(5):
+                t0 = time.perf_counter(); run(); best = min(best, time.perf_counter() - t0)
+            assert st_.iteration == n_it, (st_.iteration, n_it)
+            return 1e6 * best / n_it
+
+        G = state["G"]
+        us = cadence(lambda: rls.createLinearSolver(rls.CGNR, Ad, AHA=G, iterations=32, relTol=0.0),
+                     lambda p, st_: L.check(h, lib.rls_cgnr_step_status(p, 1, C.byref(st_)), "cgnr_step_status"), L.CgnrStatus, 32)
+        res["cgnr"] = {"us_per_iterate_call_wall": us, "iterations_per_s": 1e6 / us}
+        us = cadence(lambda: rls.createLinearSolver(rls.FISTA, Ad, AHA=G, reg=rls.L1Regularization(1e-2), rho=rho, iterations=32, relTol=0.0),
+                     lambda p, st_: L.check(h, lib.rls_fista_step_status(p, 1, C.byref(st_)), "fista_step_status"), L.FistaStatus, 32)
+        res["fista_l1"] = {"us_per_iterate_call_wall": us, "iterations_per_s": 1e6 / us}
+        us = cadence(lambda: rls.createLinearSolver(rls.ADMM, Ad, AHA=G, reg=rls.L1Regularization(1e-2), rho=0.1, iterations=8, iterationsCG=10,
+                                                    tolInner=1e-5, absTol=0.0, relTol=0.0),
+                     lambda p, st_: L.check(h, lib.rls_admm_step_status(p, 1, C.byref(st_), None, 0), "admm_step_status"), L.AdmmStatus, 8)
+        res["admm_l1_outer"] = {"us_per_iterate_call_wall": us, "outer_iterations_per_s": 1e6 / us}
+        return res
+
     for K in (8, 16, 64):
         @entry(f"cgnr_batched_{K}_rhs (BASELINE configs[3] on one GPU, f32 MFMA)")
         def _(K=K):

@@ -61,5 +61,8 @@ for srv in (1, 0):
                 lambda p, st_: L.check(h, lib.rls_cgnr_step_status(p, 1, C.byref(st_)), "cgnr"), L.CgnrStatus, 32)
     f = cadence(lambda: rls.createLinearSolver(rls.FISTA, Ad, AHA=G, reg=rls.L1Regularization(1e-2), rho=rho, iterations=32, relTol=0.0),
                 lambda p, st_: L.check(h, lib.rls_fista_step_status(p, 1, C.byref(st_)), "fista"), L.FistaStatus, 32)
-    print(f"on the explicit Gram matrix, resident_server={srv}: CGNR {c:6.1f} us per iterate call, FISTA + L1 {f:6.1f}", flush=True)
+    a = cadence(lambda: rls.createLinearSolver(rls.ADMM, Ad, AHA=G, reg=rls.L1Regularization(1e-2), rho=0.1, iterations=8, iterationsCG=10,
+                                               tolInner=1e-5, absTol=0.0, relTol=0.0),
+                lambda p, st_: L.check(h, lib.rls_admm_step_status(p, 1, C.byref(st_), None, 0), "admm"), L.AdmmStatus, 8)
+    print(f"on the explicit Gram matrix, resident_server={srv}: CGNR {c:6.1f} us per iterate call, FISTA + L1 {f:6.1f}, ADMM + L1 {a:6.1f} us per outer iteration", flush=True)
 ctx.tune(resident_server=1)
