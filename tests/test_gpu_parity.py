@@ -2469,6 +2469,15 @@ def test_batched_fista_gram_resident_launch(rls, ctx, M, N, K, kind):
         assert [s_.iteration for s_ in st] == [iters] * K and all(s_.fallbacks == 0 for s_ in st)
         for j, x in enumerate(F1.state.solutions()):
             assert np.array_equal(x.to_host(), x_once[j]), j
+        # single-iteration calls take the streaming kernels (one launch of AHA's rows would not pay): the two paths hand the
+        # plan's state to each other
+        rls.init_(F1, Bd, scheduler=rls.BatchedState)
+        for n in (1, 6, 1, 7):
+            F1.state._step(n)
+        st = F1.state.status()
+        assert [s_.iteration for s_ in st] == [iters] * K and all(s_.fallbacks == 0 for s_ in st)
+        for j, x in enumerate(F1.state.solutions()):
+            assert rel(x.to_host(), x_once[j]) < 2e-5, (j, rel(x.to_host(), x_once[j]))
         # a lost launch (wait bound of one poll) changes nothing and is re-run on the streaming kernels
         if N >= 128:
             rls.init_(F1, Bd, scheduler=rls.BatchedState)
