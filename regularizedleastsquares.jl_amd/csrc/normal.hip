@@ -2697,6 +2697,10 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
 // ---- resident Gram-mode FISTA: as cgnr_gram_resident_kernel, for src/FISTA.jl:139-185 with AHA explicit ---------------
 // Per iteration: xs = y, this workgroup's rows of AHA y published (two parities), ONE grid exchange, then the gradient
 // step, prox, restart test, theta and the next extrapolated point redundantly in every workgroup.
+// Without gradient restart nothing of an iteration depends on ||res|| but the stopping test (src/FISTA.jl:156,187-189; theta
+// follows a data-independent recursion, :179-180): the waves leave their partial ||res||^2 in LDS WITHOUT a barrier and every
+// thread adds the eight up behind the NEXT iteration's grid barrier, where a stop found late drops that iteration's exchange
+// (nothing of it has been applied) -- the block reduction and its two barriers are off the critical path.
 // SRV: the instantiation that can stay and listen (server mode, rls_fista_step_status); not built for Float32 K = 32 (it spilled)
 template <typename E, int K, int BAR, bool FULL, bool SRV = false>
 __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
@@ -2709,10 +2713,24 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
   __shared__ gram_lds<E, G, K, WV> L;
   __shared__ int flag;
+  __shared__ double wpart[2][WV];  // per-wave partial ||res||^2 of an iteration, by the parity of its exchange
   const int tid = threadIdx.x;
   const int nwg = gridDim.x;
   fista_scalars S;
   RLS_FISTA_COPY(S, *sc0);
+  constexpr bool DEFER = K != 32;  // (the 32-pieces-per-row slabs have no registers to spare for the second update path: 28 B spilled)
+  bool pend = false;  // the norm of the last applied iteration is still in wpart (uniform)
+  auto resolve = [&](unsigned par) {  // :156, :187-189 for that iteration
+    double rn = 0.0;
+#pragma unroll
+    for (int i = 0; i < WV; ++i) rn += wpart[par][i];
+    const double res_norm = sqrt(rn);
+    const float rel = (float)(res_norm / S.norm_x0);
+    S.res_norm = res_norm;
+    S.rel_res_norm = (double)rel;
+    if (rel < S.rel_tol) S.done = 1;
+    pend = false;
+  };
   E yv[EPT], xk[EPT], xp[EPT], x0v[EPT], ri[EPT];
   {
     const E* yc = S.ycur ? y1 : y0;
@@ -2745,7 +2763,8 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = 0; it < n_steps; ++it) {
     if (SRV && S.done) break;  // uniform (a command behind the one that reached the stopping test)
-    E* rq = (itg++ & 1u) ? rr1 : rr0;
+    const unsigned itn = itg++;
+    E* rq = (itn & 1u) ? rr1 : rr0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) L.xs[tid + e * NT] = yv[e];
     gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
@@ -2770,9 +2789,47 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
       raw[e] = sc1_load_elem<E>(rq + (FULL || i < N ? i : (N - 1)));
       if (!FULL && i >= N) raw[e] = elem<E>::zero();
     }
+    if (pend) {  // uniform: the previous iteration's stopping test, under the loads just requested
+      resolve((itn & 1u) ^ 1u);
+      if (S.done) break;  // it had converged: this iteration's exchange is dropped, nothing of it was applied
+    }
     E xn[EPT], yn[EPT];
-    fista_scalars Sn;
-    const bool done = fista_update_elems<E, EPT, NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    bool done;
+    if (!DEFER || S.restart) {  // uniform: the restart test needs its dot product now (:171-176)
+      fista_scalars Sn;
+      done = fista_update_elems<E, EPT, NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+      RLS_FISTA_COPY(S, Sn);
+    } else {
+      const float rho = S.rho, thr = S.rho * S.lambda;
+      double rn = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t i = tid + (int64_t)e * NT;
+        E r = elem<E>::sub(raw[e], x0v[e]);                                   // res .-= x0      :153
+        E xv = elem<E>::sub(yv[e], elem<E>::scale(rho, r));                   // x .-= rho .* res :154
+        xv = fista_proj_elem<E>(fista_prox_elem<E>(xv, S.reg_kind, thr), S.proj_kind);
+        if (!FULL && i >= N) {
+          r = elem<E>::zero();
+          xv = elem<E>::zero();
+        }
+        ri[e] = r;
+        xn[e] = xv;
+        rn += (double)elem<E>::re(r) * (double)elem<E>::re(r) + (double)elem<E>::im(r) * (double)elem<E>::im(r);
+      }
+      rn = wave_sum(rn);
+      if ((tid & 63) == 0) wpart[itn & 1u][tid >> 6] = rn;  // (read behind the next grid barrier or the barrier at the end)
+      pend = true;
+      const float theta_old = S.theta;                                        // :179
+      const float theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;  // :180
+      const float c1 = (1.f - theta_old) / theta, c2 = (theta_old - 1.f) / theta + 1.f;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) yn[e] = elem<E>::add(elem<E>::scale(c1, xk[e]), elem<E>::scale(c2, xn[e]));
+      S.theta = theta;
+      S.theta_old = theta_old;
+      S.iteration += 1;
+      S.done = S.iteration >= S.max_iter;  // the relTol half of :187-189 follows with the norm
+      done = S.done != 0;
+    }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       xp[e] = xk[e];
@@ -2780,8 +2837,11 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
       if (!done) yv[e] = yn[e];
     }
     if (!done) ycur ^= 1;
-    RLS_FISTA_COPY(S, Sn);
     if (done) break;  // uniform
+  }
+  if (alive && pend) {  // uniform: the last applied iteration's norm and stopping test
+    __syncthreads();
+    resolve((itg - 1u) & 1u);
   }
   if (!alive) {
     resident_give_up(sync, nullptr);
