@@ -70,6 +70,8 @@ def grid_exchange_floor():
             best[f[0]] = min(best.get(f[0], 1e9), float(f[1]))
         if line.startswith("group GN= 8 strided") and "fail 0" in line and "wrong sums 0" in line:
             best["two_level"] = min(best.get("two_level", 1e9), float(f[4]))
+        if len(f) >= 2 and f[0] == "groupl2" and "fail 0" in line and "wrong sums 0" in line and "misplaced workgroups 0" in line:
+            best["two_level_l2_rows"] = min(best.get("two_level_l2_rows", 1e9), float(f[1]))
     return best or None
 
 
@@ -959,7 +961,10 @@ def main():
         ge = grid_exchange_floor()
         if ge and "two_level" in ge:
             valu_us = 16.0 * M * N / (VALU_F32_PEAK_TF * 1e12) * 1e6
-            floor_us = valu_us + ge["two_level"]
+            # the exchange the kernel runs since round 4 stores its partial rows at L2 scope (an XCD-aligned group shares its L2):
+            # its stripped form is the floor; the write-through form of rounds 2-3 is kept beside it
+            xch_us = ge.get("two_level_l2_rows", ge["two_level"])
+            floor_us = valu_us + xch_us
             it_us = kern[dom]["us_per_iteration_in_kernel"]
             row_bytes = N * s
             payload_us = (2.0 * nwg * row_bytes / (INF_CACHE_TBS * 1e12) + nwg * row_bytes / (L2_SHARED_TBS * 1e12)) * 1e6
@@ -968,7 +973,8 @@ def main():
                 indep = valu_us + ge["gbar"] + ge["bar"] + payload_us
             floor = {"bound": "grid-exchange", "unit": "us per iteration", "floor": floor_us, "measured": it_us, "frac_of_floor": floor_us / it_us,
                      "components": {"products_on_the_VALU_at_peak": valu_us, "valu_peak_TFLOPs": VALU_F32_PEAK_TF,
-                                    "all_reduce_two_level_arithmetic_stripped": ge["two_level"],
+                                    "all_reduce_two_level_arithmetic_stripped": xch_us,
+                                    "all_reduce_two_level_rows_written_through (rounds 2-3)": ge["two_level"],
                                     "for_comparison": {"bare_grid_barrier_256_workgroups": ge.get("bar"),
                                                        "bare_group_barrier_8_groups_of_32": ge.get("gbar"),
                                                        "all_reduce_flat_two_hops (round 2's exchange)": ge.get("flat")}},

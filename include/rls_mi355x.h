@@ -73,7 +73,9 @@ int32_t rls_device_count(int32_t* out);
  * fit one CU's registers run a step call as a single-workgroup launch), "resident_server" (1: rls_cgnr_step_status / rls_fista_step_status leave the resident kernel listening for the
  * next call, see there), "resident_server_idle_us", "status_mailbox" (>= 1: status read-backs through a kernel
  * that stores into pinned host memory + a host spin; 2, the default: rls_*_step_status has the call's last kernel do that store where
- * it can; 0: hipMemcpyAsync + stream wait). */
+ * it can; 0: hipMemcpyAsync + stream wait), "resident_l2_rows" (1, the default: the matrix-free resident kernels keep the partial
+ * rows of their in-kernel all-reduce in the XCD's L2 whenever every workgroup sits on the XCD its group assumes -- checked in
+ * every launch; 0: always written through to the memory side). */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
 /* Device memory is STREAM-ORDERED on the context's stream (a private hipMemPool per device; RLS_ALLOC=sync or a device without
  * memory pools: hipMalloc / hipFree): rls_free does not wait for the stream, the block is reused behind everything enqueued on

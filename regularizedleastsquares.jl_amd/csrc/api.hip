@@ -283,6 +283,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "status_mailbox")) ctx->tune.status_mailbox = value;
   else if (!strcmp(key, "small")) ctx->tune.small = value;
   else if (!strcmp(key, "resident_server")) ctx->tune.resident_server = value;
+  else if (!strcmp(key, "resident_l2_rows")) ctx->tune.resident_l2_rows = value;
   else if (!strcmp(key, "resident_server_idle_us")) ctx->tune.resident_server_idle_us = value;
   else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "resident_preclear")) ctx->tune.resident_preclear = value;

@@ -1641,7 +1641,7 @@ __device__ static inline float wave_reduce_scatter(float (&v)[NVAL], int lane, i
 // `red`: WV x RF floats + RF floats of LDS scratch.
 template <typename E, int G, int K, int WV, bool FULL>
 __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K], const E (&pin)[slab_cfg<E, G, K, WV>::EPT],
-                                             float* red, __amdgpu_buffer_rsrc_t slab_rs, int64_t N) {
+                                             float* red, __amdgpu_buffer_rsrc_t slab_rs, int64_t N, bool l2rows = false) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT, RF = owner_cfg<E, G, K, WV>::RF;
   constexpr bool CX = elem<E>::cplx;
@@ -1701,10 +1701,37 @@ __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K
       out.e[j] = sum;
     }
     const int o = q * NT * NV + tid * NV;
-    if (FULL || o < N)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), slab_rs,
-                                             (uint32_t)blockIdx.x * (uint32_t)(N * sizeof(E)) + (uint32_t)(o * sizeof(E)), 0, 16);
+    if (FULL || o < N) {
+      const uint32_t off = (uint32_t)blockIdx.x * (uint32_t)(N * sizeof(E)) + (uint32_t)(o * sizeof(E));
+      // l2rows (uniform; resident_rows_at_l2 below): this row is read by members of this workgroup's group only, and they share
+      // its XCD's L2 -- the store stops there (sc0) instead of travelling to the memory side (sc1)
+      if (l2rows) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), slab_rs, off, 0, 1);
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), slab_rs, off, 0, 16);
+    }
   }
+}
+
+// The two-level exchange's FIRST hop stays inside a group (the workgroups with equal blockIdx % RES_GROUPS), and under the
+// dispatcher's round-robin placement a group is the set of workgroups on ONE XCD: they share its L2.  So the partial rows a
+// workgroup hands to its group need not be written through to the memory side: stored with sc0 they stop in the L2 (the store's
+// acknowledgement -- which the hand-off waits for -- comes from there), and the members' sc1 loads (which bypass the CU's L1 as
+// before) find them there.  tools/ubench/grid_barrier, arithmetic stripped: 7.4 -> 5.2 us per exchange.  The placement is CHECKED,
+// not assumed: every workgroup compares HW_REG_XCC_ID with blockIdx % RES_GROUPS and reports a mismatch in a word of the sync
+// block (zeroed per launch) ahead of its first arrival; the launch's first exchange runs write-through, and behind its grid
+// barrier every workgroup reads the word -- the same decision everywhere, for the rest of the launch (a kernel that stays in
+// server mode keeps it: workgroups do not move).  Rows of one XCD are never read through another XCD's L2, and the
+// end of the kernel writes the L2 back, so the next launch may decide differently.
+__device__ static inline unsigned resident_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xfu;
+}
+__device__ static inline void resident_report_placement(resident_sync* sync) {
+  if (threadIdx.x == 0 && resident_xcc_id() != (blockIdx.x % RES_GROUPS))
+    __hip_atomic_store(&sync->gcnt[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a spare word of group 0's counter line)
+}
+__device__ static inline bool resident_rows_at_l2(resident_sync* sync) {  // behind a grid barrier of this launch
+  return uni((int)__hip_atomic_load(&sync->gcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0;
 }
 
 // The grid-wide sum of the workgroups' partial rows (slab[nwg][N]: just stored write-through and drained by every storing
@@ -1857,6 +1884,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   (void)d_rs;
   unsigned epoch = 0, xchg = 0;
   bool alive = true;
+  // partial rows at L2 scope (resident_rows_at_l2): decided behind the launch's first exchange, which runs write-through
+  constexpr bool L2ROWS = BAR == 2 && OWN;
+  bool l2rows = false, placed = !L2ROWS;  // uniform
+  if constexpr (L2ROWS) resident_report_placement(sync);
   if (St.enabled) {
     // ---- cg! entry (cg_pipe_start_kernel of solvers.hip, folded in): c = AHA x through the same two exchanges, then
     // r = b - (c + rho x), p = r and the scalars of the solve, redundantly in every workgroup ----------------------------
@@ -1873,6 +1904,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, cv, [](int, E) {}, []() {})) {
       resident_give_up(sync, St.enabled ? St.poison : nullptr);
       return;
+    }
+    if (!placed) {
+      l2rows = resident_rows_at_l2(sync);
+      placed = true;
     }
     double rr = 0.0;
 #pragma unroll
@@ -1963,7 +1998,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     STAMP(8);
     // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through)
     if constexpr (OWN) {
-      owner_products<E, G, K, WV, FULL>(a, pv, R.ored, slab_rs, N);
+      owner_products<E, G, K, WV, FULL>(a, pv, R.ored, slab_rs, N, l2rows);
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
@@ -2010,6 +2045,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     if (!ok_x) {
       alive = false;
       break;
+    }
+    if (!placed) {
+      l2rows = resident_rows_at_l2(sync);
+      placed = true;
     }
     // p of this iteration, back from its LDS copy (L.xs, staged for the products and untouched since): it need not occupy
     // registers across the products and the exchange
@@ -2391,6 +2430,10 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab);
   unsigned epoch = 0, xchg = 0;
   bool alive = true;
+  // partial rows at L2 scope (resident_rows_at_l2); not in the masked instantiation, which has no register to spare (12 B spilled)
+  constexpr bool L2ROWS = BAR == 2 && OWN && FULL;
+  bool l2rows = false, placed = !L2ROWS;    // uniform
+  if constexpr (L2ROWS) resident_report_placement(sync);
   int ycur = S.ycur;
   rls_mailbox_slot srv_mb = Sv.mb;
   unsigned srv_seq = Sv.seq0;  // server mode (rls_fista_step_status): the command being served
@@ -2398,7 +2441,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   for (int it = 0; it < n_steps; ++it) {
     if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
     if constexpr (OWN) {
-      owner_products<E, G, K, WV, FULL>(a, yv, R.ored, slab_rs, N);
+      owner_products<E, G, K, WV, FULL>(a, yv, R.ored, slab_rs, N, l2rows);
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = yv[e];
@@ -2413,6 +2456,10 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
       alive = false;
       break;
+    }
+    if (!placed) {
+      l2rows = resident_rows_at_l2(sync);
+      placed = true;
     }
     // y of this iteration, back from its LDS copy (L.xs): not carried in registers across the products and the exchange
     if constexpr (!OWN) {
@@ -2558,8 +2605,11 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
   unsigned epoch = 0, xchg = 0;
   bool alive = true;
   int ran = 0;
+  constexpr bool L2ROWS = BAR == 2 && (FULL || KIND != 2);  // partial rows at L2 scope (resident_rows_at_l2); the masked restart instantiation spilled 8 B with it
+  bool l2rows = false, placed = !L2ROWS;  // uniform
+  if constexpr (L2ROWS) resident_report_placement(sync);
   for (int it = 0; it < n_steps; ++it) {
-    owner_products<E, G, K, WV, FULL>(a, xv, R.ored, slab_rs, N);
+    owner_products<E, G, K, WV, FULL>(a, xv, R.ored, slab_rs, N, l2rows);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // x0: requested here, consumed behind the exchange -- except in the masked restart instantiation, which has no registers
@@ -2574,6 +2624,10 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
     if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
       alive = false;
       break;
+    }
+    if (!placed) {
+      l2rows = resident_rows_at_l2(sync);
+      placed = true;
     }
     if constexpr (X0_LATE) load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
     float c0, c1, c2, c3, c4, c5, c6 = 0.f, rg = 0.f, th = 1.f, gamma_n = 1.f;
@@ -3642,6 +3696,7 @@ size_t rls_resident_sync_alloc_bytes(int32_t dtype, int64_t N) {  // + [2 pariti
 }
 size_t rls_resident_sync_clear_bytes() { return offsetof(resident_sync, failed); }
 size_t rls_resident_sync_flags_offset() { return offsetof(resident_sync, fail); }
+size_t rls_resident_sync_placement_offset() { return offsetof(resident_sync, gcnt) + sizeof(unsigned); }  // the word resident_report_placement sets
 bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (!ctx) return false;
   if (dtype == RLS_F32) return resident_ok_typed<float>(ctx->device, M, N, A, lda);

@@ -31,6 +31,8 @@ struct rls_tuning {
   int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
   int resident_server = 1;     // 1: rls_cgnr_step_status leaves the resident kernel listening for the next call (rls_cg_start::srv_ctl)
   int resident_server_idle_us = 300;  // ... for this long
+  int resident_l2_rows = 1;    // 1: the matrix-free resident kernels keep their partial rows in the XCD's L2 when the placement allows (normal.hip,
+                               // resident_rows_at_l2); 0: always written through (measurement switch)
   int small = 1;               // 1: systems that fit ONE CU's registers run a whole step call as a single-workgroup launch (small.hip)
   int status_mailbox = 2;      // >= 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
                                // sequence word (rls_fetch_*); 2: and rls_*_step_status has the call's LAST kernel do that
@@ -692,6 +694,7 @@ size_t rls_cgnr_resident_sync_bytes();
 size_t rls_resident_sync_alloc_bytes(int32_t dtype, int64_t N);  // sync block + the two-level exchange's group partials
 size_t rls_resident_sync_clear_bytes();
 size_t rls_resident_sync_flags_offset();   // {fail, completed, failed}: three consecutive unsigned words
+size_t rls_resident_sync_placement_offset();  // "some workgroup is not on the XCD its group assumes": nonzero = partial rows written through
 bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N);
 // cg! entry folded into a resident launch (src/ADMM.jl:236-244): r = b - (AHA + rho I) x with the warm start x, p = r,

@@ -319,6 +319,8 @@ static int32_t resident_chain(rls_ctx* ctx, void* rsync, F&& launch, bool* clean
         // arrival counters and the {fail, completed} words of THIS launch; the count of lost launches behind them is sticky
         if (clean && *clean && ctx->tune.resident_preclear) *clean = false;
         else RLS_HIP(ctx, hipMemsetAsync(rsync, 0, rls_resident_sync_clear_bytes(), ctx->stream));
+        if (!ctx->tune.resident_l2_rows)  // measurement switch: pretend a workgroup is misplaced -- partial rows are written through
+          RLS_HIP(ctx, hipMemsetAsync((char*)rsync + rls_resident_sync_placement_offset(), 1, 1, ctx->stream));
         return launch();
       });
 }

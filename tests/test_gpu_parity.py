@@ -2121,6 +2121,39 @@ def _cgnr_path(rls, sol):
     return out.value
 
 
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 4096, 4096), (np.complex64, 3000, 1502)])
+def test_resident_partial_rows_at_l2_change_no_bit(rls, ctx, dt, M, N):
+    """the matrix-free resident kernels keep the partial rows of their in-kernel all-reduce in the XCD's L2 when every workgroup
+    sits on the XCD its group assumes (csrc/normal.hip, resident_rows_at_l2; checked per launch): same loads, same summation
+    orders -- CGNR, FISTA + L1 and POGM + L1 solves must equal the write-through protocol (`resident_l2_rows = 0`) bit for bit,
+    and the float64 oracle within the gate"""
+    A, xt, b = O.make_problem(M, N, dt, 83)
+    A64, b64 = A.astype(hi(dt)), b.astype(hi(dt))
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 1e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    makers = {
+        "cgnr": lambda R, A_: (R.CGNR(A_, iterations=24, relTol=0.0) if R is O else R.createLinearSolver(R.CGNR, A_, iterations=24, relTol=0.0)),
+        "fista": lambda R, A_: (R.FISTA(A_, reg=R.L1Regularization(lam), rho=rho, iterations=24, relTol=0.0) if R is O
+                                else R.createLinearSolver(R.FISTA, A_, reg=R.L1Regularization(lam), rho=rho, iterations=24, relTol=0.0)),
+        "pogm": lambda R, A_: (R.POGM(A_, reg=R.L1Regularization(lam), rho=rho, iterations=24, relTol=0.0) if R is O
+                               else R.createLinearSolver(R.POGM, A_, reg=R.L1Regularization(lam), rho=rho, iterations=24, relTol=0.0)),
+    }
+    for name, make in makers.items():
+        got = {}
+        for l2 in (1, 0):
+            ctx.tune(resident_l2_rows=l2)
+            try:
+                S = make(rls, Ad)
+                got[l2] = rls.solve_(S, bd).to_host()
+                got[(l2, "again")] = rls.solve_(S, bd).to_host()
+            finally:
+                ctx.tune(resident_l2_rows=1)
+        assert np.array_equal(got[1], got[0]) and np.array_equal(got[1], got[(1, "again")]), (name, rel(got[1], got[0]))
+        x64 = O.solve(make(O, A64), b64)
+        parity(f"resident_l2_rows_{name}_{M}x{N}_{np.dtype(dt).name}", got[1], x64, lambda: O.solve(make(O, A), b), record=False)
+
+
 @pytest.mark.parametrize("dt,M,N,lam", [(np.complex64, 4096, 2048, 0.0), (np.complex64, 4096, 2048, 1e-2), (np.float32, 4096, 4096, 0.0),
                                        (np.float32, 2048, 4096, 1e-3),
                                        # ragged M and N: the masked instantiation (N in (NMAX / 2, NMAX], fewer workgroups than CUs)

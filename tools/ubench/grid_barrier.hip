@@ -342,6 +342,73 @@ __global__ __launch_bounds__(NT) void group_kernel(sync_block* S, float* rows, f
   if (bad) atomicAdd(&S->bad, bad);
 }
 
+// The same exchange with the partial ROWS at L2 scope: under the round-robin dispatch the members of group blockIdx % 8 sit on ONE
+// XCD and share its L2, so the rows they hand to EACH OTHER need not travel to the memory side: stored with sc0 they stop in the
+// XCD's L2 (whose acknowledgement is what the hand-off waits for), and the members' sc1 loads -- which bypass the CU's L1 as
+// before -- find them there.  The group counter and everything that leaves the group (the group-partial slices, the grid barrier)
+// stay at agent scope.  Only valid when the placement is what it is assumed to be: the kernel checks HW_REG_XCC_ID against
+// blockIdx % 8 and counts the workgroups that are somewhere else (the product decides grid-wide and falls back to sc1 stores).
+// Tried on the way and dropped: the group barrier itself inside the L2 (arrivals at workgroup scope + polls by returning atomics:
+// 62 us per round -- returning atomics on one contended line; polls by sc0 loads never see the arrivals: they hit in the CU's L1,
+// and `buffer_inv sc0` does not invalidate it), sc0 loads of the rows (same L1 problem; `buffer_inv sc1` from one wave costs 1.8 us).
+__device__ static inline void l2_store16(__amdgpu_buffer_rsrc_t r, uint32_t off, f4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, off, 0, 1);  // aux 1 = sc0
+}
+__global__ __launch_bounds__(NT) void group_l2_kernel(sync_block* S, float* rows, float* xpart, int nb, int rounds) {
+  constexpr int GN = 8;
+  int* flag = reinterpret_cast<int*>(smem);
+  f4* ex = reinterpret_cast<f4*>(smem + 1024);
+  const int tid = threadIdx.x;
+  const unsigned nwg = gridDim.x, per = nwg / GN;
+  const unsigned grp = blockIdx.x % GN, mem = blockIdx.x / GN;
+  if (mem >= per) return;
+  if (tid == 0 && xcc_id() != grp) atomicAdd(&S->xcd_hist[0], 1u);  // misplaced workgroups (the product would decide this grid-wide and fall back to sc1)
+  const unsigned slot = grp * per + mem;
+  const __amdgpu_buffer_rsrc_t rows_rs = sc1_rsrc(rows), x_rs = sc1_rsrc(xpart);
+  const int per_thread = nb / 16 / NT;
+  const int slice_b = nb / (int)per, pieces = slice_b / 16, nrg = NT / pieces;
+  unsigned gepoch = 0, xepoch = 0, bad = 0;
+  float want0 = 0.f;
+  for (unsigned b = 0; b < nwg; ++b) want0 += (float)(b % 7);
+  for (int r = 1; r <= rounds; ++r) {
+    const float val = (float)((slot % 7) + (r % 5));
+    for (int q = 0; q < per_thread; ++q)
+      l2_store16(rows_rs, slot * (uint32_t)nb + (uint32_t)(q * NT + tid) * 16u, f4{val, val, val, val});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!arrive_wait<1>(S->xcnt + grp * 32, 0, per * ++xepoch, flag)) break;
+
+    {
+      const int piece = tid % pieces, rg = tid / pieces;
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (unsigned row = rg; row < per; row += nrg)
+        acc += sc1_load16(rows_rs, (grp * per + row) * (uint32_t)nb + mem * (uint32_t)slice_b + (uint32_t)piece * 16u);
+      ex[rg * pieces + piece] = acc;
+      __syncthreads();
+      if (tid < pieces) {
+        f4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < nrg; ++g) sum += ex[g * pieces + tid];
+        sc1_store16(x_rs, grp * (uint32_t)nb + mem * (uint32_t)slice_b + (uint32_t)tid * 16u, sum);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (!arrive_wait<8>(S->cnt, blockIdx.x & 7, nwg * ++gepoch, flag)) break;
+    const float want = want0 + (float)nwg * (float)(r % 5);
+    for (int q = 0; q < per_thread; ++q) {
+      f4 t[GN];
+#pragma unroll
+      for (int x = 0; x < GN; ++x) t[x] = sc1_load16(x_rs, (uint32_t)x * (uint32_t)nb + (uint32_t)(q * NT + tid) * 16u);
+      f4 c = t[0];
+#pragma unroll
+      for (int x = 1; x < GN; ++x) c += t[x];
+      if (c.x != want || c.y != want || c.z != want || c.w != want) ++bad;
+    }
+  }
+  if (xepoch != (unsigned)rounds && tid == 0) S->fail = 1;
+  if (bad) atomicAdd(&S->bad, bad);
+}
+
 // The grouped two-level all-reduce WITHOUT barriers: every 8 bytes handed over are {one float of payload, a 32-bit tag = the round
 // number as a float}, written in 16-byte pieces (two items) and polled by the reader with 8-byte atomic loads (a buffer-load
 // intrinsic in a polling loop is hoisted out of it by the optimiser; 8-byte granules are atomic, so a torn 16-byte store shows at
@@ -567,6 +634,21 @@ int main(int argc, char** argv) {
     printf("gbar   %8.3f us per round   fail %u  wrong sums %u   (bare group barrier: 8 strided groups of %d)\n", ms * 1e3 / rounds, h.fail, h.bad, nwg / 8);
   }
   run_ll(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemset(S, 0, sizeof(sync_block)));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(group_l2_kernel, dim3(nwg), dim3(NT), lds, 0, S, rows, xpart, nb, rounds);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    sync_block h;
+    CK(hipMemcpy(&h, S, sizeof(h), hipMemcpyDeviceToHost));
+    printf("groupl2  %8.3f us per round   fail %u  wrong sums %u   (GN = 8 strided, partial rows stored at L2 scope; misplaced workgroups %u)\n", ms * 1e3 / rounds, h.fail, h.bad, h.xcd_hist[0]);
+  }
   run_group<2, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
   run_group<4, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
   run_group<8, false>(S, rows, xpart, nb, rounds, nwg, lds, e0, e1);
