@@ -37,5 +37,8 @@ tools/ubench/launch_floor > gpurun_out/${R}_launch_floor.txt 2>&1
 python3 tools/bench_small_group.py > gpurun_out/${R}_small_group.txt 2>&1
 python3 tools/bench_tv_prox.py > gpurun_out/${R}_tv_prox.txt 2>&1
 python3 tools/bench_batched_fista.py > gpurun_out/${R}_batched_fista.txt 2>&1
+rm -rf /tmp/prof_bf
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bf -o b -- python3 "$GRAFT_REPO_ROOT/tools/bench_batched_fista.py" > /dev/null 2>&1)
+cp $(find /tmp/prof_bf -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_batched_fista_kernel_stats.csv
 cp gpurun_out/parity_errors.jsonl gpurun_out/${R}_parity_errors.jsonl 2>/dev/null
 head -c 900 gpurun_out/${R}_bench_kernel_stats.csv
