@@ -378,6 +378,35 @@ def _is_projection(r):
     return isinstance(r, (PositiveRegularization, RealRegularization)) or type(r).__name__ == "ProjectionRegularization"
 
 
+def _normalize_regs(scheme, regs, A, b):
+    """normalize(norm, regs, A, b): src/Regularization/NormalizedRegularization.jl:60-84.  `scheme` in {"none",
+    "measurement", "systemmatrix"}; A is a DenseOp / ndarray / None.  Terms with a parameterised sink are wrapped in a
+    NormalizedRegularization (an existing wrapper is re-wrapped with the new factor, :74), projections pass (:73)."""
+    Amat = getattr(A, "A", A)
+    factor = normalization_factor(scheme, Amat, b)
+    if factor is None:
+        return list(regs)
+    out = []
+    for r in regs:
+        if _is_projection(r):
+            out.append(r)
+        elif isinstance(r, NormalizedRegularization):
+            out.append(NormalizedRegularization(r.reg, factor))
+        elif reg_lambda(r) is not None:
+            out.append(NormalizedRegularization(r, factor))
+        else:
+            out.append(r)
+    return out
+
+
+def _normalize_in_solver(scheme, regs, A, b):
+    """normalize(solver::AbstractLinearSolver, ...) as init! calls it: the system-matrix factor was applied by the
+    constructor and is kept (:84); the measurement factor is recomputed from the vector init! hands over."""
+    if scheme == "systemmatrix":
+        return list(regs)
+    return _normalize_regs(scheme, regs, A, b)
+
+
 # --------------------------------------------------------------------------------------
 # CGNR  (src/CGNR.jl)
 # --------------------------------------------------------------------------------------
@@ -386,8 +415,9 @@ def _is_projection(r):
 class CGNR:
     """src/CGNR.jl:48-89 (ctor), :107-130 (init!), :143-178 (iterate), :181-185 (done)."""
 
-    def __init__(self, A, AHA=None, reg=None, iterations=10, relTol=None, normal="matrixfree"):
+    def __init__(self, A, AHA=None, reg=None, iterations=10, relTol=None, normal="matrixfree", normalizeReg="none"):
         self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        self.normalizeReg = normalizeReg
         if AHA is None:
             AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
         elif not hasattr(AHA, "mul"):
@@ -396,12 +426,13 @@ class CGNR:
         self.dtype = np.dtype(AHA.dtype)
         self.T = real_dtype(self.dtype).type
         regs = [] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
-        l2 = [r for r in regs if isinstance(r, L2Regularization)]
+        regs = _normalize_regs(normalizeReg, regs, self.A, None)  # src/CGNR.jl:68
+        l2 = [r for r in regs if isinstance(sink(r), L2Regularization)]
         if len(l2) > 1:
             raise ValueError("Cannot unambigiously retrieve reg term of type L2Regularization")
         self.L2 = l2[0] if l2 else L2Regularization(0.0)
         self.constr = [r for r in regs if _is_projection(r)]
-        rest = [r for r in regs if not isinstance(r, L2Regularization) and not _is_projection(r)]
+        rest = [r for r in regs if not isinstance(sink(r), L2Regularization) and not _is_projection(r)]
         if rest:
             raise ValueError(f"CGNR does not allow for more additional regularization terms, found {len(rest)}")
         self.iterations = int(iterations)
@@ -433,6 +464,7 @@ class CGNR:
             self.r[:] = self.A.mul_adj(b)  # src/CGNR.jl:132
         self.z0 = self.T(nrm2(self.r))
         self.p[:] = self.r
+        self.L2 = _normalize_in_solver(self.normalizeReg, [self.L2], self.A, b)[0]  # src/CGNR.jl:129
 
     def converged(self):
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -497,8 +529,9 @@ class FISTA:
     """src/FISTA.jl:57-92 (ctor), :110-129 (init!), :139-185 (iterate), :187-189 (done)."""
 
     def __init__(self, A, AHA=None, reg=None, iterations=50, rho=None, theta=1, relTol=None,
-                 restart="none", normal="matrixfree"):
+                 restart="none", normal="matrixfree", normalizeReg="none"):
         self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        self.normalizeReg = normalizeReg
         if AHA is None:
             AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
         elif not hasattr(AHA, "mul"):
@@ -511,7 +544,7 @@ class FISTA:
         rest = [r for r in regs if not _is_projection(r)]
         if len(rest) != 1:
             raise ValueError(f"FISTA does not allow for more additional regularization terms, found {len(rest)}")
-        self.reg = rest[0]
+        self.reg = _normalize_regs(normalizeReg, rest, self.A, None)[0]  # src/FISTA.jl:86
         if rho is None:
             raise ValueError("oracle FISTA needs an explicit rho (the reference default uses the global RNG)")
         self.rho = self.T(rho)
@@ -544,6 +577,8 @@ class FISTA:
         self.theta = self.T(theta)
         self.theta_old = self.T(theta)
         self.rel_res_norm = self.T(np.inf)
+        # src/FISTA.jl:128: the measurement-based factor is taken of x0 = A^H b, not of b
+        self.reg = _normalize_in_solver(self.normalizeReg, [self.reg], self.A, self.x0)[0]
 
     def done(self):
         return bool(self.rel_res_norm < self.relTol) or self.iteration >= self.iterations
@@ -644,8 +679,9 @@ class ADMM:
     """src/ADMM.jl:80-162 (ctor), :191-220 (init!), :230-322 (iterate), :324-332 (converged/done)."""
 
     def __init__(self, A, AHA=None, reg=None, regTrafo=None, rho=1e-1, vary_rho="none", iterations=10,
-                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree"):
+                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree", normalizeReg="none"):
         self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        self.normalizeReg = normalizeReg
         if AHA is None:
             AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
         elif not hasattr(AHA, "mul"):
@@ -657,7 +693,7 @@ class ADMM:
         n = AHA.shape[1]
         regs = [L1Regularization(0.0)] if reg is None else (list(reg) if isinstance(reg, (list, tuple)) else [reg])
         self.proj = [r for r in regs if _is_projection(r)]
-        self.reg = [r for r in regs if not _is_projection(r)]
+        self.reg = _normalize_regs(normalizeReg, [r for r in regs if not _is_projection(r)], self.A, None)  # src/ADMM.jl:139
         if regTrafo is None:
             regTrafo = [IdentityTrafo(n) for _ in self.reg]
         elif not isinstance(regTrafo, (list, tuple)):
@@ -721,6 +757,7 @@ class ADMM:
         self.rho[:] = self.rho0
         self.iteration = 0
         self.cg_iters = []
+        self.reg = _normalize_in_solver(self.normalizeReg, self.reg, self.A, b)  # src/ADMM.jl:219, src/SplitBregman.jl:196
 
     def converged(self):
         for i in range(len(self.reg)):
@@ -870,8 +907,10 @@ def make_problem(M, N, dtype, seed, n_rhs=None):
 class OptISTA:
     """src/OptISTA.jl:61-110 (ctor), :129-160 (init!), :169-209 (iterate)"""
 
-    def __init__(self, A, AHA=None, reg=None, iterations=50, rho=None, theta=1, relTol=None, normal="matrixfree"):
+    def __init__(self, A, AHA=None, reg=None, iterations=50, rho=None, theta=1, relTol=None, normal="matrixfree",
+                 normalizeReg="none"):
         self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        self.normalizeReg = normalizeReg
         if AHA is None:
             AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
         elif not hasattr(AHA, "mul"):
@@ -883,7 +922,7 @@ class OptISTA:
         rest = [r for r in regs if not _is_projection(r)]
         if len(rest) != 1:
             raise ValueError(f"OptISTA does not allow for more additional regularization terms, found {len(rest)}")
-        self.reg = rest[0]
+        self.reg = _normalize_regs(normalizeReg, rest, self.A, None)[0]  # src/OptISTA.jl:99
         if rho is None:
             raise ValueError("oracle OptISTA needs an explicit rho")
         self.rho = self.T(rho)
@@ -912,6 +951,7 @@ class OptISTA:
         self.theta_n = (T(1) + np.sqrt(T(1) + T(8) * tn * tn)) / T(2)
         self.rel_res_norm = T(np.inf)
         self.iteration = 0
+        self.reg = _normalize_in_solver(self.normalizeReg, [self.reg], self.A, self.x0)[0]  # src/OptISTA.jl:154
 
     def done(self):
         return bool(self.rel_res_norm < self.relTol) or self.iteration >= self.iterations
@@ -953,8 +993,9 @@ class POGM:
     (reference behaviour): it starts at 1 in a fresh solver and carries over between solves."""
 
     def __init__(self, A, AHA=None, reg=None, iterations=50, rho=None, theta=1, sigma_fac=1, relTol=None,
-                 restart="none", normal="matrixfree"):
+                 restart="none", normal="matrixfree", normalizeReg="none"):
         self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
+        self.normalizeReg = normalizeReg
         if AHA is None:
             AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
         elif not hasattr(AHA, "mul"):
@@ -967,7 +1008,7 @@ class POGM:
         rest = [r for r in regs if not _is_projection(r)]
         if len(rest) != 1:
             raise ValueError(f"POGM does not allow for more additional regularization terms, found {len(rest)}")
-        self.reg = rest[0]
+        self.reg = _normalize_regs(normalizeReg, rest, self.A, None)[0]  # src/POGM.jl:108
         if rho is None:
             raise ValueError("oracle POGM needs an explicit rho")
         T = self.T
@@ -1001,6 +1042,7 @@ class POGM:
         self.sigma = T(1)
         self.rel_res_norm = T(np.inf)
         self.iteration = 0
+        self.reg = _normalize_in_solver(self.normalizeReg, [self.reg], self.A, self.x0)[0]  # src/POGM.jl:163
 
     def done(self):
         return bool(self.rel_res_norm < self.relTol) or self.iteration >= self.iterations
@@ -1056,9 +1098,10 @@ class SplitBregman(ADMM):
     the right-hand side every iterationsInner inner iterations."""
 
     def __init__(self, A, AHA=None, reg=None, regTrafo=None, rho=1e-1, iterations=10, iterationsInner=10,
-                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree"):
+                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree", normalizeReg="none"):
         super().__init__(A, AHA=AHA, reg=reg, regTrafo=regTrafo, rho=rho, iterations=iterations,
-                         iterationsCG=iterationsCG, absTol=absTol, relTol=relTol, tolInner=tolInner, normal=normal)
+                         iterationsCG=iterationsCG, absTol=absTol, relTol=relTol, tolInner=tolInner, normal=normal,
+                         normalizeReg=normalizeReg)
         self.iterationsInner = int(iterationsInner)
         self.ybreg = np.zeros_like(self.x)
 
@@ -1422,6 +1465,10 @@ class FixedScaledRegularization(_Scaled):
 
     def scalefactor(self):
         return self.factor
+
+
+class NormalizedRegularization(FixedScaledRegularization):
+    """NormalizedRegularization.jl:30-37: lambda(reg) = lambda(inner) * factor (ScaledRegularization.jl:23)"""
 
 
 class FixedParameterRegularization(_Scaled):

@@ -1,0 +1,178 @@
+"""`-m gpu`: the reference's own convex solver suite (test/testSolvers.jl:67-201) through the product's `createLinearSolver`
+and the C ABI, fixed-point certificates that pin the prox thresholds on the device without reference to the oracle's
+restatement, and the committed golden fixtures (tests/golden/*.npz) held against the HIP path directly."""
+import os
+
+import numpy as np
+import pytest
+
+import rls_oracle as O
+from conftest import parity_check as parity
+from reference_suite import convex_problem, convex_suite, lasso_kkt_violation, lasso_problem, tv_duality_gap
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a = np.asarray(a).astype(np.complex128)
+    b = np.asarray(b).astype(np.complex128)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+class ViaCreateLinearSolver:
+    """`mod.FISTA(A, **kw)` -> `rls.createLinearSolver(rls.FISTA, A; kw...)`: the suite goes through the reference's front door"""
+
+    def __init__(self, rls):
+        self.rls = rls
+
+    def __getattr__(self, name):
+        obj = getattr(self.rls, name)
+        if isinstance(obj, type) and issubclass(obj, self.rls.AbstractLinearSolver):
+            return lambda A, **kw: self.rls.createLinearSolver(obj, A, **kw)
+        return obj
+
+
+@pytest.mark.parametrize("seed", [12345, 7])
+def test_reference_convex_suite_on_device(rls, ctx, seed):
+    """test/testSolvers.jl:67-201, every statement, in ComplexF32 on the device: POGM / OptISTA / FISTA / ADMM with
+    L1Regularization(1e-3), the constructors' DEFAULT rho (power_iterations on the device, src/FISTA.jl:63), gradient restart, the
+    `F .* 1e3` + MeasurementBasedNormalization invariance, ADMM `vary_rho` :balance / :PnP from 1e6 / 1e-6, SplitBregman plain
+    and measurement-normalised; `@test x ≈ x_approx rtol = 0.1`.  Beside the reference's assertion every case is held against
+    the float64 oracle's run of the same case (the iterates of 200 iterations; Float32 noise bound from the complex64 oracle)."""
+    F, x, b = convex_problem(seed)
+    Fc, bc = F.astype(np.complex64), b.astype(np.complex64)
+    wrapA = lambda a: rls.DeviceMatrix.from_host(np.asfortranarray(a.astype(np.complex64)), ctx)
+    wrapb = lambda v: rls.DeviceVector.from_host(v.astype(np.complex64), ctx)
+    got = convex_suite(ViaCreateLinearSolver(rls), Fc, bc, wrapA, wrapb, lambda v: v.to_host().copy(), lambda A: {},
+                       admm_scale=30.0)
+    assert len(got) == 15
+    for label, xa in got.items():
+        assert np.all(np.isfinite(xa)), label
+        assert rel(xa, x) < 0.1, (label, rel(xa, x))   # the reference's own assertion
+    # the same cases on the oracle with the same (Float32-typed) lambdas; rho: the oracle's power iteration from its own start
+    # vector differs from the device's in the 4th digit, which moves a 200-iteration iterate by far less than the gate below
+    from test_oracle import oracle_default_rho
+    ref = convex_suite(O, F.astype(np.complex128), b.astype(np.complex128), lambda a: a, lambda v: v, lambda v: np.array(v),
+                       oracle_default_rho, admm_scale=30.0)
+    for label, xa in got.items():
+        assert rel(xa, ref[label]) < 2e-3, (label, rel(xa, ref[label]))
+
+
+@pytest.mark.parametrize("dt", [np.complex64, np.float32])
+def test_fixed_points_pin_the_prox_thresholds_on_device(rls, ctx, dt):
+    """the LASSO optimality conditions of what the DEVICE solvers converge to (evaluated in float64 on the host): FISTA, POGM,
+    OptISTA -> lambda (`rho * lambda` handed to prox!, src/FISTA.jl:164), ADMM -> lambda / 2 (`lambda / (2 rho)`,
+    src/ADMM.jl:261), one SplitBregman block -> lambda (`lambda / rho`, src/SplitBregman.jl:236); sigma_max(A)^2 ~ 30 and
+    rho_ADMM in {0.3, 4} so that a misplaced rho moves the threshold by a large factor.  No oracle solver is involved."""
+    A, xt, b = lasso_problem(5, dt=dt)
+    A64 = A.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
+    smax2 = np.linalg.norm(A64, 2) ** 2
+    lam = float(0.2 * np.max(np.abs(A64.conj().T @ b)))
+    rho = 0.95 / smax2
+    Ad = rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx)
+    bd = rls.DeviceVector.from_host(b, ctx)
+    for S, its, tol in ((rls.FISTA, 4000, 2e-4), (rls.POGM, 4000, 2e-4), (rls.OptISTA, 4000, 2e-3)):
+        s = rls.createLinearSolver(S, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0)
+        x = rls.solve_(s, bd).to_host()
+        v, nnz = lasso_kkt_violation(A64, b, x, lam, support_tol=1e-5)
+        assert v < tol and 0 < nnz < 40, (S.__name__, v, nnz)
+        assert lasso_kkt_violation(A64, b, x, lam * rho, 1e-5)[0] > 1 and lasso_kkt_violation(A64, b, x, lam / 2, 1e-5)[0] > 0.5
+    for rho_admm in (0.3, 4.0):
+        s = rls.createLinearSolver(rls.ADMM, Ad, reg=rls.L1Regularization(lam), rho=rho_admm, iterations=3000, iterationsCG=100,
+                                   tolInner=1e-7, absTol=0.0, relTol=0.0)
+        x = rls.solve_(s, bd).to_host()
+        # x = z at the fixed point up to the cg! tolerance; threshold x's rounding-level entries as z's prox would
+        xs = np.where(np.abs(x) > 1e-4 * np.max(np.abs(x)), x, 0)
+        v, nnz = lasso_kkt_violation(A64, b, xs, lam / 2, support_tol=1e-5)
+        assert v < 2e-3 and 0 < nnz < 60, ("ADMM", rho_admm, v, nnz)
+        assert lasso_kkt_violation(A64, b, xs, lam, 1e-5)[0] > 0.4
+
+
+def test_tv_prox_duality_gap_on_device(rls, ctx):
+    """prox!(::TVRegularization) on the device (the register-resident FGP kernel, the LDS-resident generic stencil and the
+    two-launch sequence, depending on the geometry) certified by the duality gap of 1/2 ||u - x||^2 + lambda ||grad u||_1,
+    which involves neither the oracle's FGP nor its gradient operator's sign convention beyond |D|."""
+    rng = np.random.default_rng(2)
+    for shape, dims, lam in (((40,), None, 0.4), ((12, 9), None, 0.25), ((12, 9), (1,), 0.5), ((6, 5, 4), None, 0.15),
+                             ((64, 48), None, 0.3)):
+        n = int(np.prod(shape))
+        x = (np.cumsum(rng.standard_normal(n)) * 0.3 + rng.standard_normal(n)).astype(np.float32)
+        d0 = O._as_dims(shape, dims)
+        if n <= 512:
+            D = np.stack([O.grad_apply(e, shape, d0) for e in np.eye(n)], axis=1)
+        kw = dict(shape=shape, iterationsTV=3000, dims=dims)  # dims are 1-based, as in the reference API
+        u = rls.prox_(rls.TVRegularization, rls.DeviceVector.from_host(x, ctx), lam, **kw).to_host()
+        if n <= 512:
+            gap, primal = tv_duality_gap(x, u, lam, D)
+            assert -1e-5 < gap < 2e-5, (shape, dims, gap)
+            u2 = rls.prox_(rls.TVRegularization, rls.DeviceVector.from_host(x, ctx), 2 * lam, **kw).to_host()
+            assert tv_duality_gap(x, u2, lam, D)[0] > 1e-3
+        else:  # too large for the dense certificate: the primal objective must not exceed the float64 oracle's optimum
+            P = lambda w: 0.5 * np.sum((w - x.astype(np.float64)) ** 2) + lam * np.sum(np.abs(O.grad_apply(w, shape, d0)))
+            uo = O.prox_tv_fgp(x.astype(np.float64), lam, shape, dims, 3000)
+            assert P(u.astype(np.float64)) <= P(uo) * (1 + 1e-5)
+
+
+# ---- the committed golden fixtures, held against the HIP path -------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cgnr_256x128_f32.npz", "cgnr_64x32_c64.npz"])
+def test_golden_cgnr_iterates_on_device(rls, ctx, name):
+    """tests/golden/cgnr_*.npz (BASELINE configs[0] and a 64 x 32 ComplexF32 case): x, r, p, alpha, beta of every iteration"""
+    g = np.load(os.path.join(GOLD, name))
+    A, b = g["A"], g["b"]
+    n_it = len(g["x"])
+    s = rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx),
+                               reg=rls.L2Regularization(float(g["lam"])), iterations=n_it, relTol=0.0)
+    s32 = O.CGNR(A, reg=O.L2Regularization(float(g["lam"])), iterations=n_it, relTol=0.0)
+    s32.init(b)
+    rls.init_(s, rls.DeviceVector.from_host(b, ctx))
+    z0 = np.linalg.norm(g["r"][0])
+    for k in range(n_it):
+        assert s.iterate() is not None
+        s32.iterate()
+        st = s.state
+        parity(f"golden_{name}_x{k}", st.x.to_host(), g["x"][k], s32.x.copy())
+        parity(f"golden_{name}_r{k}", st.x0.to_host(), g["r"][k], s32.r.copy(), scale=z0)
+        parity(f"golden_{name}_p{k}", st.pl.to_host(), g["p"][k], s32.p.copy(), scale=z0)
+        st._refresh(ctx.lib)
+        assert abs(st.alphal - g["alpha"][k]) <= 2e-5 * abs(g["alpha"][k])
+        assert abs(st.betal - g["beta"][k]) <= 1e-4 * abs(g["beta"][k])
+    assert s.iterate() is None
+
+
+def test_golden_fista_admm_prox_on_device(rls, ctx):
+    """tests/golden/fista_l1_64x32_c64.npz (both restart modes), admm_tv_128x64_f32.npz (solution AND the inner cg! iteration
+    counts), prox_cases.npz (L1 / L2 / L21 / Positive / Real / TV incl. the zero and tiny entries) against the device"""
+    g = np.load(os.path.join(GOLD, "fista_l1_64x32_c64.npz"))
+    Ad = rls.DeviceMatrix.from_host(np.asfortranarray(g["A"]), ctx)
+    for restart in ("none", "gradient"):
+        s = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(float(g["lam"])), rho=float(g["rho"]), iterations=50,
+                                   restart=restart)
+        x = rls.solve_(s, rls.DeviceVector.from_host(g["b"], ctx)).to_host()
+        o = O.FISTA(g["A"], reg=O.L1Regularization(float(g["lam"])), rho=float(g["rho"]), iterations=50, restart=restart)
+        parity(f"golden_fista_{restart}", x, g["x_" + restart], np.array(O.solve(o, g["b"])))
+    g = np.load(os.path.join(GOLD, "admm_tv_128x64_f32.npz"))
+    kw = dict(rho=0.1, iterations=10, iterationsCG=10, tolInner=1e-5)
+    s = rls.createLinearSolver(rls.ADMM, rls.DeviceMatrix.from_host(np.asfortranarray(g["A"]), ctx),
+                               reg=rls.TVRegularization(1e-2, shape=(8, 8)), **kw)
+    x = rls.solve_(s, rls.DeviceVector.from_host(g["b"], ctx)).to_host()
+    o = O.ADMM(g["A"], reg=O.TVRegularization(1e-2, shape=(8, 8)), **kw)
+    parity("golden_admm_tv", x, g["x"], np.array(O.solve(o, g["b"])))
+    assert s.state.iteration == 10
+    assert list(s.state.cg_iterations) == list(g["cg_iters"])
+    g = np.load(os.path.join(GOLD, "prox_cases.npz"))
+    for tag in ("f32", "c64"):
+        x = g[f"x_{tag}"]
+        dev = lambda: rls.DeviceVector.from_host(x.copy(), ctx)
+        cases = (("l1", rls.prox_(rls.L1Regularization, dev(), 0.35)), ("l2", rls.prox_(rls.L2Regularization, dev(), 0.35)),
+                 ("l21", rls.prox_(rls.L21Regularization, dev(), 0.8, slices=8)),
+                 ("pos", rls.prox_(rls.PositiveRegularization, dev())), ("real", rls.prox_(rls.RealRegularization, dev())),
+                 ("tv", rls.prox_(rls.TVRegularization, dev(), 0.3, shape=(12, 8))),
+                 ("tv1", rls.prox_(rls.TVRegularization, dev(), 0.3, shape=(12, 8), dims=(1,))))
+        for key, out in cases:
+            want = g[f"{key}_{tag}"]
+            got = out.to_host()
+            if key in ("pos", "real"):
+                assert np.array_equal(got, want.astype(got.dtype)), (key, tag)
+            else:
+                assert rel(got, want) < 2e-6, (key, tag, rel(got, want))

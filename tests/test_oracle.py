@@ -464,3 +464,91 @@ def test_adjoint_product_forms_are_bit_identical():
         want = A.conj().T @ y
         assert np.array_equal(O.DenseOp(A).mul_adj(y), want)
         assert np.array_equal(np.conj(np.conj(y) @ A), want)
+
+
+# ---- the reference's convex suite: test/testSolvers.jl:67-201 (shared with the device tests: tests/reference_suite.py) ----
+from reference_suite import convex_problem, convex_suite, lasso_kkt_violation, lasso_problem, tv_duality_gap  # noqa: E402
+
+
+def oracle_default_rho(A):
+    """rho = 0.95 / power_iterations(AHA) (src/FISTA.jl:63, src/Utils.jl:262-287) from a seeded randn start"""
+    rng = np.random.default_rng(77)
+    b0 = rng.standard_normal(A.shape[1]) + 1j * rng.standard_normal(A.shape[1])
+    return {"rho": 0.95 / O.power_iterations(O.NormalOp(O.DenseOp(A)), b0.astype(A.dtype))}
+
+
+@pytest.mark.parametrize("seed", [12345, 7])
+@pytest.mark.parametrize("dt", [np.complex128, np.complex64])
+def test_reference_convex_suite_on_the_oracle(seed, dt):
+    """test/testSolvers.jl:67-201 replayed statement by statement: POGM / OptISTA / FISTA / ADMM with L1Regularization(1e-3),
+    200 iterations, gradient restart, the `F .* 1e3` + MeasurementBasedNormalization invariance, ADMM vary_rho :balance from
+    rho = 1e6 and 1e-6 and :PnP from 1e-6, SplitBregman plain and measurement-normalised; every `@test x ≈ x_approx rtol = 0.1`.
+    The reference runs it in ComplexF64 (x is a Float64 vector: the `elType` argument only types lambda); complex64 is the
+    device's arithmetic.  One case does not survive Float32 and is rescaled by 30 instead of 1e3 there: ADMM on `F .* 1e3` with
+    the default rho = 0.1 has `cg!` solve (1e6 F'F + 0.1 I) x = beta, condition number 1e7 -- the residual's rounding error
+    (1e6 |x| eps) is the size of the right-hand side's null-space part 0.1 (z - u), so Float32 `cg!` cannot see it
+    (relative error 0.65-0.77 in the complex64 oracle, 1e-3 in complex128)."""
+    F, x, b = convex_problem(seed)
+    got = convex_suite(O, F.astype(dt), b.astype(dt), lambda a: a, lambda v: v, lambda v: np.array(v), oracle_default_rho,
+                       admm_scale=1e3 if dt == np.complex128 else 30.0)
+    assert len(got) == 15
+    for label, xa in got.items():
+        assert rel(xa, x) < 0.1, (label, rel(xa, x))
+
+
+# ---- fixed points that pin the prox scalings without reference to the restatement ----------------------------------------
+@pytest.mark.parametrize("dt", [np.complex128, np.float64])
+def test_fixed_points_pin_the_prox_thresholds(dt):
+    """What each solver converges to says which threshold it hands to prox!, whatever the restatement does in between:
+      * FISTA / POGM / OptISTA call prox!(reg, x, rho * lambda) after a step of length rho (src/FISTA.jl:157,164;
+        src/POGM.jl:212 with gamma; src/OptISTA.jl:188 with rho * gamma): fixed point = the LASSO optimum for lambda --
+        with sigma_max(A)^2 = 30 a missing or doubled rho would move the threshold by that factor;
+      * ADMM calls prox!(reg, z, lambda / (2 rho)) (src/ADMM.jl:261): its fixed point is the LASSO optimum for lambda / 2;
+      * SplitBregman calls prox!(reg, z, lambda / rho) (src/SplitBregman.jl:236): one outer iteration's fixed point is the
+        LASSO optimum for lambda.
+    KKT: g = A'(A x - b), g_i = -lambda x_i / |x_i| on the support, |g_i| <= lambda off it."""
+    A, xt, b = lasso_problem(5, dt=dt)
+    smax2 = np.linalg.norm(A, 2) ** 2
+    assert smax2 > 20
+    lam = 0.2 * np.max(np.abs(A.conj().T @ b))
+    rho = 0.95 / smax2
+    for S, its, tol in ((O.FISTA, 6000, 1e-7), (O.POGM, 6000, 1e-7), (O.OptISTA, 6000, 1e-3)):
+        s = S(A, reg=O.L1Regularization(lam), rho=rho, iterations=its, relTol=0.0)
+        x = O.solve(s, b)
+        v, nnz = lasso_kkt_violation(A, b, x, lam)
+        assert v < tol and 0 < nnz < 40, (S.__name__, v, nnz)
+        assert lasso_kkt_violation(A, b, x, lam * rho)[0] > 1 and lasso_kkt_violation(A, b, x, lam / 2)[0] > 0.5  # the test has teeth
+    for rho_admm in (0.3, 4.0):
+        s = O.ADMM(A, reg=O.L1Regularization(lam), rho=rho_admm, iterations=3000, iterationsCG=200, tolInner=1e-12, absTol=0.0,
+                   relTol=0.0)
+        x = O.solve(s, b)
+        v, nnz = lasso_kkt_violation(A, b, s.z[0], lam / 2)
+        assert v < 1e-5 and 0 < nnz < 60, ("ADMM", rho_admm, v, nnz)
+        assert rel(x, s.z[0]) < 1e-6 and lasso_kkt_violation(A, b, s.z[0], lam)[0] > 0.4
+        s = O.SplitBregman(A, reg=O.L1Regularization(lam), rho=rho_admm, iterations=1, iterationsInner=3000, iterationsCG=200,
+                           tolInner=1e-12, absTol=0.0, relTol=0.0)
+        s.init(b)
+        for _ in range(2999):  # stop short of the Bregman update, which resets z to x (src/SplitBregman.jl:253-263)
+            s.iterate()
+        v, nnz = lasso_kkt_violation(A, b, s.z[0], lam)
+        assert v < 1e-5 and 0 < nnz < 40, ("SplitBregman", rho_admm, v, nnz)
+
+
+def test_tv_prox_duality_gap():
+    """prox!(::TVRegularization) (FGP, src/proximalMaps/ProxTV.jl:82-125) against a certificate that involves none of its
+    internals: the duality gap of its output for  1/2 ||u - x||^2 + lambda ||grad u||_1.  Pins lambda's place in the primal
+    update (:107, :123) and that the 1 / (8 lambda) step (:95) converges -- for 1-D, 2-D and directional TV."""
+    rng = np.random.default_rng(2)
+    for shape, dims, lam in (((40,), None, 0.4), ((12, 9), None, 0.25), ((12, 9), (1,), 0.5), ((6, 5, 4), None, 0.15)):
+        n = int(np.prod(shape))
+        x = np.cumsum(rng.standard_normal(n)) * 0.3 + rng.standard_normal(n)
+        d0 = O._as_dims(shape, dims)
+        D = np.stack([O.grad_apply(e, shape, d0) for e in np.eye(n)], axis=1)
+        u = O.prox_tv_fgp(x.copy(), lam, shape, dims, 4000)
+        gap, primal = tv_duality_gap(x, u, lam, D)
+        assert -1e-12 < gap < 1e-6, (shape, dims, gap)
+        u10 = O.prox_tv_fgp(x.copy(), lam, shape, dims, 10)  # the default iteration count: not converged, but on its way
+        gap10, _ = tv_duality_gap(x, u10, lam, D)
+        assert gap < gap10 < 0.2, (shape, dims, gap10)
+        # a wrong lambda in the primal update would be optimal for another lambda: the certificate must reject that
+        assert tv_duality_gap(x, O.prox_tv_fgp(x.copy(), 2 * lam, shape, dims, 4000), lam, D)[0] > 1e-3
