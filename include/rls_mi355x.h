@@ -312,7 +312,13 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h);
  * (a download, init, another plan, destroy, rls_sync ...) asks it to leave first, so nothing the caller does through the
  * library waits behind it; work the caller puts on the same stream by other means waits for the idle timeout at most.
  * A caller that touches the device between iterates twice in a row is served by the per-iteration pipeline until the next
- * init.  rls_tune_set("resident_server", 0) switches the mode off.  rls_fista_step_status: the same. */
+ * init.  rls_tune_set("resident_server", 0) switches the mode off.  rls_fista_step_status: the same.
+ * VISIBILITY: while a kernel listens, rls_*_get_status / rls_*_step_status answer from the host mirror the kernel published
+ * into; the state vectors x, r, p it wrote are current for every LATER call on this context (each asks the kernel to leave
+ * first), but a consumer outside this context -- another rls context, another stream or library reading the caller-owned
+ * buffers -- sees them only after such a call (rls_ctx_sync is enough) or after the idle timeout ("resident_server_idle_us",
+ * clamped to [1, 10000]).  For that reason contexts created on a BORROWED stream (rls_ctx_create_on_stream) start with
+ * "resident_server" = 0; rls_tune_set opts in. */
 int32_t rls_cgnr_step_status(rls_cgnr* s, int32_t n_steps, rls_cgnr_status* out_h);
 /* K independent SMALL systems -- each with its own A: the distinct-A flavour of a multi-solve, one solver per problem under
  * Threads.@threads in the reference (docs/src/literate/howto/multi_threading.jl:8-17) -- advanced together in ONE launch, one
@@ -547,6 +553,9 @@ int32_t rls_cg_local_update(rls_cg* s, void* x);
  *                     summed in rank order: every rank adds the same numbers in the same order).  Ranks may share
  *                     a device, which is how the config-5 schedule runs on a one-GPU box.
  *   RLS_COMM_AUTO   : RCCL when the devices are distinct, DIRECT otherwise.
+ * rls_comm_create probes hipDeviceCanAccessPeer between every pair of distinct devices.  A requested DIRECT transport whose
+ * ranks have a device each but lack peer access somewhere is DROPPED to RCCL (rls_comm_transport tells; rls_comm_peer_access
+ * reports the matrix: 1 can store into / same device, 0 cannot, -1 the query failed) -- never a fault at the first exchange.
  * ------------------------------------------------------------------------------------------- */
 typedef struct rls_comm rls_comm;
 enum { RLS_COMM_AUTO = 0, RLS_COMM_RCCL = 1, RLS_COMM_DIRECT = 2 };
@@ -554,6 +563,8 @@ int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* 
 int32_t rls_comm_destroy(rls_comm* comm);
 int32_t rls_comm_size(rls_comm* comm);
 int32_t rls_comm_transport(rls_comm* comm);
+/* out_matrix_h[nranks * nranks] (may be NULL), *out_requested_h = the transport rls_comm_create was asked for */
+int32_t rls_comm_peer_access(rls_comm* comm, int32_t* out_matrix_h, int32_t* out_requested_h);
 int32_t rls_comm_ctx(rls_comm* comm, int32_t rank, rls_ctx** out);
 int32_t rls_comm_sync(rls_comm* comm); /* waits for every rank's stream */
 /* in place: rank_bufs[r] (device pointer on rank r's device, n elements of dtype) <- sum over ranks; asynchronous */

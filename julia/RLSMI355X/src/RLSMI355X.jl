@@ -469,6 +469,15 @@ mutable struct Comm
 end
 Base.length(c::Comm) = Int(ccall((:rls_comm_size, librls[]), Int32, (Ptr{Cvoid},), c.handle))
 transport(c::Comm) = ccall((:rls_comm_transport, librls[]), Int32, (Ptr{Cvoid},), c.handle)
+"(matrix, requested): the hipDeviceCanAccessPeer matrix `Comm(...)` probed (1 / 0 / -1 = query failed; row r, column t: rank r's device
+can store into rank t's) and the transport that was asked for; `transport(c)` is the one in use"
+function peer_access(c::Comm)
+  n = length(c)
+  m = zeros(Int32, n * n)
+  req = Ref{Int32}(-1)
+  ccall((:rls_comm_peer_access, librls[]), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ref{Int32}), c.handle, m, req) == 0 || throw(RLSError(Int32(-1), "rls_comm_peer_access"))
+  (permutedims(reshape(m, n, n)), req[])
+end
 synchronize(c::Comm) = check(c.ctxs[1], ccall((:rls_comm_sync, librls[]), Int32, (Ptr{Cvoid},), c.handle), "rls_comm_sync")
 
 "in place: every rank's vector becomes the sum over the ranks (asynchronous, on the ranks' streams)"

@@ -186,6 +186,7 @@ PROTOTYPES = {
     "rls_comm_destroy": (_i32, [_vp]),
     "rls_comm_size": (_i32, [_vp]),
     "rls_comm_transport": (_i32, [_vp]),
+    "rls_comm_peer_access": (_i32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rls_comm_ctx": (_i32, [_vp, _i32, C.POINTER(_vp)]),
     "rls_comm_sync": (_i32, [_vp]),
     "rls_allreduce_sum": (_i32, [_vp, C.POINTER(_vp), C.c_int64, _i32]),

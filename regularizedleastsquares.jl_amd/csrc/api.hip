@@ -192,6 +192,10 @@ static int32_t ctx_create_impl(int32_t device, void* stream, bool borrow, rls_ct
   if (borrow) {
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
+    // A kernel left listening keeps the state it wrote in its XCD's L2 until it leaves, and only entry points of THIS context
+    // tell it to leave.  The owner of a borrowed stream reads the state vectors by its own means (another library, another
+    // stream behind an event), so such contexts start with the mode off; rls_tune_set("resident_server", 1) opts in.
+    ctx->tune.resident_server = 0;
   } else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -284,7 +288,11 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "small")) ctx->tune.small = value;
   else if (!strcmp(key, "resident_server")) ctx->tune.resident_server = value;
   else if (!strcmp(key, "resident_l2_rows")) ctx->tune.resident_l2_rows = value;
-  else if (!strcmp(key, "resident_server_idle_us")) ctx->tune.resident_server_idle_us = value;
+  else if (!strcmp(key, "resident_server_idle_us")) {
+    // the other workgroups of a listening grid wait at a barrier whose bound is resident_spin polls (about 0.1 s at the default):
+    // an idle time beyond a fraction of that would make them give up while workgroup 0 still polls the host (a lost launch)
+    ctx->tune.resident_server_idle_us = value < 1 ? 1 : (value > 10000 ? 10000 : value);
+  }
   else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "resident_preclear")) ctx->tune.resident_preclear = value;
   else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);

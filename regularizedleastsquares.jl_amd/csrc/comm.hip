@@ -83,6 +83,10 @@ struct rls_comm {
   rccl_api rccl;
   std::vector<nccl_comm_t> comms;
   bool group_open = false;  // single-thread path: rank 0 opened an RCCL group that the last rank has not closed yet
+  // peer-access probe (rls_comm_peer_access): peer[r * n + t] = 1 rank r's device can store into rank t's (or they share a
+  // device), 0 it cannot, -1 the query itself failed; requested = the transport the caller asked for, transport = the one in use
+  std::vector<int32_t> peer;
+  int requested = 0;
 };
 
 
@@ -282,7 +286,25 @@ int32_t rls_comm_create(int32_t nranks, const int32_t* devices, rls_ctx* const* 
   bool distinct = true;
   for (int r = 0; r < nranks; ++r)
     for (int t = 0; t < r; ++t) distinct = distinct && c->ctx[r]->device != c->ctx[t]->device;
+  // Peer-access probe, whatever the transport: the direct transport stores into the peers' receive buffers, which needs
+  // hipDeviceCanAccessPeer between every pair of distinct devices.  A pair without it is REPORTED (rls_comm_peer_access) and a
+  // requested direct transport drops to RCCL when the ranks have a device each -- it never turns into a fault at the first
+  // exchange.  (A query that fails is treated as "cannot".)
+  c->peer.assign((size_t)nranks * nranks, 1);
+  bool all_peers = true;
+  for (int r = 0; r < nranks; ++r)
+    for (int t = 0; t < nranks; ++t) {
+      const int da = c->ctx[r]->device, db = c->ctx[t]->device;
+      if (da == db) continue;
+      int can = 0;
+      const hipError_t e = hipDeviceCanAccessPeer(&can, da, db);
+      if (e != hipSuccess) (void)hipGetLastError();
+      c->peer[(size_t)r * nranks + t] = e != hipSuccess ? -1 : (can ? 1 : 0);
+      all_peers = all_peers && e == hipSuccess && can;
+    }
+  c->requested = transport;
   if (transport == RLS_COMM_AUTO) transport = (distinct && nranks > 1) ? RLS_COMM_RCCL : RLS_COMM_DIRECT;
+  if (transport == RLS_COMM_DIRECT && !all_peers && distinct) transport = RLS_COMM_RCCL;  // reported, not fatal
   c->transport = transport;
   int32_t st = 0;
   if (transport == RLS_COMM_RCCL) {
@@ -354,6 +376,17 @@ int32_t rls_comm_destroy(rls_comm* c) {
 
 int32_t rls_comm_size(rls_comm* c) { return c ? c->n : RLS_E_INVALID; }
 int32_t rls_comm_transport(rls_comm* c) { return c ? c->transport : RLS_E_INVALID; }
+
+// the probe of rls_comm_create: out_matrix[r * nranks + t] (may be null) as described at rls_comm::peer; *out_requested = the
+// transport asked for, the return value of rls_comm_transport is the one in use (they differ when AUTO resolved, or when a
+// requested direct transport was dropped to RCCL because some pair of devices has no peer access)
+int32_t rls_comm_peer_access(rls_comm* c, int32_t* out_matrix, int32_t* out_requested) {
+  if (!c) return RLS_E_INVALID;
+  if (out_matrix)
+    for (size_t i = 0; i < c->peer.size(); ++i) out_matrix[i] = c->peer[i];
+  if (out_requested) *out_requested = c->requested;
+  return 0;
+}
 
 int32_t rls_comm_ctx(rls_comm* c, int32_t rank, rls_ctx** out) {
   if (!c || !out || rank < 0 || rank >= c->n) return RLS_E_INVALID;

@@ -877,6 +877,8 @@ struct rls_small_group {
   int count = 0;
   rls_small d[RLS_SMALL_GROUP_MAX];
 };
+// the group travels BY VALUE as a kernel argument: the kernarg segment is 4 KiB, and the other arguments need a few words of it
+static_assert(sizeof(rls_small_group) + 64 <= 4096, "rls_small_group no longer fits the 4 KiB kernarg segment: shrink rls_small or RLS_SMALL_GROUP_MAX");
 int32_t rls_small_group_launch(rls_ctx* ctx, int32_t dtype, const rls_small_group& G, int n_steps);
 bool rls_small_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_small_launch(rls_ctx* ctx, int32_t dtype, const rls_small& D, int n_steps);

@@ -264,6 +264,22 @@ class _BorrowedContext(Context):
 COMM_AUTO, COMM_RCCL, COMM_DIRECT = 0, 1, 2
 
 
+def comm_peer_report(lib, comm, n):
+    """rls_comm_peer_access as a dict: the hipDeviceCanAccessPeer matrix rls_comm_create probed (1 can store into / same
+    device, 0 cannot, -1 query failed), the transport that was asked for and the one in use (a requested direct transport is
+    dropped to RCCL when some pair of distinct devices has no peer access)"""
+    mat = (C.c_int32 * (n * n))()
+    req = C.c_int32(-1)
+    st = lib.rls_comm_peer_access(comm, mat, C.byref(req))
+    if st != 0:
+        return {"error": f"rls_comm_peer_access status {st}"}
+    rows = [[int(mat[r * n + t]) for t in range(n)] for r in range(n)]
+    used = int(lib.rls_comm_transport(comm))
+    return {"peer_access": rows, "all_pairs": all(v == 1 for row in rows for v in row), "transport_requested": int(req.value),
+            "transport_in_use": used, "dropped_to_rccl": bool(req.value == COMM_DIRECT and used == COMM_RCCL)}
+
+
+
 class CommRowShardedCGNR:
     """Config 5 driven from ONE host process through the library's own communicator (include/rls_mi355x.h:
     rls_comm_create, rls_cgnr_init_rowsharded, rls_cgnr_step_rowsharded): rank r owns a context, its row shard of A
@@ -301,6 +317,9 @@ class CommRowShardedCGNR:
     @property
     def transport(self):
         return self.lib.rls_comm_transport(self.comm)
+
+    def peer_report(self):
+        return comm_peer_report(self.lib, self.comm, self.n)
 
     def init(self, b_parts):
         self._b = [self.rls.DeviceVector.from_host(np.ascontiguousarray(bp), c) for bp, c in zip(b_parts, self.ctxs)]

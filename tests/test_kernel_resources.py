@@ -89,3 +89,50 @@ def test_register_budgets_admit_the_intended_occupancy(kernels):
         if "resident_kernel" in k:
             assert v["vgprs"] <= 256, (k, v)
         assert v["vgprs"] <= 512, (k, v)
+
+
+def _vregs(tok):
+    """registers named by an operand token: 'v7' -> {7}, 'v[24:25]' -> {24, 25}"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def test_hand_issued_loads_are_not_touched_before_their_hand_written_wait():
+    """`cgnr_gramk_resident_kernel` (gramk.hip) issues its 16 partial-dot loads as inline-asm `buffer_load_dwordx2 ... sc1` and waits
+    for them with a hand-written `s_waitcnt vmcnt(2 NE)` -- the compiler does not know those registers are in flight, so nothing in
+    the SHIPPED code may read, copy, spill or overwrite them between the loads and that wait, the V loads behind them must be
+    exactly the 2 NE the count assumes, and the first use must come after the wait (the advisor's round-4 finding; this is the
+    ISA-level check it asked for, on the code objects inside librls_mi355x.so)."""
+    import kernel_metadata
+
+    if not os.path.exists(kernel_metadata.LIB):
+        pytest.skip("library not built")
+    ks = kernel_metadata.disassemble("cgnr_gramk_resident_kernel")
+    assert len(ks) >= 4, sorted(ks)
+    for name, ins in ks.items():
+        ne = int(re.search(r"<(\d+),", name).group(1))
+        loads = [i for i, l in enumerate(ins) if l.startswith("buffer_load_dwordx2") and " sc1" in l]
+        assert len(loads) == 16, (name, len(loads))
+        dst = set()
+        for i in loads:
+            dst |= _vregs(ins[i].split()[1].rstrip(","))
+        assert len(dst) == 32, (name, "the 16 destinations overlap")
+        # the wait: the first s_waitcnt with a vmcnt behind the last hand-issued load
+        w = next(i for i in range(loads[-1] + 1, len(ins)) if ins[i].startswith("s_waitcnt") and "vmcnt" in ins[i])
+        assert re.search(r"vmcnt\((\d+)\)", ins[w]).group(1) == str(2 * ne), (name, ins[w])
+        between = ins[loads[0] + 1:w]
+        later_vmem = [l for l in ins[loads[-1] + 1:w] if l.startswith(("buffer_load", "global_load", "flat_load", "scratch_load"))]
+        assert len(later_vmem) == 2 * ne and all(l.startswith("buffer_load_dwordx4") for l in later_vmem), (name, later_vmem)
+        for l in between:
+            if l.startswith("buffer_load_dwordx2") and " sc1" in l:
+                continue
+            assert not l.startswith(("scratch_", "s_waitcnt")), (name, l)
+            toks = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+            hit = set().union(*[_vregs(t) for t in toks]) & dst if toks else set()
+            # the V loads may not land in, nor address through, a register that is still in flight
+            assert not hit, (name, l, sorted(hit))
+        # and the sum is formed only behind the wait
+        assert any(l.startswith("v_add_f64") for l in ins[w + 1:w + 8]), (name, ins[w + 1:w + 8])

@@ -56,6 +56,43 @@ def kernels(lib=LIB):
     return dict(zip(demangle(names), (raw[n] for n in names)))
 
 
+def disassemble(pattern, lib=LIB):
+    """{short demangled name: [instruction lines]} of the gfx950 kernels whose MANGLED name contains `pattern`, disassembled
+    (llvm-objdump) from the code objects inside the shipped library"""
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run(["objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(tmp, "copy.so")], check=True)
+        data = open(fat, "rb").read()
+        for m in re.finditer(re.escape(MAGIC), data):
+            bo = m.start()
+            n = struct.unpack_from("<Q", data, bo + 24)[0]
+            p = bo + 32
+            for _ in range(n):
+                off, size, tl = struct.unpack_from("<QQQ", data, p)
+                p += 24
+                triple = data[p:p + tl].decode()
+                p += tl
+                if "gfx950" not in triple or size == 0 or pattern.encode() not in data[bo + off:bo + off + size]:
+                    continue
+                co = os.path.join(tmp, "dev.co")
+                open(co, "wb").write(data[bo + off:bo + off + size])
+                txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True,
+                                     check=True).stdout
+                cur = None
+                for line in txt.split("\n"):
+                    h = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                    if h:
+                        cur = h.group(1) if pattern in h.group(1) and not h.group(1).startswith(("L", ".L")) else (cur if h.group(1).startswith(("L", ".L")) else None)
+                        if cur is not None and cur not in out:
+                            out[cur] = []
+                        continue
+                    if cur is not None and line.strip():
+                        out[cur].append(re.sub(r"\s*//.*$", "", line.strip()))
+    names = sorted(out)
+    return dict(zip(demangle(names), (out[n] for n in names)))
+
+
 if __name__ == "__main__":
     ks = kernels(sys.argv[1] if len(sys.argv) > 1 else LIB)
     spill = {k: v for k, v in ks.items() if v["scratch"] > 0}
