@@ -36,6 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_KIND = ("static: PMC counters cannot be read from inside this process; the figure is the committed `rocprofv3 --pmc` pass named in "
+                "traffic_source (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, separate passes), per launch of the same kernel and shape")
 HBM_PEAK_GBS = 8000.0     # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
 MFMA_F32_PEAK_TF = 157.3  # dense f32-input MFMA peak, same table
 VALU_F32_PEAK_TF = 157.3  # "Peak FP32 (vector)", same table: 64 FLOP/clk/SIMD, packed FMAs included (round 3 used twice that)
@@ -91,6 +93,26 @@ def make_A(M, N, seed, dtype=np.complex64):
 def bytes_per_cgnr_iteration(M, N, s):
     """algorithmic bytes: A read twice + the length-N / length-M vector traffic"""
     return 2 * M * N * s + (16 * N + 2 * M) * s
+
+
+def float64_cgnr(A, b, n):
+    """the in-band proof that the timed kernel did the work: n iterations of CG on the normal equations in complex128 on the host
+    (src/CGNR.jl:107-178 with lambda = 0: r = A'b, p = r; alpha = |r|^2 / <p, A'A p>, x += alpha p, r -= alpha A'A p,
+    beta = |r_new|^2 / |r|^2, p = beta p + r) -- a few lines of NumPy inside the measurement script, NOT the oracle package, so
+    that the bench line can vouch for its own `value` wherever it runs"""
+    A64 = A.astype(np.complex128)
+    AH = np.ascontiguousarray(A64.conj().T)
+    x = np.zeros(A.shape[1], np.complex128)
+    r = AH @ b.astype(np.complex128)
+    p = r.copy()
+    for _ in range(n):
+        v = AH @ (A64 @ p)
+        zeta = np.vdot(r, r).real
+        alpha = zeta / np.vdot(p, v)
+        x += alpha * p
+        r -= alpha * v
+        p = (np.vdot(r, r).real / zeta) * p + r
+    return x
 
 
 def spread(xs):
@@ -595,7 +617,7 @@ def other_paths(rls, ctx, Ad, A, b, errors):
     return out
 
 
-def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32):
+def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32, rows=65536, rehearse=False):
     """the config-5 block of the default N > 1 line: a short `--workload rowsharded` run (it/s, the per-rank step_local_a time
     and HBM fraction, the all-reduce time, the backend and world size the collective saw) and the one-process host."""
     from importlib import import_module
@@ -603,7 +625,7 @@ def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32):
     mg = import_module("rls_amd.multigpu")
     out = {}
     try:
-        full = mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W)
+        full = mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=rows)
         dom = full["roofline"]["kernel"]
         out = {"metric": full["metric"], "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"], "scaling": "strong",
                "rows_per_gpu": full["config"]["rows_per_gpu"], "collective": full["config"]["collective"],
@@ -613,7 +635,8 @@ def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32):
         out = {"error": f"{type(e).__name__}: {e}"}
     barrier()
     try:
-        out["one_process_host"] = mg.bench_rowsharded_one_process(rls, rank, world, K, W)
+        out["one_process_host"] = mg.bench_rowsharded_one_process(rls, rank, world, K, W, M=rows,
+                                                                   devices=([0] * world if rehearse else None))
     except Exception as e:
         out["one_process_host"] = {"error": f"{type(e).__name__}: {e}"}
     barrier()
@@ -632,6 +655,42 @@ def load_pmc(kernel_prefix):
         except Exception:
             continue
     return None, None
+
+
+class HostStagedDist:
+    """`--rehearse`: the part of torch.distributed this script uses, over gloo, with device tensors staged through the host
+    (`t.cpu()` waits for torch's current stream -- the stream the row-sharded kernels borrow -- and `t.copy_` is ordered on it)."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def all_reduce(self, t, op=None):
+        import torch
+
+        op = self._d.ReduceOp.SUM if op is None else op
+        c = t.cpu() if t.is_cuda else t
+        self._d.all_reduce(torch.view_as_real(c) if c.is_complex() else c, op=op)
+        if t.is_cuda:
+            t.copy_(c)
+
+    def all_gather(self, outs, t):
+        cs = [o.cpu() for o in outs]
+        self._d.all_gather(cs, t.cpu())
+        for o, c in zip(outs, cs):
+            o.copy_(c)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def get_backend(self):
+        return f"{self._d.get_backend()} (rehearsal: device tensors staged through the host)"
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
 
 
 def self_launch_command(gpus, argv, env):
@@ -663,6 +722,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--resident", type=int, default=1, help="0: force the two-launch pipeline for the headline run")
     ap.add_argument("--dry-launch", action="store_true", help="N > 1 from a plain shell: print the launch command as JSON and exit")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="run the N > 1 code path on ONE GPU: every rank on device 0, torch.distributed over gloo (device tensors staged "
+                         "through the host), the library's communicator on its direct transport with the ranks sharing the device; the "
+                         "register-resident kernels are switched off (N processes cannot all own the chip).  The line says `rehearsal`: "
+                         "its numbers are not a scaling measurement")
+    ap.add_argument("--c5-rows", type=int, default=65536, help="total rows of the config-5 matrix (rehearsals shrink it)")
     args = ap.parse_args()
 
     launch = self_launch_command(args.gpus, sys.argv[1:], os.environ)
@@ -689,16 +754,23 @@ def main():
                          "or under torch.distributed.run with --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    device = 0 if args.rehearse else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+            dist = HostStagedDist(dist)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import rls_amd as rls
 
-    ctx = rls.Context(local_rank)
+    ctx = rls.Context(device)
+    if args.rehearse:
+        ctx.tune(resident=0)
     M, N = args.M, args.N
     dt = np.complex64
     s = np.dtype(dt).itemsize
@@ -718,7 +790,7 @@ def main():
         from importlib import import_module
 
         mg = import_module("rls_amd.multigpu")
-        return finish(mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W))
+        return finish(mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=args.c5_rows))
 
     lib, h = ctx.lib, ctx.handle
 
@@ -910,6 +982,17 @@ def main():
     st._refresh(lib)
     assert st.iteration == ((K - 1) % SEGMENT) + 1, (st.iteration, K)
     assert math.isfinite(st._residual), "CGNR residual is not finite"
+    # the line proves its own work: the x the timed region left behind (st.iteration iterations into its last solve) against a
+    # float64 CGNR of the same count on the host, and against the planted solution (CG converges geometrically on this matrix)
+    x_dev = st.x.to_host().astype(np.complex128)
+    x_f64 = float64_cgnr(A, b, st.iteration)
+    sol_err = float(np.linalg.norm(x_dev - x_f64) / np.linalg.norm(x_f64))
+    sol_err_true = float(np.linalg.norm(x_dev - x_true) / np.linalg.norm(x_true))
+    assert sol_err <= 1e-5, f"the timed kernel's solution is off the float64 CGNR iterate by {sol_err:.3e} (> 1e-5)"
+    if dist is not None:
+        tt = torch.tensor([sol_err], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sol_err = float(tt.item())
 
     # ---- the dominant kernel, timed live with hipEvents on the stream it is launched on ---------------------------
     bytes_iter = bytes_per_cgnr_iteration(M, N, s)
@@ -986,6 +1069,41 @@ def main():
                                                           "result_read_by_every_workgroup (L2 rate)": nwg * row_bytes},
                                         "rates_TBps": {"infinity_cache": INF_CACHE_TBS, "l2_shared_rows": L2_SHARED_TBS}}}),
                      "source": "tools/ubench/grid_barrier (run live by bench.py); profiles/ holds a committed run"}
+    hbm_streaming = None
+    if rank == 0 and world == 1 and path.value == 4:
+        # the HBM story beside the headline's grid-exchange roof: the SAME solve on the path that does stream A every iteration
+        # (resident = 0: cgnr_pipe_a_kernel reads A once and forms both products, cgnr_pipe_r_kernel sums the partial rows)
+        try:
+            ctx.tune(resident=0)
+            try:
+                Sp = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
+                rls.solve_(Sp, bd)
+                best = float("inf")
+                for _ in range(8):
+                    rls.init_(Sp, bd)
+                    ctx.timer_start()
+                    lib.rls_cgnr_step(Sp.state._plan, SEGMENT)
+                    best = min(best, ctx.timer_stop_ms())
+                us_it = best * 1e3 / SEGMENT
+                us_a, us_r = C.c_float(), C.c_float()
+                rls.init_(Sp, bd)
+                rc = lib.rls_cgnr_step_profiled(Sp.state._plan, 100, C.byref(us_a), C.byref(us_r))
+            finally:
+                ctx.tune(resident=1)
+            real_a = M * N * s + nwg * N * s
+            tr_a, tr_src = load_pmc("cgnr_pipe_a_kernel")
+            hbm_streaming = {"path": "two-launch pipeline (resident = 0): A streamed ONCE per iteration, both products from the register slab",
+                             "us_per_iteration": us_it, "iterations_per_s": 1e6 / us_it,
+                             "frac_algorithmic": bytes_iter / us_it / 1e3 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_iteration (SURVEY 8d: A read twice)": bytes_iter}
+            if rc == 0:
+                hbm_streaming.update({"kernel": "cgnr_pipe_a_kernel", "kernel_us_back_to_back": us_a.value,
+                                      "real_bytes_per_launch (A once + the partial rows)": real_a,
+                                      "frac_real_bytes": real_a / (us_a.value * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                      "real_GBps": real_a / us_a.value / 1e3, "traffic_pmc_static": tr_a, "traffic_source": tr_src,
+                                      "reduce_kernel_us_back_to_back": us_r.value})
+        except Exception as e:  # noqa: BLE001 -- beside the headline, must not cost the line
+            hbm_streaming = {"error": repr(e)}
     n1_value = solo_rate(lambda: rls.init_(solver, bd), lambda: step(K, True), K)
     c4 = None
     if world > 1:
@@ -1008,7 +1126,7 @@ def main():
         # BASELINE configs[4] on the same job: the 65536 x 8192 problem row-partitioned over the ranks, one all-reduce of
         # A^H t per iteration through torch.distributed (RCCL); then the one-process host of the same problem -- rank 0 alone
         # driving every GPU through the library's own communicator (the Julia host's call sequence) -- while the others wait
-        c5 = config5_leg(rls, ctx, dist, rank, world, barrier)
+        c5 = config5_leg(rls, ctx, dist, rank, world, barrier, rows=args.c5_rows, rehearse=args.rehearse)
     traffic, traffic_src = load_pmc(dom)
     kd = kern[dom]
     hbm_bytes = traffic if traffic is not None else kd["min_hbm_bytes_per_launch"]
@@ -1029,6 +1147,8 @@ def main():
             "vs_baseline": None,
             "dtype": "c64 (ComplexF32 storage and arithmetic; scalar reductions accumulated in f64)",
             "data": "synthetic",
+            **({"rehearsal": "every rank on device 0, gloo control plane, resident kernels off: the N > 1 CODE PATH on one GPU -- not a "
+                             "scaling measurement"} if args.rehearse else {}),
             "config": {"workload": f"CGNR matrix-free normal operator, dense column-major ComplexF32 {M}x{N}, lambda=0, relTol=0, back-to-back "
                                    f"solves of {SEGMENT} iterations (BASELINE configs[1] shape, headline metric run of SURVEY 8d)" +
                                    ("" if world == 1 else "; one independent solve per GPU, no collectives"),
@@ -1037,13 +1157,18 @@ def main():
                              "value_is": "n_gpus * steps / median(wall); every repetition is exactly `steps` iterations between "
                                          "barrier + synchronize on both sides",
                              "iterations_per_s_hip_events": K / ev},
+            "solution_check": {"rel_err_vs_float64_cgnr_same_iteration": sol_err, "tolerance": 1e-5, "iteration": st.iteration,
+                               "rel_err_vs_planted_x_true": sol_err_true,
+                               "what": "x left by the LAST solve of the timed region (max over ranks) against a complex128 CGNR of the same "
+                                       "iteration count run on the host by bench.py itself; asserted before the line is printed"},
             "roofline": {},
         }
         hbm_view = {
             # algorithmic basis, the ITERATION as the unit (SURVEY 8d bytes per iteration x iterations / device time of the timed region)
             "peak_GBps": HBM_PEAK_GBS, "algorithmic_GBps": iter_gbs, "frac_algorithmic": frac_alg,
             # physical basis: bytes the dominant kernel really moves per launch / its launch time
-            "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "hbm_bytes_per_launch_used": hbm_bytes,
+            "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": TRAFFIC_KIND,
+            "hbm_bytes_per_launch_used": hbm_bytes,
             "note": "frac_algorithmic: SURVEY 8d algorithmic bytes per iteration (A read twice) x iterations / hipEvent time of the timed region / peak; "
                     "frac_hbm: HBM bytes of the dominant kernel per launch (PMC when collected, else the minimum it must move) / its launch time / peak"}
         if floor is not None:
@@ -1054,7 +1179,8 @@ def main():
                                "achieved": 1e6 / floor["measured"], "peak": 1e6 / floor["floor"],
                                "frac": (1e6 / floor["measured"]) / (1e6 / floor["floor"]),
                                "us_per_iteration": {"measured": floor["measured"], "floor": floor["floor"]},
-                               "traffic": traffic, "traffic_source": traffic_src,
+                               "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": TRAFFIC_KIND,
+                               "hbm_streaming": hbm_streaming,
                                "protocol_independent": floor["protocol_independent_floor"],
                                "hbm": dict(hbm_view, hbm_algorithmic_uncapped=iter_gbs,
                                            note=hbm_view["note"] + ".  A lives in VGPRs for the whole launch: per iteration only the partial-row "
@@ -1062,8 +1188,8 @@ def main():
                                "resident_floor": floor}
         else:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": iter_gbs, "frac": frac_alg,
-                               "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "hbm_bytes_per_launch_used": hbm_bytes,
-                               "note": hbm_view["note"]}
+                               "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": TRAFFIC_KIND,
+                               "hbm_streaming": hbm_streaming, "hbm_bytes_per_launch_used": hbm_bytes, "note": hbm_view["note"]}
         out["roofline"]["per_kernel"] = kern
         out["roofline"]["iteration"] = {"bytes": bytes_iter, "us_hip_events": 1e6 * ev / K, "roofline_us_at_peak": bytes_iter / HBM_PEAK_GBS / 1e3}
         # which regime `value` is in: a resident launch pays its slab load once per step call, and the first solve's init! lies

@@ -911,7 +911,7 @@ def bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=65536, N=8192):
             "residual": st["residual"]}
 
 
-def bench_rowsharded_one_process(rls, rank, world, K, W, M=65536, N=8192):
+def bench_rowsharded_one_process(rls, rank, world, K, W, M=65536, N=8192, devices=None):
     """BASELINE config 5 from ONE host process (the Julia host's shape): rank 0 of the job drives `world` GPUs through the library's
     own communicator (rls_comm_*: per-rank worker threads, the one-shot direct-write all-reduce over xGMI, then RCCL inside the
     library) while the other ranks of the job wait.  Returns (rank 0) iterations/s per transport and the host time the busiest
@@ -927,9 +927,14 @@ def bench_rowsharded_one_process(rls, rank, world, K, W, M=65536, N=8192):
         shards.append(A)
         parts.append((A @ x_true).astype(np.complex64))
     seg = 32
+    devices = list(range(world)) if devices is None else list(devices)
+    shared = len(set(devices)) < len(devices)
     for name, transport in (("direct", COMM_DIRECT), ("rccl", COMM_RCCL)):
+        if shared and transport == COMM_RCCL:  # a rehearsal on one GPU: RCCL refuses several ranks on one device
+            out[name] = {"skipped": "the ranks share a device (rehearsal): the RCCL transport needs a device per rank"}
+            continue
         try:
-            s = CommRowShardedCGNR(rls, shards, devices=list(range(world)), transport=transport, iterations=seg, relTol=0.0)
+            s = CommRowShardedCGNR(rls, shards, devices=devices, transport=transport, iterations=seg, relTol=0.0)
         except Exception as e:
             out[name] = {"error": f"{type(e).__name__}: {e}"}
             continue
@@ -953,6 +958,7 @@ def bench_rowsharded_one_process(rls, rank, world, K, W, M=65536, N=8192):
             s.lib.rls_comm_debug_busy_seconds(s.comm, busy1)
             st = s.status(0)
             out[name] = {"iterations_per_s": K / el, "us_per_iteration": 1e6 * el / K, "transport_code": int(s.transport), "ranks": world,
+                         "peer_probe": s.peer_report(),
                          "host_busy_us_per_iteration_per_rank": [1e6 * (b1 - b0) / K for b0, b1 in zip(busy0, busy1)],
                          "residual": st["residual"]}
         except Exception as e:

@@ -176,3 +176,42 @@ def test_golden_fista_admm_prox_on_device(rls, ctx):
                 assert np.array_equal(got, want.astype(got.dtype)), (key, tag)
             else:
                 assert rel(got, want) < 2e-6, (key, tag, rel(got, want))
+
+
+# ---- the N > 1 path of bench.py, rehearsed on the one GPU of this box ---------------------------------------------------
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_multi_gpu_path_rehearsed_on_one_gpu(n):
+    """`python bench.py --gpus N --rehearse`: the launcher, N ranks (all on device 0, gloo control plane), the headline leg with its
+    max-over-ranks timing and solution check, `config4_batched` (matrix-free and on the explicit Gram matrix), `config5_rowsharded`
+    (torch.distributed ranks + the one-process host through rls_comm_* on the direct transport) -- so that the driver's first
+    8-GPU run is not the first execution of that code.  Semantics: src/MultiThreading.jl:30-79 (independent columns per GPU),
+    SURVEY 8e.  Asserts ONE JSON line with n_gpus = N, per-rank rates, and no `error` anywhere in the two legs."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--rehearse", "--steps", "64", "--warmup", "32",
+                        "--c5-rows", "8192"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 64 and d["unit"] == "iterations/s" and d["value"] > 0 and "rehearsal" in d
+    assert d["solution_check"]["rel_err_vs_float64_cgnr_same_iteration"] <= 1e-5
+    assert d["n1_same_workload_value"] > 0
+
+    def errors(o, path=""):
+        if isinstance(o, dict):
+            return [f"{path}/{k}: {v}" for k, v in o.items() if k == "error"] + [e for k, v in o.items() for e in errors(v, f"{path}/{k}")]
+        return []
+
+    c4, c5 = d["config4_batched"], d["config5_rowsharded"]
+    assert not errors(c4) and not errors(c5), errors(c4) + errors(c5)
+    assert len(c4["per_rank_solve_iterations_per_s_hip_events"]) == n and c4["value"] > 0 and c4["gram_mode"]["value"] > 0
+    assert c5["value"] > 0 and c5["collective"]["world_size_seen_by_the_collective"] == n and np.isfinite(c5["residual"])
+    direct = c5["one_process_host"]["direct"]
+    assert direct["ranks"] == n and direct["iterations_per_s"] > 0 and np.isfinite(direct["residual"])
+    assert direct["peer_probe"]["transport_in_use"] == 2 and direct["peer_probe"]["all_pairs"]
+    assert "skipped" in c5["one_process_host"]["rccl"]

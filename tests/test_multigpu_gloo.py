@@ -324,3 +324,56 @@ def test_row_sharded_fista_and_admm_two_ranks_gloo():
         assert err_f < 1e-10, err_f   # sharded == unsharded FISTA
         assert err_a < 1e-6, err_a    # oracle ADMM computes in the dtype of A with Float32-typed tolerances
         assert same and it_ok and cg_ok
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py --rehearse: the gloo proxy the rehearsal puts in front of torch.distributed
+# ---------------------------------------------------------------------------------------------
+
+
+def _staged_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        d = bench.HostStagedDist(dist)
+        v = torch.tensor([1.0 + 2.0j, -3.0j], dtype=torch.complex64) * (rank + 1)   # the row-sharded vectors are complex
+        d.all_reduce(v, op=d.ReduceOp.SUM)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        outs = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        d.all_gather(outs, torch.tensor([10.0 + rank], dtype=torch.float64))
+        d.barrier()
+        q.put((rank, v.numpy().tolist(), float(t.item()), [float(o.item()) for o in outs], d.get_world_size(), d.get_backend()))
+    finally:
+        d.destroy_process_group()
+
+
+def test_rehearsal_proxy_over_gloo_two_ranks():
+    """`bench.py --gpus N --rehearse` (the N > 1 code path on one GPU) replaces torch.distributed by HostStagedDist: the calls
+    the bench makes -- all_reduce SUM of complex vectors, MAX of the elapsed time, all_gather of the per-rank rates, barrier --
+    over gloo with world size 2; and the flag reaches the ranks the parent launches"""
+    import json
+    import subprocess
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_staged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, v, mx, outs, ws, backend in res:
+        assert v == [3.0 + 6.0j, -9.0j] and mx == 1.0 and outs == [10.0, 11.0] and ws == 2 and backend.startswith("gloo")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rehearse", "--c5-rows", "8192", "--dry-launch"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert "--rehearse" in cmd and cmd[cmd.index("--c5-rows") + 1] == "8192" and "--nproc-per-node=8" in cmd
