@@ -396,6 +396,14 @@ int32_t rls_fista_init_batched(rls_fista* s, const void* B, int64_t ldb, float r
 int32_t rls_fista_get_status_batched(rls_fista* s, rls_fista_status* out_h /* [nrhs] */);
 int32_t rls_fista_destroy(rls_fista* s);
 int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t l21_slices, int32_t proj_kind);
+/* prox!(::TVRegularization) inside the plan (src/FISTA.jl:164 -> src/proximalMaps/ProxTV.jl:64-125; shape / dims (0-based) /
+ * iterations_tv as rls_prox_tv_fgp): the FGP loop is ONE single-workgroup launch between the two halves of the update, skipped
+ * once the plan is done.  RLS_E_UNSUPPORTED when the image does not fit that kernel (1-D / 2-D images up to 8192 Float32 or 4096
+ * ComplexF32 pixels, other geometries up to 2048) or on a batched plan -- the host then drives FISTA from the primitives.
+ * The plan runs on the two-product path; row-sharded plans (rls_fista_step_local_b, rls_fista_step_rowsharded) take the same
+ * launches behind their all-reduce.  proj_kind: the Positive / Real projection applied after the prox (:166-168). */
+int32_t rls_fista_set_reg_tv(rls_fista* s, float lambda, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims,
+                             int32_t iterations_tv, int32_t proj_kind);
 int32_t rls_fista_init(rls_fista* s, const void* b, float rho, float theta, float rel_tol, int32_t iterations,
                        int32_t restart_gradient);
 /* optional warm start x0 != 0 (init!(solver, b; x0), src/FISTA.jl:110,120): call right after init.  x_init: n = N

@@ -617,10 +617,14 @@ class FISTA:
 # --------------------------------------------------------------------------------------
 
 
-def cg_inplace(x, Aop: Callable, b, maxiter, reltol, abstol=0.0):
+def cg_inplace(x, Aop: Callable, b, maxiter, reltol, abstol=0.0, Pl=None):
     """Unpreconditioned CG with warm start: u=0; r=b-A x; tol=max(reltol*||r||, abstol); prev=1.
-    Returns number of iterations performed."""
+    Returns number of iterations performed.  Pl (a callable r -> Pl \\ r, the `Pl = solver.precon` keyword of the call site
+    src/ADMM.jl:244): the preconditioned recurrence of the same package (PCGIterable: c = Pl \\ r; rho = <c, r>;
+    u = c + (rho / rho_prev) u; c = A u; alpha = rho / <u, c>), the stopping test still on ||r||."""
     T = _rt(x)
+    if Pl is not None:
+        return _pcg_inplace(x, Aop, b, maxiter, reltol, abstol, Pl)
     u = np.zeros_like(x)
     r = b.copy()
     c = Aop(x)
@@ -637,6 +641,30 @@ def cg_inplace(x, Aop: Callable, b, maxiter, reltol, abstol=0.0):
         x += alpha * u
         r -= alpha * c
         prev = residual
+        residual = T(nrm2(r))
+        it += 1
+    return it
+
+
+def _pcg_inplace(x, Aop, b, maxiter, reltol, abstol, Pl):
+    T = _rt(x)
+    u = np.zeros_like(x)
+    r = b.copy()
+    r -= Aop(x)
+    residual = T(nrm2(r))
+    tol = max(T(reltol) * residual, T(abstol))
+    rho = x.dtype.type(1)
+    it = 0
+    while it < maxiter and residual > tol:
+        c = np.asarray(Pl(r), dtype=x.dtype)
+        rho_prev = rho
+        rho = x.dtype.type(dotc(c, r))
+        beta = rho / rho_prev
+        u[:] = c + beta * u
+        c = Aop(u)
+        alpha = x.dtype.type(rho / dotc(u, c))
+        x += alpha * u
+        r -= alpha * c
         residual = T(nrm2(r))
         it += 1
     return it
@@ -679,9 +707,10 @@ class ADMM:
     """src/ADMM.jl:80-162 (ctor), :191-220 (init!), :230-322 (iterate), :324-332 (converged/done)."""
 
     def __init__(self, A, AHA=None, reg=None, regTrafo=None, rho=1e-1, vary_rho="none", iterations=10,
-                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree", normalizeReg="none"):
+                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree", normalizeReg="none", precon=None):
         self.A = A if (A is None or hasattr(A, "mul")) else DenseOp(A)
         self.normalizeReg = normalizeReg
+        self.precon = precon  # callable r -> Pl \\ r, or None = Identity() (src/ADMM.jl:82)
         if AHA is None:
             AHA = NormalOp(self.A) if normal == "matrixfree" else GramOp(self.A.A)
         elif not hasattr(AHA, "mul"):
@@ -780,7 +809,7 @@ class ADMM:
             self.beta += self.rho[i] * t.mul_adj(self.z[i])
             self.beta += (-self.rho[i]) * t.mul_adj(self.u[i])
         self.xold[:] = self.x
-        self.cg_iters.append(cg_inplace(self.x, self.composite_mul, self.beta, self.iterationsCG, self.tolInner))
+        self.cg_iters.append(cg_inplace(self.x, self.composite_mul, self.beta, self.iterationsCG, self.tolInner, Pl=self.precon))
         for pr in self.proj:
             pr.prox(self.x)
         for i, t in enumerate(self.regTrafo):
@@ -1098,10 +1127,10 @@ class SplitBregman(ADMM):
     the right-hand side every iterationsInner inner iterations."""
 
     def __init__(self, A, AHA=None, reg=None, regTrafo=None, rho=1e-1, iterations=10, iterationsInner=10,
-                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree", normalizeReg="none"):
+                 iterationsCG=10, absTol=None, relTol=None, tolInner=1e-5, normal="matrixfree", normalizeReg="none", precon=None):
         super().__init__(A, AHA=AHA, reg=reg, regTrafo=regTrafo, rho=rho, iterations=iterations,
                          iterationsCG=iterationsCG, absTol=absTol, relTol=relTol, tolInner=tolInner, normal=normal,
-                         normalizeReg=normalizeReg)
+                         normalizeReg=normalizeReg, precon=precon)
         self.iterationsInner = int(iterationsInner)
         self.ybreg = np.zeros_like(self.x)
 
@@ -1122,7 +1151,7 @@ class SplitBregman(ADMM):
         for i, t in enumerate(self.regTrafo):
             self.beta += self.rho[i] * t.mul_adj(self.z[i])
             self.beta += (-self.rho[i]) * t.mul_adj(self.u[i])
-        self.cg_iters.append(cg_inplace(self.x, self.composite_mul, self.beta, self.iterationsCG, self.tolInner))
+        self.cg_iters.append(cg_inplace(self.x, self.composite_mul, self.beta, self.iterationsCG, self.tolInner, Pl=self.precon))
         for pr in self.proj:
             pr.prox(self.x)
         for i, t in enumerate(self.regTrafo):

@@ -20,7 +20,7 @@ from .regularization import (AbstractParameterizedRegularization, AbstractProjec
                              IdentityTransform, MaskedRegularization, MinMaxTransform, PlugAndPlayRegularization,
                              PnPRegularization, ProjectionRegularization, TransformedRegularization, ZTransform,
                              findfirst, findsink, findsinks, is_projection, sink, sinktype)
-from .solvers import (ADMM, CGNR, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractKrylovSolver,
+from .solvers import (ADMM, CGNR, DiagonalPreconditioner, FISTA, POGM, Kaczmarz, KaczmarzState, OptISTA, SplitBregman, AbstractKrylovSolver,
                       AbstractPrimalDualSolver, AbstractProximalGradientSolver, AbstractRowActionSolver,
                       applicableSolverList, isapplicable, AbstractLinearSolver, AdmmBatchedState, BatchedState, FistaBatchedState, CompareSolutionCallback, MultiThreadingState,  # noqa: F401
                       SequentialState, StoreConvergenceCallback, StoreSolutionCallback, createLinearSolver, init_,

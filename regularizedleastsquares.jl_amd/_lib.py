@@ -149,6 +149,7 @@ PROTOTYPES = {
     "rls_fista_create": (_i32, [_vp, _vp, _vp, _vp, _vp, _pvp]),
     "rls_fista_destroy": (_i32, [_vp]),
     "rls_fista_set_reg": (_i32, [_vp, _i32, _f, _i64, _i32]),
+    "rls_fista_set_reg_tv": (_i32, [_vp, _f, _i32, C.POINTER(C.c_int64), _i32, C.POINTER(C.c_int32), _i32, _i32]),
     "rls_fista_init": (_i32, [_vp, _vp, _f, _f, _f, _i32, _i32]),
     "rls_fista_set_start": (_i32, [_vp, _vp, C.c_int64]),
     "rls_fista_step": (_i32, [_vp, _i32]),

@@ -652,6 +652,13 @@ struct rls_fista {
   float* fk_yx = nullptr;
   void* fk_xx = nullptr;
   double* fk_dots = nullptr;
+  // TV regulariser (rls_fista_set_reg_tv): the FGP launch sits BETWEEN the two halves of the update (src/FISTA.jl:164), reading the
+  // gradient step from tv_in and leaving prox_TV of it in tv_out (plan scratch: no pointer depends on the iteration's parity)
+  int tv_ndims = 0, tv_ntv = 0, tv_iters = 10;
+  int64_t tv_shape[4] = {1, 1, 1, 1};
+  int32_t tv_dims[4] = {0, 0, 0, 0};
+  void *tv_in = nullptr, *tv_out = nullptr;
+  float rho_h = 0.f;  // rho of the last init (the prox threshold rho * lambda is a launch argument of the FGP kernel)
 };
 
 // batched launches: workgroup b = column b.  Vpart non-null: AHA y arrives as `S` partial rows per column and is
@@ -732,11 +739,14 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_init_kernel(E* __restrict__
 
 // everything of src/FISTA.jl:153-180 after res = AHA y, plus the NEXT iteration's momentum step
 // (:144-148) so that one iteration is GEMV, GEMV, this kernel.
+// `phase` splits it around a prox that is a launch of its own (TV: the FGP kernel): 0 = everything; 1 = res, the gradient step
+// into tv_in (not into x) and the residual norm; 2 = x = proj(tv_out), then the restart test, theta, `done` and the next y.
 template <typename E>
 __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict__ b0, E* __restrict__ b1,
                                                                    const E* __restrict__ x0, E* __restrict__ res,
                                                                    E* __restrict__ y, int64_t n, fista_scalars* sc,
-                                                                   fista_batch<E> Bt) {
+                                                                   fista_batch<E> Bt, int phase = 0, E* __restrict__ tv_in = nullptr,
+                                                                   const E* __restrict__ tv_out = nullptr) {
   const int b = blockIdx.x;
   b0 += b * Bt.ldv;
   b1 += b * Bt.ldv;
@@ -754,13 +764,22 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
   const int reg_kind = sc->reg_kind, proj_kind = sc->proj_kind;
   const float thr = rho * sc->lambda;  // prox!(reg, x, rho * lambda(reg))             :164
   double rn = 0.0;
+  if (phase == 2) {  // the prox ran as a launch of its own: x = proj(prox), the residual norm is phase 1's
+    for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) xnew[i] = fista_proj_elem<E>(tv_out[i], proj_kind);
+    __syncthreads();
+  } else {
   for (int64_t i = threadIdx.x; i < n; i += UPD_THREADS) {
     const E ri = elem<E>::sub(Bt.Vpart ? fista_parts<E>(Bt, b, n, i) : res[i], x0[i]);  // res .-= x0      :153
     res[i] = ri;
     rn += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
     E xi = elem<E>::sub(y[i], elem<E>::scale(rho, ri));             // x .-= rho .* res :154
+    if (phase == 1) {
+      tv_in[i] = xi;
+      continue;
+    }
     if (reg_kind != RLS_REG_L21) xi = fista_proj_elem<E>(fista_prox_elem<E>(xi, reg_kind, thr), proj_kind);
     xnew[i] = xi;
+  }
   }
   if (reg_kind == RLS_REG_L21) {  // group soft-threshold needs the whole new x         ProxL21.jl:30-35
     __syncthreads();
@@ -776,6 +795,10 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
     __syncthreads();
   }
   rn = block_sum(rn, sm);
+  if (phase == 1) {
+    if (threadIdx.x == 0) sc->res_norm = sqrt(rn);
+    return;
+  }
   float theta = sc->theta;
   if (sc->restart) {  // real(res . (x - xold)) > 0  => theta = 1                       :171-176
     double d = 0.0;
@@ -789,7 +812,7 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_kernel(E* __restrict
   }
   const float theta_old = theta;                                     // :179
   theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;    // :180
-  const double res_norm = sqrt(rn);
+  const double res_norm = phase == 2 ? sc->res_norm : sqrt(rn);
   const float rel = (float)(res_norm / sc->norm_x0);                 // :156
   const int done = (rel < sc->rel_tol) || (it + 1 >= sc->max_iter);  // :187-189
   if (!done) {
@@ -907,7 +930,14 @@ static void fista_launch_update(rls_fista* s, unsigned nblocks, const fista_batc
 #define RLS_FUPD_REG(EE)                                                                                            \
   hipLaunchKernelGGL((fista_update_reg_kernel<E, EE>), dim3(nblocks), dim3(UPD_THREADS), 0, op->ctx->stream,        \
                      (E*)s->buf[0], (E*)s->buf[1], (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt)
-  if (s->reg_kind != RLS_REG_L21 && n <= 4 * UPD_THREADS) {
+  if (s->reg_kind == RLS_REG_TV) {  // gradient step | FGP launch (its own workgroup, skipped once `done`) | projection, theta, y
+    hipLaunchKernelGGL(fista_update_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->buf[0], (E*)s->buf[1],
+                       (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt, 1, (E*)s->tv_in, (const E*)s->tv_out);
+    (void)rls_tv_single_launch(op->ctx, op->dtype, s->tv_ndims, s->tv_shape, s->tv_ntv, s->tv_dims, s->tv_in, nullptr, s->tv_out,
+                               s->rho_h * s->lambda, s->tv_iters, &s->sc->done, 1, 0, 0);
+    hipLaunchKernelGGL(fista_update_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->buf[0], (E*)s->buf[1],
+                       (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt, 2, (E*)s->tv_in, (const E*)s->tv_out);
+  } else if (s->reg_kind != RLS_REG_L21 && n <= 4 * UPD_THREADS) {
     if (n <= UPD_THREADS) RLS_FUPD_REG(1);
     else if (n <= 2 * UPD_THREADS) RLS_FUPD_REG(2);
     else RLS_FUPD_REG(4);
@@ -2978,6 +3008,8 @@ int32_t rls_fista_destroy(rls_fista* s) {
   if (s->fk_yx) dfree(s->fk_yx);
   if (s->fk_xx) dfree(s->fk_xx);
   if (s->fk_dots) dfree(s->fk_dots);
+  if (s->tv_in) dfree(s->tv_in);
+  if (s->tv_out) dfree(s->tv_out);
   dfree(s->sc);
   hfree(s->sc_h);
   delete s;
@@ -2997,6 +3029,45 @@ int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t 
   s->proj_kind = proj_kind;
   s->lambda = lambda;
   s->l21_slices = l21_slices > 0 ? l21_slices : 1;
+  return 0;
+}
+
+// FISTA with prox!(::TVRegularization) (src/FISTA.jl:164 -> src/proximalMaps/ProxTV.jl:64-125): the FGP loop is one
+// single-workgroup launch between the two halves of the update, for images that fit one workgroup (rls_tv_single_ok: 1-D / 2-D
+// images of up to 8192 Float32 / 4096 ComplexF32 pixels, other geometries up to 2048); single right-hand side.  The plan then
+// runs on the two-product path (operator apply, update half, FGP, update half); row-sharded plans (rls_fista_step_local_b,
+// rls_fista_step_rowsharded) take the same three launches behind their all-reduce.
+int32_t rls_fista_set_reg_tv(rls_fista* s, float lambda, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims,
+                             int32_t iterations_tv, int32_t proj_kind) {
+  if (!s) return RLS_E_INVALID;
+  rls_ctx* ctx = s->op->ctx;
+  if (proj_kind < RLS_PROJ_NONE || proj_kind > RLS_PROJ_POSITIVE || iterations_tv < 0 || ndims < 1 || ndims > 4 || ntv < 0 || ntv > 4 ||
+      !shape || (ntv > 0 && !dims))
+    return rls_fail(ctx, RLS_E_INVALID, "fista_set_reg_tv: bad argument");
+  int64_t n = 1;
+  for (int k = 0; k < ndims; ++k) n *= shape[k];
+  if (n != s->op->N) return rls_fail(ctx, RLS_E_INVALID, "fista_set_reg_tv: prod(shape) != N");
+  if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista_set_reg_tv: single right-hand side plans only");
+  if (!rls_tv_single_ok(s->op->dtype, ndims, shape, ntv, dims))
+    return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista_set_reg_tv: the image does not fit the single-workgroup FGP kernel; drive FISTA from the primitives");
+  RLS_HIP(ctx, rls_enter(ctx));
+  if (!s->tv_in) {
+    rls_alloc_scope alloc_scope(ctx);
+    const size_t bytes = (size_t)s->op->N * rls_elem_size(s->op->dtype);
+    RLS_HIP(ctx, dmalloc(&s->tv_in, bytes));
+    RLS_HIP(ctx, dmalloc(&s->tv_out, bytes));
+  }
+  s->tv_ndims = ndims;
+  s->tv_ntv = ntv;
+  for (int k = 0; k < 4; ++k) {
+    s->tv_shape[k] = k < ndims ? shape[k] : 1;
+    s->tv_dims[k] = k < ntv ? dims[k] : 0;
+  }
+  s->tv_iters = iterations_tv;
+  s->reg_kind = RLS_REG_TV;
+  s->proj_kind = proj_kind;
+  s->lambda = lambda;
+  s->l21_slices = 1;
   return 0;
 }
 
@@ -3035,6 +3106,7 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
   s->enq = 0;
   s->requested = 0;
   s->theta0 = theta;
+  s->rho_h = rho;
   s->srv.off = false;  // (a new solve: the caller's pattern between iterates is judged afresh)
   s->srv.short_lives = 0;
   s->initialised = true;

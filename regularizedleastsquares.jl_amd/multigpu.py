@@ -28,7 +28,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, AdmmStatus, CgnrStatus, CgStatus,
+from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, REG_TV, AdmmStatus, CgnrStatus, CgStatus,
                    FistaStatus, check)
 from .arrays import Context
 
@@ -421,14 +421,14 @@ class CommRowShardedFISTA(_CommHost):
                  relTol=float(np.finfo(np.float32).eps), restart="none", threads=True):
         super().__init__(rls, shards, ("x", "x0", "xold", "res"), devices, transport, threads)
         self.rho, self.theta, self.iterations, self.relTol, self.restart = float(rho), float(theta), int(iterations), float(relTol), restart
-        kind, lam, slices, pk = _reg_codes(rls, reg, proj)  # proj: one projection term or None
+        _reg_codes(rls, reg, proj)  # (validates; proj: one projection term or None)
         for r in range(self.n):
             v, h = self.v[r], self.ctxs[r].handle
             plan = C.c_void_p()
             check(h, self.lib.rls_fista_create(self.ops[r].handle, v["x"].ptr, v["x0"].ptr, v["xold"].ptr, v["res"].ptr, C.byref(plan)),
                   "rls_fista_create")
-            check(h, self.lib.rls_fista_set_reg(plan, kind, lam, slices, pk), "rls_fista_set_reg")
             self.plans.append(plan)
+            _fista_plan_set_reg(rls, self.lib, h, plan, reg, proj)
         self._plans_c = (C.c_void_p * self.n)(*[p.value for p in self.plans])
 
     def init(self, b_parts):
@@ -562,12 +562,34 @@ def _reg_codes(rls, reg, proj):
         kind, lam, slices = REG_L2, reg.lam, 1
     elif type(reg) is rls.L21Regularization:
         kind, lam, slices = REG_L21, reg.lam, reg.slices
+    elif type(reg) is rls.TVRegularization:
+        kind, lam, slices = REG_TV, reg.lam, 1   # rls_fista_set_reg_tv (the FGP launch of the replicated update half)
     else:
-        raise NotImplementedError("row-sharded FISTA: L1 / L2 / L21 regularisation")
+        raise NotImplementedError("row-sharded FISTA: L1 / L2 / L21 / TV regularisation")
     pk = PROJ_NONE
     if proj is not None:
-        pk = PROJ_POSITIVE if isinstance(proj, rls.PositiveRegularization) else PROJ_REAL
+        if isinstance(proj, rls.PositiveRegularization):
+            pk = PROJ_POSITIVE
+        elif isinstance(proj, rls.RealRegularization):
+            pk = PROJ_REAL
+        else:
+            raise NotImplementedError("row-sharded FISTA: Positive / Real projections")
     return kind, float(lam), int(slices), pk
+
+
+def _fista_plan_set_reg(rls, lib, h, plan, reg, proj):
+    """rls_fista_set_reg / rls_fista_set_reg_tv for one rank's plan (src/FISTA.jl:164-168: prox, then the projection)"""
+    kind, lam, slices, pk = _reg_codes(rls, reg, proj)
+    if kind == REG_TV:
+        from .regularization import _tv_geometry
+        shape, d0, cs, cd = _tv_geometry(reg.shape, reg.dims)
+        st = lib.rls_fista_set_reg_tv(plan, lam, len(shape), cs, len(d0), cd, reg.iterationsTV, pk)
+        if st == -2:
+            raise NotImplementedError("row-sharded FISTA + TV: the image does not fit the single-workgroup FGP kernel "
+                                      "(1-D / 2-D up to 8192 Float32 / 4096 ComplexF32 pixels, other geometries up to 2048)")
+        check(h, st, "rls_fista_set_reg_tv")
+    else:
+        check(h, lib.rls_fista_set_reg(plan, kind, lam, slices, pk), "rls_fista_set_reg")
 
 
 class HipFistaOps:
@@ -587,8 +609,7 @@ class HipFistaOps:
         check(h, lib.rls_fista_create(self.op.handle, self.t["x"].data_ptr(), self.t["x0"].data_ptr(),
                                       self.t["xold"].data_ptr(), self.t["res"].data_ptr(), C.byref(plan)), "rls_fista_create")
         self.plan = plan
-        kind, lam, slices, pk = _reg_codes(rls, reg, proj)
-        check(h, lib.rls_fista_set_reg(plan, kind, lam, slices, pk), "rls_fista_set_reg")
+        _fista_plan_set_reg(rls, lib, h, plan, reg, proj)
         self._b = None
 
     def init_a(self, b_local: np.ndarray):

@@ -424,6 +424,8 @@ class FISTA(AbstractProximalGradientSolver):
             kind, slices = REG_L2, 1
         elif type(r) is L21Regularization:
             kind, slices = REG_L21, r.slices
+        elif type(r) is TVRegularization and not getattr(self, "_tv_unfused", False):
+            kind, slices = REG_TV, 1  # the FGP launch between the two halves of the plan's update (rls_fista_set_reg_tv)
         else:
             return None  # nested / transformed / learned terms: the generic path calls their prox_
         if len(self.proj) > 1:
@@ -464,9 +466,21 @@ class FISTA(AbstractProximalGradientSolver):
                 state._plan = plan
                 state._keep = (self._op, b.ctx)
         state.x, state.xold = state._bufs
+        if fused is not None and fused[0] == REG_TV:
+            from .regularization import _tv_geometry
+            shape, d0, cs, cd = _tv_geometry(self.reg.shape, self.reg.dims)
+            st_tv = lib.rls_fista_set_reg_tv(state._plan, fused[1], len(shape), cs, len(d0), cd, self.reg.iterationsTV, fused[3])
+            if st_tv == -2:  # RLS_E_UNSUPPORTED: the image does not fit the plan's single-workgroup FGP launch -- primitives
+                self._tv_unfused = True
+                lib.rls_fista_destroy(state._plan)
+                state._plan = None
+                fused = None
+            else:
+                check(h, st_tv, "rls_fista_set_reg_tv")
         if fused is not None:
             kind, lam_, slices, pk = fused
-            check(h, lib.rls_fista_set_reg(state._plan, kind, lam_, slices, pk), "rls_fista_set_reg")
+            if kind != REG_TV:
+                check(h, lib.rls_fista_set_reg(state._plan, kind, lam_, slices, pk), "rls_fista_set_reg")
             check(h, lib.rls_fista_init(state._plan, b.ptr, state.rho, float(theta), state.relTol, self.iterations,
                                         1 if self.restart == "gradient" else 0), "rls_fista_init")
             if not (np.ndim(x0) == 0 and not isinstance(x0, DeviceVector) and x0 == 0):
@@ -615,14 +629,31 @@ class ADMMState(AbstractSolverState):
         self._cg = self._admm = None
 
 
+class DiagonalPreconditioner:
+    """a left preconditioner for the inner `cg!` of ADMM / SplitBregman (`precon` keyword, src/ADMM.jl:82,244): Pl \\ r =
+    r ./ d for a diagonal d given as a device vector of the solver's element type (Jacobi scaling: d = diag(AHA) + sum rho).
+    Any object with `ldiv_(out, r)` on device vectors is accepted in its place (the reference takes anything `ldiv!` accepts)."""
+
+    def __init__(self, d: DeviceVector):
+        h = d.to_host()
+        self.dinv = DeviceVector.from_host((1.0 / h).astype(h.dtype), d.ctx)
+
+    def ldiv_(self, out: DeviceVector, r: DeviceVector):
+        lib, h = r.ctx.lib, r.ctx.handle
+        # an N-vector is an N x 1 matrix: diag(dinv) * r through the row-scaling kernel (csrc/setup.hip)
+        check(h, lib.rls_scale_rows(h, r.code, r.n, 1, self.dinv.ptr, r.ptr, r.n, out.ptr, out.n), "rls_scale_rows")
+        return out
+
+
 class ADMM(AbstractPrimalDualSolver):
     """src/ADMM.jl:80-162"""
 
     def __init__(self, A=None, *, AHA=None, precon=None, reg=None, regTrafo=None, normalizeReg=None, rho=1e-1,
                  vary_rho: str = "none", iterations: int = 10, iterationsCG: int = 10, absTol=_EPS32, relTol=_EPS32,
                  tolInner=1e-5, verbose: bool = False):
-        if precon is not None:
-            raise NotImplementedError("only the Identity() preconditioner is supported")
+        if precon is not None and not hasattr(precon, "ldiv_"):
+            raise TypeError("precon: an object with ldiv_(out, r) on device vectors (e.g. DiagonalPreconditioner), or None = Identity()")
+        self.precon = precon  # Pl of the inner cg! (src/ADMM.jl:82,244); None = Identity(): the fused cg! kernels
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         regs = _as_list(reg) or [L1Regularization(0.0)]
@@ -703,7 +734,7 @@ class ADMM(AbstractPrimalDualSolver):
 
     def _plan_params(self, state):
         """rls_admm_params when the whole outer iteration can run on the device, else None"""
-        if type(self) not in (ADMM, SplitBregman) or not self.use_device_plan or not (
+        if type(self) not in (ADMM, SplitBregman) or not self.use_device_plan or self.precon is not None or not (
                 self._all_identity() and len(self.reg) == 1 and self.vary_rho == "none" and not self.verbose):
             return None
         reg, rho = self.reg[0], np.float32(state.rho[0])
@@ -807,6 +838,36 @@ class ADMM(AbstractPrimalDualSolver):
                 t.mul_adj_(out, tmp_list[i], float(state.rho[i]), 1.0)
         return out
 
+    def _cg_precond(self, state):
+        """IterativeSolvers.cg!(x, AHA, b; Pl = precon) from primitives: the preconditioned recurrence (oracle `_pcg_inplace`,
+        pinned iterate by iterate against SciPy's PCG in tests/test_oracle.py): c = Pl \\ r; rho = <c, r>; u = c + (rho / rho_prev) u;
+        c = A u; alpha = rho / <u, c>; the stopping test stays on ||r||"""
+        f32 = np.float32
+        x, b = state.x, state.beta
+        u, r, c = state.cg_u, state.cg_r, state.cg_c
+        tmp = state.zold
+        u.fill_(0)
+        r.copy_from(b)
+        self._composite_mul(state, c, x, tmp)
+        r.axpy_(-1.0, c)
+        residual = f32(r.norm())
+        tol = max(f32(state.tolInner) * residual, f32(0))
+        rho = complex(1.0)
+        it = 0
+        while it < self.iterationsCG and residual > tol:
+            self.precon.ldiv_(c, r)
+            rho_prev, rho = rho, complex(c.dot(r))
+            u.lincomb_(1.0, c, rho / rho_prev if r.dtype.kind == "c" else (rho / rho_prev).real, u)
+            self._composite_mul(state, c, u, tmp)
+            alpha = rho / complex(u.dot(c))
+            if r.dtype.kind != "c":
+                alpha = alpha.real
+            x.axpy_(alpha, u)
+            r.axpy_(-alpha, c)
+            residual = f32(r.norm())
+            it += 1
+        return it
+
     def _cg_generic(self, state):
         """IterativeSolvers.cg! from primitives (non-identity regTrafo); see oracle cg_inplace"""
         f32 = np.float32
@@ -854,7 +915,9 @@ class ADMM(AbstractPrimalDualSolver):
                 t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
                 t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
             state.xold.copy_from(state.x)
-        if self._all_identity():
+        if self.precon is not None:   # cg!(...; Pl = precon)   :244
+            state.cg_iterations.append(self._cg_precond(state))
+        elif self._all_identity():
             rho_sum = float(np.sum(state.rho, dtype=np.float32))
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, rho_sum, self.iterationsCG,
                                       float(state.tolInner)), "rls_cg_solve")
@@ -1571,7 +1634,9 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
             for i, t in enumerate(self.regTrafo):
                 t.mul_adj_(state.beta, state.z[i], float(state.rho[i]), 1.0)
                 t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
-        if self._all_identity():
+        if self.precon is not None:   # cg!(...; Pl = precon)   src/SplitBregman.jl:218
+            self._cg_precond(state)
+        elif self._all_identity():
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, float(np.sum(state.rho, dtype=np.float32)),
                                       self.iterationsCG, float(state.tolInner)), "rls_cg_solve")
             if _cg_is_resident(lib, state._cg):
@@ -2072,7 +2137,8 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
             except _lib.RLSError:
                 pass  # shape not covered by the one-pass kernel: independent per-column plans instead
         if (type(solver) is FISTA and isinstance(b, DeviceMatrix) and b.N > 1 and solver.A is not None
-                and solver._fused_kinds() is not None and not isinstance(solver.normalizeReg, MeasurementBasedNormalization)
+                and solver._fused_kinds() is not None and solver._fused_kinds()[0] != REG_TV
+                and not isinstance(solver.normalizeReg, MeasurementBasedNormalization)
                 and kw_fista_ok):
             try:
                 st = FistaBatchedState(solver, b)
@@ -2088,7 +2154,7 @@ def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
                 return
             except _lib.RLSError:
                 pass  # e.g. M or N not a multiple of 16: independent per-column plans instead
-        if (type(solver) is ADMM and isinstance(b, DeviceMatrix) and b.N > 1 and solver.A is not None and not kw
+        if (type(solver) is ADMM and solver.precon is None and isinstance(b, DeviceMatrix) and b.N > 1 and solver.A is not None and not kw
                 and solver.use_device_plan and solver._all_identity() and len(solver.reg) == 1 and solver.vary_rho == "none"
                 and not isinstance(solver.normalizeReg, (MeasurementBasedNormalization, SystemMatrixBasedNormalization))):
             try:

@@ -215,3 +215,157 @@ def test_bench_multi_gpu_path_rehearsed_on_one_gpu(n):
     assert direct["ranks"] == n and direct["iterations_per_s"] > 0 and np.isfinite(direct["residual"])
     assert direct["peer_probe"]["transport_in_use"] == 2 and direct["peer_probe"]["all_pairs"]
     assert "skipped" in c5["one_process_host"]["rccl"]
+
+
+# ---- FISTA with a TV regulariser inside the plan, single GPU and row-sharded (SURVEY 8e last row) -----------------------------
+@pytest.mark.parametrize("dt,shape,dims,proj", [(np.float32, (16, 16), None, "positive"), (np.complex64, (16, 16), None, "real"),
+                                                (np.float32, (256,), None, None), (np.float32, (8, 8, 4), None, None),
+                                                (np.float32, (16, 16), (2,), None)])
+@pytest.mark.parametrize("restart", ["none", "gradient"])
+def test_fista_tv_inside_the_plan(rls, ctx, dt, shape, dims, proj, restart):
+    """`prox!(reg, x, rho * lambda)` with reg::TVRegularization (src/FISTA.jl:164 -> ProxTV.jl:64-125) followed by the
+    projection (:166-168): the plan runs operator apply | gradient step | ONE FGP launch | projection, restart test, theta, y
+    (rls_fista_set_reg_tv) instead of the primitive-by-primitive sequence; both against the float64 oracle, and each other."""
+    N = int(np.prod(shape))
+    A, xt, b = O.make_problem(3 * N, N, dt, 211)
+    h64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    rho = 0.9 / np.linalg.norm(A.astype(h64), 2) ** 2
+    lam = 0.02 * float(np.max(np.abs(A.astype(h64).conj().T @ b)))
+    regs = lambda R: [R.TVRegularization(lam, shape=shape, dims=dims)] + (
+        [R.PositiveRegularization()] if proj == "positive" else [R.RealRegularization()] if proj == "real" else [])
+    kw = dict(rho=rho, iterations=25, relTol=0.0, restart=restart)
+    x64, x32 = (lambda f: (f(A.astype(h64), b.astype(h64)), lambda: f(A, b)))(lambda A_, b_: np.array(O.solve(O.FISTA(A_, reg=regs(O), **kw), b_)))
+    Ad = rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx)
+    s = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), **kw)
+    x = rls.solve_(s, rls.DeviceVector.from_host(b, ctx)).to_host()
+    assert s.state._plan, "the TV regulariser must run inside the plan for an image that fits one workgroup"
+    assert s.state.iteration == 25
+    parity(f"fista_tv_plan_{np.dtype(dt).name}_{shape}_{dims}_{proj}_{restart}", x, x64, x32)
+    # the primitive-by-primitive sequence (the path of images too large for the FGP launch) must agree
+    s2 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), **kw)
+    s2._tv_unfused = True
+    x2 = rls.solve_(s2, rls.DeviceVector.from_host(b, ctx)).to_host()
+    assert not s2.state._plan
+    assert rel(x2, x) < 5e-6
+    # callbacks cadence through the plan: one iterate at a time gives the same bits as the enqueued solve
+    s3 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), **kw)
+    seen = []
+    x3 = rls.solve_(s3, rls.DeviceVector.from_host(b, ctx), callbacks=[lambda sv, i: seen.append(i)]).to_host()
+    assert seen == list(range(26)) and np.array_equal(x3, x)
+    # early stop: the launches behind `done` (the FGP one included) are no-ops
+    s4 = rls.createLinearSolver(rls.FISTA, Ad, reg=regs(rls), rho=rho, iterations=25, relTol=0.3, restart=restart)
+    x4 = rls.solve_(s4, rls.DeviceVector.from_host(b, ctx)).to_host()
+    o4 = O.FISTA(A.astype(h64), reg=regs(O), rho=rho, iterations=25, relTol=0.3, restart=restart)
+    x4o = np.array(O.solve(o4, b.astype(h64)))
+    assert 0 < o4.iteration < 25 and s4.state.iteration == o4.iteration and rel(x4, x4o) < 1e-5
+
+
+def test_fista_tv_image_too_large_for_the_plan_falls_back(rls, ctx):
+    """a 3-D image of 4096 pixels does not fit the single-workgroup FGP kernel: rls_fista_set_reg_tv refuses and the solver runs
+    from the primitives (same result as the oracle)"""
+    shape = (16, 16, 16)
+    N = 4096
+    A, xt, b = O.make_problem(N + 512, N, np.float32, 5)
+    rho = 0.9 / np.linalg.norm(A.astype(np.float64), 2) ** 2
+    lam = 0.02 * float(np.max(np.abs(A.astype(np.float64).T @ b)))
+    s = rls.createLinearSolver(rls.FISTA, rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx), reg=rls.TVRegularization(lam, shape=shape),
+                               rho=rho, iterations=6, relTol=0.0)
+    x = rls.solve_(s, rls.DeviceVector.from_host(b, ctx)).to_host()
+    assert not s.state._plan and s._tv_unfused
+    x64 = np.array(O.solve(O.FISTA(A.astype(np.float64), reg=O.TVRegularization(lam, shape=shape), rho=rho, iterations=6, relTol=0.0), b.astype(np.float64)))
+    parity("fista_tv_unfused_16x16x16", x, x64, lambda: np.array(O.solve(O.FISTA(A, reg=O.TVRegularization(lam, shape=shape), rho=rho, iterations=6, relTol=0.0), b)))
+
+
+@pytest.mark.parametrize("nshards,proj", [(2, "positive"), (8, None)])
+def test_rowsharded_fista_tv_through_the_library_communicator(rls, ctx, nshards, proj):
+    """the config-5 pattern for FISTA with TV + Positive (SURVEY 8e last row; src/FISTA.jl:114,152,164-168): the operator apply is
+    the only distributed step, the gradient step, the FGP launch and the projection are replicated on every rank"""
+    from test_gpu_parity import _row_cuts
+
+    shape, N = (32, 16), 512
+    M = 1536 + 64 * nshards
+    A, xt, b = O.make_problem(M, N, np.float32, 139)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    rho = 0.95 / np.linalg.norm(A64, 2) ** 2
+    lam = 2e-2 * float(np.max(np.abs(A64.T @ b64)))
+    cuts = _row_cuts(M, nshards)
+    shards = [np.asfortranarray(A[cuts[k]:cuts[k + 1]]) for k in range(nshards)]
+    parts = [b[cuts[k]:cuts[k + 1]] for k in range(nshards)]
+    regs = lambda R: [R.TVRegularization(lam, shape=shape)] + ([R.PositiveRegularization()] if proj else [])
+    s = rls.CommRowShardedFISTA(rls, shards, reg=rls.TVRegularization(lam, shape=shape), proj=rls.PositiveRegularization() if proj else None,
+                                transport=2, rho=rho, iterations=20, restart="gradient")
+    try:
+        x = s.solve(parts)
+        xs = [s.solution(r) for r in range(nshards)]
+        assert all(np.array_equal(xs[0], xr) for xr in xs[1:])   # replicated state: the same bits on every rank
+        ref = O.FISTA(A64, reg=regs(O), rho=rho, iterations=20, restart="gradient")
+        x64 = np.array(O.solve(ref, b64))
+        assert all(s.status(r)["iteration"] == ref.iteration for r in range(nshards))
+        parity(f"rowsharded_fista_tv_comm_{nshards}_shards", x, x64,
+               lambda: np.array(O.solve(O.FISTA(A, reg=regs(O), rho=rho, iterations=20, restart="gradient"), b)))
+    finally:
+        s.close()
+    with pytest.raises(NotImplementedError, match="does not fit"):
+        rls.CommRowShardedFISTA(rls, [np.asfortranarray(np.zeros((64, 4096), np.float32))] * 2, reg=rls.TVRegularization(0.1, shape=(16, 16, 16)),
+                                transport=2)
+
+
+def test_row_sharded_fista_tv_two_shards_torch_ops(rls, ctx):
+    """the same through the one-process-per-GPU host's local ops (HipFistaOps: torch tensors, the collective stood in for)"""
+    import torch
+    from test_gpu_parity import _TwoShards
+
+    shape, N, M = (16, 16), 256, 768
+    A, xt, b = O.make_problem(M, N, np.complex64, 23)
+    rho = 0.9 / np.linalg.norm(A.astype(np.complex128), 2) ** 2
+    lam = 0.05 * float(np.max(np.abs(A.conj().T @ b)))
+    dev = torch.cuda.current_device()
+    lo = 388
+    mk = lambda rows: rls.multigpu.HipFistaOps(rls, np.asfortranarray(A[rows]), dev, reg=rls.TVRegularization(lam, shape=shape),
+                                               proj=rls.RealRegularization())
+    pair = _TwoShards(mk(slice(0, lo)), mk(slice(lo, M)))
+    f = rls.RowShardedFISTA(pair, _TwoShards.Dist, rho=rho, iterations=20, relTol=0.0)
+    f.init((b[:lo], b[lo:]))
+    f.step(20)
+    xs = [s.solution() for s in pair.shards]
+    assert np.array_equal(xs[0], xs[1])
+    regs = [O.TVRegularization(lam, shape=shape), O.RealRegularization()]
+    x64 = np.array(O.solve(O.FISTA(A.astype(np.complex128), reg=regs, rho=rho, iterations=20, relTol=0.0), b.astype(np.complex128)))
+    parity("fista_tv_rowsharded_2shards_torch_ops", xs[0], x64, lambda: np.array(O.solve(O.FISTA(A, reg=regs, rho=rho, iterations=20, relTol=0.0), b)))
+    for s in pair.shards:
+        s.close()
+
+
+@pytest.mark.parametrize("solver", ["ADMM", "SplitBregman"])
+@pytest.mark.parametrize("dt", [np.complex64, np.float32])
+def test_admm_inner_cg_with_a_preconditioner(rls, ctx, solver, dt):
+    """the `precon` keyword (src/ADMM.jl:82, src/SplitBregman.jl:84) reaches the inner cg! as `Pl` (:244 / :218): a Jacobi
+    preconditioner on a column-scaled operator, against the oracle's preconditioned cg! (pinned to SciPy's PCG on the CPU) --
+    iterates, inner iteration counts -- and it must beat the unpreconditioned solve at the same iteration budget"""
+    M, N = 512, 192
+    A, xt, b = O.make_problem(M, N, dt, 71)
+    h64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    scale = (10.0 ** np.random.default_rng(3).uniform(-1, 1, N)).astype(np.float32)
+    A = np.asfortranarray(A * scale[None, :]).astype(dt)
+    b = (A.astype(h64) @ (xt / scale)).astype(dt)
+    rho = 0.05
+    d = (np.sum(np.abs(A.astype(h64)) ** 2, axis=0) + rho).astype(np.float64)   # diag(A'A) + rho
+    kw = dict(rho=rho, iterations=6, iterationsCG=6, tolInner=1e-6, absTol=0.0, relTol=0.0)
+    extra = dict(iterationsInner=3) if solver == "SplitBregman" else {}
+    kw["iterations"] = 2 if solver == "SplitBregman" else 6
+    ref = getattr(O, solver)(A.astype(h64), reg=O.L1Regularization(1e-3), precon=lambda r: r / d, **kw, **extra)
+    x64 = np.array(O.solve(ref, b.astype(h64)))
+    Ad = rls.DeviceMatrix.from_host(A, ctx)
+    pre = rls.DiagonalPreconditioner(rls.DeviceVector.from_host(d.astype(dt), ctx))
+    s = rls.createLinearSolver(getattr(rls, solver), Ad, reg=rls.L1Regularization(1e-3), precon=pre, **kw, **extra)
+    x = rls.solve_(s, rls.DeviceVector.from_host(b, ctx)).to_host()
+    parity(f"{solver}_precon_{np.dtype(dt).name}", x, x64,
+           lambda: np.array(O.solve(getattr(O, solver)(A, reg=O.L1Regularization(1e-3), precon=lambda r: (r / d).astype(dt), **kw, **extra), b)))
+    if solver == "ADMM":
+        assert list(s.state.cg_iterations) == list(ref.cg_iters)
+    plain = rls.createLinearSolver(getattr(rls, solver), Ad, reg=rls.L1Regularization(1e-3), **kw, **extra)
+    xp = rls.solve_(plain, rls.DeviceVector.from_host(b, ctx)).to_host()
+    want = xt / scale
+    assert rel(x, want) < 0.7 * rel(xp, want)
+    with pytest.raises(TypeError, match="ldiv_"):
+        rls.createLinearSolver(rls.ADMM, Ad, precon=object())

@@ -137,10 +137,10 @@ def test_row_sharded_single_rank_equals_plain_cgnr():
 class OracleFistaOps:
     """half-steps of src/FISTA.jl:139-185 in float64 (mirrors rls_fista_*_local_a/b)"""
 
-    def __init__(self, A_local, reg):
+    def __init__(self, A_local, reg, proj=()):
         import torch
 
-        self.A, self.reg = np.asarray(A_local), reg
+        self.A, self.reg, self.proj = np.asarray(A_local), reg, tuple(proj)
         n = self.A.shape[1]
         self.t = {k: torch.zeros(n, dtype=torch.complex128) for k in ("x", "x0", "xold", "res", "y")}
 
@@ -177,6 +177,8 @@ class OracleFistaOps:
         xn = y - self.rho * res
         self.rel_res_norm = np.linalg.norm(res) / self.norm_x0
         self.reg.prox(xn, self.rho * self.reg.lam)
+        for pr in self.proj:   # src/FISTA.jl:166-168: the projections follow the prox
+            pr.prox(xn)
         if self.restart and np.real(np.vdot(res, xn - x)) > 0:
             self.theta = 1.0
         self.theta_old = self.theta
@@ -293,6 +295,14 @@ def _worker_fista_admm(rank, world, port, q):
         ref = O.FISTA(A, reg=O.L1Regularization(0.3), rho=rho, iterations=15, relTol=0.0, restart="gradient")
         O.solve(ref, b)
         err_f = float(np.linalg.norm(xf - ref.x) / np.linalg.norm(ref.x))
+        # TV + Positive (SURVEY 8e last row; src/FISTA.jl:164-168): prox and projection are replicated, only A^H A y is summed
+        tv = lambda: O.TVRegularization(0.2, shape=(5, 4))
+        ft = rls.RowShardedFISTA(OracleFistaOps(A[lo:hi], tv(), proj=[O.PositiveRegularization()]), dist, rho=rho, iterations=15,
+                                 relTol=0.0)
+        xt_ = ft.solve(b[lo:hi])
+        reft = O.FISTA(A, reg=[tv(), O.PositiveRegularization()], rho=rho, iterations=15, relTol=0.0)
+        O.solve(reft, b)
+        err_f = max(err_f, float(np.linalg.norm(xt_ - reft.x) / np.linalg.norm(reft.x)))
         kw = dict(rho=0.4, iterations=8, iterationsCG=5, tolInner=1e-3)
         a = rls.RowShardedADMM(OracleAdmmOps(A[lo:hi], O.L1Regularization(0.2)), dist, lam=0.2, **kw)
         xa = a.solve(b[lo:hi], M)
@@ -362,7 +372,7 @@ def test_rehearsal_proxy_over_gloo_two_ranks():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    port = 33500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_staged_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -552,3 +552,34 @@ def test_tv_prox_duality_gap():
         assert gap < gap10 < 0.2, (shape, dims, gap10)
         # a wrong lambda in the primal update would be optimal for another lambda: the certificate must reject that
         assert tv_duality_gap(x, O.prox_tv_fgp(x.copy(), 2 * lam, shape, dims, 4000), lam, D)[0] > 1e-3
+
+
+def test_preconditioned_cg_iterates_equal_an_independent_pcg():
+    """`cg!(...; Pl = solver.precon)` (call site src/ADMM.jl:244; IterativeSolvers is third-party and not in the tree): the
+    preconditioned restatement against SciPy's conjugate-gradient code with M = the same preconditioner, iterate by iterate,
+    with a warm start; and Pl = identity reproduces the unpreconditioned recurrence"""
+    from scipy.sparse.linalg import cg as scipy_cg, LinearOperator
+    rng = np.random.default_rng(8)
+    n = 40
+    B = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    d = 10.0 ** rng.uniform(-1.5, 1.5, n)
+    Aop = (B.conj().T @ B) * np.sqrt(d)[:, None] * np.sqrt(d)[None, :] + np.diag(d)   # badly scaled, Hermitian positive definite
+    dinv = 1.0 / np.real(np.diag(Aop))
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    x0 = 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    lin = lambda f: LinearOperator((n, n), matvec=f, dtype=np.complex128)
+    for k in (1, 2, 5, 9):
+        x = x0.copy()
+        assert O.cg_inplace(x, lambda v: Aop @ v, b, maxiter=k, reltol=0.0, Pl=lambda r: dinv * r) == k
+        xs, _ = scipy_cg(lin(lambda v: Aop @ v), b, x0=x0.copy(), maxiter=k, rtol=0.0, atol=0.0, M=lin(lambda r: dinv * r))
+        assert rel(x, xs) < 1e-9, k
+        x1, x2 = x0.copy(), x0.copy()
+        O.cg_inplace(x1, lambda v: Aop @ v, b, maxiter=k, reltol=0.0, Pl=lambda r: r.copy())
+        O.cg_inplace(x2, lambda v: Aop @ v, b, maxiter=k, reltol=0.0)
+        assert rel(x1, x2) < 1e-12
+    # the point of it: Jacobi scaling converges where plain CG has not, at the same iteration count
+    xp, xu = np.zeros(n, complex), np.zeros(n, complex)
+    O.cg_inplace(xp, lambda v: Aop @ v, b, maxiter=25, reltol=0.0, Pl=lambda r: dinv * r)
+    O.cg_inplace(xu, lambda v: Aop @ v, b, maxiter=25, reltol=0.0)
+    xt = np.linalg.solve(Aop, b)
+    assert rel(xp, xt) < 0.2 * rel(xu, xt)
