@@ -746,6 +746,13 @@ def main():
 
     import torch  # plumbing: device selection, barrier, max-over-ranks
 
+    t_start = time.perf_counter()
+
+    def trace(what):
+        """RLS_BENCH_TRACE=1: stage marks on stderr (rank, seconds since start) -- where a multi-rank run spends its time"""
+        if os.environ.get("RLS_BENCH_TRACE"):
+            print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - t_start:7.2f}s] {what}", file=sys.stderr, flush=True)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -766,6 +773,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    trace("process group up")
     import rls_amd as rls
 
     ctx = rls.Context(device)
@@ -803,6 +811,12 @@ def main():
     def timed_regions(prepare, run, est_s):
         """the contract's timed region -- barrier + synchronize, EXACTLY K steps, synchronize + barrier -- repeated
         when it is short.  Returns wall-clock seconds (max over ranks) and hipEvent seconds of every repetition."""
+        if dist is not None:
+            # every rank must run the SAME number of repetitions (each one holds a barrier and an all-reduce): the estimate is a
+            # per-rank measurement, so agree on the largest (found by the one-GPU rehearsal: rank 0 waited for ever)
+            tt = torch.tensor([est_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            est_s = float(tt.item())
         reps = 5 if est_s >= 0.010 else int(min(400, max(50, math.ceil(0.4 / max(est_s, 1e-5)))))
         walls, evs = [], []
         for _ in range(reps):
@@ -969,6 +983,7 @@ def main():
             rls._lib.check(h, lib.rls_cgnr_step(st._plan, m), "rls_cgnr_step")
             n -= m
 
+    trace("headline: operator uploaded, solver initialised")
     # setup (untimed, not part of W): the first LONG host wait of a process returns ~50 ms late, once
     # (tools/stall_probe2.py); take that hit here, outside the measurement.
     step(150 * SEGMENT)
@@ -977,15 +992,18 @@ def main():
     ctx.sync()
     t0 = time.perf_counter(); rls.init_(solver, bd); step(min(K, 4 * SEGMENT), True); ctx.sync()
     est = (time.perf_counter() - t0) * K / min(K, 4 * SEGMENT)
+    trace("headline: warm-up done")
     walls, evs = timed_regions(lambda: rls.init_(solver, bd), lambda: step(K, True), est)
+    trace("headline: timed regions done")
     elapsed, ev = statistics.median(walls), statistics.median(evs)
     st._refresh(lib)
     assert st.iteration == ((K - 1) % SEGMENT) + 1, (st.iteration, K)
     assert math.isfinite(st._residual), "CGNR residual is not finite"
     # the line proves its own work: the x the timed region left behind (st.iteration iterations into its last solve) against a
     # float64 CGNR of the same count on the host, and against the planted solution (CG converges geometrically on this matrix)
+    sol_iter = int(st.iteration)
     x_dev = st.x.to_host().astype(np.complex128)
-    x_f64 = float64_cgnr(A, b, st.iteration)
+    x_f64 = float64_cgnr(A, b, sol_iter)
     sol_err = float(np.linalg.norm(x_dev - x_f64) / np.linalg.norm(x_f64))
     sol_err_true = float(np.linalg.norm(x_dev - x_true) / np.linalg.norm(x_true))
     assert sol_err <= 1e-5, f"the timed kernel's solution is off the float64 CGNR iterate by {sol_err:.3e} (> 1e-5)"
@@ -1104,7 +1122,9 @@ def main():
                                       "reduce_kernel_us_back_to_back": us_r.value})
         except Exception as e:  # noqa: BLE001 -- beside the headline, must not cost the line
             hbm_streaming = {"error": repr(e)}
+    trace("headline: solution checked, kernel timed")
     n1_value = solo_rate(lambda: rls.init_(solver, bd), lambda: step(K, True), K)
+    trace("headline: solo rate done")
     c4 = None
     if world > 1:
         # BASELINE configs[3], shared-A flavour, on the same job: 8 right-hand sides per GPU advancing together (matrix cores)
@@ -1121,12 +1141,14 @@ def main():
             c4["gram_mode"]["roofline"] = {k: g4["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
         except Exception as e:  # noqa: BLE001 -- an extra block must not lose the line
             c4["gram_mode"] = {"error": repr(e)}
+    trace("config 4 legs done")
     c5 = None
     if world > 1:
         # BASELINE configs[4] on the same job: the 65536 x 8192 problem row-partitioned over the ranks, one all-reduce of
         # A^H t per iteration through torch.distributed (RCCL); then the one-process host of the same problem -- rank 0 alone
         # driving every GPU through the library's own communicator (the Julia host's call sequence) -- while the others wait
         c5 = config5_leg(rls, ctx, dist, rank, world, barrier, rows=args.c5_rows, rehearse=args.rehearse)
+    trace("config 5 legs done")
     traffic, traffic_src = load_pmc(dom)
     kd = kern[dom]
     hbm_bytes = traffic if traffic is not None else kd["min_hbm_bytes_per_launch"]
@@ -1157,7 +1179,7 @@ def main():
                              "value_is": "n_gpus * steps / median(wall); every repetition is exactly `steps` iterations between "
                                          "barrier + synchronize on both sides",
                              "iterations_per_s_hip_events": K / ev},
-            "solution_check": {"rel_err_vs_float64_cgnr_same_iteration": sol_err, "tolerance": 1e-5, "iteration": st.iteration,
+            "solution_check": {"rel_err_vs_float64_cgnr_same_iteration": sol_err, "tolerance": 1e-5, "iteration": sol_iter,
                                "rel_err_vs_planted_x_true": sol_err_true,
                                "what": "x left by the LAST solve of the timed region (max over ranks) against a complex128 CGNR of the same "
                                        "iteration count run on the host by bench.py itself; asserted before the line is printed"},
