@@ -134,7 +134,25 @@ const RLS_PROJ_NONE = Int32(0); const RLS_PROJ_REAL = Int32(1); const RLS_PROJ_P
 fused_reg(r::L1Regularization) = (RLS_REG_L1, 1)
 fused_reg(r::L2Regularization) = (RLS_REG_L2, 1)
 fused_reg(r::L21Regularization) = (RLS_REG_L21, r.slices)
+fused_reg(r::TVRegularization) = length(r.shape) <= 4 ? (RLS_REG_TV, 1) : nothing   # rls_fista_set_reg_tv (the FGP launch inside the plan)
 fused_reg(r) = nothing
+"rls_fista_set_reg / rls_fista_set_reg_tv for one plan (src/FISTA.jl:164-168: prox, then the projection).  `false`: the library refuses
+the regulariser for this plan (a TV image that does not fit the single-workgroup FGP launch) -- the caller takes the reference's own path"
+function fista_set_reg!(ctx, plan, reg, proj)
+  kind, slices = fused_reg(reg)
+  if kind == RLS_REG_TV
+    sh = collect(Int64, reg.shape)
+    d0 = collect(Int32, reg.dims isa Integer ? (reg.dims,) : reg.dims) .- Int32(1)
+    st = ccall((:rls_fista_set_reg_tv, librls[]), Int32, (Ptr{Cvoid}, Float32, Int32, Ptr{Int64}, Int32, Ptr{Int32}, Int32, Int32),
+               plan, Float32(λ(reg)), length(sh), sh, length(d0), d0, reg.iterationsTV, fused_proj(proj))
+    st == -2 && return false                              # RLS_E_UNSUPPORTED
+    check(ctx, st, "rls_fista_set_reg_tv")
+  else
+    check(ctx, ccall((:rls_fista_set_reg, librls[]), Int32, (Ptr{Cvoid}, Int32, Float32, Int64, Int32),
+                     plan, kind, Float32(λ(reg)), slices, fused_proj(proj)), "rls_fista_set_reg")
+  end
+  true
+end
 function fused_proj(projs)
   isempty(projs) && return RLS_PROJ_NONE
   length(projs) == 1 || return nothing
@@ -185,9 +203,11 @@ function init!(solver::FISTA, state::FISTAState{rT,vecT}, b::vecT; x0 = 0, theta
     mul!(state.x₀, adjoint(solver.A), b)
     solver.reg = normalize(solver, solver.normalizeReg, solver.reg, solver.A, state.x₀)
   end
-  kind, slices = fused_reg(solver.reg)
-  check(ctx, ccall((:rls_fista_set_reg, librls[]), Int32, (Ptr{Cvoid}, Int32, Float32, Int64, Int32),
-                   plan, kind, Float32(λ(solver.reg)), slices, fused_proj(solver.proj)), "rls_fista_set_reg")
+  if !fista_set_reg!(ctx, plan, solver.reg, solver.proj)   # (a TV image too large for the plan's FGP launch)
+    fista_plans[state] = C_NULL
+    return invoke(init!, Tuple{FISTA,FISTAState{rT,V},V} where {V<:Union{AbstractVector{rT},AbstractVector{Complex{rT}}}},
+                  solver, state, b; x0, theta)
+  end
   check(ctx, ccall((:rls_fista_init, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32, Int32, Int32),
                    plan, b.ptr, state.ρ, Float32(theta), state.relTol, solver.iterations, solver.restart == :gradient), "rls_fista_init")
   if !all(x0 .== 0)                                   # warm start: state.x .= x0 (:120), scalar or vector
@@ -526,10 +546,9 @@ function RegularizedLeastSquares.solve!(rs::RowSharded{<:FISTA}, b_parts::Vector
   plans = Ptr{Cvoid}[]
   for s in rs.solvers
     p = fista_plan_for(s, s.state)
-    p == C_NULL && error("row-sharded FISTA: L1 / L2 / L21 regularisation with at most one projection")
-    kind, slices = fused_reg(s.reg)
-    check(s.state.x.ctx, ccall((:rls_fista_set_reg, librls[]), Int32, (Ptr{Cvoid}, Int32, Float32, Int64, Int32),
-                               p, kind, Float32(λ(s.reg)), slices, fused_proj(s.proj)), "rls_fista_set_reg")
+    p == C_NULL && error("row-sharded FISTA: L1 / L2 / L21 / TV regularisation with at most one projection")
+    fista_set_reg!(s.state.x.ctx, p, s.reg, s.proj) ||
+      error("row-sharded FISTA + TV: the image does not fit the single-workgroup FGP kernel")
     push!(plans, p)
   end
   ctx = rs.comm.ctxs[1]

@@ -272,6 +272,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   if (!strcmp(key, "gemvn_g")) ctx->tune.gemvn_g = value;
   else if (!strcmp(key, "gemvn_waves")) ctx->tune.gemvn_waves = value;
   else if (!strcmp(key, "gemvt_cols")) ctx->tune.gemvt_cols = value;
+  else if (!strcmp(key, "gemvt_reverse")) ctx->tune.gemvt_reverse = value;
   else if (!strcmp(key, "graph_chunk")) ctx->tune.graph_chunk = value;
   else if (!strcmp(key, "use_graph")) ctx->tune.use_graph = value;
   else if (!strcmp(key, "fuse_level")) ctx->tune.fuse_level = value;

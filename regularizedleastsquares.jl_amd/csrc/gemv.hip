@@ -21,11 +21,12 @@ template <typename E, bool CONJ, int NV, int COLS, int WAVES, int U>
 __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const E* __restrict__ A, int64_t lda,
                                                             const E* __restrict__ x, E* __restrict__ y,
                                                             int64_t Mc, int64_t N, E alpha, E beta,
-                                                            const int* __restrict__ skip) {
+                                                            const int* __restrict__ skip, int reverse) {
   if (skip && *skip) return;
   constexpr int THREADS = WAVES * 64;
   const int tid = threadIdx.x;
-  const int64_t j0 = (int64_t)blockIdx.x * COLS;
+  // `reverse`: the first workgroups take the LAST columns (which column a workgroup owns changes no bit of any result)
+  const int64_t j0 = (int64_t)(reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * COLS;
 
   E acc[COLS];
 #pragma unroll
@@ -254,8 +255,10 @@ static void launch_t(rls_ctx* ctx, const E* A, int64_t lda, const E* x, E* y, in
   constexpr int WAVES = 4, U = 8;
   const int64_t Mc = M / NV;
   const unsigned grid = (unsigned)((N + COLS - 1) / COLS);
+  const bool out_of_cache = (double)M * (double)N * (double)sizeof(E) > 256.0 * 1024 * 1024;
+  const int reverse = ctx->tune.gemvt_reverse < 0 ? (out_of_cache ? 1 : 0) : (ctx->tune.gemvt_reverse ? 1 : 0);
   hipLaunchKernelGGL((gemv_t_kernel<E, CONJ, NV, COLS, WAVES, U>), dim3(grid), dim3(WAVES * 64), 0, ctx->stream, A,
-                     lda, x, y, Mc, N, alpha, beta, skip);
+                     lda, x, y, Mc, N, alpha, beta, skip, reverse);
 }
 
 template <typename E, bool CONJ, int NV>

@@ -17,6 +17,9 @@ struct rls_tuning {
   int gemvn_g = 0;      // lanes per row group in gemv_n (0 = heuristic)
   int gemvn_waves = 0;  // waves per workgroup in gemv_n (0 = heuristic)
   int gemvt_cols = 0;   // columns per workgroup in gemv_t (0 = heuristic)
+  int gemvt_reverse = -1;  // gemv_t walks the columns from the LAST one down (1), from the first up (0), or (-1, default) from the
+                           // last down exactly when A is larger than the Infinity Cache: the second product of the two-GEMV
+                           // normal operator then starts on the columns the first one has just left in the cache
   int graph_chunk = 16; // iterations captured per hipGraph
   int use_graph = 1;
   int fuse_level = 1;   // 0: separate BLAS-1 style update kernel; 1: fused update
