@@ -646,7 +646,7 @@ def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32, rows=65536, re
 def load_pmc(kernel_prefix):
     """HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
     rocprofv3 --pmc runs; tools/pmc_summarize.py); None if not collected for this kernel"""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             for k, v in pmc["kernels"].items():
