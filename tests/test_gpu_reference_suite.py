@@ -377,3 +377,27 @@ def test_admm_inner_cg_with_a_preconditioner(rls, ctx, solver, dt):
     assert rel(x, want) < 0.7 * rel(xp, want)
     with pytest.raises(TypeError, match="ldiv_"):
         rls.createLinearSolver(rls.ADMM, Ad, precon=object())
+
+
+@pytest.mark.parametrize("workload", ["rowsharded", "config4"])
+def test_bench_other_multi_gpu_workloads_rehearsed(workload):
+    """the two non-default N > 1 lines (`--workload rowsharded`: BASELINE configs[4], strong scaling, one all-reduce per iteration
+    through torch.distributed; `--workload config4`: configs[3], 8 right-hand sides per GPU) through the same one-GPU rehearsal"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--workload", workload, "--steps", "64",
+                        "--warmup", "32", "--c5-rows", "8192"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 64
+    if workload == "rowsharded":
+        assert d["scaling"] == "strong" and d["config"]["collective"]["world_size_seen_by_the_collective"] == 2 and np.isfinite(d["residual"])
+        assert d["config"]["rows_per_gpu"] == 4096
+    else:
+        assert d["scaling"] == "weak" and len(d["per_rank_solve_iterations_per_s_hip_events"]) == 2 and d["n1_same_workload_value"] > 0
