@@ -999,7 +999,8 @@ class ADMM(AbstractPrimalDualSolver):
                 state.rho[i] /= f32(2)
                 state.u[i].rmul_(2.0)
         if self.verbose:
-            print(f"rk/eps_pri = {state.rk[i] / state.eps_pri[i]}  sk/eps_dua = {state.sk[i] / state.eps_dua[i]}  rho = {state.rho[i]}")
+            with np.errstate(divide="ignore", invalid="ignore"):  # (Inf / NaN print as such, as Julia prints them: src/ADMM.jl:311-315)
+                print(f"rk/eps_pri = {state.rk[i] / state.eps_pri[i]}  sk/eps_dua = {state.sk[i] / state.eps_dua[i]}  rho = {state.rho[i]}")
 
     def _run(self, state):
         if state._plan_ok and not self.done(state):

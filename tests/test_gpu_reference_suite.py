@@ -401,3 +401,44 @@ def test_bench_other_multi_gpu_workloads_rehearsed(workload):
         assert d["config"]["rows_per_gpu"] == 4096
     else:
         assert d["scaling"] == "weak" and len(d["per_rank_solve_iterations_per_s_hip_events"]) == 2 and d["n1_same_workload_value"] > 0
+
+
+# ---- test/testSolvers.jl:3-65 and :222-239 exactly as the reference runs them: 3 x 2 systems with `rand` entries ----------------
+@pytest.mark.parametrize("seed", [12345, 1, 2])
+def test_reference_small_system_suite_on_device(rls, ctx, seed, capsys):
+    """testRealLinearSolver / testComplexLinearSolver / testComplexLinearAHASolver (A = rand(3, 2), every solver of
+    linearSolverList(), iterations = 200 / 100, the constructors' defaults otherwise, `x_approx ≈ x rtol = 0.1`) and
+    testVerboseSolvers (verbose = true, 3 iterations: must not throw) through createLinearSolver on the device"""
+    rng = np.random.default_rng(seed)
+    solvers = [s for s in rls.linearSolverList()]
+    assert {s.__name__ for s in solvers} >= {"CGNR", "Kaczmarz", "FISTA", "OptISTA", "POGM", "ADMM", "SplitBregman"}
+    # real (:3-22)
+    A = rng.random((3, 2)).astype(np.float32)
+    x = rng.random(2).astype(np.float32)
+    b = A @ x
+    for S in solvers:
+        sol = rls.createLinearSolver(S, rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx), iterations=200)
+        xa = rls.solve_(sol, rls.DeviceVector.from_host(b, ctx)).to_host()
+        assert rel(xa, x) < 0.1, ("real", S.__name__, rel(xa, x))
+    # complex (:24-43)
+    Ac = (rng.random((3, 2)) + 1j * rng.random((3, 2))).astype(np.complex64)
+    xc = (rng.random(2) + 1j * rng.random(2)).astype(np.complex64)
+    bc = Ac @ xc
+    for S in solvers:
+        sol = rls.createLinearSolver(S, rls.DeviceMatrix.from_host(np.asfortranarray(Ac), ctx), iterations=100)
+        xa = rls.solve_(sol, rls.DeviceVector.from_host(bc, ctx)).to_host()
+        assert rel(xa, xc) < 0.1, ("complex", S.__name__, rel(xa, xc))
+    # AHA only (:45-65): solver(nothing; AHA = A'A), b = AHA x
+    AHA = (Ac.conj().T @ Ac).astype(np.complex64)
+    bh = AHA @ xc
+    for S in solvers:
+        if S.__name__ == "Kaczmarz":
+            continue   # filtered out by the reference as well (:51)
+        sol = rls.createLinearSolver(S, None, AHA=rls.DeviceMatrix.from_host(np.asfortranarray(AHA), ctx), iterations=100)
+        xa = rls.solve_(sol, rls.DeviceVector.from_host(bh, ctx)).to_host()
+        assert rel(xa, xc) < 0.1, ("AHA", S.__name__, rel(xa, xc))
+    # verbose (:222-239)
+    for name in ("ADMM", "FISTA", "POGM", "OptISTA", "SplitBregman"):
+        sol = rls.createLinearSolver(getattr(rls, name), rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx), iterations=3, verbose=True)
+        rls.solve_(sol, rls.DeviceVector.from_host(b, ctx))
+    capsys.readouterr()
