@@ -318,7 +318,7 @@ function init!(solver::ADMM, state::ADMMState{rT,rvecT,vecT}, b::vecT; x0 = 0) w
   prm = AdmmParams(state.x.ptr, state.xᵒˡᵈ.ptr, state.β.ptr, state.β_y.ptr, P.zbuf[1].ptr, P.zbuf[2].ptr, state.u[1].ptr,
                    ρ, state.σᵃᵇˢ, state.relTol, solver.iterations, solver.iterationsCG, state.tolInner,
                    ρ == 0 ? RLS_REG_NONE : admm_reg(reg), ρ == 0 ? 0f0 : Float32(λ(reg)) / (2f0 * ρ), fused_proj(solver.proj),
-                   nd, length(dims), tv ? reg.params.iterationsTV : 0, pad4(dims, Int32), pad4(tv ? collect(reg.shape) : Int[], Int64))
+                   nd, length(dims), tv ? reg.iterationsTV : 0, pad4(dims, Int32), pad4(tv ? collect(reg.shape) : Int[], Int64))
   st = ccall((:rls_admm_init, librls[]), Int32, (Ptr{Cvoid}, Ref{AdmmParams}), P.plan, prm)
   if st == -2                                           # RLS_E_UNSUPPORTED: this regulariser runs through the generic iterate
     delete!(admm_plans, state); admm_plans[state] = nothing
