@@ -89,6 +89,8 @@ end
 function init!(solver::CGNR, state::CGNRState{T,Tc,vecTc}, b::vecTc; x0 = 0) where {T,Tc,vecTc<:RLSVector{Tc}}
   all(x0 .== 0) || error("CGNR: x0 != 0 is unsupported (the reference's branch throws as well, src/CGNR.jl:119)")
   plan = plan_for(solver, state)
+  # normalization of the regularization parameter (:129) comes FIRST here: the device init takes lambda as an argument
+  solver.L2 = normalize(solver, solver.normalizeReg, solver.L2, solver.A, b)
   check(b.ctx, ccall((:rls_cgnr_init, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int32),
                      plan, b.ptr, Float32(λ(solver.L2)), state.relTol, solver.iterations), "rls_cgnr_init")
   state.iteration = 0
@@ -277,7 +279,10 @@ function is_identity_trafo(op, probe::RLSVector)
 end
 
 function admm_fusable(solver::ADMM, state)
-  length(solver.reg) == 1 && solver.vary_ρ == :none && operator_of(solver.A, solver.AHA) !== nothing &&
+  # (a preconditioner other than IterativeSolvers.Identity() -- `precon`, src/ADMM.jl:82,244 -- is not part of the fused cg!: the
+  #  reference's own iterate then runs IterativeSolvers' preconditioned loop on RLSVector through the BLAS-1 methods)
+  length(solver.reg) == 1 && solver.vary_ρ == :none && nameof(typeof(solver.precon)) === :Identity &&
+    operator_of(solver.A, solver.AHA) !== nothing &&
     admm_reg(solver.reg[1]) !== nothing && fused_proj(solver.proj) !== nothing &&
     !(solver.reg[1] isa TVRegularization && !isempty(solver.proj)) &&
     is_identity_trafo(solver.regTrafo[1], state.β_y)      # beta_y = A'b is set by the reference's init! just before
@@ -396,11 +401,15 @@ function RLSMI355X.solve_group!(solvers::Vector{<:CGNR}, bs::Vector{<:RLSVector}
   plans = Ptr{Cvoid}[]
   for (s, st, b) in zip(solvers, states, bs)
     push!(plans, plan_for(s, st))         # (the plan is created on first use; init! itself runs inside the group launch)
+    s.L2 = normalize(s, s.normalizeReg, s.L2, s.A, b)   # src/CGNR.jl:129 (a measurement-based factor differs per right-hand side)
     st.iteration = 0
     delete!(cgnr_done, st)
   end
   first_ = solvers[1]
   lam = Float32(λ(first_.L2)); tol = Float32(states[1].relTol)
+  if !all(s -> Float32(λ(s.L2)) == lam && s.iterations == first_.iterations, solvers) || !all(st -> Float32(st.relTol) == tol, states)
+    return [RLSMI355X.solve_fused!(s, b) for (s, b) in zip(solvers, bs)]   # one launch needs one lambda / relTol / iteration count
+  end
   rc = ccall((:rls_cgnr_init_step_group, librls[]), Int32, (Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Float32, Float32, Int32, Int32),
              plans, Ptr{Cvoid}[b.ptr for b in bs], Int32(length(plans)), lam, tol, Int32(first_.iterations), Int32(first_.iterations))
   if rc == Int32(-2)

@@ -93,6 +93,15 @@ function LinearAlgebra.norm(v::RLSVector{T}) where {T}
   check(v.ctx, ccall((:rls_nrm2, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}), v.ctx.handle, dtypecode(T), v.n, v.ptr, r), "rls_nrm2")
   r[][1]
 end
+"norm(v, p) for p = 2 and p = 1 (`norm(b, 1) / length(b)`: MeasurementBasedNormalization, src/Regularization/NormalizedRegularization.jl:40-42;
+complex modulus as in ProxL1.jl:29-32)"
+function LinearAlgebra.norm(v::RLSVector{T}, p::Real) where {T}
+  p == 2 && return norm(v)
+  p == 1 || throw(ArgumentError("norm(::RLSVector, p): p = 1 or 2"))
+  r = Ref{Float32}(0f0)
+  check(v.ctx, ccall((:rls_asum, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ref{Float32}), v.ctx.handle, dtypecode(T), v.n, v.ptr, r), "rls_asum")
+  r[]
+end
 function LinearAlgebra.dot(x::RLSVector{T}, y::RLSVector{T}) where {T}
   r = Ref{NTuple{2,Float32}}((0f0, 0f0))
   check(x.ctx, ccall((:rls_dotc, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, dtypecode(T), x.n, x.ptr, y.ptr, r), "rls_dotc")
