@@ -460,7 +460,9 @@ end
 RLSMI355X.BatchedState(states::Vector) = error("BatchedState is selected with solve!(solver, B::RLSMatrix; scheduler = RLSMI355X.BatchedState)")
 
 function init!(solver::CGNR, state::AbstractSolverState, B::RLSMatrix{Tc}; scheduler = RegularizedLeastSquares.SequentialState, x0 = 0, kwargs...) where {Tc}
-  if scheduler !== RLSMI355X.BatchedState
+  if scheduler !== RLSMI355X.BatchedState || solver.normalizeReg isa MeasurementBasedNormalization
+    # (a measurement-based factor is a per-column lambda, src/CGNR.jl:129: the batched plan has one lambda for all columns)
+    scheduler === RLSMI355X.BatchedState && (scheduler = RegularizedLeastSquares.SequentialState)
     # the reference's own matrix init! (src/MultiThreading.jl:30-38), selected by a signature this method does not match
     return invoke(init!, Tuple{AbstractLinearSolver,AbstractSolverState,AbstractMatrix}, solver, state, B; scheduler, x0, kwargs...)
   end
