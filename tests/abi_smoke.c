@@ -1,7 +1,8 @@
 /* Plain-C driver of the drop-in boundary: no Python, no C++, no torch in the process -- exactly what a host that binds
  * include/rls_mi355x.h through an FFI (Julia ccall: INTEGRATION.md) executes.  create -> init -> step -> status for
  *   1. CGNR   (src/CGNR.jl:107-130, :143-178)        256 x 128 Float32, lambda = 1e-2, 10 iterations, every iterate checked
- *   2. FISTA  (src/FISTA.jl:110-129, :139-185) + L1  256 x 128 Float32, 25 iterations
+ *   2. FISTA  (src/FISTA.jl:110-129, :139-185) + L1  256 x 128 Float32, 25 iterations; + TV + Positive with the FGP prox inside
+ *      the plan (rls_fista_set_reg_tv), 15 iterations
  *   3. CGNR at the headline shape 4096 x 2048 ComplexF32 (the resident one-launch path when the device offers it)
  *   4. row-partitioned CGNR through the library's communicator (rls_comm_*, rls_cgnr_*_rowsharded): 1, 2 and 4 ranks
  *      sharing device 0 (direct transport) and, where RCCL loads, the RCCL transport with one rank
@@ -202,6 +203,66 @@ static void test_cgnr_and_fista_small(void) {
     printf("FISTA+L1 256x128 f32: 25 iterations within 1e-5 (%.2e), rel_res_norm %.3e\n", e, fs.rel_res_norm);
     free(fx0d); free(y); free(xk); free(xo); free(res); free(t); free(bd);
   }
+  /* ---- FISTA + TV + Positive with the prox INSIDE the plan (rls_fista_set_reg_tv; src/FISTA.jl:164-168,
+   *      src/proximalMaps/ProxTV.jl:89-125): x seen as a 1-D signal of N samples, 10 FGP iterations ---- */
+  {
+    const float lam_tv = 2.0f;
+    const int64_t shape1[1] = {N};
+    const int32_t dims1[1] = {0};
+    CHECK(rls_fista_set_reg_tv(fp, lam_tv, 1, shape1, 1, dims1, 10, RLS_PROJ_POSITIVE));
+    CHECK(rls_fista_init(fp, bd_, rho, 1.f, 0.f, 15, 0));
+    CHECK(rls_fista_step(fp, 15));
+    CHECK(rls_fista_get_status(fp, &fs));
+    REQUIRE(fs.iteration == 15 && fs.done == 1, "FISTA + TV iteration %d done %d", fs.iteration, fs.done);
+    CHECK(rls_fista_solution(fp, &xs));
+    CHECK(rls_memcpy_d2h(g_ctx, xh, xs, 4 * N));
+    double *fx0d = (double*)calloc(N, 8), *y = (double*)calloc(N, 8), *xk = (double*)calloc(N, 8), *xo = (double*)calloc(N, 8),
+           *res = (double*)calloc(N, 8), *t = (double*)calloc(M, 8), *bd = (double*)calloc(M, 8), *u = (double*)calloc(N, 8),
+           *pq = (double*)calloc(N, 8), *rs = (double*)calloc(N, 8), *po = (double*)calloc(N, 8), *xt = (double*)calloc(N, 8);
+    for (int64_t i = 0; i < M; ++i) bd[i] = b[i];
+    mul_t(A, M, N, bd, fx0d);
+    double theta = 1, theta_old = 1;
+    for (int it = 0; it < 15; ++it) {
+      for (int64_t j = 0; j < N; ++j) {
+        const double xn = xk[j];
+        y[j] = xk[j] * ((theta_old - 1) / theta + 1) + xo[j] * ((1 - theta_old) / theta);
+        xo[j] = xn;
+      }
+      mul_n(A, M, N, y, t);
+      mul_t(A, M, N, t, res);
+      for (int64_t j = 0; j < N; ++j) {
+        res[j] -= fx0d[j];
+        u[j] = y[j] - (double)rho * res[j];
+      }
+      /* prox_TV(u, rho * lam): FGP on the forward differences g[i] = x[i] - x[i + 1] (no boundary row), step 1 / (8 lam) */
+      const double l = (double)rho * lam_tv;
+      const int64_t ng = N - 1;
+      for (int64_t i = 0; i < ng; ++i) pq[i] = rs[i] = po[i] = 0;
+      double tt = 1;
+      for (int k = 0; k < 10; ++k) {
+        for (int64_t j = 0; j < N; ++j) xt[j] = u[j] - l * ((j < ng ? rs[j] : 0) - (j > 0 ? rs[j - 1] : 0)); /* x - l grad' rs */
+        for (int64_t i = 0; i < ng; ++i) {
+          double q = rs[i] + (xt[i] - xt[i + 1]) / (8 * l);
+          q = q / (fabs(q) > 1 ? fabs(q) : 1);
+          po[i] = pq[i];
+          pq[i] = q;
+        }
+        const double to = tt;
+        tt = (1 + sqrt(1 + 4 * to * to)) / 2;
+        for (int64_t i = 0; i < ng; ++i) rs[i] = (1 + (to - 1) / tt) * pq[i] - ((to - 1) / tt) * po[i];
+      }
+      for (int64_t j = 0; j < N; ++j) {
+        const double v = u[j] - l * ((j < ng ? pq[j] : 0) - (j > 0 ? pq[j - 1] : 0));
+        xk[j] = v > 0 ? v : 0; /* PositiveRegularization after the prox (:166-168) */
+      }
+      theta_old = theta;
+      theta = (1 + sqrt(1 + 4 * theta_old * theta_old)) / 2;
+    }
+    const double e = rel_err_f(xh, xk, N);
+    REQUIRE(e < 1e-5, "FISTA + TV solution: relative error %.3e", e);
+    printf("FISTA+TV+Positive 256x128 f32 (prox inside the plan): 15 iterations within 1e-5 (%.2e)\n", e);
+    free(fx0d); free(y); free(xk); free(xo); free(res); free(t); free(bd); free(u); free(pq); free(rs); free(po); free(xt);
+  }
   CHECK(rls_fista_destroy(fp));
 
   /* ---- the same CGNR problem row-partitioned over 1, 2 and 4 ranks on device 0 through rls_comm ---- */
@@ -210,6 +271,12 @@ static void test_cgnr_and_fista_small(void) {
     int32_t devs[4] = {0, 0, 0, 0};
     CHECK(rls_comm_create(nr, devs, NULL, RLS_COMM_DIRECT, &comm));
     REQUIRE(rls_comm_size(comm) == nr && rls_comm_transport(comm) == RLS_COMM_DIRECT, "communicator shape");
+    {
+      int32_t peer[16], asked = -1; /* the probe of rls_comm_create: ranks sharing a device can always store into each other */
+      CHECK(rls_comm_peer_access(comm, peer, &asked));
+      REQUIRE(asked == RLS_COMM_DIRECT, "requested transport %d", asked);
+      for (int q = 0; q < nr * nr; ++q) REQUIRE(peer[q] == 1, "peer matrix entry %d = %d", q, peer[q]);
+    }
     rls_operator* ops[4];
     rls_cgnr* plans[4];
     void *xs_[4], *bparts[4], *As[4], *vecs[4][3];
