@@ -693,6 +693,46 @@ class HostStagedDist:
         self._d.destroy_process_group()
 
 
+def live_pmc(kernel_prefixes, timeout_s=90):
+    """HBM bytes per launch of the named kernels measured IN THIS RUN -- two child processes, `rocprofv3 --pmc
+    FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` (separate passes, nothing but the counter: the guide's recipe) over
+    tools/pmc_probe_headline.py, FETCH_SIZE doubled as the guide prescribes for gfx950's wide coalesced reads.  Returns
+    {prefix: bytes} or {"error": ...}; never raises (the line then keeps the committed pass)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    out = {}
+    try:
+        vals = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix=f"rls_pmc_{counter.lower()}_", dir="/tmp")
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "pmc_probe_headline.py")], cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
+                               capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(files)} csv file(s): {r.stderr[-300:]}"}
+            agg = {}
+            for row in csv.DictReader(open(files[0])):
+                agg.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            vals[counter] = {k: sum(v) / len(v) * 1024.0 for k, v in agg.items()}  # KB -> bytes, mean over the launches
+            shutil.rmtree(d, ignore_errors=True)
+        for pref in kernel_prefixes:
+            f = max((v for k, v in vals["FETCH_SIZE"].items() if pref + "<" in k or pref + "(" in k), default=None)
+            w = max((v for k, v in vals["WRITE_SIZE"].items() if pref + "<" in k or pref + "(" in k), default=0.0)
+            if f is not None:
+                out[pref] = 2.0 * f + w
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+    return out or {"error": "the kernels did not appear in the counter output"}
+
+
 def self_launch_command(gpus, argv, env):
     """the torch.distributed.run command line `python bench.py --gpus N` starts when it is NOT already a rank (no WORLD_SIZE
     / RANK in the environment) and N > 1; None otherwise.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -722,6 +762,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--resident", type=int, default=1, help="0: force the two-launch pipeline for the headline run")
     ap.add_argument("--dry-launch", action="store_true", help="N > 1 from a plain shell: print the launch command as JSON and exit")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do NOT collect roofline.traffic in this run (two `rocprofv3 --pmc` child passes over a short probe of the "
+                         "same solve, about six seconds each); quote the committed pass under profiles/ instead")
     ap.add_argument("--rehearse", action="store_true",
                     help="run the N > 1 code path on ONE GPU: every rank on device 0, torch.distributed over gloo (device tensors staged "
                          "through the host), the library's communicator on its direct transport with the ranks sharing the device; the "
@@ -1150,6 +1193,17 @@ def main():
         c5 = config5_leg(rls, ctx, dist, rank, world, barrier, rows=args.c5_rows, rehearse=args.rehearse)
     trace("config 5 legs done")
     traffic, traffic_src = load_pmc(dom)
+    traffic_kind = TRAFFIC_KIND
+    if not args.no_live_pmc and rank == 0 and world == 1:
+        trace("live PMC passes")
+        lp = live_pmc([dom, "cgnr_pipe_a_kernel"])
+        if dom in lp:
+            traffic, traffic_src = lp[dom], "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (tools/pmc_probe_headline.py)"
+            traffic_kind = "live: collected by child rocprofv3 passes of this bench run (FETCH_SIZE x 2 + WRITE_SIZE, mean over the probe's launches)"
+            if hbm_streaming and "cgnr_pipe_a_kernel" in lp and "error" not in hbm_streaming:
+                hbm_streaming["traffic_pmc_live"] = lp["cgnr_pipe_a_kernel"]
+        else:
+            traffic_kind = TRAFFIC_KIND + f"  [the live passes failed: {lp.get('error')}]"
     kd = kern[dom]
     hbm_bytes = traffic if traffic is not None else kd["min_hbm_bytes_per_launch"]
     frac_hbm = hbm_bytes / (kd["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS
@@ -1189,7 +1243,7 @@ def main():
             # algorithmic basis, the ITERATION as the unit (SURVEY 8d bytes per iteration x iterations / device time of the timed region)
             "peak_GBps": HBM_PEAK_GBS, "algorithmic_GBps": iter_gbs, "frac_algorithmic": frac_alg,
             # physical basis: bytes the dominant kernel really moves per launch / its launch time
-            "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": TRAFFIC_KIND,
+            "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": traffic_kind,
             "hbm_bytes_per_launch_used": hbm_bytes,
             "note": "frac_algorithmic: SURVEY 8d algorithmic bytes per iteration (A read twice) x iterations / hipEvent time of the timed region / peak; "
                     "frac_hbm: HBM bytes of the dominant kernel per launch (PMC when collected, else the minimum it must move) / its launch time / peak"}
@@ -1201,7 +1255,7 @@ def main():
                                "achieved": 1e6 / floor["measured"], "peak": 1e6 / floor["floor"],
                                "frac": (1e6 / floor["measured"]) / (1e6 / floor["floor"]),
                                "us_per_iteration": {"measured": floor["measured"], "floor": floor["floor"]},
-                               "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": TRAFFIC_KIND,
+                               "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": traffic_kind,
                                "hbm_streaming": hbm_streaming,
                                "protocol_independent": floor["protocol_independent_floor"],
                                "hbm": dict(hbm_view, hbm_algorithmic_uncapped=iter_gbs,
@@ -1210,7 +1264,7 @@ def main():
                                "resident_floor": floor}
         else:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": iter_gbs, "frac": frac_alg,
-                               "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": TRAFFIC_KIND,
+                               "frac_hbm": frac_hbm, "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": traffic_kind,
                                "hbm_streaming": hbm_streaming, "hbm_bytes_per_launch_used": hbm_bytes, "note": hbm_view["note"]}
         out["roofline"]["per_kernel"] = kern
         out["roofline"]["iteration"] = {"bytes": bytes_iter, "us_hip_events": 1e6 * ev / K, "roofline_us_at_peak": bytes_iter / HBM_PEAK_GBS / 1e3}
