@@ -289,6 +289,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "small")) ctx->tune.small = value;
   else if (!strcmp(key, "resident_server")) ctx->tune.resident_server = value;
   else if (!strcmp(key, "resident_l2_rows")) ctx->tune.resident_l2_rows = value;
+  else if (!strcmp(key, "fista_defer")) ctx->tune.fista_defer = value;
   else if (!strcmp(key, "resident_server_idle_us")) {
     // the other workgroups of a listening grid wait at a barrier whose bound is resident_spin polls (about 0.1 s at the default):
     // an idle time beyond a fraction of that would make them give up while workgroup 0 still polls the host (a lost launch)

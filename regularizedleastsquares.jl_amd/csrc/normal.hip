@@ -2394,11 +2394,13 @@ template <typename E, int G, int K, int WV, int BAR, bool FULL>
 __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
                                                                   const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                   E* raw_g, E* slab, fista_scalars* sc,
-                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair,
+                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair_flags,
                                                                   int n_steps, unsigned spin_limit, rls_srv_args Sv) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
   static_assert(EPT % NV == 0, "16-byte ownership layout");
+  const int pair = pair_flags & 1;
+  const bool defer_on = (pair_flags & 2) == 0;  // rls_tune_set("fista_defer", 0): the measurement switch of DEFER below (uniform)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   resident_lds<E, G, K, WV>& R = *reinterpret_cast<resident_lds<E, G, K, WV>*>(smem_raw);
   slab_lds<E, G, K, WV>& L = R.L;
@@ -2409,6 +2411,15 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   // Loop-carried in registers: y, x, xold (the recurrence).  NOT carried: x0 = A^H b (read-only: re-read every iteration
   // behind the products, so that it is not live while the slab's 128 registers and the product's temporaries are) and res
   // (output only: workgroup 0 stores it every iteration) -- 16 registers less across the products, no spill.
+  // DEFER (round 5; the full-size column-owner instantiations on the two-level exchange): without gradient restart nothing of an
+  // iteration depends on ||res|| but the stopping test (theta follows a data-independent recursion, src/FISTA.jl:179-180), so
+  // the waves leave their partial ||res||^2 in LDS WITHOUT a barrier and every thread adds the eight up behind the NEXT
+  // iteration's exchange, where a stop found late drops that iteration's exchange (nothing of it has been applied) -- as
+  // fista_gram_resident_kernel does.  The registers for the second update path come from x_{k-1}: it is not part of the
+  // recurrence (only the write-back wants it), so workgroup 0 keeps it in plan scratch (`raw_g`, idle under this exchange)
+  // instead of every thread carrying it across the products.
+  // (ComplexF32 only: the Float32 column-owner instantiation, N in (2048, 4096], spilled 12 B per lane with the second path)
+  constexpr bool DEFER = owner_cfg<E, G, K, WV>::ok && FULL && BAR == 2 && elem<E>::cplx;
   E yv[EPT], xk[EPT], xp[EPT];
   if constexpr (FULL) {
     load_owned_wide<E, EPT, NT>(yv, S.ycur ? y1 : y0, tid);
@@ -2437,6 +2448,33 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   int ycur = S.ycur;
   rls_mailbox_slot srv_mb = Sv.mb;
   unsigned srv_seq = Sv.seq0;  // server mode (rls_fista_step_status): the command being served
+  const __amdgpu_buffer_rsrc_t xo_rs = sc1_rsrc(raw_g);
+  auto stash_xold = [&](const E (&src)[EPT]) {  // workgroup 0: x_{k-1} of the write-back lives in plan scratch (DEFER)
+#pragma unroll
+    for (int q = 0; q < EPT / NV; ++q) {
+      chunk<E, NV> c;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) c.e[j] = src[q * NV + j];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, c), xo_rs, (uint32_t)((q * NT * NV + tid * NV) * sizeof(E)), 0, 0);
+    }
+  };
+  if constexpr (DEFER) {
+    if (blockIdx.x == 0) stash_xold(xp);
+  }
+  bool pend = false;   // the norm of the last applied iteration is still in LDS (uniform)
+  unsigned itg = 0;    // iterations applied by this launch over all its commands: the parity of the norm slots
+  auto resolve = [&](unsigned par) {  // src/FISTA.jl:156, :187-189 for that iteration; slots [24, 32) / [40, 48) of L.red
+    double rn = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) rn += L.red[24 + 16 * par + i];
+    const double res_norm = sqrt(rn);
+    const float rel = (float)(res_norm / S.norm_x0);
+    S.res_norm = res_norm;
+    S.rel_res_norm = (double)rel;
+    if (rel < S.rel_tol) S.done = 1;
+    pend = false;
+    RLS_FISTA_UNIFORM(S);
+  };
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = 0; it < n_steps; ++it) {
     if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
@@ -2466,9 +2504,45 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
 #pragma unroll
       for (int e = 0; e < EPT; ++e) yv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
     }
+    if constexpr (DEFER) {
+      if (pend) {  // uniform: the previous iteration's stopping test, behind this exchange's barriers
+        resolve((itg & 1u) ^ 1u);
+        if (S.done) break;  // it had converged: this iteration's exchange is dropped, nothing of it was applied
+      }
+    }
     E xn[EPT], yn[EPT], ri[EPT];
-    fista_scalars Sn;
-    const bool done = fista_update_elems<E, EPT, NT, true, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    bool done;
+    if (DEFER && defer_on && !S.restart) {  // uniform
+      const float rho = S.rho, thr = S.rho * S.lambda;  // prox!(reg, x, rho * lambda(reg))        :164
+      double rn = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const E r = elem<E>::sub(raw[e], x0v[e]);                             // res .-= x0      :153
+        E xv = elem<E>::sub(yv[e], elem<E>::scale(rho, r));                   // x .-= rho .* res :154
+        xv = fista_proj_elem<E>(fista_prox_elem<E>(xv, S.reg_kind, thr), S.proj_kind);
+        ri[e] = r;
+        xn[e] = xv;
+        rn += (double)elem<E>::re(r) * (double)elem<E>::re(r) + (double)elem<E>::im(r) * (double)elem<E>::im(r);
+      }
+      rn = wave_sum(rn);
+      if ((tid & 63) == 0) L.red[24 + 16 * (itg & 1u) + (tid >> 6)] = rn;  // read behind the next exchange, or the barrier at the end
+      pend = true;
+      const float theta_old = S.theta;                                        // :179
+      const float theta = (1.f + sqrtf(1.f + 4.f * theta_old * theta_old)) / 2.f;  // :180
+      const float c1 = (1.f - theta_old) / theta, c2 = (theta_old - 1.f) / theta + 1.f;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) yn[e] = elem<E>::add(elem<E>::scale(c1, xk[e]), elem<E>::scale(c2, xn[e]));
+      S.theta = theta;
+      S.theta_old = theta_old;
+      S.iteration += 1;
+      S.done = S.iteration >= S.max_iter;  // the relTol half of :187-189 follows with the norm
+      done = S.done != 0;
+    } else {
+      fista_scalars Sn;
+      done = fista_update_elems<E, EPT, NT, true, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+      RLS_FISTA_COPY(S, Sn);
+    }
+    ++itg;
     if (blockIdx.x == 0) {  // state.res of this iteration (nothing reads it back: a launch that gives up later loses nothing)
       const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(res, 0, 0xffffffff, 0x00020000);
 #pragma unroll
@@ -2480,16 +2554,24 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
         if (FULL || o < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, c3), res_rs, (uint32_t)(o * sizeof(E)), 0, 0);
       }
     }
+    if constexpr (DEFER) {
+      if (blockIdx.x == 0) stash_xold(xk);  // x_k becomes x_{k-1}
+    }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      xp[e] = xk[e];
+      if constexpr (!DEFER) xp[e] = xk[e];
       xk[e] = xn[e];
       if (!done) yv[e] = yn[e];
     }
     if (!done) ycur ^= 1;
-    RLS_FISTA_COPY(S, Sn);
     RLS_FISTA_UNIFORM(S);
     if (done) break;  // uniform
+  }
+  if constexpr (DEFER) {
+    if (alive && pend) {  // uniform: the last applied iteration's norm and stopping test
+      lds_barrier();
+      resolve((itg - 1u) & 1u);
+    }
   }
   if (!alive) {
     resident_give_up(sync, nullptr);
@@ -2497,6 +2579,15 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     return;
   }
   if (blockIdx.x == 0) {
+    if constexpr (DEFER) {  // x_{k-1} back from plan scratch (this thread's own stores, drained first)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < EPT / NV; ++q) {
+        const chunk<E, NV> c = __builtin_bit_cast(chunk<E, NV>, sc1_load16(xo_rs, (uint32_t)((q * NT * NV + tid * NV) * sizeof(E))));
+#pragma unroll
+        for (int j = 0; j < NV; ++j) xp[q * NV + j] = c.e[j];
+      }
+    }
     S.ycur = ycur;
     S.pending = 0;
     S.fresh = 0;
@@ -3391,7 +3482,7 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
 #define RLS_LAUNCH_FRES(BB, FF)                                                                                          \
   hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab,  \
-                     P.sc, (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, Sv)
+                     P.sc, (resident_sync*)sync, Mc, P.N, pair | (ctx->tune.fista_defer ? 0 : 2), n_steps, spin_limit, Sv)
     if (resident_two_level_ok<E>(nwg, P.N, C::NT)) {
       if (full) RLS_LAUNCH_FRES(2, true);
       else RLS_LAUNCH_FRES(2, false);

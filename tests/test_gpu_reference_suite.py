@@ -442,3 +442,56 @@ def test_reference_small_system_suite_on_device(rls, ctx, seed, capsys):
         sol = rls.createLinearSolver(getattr(rls, name), rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx), iterations=3, verbose=True)
         rls.solve_(sol, rls.DeviceVector.from_host(b, ctx))
     capsys.readouterr()
+
+
+def test_fista_resident_deferred_norm_changes_no_bit(rls, ctx):
+    """round 5, lever (d): `fista_resident_kernel` sums ||res||^2 off the critical path (behind the NEXT iteration's exchange) when
+    there is no gradient restart; a stop found there drops that iteration's exchange.  Against `fista_defer = 0` (the block
+    reduction in place): the same bits of x, xold, res, the same iteration count and residual norm -- for a full solve, for a
+    relTol that stops in the middle of a launch, and for step calls of 1 / 3 / 7 iterations (server mode included)."""
+    import ctypes as C
+    M, N = 4096, 2048
+    A, xt, b = O.make_problem(M, N, np.complex64, 77)
+    Ad, bd = rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx), rls.DeviceVector.from_host(b, ctx)
+    rho = 0.9 / (np.sqrt(M) + np.sqrt(N)) ** 2
+    lam = 0.02 * float(np.max(np.abs(A.conj().T @ b)))
+    path = C.c_int32(-1)
+
+    def solve(defer, **kw):
+        ctx.tune(fista_defer=defer)
+        try:
+            s = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, **kw)
+            x = rls.solve_(s, bd).to_host()
+            ctx.lib.rls_fista_path(s.state._plan, C.byref(path))
+            return x, s.state.xold.to_host(), s.state.res.to_host(), s.state.iteration, s.state.rel_res_norm
+        finally:
+            ctx.tune(fista_defer=1)
+
+    # the oracle says where a relTol crossing lies
+    o = O.FISTA(A.astype(np.complex128), reg=O.L1Regularization(lam), rho=rho, iterations=40, relTol=0.0)
+    o.init(b.astype(np.complex128))
+    rels = []
+    while o.iterate() is not None:
+        rels.append(float(o.rel_res_norm))
+    k = max(i for i in range(3, 13) if rels[i] < 0.97 * min(rels[:i]))   # the last clear crossing among the first iterations
+    tol = float(np.sqrt(rels[k] * min(rels[:k])))
+    for kw in (dict(iterations=40, relTol=0.0), dict(iterations=40, relTol=tol), dict(iterations=1, relTol=0.0)):
+        a, b_ = solve(1, **kw), solve(0, **kw)
+        if torch_device_has_256_cus():
+            assert path.value == 4, path.value
+        assert a[3] == b_[3] and (kw["relTol"] == 0.0 or a[3] == k + 1), (kw, a[3], b_[3])
+        assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2]), kw
+        assert a[4] == b_[4]
+    x64 = np.array(O.solve(O.FISTA(A.astype(np.complex128), reg=O.L1Regularization(lam), rho=rho, iterations=40, relTol=tol), b.astype(np.complex128)))
+    parity("fista_resident_deferred_norm_reltol_stop", solve(1, iterations=40, relTol=tol)[0], x64,
+           lambda: np.array(O.solve(O.FISTA(A, reg=O.L1Regularization(lam), rho=rho, iterations=40, relTol=tol), b)))
+    # iterate-by-iterate with callbacks (server mode) against the enqueued solve: the same bits
+    s = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=40, relTol=tol)
+    seen = []
+    xs = rls.solve_(s, bd, callbacks=[lambda sv, i: seen.append(i)]).to_host()
+    assert seen == list(range(k + 2)) and np.array_equal(xs, solve(1, iterations=40, relTol=tol)[0])
+
+
+def torch_device_has_256_cus():
+    import torch
+    return torch.cuda.get_device_properties(0).multi_processor_count >= 256
