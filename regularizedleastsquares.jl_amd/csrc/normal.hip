@@ -2637,11 +2637,13 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
                                                                 E* res, const E* __restrict__ x0, E* raw_g, E* slab,
                                                                 pgm_state* st, rls_pgm_coefs CF, float norm_x0, float rel_tol,
                                                                 int reg_kind, int proj_kind, resident_sync* sync, int64_t Mc,
-                                                                int64_t N, int pair, int n_steps, int first_it,
+                                                                int64_t N, int pair_flags, int n_steps, int first_it,
                                                                 unsigned spin_limit) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
   static_assert(owner_cfg<E, G, K, WV>::ok, "column-owner layout only");
+  const int pair = pair_flags & 1;
+  const bool defer_on = (pair_flags & 2) == 0;  // rls_tune_set("fista_defer", 0): measurement switch of DEFER below (uniform)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   resident_lds<E, G, K, WV>& R = *reinterpret_cast<resident_lds<E, G, K, WV>*>(smem_raw);
   const int tid = threadIdx.x;
@@ -2699,6 +2701,19 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
   constexpr bool L2ROWS = BAR == 2 && (FULL || KIND != 2);  // partial rows at L2 scope (resident_rows_at_l2); the masked restart instantiation spilled 8 B with it
   bool l2rows = false, placed = !L2ROWS;  // uniform
   if constexpr (L2ROWS) resident_report_placement(sync);
+  // KIND 0 / 1 (no gradient restart): nothing of an iteration depends on ||res|| but the stopping test, so the waves leave their
+  // partial sums in LDS without a barrier and every thread adds them up behind the NEXT iteration's exchange (a stop found there
+  // drops that exchange: nothing of it has been applied) -- fista_resident_kernel's DEFER, round 5
+  constexpr bool DEFER = KIND != 2;
+  bool pend = false;  // uniform
+  auto resolve = [&](unsigned par) {
+    double rn = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) rn += R.L.red[24 + 16 * par + i];
+    res_norm = uni((float)sqrt(rn));
+    done = uni((int)(((double)res_norm / (double)norm_x0) < (double)rel_tol));
+    pend = false;
+  };
   for (int it = 0; it < n_steps; ++it) {
     owner_products<E, G, K, WV, FULL>(a, xv, R.ored, slab_rs, N, l2rows);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2721,6 +2736,12 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
       placed = true;
     }
     if constexpr (X0_LATE) load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
+    if constexpr (DEFER) {
+      if (pend) {  // uniform: the previous iteration's stopping test, behind this exchange's barriers
+        resolve(((unsigned)ran & 1u) ^ 1u);
+        if (done) break;  // it had converged: this iteration's exchange is dropped, nothing of it was applied
+      }
+    }
     float c0, c1, c2, c3, c4, c5, c6 = 0.f, rg = 0.f, th = 1.f, gamma_n = 1.f;
     if constexpr (KIND == 2) {
       // the coefficients of this iteration from theta, sigma, gamma: Float32, one rounding per operation, the host's order
@@ -2795,6 +2816,16 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
       store_buf(o0_rs, ov);
       store_buf(res_rs, ri);
     }
+    if constexpr (DEFER) {
+      if (defer_on) {  // uniform
+        rn = wave_sum(rn);
+        if ((tid & 63) == 0) R.L.red[24 + 16 * ((unsigned)ran & 1u) + (tid >> 6)] = rn;  // read behind the next exchange, or at the end
+        pend = true;
+        iteration += 1;
+        ran += 1;
+        continue;
+      }
+    }
     rn = block_sum_nolead<NT / 64>(rn, R.L.red);
     res_norm = uni((float)sqrt(rn));
     if constexpr (KIND == 2) {
@@ -2810,6 +2841,12 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
     ran += 1;
     done = uni((int)(((double)res_norm / (double)norm_x0) < (double)rel_tol));
     if (done) break;  // uniform: every workgroup derived the same scalar
+  }
+  if constexpr (DEFER) {
+    if (alive && pend) {  // uniform: the last applied iteration's norm and stopping test
+      lds_barrier();
+      resolve(((unsigned)ran - 1u) & 1u);
+    }
   }
   if (!alive) {
     resident_give_up(sync, nullptr);
@@ -3629,7 +3666,7 @@ static int32_t launch_pgm_resident(rls_ctx* ctx, const rls_pgm_desc& D, const rl
 #define RLS_LAUNCH_PGM(BB, FF, KK2)                                                                                              \
   hipLaunchKernelGGL((pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)D.A,    \
                      D.lda, (E*)D.v0, (E*)D.v1, (E*)D.v2, (E*)D.v3, (E*)D.o0, (E*)D.res, (const E*)D.x0, (E*)D.raw, (E*)D.slab, D.st, CF,  \
-                     D.norm_x0, D.rel_tol, D.reg_kind, D.proj_kind, (resident_sync*)sync, Mc, D.N, pair, n_steps, D.first_it, spin_limit)
+                     D.norm_x0, D.rel_tol, D.reg_kind, D.proj_kind, (resident_sync*)sync, Mc, D.N, pair | (ctx->tune.fista_defer ? 0 : 2), n_steps, D.first_it, spin_limit)
     const bool two = resident_two_level_ok<E>(nwg, D.N, C::NT);
     if (D.kind == 0) {
       if (two) { if (full) RLS_LAUNCH_PGM(2, true, 0); else RLS_LAUNCH_PGM(2, false, 0); }
