@@ -75,7 +75,11 @@ int32_t rls_device_count(int32_t* out);
  * that stores into pinned host memory + a host spin; 2, the default: rls_*_step_status has the call's last kernel do that store where
  * it can; 0: hipMemcpyAsync + stream wait), "resident_l2_rows" (1, the default: the matrix-free resident kernels keep the partial
  * rows of their in-kernel all-reduce in the XCD's L2 whenever every workgroup sits on the XCD its group assumes -- checked in
- * every launch; 0: always written through to the memory side). */
+ * every launch; 0: always written through to the memory side), "gemvt_reverse" (-1, the default: the transposed GEMV walks the
+ * columns from the last one down exactly when A is larger than the Infinity Cache -- the second product of a two-GEMV normal
+ * operator then starts on what the first one left in the cache; 0 / 1 force the direction; no bit of any result depends on it),
+ * "fista_defer" (1, the default: the matrix-free resident FISTA / OptISTA / POGM kernels sum ||res||^2 off the critical path
+ * where they can; 0: the block reduction in place -- the same bits either way). */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
 /* Device memory is STREAM-ORDERED on the context's stream (a private hipMemPool per device; RLS_ALLOC=sync or a device without
  * memory pools: hipMalloc / hipFree): rls_free does not wait for the stream, the block is reused behind everything enqueued on
