@@ -320,6 +320,8 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
     rls_normal_order_mode(value);
   } else if (!strcmp(key, "red_threads")) {
     rls_normal_red_threads(value);
+  } else if (!strcmp(key, "slab_multi")) {  // process-wide, like slab_g
+    rls_normal_slab_multi(value);
   } else if (!strcmp(key, "resident_barrier")) {
     rls_normal_resident_barrier(value);
   }

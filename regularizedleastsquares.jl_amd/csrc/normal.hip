@@ -55,10 +55,14 @@ constexpr int FIN_THREADS = 1024;  // the single-workgroup finish kernel
 // blocks b and b+8 are observed to share an XCD (speed only, never correctness): with 64-byte
 // row chunks (G = 4) two neighbouring row blocks split every 128-byte line, so give them to
 // blocks that share an L2.
+// pair: 0 = no, 1 = every block (the count is a multiple of 16), n > 1 = the first n blocks (n a multiple of 16; a ragged count's
+// last few blocks stay where they are -- without this a 516-block launch had every line fetched into two L2s: 62 us against 33).
 __device__ static inline int64_t row_block_of(int64_t b, int pair) {
-  if (!pair) return b;
+  if (!pair || (pair > 1 && b >= pair)) return b;
   return (b / 16) * 16 + (b % 8) * 2 + ((b / 8) % 2);
 }
+// the `pair` argument of the slab launches over nwg row blocks of G-lane row chunks
+static inline int slab_pairing(int G, int nwg) { return G != 4 ? 0 : (nwg % 16 == 0 ? 1 : (nwg / 16) * 16); }
 
 // sum over the G = 2/4/8 consecutive lanes of a group with DPP (full-rate VALU) instead of
 // ds_bpermute shuffles: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
@@ -244,6 +248,217 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
   }
 }
 
+// ---- several slabs per workgroup --------------------------------------------------------------------------------
+// A shape with more row blocks than the chip has CUs (8192 x 4096 Float32, BASELINE configs[2]: 512 blocks of 16 rows) used to
+// run as that many workgroups, one per CU at a time (a 128-register slab + 86 KiB of LDS): the second round started from
+// nothing when the first had drained -- another 3.5 us until loads are out, another 3.9 us of products with the memory system
+// idle.  Here ONE workgroup walks its row blocks itself: the second product of a block frees the slab registers chunk by
+// chunk, and every chunk is re-used at once for the same chunk of the NEXT block, so that block streams in under the
+// products of this one.  Block s of workgroup b is the block that workgroup s * gridDim.x + b of the one-slab launch owned
+// (so row_block_of still pairs the workgroups of an XCD that split 128-byte lines), the column sums of the blocks are added
+// in registers in that order and leave as ONE partial row per workgroup (the reduce kernel reads half as many).  Barriers
+// are LDS-only: a __syncthreads() would wait for the loads in flight.
+template <typename E, int G, int K, int WV, bool FULL>
+struct slab_walk {
+  using C = slab_cfg<E, G, K, WV>;
+  const char* base;
+  int64_t colstep;  // bytes between two columns CPR apart
+  uint32_t col_b;
+  // lane offsets of the current row block.  Ragged shapes: rounds before the last valid one (k < kl) take `off`, round kl clamps the
+  // slot to the last column (`off + off_l`), rounds past N re-read round 0 (`off + off_0`, zeroed where they are used) -- three
+  // registers and a scalar choice per load instead of a clamp per load (K of those, hoisted out of the block loop, spilled)
+  uint32_t off, off_l, off_0;
+  int slot, g, kl;
+  int64_t Mc, N;
+  int pair;
+  bool row_ok, dead_l;  // dead_l: this lane's column of round kl is past N
+  __device__ __forceinline__ void init(const E* A, int64_t lda, int64_t Mc_, int64_t N_, int pair_) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    g = lane % G;
+    slot = w * C::S + lane / G;
+    base = reinterpret_cast<const char*>(A);
+    col_b = (uint32_t)(lda * (int64_t)sizeof(E));
+    colstep = (int64_t)C::CPR * (lda * (int64_t)sizeof(E));
+    Mc = Mc_, N = N_, pair = pair_;
+    kl = (int)((N - 1) / C::CPR);
+    dead_l = kl * C::CPR + slot >= N;
+  }
+  __device__ __forceinline__ void aim(int64_t vb) {  // vb: the workgroup index of the one-slab launch that owned this block
+    const int64_t chunk_id = row_block_of(vb, pair) * G + g;
+    row_ok = chunk_id < Mc;
+    const uint32_t row_off = (uint32_t)((row_ok ? chunk_id : (Mc - 1)) * 16);
+    off = row_off + (uint32_t)slot * col_b;
+    if constexpr (!FULL) {
+      const int last = (int)N - 1 - kl * C::CPR;  // last valid slot of round kl
+      const int last0 = kl > 0 ? C::CPR - 1 : last;
+      off_l = (uint32_t)(slot < last ? slot : last) * col_b - (uint32_t)slot * col_b;  // differences to `off` (mod 2^32)
+      off_0 = (uint32_t)(slot < last0 ? slot : last0) * col_b - (uint32_t)slot * col_b;
+    }
+  }
+  __device__ __forceinline__ chunk<E, C::NV> load(int k) const {
+    if constexpr (FULL) {
+      return load_chunk<E, C::NV>(reinterpret_cast<const E*>(base + (int64_t)k * colstep + off));
+    } else {  // always-valid addresses, never a branch
+      int klo = kl;  // (opaque as well: K lane masks of comparisons against kl, hoisted, spill the scalar registers)
+      asm volatile("" : "+s"(klo));
+      const int kc = k <= klo ? k : 0;
+      // (a select between the three fields becomes an indexed load from the struct, which then lives in scratch: blend differences)
+      // and opaque copies: the differences do not change from block to block, so the K blended values would be hoisted out of the
+      // block loop as K live registers
+      uint32_t dl = off_l, d0 = off_0;
+      asm volatile("" : "+v"(dl), "+v"(d0));
+      const uint32_t o = off + (k == klo ? dl : 0u) + (k > klo ? d0 : 0u);
+      return load_chunk<E, C::NV>(reinterpret_cast<const E*>(base + (int64_t)kc * colstep + o));
+    }
+  }
+  __device__ __forceinline__ bool dead(int k, bool dead_rows) const {
+    int klo = kl;
+    asm volatile("" : "+s"(klo));
+    return dead_rows || k > klo || (k == klo && dead_l);
+  }
+};
+
+// one block: t_w = A_w xs, the block's contribution A_w^H t_w added to colsum[]; with RELOAD every chunk is re-loaded for
+// the block `W` aims at as soon as the second product has used it
+template <typename E, int G, int K, int WV, bool FULL, bool RELOAD>
+__device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L,
+                                        E (&colsum)[slab_cfg<E, G, K, WV>::EPT], bool dead_rows,
+                                        const slab_walk<E, G, K, WV, FULL>& W) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV;
+  // an opaque copy of the thread index per block: the LDS addresses of the planes beyond the 64 KiB immediate range are re-derived
+  // where they are used instead of being hoisted out of the block loop as 16 more live registers (the ComplexF32 forms sit at 256)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, w = tid >> 6;
+  const int g = lane % G, s = lane / G, slot = w * C::S + s;
+  lds_barrier();  // xs complete / the previous block's reads of xg, part, tw done
+  E acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = elem<E>::zero();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!FULL) {
+      if (W.dead(k, dead_rows)) a[k] = zero_chunk<E, NV>();
+    }
+    const E xv = L.xs[k * C::CPR + slot];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a[k].e[i], xv, acc[i]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float re, im = 0.f;
+      if (off == 8) {
+        re = elem<E>::re(acc[i]) + dpp_f(elem<E>::re(acc[i]), 0x128);
+        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + dpp_f(elem<E>::im(acc[i]), 0x128);
+      } else {
+        re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
+        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
+      }
+      acc[i] = elem<E>::make(re, im);
+    }
+  }
+  if (s == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
+  }
+  lds_barrier();
+  if (tid < G * NV) {
+    const int gg = tid / NV, i = tid % NV;
+    E sum = elem<E>::zero();
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+    L.tw[tid] = sum;
+  }
+  lds_barrier();
+  E tr[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tr[i] = L.tw[g * NV + i];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    // (with the re-loads in the loop a look-ahead of 8 hoists them over the products that still read the old chunks: both alive)
+    if (k % (RELOAD ? 2 : 8) == 0) __builtin_amdgcn_sched_barrier(0);
+    E q = elem<E>::zero();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q = elem<E>::fmac_pk(a[k].e[i], tr[i], q);
+    L.xg[g][k * C::CPR + slot] = q;
+    if constexpr (RELOAD) a[k] = W.load(k);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  lds_barrier();
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) {
+    const int c = tid + e * C::NT;
+    if (c < C::NMAX) {
+      E sum = L.xg[0][c];
+#pragma unroll
+      for (int gg = 1; gg < G; ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
+      colsum[e] = elem<E>::add(colsum[e], sum);
+    }
+  }
+}
+
+// with L.xs holding the input vector and a[] the first block of this workgroup (loaded through W): all its blocks, one partial row
+template <typename E, int G, int K, int WV, bool FULL>
+__device__ static __forceinline__ void slab_finish_multi(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L, E* __restrict__ slab,
+                                                slab_walk<E, G, K, WV, FULL>& W, int nblocks) {
+  using C = slab_cfg<E, G, K, WV>;
+  E colsum[C::EPT];
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) colsum[e] = elem<E>::zero();
+  int64_t vb = blockIdx.x;
+  bool dead_rows = !W.row_ok;
+  for (; vb + gridDim.x < nblocks; vb += gridDim.x) {
+    W.aim(vb + gridDim.x);
+    slab_pass<E, G, K, WV, FULL, true>(a, L, colsum, dead_rows, W);
+    dead_rows = !W.row_ok;
+  }
+  slab_pass<E, G, K, WV, FULL, false>(a, L, colsum, dead_rows, W);
+  E* out = slab + (int64_t)blockIdx.x * W.N;
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) {
+    const int c = threadIdx.x + e * C::NT;
+    if (c < W.N) out[c] = colsum[e];
+  }
+}
+
+template <typename E, int G, int K, int WV, bool FULL>
+__global__ __launch_bounds__(WV * 64) void normal_slab_multi_kernel(const E* __restrict__ A, int64_t lda,
+                                                                     const E* __restrict__ p, E* __restrict__ slab,
+                                                                     int64_t Mc, int64_t N, int pair, int nblocks,
+                                                                     const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  using C = slab_cfg<E, G, K, WV>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
+  E pv[C::EPT];
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) {
+    const int64_t i = threadIdx.x + (int64_t)e * C::NT;
+    pv[e] = p[i < N ? i : (N - 1)];
+    if (i >= N) pv[e] = elem<E>::zero();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  slab_walk<E, G, K, WV, FULL> W;
+  W.init(A, lda, Mc, N, pair);
+  W.aim(blockIdx.x);
+  chunk<E, C::NV> a[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) a[k] = W.load(k);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int e = 0; e < C::EPT; ++e) {
+    const int i = threadIdx.x + e * C::NT;
+    if (i < C::NMAX) L.xs[i] = pv[e];
+  }
+  slab_finish_multi<E, G, K, WV, FULL>(a, L, slab, W, nblocks);
+}
+
 template <typename E, int G, int K, int WV, bool FULL>
 __global__ __launch_bounds__(WV * 64) void normal_slab_kernel(const E* __restrict__ A, int64_t lda,
                                                                const E* __restrict__ p, E* __restrict__ slab,
@@ -423,11 +638,12 @@ __device__ __host__ constexpr bool pipe_wide() {
   return FULL && HINTED && (slab_cfg<E, G, K, WV>::EPT % elem<E>::vec == 0);
 }
 
-template <typename E, int G, int K, int WV, bool FULL, bool HINTED>
+template <typename E, int G, int K, int WV, bool FULL, bool HINTED, bool MULTI = false>
 __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L,
                                                pipe_small<E, slab_cfg<E, G, K, WV>::EPT>& sm, E* x, E* r0, E* p0,
                                                E* r1, E* p1, E* slab_b, const cgnr_scalars* sc_b, cgnr_scalars* scn_b,
-                                               int ndots, int64_t Mc, int64_t N, int64_t vo, int pair, int hint) {
+                                               int ndots, int64_t Mc, int64_t N, int64_t vo, int pair, int hint,
+                                               slab_walk<E, G, K, WV, FULL>* W = nullptr, int nblocks = 0) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int EPT = C::EPT;
   constexpr bool WIDE = pipe_wide<E, G, K, WV, FULL, HINTED>();
@@ -506,7 +722,8 @@ __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], s
     }
   }
   STAMP(3);
-  slab_finish<E, G, K, WV, FULL>(a, L, slab_b, Mc, N, pair);
+  if constexpr (MULTI) slab_finish_multi<E, G, K, WV, FULL>(a, L, slab_b, *W, nblocks);
+  else slab_finish<E, G, K, WV, FULL>(a, L, slab_b, Mc, N, pair);
   STAMP(7);
 }
 
@@ -519,13 +736,14 @@ struct pipe_rhs_ptrs {
   int hint;  // rls_cgnr_pipe::cur_hint
 };
 
-template <typename E, int G, int K, int WV, bool FULL, bool BATCHED, bool HINTED>
+// MULTI: gridDim.x < nblocks, every workgroup walks several row blocks (slab_finish_multi) and leaves one partial row
+template <typename E, int G, int K, int WV, bool FULL, bool BATCHED, bool HINTED, bool MULTI = false>
 __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* __restrict__ x,
                                                                E* r0, E* p0, E* r1, E* p1, const E* __restrict__ v,
                                                                E* __restrict__ slab, const double* __restrict__ dots,
                                                                int ndots, const cgnr_scalars* __restrict__ sc,
                                                                cgnr_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                               int pair, int order_mode, pipe_rhs_ptrs R) {
+                                                               int pair, int order_mode, pipe_rhs_ptrs R, int nblocks) {
   using C = slab_cfg<E, G, K, WV>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   slab_lds<E, G, K, WV>& L = *reinterpret_cast<slab_lds<E, G, K, WV>*>(smem_raw);
@@ -545,6 +763,18 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
   }
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, C::NV> a[K];
+  if constexpr (MULTI) {
+    static_assert(!BATCHED, "one right-hand side");
+    slab_walk<E, G, K, WV, FULL> W;
+    W.init(A, lda, Mc, N, pair);
+    W.aim(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = W.load(k);
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_process_rhs<E, G, K, WV, FULL, HINTED, true>(a, L, sm, x, r0, p0, r1, p1, slab, sc, scn, ndots, Mc, N, 0, pair, R.hint,
+                                                       &W, nblocks);
+    return;
+  }
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   STAMP(1);
@@ -817,14 +1047,14 @@ __device__ static inline bool fista_update_elems(const fista_scalars& S, const E
   return done != 0;
 }
 
-template <typename E, int G, int K, int WV, bool FULL, bool HINTED>
+template <typename E, int G, int K, int WV, bool FULL, bool HINTED, bool MULTI = false>
 __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
                                                                 const E* __restrict__ x0, E* __restrict__ res, E* y0,
                                                                 E* y1, const E* __restrict__ res_raw,
                                                                 E* __restrict__ slab,
                                                                 const fista_scalars* __restrict__ sc,
                                                                 fista_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                                int pair, int hint) {
+                                                                int pair, int hint, int nblocks) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int EPT = C::EPT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -855,7 +1085,15 @@ __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restri
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, C::NV> a[K];
-  slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
+  slab_walk<E, G, K, WV, FULL> W;  // MULTI only
+  if constexpr (MULTI) {
+    W.init(A, lda, Mc, N, pair);
+    W.aim(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = W.load(k);
+  } else {
+    slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
+  }
   __builtin_amdgcn_sched_barrier(0);
   fista_scalars S;
   RLS_FISTA_COPY(S, *sc);
@@ -929,7 +1167,8 @@ __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restri
       if (i < C::NMAX) L.xs[i] = yv[e];
     }
   }
-  slab_finish<E, G, K, WV, FULL>(a, L, slab, Mc, N, pair);
+  if constexpr (MULTI) slab_finish_multi<E, G, K, WV, FULL>(a, L, slab, W, nblocks);
+  else slab_finish<E, G, K, WV, FULL>(a, L, slab, Mc, N, pair);
 }
 
 // K_R of FISTA: res_raw = sum of the slab rows (fixed order) + commit of the staged scalars
@@ -3077,6 +3316,24 @@ static int g_force_wv = 0;
 static int g_order_mode = 1;  // 0: wait for the small loads, 1: barrier only (rls_tune_set "slab_order")
 static int g_resident_barrier = 2;  // matrix-free resident kernels' exchange: 2 = two-level where the grid allows (default), 1 = flat
 static int g_red_threads = 1024;  // reduce kernel: 16 columns x 64 row groups per workgroup (-1.0 us vs 256)
+static int g_slab_multi = 1;      // shapes with more row blocks than CUs: one workgroup walks several blocks (rls_tune_set "slab_multi")
+
+// workgroups (= partial rows) of a slab launch over `nwg` row blocks: the blocks themselves while they fit the chip's CUs, otherwise
+// one workgroup per CU (slab_finish_multi; K = 32 slabs only -- the smaller ones leave room for two workgroups per CU, which
+// overlap each other's streams by themselves)
+static int slab_grid(rls_ctx* ctx, int K, int nwg) {
+  if (!g_slab_multi || K != 32) return nwg;
+  static int cus_of[64] = {0};
+  const int d = ctx->device;
+  int cus = (d >= 0 && d < 64) ? cus_of[d] : 0;
+  if (!cus) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0) return nwg;
+    if (d >= 0 && d < 64) cus_of[d] = cus;
+  }
+  // one workgroup per CU; workgroup b walks blocks b, b + cus, b + 2 cus, ... (the last round may be a partial one: its few
+  // workgroups stream their extra block alone, at their CU's full rate)
+  return nwg <= cus ? nwg : cus;
+}
 
 // candidate slab shapes, smallest column capacity first; NMAX = K * WV * (64 / G).  (Rounds 1-2 also instantiated 16-wave
 // workgroups -- {8, 16, 16}, {4, 16, 16} -- for the measurement switch "slab_wv": at 128 VGPRs per lane every one of them
@@ -3125,23 +3382,41 @@ static void allow_big_lds(KernelT* k, size_t lds) {
 }
 
 template <typename E, int G, int K, int WV>
-static void launch_slab(rls_ctx* ctx, const E* A, int64_t lda, const E* p, E* slab, int64_t M, int64_t N, int nwg,
-                        const int* skip) {
+static int launch_slab(rls_ctx* ctx, const E* A, int64_t lda, const E* p, E* slab, int64_t M, int64_t N, int nwg,
+                       const int* skip) {
   using C = slab_cfg<E, G, K, WV>;
   const int64_t Mc = M / C::NV;
-  const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+  const int pair = slab_pairing(G, nwg);
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   static rls_device_once attr_once;  // per template instantiation and device
   if (attr_once.first(ctx->device)) {
     allow_big_lds(&normal_slab_kernel<E, G, K, WV, true>, lds);
     allow_big_lds(&normal_slab_kernel<E, G, K, WV, false>, lds);
+    if constexpr (K == 32) {
+      allow_big_lds(&normal_slab_multi_kernel<E, G, K, WV, true>, lds);
+      allow_big_lds(&normal_slab_multi_kernel<E, G, K, WV, false>, lds);
+    }
   }
-  if (N == C::NMAX && (int64_t)nwg * G == Mc)
+  const bool full = N == C::NMAX && (int64_t)nwg * G == Mc;
+  const int grid = slab_grid(ctx, K, nwg);
+  if constexpr (K == 32) {
+    if (grid < nwg) {  // several row blocks per workgroup: `grid` partial rows
+      if (full)
+        hipLaunchKernelGGL((normal_slab_multi_kernel<E, G, K, WV, true>), dim3(grid), dim3(C::NT), lds, ctx->stream, A, lda, p,
+                           slab, Mc, N, pair, nwg, skip);
+      else
+        hipLaunchKernelGGL((normal_slab_multi_kernel<E, G, K, WV, false>), dim3(grid), dim3(C::NT), lds, ctx->stream, A, lda, p,
+                           slab, Mc, N, pair, nwg, skip);
+      return grid;
+    }
+  }
+  if (full)
     hipLaunchKernelGGL((normal_slab_kernel<E, G, K, WV, true>), dim3(nwg), dim3(C::NT), lds, ctx->stream, A, lda, p,
                        slab, Mc, N, pair, skip);
   else
     hipLaunchKernelGGL((normal_slab_kernel<E, G, K, WV, false>), dim3(nwg), dim3(C::NT), lds, ctx->stream, A, lda, p,
                        slab, Mc, N, pair, skip);
+  return nwg;
 }
 
 static pipe_rhs_ptrs rhs_of(const rls_cgnr_pipe& P, int nwg) {
@@ -3153,11 +3428,12 @@ static pipe_rhs_ptrs rhs_of(const rls_cgnr_pipe& P, int nwg) {
   return R;
 }
 
+// `grid` < nwg: the MULTI instantiation (K = 32 only), `grid` workgroups walking the nwg row blocks
 template <typename E, int G, int K, int WV>
-static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
+static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg, int grid) {
   using C = slab_cfg<E, G, K, WV>;
   const int64_t Mc = P.M / C::NV;
-  const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+  const int pair = slab_pairing(G, nwg);
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   // ComplexF32 with 16 rows x 32 columns per workgroup (N in (2048, 4096]): the instantiation that loads BOTH (r, p) candidates
   // holds 6 x 8 owned elements beside a 128-register slab and spilled 28-36 B per lane.  It is not instantiated: a launch that
@@ -3172,6 +3448,14 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
     }
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, true>, lds);
     allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, true>, lds);
+    if constexpr (K == 32) {
+      if constexpr (!ALWAYS_HINTED) {
+        allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, false, true>, lds);
+        allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, false, true>, lds);
+      }
+      allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, true, true>, lds);
+      allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, true, true>, lds);
+    }
   }
   const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
   const bool batched = P.nrhs > 1;
@@ -3180,10 +3464,20 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
   const bool aligned = al16(P.r0) && al16(P.p0) && al16(P.r1) && al16(P.p1) && al16(P.v);
   const bool hinted = !batched && P.cur_hint >= 0 && aligned;
   pipe_rhs_ptrs R = rhs_of(P, nwg);
-#define RLS_LAUNCH_A(FULLV, BATCHV, HINTV)                                                                            \
-  hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV, HINTV>), dim3(nwg), dim3(C::NT), lds, ctx->stream, \
-                     (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, (E*)P.slab,   \
-                     P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, R)
+#define RLS_LAUNCH_A2(FULLV, BATCHV, HINTV, MULTIV)                                                                     \
+  hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV, HINTV, MULTIV>), dim3(MULTIV ? grid : nwg), dim3(C::NT),  \
+                     lds, ctx->stream, (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, \
+                     (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, R, nwg)
+#define RLS_LAUNCH_A(FULLV, BATCHV, HINTV)                      \
+  do {                                                          \
+    if constexpr (K == 32) {                                    \
+      if (grid < nwg) {                                         \
+        RLS_LAUNCH_A2(FULLV, BATCHV, HINTV, true);              \
+        break;                                                  \
+      }                                                         \
+    }                                                           \
+    RLS_LAUNCH_A2(FULLV, BATCHV, HINTV, false);                 \
+  } while (0)
   // (a BATCHED = true instantiation -- the slab kernel looping over several right-hand sides on the VALU -- existed until
   //  round 3 as the fallback of the matrix-core batched path; it spilled up to 528 bytes per lane and was four times slower
   //  per solve-iteration than the skinny kernels: shapes those do not cover now run one plan per column)
@@ -3199,6 +3493,7 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg) {
     else RLS_LAUNCH_A(false, false, false);
   }
 #undef RLS_LAUNCH_A
+#undef RLS_LAUNCH_A2
 }
 
 #define RLS_FOR_EACH_CFG(X) X(8, 8, 8) X(8, 16, 8) X(8, 32, 8) X(4, 32, 8)
@@ -3215,11 +3510,12 @@ static int32_t normal_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A, int6
   fused_cfg c;
   if (!pick_cfg<E>(N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "normal_fused: N too large for a register slab");
   const int nwg = (int)fused_nwg<E>(M, N);
+  int rows = nwg;  // partial rows the slab launch leaves
 #define RLS_SLAB_CASE(GG, KK, WW) \
-  if (c.G == GG && c.K == KK && c.WV == WW) launch_slab<E, GG, KK, WW>(ctx, A, lda, p, slab, M, N, nwg, skip);
+  if (c.G == GG && c.K == KK && c.WV == WW) rows = launch_slab<E, GG, KK, WW>(ctx, A, lda, p, slab, M, N, nwg, skip);
   RLS_FOR_EACH_CFG(RLS_SLAB_CASE)
 #undef RLS_SLAB_CASE
-  hipLaunchKernelGGL(slab_reduce_kernel<E>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, ctx->stream, slab, nwg, N,
+  hipLaunchKernelGGL(slab_reduce_kernel<E>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, ctx->stream, slab, rows, N,
                      v, skip);
   return launch_status(ctx);
 }
@@ -3229,15 +3525,16 @@ static int32_t pipe_iteration_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, int wh
   fused_cfg c;
   if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr pipeline: N too large");
   const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  const int rows = slab_grid(ctx, c.K, nwg);  // partial rows K_A leaves = its workgroups
 #define RLS_PIPE_CASE(GG, KK, WW) \
-  if (c.G == GG && c.K == KK && c.WV == WW) launch_pipe_a<E, GG, KK, WW>(ctx, P, nwg);
+  if (c.G == GG && c.K == KK && c.WV == WW) launch_pipe_a<E, GG, KK, WW>(ctx, P, nwg, rows);
   if (which & 1) {
     RLS_FOR_EACH_CFG(RLS_PIPE_CASE)
   }
 #undef RLS_PIPE_CASE
   if (which & 2)
     hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots, (unsigned)(P.nrhs > 0 ? P.nrhs : 1)),
-                       dim3(g_red_threads), 0, ctx->stream, (const E*)P.slab, nwg, P.N, (E*)P.v, (const E*)P.p0,
+                       dim3(g_red_threads), 0, ctx->stream, (const E*)P.slab, rows, P.N, (E*)P.v, (const E*)P.p0,
                        (const E*)P.p1, P.dots, P.sc, P.scn, rhs_of(P, nwg));
   return launch_status(ctx);
 }
@@ -3257,10 +3554,10 @@ static int32_t pipe_finish_typed(rls_ctx* ctx, const rls_cgnr_pipe& P) {
 }
 
 template <typename E, int G, int K, int WV>
-static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg) {
+static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg, int grid) {
   using C = slab_cfg<E, G, K, WV>;
   const int64_t Mc = P.M / C::NV;
-  const int pair = (G == 4 && nwg % 16 == 0) ? 1 : 0;
+  const int pair = slab_pairing(G, nwg);
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   static rls_device_once attr_once;
   if (attr_once.first(ctx->device)) {
@@ -3268,17 +3565,34 @@ static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg) {
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, false>, lds);
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, true>, lds);
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, true>, lds);
+    if constexpr (K == 32) {
+      allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, false, true>, lds);
+      allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, false, true>, lds);
+      allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, true, true>, lds);
+      allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, true, true>, lds);
+    }
   }
   const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
-#define RLS_LAUNCH_FA(FULLV, HINTV)                                                                                 \
-  hipLaunchKernelGGL((fista_pipe_a_kernel<E, G, K, WV, FULLV, HINTV>), dim3(nwg), dim3(C::NT), lds, ctx->stream,     \
-                     (const E*)P.A, P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1,      \
-                     (const E*)P.res_raw, (E*)P.slab, P.sc, P.scn, Mc, P.N, pair, P.par_hint)
+#define RLS_LAUNCH_FA2(FULLV, HINTV, MULTIV)                                                                              \
+  hipLaunchKernelGGL((fista_pipe_a_kernel<E, G, K, WV, FULLV, HINTV, MULTIV>), dim3(MULTIV ? grid : nwg), dim3(C::NT), lds,   \
+                     ctx->stream, (const E*)P.A, P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, \
+                     (const E*)P.res_raw, (E*)P.slab, P.sc, P.scn, Mc, P.N, pair, P.par_hint, nwg)
+#define RLS_LAUNCH_FA(FULLV, HINTV)                 \
+  do {                                              \
+    if constexpr (K == 32) {                        \
+      if (grid < nwg) {                             \
+        RLS_LAUNCH_FA2(FULLV, HINTV, true);         \
+        break;                                      \
+      }                                             \
+    }                                               \
+    RLS_LAUNCH_FA2(FULLV, HINTV, false);            \
+  } while (0)
   if (full && P.par_hint >= 0) RLS_LAUNCH_FA(true, true);
   else if (P.par_hint >= 0) RLS_LAUNCH_FA(false, true);
   else if (full) RLS_LAUNCH_FA(true, false);
   else RLS_LAUNCH_FA(false, false);
 #undef RLS_LAUNCH_FA
+#undef RLS_LAUNCH_FA2
 }
 
 template <typename E>
@@ -3286,12 +3600,13 @@ static int32_t fista_iteration_typed(rls_ctx* ctx, const rls_fista_pipe& P) {
   fused_cfg c;
   if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista pipeline: N too large");
   const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  const int rows = slab_grid(ctx, c.K, nwg);
 #define RLS_FISTA_CASE(GG, KK, WW) \
-  if (c.G == GG && c.K == KK && c.WV == WW) launch_fista_a<E, GG, KK, WW>(ctx, P, nwg);
+  if (c.G == GG && c.K == KK && c.WV == WW) launch_fista_a<E, GG, KK, WW>(ctx, P, nwg, rows);
   RLS_FOR_EACH_CFG(RLS_FISTA_CASE)
 #undef RLS_FISTA_CASE
   hipLaunchKernelGGL(fista_pipe_r_kernel<E>, dim3((unsigned)((P.N + 15) / 16)), dim3(g_red_threads), 0, ctx->stream,
-                     (const E*)P.slab, nwg, P.N, (E*)P.res_raw, P.sc, P.scn);
+                     (const E*)P.slab, rows, P.N, (E*)P.res_raw, P.sc, P.scn);
   return launch_status(ctx);
 }
 
@@ -3778,6 +4093,7 @@ void rls_normal_force_group(int g) { g_force_g = g; }
 void rls_normal_force_waves(int wv) { g_force_wv = wv; }
 void rls_normal_order_mode(int m) { g_order_mode = m; }
 void rls_normal_red_threads(int t) { g_red_threads = t; }
+void rls_normal_slab_multi(int on) { g_slab_multi = on ? 1 : 0; }
 void rls_normal_resident_barrier(int m) { g_resident_barrier = m == 1 ? 1 : 2; }
 
 #ifdef RLS_STAMPS

@@ -953,6 +953,7 @@ void rls_normal_force_group(int g);
 void rls_normal_force_waves(int wv);
 void rls_normal_order_mode(int m);
 void rls_normal_red_threads(int t);
+void rls_normal_slab_multi(int on);
 void rls_normal_resident_barrier(int m);
 size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,

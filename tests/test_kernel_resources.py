@@ -29,16 +29,18 @@ def kernels():
 # (config, regular expression on the demangled instantiation) -- what each BASELINE config launches on its default path
 BASELINE = [
     ("headline / configs[3] single solves: resident CGNR 4096x2048 CF32", r"cgnr_resident_kernel<c32, 8, 32, 8, 2, true>"),
-    ("headline on the two-launch pipeline", r"cgnr_pipe_a_kernel<c32, 8, 32, 8, true, false, (true|false)>"),
+    ("headline on the two-launch pipeline", r"cgnr_pipe_a_kernel<c32, 8, 32, 8, true, false, (true|false), false>"),
     ("headline on the two-launch pipeline", r"cgnr_pipe_r_kernel<c32>"),
     ("headline on the two-launch pipeline", r"cgnr_pipe_f_kernel<c32, \d+>"),
     ("configs[0]: CGNR 256x128 F32, single-workgroup kernel", r"cgnr_small_kernel<float, 8, 8>"),
-    ("configs[0] on the pipeline (small = 0)", r"cgnr_pipe_a_kernel<float, 8, 8, 8, (true|false), false, (true|false)>"),
+    ("configs[0] on the pipeline (small = 0)", r"cgnr_pipe_a_kernel<float, 8, 8, 8, (true|false), false, (true|false), false>"),
     ("configs[1]: FISTA + L1 4096x2048 CF32, resident", r"fista_resident_kernel<c32, 8, 32, 8, 2, true>"),
-    ("configs[1] on the pipeline", r"fista_pipe_a_kernel<c32, 8, 32, 8, true, (true|false)>"),
+    ("configs[1] on the pipeline", r"fista_pipe_a_kernel<c32, 8, 32, 8, true, (true|false), false>"),
     ("configs[1] shape, SURVEY 8f-1: OptISTA / POGM (2: with gradient restart) blocks of iterations as resident launches", r"pgm_resident_kernel<c32, 8, 32, 8, 2, true, (0|1|2)>"),
     ("configs[1] on the pipeline", r"fista_pipe_r_kernel<c32>"),
-    ("configs[2]: ADMM + TV 8192x4096 F32: cg! on the pipeline", r"cgnr_pipe_a_kernel<float, 4, 32, 8, true, false, (true|false)>"),
+    ("configs[2]: ADMM + TV 8192x4096 F32: cg! on the pipeline, 512 row blocks walked by 256 workgroups (last argument)", r"cgnr_pipe_a_kernel<float, 4, 32, 8, true, false, (true|false), true>"),
+    ("shapes with more row blocks than CUs: plain normal operator, FISTA", r"normal_slab_multi_kernel<(float|c32), \d, 32, 8, (true|false)>"),
+    ("shapes with more row blocks than CUs: plain normal operator, FISTA", r"fista_pipe_a_kernel<(float|c32), \d, 32, 8, (true|false), (true|false), true>"),
     ("configs[2]: cg! entry, z / u update", r"cg_pipe_start_kernel<float>"),
     ("configs[2]: cg! entry, z / u update", r"admm_zu_kernel<float>"),
     ("configs[2]: TV prox of a 64 x 64 image", r"fgp2d_kernel<float, 4>"),

@@ -38,6 +38,24 @@ if "pgm" in which:   # OptISTA / POGM on the configs[1] problem, 48
             print(f"{name} + L1 4096x2048 CF32, {'resident launches' if res else 'launch per iteration'}: {us:.2f} us/iteration "
                   f"(incl. init!; host wall {wall:.2f})")
     ctx.tune(resident=1)
+if "tall" in which:   # more row blocks than CUs (the slab kernels walk several blocks per workgroup; A/B with slab_multi=0)
+    for M, N, dt in ((8192, 4096, np.float32), (8192, 2048, np.complex64), (16384, 2048, np.complex64)):
+        A = make_A(M, N, 2, dt); Ad = rls.DeviceMatrix.from_host(A, ctx)
+        b = rls.DeviceVector.from_host((A @ np.ones(N, dt)).astype(dt), ctx)
+        tag = f"{M}x{N} {'CF32' if dt == np.complex64 else 'F32'}"
+        S = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+        for _ in range(5): rls.solve_(S, b)
+        ctx.sync(); ctx.timer_start()
+        for _ in range(20): rls.init_(S, b); ctx.lib.rls_cgnr_step(S.state._plan, 32)
+        us = ctx.timer_stop_ms() * 1e3 / (20 * 32)
+        print(f"CGNR {tag}: {us:.2f} us/iteration (32-iteration solves incl. init!)")
+        S = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2, iterations=50)
+        for _ in range(5): rls.solve_(S, b)
+        ctx.sync(); ctx.timer_start()
+        for _ in range(20): rls.init_(S, b); ctx.lib.rls_fista_step(S.state._plan, 50)
+        us = ctx.timer_stop_ms() * 1e3 / 1000
+        print(f"FISTA+L1 {tag}: {us:.2f} us/iteration (50-iteration solves incl. init!)")
+        del S, Ad
 if "admm" in which:
     M, N = 8192, 4096
     A = make_A(M, N, 3, np.float32); Ad = rls.DeviceMatrix.from_host(A, ctx)
