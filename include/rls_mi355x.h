@@ -79,7 +79,10 @@ int32_t rls_device_count(int32_t* out);
  * columns from the last one down exactly when A is larger than the Infinity Cache -- the second product of a two-GEMV normal
  * operator then starts on what the first one left in the cache; 0 / 1 force the direction; no bit of any result depends on it),
  * "fista_defer" (1, the default: the matrix-free resident FISTA / OptISTA / POGM kernels sum ||res||^2 off the critical path
- * where they can; 0: the block reduction in place -- the same bits either way). */
+ * where they can; 0: the block reduction in place -- the same bits either way).  Process-wide: "slab_multi" (1, the default: a shape
+ * with more row blocks than the device has CUs runs its one-pass kernels as one workgroup per CU that walks several blocks, the
+ * next one streaming in under the products of the current one; 0: one workgroup per block, in rounds -- the partial sums are
+ * added in a different order, so results differ in the last bits between the two settings, each being reproducible). */
 int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value);
 /* Device memory is STREAM-ORDERED on the context's stream (a private hipMemPool per device; RLS_ALLOC=sync or a device without
  * memory pools: hipMalloc / hipFree): rls_free does not wait for the stream, the block is reused behind everything enqueued on
