@@ -99,15 +99,43 @@ constexpr bool owner_cfg_ok() {
 // every lane stores its two-row (four-row for real) contribution to a column, one padded plane per
 // row chunk g (pad = 64 B so the G planes start on different banks: 2-way at worst on the store,
 // free; the column sums then read consecutive 8-byte words, conflict-free).
+// ComplexF32 with 64-byte row chunks (G = 4, N in (2048, 4096]): four planes of 4096 values + the input vector are 256 bytes MORE
+// than a CU's 160 KiB -- the shape class ran on the two-GEMV path until round 5.  Its lanes g and g ^ 1 are neighbours, so one
+// full-rate DPP add per component combines them before the store: two planes (slab_planes), half the LDS traffic of that phase.
+template <typename E, int G>
+__host__ __device__ constexpr int slab_planes() {
+  return (elem<E>::cplx && G == 4) ? 2 : G;
+}
 template <typename E, int G, int K, int WV>
 struct slab_lds {
   static constexpr int PAD = 64 / (int)sizeof(E);
-  E xg[G][slab_cfg<E, G, K, WV>::NMAX + PAD];
+  static constexpr int XP = slab_planes<E, G>();
+  E xg[XP][slab_cfg<E, G, K, WV>::NMAX + PAD];
   E xs[slab_cfg<E, G, K, WV>::NMAX];  // the GEMV input vector
   E part[WV][G][elem<E>::vec];
   E tw[G * elem<E>::vec];
   double red[48];
 };
+
+// the second product's contribution of this lane to column `col` goes to the exchange planes (see slab_lds / slab_planes)
+template <typename E, int G, int K, int WV>
+__device__ static __forceinline__ void slab_xg_store(slab_lds<E, G, K, WV>& L, int g, int col, E q) {
+  if constexpr (slab_planes<E, G>() < G) {
+    const float re = elem<E>::re(q) + dpp_f(elem<E>::re(q), 0xB1);  // quad_perm [1,0,3,2]: lane ^ 1
+    float im = 0.f;
+    if constexpr (elem<E>::cplx) im = elem<E>::im(q) + dpp_f(elem<E>::im(q), 0xB1);
+    if ((g & 1) == 0) L.xg[g >> 1][col] = elem<E>::make(re, im);
+  } else {
+    L.xg[g][col] = q;
+  }
+}
+template <typename E, int G, int K, int WV>
+__device__ static __forceinline__ E slab_xg_sum(const slab_lds<E, G, K, WV>& L, int c) {
+  E sum = L.xg[0][c];
+#pragma unroll
+  for (int gg = 1; gg < slab_planes<E, G>(); ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
+  return sum;
+}
 
 // Issue every load of the slab before anything waits.  Addresses are a wave-uniform 64-bit base per
 // load (SGPRs) plus ONE 32-bit lane offset shared by all K loads, so the K addresses cost a single
@@ -225,7 +253,7 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
       E q = elem<E>::zero();
 #pragma unroll
       for (int i = 0; i < NV; ++i) q = elem<E>::fmac_pk(a[k].e[i], tr[i], q);
-      L.xg[g][k * C::CPR + slot] = q;
+      slab_xg_store<E, G, K, WV>(L, g, k * C::CPR + slot, q);
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (HALVES > 1) lds_barrier();  // LDS only: the earlier parts' stores stay in flight
@@ -235,9 +263,7 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
     for (int e = h * (C::EPT / HALVES); e < (h + 1) * (C::EPT / HALVES); ++e) {
       const int c = tid + e * C::NT;
       if (c < C::NMAX) {
-        E sum = L.xg[0][c];
-#pragma unroll
-        for (int gg = 1; gg < G; ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
+        const E sum = slab_xg_sum<E, G, K, WV>(L, c);
         if constexpr (SC1) {
           if (c < N) sc1_store_elem<E>(out + c, sum);
         } else {
@@ -385,7 +411,7 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
     E q = elem<E>::zero();
 #pragma unroll
     for (int i = 0; i < NV; ++i) q = elem<E>::fmac_pk(a[k].e[i], tr[i], q);
-    L.xg[g][k * C::CPR + slot] = q;
+    slab_xg_store<E, G, K, WV>(L, g, k * C::CPR + slot, q);
     if constexpr (RELOAD) a[k] = W.load(k);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -394,10 +420,7 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
   for (int e = 0; e < C::EPT; ++e) {
     const int c = tid + e * C::NT;
     if (c < C::NMAX) {
-      E sum = L.xg[0][c];
-#pragma unroll
-      for (int gg = 1; gg < G; ++gg) sum = elem<E>::add(sum, L.xg[gg][c]);
-      colsum[e] = elem<E>::add(colsum[e], sum);
+      colsum[e] = elem<E>::add(colsum[e], slab_xg_sum<E, G, K, WV>(L, c));
     }
   }
 }
@@ -3347,8 +3370,9 @@ static bool pick_cfg(int64_t N, fused_cfg* c) {
     if (k.WV != wv) continue;
     if (g_force_g && k.G != g_force_g) continue;
     const int64_t nmax = (int64_t)k.K * k.WV * (64 / k.G);
-    // LDS image (slab_lds): G exchange planes + the input vector + small scratch must fit in 160 KiB
-    const int64_t lds = (k.G * (nmax + 64 / (int64_t)sizeof(E)) + nmax) * (int64_t)sizeof(E) + 4096;
+    // LDS image (slab_lds): the exchange planes + the input vector + small scratch must fit in 160 KiB
+    const int64_t planes = (elem<E>::cplx && k.G == 4) ? 2 : k.G;  // slab_planes
+    const int64_t lds = (planes * (nmax + 64 / (int64_t)sizeof(E)) + nmax) * (int64_t)sizeof(E) + 4096;
     if (N <= nmax && lds <= 160 * 1024) {
       *c = k;
       return true;
