@@ -14,7 +14,9 @@ reps = int(os.environ.get("REPS", 300))
 shapes = [(8192, 4096, "f"), (16384, 4096, "f"), (8192, 2048, "c"), (16384, 2048, "c"), (12288, 2048, "c"), (8192 + 64, 4096, "f"),
           (8192, 4000, "f"), (4096, 2048, "c"),
           # ComplexF32 with N in (2048, 4096]: on the two-GEMV path until the exchange planes of that layout fitted the LDS (round 5)
-          (4096, 4096, "c"), (2048, 4096, "c"), (3200, 3072, "c"), (8192, 4096, "c")]
+          (4096, 4096, "c"), (2048, 4096, "c"), (3200, 3072, "c"), (8192, 4096, "c"),
+          # ragged columns: the slab's column rounds past N re-read round 0
+          (8192, 3072, "f"), (8192, 1536, "c"), (16384, 1280, "c")]
 for M, N, t in shapes:
     dt = np.complex64 if t == "c" else np.float32
     A = make_A(M, N, 2, dt)
@@ -37,13 +39,13 @@ for M, N, t in shapes:
             us = ctx.timer_stop_ms() / reps * 1e3
             out.setdefault(multi, []).append((us, err))
             del op
-    if t == "c" and N > 2048:
+    if (t == "c" and N > 2048) or N % 1024:
         ctx.tune(fused_normal=0)
         op = rls.OperatorHandle(Ad)
         for _ in range(10): op.mul_normal_(v, p)
         ctx.sync(); ctx.timer_start()
         for _ in range(reps): op.mul_normal_(v, p)
-        print(f"{M}x{N} {t}32 two GEMVs (the path of this shape class before): {ctx.timer_stop_ms() / reps * 1e3:.2f} us per apply", flush=True)
+        print(f"{M}x{N} {t}32 two GEMVs: {ctx.timer_stop_ms() / reps * 1e3:.2f} us per apply", flush=True)
         ctx.tune(fused_normal=1)
         del op
     for multi in (0, 1):
