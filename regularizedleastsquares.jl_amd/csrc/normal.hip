@@ -349,7 +349,8 @@ struct slab_walk {
 template <typename E, int G, int K, int WV, bool FULL, bool RELOAD>
 __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L,
                                         E (&colsum)[slab_cfg<E, G, K, WV>::EPT], bool dead_rows,
-                                        const slab_walk<E, G, K, WV, FULL>& W) {
+                                        const slab_walk<E, G, K, WV, FULL>& W, int stamp_base = 8) {
+  (void)stamp_base;  // -DRLS_STAMPS only (tools/stamps_walk.py): slots stamp_base .. +3 = first product done, t_w known, second product done, column sums done
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV;
   // an opaque copy of the thread index per block: the LDS addresses of the planes beyond the 64 KiB immediate range are re-derived
@@ -373,6 +374,7 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
     for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a[k].e[i], xv, acc[i]);
   }
   __builtin_amdgcn_sched_barrier(0);
+  STAMP(stamp_base);
 #pragma unroll
   for (int off = G; off < 64; off <<= 1) {
 #pragma unroll
@@ -401,6 +403,7 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
     L.tw[tid] = sum;
   }
   lds_barrier();
+  STAMP(stamp_base + 1);
   E tr[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) tr[i] = L.tw[g * NV + i];
@@ -415,6 +418,7 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
     if constexpr (RELOAD) a[k] = W.load(k);
   }
   __builtin_amdgcn_sched_barrier(0);
+  STAMP(stamp_base + 2);
   lds_barrier();
 #pragma unroll
   for (int e = 0; e < C::EPT; ++e) {
@@ -423,6 +427,7 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
       colsum[e] = elem<E>::add(colsum[e], slab_xg_sum<E, G, K, WV>(L, c));
     }
   }
+  STAMP(stamp_base + 3);
 }
 
 // with L.xs holding the input vector and a[] the first block of this workgroup (loaded through W): all its blocks, one partial row
@@ -437,10 +442,10 @@ __device__ static __forceinline__ void slab_finish_multi(chunk<E, elem<E>::vec> 
   bool dead_rows = !W.row_ok;
   for (; vb + gridDim.x < nblocks; vb += gridDim.x) {
     W.aim(vb + gridDim.x);
-    slab_pass<E, G, K, WV, FULL, true>(a, L, colsum, dead_rows, W);
+    slab_pass<E, G, K, WV, FULL, true>(a, L, colsum, dead_rows, W, 8);
     dead_rows = !W.row_ok;
   }
-  slab_pass<E, G, K, WV, FULL, false>(a, L, colsum, dead_rows, W);
+  slab_pass<E, G, K, WV, FULL, false>(a, L, colsum, dead_rows, W, 12);
   E* out = slab + (int64_t)blockIdx.x * W.N;
 #pragma unroll
   for (int e = 0; e < C::EPT; ++e) {
