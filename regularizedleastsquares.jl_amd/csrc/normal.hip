@@ -1331,7 +1331,53 @@ __device__ static inline void gram_rows(chunk<E, elem<E>::vec> (&a)[K], gram_lds
   __syncthreads();
 }
 
-template <typename E, int G, int K, int WV, bool FULL>
+// the same for a workgroup that walks several row blocks of AHA (more blocks than CUs: ComplexF32 with N in (2048, 4096] has 512 of
+// them): `a` holds the block W was aimed at BEFORE its last aim(); with RELOAD every chunk is re-requested for the block W aims at
+// now as soon as the product has used it -- the single product is the last reader of the slab registers here (section 4.1b of DESIGN)
+template <typename E, int G, int K, int WV, bool FULL, bool RELOAD>
+__device__ static __forceinline__ void gram_rows_walk(chunk<E, elem<E>::vec> (&a)[K], gram_lds<E, G, K, WV>& L, bool dead_rows,
+                                                      const slab_walk<E, G, K, WV, FULL>& W) {
+  using C = slab_cfg<E, G, K, WV>;
+  constexpr int NV = C::NV;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, w = tid >> 6;
+  const int g = lane % G, s = lane / G, slot = w * C::S + s;
+  lds_barrier();  // xs complete / the previous block's reads of part done (LDS only: the loads in flight stay in flight)
+  E acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = elem<E>::zero();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k % (RELOAD ? 2 : 8) == 0) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!FULL) {
+      if (W.dead(k, dead_rows)) a[k] = zero_chunk<E, NV>();
+    }
+    const E xe = L.xs[k * C::CPR + slot];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = elem<E>::fma_pk(a[k].e[i], xe, acc[i]);
+    if constexpr (RELOAD) a[k] = W.load(k);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
+      float im = 0.f;
+      if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
+      acc[i] = elem<E>::make(re, im);
+    }
+  }
+  if (s == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
+  }
+  lds_barrier();
+}
+
+// MULTI: gridDim.x < nblocks, every workgroup walks several row blocks of AHA (gram_rows_walk) and leaves ONE set of partial dots
+template <typename E, int G, int K, int WV, bool FULL, bool MULTI = false>
 __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict__ Gm, int64_t ldg, E* __restrict__ x,
                                                             const E* __restrict__ rc, const E* __restrict__ pc,
                                                             E* __restrict__ rn_out, E* __restrict__ pn_out,
@@ -1339,7 +1385,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
                                                             const double* __restrict__ dc, double* __restrict__ dn,
                                                             int ndots, const cgnr_scalars* __restrict__ sc,
                                                             cgnr_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                            int pair, int order_mode) {
+                                                            int pair, int order_mode, int nblocks) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT;
   __shared__ gram_lds<E, G, K, WV> L;
@@ -1368,7 +1414,15 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
   }
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, NV> a[K];
-  slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
+  slab_walk<E, G, K, WV, FULL> W;  // MULTI only
+  if constexpr (MULTI) {
+    W.init(Gm, ldg, Mc, N, pair);
+    W.aim(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = W.load(k);
+  } else {
+    slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
+  }
   __builtin_amdgcn_sched_barrier(0);
   if (tid >= ndots) d0 = d1 = d2 = 0.0;
   const cgnr_scalars S = *sc;
@@ -1437,22 +1491,40 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
       if (i < C::NMAX) L.xs[i] = pv[e];
     }
   }
-  gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
-  // thread t < G*NV owns row (first chunk of the workgroup) * NV + t: its v entry and its term of the dots
+  // thread t < G*NV owns row (first chunk of the block) * NV + t: its v entry and its term of the dots (added up over the blocks of a
+  // walking workgroup in the order they are walked)
   double dre = 0.0, dim_ = 0.0, pp = 0.0;
-  if (tid < G * NV) {
-    const int gg = tid / NV, i = tid % NV;
-    E sum = elem<E>::zero();
+  auto row_terms = [&](int64_t vb) {
+    if (tid < G * NV) {
+      const int gg = tid / NV, i = tid % NV;
+      E sum = elem<E>::zero();
 #pragma unroll
-    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
-    const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
-    if (row < N) {
-      vn[row] = sum;
-      const E pj = L.xs[row];
-      dre = (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
-      dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
-      pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+      for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+      const int64_t row = (row_block_of(vb, pair) * G + gg) * NV + i;
+      if (row < N) {
+        vn[row] = sum;
+        const E pj = L.xs[row];
+        dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
+        dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
+        pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
+      }
     }
+  };
+  if constexpr (MULTI) {
+    int64_t vb = blockIdx.x;
+    const int64_t gs = gridDim.x;
+    bool dead_rows = !W.row_ok;
+    for (; vb + gs < nblocks; vb += gs) {
+      W.aim(vb + gs);
+      gram_rows_walk<E, G, K, WV, FULL, true>(a, L, dead_rows, W);
+      dead_rows = !W.row_ok;
+      row_terms(vb);
+    }
+    gram_rows_walk<E, G, K, WV, FULL, false>(a, L, dead_rows, W);
+    row_terms(vb);
+  } else {
+    gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
+    row_terms(blockIdx.x);
   }
   if (w == 0) {  // G*NV <= 16 lanes of wave 0 hold the terms; fixed-order butterfly
 #pragma unroll
@@ -1534,14 +1606,14 @@ __global__ __launch_bounds__(FIN_THREADS) void cgnr_gram_f_kernel(E* __restrict_
 
 // ---- Gram-mode FISTA: the same one-launch scheme (src/FISTA.jl:139-185 with AHA explicit, :58) ----
 // res_raw = AHA y exists in two parities; x / xold and y keep their own ping-pong (iteration parity, ycur).
-template <typename E, int G, int K, int WV, bool FULL, bool HINTED>
+template <typename E, int G, int K, int WV, bool FULL, bool HINTED, bool MULTI = false>
 __global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
                                                              const E* __restrict__ x0, E* __restrict__ res, E* y0,
                                                              E* y1, const E* __restrict__ rr_cur,
                                                              E* __restrict__ rr_next,
                                                              const fista_scalars* __restrict__ sc,
                                                              fista_scalars* __restrict__ scn, int64_t Mc, int64_t N,
-                                                             int pair, int hint) {
+                                                             int pair, int hint, int nblocks) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT;
   __shared__ gram_lds<E, G, K, WV> L;
@@ -1573,7 +1645,15 @@ __global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   chunk<E, NV> a[K];
-  slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
+  slab_walk<E, G, K, WV, FULL> W;  // MULTI only
+  if constexpr (MULTI) {
+    W.init(Gm, ldg, Mc, N, pair);
+    W.aim(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = W.load(k);
+  } else {
+    slab_load<E, G, K, WV, FULL>(a, Gm, ldg, Mc, N, pair);
+  }
   __builtin_amdgcn_sched_barrier(0);
   // No early return below: every path reaches the row product, so the compiler cannot sink part of the
   // slab loads under a branch (it did: 23 us per launch instead of 8); `active` guards the stores instead.
@@ -1647,14 +1727,31 @@ __global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict
       if (i < C::NMAX) L.xs[i] = yv[e];
     }
   }
-  gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
-  if (active && tid < G * NV) {
-    const int gg = tid / NV, i = tid % NV;
-    E sum = elem<E>::zero();
+  auto row_out = [&](int64_t vb) {
+    if (active && tid < G * NV) {
+      const int gg = tid / NV, i = tid % NV;
+      E sum = elem<E>::zero();
 #pragma unroll
-    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
-    const int64_t row = (row_block_of(blockIdx.x, pair) * G + gg) * NV + i;
-    if (row < N) rr_next[row] = sum;
+      for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
+      const int64_t row = (row_block_of(vb, pair) * G + gg) * NV + i;
+      if (row < N) rr_next[row] = sum;
+    }
+  };
+  if constexpr (MULTI) {
+    int64_t vb = blockIdx.x;
+    const int64_t gs = gridDim.x;
+    bool dead_rows = !W.row_ok;
+    for (; vb + gs < nblocks; vb += gs) {
+      W.aim(vb + gs);
+      gram_rows_walk<E, G, K, WV, FULL, true>(a, L, dead_rows, W);
+      dead_rows = !W.row_ok;
+      row_out(vb);
+    }
+    gram_rows_walk<E, G, K, WV, FULL, false>(a, L, dead_rows, W);
+    row_out(vb);
+  } else {
+    gram_rows<E, G, K, WV, FULL>(a, L, Mc, N, pair);
+    row_out(blockIdx.x);
   }
 }
 
@@ -3665,20 +3762,39 @@ static bool gram_pick(int64_t N, int* K) {  // G = 4 (64-byte row pieces: 8 / 16
   return false;
 }
 
+// workgroups of a Gram pipeline launch over nwg row blocks (= partial dots it leaves): see slab_grid
+template <typename E>
+static int gram_grid(rls_ctx* ctx, int K, int nwg) {
+  return elem<E>::cplx ? slab_grid(ctx, K, nwg) : nwg;
+}
+
 template <typename E, int K>
 static void launch_gram(rls_ctx* ctx, const rls_gram_pipe& P, int q, int nwg) {
   using C = slab_cfg<E, 4, K, 8>;
   const int64_t Mc = P.N / C::NV;
-  const int pair = (nwg % 16 == 0) ? 1 : 0;
+  const int pair = slab_pairing(4, nwg);
   const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
-#define RLS_LAUNCH_G(FULLV)                                                                                          \
-  hipLaunchKernelGGL((cgnr_gram_kernel<E, 4, K, 8, FULLV>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G,    \
-                     P.ldg, (E*)P.x, (const E*)P.r[q], (const E*)P.p[q], (E*)P.r[q ^ 1], (E*)P.p[q ^ 1],               \
-                     (const E*)P.v[q], (E*)P.v[q ^ 1], P.dots + (size_t)q * 4 * nwg, P.dots + (size_t)(q ^ 1) * 4 * nwg, \
-                     nwg, P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, g_order_mode)
+  const int grid = gram_grid<E>(ctx, K, nwg);
+#define RLS_LAUNCH_G2(FULLV, MULTIV)                                                                                         \
+  hipLaunchKernelGGL((cgnr_gram_kernel<E, 4, K, 8, FULLV, MULTIV>), dim3(MULTIV ? grid : nwg), dim3(C::NT), 0, ctx->stream,   \
+                     (const E*)P.G, P.ldg, (E*)P.x, (const E*)P.r[q], (const E*)P.p[q], (E*)P.r[q ^ 1], (E*)P.p[q ^ 1],        \
+                     (const E*)P.v[q], (E*)P.v[q ^ 1], P.dots + (size_t)q * 4 * nwg, P.dots + (size_t)(q ^ 1) * 4 * nwg,       \
+                     MULTIV ? grid : nwg, P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, g_order_mode, nwg)
+  // (Float32: N <= 4096 is at most 256 blocks of 16 rows -- nothing to walk, the instantiations would be dead code)
+#define RLS_LAUNCH_G(FULLV)               \
+  do {                                    \
+    if constexpr (K == 32 && elem<E>::cplx) { \
+      if (grid < nwg) {                   \
+        RLS_LAUNCH_G2(FULLV, true);       \
+        break;                            \
+      }                                   \
+    }                                     \
+    RLS_LAUNCH_G2(FULLV, false);          \
+  } while (0)
   if (full) RLS_LAUNCH_G(true);
   else RLS_LAUNCH_G(false);
 #undef RLS_LAUNCH_G
+#undef RLS_LAUNCH_G2
 }
 
 template <typename E>
@@ -3695,11 +3811,14 @@ static int32_t gram_iteration_typed(rls_ctx* ctx, const rls_gram_pipe& P, int q)
 template <typename E>
 static int32_t gram_finish_typed(rls_ctx* ctx, const rls_gram_pipe& P, int q) {
   const int nwg = rls_gram_pipe_nwg(elem<E>::cplx ? RLS_C32 : RLS_F32, P.N);
+  int Kp = 0;
+  gram_pick<E>(P.N, &Kp);
+  const int ndots = gram_grid<E>(ctx, Kp, nwg);  // what the last iteration's launch left (launch_gram)
   const int ept = (int)((P.N + FIN_THREADS - 1) / FIN_THREADS);
 #define RLS_GFIN_CASE(EE)                                                                                           \
   hipLaunchKernelGGL((cgnr_gram_f_kernel<E, EE>), dim3(1), dim3(FIN_THREADS), 0, ctx->stream, (E*)P.x,               \
                      (const E*)P.r[q], (const E*)P.p[q], (E*)P.r[0], (E*)P.p[0], (const E*)P.v[q], (E*)P.v[0],       \
-                     P.dots + (size_t)q * 4 * nwg, nwg, P.sc[q], P.sc[0], P.sc[1], P.N)
+                     P.dots + (size_t)q * 4 * nwg, ndots, P.sc[q], P.sc[0], P.sc[1], P.N)
   if (ept <= 1) RLS_GFIN_CASE(1);
   else if (ept <= 2) RLS_GFIN_CASE(2);
   else RLS_GFIN_CASE(4);
@@ -3711,17 +3830,29 @@ template <typename E, int K>
 static void launch_fista_gram(rls_ctx* ctx, const rls_fista_gram& P, int q, int nwg) {
   using C = slab_cfg<E, 4, K, 8>;
   const int64_t Mc = P.N / C::NV;
-  const int pair = (nwg % 16 == 0) ? 1 : 0;
+  const int pair = slab_pairing(4, nwg);
   const bool full = P.N == C::NMAX && (int64_t)nwg * 4 == Mc;
-#define RLS_LAUNCH_FG(FULLV, HINTV)                                                                                 \
-  hipLaunchKernelGGL((fista_gram_kernel<E, 4, K, 8, FULLV, HINTV>), dim3(nwg), dim3(C::NT), 0, ctx->stream,          \
-                     (const E*)P.G, P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1,         \
-                     (const E*)P.rr[q], (E*)P.rr[q ^ 1], P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, P.par_hint)
+  const int grid = gram_grid<E>(ctx, K, nwg);
+#define RLS_LAUNCH_FG2(FULLV, HINTV, MULTIV)                                                                                  \
+  hipLaunchKernelGGL((fista_gram_kernel<E, 4, K, 8, FULLV, HINTV, MULTIV>), dim3(MULTIV ? grid : nwg), dim3(C::NT), 0,         \
+                     ctx->stream, (const E*)P.G, P.ldg, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1,    \
+                     (const E*)P.rr[q], (E*)P.rr[q ^ 1], P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, P.par_hint, nwg)
+#define RLS_LAUNCH_FG(FULLV, HINTV)             \
+  do {                                          \
+    if constexpr (K == 32 && elem<E>::cplx) {   \
+      if (grid < nwg) {                         \
+        RLS_LAUNCH_FG2(FULLV, HINTV, true);     \
+        break;                                  \
+      }                                         \
+    }                                           \
+    RLS_LAUNCH_FG2(FULLV, HINTV, false);        \
+  } while (0)
   if (full && P.par_hint >= 0) RLS_LAUNCH_FG(true, true);
   else if (P.par_hint >= 0) RLS_LAUNCH_FG(false, true);
   else if (full) RLS_LAUNCH_FG(true, false);
   else RLS_LAUNCH_FG(false, false);
 #undef RLS_LAUNCH_FG
+#undef RLS_LAUNCH_FG2
 }
 
 template <typename E>

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import rls_oracle as O
+from conftest import parity_check as parity
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -133,3 +134,55 @@ def test_fista_l1_on_the_pipeline_walking_row_blocks(rls, ctx, dt, M, N):
     finally:
         ctx.tune(slab_multi=1)
     assert rel(got[1], got[0]) < 2e-6
+
+
+# Gram mode (AHA explicit, the reference constructors' default operator for a dense matrix): ComplexF32 with N in (2048, 4096] has
+# more 8-row blocks of AHA than the chip has CUs -- cgnr_gram_kernel / fista_gram_kernel walk them (gram_rows_walk, normal.hip)
+GRAM = [(np.complex64, 600, 4096), (np.complex64, 500, 3072), (np.complex64, 400, 2400)]
+
+
+@pytest.mark.parametrize("dt,M,N", GRAM)
+def test_gram_mode_pipeline_walking_row_blocks(rls, ctx, dt, M, N):
+    """CGNR (x, alpha, beta) and FISTA + L1 on the explicit Gram matrix against the float64 oracle and against one workgroup per block"""
+    A, b = _problem(dt, M, N, 11 * M + N)
+    A64, b64 = A.astype(hi(dt)), b.astype(hi(dt))
+    Ad = rls.DeviceMatrix.from_host(A)
+    Gd = Ad.gram()
+    lam = 1e-2
+    v = np.ones(N, hi(dt))
+    for _ in range(30):
+        v = A64.conj().T @ (A64 @ v)
+        ev = np.linalg.norm(v)
+        v /= ev
+    lam1 = 1e-2 * float(np.max(np.abs(A64.conj().T @ b64)))
+    got = {}
+    try:
+        for multi in (1, 0):
+            ctx.tune(slab_multi=multi, resident=0)
+            for iters in (1, 4, 9):
+                ref = O.CGNR(A64, reg=O.L2Regularization(lam), iterations=iters, relTol=0.0, normal="gram")
+                O.solve(ref, b64)
+                sol = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, reg=rls.L2Regularization(lam), iterations=iters, relTol=0.0)
+                x = rls.solve_(sol, rls.DeviceVector.from_host(b)).to_host()
+                assert sol.state.iteration == iters
+                assert rel(x, ref.x) < TOL, (multi, iters, rel(x, ref.x))
+                sol.state._refresh(ctx.lib)
+                assert abs(sol.state.alphal - ref.alpha) < 1e-5 * abs(ref.alpha), (multi, iters)
+                got["cgnr", multi, iters] = x
+            reff = O.FISTA(A64, reg=O.L1Regularization(lam1), rho=0.9 / ev, iterations=12, normal="gram", restart="gradient")
+            O.solve(reff, b64)
+            solf = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(lam1), rho=0.9 / ev, iterations=12, restart="gradient")
+            xf = rls.solve_(solf, rls.DeviceVector.from_host(b)).to_host()
+            # M < N: AHA has rank M, and it was formed in Float32 -- the gate is the usual one (1e-5 against float64, or twice what the
+            # oracle itself loses when it runs in the working precision: conftest.parity_check)
+            def f32_run():
+                r32 = O.FISTA(A, reg=O.L1Regularization(np.float32(lam1)), rho=np.float32(0.9 / ev), iterations=12, normal="gram",
+                              restart="gradient")
+                O.solve(r32, b)
+                return r32.x
+            parity(f"gram walk fista {M}x{N} multi={multi}", xf, reff.x, f32_run)
+            got["fista", multi] = xf
+    finally:
+        ctx.tune(slab_multi=1, resident=1)
+    assert rel(got["cgnr", 1, 9], got["cgnr", 0, 9]) < 2e-6
+    assert rel(got["fista", 1], got["fista", 0]) < 2e-6

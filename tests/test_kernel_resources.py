@@ -39,6 +39,7 @@ BASELINE = [
     ("configs[1] shape, SURVEY 8f-1: OptISTA / POGM (2: with gradient restart) blocks of iterations as resident launches", r"pgm_resident_kernel<c32, 8, 32, 8, 2, true, (0|1|2)>"),
     ("configs[1] on the pipeline", r"fista_pipe_r_kernel<c32>"),
     ("configs[2]: ADMM + TV 8192x4096 F32: cg! on the pipeline, 512 row blocks walked by 256 workgroups (last argument)", r"cgnr_pipe_a_kernel<float, 4, 32, 8, true, false, (true|false), true>"),
+    ("Gram mode, ComplexF32 N in (2048, 4096]: 512 row blocks of AHA walked", r"(cgnr|fista)_gram_kernel<c32, 4, 32, 8, (true|false), ((true|false), )?true>"),
     ("shapes with more row blocks than CUs: plain normal operator, FISTA", r"normal_slab_multi_kernel<(float|c32), \d, 32, 8, (true|false)>"),
     ("shapes with more row blocks than CUs: plain normal operator, FISTA", r"fista_pipe_a_kernel<(float|c32), \d, 32, 8, (true|false), (true|false), true>"),
     ("configs[2]: cg! entry, z / u update", r"cg_pipe_start_kernel<float>"),
