@@ -999,30 +999,20 @@ __global__ __launch_bounds__(FIN_THREADS) void cgnr_pipe_f_kernel(E* __restrict_
   if (tid < 64) rls_mailbox_publish(mb, Sn, tid);
 }
 
-// v[j] = sum_w slab[w][j] in a fixed order: 16 columns per workgroup, 16 row groups per column
+// v[j] = sum_w slab[w][j] in a fixed order: 16 columns per workgroup, blockDim.x / 16 row groups per column -- the loads and the
+// combine of cgnr_pipe_r_kernel (every partial row of a thread requested with the first instructions; round 5: this kernel summed
+// 16 rows per thread in a two-load loop with 256 threads and took 4.9 us where K_R, which does more, takes 3.0)
 template <typename E>
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const E* __restrict__ slab, int nwg, int64_t N,
-                                                          E* __restrict__ v, const int* __restrict__ skip) {
-  if (skip && *skip) return;
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const E* __restrict__ slab, int nwg, int64_t N,
+                                                           E* __restrict__ v, const int* __restrict__ skip) {
   __shared__ E sm[16][16];
-  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16;
+  const int cx = threadIdx.x % 16, wy = threadIdx.x / 16, ny = blockDim.x / 16;
   const int64_t j = (int64_t)blockIdx.x * 16 + cx;
   const int64_t jc = j < N ? j : (N - 1);
-  E s0 = elem<E>::zero(), s1 = elem<E>::zero();
-  int wgi = wy;
-  for (; wgi + 16 < nwg; wgi += 32) {  // two independent chains keep more loads in flight
-    s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
-    s1 = elem<E>::add(s1, slab[(int64_t)(wgi + 16) * N + jc]);
-  }
-  if (wgi < nwg) s0 = elem<E>::add(s0, slab[(int64_t)wgi * N + jc]);
-  sm[wy][cx] = elem<E>::add(s0, s1);
-  __syncthreads();
-  if (wy == 0 && j < N) {
-    E t = elem<E>::zero();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t = elem<E>::add(t, sm[i][cx]);
-    v[j] = t;
-  }
+  const E sum = slab_column_sum<E>(slab, nwg, N, jc, wy, ny);  // (requested before `skip` is looked at: it only gates the store)
+  const bool off = skip && *skip;
+  const E t = slab_group_combine<E>(sum, sm);
+  if (threadIdx.x < 16 && j < N && !off) v[j] = t;
 }
 
 // ---- FISTA pipeline: iteration = K_A (previous gradient/prox/momentum update + one pass over A) + K_R --
@@ -3641,7 +3631,7 @@ static int32_t normal_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A, int6
   if (c.G == GG && c.K == KK && c.WV == WW) rows = launch_slab<E, GG, KK, WW>(ctx, A, lda, p, slab, M, N, nwg, skip);
   RLS_FOR_EACH_CFG(RLS_SLAB_CASE)
 #undef RLS_SLAB_CASE
-  hipLaunchKernelGGL(slab_reduce_kernel<E>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, ctx->stream, slab, rows, N,
+  hipLaunchKernelGGL(slab_reduce_kernel<E>, dim3((unsigned)((N + 15) / 16)), dim3(g_red_threads), 0, ctx->stream, slab, rows, N,
                      v, skip);
   return launch_status(ctx);
 }
