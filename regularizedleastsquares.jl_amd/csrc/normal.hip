@@ -102,9 +102,12 @@ constexpr bool owner_cfg_ok() {
 // ComplexF32 with 64-byte row chunks (G = 4, N in (2048, 4096]): four planes of 4096 values + the input vector are 256 bytes MORE
 // than a CU's 160 KiB -- the shape class ran on the two-GEMV path until round 5.  Its lanes g and g ^ 1 are neighbours, so one
 // full-rate DPP add per component combines them before the store: two planes (slab_planes), half the LDS traffic of that phase.
+// The 128-byte layouts (G = 8) do the same -- four planes: the phase is LDS-bound, measured -0.4 us per CGNR iteration on the
+// pipeline at 4096 x 2048 ComplexF32, -0.8 us per plain apply, -0.6 us per iteration of the Float32 resident kernel at N = 2048;
+// Float32 with G = 4 keeps its four planes (two were 0.5 us SLOWER per apply at 8192 x 4096: one float per lane is too little to pair).
 template <typename E, int G>
 __host__ __device__ constexpr int slab_planes() {
-  return (elem<E>::cplx && G == 4) ? 2 : G;
+  return G == 8 ? 4 : (elem<E>::cplx && G == 4) ? 2 : G;
 }
 template <typename E, int G, int K, int WV>
 struct slab_lds {
@@ -3463,7 +3466,7 @@ static bool pick_cfg(int64_t N, fused_cfg* c) {
     if (g_force_g && k.G != g_force_g) continue;
     const int64_t nmax = (int64_t)k.K * k.WV * (64 / k.G);
     // LDS image (slab_lds): the exchange planes + the input vector + small scratch must fit in 160 KiB
-    const int64_t planes = (elem<E>::cplx && k.G == 4) ? 2 : k.G;  // slab_planes
+    const int64_t planes = k.G == 8 ? 4 : (elem<E>::cplx && k.G == 4) ? 2 : k.G;  // slab_planes
     const int64_t lds = (planes * (nmax + 64 / (int64_t)sizeof(E)) + nmax) * (int64_t)sizeof(E) + 4096;
     if (N <= nmax && lds <= 160 * 1024) {
       *c = k;
