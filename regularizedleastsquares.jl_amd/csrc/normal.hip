@@ -228,19 +228,17 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
     for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
   }
   __syncthreads();
-  if (tid < G * NV) {
-    const int gg = tid / NV, i = tid % NV;
-    E sum = elem<E>::zero();
-#pragma unroll
-    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
-    L.tw[tid] = sum;
-  }
-  __syncthreads();
-
+  // every thread adds the WV per-wave partials of ITS rows itself (broadcast reads, the order ww = 0, 1, ... of the version that
+  // had G * NV threads do it and hand the result over through L.tw behind a second barrier: the same bits, one barrier less)
   STAMP(5);
   E tr[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) tr[i] = L.tw[g * NV + i];
+  for (int i = 0; i < NV; ++i) {
+    E sum = elem<E>::zero();
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][g][i]);
+    tr[i] = sum;
+  }
   // The sum over the G lanes that share a column goes through LDS, not DPP: per column a lane does
   // one store here and the G-term sum below costs G reads per OUTPUT column, against 2*log2(G)
   // cross-lane adds per lane per load with shuffles (that phase was VALU-bound at 3 us).
@@ -398,18 +396,15 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
     for (int i = 0; i < NV; ++i) L.part[w][g][i] = acc[i];
   }
   lds_barrier();
-  if (tid < G * NV) {
-    const int gg = tid / NV, i = tid % NV;
+  STAMP(stamp_base + 1);
+  E tr[NV];  // (every thread sums the per-wave partials of its rows itself: see slab_finish)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
     E sum = elem<E>::zero();
 #pragma unroll
-    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][gg][i]);
-    L.tw[tid] = sum;
+    for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][g][i]);
+    tr[i] = sum;
   }
-  lds_barrier();
-  STAMP(stamp_base + 1);
-  E tr[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) tr[i] = L.tw[g * NV + i];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     // (with the re-loads in the loop a look-ahead of 8 hoists them over the products that still read the old chunks: both alive)
