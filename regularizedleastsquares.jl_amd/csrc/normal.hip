@@ -1812,7 +1812,7 @@ struct resident_lds {
   slab_lds<E, G, K, WV> L;
   f4 rp[WV][4];  // per-wave sums of the four 16-byte pieces of a 64-byte column chunk
   int flag;
-  float ored[(WV + 1) * 32];  // owner layout: per-wave sums of t_w, then t_w
+  float ored[2 * WV * 32];  // owner layout: per-wave sums of t_w, then every wave's own copy of t_w
 };
 // dynamic LDS of a resident kernel: its struct, or the 128 KiB staging area of the one-off slab transposition
 template <typename E, int G, int K, int WV>
@@ -1990,7 +1990,7 @@ __device__ static inline float wave_reduce_scatter(float (&v)[NVAL], int lane, i
 
 // one application of the slab in the owner layout: partial row of A_w^H (A_w pin) -> slab[blockIdx] (write-through, the
 // thread's own 16-byte pieces).  pin[]: the thread's owned elements of the input vector (zero beyond N).
-// `red`: WV x RF floats + RF floats of LDS scratch.
+// `red`: 2 x WV x RF floats of LDS scratch.
 template <typename E, int G, int K, int WV, bool FULL>
 __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K], const E (&pin)[slab_cfg<E, G, K, WV>::EPT],
                                              float* red, __amdgpu_buffer_rsrc_t slab_rs, int64_t N, bool l2rows = false) {
@@ -2026,19 +2026,37 @@ __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K
   //  several workgroup barriers lies between)
   if (lane < 32) red[w * RF + idx] = part;   // lanes l and l + 32 hold the same element (RF = 16: l, l + 16, ... likewise)
   lds_barrier();
-  if (tid < RF) {
-    float sum = red[tid];
+  // Every WAVE adds the WV per-wave sums up for itself (the order ww = 0, 1, ... of the version that had RF threads of the workgroup
+  // do it: the same bits) and hands the RF values to its own lanes through a wave-private row of LDS.  That needs no workgroup
+  // barrier -- the LDS operations of one wave complete in order -- where the shared copy needs a second one (round 5; full-size
+  // instantiations only: two of the ragged ones, at 254-256 registers, spilled 8-12 bytes with it and keep the shared copy).
+  const float* tw;
+  if constexpr (FULL) {
+    float* mine = red + (WV + w) * RF;
+    if (lane < RF) {
+      float sum = red[lane];
 #pragma unroll
-    for (int ww = 1; ww < WV; ++ww) sum += red[ww * RF + tid];
-    red[WV * RF + tid] = sum;
+      for (int ww = 1; ww < WV; ++ww) sum += red[ww * RF + lane];
+      mine[lane] = sum;
+    }
+    __builtin_amdgcn_wave_barrier();  // (compiler only: the reads below stay behind the store above)
+    tw = mine;
+  } else {
+    if (tid < RF) {
+      float sum = red[tid];
+#pragma unroll
+      for (int ww = 1; ww < WV; ++ww) sum += red[ww * RF + tid];
+      red[WV * RF + tid] = sum;
+    }
+    lds_barrier();
+    tw = red + WV * RF;
   }
-  lds_barrier();
   // ---- A_w^H t_w: complete inside the owner thread ----
   E tr[G * NV];
 #pragma unroll
   for (int i = 0; i < G * NV; ++i) {
-    if constexpr (CX) tr[i] = elem<E>::make(red[WV * RF + 2 * i], red[WV * RF + 2 * i + 1]);
-    else tr[i] = elem<E>::make(red[WV * RF + i], 0.f);
+    if constexpr (CX) tr[i] = elem<E>::make(tw[2 * i], tw[2 * i + 1]);
+    else tr[i] = elem<E>::make(tw[i], 0.f);
   }
 #pragma unroll
   for (int q = 0; q < EPT / NV; ++q) {
