@@ -2178,8 +2178,12 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, sum), xp_rs, grp * rowb + (mem * q + (unsigned)tid) * 16u, 0, 16);
       }
     }
+    // Threads tid < q have stored.  When q <= 64 (the headline shape: 32) that is wave 0 alone, the wave that arrives at the grid
+    // barrier below: its own drain in front of its own arrival is program order -- no workgroup barrier (there was one until
+    // round 5); the other waves go straight to the barrier inside grid_arrive_wait, and what they read next (the flag) is written
+    // by wave 0 only.  Smaller grids (more pieces per member) keep the barrier.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (q > 64u) __syncthreads();
     STAMP(12);
     if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) return false;
     STAMP(13);
