@@ -519,7 +519,9 @@ __global__ __launch_bounds__(WV * 64) void normal_slab_kernel(const E* __restric
 // The BLAS-1 part of src/CGNR.jl:153-176 for the elements one thread owns.  Every workgroup runs it
 // redundantly (same inputs, same summation order => identical alpha, beta, done); `writer` says
 // whether this workgroup also stores x, r, p.  Returns p_new in pn[].
-// LEADFREE: the resident kernels' calling pattern (see block_sum3_nolead): two workgroup barriers per update instead of four
+// LEADFREE: the calling pattern of block_sum3_nolead -- two workgroup barriers per update instead of four.  Valid where a workgroup
+// barrier lies between any read of one of the two scratch areas and the next write to it: the resident kernels (the exchange's
+// barriers between two updates) and, since round 5, the pipeline kernels (ONE update per launch: nothing has read either area before)
 template <typename E, int EPT, int NT, bool NOMASK = false, bool LEADFREE = false>
 __device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre, double nim, double pp,
                                               const E (&pv)[EPT], const E (&rv)[EPT], const E (&vv)[EPT], int64_t N,
@@ -712,7 +714,7 @@ __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], s
   cgnr_scalars Sn;
   if (S.pending) {
     E pn[EPT], rn[EPT], al;
-    const bool done = cg_update_elems<E, EPT, C::NT, WIDE>(S, sm.d0, sm.d1, sm.d2, pv, rv, sm.vv, N, L.red, pn, rn, al, Sn);
+    const bool done = cg_update_elems<E, EPT, C::NT, WIDE, true>(S, sm.d0, sm.d1, sm.d2, pv, rv, sm.vv, N, L.red, pn, rn, al, Sn);
     if (writer) {
       E* rw = (S.cur ? r0 : r1) + vo;
       E* pw = (S.cur ? p0 : p1) + vo;
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(WV * 64) void fista_pipe_a_kernel(const E* __restri
   fista_scalars Sn;
   if (S.pending) {
     E ri[EPT], xn[EPT], yn[EPT];
-    const bool done = fista_update_elems<E, EPT, C::NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    const bool done = fista_update_elems<E, EPT, C::NT, false, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
     if (writer) {
       E* xw = (S.iteration & 1) ? b0 : b1;  // the reference's pointer swap: new x goes where x_{k-1} was
       E* yw = S.ycur ? y0 : y1;
@@ -1437,7 +1439,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_gram_kernel(const E* __restrict_
   cgnr_scalars Sn;
   if (S.pending) {
     E pn[EPT], rn[EPT], al;
-    const bool done = cg_update_elems<E, EPT, C::NT>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    const bool done = cg_update_elems<E, EPT, C::NT, false, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
     Sn.pending = done ? 0 : 1;
     if (writer) {
 #pragma unroll
@@ -1680,7 +1682,7 @@ __global__ __launch_bounds__(WV * 64) void fista_gram_kernel(const E* __restrict
     }
   } else if (S.pending) {
     E ri[EPT], xn[EPT], yn[EPT];
-    const bool done = fista_update_elems<E, EPT, C::NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+    const bool done = fista_update_elems<E, EPT, C::NT, false, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
     if (writer) {
       E* xw = (S.iteration & 1) ? b0 : b1;
       E* yw = S.ycur ? y0 : y1;
@@ -2705,7 +2707,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     }
     E pn[EPT], rn[EPT], al;
     cgnr_scalars Sn;
-    const bool done = cg_update_elems<E, EPT, NT, FULL>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    const bool done = cg_update_elems<E, EPT, NT, FULL, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       xv[e] = elem<E>::fma(pv[e], al, xv[e]);
@@ -3353,7 +3355,7 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     bool done;
     if (!DEFER || S.restart) {  // uniform: the restart test needs its dot product now (:171-176)
       fista_scalars Sn;
-      done = fista_update_elems<E, EPT, NT>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
+      done = fista_update_elems<E, EPT, NT, false, true>(S, raw, x0v, yv, xk, N, L.red, ri, xn, yn, Sn);
       RLS_FISTA_COPY(S, Sn);
     } else {
       const float rho = S.rho, thr = S.rho * S.lambda;
