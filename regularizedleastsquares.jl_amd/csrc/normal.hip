@@ -2121,7 +2121,9 @@ __device__ static inline bool resident_rows_at_l2(resident_sync* sync) {  // beh
 // only; the group partials alternate between two buffers (a fast group's members may publish exchange k + 1 while a slow
 // group still reads exchange k; k + 2 cannot start before every workgroup has passed the grid barrier of k + 1).
 // Summation orders are functions of (nwg, N) alone: bit-reproducible.  Returns false when a wait ran into its bound.
-template <typename E, int G, int K, int WV, int EXCH, bool FULL, typename PC, typename PUB>
+// DPPSUM: compile the headline arrangement's slice sum in DPP rows (see there); POGM with restart, at 255 registers, spills 8 bytes with the
+// second code path and leaves it out
+template <typename E, int G, int K, int WV, int EXCH, bool FULL, bool DPPSUM = true, typename PC, typename PUB>
 __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, resident_sync* sync,
                                                  __amdgpu_buffer_rsrc_t slab_rs, E* v, int nwg, int64_t N, unsigned& epoch,
                                                  unsigned& xchg, unsigned spin_limit,
@@ -2160,7 +2162,29 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
     const __amdgpu_buffer_rsrc_t xp_rs = sc1_rsrc(xpart);
     if (!group_arrive_wait(sync->gcnt + grp * 32, per * xchg, spin_limit, &R.flag)) return false;
     STAMP(11);
-    {
+    if (DPPSUM && nrg == 16u && q == 32u && per == 32u) {
+      // The headline arrangement (256 workgroups, 16 KiB rows: 32 pieces per member, 32 rows): the 16 row groups of a piece sit in
+      // the 16 lanes of ONE DPP row, so their sum is four full-rate cross-lane additions per component -- no LDS hand-over, no
+      // workgroup barrier in front of a 16-term sum that 32 threads ran through one LDS round trip after the other (round 5).
+      // Wave w: pieces 4w .. 4w + 3, one per DPP row; lane & 15 = the row group (rows rg and rg + 16 of the group's 32).
+      const unsigned lane = (unsigned)tid & 63u, rg = lane & 15u, piece = 4u * ((unsigned)tid >> 6) + (lane >> 4);
+      const uint32_t col = (mem * 32u + piece) * 16u;
+      const f4 ta = sc1_load16(slab_rs, (grp + RES_GROUPS * rg) * rowb + col);
+      const f4 tb = sc1_load16(slab_rs, (grp + RES_GROUPS * (rg + 16u)) * rowb + col);
+      f4 acc = ta + tb;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // fixed order: pairs, quads, half rows, the row
+        float v = acc[c];
+        v += dpp_f(v, 0xB1);
+        v += dpp_f(v, 0x4E);
+        v += dpp_f(v, 0x141);
+        v += dpp_f(v, 0x140);
+        acc[c] = v;
+      }
+      if (rg == 0u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc), xp_rs, grp * rowb + (mem * 32u + piece) * 16u, 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave has stored: each drains its own, then the barrier
+      __syncthreads();
+    } else {
       const unsigned piece = (unsigned)tid & (q - 1u), rg = (unsigned)tid >> lq;
       const uint32_t col = (mem * q + piece) * 16u;
       f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -2179,13 +2203,12 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
         for (unsigned g = 1; g < nrg; ++g) sum += ex[(g << lq) + tid];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, sum), xp_rs, grp * rowb + (mem * q + (unsigned)tid) * 16u, 0, 16);
       }
+      // Threads tid < q have stored.  When q <= 64 that is wave 0 alone, the wave that arrives at the grid barrier below: its own
+      // drain in front of its own arrival is program order -- no workgroup barrier; the other waves go straight to the barrier inside
+      // grid_arrive_wait, and what they read next (the flag) is written by wave 0 only.  More pieces per member keep the barrier.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (q > 64u) __syncthreads();
     }
-    // Threads tid < q have stored.  When q <= 64 (the headline shape: 32) that is wave 0 alone, the wave that arrives at the grid
-    // barrier below: its own drain in front of its own arrival is program order -- no workgroup barrier (there was one until
-    // round 5); the other waves go straight to the barrier inside grid_arrive_wait, and what they read next (the flag) is written
-    // by wave 0 only.  Smaller grids (more pieces per member) keep the barrier.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (q > 64u) __syncthreads();
     STAMP(12);
     if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) return false;
     STAMP(13);
@@ -3103,7 +3126,7 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
       else load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
     }
     E raw[EPT];
-    if (!resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
+    if (!resident_allreduce<E, G, K, WV, BAR, FULL, KIND != 2>(R, sync, slab_rs, raw_g, nwg, N, epoch, xchg, spin_limit, raw, [](int, E) {}, []() {})) {
       alive = false;
       break;
     }
