@@ -378,7 +378,25 @@ __global__ __launch_bounds__(NT) void group_l2_kernel(sync_block* S, float* rows
     __syncthreads();
     if (!arrive_wait<1>(S->xcnt + grp * 32, 0, per * ++xepoch, flag)) break;
 
-    {
+    if (pieces == 32 && nrg == 16 && per == 32u) {
+      // what the product does at this arrangement since round 5 (resident_allreduce, normal.hip): the 16 row groups of a piece in the
+      // 16 lanes of one DPP row -- four cross-lane additions per component instead of the LDS hand-over and the 16-term sum below
+      const unsigned lane = (unsigned)tid & 63u, rg = lane & 15u, piece = 4u * ((unsigned)tid >> 6) + (lane >> 4);
+      const uint32_t col = mem * (uint32_t)slice_b + piece * 16u;
+      f4 acc = sc1_load16(rows_rs, (grp * per + rg) * (uint32_t)nb + col) + sc1_load16(rows_rs, (grp * per + rg + 16u) * (uint32_t)nb + col);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = acc[c];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+        acc[c] = v;
+      }
+      if (rg == 0u) sc1_store16(x_rs, grp * (uint32_t)nb + col, acc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
       const int piece = tid % pieces, rg = tid / pieces;
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       for (unsigned row = rg; row < per; row += nrg)
