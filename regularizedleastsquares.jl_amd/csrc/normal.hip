@@ -180,7 +180,7 @@ __device__ static inline void slab_load(chunk<E, elem<E>::vec> (&a)[K], const E*
 // with L.xs holding the input vector (zero beyond N): t_w = A_w xs, partial v = A_w^H t_w -> slab row
 template <typename E, int G, int K, int WV, bool FULL, bool SC1 = false>
 __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L, E* __restrict__ slab,
-                                          int64_t Mc, int64_t N, int pair) {
+                                          int64_t Mc, int64_t N, int pair, double* tt_out = nullptr) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -238,6 +238,16 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
 #pragma unroll
     for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][g][i]);
     tr[i] = sum;
+  }
+  if (tt_out) {  // ||t_w||^2 in Float64, the G row chunks summed in DPP steps (fixed order); the same value in every lane
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      sq += (double)elem<E>::re(tr[i]) * (double)elem<E>::re(tr[i]) + (double)elem<E>::im(tr[i]) * (double)elem<E>::im(tr[i]);
+    if constexpr (G >= 2) sq += dpp_d(sq, 0xB1);
+    if constexpr (G >= 4) sq += dpp_d(sq, 0x4E);
+    if constexpr (G >= 8) sq += dpp_d(sq, 0x141);
+    *tt_out = sq;
   }
   // The sum over the G lanes that share a column goes through LDS, not DPP: per column a lane does
   // one store here and the G-term sum below costs G reads per OUTPUT column, against 2*log2(G)
@@ -557,6 +567,53 @@ __device__ static inline bool cg_update_elems(const cgnr_scalars& S, double nre,
   Sn.rr = rr;
   Sn.alpha_re = alpha.re;
   Sn.alpha_im = alpha.im;
+  Sn.beta_re = beta;
+  Sn.beta_im = 0.0;
+  Sn.iteration = S.iteration + 1;
+  const float ratio = (float)(sqrt(rr) / S.z0);
+  Sn.done = (ratio <= S.rel_tol) || (Sn.iteration >= S.max_iter);
+  return Sn.done != 0;
+}
+
+// The same update with alpha in its CGLS form: <p, (A^H A + lambda) p> = ||A p||^2 + lambda ||p||^2, where ||A p||^2 (`tt`) is the
+// sum of the workgroups' ||t_w||^2 -- known as soon as the first product is, and summed by the exchange that sums the partial
+// rows -- and ||p||^2 (`pp`, lambda > 0 only) does not depend on the exchange either.  Both arrive COMPLETE (the same bits in every
+// thread): of the two dependent block reductions of src/CGNR.jl:153-176 only ||r||^2 is left behind the exchange.  alpha is real
+// (the reference's dot(p, v) carries a rounding-level imaginary part, SURVEY section 7 hard part 5: differences of O(eps)); no
+// cancellation anywhere -- a sum of squares.  ||r||^2 stays the norm of the STORED r (src/CGNR.jl:171).
+template <typename E, int EPT, int NT, bool NOMASK = false>
+__device__ static inline bool cg_update_elems_tt(const cgnr_scalars& S, double tt, double pp, const E (&pv)[EPT], const E (&rv)[EPT],
+                                                 const E (&vv)[EPT], int64_t N, double* red, E (&pn)[EPT], E (&rn)[EPT],
+                                                 float& a_out, cgnr_scalars& Sn) {
+  const int tid = threadIdx.x;
+  const float lambda = S.lambda;
+  const double zeta = S.rr;
+  const double alpha = zeta / (tt + (lambda > 0.f ? (double)lambda * pp : 0.0));
+  const float a = (float)alpha;
+  double rr = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = tid + (int64_t)e * NT;
+    E ri = elem<E>::make(fmaf(elem<E>::re(vv[e]), -a, elem<E>::re(rv[e])), fmaf(elem<E>::im(vv[e]), -a, elem<E>::im(rv[e])));
+    if (lambda > 0.f) {  // (p .* -lambda) * alpha, src/CGNR.jl:168
+      const E t = elem<E>::scale(-lambda, pv[e]);
+      ri = elem<E>::make(fmaf(elem<E>::re(t), a, elem<E>::re(ri)), fmaf(elem<E>::im(t), a, elem<E>::im(ri)));
+    }
+    if (!NOMASK && i >= N) ri = elem<E>::zero();
+    rn[e] = ri;
+    rr += (double)elem<E>::re(ri) * (double)elem<E>::re(ri) + (double)elem<E>::im(ri) * (double)elem<E>::im(ri);
+  }
+  rr = block_sum_nolead<NT / 64>(rr, red);
+  const double beta = rr / zeta;
+  const float bf = (float)beta;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) pn[e] = elem<E>::add(elem<E>::scale(bf, pv[e]), rn[e]);
+  a_out = a;
+  Sn = S;
+  Sn.zeta = zeta;
+  Sn.rr = rr;
+  Sn.alpha_re = alpha;
+  Sn.alpha_im = 0.0;
   Sn.beta_re = beta;
   Sn.beta_im = 0.0;
   Sn.iteration = S.iteration + 1;
@@ -1815,6 +1872,7 @@ struct resident_lds {
   f4 rp[WV][4];  // per-wave sums of the four 16-byte pieces of a 64-byte column chunk
   int flag;
   float ored[2 * WV * 32];  // owner layout: per-wave sums of t_w, then every wave's own copy of t_w
+  double tt;                // flat exchange: the grid sum of the riding scalar (resident_allreduce, SCAL)
 };
 // dynamic LDS of a resident kernel: its struct, or the 128 KiB staging area of the one-off slab transposition
 template <typename E, int G, int K, int WV>
@@ -1995,7 +2053,8 @@ __device__ static inline float wave_reduce_scatter(float (&v)[NVAL], int lane, i
 // `red`: 2 x WV x RF floats of LDS scratch.
 template <typename E, int G, int K, int WV, bool FULL>
 __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K], const E (&pin)[slab_cfg<E, G, K, WV>::EPT],
-                                             float* red, __amdgpu_buffer_rsrc_t slab_rs, int64_t N, bool l2rows = false) {
+                                             float* red, __amdgpu_buffer_rsrc_t slab_rs, int64_t N, bool l2rows = false,
+                                             const __amdgpu_buffer_rsrc_t* tt_rs = nullptr) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT, RF = owner_cfg<E, G, K, WV>::RF;
   constexpr bool CX = elem<E>::cplx;
@@ -2033,6 +2092,7 @@ __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K
   // barrier -- the LDS operations of one wave complete in order -- where the shared copy needs a second one (round 5; full-size
   // instantiations only: two of the ragged ones, at 254-256 registers, spilled 8-12 bytes with it and keep the shared copy).
   const float* tw;
+  float tsum = 0.f;  // wave 0, lanes < RF: one component of t_w
   if constexpr (FULL) {
     float* mine = red + (WV + w) * RF;
     if (lane < RF) {
@@ -2040,6 +2100,7 @@ __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K
 #pragma unroll
       for (int ww = 1; ww < WV; ++ww) sum += red[ww * RF + lane];
       mine[lane] = sum;
+      tsum = sum;
     }
     __builtin_amdgcn_wave_barrier();  // (compiler only: the reads below stay behind the store above)
     tw = mine;
@@ -2049,9 +2110,23 @@ __device__ static inline void owner_products(const chunk<E, elem<E>::vec> (&a)[K
 #pragma unroll
       for (int ww = 1; ww < WV; ++ww) sum += red[ww * RF + tid];
       red[WV * RF + tid] = sum;
+      tsum = sum;
     }
     lds_barrier();
     tw = red + WV * RF;
+  }
+  // ||t_w||^2 (Float64, fixed order) -> word blockIdx of the scalar row: the workgroup's share of ||A p||^2 = <p, A^H A p>, which
+  // the exchange sums along with the partial rows (src/CGNR.jl:153-154's dot(p, v) without a reduction over p and v behind the
+  // exchange: the CGLS form of alpha).  Stored at the scope of the partial rows; the caller's drain covers it.
+  if (tt_rs) {
+    if (w == 0) {
+      const double sq = half_wave_sum((double)tsum * (double)tsum);
+      if (lane == 0) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        if (l2rows) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, sq), *tt_rs, (uint32_t)blockIdx.x * 8u, 0, 1);
+        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, sq), *tt_rs, (uint32_t)blockIdx.x * 8u, 0, 16);
+      }
+    }
   }
   // ---- A_w^H t_w: complete inside the owner thread ----
   E tr[G * NV];
@@ -2123,17 +2198,38 @@ __device__ static inline bool resident_rows_at_l2(resident_sync* sync) {  // beh
 // Summation orders are functions of (nwg, N) alone: bit-reproducible.  Returns false when a wait ran into its bound.
 // DPPSUM: compile the headline arrangement's slice sum in DPP rows (see there); POGM with restart, at 255 registers, spills 8 bytes with the
 // second code path and leaves it out
-template <typename E, int G, int K, int WV, int EXCH, bool FULL, bool DPPSUM = true, typename PC, typename PUB>
+// SCAL: one Float64 scalar per workgroup rides along (word blockIdx of the scalar row `d_rs`, stored by the caller at the scope of
+// its partial row and drained with it): *tt = their sum over the grid, the same bits in every thread of every workgroup.
+//   EXCH 1: behind the first grid barrier the last wave of every workgroup adds all nwg words up itself (lane l: words l, l + 64, ...,
+//     then the wave butterfly) and leaves the sum in LDS; the second grid barrier's workgroup barrier hands it to the other waves.
+//   EXCH 2: behind the group barrier wave 0 of the group's member 0 adds the group's words (lane l: member l) and publishes the
+//     group's sum behind the group partials; behind the grid barrier every lane loads group (lane & 7)'s sum and three DPP steps
+//     inside the 8 lanes add them.  No workgroup barrier, no LDS, nothing but one 8-byte load on the critical path.
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ static inline double sc1_load_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16));
+}
+template <typename E, int G, int K, int WV, int EXCH, bool FULL, bool DPPSUM = true, bool SCAL = false, typename PC, typename PUB>
 __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, resident_sync* sync,
                                                  __amdgpu_buffer_rsrc_t slab_rs, E* v, int nwg, int64_t N, unsigned& epoch,
                                                  unsigned& xchg, unsigned spin_limit,
-                                                 E (&vv)[slab_cfg<E, G, K, WV>::EPT], PC&& per_column, PUB&& publish) {
+                                                 E (&vv)[slab_cfg<E, G, K, WV>::EPT], PC&& per_column, PUB&& publish,
+                                                 const __amdgpu_buffer_rsrc_t* d_rs = nullptr, double* tt = nullptr) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
   const int tid = threadIdx.x;
   if constexpr (EXCH == 1) {
     if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) return false;
     STAMP(11);
+    if constexpr (SCAL) {
+      if ((tid >> 6) == WV - 1) {
+        const int lane = tid & 63;
+        double s = 0.0;
+        for (int row = lane; row < nwg; row += 64) s += sc1_load_f64(*d_rs, (uint32_t)row * 8u);
+        s = wave_sum(s);
+        if (lane == 0) R.tt = s;
+      }
+    }
     resident_reduce_chunks<E, G, K, WV, FULL>(R, slab_rs, v, nwg, N, per_column);
     publish();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2150,6 +2246,7 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
 #pragma unroll
       for (int j = 0; j < NV; ++j) vv[q * NV + j] = ok ? c.e[j] : elem<E>::zero();
     }
+    if constexpr (SCAL) *tt = R.tt;
     return true;
   } else {
     const unsigned per = (unsigned)nwg / RES_GROUPS, grp = blockIdx.x % RES_GROUPS, mem = blockIdx.x / RES_GROUPS;
@@ -2162,6 +2259,15 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
     const __amdgpu_buffer_rsrc_t xp_rs = sc1_rsrc(xpart);
     if (!group_arrive_wait(sync->gcnt + grp * 32, per * xchg, spin_limit, &R.flag)) return false;
     STAMP(11);
+    // the group sums of the riding scalar: [2 parities][RES_GROUPS] doubles behind the group partials
+    const uint32_t gs_off = (2u - par) * RES_GROUPS * rowb + par * (RES_GROUPS * 8u);
+    if constexpr (SCAL) {
+      if (mem == 0u && tid < 64) {  // (per <= 32: the grid holds at most 256 workgroups)
+        double s = (unsigned)tid < per ? sc1_load_f64(*d_rs, (grp + RES_GROUPS * (unsigned)tid) * 8u) : 0.0;
+        s = half_wave_sum(s);
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, s), xp_rs, gs_off + grp * 8u, 0, 16);
+      }
+    }
     if (DPPSUM && nrg == 16u && q == 32u && per == 32u) {
       // The headline arrangement (256 workgroups, 16 KiB rows: 32 pieces per member, 32 rows): the 16 row groups of a piece sit in
       // the 16 lanes of ONE DPP row, so their sum is four full-rate cross-lane additions per component -- no LDS hand-over, no
@@ -2212,6 +2318,13 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
     STAMP(12);
     if (!grid_arrive_wait(sync->cnt, ++epoch, (unsigned)nwg, spin_limit, &R.flag)) return false;
     STAMP(13);
+    if constexpr (SCAL) {
+      double s = sc1_load_f64(xp_rs, gs_off + ((unsigned)tid & 7u) * 8u);
+      s += dpp_d(s, 0xB1);
+      s += dpp_d(s, 0x4E);
+      s += dpp_d(s, 0x141);
+      *tt = s;
+    }
 #pragma unroll
     for (int qq = 0; qq < EPT / NV; ++qq) {
       const int o = qq * NT * NV + tid * NV;
@@ -2279,8 +2392,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   if (!St.enabled && (S.done || n_steps <= 0)) return;  // uniform
   constexpr bool OWN = owner_cfg<E, G, K, WV>::ok;  // the slab re-arranged once so that a thread holds whole columns
   if constexpr (OWN) owner_transpose<E, G, K, WV, FULL>(a, smem_raw, Mc, N, pair);
-  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), d_rs = sc1_rsrc(dout);
-  (void)d_rs;
+  const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), d_rs = sc1_rsrc(dout);  // dout: the scalar row (word blockIdx = ||t_w||^2)
   unsigned epoch = 0, xchg = 0;
   bool alive = true;
   // partial rows at L2 scope (resident_rows_at_l2): decided behind the launch's first exchange, which runs write-through
@@ -2395,52 +2507,39 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   for (int it = 0; it < n_steps; ++it) {
     if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
     STAMP(8);
-    // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through)
+    // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through); ||t_w||^2 -> its word of the scalar row
     if constexpr (OWN) {
-      owner_products<E, G, K, WV, FULL>(a, pv, R.ored, slab_rs, N, l2rows);
+      owner_products<E, G, K, WV, FULL>(a, pv, R.ored, slab_rs, N, l2rows, &d_rs);
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
-      slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
+      double ttw;
+      slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair, &ttw);
+      if (tid == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ttw), d_rs, (uint32_t)blockIdx.x * 8u, 0, 16);
     }
     STAMP(9);
+    // ||p||^2 (lambda > 0 only; uniform): reduced here, under the flight of the partial row's stores -- not behind the exchange
+    double pp = 0.0;
+    if (S.lambda > 0.f) {
+      if constexpr (!OWN) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) pv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; ++e)
+        pp += (double)elem<E>::re(pv[e]) * (double)elem<E>::re(pv[e]) + (double)elem<E>::im(pv[e]) * (double)elem<E>::im(pv[e]);
+      pp = block_sum_nolead<NT / 64, 0>(pp, L.red);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own stores
     __syncthreads();
     STAMP(10);
     E xq[EPT];  // x, requested here and consumed behind the exchange (every workgroup: no branch around a load)
     load_owned_sc1(xq, xw);
-    // ---- v = the sum of the partial rows, in every workgroup; <p, v> and ||p||^2 ---------------------------------------
+    // ---- v = the sum of the partial rows and ||A p||^2 = the sum of the ||t_w||^2, in every workgroup ----------------------
     E vv[EPT];
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    double dre = 0.0, dim_ = 0.0, pp = 0.0;  // EXCH 1: this workgroup's share of the dots over its column chunk
-    bool ok_x;
-    if constexpr (OWN) {  // p is not staged in LDS in the owner layout: the dots are formed from the full vectors below
-      ok_x = resident_allreduce<E, G, K, WV, BAR, FULL>(R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, vv, [](int, E) {}, []() {});
-    } else {
-    ok_x = resident_allreduce<E, G, K, WV, BAR, FULL>(
-          R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, vv,
-          [&](int j, E sum) {
-            const E pj = L.xs[j];
-            dre += (double)elem<E>::re(pj) * (double)elem<E>::re(sum) + (double)elem<E>::im(pj) * (double)elem<E>::im(sum);
-            dim_ += (double)elem<E>::re(pj) * (double)elem<E>::im(sum) - (double)elem<E>::im(pj) * (double)elem<E>::re(sum);
-            pp += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
-          },
-          [&]() {
-            if (w == 0) {  // lanes 0..CW-1 hold the terms (zero elsewhere); fixed-order butterfly, lane 0 publishes
-  #pragma unroll
-              for (int off = CW / 2; off > 0; off >>= 1) {
-                dre += __shfl_xor(dre, off, 64);
-                dim_ += __shfl_xor(dim_, off, 64);
-                pp += __shfl_xor(pp, off, 64);
-              }
-              if (lane < 3) {
-                const double dv = lane == 0 ? dre : (lane == 1 ? dim_ : pp);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dout + 4 * blockIdx.x + lane),
-                                   __builtin_bit_cast(unsigned long long, dv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-          });
-    }
+    double tt = 0.0;
+    const bool ok_x = resident_allreduce<E, G, K, WV, BAR, FULL, true, true>(R, sync, slab_rs, v, nwg, N, epoch, xchg, spin_limit, vv,
+                                                                             [](int, E) {}, []() {}, &d_rs, &tt);
     if (!ok_x) {
       alive = false;
       break;
@@ -2455,33 +2554,17 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
 #pragma unroll
       for (int e = 0; e < EPT; ++e) pv[e] = L.xs[(int)own_index<E, EPT, NT, true>(tid, e)];
     }
-    if constexpr (BAR == 1 && !OWN) {  // the 256 partial dots, one per thread; cg_update_elems sums them over the workgroup
-      const int dt = tid < nwg ? tid : 0;
-      const f4 lo = sc1_load16(d_rs, (uint32_t)dt * 32u), hi = sc1_load16(d_rs, (uint32_t)dt * 32u + 16u);
-      if (tid < nwg) {
-        d0 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 0, 1));
-        d1 = __builtin_bit_cast(double, __builtin_shufflevector(lo, lo, 2, 3));
-        d2 = __builtin_bit_cast(double, __builtin_shufflevector(hi, hi, 0, 1));
-      }
-    } else {  // every workgroup holds all of p and v: the dots over this thread's elements (summed by cg_update_elems)
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const E pj = pv[e], vj = vv[e];
-        d0 += (double)elem<E>::re(pj) * (double)elem<E>::re(vj) + (double)elem<E>::im(pj) * (double)elem<E>::im(vj);
-        d1 += (double)elem<E>::re(pj) * (double)elem<E>::im(vj) - (double)elem<E>::im(pj) * (double)elem<E>::re(vj);
-        d2 += (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
-      }
-    }
-    E pn[EPT], rn[EPT], al;
+    E pn[EPT], rn[EPT];
+    float al;
     cgnr_scalars Sn;
 #ifdef RLS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(14);
 #endif
-    const bool done = cg_update_elems<E, EPT, NT, true, true>(S, d0, d1, d2, pv, rv, vv, N, L.red, pn, rn, al, Sn);
+    const bool done = cg_update_elems_tt<E, EPT, NT, true>(S, tt, pp, pv, rv, vv, N, L.red, pn, rn, al, Sn);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      xq[e] = elem<E>::fma(pv[e], al, xq[e]);
+      xq[e] = elem<E>::make(fmaf(elem<E>::re(pv[e]), al, elem<E>::re(xq[e])), fmaf(elem<E>::im(pv[e]), al, elem<E>::im(xq[e])));
       rv[e] = rn[e];
       pv[e] = pn[e];
     }
@@ -4331,7 +4414,8 @@ int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t 
 // resident CGNR (one launch per step call, A in registers across iterations)
 size_t rls_cgnr_resident_sync_bytes() { return sizeof(resident_sync); }
 size_t rls_resident_sync_alloc_bytes(int32_t dtype, int64_t N) {  // + [2 parities][RES_GROUPS][N] group-partial vectors
-  return sizeof(resident_sync) + (size_t)2 * RES_GROUPS * (size_t)N * rls_elem_size(dtype);
+  // (+ [2 parities][RES_GROUPS] group sums of the scalar that rides along in the CGNR exchange)
+  return sizeof(resident_sync) + (size_t)2 * RES_GROUPS * (size_t)N * rls_elem_size(dtype) + (size_t)2 * RES_GROUPS * sizeof(double);
 }
 size_t rls_resident_sync_clear_bytes() { return offsetof(resident_sync, failed); }
 size_t rls_resident_sync_flags_offset() { return offsetof(resident_sync, fail); }

@@ -472,16 +472,26 @@ __device__ static inline void block_sum3_nolead(double& a, double& b, double& c,
   b = sb;
   c = sc;
 }
-template <int NW>
+template <int NW, int BASE = 8>
 __device__ static inline double block_sum_nolead(double v, double* smem) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   v = wave_sum(v);
-  if (lane == 0) smem[8 + w] = v;
+  if (lane == 0) smem[BASE + w] = v;
   lds_barrier();
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < NW; ++i) s += smem[8 + i];
+  for (int i = 0; i < NW; ++i) s += smem[BASE + i];
   return s;
+}
+// sum over lanes 0..31 of a wave (row pairs of 16: four DPP steps inside a row, one shuffle across): complete in lanes 0..15 and
+// 16..31 alike; lanes >= 32 hold the sum of THEIR half.  Fixed order.
+__device__ static inline double half_wave_sum(double v) {
+  v += dpp_d(v, 0xB1);
+  v += dpp_d(v, 0x4E);
+  v += dpp_d(v, 0x141);
+  v += dpp_d(v, 0x140);
+  v += __shfl_xor(v, 16, 64);
+  return v;
 }
 
 // three sums with one barrier pair; `smem` needs 48 doubles
