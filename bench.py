@@ -617,29 +617,28 @@ def other_paths(rls, ctx, Ad, A, b, errors):
     return out
 
 
-def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32, rows=65536, rehearse=False):
+def config5_leg(rls, ctx, dist, rank, world, barrier, K=64, W=32, rows=65536, rehearse=False, agree=None, inject=None):
     """the config-5 block of the default N > 1 line: a short `--workload rowsharded` run (it/s, the per-rank step_local_a time
-    and HBM fraction, the all-reduce time, the backend and world size the collective saw) and the one-process host."""
+    and HBM fraction, the all-reduce time, the backend and world size the collective saw) and the one-process host.
+    agree(stage, err): the ranks' agreement point (main()); a failure on any rank raises LegFailed on all of them there."""
     from importlib import import_module
 
     mg = import_module("rls_amd.multigpu")
-    out = {}
-    try:
-        full = mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=rows)
-        dom = full["roofline"]["kernel"]
-        out = {"metric": full["metric"], "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"], "scaling": "strong",
-               "rows_per_gpu": full["config"]["rows_per_gpu"], "collective": full["config"]["collective"],
-               "step_local_a_us": full["roofline"]["per_kernel"][dom]["us_per_call"],
-               "step_local_a_frac_hbm": full["roofline"]["per_kernel"][dom]["frac_hbm"], "residual": full["residual"]}
-    except Exception as e:  # a leg of its own: it must not cost the headline line
-        out = {"error": f"{type(e).__name__}: {e}"}
-    barrier()
+    agree = agree or (lambda stage, err=None: (_ for _ in ()).throw(err) if err is not None else None)
+    full = mg.bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=rows, agree=agree, inject=inject)
+    dom = full["roofline"]["kernel"]
+    out = {"metric": full["metric"], "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"], "scaling": "strong",
+           "rows_per_gpu": full["config"]["rows_per_gpu"], "collective": full["config"]["collective"],
+           "step_local_a_us": full["roofline"]["per_kernel"][dom]["us_per_call"],
+           "step_local_a_frac_hbm": full["roofline"]["per_kernel"][dom]["frac_hbm"], "residual": full["residual"]}
+    # the one-process host runs on rank 0 alone (no collectives inside); the others wait at the agreement point behind it
+    err = None
     try:
         out["one_process_host"] = mg.bench_rowsharded_one_process(rls, rank, world, K, W, M=rows,
                                                                    devices=([0] * world if rehearse else None))
-    except Exception as e:
+    except Exception as e:  # noqa: BLE001
         out["one_process_host"] = {"error": f"{type(e).__name__}: {e}"}
-    barrier()
+    agree("config5: one-process host done", err)
     return out
 
 
@@ -810,11 +809,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        from datetime import timedelta
+
+        # a rank that dies inside a collective must not hold the others for torch's default 10 minutes (RLS_BENCH_DIST_TIMEOUT_S:
+        # the tests shorten it)
+        pg_timeout = timedelta(seconds=float(os.environ.get("RLS_BENCH_DIST_TIMEOUT_S", "120")))
         if args.rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
             dist = HostStagedDist(dist)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", timeout=pg_timeout, device_id=torch.device("cuda", local_rank))
 
     trace("process group up")
     import rls_amd as rls
@@ -830,12 +834,52 @@ def main():
     if workload in ("auto", "single"):
         workload = "cgnr"
 
+    legs = {"broken": None}  # set once a collective has failed or the ranks are known to be out of step: no collective after that
+
     def finish(result=None):
         if rank == 0 and result is not None:
-            print(json.dumps(result))
+            if legs["broken"]:
+                result["distributed_error"] = legs["broken"]
+            print(json.dumps(result), flush=True)
         if dist is not None:
+            if legs["broken"]:
+                # the process group is not usable any more (a barrier here would wait for its timeout, destroy may hang): the line is
+                # out, leave without the interpreter's teardown.  A rank that failed exits non-zero; the launcher relays it.
+                sys.stdout.flush(); sys.stderr.flush()
+                os._exit(0 if rank == 0 else 1)
             dist.barrier()
             dist.destroy_process_group()
+
+    class LegFailed(RuntimeError):
+        pass
+
+    def agree(stage, err=None):
+        """every rank calls this at the same point of a leg with its own error (or None): the ranks all-reduce a flag (MAX of
+        failing rank + 1), so that EITHER all go on OR all raise LegFailed and skip the rest of the leg together -- nobody is left
+        alone in the leg's next collective.  The error text stays with its owner (stderr); the line names the owner's rank."""
+        if err is not None:
+            import traceback
+
+            print(f"[bench rank {rank}] {stage}: {type(err).__name__}: {err}", file=sys.stderr, flush=True)
+            traceback.print_exception(type(err), err, err.__traceback__, file=sys.stderr)
+        flag = (rank + 1) if err is not None else 0
+        if dist is not None and not legs["broken"]:
+            try:
+                tt = torch.tensor([float(flag)], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                flag = int(tt.item())
+            except Exception as e:  # noqa: BLE001 -- the collective itself failed (a rank is gone, a timeout): stop using the group
+                legs["broken"] = f"{stage}: the agreement all-reduce failed on rank {rank}: {type(e).__name__}: {e}"
+                raise LegFailed(legs["broken"]) from e
+        if flag:
+            mine = f": {type(err).__name__}: {err}" if err is not None and flag == rank + 1 else ""
+            raise LegFailed(f"{stage}: failed on rank {flag - 1}{mine}")
+
+    def inject(leg):
+        """RLS_BENCH_FAIL=<leg>:<rank> (tests): raise inside that leg's setup on that rank"""
+        spec = os.environ.get("RLS_BENCH_FAIL", "")
+        if spec and spec.split(":")[0] == leg and int(spec.split(":")[1]) == rank:
+            raise RuntimeError(f"injected failure in leg {leg} on rank {rank} (RLS_BENCH_FAIL)")
 
     if workload == "rowsharded":
         from importlib import import_module
@@ -902,28 +946,39 @@ def main():
         barrier()
         return float(tt.item())
 
-    def config4_measure(K, W, gram=False):
+    def config4_measure(K, W, gram=False, leg_name=None):
         # ---- BASELINE configs[3]: shared A (seed 4), B = A X (X: seed 5, 64 columns), columns 8k..8k+7 on GPU k ----
         # gram: the operator the reference constructor builds for a dense matrix (AHA = A' * A explicit, src/CGNR.jl:49), shared
         # by the columns (src/MultiThreading.jl:30-48); the Gram GEMM is setup, outside the timed region, and reported
+        # leg_name: this is a leg behind the headline of an N > 1 line -- its setup (no collectives) ends at an agreement point
         R = args.rhs_per_gpu
-        A = make_A(M, N, seed=4)
-        rng = np.random.default_rng(5)
-        X = ((rng.standard_normal((N, 64)) + 1j * rng.standard_normal((N, 64))) / math.sqrt(2)).astype(dt)
-        cols = [(rank * R + j) % 64 for j in range(R)]
-        B = np.asfortranarray((A @ X[:, cols]).astype(dt))
-        Ad = rls.DeviceMatrix.from_host(A, ctx)
-        Bd = rls.DeviceMatrix.from_host(B, ctx)
         setup_ms = None
-        if gram:
-            Ad.gram(); ctx.sync()
-            t0 = time.perf_counter(); Gd = Ad.gram(); ctx.sync(); setup_ms = 1e3 * (time.perf_counter() - t0)
-            solver = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, iterations=SEGMENT, relTol=0.0)
-        else:
-            solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
-        rls.solve_(solver, Bd, scheduler=rls.BatchedState)  # builds the batched plan (and checks it runs)
-        st = solver.state
-        assert isinstance(st, rls.BatchedState), "config 4 needs the shared-A batched plan"
+        err = None
+        try:
+            if leg_name:
+                inject(leg_name)
+            A = make_A(M, N, seed=4)
+            rng = np.random.default_rng(5)
+            X = ((rng.standard_normal((N, 64)) + 1j * rng.standard_normal((N, 64))) / math.sqrt(2)).astype(dt)
+            cols = [(rank * R + j) % 64 for j in range(R)]
+            B = np.asfortranarray((A @ X[:, cols]).astype(dt))
+            Ad = rls.DeviceMatrix.from_host(A, ctx)
+            Bd = rls.DeviceMatrix.from_host(B, ctx)
+            if gram:
+                Ad.gram(); ctx.sync()
+                t0 = time.perf_counter(); Gd = Ad.gram(); ctx.sync(); setup_ms = 1e3 * (time.perf_counter() - t0)
+                solver = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, iterations=SEGMENT, relTol=0.0)
+            else:
+                solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=SEGMENT, relTol=0.0)
+            rls.solve_(solver, Bd, scheduler=rls.BatchedState)  # builds the batched plan (and checks it runs)
+            st = solver.state
+            assert isinstance(st, rls.BatchedState), "config 4 needs the shared-A batched plan"
+        except Exception as e:  # noqa: BLE001
+            if not leg_name:
+                raise
+            err = e
+        if leg_name:
+            agree(f"{leg_name}: setup", err)
 
         def init():
             rls._lib.check(h, lib.rls_cgnr_init_batched(st._plan, Bd.ptr, Bd.lda, 0.0, 0.0, SEGMENT), "init_batched")
@@ -1168,29 +1223,50 @@ def main():
     trace("headline: solution checked, kernel timed")
     n1_value = solo_rate(lambda: rls.init_(solver, bd), lambda: step(K, True), K)
     trace("headline: solo rate done")
+    # Every leg behind the headline is a unit the ranks enter and leave TOGETHER: its setup (no collectives inside) ends in agree(),
+    # its measurement (collectives inside) ends in agree(); a leg that fails on one rank is skipped by all of them and the line carries
+    # `error` with the owner's rank.  Once a collective itself has failed (legs["broken"]) nothing distributed runs any more.
+    def leg(name, fn):
+        if legs["broken"]:
+            return {"error": "skipped: " + legs["broken"]}
+        try:
+            return fn()
+        except LegFailed as e:
+            return {"error": str(e)}
+        except Exception as e:  # noqa: BLE001 -- raised on this rank outside the leg's agree() points: the others may be in a collective
+            legs["broken"] = f"leg {name}: {type(e).__name__}: {e} on rank {rank} outside an agreement point"
+            print(f"[bench rank {rank}] {legs['broken']}", file=sys.stderr, flush=True)
+            return {"error": legs["broken"]}
+
     c4 = None
     if world > 1:
         # BASELINE configs[3], shared-A flavour, on the same job: 8 right-hand sides per GPU advancing together (matrix cores)
-        c4_full = config4_measure(max(SEGMENT, min(K, 20 * SEGMENT)), SEGMENT)
-        c4 = {k: c4_full[k] for k in ("metric", "value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
-                                      "per_rank_solve_iterations_per_s_hip_events") if k in c4_full}
-        c4["roofline"] = {k: c4_full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
-        try:  # the same job on the reference constructor's default operator (explicit AHA)
-            g4 = config4_measure(max(SEGMENT, min(K, 20 * SEGMENT)), SEGMENT, gram=True)
-            c4["gram_mode"] = {k: g4[k] for k in ("value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
-                                                  "per_rank_solve_iterations_per_s_hip_events", "setup_gram_gemm_ms") if k in g4}
-            c4["gram_mode"]["operator"] = g4["config"]["operator"]
-            c4["gram_mode"]["path"] = g4["config"]["path"]
-            c4["gram_mode"]["roofline"] = {k: g4["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
-        except Exception as e:  # noqa: BLE001 -- an extra block must not lose the line
-            c4["gram_mode"] = {"error": repr(e)}
+        def c4_leg():
+            c4_full = config4_measure(max(SEGMENT, min(K, 20 * SEGMENT)), SEGMENT, leg_name="config4")
+            out4 = {k: c4_full[k] for k in ("metric", "value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
+                                            "per_rank_solve_iterations_per_s_hip_events") if k in c4_full}
+            out4["roofline"] = {k: c4_full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
+            return out4
+
+        def g4_leg():  # the same job on the reference constructor's default operator (explicit AHA)
+            g4 = config4_measure(max(SEGMENT, min(K, 20 * SEGMENT)), SEGMENT, gram=True, leg_name="config4_gram")
+            o = {k: g4[k] for k in ("value", "unit", "ms_per_step", "n1_same_workload_value", "efficiency_vs_n1_same_workload",
+                                    "per_rank_solve_iterations_per_s_hip_events", "setup_gram_gemm_ms") if k in g4}
+            o["operator"] = g4["config"]["operator"]
+            o["path"] = g4["config"]["path"]
+            o["roofline"] = {k: g4["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_batched_iteration")}
+            return o
+
+        c4 = leg("config4", c4_leg)
+        c4["gram_mode"] = leg("config4_gram", g4_leg)
     trace("config 4 legs done")
     c5 = None
     if world > 1:
         # BASELINE configs[4] on the same job: the 65536 x 8192 problem row-partitioned over the ranks, one all-reduce of
         # A^H t per iteration through torch.distributed (RCCL); then the one-process host of the same problem -- rank 0 alone
         # driving every GPU through the library's own communicator (the Julia host's call sequence) -- while the others wait
-        c5 = config5_leg(rls, ctx, dist, rank, world, barrier, rows=args.c5_rows, rehearse=args.rehearse)
+        c5 = leg("config5", lambda: config5_leg(rls, ctx, dist, rank, world, barrier, rows=args.c5_rows, rehearse=args.rehearse,
+                                                agree=agree, inject=inject))
     trace("config 5 legs done")
     traffic, traffic_src = load_pmc(dom)
     traffic_kind = TRAFFIC_KIND

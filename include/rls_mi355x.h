@@ -338,6 +338,20 @@ int32_t rls_cgnr_step_group(rls_cgnr* const* plans, int32_t count, int32_t n_ste
 int32_t rls_cgnr_get_status_group(rls_cgnr* const* plans, int32_t count, rls_cgnr_status* out_h);
 int32_t rls_cgnr_init_step_group(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol,
                                  int32_t iterations, int32_t n_steps);
+/* The distinct-A multi-solve as a QUEUE (BASELINE configs[3], distinct-A flavour; the reference's shape is one solver and one
+ * operator per task under Threads.@threads, docs/src/literate/howto/multi_threading.jl:8-17; per-problem semantics
+ * src/CGNR.jl:107-185): `count` independent problems of any shape, plans[k] an ordinary single right-hand-side plan on its own
+ * operator (all on one context).  Problem k's init! and all `iterations` iterations are enqueued behind problem k - 1's on the
+ * context's stream -- no host wait in between -- and ONE read-back at the end fills out_h[count].  b[k]: device pointers
+ * (length M_k, or N_k for a Gram-only operator).  A resident launch lost to a busy device is re-run on the per-iteration pipeline
+ * for that problem alone, as rls_cgnr_get_status does.  x, r, p of problem k are in plan k's caller-owned vectors afterwards. */
+int32_t rls_cgnr_solve_queue(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol,
+                             int32_t iterations, rls_cgnr_status* out_h);
+/* the same with HOST buffers: b_h[k] is staged through pinned memory (the plan's own, created on first use) and uploaded on the
+ * stream ahead of problem k, x_h[k] (length N_k) is filled from a pinned download queued behind its last iteration; every copy is
+ * asynchronous and the call synchronises ONCE, at the end. */
+int32_t rls_cgnr_solve_queue_host(rls_cgnr* const* plans, const void* const* b_h, void* const* x_h, int32_t count, float lambda,
+                                  float rel_tol, int32_t iterations, rls_cgnr_status* out_h);
 /* Batched plan (BASELINE config 4, shared-A flavour; semantics of solve!(solver, B; scheduler =
  * MultiThreadingState), src/MultiThreading.jl:30-79): nrhs independent CGNR solves that share ONE pass over A
  * per iteration.  X, R, P, V: caller-owned N x nrhs column-major device matrices, leading dimension ldv;

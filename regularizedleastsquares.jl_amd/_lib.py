@@ -137,6 +137,8 @@ PROTOTYPES = {
     "rls_cgnr_step_group": (_i32, [C.POINTER(C.c_void_p), _i32, _i32]),
     "rls_cgnr_get_status_group": (_i32, [C.POINTER(C.c_void_p), _i32, C.POINTER(CgnrStatus)]),
     "rls_cgnr_init_step_group": (_i32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32, _f, _f, _i32, _i32]),
+    "rls_cgnr_solve_queue": (_i32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32, _f, _f, _i32, _vp]),
+    "rls_cgnr_solve_queue_host": (_i32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32, _f, _f, _i32, _vp]),
     "rls_cgnr_create_batched": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _pvp]),
     "rls_cgnr_init_batched": (_i32, [_vp, _vp, _i64, _f, _f, _i32]),
     "rls_cgnr_get_status_batched": (_i32, [_vp, C.POINTER(CgnrStatus)]),

@@ -297,34 +297,28 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   }
   else if (!strcmp(key, "resident_spin")) ctx->tune.resident_spin = value;
   else if (!strcmp(key, "resident_preclear")) ctx->tune.resident_preclear = value;
-  else if (!strcmp(key, "skinny_t_waves")) rls_skinny_tune(0, value);
-  else if (!strcmp(key, "skinny_v_waves")) rls_skinny_tune(1, value);
-  else if (!strcmp(key, "skinny_v_splits")) rls_skinny_tune(2, value);
-  else if (!strcmp(key, "kaczmarz_nt")) rls_kaczmarz_tune(value);
-  else if (!strcmp(key, "skinny_t_u")) rls_skinny_tune(4, value);
-  else if (!strcmp(key, "skinny_v_u")) rls_skinny_tune(5, value);
-  else if (!strcmp(key, "skinny_half")) rls_skinny_tune(7, value);
-  else if (!strcmp(key, "skinny_t_roll")) rls_skinny_tune(8, value);
-  else if (!strcmp(key, "skinny_v_roll")) rls_skinny_tune(9, value);
-  else if (!strcmp(key, "skinny_g_roll")) rls_skinny_tune(10, value);
-  else if (!strcmp(key, "gram_lds_kib")) rls_skinny_tune(6, value);
-  else if (!strcmp(key, "slab_g")) {  // process-wide; must be set before the operator is created
-    rls_normal_force_group(value);
-  } else if (!strcmp(key, "slab_wv")) {
-    rls_normal_force_waves(value);
-  } else if (!strcmp(key, "tv_fused_max_n")) {
-    rls_tv_set_fused_max_n(value);
-  } else if (!strcmp(key, "tv_fused_2d")) {
-    rls_tv_set_fused_2d(value);
-  } else if (!strcmp(key, "slab_order")) {
-    rls_normal_order_mode(value);
-  } else if (!strcmp(key, "red_threads")) {
-    rls_normal_red_threads(value);
-  } else if (!strcmp(key, "slab_multi")) {  // process-wide, like slab_g
-    rls_normal_slab_multi(value);
-  } else if (!strcmp(key, "resident_barrier")) {
-    rls_normal_resident_barrier(value);
+  else if (!strcmp(key, "skinny_t_waves")) ctx->tune.skinny_t_waves = value;
+  else if (!strcmp(key, "skinny_v_waves")) ctx->tune.skinny_v_waves = value;
+  else if (!strcmp(key, "skinny_v_splits")) ctx->tune.skinny_v_splits = value;
+  else if (!strcmp(key, "kaczmarz_nt")) ctx->tune.kaczmarz_nt = value;
+  else if (!strcmp(key, "skinny_t_u")) ctx->tune.skinny_t_u = value;
+  else if (!strcmp(key, "skinny_v_u")) ctx->tune.skinny_v_u = value;
+  else if (!strcmp(key, "skinny_half")) ctx->tune.skinny_half = value;
+  else if (!strcmp(key, "skinny_fuse")) ctx->tune.skinny_fuse = value;
+  else if (!strcmp(key, "skinny_t_roll")) ctx->tune.skinny_t_roll = value;
+  else if (!strcmp(key, "skinny_v_roll")) ctx->tune.skinny_v_roll = value;
+  else if (!strcmp(key, "skinny_g_roll")) ctx->tune.skinny_g_roll = value;
+  else if (!strcmp(key, "gram_lds_kib")) ctx->tune.gram_lds = value * 1024;
+  else if (!strcmp(key, "slab_g")) ctx->tune.slab_g = value;  // must be set before the operator is created (its workspace is sized by it)
+  else if (!strcmp(key, "slab_wv")) {  // (only 8-wave slabs are instantiated since round 3: the switch is kept for old scripts)
+    if (value != 0 && value != 8) return rls_fail(ctx, RLS_E_INVALID, "tune_set: slab_wv: only 8-wave slabs exist");
   }
+  else if (!strcmp(key, "tv_fused_max_n")) ctx->tune.tv_fused_max_n = value;
+  else if (!strcmp(key, "tv_fused_2d")) ctx->tune.tv_fused_2d = value;
+  else if (!strcmp(key, "slab_order")) ctx->tune.slab_order = value;
+  else if (!strcmp(key, "red_threads")) ctx->tune.red_threads = value;
+  else if (!strcmp(key, "slab_multi")) ctx->tune.slab_multi = value ? 1 : 0;
+  else if (!strcmp(key, "resident_barrier")) ctx->tune.resident_barrier = value == 1 ? 1 : 2;
   else return rls_fail(ctx, RLS_E_INVALID, "tune_set: unknown key");
   return 0;
 }

@@ -282,8 +282,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ A,
   }
 }
 
-static int g_kz_nt = 0;  // measurement override (rls_tune_set "kaczmarz_nt")
-void rls_kaczmarz_tune(int v) { g_kz_nt = v; }
 
 static int32_t kz_status(rls_ctx* ctx) {
   hipError_t e = hipGetLastError();
@@ -308,9 +306,9 @@ static int32_t kz_launch(rls_ctx* ctx, int64_t N, const E* At, int64_t ldat, int
   } while (0)
   // measured at 4096 x 2048 ComplexF32 (tools/bench_kaczmarz.py): 512 threads x 2 chunks 0.453 us per row
   // step, 256 x 4 0.499, 1024 x 1 0.616, 256 x 4 with an 8-deep pipeline 0.493
-  if (g_kz_nt == 256 && chunks <= 1024) {
+  if (ctx->tune.kaczmarz_nt == 256 && chunks <= 1024) {
     KZ(4, 256, 4);
-  } else if (g_kz_nt == 1024 && chunks <= 1024) {
+  } else if (ctx->tune.kaczmarz_nt == 1024 && chunks <= 1024) {
     KZ(1, 1024, 4);
   } else if (chunks <= 256) {
     KZ(1, 256, 4);

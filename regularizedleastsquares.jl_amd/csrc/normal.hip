@@ -2351,12 +2351,11 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
                                                                  int n_steps, unsigned spin_limit, rls_cg_start St) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV, EPT = C::EPT, NT = C::NT;
-  constexpr int CW = 64 / (int)sizeof(E);  // columns of a 64-byte chunk: 8 complex / 16 real
   static_assert(EPT % NV == 0, "16-byte ownership layout");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   resident_lds<E, G, K, WV>& R = *reinterpret_cast<resident_lds<E, G, K, WV>*>(smem_raw);
   slab_lds<E, G, K, WV>& L = R.L;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x;
   const int nwg = gridDim.x;
   if (St.enabled && St.skip && *St.skip) {  // the ADMM plan is done: this cg! is a no-op (uniform: every workgroup reads the flag)
     if (blockIdx.x == 0 && tid == 0) {
@@ -3554,24 +3553,18 @@ struct fused_cfg {
   int G, K, WV;
 };
 
-static int g_force_g = 0;   // measurement overrides (rls_tune_set "slab_g" / "slab_wv"): 0 = heuristic
-static int g_force_wv = 0;
-static int g_order_mode = 1;  // 0: wait for the small loads, 1: barrier only (rls_tune_set "slab_order")
-static int g_resident_barrier = 2;  // matrix-free resident kernels' exchange: 2 = two-level where the grid allows (default), 1 = flat
-static int g_red_threads = 1024;  // reduce kernel: 16 columns x 64 row groups per workgroup (-1.0 us vs 256)
-static int g_slab_multi = 1;      // shapes with more row blocks than CUs: one workgroup walks several blocks (rls_tune_set "slab_multi")
+// (the measurement switches of this file -- slab_g, slab_order, resident_barrier, red_threads, slab_multi -- live in the context:
+//  rls_tuning, rls_common.hpp; rls_tune_set)
 
 // workgroups (= partial rows) of a slab launch over `nwg` row blocks: the blocks themselves while they fit the chip's CUs, otherwise
 // one workgroup per CU (slab_finish_multi; K = 32 slabs only -- the smaller ones leave room for two workgroups per CU, which
 // overlap each other's streams by themselves)
 static int slab_grid(rls_ctx* ctx, int K, int nwg) {
-  if (!g_slab_multi || K != 32) return nwg;
-  static int cus_of[64] = {0};
-  const int d = ctx->device;
-  int cus = (d >= 0 && d < 64) ? cus_of[d] : 0;
-  if (!cus) {
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0) return nwg;
-    if (d >= 0 && d < 64) cus_of[d] = cus;
+  if (!ctx->tune.slab_multi || K != 32) return nwg;
+  int cus = ctx->cus;  // (cached in the context: no shared table between the per-rank worker threads)
+  if (cus <= 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) return nwg;
+    ctx->cus = cus;
   }
   // one workgroup per CU; workgroup b walks blocks b, b + cus, b + 2 cus, ... (the last round may be a partial one: its few
   // workgroups stream their extra block alone, at their CU's full rate)
@@ -3584,11 +3577,9 @@ static int slab_grid(rls_ctx* ctx, int K, int nwg) {
 static const fused_cfg kCfgs[] = {{8, 8, 8}, {8, 16, 8}, {8, 32, 8}, {4, 32, 8}};
 
 template <typename E>
-static bool pick_cfg(int64_t N, fused_cfg* c) {
-  const int wv = g_force_wv ? g_force_wv : 8;
+static bool pick_cfg(const rls_tuning& T, int64_t N, fused_cfg* c) {
   for (const fused_cfg& k : kCfgs) {
-    if (k.WV != wv) continue;
-    if (g_force_g && k.G != g_force_g) continue;
+    if (T.slab_g && k.G != T.slab_g) continue;  // measurement override (rls_tune_set "slab_g"): set before the operator is created
     const int64_t nmax = (int64_t)k.K * k.WV * (64 / k.G);
     // LDS image (slab_lds): the exchange planes + the input vector + small scratch must fit in 160 KiB
     const int64_t planes = k.G == 8 ? 4 : (elem<E>::cplx && k.G == 4) ? 2 : k.G;  // slab_planes
@@ -3602,20 +3593,20 @@ static bool pick_cfg(int64_t N, fused_cfg* c) {
 }
 
 template <typename E>
-static bool fused_ok(int64_t M, int64_t N, const void* A, int64_t lda) {
+static bool fused_ok(const rls_tuning& T, int64_t M, int64_t N, const void* A, int64_t lda) {
   constexpr int V = elem<E>::vec;
   fused_cfg c;
   if (!(A && M > 0 && N > 0 && M % V == 0 && lda % V == 0 && (reinterpret_cast<uintptr_t>(A) % 16 == 0))) return false;
-  if (!pick_cfg<E>(N, &c)) return false;
+  if (!pick_cfg<E>(T, N, &c)) return false;
   // 32-bit lane offsets: (slots per round) * column stride + row offset must stay below 2^32
   const int64_t cpr = c.WV * (64 / c.G);
   return cpr * lda * (int64_t)sizeof(E) + (M / V) * 16 < (int64_t)0xffffffffll;
 }
 
 template <typename E>
-static int64_t fused_nwg(int64_t M, int64_t N) {
+static int64_t fused_nwg(const rls_tuning& T, int64_t M, int64_t N) {
   fused_cfg c;
-  pick_cfg<E>(N, &c);
+  pick_cfg<E>(T, N, &c);
   const int64_t Mc = M / elem<E>::vec;
   return (Mc + c.G - 1) / c.G;
 }
@@ -3711,7 +3702,7 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg, int gri
 #define RLS_LAUNCH_A2(FULLV, BATCHV, HINTV, MULTIV)                                                                     \
   hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV, HINTV, MULTIV>), dim3(MULTIV ? grid : nwg), dim3(C::NT),  \
                      lds, ctx->stream, (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, \
-                     (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, g_order_mode, R, nwg)
+                     (E*)P.slab, P.dots, P.ndots, P.sc, P.scn, Mc, P.N, pair, ctx->tune.slab_order, R, nwg)
 #define RLS_LAUNCH_A(FULLV, BATCHV, HINTV)                      \
   do {                                                          \
     if constexpr (K == 32) {                                    \
@@ -3752,14 +3743,14 @@ template <typename E>
 static int32_t normal_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A, int64_t lda, const E* p, E* v, E* slab,
                             const int* skip) {
   fused_cfg c;
-  if (!pick_cfg<E>(N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "normal_fused: N too large for a register slab");
-  const int nwg = (int)fused_nwg<E>(M, N);
+  if (!pick_cfg<E>(ctx->tune, N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "normal_fused: N too large for a register slab");
+  const int nwg = (int)fused_nwg<E>(ctx->tune, M, N);
   int rows = nwg;  // partial rows the slab launch leaves
 #define RLS_SLAB_CASE(GG, KK, WW) \
   if (c.G == GG && c.K == KK && c.WV == WW) rows = launch_slab<E, GG, KK, WW>(ctx, A, lda, p, slab, M, N, nwg, skip);
   RLS_FOR_EACH_CFG(RLS_SLAB_CASE)
 #undef RLS_SLAB_CASE
-  hipLaunchKernelGGL(slab_reduce_kernel<E>, dim3((unsigned)((N + 15) / 16)), dim3(g_red_threads), 0, ctx->stream, slab, rows, N,
+  hipLaunchKernelGGL(slab_reduce_kernel<E>, dim3((unsigned)((N + 15) / 16)), dim3(ctx->tune.red_threads), 0, ctx->stream, slab, rows, N,
                      v, skip);
   return launch_status(ctx);
 }
@@ -3767,8 +3758,8 @@ static int32_t normal_typed(rls_ctx* ctx, int64_t M, int64_t N, const E* A, int6
 template <typename E>
 static int32_t pipe_iteration_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, int which = 3) {
   fused_cfg c;
-  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr pipeline: N too large");
-  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  if (!pick_cfg<E>(ctx->tune, P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "cgnr pipeline: N too large");
+  const int nwg = (int)fused_nwg<E>(ctx->tune, P.M, P.N);
   const int rows = slab_grid(ctx, c.K, nwg);  // partial rows K_A leaves = its workgroups
 #define RLS_PIPE_CASE(GG, KK, WW) \
   if (c.G == GG && c.K == KK && c.WV == WW) launch_pipe_a<E, GG, KK, WW>(ctx, P, nwg, rows);
@@ -3778,7 +3769,7 @@ static int32_t pipe_iteration_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, int wh
 #undef RLS_PIPE_CASE
   if (which & 2)
     hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots, (unsigned)(P.nrhs > 0 ? P.nrhs : 1)),
-                       dim3(g_red_threads), 0, ctx->stream, (const E*)P.slab, rows, P.N, (E*)P.v, (const E*)P.p0,
+                       dim3(ctx->tune.red_threads), 0, ctx->stream, (const E*)P.slab, rows, P.N, (E*)P.v, (const E*)P.p0,
                        (const E*)P.p1, P.dots, P.sc, P.scn, rhs_of(P, nwg));
   return launch_status(ctx);
 }
@@ -3842,14 +3833,14 @@ static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg, int g
 template <typename E>
 static int32_t fista_iteration_typed(rls_ctx* ctx, const rls_fista_pipe& P) {
   fused_cfg c;
-  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista pipeline: N too large");
-  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  if (!pick_cfg<E>(ctx->tune, P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista pipeline: N too large");
+  const int nwg = (int)fused_nwg<E>(ctx->tune, P.M, P.N);
   const int rows = slab_grid(ctx, c.K, nwg);
 #define RLS_FISTA_CASE(GG, KK, WW) \
   if (c.G == GG && c.K == KK && c.WV == WW) launch_fista_a<E, GG, KK, WW>(ctx, P, nwg, rows);
   RLS_FOR_EACH_CFG(RLS_FISTA_CASE)
 #undef RLS_FISTA_CASE
-  hipLaunchKernelGGL(fista_pipe_r_kernel<E>, dim3((unsigned)((P.N + 15) / 16)), dim3(g_red_threads), 0, ctx->stream,
+  hipLaunchKernelGGL(fista_pipe_r_kernel<E>, dim3((unsigned)((P.N + 15) / 16)), dim3(ctx->tune.red_threads), 0, ctx->stream,
                      (const E*)P.slab, rows, P.N, (E*)P.res_raw, P.sc, P.scn);
   return launch_status(ctx);
 }
@@ -3897,7 +3888,7 @@ static void launch_gram(rls_ctx* ctx, const rls_gram_pipe& P, int q, int nwg) {
   hipLaunchKernelGGL((cgnr_gram_kernel<E, 4, K, 8, FULLV, MULTIV>), dim3(MULTIV ? grid : nwg), dim3(C::NT), 0, ctx->stream,   \
                      (const E*)P.G, P.ldg, (E*)P.x, (const E*)P.r[q], (const E*)P.p[q], (E*)P.r[q ^ 1], (E*)P.p[q ^ 1],        \
                      (const E*)P.v[q], (E*)P.v[q ^ 1], P.dots + (size_t)q * 4 * nwg, P.dots + (size_t)(q ^ 1) * 4 * nwg,       \
-                     MULTIV ? grid : nwg, P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, g_order_mode, nwg)
+                     MULTIV ? grid : nwg, P.sc[q], P.sc[q ^ 1], Mc, P.N, pair, ctx->tune.slab_order, nwg)
   // (Float32: N <= 4096 is at most 256 blocks of 16 rows -- nothing to walk, the instantiations would be dead code)
 #define RLS_LAUNCH_G(FULLV)               \
   do {                                    \
@@ -4002,8 +3993,8 @@ static int32_t fista_gram_finish_typed(rls_ctx* ctx, const rls_fista_gram& P, in
 // the two-level exchange (resident_allreduce, EXCH 2): 8 equal groups, the row split into a power-of-two number of
 // 16-byte pieces per group member, at most one piece per thread.  Other grids (ragged M) take the flat exchange.
 template <typename E>
-static bool resident_two_level_ok(int nwg, int64_t N, int nt) {
-  if (g_resident_barrier != 2 || nwg % RES_GROUPS != 0) return false;
+static bool resident_two_level_ok(const rls_tuning& T, int nwg, int64_t N, int nt) {
+  if (T.resident_barrier != 2 || nwg % RES_GROUPS != 0) return false;
   const int64_t pieces = N * (int64_t)sizeof(E) / 16, per = nwg / RES_GROUPS;
   if (N * (int64_t)sizeof(E) % 16 != 0 || pieces % per != 0) return false;
   const int64_t q = pieces / per;
@@ -4031,7 +4022,7 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
   hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.x, (E*)P.r1, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N,  \
                      pair, n_steps, spin_limit, St)
-    if (resident_two_level_ok<E>(nwg, P.N, C::NT)) {
+    if (resident_two_level_ok<E>(ctx->tune, nwg, P.N, C::NT)) {
       if (full) RLS_LAUNCH_RES(2, true);
       else RLS_LAUNCH_RES(2, false);
     } else {
@@ -4046,14 +4037,14 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
 }
 
 template <typename E>
-static bool resident_ok_typed(int device, int64_t M, int64_t N, const void* A, int64_t lda) {
-  if (!fused_ok<E>(M, N, A, lda)) return false;
+static bool resident_ok_typed(const rls_tuning& T, int device, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!fused_ok<E>(T, M, N, A, lda)) return false;
   fused_cfg c;
-  if (!pick_cfg<E>(N, &c) || (c.K != 32 && c.K != 16) || c.WV != 8 || (elem<E>::cplx && c.G == 4)) return false;
+  if (!pick_cfg<E>(T, N, &c) || (c.K != 32 && c.K != 16) || c.WV != 8 || (elem<E>::cplx && c.G == 4)) return false;
   if (((int64_t)c.K * c.WV * (64 / c.G) / (c.WV * 64)) % elem<E>::vec) return false;  // 16-byte ownership pieces: EPT % V == 0
   // the K = 32 slab shapes: N in (NMAX / 2, NMAX], N a multiple of the 16-byte piece; ragged M and N run the masked
   // instantiation (the full-size one has no clamps at all)
-  const int64_t nwg = fused_nwg<E>(M, N);
+  const int64_t nwg = fused_nwg<E>(T, M, N);
   if (N % elem<E>::vec) return false;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
@@ -4083,8 +4074,8 @@ template <typename E>
 static int32_t resident_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dout, void* sync, int n_steps,
                               unsigned spin_limit, const rls_cg_start& St) {
   fused_cfg c;
-  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident CGNR: N too large");
-  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  if (!pick_cfg<E>(ctx->tune, P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident CGNR: N too large");
+  const int nwg = (int)fused_nwg<E>(ctx->tune, P.M, P.N);
   int32_t st = RLS_E_UNSUPPORTED;
 #define RLS_RES_CASE(GG, KK, WW) \
   if (c.G == GG && c.K == KK && c.WV == WW) st = launch_resident<E, GG, KK, WW>(ctx, P, dout, sync, nwg, n_steps, spin_limit, St);
@@ -4113,7 +4104,7 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
   hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab,  \
                      P.sc, (resident_sync*)sync, Mc, P.N, pair | (ctx->tune.fista_defer ? 0 : 2), n_steps, spin_limit, Sv)
-    if (resident_two_level_ok<E>(nwg, P.N, C::NT)) {
+    if (resident_two_level_ok<E>(ctx->tune, nwg, P.N, C::NT)) {
       if (full) RLS_LAUNCH_FRES(2, true);
       else RLS_LAUNCH_FRES(2, false);
     } else {
@@ -4131,8 +4122,8 @@ template <typename E>
 static int32_t fista_resident_typed(rls_ctx* ctx, const rls_fista_pipe& P, void* sync, int n_steps, unsigned spin_limit,
                                     const rls_srv_args& Sv) {
   fused_cfg c;
-  if (!pick_cfg<E>(P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident FISTA: N too large");
-  const int nwg = (int)fused_nwg<E>(P.M, P.N);
+  if (!pick_cfg<E>(ctx->tune, P.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident FISTA: N too large");
+  const int nwg = (int)fused_nwg<E>(ctx->tune, P.M, P.N);
   int32_t st = RLS_E_UNSUPPORTED;
 #define RLS_FRES_CASE(GG, KK, WW) \
   if (c.G == GG && c.K == KK && c.WV == WW) st = launch_fista_resident<E, GG, KK, WW>(ctx, P, sync, nwg, n_steps, spin_limit, Sv);
@@ -4260,7 +4251,7 @@ static int32_t launch_pgm_resident(rls_ctx* ctx, const rls_pgm_desc& D, const rl
   hipLaunchKernelGGL((pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)D.A,    \
                      D.lda, (E*)D.v0, (E*)D.v1, (E*)D.v2, (E*)D.v3, (E*)D.o0, (E*)D.res, (const E*)D.x0, (E*)D.raw, (E*)D.slab, D.st, CF,  \
                      D.norm_x0, D.rel_tol, D.reg_kind, D.proj_kind, (resident_sync*)sync, Mc, D.N, pair | (ctx->tune.fista_defer ? 0 : 2), n_steps, D.first_it, spin_limit)
-    const bool two = resident_two_level_ok<E>(nwg, D.N, C::NT);
+    const bool two = resident_two_level_ok<E>(ctx->tune, nwg, D.N, C::NT);
     if (D.kind == 0) {
       if (two) { if (full) RLS_LAUNCH_PGM(2, true, 0); else RLS_LAUNCH_PGM(2, false, 0); }
       else { if (full) RLS_LAUNCH_PGM(1, true, 0); else RLS_LAUNCH_PGM(1, false, 0); }
@@ -4282,8 +4273,8 @@ template <typename E>
 static int32_t pgm_resident_typed(rls_ctx* ctx, const rls_pgm_desc& D, const rls_pgm_coefs& CF, void* sync, int n_steps,
                                   unsigned spin_limit) {
   fused_cfg c;
-  if (!pick_cfg<E>(D.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident OptISTA / POGM: N too large");
-  const int nwg = (int)fused_nwg<E>(D.M, D.N);
+  if (!pick_cfg<E>(ctx->tune, D.N, &c)) return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident OptISTA / POGM: N too large");
+  const int nwg = (int)fused_nwg<E>(ctx->tune, D.M, D.N);
   int32_t st = RLS_E_UNSUPPORTED;
 #define RLS_PGM_CASE(GG, KK, WW) \
   if (c.G == GG && c.K == KK && c.WV == WW) st = launch_pgm_resident<E, GG, KK, WW>(ctx, D, CF, sync, nwg, n_steps, spin_limit);
@@ -4293,10 +4284,10 @@ static int32_t pgm_resident_typed(rls_ctx* ctx, const rls_pgm_desc& D, const rls
 }
 
 template <typename E>
-static bool pgm_resident_ok_typed(int device, int64_t M, int64_t N, const void* A, int64_t lda) {
-  if (!resident_ok_typed<E>(device, M, N, A, lda)) return false;
+static bool pgm_resident_ok_typed(const rls_tuning& T, int device, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!resident_ok_typed<E>(T, device, M, N, A, lda)) return false;
   fused_cfg c;
-  if (!pick_cfg<E>(N, &c)) return false;
+  if (!pick_cfg<E>(T, N, &c)) return false;
   bool ok = false;
 #define RLS_PGM_OK(GG, KK, WW) \
   if (c.G == GG && c.K == KK && c.WV == WW) ok = owner_cfg_ok<E, GG, KK, WW>() && (KK == 16 || KK == 32) && WW == 8 && !(elem<E>::cplx && GG == 4);
@@ -4367,13 +4358,6 @@ int32_t rls_fista_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_fista_pipe&
   return fista_finish_typed<float2>(ctx, P);
 }
 
-void rls_normal_force_group(int g) { g_force_g = g; }
-void rls_normal_force_waves(int wv) { g_force_wv = wv; }
-void rls_normal_order_mode(int m) { g_order_mode = m; }
-void rls_normal_red_threads(int t) { g_red_threads = t; }
-void rls_normal_slab_multi(int on) { g_slab_multi = on ? 1 : 0; }
-void rls_normal_resident_barrier(int m) { g_resident_barrier = m == 1 ? 1 : 2; }
-
 #ifdef RLS_STAMPS
 extern "C" int32_t rls_debug_stamps(unsigned long long* out_h) {
   return (int32_t)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16 * 8);
@@ -4395,9 +4379,10 @@ int32_t rls_cgnr_pipe_finish(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P
   return pipe_finish_typed<float2>(ctx, P);
 }
 
-size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
-  if (dtype == RLS_F32) return fused_ok<float>(M, N, A, lda) ? (size_t)fused_nwg<float>(M, N) * N * 4 : 0;
-  if (dtype == RLS_C32) return fused_ok<float2>(M, N, A, lda) ? (size_t)fused_nwg<float2>(M, N) * N * 8 : 0;
+size_t rls_normal_fused_workspace(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
+  if (!ctx) return 0;
+  if (dtype == RLS_F32) return fused_ok<float>(ctx->tune, M, N, A, lda) ? (size_t)fused_nwg<float>(ctx->tune, M, N) * N * 4 : 0;
+  if (dtype == RLS_C32) return fused_ok<float2>(ctx->tune, M, N, A, lda) ? (size_t)fused_nwg<float2>(ctx->tune, M, N) * N * 8 : 0;
   return 0;
 }
 
@@ -4422,12 +4407,12 @@ size_t rls_resident_sync_flags_offset() { return offsetof(resident_sync, fail); 
 size_t rls_resident_sync_placement_offset() { return offsetof(resident_sync, gcnt) + sizeof(unsigned); }  // the word resident_report_placement sets
 bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (!ctx) return false;
-  if (dtype == RLS_F32) return resident_ok_typed<float>(ctx->device, M, N, A, lda);
-  if (dtype == RLS_C32) return resident_ok_typed<float2>(ctx->device, M, N, A, lda);
+  if (dtype == RLS_F32) return resident_ok_typed<float>(ctx->tune, ctx->device, M, N, A, lda);
+  if (dtype == RLS_C32) return resident_ok_typed<float2>(ctx->tune, ctx->device, M, N, A, lda);
   return false;
 }
-int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N) {
-  return dtype == RLS_F32 ? (int)fused_nwg<float>(M, N) : (int)fused_nwg<float2>(M, N);
+int rls_cgnr_resident_nwg(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N) {
+  return dtype == RLS_F32 ? (int)fused_nwg<float>(ctx->tune, M, N) : (int)fused_nwg<float2>(ctx->tune, M, N);
 }
 int32_t rls_cgnr_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_cgnr_pipe& P, double* dout, void* sync,
                                  int n_steps, unsigned spin_limit, const rls_cg_start& St) {
@@ -4443,8 +4428,8 @@ int32_t rls_fista_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_fista_p
 
 bool rls_pgm_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (!ctx) return false;
-  if (dtype == RLS_F32) return pgm_resident_ok_typed<float>(ctx->device, M, N, A, lda);
-  if (dtype == RLS_C32) return pgm_resident_ok_typed<float2>(ctx->device, M, N, A, lda);
+  if (dtype == RLS_F32) return pgm_resident_ok_typed<float>(ctx->tune, ctx->device, M, N, A, lda);
+  if (dtype == RLS_C32) return pgm_resident_ok_typed<float2>(ctx->tune, ctx->device, M, N, A, lda);
   return false;
 }
 int32_t rls_pgm_resident_launch(rls_ctx* ctx, int32_t dtype, const rls_pgm_desc& D, const rls_pgm_coefs& C, void* sync,

@@ -41,6 +41,21 @@ struct rls_tuning {
   int status_mailbox = 2;      // >= 1: status read-backs are a kernel writing into pinned host memory + a host spin on its
                                // sequence word (rls_fetch_*); 2: and rls_*_step_status has the call's LAST kernel do that
                                // store where it can (rls_mailbox_slot); 0: hipMemcpyAsync + stream wait
+  // ---- per-kernel-family measurement switches (rounds 1-5 kept these as file-scope statics; a context is the unit of
+  //      re-entrancy -- SURVEY 8b: all mutable state in rls_ctx -- so they live here, one copy per context) ----
+  int slab_g = 0;              // normal.hip: force the lanes per row chunk of the register slab (0 = heuristic); set before the operator is created
+  int slab_order = 1;          // 0: wait for the small loads before the slab goes out, 1: barrier only
+  int resident_barrier = 2;    // matrix-free resident kernels' exchange: 2 = two-level where the grid allows, 1 = flat
+  int red_threads = 1024;      // reduce kernels: 16 columns x 64 row groups per workgroup
+  int slab_multi = 1;          // shapes with more row blocks than CUs: one workgroup walks several blocks
+  int skinny_t_waves = 4, skinny_t_u = 4, skinny_v_waves = 4, skinny_v_u = 1, skinny_v_splits = 0;  // skinny.hip (tools/skinny_probe.py)
+  int skinny_t_roll = 8, skinny_v_roll = 2, skinny_g_roll = 8;  // rolling-window depth of the complex T / V / Gram products (0 = two-set pipeline)
+  int skinny_half = 1;         // the (re | im) operand packing for <= 8 complex right-hand sides
+  int skinny_fuse = 1;         // <= 8 complex right-hand sides: the update folded into the two products (skinny.hip, round 6)
+  int gram_lds = 96 * 1024;    // dynamic LDS requested by the Gram tile kernel as an occupancy limiter
+  int64_t tv_fused_max_n = 2048;  // tv.hip: larger images run 2 chip-wide launches per FGP iteration instead of one CU
+  int tv_fused_2d = 1;         // the register-resident 2-D FGP kernel (n <= 8192 pixels)
+  int kaczmarz_nt = 0;         // kaczmarz.hip: workgroup size override (0 = heuristic)
   int resident_spin = 100000;  // bound of every in-kernel wait, in polls (~1 us each: a wall-clock bound of ~0.1 s per
                                // wait); a launch that runs into it is a no-op and the host re-runs its iterations on the
                                // per-iteration pipeline (solvers.hip, *_recover)
@@ -60,6 +75,7 @@ struct rls_ctx {
   float* res_d = nullptr;   // small float result block on device
   float* res_h = nullptr;   // pinned host mirror
   rls_tuning tune;
+  int cus = 0;                // compute units of `device` (looked up once, by whoever asks first on this context)
   int resident_failures = 0;  // resident launches of this context that timed out; at 2 the context stops using them
   bool pools = false;         // device memory comes from the device's stream-ordered pool (rls_dev_alloc)
   // status mailbox (rls_fetch_add / rls_fetch_wait): device -> pinned copies queued for ONE publishing launch
@@ -710,7 +726,7 @@ size_t rls_resident_sync_clear_bytes();
 size_t rls_resident_sync_flags_offset();   // {fail, completed, failed}: three consecutive unsigned words
 size_t rls_resident_sync_placement_offset();  // "some workgroup is not on the XCD its group assumes": nonzero = partial rows written through
 bool rls_cgnr_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
-int rls_cgnr_resident_nwg(int32_t dtype, int64_t M, int64_t N);
+int rls_cgnr_resident_nwg(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N);
 // cg! entry folded into a resident launch (src/ADMM.jl:236-244): r = b - (AHA + rho I) x with the warm start x, p = r,
 // the scalars of the solve; with beta_y non-null b = beta_y + rho_admm (z - u) is formed on the way (and stored, with a
 // copy of x in xold, by workgroup 0).  enabled = 0: the kernel continues an initialised solve (rls_cgnr_step).
@@ -854,17 +870,15 @@ struct rls_skinny {
 };
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 // complex with at most 8 right-hand sides: the (re | im) operand packing (two MFMAs per complex block instead of four)
-int rls_skinny_half(int32_t dtype, int nrhs);
+int rls_skinny_half(const rls_ctx* ctx, int32_t dtype, int nrhs);
 static inline int rls_skinny_groups(int nrhs, int half) { return half ? 1 : (nrhs + 15) / 16; }
 static inline int rls_skinny_pad(int nrhs, int half) { return half ? 8 : ((nrhs + 15) / 16) * 16; }
-void rls_skinny_sizes(int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes, size_t* v_bytes,
-                      int* splits);
+void rls_skinny_sizes(const rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes,
+                      size_t* v_bytes, int* splits);
 int32_t rls_skinny_init(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb, float lambda,
                         float rel_tol, int max_iter);
 int32_t rls_skinny_launch(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, int which);
 int32_t rls_skinny_atb(rls_ctx* ctx, int32_t dtype, const rls_skinny& K, const void* B, int64_t ldb);
-void rls_skinny_tune(int which, int value);
-void rls_kaczmarz_tune(int v);
 bool rls_gram_tiles_ok(int64_t M, int64_t N);
 int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* G,
                        int64_t ldg);
@@ -952,19 +966,11 @@ int32_t rls_launch_gemv(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int6
                         const void* A, int64_t lda, const void* x, float br, float bi, void* y, const int* skip);
 // normal.hip: v = A^H A p in ONE pass over A (slab of A held in registers between the two products).
 // Returns the slab workspace size in bytes (0 = shape not supported by the fused kernel).
-void rls_tv_set_fused_max_n(int64_t n);
-void rls_tv_set_fused_2d(int on);
 // tv.hip: the FGP loop as ONE single-workgroup launch, out = prox_TV(xin [+ add]) (`add`, `skip` nullable)
-bool rls_tv_single_ok(int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims);
+bool rls_tv_single_ok(const rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims);
 int32_t rls_tv_single_launch(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
                              const int32_t* dims, const void* xin, const void* add, void* out, float lam, int iters,
                              const int* skip, int count = 1, int64_t ldv = 0, int skip_stride = 0);
-void rls_normal_force_group(int g);
-void rls_normal_force_waves(int wv);
-void rls_normal_order_mode(int m);
-void rls_normal_red_threads(int t);
-void rls_normal_slab_multi(int on);
-void rls_normal_resident_barrier(int m);
-size_t rls_normal_fused_workspace(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
+size_t rls_normal_fused_workspace(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda);
 int32_t rls_launch_normal_fused(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda,
                                 const void* p, void* v, void* slab, const int* skip);

@@ -652,30 +652,13 @@ __global__ __launch_bounds__(NT) void skinny_u_kernel(E* __restrict__ X, E* __re
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// measurement overrides (rls_tune_set "skinny_*"); defaults from tools/skinny_probe.py on MI355X
-static int g_t_waves = 4, g_t_u = 4, g_v_waves = 4, g_v_u = 1, g_v_splits = 0;
-// rolling-window depth of the complex T / V kernels (0 = two-set batch pipeline).  MI355X, 4096 x 2048 CF32,
-// (8, 2) against (0, 0): K = 8 32.7 -> 31.6 us, K = 16 36.6 -> 33.9 us, K = 64 120.3 -> 98.7 us per batched iteration;
-// (16, 2), (8, 4) and deeper windows measure within noise or worse: the kernels are not short of loads in flight
-static int g_t_roll = 8, g_v_roll = 2;
-static int g_g_roll = 8;  // the Gram-mode product (skinny_t_kernel<..., VOUT>): rls_tune_set "skinny_g_roll"
-static int g_half = 1;  // rls_tune_set "skinny_half": the (re | im) operand packing for <= 8 complex right-hand sides
-// dynamic LDS requested by the Gram tile kernel purely as an occupancy limiter: one workgroup (one wave per SIMD)
-// per CU keeps the MFMA pipe fed by a single instruction stream (0.92 ms vs 1.05 ms with three co-resident
-// workgroups at 4096 x 2048 CF32); rls_tune_set "gram_lds_kib"
-static int g_gram_lds = 96 * 1024;
-void rls_skinny_tune(int which, int value) {
-  if (which == 0) g_t_waves = value;
-  if (which == 1) g_v_waves = value;
-  if (which == 2) g_v_splits = value;
-  if (which == 4) g_t_u = value;
-  if (which == 5) g_v_u = value;
-  if (which == 6) g_gram_lds = value * 1024;
-  if (which == 7) g_half = value;
-  if (which == 8) g_t_roll = value;
-  if (which == 9) g_v_roll = value;
-  if (which == 10) g_g_roll = value;
-}
+// The measurement switches of this file are the context's (rls_tuning: skinny_t_waves / _t_u / _v_waves / _v_u / _v_splits, defaults
+// from tools/skinny_probe.py on MI355X; skinny_t_roll / _v_roll / _g_roll; skinny_half; gram_lds).  Rolling-window depth of the
+// complex T / V kernels (0 = two-set batch pipeline): MI355X, 4096 x 2048 CF32, (8, 2) against (0, 0): K = 8 32.7 -> 31.6 us,
+// K = 16 36.6 -> 33.9 us, K = 64 120.3 -> 98.7 us per batched iteration; (16, 2), (8, 4) and deeper windows measure within noise
+// or worse: the kernels are not short of loads in flight.  gram_lds: dynamic LDS requested by the Gram tile kernel purely as an
+// occupancy limiter -- one workgroup (one wave per SIMD) per CU keeps the MFMA pipe fed by a single instruction stream (0.92 ms
+// vs 1.05 ms with three co-resident workgroups at 4096 x 2048 CF32).
 
 bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda) {
   if (!A || M < 16 || N < 16 || M % 16 || N % 16) return false;
@@ -685,8 +668,8 @@ bool rls_skinny_ok(int32_t dtype, int64_t M, int64_t N, const void* A, int64_t l
 
 // Row splits of the A^H T product: a function of the shape only, NOT of the number of right-hand sides, so
 // that a column's arithmetic (and therefore its bits) does not depend on how many columns ride along.
-static int skinny_splits(int64_t M, int64_t N, int /*ngroups*/) {
-  if (g_v_splits > 0) return g_v_splits;
+static int skinny_splits(const rls_ctx* ctx, int64_t M, int64_t N, int /*ngroups*/) {
+  if (ctx->tune.skinny_v_splits > 0) return ctx->tune.skinny_v_splits;
   const int64_t MB = M / 16, wgs = N / 16;
   int64_t S = (512 + wgs - 1) / wgs;               // ~2 workgroups of 4 waves per CU for one group
   const int64_t smax = MB / 16 > 0 ? MB / 16 : 1;  // keep >= 16 row blocks (4 per wave) per split
@@ -696,13 +679,13 @@ static int skinny_splits(int64_t M, int64_t N, int /*ngroups*/) {
   return (int)S;
 }
 
-int rls_skinny_half(int32_t dtype, int nrhs) { return g_half && dtype == RLS_C32 && nrhs <= 8; }
+int rls_skinny_half(const rls_ctx* ctx, int32_t dtype, int nrhs) { return ctx->tune.skinny_half && dtype == RLS_C32 && nrhs <= 8; }
 
-void rls_skinny_sizes(int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes, size_t* v_bytes,
-                      int* splits) {
-  const int half = rls_skinny_half(dtype, nrhs);
+void rls_skinny_sizes(const rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, int nrhs, size_t* p_bytes, size_t* t_bytes,
+                      size_t* v_bytes, int* splits) {
+  const int half = rls_skinny_half(ctx, dtype, nrhs);
   const int G = rls_skinny_groups(nrhs, half);
-  const int S = skinny_splits(M, N, G);
+  const int S = skinny_splits(ctx, M, N, G);
   // the half layout holds 16 floats (8 re | 8 im) per row where the full one holds 16 elements; sized for the
   // full layout either way so that the switch can be flipped on a live plan by the measurement tools
   *p_bytes = (size_t)G * N * 16 * rls_elem_size(dtype);
@@ -721,14 +704,14 @@ template <typename E>
 static void launch_t(rls_ctx* ctx, const rls_skinny& K) {
   const dim3 grid((unsigned)(K.M / 16), (unsigned)K.ngroups);
 #define SK_T(W, UU, HH)                                                                                            \
-  if (g_t_waves == W && g_t_u == UU) {                                                                             \
+  if (ctx->tune.skinny_t_waves == W && ctx->tune.skinny_t_u == UU) {                                                                             \
     hipLaunchKernelGGL((skinny_t_kernel<E, W, UU, HH>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda, \
                        (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);                                                  \
     return;                                                                                                        \
   }
 #define SK_TR(HH, DD)                                                                                              \
-  if (g_t_roll == DD && (K.half != 0) == HH) {                                                                     \
-    if (g_t_waves == 8)                                                                                            \
+  if (ctx->tune.skinny_t_roll == DD && (K.half != 0) == HH) {                                                                     \
+    if (ctx->tune.skinny_t_waves == 8)                                                                                            \
       hipLaunchKernelGGL((skinny_t_kernel<E, 8, 4, HH, DD>), grid, dim3(512), 0, ctx->stream, (const E*)K.A, K.lda, \
                          (const E*)K.Ppack, (E*)K.Tpack, K.M, K.N);                                                \
     else                                                                                                           \
@@ -760,14 +743,14 @@ static void launch_v(rls_ctx* ctx, const rls_skinny& K) {
   const dim3 grid((unsigned)(K.N / 16), (unsigned)K.splits, (unsigned)K.ngroups);
   const int pad = rls_skinny_pad(K.nrhs, K.half);
 #define SK_V(W, UU, HH)                                                                                            \
-  if (g_v_waves == W && g_v_u == UU) {                                                                             \
+  if (ctx->tune.skinny_v_waves == W && ctx->tune.skinny_v_u == UU) {                                                                             \
     hipLaunchKernelGGL((skinny_v_kernel<E, W, UU, HH>), grid, dim3(W * 64), 0, ctx->stream, (const E*)K.A, K.lda, \
                        (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);                                     \
     return;                                                                                                        \
   }
 #define SK_VR(HH, DD)                                                                                              \
-  if (g_v_roll == DD && (K.half != 0) == HH) {                                                                     \
-    if (g_v_waves == 8)                                                                                            \
+  if (ctx->tune.skinny_v_roll == DD && (K.half != 0) == HH) {                                                                     \
+    if (ctx->tune.skinny_v_waves == 8)                                                                                            \
       hipLaunchKernelGGL((skinny_v_kernel<E, 8, 1, HH, DD>), grid, dim3(512), 0, ctx->stream, (const E*)K.A, K.lda, \
                          (const E*)K.Tpack, (E*)K.Vpart, K.M, K.N, pad, K.ldvp);                                   \
     else                                                                                                           \
@@ -803,12 +786,12 @@ static void launch_g(rls_ctx* ctx, const rls_skinny& K) {
                      (const E*)K.Ppack, (E*)K.Vpart, K.N, K.N, pad, K.ldvp)
   if constexpr (elem<E>::cplx) {
     if (K.half) {
-      if (g_g_roll == 16) SK_G(true, 16);
-      else if (g_g_roll == 0) SK_G(true, 0);
+      if (ctx->tune.skinny_g_roll == 16) SK_G(true, 16);
+      else if (ctx->tune.skinny_g_roll == 0) SK_G(true, 0);
       else SK_G(true, 8);
     } else {
-      if (g_g_roll == 16) SK_G(false, 16);
-      else if (g_g_roll == 0) SK_G(false, 0);
+      if (ctx->tune.skinny_g_roll == 16) SK_G(false, 16);
+      else if (ctx->tune.skinny_g_roll == 0) SK_G(false, 0);
       else SK_G(false, 8);
     }
   } else {
@@ -1052,7 +1035,7 @@ int32_t rls_gram_tiles(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const 
                        int64_t ldg) {
   const int64_t T = N / 64;
   const dim3 grid((unsigned)(T * (T + 1) / 2));
-  const size_t lds = (size_t)g_gram_lds;  // occupancy limiter, see g_gram_lds
+  const size_t lds = (size_t)ctx->tune.gram_lds;  // occupancy limiter (rls_tuning::gram_lds)
   if (lds > 64 * 1024) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_mfma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_mfma_kernel<float2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

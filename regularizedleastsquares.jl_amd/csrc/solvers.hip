@@ -190,6 +190,10 @@ struct rls_cgnr {
   float* gk_vx = nullptr;
   void* gk_xx = nullptr;
   double* gk_dots = nullptr;
+  // rls_cgnr_solve_queue_host: this problem's right-hand side on the device and the pinned staging of b and x (created on first use)
+  void* q_b = nullptr;
+  void* q_bh = nullptr;
+  void* q_xh = nullptr;
 };
 
 static bool cgnr_use_gram_pipeline(const rls_cgnr* s) {
@@ -924,17 +928,20 @@ __global__ __launch_bounds__(UPD_THREADS) void fista_update_reg_kernel(E* __rest
 
 // launch of the update half of an unfused / batched FISTA iteration: the register form when it applies
 template <typename E>
-static void fista_launch_update(rls_fista* s, unsigned nblocks, const fista_batch<E>& Bt) {
+static int32_t fista_launch_update(rls_fista* s, unsigned nblocks, const fista_batch<E>& Bt) {
   rls_operator* op = s->op;
   const int64_t n = op->N;
+  int32_t tv_status = 0;
 #define RLS_FUPD_REG(EE)                                                                                            \
   hipLaunchKernelGGL((fista_update_reg_kernel<E, EE>), dim3(nblocks), dim3(UPD_THREADS), 0, op->ctx->stream,        \
                      (E*)s->buf[0], (E*)s->buf[1], (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt)
   if (s->reg_kind == RLS_REG_TV) {  // gradient step | FGP launch (its own workgroup, skipped once `done`) | projection, theta, y
     hipLaunchKernelGGL(fista_update_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->buf[0], (E*)s->buf[1],
                        (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt, 1, (E*)s->tv_in, (const E*)s->tv_out);
-    (void)rls_tv_single_launch(op->ctx, op->dtype, s->tv_ndims, s->tv_shape, s->tv_ntv, s->tv_dims, s->tv_in, nullptr, s->tv_out,
-                               s->rho_h * s->lambda, s->tv_iters, &s->sc->done, 1, 0, 0);
+    // (the threshold rho * lambda, the geometry and iterationsTV are kernel ARGUMENTS: a cached graph of this sequence is dropped
+    //  whenever one of them changes -- fista_drop_graph in rls_fista_set_reg / _set_reg_tv / fista_init_finish)
+    tv_status = rls_tv_single_launch(op->ctx, op->dtype, s->tv_ndims, s->tv_shape, s->tv_ntv, s->tv_dims, s->tv_in, nullptr, s->tv_out,
+                                     s->rho_h * s->lambda, s->tv_iters, &s->sc->done, 1, 0, 0);
     hipLaunchKernelGGL(fista_update_kernel<E>, dim3(1), dim3(UPD_THREADS), 0, op->ctx->stream, (E*)s->buf[0], (E*)s->buf[1],
                        (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt, 2, (E*)s->tv_in, (const E*)s->tv_out);
   } else if (s->reg_kind != RLS_REG_L21 && n <= 4 * UPD_THREADS) {
@@ -946,6 +953,7 @@ static void fista_launch_update(rls_fista* s, unsigned nblocks, const fista_batc
                        (E*)s->buf[1], (const E*)s->x0, (E*)s->res, (E*)s->y, n, s->sc, Bt);
   }
 #undef RLS_FUPD_REG
+  return tv_status;  // (a refused FGP launch would leave phase 2 reading a stale tv_out: the step reports it)
 }
 
 static bool fista_pipe_ok(const rls_fista* s) {
@@ -1001,9 +1009,9 @@ static int32_t fista_enqueue_iteration(rls_fista* s) {
   rls_operator* op = s->op;
   RLS_TRY(op_normal(op, s->y, s->res, &s->sc->done));
   if (op->dtype == RLS_F32)
-    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0});
+    RLS_TRY(fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0}));
   else
-    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0});
+    RLS_TRY(fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0}));
   return launch_status(op->ctx);
 }
 
@@ -1625,9 +1633,9 @@ static int32_t fista_enqueue_batched(rls_fista* s) {
   rls_ctx* ctx = op->ctx;
   RLS_TRY(rls_skinny_launch(ctx, op->dtype, fista_skinny_desc(s), 1 | 2));
   if (op->dtype == RLS_F32)
-    fista_launch_update<float>(s, (unsigned)s->nrhs, fista_batch_desc<float>(s));
+    RLS_TRY(fista_launch_update<float>(s, (unsigned)s->nrhs, fista_batch_desc<float>(s)));
   else
-    fista_launch_update<float2>(s, (unsigned)s->nrhs, fista_batch_desc<float2>(s));
+    RLS_TRY(fista_launch_update<float2>(s, (unsigned)s->nrhs, fista_batch_desc<float2>(s)));
   return launch_status(ctx);
 }
 
@@ -1945,7 +1953,7 @@ int32_t rls_operator_create(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, c
   op->slab = nullptr;
   if (A) {
     hipError_t e = dmalloc(&op->t, (size_t)M * rls_elem_size(dtype));
-    const size_t ws = rls_normal_fused_workspace(dtype, M, N, A, lda);
+    const size_t ws = rls_normal_fused_workspace(ctx, dtype, M, N, A, lda);
     if (e == hipSuccess && ws > 0) e = dmalloc(&op->slab, ws);
     if (e != hipSuccess) {
       if (op->t) dfree(op->t);
@@ -2092,7 +2100,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMemsetAsync(s->dots, 0, nd, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
     if (e == hipSuccess && nrhs > 1 && !skinny)
-      e = dmalloc(&s->slab_b, rls_normal_fused_workspace(op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
+      e = dmalloc(&s->slab_b, rls_normal_fused_workspace(op->ctx, op->dtype, op->M, op->N, op->A, op->lda) * (size_t)nrhs);
   }
   s->small = nrhs == 1 && op->A && !op->G && rls_small_ok(op->dtype, op->M, op->N, op->A, op->lda);
   if (e == hipSuccess && s->small && !s->srv.ctl && hmalloc(&s->srv.ctl, 32 * sizeof(unsigned)) == hipSuccess) {
@@ -2101,7 +2109,7 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   }
   if (e == hipSuccess && nrhs == 1 && op->slab && op->A && !op->G &&
       rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
-    const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
+    const size_t db = (size_t)rls_cgnr_resident_nwg(op->ctx, op->dtype, op->M, op->N) * 4 * sizeof(double);
     e = resident_alloc(ctx, op, &s->rsync, &s->rsync_h);
     if (e == hipSuccess) e = dmalloc(&s->rdots, db);
     if (e == hipSuccess) e = hipMemsetAsync(s->rdots, 0, db, ctx->stream);
@@ -2135,8 +2143,8 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
   }
   if (e == hipSuccess && skinny) {
     size_t pb, tb, vb;
-    rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
-    s->half = rls_skinny_half(op->dtype, nrhs);
+    rls_skinny_sizes(op->ctx, op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+    s->half = rls_skinny_half(op->ctx, op->dtype, nrhs);
     e = dmalloc(&s->Ppack, pb);
     if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
     if (e == hipSuccess) e = dmalloc(&s->Tpack, tb);
@@ -2190,6 +2198,9 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->gk_vx) dfree(s->gk_vx);
   if (s->gk_xx) dfree(s->gk_xx);
   if (s->gk_dots) dfree(s->gk_dots);
+  if (s->q_b) dfree(s->q_b);
+  if (s->q_bh) hfree(s->q_bh);
+  if (s->q_xh) hfree(s->q_xh);
   if (s->rsync) dfree(s->rsync);
   if (s->rdots) dfree(s->rdots);
   if (s->rsync_h) hfree(s->rsync_h);
@@ -2512,6 +2523,109 @@ int32_t rls_cgnr_get_status_group(rls_cgnr* const* plans, int32_t count, rls_cgn
     RLS_TRY(rls_fetch_wait(ctx));
   }
   for (int32_t k = 0; k < count; ++k) cgnr_status_out(plans[k], *plans[k]->sc_h, out + k);
+  return 0;
+}
+
+// ---- the distinct-A multi-solve as a queue (docs/src/literate/howto/multi_threading.jl:8-17: a solver AND an operator per task) ----
+// `count` independent problems, each an ordinary single right-hand-side plan on its own operator (any shape, any kernel path; one
+// context, hence one stream): problem k's init! (r = A_k^H b_k, x = 0, p = r: src/CGNR.jl:107-130) and all of its iterations
+// (:143-178) are enqueued behind problem k - 1's, nothing is waited for in between, and ONE read-back at the end brings every
+// problem's status.  A resident launch that was lost (its grid not on the chip in time) is re-run on the per-iteration pipeline
+// exactly as rls_cgnr_get_status does it, for that problem alone.  The register-resident kernels need the whole chip each, so the
+// problems run one after the other on the device -- what the queue removes is the host between them: per problem, plan creation,
+// upload, a synchronising status call and a download (measured: 210 us of host per 320 us of kernels, round 5).
+static int32_t cgnr_queue_validate(rls_cgnr* const* plans, int32_t count, rls_ctx** ctx_out) {
+  if (!plans || count < 1 || !plans[0]) return RLS_E_INVALID;
+  rls_ctx* ctx = plans[0]->op->ctx;
+  for (int32_t k = 0; k < count; ++k) {
+    const rls_cgnr* s = plans[k];
+    if (!s || s->op->ctx != ctx || s->nrhs != 1)
+      return rls_fail(ctx, RLS_E_INVALID, "cgnr solve queue: single right-hand-side plans of one context");
+    for (int32_t j = 0; j < k; ++j)
+      if (plans[j] == s) return rls_fail(ctx, RLS_E_INVALID, "cgnr solve queue: a plan appears twice (one plan per problem)");
+  }
+  *ctx_out = ctx;
+  return 0;
+}
+
+// every plan's scalars (and, after resident launches, its sync block's flags) in as few publishing launches as the mailbox holds
+static int32_t cgnr_queue_statuses(rls_ctx* ctx, rls_cgnr* const* plans, int32_t count, rls_cgnr_status* out) {
+  constexpr int32_t PER = RLS_FETCH_MAX / 2;  // two read-backs per plan at most
+  for (int32_t k0 = 0; k0 < count; k0 += PER) {
+    const int32_t k1 = k0 + PER < count ? k0 + PER : count;
+    for (int32_t k = k0; k < k1; ++k) {
+      rls_cgnr* s = plans[k];
+      if (s->resident_used) RLS_TRY(resident_fetch_flags(ctx, s->rsync, s->rsync_h));
+      RLS_TRY(rls_fetch_add(ctx, s->sc, s->sc_h, sizeof(cgnr_scalars)));
+    }
+    RLS_TRY(rls_fetch_wait(ctx));
+  }
+  for (int32_t k = 0; k < count; ++k) {
+    rls_cgnr* s = plans[k];
+    if (s->resident_used && resident_lost(ctx, s->rsync, s->rsync_h, &s->resident_off, &s->fallbacks)) {
+      const long long missing = s->requested - (long long)s->sc_h->iteration;
+      if (!s->sc_h->done && missing > 0) {
+        RLS_TRY(cgnr_step_impl(s, (int32_t)(missing > 0x7fffffff ? 0x7fffffff : missing)));
+        RLS_TRY(fetch_scalars(ctx, s->sc, s->sc_h));
+      }
+    }
+    s->resident_used = false;
+    if (out) cgnr_status_out(s, *s->sc_h, out + k);
+  }
+  return 0;
+}
+
+int32_t rls_cgnr_solve_queue(rls_cgnr* const* plans, const void* const* b, int32_t count, float lambda, float rel_tol,
+                             int32_t iterations, rls_cgnr_status* out) {
+  rls_ctx* ctx = nullptr;
+  RLS_TRY(cgnr_queue_validate(plans, count, &ctx));
+  if (!b || iterations < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr solve queue: bad argument");
+  for (int32_t k = 0; k < count; ++k) {
+    RLS_TRY(rls_cgnr_init(plans[k], b[k], lambda, rel_tol, iterations));
+    RLS_TRY(rls_cgnr_step(plans[k], iterations));
+  }
+  return cgnr_queue_statuses(ctx, plans, count, out);
+}
+
+// the same with b and x in HOST memory (the shape of the reference's task: host arrays in, host array out): b_k is staged through
+// pinned memory and uploaded on the stream ahead of problem k's init, x_k is downloaded into pinned memory behind its last
+// iteration -- every copy asynchronous, one synchronisation for the whole queue -- and handed to x_h[k] at the end.
+int32_t rls_cgnr_solve_queue_host(rls_cgnr* const* plans, const void* const* b_h, void* const* x_h, int32_t count, float lambda,
+                                  float rel_tol, int32_t iterations, rls_cgnr_status* out) {
+  rls_ctx* ctx = nullptr;
+  RLS_TRY(cgnr_queue_validate(plans, count, &ctx));
+  if (!b_h || !x_h || iterations < 0) return rls_fail(ctx, RLS_E_INVALID, "cgnr solve queue: bad argument");
+  RLS_HIP(ctx, rls_enter(ctx));
+  for (int32_t k = 0; k < count; ++k) {
+    rls_cgnr* s = plans[k];
+    const rls_operator* op = s->op;
+    const size_t es = rls_elem_size(op->dtype);
+    const size_t bb = (size_t)(op->A ? op->M : op->N) * es, xb = (size_t)op->N * es;
+    if (!b_h[k] || !x_h[k]) return rls_fail(ctx, RLS_E_INVALID, "cgnr solve queue: null buffer");
+    if (!s->q_b) {
+      rls_alloc_scope alloc_scope(ctx);
+      RLS_HIP(ctx, dmalloc(&s->q_b, bb));
+      RLS_HIP(ctx, hmalloc(&s->q_bh, bb));
+      RLS_HIP(ctx, hmalloc(&s->q_xh, xb));
+    }
+    memcpy(s->q_bh, b_h[k], bb);
+    RLS_HIP(ctx, hipMemcpyAsync(s->q_b, s->q_bh, bb, hipMemcpyHostToDevice, ctx->stream));
+    RLS_TRY(rls_cgnr_init(s, s->q_b, lambda, rel_tol, iterations));
+    RLS_TRY(rls_cgnr_step(s, iterations));
+    RLS_HIP(ctx, hipMemcpyAsync(s->q_xh, s->x, xb, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  RLS_TRY(cgnr_queue_statuses(ctx, plans, count, out));
+  // a problem whose resident launch was lost has been re-run behind the queued download of its x: fetch that one again
+  bool any = false;
+  for (int32_t k = 0; k < count; ++k) {
+    rls_cgnr* s = plans[k];
+    if (s->resident_off && s->fallbacks > 0) {
+      RLS_HIP(ctx, hipMemcpyAsync(s->q_xh, s->x, (size_t)s->op->N * rls_elem_size(s->op->dtype), hipMemcpyDeviceToHost, ctx->stream));
+      any = true;
+    }
+  }
+  if (any) RLS_HIP(ctx, rls_stream_wait(ctx->stream));
+  for (int32_t k = 0; k < count; ++k) memcpy(x_h[k], plans[k]->q_xh, (size_t)plans[k]->op->N * rls_elem_size(plans[k]->op->dtype));
   return 0;
 }
 
@@ -3016,6 +3130,14 @@ int32_t rls_fista_destroy(rls_fista* s) {
   return 0;
 }
 
+// A cached graph of this plan's iteration holds the kernel SEQUENCE of its regulariser and, for TV, the threshold rho * lambda, the
+// image geometry and iterationsTV as kernel arguments (every other regulariser reads rho and lambda from the scalars on the device):
+// whatever changes one of them drops the graph, the next step call captures afresh.
+static void fista_drop_graph(rls_fista* s) {
+  if (s->graph.exec) hipGraphExecDestroy(s->graph.exec);
+  s->graph = step_graph();
+}
+
 int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t l21_slices, int32_t proj_kind) {
   if (!s) return RLS_E_INVALID;
   rls_ctx* ctx = s->op->ctx;
@@ -3025,6 +3147,7 @@ int32_t rls_fista_set_reg(rls_fista* s, int32_t reg_kind, float lambda, int64_t 
     return rls_fail(ctx, RLS_E_INVALID, "fista_set_reg: unknown kind");
   if (reg_kind == RLS_REG_L21 && (l21_slices <= 0 || s->op->N / l21_slices == 0))
     return rls_fail(ctx, RLS_E_INVALID, "fista_set_reg: slices must be in 1..N");
+  if (s->reg_kind == RLS_REG_TV || reg_kind != s->reg_kind) fista_drop_graph(s);  // another kernel sequence (or TV's baked arguments)
   s->reg_kind = reg_kind;
   s->proj_kind = proj_kind;
   s->lambda = lambda;
@@ -3048,7 +3171,7 @@ int32_t rls_fista_set_reg_tv(rls_fista* s, float lambda, int32_t ndims, const in
   for (int k = 0; k < ndims; ++k) n *= shape[k];
   if (n != s->op->N) return rls_fail(ctx, RLS_E_INVALID, "fista_set_reg_tv: prod(shape) != N");
   if (s->nrhs != 1) return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista_set_reg_tv: single right-hand side plans only");
-  if (!rls_tv_single_ok(s->op->dtype, ndims, shape, ntv, dims))
+  if (!rls_tv_single_ok(s->op->ctx, s->op->dtype, ndims, shape, ntv, dims))
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista_set_reg_tv: the image does not fit the single-workgroup FGP kernel; drive FISTA from the primitives");
   RLS_HIP(ctx, rls_enter(ctx));
   if (!s->tv_in) {
@@ -3057,6 +3180,12 @@ int32_t rls_fista_set_reg_tv(rls_fista* s, float lambda, int32_t ndims, const in
     RLS_HIP(ctx, dmalloc(&s->tv_in, bytes));
     RLS_HIP(ctx, dmalloc(&s->tv_out, bytes));
   }
+  // lambda, the geometry and iterationsTV are arguments of the captured FGP launch: a cached graph survives only an identical call
+  bool same = s->reg_kind == RLS_REG_TV && s->lambda == lambda && s->tv_iters == iterations_tv && s->tv_ndims == ndims &&
+              s->tv_ntv == ntv && s->proj_kind == proj_kind;
+  for (int k = 0; k < 4 && same; ++k)
+    same = s->tv_shape[k] == (k < ndims ? shape[k] : 1) && s->tv_dims[k] == (k < ntv ? dims[k] : 0);
+  if (!same) fista_drop_graph(s);
   s->tv_ndims = ndims;
   s->tv_ntv = ntv;
   for (int k = 0; k < 4; ++k) {
@@ -3106,6 +3235,12 @@ static int32_t fista_init_finish(rls_fista* s, float rho, float theta, float rel
   s->enq = 0;
   s->requested = 0;
   s->theta0 = theta;
+  if (s->reg_kind == RLS_REG_TV) {
+    if (rho != s->rho_h) fista_drop_graph(s);  // rho * lambda is an argument of the captured FGP launch
+    // the single-workgroup FGP kernel was checked when the regulariser was set; its limits are context tunables that may have moved
+    if (!rls_tv_single_ok(op->ctx, op->dtype, s->tv_ndims, s->tv_shape, s->tv_ntv, s->tv_dims))
+      return rls_fail(ctx, RLS_E_UNSUPPORTED, "fista_init: the TV image no longer fits the single-workgroup FGP kernel");
+  }
   s->rho_h = rho;
   s->srv.off = false;  // (a new solve: the caller's pattern between iterates is judged afresh)
   s->srv.short_lives = 0;
@@ -3149,9 +3284,9 @@ int32_t rls_fista_step_local_b(rls_fista* s) {
   if (!s->initialised || s->use_pipe || s->use_gram) return rls_fail(ctx, RLS_E_STATE, "fista_step_local before fista_init_local_b");
   RLS_HIP(ctx, rls_enter(ctx));
   if (op->dtype == RLS_F32)
-    fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0});
+    RLS_TRY(fista_launch_update<float>(s, 1, fista_batch<float>{0, nullptr, 1, 0, nullptr, 0}));
   else
-    fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0});
+    RLS_TRY(fista_launch_update<float2>(s, 1, fista_batch<float2>{0, nullptr, 1, 0, nullptr, 0}));
   return launch_status(ctx);
 }
 
@@ -3189,8 +3324,8 @@ int32_t rls_fista_create_batched(rls_operator* op, int32_t nrhs, void* x, void* 
   s->ldv = ldv;
   s->sc = s->sc_h = nullptr;
   size_t pb, tb, vb;
-  rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
-  s->half = rls_skinny_half(op->dtype, nrhs);
+  rls_skinny_sizes(op->ctx, op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+  s->half = rls_skinny_half(op->ctx, op->dtype, nrhs);
   const size_t yb = (size_t)ldv * nrhs * rls_elem_size(op->dtype);
   hipError_t e = dmalloc(&s->y, yb);
   if (e == hipSuccess) e = dmalloc(&s->Ypack, pb);
@@ -3635,7 +3770,7 @@ int32_t rls_cg_create(rls_operator* op, void* u, void* r, void* c, rls_cg** out)
     }
   } else if (op->slab) {
     if (op->A && rls_cgnr_resident_ok(ctx, op->dtype, op->M, op->N, op->A, op->lda)) {
-      const size_t db = (size_t)rls_cgnr_resident_nwg(op->dtype, op->M, op->N) * 4 * sizeof(double);
+      const size_t db = (size_t)rls_cgnr_resident_nwg(op->ctx, op->dtype, op->M, op->N) * 4 * sizeof(double);
       if (resident_alloc(ctx, op, &s->rsync, &s->rsync_h) != hipSuccess || dmalloc(&s->rdots, db) != hipSuccess) {
         if (s->rsync) dfree(s->rsync);
         s->rsync = nullptr;  // an optimisation only: the two-launch pipeline runs without it
@@ -3688,8 +3823,8 @@ int32_t rls_cg_create_batched(rls_operator* op, int32_t nrhs, void* U, void* R, 
   s->nrhs = nrhs;
   s->ldv = ldv;
   size_t pb, tb, vb;
-  rls_skinny_sizes(op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
-  s->half = rls_skinny_half(op->dtype, nrhs);
+  rls_skinny_sizes(op->ctx, op->dtype, op->M, op->N, nrhs, &pb, &tb, &vb, &s->splits);
+  s->half = rls_skinny_half(op->ctx, op->dtype, nrhs);
   hipError_t e = dmalloc(&s->Ppack, pb);
   if (e == hipSuccess) e = hipMemsetAsync(s->Ppack, 0, pb, ctx->stream);  // the padding columns of the last group stay zero
   if (e == hipSuccess) e = dmalloc(&s->Tpack, tb);
@@ -4076,7 +4211,7 @@ int32_t rls_admm_init(rls_admm* a, const rls_admm_params* p) {
       break;
     case RLS_REG_TV:
       if (p->proj_kind != RLS_PROJ_NONE || p->tv_iterations < 0 ||
-          !rls_tv_single_ok(dtype, p->tv_ndims, p->tv_shape, p->tv_ntv, p->tv_dims))
+          !rls_tv_single_ok(ctx, dtype, p->tv_ndims, p->tv_shape, p->tv_ntv, p->tv_dims))
         return rls_fail(ctx, RLS_E_UNSUPPORTED, "admm_init: TV prox does not fit the single-workgroup FGP kernel");
       {
         int64_t n = 1;

@@ -457,8 +457,8 @@ static fgp_graph_cache& fgp_cache_for(rls_ctx* ctx) {
 }
 
 constexpr size_t FGP_LDS_BUDGET = 160 * 1024 - 512;
-static int64_t g_fused_max_n = 2048;  // larger images: one CU is slower than 2 chip-wide launches per FGP iteration
-static int g_fused_2d = 1;            // the register-resident 2-D kernel (n <= 8192 pixels)
+// (rls_tuning::tv_fused_max_n -- larger images: one CU is slower than 2 chip-wide launches per FGP iteration -- and tv_fused_2d, the
+//  register-resident 2-D kernel for n <= 8192 pixels, are the context's)
 constexpr int FGP2D_MAX_PPT = 8;
 
 static int32_t tv_status(rls_ctx* ctx) {
@@ -474,9 +474,9 @@ static inline unsigned tv_grid(int64_t n) {
 }
 
 // geometry of the register-resident kernel: (nx, ny, use0, use1), or false
-static bool fgp2d_geom(const tv_geom& G, size_t es, unsigned* nx, unsigned* ny, int* use0, int* use1) {
+static bool fgp2d_geom(const rls_ctx* ctx, const tv_geom& G, size_t es, unsigned* nx, unsigned* ny, int* use0, int* use1) {
   // complex images: 4 pixels per thread is the register limit at 1024 threads
-  if (!g_fused_2d || G.ndims > 2 || G.ntv < 1 || G.n > 1024 * (es > 4 ? FGP2D_MAX_PPT / 2 : FGP2D_MAX_PPT)) return false;
+  if (!ctx->tune.tv_fused_2d || G.ndims > 2 || G.ntv < 1 || G.n > 1024 * (es > 4 ? FGP2D_MAX_PPT / 2 : FGP2D_MAX_PPT)) return false;
   if ((size_t)3 * G.n * es > FGP_LDS_BUDGET) return false;
   *use0 = *use1 = 0;
   for (int k = 0; k < G.ntv; ++k) {
@@ -509,7 +509,7 @@ static bool fgp_single_launch(rls_ctx* ctx, const tv_geom& G, const E* xin, cons
                               const int* skip, const tv_batch& Bt = tv_batch()) {
   unsigned nx, ny;
   int use0, use1;
-  if (fgp2d_geom(G, sizeof(E), &nx, &ny, &use0, &use1)) {
+  if (fgp2d_geom(ctx, G, sizeof(E), &nx, &ny, &use0, &use1)) {
     const unsigned n = nx * ny;
     if (n <= 1024)
       fgp2d_launch<E, 1>(ctx, nx, ny, use0, use1, xin, add, out, lam, iters, skip, Bt);
@@ -523,7 +523,7 @@ static bool fgp_single_launch(rls_ctx* ctx, const tv_geom& G, const E* xin, cons
   }
   const int64_t ng = G.goff[G.ntv], n = G.n;
   const size_t lds = (size_t)(2 * ng + 2 * n) * sizeof(E);
-  if (lds <= FGP_LDS_BUDGET && n <= g_fused_max_n) {
+  if (lds <= FGP_LDS_BUDGET && n <= ctx->tune.tv_fused_max_n) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&fgp_fused_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     hipLaunchKernelGGL(fgp_fused_kernel<E>, dim3((unsigned)Bt.count), dim3(1024), lds, ctx->stream, xin, add, out,
@@ -609,19 +609,16 @@ int32_t fgp_typed(rls_ctx* ctx, const tv_geom& G, E* x, float lam, int iters, E*
 
 }  // namespace
 
-void rls_tv_set_fused_max_n(int64_t n) { g_fused_max_n = n; }
-void rls_tv_set_fused_2d(int on) { g_fused_2d = on; }
-
-static bool tv_single_ok(const tv_geom& G, size_t es) {
+static bool tv_single_ok(const rls_ctx* ctx, const tv_geom& G, size_t es) {
   unsigned nx, ny;
   int u0, u1;
-  if (fgp2d_geom(G, es, &nx, &ny, &u0, &u1)) return true;
-  return (size_t)(2 * G.goff[G.ntv] + 2 * G.n) * es <= FGP_LDS_BUDGET && G.n <= g_fused_max_n;
+  if (fgp2d_geom(ctx, G, es, &nx, &ny, &u0, &u1)) return true;
+  return (size_t)(2 * G.goff[G.ntv] + 2 * G.n) * es <= FGP_LDS_BUDGET && G.n <= ctx->tune.tv_fused_max_n;
 }
 
-bool rls_tv_single_ok(int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims) {
+bool rls_tv_single_ok(const rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims) {
   tv_geom G;
-  return rls_dtype_ok(dtype) && make_geom(ndims, shape, ntv, dims, &G) && tv_single_ok(G, rls_elem_size(dtype));
+  return ctx && rls_dtype_ok(dtype) && make_geom(ndims, shape, ntv, dims, &G) && tv_single_ok(ctx, G, rls_elem_size(dtype));
 }
 
 int32_t rls_tv_single_launch(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv,
@@ -726,7 +723,7 @@ int32_t rls_prox_tv_fgp(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_
   if (!rls_dtype_ok(dtype) || !x || iterations < 0 || !make_geom(ndims, shape, ntv, dims, &G))
     return rls_fail(ctx, RLS_E_INVALID, "prox_tv_fgp: bad argument");
   const size_t need = (size_t)(2 * G.goff[G.ntv] + G.n) * rls_elem_size(dtype);
-  const bool fused = tv_single_ok(G, rls_elem_size(dtype));
+  const bool fused = tv_single_ok(ctx, G, rls_elem_size(dtype));
   if (!fused && (!workspace || workspace_bytes < need))
     return rls_fail(ctx, RLS_E_WORKSPACE, "prox_tv_fgp: workspace too small");
   RLS_HIP(ctx, rls_enter(ctx));

@@ -854,18 +854,30 @@ def make_row_shard(M: int, N: int, rank: int, world: int, dtype=np.complex64, se
     return A, lo, hi
 
 
-def bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=65536, N=8192):
+def bench_rowsharded(rls, ctx, dist, rank, world, K, W, M=65536, N=8192, agree=None, inject=None):
     """BASELINE config 5 measurement: iterations/s of one 65536 x 8192 ComplexF32 CGNR, row-sharded
-    over `world` GPUs (strong scaling of one problem; not the default bench line)."""
+    over `world` GPUs (strong scaling of one problem; not the default bench line).
+    agree(stage, err): the caller's agreement point (bench.py): this function's setup -- shard generation, upload, plan creation, no
+    collective -- ends there, so that a rank whose setup failed does not leave the others alone in the first all-reduce."""
     import torch
 
-    A, lo, hi = make_row_shard(M, N, rank, world)
-    rng = np.random.default_rng(7)
-    x_true = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(np.complex64)
-    b_local = (A @ x_true).astype(np.complex64)
-    ops = HipLocalOps(rls, A, torch.cuda.current_device())
-    seg = 32
-    solver = RowShardedCGNR(ops, dist, iterations=seg, relTol=0.0)
+    err = None
+    try:
+        if inject is not None:
+            inject("config5")
+        A, lo, hi = make_row_shard(M, N, rank, world)
+        rng = np.random.default_rng(7)
+        x_true = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(np.complex64)
+        b_local = (A @ x_true).astype(np.complex64)
+        ops = HipLocalOps(rls, A, torch.cuda.current_device())
+        seg = 32
+        solver = RowShardedCGNR(ops, dist, iterations=seg, relTol=0.0)
+    except Exception as e:  # noqa: BLE001
+        if agree is None:
+            raise
+        err = e
+    if agree is not None:
+        agree("config5: setup", err)
 
     def run(n):
         while n > 0:

@@ -263,49 +263,96 @@ class CGNR(AbstractKrylovSolver):
 
 def solve_group_(solvers, rhs):
     """K independent solves, each solver with its OWN matrix -- the reference's other multi-solve flavour, one solver per problem
-    under `Threads.@threads` (docs/src/literate/howto/multi_threading.jl:8-17).  CGNR solvers of small systems (every plan on the
-    single-workgroup kernel, `rls_cgnr_path` 8) with the same L2 weight, relTol and iteration count run as ONE launch: init! and all
-    iterations of all K problems, one workgroup per problem (rls_cgnr_init_step_group).  Anything else: solve_ one after the other.
-    Returns the solutions in order."""
+    under `Threads.@threads` (docs/src/literate/howto/multi_threading.jl:8-17).  CGNR solvers with the same L2 weight, relTol and
+    iteration count on one context run WITHOUT the host in between:
+      * small systems (every plan on the single-workgroup kernel, `rls_cgnr_path` 8): ONE launch -- init! and all iterations of all
+        K problems, one workgroup per problem (rls_cgnr_init_step_group);
+      * anything else: a QUEUE on the context's stream (rls_cgnr_solve_queue) -- problem k's init! and iterations enqueued behind
+        problem k - 1's, one read-back for all statuses.  rhs may be HOST arrays (numpy): they are staged through pinned memory,
+        uploaded and the solutions downloaded asynchronously inside the same queue (rls_cgnr_solve_queue_host), and the call
+        returns host arrays -- the shape of the reference's task, host arrays in and out.
+    Anything else (other solvers, different parameters, several contexts): solve_ one after the other.  Returns the solutions in order."""
     from .arrays import DeviceVector
     solvers, rhs = list(solvers), list(rhs)
     if len(solvers) != len(rhs):
         raise ValueError("solve_group_: one right-hand side per solver")
+    host = len(rhs) >= 1 and all(isinstance(b, np.ndarray) for b in rhs)
     ok = len(solvers) >= 1 and all(isinstance(s_, CGNR) and isinstance(s_._op, OperatorHandle) and s_.A is not None and
                                   isinstance(s_.state, CGNRState) for s_ in solvers)
-    if ok:
+    if ok and host:
+        ctx = solvers[0].A.ctx
+        ok = all(s_.A.ctx is ctx and s_.A.dtype == np.dtype(b.dtype) and b.ndim == 1 and b.shape[0] == s_._op.M
+                 for s_, b in zip(solvers, rhs))
+        if ok:
+            for s_, b in zip(solvers, rhs):   # the plan and its state vectors (created once per solver; `b` only lends its type)
+                s_._prepare(s_.state, _ShapeOnly(s_._op.M, np.dtype(b.dtype), ctx))
+    elif ok:
         ctx = rhs[0].ctx
         ok = all(isinstance(b, DeviceVector) and b.ctx is ctx and b.dtype == rhs[0].dtype for b in rhs)
+        if ok:
+            for s_, b in zip(solvers, rhs):
+                s_._prepare(s_.state, b)
     if ok:
-        for s_, b in zip(solvers, rhs):
-            s_._prepare(s_.state, b)
         first = solvers[0]
         ok = all(s_.L2.lam == first.L2.lam and s_.state.relTol == first.state.relTol and s_.iterations == first.iterations
                  for s_ in solvers)
-    if ok:
-        lib, K = ctx.lib, len(solvers)
-        path = C.c_int32(-1)
-        for s_ in solvers:
-            check(ctx.handle, lib.rls_cgnr_path(s_.state._plan, C.byref(path)), "rls_cgnr_path")
-            ok = ok and path.value == 8
     if not ok:
+        if host:
+            return [solve_(s_, DeviceVector.from_host(b, s_.A.ctx), _no_group=True).to_host() for s_, b in zip(solvers, rhs)]
         return [solve_(s_, b, _no_group=True) for s_, b in zip(solvers, rhs)]
+    lib, K = ctx.lib, len(solvers)
+    small = not host
+    path = C.c_int32(-1)
+    for s_ in solvers:
+        check(ctx.handle, lib.rls_cgnr_path(s_.state._plan, C.byref(path)), "rls_cgnr_path")
+        small = small and path.value == 8
     plans = (C.c_void_p * K)(*[s_.state._plan for s_ in solvers])
-    bptr = (C.c_void_p * K)(*[b.ptr for b in rhs])
-    n = min(first.iterations, max(s_._op.N for s_ in solvers))  # (each plan stops at its own min(iterations, N): src/CGNR.jl:185)
-    check(ctx.handle, lib.rls_cgnr_init_step_group(plans, bptr, K, float(first.L2.lam), float(first.state.relTol), first.iterations, n),
-          "rls_cgnr_init_step_group")
     sts = (CgnrStatus * K)()
-    check(ctx.handle, lib.rls_cgnr_get_status_group(plans, K, sts), "rls_cgnr_get_status_group")   # ONE read-back for the group
+    xs_host = None
+    if host:
+        bs = [np.ascontiguousarray(b) for b in rhs]
+        xs_host = [np.empty(s_._op.N, dtype=b.dtype) for s_, b in zip(solvers, bs)]
+        bptr = (C.c_void_p * K)(*[b.ctypes.data for b in bs])
+        xptr = (C.c_void_p * K)(*[x.ctypes.data for x in xs_host])
+        check(ctx.handle, lib.rls_cgnr_solve_queue_host(plans, bptr, xptr, K, float(first.L2.lam), float(first.state.relTol),
+                                                        first.iterations, sts), "rls_cgnr_solve_queue_host")
+    elif small:
+        bptr = (C.c_void_p * K)(*[b.ptr for b in rhs])
+        n = min(first.iterations, max(s_._op.N for s_ in solvers))  # (each plan stops at its own min(iterations, N): src/CGNR.jl:185)
+        check(ctx.handle, lib.rls_cgnr_init_step_group(plans, bptr, K, float(first.L2.lam), float(first.state.relTol), first.iterations, n),
+              "rls_cgnr_init_step_group")
+        check(ctx.handle, lib.rls_cgnr_get_status_group(plans, K, sts), "rls_cgnr_get_status_group")   # ONE read-back for the group
+    else:
+        bptr = (C.c_void_p * K)(*[b.ptr for b in rhs])
+        check(ctx.handle, lib.rls_cgnr_solve_queue(plans, bptr, K, float(first.L2.lam), float(first.state.relTol), first.iterations, sts),
+              "rls_cgnr_solve_queue")
     out = []
-    for s_, st in zip(solvers, sts):
+    for k, (s_, st) in enumerate(zip(solvers, sts)):
         CGNR._after_init(s_.state)
         s_.state._take(st)
         s_.state._status_valid = True
-        while s_.iterate(s_.state) is not None:   # (returns None at once where the solve is done: applies the constraints)
-            pass
-        out.append(s_.state.x)
+        if host and s_.constr:   # the constraints act on the device vector at exit (src/CGNR.jl:145-147): fetch it behind them
+            while s_.iterate(s_.state) is not None:
+                pass
+            xs_host[k] = s_.state.x.to_host()
+        elif host:
+            s_.state._finalised = True
+        else:
+            while s_.iterate(s_.state) is not None:   # (returns None at once where the solve is done: applies the constraints)
+                pass
+        out.append(xs_host[k] if host else s_.state.x)
     return out
+
+
+class _ShapeOnly:
+    """what CGNR._prepare asks of `b` when the right-hand side lives on the host: its length, element type, context and `similar`"""
+
+    def __init__(self, n, dtype, ctx):
+        self.n, self.dtype, self.ctx = int(n), np.dtype(dtype), ctx
+
+    def similar(self, n=None):
+        from .arrays import DeviceVector
+        return DeviceVector(self.n if n is None else int(n), self.dtype, self.ctx)
 
 
 # --------------------------------------------------------------------------------------------

@@ -180,6 +180,41 @@ def test_golden_fista_admm_prox_on_device(rls, ctx):
                 assert rel(got, want) < 2e-6, (key, tag, rel(got, want))
 
 
+def test_fista_tv_plan_reused_with_other_parameters(rls, ctx):
+    """One solver, two solves with iterations >= 2 graph chunks and DIFFERENT rho and lambda (a lambda sweep on one solver;
+    MeasurementBasedNormalization does the same per b): the TV threshold rho * lambda, the image geometry and iterationsTV are
+    arguments of the plan's captured FGP launch, so a plan that kept its graph across the change would replay the OLD threshold
+    for 16 of every 16 + k iterations (review finding, round 5).  The second solve must equal a fresh solver's, bit for bit.
+    Also L1 -> TV -> L1 on one plan (another kernel sequence).  src/FISTA.jl:164, src/proximalMaps/ProxTV.jl:64-68."""
+    shape = (16, 16)
+    N = 256
+    A, xt, b = O.make_problem(3 * N, N, np.float32, 977)
+    rho = 0.9 / np.linalg.norm(A.astype(np.float64), 2) ** 2
+    lam = 0.02 * float(np.max(np.abs(A.astype(np.float64).T @ b)))
+    Ad, bd = rls.DeviceMatrix.from_host(A, ctx), rls.DeviceVector.from_host(b, ctx)
+    s = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.TVRegularization(lam, shape=shape), rho=rho, iterations=40, relTol=0.0)
+    x1 = rls.solve_(s, bd).to_host()
+    assert s.state._plan and s.state.iteration == 40
+    for rho2, lam2, itv in ((0.5 * rho, 3.0 * lam, 10), (rho, lam, 4)):
+        s.reg = rls.TVRegularization(lam2, shape=shape, iterationsTV=itv)
+        s.state.rho = rho2
+        x2 = rls.solve_(s, bd).to_host()
+        f = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.TVRegularization(lam2, shape=shape, iterationsTV=itv), rho=rho2, iterations=40,
+                                   relTol=0.0)
+        xf = rls.solve_(f, bd).to_host()
+        assert np.array_equal(x2, xf), (rho2, lam2, itv, rel(x2, xf))
+        o = O.FISTA(A.astype(np.float64), reg=O.TVRegularization(lam2, shape=shape, iterationsTV=itv), rho=rho2, iterations=40, relTol=0.0)
+        assert rel(x2, np.array(O.solve(o, b.astype(np.float64)))) < 1e-5
+    assert not np.array_equal(x1, x2)
+    # the regulariser KIND changes on one plan: L1's one-launch update, then TV's three launches, then L1 again
+    s.reg = rls.L1Regularization(lam)
+    xa = rls.solve_(s, bd).to_host()
+    fa = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(lam), rho=rho, iterations=40, relTol=0.0)
+    assert np.array_equal(xa, rls.solve_(fa, bd).to_host())
+    s.reg = rls.TVRegularization(lam, shape=shape)
+    assert np.array_equal(rls.solve_(s, bd).to_host(), x1)
+
+
 # ---- the N > 1 path of bench.py, rehearsed on the one GPU of this box ---------------------------------------------------
 @pytest.mark.parametrize("n", [2, 8])
 def test_bench_multi_gpu_path_rehearsed_on_one_gpu(n):
@@ -217,6 +252,36 @@ def test_bench_multi_gpu_path_rehearsed_on_one_gpu(n):
     assert direct["ranks"] == n and direct["iterations_per_s"] > 0 and np.isfinite(direct["residual"])
     assert direct["peer_probe"]["transport_in_use"] == 2 and direct["peer_probe"]["all_pairs"]
     assert "skipped" in c5["one_process_host"]["rccl"]
+
+
+@pytest.mark.parametrize("where", ["config5:1", "config4_gram:0"])
+def test_bench_multi_gpu_leg_failure_on_one_rank_keeps_the_line(where):
+    """One rank failing inside the setup of a leg behind the headline (RLS_BENCH_FAIL=<leg>:<rank>) must not leave the other ranks
+    in that leg's collectives nor cost the line: the ranks agree at the end of the setup (an all-reduced flag), skip the leg TOGETHER,
+    the line prints with `error` naming the owner's rank, the legs after it still run, and the job exits 0.  (The first 8-GPU run of
+    the driver is the first run of this code on more than one device; semantics src/MultiThreading.jl:30-79.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RLS_BENCH_FAIL=where, RLS_BENCH_DIST_TIMEOUT_S="60")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "64", "--warmup", "32",
+                        "--c5-rows", "8192"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "distributed_error" not in d
+    leg, owner = where.split(":")
+    c4, c5 = d["config4_batched"], d["config5_rowsharded"]
+    if leg == "config5":
+        assert f"failed on rank {owner}" in c5["error"] and "injected failure" in r.stderr
+        assert c4["value"] > 0 and c4["gram_mode"]["value"] > 0
+    else:
+        assert f"failed on rank {owner}" in c4["gram_mode"]["error"]
+        assert c4["value"] > 0 and c5["value"] > 0 and np.isfinite(c5["residual"])  # the legs behind the failed one still ran
 
 
 # ---- FISTA with a TV regulariser inside the plan, single GPU and row-sharded (SURVEY 8e last row) -----------------------------
