@@ -568,6 +568,38 @@ def other_paths(rls, ctx, Ad, A, b, errors):
             res[f"{ns}_stream(s)"] = {"ms_per_8_solves": 1e3 * dt_, "solve_iterations_per_s": 8 * 32 / dt_}
         res["note"] = ("whole solve! calls from worker threads (plan creation, upload of b, 32 iterations, download of x); the slab / resident "
                        "kernels need the whole chip, so only setup and the small kernels overlap")
+        # the same 8 problems (host b in, host x out) as ONE queue: rls_cgnr_solve_queue_host -- plans cached per operator, uploads,
+        # init!, iterations and downloads of problem k enqueued behind problem k - 1's, one synchronisation for all eight
+        cs = ConcurrentSolves(rls, n_streams=1)
+        try:
+            dA = cs.upload(mats)
+            mk = lambda Ad_: rls.createLinearSolver(rls.CGNR, Ad_, iterations=32, relTol=0.0)
+            xs = cs.solve_queue(dA, rhs, mk)
+            errs_q = []
+            for m_, b_, x_ in zip(mats, rhs, xs):
+                errs_q.append(float(np.linalg.norm(x_.astype(np.complex128) - float64_cgnr(m_, b_, 32)) / np.linalg.norm(x_)))
+            dts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                cs.solve_queue(dA, rhs, mk)
+                dts.append(time.perf_counter() - t0)
+            dt_ = min(dts)
+        finally:
+            cs.close()
+        # the yardstick: 8 solves of 32 iterations back to back on ONE operator (init! included, device b, no copies, one synchronisation)
+        S1 = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+        rls.init_(S1, b); lib.rls_cgnr_step(S1.state._plan, 32); ctx.sync()
+        d1 = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(8):
+                rls.init_(S1, b); lib.rls_cgnr_step(S1.state._plan, 32)
+            ctx.sync(); d1.append(time.perf_counter() - t0)
+        res["queue (rls_cgnr_solve_queue_host: one stream, one synchronisation)"] = {
+            "ms_per_8_solves": 1e3 * dt_, "solve_iterations_per_s": 8 * 32 / dt_,
+            "max_rel_err_vs_float64_cgnr_32_iterations": max(errs_q),
+            "same_operator_8_solves_ms (init! + 32 iterations each, device b, no copies)": 1e3 * min(d1),
+            "of_the_single_operator_rate": min(d1) / dt_}
         return res
 
     @entry("kaczmarz_row_sweeps (one launch per solve)")

@@ -392,8 +392,9 @@ end
 
 The reference's other multi-solve flavour (docs/src/literate/howto/multi_threading.jl:8-17: one solver and one A per problem under
 `Threads.@threads`) for problems that each fit one CU's registers: `init!` and every iteration of all K problems as ONE launch, one
-workgroup per problem (`rls_cgnr_init_step_group`).  The solvers must share the L2 weight, relTol and iteration count and sit on
-`rls_cgnr_path` 8; otherwise (RLS_E_UNSUPPORTED) they are solved one after the other.
+workgroup per problem (`rls_cgnr_init_step_group`).  Larger problems (any shape, any kernel path) run as a queue on the context's
+stream with one read-back at the end (`rls_cgnr_solve_queue`).  The solvers must share the L2 weight, relTol and iteration count;
+otherwise they are solved one after the other.
 """
 function RLSMI355X.solve_group!(solvers::Vector{<:CGNR}, bs::Vector{<:RLSVector})
   length(solvers) == length(bs) || error("one right-hand side per solver")
@@ -413,7 +414,17 @@ function RLSMI355X.solve_group!(solvers::Vector{<:CGNR}, bs::Vector{<:RLSVector}
   rc = ccall((:rls_cgnr_init_step_group, librls[]), Int32, (Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Float32, Float32, Int32, Int32),
              plans, Ptr{Cvoid}[b.ptr for b in bs], Int32(length(plans)), lam, tol, Int32(first_.iterations), Int32(first_.iterations))
   if rc == Int32(-2)
-    return [RLSMI355X.solve_fused!(s, b) for (s, b) in zip(solvers, bs)]
+    # not all on the single-workgroup path: the queue -- problem k's init! and iterations enqueued behind problem k - 1's on the
+    # context's stream, ONE read-back for all statuses (rls_cgnr_solve_queue; any shape, any kernel path)
+    sts = Vector{CgnrStatus}(undef, length(plans))
+    rc = ccall((:rls_cgnr_solve_queue, librls[]), Int32, (Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Float32, Float32, Int32, Ptr{CgnrStatus}),
+               plans, Ptr{Cvoid}[b.ptr for b in bs], Int32(length(plans)), lam, tol, Int32(first_.iterations), sts)
+    check(bs[1].ctx, rc, "rls_cgnr_solve_queue")
+    for (s, st, stt) in zip(solvers, states, sts)
+      cgnr_take!(st, stt)
+      iterate(s, st)                      # done: applies `constr`, returns nothing
+    end
+    return [st.x for st in states]
   end
   check(bs[1].ctx, rc, "rls_cgnr_init_step_group")
   for (s, st) in zip(solvers, states)

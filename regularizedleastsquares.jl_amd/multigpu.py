@@ -148,7 +148,31 @@ class ConcurrentSolves:
             raise errs[0][1]
         return out
 
+    def solve_queue(self, device_matrices, rhs, make_solver):
+        """The same job as ONE queue per context (rls_cgnr_solve_queue_host through solve_group_): the solvers -- and with them the
+        plans, their state vectors and the pinned staging of b and x -- are created once per operator and cached, problem k's upload,
+        init! and iterations are enqueued behind problem k - 1's, and each context synchronises ONCE.  rhs[k]: host vectors; returns
+        host solutions in problem order.  Contexts beyond the first only matter when the matrices were uploaded to several."""
+        rls, n = self.rls, len(device_matrices)
+        cache = self.__dict__.setdefault("_solvers", {})
+        out = [None] * n
+        for c in self.ctxs:
+            ks = [k for k in range(n) if device_matrices[k].ctx is c]
+            if not ks:
+                continue
+            solvers = []
+            for k in ks:
+                key = id(device_matrices[k])
+                if key not in cache:
+                    cache[key] = (make_solver(device_matrices[k]), device_matrices[k])  # (keeps the matrix alive with its solver)
+                solvers.append(cache[key][0])
+            xs = rls.solve_group_(solvers, [np.asarray(rhs[k]) for k in ks])
+            for k, x in zip(ks, xs):
+                out[k] = x
+        return out
+
     def close(self):
+        self.__dict__.pop("_solvers", None)
         for c in self.ctxs:
             c.close()
         self.ctxs = []

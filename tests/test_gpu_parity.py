@@ -2416,6 +2416,61 @@ def test_small_problem_group_one_launch(rls, ctx, dt):
     assert np.array_equal(ys[0].to_host(), rls.solve_(make(mats[0]), rhs[0]).to_host())
 
 
+def test_distinct_operator_solve_queue(rls, ctx):
+    """BASELINE configs[3], distinct-A flavour (docs/src/literate/howto/multi_threading.jl:8-17: a solver AND an operator per task):
+    `count` problems of DIFFERENT shapes and kernel paths -- register-resident, two-launch pipeline, two-GEMV, small-system -- solved
+    as ONE queue on the context's stream (rls_cgnr_solve_queue / _host through solve_group_): per problem against the float64 oracle
+    (1e-5), against its solo solve (bit for bit: the same kernels, only the host between them is gone), iteration counts, a second
+    call on the cached plans with other right-hand sides, host arrays in and out, and a lost resident launch inside the queue."""
+    shapes = [(1024, 2048), (4096, 2048), (768, 640), (1001, 500), (96, 24), (1024, 2048)]   # (an odd M: the two-GEMV path)
+    lam, iters = 1e-3, 14
+    probs = [O.make_problem(M, N, np.complex64, 900 + k) for k, (M, N) in enumerate(shapes)]
+    mats = [rls.DeviceMatrix.from_host(A, ctx) for A, _, _ in probs]
+    make = lambda Ad: rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(lam), iterations=iters, relTol=0.0)
+    group = [make(Ad) for Ad in mats]
+    rhs = [rls.DeviceVector.from_host(b, ctx) for _, _, b in probs]
+    xs = [x.to_host() for x in rls.solve_group_(group, rhs)]
+    paths = [_cgnr_path(rls, s_) for s_ in group]
+    assert 4 in paths and len(set(paths)) >= 3, paths   # the queue mixes kernel families
+    for k, ((A, xt, b), x) in enumerate(zip(probs, xs)):
+        ref = O.CGNR(A.astype(np.complex128), reg=O.L2Regularization(lam), iterations=iters, relTol=0.0)
+        O.solve(ref, b.astype(np.complex128))
+        assert group[k].state.iteration == ref.iteration == min(iters, shapes[k][1])
+        parity(f"solve_queue_{k}_{shapes[k][0]}x{shapes[k][1]}", x, ref.x,
+               lambda A=A, b=b: O.solve(O.CGNR(A, reg=O.L2Regularization(lam), iterations=iters, relTol=0.0), b), record=k < 3)
+        assert np.array_equal(x, rls.solve_(make(mats[k]), rhs[k]).to_host()), k
+    # host arrays in, host arrays out, on the SAME solvers (cached plans), other right-hand sides
+    rng = np.random.default_rng(5)
+    rhs2 = [(A @ (rng.standard_normal(A.shape[1]) + 1j * rng.standard_normal(A.shape[1]))).astype(np.complex64) for A, _, _ in probs]
+    ys = rls.solve_group_(group, rhs2)
+    assert all(isinstance(y, np.ndarray) for y in ys)
+    for k, (A, _, _) in enumerate(probs):
+        ref = O.CGNR(A.astype(np.complex128), reg=O.L2Regularization(lam), iterations=iters, relTol=0.0)
+        O.solve(ref, rhs2[k].astype(np.complex128))
+        assert rel(ys[k], ref.x) < 1e-5, (k, rel(ys[k], ref.x))
+        assert np.array_equal(ys[k], rls.solve_(make(mats[k]), rls.DeviceVector.from_host(rhs2[k], ctx)).to_host()), k
+    # constraints act at exit (src/CGNR.jl:145-147), also behind a queue with host arrays
+    con = [rls.createLinearSolver(rls.CGNR, Ad, reg=[rls.L2Regularization(lam), rls.RealRegularization()], iterations=iters, relTol=0.0)
+           for Ad in mats[:2]]
+    zs = rls.solve_group_(con, rhs2[:2])
+    assert all(np.all(z.imag == 0) for z in zs) and rel(zs[0].real, ys[0].real) < 1e-6
+    # a resident launch lost inside the queue (wait bound of one poll): re-run on the pipeline for that problem, same result to 1e-5
+    _fresh_resident_ctx(ctx)
+    try:
+        g2 = [make(Ad) for Ad in mats[:3]]
+        for s_, b in zip(g2, rhs[:3]):
+            s_._prepare(s_.state, b)
+        ctx.tune(resident_spin=1)
+        ws = rls.solve_group_(g2, [b for _, _, b in probs[:3]])
+        ctx.tune(resident_spin=100000)
+        assert sum(s_.state.fallbacks for s_ in g2) >= 1 and [s_.state.iteration for s_ in g2] == [iters] * 3
+        for k in range(3):
+            assert rel(ws[k], xs[k]) < 1e-5
+    finally:
+        ctx.tune(resident_spin=100000)
+        _fresh_resident_ctx(ctx)
+
+
 def test_batched_gram_resident_lost_launch_is_recovered(rls, ctx):
     """the batched resident launch (csrc/gramk.hip) under the same contract as the single-column ones: with the wait bound forced
     to one poll the launch gives up having changed nothing (only workgroup 0 writes the caller's state, after its last
