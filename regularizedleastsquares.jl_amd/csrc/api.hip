@@ -304,7 +304,6 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "skinny_t_u")) ctx->tune.skinny_t_u = value;
   else if (!strcmp(key, "skinny_v_u")) ctx->tune.skinny_v_u = value;
   else if (!strcmp(key, "skinny_half")) ctx->tune.skinny_half = value;
-  else if (!strcmp(key, "skinny_fuse")) ctx->tune.skinny_fuse = value;
   else if (!strcmp(key, "skinny_t_roll")) ctx->tune.skinny_t_roll = value;
   else if (!strcmp(key, "skinny_v_roll")) ctx->tune.skinny_v_roll = value;
   else if (!strcmp(key, "skinny_g_roll")) ctx->tune.skinny_g_roll = value;

@@ -51,7 +51,6 @@ struct rls_tuning {
   int skinny_t_waves = 4, skinny_t_u = 4, skinny_v_waves = 4, skinny_v_u = 1, skinny_v_splits = 0;  // skinny.hip (tools/skinny_probe.py)
   int skinny_t_roll = 8, skinny_v_roll = 2, skinny_g_roll = 8;  // rolling-window depth of the complex T / V / Gram products (0 = two-set pipeline)
   int skinny_half = 1;         // the (re | im) operand packing for <= 8 complex right-hand sides
-  int skinny_fuse = 1;         // <= 8 complex right-hand sides: the update folded into the two products (skinny.hip, round 6)
   int gram_lds = 96 * 1024;    // dynamic LDS requested by the Gram tile kernel as an occupancy limiter
   int64_t tv_fused_max_n = 2048;  // tv.hip: larger images run 2 chip-wide launches per FGP iteration instead of one CU
   int tv_fused_2d = 1;         // the register-resident 2-D FGP kernel (n <= 8192 pixels)
