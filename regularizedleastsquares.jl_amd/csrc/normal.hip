@@ -178,9 +178,9 @@ __device__ static inline void slab_load(chunk<E, elem<E>::vec> (&a)[K], const E*
 }
 
 // with L.xs holding the input vector (zero beyond N): t_w = A_w xs, partial v = A_w^H t_w -> slab row
-template <typename E, int G, int K, int WV, bool FULL, bool SC1 = false>
-__device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L, E* __restrict__ slab,
-                                          int64_t Mc, int64_t N, int pair, double* tt_out = nullptr) {
+template <typename E, int G, int K, int WV, bool FULL, bool SC1 = false, bool TT = false>
+__device__ static inline double slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_lds<E, G, K, WV>& L, E* __restrict__ slab,
+                                            int64_t Mc, int64_t N, int pair) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int NV = C::NV;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -239,15 +239,14 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
     for (int ww = 0; ww < WV; ++ww) sum = elem<E>::add(sum, L.part[ww][g][i]);
     tr[i] = sum;
   }
-  if (tt_out) {  // ||t_w||^2 in Float64, the G row chunks summed in DPP steps (fixed order); the same value in every lane
-    double sq = 0.0;
+  double tt = 0.0;  // TT: ||t_w||^2 in Float64, the G row chunks summed in DPP steps (fixed order); the same value in every lane
+  if constexpr (TT) {
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      sq += (double)elem<E>::re(tr[i]) * (double)elem<E>::re(tr[i]) + (double)elem<E>::im(tr[i]) * (double)elem<E>::im(tr[i]);
-    if constexpr (G >= 2) sq += dpp_d(sq, 0xB1);
-    if constexpr (G >= 4) sq += dpp_d(sq, 0x4E);
-    if constexpr (G >= 8) sq += dpp_d(sq, 0x141);
-    *tt_out = sq;
+      tt += (double)elem<E>::re(tr[i]) * (double)elem<E>::re(tr[i]) + (double)elem<E>::im(tr[i]) * (double)elem<E>::im(tr[i]);
+    if constexpr (G >= 2) tt += dpp_d(tt, 0xB1);
+    if constexpr (G >= 4) tt += dpp_d(tt, 0x4E);
+    if constexpr (G >= 8) tt += dpp_d(tt, 0x141);
   }
   // The sum over the G lanes that share a column goes through LDS, not DPP: per column a lane does
   // one store here and the G-term sum below costs G reads per OUTPUT column, against 2*log2(G)
@@ -283,6 +282,7 @@ __device__ static inline void slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab_l
       }
     }
   }
+  return tt;
 }
 
 // ---- several slabs per workgroup --------------------------------------------------------------------------------
@@ -728,7 +728,7 @@ __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], s
                                                pipe_small<E, slab_cfg<E, G, K, WV>::EPT>& sm, E* x, E* r0, E* p0,
                                                E* r1, E* p1, E* slab_b, const cgnr_scalars* sc_b, cgnr_scalars* scn_b,
                                                int ndots, int64_t Mc, int64_t N, int64_t vo, int pair, int hint,
-                                               slab_walk<E, G, K, WV, FULL>* W = nullptr, int nblocks = 0) {
+                                               slab_walk<E, G, K, WV, FULL>* W = nullptr, int nblocks = 0, double* ttw_b = nullptr) {
   using C = slab_cfg<E, G, K, WV>;
   constexpr int EPT = C::EPT;
   constexpr bool WIDE = pipe_wide<E, G, K, WV, FULL, HINTED>();
@@ -807,8 +807,12 @@ __device__ static inline void pipe_process_rhs(chunk<E, elem<E>::vec> (&a)[K], s
     }
   }
   STAMP(3);
-  if constexpr (MULTI) slab_finish_multi<E, G, K, WV, FULL>(a, L, slab_b, *W, nblocks);
-  else slab_finish<E, G, K, WV, FULL>(a, L, slab_b, Mc, N, pair);
+  if constexpr (MULTI) {
+    slab_finish_multi<E, G, K, WV, FULL>(a, L, slab_b, *W, nblocks);
+  } else {
+    const double ttw = slab_finish<E, G, K, WV, FULL, false, true>(a, L, slab_b, Mc, N, pair);
+    if (ttw_b && tid == 0) ttw_b[blockIdx.x] = ttw;   // this row block's share of ||A p||^2
+  }
   STAMP(7);
 }
 
@@ -819,6 +823,12 @@ struct pipe_rhs_ptrs {
   int64_t vstride, slab_stride;
   int nrhs;
   int hint;  // rls_cgnr_pipe::cur_hint
+  // alpha in its CGLS form (cg_update_elems_tt's identity: <p, A^H A p> = ||A p||^2 = sum_w ||t_w||^2): K_A leaves ||t_w||^2 of
+  // its row block in ttw[rhs * tt_rows + workgroup], K_R folds those into the first slot of the partial dots (the second, the
+  // imaginary part, is zero) instead of forming <p, v> -- the update in the next K_A is unchanged.  Null: K_R forms <p, v> as before
+  // (the MULTI instantiations, whose complex forms have no registers left for one more accumulator across their blocks).
+  double* ttw = nullptr;
+  int tt_rows = 0;
 };
 
 // MULTI: gridDim.x < nblocks, every workgroup walks several row blocks (slab_finish_multi) and leaves one partial row
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
   slab_load<E, G, K, WV, FULL>(a, A, lda, Mc, N, pair);
   __builtin_amdgcn_sched_barrier(0);
   STAMP(1);
-  pipe_process_rhs<E, G, K, WV, FULL, HINTED>(a, L, sm, x, r0, p0, r1, p1, slab, sc, scn, ndots, Mc, N, 0, pair, R.hint);
+  pipe_process_rhs<E, G, K, WV, FULL, HINTED>(a, L, sm, x, r0, p0, r1, p1, slab, sc, scn, ndots, Mc, N, 0, pair, R.hint, nullptr, 0, R.ttw);
   // further right-hand sides reuse the registers (a separate instantiation: with the loop present the
   // compiler hoists per-load address math out of it and the single-RHS kernel spills)
   if constexpr (BATCHED)
@@ -871,7 +881,8 @@ __global__ __launch_bounds__(WV * 64) void cgnr_pipe_a_kernel(const E* __restric
     const int64_t vo = (int64_t)b * R.vstride;
     pipe_load_small<E, C::EPT, C::NT, HINTED>(sm, x, r0, p0, r1, p1, v, dots, ndots, N, vo, b, R.hint);
     pipe_process_rhs<E, G, K, WV, FULL, HINTED>(a, L, sm, x, r0, p0, r1, p1, slab + (int64_t)b * R.slab_stride, sc + b,
-                                                 scn + b, ndots, Mc, N, vo, pair, R.hint);
+                                                 scn + b, ndots, Mc, N, vo, pair, R.hint, nullptr, 0,
+                                                 R.ttw ? R.ttw + (int64_t)b * R.tt_rows : nullptr);
   }
 }
 
@@ -951,6 +962,13 @@ __global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__
     pa = p0[jc];
     pb = p1[jc];
   }
+  // CGLS form: this block's share of ||A p||^2 -- the row blocks blockIdx, blockIdx + gridDim, ... of K_A's ||t_w||^2 (requested
+  // with everything else; fixed order)
+  double ttb = 0.0;
+  if (R.ttw && threadIdx.x == 0) {
+    const double* tw = R.ttw + (int64_t)b * R.tt_rows;
+    for (int row = blockIdx.x; row < R.tt_rows; row += gridDim.x) ttb += tw[row];
+  }
   const cgnr_scalars Sn = scn[b];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     cgnr_scalars c = Sn;
@@ -966,8 +984,10 @@ __global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__
     if (j < N) {
       v[j] = t;
       const E pj = Sn.cur ? pb : pa;
-      dre = (double)elem<E>::re(pj) * (double)elem<E>::re(t) + (double)elem<E>::im(pj) * (double)elem<E>::im(t);
-      dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(t) - (double)elem<E>::im(pj) * (double)elem<E>::re(t);
+      if (!R.ttw) {
+        dre = (double)elem<E>::re(pj) * (double)elem<E>::re(t) + (double)elem<E>::im(pj) * (double)elem<E>::im(t);
+        dim_ = (double)elem<E>::re(pj) * (double)elem<E>::im(t) - (double)elem<E>::im(pj) * (double)elem<E>::re(t);
+      }
       pp = (double)elem<E>::re(pj) * (double)elem<E>::re(pj) + (double)elem<E>::im(pj) * (double)elem<E>::im(pj);
     }
 #pragma unroll
@@ -977,7 +997,7 @@ __global__ __launch_bounds__(1024) void cgnr_pipe_r_kernel(const E* __restrict__
       pp += __shfl_xor(pp, off, 64);
     }
     if (cx == 0) {
-      dots[4 * blockIdx.x] = dre;
+      dots[4 * blockIdx.x] = R.ttw ? ttb : dre;
       dots[4 * blockIdx.x + 1] = dim_;
       dots[4 * blockIdx.x + 2] = pp;
     }
@@ -2512,8 +2532,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = pv[e];
-      double ttw;
-      slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair, &ttw);
+      const double ttw = slab_finish<E, G, K, WV, FULL, true, true>(a, L, slab, Mc, N, pair);
       if (tid == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ttw), d_rs, (uint32_t)blockIdx.x * 8u, 0, 16);
     }
     STAMP(9);
@@ -3654,12 +3673,15 @@ static int launch_slab(rls_ctx* ctx, const E* A, int64_t lda, const E* p, E* sla
   return nwg;
 }
 
-static pipe_rhs_ptrs rhs_of(const rls_cgnr_pipe& P, int nwg) {
+// rows: the workgroups of K_A (= its partial rows); rows < nwg is the MULTI instantiation, which keeps <p, v>
+static pipe_rhs_ptrs rhs_of(const rls_cgnr_pipe& P, int nwg, int rows = 0) {
   pipe_rhs_ptrs R;
   R.nrhs = P.nrhs > 0 ? P.nrhs : 1;
   R.vstride = P.vstride;
   R.slab_stride = (int64_t)nwg * P.N;
   R.hint = P.cur_hint;
+  R.ttw = (rows > 0 && rows == nwg) ? P.ttw : nullptr;
+  R.tt_rows = rows;
   return R;
 }
 
@@ -3698,7 +3720,7 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg, int gri
   // single right-hand side: the hinted instantiation (its full-size form loads the vectors in 16-byte pieces)
   const bool aligned = al16(P.r0) && al16(P.p0) && al16(P.r1) && al16(P.p1) && al16(P.v);
   const bool hinted = !batched && P.cur_hint >= 0 && aligned;
-  pipe_rhs_ptrs R = rhs_of(P, nwg);
+  pipe_rhs_ptrs R = rhs_of(P, nwg, grid);
 #define RLS_LAUNCH_A2(FULLV, BATCHV, HINTV, MULTIV)                                                                     \
   hipLaunchKernelGGL((cgnr_pipe_a_kernel<E, G, K, WV, FULLV, BATCHV, HINTV, MULTIV>), dim3(MULTIV ? grid : nwg), dim3(C::NT),  \
                      lds, ctx->stream, (const E*)P.A, P.lda, (E*)P.x, (E*)P.r0, (E*)P.p0, (E*)P.r1, (E*)P.p1, (const E*)P.v, \
@@ -3770,7 +3792,7 @@ static int32_t pipe_iteration_typed(rls_ctx* ctx, const rls_cgnr_pipe& P, int wh
   if (which & 2)
     hipLaunchKernelGGL(cgnr_pipe_r_kernel<E>, dim3((unsigned)P.ndots, (unsigned)(P.nrhs > 0 ? P.nrhs : 1)),
                        dim3(ctx->tune.red_threads), 0, ctx->stream, (const E*)P.slab, rows, P.N, (E*)P.v, (const E*)P.p0,
-                       (const E*)P.p1, P.dots, P.sc, P.scn, rhs_of(P, nwg));
+                       (const E*)P.p1, P.dots, P.sc, P.scn, rhs_of(P, nwg, rows));
   return launch_status(ctx);
 }
 

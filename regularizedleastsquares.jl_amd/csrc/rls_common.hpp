@@ -703,6 +703,7 @@ struct rls_cgnr_pipe {
   int64_t lda, M, N;
   void *x, *r0, *p0, *r1, *p1, *v, *slab;
   double* dots;  // [nrhs][ndots][4]
+  double* ttw = nullptr;  // [nrhs][row blocks]: K_A's ||t_w||^2 (alpha in its CGLS form; null: K_R forms <p, v>)
   int ndots;     // ceil(N / 16)
   cgnr_scalars *sc, *scn;  // [nrhs]
   int nrhs = 1;            // right-hand sides sharing one pass over A

@@ -154,6 +154,7 @@ struct rls_cgnr {
   // fused pipeline (normal.hip): alternate (r, p) pair, partial dots, staged scalars
   void *r1, *p1;
   double* dots;
+  double* ttw = nullptr;
   cgnr_scalars* scn;
   // batched plans: nrhs right-hand sides, columns ldv elements apart, own partial-row slab
   int nrhs;
@@ -377,6 +378,7 @@ static rls_cgnr_pipe cgnr_pipe_desc(const rls_cgnr* s) {
   P.v = s->v;
   P.slab = s->slab_b ? s->slab_b : s->op->slab;
   P.dots = s->dots;
+  P.ttw = s->ttw;
   P.ndots = (int)((s->op->N + 15) / 16);
   P.sc = s->sc;
   P.scn = s->scn;
@@ -2096,6 +2098,11 @@ static int32_t cgnr_create_impl(rls_operator* op, int32_t nrhs, void* x, void* r
     if (e == hipSuccess) e = hipMemsetAsync(s->r1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->p1, 0, vb, ctx->stream);
     if (e == hipSuccess) e = dmalloc(&s->dots, nd);
+    if (e == hipSuccess && op->A && !op->G) {  // matrix-free: K_A's ||t_w||^2 per row block (alpha = zeta / ||A p||^2)
+      const size_t tb = (size_t)rls_cgnr_resident_nwg(op->ctx, op->dtype, op->M, op->N) * sizeof(double) * nrhs;
+      e = dmalloc(&s->ttw, tb);
+      if (e == hipSuccess) e = hipMemsetAsync(s->ttw, 0, tb, ctx->stream);
+    }
     if (e == hipSuccess) e = dmalloc(&s->scn, sb);
     if (e == hipSuccess) e = hipMemsetAsync(s->dots, 0, nd, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sb, ctx->stream);
@@ -2188,6 +2195,7 @@ int32_t rls_cgnr_destroy(rls_cgnr* s) {
   if (s->r1) dfree(s->r1);
   if (s->p1) dfree(s->p1);
   if (s->dots) dfree(s->dots);
+  if (s->ttw) dfree(s->ttw);
   if (s->scn) dfree(s->scn);
   if (s->slab_b) dfree(s->slab_b);
   if (s->v1) dfree(s->v1);
