@@ -269,6 +269,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   RLS_CHECK_CTX(ctx);
   if (!key) return RLS_E_INVALID;
   if (ctx->server) rls_server_stop(ctx);  // (a kernel left listening was launched under the old settings)
+  ++ctx->tune_epoch;                       // (... and so was every cached graph: run_steps captures afresh)
   if (!strcmp(key, "gemvn_g")) ctx->tune.gemvn_g = value;
   else if (!strcmp(key, "gemvn_waves")) ctx->tune.gemvn_waves = value;
   else if (!strcmp(key, "gemvt_cols")) ctx->tune.gemvt_cols = value;

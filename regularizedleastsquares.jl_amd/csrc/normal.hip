@@ -2004,27 +2004,50 @@ __device__ static inline void owner_transpose(chunk<E, elem<E>::vec> (&a)[K], ch
   (void)NT;
 }
 
-// Sum of v[0..NVAL) over the 64 lanes of a wave by halving: after the step with partner lane ^ 2^b a lane keeps the half
-// selected by its bit b (0: lower), so after log2(NVAL) steps it holds ONE value -- the sum over 2^steps lanes of element
-//   idx = sum_b bit_b(lane) * NVAL / 2^(b+1)
-// -- and the remaining steps are plain adds.  Returns that value (complete over the wave); *idx_out = its element index.
+// Sum of v[0..NVAL) over the 64 lanes of a wave by halving: after the step that pairs a lane with its partner it keeps the half
+// selected by one bit of its index, so after log2(NVAL) steps it holds ONE value, and the remaining steps are plain adds.
+// Round 6: no ds_bpermute at all.  The four steps inside a row of 16 lanes are DPP (full rate): row_mirror (i <-> 15 - i, bit 3
+// selects), row_half_mirror (i <-> 7 - i, bit 2), quad_perm [2,3,0,1] (bit 1), quad_perm [1,0,3,2] (bit 0); the two steps ACROSS
+// rows are gfx950's v_permlane16_swap / v_permlane32_swap (VALU: the odd rows of the first operand change places with the even
+// rows of the second; the upper half with the lower half) -- one swap and one add do a whole halving step: with a = the lower,
+// b = the upper value, a' + b' is the pair sum of a in the even rows and of b in the odd ones.  (Rounds 3-5 did the steps of
+// distance 4, 8, 16, 32 through ds_bpermute: four dependent LDS round trips per product.)  Returns the value (complete over the
+// wave; lanes l and l + 32 hold the same one); *idx_out = its element index.  The order of the additions is a function of the
+// lane index alone: bit-reproducible.
+// (inline assembly with its own wait states: hipcc 7.2's builtin returns the first result's register for BOTH results, and an
+// asm statement is invisible to the compiler's hazard recogniser -- tools/ubench/permlane_probe.hip)
+__device__ static inline void permlane16_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ static inline void permlane32_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 template <int NVAL>
 __device__ static inline float wave_reduce_scatter(float (&v)[NVAL], int lane, int* idx_out) {
   static_assert(NVAL == 32 || NVAL == 16, "16 or 32 values");
   int idx = 0;
-  // xor 1 and xor 2: DPP quad permutes (full rate)
   {
     constexpr int H = NVAL / 2;
-    const bool up = lane & 1;
+    const bool up = lane & 8;
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const float lo = v[j] + dpp_f(v[j], 0xB1), hi = v[H + j] + dpp_f(v[H + j], 0xB1);
+      const float lo = v[j] + dpp_f(v[j], 0x140), hi = v[H + j] + dpp_f(v[H + j], 0x140);
       v[j] = up ? hi : lo;
     }
     idx += up ? H : 0;
   }
   {
     constexpr int H = NVAL / 4;
+    const bool up = lane & 4;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const float lo = v[j] + dpp_f(v[j], 0x141), hi = v[H + j] + dpp_f(v[H + j], 0x141);
+      v[j] = up ? hi : lo;
+    }
+    idx += up ? H : 0;
+  }
+  {
+    constexpr int H = NVAL / 8;
     const bool up = lane & 2;
 #pragma unroll
     for (int j = 0; j < H; ++j) {
@@ -2033,37 +2056,32 @@ __device__ static inline float wave_reduce_scatter(float (&v)[NVAL], int lane, i
     }
     idx += up ? H : 0;
   }
-  // xor 4, 8, (16): few values left -- bpermute shuffles
-  {
-    constexpr int H = NVAL / 8;
-    const bool up = lane & 4;
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      const float lo = v[j] + __shfl_xor(v[j], 4, 64), hi = v[H + j] + __shfl_xor(v[H + j], 4, 64);
-      v[j] = up ? hi : lo;
-    }
-    idx += up ? H : 0;
-  }
   {
     constexpr int H = NVAL / 16;
-    const bool up = lane & 8;
+    const bool up = lane & 1;
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const float lo = v[j] + __shfl_xor(v[j], 8, 64), hi = v[H + j] + __shfl_xor(v[H + j], 8, 64);
+      const float lo = v[j] + dpp_f(v[j], 0xB1), hi = v[H + j] + dpp_f(v[H + j], 0xB1);
       v[j] = up ? hi : lo;
     }
     idx += up ? H : 0;
   }
   float r;
-  if constexpr (NVAL == 32) {
-    const bool up = lane & 16;
-    const float lo = v[0] + __shfl_xor(v[0], 16, 64), hi = v[1] + __shfl_xor(v[1], 16, 64);
-    r = up ? hi : lo;
-    idx += up ? 1 : 0;
-  } else {
-    r = v[0] + __shfl_xor(v[0], 16, 64);
+  if constexpr (NVAL == 32) {  // two values left: the even rows keep the pair sum of v[0], the odd rows that of v[1]
+    float a = v[0], b = v[1];
+    permlane16_swap(a, b);
+    r = a + b;
+    idx += (lane & 16) ? 1 : 0;
+  } else {                     // one value left: rows 0 + 1 and rows 2 + 3
+    float a = v[0], b = v[0];
+    permlane16_swap(a, b);
+    r = a + b;
   }
-  r += __shfl_xor(r, 32, 64);
+  {
+    float a = r, b = r;
+    permlane32_swap(a, b);
+    r = a + b;
+  }
   *idx_out = idx;
   return r;
 }

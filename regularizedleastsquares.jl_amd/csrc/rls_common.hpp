@@ -74,6 +74,7 @@ struct rls_ctx {
   float* res_d = nullptr;   // small float result block on device
   float* res_h = nullptr;   // pinned host mirror
   rls_tuning tune;
+  uint64_t tune_epoch = 0;    // bumped by every rls_tune_set: a cached hipGraph captured under other settings is dropped (solvers.hip, run_steps)
   int cus = 0;                // compute units of `device` (looked up once, by whoever asks first on this context)
   int resident_failures = 0;  // resident launches of this context that timed out; at 2 the context stops using them
   bool pools = false;         // device memory comes from the device's stream-ordered pool (rls_dev_alloc)

@@ -62,6 +62,7 @@ struct step_graph {
   void* x_bound = nullptr;  // cg plans: the solution vector whose address the captured kernels carry
   int mode = 0;  // which kernel sequence was captured
   bool failed = false;
+  uint64_t epoch = 0;  // rls_ctx::tune_epoch at capture: launch shapes and kernel choices follow the context's switches
 };
 
 // `rewind(c)`: a capture that fails has already called enqueue_one c times WITHOUT any of those launches running; a
@@ -71,7 +72,7 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
   const int chunk = ctx->tune.graph_chunk;
   while (n_steps > 0) {
     if (ctx->tune.use_graph && chunk > 1 && n_steps >= chunk && !big->failed) {
-      if (!big->exec || big->steps != chunk) {
+      if (!big->exec || big->steps != chunk || big->epoch != ctx->tune_epoch) {
         if (big->exec) {
           hipGraphExecDestroy(big->exec);
           big->exec = nullptr;
@@ -94,6 +95,7 @@ static int32_t run_steps(rls_ctx* ctx, step_graph* big, int n_steps, F&& enqueue
           rewind(calls);
         } else {
           big->steps = chunk;
+          big->epoch = ctx->tune_epoch;
         }
         if (graph) hipGraphDestroy(graph);
         if (big->failed) continue;

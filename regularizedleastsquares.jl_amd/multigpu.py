@@ -445,14 +445,18 @@ class CommRowShardedFISTA(_CommHost):
                  relTol=float(np.finfo(np.float32).eps), restart="none", threads=True):
         super().__init__(rls, shards, ("x", "x0", "xold", "res"), devices, transport, threads)
         self.rho, self.theta, self.iterations, self.relTol, self.restart = float(rho), float(theta), int(iterations), float(relTol), restart
-        _reg_codes(rls, reg, proj)  # (validates; proj: one projection term or None)
-        for r in range(self.n):
-            v, h = self.v[r], self.ctxs[r].handle
-            plan = C.c_void_p()
-            check(h, self.lib.rls_fista_create(self.ops[r].handle, v["x"].ptr, v["x0"].ptr, v["xold"].ptr, v["res"].ptr, C.byref(plan)),
-                  "rls_fista_create")
-            self.plans.append(plan)
-            _fista_plan_set_reg(rls, self.lib, h, plan, reg, proj)
+        try:
+            _reg_codes(rls, reg, proj)  # (validates; proj: one projection term or None)
+            for r in range(self.n):
+                v, h = self.v[r], self.ctxs[r].handle
+                plan = C.c_void_p()
+                check(h, self.lib.rls_fista_create(self.ops[r].handle, v["x"].ptr, v["x0"].ptr, v["xold"].ptr, v["res"].ptr, C.byref(plan)),
+                      "rls_fista_create")
+                self.plans.append(plan)
+                _fista_plan_set_reg(rls, self.lib, h, plan, reg, proj)
+        except BaseException:
+            self.close()   # a refused regulariser (e.g. a TV image beyond the single-workgroup FGP launch) must not leak the
+            raise          # communicator, its worker threads, the contexts and the plans created so far
         self._plans_c = (C.c_void_p * self.n)(*[p.value for p in self.plans])
 
     def init(self, b_parts):

@@ -471,7 +471,8 @@ class FISTA(AbstractProximalGradientSolver):
             kind, slices = REG_L2, 1
         elif type(r) is L21Regularization:
             kind, slices = REG_L21, r.slices
-        elif type(r) is TVRegularization and not getattr(self, "_tv_unfused", False):
+        elif type(r) is TVRegularization and getattr(self, "_tv_unfused", None) not in (True, (tuple(np.atleast_1d(r.shape)), r.dims)):
+            # (_tv_unfused: the geometry the plan refused -- or True, the tests' switch for the primitive-by-primitive sequence)
             kind, slices = REG_TV, 1  # the FGP launch between the two halves of the plan's update (rls_fista_set_reg_tv)
         else:
             return None  # nested / transformed / learned terms: the generic path calls their prox_
@@ -518,7 +519,7 @@ class FISTA(AbstractProximalGradientSolver):
             shape, d0, cs, cd = _tv_geometry(self.reg.shape, self.reg.dims)
             st_tv = lib.rls_fista_set_reg_tv(state._plan, fused[1], len(shape), cs, len(d0), cd, self.reg.iterationsTV, fused[3])
             if st_tv == -2:  # RLS_E_UNSUPPORTED: the image does not fit the plan's single-workgroup FGP launch -- primitives
-                self._tv_unfused = True
+                self._tv_unfused = (tuple(np.atleast_1d(self.reg.shape)), self.reg.dims)   # (THIS geometry: another one is tried afresh)
                 lib.rls_fista_destroy(state._plan)
                 state._plan = None
                 fused = None
@@ -904,9 +905,12 @@ class ADMM(AbstractPrimalDualSolver):
         while it < self.iterationsCG and residual > tol:
             self.precon.ldiv_(c, r)
             rho_prev, rho = rho, complex(c.dot(r))
-            u.lincomb_(1.0, c, rho / rho_prev if r.dtype.kind == "c" else (rho / rho_prev).real, u)
+            with np.errstate(all="ignore"):   # a breakdown (<c, r> = 0) propagates NaN as the reference's arithmetic does, no exception
+                ratio = np.complex128(rho) / np.complex128(rho_prev)
+            u.lincomb_(1.0, c, complex(ratio) if r.dtype.kind == "c" else float(ratio.real), u)
             self._composite_mul(state, c, u, tmp)
-            alpha = rho / complex(u.dot(c))
+            with np.errstate(all="ignore"):
+                alpha = complex(np.complex128(rho) / np.complex128(complex(u.dot(c))))
             if r.dtype.kind != "c":
                 alpha = alpha.real
             x.axpy_(alpha, u)

@@ -2976,7 +2976,7 @@ def test_cgnr_resident_server_survives_a_co_tenant(rls, ctx):
 
 
 @pytest.mark.parametrize("name", ["OptISTA", "POGM"])
-@pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 4096, 4096), (np.complex64, 4000, 2002), (np.float32, 4000, 2200)])
+@pytest.mark.parametrize("dt,M,N", [(np.complex64, 4096, 2048), (np.float32, 2048, 4096), (np.complex64, 4000, 2002), (np.float32, 4000, 2200)])
 def test_optista_pogm_resident_launch(rls, ctx, name, dt, M, N):
     """SURVEY 8f-1 / BASELINE configs[1] shape: the remaining iterations of OptISTA / POGM as resident launches of up to 48
     iterations (pgm_resident_kernel through rls_pgm_step_resident).  Against the float64 oracle at 30, 49 (an odd count: POGM's
@@ -3378,10 +3378,10 @@ class _ShardedPanelF64Op:
 def test_config5_full_size_eight_shards_on_one_gpu(rls, ctx):
     """BASELINE configs[4] at FULL size under the gate: one 65536 x 8192 ComplexF32 CGNR (4 GiB of A) as 8 row shards of
     512 MiB on one GPU, the library's own communicator between them (rls_comm_*, direct transport, one host worker
-    thread per rank), 4 iterations (the float64 oracle, applied shard- and panel-wise on the host, is what this test's time goes
-    into: 8 iterations took 120 s of a 450 s suite budget), replicated state bit-identical across the 8 ranks"""
+    thread per rank), 3 iterations (the float64 oracle, applied shard- and panel-wise on the host, is what this test's time goes
+    into: 8 iterations took 120 s, 4 took 52 s of the suite's 600 s budget), replicated state bit-identical across the 8 ranks"""
     from rls_amd.multigpu import make_row_shard
-    M, N, nshards, its = 65536, 8192, 8, 4
+    M, N, nshards, its = 65536, 8192, 8, 3
     shards, cuts = [], [0]
     for r in range(nshards):
         A_r, lo, hi_ = make_row_shard(M, N, r, nshards)
@@ -3402,7 +3402,7 @@ def test_config5_full_size_eight_shards_on_one_gpu(rls, ctx):
     op64 = _ShardedPanelF64Op(shards)
     x64 = O.solve(O.CGNR(op64, iterations=its, relTol=0.0), b.astype(np.complex128))
     # the Float32 bound (needed only if the 1e-5 gate alone fails): the complex64 restatement on the concatenated matrix
-    parity("BASELINE config 5 full size: CGNR 65536x8192 c64 as 8 shards on one GPU, 4 iterations", x, x64,
+    parity("BASELINE config 5 full size: CGNR 65536x8192 c64 as 8 shards on one GPU, 3 iterations", x, x64,
            lambda: O.solve(O.CGNR(np.concatenate(shards), iterations=its, relTol=0.0), b))
 
 

@@ -3,6 +3,8 @@ and the C ABI, fixed-point certificates that pin the prox thresholds on the devi
 restatement, and the committed golden fixtures (tests/golden/*.npz) held against the HIP path directly."""
 import os
 
+import math
+
 import numpy as np
 import pytest
 
@@ -341,7 +343,9 @@ def test_fista_tv_image_too_large_for_the_plan_falls_back(rls, ctx):
     shape = (16, 16, 16)
     N = 4096
     A, xt, b = O.make_problem(N + 512, N, np.float32, 5)
-    rho = 0.9 / np.linalg.norm(A.astype(np.float64), 2) ** 2
+    # (an upper bound of sigma_max^2 from the Frobenius norm of a Gram block would do; the exact 2-norm of a 4608 x 4096 matrix was
+    #  half of this test's 19 s: sigma_max of a Gaussian matrix is sqrt(M) + sqrt(N) to a per cent)
+    rho = 0.9 / (math.sqrt(N + 512) + math.sqrt(N)) ** 2 / 1.05
     lam = 0.02 * float(np.max(np.abs(A.astype(np.float64).T @ b)))
     s = rls.createLinearSolver(rls.FISTA, rls.DeviceMatrix.from_host(np.asfortranarray(A), ctx), reg=rls.TVRegularization(lam, shape=shape),
                                rho=rho, iterations=6, relTol=0.0)
