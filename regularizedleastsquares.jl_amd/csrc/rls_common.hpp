@@ -384,13 +384,47 @@ __device__ static inline double dpp_d(double v, int ctrl) {
   hi = __builtin_bit_cast(int, dpp_f(__builtin_bit_cast(float, hi), ctrl));
   return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
+// The two steps ACROSS rows: gfx950's v_permlane16_swap / v_permlane32_swap (VALU; the odd rows of the first operand change places
+// with the even rows of the second, the upper half of the wave with the lower half) instead of ds_bpermute -- with both operands
+// the same value, a' + b' is v[l] + v[l ^ 16] (v[l] + v[l ^ 32]) in every lane: the butterfly's pairs, the same bits (addition
+// commutes), without an LDS round trip per step.  Inline assembly with its own wait states: hipcc 7.2's builtin hands back the first
+// result's register for BOTH results, and an asm statement is invisible to the hazard recogniser (tools/ubench/permlane_probe.hip).
+// (returns a' + b': the sum of the pair, in both of its lanes)
+__device__ static inline float pair_sum16(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ static inline float pair_sum32(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ static inline double pair_sum16(double v) {
+  const long long q = __builtin_bit_cast(long long, v);
+  float al = __builtin_bit_cast(float, (int)(q & 0xffffffffll)), ah = __builtin_bit_cast(float, (int)(q >> 32));
+  float bl = al, bh = ah;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(al), "+v"(bl), "+v"(ah), "+v"(bh));
+  const double a = __builtin_bit_cast(double, ((long long)__builtin_bit_cast(int, ah) << 32) | (long long)(unsigned)__builtin_bit_cast(int, al));
+  const double b = __builtin_bit_cast(double, ((long long)__builtin_bit_cast(int, bh) << 32) | (long long)(unsigned)__builtin_bit_cast(int, bl));
+  return a + b;
+}
+__device__ static inline double pair_sum32(double v) {
+  const long long q = __builtin_bit_cast(long long, v);
+  float al = __builtin_bit_cast(float, (int)(q & 0xffffffffll)), ah = __builtin_bit_cast(float, (int)(q >> 32));
+  float bl = al, bh = ah;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(al), "+v"(bl), "+v"(ah), "+v"(bh));
+  const double a = __builtin_bit_cast(double, ((long long)__builtin_bit_cast(int, ah) << 32) | (long long)(unsigned)__builtin_bit_cast(int, al));
+  const double b = __builtin_bit_cast(double, ((long long)__builtin_bit_cast(int, bh) << 32) | (long long)(unsigned)__builtin_bit_cast(int, bl));
+  return a + b;
+}
 __device__ static inline double wave_sum(double v) {
   v += dpp_d(v, 0xB1);
   v += dpp_d(v, 0x4E);
   v += dpp_d(v, 0x141);
   v += dpp_d(v, 0x140);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+  v = pair_sum16(v);
+  v = pair_sum32(v);
   return v;
 }
 __device__ static inline float wave_sum(float v) {
@@ -398,8 +432,8 @@ __device__ static inline float wave_sum(float v) {
   v += dpp_f(v, 0x4E);
   v += dpp_f(v, 0x141);
   v += dpp_f(v, 0x140);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+  v = pair_sum16(v);
+  v = pair_sum32(v);
   return v;
 }
 
@@ -506,7 +540,7 @@ __device__ static inline double half_wave_sum(double v) {
   v += dpp_d(v, 0x4E);
   v += dpp_d(v, 0x141);
   v += dpp_d(v, 0x140);
-  v += __shfl_xor(v, 16, 64);
+  v = pair_sum16(v);
   return v;
 }
 
