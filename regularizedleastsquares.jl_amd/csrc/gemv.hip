@@ -222,8 +222,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_n_kernel(const E* __restrict_
   for (int off = G; off < 64; off <<= 1) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      float re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
-      float im = elem<E>::cplx ? elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64) : 0.f;
+      float re = add_xor(elem<E>::re(acc[i]), off);
+      float im = elem<E>::cplx ? add_xor(elem<E>::im(acc[i]), off) : 0.f;
       acc[i] = elem<E>::make(re, im);
     }
   }

@@ -774,9 +774,9 @@ __global__ __launch_bounds__(GK_NT) void fista_gramk_resident_kernel(rls_fgramk 
       double s = 0.0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) s += T.dsum[((lane >> 3) * 8 + i) * 8 + (lane & 7)];
-      s += __shfl_xor(s, 8, 64);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      s += dpp_d(s, 0x128);   // lane ^ 8: row_ror:8 inside the row of 16; lane ^ 16, lane ^ 32: permlane swaps (the same pairs: the same bits)
+      s = pair_sum16(s);
+      s = pair_sum32(s);
       int done = 1;
       if (lane < GK_KB) {
         fk_col& c = T.cs[lane];

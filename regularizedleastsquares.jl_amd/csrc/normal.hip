@@ -212,14 +212,9 @@ __device__ static inline double slab_finish(chunk<E, elem<E>::vec> (&a)[K], slab
   for (int off = G; off < 64; off <<= 1) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      float re, im = 0.f;
-      if (off == 8) {  // lanes l and l ^ 8 share a row of 16: row_ror:8 is the same exchange
-        re = elem<E>::re(acc[i]) + dpp_f(elem<E>::re(acc[i]), 0x128);
-        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + dpp_f(elem<E>::im(acc[i]), 0x128);
-      } else {
-        re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
-        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
-      }
+      // (off 8: row_ror:8 inside the row of 16; off 16 / 32: permlane swaps -- add_xor, rls_common.hpp)
+      float re = add_xor(elem<E>::re(acc[i]), off), im = 0.f;
+      if constexpr (elem<E>::cplx) im = add_xor(elem<E>::im(acc[i]), off);
       acc[i] = elem<E>::make(re, im);
     }
   }
@@ -390,14 +385,8 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
   for (int off = G; off < 64; off <<= 1) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      float re, im = 0.f;
-      if (off == 8) {
-        re = elem<E>::re(acc[i]) + dpp_f(elem<E>::re(acc[i]), 0x128);
-        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + dpp_f(elem<E>::im(acc[i]), 0x128);
-      } else {
-        re = elem<E>::re(acc[i]) + __shfl_xor(elem<E>::re(acc[i]), off, 64);
-        if constexpr (elem<E>::cplx) im = elem<E>::im(acc[i]) + __shfl_xor(elem<E>::im(acc[i]), off, 64);
-      }
+      float re = add_xor(elem<E>::re(acc[i]), off), im = 0.f;
+      if constexpr (elem<E>::cplx) im = add_xor(elem<E>::im(acc[i]), off);
       acc[i] = elem<E>::make(re, im);
     }
   }
@@ -926,10 +915,10 @@ template <typename E>
 __device__ static inline E slab_group_combine(E s, E (*sm)[16]) {
   const int cx = threadIdx.x % 16, w = threadIdx.x / 64, nw = blockDim.x / 64;
   float re = elem<E>::re(s), im = elem<E>::im(s);
-  re += __shfl_xor(re, 16, 64);
-  if constexpr (elem<E>::cplx) im += __shfl_xor(im, 16, 64);
-  re += __shfl_xor(re, 32, 64);
-  if constexpr (elem<E>::cplx) im += __shfl_xor(im, 32, 64);
+  re = pair_sum16(re);
+  if constexpr (elem<E>::cplx) im = pair_sum16(im);
+  re = pair_sum32(re);
+  if constexpr (elem<E>::cplx) im = pair_sum32(im);
   if ((threadIdx.x & 63) < 16) sm[w][cx] = elem<E>::make(re, im);
   __syncthreads();
   E t = elem<E>::zero();

@@ -437,6 +437,15 @@ __device__ static inline float wave_sum(float v) {
   return v;
 }
 
+// v + (the value of lane ^ off): the butterfly step of the in-wave sums of the slab kernels.  `off` is a constant after unrolling:
+// 16 and 32 are the permlane swaps above, 8 stays inside a row (row_ror:8 is the same exchange), the rest go through ds_bpermute.
+__device__ static __forceinline__ float add_xor(float v, int off) {
+  if (off == 32) return pair_sum32(v);
+  if (off == 16) return pair_sum16(v);
+  if (off == 8) return v + dpp_f(v, 0x128);
+  return v + __shfl_xor(v, off, 64);
+}
+
 // block-level sum of up to 16 waves; `smem` needs 16 doubles; result valid in every thread.
 // Deterministic: fixed tree inside the wave, fixed order across waves.
 __device__ static inline double block_sum(double v, double* smem) {
