@@ -36,6 +36,10 @@ typedef struct rls_fista rls_fista;       /* fused FISTA plan                   
 typedef struct rls_cg rls_cg;             /* fused cg! plan (ADMM x-update)                        */
 
 enum { RLS_F32 = 0, RLS_C32 = 1 };                 /* Float32, ComplexF32                          */
+/* Float64 / ComplexF64: accepted by the rls_*_d entry points ONLY (the L1 protocol with double scalars, at the end of the
+ * vector section); every other entry point -- the fused plans, the resident and matrix-core kernels -- is Float32 / ComplexF32
+ * (north_star) and answers RLS_E_INVALID for these codes. */
+enum { RLS_F64 = 2, RLS_C64 = 3 };
 enum { RLS_OP_N = 0, RLS_OP_T = 1, RLS_OP_C = 2 }; /* A, transpose(A), adjoint(A)                  */
 enum { RLS_NORMAL_MATRIXFREE = 0, RLS_NORMAL_GRAM = 1 };
 
@@ -129,6 +133,31 @@ int32_t rls_lincomb(rls_ctx* ctx, int32_t dtype, int64_t n, float a_re, float a_
 /* ---------------------------------------------------------------------------------------------
  * proximal maps (in place).   replaces prox!(reg, x, lambda)
  * ------------------------------------------------------------------------------------------- */
+/* ---- the same protocol for Float64 / ComplexF64 arrays (dtype RLS_F64 / RLS_C64): double scalars in, double results out.
+ * The reference's suites run every solver in Float32 AND Float64 (test/testSolvers.jl:242) and its prox tests in ComplexF64
+ * (test/testProxMaps.jl:47,78,106): a double-precision caller runs the reference's own loops (src/CGNR.jl:143-178,
+ * src/FISTA.jl:139-185, src/ADMM.jl:230-322) on these primitives.  Plain coalesced kernels, Float64 fixed-order reductions;
+ * the reductions synchronise and return {re, im} (nrm2: {norm, 0}).  gemv_d: y = alpha op(A) x + beta y, op as rls_gemv. */
+int32_t rls_fill_d(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, double re, double im);
+int32_t rls_scal_d(rls_ctx* ctx, int32_t dtype, int64_t n, double a_re, double a_im, void* x);
+int32_t rls_axpy_d(rls_ctx* ctx, int32_t dtype, int64_t n, double a_re, double a_im, const void* x, void* y);
+int32_t rls_lincomb_d(rls_ctx* ctx, int32_t dtype, int64_t n, double a_re, double a_im, const void* x, double b_re, double b_im,
+                      const void* y, void* z); /* z = a x + b y (y may be z: axpby; b == 0 never reads y) */
+int32_t rls_nrm2_d(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, double* result_h);
+int32_t rls_asum_d(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, double* result_h);
+int32_t rls_dotc_d(rls_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* y, double* result_h); /* conj(x).y */
+int32_t rls_gemv_d(rls_ctx* ctx, int32_t dtype, int32_t op, int64_t M, int64_t N, double alpha_re, double alpha_im, const void* A,
+                   int64_t lda, const void* x, double beta_re, double beta_im, void* y);
+int32_t rls_prox_l1_d(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, double lambda);       /* ProxL1.jl:18-22, eps(Float64) */
+int32_t rls_prox_l2_d(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, double lambda);       /* ProxL2.jl:18-21 */
+int32_t rls_prox_l21_d(rls_ctx* ctx, int32_t dtype, int64_t n, int64_t slices, void* x, double lambda); /* ProxL21.jl:30-35 */
+int32_t rls_prox_positive_d(rls_ctx* ctx, int32_t dtype, int64_t n, void* x);                /* ProxPositive.jl:16-20 */
+int32_t rls_prox_real_d(rls_ctx* ctx, int32_t dtype, int64_t n, void* x);                    /* ProxReal.jl:16-19 */
+/* proxTV! (FGP, ProxTV.jl:89-125) with the geometry arguments of rls_prox_tv_fgp; the workspace (three dual arrays + xTmp) comes
+ * from the context's stream-ordered pool */
+int32_t rls_prox_tv_fgp_d(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims, void* x,
+                          double lambda, int32_t iterations);
+
 int32_t rls_prox_l1(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, float lambda);        /* src/proximalMaps/ProxL1.jl:18-22 */
 int32_t rls_prox_l2(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, float lambda);        /* src/proximalMaps/ProxL2.jl:18-21 */
 int32_t rls_prox_l21(rls_ctx* ctx, int32_t dtype, int64_t n, int64_t slices, void* x, float lambda); /* ProxL21.jl:30-35; ext/..GPUArraysExt/ProxL21.jl:1-12 */

@@ -13,7 +13,7 @@
 module RLSMI355XRegularizedLeastSquaresExt
 
 using RLSMI355X, RegularizedLeastSquares, LinearAlgebra
-using RLSMI355X: RLSVector, RLSMatrix, RLSNormalOp, librls, check, dtypecode, Comm, colptr
+using RLSMI355X: RLSVector, RLSMatrix, RLSNormalOp, librls, check, dtypecode, Comm, colptr, RLSSingle, RLSDouble
 import RegularizedLeastSquares: prox!, proxL21!, proxTV!, enfReal!, enfPos!, tv_restrictMagnitude!, tv_linearcomb!,
                                 init!, iterate, CGNR, CGNRState, FISTA, FISTAState, ADMM, ADMMState, L1Regularization,
                                 L2Regularization, L21Regularization, TVRegularization, PositiveRegularization,
@@ -56,6 +56,30 @@ function proxTV!(reg, x::V{T}, lam::T, shape, dims; iterationsTV = 10, kwargs...
                      x.ctx.handle, dt, length(sh), sh, length(d0), d0, x.ptr, lam, iterationsTV, ws.ptr, need), "rls_prox_tv_fgp")
   x
 end
+# ---- the same maps on Float64 / ComplexF64 vectors (test/testProxMaps.jl:47,78,106 run them in ComplexF64): double scalars ----------
+function prox!(::L1Regularization, x::V{Float64}, lam::Float64)
+  check(x.ctx, ccall((:rls_prox_l1_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Float64), x.ctx.handle, dtypecode(eltype(x)), length(x), x.ptr, lam), "rls_prox_l1_d"); x
+end
+function prox!(::L2Regularization, x::V{Float64}, lam::Float64)
+  check(x.ctx, ccall((:rls_prox_l2_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Float64), x.ctx.handle, dtypecode(eltype(x)), length(x), x.ptr, lam), "rls_prox_l2_d"); x
+end
+function proxL21!(x::V{Float64}, lam::Float64, slices::Int64)
+  check(x.ctx, ccall((:rls_prox_l21_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Float64), x.ctx.handle, dtypecode(eltype(x)), length(x), slices, x.ptr, lam), "rls_prox_l21_d"); x
+end
+function enfReal!(x::RLSVector{ComplexF64})
+  check(x.ctx, ccall((:rls_prox_real_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}), x.ctx.handle, dtypecode(ComplexF64), length(x), x.ptr), "rls_prox_real_d"); nothing
+end
+function enfPos!(x::RLSVector{T}) where {T<:RLSDouble}
+  check(x.ctx, ccall((:rls_prox_positive_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}), x.ctx.handle, dtypecode(T), length(x), x.ptr), "rls_prox_positive_d"); nothing
+end
+function proxTV!(reg, x::V{Float64}, lam::Float64, shape, dims; iterationsTV = 10, kwargs...)
+  sh = collect(Int64, shape); d0 = collect(Int32, dims) .- Int32(1)
+  check(x.ctx, ccall((:rls_prox_tv_fgp_d, librls[]), Int32,
+                     (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}, Int32, Ptr{Int32}, Ptr{Cvoid}, Float64, Int32),
+                     x.ctx.handle, dtypecode(eltype(x)), length(sh), sh, length(d0), d0, x.ptr, lam, iterationsTV), "rls_prox_tv_fgp_d")
+  x
+end
+
 # the two helpers the GPUArrays ext overloads one by one (ext/.../ProxTV.jl:1-17)
 function tv_restrictMagnitude!(x::RLSVector{T}) where {T}
   check(x.ctx, ccall((:rls_tv_restrict, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}), x.ctx.handle, dtypecode(T), length(x), x.ptr), "rls_tv_restrict")
@@ -73,7 +97,7 @@ struct CgnrStatus   # rls_cgnr_status (include/rls_mi355x.h), field for field
   zeta::Float32; residual::Float32; z0::Float32; fallbacks::Int32
 end
 
-function plan_for(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
+function plan_for(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc<:RLSSingle}
   get!(cgnr_plans, state) do
     A = solver.A::RLSMatrix
     op = something(operator_of(A, solver.AHA), A.op)   # matrix-free (A' * A lazy) or Gram mode (AHA = gram(A))
@@ -86,7 +110,7 @@ function plan_for(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
 end
 
 # src/CGNR.jl:107-130
-function init!(solver::CGNR, state::CGNRState{T,Tc,vecTc}, b::vecTc; x0 = 0) where {T,Tc,vecTc<:RLSVector{Tc}}
+function init!(solver::CGNR, state::CGNRState{T,Tc,vecTc}, b::vecTc; x0 = 0) where {T,Tc<:RLSSingle,vecTc<:RLSVector{Tc}}
   all(x0 .== 0) || error("CGNR: x0 != 0 is unsupported (the reference's branch throws as well, src/CGNR.jl:119)")
   plan = plan_for(solver, state)
   # normalization of the regularization parameter (:129) comes FIRST here: the device init takes lambda as an argument
@@ -110,7 +134,7 @@ const cgnr_done = IdDict{Any,Bool}()   # state => `done` as the device last repo
 
 # src/CGNR.jl:143-178.  One library call per iteration: the step and the status read-back (`done`, the convergence record
 # the callbacks read) travel together (rls_cgnr_step_status: one host synchronisation).
-function iterate(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc}
+function iterate(solver::CGNR, state::CGNRState{T,Tc,<:RLSVector}) where {T,Tc<:RLSSingle}
   plan = plan_for(solver, state)
   st = Ref{CgnrStatus}()
   if !haskey(cgnr_done, state)   # first call after init!: is the solve done before it starts (iterations == 0, r == 0)?
@@ -177,7 +201,7 @@ struct FistaStatus   # rls_fista_status, field for field
   fallbacks::Int32
 end
 
-function fista_plan_for(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT}
+function fista_plan_for(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT<:Float32}
   haskey(fista_plans, state) && return fista_plans[state]
   op = operator_of(solver.A, solver.AHA)
   (op === nothing || fused_reg(solver.reg) === nothing || fused_proj(solver.proj) === nothing) && return C_NULL
@@ -194,7 +218,7 @@ function fista_status(state, plan)
   st[]
 end
 
-function init!(solver::FISTA, state::FISTAState{rT,vecT}, b::vecT; x0 = 0, theta = 1) where {rT,vecT<:RLSVector}
+function init!(solver::FISTA, state::FISTAState{rT,vecT}, b::vecT; x0 = 0, theta = 1) where {rT<:Float32,vecT<:RLSVector}
   plan = fista_plan_for(solver, state)
   # (configurations the fused kernels do not cover run the reference's own method.  `invoke` needs a signature that
   #  only the generic method matches: V ranges over every vector type, so this method -- V <: RLSVector -- is not it)
@@ -236,7 +260,7 @@ function fista_refresh!(state, plan, st = fista_status(state, plan))
   st
 end
 
-function iterate(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT}
+function iterate(solver::FISTA, state::FISTAState{rT,<:RLSVector}) where {rT<:Float32}
   plan = get(fista_plans, state, C_NULL)
   plan == C_NULL && return invoke(iterate, Tuple{FISTA,FISTAState}, solver, state)
   done(solver, state) && return nothing
@@ -304,7 +328,7 @@ function admm_plan_for(solver::ADMM, state::ADMMState)
   admm_plans[state] = (cg = cg[], plan = pl[], zbuf = (state.z[1], state.zᵒˡᵈ[1]))
 end
 
-function init!(solver::ADMM, state::ADMMState{rT,rvecT,vecT}, b::vecT; x0 = 0) where {rT,rvecT,vecT<:RLSVector}
+function init!(solver::ADMM, state::ADMMState{rT,rvecT,vecT}, b::vecT; x0 = 0) where {rT<:Float32,rvecT,vecT<:RLSVector}
   # the reference's own init! (:191-220), selected by a signature this method does not match (see the FISTA init! above)
   invoke(init!, Tuple{ADMM,ADMMState{rT,rvecT,V},V} where {V<:Union{AbstractVector{rT},AbstractVector{Complex{rT}}}}, solver, state, b; x0)
   P = admm_plan_for(solver, state)
@@ -333,7 +357,7 @@ function init!(solver::ADMM, state::ADMMState{rT,rvecT,vecT}, b::vecT; x0 = 0) w
   nothing
 end
 
-function iterate(solver::ADMM, state::ADMMState{rT,rvecT,<:RLSVector}) where {rT,rvecT}
+function iterate(solver::ADMM, state::ADMMState{rT,rvecT,<:RLSVector}) where {rT<:Float32,rvecT}
   P = get(admm_plans, state, nothing)
   P === nothing && return invoke(iterate, Tuple{ADMM,ADMMState}, solver, state)
   done(solver, state) && return nothing
@@ -365,7 +389,7 @@ end
 iteration where `done` holds, exactly as the iterate-by-iterate loop of `solve!` does) and one status read-back.
 `solve!(solver, b::RLSVector)` without callbacks lands here; with callbacks it stays the reference's loop.
 """
-function RLSMI355X.solve_fused!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector)
+function RLSMI355X.solve_fused!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector{<:RLSSingle})
   init!(solver, b)
   state = solver.state
   if solver isa CGNR
@@ -441,7 +465,7 @@ end
 # (the reference's loop, src/RegularizedLeastSquares.jl:103-117, would synchronise with the host once per iteration for a
 # `done` nobody else reads: 44 us against 11.7 us per CGNR iteration at 4096 x 2048 ComplexF32).  With callbacks, or with
 # init! keywords (x0, ...), the reference's loop runs as written.
-function RegularizedLeastSquares.solve!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector; callbacks = nothing, kwargs...)
+function RegularizedLeastSquares.solve!(solver::Union{CGNR,FISTA,ADMM}, b::RLSVector{<:RLSSingle}; callbacks = nothing, kwargs...)
   if callbacks === nothing && isempty(kwargs)
     RLSMI355X.solve_fused!(solver, b)
     return solversolution(solver)

@@ -12,6 +12,10 @@ using LinearAlgebra, Libdl
 const librls = Ref{String}(get(ENV, "RLS_MI355X_LIB", "librls_mi355x.so"))
 
 const RLS_F32 = Int32(0); const RLS_C32 = Int32(1)
+const RLS_F64 = Int32(2); const RLS_C64 = Int32(3)   # the rls_*_d entry points only: the L1 protocol with double scalars
+"element types of the tuned path (fused plans, resident kernels, matrix cores) / of the double-precision L1 protocol"
+const RLSSingle = Union{Float32, ComplexF32}
+const RLSDouble = Union{Float64, ComplexF64}
 const RLS_OP_N = Int32(0); const RLS_OP_T = Int32(1); const RLS_OP_C = Int32(2)
 
 struct RLSError <: Exception
@@ -45,7 +49,9 @@ context() = something(default_ctx[], (default_ctx[] = Context(0)))
 
 dtypecode(::Type{Float32}) = RLS_F32
 dtypecode(::Type{ComplexF32}) = RLS_C32
-dtypecode(T) = throw(ArgumentError("the MI355X backend computes in Float32 / ComplexF32; got $T"))
+dtypecode(::Type{Float64}) = RLS_F64
+dtypecode(::Type{ComplexF64}) = RLS_C64
+dtypecode(T) = throw(ArgumentError("the MI355X backend computes in Float32 / ComplexF32 (tuned path) and Float64 / ComplexF64 (L1 protocol); got $T"))
 
 # ---- device vector: the array type of b and of every solver state vector ------------------------
 mutable struct RLSVector{T} <: AbstractVector{T}
@@ -299,11 +305,15 @@ function RLSMatrix(a::Matrix{T}; ctx = context()) where {T}
   check(ctx, ccall((:rls_malloc, librls[]), Int32, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, sizeof(a), p), "rls_malloc")
   check(ctx, ccall((:rls_memcpy_h2d, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{T}, Csize_t), ctx.handle, p[], a, sizeof(a)), "rls_memcpy_h2d")
   o = Ref{Ptr{Cvoid}}(C_NULL)
-  check(ctx, ccall((:rls_operator_create, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}),
-                   ctx.handle, dtypecode(T), size(a, 1), size(a, 2), p[], size(a, 1), o), "rls_operator_create")
+  if T <: RLSSingle   # (Float64 / ComplexF64 operators carry no rls_operator: their products go through rls_gemv_d)
+    check(ctx, ccall((:rls_operator_create, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}),
+                     ctx.handle, dtypecode(T), size(a, 1), size(a, 2), p[], size(a, 1), o), "rls_operator_create")
+  else
+    dtypecode(T)
+  end
   A = RLSMatrix{T}(p[], size(a, 1), size(a, 2), size(a, 1), ctx, o[])
   finalizer(A) do x
-    ccall((:rls_operator_destroy, librls[]), Int32, (Ptr{Cvoid},), x.op)
+    x.op == C_NULL || ccall((:rls_operator_destroy, librls[]), Int32, (Ptr{Cvoid},), x.op)
     ccall((:rls_free, librls[]), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, x.ptr)
   end
 end
@@ -336,6 +346,63 @@ function LinearAlgebra.mul!(v::RLSVector{T}, N::RLSNormalOp{T}, p::RLSVector{T})
   v
 end
 
+# ---- Float64 / ComplexF64: the same protocol through the rls_*_d entry points (double scalars in, double results out) ------------
+# The reference's own suites run every solver in Float32 AND Float64 (test/testSolvers.jl:242) and the prox tests in ComplexF64
+# (test/testProxMaps.jl:47,78,106).  The tuned path is Float32 / ComplexF32 (SURVEY 8a); on double-precision arrays the UNCHANGED
+# loops of src/CGNR.jl, src/FISTA.jl and src/ADMM.jl run on these methods (the extension's fused init! / iterate are restricted
+# to RLSSingle element types).
+function Base.fill!(v::RLSVector{T}, c) where {T<:RLSDouble}
+  z = ComplexF64(c)
+  check(v.ctx, ccall((:rls_fill_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Float64, Float64), v.ctx.handle, dtypecode(T), v.n, v.ptr, real(z), imag(z)), "rls_fill_d")
+  v
+end
+function LinearAlgebra.norm(v::RLSVector{T}) where {T<:RLSDouble}
+  r = Ref{NTuple{2,Float64}}((0.0, 0.0))
+  check(v.ctx, ccall((:rls_nrm2_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}), v.ctx.handle, dtypecode(T), v.n, v.ptr, r), "rls_nrm2_d")
+  r[][1]
+end
+function LinearAlgebra.norm(v::RLSVector{T}, p::Real) where {T<:RLSDouble}
+  p == 2 && return norm(v)
+  p == 1 || throw(ArgumentError("norm(::RLSVector, p): p = 1 or 2"))
+  r = Ref{NTuple{2,Float64}}((0.0, 0.0))
+  check(v.ctx, ccall((:rls_asum_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}), v.ctx.handle, dtypecode(T), v.n, v.ptr, r), "rls_asum_d")
+  r[][1]
+end
+function LinearAlgebra.dot(x::RLSVector{T}, y::RLSVector{T}) where {T<:RLSDouble}
+  r = Ref{NTuple{2,Float64}}((0.0, 0.0))
+  check(x.ctx, ccall((:rls_dotc_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, dtypecode(T), x.n, x.ptr, y.ptr, r), "rls_dotc_d")
+  T <: Complex ? T(r[][1], r[][2]) : T(r[][1])
+end
+function LinearAlgebra.rmul!(v::RLSVector{T}, a::Number) where {T<:RLSDouble}
+  z = ComplexF64(a)
+  check(v.ctx, ccall((:rls_scal_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Float64, Float64, Ptr{Cvoid}), v.ctx.handle, dtypecode(T), v.n, real(z), imag(z), v.ptr), "rls_scal_d")
+  v
+end
+function axpy!(a::Number, x::RLSVector{T}, y::RLSVector{T}) where {T<:RLSDouble}
+  z = ComplexF64(a)
+  check(y.ctx, ccall((:rls_axpy_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}), y.ctx.handle, dtypecode(T), y.n, real(z), imag(z), x.ptr, y.ptr), "rls_axpy_d")
+  y
+end
+function lincomb!(z::RLSVector{T}, a::Number, x::RLSVector{T}, b::Number, y::RLSVector{T}) where {T<:RLSDouble}
+  za, zb = ComplexF64(a), ComplexF64(b)
+  check(z.ctx, ccall((:rls_lincomb_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Float64, Float64, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+                     z.ctx.handle, dtypecode(T), z.n, real(za), imag(za), x.ptr, real(zb), imag(zb), y.ptr, z.ptr), "rls_lincomb_d")
+  z
+end
+function gemv!(op::Int32, A::RLSMatrix{T}, x::RLSVector{T}, y::RLSVector{T}, alpha::Number, beta::Number) where {T<:RLSDouble}
+  a, b = ComplexF64(alpha), ComplexF64(beta)
+  check(A.ctx, ccall((:rls_gemv_d, librls[]), Int32,
+                     (Ptr{Cvoid}, Int32, Int32, Int64, Int64, Float64, Float64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}),
+                     A.ctx.handle, dtypecode(T), op, A.M, A.N, real(a), imag(a), A.ptr, A.lda, x.ptr, real(b), imag(b), y.ptr), "rls_gemv_d")
+  y
+end
+"v = A' * (A * p) as two products (no one-pass kernel in double precision)"
+function LinearAlgebra.mul!(v::RLSVector{T}, N::RLSNormalOp{T}, p::RLSVector{T}) where {T<:RLSDouble}
+  t = RLSVector{T}(undef, N.A.M; ctx = N.A.ctx)
+  gemv!(RLS_OP_N, N.A, p, t, 1, 0)
+  gemv!(RLS_OP_C, N.A, t, v, 1, 0)
+end
+
 """
     gram(A::RLSMatrix) -> RLSMatrix
 
@@ -345,6 +412,7 @@ where AHA fits the register files the whole `step` call runs as one resident lau
 lazy (matrix-free), so the unchanged constructor default keeps the reference's matrix-free arithmetic.
 """
 function gram(A::RLSMatrix{T}) where {T}
+  T <: RLSSingle || throw(ArgumentError("gram: the matrix-core Gram GEMM is Float32 / ComplexF32; got $T (form A' * A on the host and upload it)"))
   N = A.N
   p = Ref{Ptr{Cvoid}}(C_NULL)
   check(A.ctx, ccall((:rls_malloc, librls[]), Int32, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), A.ctx.handle, N * N * sizeof(T), p), "rls_malloc")

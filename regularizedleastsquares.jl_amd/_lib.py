@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librls_mi355x.so")
 
 F32, C32 = 0, 1
+F64, C64 = 2, 3   # the rls_*_d entry points only (the L1 protocol with double scalars)
 OP_N, OP_T, OP_C = 0, 1, 2
 REG_NONE, REG_L1, REG_L2, REG_L21, REG_TV = 0, 1, 2, 3, 4
 PROJ_NONE, PROJ_REAL, PROJ_POSITIVE = 0, 1, 2
@@ -55,6 +56,8 @@ class AdmmStatus(C.Structure):
 _vp, _i32, _i64, _f, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _pvp = C.POINTER(C.c_void_p)
 _pf = C.POINTER(C.c_float)
+_d = C.c_double
+_pd = C.POINTER(C.c_double)
 _pi64 = C.POINTER(C.c_int64)
 _pi32 = C.POINTER(C.c_int32)
 
@@ -87,6 +90,21 @@ PROTOTYPES = {
     "rls_axpy": (_i32, [_vp, _i32, _i64, _f, _f, _vp, _vp]),
     "rls_axpby": (_i32, [_vp, _i32, _i64, _f, _f, _vp, _f, _f, _vp]),
     "rls_lincomb": (_i32, [_vp, _i32, _i64, _f, _f, _vp, _f, _f, _vp, _vp]),
+    # ---- Float64 / ComplexF64: the L1 protocol with double scalars (csrc/f64.hip) ----
+    "rls_fill_d": (_i32, [_vp, _i32, _i64, _vp, _d, _d]),
+    "rls_scal_d": (_i32, [_vp, _i32, _i64, _d, _d, _vp]),
+    "rls_axpy_d": (_i32, [_vp, _i32, _i64, _d, _d, _vp, _vp]),
+    "rls_lincomb_d": (_i32, [_vp, _i32, _i64, _d, _d, _vp, _d, _d, _vp, _vp]),
+    "rls_nrm2_d": (_i32, [_vp, _i32, _i64, _vp, _pd]),
+    "rls_asum_d": (_i32, [_vp, _i32, _i64, _vp, _pd]),
+    "rls_dotc_d": (_i32, [_vp, _i32, _i64, _vp, _vp, _pd]),
+    "rls_gemv_d": (_i32, [_vp, _i32, _i32, _i64, _i64, _d, _d, _vp, _i64, _vp, _d, _d, _vp]),
+    "rls_prox_l1_d": (_i32, [_vp, _i32, _i64, _vp, _d]),
+    "rls_prox_l2_d": (_i32, [_vp, _i32, _i64, _vp, _d]),
+    "rls_prox_l21_d": (_i32, [_vp, _i32, _i64, _i64, _vp, _d]),
+    "rls_prox_positive_d": (_i32, [_vp, _i32, _i64, _vp]),
+    "rls_prox_real_d": (_i32, [_vp, _i32, _i64, _vp]),
+    "rls_prox_tv_fgp_d": (_i32, [_vp, _i32, _i32, _pi64, _i32, _pi32, _vp, _d, _i32]),
     "rls_prox_l1": (_i32, [_vp, _i32, _i64, _vp, _f]),
     "rls_prox_l2": (_i32, [_vp, _i32, _i64, _vp, _f]),
     "rls_prox_l21": (_i32, [_vp, _i32, _i64, _i64, _vp, _f]),

@@ -15,17 +15,22 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import _lib
-from ._lib import C32, F32, OP_C, OP_N, OP_T, RLSError, check
+from ._lib import C32, C64, F32, F64, OP_C, OP_N, OP_T, RLSError, check
 
-_DT = {np.dtype(np.float32): F32, np.dtype(np.complex64): C32}
-_NP = {F32: np.dtype(np.float32), C32: np.dtype(np.complex64)}
+_DT = {np.dtype(np.float32): F32, np.dtype(np.complex64): C32, np.dtype(np.float64): F64, np.dtype(np.complex128): C64}
+_NP = {F32: np.dtype(np.float32), C32: np.dtype(np.complex64), F64: np.dtype(np.float64), C64: np.dtype(np.complex128)}
 
 
 def dtype_code(dt) -> int:
     dt = np.dtype(dt)
     if dt not in _DT:
-        raise TypeError(f"the MI355X backend computes in Float32 / ComplexF32; got {dt}")
+        raise TypeError(f"the MI355X backend computes in Float32 / ComplexF32 (tuned path) and Float64 / ComplexF64 (L1 protocol); got {dt}")
     return _DT[dt]
+
+
+def is_double(code: int) -> bool:
+    """Float64 / ComplexF64: the rls_*_d entry points (the L1 protocol with double scalars); no fused plans, no resident kernels"""
+    return code in (F64, C64)
 
 
 class Context:
@@ -170,57 +175,69 @@ class DeviceVector:
         check(h, lib.rls_memcpy_d2d(h, self.ptr, other.ptr, self.n * self.dtype.itemsize), "rls_memcpy_d2d")
 
     # --- BLAS-1 (names follow LinearAlgebra) ----------------------------------------------------
+    # (Float64 / ComplexF64 vectors take the rls_*_d entry points: double scalars in, double results out)
     def fill_(self, value):
         value = complex(value)
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_fill(h, self.code, self.n, self.ptr, value.real, value.imag), "rls_fill")
+        if is_double(self.code):
+            check(h, lib.rls_fill_d(h, self.code, self.n, self.ptr, value.real, value.imag), "rls_fill_d")
+        else:
+            check(h, lib.rls_fill(h, self.code, self.n, self.ptr, value.real, value.imag), "rls_fill")
         return self
 
-    def norm(self) -> float:
-        r = (C.c_float * 2)()
+    def _reduce(self, name, *ptrs):
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_nrm2(h, self.code, self.n, self.ptr, r), "rls_nrm2")
-        return float(r[0])
+        if is_double(self.code):
+            r = (C.c_double * 2)()
+            check(h, getattr(lib, name + "_d")(h, self.code, self.n, *ptrs, r), name + "_d")
+        else:
+            r = (C.c_float * 2)()
+            check(h, getattr(lib, name)(h, self.code, self.n, *ptrs, r), name)
+        return r
+
+    def norm(self) -> float:
+        return float(self._reduce("rls_nrm2", self.ptr)[0])
 
     def norm1(self) -> float:
-        r = (C.c_float * 2)()
-        lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_asum(h, self.code, self.n, self.ptr, r), "rls_asum")
-        return float(r[0])
+        return float(self._reduce("rls_asum", self.ptr)[0])
 
     def dot(self, other: "DeviceVector"):
         """dot(self, other) = conj(self) . other"""
-        r = (C.c_float * 2)()
-        lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_dotc(h, self.code, self.n, self.ptr, other.ptr, r), "rls_dotc")
-        return complex(r[0], r[1]) if self.code == C32 else float(r[0])
+        r = self._reduce("rls_dotc", self.ptr, other.ptr)
+        return complex(r[0], r[1]) if self.code in (C32, C64) else float(r[0])
 
     def rmul_(self, a):
         a = complex(a)
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_scal(h, self.code, self.n, a.real, a.imag, self.ptr), "rls_scal")
+        if is_double(self.code):
+            check(h, lib.rls_scal_d(h, self.code, self.n, a.real, a.imag, self.ptr), "rls_scal_d")
+        else:
+            check(h, lib.rls_scal(h, self.code, self.n, a.real, a.imag, self.ptr), "rls_scal")
         return self
 
     def axpy_(self, a, x: "DeviceVector"):
         """self .+= a .* x"""
         a = complex(a)
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_axpy(h, self.code, self.n, a.real, a.imag, x.ptr, self.ptr), "rls_axpy")
+        if is_double(self.code):
+            check(h, lib.rls_axpy_d(h, self.code, self.n, a.real, a.imag, x.ptr, self.ptr), "rls_axpy_d")
+        else:
+            check(h, lib.rls_axpy(h, self.code, self.n, a.real, a.imag, x.ptr, self.ptr), "rls_axpy")
         return self
 
     def axpby_(self, a, x: "DeviceVector", b):
         """self = a x + b self"""
-        a, b = complex(a), complex(b)
-        lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_axpby(h, self.code, self.n, a.real, a.imag, x.ptr, b.real, b.imag, self.ptr), "rls_axpby")
-        return self
+        return self.lincomb_(a, x, b, self)
 
     def lincomb_(self, a, x: "DeviceVector", b, y: "DeviceVector"):
         """self = a x + b y"""
         a, b = complex(a), complex(b)
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_lincomb(h, self.code, self.n, a.real, a.imag, x.ptr, b.real, b.imag, y.ptr, self.ptr),
-              "rls_lincomb")
+        if is_double(self.code):
+            check(h, lib.rls_lincomb_d(h, self.code, self.n, a.real, a.imag, x.ptr, b.real, b.imag, y.ptr, self.ptr), "rls_lincomb_d")
+        else:
+            check(h, lib.rls_lincomb(h, self.code, self.n, a.real, a.imag, x.ptr, b.real, b.imag, y.ptr, self.ptr),
+                  "rls_lincomb")
         return self
 
     def stats(self):
@@ -282,7 +299,10 @@ class DeviceMatrix:
         """A .= value (every stored element, padding rows of lda included)"""
         value = complex(value)
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_fill(h, dtype_code(self.dtype), self.lda * self.N, self.ptr, value.real, value.imag), "rls_fill")
+        if is_double(self.code):
+            check(h, lib.rls_fill_d(h, self.code, self.lda * self.N, self.ptr, value.real, value.imag), "rls_fill_d")
+        else:
+            check(h, lib.rls_fill(h, dtype_code(self.dtype), self.lda * self.N, self.ptr, value.real, value.imag), "rls_fill")
         return self
 
     def column(self, j: int) -> DeviceVector:
@@ -306,8 +326,12 @@ class DeviceMatrix:
         if x.n != nx or y.n != ny:
             raise ValueError(f"gemv: dimension mismatch: A is {self.M}x{self.N}, x {x.n}, y {y.n}, op {op}")
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_gemv(h, self.code, op, self.M, self.N, alpha.real, alpha.imag, self.ptr, self.lda, x.ptr,
-                              beta.real, beta.imag, y.ptr), "rls_gemv")
+        if is_double(self.code):
+            check(h, lib.rls_gemv_d(h, self.code, op, self.M, self.N, alpha.real, alpha.imag, self.ptr, self.lda, x.ptr,
+                                    beta.real, beta.imag, y.ptr), "rls_gemv_d")
+        else:
+            check(h, lib.rls_gemv(h, self.code, op, self.M, self.N, alpha.real, alpha.imag, self.ptr, self.lda, x.ptr,
+                                  beta.real, beta.imag, y.ptr), "rls_gemv")
         return y
 
     def mul_(self, y: DeviceVector, x: DeviceVector, alpha=1.0, beta=0.0):
@@ -390,16 +414,30 @@ class OperatorHandle:
         self.M = A.M if A is not None else 0
         self.N = A.N if A is not None else gram.N
         lib, h = self.ctx.lib, self.ctx.handle
+        if gram is not None and (gram.M != self.N or gram.N != self.N):
+            raise ValueError("Gram matrix must be N x N")
+        self.double = is_double(self.code)
+        self._t = None
+        if self.double:
+            # Float64 / ComplexF64: no rls_operator (the fused plans are Float32 / ComplexF32): v = AHA p is the explicit Gram GEMV or
+            # the two GEMVs of the matrix-free normal operator, through rls_gemv_d
+            self.handle = None
+            return
         o = C.c_void_p()
         check(h, lib.rls_operator_create(h, self.code, self.M, self.N, A.ptr if A is not None else None,
                                          A.lda if A is not None else 0, C.byref(o)), "rls_operator_create")
         self.handle = o
         if gram is not None:
-            if gram.M != self.N or gram.N != self.N:
-                raise ValueError("Gram matrix must be N x N")
             check(h, lib.rls_operator_set_gram(o, gram.ptr, gram.lda), "rls_operator_set_gram")
 
     def mul_normal_(self, v: DeviceVector, p: DeviceVector):
+        if self.double:
+            if self.gram is not None:
+                return self.gram.mul_(v, p)
+            if self._t is None:
+                self._t = DeviceVector(self.M, self.dtype, self.ctx)
+            self.A.mul_(self._t, p)
+            return self.A.mul_adj_(v, self._t)
         check(self.ctx.handle, self.ctx.lib.rls_operator_mul_normal(self.handle, p.ptr, v.ptr), "rls_operator_mul_normal")
         return v
 

@@ -9,10 +9,17 @@ Both call forms of the reference are kept:
 from __future__ import annotations
 
 import ctypes as C
+
+import numpy as np
 from typing import Optional, Sequence, Tuple
 
 from ._lib import check
 from .arrays import DeviceVector
+
+
+def _dbl(x) -> bool:
+    """Float64 / ComplexF64 vector: the rls_*_d entry points (double scalars)"""
+    return x.dtype in (np.dtype(np.float64), np.dtype(np.complex128))
 
 
 class AbstractRegularization:
@@ -34,7 +41,10 @@ class L1Regularization(AbstractParameterizedRegularization):
         self.lam = float(lam)
 
     def prox_(self, x: DeviceVector, lam: float):
-        check(x.ctx.handle, x.ctx.lib.rls_prox_l1(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l1")
+        if _dbl(x):
+            check(x.ctx.handle, x.ctx.lib.rls_prox_l1_d(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l1_d")
+        else:
+            check(x.ctx.handle, x.ctx.lib.rls_prox_l1(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l1")
         return x
 
     def norm(self, x: DeviceVector, lam: float) -> float:
@@ -55,7 +65,10 @@ class L2Regularization(AbstractParameterizedRegularization):
             self.lam = float(lam)
 
     def prox_(self, x: DeviceVector, lam: float):
-        check(x.ctx.handle, x.ctx.lib.rls_prox_l2(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l2")
+        if _dbl(x):
+            check(x.ctx.handle, x.ctx.lib.rls_prox_l2_d(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l2_d")
+        else:
+            check(x.ctx.handle, x.ctx.lib.rls_prox_l2(x.ctx.handle, x.code, x.n, x.ptr, float(lam)), "rls_prox_l2")
         return x
 
     def norm(self, x: DeviceVector, lam: float) -> float:
@@ -70,7 +83,10 @@ class L21Regularization(AbstractParameterizedRegularization):
         self.slices = int(slices)
 
     def prox_(self, x: DeviceVector, lam: float):
-        check(x.ctx.handle, x.ctx.lib.rls_prox_l21(x.ctx.handle, x.code, x.n, self.slices, x.ptr, float(lam)), "rls_prox_l21")
+        if _dbl(x):
+            check(x.ctx.handle, x.ctx.lib.rls_prox_l21_d(x.ctx.handle, x.code, x.n, self.slices, x.ptr, float(lam)), "rls_prox_l21_d")
+        else:
+            check(x.ctx.handle, x.ctx.lib.rls_prox_l21(x.ctx.handle, x.code, x.n, self.slices, x.ptr, float(lam)), "rls_prox_l21")
         return x
 
     def norm(self, x: DeviceVector, lam: float) -> float:
@@ -111,6 +127,9 @@ class TVRegularization(AbstractParameterizedRegularization):
         if n != x.n:
             raise ValueError(f"TVRegularization: prod(shape)={n} does not match length(x)={x.n}")
         lib, h = x.ctx.lib, x.ctx.handle
+        if _dbl(x):   # Float64 / ComplexF64: the generic FGP sequence with double scalars (its workspace comes from the context's pool)
+            check(h, lib.rls_prox_tv_fgp_d(h, x.code, len(shape), cs, len(d0), cd, x.ptr, float(lam), self.iterationsTV), "rls_prox_tv_fgp_d")
+            return x
         need = lib.rls_prox_tv_workspace_bytes(x.code, len(shape), cs, len(d0), cd)
         if self._ws is None or self._ws.n * self._ws.dtype.itemsize < need or self._ws.ctx is not x.ctx:
             self._ws = DeviceVector((need + x.dtype.itemsize - 1) // x.dtype.itemsize, x.dtype, x.ctx)
@@ -212,7 +231,10 @@ class PositiveRegularization(AbstractProjectionRegularization):
         pass
 
     def prox_(self, x: DeviceVector, lam=None):
-        check(x.ctx.handle, x.ctx.lib.rls_prox_positive(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_positive")
+        if _dbl(x):
+            check(x.ctx.handle, x.ctx.lib.rls_prox_positive_d(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_positive_d")
+        else:
+            check(x.ctx.handle, x.ctx.lib.rls_prox_positive(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_positive")
         return x
 
 
@@ -223,7 +245,10 @@ class RealRegularization(AbstractProjectionRegularization):
         pass
 
     def prox_(self, x: DeviceVector, lam=None):
-        check(x.ctx.handle, x.ctx.lib.rls_prox_real(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_real")
+        if _dbl(x):
+            check(x.ctx.handle, x.ctx.lib.rls_prox_real_d(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_real_d")
+        else:
+            check(x.ctx.handle, x.ctx.lib.rls_prox_real(x.ctx.handle, x.code, x.n, x.ptr), "rls_prox_real")
         return x
 
 

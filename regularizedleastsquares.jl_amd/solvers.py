@@ -164,7 +164,8 @@ class CGNRState(AbstractSolverState):
         return st
 
     def convergence(self):
-        self._refresh(self.x.ctx.lib)
+        if self._plan:
+            self._refresh(self.x.ctx.lib)
         return {"residual": self._residual}  # src/CGNR.jl:136
 
     def __del__(self):
@@ -206,10 +207,70 @@ class CGNR(AbstractKrylovSolver):
             # the reference's x0 != 0 branch reads a field that does not exist (src/CGNR.jl:119)
             raise NotImplementedError("CGNR: x0 != 0 is unsupported (it throws in the reference as well)")
         lib = b.ctx.lib
+        if self._op.double:
+            return self._init_from_primitives(state, b)
         self._prepare(state, b)
         check(b.ctx.handle, lib.rls_cgnr_init(state._plan, b.ptr, float(self.L2.lam), state.relTol, self.iterations),
               "rls_cgnr_init")
         self._after_init(state)
+
+    # ---- Float64 / ComplexF64: the reference's loop on the L1 protocol (rls_*_d), statement by statement ----------------------------
+    def _init_from_primitives(self, state: CGNRState, b: DeviceVector):
+        """init!  src/CGNR.jl:107-130 on the primitives"""
+        N = self._op.N
+        self.L2 = normalize(self.normalizeReg, self.L2, self.A, b, in_solver=True)  # :129
+        if state.x is None or state.x.ctx is not b.ctx or state.x.dtype != b.dtype or state.x.n != N:
+            state.x, state.x0, state.pl, state.vl = (b.similar(N) for _ in range(4))
+        expect = self._op.M if self.A is not None else N
+        if b.n != expect:
+            raise ValueError(f"DimensionMismatch: b has length {b.n}, expected {expect}")
+        state.x.fill_(0)                                   # :108-115 (x0 = 0)
+        if self.A is not None:
+            self.A.mul_adj_(state.x0, b)                   # initCGNR :132
+        else:
+            state.x0.copy_from(b)                          # :134
+        state.z0 = state.x0.norm()                         # :125
+        state.pl.copy_from(state.x0)                       # :126
+        state.vl.fill_(0)
+        state.alphal = state.betal = state.zetal = 0.0
+        state._residual = state.z0
+        self._after_init(state)
+        state._status_valid = True
+
+    def _iterate_from_primitives(self, state: CGNRState):
+        """iterate  src/CGNR.jl:143-178 on the primitives (one dot, two norms, three axpy-like broadcasts, one rmul! per iteration)"""
+        with np.errstate(all="ignore"):
+            conv = bool(np.float64(state._residual) / np.float64(state.z0) <= state.relTol)   # converged(): :181-183 (0 / 0 = NaN: false)
+        if conv or state.iteration >= min(self.iterations, self._op.N):   # done(): :181-185
+            if not getattr(state, "_finalised", False):
+                for r in self.constr:
+                    r.prox_(state.x)
+                state._finalised = True
+            state._done = True
+            return None
+        cplx = state.x.dtype.kind == "c"
+        lam = float(self.L2.lam)
+        self._op.mul_normal_(state.vl, state.pl)           # :151
+        zeta = state.x0.norm() ** 2                        # :153
+        normvl = state.pl.dot(state.vl)                    # :154
+        den = normvl + lam * state.pl.norm() ** 2 if lam > 0 else normvl   # :158-160
+        with np.errstate(all="ignore"):
+            alpha = np.complex128(zeta) / np.complex128(den) if cplx else np.float64(zeta) / np.float64(den)
+        alpha = complex(alpha) if cplx else float(alpha)
+        state.x.axpy_(alpha, state.pl)                     # :163
+        state.x0.axpy_(-alpha, state.vl)                   # :165
+        if lam > 0:
+            state.x0.axpy_(-lam * alpha, state.pl)         # :168
+        rr = state.x0.dot(state.x0)
+        with np.errstate(all="ignore"):
+            beta = (np.complex128(rr) / np.complex128(zeta)) if cplx else np.float64(rr) / np.float64(zeta)   # :171
+        beta = complex(beta) if cplx else float(beta)
+        state.pl.rmul_(beta)                               # :173
+        state.pl.axpy_(1.0, state.x0)                      # :174
+        state.alphal, state.betal, state.zetal = alpha, beta, zeta
+        state.iteration += 1
+        state._residual = state.x0.norm()
+        return state.x, state
 
     def _prepare(self, state: CGNRState, b: DeviceVector):
         """everything of init! ahead of the device work: the normalised L2 weight, the state vectors and the plan"""
@@ -240,6 +301,8 @@ class CGNR(AbstractKrylovSolver):
         """iterate(solver, state)  src/CGNR.jl:143-178; returns None when done.  One library call per iteration: the step
         and the status read-back (`done`, the convergence record) travel together (rls_cgnr_step_status)"""
         state = state or self.state
+        if self._op.double:
+            return self._iterate_from_primitives(state)
         lib = state.x.ctx.lib
         if not getattr(state, "_status_valid", False):
             state._refresh(lib)  # first call after init! (or after work enqueued behind the host's back): is it done already?
@@ -254,6 +317,10 @@ class CGNR(AbstractKrylovSolver):
 
     def _run(self, state: CGNRState):
         """no callbacks: enqueue every remaining iteration (no-ops once done) and finalise"""
+        if self._op.double:
+            while self.iterate(state) is not None:
+                pass
+            return
         lib = state.x.ctx.lib
         n = max(min(self.iterations, self._op.N) - state.iteration, 0)
         state._step_status(lib, n)
@@ -278,7 +345,7 @@ def solve_group_(solvers, rhs):
         raise ValueError("solve_group_: one right-hand side per solver")
     host = len(rhs) >= 1 and all(isinstance(b, np.ndarray) for b in rhs)
     ok = len(solvers) >= 1 and all(isinstance(s_, CGNR) and isinstance(s_._op, OperatorHandle) and s_.A is not None and
-                                  isinstance(s_.state, CGNRState) for s_ in solvers)
+                                  isinstance(s_.state, CGNRState) and not s_._op.double for s_ in solvers)
     if ok and host:
         ctx = solvers[0].A.ctx
         ok = all(s_.A.ctx is ctx and s_.A.dtype == np.dtype(b.dtype) and b.ndim == 1 and b.shape[0] == s_._op.M
@@ -455,15 +522,17 @@ class FISTA(AbstractProximalGradientSolver):
         if rho is None:
             n = self._op.N
             rng = np.random.default_rng()
-            v = rng.standard_normal(n).astype(np.float32)
+            v = rng.standard_normal(n)
             if self._op.dtype.kind == "c":
-                v = (v + 1j * rng.standard_normal(n)).astype(np.complex64)
-            start = DeviceVector.from_host(v, self._op.ctx)
+                v = v + 1j * rng.standard_normal(n)
+            start = DeviceVector.from_host(v.astype(self._op.dtype), self._op.ctx)
             rho = 0.95 / power_iterations(_NormalApply(self._op), start)
         self.state = FISTAState(rho, theta, relTol)
 
     def _fused_kinds(self):
         """(reg_kind, lambda, slices, proj_kind) when the update is fusable, else None"""
+        if self._op.double:
+            return None  # Float64 / ComplexF64: the reference's loop on the primitives (rls_*_d); the plans are Float32 / ComplexF32
         r = self.reg
         if type(r) is L1Regularization:
             kind, slices = REG_L1, 1
@@ -576,7 +645,7 @@ class FISTA(AbstractProximalGradientSolver):
         """src/FISTA.jl:139-185 from primitives (one host read-back for the residual norm)"""
         if state.rel_res_norm < state.relTol or state.iteration >= self.iterations:
             return None
-        f32 = np.float32
+        f32 = np.float64 if self._op.double else np.float32   # (the scalars' type follows the element type, as rT does in the reference)
         state.x, state.xold = state.xold, state.x
         th, tho = f32(state.theta), f32(state.thetaold)
         state.x.rmul_(float((f32(1) - tho) / th))
@@ -748,10 +817,12 @@ class ADMM(AbstractPrimalDualSolver):
                 state._admm = None
             if state._cg:
                 lib.rls_cg_destroy(state._cg)
-            plan = C.c_void_p()
-            check(h, lib.rls_cg_create(self._op.handle, state.cg_u.ptr, state.cg_r.ptr, state.cg_c.ptr, C.byref(plan)),
-                  "rls_cg_create")
-            state._cg = plan
+                state._cg = None
+            if not self._op.double:   # (Float64 / ComplexF64: cg! from the primitives, _cg_generic; the plans are Float32 / ComplexF32)
+                plan = C.c_void_p()
+                check(h, lib.rls_cg_create(self._op.handle, state.cg_u.ptr, state.cg_r.ptr, state.cg_c.ptr, C.byref(plan)),
+                      "rls_cg_create")
+                state._cg = plan
             state._keep = (self._op, b.ctx)
             state._zbufs = None
         if len(self.reg) == 1:
@@ -773,7 +844,12 @@ class ADMM(AbstractPrimalDualSolver):
         state.sk[:] = np.inf
         state.eps_pri[:] = 0
         state.eps_dua[:] = 0
-        state.sigma_abs = np.float32(np.sqrt(np.float32(b.n))) * state.absTol
+        if self._op.double and state.rk.dtype != np.float64:   # the scalars follow the element type (rT in the reference, src/ADMM.jl:19-46)
+            for name in ("rho", "rk", "sk", "eps_pri", "eps_dua", "Delta"):
+                setattr(state, name, getattr(state, name).astype(np.float64))
+            state.absTol, state.relTol, state.tolInner = (np.float64(v) for v in (state.absTol, state.relTol, state.tolInner))
+        rt = np.float64 if self._op.double else np.float32
+        state.sigma_abs = rt(np.sqrt(rt(b.n))) * state.absTol
         state.Delta[:] = np.inf
         state.rho[:] = self.rho
         state.iteration = 0
@@ -782,7 +858,7 @@ class ADMM(AbstractPrimalDualSolver):
 
     def _plan_params(self, state):
         """rls_admm_params when the whole outer iteration can run on the device, else None"""
-        if type(self) not in (ADMM, SplitBregman) or not self.use_device_plan or self.precon is not None or not (
+        if type(self) not in (ADMM, SplitBregman) or not self.use_device_plan or self.precon is not None or self._op.double or not (
                 self._all_identity() and len(self.reg) == 1 and self.vary_rho == "none" and not self.verbose):
             return None
         reg, rho = self.reg[0], np.float32(state.rho[0])
@@ -890,7 +966,7 @@ class ADMM(AbstractPrimalDualSolver):
         """IterativeSolvers.cg!(x, AHA, b; Pl = precon) from primitives: the preconditioned recurrence (oracle `_pcg_inplace`,
         pinned iterate by iterate against SciPy's PCG in tests/test_oracle.py): c = Pl \\ r; rho = <c, r>; u = c + (rho / rho_prev) u;
         c = A u; alpha = rho / <u, c>; the stopping test stays on ||r||"""
-        f32 = np.float32
+        f32 = np.float64 if self._op.double else np.float32
         x, b = state.x, state.beta
         u, r, c = state.cg_u, state.cg_r, state.cg_c
         tmp = state.zold
@@ -920,8 +996,8 @@ class ADMM(AbstractPrimalDualSolver):
         return it
 
     def _cg_generic(self, state):
-        """IterativeSolvers.cg! from primitives (non-identity regTrafo); see oracle cg_inplace"""
-        f32 = np.float32
+        """IterativeSolvers.cg! from primitives (non-identity regTrafo; Float64 / ComplexF64 element types); see oracle cg_inplace"""
+        f32 = np.float64 if self._op.double else np.float32
         x, b = state.x, state.beta
         u, r, c = state.cg_u, state.cg_r, state.cg_c
         tmp = state.zold  # free at this point of the iteration
@@ -953,9 +1029,9 @@ class ADMM(AbstractPrimalDualSolver):
         if state._plan_ok:
             self._plan_advance(state, 1)
             return state.x, state
-        f32 = np.float32
+        f32 = np.float64 if self._op.double else np.float32
         lib, h = state.x.ctx.lib, state.x.ctx.handle
-        fused = self._all_identity() and len(self.reg) == 1
+        fused = self._all_identity() and len(self.reg) == 1 and not self._op.double
         # 1. x update                                                                  :236-244
         if fused:
             check(h, lib.rls_admm_pre(h, state.x.code, state.x.n, state.beta.ptr, state.beta_y.ptr, state.z[0].ptr,
@@ -968,7 +1044,7 @@ class ADMM(AbstractPrimalDualSolver):
             state.xold.copy_from(state.x)
         if self.precon is not None:   # cg!(...; Pl = precon)   :244
             state.cg_iterations.append(self._cg_precond(state))
-        elif self._all_identity():
+        elif self._all_identity() and not self._op.double:
             rho_sum = float(np.sum(state.rho, dtype=np.float32))
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, rho_sum, self.iterationsCG,
                                       float(state.tolInner)), "rls_cg_solve")
@@ -2268,7 +2344,7 @@ def solve_(solver: AbstractLinearSolver, b, callbacks=None, **kw):
         cbs = list(callbacks)
     no_group = kw.pop("_no_group", False)
     if (not cbs and not kw and not no_group and isinstance(solver, CGNR) and isinstance(solver.state, CGNRState) and
-            isinstance(b, DeviceVector) and isinstance(solver._op, OperatorHandle) and solver.A is not None and
+            isinstance(b, DeviceVector) and isinstance(solver._op, OperatorHandle) and solver.A is not None and not solver._op.double and
             solver._op.M * solver._op.N * b.dtype.itemsize <= 128 * 1024):
         # a system small enough for ONE CU: init! and every iteration as one launch (a group of one; the same bits as init_ + steps)
         return solve_group_([solver], [b])[0]
@@ -2311,6 +2387,12 @@ def createLinearSolver(solver_type, A=None, *, kwargWarning: bool = True, **kwar
     """createLinearSolver(T, A; kwargs...) / createLinearSolver(T; AHA, kwargs...)  :288-294"""
     if not (isinstance(solver_type, type) and issubclass(solver_type, AbstractLinearSolver)):
         raise TypeError("solver must be an AbstractLinearSolver type")
+    src = A if A is not None else kwargs.get("AHA")
+    src = getattr(src, "A", src)   # (a NormalOperator carries its A)
+    if src is not None and getattr(src, "dtype", None) in (np.dtype(np.float64), np.dtype(np.complex128)) and \
+            solver_type not in (CGNR, FISTA, ADMM):
+        raise TypeError(f"{solver_type.__name__} on a {src.dtype} operator: Float64 / ComplexF64 run the reference's loops of CGNR, FISTA and ADMM "
+                        "on the double-precision primitives (rls_*_d); the other solvers' device sequences are Float32 / ComplexF32")
     return solver_type(A, **_filter_kwargs(solver_type, kwargWarning, kwargs))
 
 

@@ -762,7 +762,9 @@ def test_errors_are_loud(rls, ctx):
     with pytest.raises(ValueError, match="DimensionMismatch"):
         rls.solve_(rls.CGNR(Ad), rls.DeviceVector.from_host(b[:5]))
     with pytest.raises(TypeError):
-        rls.DeviceVector.from_host(np.zeros(4, np.float64))
+        rls.DeviceVector.from_host(np.zeros(4, np.float16))   # (Float64 / ComplexF64 are element types since round 6: tests/test_gpu_float64.py)
+    with pytest.raises(TypeError, match="Float64 / ComplexF64"):   # ... of the L1 protocol: the solvers beyond CGNR / FISTA / ADMM say so
+        rls.createLinearSolver(rls.POGM, rls.DeviceMatrix.from_host(A.astype(np.float64)), iterations=3)
     with pytest.raises(rls.RLSError):
         rls.prox_(rls.L21Regularization, rls.DeviceVector.from_host(np.ones(4, np.float32)), 0.1, slices=9)
 

@@ -71,8 +71,10 @@ def test_dtype_guard(rls):
     from rls_amd.arrays import dtype_code
 
     assert dtype_code(np.float32) == 0 and dtype_code(np.complex64) == 1
-    with pytest.raises(TypeError, match="Float32 / ComplexF32"):
-        dtype_code(np.float64)
+    assert dtype_code(np.float64) == 2 and dtype_code(np.complex128) == 3   # round 6: the L1 protocol with double scalars (rls_*_d)
+    for bad in (np.float16, np.int32, np.complex256 if hasattr(np, "complex256") else np.int8):
+        with pytest.raises(TypeError, match="Float32 / ComplexF32"):
+            dtype_code(bad)
 
 
 def test_bench_launches_its_own_ranks():

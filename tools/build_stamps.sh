@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../regularizedleastsquares.jl_amd/csrc"
 B=$(mktemp -d)
-for f in api comm gemv normal gramk small skinny setup kaczmarz blas1 prox pgm svt tv nested solvers; do
+for f in api comm f64 gemv normal gramk small skinny setup kaczmarz blas1 prox pgm svt tv nested solvers; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -Wno-unused-value -ffp-contract=fast -fno-slp-vectorize -DRLS_STAMPS -c $f.hip -o $B/$f.o &
 done
 wait
