@@ -158,6 +158,15 @@ int32_t rls_prox_real_d(rls_ctx* ctx, int32_t dtype, int64_t n, void* x);       
 int32_t rls_prox_tv_fgp_d(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int64_t* shape, int32_t ntv, const int32_t* dims, void* x,
                           double lambda, int32_t iterations);
 
+/* the row-action solver in double precision: transpose(A) (the row-access layout of src/Kaczmarz.jl:391), rownorm² (src/Utils.jl:20-23,
+ * device output), diag(w) A, and the sweep of rls_kaczmarz_sweep with double denominators (src/Kaczmarz.jl:283-308) */
+int32_t rls_transpose_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* At, int64_t ldat);
+int32_t rls_rownorm2_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, double* out_d);
+int32_t rls_scale_rows_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* w, const void* A, int64_t lda, void* B, int64_t ldb);
+int32_t rls_kaczmarz_sweep_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* At, int64_t ldat, int32_t nrhs, void* X,
+                             int64_t ldx, const void* U, int64_t ldu, void* VL, int64_t ldvl, const int32_t* rows_d, const double* denom_d,
+                             int32_t nused, double eps_w, int32_t n_sweeps);
+
 int32_t rls_prox_l1(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, float lambda);        /* src/proximalMaps/ProxL1.jl:18-22 */
 int32_t rls_prox_l2(rls_ctx* ctx, int32_t dtype, int64_t n, void* x, float lambda);        /* src/proximalMaps/ProxL2.jl:18-21 */
 int32_t rls_prox_l21(rls_ctx* ctx, int32_t dtype, int64_t n, int64_t slices, void* x, float lambda); /* ProxL21.jl:30-35; ext/..GPUArraysExt/ProxL21.jl:1-12 */

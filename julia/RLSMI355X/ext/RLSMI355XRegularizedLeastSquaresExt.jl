@@ -633,8 +633,13 @@ end
 function normalize(::SystemMatrixBasedNormalization, A::RLSMatrix{T}, b) where {T}
   M, N = size(A)
   e = RLSVector{real(T)}(undef, M; ctx = A.ctx)
-  check(A.ctx, ccall((:rls_rownorm2, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
-                     A.ctx.handle, dtypecode(T), M, N, A.ptr, M, e.ptr), "rls_rownorm2")
+  if T <: RLSDouble
+    check(A.ctx, ccall((:rls_rownorm2_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                       A.ctx.handle, dtypecode(T), M, N, A.ptr, M, e.ptr), "rls_rownorm2_d")
+  else
+    check(A.ctx, ccall((:rls_rownorm2, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                       A.ctx.handle, dtypecode(T), M, N, A.ptr, M, e.ptr), "rls_rownorm2")
+  end
   return sum(Array(e)) / N   # norm(sqrt.(rownorm²))^2 / N
 end
 
@@ -648,8 +653,13 @@ function kaczmarz_aux_for(solver::Kaczmarz, state::KaczmarzState{T,<:RLSVector})
     A = solver.A::RLSMatrix{T}
     M, N = size(A)
     At = RLSVector{T}(undef, M * N; ctx = A.ctx)     # transpose(A), N x M column-major
-    check(A.ctx, ccall((:rls_transpose, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
-                       A.ctx.handle, dtypecode(T), M, N, A.ptr, M, At.ptr, N), "rls_transpose")
+    if T <: RLSDouble   # Float64 / ComplexF64: the same sweep on the double-precision entry points
+      check(A.ctx, ccall((:rls_transpose_d, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+                         A.ctx.handle, dtypecode(T), M, N, A.ptr, M, At.ptr, N), "rls_transpose_d")
+    else
+      check(A.ctx, ccall((:rls_transpose, librls[]), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+                         A.ctx.handle, dtypecode(T), M, N, A.ptr, M, At.ptr, N), "rls_transpose")
+    end
     (At = At, rows = Ref{Any}(nothing), den = Ref{Any}(nothing), key = Ref{Any}(nothing))
   end
 end
@@ -664,16 +674,24 @@ function iterate(solver::Kaczmarz, state::KaczmarzState{T,<:RLSVector}) where {T
   key = (objectid(solver.denom), copy(state.usedIndices))
   if aux.key[] != key   # upload the processing order: 0-based rows and their denominators
     aux.rows[] = RLSVector(collect(reinterpret(Float32, Int32.(solver.rowindex[state.usedIndices] .- 1))); ctx = state.x.ctx)  # a Vector: 0-based Int32 row numbers, bit-cast
-    aux.den[] = RLSVector(Float32.(solver.denom[state.usedIndices]); ctx = state.x.ctx)
+    aux.den[] = RLSVector(real(T).(solver.denom[state.usedIndices]); ctx = state.x.ctx)
     aux.key[] = key
   end
   A = solver.A::RLSMatrix{T}
   M, N = size(A)
-  check(A.ctx, ccall((:rls_kaczmarz_sweep, librls[]), Int32,
-                     (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64,
-                      Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Int32),
-                     A.ctx.handle, dtypecode(T), M, N, aux.At.ptr, N, 1, state.x.ptr, N, state.u.ptr, M, state.vl.ptr, M,
-                     aux.rows[].ptr, aux.den[].ptr, length(state.usedIndices), Float32(real(state.ɛw)), 1), "rls_kaczmarz_sweep")
+  if T <: RLSDouble
+    check(A.ctx, ccall((:rls_kaczmarz_sweep_d, librls[]), Int32,
+                       (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64,
+                        Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64, Int32),
+                       A.ctx.handle, dtypecode(T), M, N, aux.At.ptr, N, 1, state.x.ptr, N, state.u.ptr, M, state.vl.ptr, M,
+                       aux.rows[].ptr, aux.den[].ptr, length(state.usedIndices), Float64(real(state.ɛw)), 1), "rls_kaczmarz_sweep_d")
+  else
+    check(A.ctx, ccall((:rls_kaczmarz_sweep, librls[]), Int32,
+                       (Ptr{Cvoid}, Int32, Int64, Int64, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64,
+                        Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Int32),
+                       A.ctx.handle, dtypecode(T), M, N, aux.At.ptr, N, 1, state.x.ptr, N, state.u.ptr, M, state.vl.ptr, M,
+                       aux.rows[].ptr, aux.den[].ptr, length(state.usedIndices), Float32(real(state.ɛw)), 1), "rls_kaczmarz_sweep")
+  end
   for r in solver.reg
     prox!(r, state.x)
   end

@@ -105,6 +105,10 @@ PROTOTYPES = {
     "rls_prox_positive_d": (_i32, [_vp, _i32, _i64, _vp]),
     "rls_prox_real_d": (_i32, [_vp, _i32, _i64, _vp]),
     "rls_prox_tv_fgp_d": (_i32, [_vp, _i32, _i32, _pi64, _i32, _pi32, _vp, _d, _i32]),
+    "rls_transpose_d": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _i64]),
+    "rls_rownorm2_d": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _vp]),
+    "rls_scale_rows_d": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
+    "rls_kaczmarz_sweep_d": (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _d, _i32]),
     "rls_prox_l1": (_i32, [_vp, _i32, _i64, _vp, _f]),
     "rls_prox_l2": (_i32, [_vp, _i32, _i64, _vp, _f]),
     "rls_prox_l21": (_i32, [_vp, _i32, _i64, _i64, _vp, _f]),

@@ -355,8 +355,12 @@ class DeviceMatrix:
 
     def rownorm2(self) -> "DeviceVector":
         """rownorm²(A, m) for every row m (src/Utils.jl:20-23; GPU ext NormalizedRegularization.jl:1-5): real vector"""
-        out = DeviceVector(self.M, np.float32, self.ctx)
         lib, h = self.ctx.lib, self.ctx.handle
+        if is_double(self.code):
+            out = DeviceVector(self.M, np.float64, self.ctx)
+            check(h, lib.rls_rownorm2_d(h, self.code, self.M, self.N, self.ptr, self.lda, out.ptr), "rls_rownorm2_d")
+            return out
+        out = DeviceVector(self.M, np.float32, self.ctx)
         check(h, lib.rls_rownorm2(h, self.code, self.M, self.N, self.ptr, self.lda, out.ptr), "rls_rownorm2")
         return out
 
@@ -366,7 +370,8 @@ class DeviceMatrix:
             raise ValueError("scale_rows: weights must have length size(A, 1) and the element type of A")
         B = DeviceMatrix(self.M, self.N, self.dtype, self.ctx)
         lib, h = self.ctx.lib, self.ctx.handle
-        check(h, lib.rls_scale_rows(h, self.code, self.M, self.N, w.ptr, self.ptr, self.lda, B.ptr, B.lda), "rls_scale_rows")
+        fn = lib.rls_scale_rows_d if is_double(self.code) else lib.rls_scale_rows
+        check(h, fn(h, self.code, self.M, self.N, w.ptr, self.ptr, self.lda, B.ptr, B.lda), "rls_scale_rows")
         return B
 
     def normal_operator(self) -> "NormalOperator":

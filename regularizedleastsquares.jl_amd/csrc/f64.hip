@@ -5,7 +5,8 @@
 // Float32 / ComplexF32, so these are plain coalesced kernels with Float64 fixed-order reductions: a double-precision caller gets the
 // reference's arithmetic and its own loops (src/CGNR.jl:143-178 etc. on the primitives), not the fused fast paths.
 // Entry points: rls_fill_d, rls_scal_d, rls_axpy_d, rls_lincomb_d, rls_nrm2_d, rls_dotc_d, rls_asum_d, rls_gemv_d,
-// rls_prox_l1_d / _l2_d / _l21_d / _positive_d / _real_d, rls_prox_tv_fgp_d.
+// rls_prox_l1_d / _l2_d / _l21_d / _positive_d / _real_d, rls_prox_tv_fgp_d; rls_transpose_d, rls_rownorm2_d, rls_scale_rows_d,
+// rls_kaczmarz_sweep_d (the row-action solver's setup and sweep).
 #include "rls_common.hpp"
 
 namespace {
@@ -263,6 +264,99 @@ __global__ void d_tv_dual_kernel(D* rs_pq, const D* xtmp, const D* pq_old, D* rs
   }
 }
 
+// ---- Kaczmarz in double precision (src/Kaczmarz.jl:283-308): one workgroup per right-hand side walks the rows in order; every thread
+// owns the x entries tid, tid + 1024, ... (read and written by it alone), the rows come from transpose(A) (contiguous), and the only
+// synchronisation of a row step is one workgroup barrier for tau = dot_with_matrix_row (src/Utils.jl:55-88, no conjugation)
+template <typename D>
+__global__ __launch_bounds__(1024) void d_kaczmarz_kernel(const D* __restrict__ At, int64_t ldat, D* X, int64_t ldx, const D* __restrict__ U,
+                                                          int64_t ldu, D* VL, int64_t ldvl, const int32_t* __restrict__ rows,
+                                                          const double* __restrict__ den, int nused, int n_sweeps, double eps_w, int64_t N) {
+  __shared__ double red[2][16][2];
+  __shared__ double scal[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  D* x = X + (int64_t)blockIdx.x * ldx;
+  const D* u = U + (int64_t)blockIdx.x * ldu;
+  D* vl = VL + (int64_t)blockIdx.x * ldvl;
+  int64_t j = 0;
+  for (int sw = 0; sw < n_sweeps; ++sw) {
+    for (int k = 0; k < nused; ++k, ++j) {
+      const int row = rows[k];
+      const D* ar = At + (int64_t)row * ldat;
+      double pr = 0.0, pi = 0.0;
+      for (int64_t i = tid; i < N; i += 1024) {
+        const D p = del<D>::mul(ar[i], x[i]);
+        pr += del<D>::re(p);
+        pi += del<D>::im(p);
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        pr += __shfl_xor(pr, off);
+        pi += __shfl_xor(pi, off);
+      }
+      const int par = (int)(j & 1);
+      if (lane == 0) {
+        red[par][w][0] = pr;
+        red[par][w][1] = pi;
+      }
+      if (tid == 0) {  // vl[row] is written by thread 0 alone: the others take u, vl from LDS, never from memory
+        scal[par][0] = del<D>::re(u[row]);
+        scal[par][1] = del<D>::im(u[row]);
+        scal[par][2] = del<D>::re(vl[row]);
+        scal[par][3] = del<D>::im(vl[row]);
+      }
+      __syncthreads();  // the one barrier of a row step (the slots alternate)
+      double tr = 0.0, ti = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 16; ++ww) {
+        tr += red[par][ww][0];
+        ti += red[par][ww][1];
+      }
+      const double dn = den[k];
+      const double are = dn * ((scal[par][0] - tr) - eps_w * scal[par][2]);   // alpha = denom (u[row] - tau - eps_w vl[row])   :305
+      const double aim = dn * ((scal[par][1] - ti) - eps_w * scal[par][3]);
+      const D alpha = del<D>::make(are, aim);
+      for (int64_t i = tid; i < N; i += 1024) x[i] = del<D>::add(x[i], del<D>::mulc(ar[i], alpha));  // x += alpha conj(A[row, :])   :306
+      if (tid == 0) vl[row] = del<D>::make(scal[par][2] + are * eps_w, scal[par][3] + aim * eps_w);      // vl[row] += alpha eps_w      :307
+    }
+  }
+}
+
+template <typename D>
+__global__ __launch_bounds__(256) void d_transpose_kernel(const D* __restrict__ A, int64_t lda, D* __restrict__ At, int64_t ldat, int64_t M,
+                                                          int64_t N) {
+  __shared__ D tile[32][33];
+  const int64_t m0 = (int64_t)blockIdx.x * 32, n0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t m = m0 + tx, n = n0 + r;
+    if (m < M && n < N) tile[r][tx] = A[n * lda + m];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t n = n0 + tx, m = m0 + r;
+    if (m < M && n < N) At[m * ldat + n] = tile[tx][r];
+  }
+}
+
+// rownorm²(A, m) = sum_n |A[m, n]|² (src/Utils.jl:20-23): a thread per row, the columns in order
+template <typename D>
+__global__ void d_rownorm2_kernel(const D* __restrict__ A, int64_t lda, int64_t M, int64_t N, double* __restrict__ out) {
+  DSTRIDE(m, M) {
+    double s = 0.0;
+    for (int64_t n = 0; n < N; ++n) s += del<D>::abs2(A[n * lda + m]);
+    out[m] = s;
+  }
+}
+
+// B = diag(w) A (ProdOp(WeightingOp(w), A) materialised)
+template <typename D>
+__global__ void d_scale_rows_kernel(const D* __restrict__ w, const D* __restrict__ A, int64_t lda, D* __restrict__ B, int64_t ldb, int64_t M,
+                                    int64_t N) {
+  DSTRIDE(i, M * N) {
+    const int64_t m = i % M, n = i / M;
+    B[n * ldb + m] = del<D>::mul(w[m], A[n * lda + m]);
+  }
+}
+
 static int32_t d_status(rls_ctx* ctx) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return rls_fail(ctx, (int32_t)e, hipGetErrorString(e));
@@ -489,6 +583,51 @@ int32_t rls_prox_tv_fgp_d(rls_ctx* ctx, int32_t dtype, int32_t ndims, const int6
   RLS_HIP(ctx, rls_enter(ctx));
   if (dtype == RLS_F64) return d_fgp<double>(ctx, G, (double*)x, lambda, iterations);
   return d_fgp<double2>(ctx, G, (double2*)x, lambda, iterations);
+}
+
+int32_t rls_transpose_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, void* At, int64_t ldat) {
+  RLS_CHECK_CTX(ctx);
+  if (!d_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !At || lda < M || ldat < N) return rls_fail(ctx, RLS_E_INVALID, "transpose_d: bad argument");
+  RLS_HIP(ctx, rls_enter(ctx));
+  const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
+  if (dtype == RLS_F64) hipLaunchKernelGGL(d_transpose_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double*)A, lda, (double*)At, ldat, M, N);
+  else hipLaunchKernelGGL(d_transpose_kernel<double2>, grid, dim3(256), 0, ctx->stream, (const double2*)A, lda, (double2*)At, ldat, M, N);
+  return d_status(ctx);
+}
+int32_t rls_rownorm2_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* A, int64_t lda, double* out_d) {
+  RLS_CHECK_CTX(ctx);
+  if (!d_dtype_ok(dtype) || M <= 0 || N <= 0 || !A || !out_d || lda < M) return rls_fail(ctx, RLS_E_INVALID, "rownorm2_d: bad argument");
+  RLS_HIP(ctx, rls_enter(ctx));
+  if (dtype == RLS_F64) hipLaunchKernelGGL(d_rownorm2_kernel<double>, dim3(dgrid(M)), dim3(DT), 0, ctx->stream, (const double*)A, lda, M, N, out_d);
+  else hipLaunchKernelGGL(d_rownorm2_kernel<double2>, dim3(dgrid(M)), dim3(DT), 0, ctx->stream, (const double2*)A, lda, M, N, out_d);
+  return d_status(ctx);
+}
+int32_t rls_scale_rows_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* w, const void* A, int64_t lda, void* B, int64_t ldb) {
+  RLS_CHECK_CTX(ctx);
+  if (!d_dtype_ok(dtype) || M <= 0 || N <= 0 || !w || !A || !B || lda < M || ldb < M) return rls_fail(ctx, RLS_E_INVALID, "scale_rows_d: bad argument");
+  RLS_HIP(ctx, rls_enter(ctx));
+  if (dtype == RLS_F64)
+    hipLaunchKernelGGL(d_scale_rows_kernel<double>, dim3(dgrid(M * N)), dim3(DT), 0, ctx->stream, (const double*)w, (const double*)A, lda, (double*)B, ldb, M, N);
+  else
+    hipLaunchKernelGGL(d_scale_rows_kernel<double2>, dim3(dgrid(M * N)), dim3(DT), 0, ctx->stream, (const double2*)w, (const double2*)A, lda, (double2*)B, ldb, M, N);
+  return d_status(ctx);
+}
+int32_t rls_kaczmarz_sweep_d(rls_ctx* ctx, int32_t dtype, int64_t M, int64_t N, const void* At, int64_t ldat, int32_t nrhs, void* X,
+                             int64_t ldx, const void* U, int64_t ldu, void* VL, int64_t ldvl, const int32_t* rows_d, const double* denom_d,
+                             int32_t nused, double eps_w, int32_t n_sweeps) {
+  RLS_CHECK_CTX(ctx);
+  if (!d_dtype_ok(dtype) || M <= 0 || N <= 0 || !At || !X || !U || !VL || nrhs < 1 || ldat < N || ldx < N || ldu < M || ldvl < M || nused < 0 ||
+      n_sweeps < 0 || (nused > 0 && (!rows_d || !denom_d)))
+    return rls_fail(ctx, RLS_E_INVALID, "kaczmarz_sweep_d: bad argument");
+  if (nused == 0 || n_sweeps == 0) return 0;
+  RLS_HIP(ctx, rls_enter(ctx));
+  if (dtype == RLS_F64)
+    hipLaunchKernelGGL(d_kaczmarz_kernel<double>, dim3((unsigned)nrhs), dim3(1024), 0, ctx->stream, (const double*)At, ldat, (double*)X, ldx,
+                       (const double*)U, ldu, (double*)VL, ldvl, rows_d, denom_d, nused, n_sweeps, eps_w, N);
+  else
+    hipLaunchKernelGGL(d_kaczmarz_kernel<double2>, dim3((unsigned)nrhs), dim3(1024), 0, ctx->stream, (const double2*)At, ldat, (double2*)X, ldx,
+                       (const double2*)U, ldu, (double2*)VL, ldvl, rows_d, denom_d, nused, n_sweeps, eps_w, N);
+  return d_status(ctx);
 }
 
 }  // extern "C"

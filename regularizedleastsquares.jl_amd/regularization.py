@@ -58,7 +58,8 @@ class L2Regularization(AbstractParameterizedRegularization):
     def __init__(self, lam, **_kw):
         import numpy as _np
         if _np.ndim(lam) == 1:
-            self.lam_vector = _np.asarray(lam, dtype=_np.float32)
+            given = _np.asarray(lam)   # (a Float64 vector keeps its precision for a Float64 operator; the solver casts to its own real type)
+            self.lam_vector = given.astype(_np.float64 if given.dtype == _np.float64 else _np.float32)
             self.lam = float("nan")
         else:
             self.lam_vector = None

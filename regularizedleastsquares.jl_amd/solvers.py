@@ -22,13 +22,23 @@ from . import _lib
 from ._lib import (PROJ_NONE, PROJ_POSITIVE, PROJ_REAL, REG_L1, REG_L2, REG_L21, REG_NONE, REG_TV, AdmmParams,
                    AdmmStatus, CgnrStatus, CgStatus,
                    FistaStatus, check)
-from .arrays import DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle
+from .arrays import DeviceMatrix, DeviceVector, NormalOperator, OperatorHandle, is_double
 from .regularization import (AbstractParameterizedRegularization, AbstractProjectionRegularization, GradientOp,
                              L1Regularization, L2Regularization, findsink, findsinks, is_projection, sink,
                              L21Regularization, MeasurementBasedNormalization, NoNormalization, PositiveRegularization,
                              RealRegularization, SystemMatrixBasedNormalization, TVRegularization, normalize)
 
 _EPS32 = float(np.finfo(np.float32).eps)
+
+
+def _eps_of(op, tol=None):
+    """a tolerance keyword's default: eps(real(eltype(AHA))) (src/CGNR.jl:45, src/FISTA.jl:62, src/ADMM.jl:97-98, ...)"""
+    return float(np.finfo(_rt_of(op)).eps) if tol is None else tol
+
+
+def _rt_of(op):
+    """the scalars' type follows the element type (rT = real(eltype) in the reference's solver structs)"""
+    return np.float64 if getattr(op, "double", False) else np.float32
 
 
 # --------------------------------------------------------------------------------------------
@@ -180,7 +190,7 @@ class CGNRState(AbstractSolverState):
 class CGNR(AbstractKrylovSolver):
     """src/CGNR.jl:48-89"""
 
-    def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 10, relTol=_EPS32):
+    def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 10, relTol=None):
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         regs = normalize(normalizeReg, _as_list(reg), self.A, None)
@@ -193,7 +203,7 @@ class CGNR(AbstractKrylovSolver):
             raise ValueError(f"CGNR does not allow for more additional regularization terms, found {len(rest)}")
         self.normalizeReg = normalizeReg or NoNormalization()
         self.iterations = int(iterations)
-        self.state = CGNRState(relTol)
+        self.state = CGNRState(_eps_of(self._op, relTol))
 
     def _new_state(self):
         st = self.state
@@ -504,7 +514,7 @@ class FISTA(AbstractProximalGradientSolver):
     explicitly for reproducible runs (the reference's default depends on the global RNG)."""
 
     def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 50, verbose: bool = False,
-                 rho=None, theta=1, relTol=_EPS32, restart: str = "none"):
+                 rho=None, theta=1, relTol=None, restart: str = "none"):
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         regs = _as_list(reg) or [L1Regularization(0.0)]
@@ -527,7 +537,7 @@ class FISTA(AbstractProximalGradientSolver):
                 v = v + 1j * rng.standard_normal(n)
             start = DeviceVector.from_host(v.astype(self._op.dtype), self._op.ctx)
             rho = 0.95 / power_iterations(_NormalApply(self._op), start)
-        self.state = FISTAState(rho, theta, relTol)
+        self.state = FISTAState(rho, theta, _eps_of(self._op, relTol))
 
     def _fused_kinds(self):
         """(reg_kind, lambda, slices, proj_kind) when the update is fusable, else None"""
@@ -766,7 +776,7 @@ class ADMM(AbstractPrimalDualSolver):
     """src/ADMM.jl:80-162"""
 
     def __init__(self, A=None, *, AHA=None, precon=None, reg=None, regTrafo=None, normalizeReg=None, rho=1e-1,
-                 vary_rho: str = "none", iterations: int = 10, iterationsCG: int = 10, absTol=_EPS32, relTol=_EPS32,
+                 vary_rho: str = "none", iterations: int = 10, iterationsCG: int = 10, absTol=None, relTol=None,
                  tolInner=1e-5, verbose: bool = False):
         if precon is not None and not hasattr(precon, "ldiv_"):
             raise TypeError("precon: an object with ldiv_(out, r) on device vectors (e.g. DiagonalPreconditioner), or None = Identity()")
@@ -791,7 +801,7 @@ class ADMM(AbstractPrimalDualSolver):
         self.normalizeReg = normalizeReg or NoNormalization()
         self._track_cg = True  # record the inner CG iteration counts (one extra host read-back per outer iteration)
         self.use_device_plan = True  # whole outer iterations through rls_admm_step when the regulariser allows
-        self.state = ADMMState(len(self.reg), self.rho, absTol, relTol, tolInner)
+        self.state = ADMMState(len(self.reg), self.rho, _eps_of(self._op, absTol), _eps_of(self._op, relTol), tolInner)
 
     def _new_state(self):
         s = self.state.states[0] if isinstance(self.state, AbstractMatrixSolverState) else self.state
@@ -1145,10 +1155,10 @@ def _default_rho(op):
     """0.95 / power_iterations(AHA) with a NumPy-seeded start vector (the reference uses Julia's global RNG)"""
     n = op.N
     rng = np.random.default_rng()
-    v = rng.standard_normal(n).astype(np.float32)
+    v = rng.standard_normal(n)
     if op.dtype.kind == "c":
-        v = (v + 1j * rng.standard_normal(n)).astype(np.complex64)
-    return 0.95 / power_iterations(_NormalApply(op), DeviceVector.from_host(v, op.ctx))
+        v = v + 1j * rng.standard_normal(n)
+    return 0.95 / power_iterations(_NormalApply(op), DeviceVector.from_host(v.astype(op.dtype), op.ctx))
 
 
 def _split_regs(regs, name):
@@ -1206,7 +1216,7 @@ class OptISTA(AbstractProximalGradientSolver):
     """src/OptISTA.jl:61-110 (ctor), :129-160 (init!), :169-209 (iterate)"""
 
     def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 50, verbose: bool = False,
-                 rho=None, theta=1, relTol=_EPS32):
+                 rho=None, theta=1, relTol=None):
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         self.reg, self.proj = _split_regs(reg, "OptISTA")
@@ -1214,7 +1224,7 @@ class OptISTA(AbstractProximalGradientSolver):
         self.normalizeReg = normalizeReg or NoNormalization()
         self.verbose = bool(verbose)
         self.iterations = int(iterations)
-        self.state = _ProxGradState(_default_rho(self._op) if rho is None else rho, theta, relTol,
+        self.state = _ProxGradState(_default_rho(self._op) if rho is None else rho, theta, _eps_of(self._op, relTol),
                                     ("x", "x0", "y", "z", "zold", "res"))
 
     def _new_state(self):
@@ -1222,7 +1232,7 @@ class OptISTA(AbstractProximalGradientSolver):
         return _ProxGradState(s.rho, 1.0, s.relTol, s._names)
 
     def init_(self, st, b: DeviceVector, x0=0, theta=1):
-        f32 = np.float32
+        f32 = _rt_of(self._op)
         st._alloc(b, self._op.N)
         if self.A is None:
             st.x0.copy_from(b)
@@ -1247,7 +1257,7 @@ class OptISTA(AbstractProximalGradientSolver):
 
     def _coefficients(self, st):
         """the index-only scalars of one iteration (src/OptISTA.jl:170-175,196-204), advancing theta"""
-        f32 = np.float32
+        f32 = _rt_of(self._op)
         th, tn, rho = f32(st.theta), f32(st.theta_n), f32(st.rho)
         gamma = f32(2) * th / (tn * tn) * (tn * tn - f32(2) * th * th + th)
         st.thetaold = float(th)
@@ -1260,7 +1270,7 @@ class OptISTA(AbstractProximalGradientSolver):
         return rho, gamma, alpha, beta
 
     def _update_args(self, st, fus, rho, gamma, alpha, beta):
-        f32 = np.float32
+        f32 = _rt_of(self._op)
         return (st.x.ctx.handle, st.x.code, st.x.n, st.res.ptr, st.x0.ptr, st.x.ptr, st.y.ptr, st.z.ptr, st.zold.ptr,
                 float(rho * gamma), fus[0], float(rho * gamma * f32(self.reg.lam)), float(f32(-1) / gamma),
                 float(f32(1) / gamma), float(-beta), float(f32(1) + alpha + beta), float(-alpha))
@@ -1269,9 +1279,9 @@ class OptISTA(AbstractProximalGradientSolver):
         st = st or self.state
         if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
             return None
-        f32 = np.float32
+        f32 = _rt_of(self._op)
         rho, gamma, alpha, beta = self._coefficients(st)
-        fus = _fusable_kinds(self.reg, [])
+        fus = None if self._op.double else _fusable_kinds(self.reg, [])
         if fus is not None:  # one launch for everything after the operator apply (rls_optista_update)
             _NormalApply(self._op).mul_(st.res, st.x)
             ctx = st.x.ctx
@@ -1302,7 +1312,7 @@ class OptISTA(AbstractProximalGradientSolver):
     def _run(self, st):
         """no callbacks: every remaining iteration is enqueued at once (the coefficients depend on the index only);
         `rel_res_norm < relTol` is evaluated on the device, later launches are no-ops, ONE read-back at the end"""
-        fus = _fusable_kinds(self.reg, [])
+        fus = None if self._op.double else _fusable_kinds(self.reg, [])
         if fus is None or self.verbose or not isinstance(self._op, OperatorHandle) or st.rel_res_norm < st.relTol:
             while self.iterate(st) is not None:
                 pass
@@ -1443,7 +1453,7 @@ class POGM(AbstractProximalGradientSolver):
     by init! (reference behaviour)."""
 
     def __init__(self, A=None, *, AHA=None, reg=None, normalizeReg=None, iterations: int = 50, verbose: bool = False,
-                 rho=None, theta=1, sigma_fac=1, relTol=_EPS32, restart: str = "none"):
+                 rho=None, theta=1, sigma_fac=1, relTol=None, restart: str = "none"):
         self.A, self._op = _resolve_operator(A, AHA)
         self.AHA = AHA if AHA is not None else self.A.normal_operator()
         self.reg, self.proj = _split_regs(reg, "POGM")
@@ -1454,7 +1464,7 @@ class POGM(AbstractProximalGradientSolver):
         self.restart = restart
         self.verbose = bool(verbose)
         self.iterations = int(iterations)
-        self.state = _ProxGradState(_default_rho(self._op) if rho is None else rho, theta, relTol,
+        self.state = _ProxGradState(_default_rho(self._op) if rho is None else rho, theta, _eps_of(self._op, relTol),
                                     ("x", "x0", "xold", "y", "z", "w", "res"))
         self.state.gamma = 1.0
         self.state.sigma = 1.0
@@ -1490,9 +1500,9 @@ class POGM(AbstractProximalGradientSolver):
         st = st or self.state
         if st.rel_res_norm < st.relTol or st.iteration >= self.iterations:
             return None
-        f32 = np.float32
+        f32 = _rt_of(self._op)
         rho = f32(st.rho)
-        fus = _fusable_kinds(self.reg, self.proj)
+        fus = None if self._op.double else _fusable_kinds(self.reg, self.proj)
         if fus is None:
             st.xold.copy_from(st.x)
             _NormalApply(self._op).mul_(st.res, st.x)
@@ -1569,12 +1579,12 @@ class POGM(AbstractProximalGradientSolver):
     def _run(self, st):
         """restart = :none without callbacks: all remaining iterations enqueued at once (index-only coefficients),
         the stopping test on the device, ONE read-back at the end; otherwise iteration by iteration"""
-        fus = _fusable_kinds(self.reg, self.proj)
+        fus = None if self._op.double else _fusable_kinds(self.reg, self.proj)
         if (fus is None or self.verbose or not isinstance(self._op, OperatorHandle) or st.rel_res_norm < st.relTol):
             while self.iterate(st) is not None:
                 pass
             return
-        f32 = np.float32
+        f32 = _rt_of(self._op)
         ctx = st.x.ctx
         lib, h = ctx.lib, ctx.handle
         if self.restart == "gradient":
@@ -1681,7 +1691,7 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
     Bregman update every `iterationsInner` inner iterations."""
 
     def __init__(self, A=None, *, AHA=None, precon=None, reg=None, regTrafo=None, normalizeReg=None, rho=1e-1,
-                 iterations: int = 10, iterationsInner: int = 10, iterationsCG: int = 10, absTol=_EPS32, relTol=_EPS32,
+                 iterations: int = 10, iterationsInner: int = 10, iterationsCG: int = 10, absTol=None, relTol=None,
                  tolInner=1e-5, verbose: bool = False):
         super().__init__(A, AHA=AHA, precon=precon, reg=reg, regTrafo=regTrafo, normalizeReg=normalizeReg, rho=rho,
                          iterations=iterations, iterationsCG=iterationsCG, absTol=absTol, relTol=relTol,
@@ -1751,9 +1761,9 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
         if state._plan_ok:
             self._plan_block(state, 1)
             return state.x, state
-        f32 = np.float32
+        f32 = _rt_of(self._op)
         lib, h = state.x.ctx.lib, state.x.ctx.handle
-        fused = self._all_identity() and len(self.reg) == 1
+        fused = self._all_identity() and len(self.reg) == 1 and not self._op.double
         if fused:  # beta = beta_y + rho (z - u) in one launch (the same elementwise step as ADMM's)
             check(h, lib.rls_admm_pre(h, state.x.code, state.x.n, state.beta.ptr, state.beta_y.ptr, state.z[0].ptr,
                                       state.u[0].ptr, state.x.ptr, state.xold.ptr, float(state.rho[0]), 0), "rls_admm_pre")
@@ -1764,7 +1774,7 @@ class SplitBregman(ADMM):  # AbstractPrimalDualSolver through ADMM
                 t.mul_adj_(state.beta, state.u[i], -float(state.rho[i]), 1.0)
         if self.precon is not None:   # cg!(...; Pl = precon)   src/SplitBregman.jl:218
             self._cg_precond(state)
-        elif self._all_identity():
+        elif self._all_identity() and not self._op.double:
             check(h, lib.rls_cg_solve(state._cg, state.x.ptr, state.beta.ptr, float(np.sum(state.rho, dtype=np.float32)),
                                       self.iterationsCG, float(state.tolInner)), "rls_cg_solve")
             if _cg_is_resident(lib, state._cg):
@@ -1900,16 +1910,21 @@ class Kaczmarz(AbstractRowActionSolver):
     def _setup_rows(self, lam):
         A, ctx = self.A_in, self.A_in.ctx
         lib, h = ctx.lib, ctx.handle
+        dbl = is_double(A.code)   # Float64 / ComplexF64: the same sweep on the double-precision entry points (rls_*_d)
+        rt = np.float64 if dbl else np.float32
+        self._rt = rt
+        transpose = lib.rls_transpose_d if dbl else lib.rls_transpose
+        scale_rows = lib.rls_scale_rows_d if dbl else lib.rls_scale_rows
         At = DeviceMatrix(A.N, A.M, A.dtype, ctx)
-        check(h, lib.rls_transpose(h, A.code, A.M, A.N, A.ptr, A.lda, At.ptr, At.lda), "rls_transpose")
+        check(h, transpose(h, A.code, A.M, A.N, A.ptr, A.lda, At.ptr, At.lda), "rls_transpose")
         self._lam_vec = None
         if np.ndim(lam) == 1:
             # ||Ax - b||² + ||L x||², L = diag(sqrt(lambda)):  A <- A inv(L), lambda <- 1   (:385-395)
-            self._lam_vec = np.asarray(lam, dtype=np.float32)
-            w = DeviceVector.from_host((np.float32(1) / np.sqrt(self._lam_vec)).astype(A.dtype), ctx)
-            check(h, lib.rls_scale_rows(h, A.code, At.M, At.N, w.ptr, At.ptr, At.lda, At.ptr, At.lda), "rls_scale_rows")
+            self._lam_vec = np.asarray(lam, dtype=rt)
+            w = DeviceVector.from_host((rt(1) / np.sqrt(self._lam_vec)).astype(A.dtype), ctx)
+            check(h, scale_rows(h, A.code, At.M, At.N, w.ptr, At.ptr, At.lda, At.ptr, At.lda), "rls_scale_rows")
             Arow = DeviceMatrix(A.M, A.N, A.dtype, ctx)
-            check(h, lib.rls_transpose(h, A.code, At.M, At.N, At.ptr, At.lda, Arow.ptr, Arow.lda), "rls_transpose")
+            check(h, transpose(h, A.code, At.M, At.N, At.ptr, At.lda, Arow.ptr, Arow.lda), "rls_transpose")
             lam = 1.0
         else:
             Arow = A
@@ -1918,7 +1933,7 @@ class Kaczmarz(AbstractRowActionSolver):
         s2 = Arow.rownorm2().to_host()
         self._s2 = s2
         self.rowindex = np.nonzero(s2 > 0)[0].astype(np.int64)
-        self.denom = (np.float32(1) / (s2[self.rowindex] + np.float32(lam))).astype(np.float32)
+        self.denom = (rt(1) / (s2[self.rowindex] + rt(lam))).astype(rt)
         self.rowIndexCycle = np.arange(len(self.rowindex))
         self.probabilities = (s2[self.rowindex] / s2.sum()).astype(np.float64) if self.randomized else None
 
@@ -1940,7 +1955,7 @@ class Kaczmarz(AbstractRowActionSolver):
             self.reg = normalize(self.normalizeReg, self.reg, A, b if isinstance(b, DeviceVector) else None, in_solver=True)
             if float(self.L2.lam) != lam_prev:  # lambda changed => recompute the denominators (:186-193)
                 self._lam_used = float(self.L2.lam)
-                self.denom = (np.float32(1) / (self._s2[self.rowindex] + np.float32(self._lam_used))).astype(np.float32)
+                self.denom = (self._rt(1) / (self._s2[self.rowindex] + self._rt(self._lam_used))).astype(self._rt)
         self._rng = np.random.default_rng(self.seed) if (self.shuffleRows or self.randomized) else None
         order = self.rowIndexCycle
         if self.shuffleRows and not self.randomized:
@@ -1975,7 +1990,7 @@ class Kaczmarz(AbstractRowActionSolver):
                 col.fill_(0)
         if not self.randomized:
             self._upload_order(st, order)
-        st.eps_w = 1.0 if self._lam_vec is not None else float(np.sqrt(np.float32(self._lam_used)))
+        st.eps_w = 1.0 if self._lam_vec is not None else float(np.sqrt(self._rt(self._lam_used)))
         st.iteration = 0
 
     def _sweep(self, st, n_sweeps):
@@ -1983,9 +1998,9 @@ class Kaczmarz(AbstractRowActionSolver):
         ldx = st.x.lda if st.matrix else A.N
         ldu = st.u.lda if st.matrix else A.M
         ldvl = st.vl.lda if st.matrix else A.M
-        check(ctx.handle, ctx.lib.rls_kaczmarz_sweep(ctx.handle, A.code, A.M, A.N, self.At.ptr, self.At.lda, st.nrhs,
-                                                      st.x.ptr, ldx, st.u.ptr, ldu, st.vl.ptr, ldvl, st._rows.ptr,
-                                                      st._den.ptr, len(st.usedIndices), float(st.eps_w), int(n_sweeps)),
+        sweep = ctx.lib.rls_kaczmarz_sweep_d if is_double(A.code) else ctx.lib.rls_kaczmarz_sweep
+        check(ctx.handle, sweep(ctx.handle, A.code, A.M, A.N, self.At.ptr, self.At.lda, st.nrhs, st.x.ptr, ldx, st.u.ptr, ldu,
+                                st.vl.ptr, ldvl, st._rows.ptr, st._den.ptr, len(st.usedIndices), float(st.eps_w), int(n_sweeps)),
               "rls_kaczmarz_sweep")
 
     def iterate(self, st: Optional[KaczmarzState] = None):
@@ -2014,7 +2029,7 @@ class Kaczmarz(AbstractRowActionSolver):
         """solversolution(solver::Kaczmarz)  :262-265 (Tikhonov matrix: x .* 1 ./ sqrt.(lambda))"""
         if self._lam_vec is None:
             return st.solutions() if st.matrix else st.x
-        w = (np.float32(1) / np.sqrt(self._lam_vec)).astype(st.x.dtype)
+        w = (self._rt(1) / np.sqrt(self._lam_vec)).astype(st.x.dtype)
         cols = st.solutions() if st.matrix else [st.x]
         out = [DeviceVector.from_host(c.to_host() * w, c.ctx) for c in cols]
         return out if st.matrix else out[0]
@@ -2387,12 +2402,6 @@ def createLinearSolver(solver_type, A=None, *, kwargWarning: bool = True, **kwar
     """createLinearSolver(T, A; kwargs...) / createLinearSolver(T; AHA, kwargs...)  :288-294"""
     if not (isinstance(solver_type, type) and issubclass(solver_type, AbstractLinearSolver)):
         raise TypeError("solver must be an AbstractLinearSolver type")
-    src = A if A is not None else kwargs.get("AHA")
-    src = getattr(src, "A", src)   # (a NormalOperator carries its A)
-    if src is not None and getattr(src, "dtype", None) in (np.dtype(np.float64), np.dtype(np.complex128)) and \
-            solver_type not in (CGNR, FISTA, ADMM):
-        raise TypeError(f"{solver_type.__name__} on a {src.dtype} operator: Float64 / ComplexF64 run the reference's loops of CGNR, FISTA and ADMM "
-                        "on the double-precision primitives (rls_*_d); the other solvers' device sequences are Float32 / ComplexF32")
     return solver_type(A, **_filter_kwargs(solver_type, kwargWarning, kwargs))
 
 

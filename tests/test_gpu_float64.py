@@ -1,8 +1,8 @@
 """Float64 / ComplexF64 element types (round 6; the reference runs every solver in Float32 AND Float64, test/testSolvers.jl:242,
 and its prox tests in ComplexF64, test/testProxMaps.jl:47,78,106).  The tuned path (fused plans, resident kernels, matrix cores) is
 Float32 / ComplexF32 by SURVEY 8a; double-precision arrays get the L1 protocol with double scalars (rls_*_d, csrc/f64.hip) and the
-reference's own loops of CGNR, FISTA and ADMM on those primitives.  Bar: 1e-12 against the float64 oracle (the same arithmetic in
-another summation order)."""
+reference's own loops of every solver on those primitives (Kaczmarz: the sweep kernel in double precision).  Bar: 1e-12 against the
+float64 oracle (the same arithmetic in another summation order)."""
 import math
 import os
 import sys
@@ -131,26 +131,77 @@ def test_cgnr_fista_admm_in_double_precision(rls, ctx, dt):
         assert rel(x, ref.x) < 1e-11, rel(x, ref.x)
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_optista_pogm_splitbregman_kaczmarz_in_double_precision(rls, ctx, dt):
+    """the other four solvers of linearSolverList() on a double-precision operator (src/OptISTA.jl:169-209, src/POGM.jl:169-237,
+    src/SplitBregman.jl:204-271, src/Kaczmarz.jl:283-308): iterates against the float64 oracle"""
+    M, N = 384, 160
+    A, xt, b = O.make_problem(M, N, dt, 78)
+    Ad, bd = rls.DeviceMatrix.from_host(A, ctx), rls.DeviceVector.from_host(b, ctx)
+    rho = 0.9 / np.linalg.norm(A, 2) ** 2
+    lam1 = 0.02 * float(np.max(np.abs(A.conj().T @ b)))
+    ref = O.OptISTA(A, reg=O.L1Regularization(lam1), rho=rho, iterations=30, relTol=0.0)
+    O.solve(ref, b)
+    S = rls.createLinearSolver(rls.OptISTA, Ad, reg=rls.L1Regularization(lam1), rho=rho, iterations=30, relTol=0.0)
+    assert rel(rls.solve_(S, bd).to_host(), ref.x) < 1e-12
+    for restart in ("none", "gradient"):
+        for regs in (lambda R: R.L1Regularization(lam1), lambda R: [R.L2Regularization(lam1), R.PositiveRegularization()]):
+            ref = O.POGM(A, reg=regs(O), rho=rho, iterations=30, relTol=0.0, restart=restart)
+            O.solve(ref, b)
+            S = rls.createLinearSolver(rls.POGM, Ad, reg=regs(rls), rho=rho, iterations=30, relTol=0.0, restart=restart)
+            x = rls.solve_(S, bd).to_host()
+            assert x.dtype == np.dtype(dt) and rel(x, ref.x) < 1e-12, (restart, rel(x, ref.x))
+    for regs in (lambda R: R.L1Regularization(0.05), lambda R: R.TVRegularization(0.02, shape=(16, 10))):
+        kw = dict(rho=0.3, iterations=3, iterationsInner=4, iterationsCG=6, tolInner=1e-8, absTol=0.0, relTol=0.0)
+        ref = O.SplitBregman(A, reg=regs(O), **kw)
+        O.solve(ref, b)
+        S = rls.createLinearSolver(rls.SplitBregman, Ad, reg=regs(rls), **kw)
+        x = rls.solve_(S, bd).to_host()
+        assert rel(x, ref.x) < 1e-11, rel(x, ref.x)
+    # Kaczmarz: x and vl after full sweeps; a Tikhonov vector; a matrix right-hand side (one workgroup per column); L1 between sweeps
+    for lam in (0.0, 1e-2):
+        ref = O.Kaczmarz(A, reg=O.L2Regularization(lam), iterations=3)
+        O.solve(ref, b)
+        S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(lam), iterations=3)
+        x = rls.solve_(S, bd).to_host()
+        assert x.dtype == np.dtype(dt) and rel(x, ref.x) < 1e-12, rel(x, ref.x)
+        assert rel(S.state.vl.to_host(), ref.vl) < 1e-11 or lam == 0.0
+    lv = np.linspace(0.5, 2.0, N)
+    ref = O.Kaczmarz(A, reg=O.L2Regularization(lv), iterations=2)
+    S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(lv), iterations=2)
+    assert rel(rls.solve_(S, bd).to_host(), O.solve(ref, b)) < 1e-12
+    ref = O.Kaczmarz(A, reg=[O.L2Regularization(1e-2), O.L1Regularization(1e-3)], iterations=3)
+    S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=[rls.L2Regularization(1e-2), rls.L1Regularization(1e-3)], iterations=3)
+    assert rel(rls.solve_(S, bd).to_host(), O.solve(ref, b)) < 1e-12
+    B = np.asfortranarray(np.stack([b, 2 * b - 1, b[::-1]], axis=1))
+    S = rls.createLinearSolver(rls.Kaczmarz, Ad, reg=rls.L2Regularization(1e-2), iterations=2)
+    X = rls.solve_(S, rls.DeviceMatrix.from_host(B, ctx))
+    X = X.to_host() if hasattr(X, "to_host") else np.stack([c.to_host() for c in X], axis=1)
+    for j in range(B.shape[1]):
+        ref = O.Kaczmarz(A, reg=O.L2Regularization(1e-2), iterations=2)
+        assert rel(X[:, j], O.solve(ref, B[:, j].copy())) < 1e-12
+
+
 def test_reference_small_systems_float64_arm(rls, ctx):
-    """test/testSolvers.jl:242 `for elType in [Float32, Float64]`: the 3 x 2 `rand` systems of :3-65 in Float64 / ComplexF64 for the
-    solvers whose loops run on the double-precision primitives (CGNR, FISTA, ADMM; `x_approx ≈ x rtol = 0.1`); the others say so"""
+    """test/testSolvers.jl:242 `for elType in [Float32, Float64]`: the 3 x 2 `rand` systems of :3-65 in Float64 / ComplexF64 for every
+    solver of linearSolverList() (`x_approx ≈ x rtol = 0.1`), with A, with a complex A, and with AHA alone (:44-56)"""
     rng = np.random.default_rng(12345)
     A = np.asfortranarray(rng.random((3, 2)))
     x = rng.random(2)
     Ac = np.asfortranarray(rng.random((3, 2)) + 1j * rng.random((3, 2)))
     xc = rng.random(2) + 1j * rng.random(2)
-    for S in (rls.CGNR, rls.FISTA, rls.ADMM):
+    for S in rls.linearSolverList():
         sol = rls.createLinearSolver(S, rls.DeviceMatrix.from_host(A, ctx), iterations=200)
         assert rel(rls.solve_(sol, rls.DeviceVector.from_host(A @ x, ctx)).to_host(), x) < 0.1, S.__name__
         sol = rls.createLinearSolver(S, rls.DeviceMatrix.from_host(Ac, ctx), iterations=100)
         assert rel(rls.solve_(sol, rls.DeviceVector.from_host(Ac @ xc, ctx)).to_host(), xc) < 0.1, S.__name__
+        if S is rls.Kaczmarz:
+            continue   # (no AHA-only constructor: src/Kaczmarz.jl:76)
         AHA = np.asfortranarray(Ac.conj().T @ Ac)
         sol = rls.createLinearSolver(S, None, AHA=rls.DeviceMatrix.from_host(AHA, ctx), iterations=100)
         assert rel(rls.solve_(sol, rls.DeviceVector.from_host(AHA @ xc, ctx)).to_host(), xc) < 0.1, S.__name__
-    for S in (rls.OptISTA, rls.POGM, rls.SplitBregman, rls.Kaczmarz):
-        with pytest.raises(TypeError, match="Float64 / ComplexF64"):
-            rls.createLinearSolver(S, rls.DeviceMatrix.from_host(A, ctx), iterations=3)
-    # and the fused entry points refuse double-precision codes instead of misreading the memory
+    # the fused entry points refuse double-precision codes instead of misreading the memory
     v = rls.DeviceVector.from_host(np.ones(8), ctx)
     r = (__import__("ctypes").c_float * 2)()
     assert ctx.lib.rls_nrm2(ctx.handle, v.code, v.n, v.ptr, r) != 0
+    assert ctx.lib.rls_kaczmarz_sweep(ctx.handle, v.code, 2, 2, v.ptr, 2, 1, v.ptr, 2, v.ptr, 2, v.ptr, 2, v.ptr, v.ptr, 1, 0.0, 1) != 0
