@@ -182,6 +182,28 @@ def test_optista_pogm_splitbregman_kaczmarz_in_double_precision(rls, ctx, dt):
         assert rel(X[:, j], O.solve(ref, B[:, j].copy())) < 1e-12
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_matrix_right_hand_side_in_double_precision(rls, ctx, dt):
+    """solve!(solver, B) with a double-precision matrix B (src/MultiThreading.jl:30-79): independent per-column states on the
+    primitives (the shared-A batched plans are Float32 / ComplexF32)"""
+    M, N, K = 200, 96, 3
+    A, _, _ = O.make_problem(M, N, dt, 31)
+    rng = np.random.default_rng(32)
+    B = np.asfortranarray(draw(rng, dt, M, K))
+    B[:, 1] = A @ draw(rng, dt, N) * 1e-3   # (a consistent column of another scale)
+    Ad, Bd = rls.DeviceMatrix.from_host(A, ctx), rls.DeviceMatrix.from_host(B, ctx)
+    for mk_ref, mk in ((lambda: O.CGNR(A, reg=O.L2Regularization(1e-3), iterations=20, relTol=0.0),
+                        lambda: rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=20, relTol=0.0)),
+                       (lambda: O.FISTA(A, reg=O.L1Regularization(0.05), rho=0.9 / np.linalg.norm(A, 2) ** 2, iterations=20, relTol=0.0),
+                        lambda: rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(0.05), rho=0.9 / np.linalg.norm(A, 2) ** 2,
+                                                       iterations=20, relTol=0.0))):
+        X = rls.solve_(mk(), Bd)
+        X = X.to_host() if hasattr(X, "to_host") else np.stack([c.to_host() for c in X], axis=1)
+        assert X.dtype == np.dtype(dt) and X.shape == (N, K)
+        for j in range(K):
+            assert rel(X[:, j], O.solve(mk_ref(), B[:, j].copy())) < 1e-10, j
+
+
 def test_reference_small_systems_float64_arm(rls, ctx):
     """test/testSolvers.jl:242 `for elType in [Float32, Float64]`: the 3 x 2 `rand` systems of :3-65 in Float64 / ComplexF64 for every
     solver of linearSolverList() (`x_approx ≈ x rtol = 0.1`), with A, with a complex A, and with AHA alone (:44-56)"""
