@@ -195,6 +195,13 @@ class DeviceVector:
             check(h, getattr(lib, name)(h, self.code, self.n, *ptrs, r), name)
         return r
 
+    def _same(self, *others):
+        """operands of one launch share the element type (two precisions coexist since round 6: a Float32 vector handed to a
+        Float64 kernel would be read past its end)"""
+        for o in others:
+            if o.dtype != self.dtype:
+                raise TypeError(f"element types differ: {self.dtype} and {o.dtype} (no mixed-precision broadcasts; convert on the host)")
+
     def norm(self) -> float:
         return float(self._reduce("rls_nrm2", self.ptr)[0])
 
@@ -203,6 +210,7 @@ class DeviceVector:
 
     def dot(self, other: "DeviceVector"):
         """dot(self, other) = conj(self) . other"""
+        self._same(other)
         r = self._reduce("rls_dotc", self.ptr, other.ptr)
         return complex(r[0], r[1]) if self.code in (C32, C64) else float(r[0])
 
@@ -217,6 +225,7 @@ class DeviceVector:
 
     def axpy_(self, a, x: "DeviceVector"):
         """self .+= a .* x"""
+        self._same(x)
         a = complex(a)
         lib, h = self.ctx.lib, self.ctx.handle
         if is_double(self.code):
@@ -231,6 +240,7 @@ class DeviceVector:
 
     def lincomb_(self, a, x: "DeviceVector", b, y: "DeviceVector"):
         """self = a x + b y"""
+        self._same(x, y)
         a, b = complex(a), complex(b)
         lib, h = self.ctx.lib, self.ctx.handle
         if is_double(self.code):
@@ -325,6 +335,8 @@ class DeviceMatrix:
         nx, ny = (self.N, self.M) if op == OP_N else (self.M, self.N)
         if x.n != nx or y.n != ny:
             raise ValueError(f"gemv: dimension mismatch: A is {self.M}x{self.N}, x {x.n}, y {y.n}, op {op}")
+        if x.dtype != self.dtype or y.dtype != self.dtype:
+            raise TypeError(f"gemv: element types differ: A {self.dtype}, x {x.dtype}, y {y.dtype}")
         lib, h = self.ctx.lib, self.ctx.handle
         if is_double(self.code):
             check(h, lib.rls_gemv_d(h, self.code, op, self.M, self.N, alpha.real, alpha.imag, self.ptr, self.lda, x.ptr,

@@ -2241,8 +2241,18 @@ def _columns(b) -> List[DeviceVector]:
 # --------------------------------------------------------------------------------------------
 
 
+def _check_eltype(solver, b):
+    """b and the operator share the element type: with two precisions on the device a Float64 b under a Float32 plan would be
+    misread, not converted (the reference converts nothing either: its state vectors are `similar(b)` and `mul!` would throw)"""
+    op = getattr(solver, "_op", None) or getattr(solver, "A_in", None)
+    want = getattr(op, "dtype", None)
+    if want is not None and isinstance(b, (DeviceVector, DeviceMatrix)) and np.dtype(b.dtype) != np.dtype(want):
+        raise TypeError(f"element types differ: the operator is {np.dtype(want)}, b is {np.dtype(b.dtype)}")
+
+
 def init_(solver: AbstractLinearSolver, b, scheduler=SequentialState, **kw):
     """init!(solver, b; kwargs...)   src/RegularizedLeastSquares.jl:190, src/MultiThreading.jl:30-43"""
+    _check_eltype(solver, b)
     if isinstance(b, DeviceVector):
         if isinstance(solver.state, AdmmBatchedState):
             ref = solver.state
@@ -2358,6 +2368,7 @@ def solve_(solver: AbstractLinearSolver, b, callbacks=None, **kw):
     else:
         cbs = list(callbacks)
     no_group = kw.pop("_no_group", False)
+    _check_eltype(solver, b)
     if (not cbs and not kw and not no_group and isinstance(solver, CGNR) and isinstance(solver.state, CGNRState) and
             isinstance(b, DeviceVector) and isinstance(solver._op, OperatorHandle) and solver.A is not None and not solver._op.double and
             solver._op.M * solver._op.N * b.dtype.itemsize <= 128 * 1024):

@@ -763,8 +763,11 @@ def test_errors_are_loud(rls, ctx):
         rls.solve_(rls.CGNR(Ad), rls.DeviceVector.from_host(b[:5]))
     with pytest.raises(TypeError):
         rls.DeviceVector.from_host(np.zeros(4, np.float16))   # (Float64 / ComplexF64 are element types since round 6: tests/test_gpu_float64.py)
-    with pytest.raises(TypeError, match="Float64 / ComplexF64"):   # ... of the L1 protocol: the solvers beyond CGNR / FISTA / ADMM say so
-        rls.createLinearSolver(rls.POGM, rls.DeviceMatrix.from_host(A.astype(np.float64)), iterations=3)
+    with pytest.raises(TypeError, match="element types differ"):   # ... and a Float32 right-hand side does not meet a Float64 operator
+        rls.solve_(rls.createLinearSolver(rls.CGNR, rls.DeviceMatrix.from_host(A.astype(np.float64)), iterations=3),
+                   rls.DeviceVector.from_host(b))
+    with pytest.raises(TypeError, match="element types differ"):
+        rls.DeviceVector.from_host(b).axpy_(1.0, rls.DeviceVector.from_host(b.astype(np.float64)))
     with pytest.raises(rls.RLSError):
         rls.prox_(rls.L21Regularization, rls.DeviceVector.from_host(np.ones(4, np.float32)), 0.1, slices=9)
 
