@@ -289,6 +289,7 @@ int32_t rls_tune_set(rls_ctx* ctx, const char* key, int32_t value) {
   else if (!strcmp(key, "status_mailbox")) ctx->tune.status_mailbox = value;
   else if (!strcmp(key, "small")) ctx->tune.small = value;
   else if (!strcmp(key, "resident_server")) ctx->tune.resident_server = value;
+  else if (!strcmp(key, "resident_ahead")) ctx->tune.resident_ahead = value ? 1 : 0;
   else if (!strcmp(key, "resident_l2_rows")) ctx->tune.resident_l2_rows = value;
   else if (!strcmp(key, "fista_defer")) ctx->tune.fista_defer = value;
   else if (!strcmp(key, "resident_server_idle_us")) {

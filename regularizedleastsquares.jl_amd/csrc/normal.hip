@@ -2371,7 +2371,12 @@ __device__ static inline bool resident_allreduce(resident_lds<E, G, K, WV>& R, r
   }
 }
 
-template <typename E, int G, int K, int WV, int BAR, bool FULL>
+// SPEC (server mode only): the kernel runs ONE iteration ahead of the command that asks for it.  Behind the status and write-back of
+// command k it computes iteration k + 1 at once -- under the host's turnaround -- and only then listens; the next command finds its
+// first iteration done (nothing of it published or written back before the command is there).  Told to leave instead, the kernel
+// leaves WITHOUT a write-back: memory holds the state of command k, which is what the host was told.  A separate instantiation: the
+// plain kernel's code is the SPEC = false text, token for token.
+template <typename E, int G, int K, int WV, int BAR, bool FULL, bool SPEC = false>
 __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restrict__ A, int64_t lda, E* x, E* xw, E* r, E* p,
                                                                  E* v, E* slab, double* dout, cgnr_scalars* sc,
                                                                  resident_sync* sync, int64_t Mc, int64_t N, int pair,
@@ -2529,8 +2534,10 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   if (blockIdx.x == 0) store_owned(xw, xv);
   rls_mailbox_slot srv_mb = St.srv_mb;
   unsigned srv_seq = St.srv_seq0;  // the command being served; the host's next one carries srv_seq + 1
+  int credit = 0;      // SPEC: iterations of the current command that were computed ahead of it
+  bool ahead = false;  // SPEC: the pass below runs ahead of its command
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
-  for (int it = 0; it < n_steps; ++it) {
+  for (int it = SPEC ? credit : 0; it < n_steps; ++it) {
     if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
     STAMP(8);
     // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through); ||t_w||^2 -> its word of the scalar row
@@ -2613,6 +2620,16 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     if (St.srv_ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;  // x, r, p and the scalars are untouched: the call was a no-op
   }
+  if constexpr (SPEC) {
+    if (ahead) {  // that pass ran ahead: its command first (uniform)
+      ahead = false;
+      const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb, srv_seq - St.srv_seq0 + 1u);
+      if (cmd == RLS_SRV_EXIT) return;  // (memory holds the state of the last command served: nothing of the pass ahead was stored)
+      n_steps = (int)cmd;
+      credit = 1;
+      continue;
+    }
+  }
   if (blockIdx.x == 0) {
     S.pending = 0;
     S.cur = 0;
@@ -2643,6 +2660,14 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     }
   }
   if (!St.srv_ctl) break;  // uniform
+  if constexpr (SPEC) {
+    credit = 0;
+    if (!S.done) {  // uniform: one iteration ahead of the next command
+      ahead = true;
+      n_steps = 1;
+      continue;
+    }
+  }
   // ---- server mode: listen for the next command (resident_listen, resident_sync.hpp) ----------------------------------------
   const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb, srv_seq - St.srv_seq0 + 1u);
   if (cmd == RLS_SRV_EXIT) return;  // uniform (told to leave, left idle, or a wait ran out: the control block says which)
@@ -4046,17 +4071,33 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 2, true>, lds);
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, false>, lds);
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 2, false>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, true, true>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 2, true, true>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, false, true>, lds);
+      allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 2, false, true>, lds);
       }
-#define RLS_LAUNCH_RES(BB, FF)                                                                                          \
-  hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
+#define RLS_LAUNCH_RES(BB, FF, SS)                                                                                      \
+  hipLaunchKernelGGL((cgnr_resident_kernel<E, G, K, WV, BB, FF, SS>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.x, (E*)P.r1, (E*)P.r0, (E*)P.p0, (E*)P.v, (E*)P.slab, dout, P.sc, (resident_sync*)sync, Mc, P.N,  \
                      pair, n_steps, spin_limit, St)
+    // a kernel that stays and listens runs one iteration ahead of its commands (SPEC) unless the context says otherwise
+    const bool spec = St.srv_ctl != nullptr && ctx->tune.resident_ahead != 0;
     if (resident_two_level_ok<E>(ctx->tune, nwg, P.N, C::NT)) {
-      if (full) RLS_LAUNCH_RES(2, true);
-      else RLS_LAUNCH_RES(2, false);
+      if (spec) {
+        if (full) RLS_LAUNCH_RES(2, true, true);
+        else RLS_LAUNCH_RES(2, false, true);
+      } else {
+        if (full) RLS_LAUNCH_RES(2, true, false);
+        else RLS_LAUNCH_RES(2, false, false);
+      }
     } else {
-      if (full) RLS_LAUNCH_RES(1, true);
-      else RLS_LAUNCH_RES(1, false);
+      if (spec) {
+        if (full) RLS_LAUNCH_RES(1, true, true);
+        else RLS_LAUNCH_RES(1, false, true);
+      } else {
+        if (full) RLS_LAUNCH_RES(1, true, false);
+        else RLS_LAUNCH_RES(1, false, false);
+      }
     }
 #undef RLS_LAUNCH_RES
     return launch_status(ctx);

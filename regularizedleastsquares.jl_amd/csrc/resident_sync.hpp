@@ -136,6 +136,19 @@ __device__ static inline bool group_arrive_wait(unsigned* word, unsigned target,
 // turn into one kernel that runs for seconds: ~40 ms of one-iterate calls): the host finds `exited` instead of its status and
 // re-issues the command with a launch, as for a kernel that left idle.
 constexpr unsigned RLS_SRV_MAX_COMMANDS = 2048u;
+// the head of the control block {command sequence, n_steps, mailbox sequence, -} in ONE 16-byte read at system scope: the block lives
+// in pinned host memory, every read of it is a round trip over the link (1.5-2 us), and the three words used to be three dependent
+// reads.  The host writes the payload, a release fence, then the sequence word (server_command, solvers.hip): a read that shows the new
+// sequence shows the payload of that command (the 16 bytes are one aligned piece of one cache line).
+struct srv_head {
+  unsigned seq, n, mbseq, pad;
+};
+__device__ static inline srv_head srv_read_head(const unsigned* ctl) {
+  typedef unsigned u4h __attribute__((ext_vector_type(4)));
+  u4h w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(ctl) : "memory");
+  return srv_head{w.x, w.y, w.z, w.w};
+}
 __device__ static inline unsigned resident_listen(unsigned* ctl, unsigned& srv_seq, unsigned idle_us, resident_sync* sync, unsigned& epoch,
                                                   unsigned nwg, unsigned spin_limit, int* lds_flag, rls_mailbox_slot& mb,
                                                   unsigned served) {
@@ -143,25 +156,25 @@ __device__ static inline unsigned resident_listen(unsigned* ctl, unsigned& srv_s
   if (blockIdx.x == 0 && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back above is out before anything else is announced)
     const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)idle_us * 100ull;  // 100 MHz
-    unsigned n = RLS_SRV_EXIT, seq = srv_seq;
+    unsigned n = RLS_SRV_EXIT;
+    srv_head hd{srv_seq, 0u, 0u, 0u};
     for (; served < RLS_SRV_MAX_COMMANDS;) {
-      seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (seq != srv_seq) break;
+      hd = srv_read_head(ctl);
+      if (hd.seq != srv_seq) break;
       if (wall_clock64() - t0 > idle) {
         // leave -- unless a command slips in: "leaving" goes out, THEN the sequence word is read once more (the host posts
         // its command and THEN reads "exited": one of the two sees the other)
         __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        hd = srv_read_head(ctl);
+        if (hd.seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(8);
     }
-    if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (hd.seq != srv_seq) n = hd.n;
     __hip_atomic_store(&sync->srv_n, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sync->srv_mb, __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sync->srv_mb, hd.mbseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();

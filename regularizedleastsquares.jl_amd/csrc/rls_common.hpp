@@ -34,6 +34,7 @@ struct rls_tuning {
   int resident_preclear = 1; // 1: the init kernels zero the resident kernels' arrival counters (no memset launch ahead of the first step)
   int resident_server = 1;     // 1: rls_cgnr_step_status leaves the resident kernel listening for the next call (rls_cg_start::srv_ctl)
   int resident_server_idle_us = 300;  // ... for this long
+  int resident_ahead = 1;      // 1: a listening kernel computes one iteration ahead of the next command (the SPEC instantiations, normal.hip)
   int fista_defer = 1;         // 1: fista_resident_kernel sums ||res||^2 off the critical path where it can (normal.hip, DEFER); 0: measurement
   int resident_l2_rows = 1;    // 1: the matrix-free resident kernels keep their partial rows in the XCD's L2 when the placement allows (normal.hip,
                                // resident_rows_at_l2); 0: always written through (measurement switch)

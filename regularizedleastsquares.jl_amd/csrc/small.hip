@@ -14,6 +14,7 @@
 // State (x, r, p, v, scalars) is read at entry and written back at the end, in the layout every other path uses, so step calls
 // of this kernel and of the pipelines can follow each other.
 #include "rls_common.hpp"
+#include "resident_sync.hpp"
 
 namespace {
 
@@ -129,22 +130,23 @@ __device__ static inline void small_listen(const rls_srv_args& srv, unsigned srv
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back is out before anything else is announced)
   unsigned* ctl = srv.ctl;
   const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)srv.idle_us * 100ull;
-  unsigned n = RLS_SRV_EXIT, seq = srv_seq;
+  unsigned n = RLS_SRV_EXIT;
+  srv_head hd{srv_seq, 0u, 0u, 0u};  // (one 16-byte read of the control block's head per poll: srv_read_head, resident_sync.hpp)
   for (; srv_seq - srv.seq0 + 1u < 2048u;) {
-    seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (seq != srv_seq) break;
+    hd = srv_read_head(ctl);
+    if (hd.seq != srv_seq) break;
     if (wall_clock64() - t0 > idle) {
       __hip_atomic_store(ctl + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      seq = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      hd = srv_read_head(ctl);
+      if (hd.seq != srv_seq) __hip_atomic_store(ctl + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
     __builtin_amdgcn_s_sleep(8);
   }
-  if (seq != srv_seq) n = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (hd.seq != srv_seq) n = hd.n;
   *cmd_out = n;
-  *mbseq_out = __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  *mbseq_out = hd.mbseq;
   if (n == RLS_SRV_EXIT) __hip_atomic_store(ctl + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -2735,6 +2735,52 @@ def test_cgnr_resident_server_mode(rls, ctx, dt, M, N):
     assert rel(x_pipe, x_once) < 2e-5 and not np.array_equal(x_pipe, x_once)
 
 
+def test_cgnr_server_runs_one_iteration_ahead(rls, ctx):
+    """A listening kernel computes the NEXT iteration under the host's turnaround (the SPEC instantiations of cgnr_resident_kernel,
+    rls_tune_set("resident_ahead")): nothing of it is published or written back before its command is there.  Commands of 1, 3, 2, ...
+    iterates give the status stream and the bits of the kernel that does not run ahead (and the per-iteration pipeline's within
+    rounding); a download between two commands (the kernel is told to
+    leave AFTER it ran ahead) sees the state of the last command served, and the solve continues from there; the iteration limit and
+    the stopping test end the stream where they do without it."""
+    import ctypes as C
+    M, N, dt = 4096, 2048, np.complex64
+    A, xt, b = O.make_problem(M, N, dt, 92)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    sizes = [1, 3, 2, 1, 1, 4, 1, 2, 1]
+    iters = sum(sizes)
+    lib = ctx.lib
+    st = rls._lib.CgnrStatus()
+
+    def stream(server, ahead_, peek_at=()):
+        ctx.tune(resident_server=server, resident_ahead=ahead_)
+        sol = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=0.0)
+        rls.init_(sol, bd)
+        if _cgnr_path(rls, sol) != 4:
+            _resident_unavailable()
+        out, peeks = [], []
+        for k, n in enumerate(sizes):
+            assert lib.rls_cgnr_step_status(sol.state._plan, n, C.byref(st)) == 0
+            out.append((st.iteration, st.done, st.residual, st.alpha_re, st.beta_re))
+            if k in peek_at:
+                peeks.append(sol.state.x.to_host())      # the kernel leaves first -- behind the iteration it ran ahead
+        assert lib.rls_cgnr_step_status(sol.state._plan, 1, C.byref(st)) == 0 and st.iteration == iters and st.done == 1   # the limit
+        x_end = sol.state.x.to_host()
+        return out, peeks, x_end, int(st.fallbacks)
+
+    try:
+        pipe_out, pipe_peeks, pipe_x, _ = stream(0, 0, peek_at=(1, 4))   # a launch per command on the per-iteration pipeline
+        ref_out, ref_peeks, ref_x, fb = stream(1, 0, peek_at=(1, 4))     # the listening kernel, never ahead
+        assert fb == 0 and [o[:2] for o in ref_out] == [o[:2] for o in pipe_out] and rel(ref_x, pipe_x) < 2e-5
+        out, peeks, x, fb = stream(1, 1)
+        assert fb == 0 and out == ref_out and np.array_equal(x, ref_x)
+        out, peeks, x, fb = stream(1, 1, peek_at=(1, 4))
+        assert fb == 0 and out == ref_out and np.array_equal(x, ref_x)
+        assert len(peeks) == 2 and all(np.array_equal(a, b_) for a, b_ in zip(peeks, ref_peeks))
+        assert all(rel(a, b_) < 2e-5 for a, b_ in zip(peeks, pipe_peeks))
+    finally:
+        ctx.tune(resident_server=1, resident_ahead=1)
+
+
 @pytest.mark.parametrize("restart", ["none", "gradient"])
 def test_fista_resident_server_mode(rls, ctx, restart):
     """rls_fista_step_status with the resident kernel left listening (as test_cgnr_resident_server_mode): 40 one-iterate calls
