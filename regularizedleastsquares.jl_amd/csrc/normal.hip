@@ -2686,7 +2686,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
 // ownership and summation orders as cgnr_gram_kernel.
 // SRV: the instantiation that can stay and listen (server mode, rls_cgnr_step_status); not built for Float32 K = 32, which
 // has no registers to spare for it (it spilled 148-316 B per lane)
-template <typename E, int K, int BAR, bool FULL, bool SRV = false>
+template <typename E, int K, int BAR, bool FULL, int SRV = 0>  // SRV: 0 one pass, 1 stays and listens, 2 ... and runs one iteration ahead
 __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* x, E* r, E* p,
                                                                   E* v0, E* v1, double* dots, cgnr_scalars* sc0,
                                                                   cgnr_scalars* sc1, resident_sync* sync, int64_t Mc,
@@ -2802,8 +2802,10 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
   rls_mailbox_slot srv_mb = St.srv_mb;
   unsigned srv_seq = St.srv_seq0;  // server mode (rls_cgnr_step_status): the command being served
   unsigned itg = 0;                // iterations run by this launch, over all its commands: the parity of v and of the dots
+  int credit = 0;                  // SRV == 2: iterations of the current command computed ahead of it (as cgnr_resident_kernel's SPEC)
+  bool ahead = false;              // ... the pass below runs ahead of its command
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
-  for (int it = 0; it < n_steps; ++it) {
+  for (int it = SRV ? credit : 0; it < n_steps; ++it) {
     if (SRV && S.done) break;  // uniform (a command behind the one that reached the stopping test)
     const int q = (int)(itg++ & 1u);
     E* vq = q ? v1 : v0;
@@ -2878,6 +2880,17 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
     if (SRV && St.srv_ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;  // x, r, p, v and the scalars are untouched: the call was a no-op
   }
+  if constexpr (SRV != 0) {
+    if (ahead) {  // that pass ran ahead: its command first (uniform); told to leave, memory holds the last command served
+      ahead = false;
+      const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &flag, srv_mb,
+                                           srv_seq - St.srv_seq0 + 1u);
+      if (cmd == RLS_SRV_EXIT) return;
+      n_steps = (int)cmd;
+      credit = 1;
+      continue;
+    }
+  }
   if (blockIdx.x == 0) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -2889,7 +2902,7 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
         // the last v (a workgroup still reading parity 0 reads the same values).  A kernel that stays and listens must not leave
         // these lines DIRTY in this XCD's L2: v0 is an exchange buffer, a later command's write-through rows from other XCDs
         // would be overwritten whenever the stale lines are evicted
-        if constexpr (SRV) sc1_store_elem<E>(v0 + i, vv[e]);
+        if constexpr (SRV != 0) sc1_store_elem<E>(v0 + i, vv[e]);
         else v0[i] = vv[e];
       }
     }
@@ -2901,12 +2914,18 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
       *sc1 = S;
       sync->completed = 1u;
     }
-    if constexpr (SRV) {
+    if constexpr (SRV != 0) {
       if (St.srv_ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // the status of this command, straight to the host
     }
   }
-  if constexpr (SRV) {
+  if constexpr (SRV != 0) {
     if (!St.srv_ctl) break;  // uniform
+    credit = 0;
+    if (SRV == 2 && !S.done) {  // uniform: one iteration ahead of the next command, under the host's turnaround
+      ahead = true;
+      n_steps = 1;
+      continue;
+    }
     const unsigned cmd = resident_listen(St.srv_ctl, srv_seq, St.srv_idle_us, sync, epoch, (unsigned)nwg, spin_limit, &flag, srv_mb,
                                          srv_seq - St.srv_seq0 + 1u);
     if (cmd == RLS_SRV_EXIT) return;  // uniform
@@ -2922,6 +2941,9 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
 // Per iteration: xs = y, partial rows of AHA y, exchange 1, chunk sums -> res_raw, exchange 2, then the gradient step,
 // prox, restart test, theta and the next extrapolated point redundantly in every workgroup (fista_update_elems: its
 // two scalar sums run over full vectors every workgroup holds, so no partial dots travel).
+// (No run-ahead instantiation here, unlike cgnr_resident_kernel's SPEC and the Gram kernels' SRV = 2: state.res of the pass ahead would
+// have to wait in workgroup 0's registers for its command -- src/FISTA.jl:131 reads that array -- and the two-level instantiations
+// spilled 12-36 B per lane with it.)
 template <typename E, int G, int K, int WV, int BAR, bool FULL>
 __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
                                                                   const E* __restrict__ x0, E* res, E* y0, E* y1,
@@ -3416,7 +3438,7 @@ __global__ __launch_bounds__(WV * 64) void pgm_resident_kernel(const E* __restri
 // thread adds the eight up behind the NEXT iteration's grid barrier, where a stop found late drops that iteration's exchange
 // (nothing of it has been applied) -- the block reduction and its two barriers are off the critical path.
 // SRV: the instantiation that can stay and listen (server mode, rls_fista_step_status); not built for Float32 K = 32 (it spilled)
-template <typename E, int K, int BAR, bool FULL, bool SRV = false>
+template <typename E, int K, int BAR, bool FULL, int SRV = 0>  // SRV: 0 one pass, 1 stays and listens, 2 ... and runs one iteration ahead
 __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __restrict__ Gm, int64_t ldg, E* b0, E* b1,
                                                                    const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                    E* rr0, E* rr1, fista_scalars* sc0, fista_scalars* sc1,
@@ -3474,8 +3496,10 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
   rls_mailbox_slot srv_mb = Sv.mb;
   unsigned srv_seq = Sv.seq0;  // server mode (rls_fista_step_status): the command being served
   unsigned itg = 0;            // iterations run by this launch, over all its commands: the parity of the exchanged rows
+  int credit = 0;              // SRV == 2: iterations of the current command computed ahead of it (as cgnr_gram_resident_kernel)
+  bool ahead = false;          // ... the pass below runs ahead of its command
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
-  for (int it = 0; it < n_steps; ++it) {
+  for (int it = SRV ? credit : 0; it < n_steps; ++it) {
     if (SRV && S.done) break;  // uniform (a command behind the one that reached the stopping test)
     const unsigned itn = itg++;
     E* rq = (itn & 1u) ? rr1 : rr0;
@@ -3562,11 +3586,21 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
     if (SRV && Sv.ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(Sv.ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
+  if constexpr (SRV != 0) {
+    if (ahead) {  // that pass ran ahead: its command first (uniform); told to leave, memory holds the last command served
+      ahead = false;
+      const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &flag, srv_mb, srv_seq - Sv.seq0 + 1u);
+      if (cmd == RLS_SRV_EXIT) return;
+      n_steps = (int)cmd;
+      credit = 1;
+      continue;
+    }
+  }
   if (blockIdx.x == 0) {
     S.ycur = ycur;
     S.pending = 0;
     S.fresh = 0;
-    if constexpr (SRV) {
+    if constexpr (SRV != 0) {
       if (Sv.ctl && tid < 64) rls_mailbox_publish(srv_mb, S, tid);  // (server mode: status first, write-back under the host's turnaround)
     }
     E* xw = (S.iteration & 1) ? b1 : b0;  // state.x == buf[iteration & 1] afterwards as well
@@ -3589,8 +3623,14 @@ __global__ __launch_bounds__(512) void fista_gram_resident_kernel(const E* __res
       sync->completed = 1u;
     }
   }
-  if constexpr (SRV) {
+  if constexpr (SRV != 0) {
     if (!Sv.ctl) break;  // uniform
+    credit = 0;
+    if (SRV == 2 && !S.done) {  // uniform: one iteration ahead of the next command, under the host's turnaround
+      ahead = true;
+      n_steps = 1;
+      continue;
+    }
     const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &flag, srv_mb, srv_seq - Sv.seq0 + 1u);
     if (cmd == RLS_SRV_EXIT) return;  // uniform
     n_steps = (int)cmd;
@@ -4214,12 +4254,17 @@ static int32_t launch_gram_resident(rls_ctx* ctx, const rls_gram_pipe& P, void* 
                      (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, St)
   if constexpr (K != 32) {
     if (St.srv_ctl) {  // the instantiation that can stay and listen
-#define RLS_LAUNCH_GRS(FF)                                                                                                \
-  hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, 1, FF, true>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, \
+#define RLS_LAUNCH_GRS(FF, SS)                                                                                            \
+  hipLaunchKernelGGL((cgnr_gram_resident_kernel<E, K, 1, FF, SS>), dim3(nwg), dim3(C::NT), 0, ctx->stream, (const E*)P.G, \
                      P.ldg, (E*)P.x, (E*)P.r[0], (E*)P.p[0], (E*)P.v[0], (E*)P.v[1], P.dots, P.sc[0], P.sc[1],            \
                      (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, St)
-      if (full) RLS_LAUNCH_GRS(true);
-      else RLS_LAUNCH_GRS(false);
+      if (ctx->tune.resident_ahead) {  // one iteration ahead of its commands
+        if (full) RLS_LAUNCH_GRS(true, 2);
+        else RLS_LAUNCH_GRS(false, 2);
+      } else {
+        if (full) RLS_LAUNCH_GRS(true, 1);
+        else RLS_LAUNCH_GRS(false, 1);
+      }
 #undef RLS_LAUNCH_GRS
       return launch_status(ctx);
     }
@@ -4276,15 +4321,20 @@ static int32_t launch_fista_gram_resident(rls_ctx* ctx, const rls_fista_gram& P,
                      P.sc[0], P.sc[1], (resident_sync*)sync, Mc, P.N, pair, n_steps, spin_limit, Sv)
   if constexpr (K != 32) {
     if (Sv.ctl) {  // the listening instantiation (the host asks rls_gram_resident_server_ok first)
-      if (full) RLS_LAUNCH_FGR(1, true, true);
-      else RLS_LAUNCH_FGR(1, false, true);
+      if (ctx->tune.resident_ahead) {  // one iteration ahead of its commands
+        if (full) RLS_LAUNCH_FGR(1, true, 2);
+        else RLS_LAUNCH_FGR(1, false, 2);
+      } else {
+        if (full) RLS_LAUNCH_FGR(1, true, 1);
+        else RLS_LAUNCH_FGR(1, false, 1);
+      }
       return launch_status(ctx);
     }
   } else if (Sv.ctl) {
     return rls_fail(ctx, RLS_E_UNSUPPORTED, "resident Gram FISTA: no listening instantiation for this shape");
   }
-  if (full) RLS_LAUNCH_FGR(1, true, false);
-  else RLS_LAUNCH_FGR(1, false, false);
+  if (full) RLS_LAUNCH_FGR(1, true, 0);
+  else RLS_LAUNCH_FGR(1, false, 0);
 #undef RLS_LAUNCH_FGR
   return launch_status(ctx);
 }
