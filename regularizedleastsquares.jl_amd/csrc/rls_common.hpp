@@ -108,6 +108,7 @@ struct rls_mailbox_slot {
 rls_mailbox_slot rls_mailbox_arm(rls_ctx* ctx, void* dst_pinned);
 // server mode of the resident kernels (see rls_cg_start::srv_ctl for the protocol): what a launch that is to stay and LISTEN gets
 constexpr unsigned RLS_SRV_EXIT = 0xffffffffu;
+constexpr unsigned RLS_SRV_AHEAD = 0x80000000u;  // bit 31 of rls_srv_args::idle_us, read by the single-workgroup kernels (small.hip): one iteration ahead
 struct rls_srv_args {
   unsigned* ctl = nullptr;  // control block in pinned host memory (null: an ordinary launch)
   unsigned seq0 = 0, idle_us = 0;

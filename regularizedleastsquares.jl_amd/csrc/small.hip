@@ -129,7 +129,7 @@ __device__ static inline void small_adjoint_partials(const E (&a)[R][C], const E
 __device__ static inline void small_listen(const rls_srv_args& srv, unsigned srv_seq, unsigned* cmd_out, unsigned* mbseq_out) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back is out before anything else is announced)
   unsigned* ctl = srv.ctl;
-  const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)srv.idle_us * 100ull;
+  const unsigned long long t0 = wall_clock64(), idle = (unsigned long long)(srv.idle_us & 0x7fffffffu) * 100ull;  // (bit 31: RLS_SRV_AHEAD)
   unsigned n = RLS_SRV_EXIT;
   srv_head hd{srv_seq, 0u, 0u, 0u};  // (one 16-byte read of the control block's head per poll: srv_read_head, resident_sync.hpp)
   for (; srv_seq - srv.seq0 + 1u < 2048u;) {
@@ -239,8 +239,14 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group
   rls_mailbox_slot mbs = mb;
   unsigned srv_seq = D.srv.seq0;
   bool first = true;
+  // server mode, RLS_SRV_AHEAD: behind the status and write-back of command k the workgroup computes iteration k + 1 at once -- under the
+  // host's turnaround -- and only then listens (as the SPEC / SRV = 2 instantiations of the resident kernels, normal.hip): nothing of that
+  // pass is published or stored before its command is there; told to leave, it leaves without a write-back
+  const bool run_ahead = D.srv.ctl && (D.srv.idle_us >> 31);
+  int credit = 0;      // iterations of the current command computed ahead of it
+  bool ahead = false;  // the pass below runs ahead of its command
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
-  for (int it = 0; it < n_steps; ++it) {
+  for (int it = credit; it < n_steps; ++it) {
     if (sdone) break;  // uniform
     small_normal_partials<E, R, C>(a, ps, vpart, cb, lane, w);
     // ---- the CG update, wave 0 alone (src/CGNR.jl:153-176) -----------------------------------------------------------------------
@@ -299,7 +305,8 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group
     }
     __syncthreads();
   }
-  if (w == 0) {
+  credit = 0;
+  if (!ahead && w == 0) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int i = lane + 64 * e;
@@ -321,17 +328,27 @@ __global__ __launch_bounds__(SM_NT) void cgnr_small_kernel(const rls_small_group
     }
     S.pending = 0; S.cur = 0; S.fresh = 0;
     rls_mailbox_publish(mbs, S, lane);
-    // ---- server mode: this workgroup stays and listens for the next step call (one CU; nothing else waits for it) ----------------
-    if (D.srv.ctl && lane == 0) small_listen(D.srv, srv_seq, &srv_cmd, &srv_mbseq);
   }
   if (!D.srv.ctl) break;  // uniform
+  if (run_ahead && !ahead && !sdone) {  // uniform (sdone: behind the loop's last barrier): one iteration ahead of the next command
+    ahead = true;
+    n_steps = 1;
+    first = false;
+    continue;
+  }
+  // ---- server mode: this workgroup stays and listens for the next step call (one CU; nothing else waits for it) ----------------
+  if (w == 0 && lane == 0) small_listen(D.srv, srv_seq, &srv_cmd, &srv_mbseq);
   __syncthreads();
   const unsigned cmd = srv_cmd;
-  if (cmd == RLS_SRV_EXIT) return;  // uniform
+  if (cmd == RLS_SRV_EXIT) return;  // uniform (behind a pass ahead: memory holds the state of the last command served)
   n_steps = (int)cmd;
   mbs.seq = srv_mbseq;
   srv_seq += 1;
   first = false;
+  if (ahead) {  // the command's first iteration is done
+    ahead = false;
+    credit = 1;
+  }
   __syncthreads();  // (srv_cmd is read before the next pass can overwrite it)
   }
 }
@@ -379,8 +396,11 @@ __global__ __launch_bounds__(SM_NT) void fista_small_kernel(const E* __restrict_
   __shared__ unsigned srv_cmd, srv_mbseq;
   rls_mailbox_slot mbs = mb;
   unsigned srv_seq = srv.seq0;
+  const bool run_ahead = srv.ctl && (srv.idle_us >> 31);  // RLS_SRV_AHEAD: one iteration ahead of the next command (as cgnr_small_kernel)
+  int credit = 0;
+  bool ahead = false;
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
-  for (int it = 0; it < n_steps; ++it) {
+  for (int it = credit; it < n_steps; ++it) {
     if (sdone) break;  // uniform
     small_normal_partials<E, R, C>(a, ps, vpart, cb, lane, w);
     if (w == 0) {
@@ -441,7 +461,8 @@ __global__ __launch_bounds__(SM_NT) void fista_small_kernel(const E* __restrict_
     }
     __syncthreads();
   }
-  if (w == 0) {
+  credit = 0;
+  if (!ahead && w == 0) {
     if (ran > 0) {
       E* xw = (S.iteration & 1) ? b1 : b0;
       E* xp = (S.iteration & 1) ? b0 : b1;
@@ -461,15 +482,24 @@ __global__ __launch_bounds__(SM_NT) void fista_small_kernel(const E* __restrict_
       if (lane == 0) RLS_FISTA_COPY(*sc, S);
     }
     rls_mailbox_publish(mbs, S, lane);
-    if (srv.ctl && lane == 0) small_listen(srv, srv_seq, &srv_cmd, &srv_mbseq);
   }
   if (!srv.ctl) break;  // uniform
+  if (run_ahead && !ahead && !sdone) {  // uniform: one iteration ahead of the next command
+    ahead = true;
+    n_steps = 1;
+    continue;
+  }
+  if (w == 0 && lane == 0) small_listen(srv, srv_seq, &srv_cmd, &srv_mbseq);
   __syncthreads();
   const unsigned cmd = srv_cmd;
-  if (cmd == RLS_SRV_EXIT) return;  // uniform
+  if (cmd == RLS_SRV_EXIT) return;  // uniform (behind a pass ahead: memory holds the state of the last command served)
   n_steps = (int)cmd;
   mbs.seq = srv_mbseq;
   srv_seq += 1;
+  if (ahead) {  // the command's first iteration is done
+    ahead = false;
+    credit = 1;
+  }
   __syncthreads();
   }
 }

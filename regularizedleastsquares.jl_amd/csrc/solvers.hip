@@ -2929,6 +2929,7 @@ static int32_t server_command(rls_ctx* ctx, srv_state* v, void* mirror, int32_t 
       a.ctl = v->ctl;
       a.seq0 = v->seq;
       a.idle_us = (unsigned)(ctx->tune.resident_server_idle_us > 0 ? ctx->tune.resident_server_idle_us : 1);
+      if (ctx->tune.resident_ahead) a.idle_us |= RLS_SRV_AHEAD;  // (read by the single-workgroup kernels; the resident launches below mask it)
       a.mb.dst = mirror;
       a.mb.seq_h = ctx->mb_h;
       a.mb.seq = mbseq;
@@ -2968,7 +2969,7 @@ static int32_t cgnr_step_status_server(rls_cgnr* s, int32_t n_steps, rls_cgnr_st
     rls_cg_start St;
     St.srv_ctl = a.ctl;
     St.srv_seq0 = a.seq0;
-    St.srv_idle_us = a.idle_us;
+    St.srv_idle_us = a.idle_us & ~RLS_SRV_AHEAD;
     St.srv_mb = a.mb;
     if (cgnr_use_small(s)) {  // the single-workgroup kernel: one CU stays, nothing to chain
       rls_small D;
@@ -3681,14 +3682,16 @@ int32_t rls_fista_step_status(rls_fista* s, int32_t n_steps, rls_fista_status* o
         P.mb = a.mb;
         return rls_fista_small_launch(ctx, s->op->dtype, P, n_steps, a);
       }
+      rls_srv_args ar = a;  // (the resident kernels take the idle time as it is: the run-ahead choice is their instantiation)
+      ar.idle_us &= ~RLS_SRV_AHEAD;
       if (fista_use_gram_resident(s)) {  // AHA explicit, in the register files (fista_gram_resident_kernel)
         const rls_fista_gram Pg = fista_gram_desc(s);
         return resident_chain(ctx, s->rsync, [&]() {
-          return rls_fista_gram_resident_launch(ctx, s->op->dtype, Pg, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, a);
+          return rls_fista_gram_resident_launch(ctx, s->op->dtype, Pg, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, ar);
         }, &s->rsync_clean);
       }
       return resident_chain(ctx, s->rsync, [&]() {
-        return rls_fista_resident_launch(ctx, s->op->dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, a);
+        return rls_fista_resident_launch(ctx, s->op->dtype, P, s->rsync, n_steps, (unsigned)ctx->tune.resident_spin, ar);
       }, &s->rsync_clean);
     });
     if (r < 0) return r;

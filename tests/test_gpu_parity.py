@@ -2735,7 +2735,8 @@ def test_cgnr_resident_server_mode(rls, ctx, dt, M, N):
     assert rel(x_pipe, x_once) < 2e-5 and not np.array_equal(x_pipe, x_once)
 
 
-def test_cgnr_server_runs_one_iteration_ahead(rls, ctx):
+@pytest.mark.parametrize("M,N,dt,path,gram", [(4096, 2048, np.complex64, 4, False), (2048, 2048, np.complex64, 5, True), (256, 128, np.float32, 8, False)])
+def test_cgnr_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, path, gram):
     """A listening kernel computes the NEXT iteration under the host's turnaround (the SPEC instantiations of cgnr_resident_kernel,
     rls_tune_set("resident_ahead")): nothing of it is published or written back before its command is there.  Commands of 1, 3, 2, ...
     iterates give the status stream and the bits of the kernel that does not run ahead (and the per-iteration pipeline's within
@@ -2743,9 +2744,9 @@ def test_cgnr_server_runs_one_iteration_ahead(rls, ctx):
     leave AFTER it ran ahead) sees the state of the last command served, and the solve continues from there; the iteration limit and
     the stopping test end the stream where they do without it."""
     import ctypes as C
-    M, N, dt = 4096, 2048, np.complex64
     A, xt, b = O.make_problem(M, N, dt, 92)
     Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    Gd = Ad.gram() if gram else None   # (the matrix-free resident kernel, the resident Gram kernel, the single-workgroup kernel)
     sizes = [1, 3, 2, 1, 1, 4, 1, 2, 1]
     iters = sum(sizes)
     lib = ctx.lib
@@ -2753,9 +2754,9 @@ def test_cgnr_server_runs_one_iteration_ahead(rls, ctx):
 
     def stream(server, ahead_, peek_at=()):
         ctx.tune(resident_server=server, resident_ahead=ahead_)
-        sol = rls.createLinearSolver(rls.CGNR, Ad, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=0.0)
+        sol = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=0.0)
         rls.init_(sol, bd)
-        if _cgnr_path(rls, sol) != 4:
+        if _cgnr_path(rls, sol) != path:
             _resident_unavailable()
         out, peeks = [], []
         for k, n in enumerate(sizes):
@@ -2777,6 +2778,53 @@ def test_cgnr_server_runs_one_iteration_ahead(rls, ctx):
         assert fb == 0 and out == ref_out and np.array_equal(x, ref_x)
         assert len(peeks) == 2 and all(np.array_equal(a, b_) for a, b_ in zip(peeks, ref_peeks))
         assert all(rel(a, b_) < 2e-5 for a, b_ in zip(peeks, pipe_peeks))
+    finally:
+        ctx.tune(resident_server=1, resident_ahead=1)
+
+
+@pytest.mark.parametrize("M,N,dt,gram", [(2048, 2048, np.complex64, True), (256, 128, np.float32, False)])
+@pytest.mark.parametrize("restart", ["none", "gradient"])
+def test_fista_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, gram, restart):
+    """as test_cgnr_server_runs_one_iteration_ahead for rls_fista_step_status on the kernels that run ahead: the resident Gram kernel
+    (fista_gram_resident_kernel, SRV = 2) and the single-workgroup kernel -- status stream, x, x_{k-1} and state.res of the kernel that does
+    not; a download of state.res between two commands sees the command's residual, not the one computed ahead"""
+    import ctypes as C
+    A, xt, b = O.make_problem(M, N, dt, 93)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    Gd = Ad.gram() if gram else None
+    rho = float(0.9 / np.linalg.norm(A.astype(hi(dt)), 2) ** 2)
+    lam = 0.02 * float(np.max(np.abs(A.conj().T @ b)))
+    sizes = [1, 2, 1, 1, 3, 1, 2, 1]
+    iters = sum(sizes)
+    lib = ctx.lib
+    st = rls._lib.FistaStatus()
+
+    def stream(ahead_, peek_at=()):
+        ctx.tune(resident_server=1, resident_ahead=ahead_)
+        sol = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart)
+        rls.init_(sol, bd)
+        out, peeks = [], []
+        for k, n in enumerate(sizes):
+            assert lib.rls_fista_step_status(sol.state._plan, n, C.byref(st)) == 0
+            out.append((st.iteration, st.done, st.theta, st.rel_res_norm, st.residual))
+            if k in peek_at:
+                peeks.append(sol.state.res.to_host())    # the kernel leaves first -- behind the iteration it ran ahead
+        assert lib.rls_fista_step_status(sol.state._plan, 1, C.byref(st)) == 0 and st.iteration == iters and st.done == 1   # the limit
+        sol.state._refresh(lib)
+        return out, peeks, sol.state.x.to_host(), sol.state.xold.to_host(), sol.state.res.to_host(), int(st.fallbacks)
+
+    try:
+        ref = stream(0, peek_at=(1, 4))
+        assert ref[5] == 0 and ref[0][-1][0] == iters
+        for peek in ((), (1, 4)):
+            got = stream(1, peek_at=peek)
+            assert got[5] == 0 and got[0] == ref[0]
+            assert all(np.array_equal(a, b_) for a, b_ in zip(got[2:5], ref[2:5]))
+            assert len(got[1]) == len(peek) and all(np.array_equal(a, b_) for a, b_ in zip(got[1], ref[1]))
+        want = O.FISTA(A.astype(hi(dt)), AHA=(A.astype(hi(dt)).conj().T @ A.astype(hi(dt))) if gram else None, reg=O.L1Regularization(lam), rho=rho,
+                       iterations=iters, relTol=0.0, restart=restart)
+        O.solve(want, b.astype(hi(dt)))
+        assert rel(ref[2], want.x) < 2e-5
     finally:
         ctx.tune(resident_server=1, resident_ahead=1)
 
