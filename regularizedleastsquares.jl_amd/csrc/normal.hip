@@ -2902,8 +2902,15 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
         // the last v (a workgroup still reading parity 0 reads the same values).  A kernel that stays and listens must not leave
         // these lines DIRTY in this XCD's L2: v0 is an exchange buffer, a later command's write-through rows from other XCDs
         // would be overwritten whenever the stale lines are evicted
-        if constexpr (SRV != 0) sc1_store_elem<E>(v0 + i, vv[e]);
-        else v0[i] = vv[e];
+        // SRV == 2 with a pass ahead to follow: NOT here -- no grid barrier lies between this write-back and that pass, whose
+        // iteration publishes its rows into the buffer of the other parity than the last one: v0 whenever the last v sits in v1,
+        // and this store of the whole vector raced with the other workgroups' rows (one run in three gave another x).  Nothing
+        // reads v between launches while nothing is pending (S.pending = 0 below).
+        if constexpr (SRV != 0) {
+          if (!(SRV == 2 && St.srv_ctl && !S.done)) sc1_store_elem<E>(v0 + i, vv[e]);
+        } else {
+          v0[i] = vv[e];
+        }
       }
     }
     S.pending = 0;
