@@ -808,6 +808,9 @@ def main():
                          "its numbers are not a scaling measurement")
     ap.add_argument("--c5-rows", type=int, default=65536, help="total rows of the config-5 matrix (rehearsals shrink it)")
     args = ap.parse_args()
+    # (the pool's host driver supports dmabuf IPC only: without this RCCL's and our communicator's cross-process buffers fail with
+    #  hipIpcGetMemHandle: invalid argument.  The image exports it already; a launcher that builds its own environment may not.)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     launch = self_launch_command(args.gpus, sys.argv[1:], os.environ)
     if launch is not None:
