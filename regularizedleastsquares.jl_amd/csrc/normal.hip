@@ -2948,10 +2948,11 @@ __global__ __launch_bounds__(512) void cgnr_gram_resident_kernel(const E* __rest
 // Per iteration: xs = y, partial rows of AHA y, exchange 1, chunk sums -> res_raw, exchange 2, then the gradient step,
 // prox, restart test, theta and the next extrapolated point redundantly in every workgroup (fista_update_elems: its
 // two scalar sums run over full vectors every workgroup holds, so no partial dots travel).
-// (No run-ahead instantiation here, unlike cgnr_resident_kernel's SPEC and the Gram kernels' SRV = 2: state.res of the pass ahead would
-// have to wait in workgroup 0's registers for its command -- src/FISTA.jl:131 reads that array -- and the two-level instantiations
-// spilled 12-36 B per lane with it.)
-template <typename E, int G, int K, int WV, int BAR, bool FULL>
+// SPEC (server mode only): one iteration ahead of the command that asks for it, as cgnr_resident_kernel's SPEC.  state.res is the
+// caller's array (src/FISTA.jl:131 reads it): the pass ahead leaves its residual in plan scratch (the second half of raw_g) and workgroup
+// 0 copies it behind the status of the command that asks for that iteration (kept in registers instead, the two-level instantiations
+// spilled 12-36 B per lane).
+template <typename E, int G, int K, int WV, int BAR, bool FULL, bool SPEC = false>
 __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __restrict__ A, int64_t lda, E* b0, E* b1,
                                                                   const E* __restrict__ x0, E* res, E* y0, E* y1,
                                                                   E* raw_g, E* slab, fista_scalars* sc,
@@ -3036,8 +3037,11 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     pend = false;
     RLS_FISTA_UNIFORM(S);
   };
+  int credit = 0;            // SPEC: iterations of the current command that were computed ahead of it
+  bool ahead = false;        // SPEC: the pass below runs ahead of its command
+  bool res_parked = false;   // SPEC: state.res of the command's last iteration is still in plan scratch (uniform)
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
-  for (int it = 0; it < n_steps; ++it) {
+  for (int it = SPEC ? credit : 0; it < n_steps; ++it) {
     if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
     if constexpr (OWN) {
       owner_products<E, G, K, WV, FULL>(a, yv, R.ored, slab_rs, N, l2rows);
@@ -3104,8 +3108,12 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
       RLS_FISTA_COPY(S, Sn);
     }
     ++itg;
-    if (blockIdx.x == 0) {  // state.res of this iteration (nothing reads it back: a launch that gives up later loses nothing)
-      const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(res, 0, 0xffffffff, 0x00020000);
+    if constexpr (SPEC) res_parked = ahead;
+    // (SPEC: workgroup 1 -- every workgroup holds the same residual -- so that workgroup 0, which the others wait for at the next
+    //  exchange, has the write-back of x, x_{k-1}, y alone)
+    if (blockIdx.x == (SPEC && nwg > 1 ? 1 : 0)) {  // state.res of this iteration (nothing reads it back: a launch that gives up later loses nothing)
+      // (SPEC, the pass ahead: into plan scratch -- the caller's array changes with the command that asks for this iteration)
+      const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(SPEC && ahead ? raw_g + N : res, 0, 0xffffffff, 0x00020000);
 #pragma unroll
       for (int q = 0; q < EPT / NV; ++q) {
         chunk<E, NV> c3;
@@ -3138,6 +3146,16 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     resident_give_up(sync, nullptr);
     if (Sv.ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(Sv.ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
+  }
+  if constexpr (SPEC) {
+    if (ahead) {  // that pass ran ahead: its command first (uniform); told to leave, memory holds the last command served
+      ahead = false;
+      const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb, srv_seq - Sv.seq0 + 1u);
+      if (cmd == RLS_SRV_EXIT) return;
+      n_steps = (int)cmd;
+      credit = 1;
+      continue;
+    }
   }
   if (blockIdx.x == 0) {
     if constexpr (DEFER) {  // x_{k-1} back from plan scratch (this thread's own stores, drained first)
@@ -3177,7 +3195,33 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
       sync->completed = 1u;
     }
   }
+  if constexpr (SPEC) {
+    // uniform: the command's last iteration was the one computed ahead -- its residual, out of plan scratch (this thread's own stores,
+    // drained first), into the caller's array; the next listen lies behind it
+    if (res_parked && blockIdx.x == (nwg > 1 ? 1 : 0)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const __amdgpu_buffer_rsrc_t rp_rs = sc1_rsrc(raw_g + N);
+      const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(res, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < EPT / NV; ++q) {
+        const int o = q * NT * NV + tid * NV;
+        if (FULL || o < N) {
+          const f4 c = sc1_load16(rp_rs, (uint32_t)(o * sizeof(E)));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, c), res_rs, (uint32_t)(o * sizeof(E)), 0, 0);
+        }
+      }
+    }
+    res_parked = false;
+  }
   if (!Sv.ctl) break;  // uniform
+  if constexpr (SPEC) {
+    credit = 0;
+    if (!S.done) {  // uniform: one iteration ahead of the next command
+      ahead = true;
+      n_steps = 1;
+      continue;
+    }
+  }
   const unsigned cmd = resident_listen(Sv.ctl, srv_seq, Sv.idle_us, sync, epoch, (unsigned)nwg, spin_limit, &R.flag, srv_mb, srv_seq - Sv.seq0 + 1u);
   if (cmd == RLS_SRV_EXIT) return;  // uniform
   n_steps = (int)cmd;
@@ -4216,17 +4260,32 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 2, true>, lds);
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, false>, lds);
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 2, false>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, true, true>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 2, true, true>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, false, true>, lds);
+      allow_big_lds(&fista_resident_kernel<E, G, K, WV, 2, false, true>, lds);
       }
-#define RLS_LAUNCH_FRES(BB, FF)                                                                                          \
-  hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, BB, FF>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
+#define RLS_LAUNCH_FRES(BB, FF, SS)                                                                                      \
+  hipLaunchKernelGGL((fista_resident_kernel<E, G, K, WV, BB, FF, SS>), dim3(nwg), dim3(C::NT), lds, ctx->stream, (const E*)P.A, \
                      P.lda, (E*)P.b0, (E*)P.b1, (const E*)P.x0, (E*)P.res, (E*)P.y0, (E*)P.y1, (E*)P.res_raw, (E*)P.slab,  \
                      P.sc, (resident_sync*)sync, Mc, P.N, pair | (ctx->tune.fista_defer ? 0 : 2), n_steps, spin_limit, Sv)
+    const bool spec = Sv.ctl != nullptr && ctx->tune.resident_ahead != 0;  // a kernel that stays and listens runs one iteration ahead of its commands
     if (resident_two_level_ok<E>(ctx->tune, nwg, P.N, C::NT)) {
-      if (full) RLS_LAUNCH_FRES(2, true);
-      else RLS_LAUNCH_FRES(2, false);
+      if (spec) {
+        if (full) RLS_LAUNCH_FRES(2, true, true);
+        else RLS_LAUNCH_FRES(2, false, true);
+      } else {
+        if (full) RLS_LAUNCH_FRES(2, true, false);
+        else RLS_LAUNCH_FRES(2, false, false);
+      }
     } else {
-      if (full) RLS_LAUNCH_FRES(1, true);
-      else RLS_LAUNCH_FRES(1, false);
+      if (spec) {
+        if (full) RLS_LAUNCH_FRES(1, true, true);
+        else RLS_LAUNCH_FRES(1, false, true);
+      } else {
+        if (full) RLS_LAUNCH_FRES(1, true, false);
+        else RLS_LAUNCH_FRES(1, false, false);
+      }
     }
 #undef RLS_LAUNCH_FRES
     return launch_status(ctx);

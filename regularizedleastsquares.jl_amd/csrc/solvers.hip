@@ -3071,10 +3071,10 @@ int32_t rls_fista_create(rls_operator* op, void* x, void* x0, void* xold, void* 
   }
   if (e == hipSuccess && (op->slab || gram)) {
     e = dmalloc(&s->y1, vb);
-    if (e == hipSuccess) e = dmalloc(&s->res_raw, vb);
+    if (e == hipSuccess) e = dmalloc(&s->res_raw, 2 * vb);  // (second half: state.res of the iteration a listening kernel runs ahead, fista_resident_kernel's SPEC)
     if (e == hipSuccess) e = dmalloc(&s->scn, sizeof(fista_scalars));
     if (e == hipSuccess) e = hipMemsetAsync(s->y1, 0, vb, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(s->res_raw, 0, vb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->res_raw, 0, 2 * vb, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->scn, 0, sizeof(fista_scalars), ctx->stream);
   }
   if (e != hipSuccess) {

@@ -2753,7 +2753,11 @@ def test_cgnr_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, path, gram):
     st = rls._lib.CgnrStatus()
 
     def stream(server, ahead_, peek_at=()):
-        ctx.tune(resident_server=server, resident_ahead=ahead_)
+        # (idle time at its maximum: a host hiccup between two calls must not end a kernel's life here -- two short lives in a row put
+        #  the plan on the per-iteration pipeline, whose sums run in another order: the same iterates to rounding, not to the bit)
+        ctx.tune(resident_server=server, resident_ahead=ahead_, resident_server_idle_us=10000)
+        gc.collect()   # (an earlier solver freed by the cycle collector in the middle of this stream: rls_free -> rls_enter asks the listening
+        #                kernel to leave, and two lives that short in a row put the plan on the per-iteration pipeline -- other rounding)
         sol = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=0.0)
         rls.init_(sol, bd)
         if _cgnr_path(rls, sol) != path:
@@ -2768,6 +2772,8 @@ def test_cgnr_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, path, gram):
         x_end = sol.state.x.to_host()
         return out, peeks, x_end, int(st.fallbacks)
 
+    import gc
+    gc.disable()
     try:
         pipe_out, pipe_peeks, pipe_x, _ = stream(0, 0, peek_at=(1, 4))   # a launch per command on the per-iteration pipeline
         ref_out, ref_peeks, ref_x, fb = stream(1, 0, peek_at=(1, 4))     # the listening kernel, never ahead
@@ -2779,14 +2785,17 @@ def test_cgnr_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, path, gram):
         assert len(peeks) == 2 and all(np.array_equal(a, b_) for a, b_ in zip(peeks, ref_peeks))
         assert all(rel(a, b_) < 2e-5 for a, b_ in zip(peeks, pipe_peeks))
     finally:
-        ctx.tune(resident_server=1, resident_ahead=1)
+        gc.enable()
+        ctx.tune(resident_server=1, resident_ahead=1, resident_server_idle_us=300)
 
 
-@pytest.mark.parametrize("M,N,dt,gram", [(2048, 2048, np.complex64, True), (256, 128, np.float32, False)])
+@pytest.mark.parametrize("M,N,dt,gram", [(4096, 2048, np.complex64, False), (4000, 2200, np.float32, False), (2048, 2048, np.complex64, True),
+                                         (256, 128, np.float32, False)])
 @pytest.mark.parametrize("restart", ["none", "gradient"])
 def test_fista_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, gram, restart):
-    """as test_cgnr_server_runs_one_iteration_ahead for rls_fista_step_status on the kernels that run ahead: the resident Gram kernel
-    (fista_gram_resident_kernel, SRV = 2) and the single-workgroup kernel -- status stream, x, x_{k-1} and state.res of the kernel that does
+    """as test_cgnr_server_runs_one_iteration_ahead for rls_fista_step_status on the kernels that run ahead: the matrix-free resident
+    kernel (fista_resident_kernel, SPEC: full and ragged shape; the residual of the pass ahead waits in plan scratch), the resident Gram
+    kernel (fista_gram_resident_kernel, SRV = 2) and the single-workgroup kernel -- status stream, x, x_{k-1} and state.res of the kernel that does
     not; a download of state.res between two commands sees the command's residual, not the one computed ahead"""
     import ctypes as C
     A, xt, b = O.make_problem(M, N, dt, 93)
@@ -2800,7 +2809,8 @@ def test_fista_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, gram, restart
     st = rls._lib.FistaStatus()
 
     def stream(ahead_, peek_at=()):
-        ctx.tune(resident_server=1, resident_ahead=ahead_)
+        ctx.tune(resident_server=1, resident_ahead=ahead_, resident_server_idle_us=10000)   # (as in the CGNR test above)
+        gc.collect()
         sol = rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(lam), rho=rho, iterations=iters, relTol=0.0, restart=restart)
         rls.init_(sol, bd)
         out, peeks = [], []
@@ -2813,6 +2823,8 @@ def test_fista_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, gram, restart
         sol.state._refresh(lib)
         return out, peeks, sol.state.x.to_host(), sol.state.xold.to_host(), sol.state.res.to_host(), int(st.fallbacks)
 
+    import gc
+    gc.disable()
     try:
         ref = stream(0, peek_at=(1, 4))
         assert ref[5] == 0 and ref[0][-1][0] == iters
@@ -2826,7 +2838,8 @@ def test_fista_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, gram, restart
         O.solve(want, b.astype(hi(dt)))
         assert rel(ref[2], want.x) < 2e-5
     finally:
-        ctx.tune(resident_server=1, resident_ahead=1)
+        gc.enable()
+        ctx.tune(resident_server=1, resident_ahead=1, resident_server_idle_us=300)
 
 
 @pytest.mark.parametrize("restart", ["none", "gradient"])

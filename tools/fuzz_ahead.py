@@ -20,6 +20,7 @@ iters = 24
 cases = {
     "cgnr matrix-free": (lambda: rls.createLinearSolver(rls.CGNR, Ad, iterations=iters, relTol=0.0), b, False),
     "cgnr gram": (lambda: rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, iterations=iters, relTol=0.0), b, False),
+    "fista matrix-free": (lambda: rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=rho, iterations=iters, relTol=0.0), b, True),
     "fista gram": (lambda: rls.createLinearSolver(rls.FISTA, Ad, AHA=Gd, reg=rls.L1Regularization(1e-2), rho=rho, iterations=iters, relTol=0.0), b, True),
     "cgnr small": (lambda: rls.createLinearSolver(rls.CGNR, Asd, iterations=iters, relTol=0.0), bs, False),
     "fista small": (lambda: rls.createLinearSolver(rls.FISTA, Asd, reg=rls.L1Regularization(1e-2), rho=1e-3, iterations=iters, relTol=0.0), bs, True),
