@@ -343,6 +343,14 @@ int32_t rls_free(rls_ctx* ctx, void* p) {
     const hipError_t e = hipFree(p);
     return e == hipSuccess ? 0 : (int32_t)e;
   }
+  if (ctx->pools && ctx->server) {
+    // a kernel left listening (server mode): the pooled free is ordered behind it on the stream by itself and does not block the host.
+    // It must NOT ask that kernel to leave: frees come from the host's garbage collector at any time (a finalizer, Python's cycle
+    // collector), and two kernel lives that short in a row put the plan on the per-iteration pipeline for the rest of its solve.
+    RLS_HIP(ctx, hipSetDevice(ctx->device));
+    RLS_HIP(ctx, rls_dev_free(ctx, p));
+    return 0;
+  }
   RLS_HIP(ctx, rls_enter(ctx));
   if (!ctx->pools) RLS_HIP(ctx, rls_stream_wait(ctx->stream));  // (hipFree synchronises the whole device anyway)
   RLS_HIP(ctx, rls_dev_free(ctx, p));   // pooled: ordered behind everything enqueued on the context's stream

@@ -2735,6 +2735,30 @@ def test_cgnr_resident_server_mode(rls, ctx, dt, M, N):
     assert rel(x_pipe, x_once) < 2e-5 and not np.array_equal(x_pipe, x_once)
 
 
+def test_frees_do_not_end_a_listening_kernel(rls, ctx):
+    """rls_free while a kernel listens (a finalizer of the host's garbage collector, at any time): the pooled free is ordered behind the
+    kernel on the stream and must not ask it to leave -- with a free after EVERY iterate call the kernel's lives would all be one
+    command long, the plan would go over to the per-iteration pipeline after two of them, and the result would no longer be the bits of
+    one launch"""
+    import ctypes as C
+    A, xt, b = O.make_problem(4096, 2048, np.complex64, 94)
+    Ad, bd = rls.DeviceMatrix.from_host(A), rls.DeviceVector.from_host(b)
+    iters = 24
+    sol = rls.createLinearSolver(rls.CGNR, Ad, iterations=iters, relTol=0.0)
+    rls.init_(sol, bd)
+    if _cgnr_path(rls, sol) != 4:
+        _resident_unavailable()
+    x_once = rls.solve_(sol, bd).to_host()
+    junk = [rls.DeviceVector(1024, np.float32, ctx) for _ in range(iters)]
+    st = rls._lib.CgnrStatus()
+    rls.init_(sol, bd)
+    for k in range(iters):
+        assert ctx.lib.rls_cgnr_step_status(sol.state._plan, 1, C.byref(st)) == 0 and st.iteration == k + 1
+        junk.pop()   # -> rls_free
+    assert st.fallbacks == 0
+    assert np.array_equal(sol.state.x.to_host(), x_once)
+
+
 @pytest.mark.parametrize("M,N,dt,path,gram", [(4096, 2048, np.complex64, 4, False), (2048, 2048, np.complex64, 5, True), (256, 128, np.float32, 8, False)])
 def test_cgnr_server_runs_one_iteration_ahead(rls, ctx, M, N, dt, path, gram):
     """A listening kernel computes the NEXT iteration under the host's turnaround (the SPEC instantiations of cgnr_resident_kernel,
