@@ -2389,6 +2389,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   slab_lds<E, G, K, WV>& L = R.L;
   const int tid = threadIdx.x;
   const int nwg = gridDim.x;
+  STAMP(0);  // (launch-level stamps 0..4, tools/stamps_resident.py: entry, slab in owner layout, loop entered, loop left, written back)
   if (St.enabled && St.skip && *St.skip) {  // the ADMM plan is done: this cg! is a no-op (uniform: every workgroup reads the flag)
     if (blockIdx.x == 0 && tid == 0) {
       cgnr_scalars Z = *sc;
@@ -2423,6 +2424,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   if (!St.enabled && (S.done || n_steps <= 0)) return;  // uniform
   constexpr bool OWN = owner_cfg<E, G, K, WV>::ok;  // the slab re-arranged once so that a thread holds whole columns
   if constexpr (OWN) owner_transpose<E, G, K, WV, FULL>(a, smem_raw, Mc, N, pair);
+  STAMP(1);
   const __amdgpu_buffer_rsrc_t slab_rs = sc1_rsrc(slab), d_rs = sc1_rsrc(dout);  // dout: the scalar row (word blockIdx = ||t_w||^2)
   unsigned epoch = 0, xchg = 0;
   bool alive = true;
@@ -2536,10 +2538,16 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
   unsigned srv_seq = St.srv_seq0;  // the command being served; the host's next one carries srv_seq + 1
   int credit = 0;      // SPEC: iterations of the current command that were computed ahead of it
   bool ahead = false;  // SPEC: the pass below runs ahead of its command
+  STAMP(2);
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = SPEC ? credit : 0; it < n_steps; ++it) {
     if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
     STAMP(8);
+#ifdef RLS_STAMPS
+    if (it == 1) STAMP(5);   // (how long the first iterations of a launch take: tools/stamps_resident.py)
+    if (it == 2) STAMP(6);
+    if (it == 10) STAMP(7);
+#endif
     // t_w = A_w p, partial v = A_w^H t_w -> this workgroup's partial row (write-through); ||t_w||^2 -> its word of the scalar row
     if constexpr (OWN) {
       owner_products<E, G, K, WV, FULL>(a, pv, R.ored, slab_rs, N, l2rows, &d_rs);
@@ -2615,6 +2623,7 @@ __global__ __launch_bounds__(WV * 64) void cgnr_resident_kernel(const E* __restr
     STAMP(15);
     if (done) break;  // uniform: every workgroup derived the same scalars
   }
+  STAMP(3);
   if (!alive) {
     resident_give_up(sync, St.enabled ? St.poison : nullptr);
     if (St.srv_ctl && blockIdx.x == 0 && tid == 0) __hip_atomic_store(St.srv_ctl + 17, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

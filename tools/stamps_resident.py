@@ -27,3 +27,16 @@ for wg in range(7):
     t = [buf[wg * 16 + 8 + i] for i in range(8)]
     print(f"wg {wg*37+5}: start @{(t[0]-t00)*10:+5d} ns  " + "  ".join(f"[{i}] +{(t[i]-t[0])*10}" for i in range(1, 8)))
 print("phases: " + "; ".join(f"[{i}] {n}" for i, n in enumerate(names)))
+# launch level (one 20-iteration launch): entry -> slab loaded and re-arranged into the owner layout -> loop entered -> loop left
+e00 = min(buf[wg * 16 + 0] for wg in range(7))
+for wg in range(7):
+    t = [buf[wg * 16 + i] for i in range(8)]
+    print(f"wg {wg*37+5}: iteration 0 took {(t[5]-t[2])/100:.2f} us, iteration 1 {(t[6]-t[5])/100:.2f}, iterations 2..9 {(t[7]-t[6])/800:.2f} each, 10..19 {(t[3]-t[7])/1000:.2f} each")
+    print(f"wg {wg*37+5}: entry @{(t[0]-e00)*10:+5d} ns   slab in owner layout +{(t[1]-t[0])/100:.2f} us   loop entered +{(t[2]-t[0])/100:.2f}   loop left +{(t[3]-t[0])/100:.2f}"
+          f"   (20 iterations: {(t[3]-t[2])/100:.2f} us = {(t[3]-t[2])/2000:.3f} us each)")
+ctx.timer_start(); lib.rls_cgnr_step(solver.state._plan, 0); ctx.timer_stop_ms()
+best = 1e9
+for _ in range(20):
+    rls.init_(solver, b); ctx.sync()
+    ctx.timer_start(); lib.rls_cgnr_step(solver.state._plan, 20); best = min(best, ctx.timer_stop_ms())
+print(f"hipEvents around rls_cgnr_step(plan, 20): {best*1e3:.1f} us (stamped build)")
