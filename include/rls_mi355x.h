@@ -358,6 +358,10 @@ int32_t rls_cgnr_get_status(rls_cgnr* s, rls_cgnr_status* out_h);
  * library waits behind it; work the caller puts on the same stream by other means waits for the idle timeout at most.
  * A caller that touches the device between iterates twice in a row is served by the per-iteration pipeline until the next
  * init.  rls_tune_set("resident_server", 0) switches the mode off.  rls_fista_step_status: the same.
+ * AHEAD (round 6): a listening kernel computes ONE iteration ahead of the next command, under the host's turnaround; nothing of that
+ * iteration is published or stored before a command asks for it, and a kernel told to leave instead leaves without a write-back
+ * (memory holds the state of the last command served).  rls_tune_set("resident_ahead", 0) selects the kernels that do not.
+ * rls_free (rls_mi355x.h:memory) does not ask a listening kernel to leave: the pooled free is ordered behind it on the stream.
  * VISIBILITY: while a kernel listens, rls_*_get_status / rls_*_step_status answer from the host mirror the kernel published
  * into; the state vectors x, r, p it wrote are current for every LATER call on this context (each asks the kernel to leave
  * first), but a consumer outside this context -- another rls context, another stream or library reading the caller-owned
