@@ -973,6 +973,8 @@ def test_batched_gram_mode_matrix_rhs(rls, ctx, dt, M, N, K, resident):
         Bd = rls.DeviceMatrix.from_host(B)
         iters = 12
         tag = f"batched_gram_{M}x{N}_{np.dtype(dt).name}_K{K}_res{resident}"
+        A64 = A.astype(dt64)
+        G64, G32 = A64.conj().T @ A64, A.conj().T @ A   # formed ONCE for the K oracle solves (what normal="gram" forms per solver: the same product)
         for relTol in (0.0, 1e-4):
             S = rls.createLinearSolver(rls.CGNR, Ad, AHA=Gd, reg=rls.L2Regularization(1e-3), iterations=iters, relTol=relTol)
             xs = rls.solve_(S, Bd, scheduler=rls.BatchedState)
@@ -983,9 +985,9 @@ def test_batched_gram_mode_matrix_rhs(rls, ctx, dt, M, N, K, resident):
             assert all(s_.fallbacks == 0 for s_ in stat)
             its = [s_.iteration for s_ in stat]
             for j in range(K):
-                ref = O.CGNR(A.astype(dt64), reg=O.L2Regularization(1e-3), iterations=iters, relTol=relTol, normal="gram")
+                ref = O.CGNR(A64, AHA=G64, reg=O.L2Regularization(1e-3), iterations=iters, relTol=relTol)
                 O.solve(ref, B[:, j].astype(dt64))
-                x32 = lambda: O.solve(O.CGNR(A, reg=O.L2Regularization(1e-3), iterations=ref.iteration, relTol=0.0, normal="gram"),
+                x32 = lambda: O.solve(O.CGNR(A, AHA=G32, reg=O.L2Regularization(1e-3), iterations=ref.iteration, relTol=0.0),
                                       np.ascontiguousarray(B[:, j]))
                 assert abs(its[j] - ref.iteration) <= (1 if relTol > 0 else 0), (its, j, ref.iteration)
                 if its[j] == ref.iteration:
