@@ -28,13 +28,15 @@ def kernels():
 
 # (config, regular expression on the demangled instantiation) -- what each BASELINE config launches on its default path
 BASELINE = [
-    ("headline / configs[3] single solves: resident CGNR 4096x2048 CF32", r"cgnr_resident_kernel<c32, 8, 32, 8, 2, true>"),
+    ("headline / configs[3] single solves: resident CGNR 4096x2048 CF32", r"cgnr_resident_kernel<c32, 8, 32, 8, 2, true, false>"),
+    ("headline shape, solve! loop with callbacks: the listening kernel that runs one iteration ahead (SPEC)", r"cgnr_resident_kernel<c32, 8, 32, 8, 2, true, true>"),
     ("headline on the two-launch pipeline", r"cgnr_pipe_a_kernel<c32, 8, 32, 8, true, false, (true|false), false>"),
     ("headline on the two-launch pipeline", r"cgnr_pipe_r_kernel<c32>"),
     ("headline on the two-launch pipeline", r"cgnr_pipe_f_kernel<c32, \d+>"),
     ("configs[0]: CGNR 256x128 F32, single-workgroup kernel", r"cgnr_small_kernel<float, 8, 8>"),
     ("configs[0] on the pipeline (small = 0)", r"cgnr_pipe_a_kernel<float, 8, 8, 8, (true|false), false, (true|false), false>"),
-    ("configs[1]: FISTA + L1 4096x2048 CF32, resident", r"fista_resident_kernel<c32, 8, 32, 8, 2, true>"),
+    ("configs[1]: FISTA + L1 4096x2048 CF32, resident (last argument: the listening kernel that runs one iteration ahead)", r"fista_resident_kernel<c32, 8, 32, 8, 2, true, (true|false)>"),
+    ("headline / configs[1] shape on the reference's default operator (AHA explicit), resident; last argument 1 / 2: listens / and runs ahead", r"(cgnr|fista)_gram_resident_kernel<c32, 16, 1, true, (0|1|2)>"),
     ("configs[1] on the pipeline", r"fista_pipe_a_kernel<c32, 8, 32, 8, true, (true|false), false>"),
     ("configs[1] shape, SURVEY 8f-1: OptISTA / POGM (2: with gradient restart) blocks of iterations as resident launches", r"pgm_resident_kernel<c32, 8, 32, 8, 2, true, (0|1|2)>"),
     ("configs[1] on the pipeline", r"fista_pipe_r_kernel<c32>"),
