@@ -365,6 +365,17 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, w = tid >> 6;
   const int g = lane % G, s = lane / G, slot = w * C::S + s;
+  // The first KE rounds of the NEXT block are requested HERE, into registers of their own, not when the second product frees theirs:
+  // between the last chunk of this block and the first re-load nothing was in flight (this block's t_w is being reduced: about 1 us per
+  // block, plus the ramp of the re-loads).  8 rounds for real element types (12 spilled), 6 for ComplexF32 with 128-byte row pieces; the
+  // ComplexF32 forms with 64-byte pieces have no registers left (250 of 256).
+  constexpr int KE = !(RELOAD && K >= 16) ? 0 : !elem<E>::cplx ? 8 : G == 8 ? 6 : 0;
+  chunk<E, NV> early[KE > 0 ? KE : 1];
+  if constexpr (KE > 0) {
+#pragma unroll
+    for (int k = 0; k < KE; ++k) early[k] = W.load(k);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   lds_barrier();  // xs complete / the previous block's reads of xg, part, tw done
   E acc[NV];
 #pragma unroll
@@ -412,7 +423,10 @@ __device__ static __forceinline__ void slab_pass(chunk<E, elem<E>::vec> (&a)[K],
 #pragma unroll
     for (int i = 0; i < NV; ++i) q = elem<E>::fmac_pk(a[k].e[i], tr[i], q);
     slab_xg_store<E, G, K, WV>(L, g, k * C::CPR + slot, q);
-    if constexpr (RELOAD) a[k] = W.load(k);
+    if constexpr (RELOAD) {
+      if (k < KE) a[k] = early[k];
+      else a[k] = W.load(k);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   STAMP(stamp_base + 2);

@@ -1,5 +1,5 @@
 """Streaming (resident = 0) CGNR pipeline at 4096 x 2048 ComplexF32 under tuning variants: us per iteration from the slope of two step calls.
-usage: python tools/ab_stream.py [lib.so ...]   (each library build in a child process; env AB_SHAPE=M,N)"""
+usage: python tools/ab_stream.py [lib.so ...]   (each library build in a child process; env AB_SHAPE=M,N, AB_DTYPE=c|f)"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -19,10 +19,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         k, v = kv.split("=")
         rc = lib.rls_tune_set(ctx.handle, k.encode(), int(v))
         assert rc == 0, (kv, rc)
-    A = make_A(M, N, 2)
+    dt = np.float32 if os.environ.get("AB_DTYPE", "c") == "f" else np.complex64
+    A = make_A(M, N, 2, dt)
     rng = np.random.default_rng(1000)
-    xt = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(np.complex64)
-    b = (A @ xt).astype(np.complex64)
+    xt = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / math.sqrt(2)).astype(dt)
+    b = (A @ xt).astype(dt)
     Ad, bd = rls.DeviceMatrix.from_host(A, ctx), rls.DeviceVector.from_host(b, ctx)
     S = rls.createLinearSolver(rls.CGNR, Ad, iterations=2048, relTol=0.0)
     def t_of(n, reps=20):
