@@ -3066,6 +3066,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
   for (;;) {  // (server mode: one pass per command; otherwise one pass)
   for (int it = SPEC ? credit : 0; it < n_steps; ++it) {
     if (S.done) break;  // uniform (a command behind the one that reached the stopping test)
+    STAMP(8);  // (the slots of cgnr_resident_kernel: tools/stamps_resident.py fista)
     if constexpr (OWN) {
       owner_products<E, G, K, WV, FULL>(a, yv, R.ored, slab_rs, N, l2rows);
     } else {
@@ -3073,8 +3074,10 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
       for (int e = 0; e < EPT; ++e) L.xs[(int)own_index<E, EPT, NT, true>(tid, e)] = yv[e];
       slab_finish<E, G, K, WV, FULL, true>(a, L, slab, Mc, N, pair);
     }
+    STAMP(9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP(10);
     E x0v[EPT];  // requested here, consumed behind the exchange
     if constexpr (FULL) load_owned_wide<E, EPT, NT>(x0v, x0, tid);
     else load_owned_wide_masked<E, EPT, NT>(x0v, x0, tid, N);
@@ -3098,6 +3101,10 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
         if (S.done) break;  // it had converged: this iteration's exchange is dropped, nothing of it was applied
       }
     }
+#ifdef RLS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(14);
+#endif
     E xn[EPT], yn[EPT], ri[EPT];
     bool done;
     if (DEFER && defer_on && !S.restart) {  // uniform
@@ -3157,6 +3164,7 @@ __global__ __launch_bounds__(WV * 64) void fista_resident_kernel(const E* __rest
     }
     if (!done) ycur ^= 1;
     RLS_FISTA_UNIFORM(S);
+    STAMP(15);
     if (done) break;  // uniform
   }
   if constexpr (DEFER) {

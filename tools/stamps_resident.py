@@ -14,9 +14,15 @@ lib = ctx.lib
 M, N = 4096, 2048
 A = make_A(M, N, 2); Ad = rls.DeviceMatrix.from_host(A, ctx)
 b = rls.DeviceVector.from_host((A @ np.ones(N, np.complex64)).astype(np.complex64), ctx)
-solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
-for _ in range(5):
-    rls.init_(solver, b); lib.rls_cgnr_step(solver.state._plan, 20); ctx.sync()
+FISTA = len(sys.argv) > 1 and sys.argv[1] == "fista"   # the same slots in fista_resident_kernel (FISTA + L1)
+if FISTA:
+    solver = rls.createLinearSolver(rls.FISTA, Ad, reg=rls.L1Regularization(1e-2), rho=0.95 / (np.sqrt(M) + np.sqrt(N)) ** 2, iterations=32, relTol=0.0)
+    for _ in range(5):
+        rls.init_(solver, b); lib.rls_fista_step(solver.state._plan, 20); ctx.sync()
+else:
+    solver = rls.createLinearSolver(rls.CGNR, Ad, iterations=32, relTol=0.0)
+    for _ in range(5):
+        rls.init_(solver, b); lib.rls_cgnr_step(solver.state._plan, 20); ctx.sync()
 buf = (C.c_ulonglong * 128)()
 lib.rls_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
 print("status", lib.rls_debug_stamps(buf))
@@ -27,6 +33,8 @@ for wg in range(7):
     t = [buf[wg * 16 + 8 + i] for i in range(8)]
     print(f"wg {wg*37+5}: start @{(t[0]-t00)*10:+5d} ns  " + "  ".join(f"[{i}] +{(t[i]-t[0])*10}" for i in range(1, 8)))
 print("phases: " + "; ".join(f"[{i}] {n}" for i, n in enumerate(names)))
+if FISTA:
+    sys.exit(0)
 # launch level (one 20-iteration launch): entry -> slab loaded and re-arranged into the owner layout -> loop entered -> loop left
 e00 = min(buf[wg * 16 + 0] for wg in range(7))
 for wg in range(7):
