@@ -946,7 +946,7 @@ static bool gk_resident_ok(rls_ctx* ctx, int32_t dtype, int64_t N, int nrhs, con
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return false;
   if (!(nwg <= cus && nwg <= 256)) return false;
   static rls_device_once attr_once;
-  if (attr_once.first(ctx->device)) {
+  if (auto once_ = attr_once.first(ctx->device)) {
     gk_allow_lds<KIND, 1>();
     gk_allow_lds<KIND, 2>();
     gk_allow_lds<KIND, 4>();

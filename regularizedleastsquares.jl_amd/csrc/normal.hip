@@ -3797,7 +3797,7 @@ static int launch_slab(rls_ctx* ctx, const E* A, int64_t lda, const E* p, E* sla
   const int pair = slab_pairing(G, nwg);
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   static rls_device_once attr_once;  // per template instantiation and device
-  if (attr_once.first(ctx->device)) {
+  if (auto once_ = attr_once.first(ctx->device)) {
     allow_big_lds(&normal_slab_kernel<E, G, K, WV, true>, lds);
     allow_big_lds(&normal_slab_kernel<E, G, K, WV, false>, lds);
     if constexpr (K == 32) {
@@ -3852,7 +3852,7 @@ static void launch_pipe_a(rls_ctx* ctx, const rls_cgnr_pipe& P, int nwg, int gri
   // checks the hint on the device and re-loads the right pair, late, when it was wrong.
   constexpr bool ALWAYS_HINTED = elem<E>::cplx && G == 4 && K == 32;
   static rls_device_once attr_once;
-  if (attr_once.first(ctx->device)) {
+  if (auto once_ = attr_once.first(ctx->device)) {
     if constexpr (!ALWAYS_HINTED) {
       allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, true, false, false>, lds);
       allow_big_lds(&cgnr_pipe_a_kernel<E, G, K, WV, false, false, false>, lds);
@@ -3971,7 +3971,7 @@ static void launch_fista_a(rls_ctx* ctx, const rls_fista_pipe& P, int nwg, int g
   const int pair = slab_pairing(G, nwg);
   constexpr size_t lds = sizeof(slab_lds<E, G, K, WV>);
   static rls_device_once attr_once;
-  if (attr_once.first(ctx->device)) {
+  if (auto once_ = attr_once.first(ctx->device)) {
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, false>, lds);
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, false, false>, lds);
     allow_big_lds(&fista_pipe_a_kernel<E, G, K, WV, true, true>, lds);
@@ -4188,7 +4188,7 @@ static int32_t launch_resident(rls_ctx* ctx, const rls_cgnr_pipe& P, double* dou
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
     constexpr size_t lds = resident_lds_bytes<E, G, K, WV>();
     static rls_device_once attr_once;
-    if (attr_once.first(ctx->device)) {
+    if (auto once_ = attr_once.first(ctx->device)) {
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, true>, lds);
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 2, true>, lds);
       allow_big_lds(&cgnr_resident_kernel<E, G, K, WV, 1, false>, lds);
@@ -4286,7 +4286,7 @@ static int32_t launch_fista_resident(rls_ctx* ctx, const rls_fista_pipe& P, void
     const bool full = P.N == C::NMAX && (int64_t)nwg * G == Mc;
     constexpr size_t lds = resident_lds_bytes<E, G, K, WV>();
     static rls_device_once attr_once;
-    if (attr_once.first(ctx->device)) {
+    if (auto once_ = attr_once.first(ctx->device)) {
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, true>, lds);
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 2, true>, lds);
       allow_big_lds(&fista_resident_kernel<E, G, K, WV, 1, false>, lds);
@@ -4457,7 +4457,7 @@ static int32_t launch_pgm_resident(rls_ctx* ctx, const rls_pgm_desc& D, const rl
     const bool full = D.N == C::NMAX && (int64_t)nwg * G == Mc;
     constexpr size_t lds = resident_lds_bytes<E, G, K, WV>();
     static rls_device_once attr_once;
-    if (attr_once.first(ctx->device)) {
+    if (auto once_ = attr_once.first(ctx->device)) {
 #define RLS_PGM_ATTR(BB, FF, KK2) allow_big_lds(&pgm_resident_kernel<E, G, K, WV, BB, FF, KK2>, lds);
       RLS_PGM_ATTR(1, true, 0) RLS_PGM_ATTR(2, true, 0) RLS_PGM_ATTR(1, false, 0) RLS_PGM_ATTR(2, false, 0)
       RLS_PGM_ATTR(1, true, 1) RLS_PGM_ATTR(2, true, 1) RLS_PGM_ATTR(1, false, 1) RLS_PGM_ATTR(2, false, 1)

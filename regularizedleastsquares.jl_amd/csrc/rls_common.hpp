@@ -217,11 +217,38 @@ inline std::mutex& rls_capture_mutex() {
 // "done once per device" guard for per-function attributes (hipFuncSetAttribute applies to the function on the CURRENT
 // device: a process that drives several GPUs, rls_comm_*, must set it on each of them); race-free across host threads
 #include <atomic>
+// Per-device one-time work (the kernels' > 64 KiB dynamic-LDS attributes) that nobody may run past before it is COMPLETE: two host
+// threads entering their first solves at the same time (src/MultiThreading.jl:71) used to race here -- the second saw "seen" while
+// the first was still setting attributes and launched a kernel whose LDS size was not allowed yet (a cold-process failure of
+// tests/test_gpu_contexts.py, one run in a few).  Usage: `if (auto once = attr_once.first(device)) { ...work... }` -- the guard
+// lives through the body, publishes "done" behind it and only then lets the waiting threads go.
 struct rls_device_once {
-  std::atomic<uint64_t> mask{0};
-  bool first(int device) {  // true exactly when this device has not been seen (the caller then does the work: idempotent)
+  std::atomic<uint64_t> done{0};
+  std::mutex mu;
+  struct guard {
+    rls_device_once* o;
+    uint64_t bit;
+    bool run;
+    guard(rls_device_once* o_, uint64_t bit_, bool run_) : o(o_), bit(bit_), run(run_) {}
+    guard(const guard&) = delete;
+    guard(guard&& g) : o(g.o), bit(g.bit), run(g.run) { g.run = false; }
+    ~guard() {
+      if (run) {
+        o->done.fetch_or(bit, std::memory_order_release);
+        o->mu.unlock();
+      }
+    }
+    explicit operator bool() const { return run; }
+  };
+  guard first(int device) {  // true for exactly one caller per device; the others return once that caller's body has finished
     const uint64_t bit = 1ull << (device & 63);
-    return !(mask.fetch_or(bit, std::memory_order_acq_rel) & bit);
+    if (done.load(std::memory_order_acquire) & bit) return guard(this, bit, false);
+    mu.lock();
+    if (done.load(std::memory_order_acquire) & bit) {
+      mu.unlock();
+      return guard(this, bit, false);
+    }
+    return guard(this, bit, true);
   }
 };
 

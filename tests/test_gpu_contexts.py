@@ -43,13 +43,21 @@ def test_two_contexts_two_threads_keep_their_own_switches():
     out = [None, None]
     errs = []
 
+    go = threading.Barrier(2)
+
     def work(i):
         try:
             ctx = rls.Context(0)
             ctx.tune(**settings[i])
             Ad = rls.DeviceMatrix.from_host(A, ctx)
             bd = rls.DeviceVector.from_host(b, ctx)
-            paths, xs = [], []
+            # one solve before the two threads meet: on a cold box the first launch of a kernel loads its code object (tens of
+            # milliseconds), long enough for the OTHER thread's resident launch to give up waiting for the chip and take its fallback --
+            # correct, but not what this test is about (it is the FIRST test the GPU tier runs, on a fresh machine)
+            rls.solve_(rls.createLinearSolver(rls.CGNR, Ad, iterations=12, relTol=0.0), bd)
+            ctx.sync()
+            go.wait(timeout=120)
+            paths, xs, lost = [], [], 0
             for rep in range(6):
                 S = rls.createLinearSolver(rls.CGNR, Ad, iterations=12, relTol=0.0)
                 x = rls.solve_(S, bd).to_host()
@@ -57,20 +65,29 @@ def test_two_contexts_two_threads_keep_their_own_switches():
                 ctx.lib.rls_cgnr_path(S.state._plan, C.byref(p))
                 paths.append(p.value)
                 xs.append(x)
-            out[i] = (paths, xs)
+                lost += int(S.state._refresh(ctx.lib).fallbacks)
+            out[i] = (paths, xs, lost)
         except Exception as e:  # noqa: BLE001
             errs.append((i, repr(e)))
+            try:
+                go.abort()
+            except Exception:  # noqa: BLE001
+                pass
 
     ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
     for i in range(2):
-        paths, xs = out[i]
-        assert paths == [want_path[i]] * 6, (i, paths)
+        paths, xs, lost = out[i]
         for x in xs:
             assert np.linalg.norm(x - ref.x) / np.linalg.norm(ref.x) < 1e-5
-            assert np.array_equal(x, xs[0])  # run to run, the same bits on one context
+        if lost == 0:   # (a resident launch that could not get the chip next to the other thread's kernels re-runs on the pipeline: other bits, path 1 next)
+            assert paths == [want_path[i]] * 6, (i, paths)
+            assert all(np.array_equal(x, xs[0]) for x in xs)  # run to run, the same bits on one context
+        else:
+            assert i == 0 and set(paths) <= {4, 1}, (i, paths, lost)
+    assert out[1][0] == [1] * 6   # the context that switched the resident kernels off never ran one
 
     # the batched layout switch and the TV limits are the context's, too: what one context sets, another does not see
     c1, c2 = rls.Context(0), rls.Context(0)
@@ -92,3 +109,45 @@ def test_two_contexts_two_threads_keep_their_own_switches():
         x = rls.solve_(s_, rls.DeviceVector.from_host(bt, c)).to_host()
         assert bool(s_.state._plan) == planned
         assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-5
+
+
+COLD = r"""
+import sys, threading
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import rls_amd as rls
+rng = np.random.default_rng(1)
+M, N = 1024, 2048
+A = np.asfortranarray((rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))).astype(np.complex64))
+b = (A @ (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)).astype(np.complex64)
+out, errs = [None, None], []
+start = threading.Barrier(2)
+def work(i):
+    try:
+        ctx = rls.Context(0)
+        ctx.tune(resident=1 - i)          # thread 0: the resident kernel, thread 1: the two-launch pipeline -- both need > 64 KiB of LDS
+        Ad, bd = rls.DeviceMatrix.from_host(A, ctx), rls.DeviceVector.from_host(b, ctx)
+        S = rls.createLinearSolver(rls.CGNR, Ad, iterations=10, relTol=0.0)
+        start.wait()                      # the FIRST launches of the process, from two threads at once
+        out[i] = rls.solve_(S, bd).to_host()
+    except Exception as e:
+        errs.append((i, repr(e)))
+ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errs, errs
+assert np.all(np.isfinite(out[0])) and np.linalg.norm(out[0] - out[1]) < 1e-4 * np.linalg.norm(out[0])
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_first_launches_of_a_cold_process_from_two_threads():
+    """The one-time work behind a kernel's first launch (its > 64 KiB dynamic-LDS attribute, `rls_device_once`) is complete before ANY
+    thread launches: two threads entering their first solves at the same time in a fresh process (src/MultiThreading.jl:71).  The
+    second thread used to see "done" while the first was still setting attributes -- a cold-process failure, one run in a few."""
+    import subprocess
+
+    pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for _ in range(4):
+        r = subprocess.run([sys.executable, "-c", COLD, pkg], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
